@@ -1,0 +1,176 @@
+/*
+ * kvsketch.h -- C ABI of libkvsketch_hip.so, the MI355X (gfx950) sketch engine behind
+ * kevlar's novel-k-mer path (count -> novel -> filter -> partition).
+ *
+ * The reference has no C ABI on this path: its boundary is the Python object API of khmer
+ * (SURVEY.md section 8(b)).  Every entry point below names the khmer / kevlar call it
+ * replaces (paths are relative to the reference tree).  Plain pointers and sizes only; no
+ * torch types.  All tables live in HBM; "host" pointers are ordinary malloc'ed memory,
+ * "device" pointers are HBM addresses (e.g. a torch tensor's data_ptr()).
+ *
+ * Conventions
+ *   - every function returns KV_OK (0) or a negative KV_ERR_* code; kv_last_error() gives
+ *     the message for the calling thread.
+ *   - handles are owned by the caller and released with the matching *_destroy.
+ *   - buffers passed in are borrowed for the duration of the call.
+ *   - all work is enqueued on one HIP stream (kv_set_stream; default: the null stream) and
+ *     functions that return host data synchronise that stream before returning.
+ *   - calls on one sketch from several host threads are serialised by the library
+ *     (kevlar/count.py:41-76 starts `numthreads` threads on one sketch + one parser).
+ */
+#ifndef KVSKETCH_H
+#define KVSKETCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KV_OK 0
+#define KV_ERR_ARG (-1)      /* bad argument (maps to ValueError)                       */
+#define KV_ERR_IO (-2)       /* file cannot be opened / truncated / wrong signature      */
+#define KV_ERR_TYPE (-3)     /* sketch file type does not match the requested kind        */
+#define KV_ERR_HIP (-4)      /* HIP runtime failure (no device, OOM, launch failure)     */
+#define KV_ERR_NOTIMPL (-5)  /* e.g. reverse_hash on a *table sketch                      */
+#define KV_ERR_CAPACITY (-6) /* caller-provided buffer too small                          */
+
+/* sketch kinds = khmer classes used at kevlar/sketch.py:14-27,99-119 */
+#define KV_COUNTTABLE 0
+#define KV_SMALLCOUNTTABLE 1
+#define KV_NODETABLE 2
+#define KV_COUNTGRAPH 3
+#define KV_SMALLCOUNTGRAPH 4
+#define KV_NODEGRAPH 5
+
+#define KV_MAX_TABLES 16
+#define KV_MAX_K 255       /* murmur-hashed (*table) kinds; 2-bit (*graph) kinds need k<=32 */
+#define KV_MAX_SAMPLES 16  /* cases + controls in one novel scan                          */
+
+typedef struct kv_sketch kv_sketch; /* Count-Min / Bloom tables resident in HBM            */
+typedef struct kv_reads kv_reads;   /* a batch of reads, 2-bit packed, resident in HBM     */
+typedef struct kv_hits kv_hits;     /* sparse result of a novel scan                       */
+
+typedef struct kv_sketch_info {
+    int32_t kind, ksize, ntables, reserved;
+    uint64_t sizes[KV_MAX_TABLES]; /* khmer .hashsizes()                                   */
+    uint64_t n_occupied;           /* khmer .n_occupied(): non-zero bins of table 0        */
+    uint64_t n_unique;             /* khmer .n_unique_kmers() (see kv_consume)             */
+    uint64_t bytes_device;         /* HBM held by the tables                               */
+} kv_sketch_info;
+
+/* ---- library / device ---------------------------------------------------------------- */
+const char *kv_last_error(void);
+const char *kv_version(void);
+int kv_device_count(int *n);
+int kv_set_device(int device);       /* one process per GPU: call once with LOCAL_RANK      */
+int kv_set_stream(void *hip_stream); /* hipStream_t; NULL = null stream                     */
+int kv_synchronize(void);
+
+/* live per-kernel timing with HIP events on the library's stream (bench.py roofline leg).
+ * kv_prof_get: accumulated milliseconds and launch count for a kernel name.             */
+int kv_prof_enable(int on);
+int kv_prof_reset(void);
+int kv_prof_get(const char *kernel, double *ms, uint64_t *launches);
+int kv_prof_names(char *buf, size_t cap); /* comma separated list of kernel names seen     */
+
+/* ---- host-side helpers (no table access) --------------------------------------------- */
+/* khmer table sizing: the n largest primes below `target`, odd numbers downwards
+ * (kevlar/count.py:29-35 -> khmer Counttable(k, tablesize, n)).                           */
+int kv_primes_below(double target, int n, uint64_t *out, int *found);
+/* khmer .hash(kmer) (kevlar/novel.py:145, kevlar/tests/test_novel.py:68-77)               */
+int kv_hash_kmer(int kind, const char *kmer, int k, uint64_t *out);
+/* khmer .reverse_hash(h): *graph kinds only; KV_ERR_NOTIMPL for *table kinds
+ * (kevlar/tests/test_sketch.py:39-69)                                                     */
+int kv_reverse_hash(int kind, uint64_t h, int k, char *out /* k+1 bytes */);
+/* hash-range band of consume_seqfile_banding (kevlar/count.py:62-66): lo <= h < hi        */
+int kv_band_bounds(int nbands, int band, uint64_t *lo, uint64_t *hi);
+
+/* ---- sketches ------------------------------------------------------------------------ */
+/* khmer Counttable/SmallCounttable/Nodetable/...(k, tablesize, ntables) with the primes
+ * already chosen (kevlar/sketch.py:99-119, kevlar/filter.py:29)                           */
+int kv_sketch_create(int kind, int ksize, int ntables, const uint64_t *sizes, kv_sketch **out);
+int kv_sketch_destroy(kv_sketch *s);
+/* khmer Class.load(path) / .save(path): OXLI v4 files (kevlar/sketch.py:14-27,77-92,
+ * kevlar/count.py:95, kevlar/novel.py:92)                                                 */
+int kv_sketch_load(const char *path, int kind, kv_sketch **out);
+int kv_sketch_save(kv_sketch *s, const char *path);
+/* .ksize() .n_tables() .hashsizes() .n_occupied() .n_unique_kmers()
+ * (kevlar/sketch.py:62-74, kevlar/count.py:82-84)                                         */
+int kv_sketch_info_get(kv_sketch *s, kv_sketch_info *out);
+/* raw storage of one table, as laid out on disk (bytes / packed nibbles / packed bits)    */
+int kv_sketch_table_read(kv_sketch *s, int table, uint8_t *host_out, uint64_t nbytes);
+int kv_sketch_table_write(kv_sketch *s, int table, const uint8_t *host_in, uint64_t nbytes);
+int kv_sketch_table_devptr(kv_sketch *s, int table, void **devptr, uint64_t *nbytes);
+
+/* ---- reads --------------------------------------------------------------------------- */
+/* khmer.ReadParser stand-in (kevlar/count.py:40): the host hands over parsed sequences
+ * (ASCII, concatenated; offs has n_reads+1 entries); the library 2-bit packs them into HBM.
+ * Bases outside ACGT are packed as 'A' (khmer's read cleaning) and the read is flagged so
+ * that the novel scan skips it (kevlar/novel.py:136-139).                                 */
+int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t n_reads, kv_reads **out);
+int kv_reads_destroy(kv_reads *r);
+int kv_reads_count(const kv_reads *r, uint64_t *n_reads, uint64_t *n_bases);
+/* number of k-mers a consume of this batch visits at size k (sum over reads of len-k+1)   */
+int kv_reads_num_kmers(const kv_reads *r, int ksize, uint64_t *n_kmers);
+
+/* ---- count: sketch.consume_seqfile[_banding][_with_mask] (kevlar/count.py:43-71) ------ */
+/* nbands = 0: no banding; else 0-based `band` of `nbands` (kevlar/count.py:122).
+ * mask = NULL or a sketch queried with this sketch's hash:
+ *   consume_masked == 0: skip the k-mer if mask.get(h) >  threshold
+ *   consume_masked != 0: skip the k-mer unless mask.get(h) >= threshold
+ * n_kmers_out: k-mers added.  n_unique_kmers is accumulated with the semantics of khmer's
+ * multi-threaded consume (a k-mer counts as new if any of its bins was zero when ITS
+ * increment landed); kv_sketch_unique_exact() gives the single-thread file-order value.   */
+int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int band, const kv_sketch *mask,
+               int threshold, int consume_masked, uint64_t *n_kmers_out);
+/* Re-derive n_unique_kmers exactly as a single khmer thread would have counted it over
+ * `batches` consumed in this order into an initially empty sketch (needs 4 bytes of HBM
+ * scratch per bin).  Used by `kevlar count` when --threads 1.                             */
+int kv_unique_exact(kv_sketch *s, const kv_reads *const *batches, int n_batches, int nbands,
+                    int band, const kv_sketch *mask, int threshold, int consume_masked,
+                    uint64_t *n_unique_out);
+
+/* ---- point queries: .get / .add on many k-mers (kevlar/filter.py:32-34,67) ------------ */
+/* hash n k-mers of length k stored back to back in `kmers` (device kernel)                */
+int kv_hash_kmers(int kind, const char *kmers, int k, uint64_t n, uint64_t *hashes_out);
+int kv_get_hashes(kv_sketch *s, const uint64_t *hashes, uint64_t n, uint8_t *counts_out);
+/* adds in array order semantics are order-free (saturating); is_new_out may be NULL       */
+int kv_add_hashes(kv_sketch *s, const uint64_t *hashes, uint64_t n, uint8_t *is_new_out);
+
+/* ---- novel: the fused scan (kevlar/novel.py:21-53,123-169) ---------------------------- */
+#define KV_BAND_NONE 0
+#define KV_BAND_RANGE 1     /* keep k-mers whose hash lies in the band (count-side rule)     */
+#define KV_BAND_REFQUIRK 2  /* reference literal: (h & (N-1)) != band0-1 -> skip
+                               (kevlar/novel.py:144-147)        */
+/* Scans reads[first_read:] ; a read shorter than k or flagged non-ACGT is skipped.
+ * screen_thresh <= 0 disables --abund-screen.  If d_mask != NULL (device pointer, u32
+ * words, zeroed by the caller) bit (read * mask_stride + offset) is set for every
+ * interesting k-mer: the per-band mask that the multi-GPU merge all-reduces.             */
+int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl,
+                  const kv_reads *reads, uint64_t first_read, int case_min, int ctrl_max,
+                  int screen_thresh, int band_mode, int nbands, int band, uint32_t *d_mask,
+                  uint64_t mask_stride, kv_hits **out);
+int kv_hits_count(const kv_hits *h, uint64_t *n_hits, uint64_t *n_discarded_reads);
+/* copies hits sorted by (read, offset); abund has n_hits * (ncase+nctrl) entries          */
+int kv_hits_fetch(const kv_hits *h, uint32_t *read, uint32_t *offset, uint8_t *abund,
+                  uint64_t cap_hits, uint32_t *discarded_reads, uint64_t cap_discarded);
+int kv_hits_destroy(kv_hits *h);
+
+/* ---- partition: read graph connected components (kevlar/readgraph.py:43-84,104-137) --- */
+/* One annotation = one interesting k-mer occurrence (read index in `reads`, offset).
+ * node_of_read maps a read to its graph node (reads sharing a name share a node).
+ * K-mers are identified by their canonical (min of forward / reverse-complement) sequence;
+ * a k-mer links all nodes containing it if minabund <= #nodes <= maxabund (0 = unbounded).
+ * labels_out[node] = smallest node id of its component.  n_edges_out (optional) = number
+ * of distinct node pairs sharing at least one retained k-mer (networkx number_of_edges).  */
+int kv_readgraph_components(const kv_reads *reads, int ksize, const uint32_t *ann_read,
+                            const uint32_t *ann_offset, uint64_t n_ann,
+                            const uint32_t *node_of_read, uint32_t n_nodes, uint32_t minabund,
+                            uint32_t maxabund, uint32_t *labels_out, uint64_t *n_edges_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVSKETCH_H */

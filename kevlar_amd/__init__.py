@@ -1,0 +1,77 @@
+"""kevlar_amd -- MI355X-native drop-in for kevlar's novel-k-mer path.
+
+Mirrors the reference package surface for count -> novel -> filter -> partition (+ unband):
+kevlar/__init__.py:72-128.  The sketch engine underneath (kevlar_amd.khmer) is HIP-only.
+"""
+import builtins
+from gzip import open as gzopen
+from os import makedirs
+from os.path import dirname
+import sys
+
+__version__ = '0.7+mi355x.r1'
+
+logstream = None
+teelog = False
+
+
+def plog(*args, **kwargs):
+    """Diagnostics go to the log stream (and to stderr when there is none, or with --tee)."""
+    if logstream is not None:
+        print(*args, **kwargs, file=logstream)
+    if logstream is None or teelog:
+        print(*args, **kwargs, file=sys.stderr)
+
+
+def open(filename, mode):
+    if mode not in ('r', 'w'):
+        raise ValueError('invalid mode "{}"'.format(mode))
+    if filename in ['-', None]:
+        return sys.stdin if mode == 'r' else sys.stdout
+    if filename.endswith('.gz'):
+        return gzopen(filename, mode + 't')
+    return builtins.open(filename, mode)
+
+
+def mkdirp(path, trim=False):
+    outdir = dirname(path) if trim else path
+    makedirs(outdir, exist_ok=True)
+    return outdir
+
+
+from kevlar_amd.sequence import (Record, KmerOfInterest, revcom, parse_augmented_fastx,  # noqa: E402
+                                 print_augmented_fastx)
+
+
+def revcommin(seq):
+    rc = revcom(seq)
+    return seq if seq <= rc else rc
+
+
+def same_seq(seq1, seq2, seq2revcom=None):
+    if seq2revcom is None:
+        seq2revcom = revcom(seq2)
+    return seq1 == seq2 or seq1 == seq2revcom
+
+
+from kevlar_amd.timer import Timer  # noqa: E402
+from kevlar_amd.progress import ProgressIndicator  # noqa: E402
+from kevlar_amd import khmer  # noqa: E402
+from kevlar_amd import sequence  # noqa: E402
+from kevlar_amd import seqio  # noqa: E402
+from kevlar_amd import sketch  # noqa: E402
+from kevlar_amd.seqio import parse_partitioned_reads, parse_single_partition  # noqa: E402
+from kevlar_amd import readgraph  # noqa: E402
+from kevlar_amd.readgraph import ReadGraph  # noqa: E402
+from kevlar_amd import count  # noqa: E402
+from kevlar_amd import novel  # noqa: E402
+from kevlar_amd import filter  # noqa: E402
+from kevlar_amd import partition  # noqa: E402
+from kevlar_amd import unband  # noqa: E402
+from kevlar_amd import cli  # noqa: E402
+
+
+def multi_file_iter_khmer(filenames):
+    for filename in filenames:
+        for record in khmer.ReadParser(filename):
+            yield record

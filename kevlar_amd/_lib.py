@@ -1,0 +1,139 @@
+"""ctypes binding of libkvsketch_hip.so (include/kvsketch.h).
+
+There is no CPU fallback: if the shared object is missing, or no MI355X is visible when a
+sketch is first touched, the caller gets an exception -- never a silently different path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBNAME = 'libkvsketch_hip.so'
+LIBPATH = os.path.join(_HERE, LIBNAME)
+
+KV_OK = 0
+KV_ERR_ARG, KV_ERR_IO, KV_ERR_TYPE, KV_ERR_HIP, KV_ERR_NOTIMPL, KV_ERR_CAPACITY = -1, -2, -3, -4, -5, -6
+KV_MAX_TABLES = 16
+KV_BAND_NONE, KV_BAND_RANGE, KV_BAND_REFQUIRK = 0, 1, 2
+
+u8p = ctypes.POINTER(ctypes.c_uint8)
+u32p = ctypes.POINTER(ctypes.c_uint32)
+u64p = ctypes.POINTER(ctypes.c_uint64)
+vp = ctypes.c_void_p
+vpp = ctypes.POINTER(ctypes.c_void_p)
+i32 = ctypes.c_int
+u32 = ctypes.c_uint32
+u64 = ctypes.c_uint64
+cstr = ctypes.c_char_p
+
+
+class SketchInfo(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int32), ('ksize', ctypes.c_int32), ('ntables', ctypes.c_int32),
+                ('reserved', ctypes.c_int32), ('sizes', ctypes.c_uint64 * KV_MAX_TABLES),
+                ('n_occupied', ctypes.c_uint64), ('n_unique', ctypes.c_uint64),
+                ('bytes_device', ctypes.c_uint64)]
+
+
+# every symbol include/kvsketch.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    'kv_last_error': (cstr, []),
+    'kv_version': (cstr, []),
+    'kv_device_count': (i32, [ctypes.POINTER(i32)]),
+    'kv_set_device': (i32, [i32]),
+    'kv_set_stream': (i32, [vp]),
+    'kv_synchronize': (i32, []),
+    'kv_prof_enable': (i32, [i32]),
+    'kv_prof_reset': (i32, []),
+    'kv_prof_get': (i32, [cstr, ctypes.POINTER(ctypes.c_double), u64p]),
+    'kv_prof_names': (i32, [ctypes.c_char_p, ctypes.c_size_t]),
+    'kv_primes_below': (i32, [ctypes.c_double, i32, u64p, ctypes.POINTER(i32)]),
+    'kv_hash_kmer': (i32, [i32, cstr, i32, u64p]),
+    'kv_reverse_hash': (i32, [i32, u64, i32, ctypes.c_char_p]),
+    'kv_band_bounds': (i32, [i32, i32, u64p, u64p]),
+    'kv_sketch_create': (i32, [i32, i32, i32, u64p, vpp]),
+    'kv_sketch_destroy': (i32, [vp]),
+    'kv_sketch_load': (i32, [cstr, i32, vpp]),
+    'kv_sketch_save': (i32, [vp, cstr]),
+    'kv_sketch_info_get': (i32, [vp, ctypes.POINTER(SketchInfo)]),
+    'kv_sketch_table_read': (i32, [vp, i32, u8p, u64]),
+    'kv_sketch_table_write': (i32, [vp, i32, u8p, u64]),
+    'kv_sketch_table_devptr': (i32, [vp, i32, vpp, u64p]),
+    'kv_reads_create': (i32, [cstr, u64p, u64, vpp]),
+    'kv_reads_destroy': (i32, [vp]),
+    'kv_reads_count': (i32, [vp, u64p, u64p]),
+    'kv_reads_num_kmers': (i32, [vp, i32, u64p]),
+    'kv_consume': (i32, [vp, vp, i32, i32, vp, i32, i32, u64p]),
+    'kv_unique_exact': (i32, [vp, vpp, i32, i32, i32, vp, i32, i32, u64p]),
+    'kv_hash_kmers': (i32, [i32, cstr, i32, u64, u64p]),
+    'kv_get_hashes': (i32, [vp, u64p, u64, u8p]),
+    'kv_add_hashes': (i32, [vp, u64p, u64, u8p]),
+    'kv_novel_scan': (i32, [vpp, i32, vpp, i32, vp, u64, i32, i32, i32, i32, i32, i32, vp, u64, vpp]),
+    'kv_hits_count': (i32, [vp, u64p, u64p]),
+    'kv_hits_fetch': (i32, [vp, u32p, u32p, u8p, u64, u32p, u64]),
+    'kv_hits_destroy': (i32, [vp]),
+    'kv_readgraph_components': (i32, [vp, i32, u32p, u32p, u64, u32p, u32, u32, u32, u32p, u64p]),
+}
+
+
+class KvError(RuntimeError):
+    """HIP / library failure that has no counterpart among the reference's exceptions."""
+
+    def __init__(self, code, message):
+        super(KvError, self).__init__('[kvsketch {}] {}'.format(code, message))
+        self.code = code
+
+
+_lib = None
+_device_ready = False
+
+
+def load():
+    """Load libkvsketch_hip.so.  Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPATH):
+        raise ImportError(
+            '{} not found: the HIP extension has not been built (run '
+            '`python -c "import __graft_entry__ as g; g.build()"`). kevlar_amd has no CPU '
+            'fallback.'.format(LIBPATH))
+    lib = ctypes.CDLL(LIBPATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().kv_last_error().decode('utf-8', 'replace')
+
+
+def check(code):
+    """Map a C return code onto the reference's exception types."""
+    if code == KV_OK:
+        return
+    msg = last_error()
+    if code in (KV_ERR_ARG, KV_ERR_NOTIMPL, KV_ERR_CAPACITY):
+        raise ValueError(msg)
+    if code == KV_ERR_IO:
+        raise OSError(msg)
+    if code == KV_ERR_TYPE:
+        raise ValueError(msg)
+    raise KvError(code, msg)
+
+
+def require_device():
+    """Make sure a GPU is there before the first table is allocated; fail loudly if not."""
+    global _device_ready
+    if _device_ready:
+        return
+    lib = load()
+    n = ctypes.c_int(0)
+    check(lib.kv_device_count(ctypes.byref(n)))
+    if n.value < 1:
+        raise KvError(KV_ERR_HIP, 'no HIP device visible: kevlar_amd runs its sketches on an '
+                                  'MI355X and has no CPU fallback')
+    dev = int(os.environ.get('LOCAL_RANK', '0')) % n.value
+    check(lib.kv_set_device(dev))
+    _device_ready = True

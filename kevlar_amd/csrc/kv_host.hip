@@ -1,0 +1,576 @@
+// kv_host.hip -- host side of libkvsketch_hip: handles, OXLI v4 file I/O, table sizing,
+// read packing and the live profiler.  All table memory is HBM (hipMalloc).
+#include <cstdarg>
+#include <map>
+
+#include "kv_internal.h"
+
+// ---------------------------------------------------------------------------------------
+// errors / device / stream
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void kv_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static hipStream_t g_stream = nullptr;
+hipStream_t kv_stream() { return g_stream; }
+
+extern "C" const char *kv_last_error(void) { return g_err; }
+extern "C" const char *kv_version(void) { return "kvsketch-hip 0.1 (gfx950)"; }
+
+extern "C" int kv_device_count(int *n)
+{
+    KV_REQUIRE(n, KV_ERR_ARG, "kv_device_count: null output");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { (void)hipGetLastError(); c = 0; }
+    *n = c;
+    return KV_OK;
+}
+
+extern "C" int kv_set_device(int device)
+{
+    KV_HIP(hipSetDevice(device));
+    return KV_OK;
+}
+
+extern "C" int kv_set_stream(void *s)
+{
+    g_stream = (hipStream_t)s;
+    return KV_OK;
+}
+
+extern "C" int kv_synchronize(void)
+{
+    KV_HIP(hipStreamSynchronize(g_stream));
+    return KV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// live profiler: HIP events on the library's stream around each kernel launch
+// ---------------------------------------------------------------------------------------
+struct ProfRec { double ms = 0; uint64_t n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+static bool g_prof_on = false;
+static std::map<std::string, ProfRec> g_prof;
+static std::mutex g_prof_mu;
+
+KvProfScope::KvProfScope(const char *n) : name(n), a(nullptr), b(nullptr), on(g_prof_on)
+{
+    if (!on) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(a, g_stream);
+}
+
+KvProfScope::~KvProfScope()
+{
+    if (!on) return;
+    (void)hipEventRecord(b, g_stream);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof[name].pending.emplace_back(a, b);
+}
+
+static void prof_drain()
+{
+    for (auto &kv : g_prof) {
+        for (auto &p : kv.second.pending) {
+            float ms = 0;
+            if (hipEventSynchronize(p.second) == hipSuccess &&
+                hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+                kv.second.ms += ms;
+                kv.second.n += 1;
+            }
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+extern "C" int kv_prof_enable(int on) { g_prof_on = on != 0; return KV_OK; }
+
+extern "C" int kv_prof_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_drain();
+    g_prof.clear();
+    return KV_OK;
+}
+
+extern "C" int kv_prof_get(const char *kernel, double *ms, uint64_t *launches)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_drain();
+    auto it = g_prof.find(kernel ? kernel : "");
+    if (ms) *ms = it == g_prof.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == g_prof.end() ? 0 : it->second.n;
+    return KV_OK;
+}
+
+extern "C" int kv_prof_names(char *buf, size_t cap)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::string s;
+    for (auto &kv : g_prof) { if (!s.empty()) s += ","; s += kv.first; }
+    KV_REQUIRE(buf && s.size() + 1 <= cap, KV_ERR_CAPACITY, "kv_prof_names: buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return KV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// host hashing helpers (single k-mers: khmer .hash(); the batch paths hash on the device)
+// ---------------------------------------------------------------------------------------
+static inline uint64_t rotl64h(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t fmix64h(uint64_t k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return k;
+}
+
+uint64_t kv_host_murmur_lo(const void *data, int len, uint32_t seed)
+{
+    const uint8_t *p = (const uint8_t *)data;
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    uint64_t h1 = seed, h2 = seed;
+    int nblocks = len / 16;
+    for (int b = 0; b < nblocks; ++b) {
+        uint64_t k1, k2;
+        memcpy(&k1, p + 16 * b, 8);
+        memcpy(&k2, p + 16 * b + 8, 8);
+        k1 *= c1; k1 = rotl64h(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64h(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = rotl64h(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64h(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    const uint8_t *tail = p + 16 * nblocks;
+    int rem = len & 15;
+    uint64_t k1 = 0, k2 = 0;
+    if (rem > 8) {
+        memcpy(&k2, tail + 8, (size_t)(rem - 8));
+        k2 *= c2; k2 = rotl64h(k2, 33); k2 *= c1; h2 ^= k2;
+    }
+    if (rem > 0) {
+        memcpy(&k1, tail, (size_t)(rem > 8 ? 8 : rem));
+        k1 *= c1; k1 = rotl64h(k1, 31); k1 *= c2; h1 ^= k1;
+    }
+    h1 ^= (uint64_t)len; h2 ^= (uint64_t)len;
+    h1 += h2; h2 += h1;
+    h1 = fmix64h(h1); h2 = fmix64h(h2);
+    return h1 + h2;
+}
+
+static inline char comp_base(char c)
+{
+    switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; }
+}
+
+uint64_t kv_host_hash(int hashfam, const char *kmer, int k, bool *ok)
+{
+    *ok = true;
+    if (hashfam == HF_TWOBIT) {
+        uint64_t f = 0, r = 0;
+        for (int i = 0; i < k; ++i) {
+            int c, cc;
+            switch (kmer[i]) { case 'A': c = 0; break; case 'T': c = 1; break; case 'C': c = 2; break; case 'G': c = 3; break; default: *ok = false; return 0; }
+            switch (kmer[k - 1 - i]) { case 'A': cc = 1; break; case 'T': cc = 0; break; case 'C': cc = 3; break; case 'G': cc = 2; break; default: *ok = false; return 0; }
+            f = (f << 2) | (uint64_t)c;
+            r = (r << 2) | (uint64_t)cc;
+        }
+        return f < r ? f : r;
+    }
+    char rc[KV_MAX_K + 1];
+    for (int i = 0; i < k; ++i) rc[i] = comp_base(kmer[k - 1 - i]);
+    return kv_host_murmur_lo(kmer, k, 0) ^ kv_host_murmur_lo(rc, k, 0);
+}
+
+extern "C" int kv_hash_kmer(int kind, const char *kmer, int k, uint64_t *out)
+{
+    KV_REQUIRE(kmer && out, KV_ERR_ARG, "kv_hash_kmer: null argument");
+    KV_REQUIRE(k >= 1 && k <= KV_MAX_K, KV_ERR_ARG, "kv_hash_kmer: k=%d out of range", k);
+    int fam = kv_hashfam_of(kind);
+    KV_REQUIRE(fam != HF_TWOBIT || k <= 32, KV_ERR_ARG, "graph sketches need k <= 32 (got %d)", k);
+    bool ok;
+    *out = kv_host_hash(fam, kmer, k, &ok);
+    KV_REQUIRE(ok, KV_ERR_ARG, "invalid DNA character in k-mer");
+    return KV_OK;
+}
+
+extern "C" int kv_reverse_hash(int kind, uint64_t h, int k, char *out)
+{
+    KV_REQUIRE(out, KV_ERR_ARG, "kv_reverse_hash: null output");
+    KV_REQUIRE(kv_hashfam_of(kind) == HF_TWOBIT, KV_ERR_NOTIMPL,
+               "reverse_hash not implemented for this hash function");
+    static const char alphabet[4] = {'A', 'T', 'C', 'G'};
+    for (int i = k - 1; i >= 0; --i) { out[i] = alphabet[h & 3]; h >>= 2; }
+    out[k] = '\0';
+    return KV_OK;
+}
+
+extern "C" int kv_band_bounds(int nbands, int band, uint64_t *lo, uint64_t *hi)
+{
+    KV_REQUIRE(nbands > 0 && band >= 0 && band < nbands, KV_ERR_ARG,
+               "band %d out of range for %d bands", band, nbands);
+    uint64_t bs = UINT64_MAX / (uint64_t)nbands;
+    *lo = bs * (uint64_t)band;
+    *hi = (band == nbands - 1) ? UINT64_MAX : bs * (uint64_t)(band + 1);
+    return KV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// table sizing
+// ---------------------------------------------------------------------------------------
+static bool is_prime_u64(uint64_t n)
+{
+    if (n < 2) return false;
+    if (n == 2) return true;
+    if ((n & 1) == 0) return false;
+    for (uint64_t d = 3; d * d <= n; d += 2)
+        if (n % d == 0) return false;
+    return true;
+}
+
+extern "C" int kv_primes_below(double target, int n, uint64_t *out, int *found)
+{
+    KV_REQUIRE(out && found && n >= 0, KV_ERR_ARG, "kv_primes_below: bad argument");
+    *found = 0;
+    if (!(target >= 3.0)) return KV_OK;
+    uint64_t i = (uint64_t)target - 1;  // fractional targets truncate
+    if ((i & 1) == 0) i -= 1;
+    while (*found < n && i >= 2) {
+        if (is_prime_u64(i)) out[(*found)++] = i;
+        if (i < 3) break;
+        i -= 2;
+    }
+    return KV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// sketch handles
+// ---------------------------------------------------------------------------------------
+int kv_sketch_alloc(int kind, int ksize, int ntables, const uint64_t *sizes, kv_sketch **out)
+{
+    KV_REQUIRE(out && sizes, KV_ERR_ARG, "kv_sketch_create: null argument");
+    KV_REQUIRE(kind >= KV_COUNTTABLE && kind <= KV_NODEGRAPH, KV_ERR_ARG, "unknown sketch kind %d", kind);
+    KV_REQUIRE(ntables >= 1 && ntables <= KV_MAX_TABLES, KV_ERR_ARG,
+               "number of tables must be in 1..%d (got %d)", KV_MAX_TABLES, ntables);
+    KV_REQUIRE(ksize >= 1 && ksize <= KV_MAX_K, KV_ERR_ARG, "k=%d out of range 1..%d", ksize, KV_MAX_K);
+    KV_REQUIRE(kv_hashfam_of(kind) != HF_TWOBIT || ksize <= 32, KV_ERR_ARG,
+               "graph sketches need k <= 32 (got %d)", ksize);
+    kv_sketch *s = new kv_sketch();
+    s->kind = kind;
+    memset(&s->h, 0, sizeof(s->h));
+    s->h.ntables = ntables;
+    s->h.storage = kv_storage_of(kind);
+    s->h.hashfam = kv_hashfam_of(kind);
+    s->h.ksize = ksize;
+    s->d_desc = nullptr;
+    s->d_counters = nullptr;
+    s->n_occupied = 0;
+    s->occ_dirty = false;
+    s->n_unique = 0;
+    for (int i = 0; i < ntables; ++i) {
+        if (sizes[i] == 0) { kv_set_error("table size must be positive"); delete s; return KV_ERR_ARG; }
+        s->h.size[i] = sizes[i];
+        s->h.magic[i] = UINT64_MAX / sizes[i];
+        uint64_t nb = kv_table_nbytes(s->h.storage, sizes[i]);
+        s->alloc_bytes[i] = (nb + 15) & ~15ull;  // word-granular atomics need padding
+    }
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < ntables && e == hipSuccess; ++i) {
+        e = hipMalloc((void **)&s->h.tab[i], s->alloc_bytes[i]);
+        if (e == hipSuccess) e = hipMemsetAsync(s->h.tab[i], 0, s->alloc_bytes[i], kv_stream());
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_desc, sizeof(SketchDev));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_counters, 4 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemcpy(s->d_desc, &s->h, sizeof(SketchDev), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(s->d_counters, 0, 4 * sizeof(uint64_t));
+    if (e != hipSuccess) {
+        kv_set_error("sketch allocation failed: %s", hipGetErrorString(e));
+        kv_sketch_destroy(s);
+        return KV_ERR_HIP;
+    }
+    *out = s;
+    return KV_OK;
+}
+
+extern "C" int kv_sketch_create(int kind, int ksize, int ntables, const uint64_t *sizes, kv_sketch **out)
+{
+    return kv_sketch_alloc(kind, ksize, ntables, sizes, out);
+}
+
+extern "C" int kv_sketch_destroy(kv_sketch *s)
+{
+    if (!s) return KV_OK;
+    for (int i = 0; i < KV_MAX_TABLES; ++i)
+        if (s->h.tab[i]) (void)hipFree(s->h.tab[i]);
+    if (s->d_desc) (void)hipFree(s->d_desc);
+    if (s->d_counters) (void)hipFree(s->d_counters);
+    delete s;
+    return KV_OK;
+}
+
+extern "C" int kv_sketch_info_get(kv_sketch *s, kv_sketch_info *out)
+{
+    KV_REQUIRE(s && out, KV_ERR_ARG, "kv_sketch_info_get: null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->occ_dirty) {
+        int rc = kv_sketch_refresh_occupancy(s);
+        if (rc != KV_OK) return rc;
+    }
+    memset(out, 0, sizeof(*out));
+    out->kind = s->kind;
+    out->ksize = s->h.ksize;
+    out->ntables = s->h.ntables;
+    for (int i = 0; i < s->h.ntables; ++i) {
+        out->sizes[i] = s->h.size[i];
+        out->bytes_device += s->alloc_bytes[i];
+    }
+    out->n_occupied = s->n_occupied;
+    out->n_unique = s->n_unique;
+    return KV_OK;
+}
+
+extern "C" int kv_sketch_table_read(kv_sketch *s, int table, uint8_t *host_out, uint64_t nbytes)
+{
+    KV_REQUIRE(s && host_out && table >= 0 && table < s->h.ntables, KV_ERR_ARG, "kv_sketch_table_read: bad argument");
+    uint64_t nb = kv_table_nbytes(s->h.storage, s->h.size[table]);
+    KV_REQUIRE(nbytes >= nb, KV_ERR_CAPACITY, "table %d needs %llu bytes", table, (unsigned long long)nb);
+    std::lock_guard<std::mutex> lk(s->mu);
+    KV_HIP(hipMemcpyAsync(host_out, s->h.tab[table], nb, hipMemcpyDeviceToHost, kv_stream()));
+    KV_HIP(hipStreamSynchronize(kv_stream()));
+    return KV_OK;
+}
+
+extern "C" int kv_sketch_table_write(kv_sketch *s, int table, const uint8_t *host_in, uint64_t nbytes)
+{
+    KV_REQUIRE(s && host_in && table >= 0 && table < s->h.ntables, KV_ERR_ARG, "kv_sketch_table_write: bad argument");
+    uint64_t nb = kv_table_nbytes(s->h.storage, s->h.size[table]);
+    KV_REQUIRE(nbytes == nb, KV_ERR_ARG, "table %d holds %llu bytes", table, (unsigned long long)nb);
+    std::lock_guard<std::mutex> lk(s->mu);
+    KV_HIP(hipMemcpyAsync(s->h.tab[table], host_in, nb, hipMemcpyHostToDevice, kv_stream()));
+    KV_HIP(hipStreamSynchronize(kv_stream()));
+    s->occ_dirty = true;
+    return KV_OK;
+}
+
+extern "C" int kv_sketch_table_devptr(kv_sketch *s, int table, void **devptr, uint64_t *nbytes)
+{
+    KV_REQUIRE(s && devptr && table >= 0 && table < s->h.ntables, KV_ERR_ARG, "kv_sketch_table_devptr: bad argument");
+    *devptr = s->h.tab[table];
+    if (nbytes) *nbytes = kv_table_nbytes(s->h.storage, s->h.size[table]);
+    return KV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// OXLI v4 files.  Layouts (decoded from the reference's fixtures):
+//   Byte   : "OXLI" 04 01 use_bigcount(u8)=0 k(u32) ntables(u8) n_occupied(u64)
+//            { size(u64) bytes[size] }*  n_bigcounts(u64)=0
+//   Bit    : "OXLI" 04 02 k(u32) ntables(u8) n_occupied(u64) { size(u64) bytes[size/8+1] }*
+//   Nibble : "OXLI" 04 07 k(u32) ntables(u8) n_occupied(u64) { size(u64) bytes[size/2+1] }*
+// ---------------------------------------------------------------------------------------
+static bool rd(FILE *f, void *p, size_t n) { return fread(p, 1, n, f) == n; }
+
+extern "C" int kv_sketch_load(const char *path, int kind, kv_sketch **out)
+{
+    KV_REQUIRE(path && out, KV_ERR_ARG, "kv_sketch_load: null argument");
+    KV_REQUIRE(kind >= KV_COUNTTABLE && kind <= KV_NODEGRAPH, KV_ERR_ARG, "unknown sketch kind %d", kind);
+    FILE *f = fopen(path, "rb");
+    KV_REQUIRE(f, KV_ERR_IO, "cannot open sketch file %s", path);
+    uint8_t hdr[6];
+    uint8_t bigcount = 0, nt = 0;
+    uint32_t k = 0;
+    uint64_t occ = 0;
+    int storage = -1;
+    bool ok = rd(f, hdr, 6) && memcmp(hdr, "OXLI", 4) == 0 && hdr[4] == 4;
+    if (ok) storage = hdr[5] == 1 ? ST_BYTE : (hdr[5] == 2 ? ST_BIT : (hdr[5] == 7 ? ST_NIBBLE : -1));
+    if (!ok || storage < 0) { fclose(f); kv_set_error("%s is not an OXLI v4 sketch file", path); return KV_ERR_IO; }
+    if (storage != kv_storage_of(kind)) {
+        fclose(f);
+        kv_set_error("sketch file %s holds storage type %d, which does not match the requested sketch class", path, (int)hdr[5]);
+        return KV_ERR_TYPE;
+    }
+    if (storage == ST_BYTE) ok = rd(f, &bigcount, 1);
+    ok = ok && rd(f, &k, 4) && rd(f, &nt, 1) && rd(f, &occ, 8);
+    if (!ok || nt < 1 || nt > KV_MAX_TABLES) { fclose(f); kv_set_error("truncated or unsupported sketch header in %s", path); return KV_ERR_IO; }
+    std::vector<uint64_t> sizes(nt);
+    std::vector<std::vector<uint8_t>> data(nt);
+    for (int i = 0; i < nt && ok; ++i) {
+        ok = rd(f, &sizes[i], 8);
+        if (!ok) break;
+        data[i].resize(kv_table_nbytes(storage, sizes[i]));
+        ok = rd(f, data[i].data(), data[i].size());
+    }
+    fclose(f);
+    KV_REQUIRE(ok, KV_ERR_IO, "truncated sketch file %s", path);
+    kv_sketch *s = nullptr;
+    int rc = kv_sketch_alloc(kind, (int)k, nt, sizes.data(), &s);
+    if (rc != KV_OK) return rc;
+    for (int i = 0; i < nt; ++i) {
+        hipError_t e = hipMemcpy(s->h.tab[i], data[i].data(), data[i].size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { kv_set_error("upload of %s failed: %s", path, hipGetErrorString(e)); kv_sketch_destroy(s); return KV_ERR_HIP; }
+    }
+    s->n_occupied = occ;  // khmer keeps the header value
+    s->occ_dirty = false;
+    *out = s;
+    return KV_OK;
+}
+
+extern "C" int kv_sketch_save(kv_sketch *s, const char *path)
+{
+    KV_REQUIRE(s && path, KV_ERR_ARG, "kv_sketch_save: null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->occ_dirty) {
+        int rc = kv_sketch_refresh_occupancy(s);
+        if (rc != KV_OK) return rc;
+    }
+    FILE *f = fopen(path, "wb");
+    KV_REQUIRE(f, KV_ERR_IO, "cannot open %s for writing", path);
+    const int st = s->h.storage;
+    uint8_t hdr[6] = {'O', 'X', 'L', 'I', 4, (uint8_t)(st == ST_BYTE ? 1 : (st == ST_BIT ? 2 : 7))};
+    fwrite(hdr, 1, 6, f);
+    if (st == ST_BYTE) fputc(0, f);
+    uint32_t k = (uint32_t)s->h.ksize;
+    uint8_t nt = (uint8_t)s->h.ntables;
+    fwrite(&k, 4, 1, f);
+    fwrite(&nt, 1, 1, f);
+    fwrite(&s->n_occupied, 8, 1, f);
+    std::vector<uint8_t> buf;
+    for (int i = 0; i < s->h.ntables; ++i) {
+        uint64_t nb = kv_table_nbytes(st, s->h.size[i]);
+        buf.resize(nb);
+        hipError_t e = hipMemcpyAsync(buf.data(), s->h.tab[i], nb, hipMemcpyDeviceToHost, kv_stream());
+        if (e == hipSuccess) e = hipStreamSynchronize(kv_stream());
+        if (e != hipSuccess) { fclose(f); kv_set_error("download of table %d failed: %s", i, hipGetErrorString(e)); return KV_ERR_HIP; }
+        fwrite(&s->h.size[i], 8, 1, f);
+        fwrite(buf.data(), 1, nb, f);
+    }
+    if (st == ST_BYTE) { uint64_t z = 0; fwrite(&z, 8, 1, f); }
+    bool bad = ferror(f) != 0;
+    bad = (fclose(f) != 0) || bad;
+    KV_REQUIRE(!bad, KV_ERR_IO, "write to %s failed", path);
+    return KV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// reads: 2-bit packing on the host, upload, tile table
+// ---------------------------------------------------------------------------------------
+extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t n_reads, kv_reads **out)
+{
+    KV_REQUIRE(out && offs && (bases || n_reads == 0), KV_ERR_ARG, "kv_reads_create: null argument");
+    KV_REQUIRE(n_reads < 0xFFFFFFF0ull, KV_ERR_ARG, "too many reads in one batch");
+    kv_reads *r = new kv_reads();
+    r->n_reads = n_reads;
+    r->n_bases = n_reads ? offs[n_reads] - offs[0] : 0;
+    r->d_words = nullptr; r->d_woff = nullptr; r->d_len = nullptr; r->d_flags = nullptr; r->d_tile = nullptr;
+    r->h_len.resize(n_reads);
+    std::vector<uint64_t> woff(n_reads + 1);
+    std::vector<uint8_t> flags(n_reads);
+    std::vector<uint32_t> tiles;
+    uint64_t nw = 0;
+    uint32_t max_len = 0;
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        uint64_t len = offs[i + 1] - offs[i];
+        if (len > KV_MAX_READ_LEN) {
+            kv_set_error("read %llu has %llu bases; this build handles reads up to %d bases",
+                         (unsigned long long)i, (unsigned long long)len, (int)KV_MAX_READ_LEN);
+            delete r;
+            return KV_ERR_ARG;
+        }
+        r->h_len[i] = (uint32_t)len;
+        if (len > max_len) max_len = (uint32_t)len;
+        woff[i] = nw;
+        nw += (len + 15) / 16;
+    }
+    woff[n_reads] = nw;
+    r->n_words = nw;
+    r->max_len = max_len;
+    std::vector<uint32_t> words(nw ? nw : 1, 0);
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        const char *s = bases + offs[i];
+        uint32_t *w = words.data() + woff[i];
+        uint8_t flag = 0;
+        for (uint32_t j = 0; j < r->h_len[i]; ++j) {
+            uint32_t c;
+            switch (s[j]) {
+            case 'A': c = 0; break;
+            case 'C': c = 1; break;
+            case 'G': c = 2; break;
+            case 'T': c = 3; break;
+            case 'a': c = 0; flag = 1; break;
+            case 'c': c = 1; flag = 1; break;
+            case 'g': c = 2; flag = 1; break;
+            case 't': c = 3; flag = 1; break;
+            default: c = 0; flag = 1; break;
+            }
+            w[j >> 4] |= c << (2 * (j & 15));
+        }
+        flags[i] = flag;
+    }
+    // tiles: consecutive reads whose staged ASCII (both strands, padded) fits the LDS budget
+    {
+        uint32_t used = 0, count = 0;
+        tiles.push_back(0);
+        for (uint64_t i = 0; i < n_reads; ++i) {
+            uint32_t need = 2 * ((r->h_len[i] + KV_READ_PAD + 3) & ~3u);
+            if (count == KV_TILE_MAX_READS || used + need > KV_TILE_LDS_BYTES - 64) {
+                tiles.push_back((uint32_t)i);
+                used = 0; count = 0;
+            }
+            used += need; count += 1;
+        }
+        if (n_reads) tiles.push_back((uint32_t)n_reads);
+        r->n_tiles = (uint32_t)tiles.size() - 1;
+    }
+    hipError_t e = hipMalloc((void **)&r->d_words, words.size() * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, n_reads ? n_reads : 1);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, tiles.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(r->d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(r->d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_reads) e = hipMemcpy(r->d_len, r->h_len.data(), n_reads * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_reads) e = hipMemcpy(r->d_flags, flags.data(), n_reads, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(r->d_tile, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        kv_set_error("read batch upload failed: %s", hipGetErrorString(e));
+        kv_reads_destroy(r);
+        return KV_ERR_HIP;
+    }
+    *out = r;
+    return KV_OK;
+}
+
+extern "C" int kv_reads_destroy(kv_reads *r)
+{
+    if (!r) return KV_OK;
+    if (r->d_words) (void)hipFree(r->d_words);
+    if (r->d_woff) (void)hipFree(r->d_woff);
+    if (r->d_len) (void)hipFree(r->d_len);
+    if (r->d_flags) (void)hipFree(r->d_flags);
+    if (r->d_tile) (void)hipFree(r->d_tile);
+    delete r;
+    return KV_OK;
+}
+
+extern "C" int kv_reads_count(const kv_reads *r, uint64_t *n_reads, uint64_t *n_bases)
+{
+    KV_REQUIRE(r, KV_ERR_ARG, "kv_reads_count: null handle");
+    if (n_reads) *n_reads = r->n_reads;
+    if (n_bases) *n_bases = r->n_bases;
+    return KV_OK;
+}
+
+extern "C" int kv_reads_num_kmers(const kv_reads *r, int ksize, uint64_t *n_kmers)
+{
+    KV_REQUIRE(r && n_kmers && ksize >= 1, KV_ERR_ARG, "kv_reads_num_kmers: bad argument");
+    uint64_t n = 0;
+    for (uint32_t len : r->h_len)
+        if (len >= (uint32_t)ksize) n += len - (uint32_t)ksize + 1;
+    *n_kmers = n;
+    return KV_OK;
+}

@@ -1,0 +1,112 @@
+// kv_internal.h -- shared declarations of libkvsketch_hip (gfx950 only; no CUDA path).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kvsketch.h"
+
+enum { ST_BYTE = 0, ST_NIBBLE = 1, ST_BIT = 2 };
+enum { HF_MURMUR = 0, HF_TWOBIT = 1 };
+
+static inline int kv_storage_of(int kind)
+{
+    switch (kind) {
+    case KV_COUNTTABLE: case KV_COUNTGRAPH: return ST_BYTE;
+    case KV_SMALLCOUNTTABLE: case KV_SMALLCOUNTGRAPH: return ST_NIBBLE;
+    default: return ST_BIT;
+    }
+}
+static inline int kv_hashfam_of(int kind) { return kind >= KV_COUNTGRAPH ? HF_TWOBIT : HF_MURMUR; }
+static inline uint64_t kv_table_nbytes(int storage, uint64_t size)
+{
+    return storage == ST_BYTE ? size : (storage == ST_NIBBLE ? size / 2 + 1 : size / 8 + 1);
+}
+
+// Device-visible description of one sketch.  Lives in HBM (kv_sketch::d_desc) so kernels
+// read it through scalar loads; also kept on the host.
+struct SketchDev {
+    uint64_t size[KV_MAX_TABLES];
+    uint64_t magic[KV_MAX_TABLES];  // floor((2^64-1)/size): Barrett reciprocal for h % size
+    uint8_t *tab[KV_MAX_TABLES];
+    int32_t ntables, storage, hashfam, ksize;
+};
+
+struct kv_sketch {
+    int kind;
+    SketchDev h;          // host copy
+    SketchDev *d_desc;    // device copy
+    uint64_t alloc_bytes[KV_MAX_TABLES];
+    uint64_t n_occupied;  // valid when !occ_dirty
+    bool occ_dirty;
+    uint64_t n_unique;
+    uint64_t *d_counters; // [0] n_kmers, [1] n_unique (device accumulators)
+    std::mutex mu;
+};
+
+// Packed read batch.  Read r occupies words [woff[r], woff[r+1]) of `words`; base j sits in
+// word woff[r] + j/16 at bits 2*(j%16), code A=0 C=1 G=2 T=3.
+struct kv_reads {
+    uint64_t n_reads, n_bases, n_words;
+    uint32_t *d_words;
+    uint64_t *d_woff;   // n_reads + 1
+    uint32_t *d_len;    // n_reads
+    uint8_t *d_flags;   // n_reads: bit0 = contains a base outside ACGT (novel scan skips it)
+    uint32_t *d_tile;   // n_tiles + 1 read indices: tile t = reads [d_tile[t], d_tile[t+1])
+    uint32_t n_tiles;
+    uint32_t max_len;
+    std::vector<uint32_t> h_len;    // host copies (k-mer counting, hit bookkeeping)
+};
+
+struct kv_hits {
+    int nsamples;
+    std::vector<uint32_t> read, offset;
+    std::vector<uint8_t> abund;
+    std::vector<uint32_t> discarded;
+};
+
+// tile geometry of the hashing kernels
+#define KV_TILE_THREADS 256
+#define KV_TILE_MAX_READS 128
+#define KV_TILE_LDS_BYTES 40960  // ASCII staging (forward + reverse complement) per tile
+#define KV_READ_PAD 24           // over-read slack after each staged strand
+#define KV_MAX_READ_LEN ((KV_TILE_LDS_BYTES - 64) / 2 - KV_READ_PAD - 8)
+
+// error plumbing -------------------------------------------------------------------------
+void kv_set_error(const char *fmt, ...);
+#define KV_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            kv_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,  \
+                         __LINE__);                                                         \
+            return KV_ERR_HIP;                                                              \
+        }                                                                                   \
+    } while (0)
+#define KV_REQUIRE(cond, code, ...)                                                         \
+    do {                                                                                    \
+        if (!(cond)) { kv_set_error(__VA_ARGS__); return (code); }                          \
+    } while (0)
+
+hipStream_t kv_stream();
+
+// profiling: RAII wrapper recording HIP events around a launch when enabled
+struct KvProfScope {
+    const char *name;
+    hipEvent_t a, b;
+    bool on;
+    explicit KvProfScope(const char *n);
+    ~KvProfScope();
+};
+
+// host helpers shared between files
+uint64_t kv_host_murmur_lo(const void *data, int len, uint32_t seed);
+uint64_t kv_host_hash(int hashfam, const char *kmer, int k, bool *ok);
+int kv_sketch_alloc(int kind, int ksize, int ntables, const uint64_t *sizes, kv_sketch **out);
+int kv_sketch_refresh_occupancy(kv_sketch *s);

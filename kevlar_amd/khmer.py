@@ -1,0 +1,470 @@
+"""The khmer sketch surface that kevlar calls, backed by HIP kernels on an MI355X.
+
+Same class and method names, argument meaning and error behaviour as the khmer objects used
+by the reference:
+
+    Counttable / SmallCounttable / Nodetable / Countgraph / SmallCountgraph / Nodegraph
+        (k, tablesize, ntables[, primes])      kevlar/sketch.py:99-119, kevlar/filter.py:29
+    .load(path) / .save(path)                  kevlar/sketch.py:14-27, kevlar/count.py:95
+    .consume_seqfile[_banding][_with_mask]     kevlar/count.py:43-71
+    .get .add .hash .get_kmers .get_kmer_hashes .reverse_hash
+                                               kevlar/novel.py:38,48,143,145, filter.py:32-34,67
+    .hashsizes .n_occupied .n_unique_kmers .ksize .n_tables
+                                               kevlar/sketch.py:62-74, kevlar/count.py:84
+    ReadParser, _buckets_per_byte, khmer_args.memory_setting
+                                               kevlar/count.py:33,40, kevlar/cli/count.py:49
+
+Every table lives in HBM; every method that touches a table is a kernel launch through the
+C ABI in include/kvsketch.h.  There is no CPU implementation behind these classes.
+"""
+import ctypes
+import gzip
+import threading
+
+import numpy as np
+
+from kevlar_amd import _lib
+from kevlar_amd._lib import check
+
+KIND = {'Counttable': 0, 'SmallCounttable': 1, 'Nodetable': 2,
+        'Countgraph': 3, 'SmallCountgraph': 4, 'Nodegraph': 5}
+
+_buckets_per_byte = {'countgraph': 1, 'smallcountgraph': 2, 'nodegraph': 8}
+
+# reads handed to the device per kv_consume call when streaming a file
+BATCH_READS = 1 << 20
+
+
+def _u64p(arr):
+    return arr.ctypes.data_as(_lib.u64p)
+
+
+def _u32p(arr):
+    return arr.ctypes.data_as(_lib.u32p)
+
+
+def _u8p(arr):
+    return arr.ctypes.data_as(_lib.u8p)
+
+
+# ----------------------------------------------------------------------------------------
+# reads
+# ----------------------------------------------------------------------------------------
+class Read(object):
+    __slots__ = ('name', 'sequence', 'quality')
+
+    def __init__(self, name, sequence, quality=None):
+        self.name = name
+        self.sequence = sequence
+        self.quality = quality
+
+
+def _open_maybe_gz(path):
+    with open(path, 'rb') as fh:
+        magic = fh.read(2)
+    if magic == b'\x1f\x8b':
+        return gzip.open(path, 'rt')
+    return open(path, 'r')
+
+
+def _iter_fastx(path):
+    with _open_maybe_gz(path) as fh:
+        line = fh.readline()
+        while line:
+            if line.strip() == '':
+                line = fh.readline()
+                continue
+            first = line[0]
+            if first == '@':
+                name = line[1:].rstrip('\r\n')
+                seq = fh.readline().rstrip('\r\n')
+                fh.readline()
+                qual = fh.readline().rstrip('\r\n')
+                yield Read(name, seq, qual)
+                line = fh.readline()
+            elif first == '>':
+                name = line[1:].rstrip('\r\n')
+                chunks = []
+                line = fh.readline()
+                while line and line[0] != '>':
+                    chunks.append(line.strip())
+                    line = fh.readline()
+                yield Read(name, ''.join(chunks), None)
+            else:
+                raise ValueError('cannot parse sequence file ' + path)
+
+
+class ReadParser(object):
+    """FASTA/FASTQ reader (gzip transparent); name = the header line after '@' or '>'.
+
+    Iteration is thread-safe: kevlar/count.py:41-76 shares one parser between threads."""
+
+    def __init__(self, filename):
+        self._iter = _iter_fastx(filename)
+        self._lock = threading.Lock()
+        self.num_reads = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        with self._lock:
+            read = next(self._iter)
+            self.num_reads += 1
+            return read
+
+    def take(self, n):
+        """Up to n reads as a list (one lock acquisition)."""
+        out = []
+        with self._lock:
+            for read in self._iter:
+                self.num_reads += 1
+                out.append(read)
+                if len(out) >= n:
+                    break
+        return out
+
+
+class ReadBatch(object):
+    """A batch of reads 2-bit packed in HBM (kv_reads)."""
+
+    def __init__(self, sequences):
+        _lib.require_device()
+        lib = _lib.load()
+        n = len(sequences)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        if n:
+            np.cumsum(np.fromiter((len(s) for s in sequences), dtype=np.uint64, count=n), out=offs[1:])
+        blob = ''.join(sequences).encode('latin-1')
+        handle = ctypes.c_void_p()
+        check(lib.kv_reads_create(blob, _u64p(offs), n, ctypes.byref(handle)))
+        self._h = handle
+        self.n_reads = n
+
+    @classmethod
+    def from_arrays(cls, blob, offs):
+        """blob: bytes of concatenated ASCII bases; offs: uint64 array with n+1 entries."""
+        _lib.require_device()
+        lib = _lib.load()
+        self = cls.__new__(cls)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        handle = ctypes.c_void_p()
+        check(lib.kv_reads_create(blob, _u64p(offs), len(offs) - 1, ctypes.byref(handle)))
+        self._h = handle
+        self.n_reads = len(offs) - 1
+        return self
+
+    def num_kmers(self, ksize):
+        n = ctypes.c_uint64()
+        check(_lib.load().kv_reads_num_kmers(self._h, ksize, ctypes.byref(n)))
+        return n.value
+
+    def close(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            _lib.load().kv_reads_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+
+# ----------------------------------------------------------------------------------------
+# sketches
+# ----------------------------------------------------------------------------------------
+def primes_below(target, n):
+    out = (ctypes.c_uint64 * max(1, n))()
+    found = ctypes.c_int()
+    check(_lib.load().kv_primes_below(float(target), n, out, ctypes.byref(found)))
+    return [int(out[i]) for i in range(found.value)]
+
+
+class _Sketch(object):
+    _kind = None
+
+    def __init__(self, k, starting_size, n_tables, primes=None, _handle=None):
+        self._lock = threading.Lock()
+        self._exact = None      # when tracking: list of (ReadBatch, filter-key) seen so far
+        self._exact_cache = None
+        if _handle is not None:
+            self._h = _handle
+            return
+        _lib.require_device()
+        lib = _lib.load()
+        if not primes:
+            primes = primes_below(starting_size, int(n_tables))
+        if len(primes) == 0:
+            raise ValueError('table size {} is too small to hold any table'.format(starting_size))
+        arr = (ctypes.c_uint64 * len(primes))(*[int(p) for p in primes])
+        handle = ctypes.c_void_p()
+        check(lib.kv_sketch_create(self._kind, int(k), len(primes), arr, ctypes.byref(handle)))
+        self._h = handle
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                _lib.load().kv_sketch_destroy(h)
+            except Exception:
+                pass
+
+    @classmethod
+    def load(cls, path):
+        _lib.require_device()
+        handle = ctypes.c_void_p()
+        check(_lib.load().kv_sketch_load(path.encode(), cls._kind, ctypes.byref(handle)))
+        return cls(0, 0, 0, _handle=handle)
+
+    def save(self, path):
+        check(_lib.load().kv_sketch_save(self._h, path.encode()))
+
+    # ---- info ---------------------------------------------------------------------------
+    def _info(self):
+        info = _lib.SketchInfo()
+        check(_lib.load().kv_sketch_info_get(self._h, ctypes.byref(info)))
+        return info
+
+    def ksize(self):
+        return int(self._info().ksize)
+
+    def n_tables(self):
+        return int(self._info().ntables)
+
+    def hashsizes(self):
+        info = self._info()
+        return [int(info.sizes[i]) for i in range(info.ntables)]
+
+    def n_occupied(self):
+        return int(self._info().n_occupied)
+
+    def n_unique_kmers(self):
+        """Distinct k-mers seen.  With track_exact_unique(True) this is the value one khmer
+        thread reports for the same files in the same order; otherwise it carries the
+        semantics of khmer's multi-threaded consume (see include/kvsketch.h kv_consume)."""
+        if self._exact:
+            if self._exact_cache is None:
+                batches, key = [b for b, _ in self._exact], self._exact[0][1]
+                nbands, band, mask, threshold, consume_masked = key
+                arr = (ctypes.c_void_p * len(batches))(*[b._h for b in batches])
+                out = ctypes.c_uint64()
+                check(_lib.load().kv_unique_exact(
+                    self._h, arr, len(batches), nbands, band, mask._h if mask is not None else None,
+                    threshold, 1 if consume_masked else 0, ctypes.byref(out)))
+                self._exact_cache = out.value
+            return self._exact_cache
+        return int(self._info().n_unique)
+
+    def track_exact_unique(self, on=True):
+        """Keep the packed read batches of subsequent consume_seqfile* calls in HBM so that
+        n_unique_kmers() can be re-derived exactly (single-thread semantics)."""
+        self._exact = [] if on else None
+        self._exact_cache = None
+
+    def table_bytes(self, i):
+        """Raw on-disk form of table i (tests compare this against the oracle)."""
+        info = self._info()
+        size = int(info.sizes[i])
+        storage = {0: 'byte', 3: 'byte', 1: 'nibble', 4: 'nibble'}.get(self._kind, 'bit')
+        nbytes = size if storage == 'byte' else (size // 2 + 1 if storage == 'nibble' else size // 8 + 1)
+        buf = np.empty(nbytes, dtype=np.uint8)
+        check(_lib.load().kv_sketch_table_read(self._h, i, _u8p(buf), nbytes))
+        return buf.tobytes()
+
+    # ---- hashing ------------------------------------------------------------------------
+    def hash(self, kmer):
+        k = self.ksize()
+        if len(kmer) != k:
+            raise ValueError('k-mer length {} does not match the sketch k-size {}'.format(len(kmer), k))
+        out = ctypes.c_uint64()
+        check(_lib.load().kv_hash_kmer(self._kind, kmer.encode(), k, ctypes.byref(out)))
+        return out.value
+
+    def reverse_hash(self, h):
+        k = self.ksize()
+        buf = ctypes.create_string_buffer(k + 1)
+        check(_lib.load().kv_reverse_hash(self._kind, int(h), k, buf))
+        return buf.value.decode()
+
+    def get_kmers(self, seq):
+        k = self.ksize()
+        return [seq[i:i + k] for i in range(len(seq) - k + 1)]
+
+    def hash_kmers(self, kmers):
+        """Device-side hashing of a list of k-mers -> numpy uint64 array."""
+        k = self.ksize()
+        n = len(kmers)
+        out = np.empty(n, dtype=np.uint64)
+        if n:
+            blob = ''.join(kmers).encode('latin-1')
+            if len(blob) != n * k:
+                raise ValueError('every k-mer must have length {}'.format(k))
+            check(_lib.load().kv_hash_kmers(self._kind, blob, k, n, _u64p(out)))
+        return out
+
+    def get_kmer_hashes(self, seq):
+        return [int(h) for h in self.hash_kmers(self.get_kmers(seq))]
+
+    def _tohash(self, kmer):
+        return int(kmer) if isinstance(kmer, (int, np.integer)) else self.hash(kmer)
+
+    # ---- add / get ------------------------------------------------------------------------
+    def get_hashes(self, hashes):
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        out = np.empty(len(hashes), dtype=np.uint8)
+        if len(hashes):
+            check(_lib.load().kv_get_hashes(self._h, _u64p(hashes), len(hashes), _u8p(out)))
+        return out
+
+    def add_hashes(self, hashes):
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        out = np.empty(len(hashes), dtype=np.uint8)
+        if len(hashes):
+            check(_lib.load().kv_add_hashes(self._h, _u64p(hashes), len(hashes), _u8p(out)))
+        return out
+
+    def get(self, kmer):
+        return int(self.get_hashes(np.array([self._tohash(kmer)], dtype=np.uint64))[0])
+
+    def add(self, kmer):
+        return bool(self.add_hashes(np.array([self._tohash(kmer)], dtype=np.uint64))[0])
+
+    count = add
+
+    # ---- consume --------------------------------------------------------------------------
+    def consume_batch(self, batch, nbands=0, band=0, mask=None, threshold=0, consume_masked=False):
+        n = ctypes.c_uint64()
+        check(_lib.load().kv_consume(self._h, batch._h, nbands or 0, band or 0,
+                                     mask._h if mask is not None else None, int(threshold),
+                                     1 if consume_masked else 0, ctypes.byref(n)))
+        if self._exact is not None:
+            with self._lock:
+                key = (nbands or 0, band or 0, mask, int(threshold), bool(consume_masked))
+                if self._exact and self._exact[0][1] != key:
+                    self._exact = None   # mixed settings: exact re-derivation not defined
+                else:
+                    self._exact.append((batch, key))
+                    self._exact_cache = None
+        return n.value
+
+    def consume(self, seq):
+        return self.consume_batch(ReadBatch([seq]))
+
+    def _consume_file(self, parser, nbands, band, mask, threshold, consume_masked):
+        if isinstance(parser, str):
+            parser = ReadParser(parser)
+        nreads = nkmers = 0
+        while True:
+            reads = parser.take(BATCH_READS)
+            if not reads:
+                break
+            batch = ReadBatch([r.sequence for r in reads])
+            nkmers += self.consume_batch(batch, nbands, band, mask, threshold, consume_masked)
+            nreads += len(reads)
+        return nreads, nkmers
+
+    def consume_seqfile(self, parser):
+        return self._consume_file(parser, 0, 0, None, 0, False)
+
+    def consume_seqfile_banding(self, parser, nbands, band):
+        return self._consume_file(parser, nbands, band, None, 0, False)
+
+    def consume_seqfile_with_mask(self, parser, mask, threshold=0, consume_masked=False):
+        return self._consume_file(parser, 0, 0, mask, threshold, consume_masked)
+
+    def consume_seqfile_banding_with_mask(self, parser, nbands, band, mask, threshold=0,
+                                          consume_masked=False):
+        return self._consume_file(parser, nbands, band, mask, threshold, consume_masked)
+
+
+class Counttable(_Sketch):
+    _kind = 0
+
+
+class SmallCounttable(_Sketch):
+    _kind = 1
+
+
+class Nodetable(_Sketch):
+    _kind = 2
+
+
+class Countgraph(_Sketch):
+    _kind = 3
+
+
+class SmallCountgraph(_Sketch):
+    _kind = 4
+
+
+class Nodegraph(_Sketch):
+    _kind = 5
+
+
+# ----------------------------------------------------------------------------------------
+# the fused novel scan (no khmer analogue: replaces the per-k-mer Python loop of
+# kevlar/novel.py:123-169)
+# ----------------------------------------------------------------------------------------
+def novel_scan(cases, controls, batch, case_min, ctrl_max, screen=None, band_mode=0, nbands=0,
+               band=0, first_read=0, mask_ptr=None, mask_stride=0):
+    """Returns (read_idx, offset, abund[n, S], discarded_reads) as numpy arrays, hits sorted
+    by (read, offset)."""
+    lib = _lib.load()
+    S = len(cases) + len(controls)
+    ca = (ctypes.c_void_p * len(cases))(*[c._h for c in cases])
+    cb = (ctypes.c_void_p * max(1, len(controls)))(*[c._h for c in controls])
+    hits = ctypes.c_void_p()
+    check(lib.kv_novel_scan(ca, len(cases), cb, len(controls), batch._h, int(first_read), int(case_min),
+                            int(ctrl_max), int(screen or 0), int(band_mode), int(nbands or 0),
+                            int(band or 0), mask_ptr, int(mask_stride), ctypes.byref(hits)))
+    try:
+        n, nd = ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib.kv_hits_count(hits, ctypes.byref(n), ctypes.byref(nd)))
+        reads = np.empty(n.value, dtype=np.uint32)
+        offs = np.empty(n.value, dtype=np.uint32)
+        abund = np.empty((n.value, S), dtype=np.uint8)
+        disc = np.empty(nd.value, dtype=np.uint32)
+        check(lib.kv_hits_fetch(hits, _u32p(reads), _u32p(offs), _u8p(abund), n.value, _u32p(disc), nd.value))
+    finally:
+        lib.kv_hits_destroy(hits)
+    return reads, offs, abund, disc
+
+
+def readgraph_components(batch, ksize, ann_read, ann_offset, node_of_read, n_nodes, minabund=0,
+                         maxabund=0, want_edges=False):
+    """labels[node] = smallest node id of its connected component (kv_readgraph_components)."""
+    lib = _lib.load()
+    ann_read = np.ascontiguousarray(ann_read, dtype=np.uint32)
+    ann_offset = np.ascontiguousarray(ann_offset, dtype=np.uint32)
+    node_of_read = np.ascontiguousarray(node_of_read, dtype=np.uint32)
+    labels = np.empty(n_nodes, dtype=np.uint32)
+    nedges = ctypes.c_uint64()
+    check(lib.kv_readgraph_components(batch._h, int(ksize), _u32p(ann_read), _u32p(ann_offset), len(ann_read),
+                                      _u32p(node_of_read), int(n_nodes), int(minabund or 0), int(maxabund or 0),
+                                      _u32p(labels), ctypes.byref(nedges) if want_edges else None))
+    return (labels, nedges.value) if want_edges else labels
+
+
+# ----------------------------------------------------------------------------------------
+# khmer.khmer_args.memory_setting (kevlar/cli/count.py:49): K/M/G/T are powers of 1000
+# ----------------------------------------------------------------------------------------
+class khmer_args(object):
+    @staticmethod
+    def memory_setting(label):
+        suffixes = {'K': 1e3, 'M': 1e6, 'G': 1e9, 'T': 1e12}
+        try:
+            return float(label)
+        except ValueError:
+            prefix, suffix = label[:-1], label[-1:].upper()
+            if suffix not in suffixes:
+                raise ValueError('cannot parse memory setting "{}"'.format(label))
+            try:
+                return float(prefix) * suffixes[suffix]
+            except ValueError:
+                raise ValueError('cannot parse memory setting "{}"'.format(label))
+
+
+def calc_expected_collisions(sketch, force=False, max_false_pos=.2):
+    sizes = sketch.hashsizes()
+    return (float(sketch.n_occupied()) / min(sizes)) ** len(sizes)

@@ -1,0 +1,376 @@
+"""novel / filter / partition / unband on the HIP path vs golden vectors produced by the
+reference's own drivers (tests/golden/make_golden.py) and vs the oracle."""
+import contextlib
+import io
+import json
+import re
+
+import numpy as np
+import pytest
+
+from conftest import data_file, expected_file
+
+pytestmark = pytest.mark.gpu
+
+
+def run_cli(arglist):
+    import kevlar_amd
+    args = kevlar_amd.cli.parser().parse_args(arglist)
+    out, err = io.StringIO(), io.StringIO()
+    old = kevlar_amd.logstream
+    kevlar_amd.logstream = err
+    try:
+        with contextlib.redirect_stdout(out):
+            kevlar_amd.cli.mains[args.cmd](args)
+    finally:
+        kevlar_amd.logstream = old
+    return out.getvalue(), err.getvalue()
+
+
+def manifest():
+    return json.load(open(expected_file('manifest.json')))
+
+
+def summary(line):
+    return re.search(r'Found \d+ instances of \d+ unique novel kmers in \d+ reads', line).group(0)
+
+
+@pytest.mark.parametrize('trio', ['li', 'na'])
+def test_novel_microtrio_bytes(hk, trio):
+    """Unbanded `kevlar novel` output is byte-identical to the reference's; so are the count
+    log lines of the three samples and the summary line."""
+    base = ['novel', '--case', data_file('microtrios/trio-{}-proband.fq.gz'.format(trio)), '--ksize', '25',
+            '--case-min', '7', '--ctrl-max', '0', '--memory', '500K',
+            '--control', data_file('microtrios/trio-{}-father.fq.gz'.format(trio)),
+            '--control', data_file('microtrios/trio-{}-mother.fq.gz'.format(trio))]
+    out, log = run_cli(base)
+    name = 'novel-trio-{}.augfastq'.format(trio)
+    assert out == open(expected_file(name)).read()
+    want = manifest()['cases'][name]
+    for line in want[:-1]:
+        assert line in log
+    assert summary(want[-1]) in log
+
+
+@pytest.mark.parametrize('trio', ['li', 'na'])
+@pytest.mark.parametrize('band', [1, 2])
+def test_novel_reference_band_quirk_bytes(hk, trio, band):
+    """--ref-band-quirk reproduces the reference's per-band files literally
+    (kevlar/novel.py:144-147; band 1 of 2 is empty)."""
+    base = ['novel', '--case', data_file('microtrios/trio-{}-proband.fq.gz'.format(trio)), '--ksize', '25',
+            '--case-min', '7', '--ctrl-max', '0', '--memory', '500K',
+            '--control', data_file('microtrios/trio-{}-father.fq.gz'.format(trio)),
+            '--control', data_file('microtrios/trio-{}-mother.fq.gz'.format(trio)),
+            '--num-bands', '2', '--band', str(band), '--ref-band-quirk']
+    out, log = run_cli(base)
+    name = 'novel-trio-{}-refband-2-{}.augfastq'.format(trio, band)
+    assert out == open(expected_file(name)).read()
+    want = manifest()['cases'][name]
+    for line in want[:-1]:
+        assert line in log
+    assert summary(want[-1]) in log
+
+
+def test_novel_range_banding_union_equals_unbanded(hk):
+    """Default banding (hash-range, the count-side rule): every annotation satisfies the
+    thresholds (kevlar/tests/test_novel.py:80-105) and, with tables large enough that no
+    Count-Min collision matters, the union over bands is the unbanded result."""
+    import kevlar_amd
+    base = ['novel', '--case', data_file('microtrios/trio-li-proband.fq.gz'), '--ksize', '25',
+            '--case-min', '7', '--ctrl-max', '0', '--memory', '50M',
+            '--control', data_file('microtrios/trio-li-father.fq.gz'),
+            '--control', data_file('microtrios/trio-li-mother.fq.gz')]
+    whole, _ = run_cli(base)
+    merged = {}
+    for band in (1, 2, 3, 4):
+        out, _ = run_cli(base + ['--num-bands', '4', '--band', str(band)])
+        for line in out.split('\n'):
+            if line.endswith('#') and not line.startswith('#mateseq'):
+                m = re.search(r'(\d+) (\d+) (\d+)#$', line)
+                assert int(m.group(1)) >= 7 and m.group(2) == '0' and m.group(3) == '0', line
+        for rec in kevlar_amd.parse_augmented_fastx(io.StringIO(out)):
+            if rec is None:
+                continue
+            merged.setdefault(rec.name, set()).update((k.offset, k.abund) for k in rec.annotations)
+    want = {rec.name: set((k.offset, k.abund) for k in rec.annotations)
+            for rec in kevlar_amd.parse_augmented_fastx(io.StringIO(whole))}
+    assert merged == want and len(want) > 0
+
+
+def test_novel_skip_until(hk):
+    """kevlar/tests/test_novel.py:179-207."""
+    readname = 'bogus-genome-chr1_115_449_0:0:0_0:0:0_1f4/1'
+    base = ['novel', '--ctrl-max', '0', '--case-min', '6', '--case', data_file('trio1/case1.fq.gz'),
+            '--control', data_file('trio1/ctrl1.fq.gz'), '--control', data_file('trio1/ctrl2.fq.gz')]
+    out, log = run_cli(base + ['--skip-until', readname])
+    assert 'Found read bogus-genome-chr1_115_449_0:0:0_0:0:0_1f4/1 (skipped 1001 reads)' in log
+    assert '29 unique novel kmers in 14 reads' in log
+    assert out == open(expected_file('novel-trio1-skipuntil.augfastq')).read()
+    out, log = run_cli(base)
+    assert out == open(expected_file('novel-trio1.augfastq')).read()
+    assert 'Found 209 instances of 29 unique novel kmers in 18 reads' in log
+    out, log = run_cli(base + ['--skip-until', 'BOGUSREADNAME'])
+    assert 'Found read' not in log and '(skipped ' not in log
+    assert 'Found 0 instances of 0 unique novel kmers in 0 reads' in log
+
+
+def test_novel_abund_screen(hk):
+    """kevlar/tests/test_novel.py:167-176."""
+    out, log = run_cli(['novel', '--ksize', '25', '--ctrl-max', '1', '--case-min', '8', '--case',
+                        data_file('screen-case.fa'), '--control', data_file('screen-ctrl.fa'),
+                        '--abund-screen', '3'])
+    assert '>seq_error' not in out
+    assert out == open(expected_file('novel-screen.augfasta')).read()
+    assert summary(manifest()['cases']['novel-screen.augfasta'][0]) in log
+
+
+def test_novel_load_counts_and_ambiguous_reads(hk):
+    """kevlar/tests/test_novel.py:264-282: saved sketches + a case file with non-ACGT reads."""
+    out, log = run_cli(['novel', '-k', '25', '--case', data_file('simple-genome-case-reads.fa.gz'),
+                        data_file('ambig.fasta'), '--case-counts', data_file('simple-genome-case.ct'),
+                        '--control-counts', data_file('simple-genome-ctrl1.ct'),
+                        data_file('simple-genome-ctrl2.ct')])
+    assert 'counttables for 2 sample(s) provided' in log
+    assert out == open(expected_file('novel-simple-genome.augfasta')).read()
+
+
+def test_novel_save_counts(hk, tmp_path):
+    """kevlar/tests/test_novel.py:210-262."""
+    import filecmp
+    outdir = str(tmp_path)
+    for ind in ('father', 'mother', 'proband'):
+        run_cli(['count', '--ksize', '27', '--memory', '500K', '{}/{}.ct'.format(outdir, ind),
+                 data_file('microtrios/trio-na-{}.fq.gz'.format(ind))])
+    _, log = run_cli(['novel', '--ksize', '27', '--out', outdir + '/novel.augfastq.gz',
+                      '--save-case-counts', outdir + '/kid.ct', '--save-ctrl-counts', outdir + '/mom.ct',
+                      outdir + '/dad.ct', '--case', data_file('microtrios/trio-na-proband.fq.gz'),
+                      '--control', data_file('microtrios/trio-na-mother.fq.gz'),
+                      '--control', data_file('microtrios/trio-na-father.fq.gz'), '--memory', '500K'])
+    for a, b in zip(('father', 'mother', 'proband'), ('dad', 'mom', 'kid')):
+        assert filecmp.cmp('{}/{}.ct'.format(outdir, a), '{}/{}.ct'.format(outdir, b), shallow=False)
+    _, log = run_cli(['novel', '--ksize', '27', '--out', outdir + '/novel2.augfastq.gz',
+                      '--save-case-counts', outdir + '/kid2.ct', '--save-ctrl-counts', outdir + '/mom2.ct',
+                      outdir + '/dad2.ct', outdir + '/sib2.ct', '--case', data_file('microtrios/trio-na-proband.fq.gz'),
+                      '--control', data_file('microtrios/trio-na-mother.fq.gz'),
+                      '--control', data_file('microtrios/trio-na-father.fq.gz'), '--memory', '500K'])
+    assert 'stubbornly refusing to save k-mer counts' in log
+
+
+def test_novel_api_errors(hk):
+    import kevlar_amd
+    with pytest.raises(ValueError, match='Must specify `numbands` and `band` together'):
+        list(kevlar_amd.novel.novel(None, [], [], numbands=4))
+    with pytest.raises(ValueError, match='Must specify `numbands` and `band` together'):
+        list(kevlar_amd.novel.novel(None, [], [], band=0))
+    with pytest.raises(ValueError, match='`band` must be a value between 0 and 3'):
+        list(kevlar_amd.novel.novel(None, [], [], numbands=4, band=-1))
+    args = kevlar_amd.cli.parser().parse_args(['novel', '--case', 'case1.fq', '--control', 'cntl1.fq', '--band', '1'])
+    with pytest.raises(ValueError, match='Must specify --num-bands and --band together'):
+        kevlar_amd.novel.main(args)
+
+
+def test_novel_scan_vs_oracle_multi_sample_k51(hk, ok):
+    """Config-5 shape in miniature: 1 case + 3 controls, k=51 (3 murmur blocks + 3-byte tail),
+    with and without the abundance screen, both band modes."""
+    rng = np.random.default_rng(3)
+    letters = np.array(list('ACGT'))
+    genome = rng.integers(0, 4, size=6000)
+
+    def sample(g, n, err=0.004):
+        out = []
+        for s in rng.integers(0, len(g) - 120, size=n):
+            r = g[s:s + 120].copy()
+            mut = rng.random(120) < err
+            r[mut] = (r[mut] + rng.integers(1, 4, size=int(mut.sum()))) % 4
+            out.append(''.join(letters[r]))
+        return out
+
+    kid = genome.copy()
+    kid[[1500, 3000, 4500]] = (kid[[1500, 3000, 4500]] + 1) % 4
+    samples = [sample(kid, 2500)] + [sample(genome, 2500) for _ in range(3)]
+    dev = [hk.Counttable(51, 3e5, 4) for _ in samples]
+    ref = [ok.Counttable(51, 3e5, 4) for _ in samples]
+    for d, r, seqs in zip(dev, ref, samples):
+        d.consume_batch(hk.ReadBatch(seqs))
+        bases, offs = ok.concat_reads(seqs)
+        ok.consume_reads(r, bases, offs, len(seqs))
+    batch = hk.ReadBatch(samples[0])
+    bases, offs = ok.concat_reads(samples[0])
+    for screen, band_mode, nbands, band in [(0, 0, 0, 0), (2, 0, 0, 0), (0, 1, 4, 1), (0, 2, 4, 2), (3, 1, 2, 0)]:
+        r, o, a, disc = hk.novel_scan(dev[:1], dev[1:], batch, 5, 1, screen=screen, band_mode=band_mode,
+                                      nbands=nbands, band=band)
+        got = [(int(r[i]), int(o[i]), tuple(int(x) for x in a[i])) for i in range(len(r))]
+        want, status = ok.novel_scan(ref[:1], ref[1:], bases, offs, len(samples[0]), 51, 5, 1, screen=screen,
+                                     band_mode=band_mode, nbands=nbands, band=band)
+        assert got == want
+        assert sorted(disc.tolist()) == [i for i, s in enumerate(status) if s == 2]
+        if screen == 0 and band_mode == 0:
+            assert len(got) > 0
+
+
+def test_filter_golden(hk):
+    """kevlar/tests/test_filter.py:27-87."""
+    import kevlar_amd
+    out, log = run_cli(['filter', '--mask', data_file('bogus-genome/mask.nt'), '--memory', '10M', '--max-fpr',
+                        '0.001', '--case-min', '6', data_file('trio1/novel_3_1,2.txt')])
+    assert 'Processed 178 reads' in log and 'Validated 18 reads' in log
+    assert 'FPR for re-computed k-mer counts: 0.000' in log
+    assert out == open(expected_file('filter-trio1-masked.augfastq')).read()
+    for name, infile, kw, nreads in [
+            ('filter-trio1-nomask.augfastq', 'trio1/novel_3_1,2.txt', dict(memory=1e7), None),
+            ('filter-alpha.augfastq', 'collect.alpha.txt', dict(memory=500), 8),
+            ('filter-worm.augfasta', 'worm.augfasta', dict(memory=1000, casemin=5, ctrlmax=0), 5)]:
+        buf = io.StringIO()
+        recs = list(kevlar_amd.filter.filter(data_file(infile), **kw))
+        for rec in recs:
+            kevlar_amd.print_augmented_fastx(rec, buf)
+        assert buf.getvalue() == open(expected_file(name)).read()
+        if nreads is not None:
+            assert len(recs) == nreads
+    # (424, 5782) with no mask / (13, 171) with the genome mask: kevlar/tests/test_filter.py:44-57
+    for mask, nkmers, ninst in [(None, 424, 5782), (kevlar_amd.sketch.load(data_file('bogus-genome/mask.nt')), 13, 171)]:
+        ikmers = {}
+        for read in kevlar_amd.filter.filter(data_file('trio1/novel_3_1,2.txt'), memory=1e7, mask=mask):
+            for ikmer in read.annotations:
+                key = kevlar_amd.revcommin(read.ikmerseq(ikmer))
+                ikmers[key] = ikmers.get(key, 0) + 1
+        assert (len(ikmers), sum(ikmers.values())) == (nkmers, ninst)
+
+
+def load_partitions(text):
+    import kevlar_amd
+    parts = {}
+    if text.strip():
+        for rec in kevlar_amd.parse_augmented_fastx(io.StringIO(text)):
+            pid = kevlar_amd.seqio.partition_id(rec.name)
+            parts.setdefault(pid, []).append([rec.name.rsplit(' kvcc=', 1)[0], kevlar_amd.revcommin(rec.sequence)])
+    return parts
+
+
+@pytest.mark.parametrize('name,infile,extra', [
+    ('partition-dup', 'dup.augfastq', []),
+    ('partition-dup-nodedup', 'dup.augfastq', ['--no-dedup']),
+    ('partition-pico-minabund5', 'pico-filtered.fq.gz', ['--min-abund', '5']),
+    ('partition-pico-default', 'pico-filtered.fq.gz', []),
+    ('partition-conn1311', 'connectivity-1311.augfastq', []),
+    ('partition-conn1541-nodedup', 'connectivity-1541.augfastq', ['--no-dedup']),
+])
+def test_partition_golden(hk, name, infile, extra):
+    """Partition ids and membership vs the reference (relation P3 of SURVEY.md 8(a): same
+    numbering; per partition the same set of canonical sequences, and the same names up to
+    identical-sequence duplicates when dedup is on)."""
+    out, log = run_cli(['partition'] + extra + [data_file(infile)])
+    want = json.load(open(expected_file(name + '.json')))
+    got = load_partitions(out)
+    assert sorted(got) == sorted(want['partitions'])
+    for pid in got:
+        assert sorted(set(s for _, s in got[pid])) == sorted(set(s for _, s in want['partitions'][pid]))
+        assert len(got[pid]) == len(want['partitions'][pid])
+        if '--no-dedup' in extra:
+            assert sorted(got[pid]) == sorted(want['partitions'][pid])
+    assert want['log'][0].split('] ')[-1] in log
+
+
+def test_partition_known_answers(hk, tmp_path):
+    """kevlar/tests/test_partition.py:37-154."""
+    import kevlar_amd
+    out, log = run_cli(['partition', '--split', str(tmp_path / 'dedup'), data_file('dup.augfastq')])
+    assert 'grouped 16 reads into 1 connected components' in log
+    recs = list(kevlar_amd.parse_augmented_fastx(kevlar_amd.open(str(tmp_path / 'dedup.cc1.augfastq.gz'), 'r')))
+    assert len(recs) == 16
+    out, log = run_cli(['partition', '--no-dedup', data_file('dup.augfastq')])
+    assert 'grouped 18 reads into 1 connected components' in log
+    stream = kevlar_amd.parse_augmented_fastx(kevlar_amd.open(data_file('dupl-part.augfastq.gz'), 'r'))
+    assert len(list(kevlar_amd.partition.partition(stream, minabund=5))) == 0
+    stream = kevlar_amd.parse_augmented_fastx(kevlar_amd.open(data_file('dupl-part-2reads.augfastq.gz'), 'r'))
+    assert len(list(kevlar_amd.partition.partition(stream, minabund=5, dedup=False))) == 0
+    stream = kevlar_amd.parse_augmented_fastx(kevlar_amd.open(data_file('pico-filtered.fq.gz'), 'r'))
+    assert len(list(kevlar_amd.partition.partition(stream, minabund=6))) == 10
+    out, log = run_cli(['partition', '--min-abund', '5', data_file('pico-filtered.fq.gz')])
+    assert len(set(re.findall(r'kvcc=\d+', out))) == 10
+
+
+def test_readgraph_edges(hk):
+    """kevlar/tests/test_readgraph.py:20-31 (relaxed mode)."""
+    import kevlar_amd
+    want = manifest()['readgraph_edges']
+    for infile, edges in [('connectivity-1311.augfastq', 30), ('connectivity-1541.augfastq', 31)]:
+        with open(data_file(infile)) as fh:
+            reads = list(kevlar_amd.parse_augmented_fastx(fh))
+        rg = kevlar_amd.ReadGraph()
+        rg.load(reads)
+        rg.populate_edges()
+        assert rg.number_of_edges() == want[infile]['relaxed']
+        assert rg.number_of_edges() == pytest.approx(edges, 1)
+
+
+def test_readgraph_components_random_vs_host_union_find(hk):
+    """Randomised check of the device union-find against a plain dict/set restatement of
+    kevlar/readgraph.py:43-84,104-125 (min/max abundance filter included)."""
+    rng = np.random.default_rng(99)
+    letters = np.array(list('ACGT'))
+    k = 19
+    genome = ''.join(letters[rng.integers(0, 4, size=3000)])
+    rc = lambda s: s[::-1].translate(str.maketrans('ACGT', 'TGCA'))  # noqa: E731
+    reads, ann_read, ann_off = [], [], []
+    for i in range(400):
+        s = int(rng.integers(0, len(genome) - 80))
+        seq = genome[s:s + 80]
+        if rng.random() < 0.5:
+            seq = rc(seq)
+        reads.append(seq)
+        for off in rng.choice(80 - k + 1, size=int(rng.integers(0, 4)), replace=False):
+            ann_read.append(i)
+            ann_off.append(int(off))
+    node_of_read = np.arange(len(reads), dtype=np.uint32)
+    node_of_read[350:] = node_of_read[:50]           # duplicate names share a node
+    n_nodes = 350
+    batch = hk.ReadBatch(reads)
+    for minab, maxab in [(0, 0), (2, 0), (2, 3), (0, 2)]:
+        labels, nedges = hk.readgraph_components(batch, k, ann_read, ann_off, node_of_read, n_nodes, minab, maxab,
+                                                 want_edges=True)
+        groups = {}
+        for r, o in zip(ann_read, ann_off):
+            km = reads[r][o:o + k]
+            groups.setdefault(min(km, rc(km)), set()).add(int(node_of_read[r]))
+        parent = list(range(n_nodes))
+
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        edges = set()
+        for nodes in groups.values():
+            if (minab and len(nodes) < minab) or (maxab and len(nodes) > maxab):
+                continue
+            nodes = sorted(nodes)
+            for a in nodes:
+                for b in nodes:
+                    if a < b:
+                        edges.add((a, b))
+                ra, rb = find(nodes[0]), find(a)
+                if ra != rb:
+                    parent[max(ra, rb)] = min(ra, rb)
+        want = {}
+        for x in range(n_nodes):
+            want.setdefault(find(x), []).append(x)
+        want_labels = np.empty(n_nodes, dtype=np.uint32)
+        for members in want.values():
+            want_labels[members] = min(members)
+        assert np.array_equal(labels, want_labels)
+        assert nedges == len(edges)
+
+
+def test_unband_golden(hk):
+    """kevlar/tests/test_unband.py:25-45 (host-side merge; order is name-sorted here)."""
+    import kevlar_amd
+    infiles = [data_file('helium-unband/novel.band{}.augfastq.gz'.format(i)) for i in (1, 2, 3, 4)]
+    reads = sorted(kevlar_amd.unband.unband(kevlar_amd.seqio.afxstream(infiles), numbatches=16), key=lambda r: r.name)
+    assert len(reads) == 135
+    some = [r for r in reads if r.name == 'seq1_haplo1_285110_285519_1:0:0_0:0:0_2dbcd/1'][0]
+    assert len(some.annotations) == 75
+    buf = io.StringIO()
+    for rec in reads:
+        kevlar_amd.print_augmented_fastx(rec, buf)
+    assert buf.getvalue() == open(expected_file('unband-helium.sorted.augfastq')).read()

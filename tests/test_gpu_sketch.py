@@ -1,0 +1,269 @@
+"""Parity of the HIP sketch engine with the CPU oracle and the reference's golden files.
+Everything here goes through the C ABI (kevlar_amd.khmer -> libkvsketch_hip.so)."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import data_file, expected_file
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ['Counttable', 'SmallCounttable', 'Nodetable', 'Countgraph', 'SmallCountgraph', 'Nodegraph']
+
+
+def random_reads(seed, n, lo=20, hi=160, alphabet='ACGT'):
+    rng = np.random.default_rng(seed)
+    letters = np.array(list(alphabet))
+    return [''.join(letters[rng.integers(0, len(letters), size=int(rng.integers(lo, hi + 1)))]) for _ in range(n)]
+
+
+def test_library_loaded_and_device_present(hk):
+    from kevlar_amd import _lib
+    lib = _lib.load()
+    assert os.path.basename(_lib.LIBPATH) == 'libkvsketch_hip.so'
+    _lib.require_device()
+    assert b'gfx950' in lib.kv_version()
+
+
+@pytest.mark.parametrize('k', [1, 7, 15, 16, 17, 21, 25, 31, 32, 33, 47, 48, 51, 64, 65, 100])
+def test_device_kmer_hashing_matches_oracle(hk, ok, k):
+    reads = random_reads(k, 40, lo=k, hi=k + 60)
+    kmers = [r[i:i + k] for r in reads for i in range(len(r) - k + 1)]
+    dev = hk.Counttable(k, 1e4, 2)
+    ref = ok.Counttable(k, 1e4, 2)
+    got = dev.hash_kmers(kmers)
+    want = np.array([ref.hash(km) for km in kmers], dtype=np.uint64)
+    assert np.array_equal(got, want)
+    assert dev.hash(kmers[0]) == int(want[0])           # host-side single k-mer hash
+    if k <= 32:
+        devg, refg = hk.Countgraph(k, 1e4, 2), ok.Countgraph(k, 1e4, 2)
+        assert np.array_equal(devg.hash_kmers(kmers), np.array([refg.hash(km) for km in kmers], dtype=np.uint64))
+
+
+@pytest.mark.parametrize('kind', KINDS)
+@pytest.mark.parametrize('k,tablesize', [(21, 5e3), (31, 4e4)])
+def test_consume_tables_bit_exact(hk, ok, kind, k, tablesize):
+    """The tile kernel (LDS-staged murmur + saturating atomics) == scalar oracle, byte for byte,
+    for every storage width and both hash families; small tables force saturation."""
+    reads = random_reads(11, 700, lo=10, hi=150) + ['A' * 150] * 30 + ['ACGT' * 30] * 5 + ['', 'ACG']
+    dev = getattr(hk, kind)(k, tablesize, 4)
+    ref = getattr(ok, kind)(k, tablesize, 4)
+    assert dev.hashsizes() == ref.hashsizes()
+    n_dev = dev.consume_batch(hk.ReadBatch(reads))
+    bases, offs = ok.concat_reads(reads)
+    n_ref = ok.consume_reads(ref, bases, offs, len(reads))
+    assert n_dev == n_ref
+    for t in range(4):
+        assert dev.table_bytes(t) == ref.table_bytes(t)
+    assert dev.n_occupied() == ref.n_occupied()
+
+
+def test_consume_ambiguous_and_lowercase_bases(hk, ok):
+    reads = ['ACGTNNACGTTTGACCAGTACGATCAGTACGATCGATCGATCGACTAGCTAGCTAGC',
+             'acgtacgtagctagctagcatcgatcgatcgatcgatcagctagctagctagctagct',
+             'ACGTRYACGTAGCTAGCATCGATGCATGCATCGATCGATCGATCGATGCATGCATGCA']
+    dev, ref = hk.Counttable(21, 1e4, 4), ok.Counttable(21, 1e4, 4)
+    dev.consume_batch(hk.ReadBatch(reads))
+    for r in reads:
+        ref.consume(r)
+    for t in range(4):
+        assert dev.table_bytes(t) == ref.table_bytes(t)
+
+
+@pytest.mark.parametrize('nbands,band', [(2, 0), (2, 1), (16, 6), (9, 8)])
+def test_consume_banding(hk, ok, nbands, band):
+    reads = random_reads(5, 400, lo=40, hi=120)
+    dev, ref = hk.Counttable(25, 2e4, 4), ok.Counttable(25, 2e4, 4)
+    bases, offs = ok.concat_reads(reads)
+    assert dev.consume_batch(hk.ReadBatch(reads), nbands, band) == \
+        ok.consume_reads(ref, bases, offs, len(reads), nbands, band)
+    for t in range(4):
+        assert dev.table_bytes(t) == ref.table_bytes(t)
+
+
+@pytest.mark.parametrize('consume_masked', [False, True])
+@pytest.mark.parametrize('maskkind', ['Nodetable', 'Counttable'])
+def test_consume_with_mask(hk, ok, consume_masked, maskkind):
+    reads = random_reads(6, 300, lo=50, hi=120)
+    maskreads = reads[:60]
+    dmask, rmask = getattr(hk, maskkind)(21, 3e4, 4), getattr(ok, maskkind)(21, 3e4, 4)
+    dmask.consume_batch(hk.ReadBatch(maskreads))
+    for r in maskreads:
+        rmask.consume(r)
+    threshold = 1 if consume_masked else 0
+    dev, ref = hk.SmallCounttable(21, 2e4, 4), ok.SmallCounttable(21, 2e4, 4)
+    bases, offs = ok.concat_reads(reads)
+    n_dev = dev.consume_batch(hk.ReadBatch(reads), 0, 0, dmask, threshold, consume_masked)
+    n_ref = ok.consume_reads(ref, bases, offs, len(reads), 0, 0, rmask, threshold, consume_masked)
+    assert n_dev == n_ref and n_dev > 0
+    for t in range(4):
+        assert dev.table_bytes(t) == ref.table_bytes(t)
+
+
+def test_get_add_point_queries(hk, ok):
+    reads = random_reads(8, 200, lo=60, hi=100)
+    dev, ref = hk.Counttable(27, 1e4, 4), ok.Counttable(27, 1e4, 4)
+    dev.consume_batch(hk.ReadBatch(reads))
+    for r in reads:
+        ref.consume(r)
+    kmers = [r[i:i + 27] for r in reads[:20] for i in range(0, len(r) - 27 + 1, 5)] + ['GATTACA' * 3 + 'GATTAC']
+    hashes = dev.hash_kmers(kmers)
+    assert dev.get_hashes(hashes).tolist() == [ref.get(km) for km in kmers]
+    assert dev.get(kmers[3]) == ref.get(kmers[3])
+    new_dev = dev.add_hashes(hashes)
+    for km in kmers:
+        ref.add(km)
+    for t in range(4):
+        assert dev.table_bytes(t) == ref.table_bytes(t)
+    assert int(new_dev.sum()) >= 1          # the GATTACA k-mer is new
+    assert dev.get_kmers('ACGTACGTACGTACGTACGTACGTACGTACG') == ref.get_kmers('ACGTACGTACGTACGTACGTACGTACGTACG')
+
+
+@pytest.mark.parametrize('filename,cls,testkmer', [
+    ('test.countgraph', 'Countgraph', 'TGGAACCGGCAACGACGAAAA'),
+    ('test.smallcountgraph', 'SmallCountgraph', 'CTGTACTACAGCTACTACAGT'),
+    ('test.counttable', 'Counttable', 'CCTGATATCCGGAATCTTAGC'),
+    ('test.smallcounttable', 'SmallCounttable', 'GGGCCCCCATCTCTATCTTGC'),
+    ('test.nodegraph', 'Nodegraph', 'GGGAACTTACCTGGGGGTGCG'),
+    ('test.nodetable', 'Nodetable', 'CTGTTCGATATGAGGAATCTG'),
+])
+def test_sketch_load_save(hk, tmp_path, filename, cls, testkmer):
+    """kevlar/tests/test_sketch.py:17-29 through kevlar_amd.sketch.load + byte-exact save."""
+    import kevlar_amd
+    infile = data_file(filename)
+    if '.' + filename.split('.')[-1] in kevlar_amd.sketch.sketch_loader_by_filename_extension:
+        sketch = kevlar_amd.sketch.load(infile)
+        assert type(sketch).__name__ == cls
+    sketch = getattr(hk, cls).load(infile)
+    assert sketch.get(testkmer) > 0
+    assert sketch.get('GATTACA' * 3) == 0
+    out = str(tmp_path / filename)
+    sketch.save(out)
+    assert open(out, 'rb').read() == open(infile, 'rb').read()
+
+
+def test_sketch_load_errors(hk):
+    import kevlar_amd
+    with pytest.raises(kevlar_amd.sketch.KevlarSketchTypeError, match='sketch type from filename'):
+        kevlar_amd.sketch.load(data_file('test.notasketchtype'))
+    with pytest.raises(ValueError):
+        hk.Nodetable.load(data_file('test.counttable'))        # storage type mismatch
+    with pytest.raises(OSError):
+        hk.Counttable.load(data_file('does-not-exist.ct'))
+    with pytest.raises(ValueError, match='not implemented'):
+        hk.Counttable(35, 1e4, 4).reverse_hash(12345)
+    g = hk.Countgraph(21, 1e4, 4)
+    kmer = 'GCATAGTGTCTCTGCTGCGCA'
+    assert kevlar_amd.same_seq(g.reverse_hash(g.hash(kmer)), kmer)
+    with pytest.raises(ValueError):
+        hk.Countgraph(35, 1e4, 4)
+
+
+@pytest.mark.parametrize('infile,testout,numbands,band,kmers_stored', [
+    ('case', 'case', 0, 0, 973),
+    ('ctrl1', 'ctrl1', 0, 0, 973),
+    ('ctrl2', 'ctrl2', 0, 0, 966),
+    ('case', 'case-band-2-1', 2, 1, 501),
+    ('case', 'case-band-16-7', 16, 7, 68),
+])
+def test_count_cli_golden_bytes(hk, tmp_path, kevlar_log, infile, testout, numbands, band, kmers_stored):
+    """The reference's own golden test (kevlar/tests/test_count.py:45-68) against the HIP path:
+    `kevlar count` output file bytes == committed .ct, and the asserted log lines."""
+    import kevlar_amd
+    out = str(tmp_path / 'out')
+    arglist = ['count', '--ksize', '25', '--memory', '10K', '--num-bands', str(numbands), '--band', str(band),
+               out, data_file('simple-genome-{}-reads.fa.gz'.format(infile))]
+    args = kevlar_amd.cli.parser().parse_args(arglist)
+    kevlar_amd.count.main(args)
+    log = kevlar_log.getvalue()
+    assert '600 reads processed' in log
+    assert '{:d} distinct k-mers stored'.format(kmers_stored) in log
+    with open(out + '.counttable', 'rb') as f1, open(data_file('simple-genome-{}.ct'.format(testout)), 'rb') as f2:
+        assert f1.read() == f2.read()
+    manifest = json.load(open(expected_file('manifest.json')))
+    for line in manifest['cases']['count-' + testout]:
+        assert line in log
+
+
+def test_count_cli_with_mask_known_answer(hk, tmp_path, kevlar_log):
+    """kevlar/tests/test_count.py:150-166: '36898 distinct k-mers stored'."""
+    import kevlar_amd
+    mask = hk.Nodetable(21, 1e4, 4)
+    mask.consume('CACCAATCCGTACGGAGAGCCGTATATATAGACTGCTATACTATTGGATCGTACGGGGC')
+    maskfile, countfile = str(tmp_path / 'mask.nt'), str(tmp_path / 'counts.sct')
+    mask.save(maskfile)
+    args = kevlar_amd.cli.parser().parse_args(['count', '--ksize', '21', '--mask', maskfile, '--memory', '1M',
+                                               countfile, data_file('bogus-genome/refr.fa')])
+    kevlar_amd.count.main(args)
+    assert '36898 distinct k-mers stored' in kevlar_log.getvalue()
+
+
+@pytest.mark.parametrize('count,smallcount,count_masked,kpresent,kabsent', [
+    (True, True, True, 'CACCAATCCGTACGGAGAGCC', 'GAATCGGTGGCTGGTTGCCGT'),
+    (True, False, True, 'CACCAATCCGTACGGAGAGCC', 'GAATCGGTGGCTGGTTGCCGT'),
+    (False, False, True, 'CACCAATCCGTACGGAGAGCC', 'GAATCGGTGGCTGGTTGCCGT'),
+    (True, True, False, 'GAATCGGTGGCTGGTTGCCGT', 'CACCAATCCGTACGGAGAGCC'),
+    (True, False, False, 'GAATCGGTGGCTGGTTGCCGT', 'CACCAATCCGTACGGAGAGCC'),
+    (False, False, False, 'GAATCGGTGGCTGGTTGCCGT', 'CACCAATCCGTACGGAGAGCC'),
+])
+def test_load_sample_seqfile_withmask(hk, kevlar_log, count, smallcount, count_masked, kpresent, kabsent):
+    """kevlar/tests/test_count.py:130-147."""
+    import kevlar_amd
+    mask = hk.Nodetable(21, 1e4, 4)
+    mask.consume('CACCAATCCGTACGGAGAGCCGTATATATAGACTGCTATACTATTGGATCGTACGGGGC')
+    sketch = kevlar_amd.count.load_sample_seqfile(
+        [data_file('bogus-genome/refr.fa')], 21, 1e6, mask=mask, consume_masked=count_masked, count=count,
+        smallcount=smallcount)
+    assert sketch.get(kpresent) > 0
+    assert sketch.get(kabsent) == 0
+    assert sketch.get('GATTACAGATTACAGATTACA') == 0
+
+
+def test_count_problematic_and_threads(hk, tmp_path, kevlar_log):
+    """kevlar/tests/test_count.py:71-105."""
+    import kevlar_amd
+    args = kevlar_amd.cli.parser().parse_args(['count', '--ksize', '21', '--memory', '200K', '--band', '2',
+                                               'bogusoutput', data_file('trio1/ctrl1.fq.gz')])
+    with pytest.raises(ValueError, match='Must specify --num-bands and --band together'):
+        kevlar_amd.count.main(args)
+    args = kevlar_amd.cli.parser().parse_args(['count', '--ksize', '21', '--memory', '97', 'bogusoutput',
+                                               data_file('trio1/ctrl1.fq.gz')])
+    with pytest.raises(kevlar_amd.sketch.KevlarUnsuitableFPRError):
+        kevlar_amd.count.main(args)
+    out = str(tmp_path / 'thr.counttable')
+    args = kevlar_amd.cli.parser().parse_args(['count', '--ksize', '19', '--memory', '500K', '--threads', '2', out,
+                                               data_file('trio1/case1.fq.gz')])
+    kevlar_amd.count.main(args)
+    one = kevlar_amd.count.load_sample_seqfile([data_file('trio1/case1.fq.gz')], 19, 5e5)
+    two = hk.Counttable.load(out)
+    for t in range(4):                      # threading never changes the tables
+        assert one.table_bytes(t) == two.table_bytes(t)
+
+
+def test_memory_to_table_size(hk, kevlar_log):
+    """kevlar/tests/test_count.py:169-182."""
+    import kevlar_amd
+    for count, smallcount, sketchtype in [(False, False, 'nodegraph'), (True, False, 'countgraph'),
+                                          (True, True, 'smallcountgraph')]:
+        sketch = kevlar_amd.count.load_sample_seqfile([data_file('bogus-genome/refr.fa')], 21, 2e6, count=count,
+                                                      smallcount=smallcount)
+        actual = sum(sketch.hashsizes()) / hk._buckets_per_byte[sketchtype]
+        assert actual / 2e6 == pytest.approx(1.0, rel=1e-4)
+
+
+def test_exact_unique_matches_single_thread_oracle(hk, ok):
+    """n_unique_kmers() with tracking == the value one khmer thread computes in file order."""
+    reads = random_reads(21, 1500, lo=30, hi=140) * 2 + random_reads(22, 300, lo=30, hi=140)
+    for nbands, band in [(0, 0), (4, 2)]:
+        dev, ref = hk.Counttable(23, 6e3, 4), ok.Counttable(23, 6e3, 4)   # small tables: many collisions
+        dev.track_exact_unique(True)
+        half = len(reads) // 2
+        dev.consume_batch(hk.ReadBatch(reads[:half]), nbands, band)
+        dev.consume_batch(hk.ReadBatch(reads[half:]), nbands, band)
+        bases, offs = ok.concat_reads(reads)
+        ok.consume_reads(ref, bases, offs, len(reads), nbands, band)
+        assert dev.n_unique_kmers() == ref.n_unique_kmers()
+        assert dev.n_occupied() == ref.n_occupied()
