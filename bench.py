@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/sec through count + novel on a synthetic trio (BASELINE.json metric).
+
+A "step" is one full pass of the hot path over one synthetic trio already resident in HBM
+as 2-bit packed reads: zero the three sketches, `count` all three samples (kv_consume), then
+the fused `novel` scan of the proband against both parents (kv_novel_scan).
+    value = (reads of all three samples) / (time per step), whole job.
+
+N = 1 : workload = BASELINE.json configs[1] (25 Mb genome, 30x, k=31, 2 GB sketch per sample).
+N > 1 : configs[2]: the same trio, kevlar's k-mer banding with band b on GPU b (each GPU
+        streams all reads, owns 1/N of the hash space and 1/N of the table memory), then one
+        RCCL all-reduce of the per-band interesting-k-mer bitmask + an all-gather of the hit
+        counts.  Total work is fixed -> "scaling": "strong".
+
+Also reported: `roofline` for the dominant kernel (algorithmic bytes / live HIP-event time,
+see DESIGN.md) and `cpu_baseline` (the C oracle on one host core, bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=3)
+    p.add_argument('--warmup', type=int, default=1)
+    p.add_argument('--genome-mb', type=float, default=25.0)
+    p.add_argument('--coverage', type=float, default=30.0)
+    p.add_argument('--read-len', type=int, default=100)
+    p.add_argument('--ksize', type=int, default=31)
+    p.add_argument('--memory', type=float, default=2e9, help='sketch bytes per sample (all bands together)')
+    p.add_argument('--case-min', type=int, default=6)
+    p.add_argument('--ctrl-max', type=int, default=1)
+    p.add_argument('--cpu-reads', type=int, default=40000, help='reads per sample for the CPU baseline leg')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    return p.parse_args()
+
+
+def prof(lib, name):
+    ms, n = ctypes.c_double(), ctypes.c_uint64()
+    lib.kv_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(n))
+    return ms.value, n.value
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node {}'.format(args.gpus))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__
+    __graft_entry__.build()
+    from kevlar_amd import _lib, khmer as hk, synth
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    lib = _lib.load()
+    _lib.require_device()
+
+    # ---- synthetic trio (same seeds on every rank), packed on the host, uploaded once
+    L, k = args.read_len, args.ksize
+    genome_len = int(args.genome_mb * 1e6)
+    t0 = time.time()
+    packed = synth.trio_reads_packed(genome_len, args.coverage, L)
+    names = ('proband', 'mother', 'father')
+    n_reads = packed['proband'].shape[0]
+    batches = {n: hk.ReadBatch.from_packed(packed[n], L) for n in names}
+    gen_s = time.time() - t0
+    nk = L - k + 1
+    T = 4
+    nbands = world if world > 1 else 0
+    band = rank
+    mem_per_gpu = args.memory / max(1, world)
+    sketches = {n: hk.Counttable(k, mem_per_gpu / T, T) for n in names}
+    mask = None
+    if world > 1:
+        mask = torch.zeros((n_reads * nk + 31) // 32, dtype=torch.int32, device='cuda')
+
+    wall = {'count': 0.0, 'novel': 0.0, 'merge': 0.0}
+
+    def step():
+        kmers = 0
+        t_a = time.perf_counter()
+        for n in names:
+            sketches[n].clear()
+            kmers += sketches[n].consume_batch(batches[n], nbands, band)
+        if mask is not None:
+            mask.zero_()
+        t_b = time.perf_counter()
+        r, o, a, _ = hk.novel_scan(
+            [sketches['proband']], [sketches['mother'], sketches['father']], batches['proband'],
+            args.case_min, args.ctrl_max, band_mode=1 if world > 1 else 0, nbands=nbands, band=band,
+            mask_ptr=mask.data_ptr() if mask is not None else None, mask_stride=nk)
+        nhits = len(r)
+        t_c = time.perf_counter()
+        if world > 1:
+            dist.all_reduce(mask)                       # bands are disjoint: sum == OR
+            counts = torch.tensor([nhits], dtype=torch.int64, device='cuda')
+            gathered = [torch.zeros_like(counts) for _ in range(world)]
+            dist.all_gather(gathered, counts)
+            nhits = int(sum(int(g.item()) for g in gathered))
+        wall['count'] += t_b - t_a
+        wall['novel'] += t_c - t_b
+        wall['merge'] += time.perf_counter() - t_c
+        return kmers, nhits, (r, o, a)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    lib.kv_prof_reset()
+    lib.kv_prof_enable(1)
+    for key in wall:
+        wall[key] = 0.0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kmers, nhits, hits = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.kv_prof_enable(0)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- cheap end-to-end sanity on the timed result (parity proper lives in tests/)
+    r, o, a = hits
+    assert nhits > 0, 'synthetic trio must yield interesting k-mers'
+    assert (a[:, 0] >= args.case_min).all() and (a[:, 1:] <= args.ctrl_max).all()
+    if world == 1:
+        assert kmers == 3 * n_reads * nk
+
+    ms_step = elapsed / args.steps * 1e3
+    total_reads = 3 * n_reads
+    value = total_reads / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel: algorithmic bytes per launch / avg HIP-event time
+    frac_band = 1.0 / max(1, world)
+    alg = {
+        'k_consume': n_reads * (L / 4.0 + 2 * T * nk * frac_band),          # A_count  
+        'k_novel': n_reads * (L / 4.0 + T * 3 * nk * frac_band),            # A_novel, S = 3
+    }
+    times = {name: prof(lib, name) for name in alg}
+    dominant = max(times, key=lambda n_: times[n_][0])
+    ms_tot, launches = times[dominant]
+    avg_ms = ms_tot / max(1, launches)
+    achieved = alg[dominant] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {
+        'bound': 'hbm', 'kernel': dominant, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+        'avg_launch_ms': round(avg_ms, 4), 'launches': int(launches),
+        'algorithmic_bytes_per_launch': int(alg[dominant]),
+        'kernels_ms_per_step': {name: round(times[name][0] / args.steps, 4) for name in times},
+        'host_wall_ms_per_step': {key: round(val / args.steps * 1e3, 3) for key, val in wall.items()},
+    }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, packed, names, synth)
+
+    if rank == 0:
+        out = {
+            'metric': 'reads/sec through count+novel (trio, k={})'.format(k),
+            'value': round(value, 1), 'unit': 'reads/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_step, 3), 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'u64 hash / u8 counters', 'data': 'synthetic',
+            'config': {
+                'workload': 'synthetic {:g} Mb trio, {:g}x, {} bp reads, k={}, {} reads/sample, '
+                            '{:g} GB Count-Min sketch per sample ({} tables), case-min {}, ctrl-max {}'.format(
+                                args.genome_mb, args.coverage, L, k, n_reads, args.memory / 1e9, T,
+                                args.case_min, args.ctrl_max),
+                'parallelism': 'single band' if world == 1 else '{} k-mer bands, 1 per GPU'.format(world),
+                'interesting_kmer_instances': nhits, 'host_generate_pack_upload_s': round(gen_s, 1),
+            },
+            'roofline': roofline,
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, packed, names, synth):
+    """The C oracle (oracle/kvoracle.c, one core) on the first --cpu-reads reads of each sample,
+    with full-size sketches: count x3 then the novel scan of the proband sample."""
+    from oracle import okhmer as ok
+    n = min(args.cpu_reads, packed['proband'].shape[0])
+    data = {}
+    for name in names:
+        seqs = synth.unpack_reads(packed[name][:n], args.read_len)
+        data[name] = ok.concat_reads(seqs)
+    sk = {name: ok.Counttable(args.ksize, args.memory / 4, 4) for name in names}
+    t0 = time.perf_counter()
+    for name in names:
+        ok.consume_reads(sk[name], data[name][0], data[name][1], n)
+    hits, _ = ok.novel_scan([sk['proband']], [sk['mother'], sk['father']], data['proband'][0], data['proband'][1],
+                            n, args.ksize, args.case_min, args.ctrl_max)
+    dt = time.perf_counter() - t0
+    return {'value': round(3 * n / dt, 1), 'unit': 'reads/s', 'cores': 1, 'kind': 'port',
+            'sample': 'first {} reads of each of the 3 samples, full-size sketches, {:.1f} s'.format(n, dt)}
+
+
+if __name__ == '__main__':
+    main()

@@ -103,6 +103,8 @@ int kv_sketch_info_get(kv_sketch *s, kv_sketch_info *out);
 int kv_sketch_table_read(kv_sketch *s, int table, uint8_t *host_out, uint64_t nbytes);
 int kv_sketch_table_write(kv_sketch *s, int table, const uint8_t *host_in, uint64_t nbytes);
 int kv_sketch_table_devptr(kv_sketch *s, int table, void **devptr, uint64_t *nbytes);
+/* zero every table and counter (a fresh sketch of the same geometry; asynchronous)         */
+int kv_sketch_clear(kv_sketch *s);
 
 /* ---- reads --------------------------------------------------------------------------- */
 /* khmer.ReadParser stand-in (kevlar/count.py:40): the host hands over parsed sequences
@@ -110,6 +112,10 @@ int kv_sketch_table_devptr(kv_sketch *s, int table, void **devptr, uint64_t *nby
  * Bases outside ACGT are packed as 'A' (khmer's read cleaning) and the read is flagged so
  * that the novel scan skips it (kevlar/novel.py:136-139).                                 */
 int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t n_reads, kv_reads **out);
+/* Same, for reads that are already 2-bit packed on the host (A=0 C=1 G=2 T=3, base j of read
+ * r in word r*words_per_read + j/16 at bits 2*(j%16)), all of length read_len, ACGT only.
+ * Used by synthetic-read generators that never materialise ASCII.                        */
+int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, uint32_t read_len, kv_reads **out);
 int kv_reads_destroy(kv_reads *r);
 int kv_reads_count(const kv_reads *r, uint64_t *n_reads, uint64_t *n_bases);
 /* number of k-mers a consume of this batch visits at size k (sum over reads of len-k+1)   */

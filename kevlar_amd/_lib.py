@@ -57,7 +57,9 @@ SIGNATURES = {
     'kv_sketch_table_read': (i32, [vp, i32, u8p, u64]),
     'kv_sketch_table_write': (i32, [vp, i32, u8p, u64]),
     'kv_sketch_table_devptr': (i32, [vp, i32, vpp, u64p]),
+    'kv_sketch_clear': (i32, [vp]),
     'kv_reads_create': (i32, [cstr, u64p, u64, vpp]),
+    'kv_reads_create_packed': (i32, [u32p, u64, u32, vpp]),
     'kv_reads_destroy': (i32, [vp]),
     'kv_reads_count': (i32, [vp, u64p, u64p]),
     'kv_reads_num_kmers': (i32, [vp, i32, u64p]),

@@ -358,6 +358,18 @@ extern "C" int kv_sketch_table_write(kv_sketch *s, int table, const uint8_t *hos
     return KV_OK;
 }
 
+extern "C" int kv_sketch_clear(kv_sketch *s)
+{
+    KV_REQUIRE(s, KV_ERR_ARG, "kv_sketch_clear: null handle");
+    std::lock_guard<std::mutex> lk(s->mu);
+    KvProfScope prof("memset_tables");
+    for (int i = 0; i < s->h.ntables; ++i) KV_HIP(hipMemsetAsync(s->h.tab[i], 0, s->alloc_bytes[i], kv_stream()));
+    s->n_occupied = 0;
+    s->n_unique = 0;
+    s->occ_dirty = false;
+    return KV_OK;
+}
+
 extern "C" int kv_sketch_table_devptr(kv_sketch *s, int table, void **devptr, uint64_t *nbytes)
 {
     KV_REQUIRE(s && devptr && table >= 0 && table < s->h.ntables, KV_ERR_ARG, "kv_sketch_table_devptr: bad argument");
@@ -535,6 +547,44 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
     if (e == hipSuccess) e = hipMemcpy(r->d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess && n_reads) e = hipMemcpy(r->d_len, r->h_len.data(), n_reads * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && n_reads) e = hipMemcpy(r->d_flags, flags.data(), n_reads, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(r->d_tile, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        kv_set_error("read batch upload failed: %s", hipGetErrorString(e));
+        kv_reads_destroy(r);
+        return KV_ERR_HIP;
+    }
+    *out = r;
+    return KV_OK;
+}
+
+extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, uint32_t read_len, kv_reads **out)
+{
+    KV_REQUIRE(out && (words || n_reads == 0), KV_ERR_ARG, "kv_reads_create_packed: null argument");
+    KV_REQUIRE(n_reads < 0xFFFFFFF0ull, KV_ERR_ARG, "too many reads in one batch");
+    KV_REQUIRE(read_len >= 1 && read_len <= KV_MAX_READ_LEN, KV_ERR_ARG, "read length %u out of range", read_len);
+    kv_reads *r = new kv_reads();
+    const uint64_t wpr = (read_len + 15) / 16;
+    r->n_reads = n_reads; r->n_bases = n_reads * read_len; r->n_words = n_reads * wpr; r->max_len = read_len;
+    r->d_words = nullptr; r->d_woff = nullptr; r->d_len = nullptr; r->d_flags = nullptr; r->d_tile = nullptr;
+    r->h_len.assign(n_reads, read_len);
+    std::vector<uint64_t> woff(n_reads + 1);
+    for (uint64_t i = 0; i <= n_reads; ++i) woff[i] = i * wpr;
+    const uint32_t need = 2 * ((read_len + KV_READ_PAD + 3) & ~3u);
+    uint32_t per_tile = (KV_TILE_LDS_BYTES - 64) / need;
+    if (per_tile > KV_TILE_MAX_READS) per_tile = KV_TILE_MAX_READS;
+    std::vector<uint32_t> tiles;
+    for (uint64_t i = 0; i < n_reads; i += per_tile) tiles.push_back((uint32_t)i);
+    tiles.push_back((uint32_t)n_reads);
+    r->n_tiles = n_reads ? (uint32_t)tiles.size() - 1 : 0;
+    hipError_t e = hipMalloc((void **)&r->d_words, (r->n_words ? r->n_words : 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, n_reads ? n_reads : 1);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, tiles.size() * 4);
+    if (e == hipSuccess && r->n_words) e = hipMemcpy(r->d_words, words, r->n_words * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(r->d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_reads) e = hipMemcpy(r->d_len, r->h_len.data(), n_reads * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(r->d_flags, 0, n_reads ? n_reads : 1);
     if (e == hipSuccess) e = hipMemcpy(r->d_tile, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         kv_set_error("read batch upload failed: %s", hipGetErrorString(e));

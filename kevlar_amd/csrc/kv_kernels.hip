@@ -56,10 +56,10 @@ struct NovelParams {
     int band_mode, nbands, band;
     uint64_t band_lo, band_hi;
     uint64_t first_read;
-    uint32_t cap_hits, cap_disc;
+    uint32_t cap_hits;
     uint32_t *hit_read, *hit_off;
     uint8_t *hit_abund;
-    uint32_t *disc_read;
+    uint8_t *disc_flag;   // per read: dropped by the abundance screen
     uint32_t *mask;
     uint64_t mask_stride;
 };
@@ -108,8 +108,7 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel(ReadsDev rd, NovelPar
         }
         const uint32_t gread = read0 + r;
         if (discard) {
-            const unsigned long long d = atomicAdd((unsigned long long *)&counters[3], 1ull);
-            if (d < p.cap_disc) p.disc_read[d] = gread;
+            p.disc_flag[gread] = 1;   // any number of k-mers may flag the same read: plain store
             continue;
         }
         if (!interesting) continue;
@@ -383,16 +382,17 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     kv_hits *hits = new kv_hits();
     hits->nsamples = S;
     uint64_t *d_cnt = nullptr;
-    uint64_t cap = 1u << 20, cap_disc = reads->n_reads ? reads->n_reads : 1;
-    if (cap_disc > 0xFFFFFFFFull) cap_disc = 0xFFFFFFFFull;
+    uint64_t cap = 1u << 20;
+    const uint64_t nflags = reads->n_reads ? reads->n_reads : 1;
     hipError_t e = hipMalloc((void **)&d_cnt, 4 * sizeof(uint64_t));
+    if (e == hipSuccess && p.screen > 0) e = hipMalloc((void **)&p.disc_flag, nflags);
     uint64_t c[4] = {0, 0, 0, 0};
     for (int attempt = 0; attempt < 2 && e == hipSuccess; ++attempt) {
-        p.cap_hits = (uint32_t)cap; p.cap_disc = (uint32_t)cap_disc;
+        p.cap_hits = (uint32_t)cap;
         e = hipMalloc((void **)&p.hit_read, cap * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&p.hit_off, cap * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&p.hit_abund, cap * (uint64_t)S);
-        if (e == hipSuccess && p.screen > 0) e = hipMalloc((void **)&p.disc_read, cap_disc * 4);
+        if (e == hipSuccess && p.disc_flag) e = hipMemsetAsync(p.disc_flag, 0, nflags, kv_stream());
         if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 4 * sizeof(uint64_t), kv_stream());
         if (e == hipSuccess && reads->n_tiles > 0) {
             KvProfScope prof("k_novel");
@@ -403,22 +403,25 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         if (e == hipSuccess) e = hipStreamSynchronize(kv_stream());
         if (e == hipSuccess && c[2] <= cap) {
             hits->read.resize(c[2]); hits->offset.resize(c[2]); hits->abund.resize(c[2] * (uint64_t)S);
-            const uint64_t nd = c[3] < cap_disc ? c[3] : cap_disc;
-            hits->discarded.resize(nd);
             if (c[2]) {
                 e = hipMemcpy(hits->read.data(), p.hit_read, c[2] * 4, hipMemcpyDeviceToHost);
                 if (e == hipSuccess) e = hipMemcpy(hits->offset.data(), p.hit_off, c[2] * 4, hipMemcpyDeviceToHost);
                 if (e == hipSuccess) e = hipMemcpy(hits->abund.data(), p.hit_abund, c[2] * (uint64_t)S, hipMemcpyDeviceToHost);
             }
-            if (e == hipSuccess && nd) e = hipMemcpy(hits->discarded.data(), p.disc_read, nd * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && p.disc_flag && reads->n_reads) {
+                std::vector<uint8_t> flags(reads->n_reads);
+                e = hipMemcpy(flags.data(), p.disc_flag, reads->n_reads, hipMemcpyDeviceToHost);
+                for (uint64_t i = 0; i < reads->n_reads; ++i)
+                    if (flags[i]) hits->discarded.push_back((uint32_t)i);
+            }
             attempt = 2;
         } else if (e == hipSuccess) {
-            cap = c[2];  // second pass with exactly enough room (the mask bits are idempotent)
+            cap = c[2];  // second pass with exactly enough room (mask bits and flags are idempotent)
         }
         (void)hipFree(p.hit_read); (void)hipFree(p.hit_off); (void)hipFree(p.hit_abund);
-        if (p.disc_read) (void)hipFree(p.disc_read);
-        p.hit_read = p.hit_off = nullptr; p.hit_abund = nullptr; p.disc_read = nullptr;
+        p.hit_read = p.hit_off = nullptr; p.hit_abund = nullptr;
     }
+    if (p.disc_flag) (void)hipFree(p.disc_flag);
     if (d_cnt) (void)hipFree(d_cnt);
     if (e != hipSuccess) {
         delete hits;
@@ -427,9 +430,7 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     }
     // canonical order: by read, then offset; a discarded read drops all of its hits
     {
-        std::vector<uint32_t> &disc = hits->discarded;
-        std::sort(disc.begin(), disc.end());
-        disc.erase(std::unique(disc.begin(), disc.end()), disc.end());
+        std::vector<uint32_t> &disc = hits->discarded;   // ascending by construction
         const uint64_t n = hits->read.size();
         std::vector<uint64_t> order(n);
         for (uint64_t i = 0; i < n; ++i) order[i] = i;

@@ -154,6 +154,18 @@ class ReadBatch(object):
         self.n_reads = len(offs) - 1
         return self
 
+    @classmethod
+    def from_packed(cls, words, read_len):
+        """words: uint32 array [n_reads, ceil(read_len/16)], 2 bits per base (A0 C1 G2 T3)."""
+        _lib.require_device()
+        self = cls.__new__(cls)
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        handle = ctypes.c_void_p()
+        check(_lib.load().kv_reads_create_packed(_u32p(words), words.shape[0], int(read_len), ctypes.byref(handle)))
+        self._h = handle
+        self.n_reads = int(words.shape[0])
+        return self
+
     def num_kmers(self, ksize):
         n = ctypes.c_uint64()
         check(_lib.load().kv_reads_num_kmers(self._h, ksize, ctypes.byref(n)))
@@ -219,6 +231,13 @@ class _Sketch(object):
 
     def save(self, path):
         check(_lib.load().kv_sketch_save(self._h, path.encode()))
+
+    def clear(self):
+        """Zero all tables (same geometry, fresh counts)."""
+        check(_lib.load().kv_sketch_clear(self._h))
+        if self._exact is not None:
+            self._exact = []
+        self._exact_cache = None
 
     # ---- info ---------------------------------------------------------------------------
     def _info(self):

@@ -105,7 +105,7 @@ def test_consume_with_mask(hk, ok, consume_masked, maskkind):
 
 def test_get_add_point_queries(hk, ok):
     reads = random_reads(8, 200, lo=60, hi=100)
-    dev, ref = hk.Counttable(27, 1e4, 4), ok.Counttable(27, 1e4, 4)
+    dev, ref = hk.Counttable(27, 1e6, 4), ok.Counttable(27, 1e6, 4)
     dev.consume_batch(hk.ReadBatch(reads))
     for r in reads:
         ref.consume(r)
