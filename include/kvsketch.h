@@ -128,7 +128,7 @@ int kv_reads_num_kmers(const kv_reads *r, int ksize, uint64_t *n_kmers);
  *   consume_masked != 0: skip the k-mer unless mask.get(h) >= threshold
  * n_kmers_out: k-mers added.  n_unique_kmers is accumulated with the semantics of khmer's
  * multi-threaded consume (a k-mer counts as new if any of its bins was zero when ITS
- * increment landed); kv_sketch_unique_exact() gives the single-thread file-order value.   */
+ * increment landed); kv_unique_exact() gives the single-thread file-order value.   */
 int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int band, const kv_sketch *mask,
                int threshold, int consume_masked, uint64_t *n_kmers_out);
 /* Re-derive n_unique_kmers exactly as a single khmer thread would have counted it over

@@ -1,0 +1,244 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, the product
+fails loudly without a GPU, and the host logic (augfastx codec, seqio, CLI, unband, timers)
+matches the reference's own expectations.  No kernel is launched here."""
+import io
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, data_file, expected_file
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    from kevlar_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, 'include', 'kvsketch.h')).read()
+    declared = set(re.findall(r'\b(kv_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations found'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b'gfx950' in lib.kv_version()
+
+
+def test_host_helpers_need_no_gpu(ok):
+    """prime picking, single k-mer hashing and band bounds are host code in the library."""
+    import ctypes
+    from kevlar_amd import _lib, khmer
+    lib = _lib.load()
+    assert khmer.primes_below(2500, 4) == [2477, 2473, 2467, 2459]
+    assert khmer.primes_below(2e5, 4) == ok.primes_below(2e5, 4)
+    for target in (3, 4, 10, 97 / 4, 1e6 / 4, 12345.9):
+        assert khmer.primes_below(target, 4) == ok.primes_below(target, 4)
+    out = ctypes.c_uint64()
+    for kmer in ('GATTACAGATTACAGATTACA', 'A' * 31, ('ACGTTGCA' * 7)[:51]):
+        assert lib.kv_hash_kmer(0, kmer.encode(), len(kmer), ctypes.byref(out)) == 0
+        assert out.value == ok.Counttable(len(kmer), 100, 1).hash(kmer)
+    assert lib.kv_hash_kmer(3, b'GATTACAGATTACAGATTACA', 21, ctypes.byref(out)) == 0
+    assert out.value == ok.Countgraph(21, 100, 1).hash('GATTACAGATTACAGATTACA')
+    assert lib.kv_hash_kmer(0, b'GATTACANATTACAGATTACA', 21, ctypes.byref(out)) == 0   # murmur takes any byte
+    assert lib.kv_hash_kmer(3, b'GATTACANATTACAGATTACA', 21, ctypes.byref(out)) == _lib.KV_ERR_ARG
+    lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
+    assert lib.kv_band_bounds(8, 0, ctypes.byref(lo), ctypes.byref(hi)) == 0
+    assert (lo.value, hi.value) == ok.band_bounds(8, 0)
+    assert lib.kv_band_bounds(8, 8, ctypes.byref(lo), ctypes.byref(hi)) == _lib.KV_ERR_ARG
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    from kevlar_amd import khmer, _lib
+    with pytest.raises(_lib.KvError, match='no HIP device'):
+        khmer.Counttable(31, 1e6, 4)
+    with pytest.raises(_lib.KvError, match='no HIP device'):
+        khmer.ReadBatch(['ACGT'])
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under kevlar_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'kevlar_amd')):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert 'okhmer' not in text and 'kvoracle' not in text and 'from oracle' not in text, fn
+
+
+def test_memory_setting_and_cli_defaults():
+    import kevlar_amd
+    ms = kevlar_amd.khmer.khmer_args.memory_setting
+    assert ms('10K') == 1e4 and ms('500M') == 5e8 and ms('1e7') == 1e7 and ms('2g') == 2e9
+    with pytest.raises(ValueError):
+        ms('12Q')
+    args = kevlar_amd.cli.parser().parse_args(['novel', '--case', 'case1.fq', '--control', 'cntl1.fq',
+                                               '--control', 'cntl2.fq', '-k', '17'])
+    assert (args.ksize, args.case_min, args.ctrl_max, args.num_bands, args.band) == (17, 6, 1, None, None)
+    args = kevlar_amd.cli.parser().parse_args(['novel', '--num-bands', '8', '--band', '1', '--case', 'case1.fq',
+                                               '--control', 'cntl1.fq', '--control', 'cntl2.fq'])
+    assert (args.ksize, args.num_bands, args.band) == (31, 8, 1)
+    args = kevlar_amd.cli.parser().parse_args(['count', 'out.ct', 'in.fq'])
+    assert (args.ksize, args.counter_size, args.memory, args.max_fpr, args.threads) == (31, 8, 1e6, 0.2, 1)
+    args = kevlar_amd.cli.parser().parse_args(['filter', 'in.augfastq'])
+    assert (args.memory, args.max_fpr, args.ctrl_max, args.case_min) == (1e6, 0.01, 1, 6)
+    args = kevlar_amd.cli.parser().parse_args(['partition', 'in.augfastq'])
+    assert (args.min_abund, args.max_abund, args.dedup, args.strict) == (2, 200, True, False)
+    args = kevlar_amd.cli.parser().parse_args(['unband', 'a', 'b'])
+    assert args.n_batches == 16 and args.infile == ['a', 'b']
+    assert set(kevlar_amd.cli.mains) == {'count', 'novel', 'filter', 'partition', 'unband'}
+    assert kevlar_amd.sketch.get_extension() == ('.nt', '.nodetable')
+    assert kevlar_amd.sketch.get_extension(count=True) == ('.ct', '.counttable')
+    assert kevlar_amd.sketch.get_extension(count=True, smallcount=True) == ('.sct', '.smallcounttable')
+
+
+def test_augfastx_reader():
+    """kevlar/tests/test_seqio.py:46-132."""
+    import kevlar_amd
+    n = -1
+    for n, record in enumerate(kevlar_amd.parse_augmented_fastx(open(data_file('collect.beta.1.txt')))):
+        assert record.name.startswith('good')
+        assert record.sequence == 'TTAACTCTAGATTAGGGGCGTGACTTAATAAGGTGTGGGCCTAAGCGTCT'
+        assert len(record.annotations) == 2
+        assert all(k.abund == (8, 0, 0) for k in record.annotations)
+    assert n == 7
+    record = next(kevlar_amd.parse_augmented_fastx(open(data_file('example1.augfastq'))))
+    assert record.name == 'e1' and len(record.annotations) == 2
+    ik = record.annotations[0]
+    assert (record.ikmerseq(ik), ik.ksize, ik.offset, ik.abund) == ('AGGGGCGTGACTTAATAAG', 19, 13, (12, 15, 1, 1))
+    ik = record.annotations[1]
+    assert (record.ikmerseq(ik), ik.offset, ik.abund) == ('GGGCGTGACTTAATAAGGT', 15, (20, 28, 0, 1))
+    record = next(kevlar_amd.parse_augmented_fastx(open(data_file('example2.augfastq'))))
+    assert record.name == 'ERR894724.125497791/1'
+    assert [(k.ksize, k.offset, k.abund) for k in record.annotations] == [(31, 74, (23, 0, 0)), (31, 83, (23, 0, 0))]
+    reader = kevlar_amd.parse_augmented_fastx(kevlar_amd.open(data_file('seqs-mates.augfastq'), 'r'))
+    shape = [(len(r.annotations), len(r.mates)) for r in reader]
+    assert shape == [(5, 1), (4, 1), (21, 0), (2, 1)]
+
+
+def test_augfastx_writer_golden_text():
+    """kevlar/tests/test_seqio.py:135-182: the literal expected output."""
+    import kevlar_amd
+    from kevlar_amd.sequence import KmerOfInterest, Record
+    output = io.StringIO()
+    kevlar_amd.print_augmented_fastx(Record(
+        name='BasiliscusVulgarisRead84467/1', sequence='TTAACTCTAGATTAGGGGCGTGACTTAATAAGGTGTGGGCCTAAGCGTCT',
+        quality='B' * 50, annotations=[KmerOfInterest(19, 13, (12, 1, 1)), KmerOfInterest(19, 15, (20, 0, 1))]), output)
+    kevlar_amd.print_augmented_fastx(Record(
+        name='BasiliscusVulgarisRead90577/2', sequence='CTGTAATCCCAGCACTTTGGGAGGCCGAGGCAAGCAGATGATGCGGTCAG',
+        quality='B' * 50, annotations=[KmerOfInterest(19, 1, (5, 7, 9)), KmerOfInterest(19, 2, (7, 10, 9))],
+        mates=['CAGATGTGTCTTGTGGGCAGTGCAGCGGAGAGGTGCAAATATGGGTTTGG']), output)
+    kevlar_amd.print_augmented_fastx(Record(
+        name='BasiliscusVulgarisRead99037/1', sequence='AGCACTTTGGGAGGCCGAGGCAAGCAGATGATGCGGTCAGGATTACAGAT',
+        quality='B' * 50), output)
+    assert output.getvalue() == (
+        '@BasiliscusVulgarisRead84467/1\nTTAACTCTAGATTAGGGGCGTGACTTAATAAGGTGTGGGCCTAAGCGTCT\n+\n' + 'B' * 50 + '\n'
+        '             AGGGGCGTGACTTAATAAG          12 1 1#\n'
+        '               GGGCGTGACTTAATAAGGT          20 0 1#\n'
+        '@BasiliscusVulgarisRead90577/2\nCTGTAATCCCAGCACTTTGGGAGGCCGAGGCAAGCAGATGATGCGGTCAG\n+\n' + 'B' * 50 + '\n'
+        ' TGTAATCCCAGCACTTTGG          5 7 9#\n'
+        '  GTAATCCCAGCACTTTGGG          7 10 9#\n'
+        '#mateseq=CAGATGTGTCTTGTGGGCAGTGCAGCGGAGAGGTGCAAATATGGGTTTGG#\n'
+        '@BasiliscusVulgarisRead99037/1\nAGCACTTTGGGAGGCCGAGGCAAGCAGATGATGCGGTCAGGATTACAGAT\n+\n' + 'B' * 50 + '\n')
+
+
+@pytest.mark.parametrize('name', ['novel-trio-li.augfastq', 'filter-trio1-masked.augfastq', 'novel-screen.augfasta',
+                                  'unband-helium.sorted.augfastq'])
+def test_augfastx_roundtrip_is_byte_exact(name):
+    """parse -> print reproduces files written by the reference's own (Cython) codec."""
+    import kevlar_amd
+    text = open(expected_file(name)).read()
+    buf = io.StringIO()
+    for rec in kevlar_amd.parse_augmented_fastx(io.StringIO(text)):
+        kevlar_amd.print_augmented_fastx(rec, buf)
+    assert buf.getvalue() == text
+
+
+def test_kmer_rep_in_read_and_revcom():
+    import kevlar_amd
+    read = 'AGGATGAGGATGAGGATGAGGATGAGGATGAGGATGAGGATGAGGATGAGGATGAGGATGAGGATGAGGATGAGGATGAGGAT'
+    record = kevlar_amd.sequence.Record(name='reqseq', sequence=read)
+    record.annotate('GATGAGGATGAGGATGAGGATGAGG', 2, (11, 1, 0))
+    record.annotate('GATGAGGATGAGGATGAGGATGAGG', 8, (11, 1, 0))
+    assert read in kevlar_amd.sequence.format_augmented_fastx(record)
+    assert kevlar_amd.revcom('AACGTN') == 'NACGTT'
+    assert kevlar_amd.revcommin('TTTT') == 'AAAA' and kevlar_amd.revcommin('ACGG') == 'ACGG'
+    with pytest.raises(AssertionError):
+        record.annotate('CCCC', 0, (1,))
+
+
+def test_seqio_partition_readers():
+    import kevlar_amd
+    lines = '>seq1\nACGT\n>seq2 yo\nGATTACA\nGATTACA\n>seq3\tdescrip\nATGATGTGA'.split('\n')
+    assert dict(kevlar_amd.seqio.parse_fasta(lines)) == {'>seq1': 'ACGT', '>seq2 yo': 'GATTACAGATTACA',
+                                                         '>seq3\tdescrip': 'ATGATGTGA'}
+    assert kevlar_amd.seqio.parse_seq_dict(lines) == {'seq1': 'ACGT', 'seq2': 'GATTACAGATTACA', 'seq3': 'ATGATGTGA'}
+    stream = kevlar_amd.parse_augmented_fastx(kevlar_amd.open(data_file('part-reads-simple.fa'), 'r'))
+    parts = [p for _, p in kevlar_amd.parse_partitioned_reads(stream)]
+    assert [len(p) for p in parts] == [4, 2]
+    stream = kevlar_amd.parse_augmented_fastx(kevlar_amd.open(data_file('part-reads-mixed.fa'), 'r'))
+    with pytest.raises(kevlar_amd.seqio.KevlarPartitionLabelError, match='with and without partition labels'):
+        list(kevlar_amd.parse_partitioned_reads(stream))
+
+
+def test_unband_golden():
+    """kevlar/tests/test_unband.py:15-45 (host-side merge; the golden file is name-sorted)."""
+    import kevlar_amd
+    infiles = [data_file('helium-unband/novel.band{}.augfastq.gz'.format(i)) for i in (1, 2, 3, 4)]
+    reads = sorted(kevlar_amd.unband.unband(kevlar_amd.seqio.afxstream(infiles), numbatches=16), key=lambda r: r.name)
+    assert len(reads) == 135
+    some = [r for r in reads if r.name == 'seq1_haplo1_285110_285519_1:0:0_0:0:0_2dbcd/1'][0]
+    assert len(some.annotations) == 75
+    buf = io.StringIO()
+    for rec in reads:
+        kevlar_amd.print_augmented_fastx(rec, buf)
+    assert buf.getvalue() == open(expected_file('unband-helium.sorted.augfastq')).read()
+    beta = [data_file('collect.beta.{}.txt'.format(i)) for i in (1, 2)]
+    merged = sorted(kevlar_amd.unband.unband(kevlar_amd.seqio.afxstream(beta), numbatches=2), key=lambda r: r.name)
+    assert len(merged) == 8 and len(merged[0].annotations) == 4
+
+
+def test_timer_progress_and_logging(capsys):
+    import kevlar_amd
+    timer = kevlar_amd.Timer()
+    timer.start()
+    timer.start('x')
+    with pytest.raises(ValueError, match='Timer already started'):
+        timer.start('x')
+    with pytest.raises(ValueError, match='No timer started'):
+        timer.stop('y')
+    assert timer.probe('x') >= 0 and timer.stop('x') >= 0 and timer.stop() >= 0
+    buf = io.StringIO()
+    old = kevlar_amd.logstream
+    kevlar_amd.logstream = buf
+    try:
+        pi = kevlar_amd.ProgressIndicator('processed {counter}', interval=10, breaks=[100, 1000])
+        for _ in range(1500):
+            pi.update()
+    finally:
+        kevlar_amd.logstream = old
+    lines = buf.getvalue().strip().split('\n')
+    assert lines[0] == 'processed 10' and 'processed 100' in lines and lines[-1] == 'processed 1000'
+    assert len(lines) == 10 + 9
+    with pytest.raises(ValueError, match='invalid mode'):
+        kevlar_amd.open('x', 'a')
+
+
+def test_synthetic_trio_generator_properties():
+    from kevlar_amd import synth
+    trio = synth.make_trio(200000, 42)
+    again = synth.make_trio(200000, 42)
+    assert all(np.array_equal(a, b) for n in trio for a, b in zip(trio[n], again[n]))
+    words = synth.sample_reads_packed(trio['proband'], 2000, 100, 0.0, 7)
+    assert np.array_equal(words, synth.sample_reads_packed(trio['proband'], 2000, 100, 0.0, 7))
+    haps = [''.join('ACGT'[c] for c in h) for h in trio['proband']]
+    rc = lambda s: s[::-1].translate(str.maketrans('ACGT', 'TGCA'))  # noqa: E731
+    for read in synth.unpack_reads(words[:100], 100):
+        assert len(read) == 100 and any(read in h or rc(read) in h for h in haps)
+    noisy = synth.unpack_reads(synth.sample_reads_packed(trio['proband'], 2000, 100, 0.005, 7), 100)
+    clean = synth.unpack_reads(words, 100)
+    diff = sum(a != b for x, y in zip(noisy, clean) for a, b in zip(x, y))
+    assert 600 < diff < 1400            # ~0.5 % of 200k bases
