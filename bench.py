@@ -159,7 +159,7 @@ def main():
     frac_band = 1.0 / max(1, world)
     alg = {
         'k_consume': n_reads * (L / 4.0 + 2 * T * nk * frac_band),          # A_count  
-        'k_novel': n_reads * (L / 4.0 + T * 3 * nk * frac_band),            # A_novel, S = 3
+        'k_novel_mark': n_reads * (L / 4.0 + T * 3 * nk * frac_band),            # A_novel, S = 3
     }
     times = {name: prof(lib, name) for name in alg}
     dominant = max(times, key=lambda n_: times[n_][0])

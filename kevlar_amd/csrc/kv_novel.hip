@@ -1,0 +1,330 @@
+// kv_novel.hip -- K3, the fused novel scan: novel() + kmer_is_interesting()
+// (kevlar/novel.py:21-53,123-169) as three launches over the packed case reads:
+//
+//   k_novel_mark  one workgroup per tile: hash every k-mer, band filter, probe the control and
+//                 case sketches, and set bit (read * stride + offset) for each interesting k-mer;
+//                 per-tile hit counts on the side.  This is the whole cost of the scan.
+//   k_tile_scan   exclusive prefix sum of the tile hit counts (one workgroup).
+//   k_novel_emit  tiles that own hits are staged again; the set bits are ranked in (read, offset)
+//                 order with ballots and each hit's abundances are read from every sketch.
+//
+// Hits therefore reach the host already sorted, in exactly the order the reference annotates
+// them, and the bit mask doubles as the per-band mask that the multi-GPU merge all-reduces.
+#include <algorithm>
+
+#include "kv_device.h"
+
+namespace {
+
+struct NovelParams {
+    HashParams hp;
+    int ncase, nctrl;
+    const SketchDev *sk[KV_MAX_SAMPLES];  // cases first, then controls
+    int case_min, ctrl_max, screen;
+    int band_mode, nbands, band;
+    uint64_t band_lo, band_hi;
+    uint64_t first_read;
+    uint8_t *disc_flag;     // per read: dropped by the abundance screen (NULL when screen is off)
+    uint32_t *mask;         // bit (read * mask_stride + offset)
+    uint64_t mask_stride;
+    uint32_t *tile_count;   // hits per tile
+    const uint64_t *tile_base;
+    uint32_t *hit_read, *hit_off;
+    uint8_t *hit_abund;
+};
+
+__device__ __forceinline__ bool band_pass(const NovelParams &p, uint64_t h)
+{
+    if (p.band_mode == KV_BAND_RANGE) return h >= p.band_lo && h < p.band_hi;
+    if (p.band_mode == KV_BAND_REFQUIRK) return (h & (uint64_t)(p.nbands - 1)) == (uint64_t)(int64_t)(p.band - 1);
+    return true;
+}
+
+// The abundance test.  Without a screen the predicate is evaluated cheapest-evidence-first: a
+// control passes as soon as ONE table is <= ctrl_max (its Count-Min minimum is then <= ctrl_max)
+// and fails only after all T tables exceed it; a case fails as soon as ONE table is < case_min.
+// The typical inherited k-mer is rejected after T loads.  With a screen the reference order is
+// kept (cases in order with full minima, novel.py:36-44) because `discard` depends on it.
+__device__ __forceinline__ bool novel_test(const NovelParams &p, uint64_t h, bool &discard)
+{
+    bool interesting = true;
+    discard = false;
+    if (p.screen > 0) {
+        for (int c = 0; c < p.ncase && interesting; ++c) {
+            const int a = (int)sketch_get(p.sk[c], h);
+            if (a < p.case_min) { interesting = false; discard = a < p.screen; }
+        }
+        for (int c = 0; c < p.nctrl && interesting; ++c)
+            if ((int)sketch_get(p.sk[p.ncase + c], h) > p.ctrl_max) interesting = false;
+        return interesting;
+    }
+    for (int c = 0; c < p.nctrl && interesting; ++c) {
+        const SketchDev *s = p.sk[p.ncase + c];
+        bool pass = false;
+        for (int t = 0; t < s->ntables && !pass; ++t) pass = (int)table_get(s, t, h) <= p.ctrl_max;
+        interesting = pass;
+    }
+    for (int c = 0; c < p.ncase && interesting; ++c) {
+        const SketchDev *s = p.sk[c];
+        for (int t = 0; t < s->ntables && interesting; ++t) interesting = (int)table_get(s, t, h) >= p.case_min;
+    }
+    return interesting;
+}
+
+__global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_mark(ReadsDev rd, NovelParams p)
+{
+    __shared__ TileShared sh;
+    __shared__ uint32_t tile_hits;
+    uint32_t read0;
+    if (threadIdx.x == 0) tile_hits = 0;
+    const uint32_t nr = stage_tile(sh, rd, blockIdx.x, p.hp.k, 1, p.first_read, read0);
+    const uint32_t total = sh.kpre[nr];
+    uint32_t mine = 0;
+    for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
+        uint32_t r, i;
+        locate_kmer(sh, nr, q, r, i);
+        const uint32_t fwd = sh.foff[r] + i;
+        const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)p.hp.k - i);
+        const uint64_t h = kmer_hash_lds(sh.ascii, fwd, rc, p.hp);
+        if (!band_pass(p, h)) continue;
+        bool discard;
+        const bool interesting = novel_test(p, h, discard);
+        const uint32_t gread = read0 + r;
+        if (discard) p.disc_flag[gread] = 1;   // several k-mers may flag one read: plain store
+        if (!interesting) continue;
+        const uint64_t bit = (uint64_t)gread * p.mask_stride + i;
+        atomicOr(&p.mask[bit >> 5], 1u << (bit & 31));
+        mine += 1;
+    }
+    mine = (uint32_t)wave_sum_u64(mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&tile_hits, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) p.tile_count[blockIdx.x] = tile_hits;
+}
+
+// exclusive scan of n 32-bit counts into 64-bit bases (single 1024-thread workgroup)
+__global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t *counts, uint32_t n, uint64_t *base)
+{
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t start = 0; start < n; start += 1024) {
+        const uint32_t i = start + threadIdx.x;
+        const uint64_t v = i < n ? counts[i] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint64_t before = carry;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < n) base[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) base[n] = carry;
+}
+
+__global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_emit(ReadsDev rd, NovelParams p)
+{
+    __shared__ TileShared sh;
+    __shared__ uint32_t wcount[KV_TILE_THREADS / 64];
+    if (p.tile_count[blockIdx.x] == 0) return;
+    uint32_t read0;
+    const uint32_t nr = stage_tile(sh, rd, blockIdx.x, p.hp.k, 1, p.first_read, read0);
+    const uint32_t total = sh.kpre[nr];
+    const int S = p.ncase + p.nctrl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t out = p.tile_base[blockIdx.x];
+    for (uint32_t q0 = 0; q0 < total; q0 += blockDim.x) {
+        const uint32_t q = q0 + threadIdx.x;
+        uint32_t r = 0, i = 0;
+        bool hit = false;
+        if (q < total) {
+            locate_kmer(sh, nr, q, r, i);
+            const uint64_t bit = (uint64_t)(read0 + r) * p.mask_stride + i;
+            hit = (p.mask[bit >> 5] >> (bit & 31)) & 1u;
+        }
+        const unsigned long long ballot = __ballot(hit);
+        if (lane == 0) wcount[wave] = (uint32_t)__popcll(ballot);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (int w = 0; w < KV_TILE_THREADS / 64; ++w) {
+            if (w < wave) before += wcount[w];
+            all += wcount[w];
+        }
+        if (hit) {
+            const uint64_t slot = out + before + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+            const uint32_t fwd = sh.foff[r] + i;
+            const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)p.hp.k - i);
+            const uint64_t h = kmer_hash_lds(sh.ascii, fwd, rc, p.hp);
+            p.hit_read[slot] = read0 + r;
+            p.hit_off[slot] = i;
+            for (int c = 0; c < S; ++c) p.hit_abund[slot * (uint64_t)S + c] = (uint8_t)sketch_get(p.sk[c], h);
+        }
+        out += all;
+        __syncthreads();
+    }
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+    template <typename T> T *as() { return (T *)p; }
+};
+
+}  // namespace
+
+extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl,
+                             const kv_reads *reads, uint64_t first_read, int case_min, int ctrl_max,
+                             int screen_thresh, int band_mode, int nbands, int band, uint32_t *d_mask,
+                             uint64_t mask_stride, kv_hits **out)
+{
+    KV_REQUIRE(cases && reads && out && ncase >= 1 && nctrl >= 0 && (ctrls || nctrl == 0), KV_ERR_ARG,
+               "kv_novel_scan: bad argument");
+    KV_REQUIRE(ncase + nctrl <= KV_MAX_SAMPLES, KV_ERR_ARG, "at most %d samples per scan", KV_MAX_SAMPLES);
+    KV_REQUIRE(band_mode == KV_BAND_NONE || (nbands > 0 && band >= 0 && band < nbands), KV_ERR_ARG,
+               "band %d out of range for %d bands", band, nbands);
+    NovelParams p;
+    memset(&p, 0, sizeof(p));
+    const int k = cases[0]->h.ksize, fam = cases[0]->h.hashfam;
+    for (int c = 0; c < ncase + nctrl; ++c) {
+        const kv_sketch *s = c < ncase ? cases[c] : ctrls[c - ncase];
+        KV_REQUIRE(s, KV_ERR_ARG, "kv_novel_scan: null sketch");
+        KV_REQUIRE(s->h.ksize == k && s->h.hashfam == fam, KV_ERR_ARG,
+                   "all sketches of one scan must share k and hash function");
+        p.sk[c] = s->d_desc;
+    }
+    const uint64_t min_stride = reads->max_len >= (uint32_t)k ? reads->max_len - (uint32_t)k + 1 : 1;
+    if (d_mask) KV_REQUIRE(mask_stride >= min_stride, KV_ERR_ARG, "mask_stride %llu is smaller than the longest read's %llu k-mers",
+                           (unsigned long long)mask_stride, (unsigned long long)min_stride);
+    p.hp = make_hash_params(k, fam);
+    p.ncase = ncase; p.nctrl = nctrl;
+    p.case_min = case_min; p.ctrl_max = ctrl_max; p.screen = screen_thresh > 0 ? screen_thresh : 0;
+    p.band_mode = band_mode; p.nbands = nbands; p.band = band;
+    if (band_mode == KV_BAND_RANGE) kv_band_bounds(nbands, band, &p.band_lo, &p.band_hi);
+    p.first_read = first_read;
+    const int S = ncase + nctrl;
+    hipStream_t st = kv_stream();
+
+    kv_hits *hits = new kv_hits();
+    hits->nsamples = S;
+    *out = hits;
+    if (reads->n_tiles == 0) return KV_OK;
+
+    DevBuf own_mask, d_flags, d_tcount, d_tbase, d_read, d_off, d_abund;
+    hipError_t e = hipSuccess;
+    if (d_mask) {
+        p.mask = d_mask; p.mask_stride = mask_stride;
+    } else {
+        p.mask_stride = min_stride;
+        const uint64_t words = (reads->n_reads * min_stride + 31) / 32;
+        e = own_mask.alloc(words * 4);
+        if (e == hipSuccess) e = hipMemsetAsync(own_mask.p, 0, words * 4, st);
+        p.mask = own_mask.as<uint32_t>();
+    }
+    if (e == hipSuccess && p.screen > 0) {
+        e = d_flags.alloc(reads->n_reads);
+        if (e == hipSuccess) e = hipMemsetAsync(d_flags.p, 0, reads->n_reads, st);
+        p.disc_flag = d_flags.as<uint8_t>();
+    }
+    if (e == hipSuccess) e = d_tcount.alloc((uint64_t)reads->n_tiles * 4);
+    if (e == hipSuccess) e = d_tbase.alloc(((uint64_t)reads->n_tiles + 1) * 8);
+    p.tile_count = d_tcount.as<uint32_t>();
+    p.tile_base = d_tbase.as<uint64_t>();
+    uint64_t nhits = 0;
+    if (e == hipSuccess) {
+        {
+            KvProfScope prof("k_novel_mark");
+            hipLaunchKernelGGL(k_novel_mark, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), 0, st, reads_dev(reads), p);
+        }
+        {
+            KvProfScope prof("k_tile_scan");
+            hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p.tile_count, reads->n_tiles, d_tbase.as<uint64_t>());
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&nhits, d_tbase.as<uint64_t>() + reads->n_tiles, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && nhits) {
+        e = d_read.alloc(nhits * 4);
+        if (e == hipSuccess) e = d_off.alloc(nhits * 4);
+        if (e == hipSuccess) e = d_abund.alloc(nhits * (uint64_t)S);
+        p.hit_read = d_read.as<uint32_t>(); p.hit_off = d_off.as<uint32_t>(); p.hit_abund = d_abund.as<uint8_t>();
+        if (e == hipSuccess) {
+            KvProfScope prof("k_novel_emit");
+            hipLaunchKernelGGL(k_novel_emit, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), 0, st, reads_dev(reads), p);
+            e = hipGetLastError();
+        }
+        hits->read.resize(nhits); hits->offset.resize(nhits); hits->abund.resize(nhits * (uint64_t)S);
+        if (e == hipSuccess) e = hipMemcpyAsync(hits->read.data(), p.hit_read, nhits * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(hits->offset.data(), p.hit_off, nhits * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(hits->abund.data(), p.hit_abund, nhits * (uint64_t)S, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (e == hipSuccess && p.disc_flag) {
+        std::vector<uint8_t> flags(reads->n_reads);
+        e = hipMemcpy(flags.data(), p.disc_flag, reads->n_reads, hipMemcpyDeviceToHost);
+        for (uint64_t i = 0; i < reads->n_reads; ++i)
+            if (flags[i]) hits->discarded.push_back((uint32_t)i);
+    }
+    if (e != hipSuccess) {
+        delete hits;
+        *out = nullptr;
+        kv_set_error("kv_novel_scan failed: %s", hipGetErrorString(e));
+        return KV_ERR_HIP;
+    }
+    // a read dropped by the abundance screen loses all of its hits (novel.py:152-154,164)
+    if (!hits->discarded.empty()) {
+        const std::vector<uint32_t> &disc = hits->discarded;
+        uint64_t w = 0;
+        for (uint64_t i = 0; i < hits->read.size(); ++i) {
+            if (std::binary_search(disc.begin(), disc.end(), hits->read[i])) continue;
+            hits->read[w] = hits->read[i];
+            hits->offset[w] = hits->offset[i];
+            if (w != i) memmove(&hits->abund[w * (uint64_t)S], &hits->abund[i * (uint64_t)S], (size_t)S);
+            ++w;
+        }
+        hits->read.resize(w); hits->offset.resize(w); hits->abund.resize(w * (uint64_t)S);
+    }
+    return KV_OK;
+}
+
+extern "C" int kv_hits_count(const kv_hits *h, uint64_t *n_hits, uint64_t *n_discarded_reads)
+{
+    KV_REQUIRE(h, KV_ERR_ARG, "kv_hits_count: null handle");
+    if (n_hits) *n_hits = h->read.size();
+    if (n_discarded_reads) *n_discarded_reads = h->discarded.size();
+    return KV_OK;
+}
+
+extern "C" int kv_hits_fetch(const kv_hits *h, uint32_t *read, uint32_t *offset, uint8_t *abund, uint64_t cap_hits,
+                             uint32_t *discarded_reads, uint64_t cap_discarded)
+{
+    KV_REQUIRE(h, KV_ERR_ARG, "kv_hits_fetch: null handle");
+    KV_REQUIRE(cap_hits >= h->read.size(), KV_ERR_CAPACITY, "hit buffer too small");
+    if (!h->read.empty()) {
+        KV_REQUIRE(read && offset && abund, KV_ERR_ARG, "kv_hits_fetch: null output");
+        memcpy(read, h->read.data(), h->read.size() * 4);
+        memcpy(offset, h->offset.data(), h->offset.size() * 4);
+        memcpy(abund, h->abund.data(), h->abund.size());
+    }
+    if (discarded_reads) {
+        KV_REQUIRE(cap_discarded >= h->discarded.size(), KV_ERR_CAPACITY, "discard buffer too small");
+        if (!h->discarded.empty()) memcpy(discarded_reads, h->discarded.data(), h->discarded.size() * 4);
+    }
+    return KV_OK;
+}
+
+extern "C" int kv_hits_destroy(kv_hits *h)
+{
+    delete h;
+    return KV_OK;
+}
