@@ -45,12 +45,6 @@ __device__ __forceinline__ uint64_t fastmod(uint64_t h, uint64_t size, uint64_t 
     return r;
 }
 
-struct HashParams {
-    int k, nblocks, rem;   // k = 16*nblocks + rem
-    uint64_t m1, m2;       // byte masks for the murmur tail words
-    int hashfam;
-};
-
 // MurmurHash3_x64_128 (low word) of the k bytes at LDS byte address `a`
 __device__ __forceinline__ uint64_t murmur_lds(const uint32_t *lds, uint32_t a, const HashParams &hp)
 {
@@ -317,14 +311,6 @@ inline ReadsDev reads_dev(const kv_reads *r)
     return d;
 }
 
-
-// band + mask predicate of consume_seqfile[_banding][_with_mask] (kevlar/count.py:43-71)
-struct ConsumeFilter {
-    HashParams hp;
-    int use_band;
-    uint64_t band_lo, band_hi;
-    int use_mask, threshold, consume_masked;
-};
 
 __device__ __forceinline__ bool consume_filter_pass(const ConsumeFilter &f, const SketchDev *mask, uint64_t h)
 {

@@ -71,6 +71,26 @@ struct kv_hits {
     std::vector<uint32_t> discarded;
 };
 
+struct HashParams {
+    int k, nblocks, rem;   // k = 16*nblocks + rem
+    uint64_t m1, m2;       // byte masks for the murmur tail words
+    int hashfam;
+};
+
+// band + mask predicate of consume_seqfile[_banding][_with_mask] (kevlar/count.py:43-71)
+struct ConsumeFilter {
+    HashParams hp;
+    int use_band;
+    uint64_t band_lo, band_hi;
+    int use_mask, threshold, consume_masked;
+};
+
+// partitioned count (kv_binned.hip)
+bool kv_binned_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_kmers, int nbands);
+int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &filter, const kv_sketch *mask,
+                      uint64_t n_kmers, int nbands, uint64_t *n_added);
+double kv_estimate_distinct(uint64_t occupied, uint64_t size);
+
 // tile geometry of the hashing kernels
 #define KV_TILE_THREADS 256
 #define KV_TILE_MAX_READS 128

@@ -172,6 +172,17 @@ extern "C" int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int b
     std::lock_guard<std::mutex> lk(s->mu);
     const ConsumeFilter p = make_consume_filter(s->h.ksize, s->h.hashfam, nbands, band, mask != nullptr, threshold,
                                                 consume_masked);
+    uint64_t n_kmers = 0;
+    kv_reads_num_kmers(reads, s->h.ksize, &n_kmers);
+    if (kv_binned_eligible(s, reads, n_kmers, nbands)) {
+        uint64_t added = 0;
+        const int rc = kv_consume_binned(s, reads, p, mask, n_kmers, nbands, &added);
+        if (rc == KV_OK) {
+            if (n_kmers_out) *n_kmers_out = added;
+            return KV_OK;
+        }
+        if (rc != KV_ERR_CAPACITY) return rc;   // capacity: tables untouched, fall through to the atomic kernel
+    }
     KV_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(uint64_t), kv_stream()));
     if (reads->n_tiles > 0) {
         KvProfScope prof("k_consume");
