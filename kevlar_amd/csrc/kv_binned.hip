@@ -30,27 +30,28 @@
 
 namespace {
 
-#define BIN_C 64            // coarse buckets per table
+#define BIN_C 64            // most coarse buckets per table
 #define BIN_MAX_T 4         // tables handled by the partitioned path
-#define BIN_NS (BIN_C * BIN_MAX_T)
-#define BIN_RING_BUDGET 16384   // LDS ring entries shared by all streams of a workgroup
 #define BIN_RING_MIN 64
-#define BIN_RING_MAX 4096       // a round appends at most 1024 items to one stream
-#define BIN_A_THREADS 1024
-#define BIN_B_THREADS 256
-#define BIN_B_CHUNK 131072  // items of one coarse bucket handled by one stage-B workgroup
+#define BIN_RING_MAX 4096   // a round appends at most 2048 items to one stream
+#define BIN_B_THREADS 512   // 8 waves: one lane per slice stream for F <= 512
+#define BIN_B_ITEMS 8       // items per thread per round in stage B
+#define BIN_B_BUDGET 16384  // LDS ring entries (u16) per stage-B workgroup
 #define BIN_C_THREADS 512
 #define BIN_MAX_F 512
 
 struct BinGeom {
     int T, F, C;                     // tables, slices per coarse bucket, coarse buckets in use (<= BIN_C)
     uint32_t ringA, ringB;           // LDS ring entries per stream in stages A / B (powers of two)
-    uint32_t recipF;                 // ceil(2^32 / F): slice / F by multiply-high
+    uint32_t recipF;                 // floor(2^32 / F) + 1: slice / F by multiply-high
     uint32_t nslices[BIN_MAX_T];
-    uint64_t cap1, cap2, spill_cap;
-    uint32_t *gbuf1;                 // [T*C][cap1] coarse items: (slice-in-bucket << 16) | offset
-    uint16_t *gbuf2;                 // [T*C*F][cap2] offsets inside a slice
-    uint32_t *gcnt1, *gcnt2;         // items appended per coarse bucket / per slice
+    uint32_t tile_lds;               // bytes of dynamic LDS in front of the stage-A rings
+    uint32_t nwgA, nwgB;             // writers per coarse bucket (stage-A workgroups) / per slice (stage-B workgroups of the bucket)
+    uint64_t cap1, cap2, spill_cap;  // items per PRIVATE segment: every writer owns its own region of every stream,
+                                     // so appending needs no global atomic (and no round trip) at all
+    uint32_t *gbuf1;                 // [T*C][nwgA][cap1] coarse items: (slice-in-bucket << 16) | offset
+    uint16_t *gbuf2;                 // [T*C*F][nwgB][cap2] offsets inside a slice
+    uint32_t *gcnt1, *gcnt2;         // [T*C][nwgA] / [T*C*F][nwgB] items written per segment
     unsigned long long *spill;       // (table << 32) | bin
     unsigned long long *ctr;         // [0] spill count, [1] overflow flag, [2] k-mers added, [3] occupancy delta
 };
@@ -62,60 +63,96 @@ __device__ __forceinline__ void spill_item(const BinGeom &g, int t, uint64_t bin
     else g.ctr[1] = 1;
 }
 
-// ---- stage A -----------------------------------------------------------------------------
-struct StreamsA {
-    uint32_t ring[BIN_RING_BUDGET];   // stream s owns [s * ringA, (s + 1) * ringA)
-    uint32_t cnt[BIN_NS], base[BIN_NS];
-    uint32_t fl_n[BIN_NS], fl_pos[BIN_NS], fl_base[BIN_NS];
+// ---- LDS write-combining rings ------------------------------------------------------------
+// ns streams, each a ring of R items (R a power of two) plus an append counter and a flushed
+// counter.  Appends are LDS atomics; after a workgroup barrier every wave flushes the streams it
+// owns: the owning lane decides, one global atomic claims the space, then the whole wave copies
+// the burst (coalesced).  A stream that receives more than R items between two flushes diverts
+// the excess to the caller's overflow path, so skew costs speed, never correctness.
+template <typename ItemT>
+struct Rings {
+    ItemT *ring;
+    uint32_t *cnt, *base;
+    uint32_t R;
 };
 
-__device__ __forceinline__ void flush_streams_a(StreamsA &st, const BinGeom &g, int ns, bool final)
+template <typename ItemT>
+__device__ __forceinline__ bool ring_append(const Rings<ItemT> &rs, uint32_t s, ItemT item)
 {
-    // decide (one thread per stream), then copy (one wave per stream, lanes = items)
-    const uint32_t R = g.ringA;
-    for (int s = threadIdx.x; s < ns; s += blockDim.x) {
-        const uint32_t base = st.base[s], avail = st.cnt[s] - base;
-        uint32_t n = 0, newbase = base;
-        if (avail > R) { n = R; newbase = st.cnt[s]; }       // ring overran: the excess went to the spill list
-        else if (final) { n = avail; newbase = base + n; }
-        else if (avail >= R / 2) { n = avail & ~15u; newbase = base + n; }
-        st.fl_n[s] = n;
-        st.fl_base[s] = base;
-        if (n) st.fl_pos[s] = atomicAdd(&g.gcnt1[s], n);
-        st.base[s] = newbase;
-    }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    for (int s = wave; s < ns; s += nwaves) {
-        const uint32_t n = st.fl_n[s];
-        for (uint32_t j = lane; j < n; j += 64) {
-            const uint32_t item = st.ring[(uint32_t)s * R + ((st.fl_base[s] + j) & (R - 1))];
-            const uint64_t pos = (uint64_t)st.fl_pos[s] + j;
-            if (pos < g.cap1) {
-                g.gbuf1[(uint64_t)s * g.cap1 + pos] = item;
-            } else {   // coarse bucket full: keep the increment, apply it later with an atomic
-                const int t = s / g.C, c = s % g.C;
-                spill_item(g, t, (((uint64_t)c * g.F + (item >> 16)) << 16) | (item & 0xffffu));
-            }
-        }
-    }
-    __syncthreads();
+    const uint32_t pos = atomicAdd(&rs.cnt[s], 1u);
+    if (pos - rs.base[s] >= rs.R) return false;
+    rs.ring[s * rs.R + (pos & (rs.R - 1))] = item;
+    return true;
 }
 
-__global__ __launch_bounds__(BIN_A_THREADS) void k_bin_hash(ReadsDev rd, uint32_t n_tiles, const SketchDev *__restrict__ sk,
-                                                            const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
+// `written` is the owning lane's count of items already flushed for ITS stream (one stream per
+// lane: callers guarantee ns <= 64 * waves), i.e. the position inside the private segment.
+template <typename ItemT, typename Emit>
+__device__ __forceinline__ void rings_flush(const Rings<ItemT> &rs, uint32_t ns, bool final, uint32_t &written, Emit emit)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const uint32_t per_wave = (ns + nwaves - 1) / nwaves;             // <= 64
+    const uint32_t s0 = wave * per_wave, s_end = min(ns, s0 + per_wave);
+    const uint32_t s = s0 + lane;
+    uint32_t n = 0, base = 0, pos = 0;
+    if (s < s_end) {
+        base = rs.base[s];
+        const uint32_t avail = rs.cnt[s] - base;
+        uint32_t newbase = base;
+        if (avail > rs.R) { n = rs.R; newbase = base + avail; }   // overran: the excess was diverted at append time
+        else if (final) { n = avail; newbase = base + n; }
+        else if (avail >= rs.R / 2) { n = avail & ~15u; newbase = base + n; }
+        if (n) { pos = written; written += n; rs.base[s] = newbase; }
+    }
+    unsigned long long todo = __ballot(n > 0);
+    while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t sl = s0 + (uint32_t)l;   // l is wave-uniform: v_readlane, not an LDS permute
+        const uint32_t nl = __builtin_amdgcn_readlane(n, l), bl = __builtin_amdgcn_readlane(base, l), pl = __builtin_amdgcn_readlane(pos, l);
+        for (uint32_t j = lane; j < nl; j += 64) emit(sl, pl + j, rs.ring[sl * rs.R + ((bl + j) & (rs.R - 1))]);
+    }
+}
+
+__device__ __forceinline__ void rings_store_counts(uint32_t ns, uint32_t written, uint32_t cap, uint32_t *counts, uint32_t stride, uint32_t writer)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const uint32_t per_wave = (ns + nwaves - 1) / nwaves;
+    const uint32_t s = wave * per_wave + lane;
+    if (lane < per_wave && s < ns) counts[(uint64_t)s * stride + writer] = written < cap ? written : cap;
+}
+
+// ---- stage A -----------------------------------------------------------------------------
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bin_hash(ReadsDev rd, uint32_t n_tiles, const SketchDev *__restrict__ sk,
+                                                      const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
     __shared__ TileShared sh;
-    __shared__ StreamsA st;
-    const int ns = g.T * g.C;
-    for (int s = threadIdx.x; s < BIN_NS; s += blockDim.x) { st.cnt[s] = 0; st.base[s] = 0; }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (threadIdx.x == 0) sh.ascii = (uint32_t *)smem;     // [0, tile_lds): staged ASCII; rings follow
+    const uint32_t ns = (uint32_t)(g.T * g.C);
+    Rings<uint32_t> rs;
+    rs.R = g.ringA;
+    rs.ring = (uint32_t *)(smem + g.tile_lds);
+    rs.cnt = rs.ring + (size_t)ns * rs.R;
+    rs.base = rs.cnt + ns;
+    for (uint32_t s = threadIdx.x; s < ns; s += THREADS) { rs.cnt[s] = 0; rs.base[s] = 0; }
     __syncthreads();
+    uint32_t written = 0;
+    auto emit = [&](uint32_t s, uint32_t pos, uint32_t item) {
+        if (pos < g.cap1) {
+            g.gbuf1[((uint64_t)s * g.nwgA + blockIdx.x) * g.cap1 + pos] = item;
+        } else {   // private segment full: keep the increment, apply it later with an atomic
+            const uint32_t t = s / (uint32_t)g.C, c = s % (uint32_t)g.C;
+            spill_item(g, (int)t, (((uint64_t)c * g.F + (item >> 16)) << 16) | (item & 0xffffu));
+        }
+    };
     uint64_t n_added = 0;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         uint32_t read0;
         const uint32_t nr = stage_tile(sh, rd, tile, f.hp.k, 0, 0, read0);
         const uint32_t total = sh.kpre[nr];
-        for (uint32_t q0 = 0; q0 < total; q0 += blockDim.x) {
+        for (uint32_t q0 = 0; q0 < total; q0 += THREADS) {
             const uint32_t q = q0 + threadIdx.x;
             if (q < total) {
                 uint32_t r, i;
@@ -130,18 +167,17 @@ __global__ __launch_bounds__(BIN_A_THREADS) void k_bin_hash(ReadsDev rd, uint32_
                         const uint32_t slice = (uint32_t)(bin >> 16);
                         const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
                         const uint32_t item = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu);
-                        const int s = t * g.C + (int)c;
-                        const uint32_t pos = atomicAdd(&st.cnt[s], 1u);
-                        if (pos - st.base[s] < g.ringA) st.ring[(uint32_t)s * g.ringA + (pos & (g.ringA - 1))] = item;
-                        else spill_item(g, t, bin);
+                        if (!ring_append(rs, (uint32_t)t * (uint32_t)g.C + c, item)) spill_item(g, t, bin);
                     }
                 }
             }
             __syncthreads();
-            flush_streams_a(st, g, ns, false);
+            rings_flush(rs, ns, false, written, emit);
+            __syncthreads();
         }
     }
-    flush_streams_a(st, g, ns, true);
+    rings_flush(rs, ns, true, written, emit);
+    rings_store_counts(ns, written, (uint32_t)g.cap1, g.gcnt1, g.nwgA, blockIdx.x);
     n_added = wave_sum_u64(n_added);
     if ((threadIdx.x & 63) == 0 && n_added) atomicAdd(&g.ctr[2], (unsigned long long)n_added);
 }
@@ -150,64 +186,59 @@ __global__ __launch_bounds__(BIN_A_THREADS) void k_bin_hash(ReadsDev rd, uint32_
 __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: ring[F][ringB] u16 | cnt[F] | base[F] | fl_n[F] | fl_pos[F] | fl_base[F]
-    const uint32_t R = g.ringB;
-    uint16_t *ring = (uint16_t *)smem;
-    uint32_t *cnt = (uint32_t *)(smem + (size_t)g.F * R * 2);
-    uint32_t *base = cnt + g.F, *fl_n = base + g.F, *fl_pos = fl_n + g.F, *fl_base = fl_pos + g.F;
-    const int s = blockIdx.y;                       // coarse stream = table * C + bucket
-    const int t = s / g.C, c = s % g.C;
-    uint64_t total = g.gcnt1[s];
-    if (total > g.cap1) total = g.cap1;
-    const uint64_t start = (uint64_t)blockIdx.x * BIN_B_CHUNK;
-    if (start >= total) return;
-    const uint64_t end = total < start + BIN_B_CHUNK ? total : start + BIN_B_CHUNK;
-    for (int fidx = threadIdx.x; fidx < g.F; fidx += blockDim.x) { cnt[fidx] = 0; base[fidx] = 0; }
+    const uint32_t s = blockIdx.y;                  // coarse stream = table * C + bucket
+    const uint32_t t = s / (uint32_t)g.C, c = s % (uint32_t)g.C;
+    const uint32_t F = (uint32_t)g.F;
+    Rings<uint16_t> rs;
+    rs.R = g.ringB;
+    rs.ring = (uint16_t *)smem;
+    rs.cnt = (uint32_t *)(smem + (((size_t)F * rs.R * 2 + 15) & ~(size_t)15));
+    rs.base = rs.cnt + F;
+    for (uint32_t i = threadIdx.x; i < F; i += BIN_B_THREADS) { rs.cnt[i] = 0; rs.base[i] = 0; }
     __syncthreads();
-    const uint32_t *src = g.gbuf1 + (uint64_t)s * g.cap1;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    for (uint64_t r0 = start; r0 < end; r0 += (uint64_t)blockDim.x * 4) {
-        const uint64_t i0 = r0 + (uint64_t)threadIdx.x * 4;
-        uint32_t items[4];
-        int have = 0;
-        if (i0 + 4 <= end) {
-            const uint4 v = *(const uint4 *)(src + i0);
-            items[0] = v.x; items[1] = v.y; items[2] = v.z; items[3] = v.w;
-            have = 4;
-        } else {
-            for (uint64_t i = i0; i < end; ++i) items[have++] = src[i];
-        }
-        for (int j = 0; j < have; ++j) {
-            const uint32_t fidx = items[j] >> 16, off = items[j] & 0xffffu;
-            const uint32_t pos = atomicAdd(&cnt[fidx], 1u);
-            if (pos - base[fidx] < R) ring[fidx * R + (pos & (R - 1))] = (uint16_t)off;
-            else spill_item(g, t, (((uint64_t)c * g.F + fidx) << 16) | off);
-        }
-        __syncthreads();
-        const bool final = r0 + (uint64_t)blockDim.x * 4 >= end;
-        for (int fidx = threadIdx.x; fidx < g.F; fidx += blockDim.x) {
-            const uint32_t b = base[fidx], avail = cnt[fidx] - b;
-            uint32_t n = 0, nb = b;
-            if (avail > R) { n = R; nb = cnt[fidx]; }
-            else if (final) { n = avail; nb = b + n; }
-            else if (avail >= R / 2) { n = avail & ~15u; nb = b + n; }
-            fl_n[fidx] = n;
-            fl_base[fidx] = b;
-            if (n) fl_pos[fidx] = atomicAdd(&g.gcnt2[(uint64_t)s * g.F + fidx], n);
-            base[fidx] = nb;
-        }
-        __syncthreads();
-        for (int fidx = wave; fidx < g.F; fidx += nwaves) {
-            const uint32_t n = fl_n[fidx];
-            for (uint32_t j = lane; j < n; j += 64) {
-                const uint16_t off = ring[fidx * R + ((fl_base[fidx] + j) & (R - 1))];
-                const uint64_t pos = (uint64_t)fl_pos[fidx] + j;
-                if (pos < g.cap2) g.gbuf2[((uint64_t)s * g.F + fidx) * g.cap2 + pos] = off;
-                else spill_item(g, t, (((uint64_t)c * g.F + fidx) << 16) | off);
+    uint32_t written = 0;
+    auto emit = [&](uint32_t fi, uint32_t pos, uint16_t off) {
+        if (pos < g.cap2) g.gbuf2[(((uint64_t)s * F + fi) * g.nwgB + blockIdx.x) * g.cap2 + pos] = off;
+        else spill_item(g, (int)t, (((uint64_t)c * F + fi) << 16) | off);
+    };
+    const uint64_t step = (uint64_t)BIN_B_THREADS * BIN_B_ITEMS;
+    // this workgroup drains the private segments seg = blockIdx.x, blockIdx.x + nwgB, ... of bucket s
+    for (uint32_t seg = blockIdx.x; seg < g.nwgA; seg += g.nwgB) {
+        uint64_t end = g.gcnt1[(uint64_t)s * g.nwgA + seg];
+        if (end > g.cap1) end = g.cap1;
+        const uint32_t *src = g.gbuf1 + ((uint64_t)s * g.nwgA + seg) * g.cap1;
+        uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+        auto fetch = [&](uint64_t r0, uint4 &a, uint4 &b) {
+            const uint64_t i0 = r0 + (uint64_t)threadIdx.x * BIN_B_ITEMS;
+            if (i0 + BIN_B_ITEMS <= end) { a = *(const uint4 *)(src + i0); b = *(const uint4 *)(src + i0 + 4); }
+        };
+        fetch(0, va, vb);
+        for (uint64_t r0 = 0; r0 < end; r0 += step) {
+            const uint64_t i0 = r0 + (uint64_t)threadIdx.x * BIN_B_ITEMS;
+            uint32_t items[BIN_B_ITEMS];
+            int have = 0;
+            if (i0 + BIN_B_ITEMS <= end) {
+                items[0] = va.x; items[1] = va.y; items[2] = va.z; items[3] = va.w;
+                items[4] = vb.x; items[5] = vb.y; items[6] = vb.z; items[7] = vb.w;
+                have = BIN_B_ITEMS;
+            } else {
+                for (uint64_t i = i0; i < end; ++i) items[have++] = src[i];
             }
+            if (r0 + step < end) fetch(r0 + step, va, vb);          // next round's items fly during this round
+#pragma unroll
+            for (int j = 0; j < BIN_B_ITEMS; ++j) {
+                if (j < have) {
+                    const uint32_t fi = items[j] >> 16, off = items[j] & 0xffffu;
+                    if (!ring_append(rs, fi, (uint16_t)off)) spill_item(g, (int)t, (((uint64_t)c * F + fi) << 16) | off);
+                }
+            }
+            __syncthreads();
+            rings_flush(rs, F, false, written, emit);
+            __syncthreads();
         }
-        __syncthreads();
     }
+    rings_flush(rs, F, true, written, emit);
+    rings_store_counts(F, written, (uint32_t)g.cap2, g.gcnt2 + (uint64_t)s * F * g.nwgB, g.nwgB, blockIdx.x);
 }
 
 // ---- stage C -----------------------------------------------------------------------------
@@ -243,9 +274,6 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
     if (slice >= g.nslices[t]) return;
     const uint32_t c = slice / (uint32_t)g.F, fidx = slice % (uint32_t)g.F;
     const uint64_t stream = ((uint64_t)t * g.C + c) * g.F + fidx;
-    uint64_t n = g.gcnt2[stream];
-    if (n > g.cap2) n = g.cap2;
-    if (n == 0) return;                                            // untouched slice: no traffic at all
     const int storage = sk->storage;
     const uint64_t bin0 = (uint64_t)slice << 16;
     const uint64_t left = sk->size[t] - bin0, nb = left < 65536 ? left : 65536;
@@ -255,13 +283,49 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
     const uint32_t nvec = (uint32_t)((nbytes + 15) / 16);
     uint4 *tab = (uint4 *)(sk->tab[t] + byte0);
     uint4 *l4 = (uint4 *)lds;
-    for (uint32_t i = threadIdx.x; i < nvec; i += blockDim.x) l4[i] = tab[i];
+    // the slice's items sit in nwgB private segments of cap2 slots (cap2 % 64 == 0: 128-B aligned);
+    // enumerate their 8-item vectors flat so all 512 threads stay busy whatever the segment sizes
+    const uint16_t *items = g.gbuf2 + stream * g.nwgB * g.cap2;
+    const uint32_t *counts = g.gcnt2 + stream * g.nwgB;
+    const uint32_t vps = (uint32_t)(g.cap2 / 8), nslots = vps * g.nwgB;
+    bool mine = false;
+    for (uint32_t j = threadIdx.x; j < g.nwgB; j += BIN_C_THREADS) mine |= counts[j] != 0;
+    if (!__syncthreads_or(mine)) return;                           // untouched slice: no table traffic at all
+    // software pipeline: the next vector of items is requested before the current one is applied
+    auto locate = [&](uint32_t v, uint32_t &n_left, const uint16_t *&p) {
+        n_left = 0;
+        if (v >= nslots) return;
+        const uint32_t seg = v / vps, j8 = (v - seg * vps) * 8;
+        const uint32_t n = counts[seg];
+        if (j8 >= n) return;
+        n_left = n - j8;
+        p = items + (uint64_t)seg * g.cap2 + j8;
+    };
+    uint32_t n_cur = 0, n_next = 0;
+    const uint16_t *p_cur = items, *p_next = items;
+    uint4 q_cur = make_uint4(0, 0, 0, 0), q_next = q_cur;
+    locate(threadIdx.x, n_cur, p_cur);
+    if (n_cur >= 8) q_cur = *(const uint4 *)p_cur;
+    for (uint32_t j = threadIdx.x; j < nvec; j += BIN_C_THREADS) l4[j] = tab[j];
     __syncthreads();
-    const uint16_t *items = g.gbuf2 + stream * g.cap2;
     uint32_t fresh = 0;
-    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) fresh += lds_inc(lds, items[i], storage) ? 1u : 0u;
+    for (uint32_t v = threadIdx.x; v < nslots; v += BIN_C_THREADS) {
+        locate(v + BIN_C_THREADS, n_next, p_next);
+        if (n_next >= 8) q_next = *(const uint4 *)p_next;
+        if (n_cur >= 8) {
+            const uint32_t w[4] = {q_cur.x, q_cur.y, q_cur.z, q_cur.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                fresh += lds_inc(lds, w[e] & 0xffffu, storage) ? 1u : 0u;
+                fresh += lds_inc(lds, w[e] >> 16, storage) ? 1u : 0u;
+            }
+        } else {
+            for (uint32_t e = 0; e < n_cur; ++e) fresh += lds_inc(lds, p_cur[e], storage) ? 1u : 0u;
+        }
+        n_cur = n_next; p_cur = p_next; q_cur = q_next;
+    }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nvec; i += blockDim.x) tab[i] = l4[i];
+    for (uint32_t j = threadIdx.x; j < nvec; j += BIN_C_THREADS) tab[j] = l4[j];
     if (t == 0) {
         const uint64_t tot = wave_sum_u64(fresh);
         if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&g.ctr[3], (unsigned long long)tot);
@@ -359,6 +423,7 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
     BinGeom g;
     memset(&g, 0, sizeof(g));
     g.T = s->h.ntables;
+    g.tile_lds = reads->tile_lds_bytes;
     uint64_t pmin = UINT64_MAX;
     uint32_t maxsl = 1;
     for (int t = 0; t < g.T; ++t) {
@@ -366,23 +431,37 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
         maxsl = std::max(maxsl, g.nslices[t]);
         pmin = std::min(pmin, s->h.size[t]);
     }
-    g.F = (int)((maxsl + BIN_C - 1) / BIN_C);
+    // 32 coarse buckets and 512-thread workgroups (two per CU) while the slices still fit F <= 512;
+    // 64 buckets / 1024 threads for tables beyond 2^30 bins
+    const int cmax = maxsl <= 32u * BIN_MAX_F ? 32 : BIN_C;
+    g.F = (int)((maxsl + (uint32_t)cmax - 1) / (uint32_t)cmax);
     g.C = (int)((maxsl + (uint32_t)g.F - 1) / (uint32_t)g.F);
-    auto ring_for = [](uint32_t streams) {
+    g.recipF = g.F == 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)g.F + 1);   // F == 1: kernels take slice as is
+    auto ring_for = [](uint32_t streams, uint32_t budget) {
         uint32_t r = BIN_RING_MIN;
-        while (r * 2 <= BIN_RING_MAX && (uint64_t)r * 2 * streams <= BIN_RING_BUDGET) r *= 2;
+        while (r * 2 <= BIN_RING_MAX && (uint64_t)r * 2 * streams <= budget) r *= 2;
         return r;
     };
-    g.ringA = ring_for((uint32_t)(g.T * g.C));
-    g.ringB = ring_for((uint32_t)g.F);
-    g.recipF = g.F == 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)g.F + 1);   // F == 1: kernels take slice as is
+    const uint32_t budgetA = cmax == 32 ? 8192u : 16384u;
+    g.ringA = ring_for((uint32_t)(g.T * g.C), budgetA);
+    g.ringB = ring_for((uint32_t)g.F, BIN_B_BUDGET);
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const double expected = (double)(nbands > 0 && !filter.use_mask ? n_kmers / (uint64_t)nbands + 1 : n_kmers);
-    g.cap1 = round_up((uint64_t)(expected * std::min(1.0, (double)g.F * 65536.0 / (double)pmin) * 1.03) + 65536, 64);
-    g.cap2 = round_up((uint64_t)(expected * std::min(1.0, 65536.0 / (double)pmin) * 1.10) + 2048, 64);
-    g.spill_cap = std::max<uint64_t>(1u << 20, (uint64_t)(expected * g.T / 8));
     const uint64_t ns = (uint64_t)g.T * g.C;
-    const size_t b_buf1 = round_up(ns * g.cap1 * 4, 256), b_buf2 = round_up(ns * g.F * g.cap2 * 2, 256);
-    const size_t b_cnt1 = round_up(ns * 4, 256), b_cnt2 = round_up(ns * g.F * 4, 256);
+    // writers: stage A = persistent workgroups (tiles dealt round-robin, so their loads are equal
+    // to within one tile); stage B = nwgB workgroups per coarse bucket, ~256 k items each
+    g.nwgA = std::min<uint32_t>(reads->n_tiles, (cmax == 32 ? 3u : 1u) * (uint32_t)cus);
+    const double per_bucket = expected * std::min(1.0, (double)g.F * 65536.0 / (double)pmin);
+    const double per_slice = expected * std::min(1.0, 65536.0 / (double)pmin);
+    g.nwgB = (uint32_t)std::max(1.0, std::min((double)std::min<uint32_t>(g.nwgA, 512), std::ceil(per_bucket / 524288.0)));
+    const double m1 = per_bucket / g.nwgA, m2 = per_slice / g.nwgB;
+    g.cap1 = round_up((uint64_t)(m1 * 1.05 + 8.0 * std::sqrt(m1)) + 2048, 64);
+    g.cap2 = round_up((uint64_t)(m2 * 1.05 + 8.0 * std::sqrt(m2)) + 64, 64);
+    g.spill_cap = std::max<uint64_t>(1u << 20, (uint64_t)(expected * g.T / 8));
+    const size_t b_buf1 = round_up(ns * g.nwgA * g.cap1 * 4, 256), b_buf2 = round_up(ns * g.F * g.nwgB * g.cap2 * 2, 256);
+    const size_t b_cnt1 = round_up(ns * g.nwgA * 4, 256), b_cnt2 = round_up(ns * g.F * g.nwgB * 4, 256);
     const size_t b_spill = round_up(g.spill_cap * 8, 256), b_ctr = 256;
     KV_HIP(g_scratch.need(b_buf1 + b_buf2 + b_cnt1 + b_cnt2 + b_spill + b_ctr));
     unsigned char *base = (unsigned char *)g_scratch.p;
@@ -392,25 +471,29 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
     g.gcnt2 = (uint32_t *)base; base += b_cnt2;
     g.spill = (unsigned long long *)base; base += b_spill;
     g.ctr = (unsigned long long *)base;
-    KV_HIP(hipMemsetAsync(g.gcnt1, 0, b_cnt1 + b_cnt2, st));
-    KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));
+    KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));   // every segment count is written by its owner: no other memset
 
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const SketchDev *d_mask = mask ? mask->d_desc : nullptr;
     {
         KvProfScope prof("k_bin_hash");
-        const unsigned grid = std::min<unsigned>(reads->n_tiles, (unsigned)cus);
-        hipLaunchKernelGGL(k_bin_hash, dim3(grid), dim3(BIN_A_THREADS), 0, st, reads_dev(reads), reads->n_tiles,
-                           (const SketchDev *)s->d_desc, d_mask, filter, g);
+        const size_t lds = (size_t)g.tile_lds + ns * g.ringA * 4 + ns * 8;
+        if (cmax == 32) {
+            const unsigned grid = g.nwgA;
+            (void)hipFuncSetAttribute((const void *)k_bin_hash<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_bin_hash<512>, dim3(grid), dim3(512), lds, st, reads_dev(reads), reads->n_tiles,
+                               (const SketchDev *)s->d_desc, d_mask, filter, g);
+        } else {
+            const unsigned grid = g.nwgA;
+            (void)hipFuncSetAttribute((const void *)k_bin_hash<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_bin_hash<1024>, dim3(grid), dim3(1024), lds, st, reads_dev(reads), reads->n_tiles,
+                               (const SketchDev *)s->d_desc, d_mask, filter, g);
+        }
     }
     {
         KvProfScope prof("k_bin_split");
-        const unsigned chunks = (unsigned)((g.cap1 + BIN_B_CHUNK - 1) / BIN_B_CHUNK);
-        const size_t lds = (size_t)g.F * g.ringB * 2 + (size_t)g.F * 5 * 4;
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_bin_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_bin_split, dim3(chunks, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
+        const size_t lds = (((size_t)g.F * g.ringB * 2 + 15) & ~(size_t)15) + (size_t)g.F * 2 * 4;
+        (void)hipFuncSetAttribute((const void *)k_bin_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_bin_split, dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
     }
     KV_HIP(hipGetLastError());
     unsigned long long ctr[4] = {0, 0, 0, 0};

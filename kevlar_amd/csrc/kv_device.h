@@ -170,8 +170,9 @@ __device__ __forceinline__ bool sketch_add(const SketchDev *s, uint64_t h)
 // ---------------------------------------------------------------------------------------
 // tile staging: packed words (HBM) -> ASCII forward + reverse complement (LDS)
 // ---------------------------------------------------------------------------------------
+// (the ASCII itself lives in dynamic LDS: kv_reads::tile_lds_bytes, so one long read can own a big tile)
 struct TileShared {
-    uint32_t ascii[KV_TILE_LDS_BYTES / 4];
+    uint32_t *ascii;
     uint32_t foff[KV_TILE_MAX_READS];      // LDS byte offset of the forward strand
     uint32_t roff[KV_TILE_MAX_READS];      // ... of the reverse complement
     uint32_t len[KV_TILE_MAX_READS];

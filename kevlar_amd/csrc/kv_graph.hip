@@ -187,6 +187,8 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_first_touch(ReadsDev rd, co
                                                                 const SketchDev *__restrict__ mask, FirstTouchParams p)
 {
     __shared__ TileShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+    if (threadIdx.x == 0) sh.ascii = (uint32_t *)tile_smem;
     uint32_t read0;
     const uint32_t nr = stage_tile(sh, rd, blockIdx.x, p.f.hp.k, 0, 0, read0);
     const uint32_t total = sh.kpre[nr];
@@ -379,7 +381,8 @@ extern "C" int kv_unique_exact(kv_sketch *s, const kv_reads *const *batches, int
         p.kprefix = d_kpre.as<uint64_t>();
         if (r->n_tiles) {
             KvProfScope prof("k_first_touch");
-            hipLaunchKernelGGL(k_first_touch, dim3(r->n_tiles), dim3(KV_TILE_THREADS), 0, st, reads_dev(r),
+            (void)hipFuncSetAttribute((const void *)k_first_touch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->tile_lds_bytes);
+            hipLaunchKernelGGL(k_first_touch, dim3(r->n_tiles), dim3(KV_TILE_THREADS), r->tile_lds_bytes, st, reads_dev(r),
                                (const SketchDev *)s->d_desc, (const SketchDev *)(mask ? mask->d_desc : nullptr), p);
         }
         KV_HIP(hipGetLastError());

@@ -1,5 +1,6 @@
 // kv_host.hip -- host side of libkvsketch_hip: handles, OXLI v4 file I/O, table sizing,
 // read packing and the live profiler.  All table memory is HBM (hipMalloc).
+#include <algorithm>
 #include <cstdarg>
 #include <map>
 
@@ -523,20 +524,23 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
         }
         flags[i] = flag;
     }
-    // tiles: consecutive reads whose staged ASCII (both strands, padded) fits the LDS budget
+    // tiles: consecutive reads whose staged ASCII (both strands, padded) fits the LDS budget; a read
+    // that alone exceeds the budget gets a tile of its own and raises the batch's dynamic LDS size
     {
-        uint32_t used = 0, count = 0;
+        uint32_t used = 0, count = 0, biggest = 0;
         tiles.push_back(0);
         for (uint64_t i = 0; i < n_reads; ++i) {
             uint32_t need = 2 * ((r->h_len[i] + KV_READ_PAD + 3) & ~3u);
-            if (count == KV_TILE_MAX_READS || used + need > KV_TILE_LDS_BYTES - 64) {
+            if (count > 0 && (count == KV_TILE_MAX_READS || used + need > KV_TILE_LDS_BYTES - 64)) {
                 tiles.push_back((uint32_t)i);
                 used = 0; count = 0;
             }
             used += need; count += 1;
+            if (used > biggest) biggest = used;
         }
         if (n_reads) tiles.push_back((uint32_t)n_reads);
         r->n_tiles = (uint32_t)tiles.size() - 1;
+        r->tile_lds_bytes = std::max<uint32_t>(KV_TILE_LDS_BYTES, (biggest + 64 + 255) & ~255u);
     }
     hipError_t e = hipMalloc((void **)&r->d_words, words.size() * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
@@ -572,10 +576,12 @@ extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, u
     const uint32_t need = 2 * ((read_len + KV_READ_PAD + 3) & ~3u);
     uint32_t per_tile = (KV_TILE_LDS_BYTES - 64) / need;
     if (per_tile > KV_TILE_MAX_READS) per_tile = KV_TILE_MAX_READS;
+    if (per_tile < 1) per_tile = 1;
     std::vector<uint32_t> tiles;
     for (uint64_t i = 0; i < n_reads; i += per_tile) tiles.push_back((uint32_t)i);
     tiles.push_back((uint32_t)n_reads);
     r->n_tiles = n_reads ? (uint32_t)tiles.size() - 1 : 0;
+    r->tile_lds_bytes = std::max<uint32_t>(KV_TILE_LDS_BYTES, (per_tile * need + 64 + 255) & ~255u);
     hipError_t e = hipMalloc((void **)&r->d_words, (r->n_words ? r->n_words : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);

@@ -60,6 +60,7 @@ struct kv_reads {
     uint8_t *d_flags;   // n_reads: bit0 = contains a base outside ACGT (novel scan skips it)
     uint32_t *d_tile;   // n_tiles + 1 read indices: tile t = reads [d_tile[t], d_tile[t+1])
     uint32_t n_tiles;
+    uint32_t tile_lds_bytes;  // dynamic LDS the tile kernels need for this batch (>= KV_TILE_LDS_BYTES)
     uint32_t max_len;
     std::vector<uint32_t> h_len;    // host copies (k-mer counting, hit bookkeeping)
 };
@@ -93,10 +94,10 @@ double kv_estimate_distinct(uint64_t occupied, uint64_t size);
 
 // tile geometry of the hashing kernels
 #define KV_TILE_THREADS 256
-#define KV_TILE_MAX_READS 128
-#define KV_TILE_LDS_BYTES 40960  // ASCII staging (forward + reverse complement) per tile
+#define KV_TILE_MAX_READS 64
+#define KV_TILE_LDS_BYTES 16384  // ASCII staging (forward + reverse complement) per tile: 64 reads of 100 bp
 #define KV_READ_PAD 24           // over-read slack after each staged strand
-#define KV_MAX_READ_LEN ((KV_TILE_LDS_BYTES - 64) / 2 - KV_READ_PAD - 8)
+#define KV_MAX_READ_LEN 49000    // a longer read would not fit one workgroup's LDS next to the partition rings
 
 // error plumbing -------------------------------------------------------------------------
 void kv_set_error(const char *fmt, ...);

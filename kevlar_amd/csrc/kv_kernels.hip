@@ -23,6 +23,8 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_consume(ReadsDev rd, const 
                                                             uint64_t *counters)
 {
     __shared__ TileShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+    if (threadIdx.x == 0) sh.ascii = (uint32_t *)tile_smem;
     uint32_t read0;
     const uint32_t nr = stage_tile(sh, rd, blockIdx.x, p.hp.k, 0, 0, read0);
     const uint32_t total = sh.kpre[nr];
@@ -186,7 +188,8 @@ extern "C" int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int b
     KV_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(uint64_t), kv_stream()));
     if (reads->n_tiles > 0) {
         KvProfScope prof("k_consume");
-        hipLaunchKernelGGL(k_consume, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), 0, kv_stream(), reads_dev(reads),
+        (void)hipFuncSetAttribute((const void *)k_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads->tile_lds_bytes);
+        hipLaunchKernelGGL(k_consume, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, kv_stream(), reads_dev(reads),
                            (const SketchDev *)s->d_desc, (const SketchDev *)(mask ? mask->d_desc : nullptr), p,
                            s->d_counters);
     }

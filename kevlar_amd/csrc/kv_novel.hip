@@ -74,6 +74,8 @@ __device__ __forceinline__ bool novel_test(const NovelParams &p, uint64_t h, boo
 __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_mark(ReadsDev rd, NovelParams p)
 {
     __shared__ TileShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+    if (threadIdx.x == 0) sh.ascii = (uint32_t *)tile_smem;
     __shared__ uint32_t tile_hits;
     uint32_t read0;
     if (threadIdx.x == 0) tile_hits = 0;
@@ -136,6 +138,8 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_emit(ReadsDev rd, Nov
     __shared__ TileShared sh;
     __shared__ uint32_t wcount[KV_TILE_THREADS / 64];
     if (p.tile_count[blockIdx.x] == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+    if (threadIdx.x == 0) sh.ascii = (uint32_t *)tile_smem;
     uint32_t read0;
     const uint32_t nr = stage_tile(sh, rd, blockIdx.x, p.hp.k, 1, p.first_read, read0);
     const uint32_t total = sh.kpre[nr];
@@ -243,7 +247,8 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     if (e == hipSuccess) {
         {
             KvProfScope prof("k_novel_mark");
-            hipLaunchKernelGGL(k_novel_mark, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), 0, st, reads_dev(reads), p);
+            (void)hipFuncSetAttribute((const void *)k_novel_mark, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads->tile_lds_bytes);
+            hipLaunchKernelGGL(k_novel_mark, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, st, reads_dev(reads), p);
         }
         {
             KvProfScope prof("k_tile_scan");
@@ -260,7 +265,8 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         p.hit_read = d_read.as<uint32_t>(); p.hit_off = d_off.as<uint32_t>(); p.hit_abund = d_abund.as<uint8_t>();
         if (e == hipSuccess) {
             KvProfScope prof("k_novel_emit");
-            hipLaunchKernelGGL(k_novel_emit, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), 0, st, reads_dev(reads), p);
+            (void)hipFuncSetAttribute((const void *)k_novel_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads->tile_lds_bytes);
+            hipLaunchKernelGGL(k_novel_emit, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, st, reads_dev(reads), p);
             e = hipGetLastError();
         }
         hits->read.resize(nhits); hits->offset.resize(nhits); hits->abund.resize(nhits * (uint64_t)S);

@@ -267,3 +267,27 @@ def test_exact_unique_matches_single_thread_oracle(hk, ok):
         ok.consume_reads(ref, bases, offs, len(reads), nbands, band)
         assert dev.n_unique_kmers() == ref.n_unique_kmers()
         assert dev.n_occupied() == ref.n_occupied()
+
+
+def test_long_sequences_get_their_own_tile(hk, ok):
+    """FASTA records of tens of kilobases (the reference counts bogus-genome/refr.fa, 3 x 12 kb)
+    ride in a tile of their own with a larger dynamic LDS allocation."""
+    rng = np.random.default_rng(4)
+    letters = np.array(list('ACGT'))
+    reads = [''.join(letters[rng.integers(0, 4, size=n)]) for n in (12345, 100, 40000, 31, 30, 48999, 250)]
+    for path in ('atomic', 'binned'):
+        os.environ['KV_COUNT_PATH'] = path
+        try:
+            dev, ref = hk.Counttable(31, 3e5, 4), ok.Counttable(31, 3e5, 4)
+            n_dev = dev.consume_batch(hk.ReadBatch(reads))
+        finally:
+            os.environ.pop('KV_COUNT_PATH', None)
+        bases, offs = ok.concat_reads(reads)
+        assert n_dev == ok.consume_reads(ref, bases, offs, len(reads))
+        for t in range(4):
+            assert dev.table_bytes(t) == ref.table_bytes(t)
+    r, o, a, _ = hk.novel_scan([dev], [], hk.ReadBatch(reads), 1, 0)
+    hits, _ = ok.novel_scan([ref], [], bases, offs, len(reads), 31, 1, 0)
+    assert [(int(x), int(y)) for x, y in zip(r, o)] == [(h[0], h[1]) for h in hits]
+    with pytest.raises(ValueError, match='reads up to'):
+        hk.ReadBatch(['A' * 60000])
