@@ -46,6 +46,7 @@ struct BinGeom {
     uint32_t recipF;                 // floor(2^32 / F) + 1: slice / F by multiply-high
     uint32_t nslices[BIN_MAX_T];
     uint32_t tile_lds;               // bytes of dynamic LDS in front of the stage-A rings
+    uint32_t debug;                  // KV_BIN_DEBUG: 1 = skip ring appends, 2 = skip burst stores (timing experiments only)
     uint32_t nwgA, nwgB;             // writers per coarse bucket (stage-A workgroups) / per slice (stage-B workgroups of the bucket)
     uint64_t cap1, cap2, spill_cap;  // items per PRIVATE segment: every writer owns its own region of every stream,
                                      // so appending needs no global atomic (and no round trip) at all
@@ -81,7 +82,7 @@ __device__ __forceinline__ bool ring_append(const Rings<ItemT> &rs, uint32_t s, 
 {
     const uint32_t pos = atomicAdd(&rs.cnt[s], 1u);
     if (pos - rs.base[s] >= rs.R) return false;
-    rs.ring[s * rs.R + (pos & (rs.R - 1))] = item;
+    rs.ring[s * rs.R + ((pos + s) & (rs.R - 1))] = item;   // + s: streams fill in step, so unskewed slots would share LDS banks
     return true;
 }
 
@@ -110,7 +111,7 @@ __device__ __forceinline__ void rings_flush(const Rings<ItemT> &rs, uint32_t ns,
         todo &= todo - 1;
         const uint32_t sl = s0 + (uint32_t)l;   // l is wave-uniform: v_readlane, not an LDS permute
         const uint32_t nl = __builtin_amdgcn_readlane(n, l), bl = __builtin_amdgcn_readlane(base, l), pl = __builtin_amdgcn_readlane(pos, l);
-        for (uint32_t j = lane; j < nl; j += 64) emit(sl, pl + j, rs.ring[sl * rs.R + ((bl + j) & (rs.R - 1))]);
+        for (uint32_t j = lane; j < nl; j += 64) emit(sl, pl + j, rs.ring[sl * rs.R + ((bl + j + sl) & (rs.R - 1))]);
     }
 }
 
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_hash(ReadsDev rd, uint32_t n_ti
     __syncthreads();
     uint32_t written = 0;
     auto emit = [&](uint32_t s, uint32_t pos, uint32_t item) {
+        if (g.debug & 2u) return;
         if (pos < g.cap1) {
             g.gbuf1[((uint64_t)s * g.nwgA + blockIdx.x) * g.cap1 + pos] = item;
         } else {   // private segment full: keep the increment, apply it later with an atomic
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_hash(ReadsDev rd, uint32_t n_ti
                         const uint32_t slice = (uint32_t)(bin >> 16);
                         const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
                         const uint32_t item = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu);
+                        if (g.debug & 1u) { n_added += item & 1u; continue; }
                         if (!ring_append(rs, (uint32_t)t * (uint32_t)g.C + c, item)) spill_item(g, t, bin);
                     }
                 }
@@ -424,6 +427,7 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
     memset(&g, 0, sizeof(g));
     g.T = s->h.ntables;
     g.tile_lds = reads->tile_lds_bytes;
+    g.debug = getenv("KV_BIN_DEBUG") ? (uint32_t)atoi(getenv("KV_BIN_DEBUG")) : 0u;
     uint64_t pmin = UINT64_MAX;
     uint32_t maxsl = 1;
     for (int t = 0; t < g.T; ++t) {

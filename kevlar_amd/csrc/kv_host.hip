@@ -624,9 +624,14 @@ extern "C" int kv_reads_count(const kv_reads *r, uint64_t *n_reads, uint64_t *n_
 extern "C" int kv_reads_num_kmers(const kv_reads *r, int ksize, uint64_t *n_kmers)
 {
     KV_REQUIRE(r && n_kmers && ksize >= 1, KV_ERR_ARG, "kv_reads_num_kmers: bad argument");
-    uint64_t n = 0;
-    for (uint32_t len : r->h_len)
-        if (len >= (uint32_t)ksize) n += len - (uint32_t)ksize + 1;
-    *n_kmers = n;
+    if (r->nk_cached_k != ksize) {
+        uint64_t n = 0;
+        for (uint32_t len : r->h_len)
+            if (len >= (uint32_t)ksize) n += len - (uint32_t)ksize + 1;
+        kv_reads *w = const_cast<kv_reads *>(r);
+        w->nk_cached = n;
+        w->nk_cached_k = ksize;
+    }
+    *n_kmers = r->nk_cached;
     return KV_OK;
 }

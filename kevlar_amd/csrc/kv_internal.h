@@ -63,6 +63,8 @@ struct kv_reads {
     uint32_t tile_lds_bytes;  // dynamic LDS the tile kernels need for this batch (>= KV_TILE_LDS_BYTES)
     uint32_t max_len;
     std::vector<uint32_t> h_len;    // host copies (k-mer counting, hit bookkeeping)
+    int nk_cached_k = -1;           // kv_reads_num_kmers memo (the length vector can hold 1e7+ entries)
+    uint64_t nk_cached = 0;
 };
 
 struct kv_hits {
