@@ -33,11 +33,11 @@ namespace {
 #define BIN_C 64            // most coarse buckets per table
 #define BIN_MAX_T 4         // tables handled by the partitioned path
 #define BIN_RING_MIN 64
-#define BIN_RING_MAX 4096   // a round appends at most 2048 items to one stream
+#define BIN_RING_MAX 4096   // a round appends at most 4096 items to one stream
 #define BIN_B_THREADS 512   // 8 waves: one lane per slice stream for F <= 512
 #define BIN_B_ITEMS 8       // items per thread per round in stage B
 #define BIN_B_BUDGET 16384  // LDS ring entries (u16) per stage-B workgroup
-#define BIN_C_THREADS 512
+#define BIN_C_THREADS 1024
 #define BIN_MAX_F 512
 
 struct BinGeom {
@@ -124,7 +124,7 @@ __device__ __forceinline__ void rings_store_counts(uint32_t ns, uint32_t written
 }
 
 // ---- stage A -----------------------------------------------------------------------------
-template <int THREADS>
+template <int THREADS, int KPT>
 __global__ __launch_bounds__(THREADS) void k_bin_hash(ReadsDev rd, uint32_t n_tiles, const SketchDev *__restrict__ sk,
                                                       const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
@@ -154,24 +154,42 @@ __global__ __launch_bounds__(THREADS) void k_bin_hash(ReadsDev rd, uint32_t n_ti
         uint32_t read0;
         const uint32_t nr = stage_tile(sh, rd, tile, f.hp.k, 0, 0, read0);
         const uint32_t total = sh.kpre[nr];
-        for (uint32_t q0 = 0; q0 < total; q0 += THREADS) {
-            const uint32_t q = q0 + threadIdx.x;
-            if (q < total) {
+        for (uint32_t q0 = 0; q0 < total; q0 += THREADS * KPT) {
+#pragma unroll
+            for (int rep = 0; rep < KPT; ++rep) {
+                const uint32_t q = q0 + (uint32_t)rep * THREADS + threadIdx.x;
+                if (q >= total) continue;
                 uint32_t r, i;
                 locate_kmer(sh, nr, q, r, i);
                 const uint32_t fwd = sh.foff[r] + i;
                 const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)f.hp.k - i);
                 const uint64_t h = kmer_hash_lds(sh.ascii, fwd, rc, f.hp);
-                if (consume_filter_pass(f, mask, h)) {
-                    n_added += 1;
-                    for (int t = 0; t < g.T; ++t) {
-                        const uint64_t bin = fastmod(h, sk->size[t], sk->magic[t]);
-                        const uint32_t slice = (uint32_t)(bin >> 16);
-                        const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
-                        const uint32_t item = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu);
-                        if (g.debug & 1u) { n_added += item & 1u; continue; }
-                        if (!ring_append(rs, (uint32_t)t * (uint32_t)g.C + c, item)) spill_item(g, t, bin);
-                    }
+                if (!consume_filter_pass(f, mask, h)) continue;
+                n_added += 1;
+                // all T ring positions are requested back to back (independent LDS atomics in flight
+                // together) before any of them is consumed
+                uint32_t sidx[BIN_MAX_T], item[BIN_MAX_T], pos[BIN_MAX_T];
+                uint64_t bins[BIN_MAX_T];
+#pragma unroll
+                for (int t = 0; t < BIN_MAX_T; ++t) {
+                    if (t >= g.T) break;
+                    const uint64_t bin = fastmod(h, sk->size[t], sk->magic[t]);
+                    const uint32_t slice = (uint32_t)(bin >> 16);
+                    const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
+                    bins[t] = bin;
+                    item[t] = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu);
+                    sidx[t] = (uint32_t)t * (uint32_t)g.C + c;
+                }
+                if (g.debug & 1u) { n_added += item[0] & 1u; continue; }
+#pragma unroll
+                for (int t = 0; t < BIN_MAX_T; ++t)
+                    if (t < g.T) pos[t] = atomicAdd(&rs.cnt[sidx[t]], 1u);
+#pragma unroll
+                for (int t = 0; t < BIN_MAX_T; ++t) {
+                    if (t >= g.T) break;
+                    const uint32_t s_ = sidx[t];
+                    if (pos[t] - rs.base[s_] < rs.R) rs.ring[s_ * rs.R + ((pos[t] + s_) & (rs.R - 1))] = item[t];
+                    else spill_item(g, t, bins[t]);
                 }
             }
             __syncthreads();
@@ -437,6 +455,8 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
     }
     // 32 coarse buckets and 512-thread workgroups (two per CU) while the slices still fit F <= 512;
     // 64 buckets / 1024 threads for tables beyond 2^30 bins
+    // 32 buckets, 512-thread workgroups (three per CU) while F <= 512 allows; 64 buckets / 1024 threads beyond 2^30 bins
+    // (a 16-bucket / 2-k-mers-per-thread variant measured slower overall: stage B pays for the wider fan-out)
     const int cmax = maxsl <= 32u * BIN_MAX_F ? 32 : BIN_C;
     g.F = (int)((maxsl + (uint32_t)cmax - 1) / (uint32_t)cmax);
     g.C = (int)((maxsl + (uint32_t)g.F - 1) / (uint32_t)g.F);
@@ -446,7 +466,7 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
         while (r * 2 <= BIN_RING_MAX && (uint64_t)r * 2 * streams <= budget) r *= 2;
         return r;
     };
-    const uint32_t budgetA = cmax == 32 ? 8192u : 16384u;
+    const uint32_t budgetA = cmax <= 32 ? 8192u : 16384u;
     g.ringA = ring_for((uint32_t)(g.T * g.C), budgetA);
     g.ringB = ring_for((uint32_t)g.F, BIN_B_BUDGET);
     int dev = 0, cus = 256;
@@ -456,7 +476,7 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
     const uint64_t ns = (uint64_t)g.T * g.C;
     // writers: stage A = persistent workgroups (tiles dealt round-robin, so their loads are equal
     // to within one tile); stage B = nwgB workgroups per coarse bucket, ~256 k items each
-    g.nwgA = std::min<uint32_t>(reads->n_tiles, (cmax == 32 ? 3u : 1u) * (uint32_t)cus);
+    g.nwgA = std::min<uint32_t>(reads->n_tiles, (cmax <= 32 ? 3u : 1u) * (uint32_t)cus);
     const double per_bucket = expected * std::min(1.0, (double)g.F * 65536.0 / (double)pmin);
     const double per_slice = expected * std::min(1.0, 65536.0 / (double)pmin);
     g.nwgB = (uint32_t)std::max(1.0, std::min((double)std::min<uint32_t>(g.nwgA, 512), std::ceil(per_bucket / 524288.0)));
@@ -481,15 +501,18 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
     {
         KvProfScope prof("k_bin_hash");
         const size_t lds = (size_t)g.tile_lds + ns * g.ringA * 4 + ns * 8;
-        if (cmax == 32) {
-            const unsigned grid = g.nwgA;
-            (void)hipFuncSetAttribute((const void *)k_bin_hash<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_bin_hash<512>, dim3(grid), dim3(512), lds, st, reads_dev(reads), reads->n_tiles,
+        const unsigned grid = g.nwgA;
+        if (cmax == 16) {
+            (void)hipFuncSetAttribute((const void *)k_bin_hash<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_bin_hash<512, 2>), dim3(grid), dim3(512), lds, st, reads_dev(reads), reads->n_tiles,
+                               (const SketchDev *)s->d_desc, d_mask, filter, g);
+        } else if (cmax == 32) {
+            (void)hipFuncSetAttribute((const void *)k_bin_hash<512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_bin_hash<512, 1>), dim3(grid), dim3(512), lds, st, reads_dev(reads), reads->n_tiles,
                                (const SketchDev *)s->d_desc, d_mask, filter, g);
         } else {
-            const unsigned grid = g.nwgA;
-            (void)hipFuncSetAttribute((const void *)k_bin_hash<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_bin_hash<1024>, dim3(grid), dim3(1024), lds, st, reads_dev(reads), reads->n_tiles,
+            (void)hipFuncSetAttribute((const void *)k_bin_hash<1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_bin_hash<1024, 1>), dim3(grid), dim3(1024), lds, st, reads_dev(reads), reads->n_tiles,
                                (const SketchDev *)s->d_desc, d_mask, filter, g);
         }
     }
