@@ -177,10 +177,19 @@ def main():
     stage = 'count' if dominant in groups['count'] else 'novel'
     stage_ms = sum(times[n_][0] for n_ in groups[stage]) / max(1, launches)
     achieved = alg[dominant] / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
+    traffic = None
+    pmc_file = os.path.join(ROOT, 'profiles', 'r1_partitioned', 'pmc_hbm_bytes.json')
+    if world == 1 and os.path.exists(pmc_file) and (args.genome_mb, args.coverage, k, args.memory) == (25.0, 30.0, 31, 2e9):
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (profiles/README.md):
+        # FETCH_SIZE doubled for the wide coalesced streams of the k_bin_* kernels, as the guide prescribes
+        pmc = json.load(open(pmc_file)).get(dominant)
+        if pmc:
+            fetch = pmc.get('FETCH_SIZE_KB_per_launch_avg', 0.0) * (2.0 if dominant.startswith('k_bin_') else 1.0)
+            traffic = int((fetch + pmc.get('WRITE_SIZE_KB_per_launch_avg', 0.0)) * 1024)
     roofline = {
         'bound': 'hbm', 'kernel': dominant, 'stage': stage,
         'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+        'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
         'avg_launch_ms': round(avg_ms, 4), 'stage_ms_per_sample': round(stage_ms, 4), 'launches': int(launches),
         'algorithmic_bytes_per_launch': int(alg[dominant]),
         'note': 'achieved = algorithmic bytes of one sample / summed duration of all kernels of that stage',
