@@ -65,8 +65,12 @@ const char *kv_last_error(void);
 const char *kv_version(void);
 int kv_device_count(int *n);
 int kv_set_device(int device);       /* one process per GPU: call once with LOCAL_RANK      */
-int kv_set_stream(void *hip_stream); /* hipStream_t; NULL = null stream                     */
+int kv_set_stream(void *hip_stream); /* hipStream_t for the CALLING host thread; NULL = null stream */
 int kv_synchronize(void);
+/* streams for host threads that count different samples at the same time (kevlar/novel.py:64-72
+ * counts its samples one after the other; their kernels are independent)                     */
+int kv_stream_create(void **out);
+int kv_stream_destroy(void *hip_stream);
 
 /* live per-kernel timing with HIP events on the library's stream (bench.py roofline leg).
  * kv_prof_get: accumulated milliseconds and launch count for a kernel name.             */

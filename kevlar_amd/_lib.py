@@ -41,6 +41,8 @@ SIGNATURES = {
     'kv_set_device': (i32, [i32]),
     'kv_set_stream': (i32, [vp]),
     'kv_synchronize': (i32, []),
+    'kv_stream_create': (i32, [vpp]),
+    'kv_stream_destroy': (i32, [vp]),
     'kv_prof_enable': (i32, [i32]),
     'kv_prof_reset': (i32, []),
     'kv_prof_get': (i32, [cstr, ctypes.POINTER(ctypes.c_double), u64p]),

@@ -8,7 +8,7 @@ from kevlar_amd.sketch import allocate, get_extension
 
 def load_sample_seqfile(seqfiles, ksize, memory, maxfpr=0.2, count=True, smallcount=False,
                         mask=None, maskmaxabund=0, consume_masked=False, numbands=None,
-                        band=None, outfile=None, numthreads=1):
+                        band=None, outfile=None, numthreads=1, log=None):
     """Count the k-mers of one sample (one or more FASTA/FASTQ files) into a fresh sketch.
 
     tablesize = memory / 4 * buckets-per-byte, four tables (kevlar/count.py:29-35); the hot
@@ -16,6 +16,7 @@ def load_sample_seqfile(seqfiles, ksize, memory, maxfpr=0.2, count=True, smallco
     as the reference's threads do; with one thread the "distinct k-mers stored" figure is the
     exact single-thread value.
     """
+    log = log or kevlar_amd.plog
     numtables = 4
     sketchtype = 'nodegraph'
     if count:
@@ -26,7 +27,7 @@ def load_sample_seqfile(seqfiles, ksize, memory, maxfpr=0.2, count=True, smallco
         sketch.track_exact_unique(True)
     numreads = 0
     for seqfile in seqfiles:
-        kevlar_amd.plog('[kevlar::count]', '- processing "{}"'.format(seqfile))
+        log('[kevlar::count]', '- processing "{}"'.format(seqfile))
         parser = khmer.ReadParser(seqfile)
         if mask:
             kwargs = {'consume_masked': consume_masked,
@@ -82,7 +83,7 @@ def load_sample_seqfile(seqfiles, ksize, memory, maxfpr=0.2, count=True, smallco
             outfile += extensions[1]
         sketch.save(outfile)
         message += ';\n    saved to "{:s}"'.format(outfile)
-    kevlar_amd.plog('[kevlar::count]', message)
+    log('[kevlar::count]', message)
     return sketch
 
 

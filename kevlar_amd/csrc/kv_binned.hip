@@ -25,6 +25,7 @@
 // if even that overflows, the launcher reports it and kv_consume falls back to k_consume.
 #include <algorithm>
 #include <cmath>
+#include <map>
 
 #include "kv_device.h"
 
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
     __shared__ __attribute__((aligned(16))) uint32_t lds[16384];   // one slice: 65536 counters of <= 8 bits
     const int t = blockIdx.y;
     const uint32_t slice = blockIdx.x;
-    if (slice >= g.nslices[t]) return;
+    if (slice >= g.nslices[t] || g.ctr[1] != 0) return;    // overflow flag: leave the tables untouched for the fallback
     const uint32_t c = slice / (uint32_t)g.F, fidx = slice % (uint32_t)g.F;
     const uint64_t stream = ((uint64_t)t * g.C + c) * g.F + fidx;
     const int storage = sk->storage;
@@ -380,6 +381,7 @@ __device__ __forceinline__ bool table_inc_bin(const SketchDev *s, int t, uint64_
 
 __global__ void k_bin_spill(const SketchDev *__restrict__ sk, BinGeom g)
 {
+    if (g.ctr[1] != 0) return;
     unsigned long long n = g.ctr[0];
     if (n > g.spill_cap) n = g.spill_cap;
     uint64_t fresh = 0;
@@ -407,8 +409,40 @@ struct Scratch {
         return e;
     }
 };
-Scratch g_scratch;
+// one grow-only arena per stream, so host threads counting different samples do not share buffers
+std::map<hipStream_t, Scratch> g_scratch;
 std::mutex g_scratch_mu;
+
+Scratch &scratch_for(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    return g_scratch[st];
+}
+
+template <typename K>
+void ensure_dynamic_lds(K kernel, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<const void *, size_t> granted;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t &have = granted[(const void *)kernel];
+    if (bytes > have) {
+        (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        have = bytes;
+    }
+}
+
+int device_cus()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        cus = n;
+    }
+    return cus;
+}
 
 inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
 
@@ -439,8 +473,8 @@ bool kv_binned_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_km
 int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &filter, const kv_sketch *mask,
                       uint64_t n_kmers, int nbands, uint64_t *n_added)
 {
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
     hipStream_t st = kv_stream();
+    Scratch &scratch = scratch_for(st);
     BinGeom g;
     memset(&g, 0, sizeof(g));
     g.T = s->h.ntables;
@@ -469,14 +503,12 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
     const uint32_t budgetA = cmax <= 32 ? 8192u : 16384u;
     g.ringA = ring_for((uint32_t)(g.T * g.C), budgetA);
     g.ringB = ring_for((uint32_t)g.F, BIN_B_BUDGET);
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = device_cus();
     const double expected = (double)(nbands > 0 && !filter.use_mask ? n_kmers / (uint64_t)nbands + 1 : n_kmers);
     const uint64_t ns = (uint64_t)g.T * g.C;
     // writers: stage A = persistent workgroups (tiles dealt round-robin, so their loads are equal
     // to within one tile); stage B = nwgB workgroups per coarse bucket, ~256 k items each
-    g.nwgA = std::min<uint32_t>(reads->n_tiles, (cmax <= 32 ? 3u : 1u) * (uint32_t)cus);
+    g.nwgA = std::min<uint32_t>(reads->n_tiles, (cmax <= 32 ? 2u : 1u) * (uint32_t)cus);
     const double per_bucket = expected * std::min(1.0, (double)g.F * 65536.0 / (double)pmin);
     const double per_slice = expected * std::min(1.0, 65536.0 / (double)pmin);
     g.nwgB = (uint32_t)std::max(1.0, std::min((double)std::min<uint32_t>(g.nwgA, 512), std::ceil(per_bucket / 524288.0)));
@@ -487,8 +519,8 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
     const size_t b_buf1 = round_up(ns * g.nwgA * g.cap1 * 4, 256), b_buf2 = round_up(ns * g.F * g.nwgB * g.cap2 * 2, 256);
     const size_t b_cnt1 = round_up(ns * g.nwgA * 4, 256), b_cnt2 = round_up(ns * g.F * g.nwgB * 4, 256);
     const size_t b_spill = round_up(g.spill_cap * 8, 256), b_ctr = 256;
-    KV_HIP(g_scratch.need(b_buf1 + b_buf2 + b_cnt1 + b_cnt2 + b_spill + b_ctr));
-    unsigned char *base = (unsigned char *)g_scratch.p;
+    KV_HIP(scratch.need(b_buf1 + b_buf2 + b_cnt1 + b_cnt2 + b_spill + b_ctr));
+    unsigned char *base = (unsigned char *)scratch.p;
     g.gbuf1 = (uint32_t *)base; base += b_buf1;
     g.gbuf2 = (uint16_t *)base; base += b_buf2;
     g.gcnt1 = (uint32_t *)base; base += b_cnt1;
@@ -503,15 +535,15 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
         const size_t lds = (size_t)g.tile_lds + ns * g.ringA * 4 + ns * 8;
         const unsigned grid = g.nwgA;
         if (cmax == 16) {
-            (void)hipFuncSetAttribute((const void *)k_bin_hash<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            ensure_dynamic_lds(k_bin_hash<512, 2>, lds);
             hipLaunchKernelGGL((k_bin_hash<512, 2>), dim3(grid), dim3(512), lds, st, reads_dev(reads), reads->n_tiles,
                                (const SketchDev *)s->d_desc, d_mask, filter, g);
         } else if (cmax == 32) {
-            (void)hipFuncSetAttribute((const void *)k_bin_hash<512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            ensure_dynamic_lds(k_bin_hash<512, 1>, lds);
             hipLaunchKernelGGL((k_bin_hash<512, 1>), dim3(grid), dim3(512), lds, st, reads_dev(reads), reads->n_tiles,
                                (const SketchDev *)s->d_desc, d_mask, filter, g);
         } else {
-            (void)hipFuncSetAttribute((const void *)k_bin_hash<1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            ensure_dynamic_lds(k_bin_hash<1024, 1>, lds);
             hipLaunchKernelGGL((k_bin_hash<1024, 1>), dim3(grid), dim3(1024), lds, st, reads_dev(reads), reads->n_tiles,
                                (const SketchDev *)s->d_desc, d_mask, filter, g);
         }
@@ -519,8 +551,16 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
     {
         KvProfScope prof("k_bin_split");
         const size_t lds = (((size_t)g.F * g.ringB * 2 + 15) & ~(size_t)15) + (size_t)g.F * 2 * 4;
-        (void)hipFuncSetAttribute((const void *)k_bin_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ensure_dynamic_lds(k_bin_split, lds);
         hipLaunchKernelGGL(k_bin_split, dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
+    }
+    {
+        KvProfScope prof("k_bin_apply");
+        hipLaunchKernelGGL(k_bin_apply, dim3(maxsl, (unsigned)g.T), dim3(BIN_C_THREADS), 0, st, (const SketchDev *)s->d_desc, g);
+    }
+    {
+        KvProfScope prof("k_bin_spill");   // usually a handful of items; the kernels check the overflow flag themselves
+        hipLaunchKernelGGL(k_bin_spill, dim3(256), dim3(256), 0, st, (const SketchDev *)s->d_desc, g);
     }
     KV_HIP(hipGetLastError());
     unsigned long long ctr[4] = {0, 0, 0, 0};
@@ -530,18 +570,6 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
         kv_set_error("partitioned count: spill list overflow (%llu items)", ctr[0]);
         return KV_ERR_CAPACITY;
     }
-    {
-        KvProfScope prof("k_bin_apply");
-        hipLaunchKernelGGL(k_bin_apply, dim3(maxsl, (unsigned)g.T), dim3(BIN_C_THREADS), 0, st, (const SketchDev *)s->d_desc, g);
-    }
-    if (ctr[0] > 0) {
-        KvProfScope prof("k_bin_spill");
-        const unsigned grid = (unsigned)std::min<uint64_t>((ctr[0] + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_bin_spill, dim3(grid), dim3(256), 0, st, (const SketchDev *)s->d_desc, g);
-    }
-    KV_HIP(hipGetLastError());
-    KV_HIP(hipMemcpyAsync(ctr, g.ctr, sizeof(ctr), hipMemcpyDeviceToHost, st));
-    KV_HIP(hipStreamSynchronize(st));
     *n_added = ctr[2];
     // exact occupancy bookkeeping; n_unique_kmers as a linear-counting estimate
     if (s->occ_dirty) {

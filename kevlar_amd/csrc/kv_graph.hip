@@ -381,7 +381,7 @@ extern "C" int kv_unique_exact(kv_sketch *s, const kv_reads *const *batches, int
         p.kprefix = d_kpre.as<uint64_t>();
         if (r->n_tiles) {
             KvProfScope prof("k_first_touch");
-            (void)hipFuncSetAttribute((const void *)k_first_touch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->tile_lds_bytes);
+            kv_ensure_dynamic_lds((const void *)k_first_touch, r->tile_lds_bytes);
             hipLaunchKernelGGL(k_first_touch, dim3(r->n_tiles), dim3(KV_TILE_THREADS), r->tile_lds_bytes, st, reads_dev(r),
                                (const SketchDev *)s->d_desc, (const SketchDev *)(mask ? mask->d_desc : nullptr), p);
         }

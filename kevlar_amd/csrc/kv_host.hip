@@ -19,7 +19,7 @@ void kv_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-static hipStream_t g_stream = nullptr;
+static thread_local hipStream_t g_stream = nullptr;   // per host thread: concurrent samples use concurrent streams
 hipStream_t kv_stream() { return g_stream; }
 
 extern "C" const char *kv_last_error(void) { return g_err; }
@@ -47,9 +47,36 @@ extern "C" int kv_set_stream(void *s)
     return KV_OK;
 }
 
+void kv_ensure_dynamic_lds(const void *kernel, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<const void *, size_t> granted;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t &have = granted[kernel];
+    if (bytes > have) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        have = bytes;
+    }
+}
+
 extern "C" int kv_synchronize(void)
 {
     KV_HIP(hipStreamSynchronize(g_stream));
+    return KV_OK;
+}
+
+extern "C" int kv_stream_create(void **out)
+{
+    KV_REQUIRE(out, KV_ERR_ARG, "kv_stream_create: null output");
+    hipStream_t s = nullptr;
+    KV_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (void *)s;
+    return KV_OK;
+}
+
+extern "C" int kv_stream_destroy(void *s)
+{
+    if (s) KV_HIP(hipStreamDestroy((hipStream_t)s));
     return KV_OK;
 }
 
@@ -65,13 +92,13 @@ KvProfScope::KvProfScope(const char *n) : name(n), a(nullptr), b(nullptr), on(g_
 {
     if (!on) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
-    (void)hipEventRecord(a, g_stream);
+    (void)hipEventRecord(a, kv_stream());
 }
 
 KvProfScope::~KvProfScope()
 {
     if (!on) return;
-    (void)hipEventRecord(b, g_stream);
+    (void)hipEventRecord(b, kv_stream());
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof[name].pending.emplace_back(a, b);
 }

@@ -188,7 +188,7 @@ extern "C" int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int b
     KV_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(uint64_t), kv_stream()));
     if (reads->n_tiles > 0) {
         KvProfScope prof("k_consume");
-        (void)hipFuncSetAttribute((const void *)k_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads->tile_lds_bytes);
+        kv_ensure_dynamic_lds((const void *)k_consume, reads->tile_lds_bytes);
         hipLaunchKernelGGL(k_consume, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, kv_stream(), reads_dev(reads),
                            (const SketchDev *)s->d_desc, (const SketchDev *)(mask ? mask->d_desc : nullptr), p,
                            s->d_counters);

@@ -247,7 +247,7 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     if (e == hipSuccess) {
         {
             KvProfScope prof("k_novel_mark");
-            (void)hipFuncSetAttribute((const void *)k_novel_mark, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads->tile_lds_bytes);
+            kv_ensure_dynamic_lds((const void *)k_novel_mark, reads->tile_lds_bytes);
             hipLaunchKernelGGL(k_novel_mark, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, st, reads_dev(reads), p);
         }
         {
@@ -265,7 +265,7 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         p.hit_read = d_read.as<uint32_t>(); p.hit_off = d_off.as<uint32_t>(); p.hit_abund = d_abund.as<uint8_t>();
         if (e == hipSuccess) {
             KvProfScope prof("k_novel_emit");
-            (void)hipFuncSetAttribute((const void *)k_novel_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reads->tile_lds_bytes);
+            kv_ensure_dynamic_lds((const void *)k_novel_emit, reads->tile_lds_bytes);
             hipLaunchKernelGGL(k_novel_emit, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, st, reads_dev(reads), p);
             e = hipGetLastError();
         }

@@ -48,6 +48,63 @@ def _u8p(arr):
 
 
 # ----------------------------------------------------------------------------------------
+# streams: independent samples are counted by concurrent host threads on concurrent HIP streams
+# ----------------------------------------------------------------------------------------
+class Stream(object):
+    def __init__(self):
+        _lib.require_device()
+        handle = ctypes.c_void_p()
+        check(_lib.load().kv_stream_create(ctypes.byref(handle)))
+        self._h = handle
+
+    def bind(self):
+        """Make this the stream of the calling host thread."""
+        check(_lib.load().kv_set_stream(self._h))
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                _lib.load().kv_stream_destroy(h)
+            except Exception:
+                pass
+
+
+_pool_lock = threading.Lock()
+_pool_streams = []
+
+
+def run_concurrently(jobs):
+    """Run zero-argument callables on separate host threads, each bound to its own HIP stream;
+    returns their results in order.  Kernels of different jobs overlap on the GPU."""
+    if len(jobs) <= 1:
+        return [job() for job in jobs]
+    with _pool_lock:
+        while len(_pool_streams) < len(jobs):
+            _pool_streams.append(Stream())
+        streams = _pool_streams[:len(jobs)]
+    results, errors = [None] * len(jobs), []
+
+    def work(i):
+        try:
+            streams[i].bind()
+            results[i] = jobs[i]()
+        except BaseException as exc:
+            errors.append(exc)
+        finally:
+            _lib.load().kv_set_stream(None)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results
+
+
+# ----------------------------------------------------------------------------------------
 # reads
 # ----------------------------------------------------------------------------------------
 class Read(object):
