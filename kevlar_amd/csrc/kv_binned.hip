@@ -508,7 +508,7 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
     const uint64_t ns = (uint64_t)g.T * g.C;
     // writers: stage A = persistent workgroups (tiles dealt round-robin, so their loads are equal
     // to within one tile); stage B = nwgB workgroups per coarse bucket, ~256 k items each
-    g.nwgA = std::min<uint32_t>(reads->n_tiles, (cmax <= 32 ? 2u : 1u) * (uint32_t)cus);
+    g.nwgA = std::min<uint32_t>(reads->n_tiles, (cmax <= 32 ? 3u : 1u) * (uint32_t)cus);
     const double per_bucket = expected * std::min(1.0, (double)g.F * 65536.0 / (double)pmin);
     const double per_slice = expected * std::min(1.0, 65536.0 / (double)pmin);
     g.nwgB = (uint32_t)std::max(1.0, std::min((double)std::min<uint32_t>(g.nwgA, 512), std::ceil(per_bucket / 524288.0)));

@@ -96,8 +96,8 @@ double kv_estimate_distinct(uint64_t occupied, uint64_t size);
 
 // tile geometry of the hashing kernels
 #define KV_TILE_THREADS 256
-#define KV_TILE_MAX_READS 48
-#define KV_TILE_LDS_BYTES 12288  // ASCII staging (forward + reverse complement) per tile: 48 reads of 100 bp
+#define KV_TILE_MAX_READS 64
+#define KV_TILE_LDS_BYTES 16384  // ASCII staging (forward + reverse complement) per tile: 64 reads of 100 bp
 #define KV_READ_PAD 24           // over-read slack after each staged strand
 #define KV_MAX_READ_LEN 49000    // a longer read would not fit one workgroup's LDS next to the partition rings
 
