@@ -42,6 +42,7 @@ def parse_args():
     p.add_argument('--ctrl-max', type=int, default=1)
     p.add_argument('--cpu-reads', type=int, default=40000, help='reads per sample for the CPU baseline leg')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--backend', default='nccl', help='nccl (= RCCL) is what the driver runs; gloo lets two ranks share one GPU in tests')
     return p.parse_args()
 
 
@@ -67,9 +68,16 @@ def main():
     __graft_entry__.build()
     from kevlar_amd import _lib, khmer as hk, synth
 
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(1, ndev)
+    os.environ['LOCAL_RANK'] = str(dev_index)      # kevlar_amd._lib binds the library to the same device
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(args.backend)
+    coll_device = torch.device('cuda', dev_index) if args.backend == 'nccl' else torch.device('cpu')
     lib = _lib.load()
     _lib.require_device()
 
@@ -110,11 +118,15 @@ def main():
         nhits = len(r)
         t_c = time.perf_counter()
         if world > 1:
-            dist.all_reduce(mask)                       # bands are disjoint: sum == OR
-            counts = torch.tensor([nhits], dtype=torch.int64, device='cuda')
-            gathered = [torch.zeros_like(counts) for _ in range(world)]
-            dist.all_gather(gathered, counts)
-            nhits = int(sum(int(g.item()) for g in gathered))
+            from kevlar_amd import bandmerge
+            if args.backend == 'nccl':
+                bandmerge.allreduce_mask(mask)          # bands are disjoint: sum == OR
+            else:
+                host_mask = mask.cpu()
+                bandmerge.allreduce_mask(host_mask)
+                mask.copy_(host_mask)
+            r, o, a = bandmerge.allgather_hits(r, o, a, coll_device)
+            nhits = len(r)
         wall['count'] += t_b - t_a
         wall['novel'] += t_c - t_b
         wall['merge'] += time.perf_counter() - t_c
@@ -140,7 +152,7 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.kv_prof_enable(0)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -35,7 +35,9 @@ def mask_to_hits(mask, stride):
 
 
 def allgather_hits(read, offset, abund, device, group=None):
-    """Concatenate every rank's hits and return them sorted by (read, offset) as numpy arrays."""
+    """Concatenate every rank's hits and return them sorted by (read, offset) as numpy arrays.
+
+    One padded all-gather of packed rows: 4 B read, 4 B offset, S abundance bytes (S <= 16)."""
     world = dist.get_world_size(group)
     S = abund.shape[1] if abund.ndim == 2 else 0
     n = torch.tensor([len(read)], dtype=torch.int64, device=device)
@@ -43,15 +45,18 @@ def allgather_hits(read, offset, abund, device, group=None):
     dist.all_gather(sizes, n, group=group)
     sizes = [int(s.item()) for s in sizes]
     cap = max(max(sizes), 1)
-    rec = torch.zeros((cap, 2 + S), dtype=torch.int64, device=device)
+    width = 8 + S
+    rows = np.zeros((cap, width), dtype=np.uint8)
     if len(read):
-        rec[:len(read), 0] = torch.from_numpy(read.astype(np.int64)).to(device)
-        rec[:len(read), 1] = torch.from_numpy(offset.astype(np.int64)).to(device)
+        rows[:len(read), 0:4] = np.ascontiguousarray(read, dtype='<u4').view(np.uint8).reshape(-1, 4)
+        rows[:len(read), 4:8] = np.ascontiguousarray(offset, dtype='<u4').view(np.uint8).reshape(-1, 4)
         if S:
-            rec[:len(read), 2:] = torch.from_numpy(abund.astype(np.int64)).to(device)
+            rows[:len(read), 8:] = abund
+    rec = torch.from_numpy(rows).to(device)
     parts = [torch.zeros_like(rec) for _ in range(world)]
     dist.all_gather(parts, rec, group=group)
-    rows = torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0).cpu().numpy()
-    order = np.lexsort((rows[:, 1], rows[:, 0]))
-    rows = rows[order]
-    return rows[:, 0].astype(np.uint32), rows[:, 1].astype(np.uint32), rows[:, 2:].astype(np.uint8)
+    merged = torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0).cpu().numpy()
+    mread = np.ascontiguousarray(merged[:, 0:4]).view('<u4').reshape(-1)
+    moff = np.ascontiguousarray(merged[:, 4:8]).view('<u4').reshape(-1)
+    order = np.lexsort((moff, mread))
+    return mread[order].astype(np.uint32), moff[order].astype(np.uint32), merged[order][:, 8:].astype(np.uint8)
