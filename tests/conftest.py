@@ -36,6 +36,14 @@ def hk():
     import __graft_entry__
     if not os.path.exists(__graft_entry__.LIB):
         __graft_entry__.build()
+    # Tests that also use torch tensors (band masks) need torch's bundled HIP runtime to be the one
+    # the process loads: initialise torch.cuda BEFORE libkvsketch_hip touches the device.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from kevlar_amd import khmer
     return khmer
 
