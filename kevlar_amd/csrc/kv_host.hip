@@ -1,6 +1,7 @@
 // kv_host.hip -- host side of libkvsketch_hip: handles, OXLI v4 file I/O, table sizing,
 // read packing and the live profiler.  All table memory is HBM (hipMalloc).
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <map>
 
@@ -289,7 +290,9 @@ int kv_sketch_alloc(int kind, int ksize, int ntables, const uint64_t *sizes, kv_
     KV_REQUIRE(ksize >= 1 && ksize <= KV_MAX_K, KV_ERR_ARG, "k=%d out of range 1..%d", ksize, KV_MAX_K);
     KV_REQUIRE(kv_hashfam_of(kind) != HF_TWOBIT || ksize <= 32, KV_ERR_ARG,
                "graph sketches need k <= 32 (got %d)", ksize);
+    static std::atomic<uint64_t> next_uid{1};
     kv_sketch *s = new kv_sketch();
+    s->uid = next_uid.fetch_add(1);
     s->kind = kind;
     memset(&s->h, 0, sizeof(s->h));
     s->h.ntables = ntables;
@@ -380,6 +383,7 @@ extern "C" int kv_sketch_table_write(kv_sketch *s, int table, const uint8_t *hos
     uint64_t nb = kv_table_nbytes(s->h.storage, s->h.size[table]);
     KV_REQUIRE(nbytes == nb, KV_ERR_ARG, "table %d holds %llu bytes", table, (unsigned long long)nb);
     std::lock_guard<std::mutex> lk(s->mu);
+    s->version++;
     KV_HIP(hipMemcpyAsync(s->h.tab[table], host_in, nb, hipMemcpyHostToDevice, kv_stream()));
     KV_HIP(hipStreamSynchronize(kv_stream()));
     s->occ_dirty = true;
@@ -390,6 +394,7 @@ extern "C" int kv_sketch_clear(kv_sketch *s)
 {
     KV_REQUIRE(s, KV_ERR_ARG, "kv_sketch_clear: null handle");
     std::lock_guard<std::mutex> lk(s->mu);
+    s->version++;
     KvProfScope prof("memset_tables");
     for (int i = 0; i < s->h.ntables; ++i) KV_HIP(hipMemsetAsync(s->h.tab[i], 0, s->alloc_bytes[i], kv_stream()));
     s->n_occupied = 0;

@@ -46,6 +46,8 @@ struct kv_sketch {
     uint64_t n_occupied;  // valid when !occ_dirty
     bool occ_dirty;
     uint64_t n_unique;
+    uint64_t uid = 0;      // unique per allocation (pointers get recycled)
+    uint64_t version = 0;  // bumped by everything that changes a table (invalidates cached scan verdicts)
     uint64_t *d_counters; // [0] n_kmers, [1] n_unique (device accumulators)
     std::mutex mu;
 };

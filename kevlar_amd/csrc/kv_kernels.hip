@@ -172,6 +172,7 @@ extern "C" int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int b
     KV_REQUIRE(nbands >= 0 && (nbands == 0 || (band >= 0 && band < nbands)), KV_ERR_ARG,
                "band %d out of range for %d bands", band, nbands);
     std::lock_guard<std::mutex> lk(s->mu);
+    s->version++;
     const ConsumeFilter p = make_consume_filter(s->h.ksize, s->h.hashfam, nbands, band, mask != nullptr, threshold,
                                                 consume_masked);
     uint64_t n_kmers = 0;
@@ -258,6 +259,7 @@ extern "C" int kv_add_hashes(kv_sketch *s, const uint64_t *hashes, uint64_t n, u
     KV_REQUIRE(s && (hashes || n == 0), KV_ERR_ARG, "kv_add_hashes: null argument");
     if (n == 0) return KV_OK;
     std::lock_guard<std::mutex> lk(s->mu);
+    s->version++;
     uint64_t *d_h = nullptr;
     uint8_t *d_o = nullptr;
     KV_HIP(hipMalloc((void **)&d_h, n * 8));

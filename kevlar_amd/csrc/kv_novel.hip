@@ -11,6 +11,7 @@
 // Hits therefore reach the host already sorted, in exactly the order the reference annotates
 // them, and the bit mask doubles as the per-band mask that the multi-GPU merge all-reduces.
 #include <algorithm>
+#include <map>
 
 #include "kv_device.h"
 
@@ -31,6 +32,8 @@ struct NovelParams {
     const uint64_t *tile_base;
     uint32_t *hit_read, *hit_off;
     uint8_t *hit_abund;
+    unsigned long long *vcache;   // hashes proven rejected by a control (NULL = off)
+    int vcache_shift;             // slot = h >> shift
 };
 
 __device__ __forceinline__ bool band_pass(const NovelParams &p, uint64_t h)
@@ -40,34 +43,90 @@ __device__ __forceinline__ bool band_pass(const NovelParams &p, uint64_t h)
     return true;
 }
 
-// The abundance test.  Without a screen the predicate is evaluated cheapest-evidence-first: a
-// control passes as soon as ONE table is <= ctrl_max (its Count-Min minimum is then <= ctrl_max)
-// and fails only after all T tables exceed it; a case fails as soon as ONE table is < case_min.
-// The typical inherited k-mer is rejected after T loads.  With a screen the reference order is
-// kept (cases in order with full minima, novel.py:36-44) because `discard` depends on it.
-__device__ __forceinline__ bool novel_test(const NovelParams &p, uint64_t h, bool &discard)
+// Table descriptors of every sample, copied to LDS once per workgroup: the probe loops then read
+// sizes / reciprocals / base pointers with broadcast LDS loads instead of three dependent global
+// loads per probe (which is what the compiler emits for `p.sk[c]->size[t]` inside a divergent loop).
+struct ProbeDesc {
+    uint64_t size, magic;
+    const uint8_t *tab;
+};
+struct NovelShared {
+    ProbeDesc d[KV_MAX_SAMPLES * KV_MAX_TABLES];
+    int ntab[KV_MAX_SAMPLES];
+    int storage[KV_MAX_SAMPLES];
+};
+
+__device__ __forceinline__ void load_descs(NovelShared &ns, const NovelParams &p)
+{
+    const int S = p.ncase + p.nctrl;
+    for (int i = threadIdx.x; i < S * KV_MAX_TABLES; i += blockDim.x) {
+        const int c = i / KV_MAX_TABLES, t = i % KV_MAX_TABLES;
+        const SketchDev *s = p.sk[c];
+        if (t < s->ntables) { ns.d[i].size = s->size[t]; ns.d[i].magic = s->magic[t]; ns.d[i].tab = s->tab[t]; }
+        if (t == 0) { ns.ntab[c] = s->ntables; ns.storage[c] = s->storage; }
+    }
+}
+
+__device__ __forceinline__ uint32_t probe(const NovelShared &ns, int c, int t, uint64_t h)
+{
+    const ProbeDesc &d = ns.d[c * KV_MAX_TABLES + t];
+    const uint64_t bin = fastmod(h, d.size, d.magic);
+    const int st = ns.storage[c];
+    if (st == ST_BYTE) return d.tab[bin];
+    if (st == ST_NIBBLE) return (d.tab[bin >> 1] >> ((bin & 1) ? 0 : 4)) & 15u;
+    return (d.tab[bin >> 3] >> (bin & 7)) & 1u;
+}
+
+// The abundance test (screen off).  Same predicate as kmer_is_interesting(), cheapest evidence first:
+// a control passes as soon as ONE table is <= ctrl_max (its Count-Min minimum is then <= ctrl_max) and
+// rejects only after all T exceed it; a case fails as soon as ONE table is < case_min.  Measured: the
+// scan is bound by the rate of random 64-B requests (~55 G/s), so probes are spent one at a time --
+// issuing a control's T probes together was slower.
+//
+// Verdict cache: whether a k-mer is rejected by the controls is a pure function of its 64-bit hash
+// (every bin derives from it), and an inherited k-mer recurs once per unit of coverage.  A direct-
+// mapped table of hashes already proven "rejected by a control" turns its T probes into one.  Entries
+// are single 8-byte words, races only cost a re-evaluation, a wrong answer is impossible: a slot
+// either holds exactly this hash (proven) or it does not.
+__device__ __forceinline__ bool novel_test_fast(const NovelShared &ns, const NovelParams &p, uint64_t h)
+{
+    unsigned long long *slot = nullptr;
+    if (p.vcache) {
+        slot = p.vcache + (h >> p.vcache_shift);
+        if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == h) return false;
+    }
+    // table 0 of every case first: a sequencing-error k-mer (case count 1) leaves here after one probe
+    for (int c = 0; c < p.ncase; ++c)
+        if ((int)probe(ns, c, 0, h) < p.case_min) return false;
+    for (int c = p.ncase; c < p.ncase + p.nctrl; ++c) {
+        const int T = ns.ntab[c];
+        bool pass = false;
+        for (int t = 0; t < T && !pass; ++t) pass = (int)probe(ns, c, t, h) <= p.ctrl_max;
+        if (!pass) {
+            if (slot) __hip_atomic_store(slot, (unsigned long long)h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    for (int c = 0; c < p.ncase; ++c) {
+        const int T = ns.ntab[c];
+        for (int t = 1; t < T; ++t)
+            if ((int)probe(ns, c, t, h) < p.case_min) return false;
+    }
+    return true;
+}
+
+// With --abund-screen the reference order is kept (cases in order with full minima, novel.py:36-44)
+// because `discard` depends on which case fails first.
+__device__ __forceinline__ bool novel_test_screen(const NovelParams &p, uint64_t h, bool &discard)
 {
     bool interesting = true;
     discard = false;
-    if (p.screen > 0) {
-        for (int c = 0; c < p.ncase && interesting; ++c) {
-            const int a = (int)sketch_get(p.sk[c], h);
-            if (a < p.case_min) { interesting = false; discard = a < p.screen; }
-        }
-        for (int c = 0; c < p.nctrl && interesting; ++c)
-            if ((int)sketch_get(p.sk[p.ncase + c], h) > p.ctrl_max) interesting = false;
-        return interesting;
-    }
-    for (int c = 0; c < p.nctrl && interesting; ++c) {
-        const SketchDev *s = p.sk[p.ncase + c];
-        bool pass = false;
-        for (int t = 0; t < s->ntables && !pass; ++t) pass = (int)table_get(s, t, h) <= p.ctrl_max;
-        interesting = pass;
-    }
     for (int c = 0; c < p.ncase && interesting; ++c) {
-        const SketchDev *s = p.sk[c];
-        for (int t = 0; t < s->ntables && interesting; ++t) interesting = (int)table_get(s, t, h) >= p.case_min;
+        const int a = (int)sketch_get(p.sk[c], h);
+        if (a < p.case_min) { interesting = false; discard = a < p.screen; }
     }
+    for (int c = 0; c < p.nctrl && interesting; ++c)
+        if ((int)sketch_get(p.sk[p.ncase + c], h) > p.ctrl_max) interesting = false;
     return interesting;
 }
 
@@ -77,8 +136,10 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_mark(ReadsDev rd, Nov
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
     if (threadIdx.x == 0) sh.ascii = (uint32_t *)tile_smem;
     __shared__ uint32_t tile_hits;
+    __shared__ NovelShared ns;
     uint32_t read0;
     if (threadIdx.x == 0) tile_hits = 0;
+    load_descs(ns, p);
     const uint32_t nr = stage_tile(sh, rd, blockIdx.x, p.hp.k, 1, p.first_read, read0);
     const uint32_t total = sh.kpre[nr];
     uint32_t mine = 0;
@@ -89,8 +150,8 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_mark(ReadsDev rd, Nov
         const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)p.hp.k - i);
         const uint64_t h = kmer_hash_lds(sh.ascii, fwd, rc, p.hp);
         if (!band_pass(p, h)) continue;
-        bool discard;
-        const bool interesting = novel_test(p, h, discard);
+        bool discard = false;
+        const bool interesting = p.screen > 0 ? novel_test_screen(p, h, discard) : novel_test_fast(ns, p, h);
         const uint32_t gread = read0 + r;
         if (discard) p.disc_flag[gread] = 1;   // several k-mers may flag one read: plain store
         if (!interesting) continue;
@@ -177,6 +238,16 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_emit(ReadsDev rd, Nov
     }
 }
 
+// verdict cache kept across the batches of one scan: valid as long as the same sketches (unmodified),
+// thresholds and band settings are used; otherwise it is cleared
+struct VerdictCache {
+    unsigned long long *p = nullptr;
+    int bits = 0;
+    uint64_t signature = 0;
+};
+std::map<hipStream_t, VerdictCache> g_vcache;
+std::mutex g_vcache_mu;
+
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -217,6 +288,39 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     p.first_read = first_read;
     const int S = ncase + nctrl;
     hipStream_t st = kv_stream();
+    uint64_t n_kmers = 0;
+    kv_reads_num_kmers(reads, k, &n_kmers);
+    const char *vc_env = getenv("KV_NOVEL_VCACHE");
+    if (nctrl > 0 && p.screen == 0 && !(vc_env && atoi(vc_env) == 0)) {
+        // signature of everything the cached verdicts depend on
+        uint64_t sig = 0x9e3779b97f4a7c15ull ^ (uint64_t)(uint32_t)ctrl_max;
+        for (int c = ncase; c < ncase + nctrl; ++c) {
+            const kv_sketch *sk = ctrls[c - ncase];
+            sig = (sig ^ sk->uid) * 0xff51afd7ed558ccdull;
+            sig = (sig ^ sk->version) * 0xc4ceb9fe1a85ec53ull;
+        }
+        VerdictCache *vc;
+        {
+            std::lock_guard<std::mutex> lk(g_vcache_mu);
+            vc = &g_vcache[st];
+        }
+        int want = 20;
+        while (want < 28 && (1ull << want) < n_kmers / 2) ++want;   // ~2 slots per distinct inherited k-mer at 30x
+        if (vc->p == nullptr || vc->bits < want) {
+            if (vc->p) (void)hipFree(vc->p);
+            vc->p = nullptr;
+            if (hipMalloc((void **)&vc->p, (size_t)8 << want) == hipSuccess) { vc->bits = want; vc->signature = 0; }
+            else { (void)hipGetLastError(); vc->bits = 0; }
+        }
+        if (vc->p) {
+            if (vc->signature != sig) {
+                KV_HIP(hipMemsetAsync(vc->p, 0, (size_t)8 << vc->bits, st));
+                vc->signature = sig;
+            }
+            p.vcache = vc->p;
+            p.vcache_shift = 64 - vc->bits;
+        }
+    }
 
     kv_hits *hits = new kv_hits();
     hits->nsamples = S;
