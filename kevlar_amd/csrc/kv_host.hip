@@ -89,10 +89,25 @@ static bool g_prof_on = false;
 static std::map<std::string, ProfRec> g_prof;
 static std::mutex g_prof_mu;
 
+static std::vector<hipEvent_t> g_event_pool;   // events are recycled: creating one costs far more than recording it
+
+static hipEvent_t prof_event()
+{
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
 KvProfScope::KvProfScope(const char *n) : name(n), a(nullptr), b(nullptr), on(g_prof_on)
 {
     if (!on) return;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+    a = prof_event();
+    b = prof_event();
+    if (!a || !b) { on = false; return; }
     (void)hipEventRecord(a, kv_stream());
 }
 
@@ -114,8 +129,8 @@ static void prof_drain()
                 kv.second.ms += ms;
                 kv.second.n += 1;
             }
-            (void)hipEventDestroy(p.first);
-            (void)hipEventDestroy(p.second);
+            g_event_pool.push_back(p.first);
+            g_event_pool.push_back(p.second);
         }
         kv.second.pending.clear();
     }

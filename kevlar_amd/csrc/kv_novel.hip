@@ -88,13 +88,10 @@ __device__ __forceinline__ uint32_t probe(const NovelShared &ns, int c, int t, u
 // mapped table of hashes already proven "rejected by a control" turns its T probes into one.  Entries
 // are single 8-byte words, races only cost a re-evaluation, a wrong answer is impossible: a slot
 // either holds exactly this hash (proven) or it does not.
-__device__ __forceinline__ bool novel_test_fast(const NovelShared &ns, const NovelParams &p, uint64_t h)
+__device__ __forceinline__ bool novel_test_fast(const NovelShared &ns, const NovelParams &p, uint64_t h,
+                                                unsigned long long *slot, unsigned long long cached)
 {
-    unsigned long long *slot = nullptr;
-    if (p.vcache) {
-        slot = p.vcache + (h >> p.vcache_shift);
-        if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == h) return false;
-    }
+    if (slot && cached == h) return false;
     // table 0 of every case first: a sequencing-error k-mer (case count 1) leaves here after one probe
     for (int c = 0; c < p.ncase; ++c)
         if ((int)probe(ns, c, 0, h) < p.case_min) return false;
@@ -143,21 +140,46 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_mark(ReadsDev rd, Nov
     const uint32_t nr = stage_tile(sh, rd, blockIdx.x, p.hp.k, 1, p.first_read, read0);
     const uint32_t total = sh.kpre[nr];
     uint32_t mine = 0;
-    for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
+    // two-deep software pipeline: the next k-mer is hashed and its verdict-cache word requested
+    // before the current k-mer is evaluated, so that round trip hides behind useful work
+    struct Cand {
         uint32_t r, i;
-        locate_kmer(sh, nr, q, r, i);
-        const uint32_t fwd = sh.foff[r] + i;
-        const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)p.hp.k - i);
-        const uint64_t h = kmer_hash_lds(sh.ascii, fwd, rc, p.hp);
-        if (!band_pass(p, h)) continue;
-        bool discard = false;
-        const bool interesting = p.screen > 0 ? novel_test_screen(p, h, discard) : novel_test_fast(ns, p, h);
-        const uint32_t gread = read0 + r;
-        if (discard) p.disc_flag[gread] = 1;   // several k-mers may flag one read: plain store
-        if (!interesting) continue;
-        const uint64_t bit = (uint64_t)gread * p.mask_stride + i;
-        atomicOr(&p.mask[bit >> 5], 1u << (bit & 31));
-        mine += 1;
+        uint64_t h;
+        unsigned long long *slot;
+        unsigned long long cached;
+        bool live;
+    };
+    auto fetch = [&](uint32_t q) {
+        Cand c;
+        c.live = false; c.slot = nullptr; c.cached = 0; c.h = 0; c.r = 0; c.i = 0;
+        if (q >= total) return c;
+        locate_kmer(sh, nr, q, c.r, c.i);
+        const uint32_t fwd = sh.foff[c.r] + c.i;
+        const uint32_t rc = sh.roff[c.r] + (sh.len[c.r] - (uint32_t)p.hp.k - c.i);
+        c.h = kmer_hash_lds(sh.ascii, fwd, rc, p.hp);
+        c.live = band_pass(p, c.h);
+        if (c.live && p.vcache && p.screen == 0) {
+            c.slot = p.vcache + (c.h >> p.vcache_shift);
+            c.cached = __hip_atomic_load(c.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return c;
+    };
+    Cand cur = fetch(threadIdx.x);
+    for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
+        const Cand nxt = fetch(q + blockDim.x);
+        if (cur.live) {
+            bool discard = false;
+            const bool interesting = p.screen > 0 ? novel_test_screen(p, cur.h, discard)
+                                                  : novel_test_fast(ns, p, cur.h, cur.slot, cur.cached);
+            const uint32_t gread = read0 + cur.r;
+            if (discard) p.disc_flag[gread] = 1;   // several k-mers may flag one read: plain store
+            if (interesting) {
+                const uint64_t bit = (uint64_t)gread * p.mask_stride + cur.i;
+                atomicOr(&p.mask[bit >> 5], 1u << (bit & 31));
+                mine += 1;
+            }
+        }
+        cur = nxt;
     }
     mine = (uint32_t)wave_sum_u64(mine);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&tile_hits, mine);
