@@ -190,7 +190,7 @@ def main():
     stage_ms = sum(times[n_][0] for n_ in groups[stage]) / max(1, launches)
     achieved = alg[dominant] / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
     traffic = None
-    pmc_file = os.path.join(ROOT, 'profiles', 'r1_partitioned', 'pmc_hbm_bytes.json')
+    pmc_file = os.path.join(ROOT, 'profiles', 'r1_final', 'pmc_hbm_bytes.json')
     if world == 1 and os.path.exists(pmc_file) and (args.genome_mb, args.coverage, k, args.memory) == (25.0, 30.0, 31, 2e9):
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (profiles/README.md):
         # FETCH_SIZE doubled for the wide coalesced streams of the k_bin_* kernels, as the guide prescribes
