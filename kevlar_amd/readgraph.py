@@ -68,10 +68,46 @@ class ReadGraph(object):
     # ---- kevlar/readgraph.py:104-125 ------------------------------------------------------
     def populate_edges(self, strict=False):
         if strict:
-            raise NotImplementedError(
-                'partition --strict (ReadPair overlap validation, kevlar/readpair.py) is not part '
-                'of this build yet; relaxed mode is the reference default')
-        self._solve(want_edges=False)
+            self._solve_strict()
+        else:
+            self._solve(want_edges=False)
+
+    def _solve_strict(self):
+        """Strict mode (kevlar/readgraph.py:113-123): an edge only where the two reads overlap
+        perfectly around a shared k-mer.  Host-side; see kevlar_amd/readpair.py."""
+        from itertools import combinations
+        from kevlar_amd.readpair import validate
+        names = list(self.records)
+        node_id = {name: i for i, name in enumerate(names)}
+        ikmers = {}
+        for record in self._reads:
+            for ikmer in record.annotations:
+                ikmers.setdefault(kevlar_amd.revcommin(record.ikmerseq(ikmer)), set()).add(record.name)
+        parent = list(range(len(names)))
+
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        edges = set()
+        for kmer, readset in ikmers.items():
+            n = len(readset)
+            if (self._minabund and n < self._minabund) or (self._maxabund and n > self._maxabund):
+                continue
+            for name1, name2 in combinations(sorted(readset), 2):
+                if (name1, name2) in edges:
+                    continue
+                result = validate(self.records[name1], self.records[name2], kmer)
+                if result is None:
+                    continue
+                tailname, headname = result[1], result[2]      # may be one and the same read (see readpair.validate)
+                edges.add((min(tailname, headname), max(tailname, headname)))
+                a, b = find(node_id[tailname]), find(node_id[headname])
+                if a != b:
+                    parent[max(a, b)] = min(a, b)
+        self._labels = np.array([find(i) for i in range(len(names))], dtype=np.uint32)
+        self._nedges = len(edges)
 
     def _solve(self, want_edges):
         names = list(self.records)

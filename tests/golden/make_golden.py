@@ -223,7 +223,10 @@ def main():
             ('partition-pico-minabund5', 'pico-filtered.fq.gz', ['--min-abund', '5']),
             ('partition-pico-default', 'pico-filtered.fq.gz', []),
             ('partition-conn1311', 'connectivity-1311.augfastq', []),
-            ('partition-conn1541-nodedup', 'connectivity-1541.augfastq', ['--no-dedup'])]:
+            ('partition-conn1541-nodedup', 'connectivity-1541.augfastq', ['--no-dedup']),
+            ('partition-conn1311-strict', 'connectivity-1311.augfastq', ['--strict']),
+            ('partition-conn1541-strict-nodedup', 'connectivity-1541.augfastq', ['--strict', '--no-dedup']),
+            ('partition-pico-strict', 'pico-filtered.fq.gz', ['--strict'])]:
         out, log = run_cli(kevlar, ['partition'] + extra + [d(infile)])
         parts = {}
         reader = kevlar.parse_augmented_fastx(io.StringIO(out))

@@ -242,3 +242,54 @@ def test_synthetic_trio_generator_properties():
     clean = synth.unpack_reads(words, 100)
     diff = sum(a != b for x, y in zip(noisy, clean) for a, b in zip(x, y))
     assert 600 < diff < 1400            # ~0.5 % of 200k bases
+
+
+def test_readgraph_strict_mode_edges_and_cli(tmp_path):
+    """kevlar/tests/test_readgraph.py:20-31 strict edge counts (the reference asserts 11 and 12 +-1;
+    its own drivers give 11 and 11, tests/golden/expected/manifest.json) -- strict mode is host-side."""
+    import json
+    import kevlar_amd
+    want = json.load(open(expected_file('manifest.json')))['readgraph_edges']
+    for infile, approx in [('connectivity-1311.augfastq', 11), ('connectivity-1541.augfastq', 12)]:
+        with open(data_file(infile)) as fh:
+            reads = list(kevlar_amd.parse_augmented_fastx(fh))
+        rg = kevlar_amd.ReadGraph()
+        rg.load(reads)
+        rg.populate_edges(strict=True)
+        # the reference's count depends on Python set order (which read of a tied pair receives the
+        # self-loop); its own test allows +-100 %.  Components are order-free and compared below.
+        assert abs(rg.number_of_edges() - want[infile]['strict']) <= 2
+        assert abs(rg.number_of_edges() - approx) <= 2
+    import io
+    for name, infile, extra in [('partition-conn1311-strict', 'connectivity-1311.augfastq', ['--strict']),
+                                ('partition-conn1541-strict-nodedup', 'connectivity-1541.augfastq', ['--strict', '--no-dedup']),
+                                ('partition-pico-strict', 'pico-filtered.fq.gz', ['--strict'])]:
+        gold = json.load(open(expected_file(name + '.json')))
+        args = kevlar_amd.cli.parser().parse_args(['partition'] + extra + ['-o', str(tmp_path / 'out.augfastq'), data_file(infile)])
+        log = io.StringIO()
+        old, kevlar_amd.logstream = kevlar_amd.logstream, log
+        try:
+            kevlar_amd.partition.main(args)
+        finally:
+            kevlar_amd.logstream = old
+        got = {}
+        for rec in kevlar_amd.parse_augmented_fastx(open(str(tmp_path / 'out.augfastq'))):
+            pid = kevlar_amd.seqio.partition_id(rec.name)
+            got.setdefault(pid, []).append(kevlar_amd.revcommin(rec.sequence))
+        assert sorted(got) == sorted(gold['partitions'])
+        for pid in got:
+            assert sorted(set(got[pid])) == sorted(set(seq for _, seq in gold['partitions'][pid]))
+        assert gold['log'][0].split('] ')[-1] in log.getvalue()
+    # readpair known answers in the spirit of kevlar/tests/test_readpair.py: a perfect overlap merges,
+    # a mismatch inside the overlap does not
+    from kevlar_amd.readpair import merged_sequence
+    from kevlar_amd.sequence import KmerOfInterest, Record
+    k = 'GGGCGTGACTTAATAAGGT'
+    a = Record('a', 'TTAACTCTAGATTAGGGGCGTGACTTAATAAGGTGTGGGCCTAAGCGTCT', annotations=[KmerOfInterest(19, 15, (20, 0, 0))])
+    b = Record('b', 'GATTAGGGGCGTGACTTAATAAGGTGTGGGCCTAAGCGTCTAACGTTTAC', annotations=[KmerOfInterest(19, 6, (20, 0, 0))])
+    assert kevlar_amd.revcommin(merged_sequence(a, b, k)) == kevlar_amd.revcommin(
+        'TTAACTCTAGATTAGGGGCGTGACTTAATAAGGTGTGGGCCTAAGCGTCTAACGTTTAC')
+    brc = Record('brc', kevlar_amd.revcom(b.sequence), annotations=[KmerOfInterest(19, 50 - 6 - 19, (20, 0, 0))])
+    assert merged_sequence(a, brc, k) is not None
+    c = Record('c', 'GATTAGGGGCGTGACTTAATAAGGTGTGGGCCTAAGCGACTAACGTTTAC', annotations=[KmerOfInterest(19, 6, (20, 0, 0))])
+    assert merged_sequence(a, c, k) is None
