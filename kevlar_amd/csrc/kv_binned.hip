@@ -126,7 +126,8 @@ __device__ __forceinline__ void rings_store_counts(uint32_t ns, uint32_t written
 
 // ---- stage A -----------------------------------------------------------------------------
 template <int THREADS, int KPT>
-__global__ __launch_bounds__(THREADS) void k_bin_hash(ReadsDev rd, uint32_t n_tiles, const SketchDev *__restrict__ sk,
+__global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash(   // 3 x 8 waves (or 1 x 16) per CU must fit the register file
+    ReadsDev rd, uint32_t n_tiles, const SketchDev *__restrict__ sk,
                                                       const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
     __shared__ TileShared sh;

@@ -178,6 +178,8 @@ struct TileShared {
     uint32_t len[KV_TILE_MAX_READS];
     uint32_t wpre[KV_TILE_MAX_READS + 1];  // packed-word prefix within the tile
     uint32_t kpre[KV_TILE_MAX_READS + 1];  // k-mer prefix within the tile
+    uint32_t unk;                          // k-mers per read if every read of the tile has the same count, else 0
+    float unk_inv;
 };
 
 struct ReadsDev {
@@ -237,6 +239,11 @@ __device__ __forceinline__ uint32_t stage_tile(TileShared &sh, const ReadsDev &r
         if (i0 < nr) sh.kpre[i0] = ka;
         if (i1 < nr) sh.kpre[i1] = kb;
         if (threadIdx.x == 0) sh.kpre[nr] = ktot;
+        // uniform tile (the common case: fixed-length reads): k-mer -> read is a division, not a search
+        const uint32_t ref_k = __shfl(k0, 0);
+        const bool same = (i0 >= nr || k0 == ref_k) && (i1 >= nr || k1 == ref_k);
+        const bool uniform = __all(same) && ref_k > 0;
+        if (threadIdx.x == 0) { sh.unk = uniform ? ref_k : 0u; sh.unk_inv = uniform ? 1.0f / (float)ref_k : 0.0f; }
         if (i0 < nr) sh.wpre[i0] = (uint32_t)(rd.woff[r0 + i0] - w0);
         if (i1 < nr) sh.wpre[i1] = (uint32_t)(rd.woff[r0 + i1] - w0);
         if (threadIdx.x == 0) sh.wpre[nr] = (uint32_t)(rd.woff[r1] - w0);
@@ -275,6 +282,14 @@ __device__ __forceinline__ uint32_t stage_tile(TileShared &sh, const ReadsDev &r
 
 __device__ __forceinline__ void locate_kmer(const TileShared &sh, uint32_t nr, uint32_t q, uint32_t &r, uint32_t &i)
 {
+    if (sh.unk) {   // q < 2^16 here, so the float quotient is off by at most one
+        uint32_t rr = (uint32_t)((float)q * sh.unk_inv);
+        if (rr * sh.unk > q) rr -= 1;
+        else if ((rr + 1) * sh.unk <= q) rr += 1;
+        r = rr;
+        i = q - rr * sh.unk;
+        return;
+    }
     uint32_t lo = 0, hi = nr;  // largest r with kpre[r] <= q
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
