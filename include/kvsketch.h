@@ -121,6 +121,22 @@ int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t n_reads, k
  * Used by synthetic-read generators that never materialise ASCII.                        */
 int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, uint32_t read_len, kv_reads **out);
 int kv_reads_destroy(kv_reads *r);
+
+/* Native FASTA/FASTQ reader (gzip transparent) = khmer.ReadParser (kevlar/count.py:40,
+ * kevlar/__init__.py:125-128).  kv_fastx_next parses up to max_reads records; with upload != 0 the
+ * sequences are 2-bit packed into a new kv_reads batch in HBM (NULL at end of file).  The text of the
+ * batch just parsed (names = header lines after '@'/'>', sequences, qualities; blobs + n+1 offsets;
+ * is_fastq[i] = record had a quality line) stays valid until the next kv_fastx_next on the handle.
+ * One handle may be shared by several host threads (kevlar/count.py:41-76): kv_fastx_next is
+ * serialised, but then only the returned kv_reads -- not the shared batch text -- may be used.      */
+typedef struct kv_fastx kv_fastx;
+int kv_fastx_open(const char *path, kv_fastx **out);
+int kv_fastx_next(kv_fastx *f, uint64_t max_reads, int upload, kv_reads **reads_out, uint64_t *n_reads_out);
+int kv_fastx_batch_text(kv_fastx *f, const char **names, const uint64_t **name_offs, const char **seqs,
+                        const uint64_t **seq_offs, const char **quals, const uint64_t **qual_offs,
+                        const uint8_t **is_fastq);
+int kv_fastx_num_reads(kv_fastx *f, uint64_t *n); /* khmer parser.num_reads */
+int kv_fastx_close(kv_fastx *f);
 int kv_reads_count(const kv_reads *r, uint64_t *n_reads, uint64_t *n_bases);
 /* number of k-mers a consume of this batch visits at size k (sum over reads of len-k+1)   */
 int kv_reads_num_kmers(const kv_reads *r, int ksize, uint64_t *n_kmers);

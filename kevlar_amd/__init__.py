@@ -71,7 +71,19 @@ from kevlar_amd import unband  # noqa: E402
 from kevlar_amd import cli  # noqa: E402
 
 
-def multi_file_iter_khmer(filenames):
-    for filename in filenames:
-        for record in khmer.ReadParser(filename):
-            yield record
+class multi_file_iter_khmer(object):
+    """Records of several sequence files, one after the other (kevlar/__init__.py:125-128).
+    Iterating yields records; text_batches() hands the novel scan whole parsed batches instead."""
+
+    def __init__(self, filenames):
+        self.filenames = list(filenames)
+
+    def __iter__(self):
+        for filename in self.filenames:
+            for record in khmer.ReadParser(filename):
+                yield record
+
+    def text_batches(self, max_reads):
+        for filename in self.filenames:
+            for tb in khmer.ReadParser(filename).text_batches(max_reads):
+                yield tb

@@ -63,6 +63,13 @@ SIGNATURES = {
     'kv_reads_create': (i32, [cstr, u64p, u64, vpp]),
     'kv_reads_create_packed': (i32, [u32p, u64, u32, vpp]),
     'kv_reads_destroy': (i32, [vp]),
+    'kv_fastx_open': (i32, [cstr, vpp]),
+    'kv_fastx_next': (i32, [vp, u64, i32, vpp, u64p]),
+    'kv_fastx_batch_text': (i32, [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u64p), ctypes.POINTER(ctypes.c_void_p),
+                                  ctypes.POINTER(u64p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u64p),
+                                  ctypes.POINTER(u8p)]),
+    'kv_fastx_num_reads': (i32, [vp, u64p]),
+    'kv_fastx_close': (i32, [vp]),
     'kv_reads_count': (i32, [vp, u64p, u64p]),
     'kv_reads_num_kmers': (i32, [vp, i32, u64p]),
     'kv_consume': (i32, [vp, vp, i32, i32, vp, i32, i32, u64p]),

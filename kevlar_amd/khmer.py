@@ -151,34 +151,145 @@ def _iter_fastx(path):
                 raise ValueError('cannot parse sequence file ' + path)
 
 
+class TextBatch(object):
+    """One parsed batch: the packed reads in HBM (optional) plus the records' text as blobs.
+    Python Read objects are only built on demand (record(i))."""
+
+    def __init__(self, n, names, name_offs, seqs, seq_offs, quals, qual_offs, is_fastq, batch):
+        self.n = n
+        self._names, self._no = names, name_offs
+        self._seqs, self._so = seqs, seq_offs
+        self._quals, self._qo = quals, qual_offs
+        self._fq = is_fastq
+        self.batch = batch
+
+    def name(self, i):
+        return self._names[self._no[i]:self._no[i + 1]].decode('latin-1')
+
+    def sequence(self, i):
+        return self._seqs[self._so[i]:self._so[i + 1]].decode('latin-1')
+
+    def record(self, i):
+        qual = self._quals[self._qo[i]:self._qo[i + 1]].decode('latin-1') if self._fq[i] else None
+        return Read(self.name(i), self.sequence(i), qual)
+
+    def find_name(self, name):
+        """Index of the first record called `name`, or -1."""
+        raw = name.encode('latin-1')
+        start = 0
+        while True:
+            pos = self._names.find(raw, start)
+            if pos < 0:
+                return -1
+            i = int(np.searchsorted(self._no, pos, side='right')) - 1
+            if self._no[i] == pos and self._no[i + 1] - pos == len(raw):
+                return i
+            start = pos + 1
+
+
 class ReadParser(object):
-    """FASTA/FASTQ reader (gzip transparent); name = the header line after '@' or '>'.
+    """FASTA/FASTQ reader (gzip transparent) over the native parser (kv_fastx_*); name = the header
+    line after '@' or '>'.  Iteration yields Read objects (khmer's interface); the drivers use
+    take_batch()/text_batches(), which never build per-read Python objects.
 
     Iteration is thread-safe: kevlar/count.py:41-76 shares one parser between threads."""
 
     def __init__(self, filename):
-        self._iter = _iter_fastx(filename)
+        handle = ctypes.c_void_p()
+        check(_lib.load().kv_fastx_open(filename.encode(), ctypes.byref(handle)))
+        self._h = handle
         self._lock = threading.Lock()
-        self.num_reads = 0
+        self._pending = None
+        self._cursor = 0
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                _lib.load().kv_fastx_close(h)
+            except Exception:
+                pass
+
+    @property
+    def num_reads(self):
+        n = ctypes.c_uint64()
+        check(_lib.load().kv_fastx_num_reads(self._h, ctypes.byref(n)))
+        return n.value - (self._pending.n - self._cursor if self._pending is not None else 0)
+
+    def _next_text(self, max_reads, upload):
+        lib = _lib.load()
+        n = ctypes.c_uint64()
+        reads = ctypes.c_void_p()
+        check(lib.kv_fastx_next(self._h, max_reads, 1 if upload else 0, ctypes.byref(reads), ctypes.byref(n)))
+        if n.value == 0:
+            return None
+        batch = None
+        if upload:
+            batch = ReadBatch.__new__(ReadBatch)
+            batch._h = reads
+            batch.n_reads = n.value
+        return n.value, batch
+
+    def take_batch(self, max_reads):
+        """Next max_reads records as a ReadBatch in HBM (None at end of file); no text is copied."""
+        _lib.require_device()
+        with self._lock:
+            got = self._next_text(max_reads, True)
+        return None if got is None else got[1]
+
+    def text_batch(self, max_reads, upload=True):
+        """Next records as a TextBatch (text copied out of the parser; packed reads in HBM if upload)."""
+        if upload:
+            _lib.require_device()
+        lib = _lib.load()
+        with self._lock:
+            got = self._next_text(max_reads, upload)
+            if got is None:
+                return None
+            n, batch = got
+            vp, u64p, u8p = ctypes.c_void_p, _lib.u64p, _lib.u8p
+            names, seqs, quals = vp(), vp(), vp()
+            no, so, qo, fq = u64p(), u64p(), u64p(), u8p()
+            check(lib.kv_fastx_batch_text(self._h, ctypes.byref(names), ctypes.byref(no), ctypes.byref(seqs),
+                                          ctypes.byref(so), ctypes.byref(quals), ctypes.byref(qo), ctypes.byref(fq)))
+            name_offs = np.ctypeslib.as_array(no, shape=(n + 1,)).copy()
+            seq_offs = np.ctypeslib.as_array(so, shape=(n + 1,)).copy()
+            qual_offs = np.ctypeslib.as_array(qo, shape=(n + 1,)).copy()
+            is_fastq = np.ctypeslib.as_array(fq, shape=(n,)).copy()
+            tb = TextBatch(n, ctypes.string_at(names, int(name_offs[n])), name_offs,
+                           ctypes.string_at(seqs, int(seq_offs[n])), seq_offs,
+                           ctypes.string_at(quals, int(qual_offs[n])), qual_offs, is_fastq, batch)
+        return tb
+
+    def text_batches(self, max_reads, upload=True):
+        while True:
+            tb = self.text_batch(max_reads, upload)
+            if tb is None:
+                return
+            yield tb
 
     def __iter__(self):
         return self
 
     def __next__(self):
         with self._lock:
-            read = next(self._iter)
-            self.num_reads += 1
-            return read
+            pass
+        if self._pending is None or self._cursor >= self._pending.n:
+            self._pending = self.text_batch(4096, upload=False)
+            self._cursor = 0
+            if self._pending is None:
+                raise StopIteration
+        rec = self._pending.record(self._cursor)
+        self._cursor += 1
+        return rec
 
     def take(self, n):
-        """Up to n reads as a list (one lock acquisition)."""
+        """Up to n reads as a list of Read objects."""
         out = []
-        with self._lock:
-            for read in self._iter:
-                self.num_reads += 1
-                out.append(read)
-                if len(out) >= n:
-                    break
+        for read in self:
+            out.append(read)
+            if len(out) >= n:
+                break
         return out
 
 
@@ -432,12 +543,11 @@ class _Sketch(object):
             parser = ReadParser(parser)
         nreads = nkmers = 0
         while True:
-            reads = parser.take(BATCH_READS)
-            if not reads:
+            batch = parser.take_batch(BATCH_READS)     # parsed and packed natively, straight into HBM
+            if batch is None:
                 break
-            batch = ReadBatch([r.sequence for r in reads])
             nkmers += self.consume_batch(batch, nbands, band, mask, threshold, consume_masked)
-            nreads += len(reads)
+            nreads += batch.n_reads
         return nreads, nkmers
 
     def consume_seqfile(self, parser):

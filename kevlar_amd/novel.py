@@ -74,15 +74,39 @@ def save_counts(filelist, tablelist):
         counttable.save(outfile)
 
 
-def _batches(stream, size):
-    batch = []
-    for record in stream:
-        batch.append(record)
-        if len(batch) >= size:
-            yield batch
-            batch = []
-    if batch:
-        yield batch
+class _RecordBatch(object):
+    """Adapter giving a list of already-parsed records the interface of khmer.TextBatch."""
+
+    def __init__(self, records, ksize):
+        self.records = records
+        self.n = len(records)
+        self.batch = khmer.ReadBatch([r.sequence if len(r.sequence) >= ksize else '' for r in records])
+
+    def record(self, i):
+        return self.records[i]
+
+    def find_name(self, name):
+        for j, record in enumerate(self.records):
+            if record.name == name:
+                return j
+        return -1
+
+
+def _scan_batches(casestream, ksize, sketch_ksize, size):
+    """Batches of case reads, packed in HBM.  Streams that can hand over whole parsed batches
+    (kevlar_amd.multi_file_iter_khmer) skip per-read Python objects altogether."""
+    if hasattr(casestream, 'text_batches') and ksize == sketch_ksize:
+        for tb in casestream.text_batches(size):
+            yield tb
+        return
+    chunk = []
+    for record in casestream:
+        chunk.append(record)
+        if len(chunk) >= size:
+            yield _RecordBatch(chunk, ksize)
+            chunk = []
+    if chunk:
+        yield _RecordBatch(chunk, ksize)
 
 
 def novel(casestream, casecounts, controlcounts, ksize=31, abundscreen=None, casemin=5, ctrlmax=0,
@@ -116,44 +140,35 @@ def novel(casestream, casecounts, controlcounts, ksize=31, abundscreen=None, cas
     if numbands:
         band_mode = KV_BAND_REFQUIRK if refbandquirk else KV_BAND_RANGE
     nseen = 0
+    k = casecounts[0].ksize() if casecounts else ksize
 
-    for records in _batches(casestream, batchsize):
-        progress.update(len(records))
+    for tb in _scan_batches(casestream, ksize, k, batchsize):
+        progress.update(tb.n)
+        first_read = 0
         if skipuntil:
             # reads up to and including the named one are skipped (kevlar/novel.py:124-132)
-            found = None
-            for j, record in enumerate(records):
-                if record.name == skipuntil:
-                    found = j
-                    break
-            if found is None:
-                nseen += len(records)
+            found = tb.find_name(skipuntil)
+            if found < 0:
+                nseen += tb.n
+                tb.batch.close()
                 continue
             message = 'Found read {:s} (skipped {:d} reads)'.format(skipuntil, nseen + found + 1)
             kevlar_amd.plog('[kevlar::novel]', message)
             skipuntil = False
             progress.message = update_message
-            nseen += len(records)
-            records = records[found + 1:]
-            if not records:
-                continue
-        else:
-            nseen += len(records)
-
-        seqs = [r.sequence if len(r.sequence) >= ksize else '' for r in records]
-        batch = khmer.ReadBatch(seqs)
+            first_read = found + 1
+        nseen += tb.n
         hitread, hitoff, hitabund, _ = khmer.novel_scan(
-            casecounts, controlcounts, batch, casemin, ctrlmax, screen=abundscreen,
-            band_mode=band_mode, nbands=numbands or 0, band=band or 0)
-        batch.close()
+            casecounts, controlcounts, tb.batch, casemin, ctrlmax, screen=abundscreen,
+            band_mode=band_mode, nbands=numbands or 0, band=band or 0, first_read=first_read)
+        tb.batch.close()
         if len(hitread) == 0:
             continue
-        k = casecounts[0].ksize()
         bounds = np.flatnonzero(np.diff(hitread)) + 1
         starts = np.concatenate(([0], bounds))
         ends = np.concatenate((bounds, [len(hitread)]))
         for s, e in zip(starts, ends):
-            record = records[int(hitread[s])]
+            record = tb.record(int(hitread[s]))
             irecord = kevlar_amd.sequence.copy_record(record)
             for j in range(s, e):
                 offset = int(hitoff[j])

@@ -293,3 +293,31 @@ def test_readgraph_strict_mode_edges_and_cli(tmp_path):
     assert merged_sequence(a, brc, k) is not None
     c = Record('c', 'GATTAGGGGCGTGACTTAATAAGGTGTGGGCCTAAGCGACTAACGTTTAC', annotations=[KmerOfInterest(19, 6, (20, 0, 0))])
     assert merged_sequence(a, c, k) is None
+
+
+def test_native_fastx_reader_matches_record_parser(ok, tmp_path):
+    """kv_fastx_* (zlib + C++ record splitter) vs the oracle's plain Python reader on the reference's
+    own FASTA/FASTQ fixtures, plus CRLF / no-trailing-newline / blank-line handling."""
+    from kevlar_amd import khmer
+    files = ['trio1/case1.fq.gz', 'bogus-genome/refr.fa', 'simple-genome-case-reads.fa.gz', 'ambig.fasta',
+             'screen-case.fa', 'microtrios/trio-li-proband.fq.gz', 'bogus-genome/mask-chr1.fa']
+    for rel in files:
+        got = [(r.name, r.sequence, r.quality) for r in khmer.ReadParser(data_file(rel))]
+        want = [(r.name, r.sequence, r.quality) for r in ok.ReadParser(data_file(rel))]
+        assert got == want and len(got) > 0, rel
+        parser = khmer.ReadParser(data_file(rel))
+        total = sum(tb.n for tb in parser.text_batches(1000, upload=False))
+        assert total == len(want) == parser.num_reads
+    odd = tmp_path / 'odd.fx'
+    odd.write_bytes(b'>s1 desc\r\nACGT\r\nAC GT \r\n\r\n@q1\r\nGATTACA\r\n+\r\n@@@IIII\r\n>s2\nTT\nGG')
+    got = [(r.name, r.sequence, r.quality) for r in khmer.ReadParser(str(odd))]
+    assert got == [('s1 desc', 'ACGTAC GT', None), ('q1', 'GATTACA', '@@@IIII'), ('s2', 'TTGG', None)]
+    tb = khmer.ReadParser(data_file('trio1/case1.fq.gz')).text_batch(5000, upload=False)
+    assert tb.find_name('bogus-genome-chr1_115_449_0:0:0_0:0:0_1f4/1') == 1000
+    assert tb.find_name('bogus-genome-chr1_115_449') == -1 and tb.record(1000).name.endswith('1f4/1')
+    with pytest.raises(OSError):
+        khmer.ReadParser(str(tmp_path / 'missing.fq'))
+    bad = tmp_path / 'bad.fq'
+    bad.write_text('ACGT\n')
+    with pytest.raises(OSError):
+        list(khmer.ReadParser(str(bad)))
