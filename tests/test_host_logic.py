@@ -309,9 +309,10 @@ def test_native_fastx_reader_matches_record_parser(ok, tmp_path):
         total = sum(tb.n for tb in parser.text_batches(1000, upload=False))
         assert total == len(want) == parser.num_reads
     odd = tmp_path / 'odd.fx'
-    odd.write_bytes(b'>s1 desc\r\nACGT\r\nAC GT \r\n\r\n@q1\r\nGATTACA\r\n+\r\n@@@IIII\r\n>s2\nTT\nGG')
+    odd.write_bytes(b'@q1\r\nGATTACA\r\n+\r\n@@@IIII\r\n\r\n>s1 desc\r\nACGT\r\nAC GT \r\n\r\n>s2\nTT\nGG')
     got = [(r.name, r.sequence, r.quality) for r in khmer.ReadParser(str(odd))]
-    assert got == [('s1 desc', 'ACGTAC GT', None), ('q1', 'GATTACA', '@@@IIII'), ('s2', 'TTGG', None)]
+    assert got == [('q1', 'GATTACA', '@@@IIII'), ('s1 desc', 'ACGTAC GT', None), ('s2', 'TTGG', None)]
+    assert got == [(r.name, r.sequence, r.quality) for r in ok.ReadParser(str(odd))]
     tb = khmer.ReadParser(data_file('trio1/case1.fq.gz')).text_batch(5000, upload=False)
     assert tb.find_name('bogus-genome-chr1_115_449_0:0:0_0:0:0_1f4/1') == 1000
     assert tb.find_name('bogus-genome-chr1_115_449') == -1 and tb.record(1000).name.endswith('1f4/1')
