@@ -125,7 +125,7 @@ __device__ __forceinline__ void rings_store_counts(uint32_t ns, uint32_t written
 }
 
 // ---- stage A -----------------------------------------------------------------------------
-template <int THREADS, int KPT>
+template <int THREADS, int NW>
 __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash(   // 3 x 8 waves (or 1 x 16) per CU must fit the register file
     ReadsDev rd, uint32_t n_tiles, const SketchDev *__restrict__ sk,
                                                       const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
@@ -156,42 +156,60 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash(
         uint32_t read0;
         const uint32_t nr = stage_tile(sh, rd, tile, f.hp.k, 0, 0, read0);
         const uint32_t total = sh.kpre[nr];
-        for (uint32_t q0 = 0; q0 < total; q0 += THREADS * KPT) {
-#pragma unroll
-            for (int rep = 0; rep < KPT; ++rep) {
-                const uint32_t q = q0 + (uint32_t)rep * THREADS + threadIdx.x;
-                if (q >= total) continue;
-                uint32_t r, i;
-                locate_kmer(sh, nr, q, r, i);
-                const uint32_t fwd = sh.foff[r] + i;
-                const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)f.hp.k - i);
-                const uint64_t h = kmer_hash_lds(sh.ascii, fwd, rc, f.hp);
-                if (!consume_filter_pass(f, mask, h)) continue;
-                n_added += 1;
-                // all T ring positions are requested back to back (independent LDS atomics in flight
-                // together) before any of them is consumed
-                uint32_t sidx[BIN_MAX_T], item[BIN_MAX_T], pos[BIN_MAX_T];
-                uint64_t bins[BIN_MAX_T];
-#pragma unroll
-                for (int t = 0; t < BIN_MAX_T; ++t) {
-                    if (t >= g.T) break;
-                    const uint64_t bin = fastmod(h, sk->size[t], sk->magic[t]);
-                    const uint32_t slice = (uint32_t)(bin >> 16);
-                    const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
-                    bins[t] = bin;
-                    item[t] = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu);
-                    sidx[t] = (uint32_t)t * (uint32_t)g.C + c;
+        // every thread owns a run of consecutive k-mers (rolling register windows when NW > 0); one
+        // k-mer per thread per round, then the workgroup flushes its rings
+        const uint32_t run = (total + THREADS - 1) / THREADS;
+        const uint32_t q0 = threadIdx.x * run, q1 = min(total, q0 + run);
+        KmerRoll<(NW > 0 ? NW : 8)> w;
+        if (NW > 0 && q0 < q1) {
+            locate_kmer(sh, nr, q0, w.r, w.i);
+            roll_load(w, sh, f.hp.k);
+        }
+        for (uint32_t step = 0; step < run; ++step) {
+            const uint32_t q = NW > 0 ? q0 + step : step * THREADS + threadIdx.x;
+            const bool live = NW > 0 ? q < q1 : q < total;
+            if (live) {
+                uint64_t h;
+                if (NW > 0) {
+                    h = roll_hash(w, f.hp);
+                    if (q + 1 < q1) roll_step(w, sh, nr, f.hp.k);
+                } else {
+                    uint32_t r, i;
+                    locate_kmer(sh, nr, q, r, i);
+                    const uint32_t fwd = sh.foff[r] + i;
+                    const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)f.hp.k - i);
+                    h = kmer_hash_lds(sh.ascii, fwd, rc, f.hp);
                 }
-                if (g.debug & 1u) { n_added += item[0] & 1u; continue; }
+                if (consume_filter_pass(f, mask, h)) {
+                    n_added += 1;
+                    // all T ring positions are requested back to back (independent LDS atomics in flight
+                    // together) before any of them is consumed
+                    uint32_t sidx[BIN_MAX_T], item[BIN_MAX_T], pos[BIN_MAX_T];
+                    uint64_t bins[BIN_MAX_T];
 #pragma unroll
-                for (int t = 0; t < BIN_MAX_T; ++t)
-                    if (t < g.T) pos[t] = atomicAdd(&rs.cnt[sidx[t]], 1u);
+                    for (int t = 0; t < BIN_MAX_T; ++t) {
+                        if (t >= g.T) break;
+                        const uint64_t bin = fastmod(h, sk->size[t], sk->magic[t]);
+                        const uint32_t slice = (uint32_t)(bin >> 16);
+                        const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
+                        bins[t] = bin;
+                        item[t] = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu);
+                        sidx[t] = (uint32_t)t * (uint32_t)g.C + c;
+                    }
+                    if (!(g.debug & 1u)) {
 #pragma unroll
-                for (int t = 0; t < BIN_MAX_T; ++t) {
-                    if (t >= g.T) break;
-                    const uint32_t s_ = sidx[t];
-                    if (pos[t] - rs.base[s_] < rs.R) rs.ring[s_ * rs.R + ((pos[t] + s_) & (rs.R - 1))] = item[t];
-                    else spill_item(g, t, bins[t]);
+                        for (int t = 0; t < BIN_MAX_T; ++t)
+                            if (t < g.T) pos[t] = atomicAdd(&rs.cnt[sidx[t]], 1u);
+#pragma unroll
+                        for (int t = 0; t < BIN_MAX_T; ++t) {
+                            if (t >= g.T) break;
+                            const uint32_t s_ = sidx[t];
+                            if (pos[t] - rs.base[s_] < rs.R) rs.ring[s_ * rs.R + ((pos[t] + s_) & (rs.R - 1))] = item[t];
+                            else spill_item(g, t, bins[t]);
+                        }
+                    } else {
+                        n_added += item[0] & 1u;
+                    }
                 }
             }
             __syncthreads();
@@ -535,19 +553,24 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
         KvProfScope prof("k_bin_hash");
         const size_t lds = (size_t)g.tile_lds + ns * g.ringA * 4 + ns * 8;
         const unsigned grid = g.nwgA;
-        if (cmax == 16) {
-            ensure_dynamic_lds(k_bin_hash<512, 2>, lds);
-            hipLaunchKernelGGL((k_bin_hash<512, 2>), dim3(grid), dim3(512), lds, st, reads_dev(reads), reads->n_tiles,
-                               (const SketchDev *)s->d_desc, d_mask, filter, g);
-        } else if (cmax == 32) {
-            ensure_dynamic_lds(k_bin_hash<512, 1>, lds);
-            hipLaunchKernelGGL((k_bin_hash<512, 1>), dim3(grid), dim3(512), lds, st, reads_dev(reads), reads->n_tiles,
-                               (const SketchDev *)s->d_desc, d_mask, filter, g);
+        const int k = s->h.ksize;
+        const int nw = (s->h.hashfam == HF_MURMUR && !getenv("KV_NO_ROLL")) ? (k <= 32 ? 8 : (k <= 64 ? 16 : 0)) : 0;
+#define KV_LAUNCH_BIN_HASH(THREADS_, NW_)                                                                         \
+        do {                                                                                                      \
+            ensure_dynamic_lds(k_bin_hash<THREADS_, NW_>, lds);                                                   \
+            hipLaunchKernelGGL((k_bin_hash<THREADS_, NW_>), dim3(grid), dim3(THREADS_), lds, st, reads_dev(reads), \
+                               reads->n_tiles, (const SketchDev *)s->d_desc, d_mask, filter, g);                  \
+        } while (0)
+        if (cmax <= 32) {
+            if (nw == 8) KV_LAUNCH_BIN_HASH(512, 8);
+            else if (nw == 16) KV_LAUNCH_BIN_HASH(512, 16);
+            else KV_LAUNCH_BIN_HASH(512, 0);
         } else {
-            ensure_dynamic_lds(k_bin_hash<1024, 1>, lds);
-            hipLaunchKernelGGL((k_bin_hash<1024, 1>), dim3(grid), dim3(1024), lds, st, reads_dev(reads), reads->n_tiles,
-                               (const SketchDev *)s->d_desc, d_mask, filter, g);
+            if (nw == 8) KV_LAUNCH_BIN_HASH(1024, 8);
+            else if (nw == 16) KV_LAUNCH_BIN_HASH(1024, 16);
+            else KV_LAUNCH_BIN_HASH(1024, 0);
         }
+#undef KV_LAUNCH_BIN_HASH
     }
     {
         KvProfScope prof("k_bin_split");

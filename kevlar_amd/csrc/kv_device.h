@@ -328,6 +328,91 @@ inline ReadsDev reads_dev(const kv_reads *r)
 }
 
 
+
+// ---------------------------------------------------------------------------------------
+// Rolling k-mer windows (k <= 4*NW - 1 + 1): each thread walks a RUN of consecutive k-mers.
+// The k-mer's ASCII bytes live in registers, byte 0 of w[0] = first base, so murmur reads its
+// words directly; moving to the next k-mer is one byte-shift per dword plus ONE LDS byte per
+// strand, instead of 2 x (k/4 + 2) LDS dwords and a k-mer -> read search per k-mer.
+// ---------------------------------------------------------------------------------------
+template <int NW>
+struct KmerRoll {
+    uint32_t wf[NW], wr[NW];
+    uint32_t r, i, nk_r;        // read slot, offset of the current k-mer, k-mers of this read
+    uint32_t fa, ra;            // LDS byte address of the forward / reverse-complement k-mer
+};
+
+template <int NW>
+__device__ __forceinline__ void roll_load(KmerRoll<NW> &w, const TileShared &sh, int k)
+{
+    w.nk_r = sh.kpre[w.r + 1] - sh.kpre[w.r];
+    w.fa = sh.foff[w.r] + w.i;
+    w.ra = sh.roff[w.r] + (sh.len[w.r] - (uint32_t)k - w.i);
+    {
+        const uint32_t s = w.fa & 3u;
+        const uint32_t *p = sh.ascii + (w.fa >> 2);
+        uint32_t prev = p[0];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) { const uint32_t nxt = p[j + 1]; w.wf[j] = __builtin_amdgcn_alignbyte(nxt, prev, s); prev = nxt; }
+    }
+    {
+        const uint32_t s = w.ra & 3u;
+        const uint32_t *p = sh.ascii + (w.ra >> 2);
+        uint32_t prev = p[0];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) { const uint32_t nxt = p[j + 1]; w.wr[j] = __builtin_amdgcn_alignbyte(nxt, prev, s); prev = nxt; }
+    }
+}
+
+// advance to the next k-mer of the tile (flat order); reloads at read boundaries
+template <int NW>
+__device__ __forceinline__ void roll_step(KmerRoll<NW> &w, const TileShared &sh, uint32_t nr, int k)
+{
+    w.i += 1;
+    if (w.i >= w.nk_r) {
+        w.i = 0;
+        do { w.r += 1; } while (w.r < nr && sh.kpre[w.r + 1] == sh.kpre[w.r]);
+        if (w.r < nr) roll_load(w, sh, k);
+        return;
+    }
+    const uint32_t nf = lds_byte(sh.ascii, w.fa + 4u * NW);      // byte entering the forward window at the top
+    const uint32_t nb = lds_byte(sh.ascii, w.ra - 1u);           // byte entering the reverse window at the bottom
+    w.fa += 1; w.ra -= 1;
+#pragma unroll
+    for (int j = 0; j < NW - 1; ++j) w.wf[j] = __builtin_amdgcn_alignbyte(w.wf[j + 1], w.wf[j], 1);
+    w.wf[NW - 1] = (w.wf[NW - 1] >> 8) | (nf << 24);
+#pragma unroll
+    for (int j = NW - 1; j > 0; --j) w.wr[j] = __builtin_amdgcn_alignbyte(w.wr[j], w.wr[j - 1], 3);
+    w.wr[0] = (w.wr[0] << 8) | nb;
+}
+
+template <int NW>
+__device__ __forceinline__ uint64_t murmur_regs(const uint32_t (&w)[NW], const HashParams &hp)
+{
+    uint64_t h1 = 0, h2 = 0;
+#pragma unroll
+    for (int b = 0; b < NW / 4; ++b) {
+        if (b < hp.nblocks) {
+            mm_block(h1, h2, (uint64_t)w[4 * b] | ((uint64_t)w[4 * b + 1] << 32),
+                     (uint64_t)w[4 * b + 2] | ((uint64_t)w[4 * b + 3] << 32));
+        } else if (b == hp.nblocks && hp.rem > 0) {
+            if (hp.rem > 8) {
+                uint64_t k2 = ((uint64_t)w[4 * b + 2] | ((uint64_t)w[4 * b + 3] << 32)) & hp.m2;
+                k2 *= MM_C2; k2 = rotl64(k2, 33); k2 *= MM_C1; h2 ^= k2;
+            }
+            uint64_t k1 = ((uint64_t)w[4 * b] | ((uint64_t)w[4 * b + 1] << 32)) & hp.m1;
+            k1 *= MM_C1; k1 = rotl64(k1, 31); k1 *= MM_C2; h1 ^= k1;
+        }
+    }
+    return mm_final(h1, h2, hp.k);
+}
+
+template <int NW>
+__device__ __forceinline__ uint64_t roll_hash(const KmerRoll<NW> &w, const HashParams &hp)
+{
+    return murmur_regs<NW>(w.wf, hp) ^ murmur_regs<NW>(w.wr, hp);
+}
+
 __device__ __forceinline__ bool consume_filter_pass(const ConsumeFilter &f, const SketchDev *mask, uint64_t h)
 {
     if (f.use_band && !(h >= f.band_lo && h < f.band_hi)) return false;

@@ -587,7 +587,7 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
         }
         if (n_reads) tiles.push_back((uint32_t)n_reads);
         r->n_tiles = (uint32_t)tiles.size() - 1;
-        r->tile_lds_bytes = std::max<uint32_t>(KV_TILE_LDS_BYTES, (biggest + 64 + 255) & ~255u);
+        r->tile_lds_bytes = std::max<uint32_t>(KV_TILE_LDS_BYTES, (biggest + 64 + 255) & ~255u) + 256;   // + rolling-window over-read
     }
     hipError_t e = hipMalloc((void **)&r->d_words, words.size() * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
@@ -628,7 +628,7 @@ extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, u
     for (uint64_t i = 0; i < n_reads; i += per_tile) tiles.push_back((uint32_t)i);
     tiles.push_back((uint32_t)n_reads);
     r->n_tiles = n_reads ? (uint32_t)tiles.size() - 1 : 0;
-    r->tile_lds_bytes = std::max<uint32_t>(KV_TILE_LDS_BYTES, (per_tile * need + 64 + 255) & ~255u);
+    r->tile_lds_bytes = std::max<uint32_t>(KV_TILE_LDS_BYTES, (per_tile * need + 64 + 255) & ~255u) + 256;
     hipError_t e = hipMalloc((void **)&r->d_words, (r->n_words ? r->n_words : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);

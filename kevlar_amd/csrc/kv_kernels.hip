@@ -18,6 +18,7 @@ namespace {
 // ---------------------------------------------------------------------------------------
 // K2 consume: sketch.consume_seqfile[_banding][_with_mask]  (kevlar/count.py:43-71)
 // ---------------------------------------------------------------------------------------
+template <int NW>
 __global__ __launch_bounds__(KV_TILE_THREADS) void k_consume(ReadsDev rd, const SketchDev *__restrict__ sk,
                                                             const SketchDev *__restrict__ mask, ConsumeFilter p,
                                                             uint64_t *counters)
@@ -29,15 +30,34 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_consume(ReadsDev rd, const 
     const uint32_t nr = stage_tile(sh, rd, blockIdx.x, p.hp.k, 0, 0, read0);
     const uint32_t total = sh.kpre[nr];
     uint64_t n_added = 0, n_new = 0;
-    for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
-        uint32_t r, i;
-        locate_kmer(sh, nr, q, r, i);
-        const uint32_t fwd = sh.foff[r] + i;
-        const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)p.hp.k - i);
-        const uint64_t h = kmer_hash_lds(sh.ascii, fwd, rc, p.hp);
-        if (!consume_filter_pass(p, mask, h)) continue;
-        n_new += sketch_add(sk, h) ? 1 : 0;
-        n_added += 1;
+    if (NW > 0) {
+        // every thread owns a run of consecutive k-mers and rolls its register windows along it
+        const uint32_t run = (total + blockDim.x - 1) / blockDim.x;
+        const uint32_t q0 = threadIdx.x * run, q1 = min(total, q0 + run);
+        if (q0 < q1) {
+            KmerRoll<(NW > 0 ? NW : 8)> w;
+            locate_kmer(sh, nr, q0, w.r, w.i);
+            roll_load(w, sh, p.hp.k);
+            for (uint32_t q = q0; q < q1; ++q) {
+                const uint64_t h = roll_hash(w, p.hp);
+                if (consume_filter_pass(p, mask, h)) {
+                    n_new += sketch_add(sk, h) ? 1 : 0;
+                    n_added += 1;
+                }
+                if (q + 1 < q1) roll_step(w, sh, nr, p.hp.k);
+            }
+        }
+    } else {
+        for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
+            uint32_t r, i;
+            locate_kmer(sh, nr, q, r, i);
+            const uint32_t fwd = sh.foff[r] + i;
+            const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)p.hp.k - i);
+            const uint64_t h = kmer_hash_lds(sh.ascii, fwd, rc, p.hp);
+            if (!consume_filter_pass(p, mask, h)) continue;
+            n_new += sketch_add(sk, h) ? 1 : 0;
+            n_added += 1;
+        }
     }
     n_added = wave_sum_u64(n_added);
     n_new = wave_sum_u64(n_new);
@@ -189,10 +209,19 @@ extern "C" int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int b
     KV_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(uint64_t), kv_stream()));
     if (reads->n_tiles > 0) {
         KvProfScope prof("k_consume");
-        kv_ensure_dynamic_lds((const void *)k_consume, reads->tile_lds_bytes);
-        hipLaunchKernelGGL(k_consume, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, kv_stream(), reads_dev(reads),
-                           (const SketchDev *)s->d_desc, (const SketchDev *)(mask ? mask->d_desc : nullptr), p,
-                           s->d_counters);
+        const SketchDev *dm = mask ? mask->d_desc : nullptr;
+        const unsigned lds = reads->tile_lds_bytes;
+        const bool roll = s->h.hashfam == HF_MURMUR && !getenv("KV_NO_ROLL");
+#define KV_LAUNCH_CONSUME(NW_)                                                                                   \
+        do {                                                                                                     \
+            kv_ensure_dynamic_lds((const void *)k_consume<NW_>, lds);                                            \
+            hipLaunchKernelGGL((k_consume<NW_>), dim3(reads->n_tiles), dim3(KV_TILE_THREADS), lds, kv_stream(), \
+                               reads_dev(reads), (const SketchDev *)s->d_desc, dm, p, s->d_counters);            \
+        } while (0)
+        if (roll && s->h.ksize <= 32) KV_LAUNCH_CONSUME(8);
+        else if (roll && s->h.ksize <= 64) KV_LAUNCH_CONSUME(16);
+        else KV_LAUNCH_CONSUME(0);
+#undef KV_LAUNCH_CONSUME
     }
     KV_HIP(hipGetLastError());
     uint64_t c[2] = {0, 0};
