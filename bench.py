@@ -226,6 +226,8 @@ def main():
                                 args.case_min, args.ctrl_max),
                 'parallelism': 'single band' if world == 1 else '{} k-mer bands, 1 per GPU'.format(world),
                 'interesting_kmer_instances': nhits, 'host_generate_pack_upload_s': round(gen_s, 1),
+                'device': '{} ({} CUs)'.format(torch.cuda.get_device_properties(dev_index).name,
+                                               torch.cuda.get_device_properties(dev_index).multi_processor_count),
             },
             'roofline': roofline,
             'cpu_baseline': cpu,

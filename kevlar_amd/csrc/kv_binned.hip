@@ -88,9 +88,13 @@ __device__ __forceinline__ bool ring_append(const Rings<ItemT> &rs, uint32_t s, 
 }
 
 // `written` is the owning lane's count of items already flushed for ITS stream (one stream per
-// lane: callers guarantee ns <= 64 * waves), i.e. the position inside the private segment.
-template <typename ItemT, typename Emit>
-__device__ __forceinline__ void rings_flush(const Rings<ItemT> &rs, uint32_t ns, bool final, uint32_t &written, Emit emit)
+// lane: callers guarantee ns <= 64 * waves), i.e. the position inside the private segment whose
+// first element index the same lane holds in `seg_base`.  Bursts are copied two at a time, one per
+// half-wave (a burst is 32-48 items, so a whole wave per burst would idle half its lanes), and all
+// per-burst parameters travel by v_readlane: the flush phase is instruction-bound, not bandwidth-bound.
+template <typename ItemT, typename Store, typename Overflow>
+__device__ __forceinline__ void rings_flush(const Rings<ItemT> &rs, uint32_t ns, bool final, uint32_t &written,
+                                            uint64_t seg_base, uint32_t cap, Store store, Overflow overflow)
 {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
     const uint32_t per_wave = (ns + nwaves - 1) / nwaves;             // <= 64
@@ -106,13 +110,30 @@ __device__ __forceinline__ void rings_flush(const Rings<ItemT> &rs, uint32_t ns,
         else if (avail >= rs.R / 2) { n = avail & ~15u; newbase = base + n; }
         if (n) { pos = written; written += n; rs.base[s] = newbase; }
     }
+    const uint32_t seg_lo = (uint32_t)seg_base, seg_hi = (uint32_t)(seg_base >> 32);
+    const bool upper = lane >= 32;
+    const uint32_t sub = lane & 31u;
     unsigned long long todo = __ballot(n > 0);
     while (todo) {
-        const int l = __ffsll((long long)todo) - 1;
+        const int l0 = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        const uint32_t sl = s0 + (uint32_t)l;   // l is wave-uniform: v_readlane, not an LDS permute
-        const uint32_t nl = __builtin_amdgcn_readlane(n, l), bl = __builtin_amdgcn_readlane(base, l), pl = __builtin_amdgcn_readlane(pos, l);
-        for (uint32_t j = lane; j < nl; j += 64) emit(sl, pl + j, rs.ring[sl * rs.R + ((bl + j + sl) & (rs.R - 1))]);
+        const int l1 = todo ? __ffsll((long long)todo) - 1 : l0;
+        const bool two = todo != 0;
+        if (two) todo &= todo - 1;
+        // wave-uniform lane indices: v_readlane, not an LDS permute
+        const uint32_t n0 = __builtin_amdgcn_readlane(n, l0), n1 = two ? __builtin_amdgcn_readlane(n, l1) : 0u;
+        const uint32_t b0 = __builtin_amdgcn_readlane(base, l0), b1 = __builtin_amdgcn_readlane(base, l1);
+        const uint32_t p0 = __builtin_amdgcn_readlane(pos, l0), p1 = __builtin_amdgcn_readlane(pos, l1);
+        const uint32_t g0l = __builtin_amdgcn_readlane(seg_lo, l0), g1l = __builtin_amdgcn_readlane(seg_lo, l1);
+        const uint32_t g0h = __builtin_amdgcn_readlane(seg_hi, l0), g1h = __builtin_amdgcn_readlane(seg_hi, l1);
+        const uint32_t sl = s0 + (uint32_t)(upper ? l1 : l0);
+        const uint32_t nl = upper ? n1 : n0, bl = upper ? b1 : b0, pl = upper ? p1 : p0;
+        const uint64_t gl = ((uint64_t)(upper ? g1h : g0h) << 32) | (upper ? g1l : g0l);
+        for (uint32_t j = sub; j < nl; j += 32) {
+            const ItemT item = rs.ring[sl * rs.R + ((bl + j + sl) & (rs.R - 1))];
+            if (pl + j < cap) store(gl + pl + j, item);
+            else overflow(sl, item);
+        }
     }
 }
 
@@ -142,17 +163,28 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash(
     for (uint32_t s = threadIdx.x; s < ns; s += THREADS) { rs.cnt[s] = 0; rs.base[s] = 0; }
     __syncthreads();
     uint32_t written = 0;
-    auto emit = [&](uint32_t s, uint32_t pos, uint32_t item) {
-        if (g.debug & 2u) return;
-        if (pos < g.cap1) {
-            g.gbuf1[((uint64_t)s * g.nwgA + blockIdx.x) * g.cap1 + pos] = item;
-        } else {   // private segment full: keep the increment, apply it later with an atomic
-            const uint32_t t = s / (uint32_t)g.C, c = s % (uint32_t)g.C;
-            spill_item(g, (int)t, (((uint64_t)c * g.F + (item >> 16)) << 16) | (item & 0xffffu));
-        }
+    uint64_t seg_base = 0;        // element index of this lane's private segment (lane <-> stream as in rings_flush)
+    {
+        const uint32_t nwaves = THREADS >> 6, per_wave = (ns + nwaves - 1) / nwaves;
+        const uint32_t mine = (threadIdx.x >> 6) * per_wave + (threadIdx.x & 63);
+        if ((threadIdx.x & 63) < per_wave && mine < ns) seg_base = ((uint64_t)mine * g.nwgA + blockIdx.x) * g.cap1;
+    }
+    auto store = [&](uint64_t idx, uint32_t item) { if (!(g.debug & 2u)) g.gbuf1[idx] = item; };
+    auto overflow = [&](uint32_t s, uint32_t item) {   // private segment full: keep the increment, apply it later with an atomic
+        const uint32_t t = s / (uint32_t)g.C, c = s % (uint32_t)g.C;
+        spill_item(g, (int)t, (((uint64_t)c * g.F + (item >> 16)) << 16) | (item & 0xffffu));
     };
     uint64_t n_added = 0;
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // tiles are handed out dynamically (one global atomic per tile): a workgroup that becomes resident
+    // late, or shares its CU with fewer siblings, simply takes fewer -- a static deal is hostage to the
+    // slowest workgroup, which showed as 46 vs 64 ms for the same launch on different boxes
+    __shared__ uint32_t next_tile;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) next_tile = (uint32_t)atomicAdd(&g.ctr[4], 1ull);
+        __syncthreads();
+        const uint32_t tile = next_tile;
+        if (tile >= n_tiles) break;
         uint32_t read0;
         const uint32_t nr = stage_tile(sh, rd, tile, f.hp.k, 0, 0, read0);
         const uint32_t total = sh.kpre[nr];
@@ -213,11 +245,11 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash(
                 }
             }
             __syncthreads();
-            rings_flush(rs, ns, false, written, emit);
+            rings_flush(rs, ns, false, written, seg_base, (uint32_t)g.cap1, store, overflow);
             __syncthreads();
         }
     }
-    rings_flush(rs, ns, true, written, emit);
+    rings_flush(rs, ns, true, written, seg_base, (uint32_t)g.cap1, store, overflow);
     rings_store_counts(ns, written, (uint32_t)g.cap1, g.gcnt1, g.nwgA, blockIdx.x);
     n_added = wave_sum_u64(n_added);
     if ((threadIdx.x & 63) == 0 && n_added) atomicAdd(&g.ctr[2], (unsigned long long)n_added);
@@ -238,10 +270,14 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
     for (uint32_t i = threadIdx.x; i < F; i += BIN_B_THREADS) { rs.cnt[i] = 0; rs.base[i] = 0; }
     __syncthreads();
     uint32_t written = 0;
-    auto emit = [&](uint32_t fi, uint32_t pos, uint16_t off) {
-        if (pos < g.cap2) g.gbuf2[(((uint64_t)s * F + fi) * g.nwgB + blockIdx.x) * g.cap2 + pos] = off;
-        else spill_item(g, (int)t, (((uint64_t)c * F + fi) << 16) | off);
-    };
+    uint64_t seg_base = 0;
+    {
+        const uint32_t nwaves = BIN_B_THREADS >> 6, per_wave = (F + nwaves - 1) / nwaves;
+        const uint32_t mine = (threadIdx.x >> 6) * per_wave + (threadIdx.x & 63);
+        if ((threadIdx.x & 63) < per_wave && mine < F) seg_base = (((uint64_t)s * F + mine) * g.nwgB + blockIdx.x) * g.cap2;
+    }
+    auto store = [&](uint64_t idx, uint16_t off) { g.gbuf2[idx] = off; };
+    auto overflow = [&](uint32_t fi, uint16_t off) { spill_item(g, (int)t, (((uint64_t)c * F + fi) << 16) | off); };
     const uint64_t step = (uint64_t)BIN_B_THREADS * BIN_B_ITEMS;
     // this workgroup drains the private segments seg = blockIdx.x, blockIdx.x + nwgB, ... of bucket s
     for (uint32_t seg = blockIdx.x; seg < g.nwgA; seg += g.nwgB) {
@@ -274,11 +310,11 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
                 }
             }
             __syncthreads();
-            rings_flush(rs, F, false, written, emit);
+            rings_flush(rs, F, false, written, seg_base, (uint32_t)g.cap2, store, overflow);
             __syncthreads();
         }
     }
-    rings_flush(rs, F, true, written, emit);
+    rings_flush(rs, F, true, written, seg_base, (uint32_t)g.cap2, store, overflow);
     rings_store_counts(F, written, (uint32_t)g.cap2, g.gcnt2 + (uint64_t)s * F * g.nwgB, g.nwgB, blockIdx.x);
 }
 
@@ -532,7 +568,7 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
     const double per_slice = expected * std::min(1.0, 65536.0 / (double)pmin);
     g.nwgB = (uint32_t)std::max(1.0, std::min((double)std::min<uint32_t>(g.nwgA, 512), std::ceil(per_bucket / 524288.0)));
     const double m1 = per_bucket / g.nwgA, m2 = per_slice / g.nwgB;
-    g.cap1 = round_up((uint64_t)(m1 * 1.05 + 8.0 * std::sqrt(m1)) + 2048, 64);
+    g.cap1 = round_up((uint64_t)(m1 * 1.5 + 8.0 * std::sqrt(m1)) + 2048, 64);   // tiles are dealt dynamically: shares are uneven
     g.cap2 = round_up((uint64_t)(m2 * 1.05 + 8.0 * std::sqrt(m2)) + 64, 64);
     g.spill_cap = std::max<uint64_t>(1u << 20, (uint64_t)(expected * g.T / 8));
     const size_t b_buf1 = round_up(ns * g.nwgA * g.cap1 * 4, 256), b_buf2 = round_up(ns * g.F * g.nwgB * g.cap2 * 2, 256);

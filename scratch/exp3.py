@@ -10,7 +10,7 @@ batch = hk.ReadBatch.from_packed(words, L)
 sk = hk.Counttable(k, 2e9 / 4, 4)
 def prof(name):
     ms, c = ctypes.c_double(), ctypes.c_uint64(); lib.kv_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(c)); return ms.value / max(1, c.value)
-for dbg in ('0', '1', '2', '3'):
+for dbg in ('0', '1', '2', '4', '8', '12'):
     os.environ['KV_BIN_DEBUG'] = dbg
     sk.clear(); sk.consume_batch(batch)
     lib.kv_prof_reset(); lib.kv_prof_enable(1)
