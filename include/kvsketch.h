@@ -182,6 +182,10 @@ int kv_hits_count(const kv_hits *h, uint64_t *n_hits, uint64_t *n_discarded_read
 /* copies hits sorted by (read, offset); abund has n_hits * (ncase+nctrl) entries          */
 int kv_hits_fetch(const kv_hits *h, uint32_t *read, uint32_t *offset, uint8_t *abund,
                   uint64_t cap_hits, uint32_t *discarded_reads, uint64_t cap_discarded);
+/* zero-copy alternative to kv_hits_fetch: pointers into the handle's (pinned) host arrays, valid until
+ * kv_hits_destroy; sizes as reported by kv_hits_count                                              */
+int kv_hits_view(const kv_hits *h, const uint32_t **read, const uint32_t **offset, const uint8_t **abund,
+                 const uint32_t **discarded_reads);
 int kv_hits_destroy(kv_hits *h);
 
 /* ---- partition: read graph connected components (kevlar/readgraph.py:43-84,104-137) --- */

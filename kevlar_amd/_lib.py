@@ -80,6 +80,7 @@ SIGNATURES = {
     'kv_novel_scan': (i32, [vpp, i32, vpp, i32, vp, u64, i32, i32, i32, i32, i32, i32, vp, u64, vpp]),
     'kv_hits_count': (i32, [vp, u64p, u64p]),
     'kv_hits_fetch': (i32, [vp, u32p, u32p, u8p, u64, u32p, u64]),
+    'kv_hits_view': (i32, [vp, ctypes.POINTER(u32p), ctypes.POINTER(u32p), ctypes.POINTER(u8p), ctypes.POINTER(u32p)]),
     'kv_hits_destroy': (i32, [vp]),
     'kv_readgraph_components': (i32, [vp, i32, u32p, u32p, u64, u32p, u32, u32, u32, u32p, u64p]),
 }

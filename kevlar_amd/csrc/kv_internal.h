@@ -69,10 +69,30 @@ struct kv_reads {
     uint64_t nk_cached = 0;
 };
 
+// hits of one scan in pinned host memory (fast DMA from the device; the Python side views it in place)
+template <typename T>
+struct PinnedVec {
+    T *p = nullptr;
+    uint64_t n = 0;
+    ~PinnedVec() { if (p) (void)hipHostFree(p); }
+    hipError_t resize(uint64_t count)
+    {
+        if (p) { (void)hipHostFree(p); p = nullptr; }
+        n = count;
+        return count ? hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault) : hipSuccess;
+    }
+    uint64_t size() const { return n; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](uint64_t i) { return p[i]; }
+    const T &operator[](uint64_t i) const { return p[i]; }
+    bool empty() const { return n == 0; }
+};
+
 struct kv_hits {
     int nsamples;
-    std::vector<uint32_t> read, offset;
-    std::vector<uint8_t> abund;
+    PinnedVec<uint32_t> read, offset;
+    PinnedVec<uint8_t> abund;
     std::vector<uint32_t> discarded;
 };
 

@@ -395,7 +395,9 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
             hipLaunchKernelGGL(k_novel_emit, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, st, reads_dev(reads), p);
             e = hipGetLastError();
         }
-        hits->read.resize(nhits); hits->offset.resize(nhits); hits->abund.resize(nhits * (uint64_t)S);
+        if (e == hipSuccess) e = hits->read.resize(nhits);
+        if (e == hipSuccess) e = hits->offset.resize(nhits);
+        if (e == hipSuccess) e = hits->abund.resize(nhits * (uint64_t)S);
         if (e == hipSuccess) e = hipMemcpyAsync(hits->read.data(), p.hit_read, nhits * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(hits->offset.data(), p.hit_off, nhits * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(hits->abund.data(), p.hit_abund, nhits * (uint64_t)S, hipMemcpyDeviceToHost, st);
@@ -424,7 +426,7 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
             if (w != i) memmove(&hits->abund[w * (uint64_t)S], &hits->abund[i * (uint64_t)S], (size_t)S);
             ++w;
         }
-        hits->read.resize(w); hits->offset.resize(w); hits->abund.resize(w * (uint64_t)S);
+        hits->read.n = w; hits->offset.n = w; hits->abund.n = w * (uint64_t)S;   // shrink in place
     }
     return KV_OK;
 }
@@ -452,6 +454,17 @@ extern "C" int kv_hits_fetch(const kv_hits *h, uint32_t *read, uint32_t *offset,
         KV_REQUIRE(cap_discarded >= h->discarded.size(), KV_ERR_CAPACITY, "discard buffer too small");
         if (!h->discarded.empty()) memcpy(discarded_reads, h->discarded.data(), h->discarded.size() * 4);
     }
+    return KV_OK;
+}
+
+extern "C" int kv_hits_view(const kv_hits *h, const uint32_t **read, const uint32_t **offset, const uint8_t **abund,
+                            const uint32_t **discarded_reads)
+{
+    KV_REQUIRE(h, KV_ERR_ARG, "kv_hits_view: null handle");
+    if (read) *read = h->read.data();
+    if (offset) *offset = h->offset.data();
+    if (abund) *abund = h->abund.data();
+    if (discarded_reads) *discarded_reads = h->discarded.data();
     return KV_OK;
 }
 

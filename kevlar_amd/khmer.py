@@ -604,17 +604,48 @@ def novel_scan(cases, controls, batch, case_min, ctrl_max, screen=None, band_mod
     check(lib.kv_novel_scan(ca, len(cases), cb, len(controls), batch._h, int(first_read), int(case_min),
                             int(ctrl_max), int(screen or 0), int(band_mode), int(nbands or 0),
                             int(band or 0), mask_ptr, int(mask_stride), ctypes.byref(hits)))
-    try:
-        n, nd = ctypes.c_uint64(), ctypes.c_uint64()
-        check(lib.kv_hits_count(hits, ctypes.byref(n), ctypes.byref(nd)))
-        reads = np.empty(n.value, dtype=np.uint32)
-        offs = np.empty(n.value, dtype=np.uint32)
-        abund = np.empty((n.value, S), dtype=np.uint8)
-        disc = np.empty(nd.value, dtype=np.uint32)
-        check(lib.kv_hits_fetch(hits, _u32p(reads), _u32p(offs), _u8p(abund), n.value, _u32p(disc), nd.value))
-    finally:
-        lib.kv_hits_destroy(hits)
+    holder = _HitsHandle(hits)
+    n, nd = ctypes.c_uint64(), ctypes.c_uint64()
+    check(lib.kv_hits_count(hits, ctypes.byref(n), ctypes.byref(nd)))
+    pr, po, pa, pd = _lib.u32p(), _lib.u32p(), _lib.u8p(), _lib.u32p()
+    check(lib.kv_hits_view(hits, ctypes.byref(pr), ctypes.byref(po), ctypes.byref(pa), ctypes.byref(pd)))
+    # views into the handle's pinned arrays: no second copy; the handle lives as long as the arrays do
+
+    def view(ptr, shape, dtype):
+        if int(np.prod(shape)) == 0:
+            return np.empty(shape, dtype=dtype)
+        arr = np.ctypeslib.as_array(ptr, shape=shape)
+        return _Owned(arr, holder)
+    reads = view(pr, (n.value,), np.uint32)
+    offs = view(po, (n.value,), np.uint32)
+    abund = view(pa, (n.value, S), np.uint8)
+    disc = np.array(np.ctypeslib.as_array(pd, shape=(nd.value,)), dtype=np.uint32) if nd.value else np.empty(0, dtype=np.uint32)
     return reads, offs, abund, disc
+
+
+class _HitsHandle(object):
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        h, self._h = self._h, None
+        if h:
+            try:
+                _lib.load().kv_hits_destroy(h)
+            except Exception:
+                pass
+
+
+class _Owned(np.ndarray):
+    """ndarray view that keeps the kv_hits handle (the owner of its memory) alive."""
+
+    def __new__(cls, arr, owner):
+        obj = np.asarray(arr).view(cls)
+        obj._owner = owner
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, '_owner', None)
 
 
 def readgraph_components(batch, ksize, ann_read, ann_offset, node_of_read, n_nodes, minabund=0,
