@@ -7,10 +7,16 @@ the fused `novel` scan of the proband against both parents (kv_novel_scan).
     value = (reads of all three samples) / (time per step), whole job.
 
 N = 1 : workload = BASELINE.json configs[1] (25 Mb genome, 30x, k=31, 2 GB sketch per sample).
-N > 1 : configs[2]: the same trio, kevlar's k-mer banding with band b on GPU b (each GPU
-        streams all reads, owns 1/N of the hash space and 1/N of the table memory), then one
-        RCCL all-reduce of the per-band interesting-k-mer bitmask + an all-gather of the hit
-        counts.  Total work is fixed -> "scaling": "strong".
+N > 1 : configs[2]: the same trio, kevlar's k-mer banding with band b on GPU b (1/N of the hash
+        space and of the table memory per GPU).  Total work is fixed -> "scaling": "strong".
+        --multi banded   : the reference's layout -- every GPU streams and hashes all reads, keeps
+                           its band; then one RCCL all-gather of the per-band hits, sorted on the
+                           device.
+        --multi exchange : every GPU hashes 1/N of the reads once and one RCCL all-to-all delivers
+                           each hash to its band's owner (kevlar_amd/shardrun.py); sketches and
+                           hits are identical to the banded run's.  Default from 4 GPUs up (with 2
+                           GPUs the single xGMI link between them makes the exchange slower than
+                           the replicated hashing).
 
 Also reported: `roofline` for the dominant kernel (algorithmic bytes / live HIP-event time,
 see DESIGN.md) and `cpu_baseline` (the C oracle on one host core, bounded sample).
@@ -42,6 +48,9 @@ def parse_args():
     p.add_argument('--ctrl-max', type=int, default=1)
     p.add_argument('--cpu-reads', type=int, default=40000, help='reads per sample for the CPU baseline leg')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--multi', default='auto', choices=['auto', 'exchange', 'banded'],
+                   help='N>1: exchange = shard the reads, hash once, all-to-all the hashes by band (kevlar_amd/shardrun.py); '
+                        'banded = every rank hashes all reads and keeps its band; auto = exchange from 4 GPUs up')
     p.add_argument('--backend', default='nccl', help='nccl (= RCCL) is what the driver runs; gloo lets two ranks share one GPU in tests')
     return p.parse_args()
 
@@ -88,7 +97,15 @@ def main():
     packed = synth.trio_reads_packed(genome_len, args.coverage, L)
     names = ('proband', 'mother', 'father')
     n_reads = packed['proband'].shape[0]
-    batches = {n: hk.ReadBatch.from_packed(packed[n], L) for n in names}
+    multi = args.multi if args.multi != 'auto' else ('exchange' if world >= 4 else 'banded')
+    exchange = world > 1 and multi == 'exchange'
+    if exchange:
+        from kevlar_amd import shardrun
+        bounds = {n: shardrun.shard_bounds(n_reads, world, rank) for n in names}
+        batches = {n: hk.ReadBatch.from_packed(packed[n][bounds[n][0]:bounds[n][1]], L) for n in names}
+        run = shardrun.ShardedTrio(k, hk.Counttable)
+    else:
+        batches = {n: hk.ReadBatch.from_packed(packed[n], L) for n in names}
     gen_s = time.time() - t0
     nk = L - k + 1
     T = 4
@@ -96,41 +113,51 @@ def main():
     band = rank
     mem_per_gpu = args.memory / max(1, world)
     sketches = {n: hk.Counttable(k, mem_per_gpu / T, T) for n in names}
-    mask = None
-    if world > 1:
-        mask = torch.zeros((n_reads * nk + 31) // 32, dtype=torch.int32, device='cuda')
 
     wall = {'count': 0.0, 'novel': 0.0, 'merge': 0.0}
 
-    def step():
+    def step_exchange():
+        # route + exchange of sample i+1 overlap the count of sample i (RCCL runs on its own stream)
+        t_a = time.perf_counter()
+        for n in names:
+            sketches[n].clear()
+        kmers = 0
+        pending = run.start(batches[names[0]], bounds[names[0]][0], True)
+        for i, n in enumerate(names):
+            nxt = run.start(batches[names[i + 1]], bounds[names[i + 1]][0], False) if i + 1 < len(names) else None
+            kmers += run.finish(pending, sketches[n], keep_for_scan=(i == 0))
+            pending = nxt
+        t_b = time.perf_counter()
+        r, o, a = run.scan([sketches['proband']], [sketches['mother'], sketches['father']], args.case_min, args.ctrl_max)
+        t_c = time.perf_counter()
+        wall['count'] += t_b - t_a
+        wall['novel'] += t_c - t_b
+        return kmers, len(r), (r, o, a)
+
+    def step_banded():
         kmers = 0
         t_a = time.perf_counter()
         for n in names:
             sketches[n].clear()
             kmers += sketches[n].consume_batch(batches[n], nbands, band)
-        if mask is not None:
-            mask.zero_()
         t_b = time.perf_counter()
         r, o, a, _ = hk.novel_scan(
             [sketches['proband']], [sketches['mother'], sketches['father']], batches['proband'],
-            args.case_min, args.ctrl_max, band_mode=1 if world > 1 else 0, nbands=nbands, band=band,
-            mask_ptr=mask.data_ptr() if mask is not None else None, mask_stride=nk)
+            args.case_min, args.ctrl_max, band_mode=1 if world > 1 else 0, nbands=nbands, band=band)
         nhits = len(r)
         t_c = time.perf_counter()
         if world > 1:
+            # every band's hits to every rank, sorted on the device (the per-band bit mask that `kevlar unband`
+            # would OR together carries no information beyond the hits, so it is not exchanged here)
             from kevlar_amd import bandmerge
-            if args.backend == 'nccl':
-                bandmerge.allreduce_mask(mask)          # bands are disjoint: sum == OR
-            else:
-                host_mask = mask.cpu()
-                bandmerge.allreduce_mask(host_mask)
-                mask.copy_(host_mask)
-            r, o, a = bandmerge.allgather_hits(r, o, a, coll_device)
+            r, o, a = bandmerge.allgather_hits_device(r, o, a, torch.device('cuda', dev_index), staged=(args.backend != 'nccl'))
             nhits = len(r)
         wall['count'] += t_b - t_a
         wall['novel'] += t_c - t_b
         wall['merge'] += time.perf_counter() - t_c
         return kmers, nhits, (r, o, a)
+
+    step = step_exchange if exchange else step_banded
 
     def fence():
         torch.cuda.synchronize()
@@ -162,6 +189,10 @@ def main():
     assert (a[:, 0] >= args.case_min).all() and (a[:, 1:] <= args.ctrl_max).all()
     if world == 1:
         assert kmers == 3 * n_reads * nk
+    elif exchange:
+        tot = torch.tensor([kmers], dtype=torch.int64, device=coll_device)
+        dist.all_reduce(tot)
+        assert int(tot.item()) == 3 * n_reads * nk, 'every k-mer of the trio must be counted by exactly one rank' 
 
     ms_step = elapsed / args.steps * 1e3
     total_reads = 3 * n_reads
@@ -176,7 +207,7 @@ def main():
     lib.kv_prof_names(buf, 4096)
     times = {name: prof(lib, name) for name in buf.value.decode().split(',') if name}
     # the count is one logical kernel split over k_bin_* launches (or k_consume on the atomic path)
-    groups = {'count': [n_ for n_ in times if n_.startswith('k_bin_') or n_ == 'k_consume'],
+    groups = {'count': [n_ for n_ in times if n_.startswith('k_bin_') or n_.startswith('k_route_') or n_ == 'k_consume'],
               'novel': [n_ for n_ in times if n_.startswith('k_novel_') or n_ == 'k_tile_scan']}
     alg = {}
     for name in groups['count']:
@@ -224,7 +255,7 @@ def main():
                             '{:g} GB Count-Min sketch per sample ({} tables), case-min {}, ctrl-max {}'.format(
                                 args.genome_mb, args.coverage, L, k, n_reads, args.memory / 1e9, T,
                                 args.case_min, args.ctrl_max),
-                'parallelism': 'single band' if world == 1 else '{} k-mer bands, 1 per GPU'.format(world),
+                'parallelism': 'single band' if world == 1 else ('{} k-mer bands, 1 per GPU; reads sharded, hashes exchanged by band (all-to-all)'.format(world) if exchange else '{} k-mer bands, 1 per GPU; every rank hashes all reads'.format(world)),
                 'interesting_kmer_instances': nhits, 'host_generate_pack_upload_s': round(gen_s, 1),
                 'device': '{} ({} CUs)'.format(torch.cuda.get_device_properties(dev_index).name,
                                                torch.cuda.get_device_properties(dev_index).multi_processor_count),

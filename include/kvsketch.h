@@ -188,6 +188,30 @@ int kv_hits_view(const kv_hits *h, const uint32_t **read, const uint32_t **offse
                  const uint32_t **discarded_reads);
 int kv_hits_destroy(kv_hits *h);
 
+/* ---- read-sharded multi-GPU count / scan (kevlar's banding, docs/banding.rst,
+ *      kevlar/count.py:62-66, with the hashing done once per k-mer instead of once per band) ------
+ * All buffer arguments named d_* are DEVICE pointers owned by the caller (bench.py and
+ * kevlar_amd/shardrun.py hand in torch tensors so RCCL can move them); only kernels touch them.    */
+/* Hash every k-mer of `reads` and append it to the send buffer of the band (= rank) that owns it:
+ * d_out is [ndest][cap_items] u64 hashes, or with_tags: [ndest][cap_items] pairs (hash, tag) with
+ * tag = (read_index_base + read) << 16 | offset and bit 63 set for reads the novel scan skips
+ * (non-ACGT).  counts_out[ndest] (host) = items per destination.  kind = KV_COUNTTABLE ... selects
+ * the hash function as in kv_hash_kmers.                                                          */
+int kv_route_hashes(const kv_reads *reads, int kind, int ksize, int ndest, uint64_t read_index_base,
+                    int with_tags, void *d_out, uint64_t cap_items, uint64_t *counts_out);
+/* count n hashes resident in HBM, element i at ((uint64_t*)d_hashes)[i * stride_words]            */
+int kv_consume_hashes(kv_sketch *s, const void *d_hashes, uint64_t n, uint32_t stride_words,
+                      uint64_t *n_added_out);
+/* kmer_is_interesting() over n_items (hash, tag) pairs; hits leave unordered as d_hit_tags[i] and
+ * d_hit_abund[i * (ncase+nctrl) ...]                                                              */
+int kv_novel_scan_hashes(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl,
+                         const void *d_items, uint64_t n_items, int case_min, int ctrl_max,
+                         void *d_hit_tags, void *d_hit_abund, uint64_t hit_cap, uint64_t *n_hits);
+/* sort n_total gathered (tag, abundances) hits by tag; the n_valid smallest are real (padding has
+ * tag ~0) and come back as an ordinary kv_hits in (read, offset) order                            */
+int kv_hits_from_tagged(const void *d_tags, const void *d_abund, uint64_t n_total, uint64_t n_valid,
+                        int nsamples, kv_hits **out);
+
 /* ---- partition: read graph connected components (kevlar/readgraph.py:43-84,104-137) --- */
 /* One annotation = one interesting k-mer occurrence (read index in `reads`, offset).
  * node_of_read maps a read to its graph node (reads sharing a name share a node).

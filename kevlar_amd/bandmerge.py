@@ -60,3 +60,20 @@ def allgather_hits(read, offset, abund, device, group=None):
     moff = np.ascontiguousarray(merged[:, 4:8]).view('<u4').reshape(-1)
     order = np.lexsort((moff, mread))
     return mread[order].astype(np.uint32), moff[order].astype(np.uint32), merged[order][:, 8:].astype(np.uint8)
+
+
+def allgather_hits_device(read, offset, abund, device, group=None, staged=False):
+    """allgather_hits for ranks that own a GPU: the rows travel as (tag = read << 16 | offset, abundances),
+    are gathered on the device and sorted there (kv_hits_from_tagged) -- a host lexsort of a few million
+    hits would cost more than the whole banded scan.  `staged` = gloo transport (host-staged)."""
+    from kevlar_amd import khmer as hk
+    from kevlar_amd import shardrun
+    S = abund.shape[1]
+    n = len(read)
+    tags = (np.asarray(read).astype(np.int64) << 16) | np.asarray(offset).astype(np.int64)
+    d_tags = torch.from_numpy(tags).to(device)
+    d_abund = torch.from_numpy(np.ascontiguousarray(abund)).to(device) if n else torch.zeros((0, S), dtype=torch.uint8, device=device)
+    all_tags, total = shardrun.gather_rows(d_tags, n, -1, group, staged)
+    all_abund, _ = shardrun.gather_rows(d_abund, n, 0, group, staged)
+    torch.cuda.synchronize()
+    return hk.hits_from_tagged(all_tags.data_ptr(), all_abund.data_ptr(), all_tags.shape[0], total, S)

@@ -145,6 +145,36 @@ __device__ __forceinline__ void rings_store_counts(uint32_t ns, uint32_t written
     if (lane < per_wave && s < ns) counts[(uint64_t)s * stride + writer] = written < cap ? written : cap;
 }
 
+// one k-mer -> T ring appends.  All T ring positions are requested back to back (independent LDS
+// atomics in flight together) before any of them is consumed.
+__device__ __forceinline__ uint32_t bin_push(const Rings<uint32_t> &rs, const BinGeom &g, const SketchDev *__restrict__ sk, uint64_t h)
+{
+    uint32_t sidx[BIN_MAX_T], item[BIN_MAX_T], pos[BIN_MAX_T];
+    uint64_t bins[BIN_MAX_T];
+#pragma unroll
+    for (int t = 0; t < BIN_MAX_T; ++t) {
+        if (t >= g.T) break;
+        const uint64_t bin = fastmod(h, sk->size[t], sk->magic[t]);
+        const uint32_t slice = (uint32_t)(bin >> 16);
+        const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
+        bins[t] = bin;
+        item[t] = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu);
+        sidx[t] = (uint32_t)t * (uint32_t)g.C + c;
+    }
+    if (g.debug & 1u) return item[0] & 1u;
+#pragma unroll
+    for (int t = 0; t < BIN_MAX_T; ++t)
+        if (t < g.T) pos[t] = atomicAdd(&rs.cnt[sidx[t]], 1u);
+#pragma unroll
+    for (int t = 0; t < BIN_MAX_T; ++t) {
+        if (t >= g.T) break;
+        const uint32_t s_ = sidx[t];
+        if (pos[t] - rs.base[s_] < rs.R) rs.ring[s_ * rs.R + ((pos[t] + s_) & (rs.R - 1))] = item[t];
+        else spill_item(g, t, bins[t]);
+    }
+    return 0u;
+}
+
 // ---- stage A -----------------------------------------------------------------------------
 template <int THREADS, int NW>
 __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash(   // 3 x 8 waves (or 1 x 16) per CU must fit the register file
@@ -214,34 +244,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash(
                 }
                 if (consume_filter_pass(f, mask, h)) {
                     n_added += 1;
-                    // all T ring positions are requested back to back (independent LDS atomics in flight
-                    // together) before any of them is consumed
-                    uint32_t sidx[BIN_MAX_T], item[BIN_MAX_T], pos[BIN_MAX_T];
-                    uint64_t bins[BIN_MAX_T];
-#pragma unroll
-                    for (int t = 0; t < BIN_MAX_T; ++t) {
-                        if (t >= g.T) break;
-                        const uint64_t bin = fastmod(h, sk->size[t], sk->magic[t]);
-                        const uint32_t slice = (uint32_t)(bin >> 16);
-                        const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
-                        bins[t] = bin;
-                        item[t] = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu);
-                        sidx[t] = (uint32_t)t * (uint32_t)g.C + c;
-                    }
-                    if (!(g.debug & 1u)) {
-#pragma unroll
-                        for (int t = 0; t < BIN_MAX_T; ++t)
-                            if (t < g.T) pos[t] = atomicAdd(&rs.cnt[sidx[t]], 1u);
-#pragma unroll
-                        for (int t = 0; t < BIN_MAX_T; ++t) {
-                            if (t >= g.T) break;
-                            const uint32_t s_ = sidx[t];
-                            if (pos[t] - rs.base[s_] < rs.R) rs.ring[s_ * rs.R + ((pos[t] + s_) & (rs.R - 1))] = item[t];
-                            else spill_item(g, t, bins[t]);
-                        }
-                    } else {
-                        n_added += item[0] & 1u;
-                    }
+                    n_added += bin_push(rs, g, sk, h);
                 }
             }
             __syncthreads();
@@ -253,6 +256,139 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash(
     rings_store_counts(ns, written, (uint32_t)g.cap1, g.gcnt1, g.nwgA, blockIdx.x);
     n_added = wave_sum_u64(n_added);
     if ((threadIdx.x & 63) == 0 && n_added) atomicAdd(&g.ctr[2], (unsigned long long)n_added);
+}
+
+// Stage A without LDS rings: every workgroup still owns a private segment of every coarse bucket, but
+// the segment's write cursor lives in LDS and each item is stored straight to HBM -- no barrier, no
+// flush phase between hashing a k-mer and storing its T items.  The write frontier (workgroups x
+// buckets x one 128-B line) sits in L2, which merges the partial lines before they reach HBM.
+template <int THREADS, int NW>
+__global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash_direct(
+    ReadsDev rd, uint32_t n_tiles, const SketchDev *__restrict__ sk, const SketchDev *__restrict__ mask,
+    ConsumeFilter f, BinGeom g)
+{
+    __shared__ TileShared sh;
+    __shared__ uint32_t cur[BIN_MAX_T * BIN_C];
+    __shared__ uint32_t next_tile;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (threadIdx.x == 0) sh.ascii = (uint32_t *)smem;
+    const uint32_t ns = (uint32_t)(g.T * g.C);
+    for (uint32_t s = threadIdx.x; s < ns; s += THREADS) cur[s] = 0;
+    uint64_t n_added = 0;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) next_tile = (uint32_t)atomicAdd(&g.ctr[4], 1ull);
+        __syncthreads();
+        const uint32_t tile = next_tile;
+        if (tile >= n_tiles) break;
+        uint32_t read0;
+        const uint32_t nr = stage_tile(sh, rd, tile, f.hp.k, 0, 0, read0);
+        const uint32_t total = sh.kpre[nr];
+        const uint32_t run = (total + THREADS - 1) / THREADS;
+        const uint32_t q0 = threadIdx.x * run, q1 = min(total, q0 + run);
+        KmerRoll<(NW > 0 ? NW : 8)> w;
+        if (NW > 0 && q0 < q1) {
+            locate_kmer(sh, nr, q0, w.r, w.i);
+            roll_load(w, sh, f.hp.k);
+        }
+        for (uint32_t step = 0; step < run; ++step) {
+            const uint32_t q = NW > 0 ? q0 + step : step * THREADS + threadIdx.x;
+            const bool live = NW > 0 ? q < q1 : q < total;
+            if (!live) continue;
+            uint64_t h;
+            if (NW > 0) {
+                h = roll_hash(w, f.hp);
+                if (q + 1 < q1) roll_step(w, sh, nr, f.hp.k);
+            } else {
+                uint32_t r, i;
+                locate_kmer(sh, nr, q, r, i);
+                const uint32_t fwd = sh.foff[r] + i;
+                const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)f.hp.k - i);
+                h = kmer_hash_lds(sh.ascii, fwd, rc, f.hp);
+            }
+            if (!consume_filter_pass(f, mask, h)) continue;
+            n_added += 1;
+            uint32_t sidx[BIN_MAX_T], item[BIN_MAX_T], pos[BIN_MAX_T];
+            uint64_t bins[BIN_MAX_T];
+#pragma unroll
+            for (int t = 0; t < BIN_MAX_T; ++t) {
+                if (t >= g.T) break;
+                const uint64_t bin = fastmod(h, sk->size[t], sk->magic[t]);
+                const uint32_t slice = (uint32_t)(bin >> 16);
+                const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
+                bins[t] = bin;
+                item[t] = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu);
+                sidx[t] = (uint32_t)t * (uint32_t)g.C + c;
+            }
+#pragma unroll
+            for (int t = 0; t < BIN_MAX_T; ++t)
+                if (t < g.T) pos[t] = atomicAdd(&cur[sidx[t]], 1u);
+#pragma unroll
+            for (int t = 0; t < BIN_MAX_T; ++t) {
+                if (t >= g.T) break;
+                if (pos[t] < g.cap1) { if (!(g.debug & 2u)) g.gbuf1[((uint64_t)sidx[t] * g.nwgA + blockIdx.x) * g.cap1 + pos[t]] = item[t]; }
+                else spill_item(g, t, bins[t]);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < ns; s += THREADS)
+        g.gcnt1[(uint64_t)s * g.nwgA + blockIdx.x] = (uint32_t)min((uint64_t)cur[s], g.cap1);
+    n_added = wave_sum_u64(n_added);
+    if ((threadIdx.x & 63) == 0 && n_added) atomicAdd(&g.ctr[2], (unsigned long long)n_added);
+}
+
+// stage A over a list of hashes already in HBM (read-sharded multi-GPU count: the hashes of this
+// rank's band arrive from the other ranks, kv_shard.hip).  Element i sits at list[i * stride].
+#define BIN_LIST_ROUNDS 16
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_list(
+    const uint64_t *__restrict__ list, uint64_t n, uint32_t stride, const SketchDev *__restrict__ sk, BinGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t ns = (uint32_t)(g.T * g.C);
+    Rings<uint32_t> rs;
+    rs.R = g.ringA;
+    rs.ring = (uint32_t *)smem;
+    rs.cnt = rs.ring + (size_t)ns * rs.R;
+    rs.base = rs.cnt + ns;
+    for (uint32_t s = threadIdx.x; s < ns; s += THREADS) { rs.cnt[s] = 0; rs.base[s] = 0; }
+    __syncthreads();
+    uint32_t written = 0;
+    uint64_t seg_base = 0;
+    {
+        const uint32_t nwaves = THREADS >> 6, per_wave = (ns + nwaves - 1) / nwaves;
+        const uint32_t mine = (threadIdx.x >> 6) * per_wave + (threadIdx.x & 63);
+        if ((threadIdx.x & 63) < per_wave && mine < ns) seg_base = ((uint64_t)mine * g.nwgA + blockIdx.x) * g.cap1;
+    }
+    auto store = [&](uint64_t idx, uint32_t item) { g.gbuf1[idx] = item; };
+    auto overflow = [&](uint32_t s, uint32_t item) {
+        const uint32_t t = s / (uint32_t)g.C, c = s % (uint32_t)g.C;
+        spill_item(g, (int)t, (((uint64_t)c * g.F + (item >> 16)) << 16) | (item & 0xffffu));
+    };
+    const uint64_t chunk = (uint64_t)THREADS * BIN_LIST_ROUNDS;
+    __shared__ uint64_t next_chunk;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) next_chunk = (uint64_t)atomicAdd(&g.ctr[4], 1ull);
+        __syncthreads();
+        const uint64_t i0 = next_chunk * chunk;
+        if (i0 >= n) break;
+        uint64_t idx = i0 + threadIdx.x;
+        uint64_t h_next = idx < n ? list[idx * stride] : 0;
+        for (int round = 0; round < BIN_LIST_ROUNDS; ++round) {
+            const uint64_t h = h_next;
+            const bool live = idx < n;
+            idx += THREADS;
+            if (round + 1 < BIN_LIST_ROUNDS && idx < n) h_next = list[idx * stride];   // flies during this round
+            if (live) (void)bin_push(rs, g, sk, h);
+            __syncthreads();
+            rings_flush(rs, ns, false, written, seg_base, (uint32_t)g.cap1, store, overflow);
+            __syncthreads();
+        }
+    }
+    rings_flush(rs, ns, true, written, seg_base, (uint32_t)g.cap1, store, overflow);
+    rings_store_counts(ns, written, (uint32_t)g.cap1, g.gcnt1, g.nwgA, blockIdx.x);
 }
 
 // ---- stage B -----------------------------------------------------------------------------
@@ -512,28 +648,30 @@ double kv_estimate_distinct(uint64_t occupied, uint64_t size)
 
 bool kv_binned_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_kmers, int nbands)
 {
+    // reads == nullptr: the items come from a hash list (kv_consume_hashes)
     const char *force = getenv("KV_COUNT_PATH");
     if (force && strcmp(force, "atomic") == 0) return false;
     if (s->h.ntables > BIN_MAX_T) return false;
     uint64_t pmin = UINT64_MAX, pmax = 0;
     for (int t = 0; t < s->h.ntables; ++t) { pmin = std::min(pmin, s->h.size[t]); pmax = std::max(pmax, s->h.size[t]); }
     if (pmax > (uint64_t)BIN_C * BIN_MAX_F * 65536ull) return false;      // <= 2^31 bins per table
-    if (force && strcmp(force, "binned") == 0) return reads->n_tiles > 0;
+    if (force && strcmp(force, "binned") == 0) return reads ? reads->n_tiles > 0 : n_kmers > 0;
     const uint64_t expected = nbands > 0 ? n_kmers / (uint64_t)nbands : n_kmers;
     // worth it once the batch touches the tables about as densely as streaming them costs
     return pmin >= (1ull << 20) && expected >= (1ull << 22) && expected * 8 >= pmax;
 }
 
 // returns KV_OK, or KV_ERR_CAPACITY when the spill list overflowed (tables untouched: caller falls back)
-int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &filter, const kv_sketch *mask,
-                      uint64_t n_kmers, int nbands, uint64_t *n_added)
+int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_list, uint32_t list_stride,
+                      const ConsumeFilter &filter, const kv_sketch *mask, uint64_t n_kmers, int nbands, uint64_t *n_added)
 {
+    // source: the packed reads (hash in stage A) or, when reads == nullptr, n_kmers hashes at d_list[i * list_stride]
     hipStream_t st = kv_stream();
     Scratch &scratch = scratch_for(st);
     BinGeom g;
     memset(&g, 0, sizeof(g));
     g.T = s->h.ntables;
-    g.tile_lds = reads->tile_lds_bytes;
+    g.tile_lds = reads ? reads->tile_lds_bytes : 0u;
     g.debug = getenv("KV_BIN_DEBUG") ? (uint32_t)atoi(getenv("KV_BIN_DEBUG")) : 0u;
     uint64_t pmin = UINT64_MAX;
     uint32_t maxsl = 1;
@@ -563,7 +701,9 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
     const uint64_t ns = (uint64_t)g.T * g.C;
     // writers: stage A = persistent workgroups (tiles dealt round-robin, so their loads are equal
     // to within one tile); stage B = nwgB workgroups per coarse bucket, ~256 k items each
-    g.nwgA = std::min<uint32_t>(reads->n_tiles, (cmax <= 32 ? 3u : 1u) * (uint32_t)cus);
+    const uint32_t threadsA = cmax <= 32 ? 512u : 1024u;
+    const uint64_t work_units = reads ? reads->n_tiles : (n_kmers + (uint64_t)threadsA * BIN_LIST_ROUNDS - 1) / ((uint64_t)threadsA * BIN_LIST_ROUNDS);
+    g.nwgA = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(work_units, 1), (cmax <= 32 ? 3u : 1u) * (uint32_t)cus);
     const double per_bucket = expected * std::min(1.0, (double)g.F * 65536.0 / (double)pmin);
     const double per_slice = expected * std::min(1.0, 65536.0 / (double)pmin);
     g.nwgB = (uint32_t)std::max(1.0, std::min((double)std::min<uint32_t>(g.nwgA, 512), std::ceil(per_bucket / 524288.0)));
@@ -585,8 +725,11 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
     KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));   // every segment count is written by its owner: no other memset
 
     const SketchDev *d_mask = mask ? mask->d_desc : nullptr;
-    {
-        KvProfScope prof("k_bin_hash");
+    if (reads) {
+        // default: direct stores through LDS cursors (k_bin_hash_direct); KV_BIN_DIRECT=0 selects the LDS-ring
+        // variant, which measured ~10% slower on this stage (profiles/README.md)
+        const bool direct = !(getenv("KV_BIN_DIRECT") && atoi(getenv("KV_BIN_DIRECT")) == 0);
+        KvProfScope prof(direct ? "k_bin_hash_direct" : "k_bin_hash");
         const size_t lds = (size_t)g.tile_lds + ns * g.ringA * 4 + ns * 8;
         const unsigned grid = g.nwgA;
         const int k = s->h.ksize;
@@ -597,7 +740,21 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
             hipLaunchKernelGGL((k_bin_hash<THREADS_, NW_>), dim3(grid), dim3(THREADS_), lds, st, reads_dev(reads), \
                                reads->n_tiles, (const SketchDev *)s->d_desc, d_mask, filter, g);                  \
         } while (0)
-        if (cmax <= 32) {
+#define KV_LAUNCH_BIN_DIRECT(THREADS_, NW_)                                                                       \
+        do {                                                                                                      \
+            ensure_dynamic_lds(k_bin_hash_direct<THREADS_, NW_>, (size_t)g.tile_lds);                             \
+            hipLaunchKernelGGL((k_bin_hash_direct<THREADS_, NW_>), dim3(grid), dim3(THREADS_), g.tile_lds, st,    \
+                               reads_dev(reads), reads->n_tiles, (const SketchDev *)s->d_desc, d_mask, filter, g); \
+        } while (0)
+        if (direct && cmax <= 32) {
+            if (nw == 8) KV_LAUNCH_BIN_DIRECT(512, 8);
+            else if (nw == 16) KV_LAUNCH_BIN_DIRECT(512, 16);
+            else KV_LAUNCH_BIN_DIRECT(512, 0);
+        } else if (direct) {
+            if (nw == 8) KV_LAUNCH_BIN_DIRECT(1024, 8);
+            else if (nw == 16) KV_LAUNCH_BIN_DIRECT(1024, 16);
+            else KV_LAUNCH_BIN_DIRECT(1024, 0);
+        } else if (cmax <= 32) {
             if (nw == 8) KV_LAUNCH_BIN_HASH(512, 8);
             else if (nw == 16) KV_LAUNCH_BIN_HASH(512, 16);
             else KV_LAUNCH_BIN_HASH(512, 0);
@@ -606,7 +763,20 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
             else if (nw == 16) KV_LAUNCH_BIN_HASH(1024, 16);
             else KV_LAUNCH_BIN_HASH(1024, 0);
         }
+#undef KV_LAUNCH_BIN_DIRECT
 #undef KV_LAUNCH_BIN_HASH
+    } else {
+        KvProfScope prof("k_bin_list");
+        const size_t lds = ns * g.ringA * 4 + ns * 8;
+        if (cmax <= 32) {
+            ensure_dynamic_lds(k_bin_list<512>, lds);
+            hipLaunchKernelGGL((k_bin_list<512>), dim3(g.nwgA), dim3(512), lds, st, d_list, n_kmers, list_stride,
+                               (const SketchDev *)s->d_desc, g);
+        } else {
+            ensure_dynamic_lds(k_bin_list<1024>, lds);
+            hipLaunchKernelGGL((k_bin_list<1024>), dim3(g.nwgA), dim3(1024), lds, st, d_list, n_kmers, list_stride,
+                               (const SketchDev *)s->d_desc, g);
+        }
     }
     {
         KvProfScope prof("k_bin_split");
@@ -630,7 +800,7 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &
         kv_set_error("partitioned count: spill list overflow (%llu items)", ctr[0]);
         return KV_ERR_CAPACITY;
     }
-    *n_added = ctr[2];
+    *n_added = reads ? ctr[2] : n_kmers;
     // exact occupancy bookkeeping; n_unique_kmers as a linear-counting estimate
     if (s->occ_dirty) {
         int rc = kv_sketch_refresh_occupancy(s);   // recount includes this batch

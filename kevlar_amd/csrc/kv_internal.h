@@ -112,8 +112,8 @@ struct ConsumeFilter {
 
 // partitioned count (kv_binned.hip)
 bool kv_binned_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_kmers, int nbands);
-int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &filter, const kv_sketch *mask,
-                      uint64_t n_kmers, int nbands, uint64_t *n_added);
+int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_list, uint32_t list_stride,
+                      const ConsumeFilter &filter, const kv_sketch *mask, uint64_t n_kmers, int nbands, uint64_t *n_added);
 double kv_estimate_distinct(uint64_t occupied, uint64_t size);
 
 // tile geometry of the hashing kernels

@@ -76,12 +76,12 @@ __global__ void k_get_hashes(const SketchDev *__restrict__ sk, const uint64_t *h
         out[i] = (uint8_t)sketch_get(sk, hashes[i]);
 }
 
-__global__ void k_add_hashes(const SketchDev *__restrict__ sk, const uint64_t *hashes, uint64_t n, uint8_t *is_new,
-                             uint64_t *counters)
+__global__ void k_add_hashes(const SketchDev *__restrict__ sk, const uint64_t *hashes, uint64_t n, uint32_t stride,
+                             uint8_t *is_new, uint64_t *counters)
 {
     uint64_t n_new = 0;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const bool nw = sketch_add(sk, hashes[i]);
+        const bool nw = sketch_add(sk, hashes[i * stride]);
         if (is_new) is_new[i] = nw ? 1 : 0;
         n_new += nw ? 1 : 0;
     }
@@ -199,7 +199,7 @@ extern "C" int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int b
     kv_reads_num_kmers(reads, s->h.ksize, &n_kmers);
     if (kv_binned_eligible(s, reads, n_kmers, nbands)) {
         uint64_t added = 0;
-        const int rc = kv_consume_binned(s, reads, p, mask, n_kmers, nbands, &added);
+        const int rc = kv_consume_binned(s, reads, nullptr, 1, p, mask, n_kmers, nbands, &added);
         if (rc == KV_OK) {
             if (n_kmers_out) *n_kmers_out = added;
             return KV_OK;
@@ -299,7 +299,7 @@ extern "C" int kv_add_hashes(kv_sketch *s, const uint64_t *hashes, uint64_t n, u
     if (e == hipSuccess) {
         KvProfScope prof("k_add_hashes");
         const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
-        hipLaunchKernelGGL(k_add_hashes, dim3(grid), dim3(256), 0, kv_stream(), (const SketchDev *)s->d_desc, d_h, n, d_o,
+        hipLaunchKernelGGL(k_add_hashes, dim3(grid), dim3(256), 0, kv_stream(), (const SketchDev *)s->d_desc, d_h, n, 1u, d_o,
                            s->d_counters);
         e = hipGetLastError();
     }
@@ -310,6 +310,39 @@ extern "C" int kv_add_hashes(kv_sketch *s, const uint64_t *hashes, uint64_t n, u
     (void)hipFree(d_h);
     if (d_o) (void)hipFree(d_o);
     KV_REQUIRE(e == hipSuccess, KV_ERR_HIP, "kv_add_hashes failed: %s", hipGetErrorString(e));
+    s->n_unique += c[1];
+    s->occ_dirty = true;
+    return KV_OK;
+}
+
+// Count n hashes that are already in HBM (element i at d_hashes[i * stride_words]): the receive side of
+// the read-sharded multi-GPU count, where the hashes of this rank's band were computed by the ranks
+// that hold the reads (kv_route_hashes).  Same partitioned path as kv_consume for large lists.
+extern "C" int kv_consume_hashes(kv_sketch *s, const void *d_hashes, uint64_t n, uint32_t stride_words, uint64_t *n_added_out)
+{
+    KV_REQUIRE(s && (d_hashes || n == 0) && stride_words >= 1, KV_ERR_ARG, "kv_consume_hashes: bad argument");
+    if (n_added_out) *n_added_out = n;
+    if (n == 0) return KV_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->version++;
+    if (kv_binned_eligible(s, nullptr, n, 0)) {
+        const ConsumeFilter p = make_consume_filter(s->h.ksize, s->h.hashfam, 0, 0, false, 0, 0);
+        uint64_t added = 0;
+        const int rc = kv_consume_binned(s, nullptr, (const uint64_t *)d_hashes, stride_words, p, nullptr, n, 0, &added);
+        if (rc == KV_OK) return KV_OK;
+        if (rc != KV_ERR_CAPACITY) return rc;
+    }
+    KV_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(uint64_t), kv_stream()));
+    {
+        KvProfScope prof("k_add_hashes");
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 8192);
+        hipLaunchKernelGGL(k_add_hashes, dim3(grid), dim3(256), 0, kv_stream(), (const SketchDev *)s->d_desc,
+                           (const uint64_t *)d_hashes, n, stride_words, (uint8_t *)nullptr, s->d_counters);
+    }
+    KV_HIP(hipGetLastError());
+    uint64_t c[2] = {0, 0};
+    KV_HIP(hipMemcpyAsync(c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost, kv_stream()));
+    KV_HIP(hipStreamSynchronize(kv_stream()));
     s->n_unique += c[1];
     s->occ_dirty = true;
     return KV_OK;

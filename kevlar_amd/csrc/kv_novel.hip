@@ -277,6 +277,44 @@ struct DevBuf {
     template <typename T> T *as() { return (T *)p; }
 };
 
+// point p.vcache at this stream's verdict cache, (re)allocating or clearing it as the signature requires
+int attach_vcache(NovelParams &p, kv_sketch *const *ctrls, int ncase, int nctrl, int ctrl_max, uint64_t n_kmers, hipStream_t st)
+{
+    const char *vc_env = getenv("KV_NOVEL_VCACHE");
+    if (nctrl > 0 && p.screen == 0 && !(vc_env && atoi(vc_env) == 0)) {
+        // signature of everything the cached verdicts depend on
+        uint64_t sig = 0x9e3779b97f4a7c15ull ^ (uint64_t)(uint32_t)ctrl_max;
+        for (int c = ncase; c < ncase + nctrl; ++c) {
+            const kv_sketch *sk = ctrls[c - ncase];
+            sig = (sig ^ sk->uid) * 0xff51afd7ed558ccdull;
+            sig = (sig ^ sk->version) * 0xc4ceb9fe1a85ec53ull;
+        }
+        VerdictCache *vc;
+        {
+            std::lock_guard<std::mutex> lk(g_vcache_mu);
+            vc = &g_vcache[st];
+        }
+        int want = 20;
+        while (want < 28 && (1ull << want) < n_kmers / 2) ++want;   // ~2 slots per distinct inherited k-mer at 30x
+        if (vc->p == nullptr || vc->bits < want) {
+            if (vc->p) (void)hipFree(vc->p);
+            vc->p = nullptr;
+            if (hipMalloc((void **)&vc->p, (size_t)8 << want) == hipSuccess) { vc->bits = want; vc->signature = 0; }
+            else { (void)hipGetLastError(); vc->bits = 0; }
+        }
+        if (vc->p) {
+            if (vc->signature != sig) {
+                KV_HIP(hipMemsetAsync(vc->p, 0, (size_t)8 << vc->bits, st));
+                vc->signature = sig;
+            }
+            p.vcache = vc->p;
+            p.vcache_shift = 64 - vc->bits;
+        }
+    }
+
+    return KV_OK;
+}
+
 }  // namespace
 
 extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl,
@@ -312,37 +350,7 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     hipStream_t st = kv_stream();
     uint64_t n_kmers = 0;
     kv_reads_num_kmers(reads, k, &n_kmers);
-    const char *vc_env = getenv("KV_NOVEL_VCACHE");
-    if (nctrl > 0 && p.screen == 0 && !(vc_env && atoi(vc_env) == 0)) {
-        // signature of everything the cached verdicts depend on
-        uint64_t sig = 0x9e3779b97f4a7c15ull ^ (uint64_t)(uint32_t)ctrl_max;
-        for (int c = ncase; c < ncase + nctrl; ++c) {
-            const kv_sketch *sk = ctrls[c - ncase];
-            sig = (sig ^ sk->uid) * 0xff51afd7ed558ccdull;
-            sig = (sig ^ sk->version) * 0xc4ceb9fe1a85ec53ull;
-        }
-        VerdictCache *vc;
-        {
-            std::lock_guard<std::mutex> lk(g_vcache_mu);
-            vc = &g_vcache[st];
-        }
-        int want = 20;
-        while (want < 28 && (1ull << want) < n_kmers / 2) ++want;   // ~2 slots per distinct inherited k-mer at 30x
-        if (vc->p == nullptr || vc->bits < want) {
-            if (vc->p) (void)hipFree(vc->p);
-            vc->p = nullptr;
-            if (hipMalloc((void **)&vc->p, (size_t)8 << want) == hipSuccess) { vc->bits = want; vc->signature = 0; }
-            else { (void)hipGetLastError(); vc->bits = 0; }
-        }
-        if (vc->p) {
-            if (vc->signature != sig) {
-                KV_HIP(hipMemsetAsync(vc->p, 0, (size_t)8 << vc->bits, st));
-                vc->signature = sig;
-            }
-            p.vcache = vc->p;
-            p.vcache_shift = 64 - vc->bits;
-        }
-    }
+    { const int rc = attach_vcache(p, ctrls, ncase, nctrl, ctrl_max, n_kmers, st); if (rc != KV_OK) return rc; }
 
     kv_hits *hits = new kv_hits();
     hits->nsamples = S;
@@ -471,5 +479,110 @@ extern "C" int kv_hits_view(const kv_hits *h, const uint32_t **read, const uint3
 extern "C" int kv_hits_destroy(kv_hits *h)
 {
     delete h;
+    return KV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// scan of a routed hash list (read-sharded multi-GPU path, kv_shard.hip): the items are
+// (hash, tag) pairs of the k-mers whose band this rank owns; tag = read << 16 | offset, bit 63
+// set for k-mers of reads the scan must skip (non-ACGT).  Same predicate, same verdict cache.
+// Hits leave as (tag, abundances) in arbitrary order; kv_hits_from_tagged sorts them.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void k_novel_list(NovelParams p, const uint64_t *__restrict__ items, uint64_t n,
+                                                    uint64_t *hit_tag, uint8_t *hit_abund,
+                                                    unsigned long long *hit_count, uint64_t cap)
+{
+    __shared__ NovelShared ns;
+    load_descs(ns, p);
+    __syncthreads();
+    const int S = p.ncase + p.nctrl;
+    struct Cand {
+        uint64_t h, tag;
+        unsigned long long *slot;
+        unsigned long long cached;
+        bool live;
+    };
+    auto fetch = [&](uint64_t i) {
+        Cand c;
+        c.live = false; c.slot = nullptr; c.cached = 0; c.h = 0; c.tag = 0;
+        if (i >= n) return c;
+        const ulonglong2 v = *(const ulonglong2 *)(items + 2 * i);
+        c.h = v.x; c.tag = v.y;
+        c.live = (c.tag >> 63) == 0;
+        if (c.live && p.vcache) {
+            c.slot = p.vcache + (c.h >> p.vcache_shift);
+            c.cached = __hip_atomic_load(c.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return c;
+    };
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t i0 = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    Cand cur = fetch(i0);
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = blockIdx.x * (uint64_t)blockDim.x; base < n; base += stride) {   // wave-uniform trip count
+        const Cand nxt = fetch(base + threadIdx.x + stride);
+        const bool interesting = cur.live && novel_test_fast(ns, p, cur.h, cur.slot, cur.cached);
+        const unsigned long long ballot = __ballot(interesting);
+        if (ballot) {
+            unsigned long long first = 0;
+            if (lane == 0) first = atomicAdd(hit_count, (unsigned long long)__popcll(ballot));
+            first = __shfl(first, 0);
+            if (interesting) {
+                const uint64_t pos = first + (uint64_t)__popcll(ballot & ((1ull << lane) - 1ull));
+                if (pos < cap) {
+                    hit_tag[pos] = cur.tag;
+                    for (int c = 0; c < S; ++c) hit_abund[pos * (uint64_t)S + c] = (uint8_t)sketch_get(p.sk[c], cur.h);
+                }
+            }
+        }
+        cur = nxt;
+    }
+}
+
+}  // namespace
+
+extern "C" int kv_novel_scan_hashes(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl,
+                                    const void *d_items, uint64_t n_items, int case_min, int ctrl_max,
+                                    void *d_hit_tags, void *d_hit_abund, uint64_t hit_cap, uint64_t *n_hits)
+{
+    KV_REQUIRE(cases && n_hits && ncase >= 1 && nctrl >= 0 && (ctrls || nctrl == 0), KV_ERR_ARG,
+               "kv_novel_scan_hashes: bad argument");
+    KV_REQUIRE(ncase + nctrl <= KV_MAX_SAMPLES, KV_ERR_ARG, "at most %d samples per scan", KV_MAX_SAMPLES);
+    KV_REQUIRE(n_items == 0 || (d_items && d_hit_tags && d_hit_abund), KV_ERR_ARG, "kv_novel_scan_hashes: null buffer");
+    *n_hits = 0;
+    if (n_items == 0) return KV_OK;
+    NovelParams p;
+    memset(&p, 0, sizeof(p));
+    const int k = cases[0]->h.ksize, fam = cases[0]->h.hashfam;
+    for (int c = 0; c < ncase + nctrl; ++c) {
+        const kv_sketch *s = c < ncase ? cases[c] : ctrls[c - ncase];
+        KV_REQUIRE(s, KV_ERR_ARG, "kv_novel_scan_hashes: null sketch");
+        KV_REQUIRE(s->h.ksize == k && s->h.hashfam == fam, KV_ERR_ARG,
+                   "all sketches of one scan must share k and hash function");
+        p.sk[c] = s->d_desc;
+    }
+    p.hp = make_hash_params(k, fam);
+    p.ncase = ncase; p.nctrl = nctrl;
+    p.case_min = case_min; p.ctrl_max = ctrl_max;
+    hipStream_t st = kv_stream();
+    { const int rc = attach_vcache(p, ctrls, ncase, nctrl, ctrl_max, n_items, st); if (rc != KV_OK) return rc; }
+    DevBuf d_count;
+    KV_HIP(d_count.alloc(8));
+    KV_HIP(hipMemsetAsync(d_count.p, 0, 8, st));
+    {
+        KvProfScope prof("k_novel_list");
+        const unsigned grid = (unsigned)std::min<uint64_t>((n_items + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(k_novel_list, dim3(grid), dim3(256), 0, st, p, (const uint64_t *)d_items, n_items,
+                           (uint64_t *)d_hit_tags, (uint8_t *)d_hit_abund, d_count.as<unsigned long long>(), hit_cap);
+    }
+    KV_HIP(hipGetLastError());
+    unsigned long long cnt = 0;
+    KV_HIP(hipMemcpyAsync(&cnt, d_count.p, 8, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    KV_REQUIRE(cnt <= hit_cap, KV_ERR_CAPACITY, "kv_novel_scan_hashes: %llu hits exceed the buffer of %llu", cnt,
+               (unsigned long long)hit_cap);
+    *n_hits = cnt;
     return KV_OK;
 }

@@ -1,0 +1,364 @@
+// kv_shard.hip -- read-sharded multi-GPU count and scan: hash once, route by band.
+//
+// kevlar shards a trio by k-mer hash band (docs/banding.rst; kevlar/count.py:62-66): band b owns
+// the hash range [b*bs, (b+1)*bs).  Run the reference way, every band's process still parses and
+// hashes EVERY read, and so does the one-band-per-GPU layout of bench.py's "banded" mode: measured,
+// hashing is ~2/3 of a banded rank's time and eight GPUs give 2.5x.  With the GPUs of one node on
+// xGMI the reads can be sharded instead: each rank hashes 1/N of every sample exactly once and
+// sends each hash to the rank that owns its band (one all-to-all, 8 B per k-mer, 16 B for the case
+// sample whose hits need their (read, offset) back).  The owner counts what it receives with the
+// same partitioned kernels (kv_consume_hashes) and scans the case hashes it received
+// (kv_novel_scan_hashes); sketches, bands and results are exactly those of the banded run.
+//
+//   k_route_hashes  LDS-staged tiles and rolling murmur windows as in k_bin_hash; the destination of
+//                   a hash is its band; items collect in one LDS ring per destination and leave as
+//                   >= 1 KB bursts into that destination's contiguous send buffer (one global atomic
+//                   per burst claims the space).
+//   kv_hits_from_tagged  radix sort (rocPRIM) of the gathered (tag, abundances) hits back into the
+//                   (read, offset) order of the reference's output.
+#include <cmath>
+#include <cstring>
+#include <map>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "kv_device.h"
+
+namespace {
+
+#define ROUTE_THREADS 512
+#define ROUTE_MAX_DEST 16
+#define ROUTE_MAX_WG 1024
+
+// Every workgroup owns one private segment per destination and appends to it through a cursor in
+// LDS: no global atomic, no barrier and no staging between hashing a k-mer and storing it (the
+// write frontier -- workgroups x destinations x one 128-B line -- lives in L2, which merges the
+// partial lines).  Tiles are handed out dynamically up to a quota per workgroup, which bounds what a
+// segment can receive; anything beyond a segment's capacity (skewed input: one k-mer repeated
+// thousands of times lands in one band) goes to a shared overflow list.  k_route_compact then packs
+// the segments into the caller's contiguous per-destination send buffers.
+struct RouteParams {
+    HashParams hp;
+    int ndest;
+    uint32_t nwg, quota;         // workgroups, tiles per workgroup at most
+    uint64_t bs;                 // band width UINT64_MAX / ndest (kv_band_bounds)
+    uint64_t read_base;          // global index of this shard's first read
+    uint64_t seg_cap;            // items per private segment
+    uint64_t *seg;               // [ndest][nwg][seg_cap] items (1 or 2 words each)
+    uint32_t *seg_count;         // [ndest][nwg]
+    uint64_t *seg_off;           // [ndest][nwg] position of the segment in the packed output
+    uint64_t *ovf;               // overflow items
+    uint8_t *ovf_dest;
+    uint64_t ovf_cap;
+    unsigned long long *ctr;     // [0] tile hand-out, [1] overflow items, [2 + d] packed items of destination d
+    uint64_t cap;                // items per destination in the caller's buffer
+    uint64_t *out;               // [ndest][cap] items
+};
+
+template <int NW, bool TAGS>
+__global__ __launch_bounds__(ROUTE_THREADS, 6) void k_route_hashes(ReadsDev rd, uint32_t n_tiles, RouteParams p)
+{
+    __shared__ TileShared sh;
+    __shared__ uint32_t cur[ROUTE_MAX_DEST];
+    __shared__ uint64_t lo[ROUTE_MAX_DEST];
+    __shared__ uint8_t flagged[KV_TILE_MAX_READS];
+    __shared__ uint32_t next_tile;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t W = TAGS ? 2 : 1;
+    if (threadIdx.x == 0) sh.ascii = (uint32_t *)smem;
+    if (threadIdx.x < (uint32_t)p.ndest) { cur[threadIdx.x] = 0; lo[threadIdx.x] = p.bs * (uint64_t)threadIdx.x; }
+    for (uint32_t done = 0; done < p.quota; ++done) {
+        __syncthreads();
+        if (threadIdx.x == 0) next_tile = (uint32_t)atomicAdd(&p.ctr[0], 1ull);
+        __syncthreads();
+        const uint32_t tile = next_tile;
+        if (tile >= n_tiles) break;
+        uint32_t read0;
+        const uint32_t nr = stage_tile(sh, rd, tile, p.hp.k, 0, 0, read0);
+        if (TAGS) {
+            if (threadIdx.x < nr) flagged[threadIdx.x] = rd.flags[read0 + threadIdx.x] & 1;
+            __syncthreads();
+        }
+        const uint32_t total = sh.kpre[nr];
+        const uint32_t run = (total + ROUTE_THREADS - 1) / ROUTE_THREADS;
+        const uint32_t q0 = threadIdx.x * run, q1 = min(total, q0 + run);
+        KmerRoll<(NW > 0 ? NW : 8)> w;
+        if (NW > 0 && q0 < q1) {
+            locate_kmer(sh, nr, q0, w.r, w.i);
+            roll_load(w, sh, p.hp.k);
+        }
+        for (uint32_t step = 0; step < run; ++step) {
+            const uint32_t q = NW > 0 ? q0 + step : step * ROUTE_THREADS + threadIdx.x;
+            const bool live = NW > 0 ? q < q1 : q < total;
+            if (!live) continue;
+            uint64_t h;
+            uint32_t r, i;
+            if (NW > 0) {
+                h = roll_hash(w, p.hp);
+                r = w.r; i = w.i;
+                if (q + 1 < q1) roll_step(w, sh, nr, p.hp.k);
+            } else {
+                locate_kmer(sh, nr, q, r, i);
+                const uint32_t fwd = sh.foff[r] + i;
+                const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)p.hp.k - i);
+                h = kmer_hash_lds(sh.ascii, fwd, rc, p.hp);
+            }
+            if (h == UINT64_MAX) continue;   // the top hash value belongs to no band (count.py:64-66: bands are half-open)
+            uint32_t d = 0;
+            for (int b = 1; b < p.ndest; ++b) d += h >= lo[b] ? 1u : 0u;
+            uint64_t tag = 0;
+            if (TAGS) {
+                tag = ((p.read_base + read0 + r) << 16) | (uint64_t)i;
+                if (flagged[r]) tag |= 1ull << 63;
+            }
+            const uint32_t pos = atomicAdd(&cur[d], 1u);
+            if (pos < p.seg_cap) {
+                uint64_t *dst = p.seg + (((uint64_t)d * p.nwg + blockIdx.x) * p.seg_cap + pos) * W;
+                if (TAGS) *(ulonglong2 *)dst = make_ulonglong2(h, tag);
+                else *dst = h;
+            } else {
+                const unsigned long long o = atomicAdd(&p.ctr[1], 1ull);
+                if (o < p.ovf_cap) {
+                    if (TAGS) *(ulonglong2 *)(p.ovf + 2 * o) = make_ulonglong2(h, tag);
+                    else p.ovf[o] = h;
+                    p.ovf_dest[o] = (uint8_t)d;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)p.ndest)
+        p.seg_count[(uint64_t)threadIdx.x * p.nwg + blockIdx.x] = (uint32_t)min((uint64_t)cur[threadIdx.x], p.seg_cap);
+}
+
+// one workgroup per destination: exclusive scan of its nwg (<= 1024) segment counts
+__global__ __launch_bounds__(ROUTE_MAX_WG) void k_route_scan(RouteParams p)
+{
+    __shared__ uint64_t wsum[ROUTE_MAX_WG / 64];
+    const uint32_t d = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t v = threadIdx.x < p.nwg ? p.seg_count[(uint64_t)d * p.nwg + threadIdx.x] : 0;
+    uint64_t incl = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint64_t up = __shfl_up(incl, s);
+        if (lane >= (uint32_t)s) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint64_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
+    if (threadIdx.x < p.nwg) p.seg_off[(uint64_t)d * p.nwg + threadIdx.x] = before + incl - v;
+    if (threadIdx.x == ROUTE_MAX_WG - 1) p.ctr[2 + d] = before + incl;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_route_compact(RouteParams p)
+{
+    const uint32_t wg = blockIdx.x, d = blockIdx.y;
+    const uint64_t n = p.seg_count[(uint64_t)d * p.nwg + wg];
+    const uint64_t *src = p.seg + ((uint64_t)d * p.nwg + wg) * p.seg_cap * W;
+    uint64_t *dst = p.out + ((uint64_t)d * p.cap + p.seg_off[(uint64_t)d * p.nwg + wg]) * W;
+    for (uint64_t j = threadIdx.x; j < n * W; j += 256) dst[j] = src[j];
+}
+
+// overflow items join the tail of their destination (after the packed segments)
+template <int W>
+__global__ void k_route_tail(RouteParams p)
+{
+    unsigned long long n = p.ctr[1];
+    if (n > p.ovf_cap) n = p.ovf_cap;
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t d = p.ovf_dest[j];
+        const unsigned long long pos = atomicAdd(&p.ctr[2 + d], 1ull);
+        if (pos < p.cap)
+            for (int w = 0; w < W; ++w) p.out[((uint64_t)d * p.cap + pos) * W + w] = p.ovf[j * W + w];
+    }
+}
+
+struct Scratch {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t need(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+};
+std::map<hipStream_t, Scratch> g_route_scratch;   // grow-only, one arena per stream
+std::mutex g_route_mu;
+
+inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+__global__ void k_iota_u32(uint32_t *v, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
+}
+
+__global__ void k_gather_hits(const uint64_t *sorted_tags, const uint32_t *sorted_idx, const uint8_t *abund, uint64_t n,
+                              int S, uint32_t *out_read, uint32_t *out_off, uint8_t *out_abund)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t tag = sorted_tags[i];
+        out_read[i] = (uint32_t)(tag >> 16);
+        out_off[i] = (uint32_t)(tag & 0xffffu);
+        const uint64_t src = sorted_idx[i];
+        for (int c = 0; c < S; ++c) out_abund[i * (uint64_t)S + c] = abund[src * (uint64_t)S + c];
+    }
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+    template <typename T> T *as() { return (T *)p; }
+};
+
+}  // namespace
+
+extern "C" int kv_route_hashes(const kv_reads *reads, int kind, int ksize, int ndest, uint64_t read_index_base,
+                               int with_tags, void *d_out, uint64_t cap_items, uint64_t *counts_out)
+{
+    KV_REQUIRE(reads && d_out && counts_out, KV_ERR_ARG, "kv_route_hashes: null argument");
+    KV_REQUIRE(ndest >= 1 && ndest <= ROUTE_MAX_DEST, KV_ERR_ARG, "kv_route_hashes: 1..%d destinations, got %d",
+               ROUTE_MAX_DEST, ndest);
+    KV_REQUIRE(ksize >= 1 && reads->max_len < 65536, KV_ERR_ARG, "kv_route_hashes: bad k or read longer than a tag can address");
+    KV_REQUIRE(read_index_base + reads->n_reads < (1ull << 46), KV_ERR_ARG, "kv_route_hashes: read index does not fit the tag");
+    uint64_t n_kmers = 0;
+    kv_reads_num_kmers(reads, ksize, &n_kmers);
+    KV_REQUIRE(cap_items >= n_kmers, KV_ERR_CAPACITY,
+               "kv_route_hashes: each destination needs room for all %llu k-mers of the shard (worst case)",
+               (unsigned long long)n_kmers);
+    for (int d = 0; d < ndest; ++d) counts_out[d] = 0;
+    if (reads->n_tiles == 0 || n_kmers == 0) return KV_OK;
+    const uint32_t W = with_tags ? 2u : 1u;
+    RouteParams p;
+    memset(&p, 0, sizeof(p));
+    p.hp = make_hash_params(ksize, kv_hashfam_of(kind));
+    p.ndest = ndest;
+    p.bs = UINT64_MAX / (uint64_t)ndest;
+    p.read_base = read_index_base;
+    p.cap = cap_items;
+    p.out = (uint64_t *)d_out;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const size_t lds = reads->tile_lds_bytes;
+    const int per_cu = std::max(1, std::min(3, (int)(160 * 1024 / (lds + 2048))));
+    p.nwg = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(reads->n_tiles, (uint64_t)per_cu * (uint64_t)cus), ROUTE_MAX_WG);
+    // dynamic hand-out, at most 1.5x the average share: bounds what one workgroup can put into a segment
+    p.quota = (uint32_t)((reads->n_tiles + p.nwg - 1) / p.nwg);
+    p.quota += p.quota / 2 + 1;
+    const double m = 1.5 * (double)n_kmers / ((double)p.nwg * ndest);   // a full quota, spread evenly over the bands
+    p.seg_cap = round_up((uint64_t)(m * 1.1 + 8.0 * std::sqrt(m)) + 1024, 64);
+    p.ovf_cap = n_kmers;                                                    // worst case: no capacity error possible
+    const size_t b_seg = round_up((uint64_t)ndest * p.nwg * p.seg_cap * 8 * W, 256);
+    const size_t b_cnt = round_up((uint64_t)ndest * p.nwg * 4, 256), b_off = round_up((uint64_t)ndest * p.nwg * 8, 256);
+    const size_t b_ovf = round_up(p.ovf_cap * 8 * W, 256), b_od = round_up(p.ovf_cap, 256), b_ctr = 256;
+    hipStream_t st = kv_stream();
+    Scratch *scratch;
+    {
+        std::lock_guard<std::mutex> lk(g_route_mu);
+        scratch = &g_route_scratch[st];
+    }
+    KV_HIP(scratch->need(b_seg + b_cnt + b_off + b_ovf + b_od + b_ctr));
+    unsigned char *base = (unsigned char *)scratch->p;
+    p.seg = (uint64_t *)base; base += b_seg;
+    p.seg_count = (uint32_t *)base; base += b_cnt;
+    p.seg_off = (uint64_t *)base; base += b_off;
+    p.ovf = (uint64_t *)base; base += b_ovf;
+    p.ovf_dest = (uint8_t *)base; base += b_od;
+    p.ctr = (unsigned long long *)base;
+    KV_HIP(hipMemsetAsync(p.ctr, 0, b_ctr, st));
+    {
+        KvProfScope prof("k_route_hashes");
+        const int nw = p.hp.hashfam == HF_MURMUR ? (ksize <= 32 ? 8 : (ksize <= 64 ? 16 : 0)) : 0;
+#define KV_LAUNCH_ROUTE(NW_, TAGS_)                                                                              \
+        do {                                                                                                     \
+            kv_ensure_dynamic_lds((const void *)k_route_hashes<NW_, TAGS_>, lds);                                \
+            hipLaunchKernelGGL((k_route_hashes<NW_, TAGS_>), dim3(p.nwg), dim3(ROUTE_THREADS), lds, st,          \
+                               reads_dev(reads), reads->n_tiles, p);                                             \
+        } while (0)
+        if (with_tags) {
+            if (nw == 8) KV_LAUNCH_ROUTE(8, true); else if (nw == 16) KV_LAUNCH_ROUTE(16, true); else KV_LAUNCH_ROUTE(0, true);
+        } else {
+            if (nw == 8) KV_LAUNCH_ROUTE(8, false); else if (nw == 16) KV_LAUNCH_ROUTE(16, false); else KV_LAUNCH_ROUTE(0, false);
+        }
+#undef KV_LAUNCH_ROUTE
+    }
+    {
+        KvProfScope prof("k_route_compact");
+        hipLaunchKernelGGL(k_route_scan, dim3((unsigned)ndest), dim3(ROUTE_MAX_WG), 0, st, p);
+        if (with_tags) {
+            hipLaunchKernelGGL(k_route_compact<2>, dim3(p.nwg, (unsigned)ndest), dim3(256), 0, st, p);
+            hipLaunchKernelGGL(k_route_tail<2>, dim3(256), dim3(256), 0, st, p);
+        } else {
+            hipLaunchKernelGGL(k_route_compact<1>, dim3(p.nwg, (unsigned)ndest), dim3(256), 0, st, p);
+            hipLaunchKernelGGL(k_route_tail<1>, dim3(256), dim3(256), 0, st, p);
+        }
+    }
+    KV_HIP(hipGetLastError());
+    unsigned long long host[ROUTE_MAX_DEST + 2];
+    KV_HIP(hipMemcpyAsync(host, p.ctr, (size_t)(ndest + 2) * 8, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    KV_REQUIRE(host[0] >= reads->n_tiles, KV_ERR_HIP, "kv_route_hashes: %llu of %u tiles processed", host[0], reads->n_tiles);
+    for (int d = 0; d < ndest; ++d) counts_out[d] = host[2 + d];
+    return KV_OK;
+}
+
+// n_total gathered hits (tag, S abundance bytes each), of which the n_valid smallest tags are real
+// (padding carries tag ~0): sort by tag = (read, offset) and hand back an ordinary kv_hits.
+extern "C" int kv_hits_from_tagged(const void *d_tags, const void *d_abund, uint64_t n_total, uint64_t n_valid,
+                                   int nsamples, kv_hits **out)
+{
+    KV_REQUIRE(out && n_valid <= n_total && nsamples >= 1 && nsamples <= KV_MAX_SAMPLES, KV_ERR_ARG,
+               "kv_hits_from_tagged: bad argument");
+    KV_REQUIRE(n_total == 0 || (d_tags && d_abund), KV_ERR_ARG, "kv_hits_from_tagged: null buffer");
+    KV_REQUIRE(n_total < (1ull << 32), KV_ERR_ARG, "kv_hits_from_tagged: too many hits");
+    kv_hits *hits = new kv_hits();
+    hits->nsamples = nsamples;
+    *out = hits;
+    if (n_valid == 0) return KV_OK;
+    hipStream_t st = kv_stream();
+    DevBuf k_out, v_in, v_out, tmp, o_read, o_off, o_abund;
+    hipError_t e = k_out.alloc(n_total * 8);
+    if (e == hipSuccess) e = v_in.alloc(n_total * 4);
+    if (e == hipSuccess) e = v_out.alloc(n_total * 4);
+    if (e == hipSuccess) e = o_read.alloc(n_valid * 4);
+    if (e == hipSuccess) e = o_off.alloc(n_valid * 4);
+    if (e == hipSuccess) e = o_abund.alloc(n_valid * (uint64_t)nsamples);
+    size_t tmp_bytes = 0;
+    if (e == hipSuccess)
+        e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned long long *)d_tags, k_out.as<unsigned long long>(),
+                                      v_in.as<uint32_t>(), v_out.as<uint32_t>(), (size_t)n_total, 0, 64, st);
+    if (e == hipSuccess) e = tmp.alloc(tmp_bytes);
+    if (e == hipSuccess) {
+        KvProfScope prof("sort_hits");
+        hipLaunchKernelGGL(k_iota_u32, dim3(256), dim3(256), 0, st, v_in.as<uint32_t>(), n_total);
+        e = rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (const unsigned long long *)d_tags, k_out.as<unsigned long long>(),
+                                      v_in.as<uint32_t>(), v_out.as<uint32_t>(), (size_t)n_total, 0, 64, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_gather_hits, dim3(256), dim3(256), 0, st, k_out.as<uint64_t>(), v_out.as<uint32_t>(),
+                               (const uint8_t *)d_abund, n_valid, nsamples, o_read.as<uint32_t>(), o_off.as<uint32_t>(),
+                               o_abund.as<uint8_t>());
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) e = hits->read.resize(n_valid);
+    if (e == hipSuccess) e = hits->offset.resize(n_valid);
+    if (e == hipSuccess) e = hits->abund.resize(n_valid * (uint64_t)nsamples);
+    if (e == hipSuccess) e = hipMemcpyAsync(hits->read.data(), o_read.p, n_valid * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hits->offset.data(), o_off.p, n_valid * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hits->abund.data(), o_abund.p, n_valid * (uint64_t)nsamples, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        delete hits;
+        *out = nullptr;
+        kv_set_error("kv_hits_from_tagged failed: %s", hipGetErrorString(e));
+        return KV_ERR_HIP;
+    }
+    return KV_OK;
+}

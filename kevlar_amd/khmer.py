@@ -535,6 +535,13 @@ class _Sketch(object):
                     self._exact_cache = None
         return n.value
 
+    def consume_hashes(self, hashes_ptr, n, stride_words=1):
+        """Count n hashes resident in HBM (device address; element i at word i * stride_words)."""
+        added = ctypes.c_uint64()
+        check(_lib.load().kv_consume_hashes(self._h, ctypes.c_void_p(hashes_ptr), int(n), int(stride_words),
+                                            ctypes.byref(added)))
+        return added.value
+
     def consume(self, seq):
         return self.consume_batch(ReadBatch([seq]))
 
@@ -604,12 +611,18 @@ def novel_scan(cases, controls, batch, case_min, ctrl_max, screen=None, band_mod
     check(lib.kv_novel_scan(ca, len(cases), cb, len(controls), batch._h, int(first_read), int(case_min),
                             int(ctrl_max), int(screen or 0), int(band_mode), int(nbands or 0),
                             int(band or 0), mask_ptr, int(mask_stride), ctypes.byref(hits)))
+    return _hits_arrays(hits, S)
+
+
+def _hits_arrays(hits, S):
+    """(read, offset, abund[n, S], discarded) views into a kv_hits handle's pinned arrays: no second
+    copy; the handle lives as long as the arrays do."""
+    lib = _lib.load()
     holder = _HitsHandle(hits)
     n, nd = ctypes.c_uint64(), ctypes.c_uint64()
     check(lib.kv_hits_count(hits, ctypes.byref(n), ctypes.byref(nd)))
     pr, po, pa, pd = _lib.u32p(), _lib.u32p(), _lib.u8p(), _lib.u32p()
     check(lib.kv_hits_view(hits, ctypes.byref(pr), ctypes.byref(po), ctypes.byref(pa), ctypes.byref(pd)))
-    # views into the handle's pinned arrays: no second copy; the handle lives as long as the arrays do
 
     def view(ptr, shape, dtype):
         if int(np.prod(shape)) == 0:
@@ -621,6 +634,39 @@ def novel_scan(cases, controls, batch, case_min, ctrl_max, screen=None, band_mod
     abund = view(pa, (n.value, S), np.uint8)
     disc = np.array(np.ctypeslib.as_array(pd, shape=(nd.value,)), dtype=np.uint32) if nd.value else np.empty(0, dtype=np.uint32)
     return reads, offs, abund, disc
+
+
+# ----------------------------------------------------------------------------------------
+# read-sharded multi-GPU primitives (kv_shard.hip; driven by kevlar_amd/shardrun.py).  The *_ptr
+# arguments are device addresses of caller-owned buffers (torch tensors' data_ptr()).
+# ----------------------------------------------------------------------------------------
+def route_hashes(batch, sketch_cls, ksize, ndest, read_index_base, with_tags, out_ptr, cap_items):
+    """Hash every k-mer of `batch` and append it to the send buffer of the band that owns it;
+    returns the number of items per destination."""
+    counts = (ctypes.c_uint64 * int(ndest))()
+    check(_lib.load().kv_route_hashes(batch._h, sketch_cls._kind, int(ksize), int(ndest), int(read_index_base),
+                                      1 if with_tags else 0, ctypes.c_void_p(out_ptr), int(cap_items), counts))
+    return [int(c) for c in counts]
+
+
+def novel_scan_hashes(cases, controls, items_ptr, n_items, case_min, ctrl_max, hit_tags_ptr, hit_abund_ptr, hit_cap):
+    """kmer_is_interesting() over (hash, tag) pairs in HBM; returns the number of hits written."""
+    ca = (ctypes.c_void_p * len(cases))(*[c._h for c in cases])
+    cb = (ctypes.c_void_p * max(1, len(controls)))(*[c._h for c in controls])
+    n = ctypes.c_uint64()
+    check(_lib.load().kv_novel_scan_hashes(ca, len(cases), cb, len(controls), ctypes.c_void_p(items_ptr), int(n_items),
+                                           int(case_min), int(ctrl_max), ctypes.c_void_p(hit_tags_ptr),
+                                           ctypes.c_void_p(hit_abund_ptr), int(hit_cap), ctypes.byref(n)))
+    return n.value
+
+
+def hits_from_tagged(tags_ptr, abund_ptr, n_total, n_valid, nsamples):
+    """Sort gathered (tag, abundances) hits into (read, offset) order; returns (read, offset, abund)."""
+    hits = ctypes.c_void_p()
+    check(_lib.load().kv_hits_from_tagged(ctypes.c_void_p(tags_ptr), ctypes.c_void_p(abund_ptr), int(n_total),
+                                          int(n_valid), int(nsamples), ctypes.byref(hits)))
+    r, o, a, _ = _hits_arrays(hits, nsamples)
+    return r, o, a
 
 
 class _HitsHandle(object):

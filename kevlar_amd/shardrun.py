@@ -1,0 +1,190 @@
+"""Read-sharded trio run over the GPUs of one node: hash once, exchange by band.
+
+kevlar's way to split a trio over N workers is k-mer banding (docs/banding.rst,
+kevlar/count.py:62-66, kevlar/novel.py:144-147): worker b owns the hash range of band b -- but
+every worker still reads and hashes every read.  On one node that replication is most of a banded
+rank's time.  Here rank r holds reads [r*n/N, (r+1)*n/N) of every sample,
+hashes them once (kv_route_hashes), and one all-to-all over RCCL/xGMI delivers each hash to the
+rank that owns its band; the owner counts what it receives (kv_consume_hashes) into the very
+sketch the banded run would have built, and scans the case k-mers it received
+(kv_novel_scan_hashes).  Hits are all-gathered and sorted back into (read, offset) order.
+
+torch is plumbing: it owns the exchange buffers and moves them; all arithmetic is in the HIP
+library.  With the gloo backend (CPU tests, or several ranks sharing one GPU) the buffers are
+staged through host memory.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from kevlar_amd import khmer as hk
+
+
+def shard_bounds(n_reads, world, rank):
+    """Reads [lo, hi) of a sample that rank `rank` hashes."""
+    return (n_reads * rank) // world, (n_reads * (rank + 1)) // world
+
+
+class _Exchange(object):
+    """An all-to-all in flight: wait() returns the received rows."""
+
+    def __init__(self, work, recv, recv_counts, keep):
+        self.work, self.recv, self.recv_counts, self._keep = work, recv, recv_counts, keep
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        # the HIP library runs on its own stream: order by the host, but wait for THIS exchange only
+        # (a later one may still be in flight on RCCL's stream)
+        torch.cuda.current_stream().synchronize()
+        self._keep = None
+        return self.recv
+
+
+def exchange_rows_async(send, counts, group=None, staged=False):
+    """All-to-all of variable-length row blocks.
+
+    send: tensor [world, cap, ...]; rows [d, :counts[d]] go to rank d.  The received blocks (from rank
+    0, 1, ... back to back) come from the returned handle's wait().  When this returns `send` may be
+    reused: its rows were packed into a private buffer.  `staged` moves the data through host memory
+    (gloo cannot transport device tensors) and completes before returning."""
+    world = dist.get_world_size(group)
+    assert send.shape[0] == world and len(counts) == world
+    coll_dev = torch.device('cpu') if staged else send.device
+    mine = torch.tensor(counts, dtype=torch.int64, device=coll_dev)
+    table = torch.empty(world * world, dtype=torch.int64, device=coll_dev)
+    dist.all_gather_into_tensor(table, mine, group=group)
+    table = table.view(world, world).cpu()
+    rank = dist.get_rank(group)
+    recv_counts = [int(table[src, rank]) for src in range(world)]
+    packed = torch.cat([send[d, :counts[d]] for d in range(world)], dim=0)
+    recv = torch.empty((sum(recv_counts),) + tuple(send.shape[2:]), dtype=send.dtype, device=send.device)
+    if staged:
+        src_host = packed.cpu()
+        dst_host = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(dst_host, src_host, recv_counts, list(counts), group=group)
+        recv.copy_(dst_host)
+        torch.cuda.synchronize()
+        return _Exchange(None, recv, recv_counts, None)
+    torch.cuda.current_stream().synchronize()      # packed is complete: the caller may overwrite `send`
+    work = dist.all_to_all_single(recv, packed, recv_counts, list(counts), group=group, async_op=True)
+    return _Exchange(work, recv, recv_counts, packed)
+
+
+def exchange_rows(send, counts, group=None, staged=False):
+    """Blocking form of exchange_rows_async: returns (recv, recv_counts)."""
+    ex = exchange_rows_async(send, counts, group, staged)
+    return ex.wait(), ex.recv_counts
+
+
+def gather_rows(rows, n_valid, fill, group=None, staged=False):
+    """All-gather of each rank's first n_valid rows, padded with `fill` to the longest; returns
+    (gathered [world * longest, ...], total valid)."""
+    world = dist.get_world_size(group)
+    coll_dev = torch.device('cpu') if staged else rows.device
+    mine = torch.tensor([n_valid], dtype=torch.int64, device=coll_dev)
+    sizes = torch.empty(world, dtype=torch.int64, device=coll_dev)
+    dist.all_gather_into_tensor(sizes, mine, group=group)
+    sizes = [int(v) for v in sizes.cpu()]
+    longest = max(max(sizes), 1)
+    padded = torch.full((longest,) + tuple(rows.shape[1:]), fill, dtype=rows.dtype, device=rows.device)
+    padded[:n_valid] = rows[:n_valid]
+    out = torch.empty((world * longest,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    if staged:
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host_out, padded.cpu(), group=group)
+        out.copy_(host_out)
+    else:
+        dist.all_gather_into_tensor(out, padded, group=group)
+    return out, sum(sizes)
+
+
+class ShardedTrio(object):
+    """One rank of a read-sharded count + novel run.  Every rank calls the same methods in the
+    same order (they contain collectives).
+
+    sketch_cls: kevlar_amd.khmer sketch class; the rank's sketches are ordinary sketches of 1/N of
+    the memory, i.e. exactly band `rank` of an N-band run."""
+
+    def __init__(self, ksize, sketch_cls=hk.Counttable, group=None, staged=None, device=None):
+        self.ksize = int(ksize)
+        self.sketch_cls = sketch_cls
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        backend = dist.get_backend(group)
+        self.staged = (backend != 'nccl') if staged is None else bool(staged)
+        self.device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self._send = {}          # words per item -> send buffer [world, cap, words]
+        self.case_items = None   # (hash, tag) pairs of the case k-mers this rank owns
+        self.timing = {'route': 0.0, 'exchange': 0.0, 'count': 0.0, 'scan': 0.0, 'gather': 0.0}
+
+    def _send_buffer(self, cap, words):
+        buf = self._send.get(words)
+        if buf is None or buf.shape[1] < cap:
+            self._send[words] = None
+            buf = torch.empty((self.world, cap, words), dtype=torch.int64, device=self.device)
+            self._send[words] = buf
+        return buf
+
+    def start(self, batch, read_index_base, with_tags):
+        """Hash this rank's shard of a sample and start delivering every hash to its band's owner.
+        Returns a handle for finish(); the next sample's start() may run while the exchange flies."""
+        import time
+        words = 2 if with_tags else 1
+        cap = max(batch.num_kmers(self.ksize), 1)       # worst case: every k-mer of the shard in one band
+        send = self._send_buffer(cap, words)
+        t0 = time.perf_counter()
+        counts = hk.route_hashes(batch, self.sketch_cls, self.ksize, self.world, read_index_base, with_tags,
+                                 send.data_ptr(), send.shape[1])
+        t1 = time.perf_counter()
+        ex = exchange_rows_async(send, counts, self.group, self.staged)
+        self.timing['route'] += t1 - t0
+        self.timing['exchange'] += time.perf_counter() - t1
+        return ex
+
+    def finish(self, ex, sketch, keep_for_scan=False):
+        """Wait for the exchange and count the received hashes into `sketch` (= band `rank`).
+        keep_for_scan: this is a case sample -- keep its (hash, tag) pairs for scan().  Returns the
+        number of k-mers counted on this rank."""
+        import time
+        t0 = time.perf_counter()
+        recv = ex.wait()
+        t1 = time.perf_counter()
+        n = recv.shape[0]
+        if n:
+            sketch.consume_hashes(recv.data_ptr(), n, recv.shape[1])
+        self.timing['exchange'] += t1 - t0
+        self.timing['count'] += time.perf_counter() - t1
+        if keep_for_scan:
+            self.case_items = recv
+        return n
+
+    def count_sample(self, sketch, batch, read_index_base=0, keep_for_scan=False):
+        """start() + finish() for one sample: `batch` is this rank's shard of its reads (global index of
+        its first read = read_index_base)."""
+        return self.finish(self.start(batch, read_index_base, keep_for_scan), sketch, keep_for_scan)
+
+    def scan(self, cases, controls, case_min, ctrl_max):
+        """kmer_is_interesting() over the case k-mers this rank owns, then gather: every rank returns
+        the complete (read, offset, abund[n, S]) hit arrays in (read, offset) order."""
+        import time
+        assert self.case_items is not None, 'count_sample(..., keep_for_scan=True) first'
+        S = len(cases) + len(controls)
+        items = self.case_items
+        n = items.shape[0]
+        t0 = time.perf_counter()
+        cap = max(min(n, 1 << 26), 1)
+        tags = torch.empty(cap, dtype=torch.int64, device=self.device)
+        abund = torch.empty((cap, S), dtype=torch.uint8, device=self.device)
+        n_hits = hk.novel_scan_hashes(cases, controls, items.data_ptr(), n, case_min, ctrl_max,
+                                      tags.data_ptr(), abund.data_ptr(), cap) if n else 0
+        t1 = time.perf_counter()
+        all_tags, total = gather_rows(tags, n_hits, -1, self.group, self.staged)
+        all_abund, _ = gather_rows(abund, n_hits, 0, self.group, self.staged)
+        torch.cuda.synchronize()
+        r, o, a = hk.hits_from_tagged(all_tags.data_ptr(), all_abund.data_ptr(), all_tags.shape[0], total, S)
+        self.timing['scan'] += t1 - t0
+        self.timing['gather'] += time.perf_counter() - t1
+        return r, o, a

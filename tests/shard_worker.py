@@ -1,0 +1,54 @@
+"""One rank of tests/test_gpu_shard.py::test_sharded_trio_ranks_share_one_gpu (not a test module)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def main():
+    torch.cuda.init()
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from kevlar_amd import _lib, bandmerge, khmer as hk, shardrun, synth
+    _lib.load()
+    _lib.require_device()
+    k, mem = 31, 4.0e6
+    trio = synth.make_trio(250000, 33)
+    names = ('proband', 'mother', 'father')
+    reads = {n: synth.unpack_reads(synth.sample_reads_packed(trio[n], 50001, 100, 0.005, 7 + i), 100)
+             for i, n in enumerate(names)}
+    reads['proband'][3] = reads['proband'][3][:30] + 'N' + reads['proband'][3][31:]
+
+    run = shardrun.ShardedTrio(k, hk.Counttable)
+    sharded = {n: hk.Counttable(k, mem / world / 4, 4) for n in names}
+    for n in names:
+        lo, hi = shardrun.shard_bounds(len(reads[n]), world, rank)
+        run.count_sample(sharded[n], hk.ReadBatch(reads[n][lo:hi]), lo, keep_for_scan=(n == 'proband'))
+    r, o, a = run.scan([sharded['proband']], [sharded['mother'], sharded['father']], 6, 1)
+
+    # the banded run of the same trio, band = rank, every read hashed here
+    full = {n: hk.ReadBatch(reads[n]) for n in names}
+    banded = {n: hk.Counttable(k, mem / world / 4, 4) for n in names}
+    for n in names:
+        banded[n].consume_batch(full[n], world, rank)
+        for t in range(4):
+            assert sharded[n].table_bytes(t) == banded[n].table_bytes(t), (n, t)
+        assert sharded[n].n_occupied() == banded[n].n_occupied()
+    br, bo, ba, _ = hk.novel_scan([banded['proband']], [banded['mother'], banded['father']], full['proband'], 6, 1,
+                                  band_mode=1, nbands=world, band=rank)
+    mr, mo, ma = bandmerge.allgather_hits(br, bo, ba, torch.device('cpu'))
+    assert len(mr) > 50
+    assert np.array_equal(r, mr) and np.array_equal(o, mo) and np.array_equal(a, ma)
+    dist.barrier()
+    dist.destroy_process_group()
+    print('shard worker ok: rank {} of {}, {} hits'.format(rank, world, len(r)))
+
+
+if __name__ == '__main__':
+    main()

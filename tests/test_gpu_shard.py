@@ -1,0 +1,176 @@
+"""Read-sharded multi-GPU path (kv_shard.hip, kevlar_amd/shardrun.py): hashes routed by band must be
+exactly the oracle's hashes, a sketch counted from routed hashes must equal the band-b sketch of a
+banded run, and the gathered hits must equal the banded scan's -- first inside one process, then with
+two ranks sharing this GPU (gloo, host-staged exchange: the nccl path differs only in the transport)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_reads(n, seed, with_n=True):
+    from kevlar_amd import synth
+    trio = synth.make_trio(300000, seed)
+    words = synth.sample_reads_packed(trio['proband'], n, 100, 0.005, seed + 1)
+    reads = synth.unpack_reads(words, 100)
+    if with_n:
+        reads[7] = reads[7][:40] + 'N' + reads[7][41:]      # scan skips it, count keeps its k-mers' stand-ins
+        reads[11] = reads[11][:20]                            # shorter than k: contributes nothing
+        reads.append('ACGT' * 13)                             # ragged lengths -> non-uniform tile
+    return reads
+
+
+@pytest.mark.parametrize('ndest,with_tags', [(1, False), (4, False), (3, True), (8, True)])
+def test_route_matches_oracle_hashes(hk, ok, ndest, with_tags):
+    import torch
+    k = 31
+    reads = make_reads(3000, 3)
+    batch = hk.ReadBatch(reads)
+    nk = batch.num_kmers(k)
+    words = 2 if with_tags else 1
+    send = torch.zeros((ndest, nk, words), dtype=torch.int64, device='cuda')
+    base = 1000
+    counts = hk.route_hashes(batch, hk.Counttable, k, ndest, base, with_tags, send.data_ptr(), nk)
+    assert sum(counts) == nk
+    host = send.cpu().numpy().view(np.uint64)
+    bs = (2 ** 64 - 1) // ndest
+    ct = ok.Counttable(k, 1000, 1)
+    expect = {}          # (read, offset) -> hash, over what the device counts (N is packed as a stand-in base)
+    for r, seq in enumerate(reads):
+        if len(seq) < k:
+            continue
+        hashes = ct.get_kmer_hashes(seq.replace('N', 'A'))
+        for i, h in enumerate(hashes):
+            expect[(r, i)] = int(h)
+    got_multiset = []
+    for d in range(ndest):
+        block = host[d, :counts[d]]
+        hs = block[:, 0]
+        lo = bs * d
+        hi = 2 ** 64 - 1 if d == ndest - 1 else bs * (d + 1)
+        assert ((hs >= lo) & (hs < hi)).all()
+        got_multiset.append(hs)
+        if with_tags:
+            tags = block[:, 1]
+            flagged = (tags >> np.uint64(63)).astype(bool)
+            rd = ((tags & np.uint64(2 ** 63 - 1)) >> np.uint64(16)).astype(np.int64) - base
+            off = (tags & np.uint64(0xffff)).astype(np.int64)
+            for j in range(len(hs)):
+                assert expect[(int(rd[j]), int(off[j]))] == int(hs[j])
+                assert bool(flagged[j]) == ('N' in reads[int(rd[j])])
+    got = np.sort(np.concatenate(got_multiset))
+    assert np.array_equal(got, np.sort(np.array(list(expect.values()), dtype=np.uint64)))
+
+
+@pytest.mark.parametrize('force', [None, 'binned'])
+def test_consume_hashes_equals_banded_consume(hk, force):
+    """band b of a banded run == hashes routed to destination b, then kv_consume_hashes"""
+    import torch
+    k, nb = 25, 3
+    reads = make_reads(70000, 5, with_n=False)
+    batch = hk.ReadBatch(reads)
+    nk = batch.num_kmers(k)
+    send = torch.zeros((nb, nk, 1), dtype=torch.int64, device='cuda')
+    counts = hk.route_hashes(batch, hk.SmallCounttable, k, nb, 0, False, send.data_ptr(), nk)
+    if force:
+        os.environ['KV_COUNT_PATH'] = force
+    try:
+        for b in range(nb):
+            banded = hk.SmallCounttable(k, 1.4e6, 4)
+            n_b = banded.consume_batch(batch, nb, b)
+            routed = hk.SmallCounttable(k, 1.4e6, 4)
+            assert routed.consume_hashes(send[b].data_ptr(), counts[b]) == counts[b] == n_b
+            for t in range(4):
+                assert routed.table_bytes(t) == banded.table_bytes(t)
+            assert routed.n_occupied() == banded.n_occupied()
+    finally:
+        os.environ.pop('KV_COUNT_PATH', None)
+
+
+def test_consume_hashes_strided_large(hk):
+    """the partitioned list kernel on its natural size, reading (hash, tag) pairs"""
+    import torch
+    k = 31
+    reads = make_reads(80000, 9, with_n=False)
+    batch = hk.ReadBatch(reads)
+    nk = batch.num_kmers(k)
+    send = torch.zeros((1, nk, 2), dtype=torch.int64, device='cuda')
+    counts = hk.route_hashes(batch, hk.Counttable, k, 1, 0, True, send.data_ptr(), nk)
+    assert counts == [nk]
+    direct = hk.Counttable(k, 3.0e6, 4)
+    direct.consume_batch(batch)
+    routed = hk.Counttable(k, 3.0e6, 4)
+    routed.consume_hashes(send.data_ptr(), nk, 2)
+    for t in range(4):
+        assert routed.table_bytes(t) == direct.table_bytes(t)
+
+
+def test_scan_hashes_equals_novel_scan(hk, ok):
+    import torch
+    from kevlar_amd import synth
+    k = 31
+    trio = synth.make_trio(200000, 21)
+    reads = {n: synth.unpack_reads(synth.sample_reads_packed(trio[n], 30000, 100, 0.005, 5 + i), 100)
+             for i, n in enumerate(('proband', 'mother', 'father'))}
+    reads['proband'][5] = reads['proband'][5][:50] + 'N' + reads['proband'][5][51:]
+    batches = {n: hk.ReadBatch(reads[n]) for n in reads}
+    sk = {n: hk.Counttable(k, 2.0e6, 4) for n in reads}
+    for n in reads:
+        sk[n].consume_batch(batches[n])
+    r0, o0, a0, _ = hk.novel_scan([sk['proband']], [sk['mother'], sk['father']], batches['proband'], 6, 1)
+    assert len(r0) > 50
+    nk = batches['proband'].num_kmers(k)
+    send = torch.zeros((1, nk, 2), dtype=torch.int64, device='cuda')
+    counts = hk.route_hashes(batches['proband'], hk.Counttable, k, 1, 0, True, send.data_ptr(), nk)
+    tags = torch.empty(nk, dtype=torch.int64, device='cuda')
+    abund = torch.empty((nk, 3), dtype=torch.uint8, device='cuda')
+    n_hits = hk.novel_scan_hashes([sk['proband']], [sk['mother'], sk['father']], send.data_ptr(), counts[0], 6, 1,
+                                  tags.data_ptr(), abund.data_ptr(), nk)
+    assert n_hits == len(r0)
+    # pad as the gather does, then sort
+    pad = torch.full((n_hits + 100,), -1, dtype=torch.int64, device='cuda')
+    pad[:n_hits] = tags[:n_hits]
+    pa = torch.zeros((n_hits + 100, 3), dtype=torch.uint8, device='cuda')
+    pa[:n_hits] = abund[:n_hits]
+    torch.cuda.synchronize()
+    r1, o1, a1 = hk.hits_from_tagged(pad.data_ptr(), pa.data_ptr(), n_hits + 100, n_hits, 3)
+    assert np.array_equal(r0, r1) and np.array_equal(o0, o1) and np.array_equal(a0, a1)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_trio_ranks_share_one_gpu(hk, world):
+    """N ranks on this one GPU (gloo, staged exchange): each rank's sketches must equal band `rank` of a
+    banded count of ALL reads, and the gathered hits the merged banded scan (tests/shard_worker.py)."""
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'shard_worker.py')], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out.decode(errors='replace'))
+    for rank, p in enumerate(procs):
+        assert p.returncode == 0, 'rank {} failed:\n{}'.format(rank, outs[rank][-3000:])
+        assert 'shard worker ok' in outs[rank]
