@@ -40,6 +40,7 @@ namespace {
 #define BIN_B_BUDGET 16384  // LDS ring entries (u16) per stage-B workgroup
 #define BIN_C_THREADS 1024
 #define BIN_MAX_F 512
+#define BIN_MAX_SEG 512      // stage-B writers per slice (nwgB)
 
 struct BinGeom {
     int T, F, C;                     // tables, slices per coarse bucket, coarse buckets in use (<= BIN_C)
@@ -479,6 +480,56 @@ __device__ __forceinline__ bool lds_inc(uint32_t *lds, uint32_t off, int storage
     }
 }
 
+// Eight saturating increments with the LDS round trips overlapped: all eight words are read first, then
+// all eight compare-and-swaps are issued, and only an item whose word changed in between (another lane, or
+// an earlier item of this same vector, hit the same word) takes the retry loop.  Returns how many bins went 0 -> 1.
+__device__ __forceinline__ uint32_t lds_inc8(uint32_t *lds, const uint32_t (&w)[4], uint32_t n, int storage)
+{
+    uint32_t fresh = 0;
+    if (storage == ST_BIT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t off = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+            if ((uint32_t)e < n) {
+                const uint32_t bit = 1u << (off & 31);
+                fresh += (atomicOr(&lds[off >> 5], bit) & bit) == 0 ? 1u : 0u;
+            }
+        }
+        return fresh;
+    }
+    uint32_t widx[8], shift[8], old[8];
+    const uint32_t maxv = storage == ST_BYTE ? 255u : 15u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t off = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+        if (storage == ST_BYTE) { widx[e] = off >> 2; shift[e] = (off & 3) * 8u; }
+        else { const uint32_t byte = off >> 1; widx[e] = byte >> 2; shift[e] = (byte & 3) * 8u + ((off & 1) ? 0u : 4u); }
+        old[e] = (uint32_t)e < n ? lds[widx[e]] : 0u;
+    }
+    uint32_t prev[8];
+    bool tried[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        tried[e] = (uint32_t)e < n && ((old[e] >> shift[e]) & maxv) != maxv;
+        prev[e] = old[e];
+        if (tried[e]) prev[e] = atomicCAS(&lds[widx[e]], old[e], old[e] + (1u << shift[e]));
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (!tried[e]) continue;                       // absent, or saturated when read (it can only stay saturated)
+        if (prev[e] == old[e]) { fresh += ((old[e] >> shift[e]) & maxv) == 0 ? 1u : 0u; continue; }
+        uint32_t cur_word = prev[e];                   // lost the race: classic retry loop
+        for (;;) {
+            const uint32_t cur = (cur_word >> shift[e]) & maxv;
+            if (cur == maxv) break;
+            const uint32_t seen = atomicCAS(&lds[widx[e]], cur_word, cur_word + (1u << shift[e]));
+            if (seen == cur_word) { fresh += cur == 0 ? 1u : 0u; break; }
+            cur_word = seen;
+        }
+    }
+    return fresh;
+}
+
 __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__restrict__ sk, BinGeom g)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[16384];   // one slice: 65536 counters of <= 8 bits
@@ -496,46 +547,62 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
     const uint32_t nvec = (uint32_t)((nbytes + 15) / 16);
     uint4 *tab = (uint4 *)(sk->tab[t] + byte0);
     uint4 *l4 = (uint4 *)lds;
-    // the slice's items sit in nwgB private segments of cap2 slots (cap2 % 64 == 0: 128-B aligned);
-    // enumerate their 8-item vectors flat so all 512 threads stay busy whatever the segment sizes
+    // the slice's items sit in nwgB private segments of cap2 slots (cap2 % 64 == 0: 128-B aligned, so a
+    // 16-byte vector never leaves its segment).  Their 8-item vectors are enumerated compactly through a
+    // prefix sum over the segments (LDS), so every thread has work whatever the segment fill levels.
+    __shared__ uint32_t seg_cnt[BIN_MAX_SEG], vpre[BIN_MAX_SEG];
+    __shared__ uint32_t wsum[BIN_C_THREADS / 64];
+    __shared__ uint32_t total_vec_sh;
     const uint16_t *items = g.gbuf2 + stream * g.nwgB * g.cap2;
     const uint32_t *counts = g.gcnt2 + stream * g.nwgB;
-    const uint32_t vps = (uint32_t)(g.cap2 / 8), nslots = vps * g.nwgB;
-    bool mine = false;
-    for (uint32_t j = threadIdx.x; j < g.nwgB; j += BIN_C_THREADS) mine |= counts[j] != 0;
-    if (!__syncthreads_or(mine)) return;                           // untouched slice: no table traffic at all
-    // software pipeline: the next vector of items is requested before the current one is applied
-    auto locate = [&](uint32_t v, uint32_t &n_left, const uint16_t *&p) {
-        n_left = 0;
-        if (v >= nslots) return;
-        const uint32_t seg = v / vps, j8 = (v - seg * vps) * 8;
-        const uint32_t n = counts[seg];
-        if (j8 >= n) return;
-        n_left = n - j8;
-        p = items + (uint64_t)seg * g.cap2 + j8;
+    {
+        uint32_t myc = 0;
+        if (threadIdx.x < g.nwgB) { myc = counts[threadIdx.x]; seg_cnt[threadIdx.x] = myc; }
+        const uint32_t myv = (myc + 7) >> 3;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t incl = myv;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (threadIdx.x < g.nwgB) vpre[threadIdx.x] = before + incl - myv;
+        if (threadIdx.x == BIN_C_THREADS - 1) total_vec_sh = before + incl;
+        __syncthreads();
+    }
+    const uint32_t total_vec = total_vec_sh;
+    if (total_vec == 0) return;                                    // untouched slice: no table traffic at all
+    // a vector: its 8 items (always loaded whole) and how many of them are real
+    struct Vec { uint4 q; uint32_t n; };
+    auto fetch = [&](uint32_t v) {
+        Vec r;
+        r.q = make_uint4(0, 0, 0, 0); r.n = 0;
+        if (v >= total_vec) return r;
+        uint32_t lo = 0, hi = g.nwgB;      // largest segment with vpre[seg] <= v (empty segments share their successor's prefix)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (vpre[mid] <= v) lo = mid; else hi = mid;
+        }
+        const uint32_t j8 = (v - vpre[lo]) * 8u;
+        r.n = min(8u, seg_cnt[lo] - j8);
+        r.q = *(const uint4 *)(items + (uint64_t)lo * g.cap2 + j8);
+        return r;
     };
-    uint32_t n_cur = 0, n_next = 0;
-    const uint16_t *p_cur = items, *p_next = items;
-    uint4 q_cur = make_uint4(0, 0, 0, 0), q_next = q_cur;
-    locate(threadIdx.x, n_cur, p_cur);
-    if (n_cur >= 8) q_cur = *(const uint4 *)p_cur;
+    // software pipeline, two vectors ahead: item requests fly while the slice loads and while earlier items are applied
+    Vec v0 = fetch(threadIdx.x), v1 = fetch(threadIdx.x + BIN_C_THREADS);
     for (uint32_t j = threadIdx.x; j < nvec; j += BIN_C_THREADS) l4[j] = tab[j];
     __syncthreads();
     uint32_t fresh = 0;
-    for (uint32_t v = threadIdx.x; v < nslots; v += BIN_C_THREADS) {
-        locate(v + BIN_C_THREADS, n_next, p_next);
-        if (n_next >= 8) q_next = *(const uint4 *)p_next;
-        if (n_cur >= 8) {
-            const uint32_t w[4] = {q_cur.x, q_cur.y, q_cur.z, q_cur.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                fresh += lds_inc(lds, w[e] & 0xffffu, storage) ? 1u : 0u;
-                fresh += lds_inc(lds, w[e] >> 16, storage) ? 1u : 0u;
-            }
-        } else {
-            for (uint32_t e = 0; e < n_cur; ++e) fresh += lds_inc(lds, p_cur[e], storage) ? 1u : 0u;
-        }
-        n_cur = n_next; p_cur = p_next; q_cur = q_next;
+    for (uint32_t v = threadIdx.x; v < ((g.debug & 32u) ? 0u : total_vec); v += BIN_C_THREADS) {
+        const Vec v2 = fetch(v + 2 * BIN_C_THREADS);
+        const uint32_t w[4] = {v0.q.x, v0.q.y, v0.q.z, v0.q.w};
+        if (g.debug & 16u) { fresh += w[0] ^ w[1] ^ w[2] ^ w[3]; }
+        else fresh += lds_inc8(lds, w, v0.n, storage);
+        v0 = v1; v1 = v2;
     }
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < nvec; j += BIN_C_THREADS) tab[j] = l4[j];

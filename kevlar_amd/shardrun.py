@@ -37,7 +37,8 @@ class _Exchange(object):
             self.work = None
         # the HIP library runs on its own stream: order by the host, but wait for THIS exchange only
         # (a later one may still be in flight on RCCL's stream)
-        torch.cuda.current_stream().synchronize()
+        if self.recv.is_cuda:
+            torch.cuda.current_stream().synchronize()
         self._keep = None
         return self.recv
 
@@ -65,7 +66,8 @@ def exchange_rows_async(send, counts, group=None, staged=False):
         dst_host = torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_to_all_single(dst_host, src_host, recv_counts, list(counts), group=group)
         recv.copy_(dst_host)
-        torch.cuda.synchronize()
+        if recv.is_cuda:
+            torch.cuda.synchronize()
         return _Exchange(None, recv, recv_counts, None)
     torch.cuda.current_stream().synchronize()      # packed is complete: the caller may overwrite `send`
     work = dist.all_to_all_single(recv, packed, recv_counts, list(counts), group=group, async_op=True)

@@ -14,7 +14,7 @@ def prof_all():
         ms, c = ctypes.c_double(), ctypes.c_uint64(); lib.kv_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(c)); out[name] = round(ms.value / max(1, c.value), 2)
     return out
 ref = None
-for mode, dbg in (('1', '0'), ('1', '2'), ('0', '0'), ('0', '2')):
+for mode, dbg in (('1', '0'), ('1', '0')):
     os.environ['KV_BIN_DIRECT'] = mode; os.environ['KV_BIN_DEBUG'] = dbg
     sk = hk.Counttable(k, 5e8, 4)
     sk.consume_batch(b); sk.clear()

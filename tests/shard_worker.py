@@ -13,7 +13,11 @@ import torch.distributed as dist
 def main():
     torch.cuda.init()
     torch.cuda.set_device(0)
-    dist.init_process_group('gloo')
+    backend = os.environ.get('SHARD_BACKEND', 'gloo')
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+    else:
+        dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     from kevlar_amd import _lib, bandmerge, khmer as hk, shardrun, synth
     _lib.load()
@@ -42,7 +46,10 @@ def main():
         assert sharded[n].n_occupied() == banded[n].n_occupied()
     br, bo, ba, _ = hk.novel_scan([banded['proband']], [banded['mother'], banded['father']], full['proband'], 6, 1,
                                   band_mode=1, nbands=world, band=rank)
-    mr, mo, ma = bandmerge.allgather_hits(br, bo, ba, torch.device('cpu'))
+    mr, mo, ma = bandmerge.allgather_hits_device(br, bo, ba, torch.device('cuda', 0), staged=(backend != 'nccl'))
+    if backend != 'nccl':
+        hr, ho, ha = bandmerge.allgather_hits(br, bo, ba, torch.device('cpu'))     # the host merge agrees with the device merge
+        assert np.array_equal(hr, mr) and np.array_equal(ho, mo) and np.array_equal(ha, ma)
     assert len(mr) > 50
     assert np.array_equal(r, mr) and np.array_equal(o, mo) and np.array_equal(a, ma)
     dist.barrier()

@@ -152,15 +152,17 @@ def free_port():
     return port
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_sharded_trio_ranks_share_one_gpu(hk, world):
+@pytest.mark.parametrize('world,backend', [(2, 'gloo'), (3, 'gloo'), (1, 'nccl')])
+def test_sharded_trio_ranks_share_one_gpu(hk, world, backend):
     """N ranks on this one GPU (gloo, staged exchange): each rank's sketches must equal band `rank` of a
-    banded count of ALL reads, and the gathered hits the merged banded scan (tests/shard_worker.py)."""
+    banded count of ALL reads, and the gathered hits the merged banded scan (tests/shard_worker.py).  The
+    (1, 'nccl') case drives the RCCL transport itself -- device tensors, async all-to-all -- with the one
+    rank a single-GPU box allows."""
     port = free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), SHARD_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'shard_worker.py')], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
