@@ -481,12 +481,15 @@ __device__ __forceinline__ bool lds_inc(uint32_t *lds, uint32_t off, int storage
 }
 
 // Eight saturating increments with the LDS round trips overlapped: all eight words are read first, then
-// all eight compare-and-swaps are issued, and only an item whose word changed in between (another lane, or
-// an earlier item of this same vector, hit the same word) takes the retry loop.  Returns how many bins went 0 -> 1.
-__device__ __forceinline__ uint32_t lds_inc8(uint32_t *lds, const uint32_t (&w)[4], uint32_t n, int storage)
+// all eight compare-and-swaps are issued back to back, and only an item whose word changed in between
+// (another lane, or an earlier item of this same vector, hit the same word) takes the retry loop.  Returns
+// how many bins went 0 -> 1.  STORAGE is a template parameter and the fast path is branch-free: with a
+// run-time switch and a branch per item this loop was instruction-bound (~175 instructions per item).
+template <int STORAGE>
+__device__ __forceinline__ uint32_t lds_inc8(uint32_t *lds, const uint32_t (&w)[4], uint32_t n)
 {
     uint32_t fresh = 0;
-    if (storage == ST_BIT) {
+    if (STORAGE == ST_BIT) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const uint32_t off = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
@@ -497,39 +500,50 @@ __device__ __forceinline__ uint32_t lds_inc8(uint32_t *lds, const uint32_t (&w)[
         }
         return fresh;
     }
-    uint32_t widx[8], shift[8], old[8];
-    const uint32_t maxv = storage == ST_BYTE ? 255u : 15u;
+    constexpr uint32_t maxv = STORAGE == ST_BYTE ? 255u : 15u;
+    uint32_t widx[8], inc[8], old[8], prev[8];
+    uint32_t retry = 0;                                  // bit e: item e lost its CAS
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const uint32_t off = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
-        if (storage == ST_BYTE) { widx[e] = off >> 2; shift[e] = (off & 3) * 8u; }
-        else { const uint32_t byte = off >> 1; widx[e] = byte >> 2; shift[e] = (byte & 3) * 8u + ((off & 1) ? 0u : 4u); }
-        old[e] = (uint32_t)e < n ? lds[widx[e]] : 0u;
+        uint32_t shift;
+        if (STORAGE == ST_BYTE) { widx[e] = off >> 2; shift = (off & 3u) << 3; }
+        else { widx[e] = off >> 3; shift = (((off >> 1) & 3u) << 3) + ((off & 1u) ? 0u : 4u); }
+        inc[e] = 1u << shift;
+        old[e] = lds[widx[e]];                           // absent items (e >= n) read a harmless word
     }
-    uint32_t prev[8];
-    bool tried[8];
+    bool live[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        tried[e] = (uint32_t)e < n && ((old[e] >> shift[e]) & maxv) != maxv;
-        prev[e] = old[e];
-        if (tried[e]) prev[e] = atomicCAS(&lds[widx[e]], old[e], old[e] + (1u << shift[e]));
+        // a saturated counter (field == inc * maxv) can only stay saturated; it and absent items issue a
+        // compare-and-swap that writes back what it compared against: branch-free, and a no-op either way
+        live[e] = (uint32_t)e < n && (old[e] & (inc[e] * maxv)) != inc[e] * maxv;
+        prev[e] = atomicCAS(&lds[widx[e]], old[e], old[e] + (live[e] ? inc[e] : 0u));
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        if (!tried[e]) continue;                       // absent, or saturated when read (it can only stay saturated)
-        if (prev[e] == old[e]) { fresh += ((old[e] >> shift[e]) & maxv) == 0 ? 1u : 0u; continue; }
-        uint32_t cur_word = prev[e];                   // lost the race: classic retry loop
-        for (;;) {
-            const uint32_t cur = (cur_word >> shift[e]) & maxv;
-            if (cur == maxv) break;
-            const uint32_t seen = atomicCAS(&lds[widx[e]], cur_word, cur_word + (1u << shift[e]));
-            if (seen == cur_word) { fresh += cur == 0 ? 1u : 0u; break; }
-            cur_word = seen;
+        const bool won = prev[e] == old[e];
+        fresh += (live[e] && won && (old[e] & (inc[e] * maxv)) == 0) ? 1u : 0u;
+        retry |= (live[e] && !won) ? (1u << e) : 0u;
+    }
+    if (retry) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (!(retry & (1u << e))) continue;
+            uint32_t cur_word = prev[e];
+            for (;;) {
+                const uint32_t field = cur_word & (inc[e] * maxv);
+                if (field == inc[e] * maxv) break;
+                const uint32_t seen = atomicCAS(&lds[widx[e]], cur_word, cur_word + inc[e]);
+                if (seen == cur_word) { fresh += field == 0 ? 1u : 0u; break; }
+                cur_word = seen;
+            }
         }
     }
     return fresh;
 }
 
+template <int STORAGE>
 __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__restrict__ sk, BinGeom g)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[16384];   // one slice: 65536 counters of <= 8 bits
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
     if (slice >= g.nslices[t] || g.ctr[1] != 0) return;    // overflow flag: leave the tables untouched for the fallback
     const uint32_t c = slice / (uint32_t)g.F, fidx = slice % (uint32_t)g.F;
     const uint64_t stream = ((uint64_t)t * g.C + c) * g.F + fidx;
-    const int storage = sk->storage;
+    constexpr int storage = STORAGE;
     const uint64_t bin0 = (uint64_t)slice << 16;
     const uint64_t left = sk->size[t] - bin0, nb = left < 65536 ? left : 65536;
     // byte range of the slice inside the table (the allocation is padded to 16 B)
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
         const Vec v2 = fetch(v + 2 * BIN_C_THREADS);
         const uint32_t w[4] = {v0.q.x, v0.q.y, v0.q.z, v0.q.w};
         if (g.debug & 16u) { fresh += w[0] ^ w[1] ^ w[2] ^ w[3]; }
-        else fresh += lds_inc8(lds, w, v0.n, storage);
+        else fresh += lds_inc8<STORAGE>(lds, w, v0.n);
         v0 = v1; v1 = v2;
     }
     __syncthreads();
@@ -853,7 +867,10 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
     }
     {
         KvProfScope prof("k_bin_apply");
-        hipLaunchKernelGGL(k_bin_apply, dim3(maxsl, (unsigned)g.T), dim3(BIN_C_THREADS), 0, st, (const SketchDev *)s->d_desc, g);
+        const dim3 gridC(maxsl, (unsigned)g.T);
+        if (s->h.storage == ST_BYTE) hipLaunchKernelGGL(k_bin_apply<ST_BYTE>, gridC, dim3(BIN_C_THREADS), 0, st, (const SketchDev *)s->d_desc, g);
+        else if (s->h.storage == ST_NIBBLE) hipLaunchKernelGGL(k_bin_apply<ST_NIBBLE>, gridC, dim3(BIN_C_THREADS), 0, st, (const SketchDev *)s->d_desc, g);
+        else hipLaunchKernelGGL(k_bin_apply<ST_BIT>, gridC, dim3(BIN_C_THREADS), 0, st, (const SketchDev *)s->d_desc, g);
     }
     {
         KvProfScope prof("k_bin_spill");   // usually a handful of items; the kernels check the overflow flag themselves
