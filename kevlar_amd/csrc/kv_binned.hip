@@ -413,7 +413,7 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
         const uint32_t mine = (threadIdx.x >> 6) * per_wave + (threadIdx.x & 63);
         if ((threadIdx.x & 63) < per_wave && mine < F) seg_base = (((uint64_t)s * F + mine) * g.nwgB + blockIdx.x) * g.cap2;
     }
-    auto store = [&](uint64_t idx, uint16_t off) { g.gbuf2[idx] = off; };
+    auto store = [&](uint64_t idx, uint16_t off) { if (!(g.debug & 128u)) g.gbuf2[idx] = off; };
     auto overflow = [&](uint32_t fi, uint16_t off) { spill_item(g, (int)t, (((uint64_t)c * F + fi) << 16) | off); };
     const uint64_t step = (uint64_t)BIN_B_THREADS * BIN_B_ITEMS;
     // this workgroup drains the private segments seg = blockIdx.x, blockIdx.x + nwgB, ... of bucket s
@@ -439,9 +439,29 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
                 for (uint64_t i = i0; i < end; ++i) items[have++] = src[i];
             }
             if (r0 + step < end) fetch(r0 + step, va, vb);          // next round's items fly during this round
+            if (g.debug & 64u) { if (have && items[0] == 0x12345u) spill_item(g, 0, 1); }
+            else if (have == BIN_B_ITEMS) {
+                // full vector: all ring positions are requested back to back (independent LDS atomics in flight
+                // together), then consumed; an item whose ring is full is rare and handled after the fast path
+                uint32_t pos[BIN_B_ITEMS], rbase[BIN_B_ITEMS];
 #pragma unroll
-            for (int j = 0; j < BIN_B_ITEMS; ++j) {
-                if (j < have) {
+                for (int j = 0; j < BIN_B_ITEMS; ++j) pos[j] = atomicAdd(&rs.cnt[items[j] >> 16], 1u);
+#pragma unroll
+                for (int j = 0; j < BIN_B_ITEMS; ++j) rbase[j] = rs.base[items[j] >> 16];
+                uint32_t full = 0;
+#pragma unroll
+                for (int j = 0; j < BIN_B_ITEMS; ++j) {
+                    const uint32_t fi = items[j] >> 16;
+                    if (pos[j] - rbase[j] < rs.R) rs.ring[fi * rs.R + ((pos[j] + fi) & (rs.R - 1))] = (uint16_t)(items[j] & 0xffffu);
+                    else full |= 1u << j;
+                }
+                if (full) {
+#pragma unroll
+                    for (int j = 0; j < BIN_B_ITEMS; ++j)
+                        if (full & (1u << j)) spill_item(g, (int)t, (((uint64_t)c * F + (items[j] >> 16)) << 16) | (items[j] & 0xffffu));
+                }
+            } else {
+                for (int j = 0; j < have; ++j) {
                     const uint32_t fi = items[j] >> 16, off = items[j] & 0xffffu;
                     if (!ring_append(rs, fi, (uint16_t)off)) spill_item(g, (int)t, (((uint64_t)c * F + fi) << 16) | off);
                 }
@@ -761,22 +781,24 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
         maxsl = std::max(maxsl, g.nslices[t]);
         pmin = std::min(pmin, s->h.size[t]);
     }
-    // 32 coarse buckets and 512-thread workgroups (two per CU) while the slices still fit F <= 512;
-    // 64 buckets / 1024 threads for tables beyond 2^30 bins
-    // 32 buckets, 512-thread workgroups (three per CU) while F <= 512 allows; 64 buckets / 1024 threads beyond 2^30 bins
-    // (a 16-bucket / 2-k-mers-per-thread variant measured slower overall: stage B pays for the wider fan-out)
-    const int cmax = maxsl <= 32u * BIN_MAX_F ? 32 : BIN_C;
+    // Coarse buckets per table: as few as keep stage B's fan-out F at <= 384 slices per bucket (its u16 rings then
+    // fit three workgroups per CU), between 4 and 32 with 512-thread stage-A workgroups; 64 buckets / 1024 threads
+    // beyond 2^30 bins.  Fewer buckets = fewer distinct lines per stage-A store instruction (that stage is bound by
+    // L2 write requests): measured per 525 M k-mers into 5e8-bin tables, A/B/C = 10.5/5.0/4.0 ms with 32 buckets,
+    // 8.7/4.9/4.0 with 20, 8.3/6.1/4.0 with 16 (F = 478: rings too big for three workgroups).
+    int cmax = maxsl <= 32u * BIN_MAX_F ? (int)std::min<uint32_t>(32u, std::max<uint32_t>(4u, (maxsl + 383u) / 384u)) : BIN_C;
+    if (getenv("KV_BIN_CMAX") && maxsl <= (uint32_t)atoi(getenv("KV_BIN_CMAX")) * BIN_MAX_F) cmax = atoi(getenv("KV_BIN_CMAX"));   // experiments
     g.F = (int)((maxsl + (uint32_t)cmax - 1) / (uint32_t)cmax);
     g.C = (int)((maxsl + (uint32_t)g.F - 1) / (uint32_t)g.F);
     g.recipF = g.F == 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)g.F + 1);   // F == 1: kernels take slice as is
     auto ring_for = [](uint32_t streams, uint32_t budget) {
-        uint32_t r = BIN_RING_MIN;
+        uint32_t r = getenv("KV_BIN_RMIN") ? (uint32_t)atoi(getenv("KV_BIN_RMIN")) : BIN_RING_MIN;
         while (r * 2 <= BIN_RING_MAX && (uint64_t)r * 2 * streams <= budget) r *= 2;
         return r;
     };
     const uint32_t budgetA = cmax <= 32 ? 8192u : 16384u;
     g.ringA = ring_for((uint32_t)(g.T * g.C), budgetA);
-    g.ringB = ring_for((uint32_t)g.F, BIN_B_BUDGET);
+    g.ringB = ring_for((uint32_t)g.F, getenv("KV_BIN_BBUDGET") ? (uint32_t)atoi(getenv("KV_BIN_BBUDGET")) : BIN_B_BUDGET);
     const int cus = device_cus();
     const double expected = (double)(nbands > 0 && !filter.use_mask ? n_kmers / (uint64_t)nbands + 1 : n_kmers);
     const uint64_t ns = (uint64_t)g.T * g.C;
