@@ -46,7 +46,7 @@ def parse_args():
     p.add_argument('--memory', type=float, default=2e9, help='sketch bytes per sample (all bands together)')
     p.add_argument('--case-min', type=int, default=6)
     p.add_argument('--ctrl-max', type=int, default=1)
-    p.add_argument('--cpu-reads', type=int, default=40000, help='reads per sample for the CPU baseline leg')
+    p.add_argument('--cpu-reads', type=int, default=150000, help='reads per sample for the CPU baseline leg')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--multi', default='auto', choices=['auto', 'exchange', 'banded'],
                    help='N>1: exchange = shard the reads, hash once, all-to-all the hashes by band (kevlar_amd/shardrun.py); '
