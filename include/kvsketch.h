@@ -165,6 +165,12 @@ int kv_get_hashes(kv_sketch *s, const uint64_t *hashes, uint64_t n, uint8_t *cou
 /* adds in array order semantics are order-free (saturating); is_new_out may be NULL       */
 int kv_add_hashes(kv_sketch *s, const uint64_t *hashes, uint64_t n, uint8_t *is_new_out);
 
+/* ---- dist: khmer's abundance_distribution(parser, tracking) (kevlar/dist.py:47-77) ----------
+ * In read order, a k-mer that `tracking` has not seen is recorded there and bumps
+ * hist_out[counts.get(kmer)]; hist_out has 65536 entries.  Same result as the single-thread loop. */
+int kv_abundance_distribution(kv_sketch *counts, kv_sketch *tracking, const kv_reads *const *batches,
+                              int n_batches, uint64_t *hist_out);
+
 /* ---- novel: the fused scan (kevlar/novel.py:21-53,123-169) ---------------------------- */
 #define KV_BAND_NONE 0
 #define KV_BAND_RANGE 1     /* keep k-mers whose hash lies in the band (count-side rule)     */

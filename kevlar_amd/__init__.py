@@ -68,6 +68,7 @@ from kevlar_amd import novel  # noqa: E402
 from kevlar_amd import filter  # noqa: E402
 from kevlar_amd import partition  # noqa: E402
 from kevlar_amd import unband  # noqa: E402
+from kevlar_amd import dist  # noqa: E402
 from kevlar_amd import cli  # noqa: E402
 
 

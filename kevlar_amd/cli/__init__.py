@@ -1,7 +1,7 @@
-"""Command line of the drop-in: `kevlar count | novel | filter | partition | unband`.
+"""Command line of the drop-in: `kevlar count | novel | filter | partition | unband | dist`.
 
 Flag names, defaults and dispatch follow the reference (kevlar/cli/__init__.py:31-108 and
-kevlar/cli/{count,novel,filter,partition,unband}.py); only the subcommands on the
+kevlar/cli/{count,novel,filter,partition,unband,dist}.py); only the subcommands on the
 novel-k-mer path exist here.  `novel` has one extra switch, --ref-band-quirk (see
 kevlar_amd/novel.py).
 """
@@ -100,8 +100,25 @@ def _unband(sub):
     p.add_argument('infile', nargs='+', help='augmented FASTA/FASTQ files')
 
 
+def _dist(sub):
+    p = sub.add_parser('dist', description='Compute the k-mer abundance distribution for a data set.')
+    p.add_argument('-o', '--out', metavar='FILE', help='output file; default is terminal (stdout)')
+    p.add_argument('-k', '--ksize', metavar='K', type=int, default=31, help='k-mer size; default is 31')
+    p.add_argument('-M', '--memory', type=memory, default=1e6, metavar='MEM', help='memory to allocate for k-mer counting')
+    p.add_argument('-t', '--threads', type=int, metavar='T', default=1,
+                   help='accepted for compatibility: the passes run on the GPU; default is 1')
+    p.add_argument('-p', '--plot', metavar='PNG', help='plot k-mer abundance distribution to file `PNG`')
+    p.add_argument('--tsv', metavar='TSV', help='write k-mer abundance distribution out to file formatted as '
+                   'tab-separated values')
+    p.add_argument('--plot-xlim', metavar=('MIN', 'MAX'), type=int, nargs=2, default=(0, 100),
+                   help='define the minimum and maximum x values (k-mer abundance) for the plot; default is `0 100`')
+    p.add_argument('mask', help='nodetable containing target k-mers to count (such as single-copy exonic k-mers)')
+    p.add_argument('infiles', nargs='+', help='input files in FASTA/FASTQ format')
+
+
 mains = {
     'count': kevlar_amd.count.main,
+    'dist': kevlar_amd.dist.main,
     'novel': kevlar_amd.novel.main,
     'filter': kevlar_amd.filter.main,
     'partition': kevlar_amd.partition.main,
@@ -110,6 +127,7 @@ mains = {
 
 subparser_funcs = {
     'count': _count,
+    'dist': _dist,
     'novel': _novel,
     'filter': _filter,
     'partition': _partition,
@@ -120,7 +138,7 @@ subparser_funcs = {
 def parser():
     top = argparse.ArgumentParser(
         prog='kevlar', formatter_class=argparse.RawDescriptionHelpFormatter,
-        description='kevlar novel-k-mer discovery on AMD MI355X (count, novel, filter, partition, unband)')
+        description='kevlar novel-k-mer discovery on AMD MI355X (count, novel, filter, partition, unband, dist)')
     top._positionals.title = 'Subcommands'
     top._optionals.title = 'Global arguments'
     top.add_argument('-v', '--version', action='version', version='kevlar v{}'.format(kevlar_amd.__version__))

@@ -221,6 +221,58 @@ __global__ void k_popcount(const uint32_t *w, uint64_t n, unsigned long long *ou
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
 }
 
+// ---- kevlar dist: abundance distribution over first occurrences ---------------------------------
+__device__ __forceinline__ uint32_t bin_value(const SketchDev *s, int t, uint64_t bin)
+{
+    const uint8_t *tab = s->tab[t];
+    if (s->storage == ST_BYTE) return tab[bin];
+    if (s->storage == ST_NIBBLE) return (tab[bin >> 1] >> ((bin & 1) ? 0 : 4)) & 15u;
+    return (tab[bin >> 3] >> (bin & 7)) & 1u;
+}
+
+// a bin's first toucher is a NEW k-mer only if the tracking table had not recorded the bin before this call
+__global__ void k_mark_first_untracked(const uint32_t *first, const SketchDev *__restrict__ tracking, int t, uint32_t *bitmap)
+{
+    const uint64_t nbins = tracking->size[t];
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < nbins; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t o = first[i];
+        if (o != EMPTY32 && bin_value(tracking, t, i) == 0) atomicOr(&bitmap[o >> 5], 1u << (o & 31));
+    }
+}
+
+struct AbundParams {
+    HashParams hp;
+    uint64_t ordinal_base;
+    const uint64_t *kprefix;
+    const uint32_t *bitmap;          // bit per k-mer ordinal: first occurrence of a k-mer new to tracking
+    unsigned long long *hist;        // 256 entries (counts saturate at 255 / 15 / 1)
+};
+
+__global__ __launch_bounds__(KV_TILE_THREADS) void k_abund_hist(ReadsDev rd, const SketchDev *__restrict__ counts, AbundParams p)
+{
+    __shared__ TileShared sh;
+    __shared__ uint32_t lhist[256];
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+    if (threadIdx.x == 0) sh.ascii = (uint32_t *)tile_smem;
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) lhist[i] = 0;
+    uint32_t read0;
+    const uint32_t nr = stage_tile(sh, rd, blockIdx.x, p.hp.k, 0, 0, read0);
+    const uint32_t total = sh.kpre[nr];
+    for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
+        uint32_t r, i;
+        locate_kmer(sh, nr, q, r, i);
+        const uint64_t ordinal = p.ordinal_base + p.kprefix[read0 + r] + i;
+        if (!((p.bitmap[ordinal >> 5] >> (ordinal & 31)) & 1u)) continue;
+        const uint32_t fwd = sh.foff[r] + i;
+        const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)p.hp.k - i);
+        const uint64_t h = kmer_hash_lds(sh.ascii, fwd, rc, p.hp);
+        atomicAdd(&lhist[sketch_get(counts, h) & 255u], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x)
+        if (lhist[i]) atomicAdd(&p.hist[i], (unsigned long long)lhist[i]);
+}
+
 struct DevBuf {  // frees on scope exit
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -396,5 +448,104 @@ extern "C" int kv_unique_exact(kv_sketch *s, const kv_reads *const *batches, int
     KV_HIP(hipGetLastError());
     KV_HIP(hipMemcpyAsync(n_unique_out, d_out.p, 8, hipMemcpyDeviceToHost, st));
     KV_HIP(hipStreamSynchronize(st));
+    return KV_OK;
+}
+
+// khmer's Hashtable::abundance_distribution(parser, tracking), the second pass of `kevlar dist`
+// (kevlar/dist.py:47-77): walking the k-mers in order, a k-mer that `tracking` has not seen
+// (get == 0) is recorded there and bumps hist[counts.get(kmer)].  "Not seen" at occurrence o means
+// some bin of the k-mer was clear before the call and no earlier occurrence of the call touched it --
+// the same first-toucher rule as kv_unique_exact, so the result is the single-thread one.  hist_out
+// has 65536 entries like khmer's (only the first 256 can be non-zero); tracking is updated.
+extern "C" int kv_abundance_distribution(kv_sketch *counts, kv_sketch *tracking, const kv_reads *const *batches,
+                                         int n_batches, uint64_t *hist_out)
+{
+    KV_REQUIRE(counts && tracking && hist_out && (batches || n_batches == 0) && n_batches >= 0, KV_ERR_ARG,
+               "kv_abundance_distribution: bad argument");
+    KV_REQUIRE(counts->h.ksize == tracking->h.ksize && counts->h.hashfam == tracking->h.hashfam, KV_ERR_ARG,
+               "counts and tracking sketches must share k and hash function");
+    memset(hist_out, 0, 65536 * sizeof(uint64_t));
+    hipStream_t st = kv_stream();
+    const int k = counts->h.ksize;
+    uint64_t total = 0;
+    for (int b = 0; b < n_batches; ++b) {
+        uint64_t nk = 0;
+        KV_REQUIRE(batches[b], KV_ERR_ARG, "kv_abundance_distribution: null batch");
+        kv_reads_num_kmers(batches[b], k, &nk);
+        total += nk;
+    }
+    KV_REQUIRE(total < 0xFFFFFFF0ull, KV_ERR_CAPACITY,
+               "abundance_distribution handles up to 4.29e9 k-mers per call (got %llu)", (unsigned long long)total);
+    if (total == 0) return KV_OK;
+    {
+        std::lock_guard<std::mutex> lk(tracking->mu);
+        FirstTouchParams p;
+        memset(&p, 0, sizeof(p));
+        p.f = make_consume_filter(k, tracking->h.hashfam, 0, 0, false, 0, 0);
+        std::vector<DevBuf> first(tracking->h.ntables);
+        for (int t = 0; t < tracking->h.ntables; ++t) {
+            hipError_t e = first[t].alloc(tracking->h.size[t] * 4);
+            KV_REQUIRE(e == hipSuccess, KV_ERR_HIP, "first-touch scratch (%llu bytes) allocation failed: %s",
+                       (unsigned long long)(tracking->h.size[t] * 4), hipGetErrorString(e));
+            KV_HIP(hipMemsetAsync(first[t].p, 0xFF, tracking->h.size[t] * 4, st));
+            p.first[t] = first[t].as<uint32_t>();
+        }
+        const uint64_t bm_words = (total + 31) / 32;
+        DevBuf d_bm, d_hist;
+        KV_HIP(d_bm.alloc(bm_words * 4));
+        KV_HIP(d_hist.alloc(256 * 8));
+        KV_HIP(hipMemsetAsync(d_bm.p, 0, bm_words * 4, st));
+        KV_HIP(hipMemsetAsync(d_hist.p, 0, 256 * 8, st));
+        std::vector<DevBuf> d_kpre(n_batches);
+        std::vector<uint64_t> bases(n_batches, 0);
+        uint64_t base = 0;
+        for (int b = 0; b < n_batches; ++b) {
+            const kv_reads *r = batches[b];
+            std::vector<uint64_t> kpre(r->n_reads + 1, 0);
+            for (uint64_t i = 0; i < r->n_reads; ++i)
+                kpre[i + 1] = kpre[i] + (r->h_len[i] >= (uint32_t)k ? r->h_len[i] - (uint32_t)k + 1 : 0);
+            KV_HIP(d_kpre[b].alloc(kpre.size() * 8));
+            KV_HIP(hipMemcpyAsync(d_kpre[b].p, kpre.data(), kpre.size() * 8, hipMemcpyHostToDevice, st));
+            p.ordinal_base = base;
+            p.kprefix = d_kpre[b].as<uint64_t>();
+            bases[b] = base;
+            if (r->n_tiles) {
+                KvProfScope prof("k_first_touch");
+                kv_ensure_dynamic_lds((const void *)k_first_touch, r->tile_lds_bytes);
+                hipLaunchKernelGGL(k_first_touch, dim3(r->n_tiles), dim3(KV_TILE_THREADS), r->tile_lds_bytes, st, reads_dev(r),
+                                   (const SketchDev *)tracking->d_desc, (const SketchDev *)nullptr, p);
+            }
+            KV_HIP(hipGetLastError());
+            KV_HIP(hipStreamSynchronize(st));     // kpre (host vector) must outlive its copy
+            base += kpre[r->n_reads];
+        }
+        for (int t = 0; t < tracking->h.ntables; ++t)
+            hipLaunchKernelGGL(k_mark_first_untracked, dim3(grid_for(tracking->h.size[t])), dim3(256), 0, st, p.first[t],
+                               (const SketchDev *)tracking->d_desc, t, d_bm.as<uint32_t>());
+        AbundParams a;
+        memset(&a, 0, sizeof(a));
+        a.hp = make_hash_params(k, counts->h.hashfam);
+        a.bitmap = d_bm.as<uint32_t>();
+        a.hist = d_hist.as<unsigned long long>();
+        for (int b = 0; b < n_batches; ++b) {
+            const kv_reads *r = batches[b];
+            if (!r->n_tiles) continue;
+            a.ordinal_base = bases[b];
+            a.kprefix = d_kpre[b].as<uint64_t>();
+            KvProfScope prof("k_abund_hist");
+            kv_ensure_dynamic_lds((const void *)k_abund_hist, r->tile_lds_bytes);
+            hipLaunchKernelGGL(k_abund_hist, dim3(r->n_tiles), dim3(KV_TILE_THREADS), r->tile_lds_bytes, st, reads_dev(r),
+                               (const SketchDev *)counts->d_desc, a);
+        }
+        KV_HIP(hipGetLastError());
+        KV_HIP(hipMemcpyAsync(hist_out, d_hist.p, 256 * 8, hipMemcpyDeviceToHost, st));
+        KV_HIP(hipStreamSynchronize(st));
+    }
+    // record every k-mer of the call in tracking (bins of k-mers that were not new are set already)
+    for (int b = 0; b < n_batches; ++b) {
+        uint64_t n = 0;
+        const int rc = kv_consume(tracking, batches[b], 0, 0, nullptr, 0, 0, &n);
+        if (rc != KV_OK) return rc;
+    }
     return KV_OK;
 }

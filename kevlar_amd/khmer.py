@@ -560,6 +560,30 @@ class _Sketch(object):
     def consume_seqfile(self, parser):
         return self._consume_file(parser, 0, 0, None, 0, False)
 
+    def abundance_distribution(self, parser, tracking):
+        """khmer's Hashtable.abundance_distribution (kevlar/dist.py:53-54): a 65536-entry list whose entry c
+        is the number of k-mers, each counted at its first occurrence according to `tracking` (which is
+        updated), whose count in this sketch is c.  `parser`: file name, ReadParser or ReadBatch."""
+        lib = _lib.load()
+        total = np.zeros(65536, dtype=np.uint64)
+
+        def one(batch):
+            hist = np.zeros(65536, dtype=np.uint64)
+            arr = (ctypes.c_void_p * 1)(batch._h)
+            check(lib.kv_abundance_distribution(self._h, tracking._h, arr, 1, _u64p(hist)))
+            np.add(total, hist, out=total)
+        if isinstance(parser, ReadBatch):
+            one(parser)
+        else:
+            if isinstance(parser, str):
+                parser = ReadParser(parser)
+            while True:
+                batch = parser.take_batch(BATCH_READS)
+                if batch is None:
+                    break
+                one(batch)
+        return [int(v) for v in total]
+
     def consume_seqfile_banding(self, parser, nbands, band):
         return self._consume_file(parser, nbands, band, None, 0, False)
 

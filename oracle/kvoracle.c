@@ -346,6 +346,30 @@ uint64_t kvo_consume_reads(kvo_sketch *s, const char *bases, const uint64_t *off
     return n;
 }
 
+/* khmer Hashtable::abundance_distribution, the second pass of `kevlar dist` (kevlar/dist.py:47-77;
+ * khmer 2.1.1, un-vendored: lib/hashtable.cc).  For every k-mer of the read, in order: if `tracking`
+ * has not seen it (get == 0), record it in tracking and bump hist[counts.get(kmer)].  hist has 65536
+ * entries (MAX_BIGCOUNT + 1).  Returns the number of k-mers newly recorded.                        */
+uint64_t kvo_abundance_distribution(const kvo_sketch *counts, kvo_sketch *tracking, const char *seq,
+                                    size_t len, uint64_t *hist)
+{
+    const int k = counts->ksize;
+    if (len < (size_t)k || k > KVO_MAXK) return 0;
+    uint64_t n = 0;
+    char *clean = (char *)malloc(len);
+    for (size_t i = 0; i < len; ++i) clean[i] = clean_base(seq[i]);
+    for (size_t i = 0; i + (size_t)k <= len; ++i) {
+        uint64_t h = kvo_hash(counts->kind, clean + i, k);
+        if (kvo_get_hash(tracking, h) != 0) continue;
+        kvo_add_hash(tracking, h);
+        int c = kvo_get_hash(counts, h);
+        hist[c & 0xffff] += 1;
+        ++n;
+    }
+    free(clean);
+    return n;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* H11: OXLI v4 files (layouts decoded from the fixtures)               */
 /* ------------------------------------------------------------------------------------ */

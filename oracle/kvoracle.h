@@ -78,6 +78,9 @@ uint64_t kvo_consume_reads(kvo_sketch *s, const char *bases, const uint64_t *off
 
 /* band bounds (H4): keep iff lo <= h < hi ; last band hi = 2^64-1 */
 void kvo_band_bounds(int nbands, int band, uint64_t *lo, uint64_t *hi);
+/* kevlar dist second pass (kevlar/dist.py:47-77): hist[65536] */
+uint64_t kvo_abundance_distribution(const kvo_sketch *counts, kvo_sketch *tracking, const char *seq,
+                                    size_t len, uint64_t *hist);
 
 /* --- novel scan (H7-H9: kevlar/novel.py:21-53,123-169) ---
  * band_mode: 0 = none; 1 = hash-range band (count-side semantics, kevlar/count.py:62-66);

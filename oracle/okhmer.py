@@ -61,6 +61,7 @@ def _load():
         'kvo_consume': (u64, [vp, cp, ctypes.c_size_t, i32, i32, vp, i32, i32]),
         'kvo_consume_reads': (u64, [vp, cp, pu64, u64, i32, i32, vp, i32, i32]),
         'kvo_band_bounds': (None, [i32, i32, pu64, pu64]),
+        'kvo_abundance_distribution': (u64, [vp, vp, cp, ctypes.c_size_t, pu64]),
         'kvo_novel_scan': (ctypes.c_int64, [
             ctypes.POINTER(vp), i32, ctypes.POINTER(vp), i32, cp, pu64, u64, i32, i32, i32, i32,
             i32, i32, i32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint16),
@@ -273,6 +274,17 @@ class _Sketch(object):
 
     def consume_seqfile(self, parser):
         return self._consume_file(parser, 0, 0, None, 0, False)
+
+    def abundance_distribution(self, parser, tracking):
+        """khmer's Hashtable.abundance_distribution (kevlar/dist.py:53-54): a 65536-entry list,
+        entry c = number of distinct (per `tracking`) k-mers whose count in this sketch is c."""
+        if isinstance(parser, str):
+            parser = ReadParser(parser)
+        hist = (ctypes.c_uint64 * 65536)()
+        for read in parser:
+            b = read.sequence.encode()
+            lib.kvo_abundance_distribution(self._h, tracking._h, b, len(b), hist)
+        return list(hist)
 
     def consume_seqfile_banding(self, parser, nbands, band):
         return self._consume_file(parser, nbands, band, None, 0, False)

@@ -57,7 +57,10 @@ FIXTURES = [
     'pico-filtered.fq.gz', 'connectivity-1311.augfastq', 'connectivity-1541.augfastq',
     'helium-unband/novel.band1.augfastq.gz', 'helium-unband/novel.band2.augfastq.gz',
     'helium-unband/novel.band3.augfastq.gz', 'helium-unband/novel.band4.augfastq.gz',
-    'part-reads-simple.fa', 'part-reads-mixed.fa',
+    'part-reads-simple.fa',
+    # kevlar dist (kevlar/tests/test_dist.py)
+    'minitrio/mask.nt', 'minitrio/trio-proband.fq.gz', 'minitrio/trio-proband-mask-counts.ct',
+    'minitrio/trio-proband-dist.tsv', 'part-reads-mixed.fa',
 ]
 # the three trio1 files behind test_novel.py:179-207 are 1.8 MB each: stored gzipped
 GZ_FIXTURES = ['trio1/case1.fq', 'trio1/ctrl1.fq', 'trio1/ctrl2.fq']

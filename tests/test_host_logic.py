@@ -89,7 +89,9 @@ def test_memory_setting_and_cli_defaults():
     assert (args.min_abund, args.max_abund, args.dedup, args.strict) == (2, 200, True, False)
     args = kevlar_amd.cli.parser().parse_args(['unband', 'a', 'b'])
     assert args.n_batches == 16 and args.infile == ['a', 'b']
-    assert set(kevlar_amd.cli.mains) == {'count', 'novel', 'filter', 'partition', 'unband'}
+    args = kevlar_amd.cli.parser().parse_args(['dist', 'mask.nt', 'a.fq', 'b.fq'])
+    assert (args.ksize, args.memory, args.threads, args.plot_xlim, args.infiles) == (31, 1e6, 1, (0, 100), ['a.fq', 'b.fq'])
+    assert set(kevlar_amd.cli.mains) == {'count', 'novel', 'filter', 'partition', 'unband', 'dist'}
     assert kevlar_amd.sketch.get_extension() == ('.nt', '.nodetable')
     assert kevlar_amd.sketch.get_extension(count=True) == ('.ct', '.counttable')
     assert kevlar_amd.sketch.get_extension(count=True, smallcount=True) == ('.sct', '.smallcounttable')
@@ -322,3 +324,18 @@ def test_native_fastx_reader_matches_record_parser(ok, tmp_path):
     bad.write_text('ACGT\n')
     with pytest.raises(OSError):
         list(khmer.ReadParser(str(bad)))
+
+
+# ---- kevlar dist host arithmetic (kevlar/tests/test_dist.py)
+def test_dist_mu_sigma_and_table():
+    import pytest
+    from kevlar_amd.dist import calc_mu_sigma, compute_dist, KevlarZeroAbundanceDistError
+    abund = {10: 6, 11: 10, 12: 12, 13: 18, 14: 16, 15: 11, 16: 9, 17: 9, 18: 11, 19: 8, 20: 9, 21: 7, 22: 3}
+    mu, sigma = calc_mu_sigma(abund)
+    assert mu == pytest.approx(15.32558, abs=1e-5) and sigma == pytest.approx(3.280581, abs=1e-6)
+    with pytest.raises(KevlarZeroAbundanceDistError):
+        calc_mu_sigma(dict())
+    data = compute_dist(abund)
+    assert list(data['Count'][:5]) == [6.0, 10.0, 12.0, 18.0, 16.0]
+    assert list(data['CumulativeCount'][:5]) == [6.0, 16.0, 28.0, 46.0, 62.0]
+    assert data['CumulativeFraction'].iloc[-1] == 1.0

@@ -163,3 +163,41 @@ def test_novel_scan_reproduces_reference_output(ok):
     assert '209 instances of 29 unique novel kmers in 18 reads' in manifest['cases']['novel-trio1.augfastq'][0]
     assert '29 unique novel kmers in 14 reads' in manifest['cases']['novel-trio1-skipuntil.augfastq'][1]
     assert len(want) == 209 and len(set(n for n, _, _ in want)) == 18
+
+
+# ---- kevlar dist (kevlar/tests/test_dist.py): the oracle's two passes against the reference's goldens
+def test_dist_first_pass_file_is_byte_exact(ok, tmp_path):
+    import filecmp
+    mask = ok.Nodetable.load(data_file('minitrio/mask.nt'))
+    counts = ok.Counttable(31, 1e4, 4)
+    counts.consume_seqfile_with_mask(data_file('minitrio/trio-proband.fq.gz'), mask, threshold=1, consume_masked=True)
+    out = str(tmp_path / 'first.ct')
+    counts.save(out)
+    assert filecmp.cmp(data_file('minitrio/trio-proband-mask-counts.ct'), out, shallow=False)
+
+
+def test_dist_second_pass_golden_abundances(ok):
+    counts = ok.Counttable.load(data_file('minitrio/trio-proband-mask-counts.ct'))
+    tracking = ok.Nodetable(counts.ksize(), 1, 1, primes=counts.hashsizes())
+    hist = counts.abundance_distribution(data_file('minitrio/trio-proband.fq.gz'), tracking)
+    assert len(hist) == 65536
+    abund = {i: c for i, c in enumerate(hist) if i > 0 and c > 0}
+    assert abund == {10: 6, 11: 10, 12: 12, 13: 18, 14: 16, 15: 11, 16: 9, 17: 9, 18: 11, 19: 8, 20: 9, 21: 7, 22: 3}
+
+
+def test_dist_tsv_golden_through_the_oracle(ok):
+    """default memory (1e6): the cumulative counts the reference's test_tsv expects, and its TSV fixture"""
+    mask = ok.Nodetable.load(data_file('minitrio/mask.nt'))
+    counts = ok.Counttable(31, 1e6 / 4, 4)
+    counts.consume_seqfile_with_mask(data_file('minitrio/trio-proband.fq.gz'), mask, threshold=1, consume_masked=True)
+    tracking = ok.Nodetable(31, 1, 1, primes=counts.hashsizes())
+    hist = counts.abundance_distribution(data_file('minitrio/trio-proband.fq.gz'), tracking)
+    abund = {i: c for i, c in enumerate(hist) if i > 0 and c > 0}
+    cuml, run = [], 0
+    for a in sorted(abund):
+        run += abund[a]
+        cuml.append(float(run))
+    assert cuml == [15.0, 18.0, 24.0, 44.0, 78.0, 153.0, 222.0, 325.0, 423.0, 515.0, 585.0, 666.0, 756.0, 814.0,
+                    861.0, 888.0, 902.0, 903.0]
+    rows = [line.split('\t') for line in open(data_file('minitrio/trio-proband-dist.tsv')).read().strip().split('\n')[1:]]
+    assert [(float(r[0]), float(r[1])) for r in rows] == [(float(a), float(abund[a])) for a in sorted(abund)]
