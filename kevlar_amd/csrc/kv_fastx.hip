@@ -22,6 +22,7 @@ struct kv_fastx {
     size_t pos = 0, end = 0;
     bool eof = false;
     std::string pending;          // a header line read ahead while scanning a FASTA record
+    std::string pending_view;     // backing store of the view handed out for it
     bool have_pending = false;
     uint64_t num_reads = 0;
     // text of the last batch
@@ -44,32 +45,54 @@ static bool fx_fill(kv_fastx *f)
     return true;
 }
 
-// next line without its terminator (\n or \r\n); false at end of file
-static bool fx_line(kv_fastx *f, std::string &out)
+// next line without its terminator (\n or \r\n) as a view into the inflate buffer, valid until the
+// next call; false at end of file
+static bool fx_view(kv_fastx *f, const char *&p, size_t &n)
 {
-    if (f->have_pending) { out.swap(f->pending); f->have_pending = false; return true; }
+    if (f->have_pending) {          // a header read ahead while scanning a FASTA record
+        f->pending_view.swap(f->pending);
+        f->have_pending = false;
+        p = f->pending_view.data(); n = f->pending_view.size();
+        return true;
+    }
     for (;;) {
         const char *start = f->buf.data() + f->pos;
         const char *nl = (const char *)memchr(start, '\n', f->end - f->pos);
         if (nl) {
-            size_t n = (size_t)(nl - start);
-            f->pos += n + 1;
-            if (n && start[n - 1] == '\r') --n;
-            out.assign(start, n);
+            size_t len = (size_t)(nl - start);
+            f->pos += len + 1;
+            if (len && start[len - 1] == '\r') --len;
+            p = start; n = len;
             return true;
         }
         if (!fx_fill(f)) {
             if (f->pos < f->end) {          // last line without newline
-                size_t n = f->end - f->pos;
-                const char *s = f->buf.data() + f->pos;
+                size_t len = f->end - f->pos;
+                const char *s0 = f->buf.data() + f->pos;
                 f->pos = f->end;
-                if (n && s[n - 1] == '\r') --n;
-                out.assign(s, n);
+                if (len && s0[len - 1] == '\r') --len;
+                p = s0; n = len;
                 return true;
             }
             return false;
         }
     }
+}
+
+static bool fx_line(kv_fastx *f, std::string &out)
+{
+    const char *p;
+    size_t n;
+    if (!fx_view(f, p, n)) return false;
+    out.assign(p, n);
+    return true;
+}
+
+static inline bool fx_blank_view(const char *p, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (p[i] != ' ' && p[i] != '\t' && p[i] != '\r') return false;
+    return true;
 }
 
 static inline bool fx_blank(const std::string &s)
@@ -123,22 +146,22 @@ extern "C" int kv_fastx_next(kv_fastx *f, uint64_t max_reads, int upload, kv_rea
     f->names.clear(); f->seqs.clear(); f->quals.clear();
     f->name_offs.assign(1, 0); f->seq_offs.assign(1, 0); f->qual_offs.assign(1, 0);
     f->is_fastq.clear();
-    std::string line, seq;
+    std::string seq;
     uint64_t n = 0;
-    while (n < max_reads && fx_line(f, line)) {
-        if (fx_blank(line)) continue;
-        const char first = line[0];
+    const char *lp;
+    size_t ln;
+    while (n < max_reads && fx_view(f, lp, ln)) {
+        if (fx_blank_view(lp, ln)) continue;
+        const char first = lp[0];
         if (first == '@') {
-            f->names.append(line, 1, std::string::npos);
-            if (!fx_line(f, seq)) seq.clear();
-            f->seqs += seq;
-            std::string plus, qual;
-            fx_line(f, plus);
-            if (!fx_line(f, qual)) qual.clear();
-            f->quals += qual;
+            // four lines, each appended to its blob straight from the inflate buffer
+            f->names.append(lp + 1, ln - 1);
+            if (fx_view(f, lp, ln)) f->seqs.append(lp, ln);
+            (void)fx_view(f, lp, ln);                               // '+' line
+            if (fx_view(f, lp, ln)) f->quals.append(lp, ln);
             f->is_fastq.push_back(1);
         } else if (first == '>') {
-            f->names.append(line, 1, std::string::npos);
+            f->names.append(lp + 1, ln - 1);
             std::string piece;
             while (fx_line(f, piece)) {
                 if (!piece.empty() && piece[0] == '>') { f->pending.swap(piece); f->have_pending = true; break; }

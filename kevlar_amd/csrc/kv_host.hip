@@ -517,8 +517,87 @@ extern "C" int kv_sketch_save(kv_sketch *s, const char *path)
 }
 
 // ---------------------------------------------------------------------------------------
-// reads: 2-bit packing on the host, upload, tile table
+// pinned host blocks, recycled (first fit within 2x of the request; at most 512 MB parked)
 // ---------------------------------------------------------------------------------------
+namespace {
+struct PinnedBlock { void *p; size_t cap; };
+std::vector<PinnedBlock> g_pinned_free;
+size_t g_pinned_parked = 0;
+std::mutex g_pinned_mu;
+}  // namespace
+
+void *kv_pinned_get(size_t bytes, size_t *capacity)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        for (size_t i = 0; i < g_pinned_free.size(); ++i) {
+            if (g_pinned_free[i].cap >= bytes && g_pinned_free[i].cap <= 2 * bytes + 4096) {
+                PinnedBlock b = g_pinned_free[i];
+                g_pinned_free.erase(g_pinned_free.begin() + (long)i);
+                g_pinned_parked -= b.cap;
+                *capacity = b.cap;
+                return b.p;
+            }
+        }
+    }
+    void *p = nullptr;
+    const size_t cap = (bytes + 4095) & ~(size_t)4095;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *capacity = cap;
+    return p;
+}
+
+void kv_pinned_put(void *p, size_t capacity)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        if (g_pinned_parked + capacity <= ((size_t)512 << 20) && g_pinned_free.size() < 64) {
+            g_pinned_free.push_back({p, capacity});
+            g_pinned_parked += capacity;
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
+// ---------------------------------------------------------------------------------------
+// reads: ASCII upload, 2-bit packing on the device, tile table
+// ---------------------------------------------------------------------------------------
+// One thread per packed word (16 bases): locate the read by binary search over the word offsets,
+// translate, and flag the read if any base is outside upper-case ACGT (stand-in code: A; the novel
+// scan skips flagged reads, the count keeps them -- same rule as the oracle's clean_base()).
+__global__ void k_pack_reads(const char *__restrict__ ascii, const uint64_t *__restrict__ offs,
+                             const uint64_t *__restrict__ woff, uint64_t n_reads, uint64_t n_words,
+                             uint32_t *__restrict__ words, uint32_t *__restrict__ flags32)
+{
+    for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t lo = 0, hi = n_reads;            // largest r with woff[r] <= w (empty reads share their successor's offset)
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (woff[mid] <= w) lo = mid; else hi = mid;
+        }
+        const uint64_t r = lo;
+        const uint64_t j0 = (w - woff[r]) * 16;
+        const uint64_t len = offs[r + 1] - offs[r];
+        const char *src = ascii + (offs[r] - offs[0]) + j0;
+        const uint32_t n = (uint32_t)(len - j0 < 16 ? len - j0 : 16);
+        uint32_t out = 0, bad = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            const char c = src[j];
+            uint32_t code = 0;
+            if (c == 'A') code = 0;
+            else if (c == 'C') code = 1;
+            else if (c == 'G') code = 2;
+            else if (c == 'T') code = 3;
+            else { bad = 1; code = (c == 'c') ? 1u : (c == 'g') ? 2u : (c == 't') ? 3u : 0u; }
+            out |= code << (2 * j);
+        }
+        words[w] = out;
+        if (bad) atomicOr(&flags32[r >> 2], 1u << ((r & 3) * 8));
+    }
+}
+
 extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t n_reads, kv_reads **out)
 {
     KV_REQUIRE(out && offs && (bases || n_reads == 0), KV_ERR_ARG, "kv_reads_create: null argument");
@@ -529,7 +608,6 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
     r->d_words = nullptr; r->d_woff = nullptr; r->d_len = nullptr; r->d_flags = nullptr; r->d_tile = nullptr;
     r->h_len.resize(n_reads);
     std::vector<uint64_t> woff(n_reads + 1);
-    std::vector<uint8_t> flags(n_reads);
     std::vector<uint32_t> tiles;
     uint64_t nw = 0;
     uint32_t max_len = 0;
@@ -549,28 +627,6 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
     woff[n_reads] = nw;
     r->n_words = nw;
     r->max_len = max_len;
-    std::vector<uint32_t> words(nw ? nw : 1, 0);
-    for (uint64_t i = 0; i < n_reads; ++i) {
-        const char *s = bases + offs[i];
-        uint32_t *w = words.data() + woff[i];
-        uint8_t flag = 0;
-        for (uint32_t j = 0; j < r->h_len[i]; ++j) {
-            uint32_t c;
-            switch (s[j]) {
-            case 'A': c = 0; break;
-            case 'C': c = 1; break;
-            case 'G': c = 2; break;
-            case 'T': c = 3; break;
-            case 'a': c = 0; flag = 1; break;
-            case 'c': c = 1; flag = 1; break;
-            case 'g': c = 2; flag = 1; break;
-            case 't': c = 3; flag = 1; break;
-            default: c = 0; flag = 1; break;
-            }
-            w[j >> 4] |= c << (2 * (j & 15));
-        }
-        flags[i] = flag;
-    }
     // tiles: consecutive reads whose staged ASCII (both strands, padded) fits the LDS budget; a read
     // that alone exceeds the budget gets a tile of its own and raises the batch's dynamic LDS size
     {
@@ -589,16 +645,33 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
         r->n_tiles = (uint32_t)tiles.size() - 1;
         r->tile_lds_bytes = std::max<uint32_t>(KV_TILE_LDS_BYTES, (biggest + 64 + 255) & ~255u) + 256;   // + rolling-window over-read
     }
-    hipError_t e = hipMalloc((void **)&r->d_words, words.size() * 4);
+    const uint64_t flag_bytes = ((n_reads + 3) & ~3ull) + 4;
+    char *d_ascii = nullptr;
+    uint64_t *d_offs = nullptr;
+    hipStream_t st = kv_stream();
+    hipError_t e = hipMalloc((void **)&r->d_words, (nw ? nw : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, n_reads ? n_reads : 1);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, flag_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, tiles.size() * 4);
-    if (e == hipSuccess) e = hipMemcpy(r->d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(r->d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess && n_reads) e = hipMemcpy(r->d_len, r->h_len.data(), n_reads * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && n_reads) e = hipMemcpy(r->d_flags, flags.data(), n_reads, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(r->d_tile, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_ascii, r->n_bases ? r->n_bases : 1);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_offs, woff.size() * 8);
+    if (e == hipSuccess && r->n_bases) e = hipMemcpyAsync(d_ascii, bases + offs[0], r->n_bases, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_offs, offs, (n_reads + 1) * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_reads) e = hipMemcpyAsync(r->d_len, r->h_len.data(), n_reads * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_flags, 0, flag_bytes, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->d_tile, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && nw) {
+        KvProfScope prof("k_pack_reads");
+        const unsigned grid = (unsigned)std::min<uint64_t>((nw + 255) / 256, 65536);
+        hipLaunchKernelGGL(k_pack_reads, dim3(grid), dim3(256), 0, st, (const char *)d_ascii, (const uint64_t *)d_offs,
+                           (const uint64_t *)r->d_woff, n_reads, nw, r->d_words, (uint32_t *)r->d_flags);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);      // the host vectors and the caller's blob are free after this
+    if (d_ascii) (void)hipFree(d_ascii);
+    if (d_offs) (void)hipFree(d_offs);
     if (e != hipSuccess) {
         kv_set_error("read batch upload failed: %s", hipGetErrorString(e));
         kv_reads_destroy(r);

@@ -69,17 +69,25 @@ struct kv_reads {
     uint64_t nk_cached = 0;
 };
 
-// hits of one scan in pinned host memory (fast DMA from the device; the Python side views it in place)
+// hits of one scan in pinned host memory (fast DMA from the device; the Python side views it in place).
+// Blocks come from a small recycling pool (kv_host.hip): hipHostMalloc costs ~1 ms per call, more than
+// copying the hits of a whole scan.
+void *kv_pinned_get(size_t bytes, size_t *capacity);
+void kv_pinned_put(void *p, size_t capacity);
+
 template <typename T>
 struct PinnedVec {
     T *p = nullptr;
     uint64_t n = 0;
-    ~PinnedVec() { if (p) (void)hipHostFree(p); }
+    size_t cap = 0;
+    ~PinnedVec() { if (p) kv_pinned_put(p, cap); }
     hipError_t resize(uint64_t count)
     {
-        if (p) { (void)hipHostFree(p); p = nullptr; }
+        if (p) { kv_pinned_put(p, cap); p = nullptr; cap = 0; }
         n = count;
-        return count ? hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault) : hipSuccess;
+        if (count == 0) return hipSuccess;
+        p = (T *)kv_pinned_get(count * sizeof(T), &cap);
+        return p ? hipSuccess : hipErrorOutOfMemory;
     }
     uint64_t size() const { return n; }
     T *data() { return p; }

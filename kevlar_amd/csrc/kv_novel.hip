@@ -277,6 +277,26 @@ struct DevBuf {
     template <typename T> T *as() { return (T *)p; }
 };
 
+// grow-only scratch of the scan, one pair of arenas per stream: hipMalloc / hipFree of the 66 MB bit mask and
+// the hit arrays on every call cost more than the emit kernel
+struct Arena {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t need(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+};
+struct ScanArenas { Arena work, hits; std::mutex mu; };   // mu: one scan at a time per stream
+std::map<hipStream_t, ScanArenas> g_scan_arenas;
+std::mutex g_scan_arenas_mu;
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
 // point p.vcache at this stream's verdict cache, (re)allocating or clearing it as the signature requires
 int attach_vcache(NovelParams &p, kv_sketch *const *ctrls, int ncase, int nctrl, int ctrl_max, uint64_t n_kmers, hipStream_t st)
 {
@@ -357,26 +377,36 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     *out = hits;
     if (reads->n_tiles == 0) return KV_OK;
 
-    DevBuf own_mask, d_flags, d_tcount, d_tbase, d_read, d_off, d_abund;
+    ScanArenas *arenas;
+    {
+        std::lock_guard<std::mutex> lk(g_scan_arenas_mu);
+        arenas = &g_scan_arenas[st];
+    }
+    std::lock_guard<std::mutex> arena_lock(arenas->mu);
     hipError_t e = hipSuccess;
-    if (d_mask) {
-        p.mask = d_mask; p.mask_stride = mask_stride;
-    } else {
-        p.mask_stride = min_stride;
-        const uint64_t words = (reads->n_reads * min_stride + 31) / 32;
-        e = own_mask.alloc(words * 4);
-        if (e == hipSuccess) e = hipMemsetAsync(own_mask.p, 0, words * 4, st);
-        p.mask = own_mask.as<uint32_t>();
+    const uint64_t mask_words = d_mask ? 0 : (reads->n_reads * min_stride + 31) / 32;
+    const size_t b_mask = up256(mask_words * 4), b_flags = p.screen > 0 ? up256(reads->n_reads) : 0;
+    const size_t b_tcount = up256((uint64_t)reads->n_tiles * 4), b_tbase = up256(((uint64_t)reads->n_tiles + 1) * 8);
+    e = arenas->work.need(b_mask + b_flags + b_tcount + b_tbase + 256);
+    unsigned char *wp = (unsigned char *)arenas->work.p;
+    if (e == hipSuccess) {
+        if (d_mask) {
+            p.mask = d_mask; p.mask_stride = mask_stride;
+        } else {
+            p.mask_stride = min_stride;
+            p.mask = (uint32_t *)wp;
+            e = hipMemsetAsync(p.mask, 0, mask_words * 4, st);
+        }
+        wp += b_mask;
     }
     if (e == hipSuccess && p.screen > 0) {
-        e = d_flags.alloc(reads->n_reads);
-        if (e == hipSuccess) e = hipMemsetAsync(d_flags.p, 0, reads->n_reads, st);
-        p.disc_flag = d_flags.as<uint8_t>();
+        p.disc_flag = (uint8_t *)wp;
+        e = hipMemsetAsync(p.disc_flag, 0, reads->n_reads, st);
     }
-    if (e == hipSuccess) e = d_tcount.alloc((uint64_t)reads->n_tiles * 4);
-    if (e == hipSuccess) e = d_tbase.alloc(((uint64_t)reads->n_tiles + 1) * 8);
-    p.tile_count = d_tcount.as<uint32_t>();
-    p.tile_base = d_tbase.as<uint64_t>();
+    wp += b_flags;
+    p.tile_count = (uint32_t *)wp; wp += b_tcount;
+    uint64_t *d_tbase_p = (uint64_t *)wp;
+    p.tile_base = d_tbase_p;
     uint64_t nhits = 0;
     if (e == hipSuccess) {
         {
@@ -386,17 +416,17 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         }
         {
             KvProfScope prof("k_tile_scan");
-            hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p.tile_count, reads->n_tiles, d_tbase.as<uint64_t>());
+            hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p.tile_count, reads->n_tiles, d_tbase_p);
         }
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&nhits, d_tbase.as<uint64_t>() + reads->n_tiles, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&nhits, d_tbase_p + reads->n_tiles, 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess && nhits) {
-        e = d_read.alloc(nhits * 4);
-        if (e == hipSuccess) e = d_off.alloc(nhits * 4);
-        if (e == hipSuccess) e = d_abund.alloc(nhits * (uint64_t)S);
-        p.hit_read = d_read.as<uint32_t>(); p.hit_off = d_off.as<uint32_t>(); p.hit_abund = d_abund.as<uint8_t>();
+        e = arenas->hits.need(2 * up256(nhits * 4) + up256(nhits * (uint64_t)S));
+        p.hit_read = (uint32_t *)arenas->hits.p;
+        p.hit_off = (uint32_t *)((unsigned char *)arenas->hits.p + up256(nhits * 4));
+        p.hit_abund = (uint8_t *)arenas->hits.p + 2 * up256(nhits * 4);
         if (e == hipSuccess) {
             KvProfScope prof("k_novel_emit");
             kv_ensure_dynamic_lds((const void *)k_novel_emit, reads->tile_lds_bytes);

@@ -124,7 +124,7 @@ def parse_augmented_fastx(instream):
                 record.add_mate(_MATE_RE.search(line).group(1))
                 continue
             offset = len(line) - len(line.lstrip())
-            fields = re.split(r'\s+', line.strip()[:-1])
+            fields = line.strip()[:-1].split()
             kmer = fields[0]
             record.annotate(kmer, offset, tuple(int(a) for a in fields[1:]))
         else:

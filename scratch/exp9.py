@@ -1,0 +1,26 @@
+import sys, time, ctypes, os
+sys.path.insert(0, '.')
+import torch
+torch.cuda.init()
+from kevlar_amd import _lib, khmer as hk, synth
+lib = _lib.load(); _lib.require_device()
+L, k = 100, 31
+packed = synth.trio_reads_packed(25_000_000, 30, L)
+names = ('proband', 'mother', 'father')
+batches = {n: hk.ReadBatch.from_packed(packed[n], L) for n in names}
+sk = {n: hk.Counttable(k, 5e8, 4) for n in names}
+for n in names: sk[n].consume_batch(batches[n])
+def prof_all():
+    buf = ctypes.create_string_buffer(4096); lib.kv_prof_names(buf, 4096); out = {}
+    for name in buf.value.decode().split(','):
+        if not name: continue
+        ms, c = ctypes.c_double(), ctypes.c_uint64(); lib.kv_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(c)); out[name] = round(ms.value / max(1, c.value), 2)
+    return out
+for rep in range(3):
+    sk['mother'].add('A' * k)   # bump the version: the verdict cache starts cold, as in every bench step
+    lib.kv_prof_reset(); lib.kv_prof_enable(1)
+    t0 = time.perf_counter()
+    r = hk.novel_scan([sk['proband']], [sk['mother'], sk['father']], batches['proband'], 6, 1)
+    dt = (time.perf_counter() - t0) * 1e3
+    lib.kv_prof_enable(0)
+    print('novel %.1f ms hits %d %s' % (dt, len(r[0]), prof_all()), flush=True)
