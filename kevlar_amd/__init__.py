@@ -69,6 +69,8 @@ from kevlar_amd import filter  # noqa: E402
 from kevlar_amd import partition  # noqa: E402
 from kevlar_amd import unband  # noqa: E402
 from kevlar_amd import dist  # noqa: E402
+from kevlar_amd import split  # noqa: E402
+from kevlar_amd import augment  # noqa: E402
 from kevlar_amd import cli  # noqa: E402
 
 

@@ -1,4 +1,4 @@
-"""Command line of the drop-in: `kevlar count | novel | filter | partition | unband | dist`.
+"""Command line of the drop-in: `kevlar count | novel | filter | partition | unband | dist | split | augment`.
 
 Flag names, defaults and dispatch follow the reference (kevlar/cli/__init__.py:31-108 and
 kevlar/cli/{count,novel,filter,partition,unband,dist}.py); only the subcommands on the
@@ -116,7 +116,26 @@ def _dist(sub):
     p.add_argument('infiles', nargs='+', help='input files in FASTA/FASTQ format')
 
 
+def _split(sub):
+    p = sub.add_parser('split', description='Split partitioned reads into N output files.')
+    p.add_argument('infile', help='input file; partitioned reads in augmented Fastq/Fasta format')
+    p.add_argument('numfiles', type=int, help='number of output files to create')
+    p.add_argument('base', help='prefix of all output files')
+
+
+def _augment(sub):
+    p = sub.add_parser('augment', description='Internally, kevlar annotates sequences with "interesting k-mers" '
+                       'and uses "augmented" Fastq and Fasta formats. Processing sequences with third-party tools '
+                       'usually requires discarding these annotations. This command is used to augment/reaugment '
+                       'a set of sequences using annotations from an already augmented sequence file.')
+    p.add_argument('-o', '--out', metavar='FILE', help='output file; default is terminal (stdout)')
+    p.add_argument('augseqs', help='augmented sequence file')
+    p.add_argument('seqs', help='sequences to annotate')
+
+
 mains = {
+    'augment': kevlar_amd.augment.main,
+    'split': kevlar_amd.split.main,
     'count': kevlar_amd.count.main,
     'dist': kevlar_amd.dist.main,
     'novel': kevlar_amd.novel.main,
@@ -126,6 +145,8 @@ mains = {
 }
 
 subparser_funcs = {
+    'augment': _augment,
+    'split': _split,
     'count': _count,
     'dist': _dist,
     'novel': _novel,
@@ -138,7 +159,7 @@ subparser_funcs = {
 def parser():
     top = argparse.ArgumentParser(
         prog='kevlar', formatter_class=argparse.RawDescriptionHelpFormatter,
-        description='kevlar novel-k-mer discovery on AMD MI355X (count, novel, filter, partition, unband, dist)')
+        description='kevlar novel-k-mer discovery on AMD MI355X (count, novel, filter, partition, unband, dist, split, augment)')
     top._positionals.title = 'Subcommands'
     top._optionals.title = 'Global arguments'
     top.add_argument('-v', '--version', action='version', version='kevlar v{}'.format(kevlar_amd.__version__))

@@ -60,7 +60,10 @@ FIXTURES = [
     'part-reads-simple.fa',
     # kevlar dist (kevlar/tests/test_dist.py)
     'minitrio/mask.nt', 'minitrio/trio-proband.fq.gz', 'minitrio/trio-proband-mask-counts.ct',
-    'minitrio/trio-proband-dist.tsv', 'part-reads-mixed.fa',
+    'minitrio/trio-proband-dist.tsv',
+    # kevlar split / augment (kevlar/tests/test_split.py, test_augment.py)
+    'fiveparts.augfastq.gz', 'snorkel.augfastq', 'snorkel-contig.fasta', 'reaugment.augfastq', 'reaugment.fq',
+    'reaugment.out', 'deadbeef.augfastq.gz', 'deadbeef.contig.fa', 'deadbeef.fq.gz', 'part-reads-mixed.fa',
 ]
 # the three trio1 files behind test_novel.py:179-207 are 1.8 MB each: stored gzipped
 GZ_FIXTURES = ['trio1/case1.fq', 'trio1/ctrl1.fq', 'trio1/ctrl2.fq']

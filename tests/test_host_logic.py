@@ -91,7 +91,7 @@ def test_memory_setting_and_cli_defaults():
     assert args.n_batches == 16 and args.infile == ['a', 'b']
     args = kevlar_amd.cli.parser().parse_args(['dist', 'mask.nt', 'a.fq', 'b.fq'])
     assert (args.ksize, args.memory, args.threads, args.plot_xlim, args.infiles) == (31, 1e6, 1, (0, 100), ['a.fq', 'b.fq'])
-    assert set(kevlar_amd.cli.mains) == {'count', 'novel', 'filter', 'partition', 'unband', 'dist'}
+    assert set(kevlar_amd.cli.mains) == {'count', 'novel', 'filter', 'partition', 'unband', 'dist', 'split', 'augment'}
     assert kevlar_amd.sketch.get_extension() == ('.nt', '.nodetable')
     assert kevlar_amd.sketch.get_extension(count=True) == ('.ct', '.counttable')
     assert kevlar_amd.sketch.get_extension(count=True, smallcount=True) == ('.sct', '.smallcounttable')
@@ -339,3 +339,53 @@ def test_dist_mu_sigma_and_table():
     assert list(data['Count'][:5]) == [6.0, 10.0, 12.0, 18.0, 16.0]
     assert list(data['CumulativeCount'][:5]) == [6.0, 16.0, 28.0, 46.0, 62.0]
     assert data['CumulativeFraction'].iloc[-1] == 1.0
+
+
+# ---- kevlar split / augment (kevlar/tests/test_split.py, test_augment.py): host text plumbing
+def test_split_round_robin_and_cli(tmp_path):
+    from io import StringIO
+    import kevlar_amd
+    from conftest import data_file
+
+    def partitions_of(path):
+        stream = kevlar_amd.parse_augmented_fastx(kevlar_amd.open(path, 'r'))
+        return [part for _, part in kevlar_amd.parse_partitioned_reads(stream)]
+    infile = data_file('fiveparts.augfastq.gz')
+    partstream = kevlar_amd.parse_partitioned_reads(kevlar_amd.parse_augmented_fastx(kevlar_amd.open(infile, 'r')))
+    outstreams = [StringIO(), StringIO(), StringIO()]
+    kevlar_amd.split.split(partstream, outstreams)
+    for part, stream in ((1, 0), (2, 1), (3, 2), (4, 0), (5, 1)):
+        assert 'kvcc={}'.format(part) in outstreams[stream].getvalue()
+    args = kevlar_amd.cli.parser().parse_args(['split', infile, '3', str(tmp_path / 'out')])
+    kevlar_amd.split.main(args)
+    sizes = [[len(p) for p in partitions_of(str(tmp_path / 'out.{}.augfastx.gz'.format(i)))] for i in range(3)]
+    assert sizes == [[67, 12], [23, 11], [15]]
+
+
+def test_augment_contigs_reads_and_cli(capsys):
+    import kevlar_amd
+    from kevlar_amd.augment import augment
+    from conftest import data_file
+
+    def stream(name):
+        return kevlar_amd.parse_augmented_fastx(kevlar_amd.open(data_file(name), 'r'))
+    augseqs = list(augment(stream('snorkel.augfastq'), stream('snorkel-contig.fasta')))
+    assert len(augseqs) == 1 and [k.offset for k in augseqs[0].annotations] == [17, 20, 22]
+    contigs = list(augment(stream('deadbeef.augfastq.gz'), stream('deadbeef.contig.fa')))
+    assert len(contigs) == 1 and len(contigs[0].annotations) == 74
+    augreads = list(stream('deadbeef.augfastq.gz'))
+    newreads = list(augment(augreads, stream('deadbeef.fq.gz'), upint=5))
+    for oldread, newread in zip(augreads, newreads):
+        assert oldread.sequence == newread.sequence and oldread.annotations == newread.annotations
+    args = kevlar_amd.cli.parser().parse_args(['augment', data_file('reaugment.augfastq'), data_file('reaugment.fq')])
+    kevlar_amd.augment.main(args)
+    out, _ = capsys.readouterr()
+    assert out == open(data_file('reaugment.out')).read()
+    args = kevlar_amd.cli.parser().parse_args(['augment', data_file('snorkel.augfastq'), data_file('snorkel-contig.fasta')])
+    kevlar_amd.augment.main(args)
+    out, _ = capsys.readouterr()
+    assert out.strip() == """>contig1
+AGGTCTTCGATGCTAGCATTTTTACGACAGACAAAAACAAGATTACATTCCAAAATACATACCGCGCC
+                 ATTTTTACGAC          8 0 0#
+                    TTTACGACAGA          11 0 0#
+                      TACGACAGACA          9 0 0#"""
