@@ -28,8 +28,12 @@ def build(force=False):
     stale = (not os.path.exists(_LIBPATH)
              or os.path.getmtime(_LIBPATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
     if force or stale:
-        subprocess.check_call(['make', '-C', _HERE, '-B', 'libkvoracle.so'],
-                              stdout=subprocess.DEVNULL)
+        import fcntl
+        with open(_LIBPATH + '.lock', 'w') as lock:      # concurrent test workers / ranks: one builds
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or not os.path.exists(_LIBPATH) or \
+                    os.path.getmtime(_LIBPATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+                subprocess.check_call(['make', '-C', _HERE, '-B', 'libkvoracle.so'], stdout=subprocess.DEVNULL)
     return _LIBPATH
 
 
