@@ -95,6 +95,7 @@ def main():
     genome_len = int(args.genome_mb * 1e6)
     t0 = time.time()
     packed = synth.trio_reads_packed(genome_len, args.coverage, L)
+    upload_s = None
     names = ('proband', 'mother', 'father')
     n_reads = packed['proband'].shape[0]
     multi = args.multi if args.multi != 'auto' else ('exchange' if world >= 4 else 'banded')
@@ -105,7 +106,10 @@ def main():
         batches = {n: hk.ReadBatch.from_packed(packed[n][bounds[n][0]:bounds[n][1]], L) for n in names}
         run = shardrun.ShardedTrio(k, hk.Counttable)
     else:
+        t_up = time.time()
         batches = {n: hk.ReadBatch.from_packed(packed[n], L) for n in names}
+        lib.kv_synchronize()
+        upload_s = time.time() - t_up
     gen_s = time.time() - t0
     nk = L - k + 1
     T = 4
@@ -257,6 +261,7 @@ def main():
                                 args.case_min, args.ctrl_max),
                 'parallelism': 'single band' if world == 1 else ('{} k-mer bands, 1 per GPU; reads sharded, hashes exchanged by band (all-to-all)'.format(world) if exchange else '{} k-mer bands, 1 per GPU; every rank hashes all reads'.format(world)),
                 'interesting_kmer_instances': nhits, 'host_generate_pack_upload_s': round(gen_s, 1),
+                'packed_reads_upload_s': round(upload_s, 3) if upload_s is not None else None,
                 'device': '{} ({} CUs)'.format(torch.cuda.get_device_properties(dev_index).name,
                                                torch.cuda.get_device_properties(dev_index).multi_processor_count),
             },

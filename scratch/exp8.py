@@ -14,8 +14,8 @@ def prof_all():
         ms, c = ctypes.c_double(), ctypes.c_uint64(); lib.kv_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(c)); out[name] = round(ms.value / max(1, c.value), 2)
     return out
 ref = None
-for mode, dbg in (('x', '0'), ('x', '256'), ('x', '0'), ('x', '256')):
-    os.environ['KV_BIN_DEBUG'] = dbg
+for mode, dbg in (('x', '0'), ('x', '1'), ('x', '0'), ('x', '1')):
+    os.environ['KV_BIN_A256'] = dbg
     sk = hk.Counttable(k, 5e8, 4)
     sk.consume_batch(b); sk.clear()
     lib.kv_prof_reset(); lib.kv_prof_enable(1)
