@@ -135,7 +135,7 @@ def novel(casestream, casecounts, controlcounts, ksize=31, abundscreen=None, cas
     if skipuntil:
         first_message += '; skipping reads in search of {read}'.format(read=skipuntil)
     progress = kevlar_amd.ProgressIndicator(first_message, interval=1e6, breaks=[1e7, 1e8, 1e9], usetimer=True)
-    unique_kmers = set()
+    seen_kmers = set()          # as read; canonicalised once at the end (distinct strings, not instances)
     band_mode = KV_BAND_NONE
     if numbands:
         band_mode = KV_BAND_REFQUIRK if refbandquirk else KV_BAND_RANGE
@@ -167,20 +167,24 @@ def novel(casestream, casecounts, controlcounts, ksize=31, abundscreen=None, cas
         bounds = np.flatnonzero(np.diff(hitread)) + 1
         starts = np.concatenate(([0], bounds))
         ends = np.concatenate((bounds, [len(hitread)]))
-        for s, e in zip(starts, ends):
-            record = tb.record(int(hitread[s]))
+        # plain Python lists: indexing numpy scalars one by one costs more than the scan itself
+        offs, abunds, first = hitoff.tolist(), hitabund.tolist(), hitread[starts].tolist()
+        for s, e, ridx in zip(starts.tolist(), ends.tolist(), first):
+            record = tb.record(ridx)
             irecord = kevlar_amd.sequence.copy_record(record)
+            sequence = record.sequence
             for j in range(s, e):
-                offset = int(hitoff[j])
-                kmer = record.sequence[offset:offset + k]
-                irecord.annotate(kmer, offset, tuple(int(a) for a in hitabund[j]))
-                unique_kmers.add(kevlar_amd.revcommin(kmer))
+                offset = offs[j]
+                kmer = sequence[offset:offset + k]
+                irecord.annotate(kmer, offset, tuple(abunds[j]))
+                seen_kmers.add(kmer)
             nreads += 1
-            nkmers += len(irecord.annotations)
+            nkmers += e - s
             yield irecord
 
     elapsed = timer.stop()
     message = 'Found {:d} instances'.format(nkmers)
+    unique_kmers = {kevlar_amd.revcommin(kmer) for kmer in seen_kmers}
     message += ' of {:d} unique novel kmers'.format(len(unique_kmers))
     message += ' in {:d} reads'.format(nreads)
     message += ' in {:.2f} seconds'.format(elapsed)

@@ -28,25 +28,30 @@ def tostr(stringlike):
 
 
 class Record(object):
-    __slots__ = ('name', 'sequence', 'quality', 'annotations', 'mates', 'ikmers')
+    __slots__ = ('name', 'sequence', 'quality', 'annotations', 'mates', '_ikmers', '_ikmers_n')
 
     def __init__(self, name, sequence, quality=None, annotations=None, mates=None, ikmers=None):
         self.name = name
         self.sequence = sequence
         self.quality = quality
         self.mates = [] if mates is None else mates
-        self.ikmers = {}
-        if annotations is None:
-            self.annotations = []
-        else:
-            self.annotations = annotations
-            if ikmers is not None:
-                self.ikmers = ikmers
-            else:
-                for ikmer in annotations:
-                    seq = self.ikmerseq(ikmer)
-                    self.ikmers[seq] = ikmer
-                    self.ikmers[revcom(seq)] = ikmer
+        self.annotations = [] if annotations is None else annotations
+        self._ikmers = ikmers          # k-mer sequence (both strands) -> KmerOfInterest; built on first use
+        self._ikmers_n = len(self.annotations) if ikmers is not None else -1
+
+    @property
+    def ikmers(self):
+        """{k-mer sequence or its reverse complement: KmerOfInterest} (sequence.pyx:38-49).  Only the strict
+        read-pair logic looks k-mers up by sequence, so the dictionary is built on demand, not per annotation."""
+        if self._ikmers is None or self._ikmers_n != len(self.annotations):
+            table = {}
+            for ikmer in self.annotations:
+                seq = self.ikmerseq(ikmer)
+                table[seq] = ikmer
+                table[revcom(seq)] = ikmer
+            self._ikmers = table
+            self._ikmers_n = len(self.annotations)
+        return self._ikmers
 
     def __len__(self):
         return len(self.sequence)
@@ -61,10 +66,7 @@ class Record(object):
     def annotate(self, sequence, offset, abundances):
         found = self.sequence[offset:offset + len(sequence)]
         assert found == sequence, (found, sequence)
-        ikmer = KmerOfInterest(len(sequence), offset, abundances)
-        self.annotations.append(ikmer)
-        self.ikmers[sequence] = ikmer
-        self.ikmers[revcom(sequence)] = ikmer
+        self.annotations.append(KmerOfInterest(len(sequence), offset, abundances))
 
     def ikmerseq(self, ikmer):
         return self.sequence[ikmer.offset:ikmer.offset + ikmer.ksize]
@@ -75,17 +77,18 @@ def copy_record(record):
     return Record(record.name, record.sequence, quality)
 
 
+def _by_offset(ikmer):
+    return ikmer[1]
+
+
 def format_augmented_fastx(record):
     if record.quality is not None:
         parts = ['@', record.name, '\n', record.sequence, '\n+\n', record.quality, '\n']
     else:
         parts = ['>', record.name, '\n', record.sequence, '\n']
-    for ikmer in sorted(record.annotations, key=lambda k: k.offset):
-        parts.append(' ' * ikmer.offset)
-        parts.append(record.sequence[ikmer.offset:ikmer.offset + ikmer.ksize])
-        parts.append(' ' * 10)
-        parts.append(' '.join(str(a) for a in ikmer.abund))
-        parts.append('#\n')
+    seq = record.sequence
+    for ksize, offset, abund in sorted(record.annotations, key=_by_offset):
+        parts.append('{}{}          {}#\n'.format(' ' * offset, seq[offset:offset + ksize], ' '.join(map(str, abund))))
     for mateseq in record.mates:
         parts.append('#mateseq={}#\n'.format(mateseq))
     return ''.join(parts)
@@ -123,10 +126,9 @@ def parse_augmented_fastx(instream):
             if line.startswith('#mateseq='):
                 record.add_mate(_MATE_RE.search(line).group(1))
                 continue
-            offset = len(line) - len(line.lstrip())
-            fields = line.strip()[:-1].split()
-            kmer = fields[0]
-            record.annotate(kmer, offset, tuple(int(a) for a in fields[1:]))
+            body = line.lstrip()
+            fields = body[:-2].split()
+            record.annotate(fields[0], len(line) - len(body), tuple(map(int, fields[1:])))
         else:
             raise Exception(line)
     yield record
