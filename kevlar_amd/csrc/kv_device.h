@@ -180,6 +180,7 @@ struct TileShared {
     uint32_t kpre[KV_TILE_MAX_READS + 1];  // k-mer prefix within the tile
     uint32_t unk;                          // k-mers per read if every read of the tile has the same count, else 0
     float unk_inv;
+    uint32_t seg_start;                    // segment tile: offset of the staged bases inside their read (else 0)
 };
 
 struct ReadsDev {
@@ -187,7 +188,7 @@ struct ReadsDev {
     const uint64_t *woff;
     const uint32_t *len;
     const uint8_t *flags;
-    const uint32_t *tile;
+    const TileDesc *tile;
 };
 
 // exclusive prefix sums over <= 128 reads by wave 0 (two entries per lane)
@@ -211,15 +212,20 @@ __device__ __forceinline__ uint32_t wave_excl_scan2(uint32_t a, uint32_t b, uint
 __device__ __forceinline__ uint32_t stage_tile(TileShared &sh, const ReadsDev &rd, uint32_t tile_id, int k,
                                                int skip_mode, uint64_t first_read, uint32_t &read0)
 {
-    const uint32_t r0 = rd.tile[tile_id], r1 = rd.tile[tile_id + 1];
-    const uint32_t nr = r1 - r0;
+    const TileDesc td = rd.tile[tile_id];
+    const uint32_t r0 = td.first, nr = td.count;
+    const uint32_t seg_start = td.seg ? td.seg_start : 0u;       // multiple of 16: word aligned
     read0 = r0;
-    const uint64_t w0 = rd.woff[r0];
+    const uint64_t w0 = rd.woff[r0] + (seg_start >> 4);
     if (threadIdx.x < 64) {
         const uint32_t i0 = 2 * threadIdx.x, i1 = i0 + 1;
         uint32_t l0 = 0, l1 = 0, k0 = 0, k1 = 0;
         if (i0 < nr) {
             l0 = rd.len[r0 + i0];
+            if (td.seg) {   // (nr == 1) stage the segment's k-mer starts plus the k - 1 bases that complete its last k-mers
+                const uint32_t rest = l0 - seg_start, want = (uint32_t)KV_SEG_BASES + (uint32_t)k - 1u;
+                l0 = rest < want ? rest : want;
+            }
             const bool skip = skip_mode && ((rd.flags[r0 + i0] & 1) || (uint64_t)(r0 + i0) < first_read);
             k0 = (l0 >= (uint32_t)k && !skip) ? l0 - (uint32_t)k + 1 : 0;
         }
@@ -238,15 +244,19 @@ __device__ __forceinline__ uint32_t stage_tile(TileShared &sh, const ReadsDev &r
         const uint32_t ka = wave_excl_scan2(k0, k1, kb, ktot);
         if (i0 < nr) sh.kpre[i0] = ka;
         if (i1 < nr) sh.kpre[i1] = kb;
-        if (threadIdx.x == 0) sh.kpre[nr] = ktot;
+        if (threadIdx.x == 0) { sh.kpre[nr] = ktot; sh.seg_start = seg_start; }
         // uniform tile (the common case: fixed-length reads): k-mer -> read is a division, not a search
         const uint32_t ref_k = __shfl(k0, 0);
         const bool same = (i0 >= nr || k0 == ref_k) && (i1 >= nr || k1 == ref_k);
         const bool uniform = __all(same) && ref_k > 0;
         if (threadIdx.x == 0) { sh.unk = uniform ? ref_k : 0u; sh.unk_inv = uniform ? 1.0f / (float)ref_k : 0.0f; }
-        if (i0 < nr) sh.wpre[i0] = (uint32_t)(rd.woff[r0 + i0] - w0);
-        if (i1 < nr) sh.wpre[i1] = (uint32_t)(rd.woff[r0 + i1] - w0);
-        if (threadIdx.x == 0) sh.wpre[nr] = (uint32_t)(rd.woff[r1] - w0);
+        if (td.seg) {
+            if (threadIdx.x == 0) { sh.wpre[0] = 0; sh.wpre[1] = (l0 + 15) >> 4; }
+        } else {
+            if (i0 < nr) sh.wpre[i0] = (uint32_t)(rd.woff[r0 + i0] - w0);
+            if (i1 < nr) sh.wpre[i1] = (uint32_t)(rd.woff[r0 + i1] - w0);
+            if (threadIdx.x == 0) sh.wpre[nr] = (uint32_t)(rd.woff[r0 + nr] - w0);
+        }
     }
     __syncthreads();
     const uint32_t nwords = sh.wpre[nr];

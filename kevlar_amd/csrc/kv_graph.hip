@@ -199,7 +199,7 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_first_touch(ReadsDev rd, co
         const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)p.f.hp.k - i);
         const uint64_t h = kmer_hash_lds(sh.ascii, fwd, rc, p.f.hp);
         if (!consume_filter_pass(p.f, mask, h)) continue;
-        const uint32_t ordinal = (uint32_t)(p.ordinal_base + p.kprefix[read0 + r] + i);
+        const uint32_t ordinal = (uint32_t)(p.ordinal_base + p.kprefix[read0 + r] + sh.seg_start + i);
         for (int t = 0; t < sk->ntables; ++t)
             atomicMin(&p.first[t][fastmod(h, sk->size[t], sk->magic[t])], ordinal);
     }
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_abund_hist(ReadsDev rd, con
     for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
         uint32_t r, i;
         locate_kmer(sh, nr, q, r, i);
-        const uint64_t ordinal = p.ordinal_base + p.kprefix[read0 + r] + i;
+        const uint64_t ordinal = p.ordinal_base + p.kprefix[read0 + r] + sh.seg_start + i;
         if (!((p.bitmap[ordinal >> 5] >> (ordinal & 31)) & 1u)) continue;
         const uint32_t fwd = sh.foff[r] + i;
         const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)p.hp.k - i);

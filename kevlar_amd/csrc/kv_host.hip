@@ -608,7 +608,7 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
     r->d_words = nullptr; r->d_woff = nullptr; r->d_len = nullptr; r->d_flags = nullptr; r->d_tile = nullptr;
     r->h_len.resize(n_reads);
     std::vector<uint64_t> woff(n_reads + 1);
-    std::vector<uint32_t> tiles;
+    std::vector<TileDesc> tiles;
     uint64_t nw = 0;
     uint32_t max_len = 0;
     for (uint64_t i = 0; i < n_reads; ++i) {
@@ -627,23 +627,32 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
     woff[n_reads] = nw;
     r->n_words = nw;
     r->max_len = max_len;
-    // tiles: consecutive reads whose staged ASCII (both strands, padded) fits the LDS budget; a read
-    // that alone exceeds the budget gets a tile of its own and raises the batch's dynamic LDS size
+    // tiles: consecutive reads whose staged ASCII (both strands, padded) fits the LDS budget; a sequence
+    // too long for one tile (contigs, the chromosomes of a reference genome counted into a mask) becomes a
+    // series of segment tiles of KV_SEG_BASES k-mer starts each
     {
-        uint32_t used = 0, count = 0, biggest = 0;
-        tiles.push_back(0);
+        const uint32_t budget = KV_TILE_LDS_BYTES - 64;
+        uint32_t used = 0, count = 0, first = 0;
+        auto close_run = [&](uint32_t next_first) {
+            if (count) tiles.push_back(TileDesc{first, count, 0u, 0u});
+            used = 0; count = 0; first = next_first;
+        };
         for (uint64_t i = 0; i < n_reads; ++i) {
-            uint32_t need = 2 * ((r->h_len[i] + KV_READ_PAD + 3) & ~3u);
-            if (count > 0 && (count == KV_TILE_MAX_READS || used + need > KV_TILE_LDS_BYTES - 64)) {
-                tiles.push_back((uint32_t)i);
-                used = 0; count = 0;
+            const uint32_t need = 2 * ((r->h_len[i] + KV_READ_PAD + 3) & ~3u);
+            if (need > budget) {
+                close_run((uint32_t)i + 1);
+                for (uint32_t start = 0; start < r->h_len[i]; start += KV_SEG_BASES)
+                    tiles.push_back(TileDesc{(uint32_t)i, 1u, start, 1u});
+                continue;
             }
+            if (count > 0 && (count == KV_TILE_MAX_READS || used + need > budget)) close_run((uint32_t)i);
+            if (count == 0) first = (uint32_t)i;
             used += need; count += 1;
-            if (used > biggest) biggest = used;
         }
-        if (n_reads) tiles.push_back((uint32_t)n_reads);
-        r->n_tiles = (uint32_t)tiles.size() - 1;
-        r->tile_lds_bytes = std::max<uint32_t>(KV_TILE_LDS_BYTES, (biggest + 64 + 255) & ~255u) + 256;   // + rolling-window over-read
+        close_run((uint32_t)n_reads);
+        r->n_tiles = (uint32_t)tiles.size();
+        r->tile_lds_bytes = KV_TILE_LDS_BYTES + 256;   // + rolling-window over-read
+        if (tiles.empty()) tiles.push_back(TileDesc{0u, 0u, 0u, 0u});
     }
     const uint64_t flag_bytes = ((n_reads + 3) & ~3ull) + 4;
     char *d_ascii = nullptr;
@@ -653,7 +662,7 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, flag_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, tiles.size() * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, tiles.size() * sizeof(TileDesc));
     if (e == hipSuccess) e = hipMalloc((void **)&d_ascii, r->n_bases ? r->n_bases : 1);
     if (e == hipSuccess) e = hipMalloc((void **)&d_offs, woff.size() * 8);
     if (e == hipSuccess && r->n_bases) e = hipMemcpyAsync(d_ascii, bases + offs[0], r->n_bases, hipMemcpyHostToDevice, st);
@@ -661,7 +670,7 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
     if (e == hipSuccess) e = hipMemcpyAsync(r->d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && n_reads) e = hipMemcpyAsync(r->d_len, r->h_len.data(), n_reads * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(r->d_flags, 0, flag_bytes, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(r->d_tile, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->d_tile, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, st);
     if (e == hipSuccess && nw) {
         KvProfScope prof("k_pack_reads");
         const unsigned grid = (unsigned)std::min<uint64_t>((nw + 255) / 256, 65536);
@@ -697,21 +706,23 @@ extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, u
     uint32_t per_tile = (KV_TILE_LDS_BYTES - 64) / need;
     if (per_tile > KV_TILE_MAX_READS) per_tile = KV_TILE_MAX_READS;
     if (per_tile < 1) per_tile = 1;
-    std::vector<uint32_t> tiles;
-    for (uint64_t i = 0; i < n_reads; i += per_tile) tiles.push_back((uint32_t)i);
-    tiles.push_back((uint32_t)n_reads);
-    r->n_tiles = n_reads ? (uint32_t)tiles.size() - 1 : 0;
-    r->tile_lds_bytes = std::max<uint32_t>(KV_TILE_LDS_BYTES, (per_tile * need + 64 + 255) & ~255u) + 256;
+    KV_REQUIRE(need <= KV_TILE_LDS_BYTES - 64, KV_ERR_ARG, "kv_reads_create_packed: read length %u needs kv_reads_create", read_len);
+    std::vector<TileDesc> tiles;
+    for (uint64_t i = 0; i < n_reads; i += per_tile)
+        tiles.push_back(TileDesc{(uint32_t)i, (uint32_t)std::min<uint64_t>(per_tile, n_reads - i), 0u, 0u});
+    r->n_tiles = (uint32_t)tiles.size();
+    if (tiles.empty()) tiles.push_back(TileDesc{0u, 0u, 0u, 0u});
+    r->tile_lds_bytes = KV_TILE_LDS_BYTES + 256;
     hipError_t e = hipMalloc((void **)&r->d_words, (r->n_words ? r->n_words : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, n_reads ? n_reads : 1);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, tiles.size() * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, tiles.size() * sizeof(TileDesc));
     if (e == hipSuccess && r->n_words) e = hipMemcpy(r->d_words, words, r->n_words * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(r->d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess && n_reads) e = hipMemcpy(r->d_len, r->h_len.data(), n_reads * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(r->d_flags, 0, n_reads ? n_reads : 1);
-    if (e == hipSuccess) e = hipMemcpy(r->d_tile, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(r->d_tile, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         kv_set_error("read batch upload failed: %s", hipGetErrorString(e));
         kv_reads_destroy(r);

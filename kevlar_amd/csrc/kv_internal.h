@@ -52,6 +52,14 @@ struct kv_sketch {
     std::mutex mu;
 };
 
+// One unit of work of the hashing kernels: `count` whole reads starting at read `first`, or (seg != 0) the
+// segment of read `first` whose k-mers START in [seg_start, seg_start + KV_SEG_BASES): the kernel stages
+// KV_SEG_BASES + k - 1 bases, so every k-mer of a chromosome-length sequence belongs to exactly one tile
+// whatever k is (the tile table itself does not depend on k).
+struct TileDesc {
+    uint32_t first, count, seg_start, seg;
+};
+
 // Packed read batch.  Read r occupies words [woff[r], woff[r+1]) of `words`; base j sits in
 // word woff[r] + j/16 at bits 2*(j%16), code A=0 C=1 G=2 T=3.
 struct kv_reads {
@@ -60,7 +68,7 @@ struct kv_reads {
     uint64_t *d_woff;   // n_reads + 1
     uint32_t *d_len;    // n_reads
     uint8_t *d_flags;   // n_reads: bit0 = contains a base outside ACGT (novel scan skips it)
-    uint32_t *d_tile;   // n_tiles + 1 read indices: tile t = reads [d_tile[t], d_tile[t+1])
+    struct TileDesc *d_tile;   // n_tiles descriptors: a run of whole reads, or one segment of a long read
     uint32_t n_tiles;
     uint32_t tile_lds_bytes;  // dynamic LDS the tile kernels need for this batch (>= KV_TILE_LDS_BYTES)
     uint32_t max_len;
@@ -129,7 +137,8 @@ double kv_estimate_distinct(uint64_t occupied, uint64_t size);
 #define KV_TILE_MAX_READS 64
 #define KV_TILE_LDS_BYTES 16384  // ASCII staging (forward + reverse complement) per tile: 64 reads of 100 bp
 #define KV_READ_PAD 24           // over-read slack after each staged strand
-#define KV_MAX_READ_LEN 49000    // a longer read would not fit one workgroup's LDS next to the partition rings
+#define KV_MAX_READ_LEN 0x7fffffff   // sequences longer than a tile are cut into segment tiles (reference genomes for masks)
+#define KV_SEG_BASES 7680        // k-mer starts per segment tile: 2 x (7680 + KV_MAX_K - 1 + pad) bytes of ASCII fit the tile budget
 
 // error plumbing -------------------------------------------------------------------------
 void kv_set_error(const char *fmt, ...);

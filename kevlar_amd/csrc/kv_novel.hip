@@ -174,7 +174,7 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_mark(ReadsDev rd, Nov
             const uint32_t gread = read0 + cur.r;
             if (discard) p.disc_flag[gread] = 1;   // several k-mers may flag one read: plain store
             if (interesting) {
-                const uint64_t bit = (uint64_t)gread * p.mask_stride + cur.i;
+                const uint64_t bit = (uint64_t)gread * p.mask_stride + sh.seg_start + cur.i;
                 atomicOr(&p.mask[bit >> 5], 1u << (bit & 31));
                 mine += 1;
             }
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_emit(ReadsDev rd, Nov
         bool hit = false;
         if (q < total) {
             locate_kmer(sh, nr, q, r, i);
-            const uint64_t bit = (uint64_t)(read0 + r) * p.mask_stride + i;
+            const uint64_t bit = (uint64_t)(read0 + r) * p.mask_stride + sh.seg_start + i;
             hit = (p.mask[bit >> 5] >> (bit & 31)) & 1u;
         }
         const unsigned long long ballot = __ballot(hit);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_emit(ReadsDev rd, Nov
             const uint32_t rc = sh.roff[r] + (sh.len[r] - (uint32_t)p.hp.k - i);
             const uint64_t h = kmer_hash_lds(sh.ascii, fwd, rc, p.hp);
             p.hit_read[slot] = read0 + r;
-            p.hit_off[slot] = i;
+            p.hit_off[slot] = sh.seg_start + i;
             for (int c = 0; c < S; ++c) p.hit_abund[slot * (uint64_t)S + c] = (uint8_t)sketch_get(p.sk[c], h);
         }
         out += all;

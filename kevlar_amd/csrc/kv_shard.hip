@@ -108,7 +108,7 @@ __global__ __launch_bounds__(ROUTE_THREADS, 6) void k_route_hashes(ReadsDev rd, 
             for (int b = 1; b < p.ndest; ++b) d += h >= lo[b] ? 1u : 0u;
             uint64_t tag = 0;
             if (TAGS) {
-                tag = ((p.read_base + read0 + r) << 16) | (uint64_t)i;
+                tag = ((p.read_base + read0 + r) << 16) | (uint64_t)(sh.seg_start + i);
                 if (flagged[r]) tag |= 1ull << 63;
             }
             const uint32_t pos = atomicAdd(&cur[d], 1u);

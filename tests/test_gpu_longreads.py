@@ -1,0 +1,102 @@
+"""Sequences longer than a tile (contigs; the chromosomes of a reference genome that `kevlar count`
+turns into a mask, mark-I/Snakefile:211-218) are cut into segment tiles of KV_SEG_BASES k-mer starts.
+Every k-mer must still be counted exactly once, for any k, on both count paths, and the scan / dist /
+exact-distinct kernels must report read-relative positions."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def long_reads(seed=4):
+    rng = np.random.default_rng(seed)
+    letters = np.array(list('ACGT'))
+
+    def rnd(n):
+        return ''.join(letters[rng.integers(0, 4, size=n)])
+    chrom = rnd(100003)
+    chrom = chrom[:50000] + 'N' * 7 + chrom[50007:]          # an assembly gap
+    # lengths around the segment size (7680) and the tile budget (~8 kb), short reads in between
+    return [rnd(120), chrom, rnd(7680), rnd(7681), rnd(8200), rnd(15360 + 30), rnd(40), rnd(23041), rnd(90)]
+
+
+@pytest.mark.parametrize('kind,k,force', [('Nodetable', 31, None), ('Counttable', 31, 'binned'), ('Counttable', 200, None),
+                                          ('SmallCounttable', 21, 'binned'), ('Nodegraph', 25, None)])
+def test_count_long_sequences_matches_oracle(hk, ok, kind, k, force):
+    reads = long_reads()
+    dev, ref = getattr(hk, kind)(k, 4e5, 4), getattr(ok, kind)(k, 4e5, 4)
+    if force:
+        os.environ['KV_COUNT_PATH'] = force
+    try:
+        n_dev = dev.consume_batch(hk.ReadBatch(reads))
+    finally:
+        os.environ.pop('KV_COUNT_PATH', None)
+    bases, offs = ok.concat_reads(reads)
+    assert n_dev == ok.consume_reads(ref, bases, offs, len(reads))
+    for t in range(4):
+        assert dev.table_bytes(t) == ref.table_bytes(t)
+    assert dev.n_occupied() == ref.n_occupied()
+
+
+def test_banded_masked_count_long_sequences(hk, ok):
+    reads = long_reads(9)
+    k = 31
+    dmask, rmask = hk.Nodetable(k, 2e5, 4), ok.Nodetable(k, 2e5, 4)
+    dmask.consume(reads[4]); rmask.consume(reads[4])
+    for nb, band in ((3, 1), (0, 0)):
+        dev, ref = hk.Counttable(k, 3e5, 4), ok.Counttable(k, 3e5, 4)
+        n_dev = dev.consume_batch(hk.ReadBatch(reads), nb, band, dmask, 0, False)
+        bases, offs = ok.concat_reads(reads)
+        assert n_dev == ok.consume_reads(ref, bases, offs, len(reads), nb, band, rmask, 0, False)
+        for t in range(4):
+            assert dev.table_bytes(t) == ref.table_bytes(t)
+
+
+def test_novel_scan_reports_read_relative_offsets_in_long_reads(hk, ok):
+    """case = a mutated copy of a long contig; controls = the original: hits deep inside the contig"""
+    rng = np.random.default_rng(11)
+    letters = np.array(list('ACGT'))
+    contig = ''.join(letters[rng.integers(0, 4, size=30011)])
+    mutated = list(contig)
+    for pos in (100, 7679, 7680, 7700, 15359, 23040, 29990):
+        mutated[pos] = 'A' if mutated[pos] != 'A' else 'C'
+    mutated = ''.join(mutated)
+    k = 31
+    case_reads = [mutated[:90], mutated, mutated[200:9000]]
+    dev = {'case': hk.Counttable(k, 5e5, 4), 'ctrl': hk.Counttable(k, 5e5, 4)}
+    ref = {'case': ok.Counttable(k, 5e5, 4), 'ctrl': ok.Counttable(k, 5e5, 4)}
+    for _ in range(6):                       # abundance 6 in the case sample
+        dev['case'].consume_batch(hk.ReadBatch([mutated]))
+        ref['case'].consume(mutated)
+    for _ in range(3):
+        dev['ctrl'].consume_batch(hk.ReadBatch([contig]))
+        ref['ctrl'].consume(contig)
+    batch = hk.ReadBatch(case_reads)
+    r, o, a, _ = hk.novel_scan([dev['case']], [dev['ctrl']], batch, 6, 0)
+    bases, offs = ok.concat_reads(case_reads)
+    hits, _ = ok.novel_scan([ref['case']], [ref['ctrl']], bases, offs, len(case_reads), k, 6, 0)
+    got = [(int(r[i]), int(o[i]), tuple(int(x) for x in a[i])) for i in range(len(r))]
+    assert got == hits
+    assert max(h[1] for h in hits) > 29000 and len(hits) > 150
+
+
+def test_dist_and_exact_distinct_on_long_sequences(hk, ok):
+    import ctypes
+    reads = long_reads(21)
+    k = 27
+    dev, ref = hk.Counttable(k, 2.5e5, 4), ok.Counttable(k, 2.5e5, 4)
+    dev.track_exact_unique(True)
+    dev.consume_batch(hk.ReadBatch(reads))
+    bases, offs = ok.concat_reads(reads)
+    ok.consume_reads(ref, bases, offs, len(reads))
+    assert dev.n_unique_kmers() == ref.n_unique_kmers()
+    dtrack = hk.Nodetable(k, 1, 1, primes=dev.hashsizes())
+    rtrack = ok.Nodetable(k, 1, 1, primes=ref.hashsizes())
+    got = dev.abundance_distribution(hk.ReadBatch(reads), dtrack)
+    hist = (ctypes.c_uint64 * 65536)()
+    for seq in reads:
+        b = seq.encode()
+        ok.lib.kvo_abundance_distribution(ref._h, rtrack._h, b, len(b), hist)
+    assert got == list(hist)

@@ -269,9 +269,9 @@ def test_exact_unique_matches_single_thread_oracle(hk, ok):
         assert dev.n_occupied() == ref.n_occupied()
 
 
-def test_long_sequences_get_their_own_tile(hk, ok):
-    """FASTA records of tens of kilobases (the reference counts bogus-genome/refr.fa, 3 x 12 kb)
-    ride in a tile of their own with a larger dynamic LDS allocation."""
+def test_long_sequences_are_cut_into_segment_tiles(hk, ok):
+    """FASTA records of tens of kilobases (the reference counts bogus-genome/refr.fa, 3 x 12 kb) do not
+    fit one tile: they become segment tiles (more cases in test_gpu_longreads.py)."""
     rng = np.random.default_rng(4)
     letters = np.array(list('ACGT'))
     reads = [''.join(letters[rng.integers(0, 4, size=n)]) for n in (12345, 100, 40000, 31, 30, 48999, 250)]
@@ -289,5 +289,4 @@ def test_long_sequences_get_their_own_tile(hk, ok):
     r, o, a, _ = hk.novel_scan([dev], [], hk.ReadBatch(reads), 1, 0)
     hits, _ = ok.novel_scan([ref], [], bases, offs, len(reads), 31, 1, 0)
     assert [(int(x), int(y)) for x, y in zip(r, o)] == [(h[0], h[1]) for h in hits]
-    with pytest.raises(ValueError, match='reads up to'):
-        hk.ReadBatch(['A' * 60000])
+    assert hk.ReadBatch(['A' * 60000]).num_kmers(31) == 60000 - 30        # no length limit any more
