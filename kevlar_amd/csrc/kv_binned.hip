@@ -48,7 +48,6 @@ struct BinGeom {
     uint32_t recipF;                 // floor(2^32 / F) + 1: slice / F by multiply-high
     uint32_t nslices[BIN_MAX_T];
     uint32_t tile_lds;               // bytes of dynamic LDS in front of the stage-A rings
-    uint32_t debug;                  // KV_BIN_DEBUG: 1 = skip ring appends, 2 = skip burst stores (timing experiments only)
     uint32_t nwgA, nwgB;             // writers per coarse bucket (stage-A workgroups) / per slice (stage-B workgroups of the bucket)
     uint64_t cap1, cap2, spill_cap;  // items per PRIVATE segment: every writer owns its own region of every stream,
                                      // so appending needs no global atomic (and no round trip) at all
@@ -162,7 +161,6 @@ __device__ __forceinline__ uint32_t bin_push(const Rings<uint32_t> &rs, const Bi
         item[t] = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu);
         sidx[t] = (uint32_t)t * (uint32_t)g.C + c;
     }
-    if (g.debug & 1u) return item[0] & 1u;
 #pragma unroll
     for (int t = 0; t < BIN_MAX_T; ++t)
         if (t < g.T) pos[t] = atomicAdd(&rs.cnt[sidx[t]], 1u);
@@ -200,7 +198,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash(
         const uint32_t mine = (threadIdx.x >> 6) * per_wave + (threadIdx.x & 63);
         if ((threadIdx.x & 63) < per_wave && mine < ns) seg_base = ((uint64_t)mine * g.nwgA + blockIdx.x) * g.cap1;
     }
-    auto store = [&](uint64_t idx, uint32_t item) { if (!(g.debug & 2u)) g.gbuf1[idx] = item; };
+    auto store = [&](uint64_t idx, uint32_t item) { g.gbuf1[idx] = item; };
     auto overflow = [&](uint32_t s, uint32_t item) {   // private segment full: keep the increment, apply it later with an atomic
         const uint32_t t = s / (uint32_t)g.C, c = s % (uint32_t)g.C;
         spill_item(g, (int)t, (((uint64_t)c * g.F + (item >> 16)) << 16) | (item & 0xffffu));
@@ -327,7 +325,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash_
 #pragma unroll
             for (int t = 0; t < BIN_MAX_T; ++t) {
                 if (t >= g.T) break;
-                if (pos[t] < g.cap1) { if (!(g.debug & 2u)) g.gbuf1[((uint64_t)sidx[t] * g.nwgA + blockIdx.x) * g.cap1 + pos[t]] = item[t]; }
+                if (pos[t] < g.cap1) g.gbuf1[((uint64_t)sidx[t] * g.nwgA + blockIdx.x) * g.cap1 + pos[t]] = item[t];
                 else spill_item(g, t, bins[t]);
             }
         }
@@ -413,7 +411,7 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
         const uint32_t mine = (threadIdx.x >> 6) * per_wave + (threadIdx.x & 63);
         if ((threadIdx.x & 63) < per_wave && mine < F) seg_base = (((uint64_t)s * F + mine) * g.nwgB + blockIdx.x) * g.cap2;
     }
-    auto store = [&](uint64_t idx, uint16_t off) { if (!(g.debug & 128u)) g.gbuf2[idx] = off; };
+    auto store = [&](uint64_t idx, uint16_t off) { g.gbuf2[idx] = off; };
     auto overflow = [&](uint32_t fi, uint16_t off) { spill_item(g, (int)t, (((uint64_t)c * F + fi) << 16) | off); };
     const uint64_t step = (uint64_t)BIN_B_THREADS * BIN_B_ITEMS;
     // this workgroup drains the private segments seg = blockIdx.x, blockIdx.x + nwgB, ... of bucket s
@@ -439,8 +437,7 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
                 for (uint64_t i = i0; i < end; ++i) items[have++] = src[i];
             }
             if (r0 + step < end) fetch(r0 + step, va, vb);          // next round's items fly during this round
-            if (g.debug & 64u) { if (have && items[0] == 0x12345u) spill_item(g, 0, 1); }
-            else if (have == BIN_B_ITEMS) {
+            if (have == BIN_B_ITEMS) {
                 // full vector: all ring positions are requested back to back (independent LDS atomics in flight
                 // together), then consumed; an item whose ring is full is rare and handled after the fast path
                 uint32_t pos[BIN_B_ITEMS], rbase[BIN_B_ITEMS];
@@ -631,11 +628,10 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
     for (uint32_t j = threadIdx.x; j < nvec; j += BIN_C_THREADS) l4[j] = tab[j];
     __syncthreads();
     uint32_t fresh = 0;
-    for (uint32_t v = threadIdx.x; v < ((g.debug & 32u) ? 0u : total_vec); v += BIN_C_THREADS) {
+    for (uint32_t v = threadIdx.x; v < total_vec; v += BIN_C_THREADS) {
         const Vec v2 = fetch(v + 2 * BIN_C_THREADS);
         const uint32_t w[4] = {v0.q.x, v0.q.y, v0.q.z, v0.q.w};
-        if (g.debug & 16u) { fresh += w[0] ^ w[1] ^ w[2] ^ w[3]; }
-        else fresh += lds_inc8<STORAGE>(lds, w, v0.n);
+        fresh += lds_inc8<STORAGE>(lds, w, v0.n);
         v0 = v1; v1 = v2;
     }
     __syncthreads();
@@ -773,7 +769,6 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
     memset(&g, 0, sizeof(g));
     g.T = s->h.ntables;
     g.tile_lds = reads ? reads->tile_lds_bytes : 0u;
-    g.debug = getenv("KV_BIN_DEBUG") ? (uint32_t)atoi(getenv("KV_BIN_DEBUG")) : 0u;
     uint64_t pmin = UINT64_MAX;
     uint32_t maxsl = 1;
     for (int t = 0; t < g.T; ++t) {
@@ -786,19 +781,18 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
     // beyond 2^30 bins.  Fewer buckets = fewer distinct lines per stage-A store instruction (that stage is bound by
     // L2 write requests): measured per 525 M k-mers into 5e8-bin tables, A/B/C = 10.5/5.0/4.0 ms with 32 buckets,
     // 8.7/4.9/4.0 with 20, 8.3/6.1/4.0 with 16 (F = 478: rings too big for three workgroups).
-    int cmax = maxsl <= 32u * BIN_MAX_F ? (int)std::min<uint32_t>(32u, std::max<uint32_t>(4u, (maxsl + 383u) / 384u)) : BIN_C;
-    if (getenv("KV_BIN_CMAX") && maxsl <= (uint32_t)atoi(getenv("KV_BIN_CMAX")) * BIN_MAX_F) cmax = atoi(getenv("KV_BIN_CMAX"));   // experiments
+    const int cmax = maxsl <= 32u * BIN_MAX_F ? (int)std::min<uint32_t>(32u, std::max<uint32_t>(4u, (maxsl + 383u) / 384u)) : BIN_C;
     g.F = (int)((maxsl + (uint32_t)cmax - 1) / (uint32_t)cmax);
     g.C = (int)((maxsl + (uint32_t)g.F - 1) / (uint32_t)g.F);
     g.recipF = g.F == 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)g.F + 1);   // F == 1: kernels take slice as is
     auto ring_for = [](uint32_t streams, uint32_t budget) {
-        uint32_t r = getenv("KV_BIN_RMIN") ? (uint32_t)atoi(getenv("KV_BIN_RMIN")) : BIN_RING_MIN;
+        uint32_t r = BIN_RING_MIN;
         while (r * 2 <= BIN_RING_MAX && (uint64_t)r * 2 * streams <= budget) r *= 2;
         return r;
     };
     const uint32_t budgetA = cmax <= 32 ? 8192u : 16384u;
     g.ringA = ring_for((uint32_t)(g.T * g.C), budgetA);
-    g.ringB = ring_for((uint32_t)g.F, getenv("KV_BIN_BBUDGET") ? (uint32_t)atoi(getenv("KV_BIN_BBUDGET")) : BIN_B_BUDGET);
+    g.ringB = ring_for((uint32_t)g.F, BIN_B_BUDGET);
     const int cus = device_cus();
     const double expected = (double)(nbands > 0 && !filter.use_mask ? n_kmers / (uint64_t)nbands + 1 : n_kmers);
     const uint64_t ns = (uint64_t)g.T * g.C;
