@@ -490,6 +490,14 @@ class _Sketch(object):
             check(_lib.load().kv_hash_kmers(self._kind, blob, k, n, _u64p(out)))
         return out
 
+    def get_kmer_counts(self, seq):
+        """khmer's Hashtable.get_kmer_counts: the count of every k-mer of `seq`, in order
+        (kevlar/simlike.py:24-35,87)."""
+        k = self.ksize()
+        if len(seq) < k:
+            return []
+        return [int(c) for c in self.get_hashes(self.hash_kmers(self.get_kmers(seq)))]
+
     def get_kmer_hashes(self, seq):
         return [int(h) for h in self.hash_kmers(self.get_kmers(seq))]
 

@@ -244,6 +244,9 @@ class _Sketch(object):
         k = self.ksize()
         return [seq[i:i + k] for i in range(len(seq) - k + 1)]
 
+    def get_kmer_counts(self, seq):
+        return [self.get(kmer) for kmer in self.get_kmers(seq)]
+
     def get_kmer_hashes(self, seq):
         return [self.hash(km) for km in self.get_kmers(seq)]
 

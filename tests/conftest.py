@@ -58,3 +58,39 @@ def kevlar_log():
     kevlar_amd.logstream = buf
     yield buf
     kevlar_amd.logstream = old
+
+SIMLIKE_ALT = 'TGTCTCCCTCCCCTCCACCCCCAGAAATGGGTTTTTGATAGTCTTCCAAAGTTAGGGTAGT'
+SIMLIKE_REF = 'TGTCTCCCTCCCCTCCACCCCCAGAAATGGCTTTTTGATAGTCTTCCAAAGTTAGGGTAGT'
+SIMLIKE_INDEL = 'TGTCTCCCTCCCCTCCACCCCCAGAAATGGGAAATTTTTGATAGTCTTCCAAAGTTAGGGTAGT'
+SIMLIKE_GOLD_ALT = [
+    [7, 6, 6, 6, 6, 6, 6, 6, 6, 6, 7, 9, 8, 8, 9, 9, 9, 7, 7, 8, 8, 8, 7, 7, 7, 7, 7, 7],
+    [1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1],
+    [0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+]
+SIMLIKE_GOLD_REFR = [2, 2, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1]
+
+
+def simlike_minitrio(khmer_module):
+    """kevlar/tests/test_simlike.py:21-31"""
+    kid = khmer_module.Counttable(31, 1e6, 4)
+    mom = khmer_module.Counttable(31, 1e6, 4)
+    dad = khmer_module.Counttable(31, 1e6, 4)
+    ref = khmer_module.SmallCounttable(31, 125000, 4)
+    kid.consume_seqfile(data_file('minitrio/trio-proband.fq.gz'))
+    mom.consume_seqfile(data_file('minitrio/trio-mother.fq.gz'))
+    dad.consume_seqfile(data_file('minitrio/trio-father.fq.gz'))
+    ref.consume_seqfile(data_file('minitrio/refr.fa'))
+    return kid, mom, dad, ref
+
+
+def check_spanning_kmer_abundances(khmer_module):
+    """kevlar/tests/test_simlike.py:82-106"""
+    from kevlar_amd.simlike import spanning_kmer_abundances
+    kid, mom, dad, ref = simlike_minitrio(khmer_module)
+    altabund, refrabund, ndropped = spanning_kmer_abundances(SIMLIKE_ALT, SIMLIKE_REF, kid, (mom, dad), ref)
+    assert ndropped == 3
+    assert altabund == SIMLIKE_GOLD_ALT
+    assert refrabund == SIMLIKE_GOLD_REFR
+    altabund, refrabund, ndropped = spanning_kmer_abundances(SIMLIKE_ALT, SIMLIKE_INDEL, kid, (mom, dad), ref)
+    assert ndropped == 3
+    assert refrabund == [None] * len(altabund[0])

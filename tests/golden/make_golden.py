@@ -60,7 +60,7 @@ FIXTURES = [
     'part-reads-simple.fa',
     # kevlar dist (kevlar/tests/test_dist.py)
     'minitrio/mask.nt', 'minitrio/trio-proband.fq.gz', 'minitrio/trio-proband-mask-counts.ct',
-    'minitrio/trio-proband-dist.tsv',
+    'minitrio/trio-proband-dist.tsv', 'minitrio/trio-mother.fq.gz', 'minitrio/trio-father.fq.gz', 'minitrio/refr.fa',
     # kevlar split / augment (kevlar/tests/test_split.py, test_augment.py)
     'fiveparts.augfastq.gz', 'snorkel.augfastq', 'snorkel-contig.fasta', 'reaugment.augfastq', 'reaugment.fq',
     'reaugment.out', 'deadbeef.augfastq.gz', 'deadbeef.contig.fa', 'deadbeef.fq.gz', 'part-reads-mixed.fa',

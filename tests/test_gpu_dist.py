@@ -97,3 +97,9 @@ def test_abundance_distribution_matches_oracle_across_batches(hk, ok):
         assert sum(got) > 1000
         for t in range(4):
             assert dev_track.table_bytes(t) == ref_track.table_bytes(t)
+
+
+def test_simlike_spanning_kmer_abundances_golden(hk):
+    """kevlar/tests/test_simlike.py:82-106 on the device: four sketches counted from files, batched gets"""
+    from conftest import check_spanning_kmer_abundances
+    check_spanning_kmer_abundances(hk)

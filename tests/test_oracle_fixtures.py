@@ -201,3 +201,10 @@ def test_dist_tsv_golden_through_the_oracle(ok):
                     861.0, 888.0, 902.0, 903.0]
     rows = [line.split('\t') for line in open(data_file('minitrio/trio-proband-dist.tsv')).read().strip().split('\n')[1:]]
     assert [(float(r[0]), float(r[1])) for r in rows] == [(float(a), float(abund[a])) for a in sorted(abund)]
+
+
+def test_simlike_spanning_kmer_abundances_golden(ok):
+    """the oracle's counts + gets reproduce the reference's golden abundance lists for a
+    variant window of the minitrio (three FASTQ samples and a reference FASTA counted from scratch)."""
+    from conftest import check_spanning_kmer_abundances
+    check_spanning_kmer_abundances(ok)
