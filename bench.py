@@ -51,6 +51,10 @@ def parse_args():
     p.add_argument('--multi', default='auto', choices=['auto', 'exchange', 'banded'],
                    help='N>1: exchange = shard the reads, hash once, all-to-all the hashes by band (kevlar_amd/shardrun.py); '
                         'banded = every rank hashes all reads and keeps its band; auto = exchange from 4 GPUs up')
+    p.add_argument('--count-streams', type=int, default=1,
+                   help='N=1: count the three samples concurrently on this many HIP streams.  3 is ~4 %% faster (the '
+                        'hashing stage of one sample overlaps the LDS/HBM-bound stages of another) but per-kernel HIP-event '
+                        'durations then include time sharing, so the default keeps the launches back to back')
     p.add_argument('--backend', default='nccl', help='nccl (= RCCL) is what the driver runs; gloo lets two ranks share one GPU in tests')
     return p.parse_args()
 
@@ -141,9 +145,20 @@ def main():
     def step_banded():
         kmers = 0
         t_a = time.perf_counter()
-        for n in names:
-            sketches[n].clear()
-            kmers += sketches[n].consume_batch(batches[n], nbands, band)
+        if world == 1 and args.count_streams > 1:
+            # the samples are independent: their counts run on separate HIP streams (host threads), so the
+            # ALU-bound hashing stage of one overlaps the LDS/HBM-bound stages of another
+            def job(n):
+                def count_one():
+                    sketches[n].clear()
+                    return sketches[n].consume_batch(batches[n], nbands, band)
+                return count_one
+            for lo in range(0, len(names), args.count_streams):
+                kmers += sum(hk.run_concurrently([job(n) for n in names[lo:lo + args.count_streams]]))
+        else:
+            for n in names:
+                sketches[n].clear()
+                kmers += sketches[n].consume_batch(batches[n], nbands, band)
         t_b = time.perf_counter()
         r, o, a, _ = hk.novel_scan(
             [sketches['proband']], [sketches['mother'], sketches['father']], batches['proband'],

@@ -49,6 +49,7 @@ struct BinGeom {
     uint32_t nslices[BIN_MAX_T];
     uint32_t tile_lds;               // bytes of dynamic LDS in front of the stage-A rings
     uint32_t nwgA, nwgB;             // writers per coarse bucket (stage-A workgroups) / per slice (stage-B workgroups of the bucket)
+    uint32_t quotaA;                 // work units (tiles / list chunks) one stage-A workgroup may take: bounds its segments' fill
     uint64_t cap1, cap2, spill_cap;  // items per PRIVATE segment: every writer owns its own region of every stream,
                                      // so appending needs no global atomic (and no round trip) at all
     uint32_t *gbuf1;                 // [T*C][nwgA][cap1] coarse items: (slice-in-bucket << 16) | offset
@@ -206,9 +207,11 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash(
     uint64_t n_added = 0;
     // tiles are handed out dynamically (one global atomic per tile): a workgroup that becomes resident
     // late, or shares its CU with fewer siblings, simply takes fewer -- a static deal is hostage to the
-    // slowest workgroup, which showed as 46 vs 64 ms for the same launch on different boxes
+    // slowest workgroup, which showed as 46 vs 64 ms for the same launch on different boxes.  A quota of
+    // 1.5x the average share keeps early workgroups from swallowing everything when the grid is not fully
+    // resident (GPU shared with another stream or process): that overflowed their segments into the spill list
     __shared__ uint32_t next_tile;
-    for (;;) {
+    for (uint32_t taken = 0; taken < g.quotaA; ++taken) {
         __syncthreads();
         if (threadIdx.x == 0) next_tile = (uint32_t)atomicAdd(&g.ctr[4], 1ull);
         __syncthreads();
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash_
     const uint32_t ns = (uint32_t)(g.T * g.C);
     for (uint32_t s = threadIdx.x; s < ns; s += THREADS) cur[s] = 0;
     uint64_t n_added = 0;
-    for (;;) {
+    for (uint32_t taken = 0; taken < g.quotaA; ++taken) {
         __syncthreads();
         if (threadIdx.x == 0) next_tile = (uint32_t)atomicAdd(&g.ctr[4], 1ull);
         __syncthreads();
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_list(
     };
     const uint64_t chunk = (uint64_t)THREADS * BIN_LIST_ROUNDS;
     __shared__ uint64_t next_chunk;
-    for (;;) {
+    for (uint32_t taken = 0; taken < g.quotaA; ++taken) {
         __syncthreads();
         if (threadIdx.x == 0) next_chunk = (uint64_t)atomicAdd(&g.ctr[4], 1ull);
         __syncthreads();
@@ -801,6 +804,10 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
     const uint32_t threadsA = cmax <= 32 ? 512u : 1024u;
     const uint64_t work_units = reads ? reads->n_tiles : (n_kmers + (uint64_t)threadsA * BIN_LIST_ROUNDS - 1) / ((uint64_t)threadsA * BIN_LIST_ROUNDS);
     g.nwgA = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(work_units, 1), (cmax <= 32 ? 3u : 1u) * (uint32_t)cus);
+    {
+        const uint64_t avg = (work_units + g.nwgA - 1) / g.nwgA;
+        g.quotaA = (uint32_t)std::min<uint64_t>(avg + avg / 2 + 1, 0xffffffffull);   // matches the 1.5x slack of cap1
+    }
     const double per_bucket = expected * std::min(1.0, (double)g.F * 65536.0 / (double)pmin);
     const double per_slice = expected * std::min(1.0, 65536.0 / (double)pmin);
     g.nwgB = (uint32_t)std::max(1.0, std::min((double)std::min<uint32_t>(g.nwgA, 512), std::ceil(per_bucket / 524288.0)));
