@@ -5,13 +5,16 @@
 // (269 GB per 525 M k-mers, profiles/r1_naive) and the device tops out at ~27 G atomics/s.
 // Counting is a histogram, so this file computes it the way large GPU histograms are done:
 //
-//   A  k_bin_hash   hash every k-mer once (same LDS-staged tiles as k_consume), band/mask filter,
+//   A  k_bin_hash_direct  hash every k-mer once (same LDS-staged tiles as k_consume), band/mask filter,
 //                   and for each of the T tables append the bin to one of C coarse buckets
-//                   (bin range = F slices of 65536 bins).  Appends go through per-workgroup LDS
-//                   ring buffers and reach HBM as 64..256-byte coalesced bursts; one global
-//                   atomic claims space per burst.
+//                   (bin range = F slices of 65536 bins).  Every workgroup owns a private segment
+//                   of every bucket; its write cursor lives in LDS and the item is stored straight
+//                   to HBM (L2 merges the partial lines): no global atomic, no barrier.
+//                   (k_bin_hash is the earlier variant that stages items in LDS rings and flushes
+//                   coalesced bursts; k_bin_list takes hashes from a list instead of reads.)
 //   B  k_bin_split  each coarse bucket is split into its F slices; items shrink to the 16-bit
-//                   offset inside the slice.
+//                   offset inside the slice.  The fan-out is too wide for direct stores here, so
+//                   items collect in per-workgroup LDS rings and leave as coalesced bursts.
 //   C  k_bin_apply  one workgroup per (table, slice): the slice's 64 KB of counters is loaded
 //                   into LDS, every item is applied with an LDS compare-and-swap (saturating at
 //                   255 / 15 / 1), and the slice is written back once.  Table 0 also yields the
