@@ -260,6 +260,111 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_emit(ReadsDev rd, Nov
     }
 }
 
+// k_novel_emit without re-staging the tile: the hits of a tile are the set bits of its (contiguous) range
+// of the bit mask, so the workgroup scans those mask words (about 140 for 64 reads of 100 bp), ranks the
+// set bits with a prefix sum and hands one hit to each lane; the lane rebuilds the k-mer and its reverse
+// complement in registers from the packed words and reads the S abundances.  Murmur kinds with k <= 64 (the
+// register windows of KmerRoll); other cases use k_novel_emit.
+template <int NW>
+__global__ __launch_bounds__(256) void k_novel_emit_bits(ReadsDev rd, NovelParams p)
+{
+    __shared__ uint32_t wcnt[256];      // set bits per word of the current chunk, then their exclusive prefix
+    __shared__ uint32_t wbits[256];
+    __shared__ uint32_t wave_tot[4];
+    __shared__ NovelShared ns;
+    const uint32_t nhit_tile = p.tile_count[blockIdx.x];
+    if (nhit_tile == 0) return;
+    load_descs(ns, p);
+    const TileDesc td = rd.tile[blockIdx.x];
+    uint64_t b0, b1;
+    if (td.seg) {
+        b0 = (uint64_t)td.first * p.mask_stride + td.seg_start;
+        b1 = min(b0 + (uint64_t)KV_SEG_BASES, ((uint64_t)td.first + 1) * p.mask_stride);
+    } else {
+        b0 = (uint64_t)td.first * p.mask_stride;
+        b1 = ((uint64_t)td.first + td.count) * p.mask_stride;
+    }
+    const int S = p.ncase + p.nctrl;
+    const int k = p.hp.k;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t out = p.tile_base[blockIdx.x];
+    uint32_t emitted = 0;
+    for (uint64_t w0 = b0 >> 5; w0 < ((b1 + 31) >> 5) && emitted < nhit_tile; w0 += 256) {
+        const uint64_t w = w0 + threadIdx.x;
+        uint32_t bits = 0;
+        if (w < ((b1 + 31) >> 5)) {
+            bits = p.mask[w];
+            const uint64_t wlo = w << 5;
+            if (wlo < b0) bits &= ~0u << (uint32_t)(b0 - wlo);                 // bits of the previous tile
+            if (wlo + 32 > b1) bits &= b1 > wlo ? (~0u >> (uint32_t)(wlo + 32 - b1)) : 0u;   // ... of the next
+        }
+        const uint32_t c = (uint32_t)__popc(bits);
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, chunk_hits = 0;
+        for (int v = 0; v < 4; ++v) {
+            if (v < wave) before += wave_tot[v];
+            chunk_hits += wave_tot[v];
+        }
+        wcnt[threadIdx.x] = before + incl - c;
+        wbits[threadIdx.x] = bits;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < chunk_hits; j += 256) {
+            uint32_t lo = 0, hi = 256;                         // word holding the j-th set bit of the chunk
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (wcnt[mid] <= j) lo = mid; else hi = mid;
+            }
+            uint32_t word = wbits[lo];
+            for (uint32_t skip = j - wcnt[lo]; skip > 0; --skip) word &= word - 1;   // drop the lower set bits
+            const uint64_t bit = ((w0 + lo) << 5) + (uint32_t)(__ffs((int)word) - 1);
+            const uint64_t read = bit / p.mask_stride;
+            const uint32_t off = (uint32_t)(bit - read * p.mask_stride);
+            // the k-mer and its reverse complement as ASCII register windows (byte 0 = first base)
+            uint32_t wf[NW], wr[NW];
+#pragma unroll
+            for (int q = 0; q < NW; ++q) { wf[q] = 0; wr[q] = 0; }
+            const uint32_t *words = rd.words + rd.woff[read];
+            for (int i = 0; i < k; ++i) {
+                const uint32_t pos = off + (uint32_t)i;
+                const uint32_t code = (words[pos >> 4] >> (2 * (pos & 15))) & 3u;
+                const uint32_t fwd = (0x54474341u >> (8 * code)) & 0xffu;      // "ACGT"
+                const uint32_t rev = (0x41434754u >> (8 * code)) & 0xffu;      // "TGCA"
+                const int ri = k - 1 - i;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) {
+                    if (q == (i >> 2)) wf[q] |= fwd << (8 * (i & 3));
+                    if (q == (ri >> 2)) wr[q] |= rev << (8 * (ri & 3));
+                }
+            }
+            const uint64_t h = murmur_regs<NW>(wf, p.hp) ^ murmur_regs<NW>(wr, p.hp);
+            const uint64_t slot = out + j;
+            p.hit_read[slot] = (uint32_t)read;
+            p.hit_off[slot] = off;
+            // a sample's T probes are independent loads (descriptors come from LDS): issued together, then reduced
+            for (int c2 = 0; c2 < S; ++c2) {
+                const int T = ns.ntab[c2];
+                uint32_t v[KV_MAX_TABLES];
+#pragma unroll
+                for (int t = 0; t < KV_MAX_TABLES; ++t) v[t] = t < T ? probe(ns, c2, t, h) : 255u;
+                uint32_t best = 255u;
+#pragma unroll
+                for (int t = 0; t < KV_MAX_TABLES; ++t) best = v[t] < best ? v[t] : best;
+                p.hit_abund[slot * (uint64_t)S + c2] = (uint8_t)best;
+            }
+        }
+        out += chunk_hits;
+        emitted += chunk_hits;
+        __syncthreads();
+    }
+}
+
 // verdict cache kept across the batches of one scan: valid as long as the same sketches (unmodified),
 // thresholds and band settings are used; otherwise it is cleared
 struct VerdictCache {
@@ -429,8 +534,15 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         p.hit_abund = (uint8_t *)arenas->hits.p + 2 * up256(nhits * 4);
         if (e == hipSuccess) {
             KvProfScope prof("k_novel_emit");
-            kv_ensure_dynamic_lds((const void *)k_novel_emit, reads->tile_lds_bytes);
-            hipLaunchKernelGGL(k_novel_emit, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, st, reads_dev(reads), p);
+            const bool from_bits = fam == HF_MURMUR && k <= 64 && !getenv("KV_NOVEL_EMIT_TILES");
+            if (from_bits && k <= 32) {
+                hipLaunchKernelGGL(k_novel_emit_bits<8>, dim3(reads->n_tiles), dim3(256), 0, st, reads_dev(reads), p);
+            } else if (from_bits) {
+                hipLaunchKernelGGL(k_novel_emit_bits<16>, dim3(reads->n_tiles), dim3(256), 0, st, reads_dev(reads), p);
+            } else {
+                kv_ensure_dynamic_lds((const void *)k_novel_emit, reads->tile_lds_bytes);
+                hipLaunchKernelGGL(k_novel_emit, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, st, reads_dev(reads), p);
+            }
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hits->read.resize(nhits);
