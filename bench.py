@@ -73,7 +73,6 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node {}'.format(args.gpus))
-    import numpy as np
     import torch
     import torch.distributed as dist
 

@@ -13,7 +13,8 @@ torch is plumbing: it owns the exchange buffers and moves them; all arithmetic i
 library.  With the gloo backend (CPU tests, or several ranks sharing one GPU) the buffers are
 staged through host memory.
 """
-import numpy as np
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -133,7 +134,6 @@ class ShardedTrio(object):
     def start(self, batch, read_index_base, with_tags):
         """Hash this rank's shard of a sample and start delivering every hash to its band's owner.
         Returns a handle for finish(); the next sample's start() may run while the exchange flies."""
-        import time
         words = 2 if with_tags else 1
         cap = max(batch.num_kmers(self.ksize), 1)       # worst case: every k-mer of the shard in one band
         send = self._send_buffer(cap, words)
@@ -150,7 +150,6 @@ class ShardedTrio(object):
         """Wait for the exchange and count the received hashes into `sketch` (= band `rank`).
         keep_for_scan: this is a case sample -- keep its (hash, tag) pairs for scan().  Returns the
         number of k-mers counted on this rank."""
-        import time
         t0 = time.perf_counter()
         recv = ex.wait()
         t1 = time.perf_counter()
@@ -171,7 +170,6 @@ class ShardedTrio(object):
     def scan(self, cases, controls, case_min, ctrl_max):
         """kmer_is_interesting() over the case k-mers this rank owns, then gather: every rank returns
         the complete (read, offset, abund[n, S]) hit arrays in (read, offset) order."""
-        import time
         assert self.case_items is not None, 'count_sample(..., keep_for_scan=True) first'
         S = len(cases) + len(controls)
         items = self.case_items

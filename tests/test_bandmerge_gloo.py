@@ -8,7 +8,6 @@ import os
 import sys
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

@@ -10,7 +10,6 @@ checked through properties that do not depend on size:
   mask and its hit list agree, and a seeded sample of hits re-derives bit-exactly from the oracle
   evaluated on the same table bytes.
 """
-import ctypes
 import os
 
 import numpy as np

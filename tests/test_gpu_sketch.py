@@ -1,6 +1,5 @@
 """Parity of the HIP sketch engine with the CPU oracle and the reference's golden files.
 Everything here goes through the C ABI (kevlar_amd.khmer -> libkvsketch_hip.so)."""
-import io
 import json
 import os
 

@@ -4,7 +4,6 @@ matches the reference's own expectations.  No kernel is launched here."""
 import io
 import os
 import re
-import sys
 
 import numpy as np
 import pytest
