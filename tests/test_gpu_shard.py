@@ -27,21 +27,23 @@ def make_reads(n, seed, with_n=True):
     return reads
 
 
-@pytest.mark.parametrize('ndest,with_tags', [(1, False), (4, False), (3, True), (8, True)])
-def test_route_matches_oracle_hashes(hk, ok, ndest, with_tags):
+@pytest.mark.parametrize('ndest,with_tags,kind,k', [(1, False, 'Counttable', 31), (4, False, 'Counttable', 31),
+                                                     (3, True, 'Counttable', 31), (8, True, 'Counttable', 31),
+                                                     (5, True, 'Countgraph', 25), (2, True, 'Nodetable', 51),
+                                                     (3, False, 'Counttable', 80)])
+def test_route_matches_oracle_hashes(hk, ok, ndest, with_tags, kind, k):
     import torch
-    k = 31
     reads = make_reads(3000, 3)
     batch = hk.ReadBatch(reads)
     nk = batch.num_kmers(k)
     words = 2 if with_tags else 1
     send = torch.zeros((ndest, nk, words), dtype=torch.int64, device='cuda')
     base = 1000
-    counts = hk.route_hashes(batch, hk.Counttable, k, ndest, base, with_tags, send.data_ptr(), nk)
+    counts = hk.route_hashes(batch, getattr(hk, kind), k, ndest, base, with_tags, send.data_ptr(), nk)
     assert sum(counts) == nk
     host = send.cpu().numpy().view(np.uint64)
     bs = (2 ** 64 - 1) // ndest
-    ct = ok.Counttable(k, 1000, 1)
+    ct = getattr(ok, kind)(k, 1000, 1)
     expect = {}          # (read, offset) -> hash, over what the device counts (N is packed as a stand-in base)
     for r, seq in enumerate(reads):
         if len(seq) < k:
