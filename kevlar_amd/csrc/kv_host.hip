@@ -658,7 +658,7 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
     char *d_ascii = nullptr;
     uint64_t *d_offs = nullptr;
     hipStream_t st = kv_stream();
-    hipError_t e = hipMalloc((void **)&r->d_words, (nw ? nw : 1) * 4);
+    hipError_t e = hipMalloc((void **)&r->d_words, (nw + 4) * 4);   // + slack: k-mer extraction reads up to two words ahead
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, flag_bytes);
@@ -713,7 +713,7 @@ extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, u
     r->n_tiles = (uint32_t)tiles.size();
     if (tiles.empty()) tiles.push_back(TileDesc{0u, 0u, 0u, 0u});
     r->tile_lds_bytes = KV_TILE_LDS_BYTES + 256;
-    hipError_t e = hipMalloc((void **)&r->d_words, (r->n_words ? r->n_words : 1) * 4);
+    hipError_t e = hipMalloc((void **)&r->d_words, (r->n_words + 4) * 4);   // + slack: k-mer extraction reads up to two words ahead
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, n_reads ? n_reads : 1);

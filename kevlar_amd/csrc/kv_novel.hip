@@ -34,6 +34,9 @@ struct NovelParams {
     uint8_t *hit_abund;
     unsigned long long *vcache;   // hashes proven rejected by a control (NULL = off)
     int vcache_shift;             // slot = h >> shift
+    int vcache_sets;              // k_novel_mark: 8-entry sets indexed by the k-mer's minimizer (0 = direct-mapped by hash)
+    uint32_t vcache_set_mask;     // number of sets - 1
+    int vcache_window;            // m-mers per k-mer considered for the minimizer
 };
 
 __device__ __forceinline__ bool band_pass(const NovelParams &p, uint64_t h)
@@ -75,6 +78,44 @@ __device__ __forceinline__ uint32_t probe(const NovelShared &ns, int c, int t, u
     if (st == ST_BYTE) return d.tab[bin];
     if (st == ST_NIBBLE) return (d.tab[bin >> 1] >> ((bin & 1) ? 0 : 4)) & 15u;
     return (d.tab[bin >> 3] >> (bin & 7)) & 1u;
+}
+
+// Set index of the verdict cache for k_novel_mark (16 <= k <= 32): a hash of the k-mer's minimizer -- the
+// smallest canonical (k-2)-mer among its three.  It is a pure function of the k-mer and strand-symmetric like
+// the k-mer hash itself, and neighbouring k-mers of a read share it every other time, so the 64 lanes of a
+// wave, which hold 64 consecutive k-mers, ask for ~32 distinct 64-byte sets instead of 64 distinct sectors,
+// and an 8-way set loses far fewer entries to conflicts than a direct-mapped slot.  Which set a hash is stored in only affects the hit rate: an entry anywhere in the cache is a hash
+// proven rejected, so a match is always right.
+#define VC_WINDOW 3   // measured at config 2: 3 -> 15.1 ms, 4 -> 15.2, 5 -> 16.1, 7 -> 16.9, 2 -> 15.6, 1 -> 18.1 (direct-mapped: 21.1)
+#define VC_WINDOW_MAX 9
+__device__ __forceinline__ uint32_t kmer_minimizer_key(const uint32_t *__restrict__ words, uint32_t pos, int k, int window)
+{
+    // the k-mer's 2 bits/base, base j at bits 2j (codes A0 C1 G2 T3 as packed by k_pack_reads)
+    const uint32_t w0 = pos >> 4, sh = 2u * (pos & 15u);
+    const uint64_t lo = (uint64_t)words[w0] | ((uint64_t)words[w0 + 1] << 32);
+    uint64_t code = lo >> sh;
+    if (sh) code |= (uint64_t)words[w0 + 2] << (64u - sh);
+    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    code &= kmask;
+    // reverse complement in the same layout: reverse the 2-bit groups, complement (3 - code)
+    uint64_t rev = __brevll(code);
+    rev = ((rev >> 1) & 0x5555555555555555ull) | ((rev & 0x5555555555555555ull) << 1);
+    rev = (~rev >> (64 - 2 * k)) & kmask;
+    const int m = k - (window - 1);
+    const uint64_t mmask = (1ull << (2 * m)) - 1ull;
+    uint32_t best = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < VC_WINDOW_MAX; ++j) {
+        if (j >= window) break;
+        const uint64_t f = (code >> (2 * j)) & mmask;
+        const uint64_t r = (rev >> (2 * (window - 1 - j))) & mmask;         // reverse complement of the same m-mer
+        const uint64_t c = f < r ? f : r;
+        uint32_t v = (uint32_t)c ^ (uint32_t)(c >> 27);
+        v *= 0x9E3779B1u;
+        v ^= v >> 15;
+        best = v < best ? v : best;
+    }
+    return best;
 }
 
 // The abundance test (screen off).  Same predicate as kmer_is_interesting(), cheapest evidence first:
@@ -159,8 +200,28 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_mark(ReadsDev rd, Nov
         c.h = kmer_hash_lds(sh.ascii, fwd, rc, p.hp);
         c.live = band_pass(p, c.h);
         if (c.live && p.vcache && p.screen == 0) {
-            c.slot = p.vcache + (c.h >> p.vcache_shift);
-            c.cached = __hip_atomic_load(c.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.vcache_sets) {
+                const uint32_t gread = read0 + c.r;
+                const uint32_t key = kmer_minimizer_key(rd.words + rd.woff[gread], sh.seg_start + c.i, p.hp.k, p.vcache_window);
+                const unsigned long long *set = p.vcache + ((uint64_t)(key & p.vcache_set_mask) << 3);
+                // plain loads: a stale line can only hide an entry (a miss), never invent one
+                const ulonglong2 e0 = ((const ulonglong2 *)set)[0], e1 = ((const ulonglong2 *)set)[1];
+                const ulonglong2 e2 = ((const ulonglong2 *)set)[2], e3 = ((const ulonglong2 *)set)[3];
+                const unsigned long long e[8] = {e0.x, e0.y, e1.x, e1.y, e2.x, e2.y, e3.x, e3.y};
+                bool hit = false;
+                uint32_t way = (uint32_t)(c.h >> 7) & 7u, empty = 8;
+#pragma unroll
+                for (int w = 7; w >= 0; --w) {
+                    hit |= e[w] == c.h;
+                    if (e[w] == 0) empty = (uint32_t)w;
+                }
+                if (e[way] != 0 && empty < 8) way = empty;      // own way taken: first free one, else overwrite own way
+                c.slot = const_cast<unsigned long long *>(set) + way;
+                c.cached = hit ? c.h : ~c.h;
+            } else {
+                c.slot = p.vcache + (c.h >> p.vcache_shift);
+                c.cached = __hip_atomic_load(c.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         return c;
     };
@@ -402,6 +463,12 @@ std::map<hipStream_t, ScanArenas> g_scan_arenas;
 std::mutex g_scan_arenas_mu;
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+inline int vc_sets_env()
+{
+    const char *e = getenv("KV_NOVEL_VCSETS");   // 0: direct-mapped cache in k_novel_mark as well
+    return e ? atoi(e) : -1;
+}
+
 // point p.vcache at this stream's verdict cache, (re)allocating or clearing it as the signature requires
 int attach_vcache(NovelParams &p, kv_sketch *const *ctrls, int ncase, int nctrl, int ctrl_max, uint64_t n_kmers, hipStream_t st)
 {
@@ -476,6 +543,11 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     uint64_t n_kmers = 0;
     kv_reads_num_kmers(reads, k, &n_kmers);
     { const int rc = attach_vcache(p, ctrls, ncase, nctrl, ctrl_max, n_kmers, st); if (rc != KV_OK) return rc; }
+    if (p.vcache && k >= 16 && k <= 32 && !(vc_sets_env() == 0)) {
+        p.vcache_sets = 1;
+        p.vcache_window = VC_WINDOW;
+        p.vcache_set_mask = (uint32_t)((1ull << (64 - p.vcache_shift - 3)) - 1ull);   // entries / 8 sets
+    }
 
     kv_hits *hits = new kv_hits();
     hits->nsamples = S;
