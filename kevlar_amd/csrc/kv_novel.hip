@@ -726,8 +726,22 @@ __global__ __launch_bounds__(256) void k_novel_list(NovelParams p, const uint64_
         c.h = v.x; c.tag = v.y;
         c.live = (c.tag >> 63) == 0;
         if (c.live && p.vcache) {
-            c.slot = p.vcache + (c.h >> p.vcache_shift);
-            c.cached = __hip_atomic_load(c.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // no sequence here, so no minimizer: the set comes from the hash itself; 8 ways still lose
+            // fewer entries to conflicts than a direct-mapped slot
+            const unsigned long long *set = p.vcache + ((c.h >> (p.vcache_shift + 3)) << 3);
+            const ulonglong2 e0 = ((const ulonglong2 *)set)[0], e1 = ((const ulonglong2 *)set)[1];
+            const ulonglong2 e2 = ((const ulonglong2 *)set)[2], e3 = ((const ulonglong2 *)set)[3];
+            const unsigned long long e[8] = {e0.x, e0.y, e1.x, e1.y, e2.x, e2.y, e3.x, e3.y};
+            bool hit = false;
+            uint32_t way = (uint32_t)(c.h >> 7) & 7u, empty = 8;
+#pragma unroll
+            for (int w = 7; w >= 0; --w) {
+                hit |= e[w] == c.h;
+                if (e[w] == 0) empty = (uint32_t)w;
+            }
+            if (e[way] != 0 && empty < 8) way = empty;
+            c.slot = const_cast<unsigned long long *>(set) + way;
+            c.cached = hit ? c.h : ~c.h;
         }
         return c;
     };
