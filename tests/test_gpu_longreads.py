@@ -100,3 +100,29 @@ def test_dist_and_exact_distinct_on_long_sequences(hk, ok):
         b = seq.encode()
         ok.lib.kvo_abundance_distribution(ref._h, rtrack._h, b, len(b), hist)
     assert got == list(hist)
+
+
+@pytest.mark.parametrize('k', [15, 16, 17, 24, 31, 32, 33])
+def test_novel_scan_cache_forms_agree_with_oracle(hk, ok, k):
+    """the verdict cache is direct-mapped for k < 16 or k > 32 and minimizer-indexed sets in between
+    (bit tricks at the k = 32 edge); cold and warm cache, reads on both strands, an ambiguous read"""
+    from kevlar_amd import synth
+    trio = synth.make_trio(80000, 5)
+    names = ('proband', 'mother', 'father')
+    reads = {n: synth.unpack_reads(synth.sample_reads_packed(trio[n], 14000, 100, 0.005, 11 + i), 100)
+             for i, n in enumerate(names)}
+    reads['proband'][7] = reads['proband'][7][:33] + 'N' + reads['proband'][7][34:]
+    dev = {n: hk.Counttable(k, 1.2e6, 4) for n in names}
+    ref = {n: ok.Counttable(k, 1.2e6, 4) for n in names}
+    for n in names:
+        dev[n].consume_batch(hk.ReadBatch(reads[n]))
+        bases, offs = ok.concat_reads(reads[n])
+        ok.consume_reads(ref[n], bases, offs, len(reads[n]))
+    bases, offs = ok.concat_reads(reads['proband'])
+    hits, _ = ok.novel_scan([ref['proband']], [ref['mother'], ref['father']], bases, offs, len(reads['proband']), k, 5, 1)
+    assert len(hits) > 20
+    batch = hk.ReadBatch(reads['proband'])
+    for attempt in range(2):          # second pass: every inherited k-mer answers from the cache
+        r, o, a, _ = hk.novel_scan([dev['proband']], [dev['mother'], dev['father']], batch, 5, 1)
+        got = [(int(r[i]), int(o[i]), tuple(int(x) for x in a[i])) for i in range(len(r))]
+        assert got == hits
