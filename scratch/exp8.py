@@ -14,9 +14,7 @@ def prof_all():
         ms, c = ctypes.c_double(), ctypes.c_uint64(); lib.kv_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(c)); out[name] = round(ms.value / max(1, c.value), 2)
     return out
 ref = None
-for mode, dbg in (('x', ''), ('x', '1'), ('x', ''), ('x', '1')):
-    if dbg: os.environ['KV_BIN_WG4'] = dbg
-    else: os.environ.pop('KV_BIN_WG4', None)
+for mode, dbg in (('x', ''), ('x', '')):
     sk = hk.Counttable(k, 5e8, 4)
     sk.consume_batch(b); sk.clear()
     lib.kv_prof_reset(); lib.kv_prof_enable(1)
