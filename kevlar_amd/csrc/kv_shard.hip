@@ -3,17 +3,17 @@
 // kevlar shards a trio by k-mer hash band (docs/banding.rst; kevlar/count.py:62-66): band b owns
 // the hash range [b*bs, (b+1)*bs).  Run the reference way, every band's process still parses and
 // hashes EVERY read, and so does the one-band-per-GPU layout of bench.py's "banded" mode: measured,
-// hashing is ~2/3 of a banded rank's time and eight GPUs give 2.5x.  With the GPUs of one node on
+// hashing is ~2/3 of a banded rank's time and eight GPUs give 2x.  With the GPUs of one node on
 // xGMI the reads can be sharded instead: each rank hashes 1/N of every sample exactly once and
 // sends each hash to the rank that owns its band (one all-to-all, 8 B per k-mer, 16 B for the case
 // sample whose hits need their (read, offset) back).  The owner counts what it receives with the
 // same partitioned kernels (kv_consume_hashes) and scans the case hashes it received
 // (kv_novel_scan_hashes); sketches, bands and results are exactly those of the banded run.
 //
-//   k_route_hashes  LDS-staged tiles and rolling murmur windows as in k_bin_hash; the destination of
-//                   a hash is its band; items collect in one LDS ring per destination and leave as
-//                   >= 1 KB bursts into that destination's contiguous send buffer (one global atomic
-//                   per burst claims the space).
+//   k_route_hashes  LDS-staged tiles and rolling murmur windows as in k_bin_hash_direct; the destination
+//                   of a hash is its band; every workgroup appends to a private segment per destination
+//                   through an LDS cursor (direct stores, no barrier), and k_route_scan / k_route_compact /
+//                   k_route_tail pack the segments into that destination's contiguous send buffer.
 //   kv_hits_from_tagged  radix sort (rocPRIM) of the gathered (tag, abundances) hits back into the
 //                   (read, offset) order of the reference's output.
 #include <cmath>
