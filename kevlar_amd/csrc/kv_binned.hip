@@ -80,6 +80,8 @@ struct Rings {
     ItemT *ring;
     uint32_t *cnt, *base;
     uint32_t R;
+    uint32_t skew;      // item p of stream s sits in slot (p + skew * s) & (R - 1): streams fill in step, so unskewed
+                        // slots would share LDS banks; stage B uses 8 so that 8-item vectors stay aligned
 };
 
 template <typename ItemT>
@@ -87,7 +89,7 @@ __device__ __forceinline__ bool ring_append(const Rings<ItemT> &rs, uint32_t s, 
 {
     const uint32_t pos = atomicAdd(&rs.cnt[s], 1u);
     if (pos - rs.base[s] >= rs.R) return false;
-    rs.ring[s * rs.R + ((pos + s) & (rs.R - 1))] = item;   // + s: streams fill in step, so unskewed slots would share LDS banks
+    rs.ring[s * rs.R + ((pos + rs.skew * s) & (rs.R - 1))] = item;
     return true;
 }
 
@@ -111,7 +113,7 @@ __device__ __forceinline__ void rings_flush(const Rings<ItemT> &rs, uint32_t ns,
         uint32_t newbase = base;
         if (avail > rs.R) { n = rs.R; newbase = base + avail; }   // overran: the excess was diverted at append time
         else if (final) { n = avail; newbase = base + n; }
-        else if (avail >= rs.R / 2) { n = avail & ~15u; newbase = base + n; }
+        else if (avail >= rs.R / 2) { n = avail & ~31u; newbase = base + n; }   // whole half-wave bursts: one copy iteration, all lanes busy
         if (n) { pos = written; written += n; rs.base[s] = newbase; }
     }
     const uint32_t seg_lo = (uint32_t)seg_base, seg_hi = (uint32_t)(seg_base >> 32);
@@ -134,10 +136,49 @@ __device__ __forceinline__ void rings_flush(const Rings<ItemT> &rs, uint32_t ns,
         const uint32_t nl = upper ? n1 : n0, bl = upper ? b1 : b0, pl = upper ? p1 : p0;
         const uint64_t gl = ((uint64_t)(upper ? g1h : g0h) << 32) | (upper ? g1l : g0l);
         for (uint32_t j = sub; j < nl; j += 32) {
-            const ItemT item = rs.ring[sl * rs.R + ((bl + j + sl) & (rs.R - 1))];
+            const ItemT item = rs.ring[sl * rs.R + ((bl + j + rs.skew * sl) & (rs.R - 1))];
             if (pl + j < cap) store(gl + pl + j, item);
             else overflow(sl, item);
         }
+    }
+}
+
+// Stage B's flush between rounds: the flush phase of rings_flush is instruction-bound (PMC: ~600 VALU
+// wave-instructions per wave and round, 4/5 of them broadcasting per-burst parameters and looping), so here
+// every lane that owns a ready stream copies its own burst: 32 (or R) u16 items as 16-byte vectors, LDS read ->
+// global store, all streams of the wave in parallel.  Bursts are multiples of 32 items and the ring skew is 8,
+// so vectors stay 16-byte aligned in LDS and 64-byte aligned in the segment.  The rare misfits (segment nearly
+// full, ring overrun that left the base unaligned) are left to rings_flush.
+template <typename Overflow>
+__device__ __forceinline__ void rings_flush_lanes16(const Rings<uint16_t> &rs, uint32_t ns, uint32_t &written, uint64_t seg_base,
+                                                    uint32_t cap, uint16_t *gbuf, Overflow overflow)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const uint32_t per_wave = (ns + nwaves - 1) / nwaves;
+    const uint32_t s0 = wave * per_wave, s_end = min(ns, s0 + per_wave);
+    const uint32_t s = s0 + lane;
+    bool misfit = false;
+    if (s < s_end) {
+        const uint32_t base = rs.base[s];
+        const uint32_t avail = rs.cnt[s] - base;
+        uint32_t n = 0, newbase = base;
+        if (avail > rs.R) { n = rs.R; newbase = base + avail; }
+        else if (avail >= rs.R / 2) { n = avail & ~31u; newbase = base + n; }
+        if (n) {
+            if ((base & 7u) || written + n > cap || (newbase & 7u)) misfit = true;
+            else {
+                const uint16_t *ring = rs.ring + s * rs.R;
+                uint16_t *dst = gbuf + seg_base + written;
+                for (uint32_t v = 0; v < n; v += 8)
+                    *(uint4 *)(dst + v) = *(const uint4 *)(ring + ((base + v + rs.skew * s) & (rs.R - 1)));
+                written += n;
+                rs.base[s] = newbase;
+            }
+        }
+    }
+    if (__ballot(misfit)) {
+        auto store = [&](uint64_t idx, uint16_t off) { gbuf[idx] = off; };
+        rings_flush(rs, ns, false, written, seg_base, cap, store, overflow);
     }
 }
 
@@ -172,7 +213,7 @@ __device__ __forceinline__ uint32_t bin_push(const Rings<uint32_t> &rs, const Bi
     for (int t = 0; t < BIN_MAX_T; ++t) {
         if (t >= g.T) break;
         const uint32_t s_ = sidx[t];
-        if (pos[t] - rs.base[s_] < rs.R) rs.ring[s_ * rs.R + ((pos[t] + s_) & (rs.R - 1))] = item[t];
+        if (pos[t] - rs.base[s_] < rs.R) rs.ring[s_ * rs.R + ((pos[t] + rs.skew * s_) & (rs.R - 1))] = item[t];
         else spill_item(g, t, bins[t]);
     }
     return 0u;
@@ -190,6 +231,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash(
     const uint32_t ns = (uint32_t)(g.T * g.C);
     Rings<uint32_t> rs;
     rs.R = g.ringA;
+    rs.skew = 1;
     rs.ring = (uint32_t *)(smem + g.tile_lds);
     rs.cnt = rs.ring + (size_t)ns * rs.R;
     rs.base = rs.cnt + ns;
@@ -354,6 +396,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_list(
     const uint32_t ns = (uint32_t)(g.T * g.C);
     Rings<uint32_t> rs;
     rs.R = g.ringA;
+    rs.skew = 1;
     rs.ring = (uint32_t *)smem;
     rs.cnt = rs.ring + (size_t)ns * rs.R;
     rs.base = rs.cnt + ns;
@@ -405,6 +448,7 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
     const uint32_t F = (uint32_t)g.F;
     Rings<uint16_t> rs;
     rs.R = g.ringB;
+    rs.skew = 8;
     rs.ring = (uint16_t *)smem;
     rs.cnt = (uint32_t *)(smem + (((size_t)F * rs.R * 2 + 15) & ~(size_t)15));
     rs.base = rs.cnt + F;
@@ -455,7 +499,7 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
 #pragma unroll
                 for (int j = 0; j < BIN_B_ITEMS; ++j) {
                     const uint32_t fi = items[j] >> 16;
-                    if (pos[j] - rbase[j] < rs.R) rs.ring[fi * rs.R + ((pos[j] + fi) & (rs.R - 1))] = (uint16_t)(items[j] & 0xffffu);
+                    if (pos[j] - rbase[j] < rs.R) rs.ring[fi * rs.R + ((pos[j] + rs.skew * fi) & (rs.R - 1))] = (uint16_t)(items[j] & 0xffffu);
                     else full |= 1u << j;
                 }
                 if (full) {
@@ -470,7 +514,7 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
                 }
             }
             __syncthreads();
-            rings_flush(rs, F, false, written, seg_base, (uint32_t)g.cap2, store, overflow);
+            rings_flush_lanes16(rs, F, written, seg_base, (uint32_t)g.cap2, g.gbuf2, overflow);
             __syncthreads();
         }
     }
