@@ -577,21 +577,26 @@ __device__ __forceinline__ uint32_t lds_inc8(uint32_t *lds, const uint32_t (&w)[
         if (STORAGE == ST_BYTE) { widx[e] = off >> 2; shift = (off & 3u) << 3; }
         else { widx[e] = off >> 3; shift = (((off >> 1) & 3u) << 3) + ((off & 1u) ? 0u : 4u); }
         inc[e] = 1u << shift;
-        old[e] = lds[widx[e]];                           // absent items (e >= n) read a harmless word
     }
-    bool live[8];
+    // two groups of four: the window between reading a word and swapping it stays short (fewer lost races)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        // a saturated counter (field == inc * maxv) can only stay saturated; it and absent items issue a
-        // compare-and-swap that writes back what it compared against: branch-free, and a no-op either way
-        live[e] = (uint32_t)e < n && (old[e] & (inc[e] * maxv)) != inc[e] * maxv;
-        prev[e] = atomicCAS(&lds[widx[e]], old[e], old[e] + (live[e] ? inc[e] : 0u));
-    }
+    for (int g4 = 0; g4 < 8; g4 += 4) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const bool won = prev[e] == old[e];
-        fresh += (live[e] && won && (old[e] & (inc[e] * maxv)) == 0) ? 1u : 0u;
-        retry |= (live[e] && !won) ? (1u << e) : 0u;
+        for (int e = g4; e < g4 + 4; ++e) old[e] = lds[widx[e]];          // absent items (e >= n) read a harmless word
+        bool live[4];
+#pragma unroll
+        for (int e = g4; e < g4 + 4; ++e) {
+            // a saturated counter (field == inc * maxv) can only stay saturated; it and absent items issue a
+            // compare-and-swap that writes back what it compared against: branch-free, and a no-op either way
+            live[e - g4] = (uint32_t)e < n && (old[e] & (inc[e] * maxv)) != inc[e] * maxv;
+            prev[e] = atomicCAS(&lds[widx[e]], old[e], old[e] + (live[e - g4] ? inc[e] : 0u));
+        }
+#pragma unroll
+        for (int e = g4; e < g4 + 4; ++e) {
+            const bool won = prev[e] == old[e];
+            fresh += (live[e - g4] && won && (old[e] & (inc[e] * maxv)) == 0) ? 1u : 0u;
+            retry |= (live[e - g4] && !won) ? (1u << e) : 0u;
+        }
     }
     if (retry) {
 #pragma unroll
