@@ -253,7 +253,9 @@ def main():
         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
         'avg_launch_ms': round(avg_ms, 4), 'stage_ms_per_sample': round(stage_ms, 4), 'launches': int(launches),
         'algorithmic_bytes_per_launch': int(alg[dominant]),
-        'note': 'achieved = algorithmic bytes of one sample / summed duration of all kernels of that stage',
+        'note': 'achieved = algorithmic bytes of one sample / summed duration of all kernels of that stage; the dominant '
+                'kernel hashes (two murmur3 per k-mer) and is VALU-issue-bound per the SQ counters (DESIGN.md 4.1), '
+                'so the HBM roofline is an upper bound it cannot approach',
         'kernels_ms_per_step': {name: round(times[name][0] / args.steps, 4) for name in sorted(times)},
         'host_wall_ms_per_step': {key: round(val / args.steps * 1e3, 3) for key, val in wall.items()},
     }
