@@ -392,30 +392,12 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_list(
     const uint64_t *__restrict__ list, uint64_t n, uint32_t stride, const SketchDev *__restrict__ sk, BinGeom g)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t ns = (uint32_t)(g.T * g.C);
-    Rings<uint32_t> rs;
-    rs.R = g.ringA;
-    rs.skew = 1;
-    rs.ring = (uint32_t *)smem;
-    rs.cnt = rs.ring + (size_t)ns * rs.R;
-    rs.base = rs.cnt + ns;
-    for (uint32_t s = threadIdx.x; s < ns; s += THREADS) { rs.cnt[s] = 0; rs.base[s] = 0; }
-    __syncthreads();
-    uint32_t written = 0;
-    uint64_t seg_base = 0;
-    {
-        const uint32_t nwaves = THREADS >> 6, per_wave = (ns + nwaves - 1) / nwaves;
-        const uint32_t mine = (threadIdx.x >> 6) * per_wave + (threadIdx.x & 63);
-        if ((threadIdx.x & 63) < per_wave && mine < ns) seg_base = ((uint64_t)mine * g.nwgA + blockIdx.x) * g.cap1;
-    }
-    auto store = [&](uint64_t idx, uint32_t item) { g.gbuf1[idx] = item; };
-    auto overflow = [&](uint32_t s, uint32_t item) {
-        const uint32_t t = s / (uint32_t)g.C, c = s % (uint32_t)g.C;
-        spill_item(g, (int)t, (((uint64_t)c * g.F + (item >> 16)) << 16) | (item & 0xffffu));
-    };
-    const uint64_t chunk = (uint64_t)THREADS * BIN_LIST_ROUNDS;
+    // same direct stores through LDS cursors as k_bin_hash_direct; the hashes just come from HBM
+    __shared__ uint32_t cur[BIN_MAX_T * BIN_C];
     __shared__ uint64_t next_chunk;
+    const uint32_t ns = (uint32_t)(g.T * g.C);
+    for (uint32_t s = threadIdx.x; s < ns; s += THREADS) cur[s] = 0;
+    const uint64_t chunk = (uint64_t)THREADS * BIN_LIST_ROUNDS;
     for (uint32_t taken = 0; taken < g.quotaA; ++taken) {
         __syncthreads();
         if (threadIdx.x == 0) next_chunk = (uint64_t)atomicAdd(&g.ctr[4], 1ull);
@@ -428,15 +410,34 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_list(
             const uint64_t h = h_next;
             const bool live = idx < n;
             idx += THREADS;
-            if (round + 1 < BIN_LIST_ROUNDS && idx < n) h_next = list[idx * stride];   // flies during this round
-            if (live) (void)bin_push(rs, g, sk, h);
-            __syncthreads();
-            rings_flush(rs, ns, false, written, seg_base, (uint32_t)g.cap1, store, overflow);
-            __syncthreads();
+            if (round + 1 < BIN_LIST_ROUNDS && idx < n) h_next = list[idx * stride];   // flies while this one is routed
+            if (!live) continue;
+            uint32_t sidx[BIN_MAX_T], item[BIN_MAX_T], pos[BIN_MAX_T];
+            uint64_t bins[BIN_MAX_T];
+#pragma unroll
+            for (int t = 0; t < BIN_MAX_T; ++t) {
+                if (t >= g.T) break;
+                const uint64_t bin = fastmod(h, sk->size[t], sk->magic[t]);
+                const uint32_t slice = (uint32_t)(bin >> 16);
+                const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
+                bins[t] = bin;
+                item[t] = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu);
+                sidx[t] = (uint32_t)t * (uint32_t)g.C + c;
+            }
+#pragma unroll
+            for (int t = 0; t < BIN_MAX_T; ++t)
+                if (t < g.T) pos[t] = atomicAdd(&cur[sidx[t]], 1u);
+#pragma unroll
+            for (int t = 0; t < BIN_MAX_T; ++t) {
+                if (t >= g.T) break;
+                if (pos[t] < g.cap1) g.gbuf1[((uint64_t)sidx[t] * g.nwgA + blockIdx.x) * g.cap1 + pos[t]] = item[t];
+                else spill_item(g, t, bins[t]);
+            }
         }
     }
-    rings_flush(rs, ns, true, written, seg_base, (uint32_t)g.cap1, store, overflow);
-    rings_store_counts(ns, written, (uint32_t)g.cap1, g.gcnt1, g.nwgA, blockIdx.x);
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < ns; s += THREADS)
+        g.gcnt1[(uint64_t)s * g.nwgA + blockIdx.x] = (uint32_t)min((uint64_t)cur[s], g.cap1);
 }
 
 // ---- stage B -----------------------------------------------------------------------------
@@ -923,16 +924,12 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
 #undef KV_LAUNCH_BIN_HASH
     } else {
         KvProfScope prof("k_bin_list");
-        const size_t lds = ns * g.ringA * 4 + ns * 8;
-        if (cmax <= 32) {
-            ensure_dynamic_lds(k_bin_list<512>, lds);
-            hipLaunchKernelGGL((k_bin_list<512>), dim3(g.nwgA), dim3(512), lds, st, d_list, n_kmers, list_stride,
+        if (cmax <= 32)
+            hipLaunchKernelGGL((k_bin_list<512>), dim3(g.nwgA), dim3(512), 0, st, d_list, n_kmers, list_stride,
                                (const SketchDev *)s->d_desc, g);
-        } else {
-            ensure_dynamic_lds(k_bin_list<1024>, lds);
-            hipLaunchKernelGGL((k_bin_list<1024>), dim3(g.nwgA), dim3(1024), lds, st, d_list, n_kmers, list_stride,
+        else
+            hipLaunchKernelGGL((k_bin_list<1024>), dim3(g.nwgA), dim3(1024), 0, st, d_list, n_kmers, list_stride,
                                (const SketchDev *)s->d_desc, g);
-        }
     }
     {
         KvProfScope prof("k_bin_split");
