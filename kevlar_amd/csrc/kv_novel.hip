@@ -562,6 +562,15 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     std::lock_guard<std::mutex> arena_lock(arenas->mu);
     hipError_t e = hipSuccess;
     const uint64_t mask_words = d_mask ? 0 : (reads->n_reads * min_stride + 31) / 32;
+    if (mask_words * 4 > ((uint64_t)64 << 30)) {
+        // one bit per (read, offset) with the stride of the longest read: a chromosome among a million reads
+        kv_set_error("kv_novel_scan: %llu reads with a longest read of %u bases need a %llu GB hit mask; "
+                     "scan long sequences in a batch of their own", (unsigned long long)reads->n_reads, reads->max_len,
+                     (unsigned long long)(mask_words * 4 >> 30));
+        delete hits;
+        *out = nullptr;
+        return KV_ERR_CAPACITY;
+    }
     const size_t b_mask = up256(mask_words * 4), b_flags = p.screen > 0 ? up256(reads->n_reads) : 0;
     const size_t b_tcount = up256((uint64_t)reads->n_tiles * 4), b_tbase = up256(((uint64_t)reads->n_tiles + 1) * 8);
     e = arenas->work.need(b_mask + b_flags + b_tcount + b_tbase + 256);
