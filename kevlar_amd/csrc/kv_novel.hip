@@ -5,8 +5,9 @@
 //                 case sketches, and set bit (read * stride + offset) for each interesting k-mer;
 //                 per-tile hit counts on the side.  This is the whole cost of the scan.
 //   k_tile_scan   exclusive prefix sum of the tile hit counts (one workgroup).
-//   k_novel_emit  tiles that own hits are staged again; the set bits are ranked in (read, offset)
-//                 order with ballots and each hit's abundances are read from every sketch.
+//   k_novel_emit_bits  a tile's hits are the set bits of its range of the mask: ranked with a prefix sum,
+//                 one hit per lane, k-mer rebuilt from the packed words, S abundances read.
+//                 (k_novel_emit, which stages the tile again, serves 2-bit-hash kinds and k > 64.)
 //
 // Hits therefore reach the host already sorted, in exactly the order the reference annotates
 // them, and the bit mask doubles as the per-band mask that the multi-GPU merge all-reduces.
@@ -84,8 +85,9 @@ __device__ __forceinline__ uint32_t probe(const NovelShared &ns, int c, int t, u
 // smallest canonical (k-2)-mer among its three.  It is a pure function of the k-mer and strand-symmetric like
 // the k-mer hash itself, and neighbouring k-mers of a read share it every other time, so the 64 lanes of a
 // wave, which hold 64 consecutive k-mers, ask for ~32 distinct 64-byte sets instead of 64 distinct sectors,
-// and an 8-way set loses far fewer entries to conflicts than a direct-mapped slot.  Which set a hash is stored in only affects the hit rate: an entry anywhere in the cache is a hash
-// proven rejected, so a match is always right.
+// and an 8-way set loses far fewer entries to conflicts than a direct-mapped slot.  Which set a hash is
+// stored in only affects the hit rate: an entry anywhere in the cache is a hash proven rejected, so a
+// match is always right.
 #define VC_WINDOW 3   // measured at config 2: 3 -> 15.1 ms, 4 -> 15.2, 5 -> 16.1, 7 -> 16.9, 2 -> 15.6, 1 -> 18.1 (direct-mapped: 21.1)
 #define VC_WINDOW_MAX 9
 __device__ __forceinline__ uint32_t kmer_minimizer_key(const uint32_t *__restrict__ words, uint32_t pos, int k, int window)
