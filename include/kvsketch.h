@@ -198,11 +198,12 @@ int kv_hits_destroy(kv_hits *h);
  *      kevlar/count.py:62-66, with the hashing done once per k-mer instead of once per band) ------
  * All buffer arguments named d_* are DEVICE pointers owned by the caller (bench.py and
  * kevlar_amd/shardrun.py hand in torch tensors so RCCL can move them); only kernels touch them.    */
-/* Hash every k-mer of `reads` and append it to the send buffer of the band (= rank) that owns it:
- * d_out is [ndest][cap_items] u64 hashes, or with_tags: [ndest][cap_items] pairs (hash, tag) with
- * tag = (read_index_base + read) << 16 | offset and bit 63 set for reads the novel scan skips
- * (non-ACGT).  counts_out[ndest] (host) = items per destination.  kind = KV_COUNTTABLE ... selects
- * the hash function as in kv_hash_kmers.                                                          */
+/* Hash every k-mer of `reads` and group the hashes by the band (= rank) that owns them: d_out receives the
+ * items of destination 0, then destination 1, ... back to back (cap_items >= the k-mers of the shard), the
+ * layout an all-to-all with split sizes sends as it is; an item is a u64 hash or, with_tags, the pair
+ * (hash, tag) with tag = (read_index_base + read) << 16 | offset and bit 63 set for reads the novel scan skips
+ * (non-ACGT).  counts_out[ndest] (host) = items per destination.  kind = KV_COUNTTABLE ... selects the hash
+ * function as in kv_hash_kmers.                                                                            */
 int kv_route_hashes(const kv_reads *reads, int kind, int ksize, int ndest, uint64_t read_index_base,
                     int with_tags, void *d_out, uint64_t cap_items, uint64_t *counts_out);
 /* count n hashes resident in HBM, element i at ((uint64_t*)d_hashes)[i * stride_words]            */

@@ -36,7 +36,8 @@ namespace {
 // partial lines).  Tiles are handed out dynamically up to a quota per workgroup, which bounds what a
 // segment can receive; anything beyond a segment's capacity (skewed input: one k-mer repeated
 // thousands of times lands in one band) goes to a shared overflow list.  k_route_compact then packs
-// the segments into the caller's contiguous per-destination send buffers.
+// the segments into the caller's send buffer, destination after destination with no gaps -- the layout an
+// all-to-all with split sizes takes as it is.
 struct RouteParams {
     HashParams hp;
     int ndest;
@@ -50,9 +51,10 @@ struct RouteParams {
     uint64_t *ovf;               // overflow items
     uint8_t *ovf_dest;
     uint64_t ovf_cap;
-    unsigned long long *ctr;     // [0] tile hand-out, [1] overflow items, [2 + d] packed items of destination d
-    uint64_t cap;                // items per destination in the caller's buffer
-    uint64_t *out;               // [ndest][cap] items
+    unsigned long long *ctr;     // [0] tile hand-out, [1] overflow items; per destination d: [2 + d] items in segments,
+                                 // [18 + d] overflow items, [34 + d] first item in `out`, [50 + d] cursor of its overflow tail
+    uint64_t cap;                // items in the caller's buffer (>= all k-mers of the shard)
+    uint64_t *out;               // destination 0's items, then destination 1's, ... back to back
 };
 
 template <int NW, bool TAGS>
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(ROUTE_THREADS, 6) void k_route_hashes(ReadsDev rd, 
             } else {
                 const unsigned long long o = atomicAdd(&p.ctr[1], 1ull);
                 if (o < p.ovf_cap) {
+                    atomicAdd(&p.ctr[18 + d], 1ull);
                     if (TAGS) *(ulonglong2 *)(p.ovf + 2 * o) = make_ulonglong2(h, tag);
                     else p.ovf[o] = h;
                     p.ovf_dest[o] = (uint8_t)d;
@@ -151,13 +154,25 @@ __global__ __launch_bounds__(ROUTE_MAX_WG) void k_route_scan(RouteParams p)
     if (threadIdx.x == ROUTE_MAX_WG - 1) p.ctr[2 + d] = before + incl;
 }
 
+// where each destination's block starts in the flat output: segments first, overflow items after them
+__global__ void k_route_bases(RouteParams p)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long base = 0;
+    for (int d = 0; d < p.ndest; ++d) {
+        p.ctr[34 + d] = base;
+        p.ctr[50 + d] = base + p.ctr[2 + d];
+        base += p.ctr[2 + d] + p.ctr[18 + d];
+    }
+}
+
 template <int W>
 __global__ __launch_bounds__(256) void k_route_compact(RouteParams p)
 {
     const uint32_t wg = blockIdx.x, d = blockIdx.y;
     const uint64_t n = p.seg_count[(uint64_t)d * p.nwg + wg];
     const uint64_t *src = p.seg + ((uint64_t)d * p.nwg + wg) * p.seg_cap * W;
-    uint64_t *dst = p.out + ((uint64_t)d * p.cap + p.seg_off[(uint64_t)d * p.nwg + wg]) * W;
+    uint64_t *dst = p.out + (p.ctr[34 + d] + p.seg_off[(uint64_t)d * p.nwg + wg]) * W;
     for (uint64_t j = threadIdx.x; j < n * W; j += 256) dst[j] = src[j];
 }
 
@@ -169,9 +184,9 @@ __global__ void k_route_tail(RouteParams p)
     if (n > p.ovf_cap) n = p.ovf_cap;
     for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t d = p.ovf_dest[j];
-        const unsigned long long pos = atomicAdd(&p.ctr[2 + d], 1ull);
+        const unsigned long long pos = atomicAdd(&p.ctr[50 + d], 1ull);
         if (pos < p.cap)
-            for (int w = 0; w < W; ++w) p.out[((uint64_t)d * p.cap + pos) * W + w] = p.ovf[j * W + w];
+            for (int w = 0; w < W; ++w) p.out[pos * W + w] = p.ovf[j * W + w];
     }
 }
 
@@ -229,8 +244,7 @@ extern "C" int kv_route_hashes(const kv_reads *reads, int kind, int ksize, int n
     KV_REQUIRE(read_index_base + reads->n_reads < (1ull << 46), KV_ERR_ARG, "kv_route_hashes: read index does not fit the tag");
     uint64_t n_kmers = 0;
     kv_reads_num_kmers(reads, ksize, &n_kmers);
-    KV_REQUIRE(cap_items >= n_kmers, KV_ERR_CAPACITY,
-               "kv_route_hashes: each destination needs room for all %llu k-mers of the shard (worst case)",
+    KV_REQUIRE(cap_items >= n_kmers, KV_ERR_CAPACITY, "kv_route_hashes: the output needs room for the %llu k-mers of the shard",
                (unsigned long long)n_kmers);
     for (int d = 0; d < ndest; ++d) counts_out[d] = 0;
     if (reads->n_tiles == 0 || n_kmers == 0) return KV_OK;
@@ -257,7 +271,7 @@ extern "C" int kv_route_hashes(const kv_reads *reads, int kind, int ksize, int n
     p.ovf_cap = n_kmers;                                                    // worst case: no capacity error possible
     const size_t b_seg = round_up((uint64_t)ndest * p.nwg * p.seg_cap * 8 * W, 256);
     const size_t b_cnt = round_up((uint64_t)ndest * p.nwg * 4, 256), b_off = round_up((uint64_t)ndest * p.nwg * 8, 256);
-    const size_t b_ovf = round_up(p.ovf_cap * 8 * W, 256), b_od = round_up(p.ovf_cap, 256), b_ctr = 256;
+    const size_t b_ovf = round_up(p.ovf_cap * 8 * W, 256), b_od = round_up(p.ovf_cap, 256), b_ctr = 1024;
     hipStream_t st = kv_stream();
     Scratch *scratch;
     {
@@ -292,6 +306,7 @@ extern "C" int kv_route_hashes(const kv_reads *reads, int kind, int ksize, int n
     {
         KvProfScope prof("k_route_compact");
         hipLaunchKernelGGL(k_route_scan, dim3((unsigned)ndest), dim3(ROUTE_MAX_WG), 0, st, p);
+        hipLaunchKernelGGL(k_route_bases, dim3(1), dim3(64), 0, st, p);
         if (with_tags) {
             hipLaunchKernelGGL(k_route_compact<2>, dim3(p.nwg, (unsigned)ndest), dim3(256), 0, st, p);
             hipLaunchKernelGGL(k_route_tail<2>, dim3(256), dim3(256), 0, st, p);
@@ -301,11 +316,11 @@ extern "C" int kv_route_hashes(const kv_reads *reads, int kind, int ksize, int n
         }
     }
     KV_HIP(hipGetLastError());
-    unsigned long long host[ROUTE_MAX_DEST + 2];
-    KV_HIP(hipMemcpyAsync(host, p.ctr, (size_t)(ndest + 2) * 8, hipMemcpyDeviceToHost, st));
+    unsigned long long host[34];
+    KV_HIP(hipMemcpyAsync(host, p.ctr, sizeof(host), hipMemcpyDeviceToHost, st));
     KV_HIP(hipStreamSynchronize(st));
     KV_REQUIRE(host[0] >= reads->n_tiles, KV_ERR_HIP, "kv_route_hashes: %llu of %u tiles processed", host[0], reads->n_tiles);
-    for (int d = 0; d < ndest; ++d) counts_out[d] = host[2 + d];
+    for (int d = 0; d < ndest; ++d) counts_out[d] = host[2 + d] + host[18 + d];
     return KV_OK;
 }
 

@@ -673,7 +673,8 @@ def _hits_arrays(hits, S):
 # arguments are device addresses of caller-owned buffers (torch tensors' data_ptr()).
 # ----------------------------------------------------------------------------------------
 def route_hashes(batch, sketch_cls, ksize, ndest, read_index_base, with_tags, out_ptr, cap_items):
-    """Hash every k-mer of `batch` and append it to the send buffer of the band that owns it;
+    """Hash every k-mer of `batch` and write the hashes grouped by the band that owns them (destination 0's
+    items, then destination 1's, ... back to back in the buffer at out_ptr, cap_items >= batch.num_kmers);
     returns the number of items per destination."""
     counts = (ctypes.c_uint64 * int(ndest))()
     check(_lib.load().kv_route_hashes(batch._h, sketch_cls._kind, int(ksize), int(ndest), int(read_index_base),

@@ -47,12 +47,12 @@ class _Exchange(object):
 def exchange_rows_async(send, counts, group=None, staged=False):
     """All-to-all of variable-length row blocks.
 
-    send: tensor [world, cap, ...]; rows [d, :counts[d]] go to rank d.  The received blocks (from rank
-    0, 1, ... back to back) come from the returned handle's wait().  When this returns `send` may be
-    reused: its rows were packed into a private buffer.  `staged` moves the data through host memory
-    (gloo cannot transport device tensors) and completes before returning."""
+    send: tensor [rows, ...] holding the block for rank 0, then rank 1, ... back to back (counts[d] rows for
+    rank d), exactly as kv_route_hashes leaves them.  The received blocks (from rank 0, 1, ...) come from the
+    returned handle's wait(); `send` must stay untouched until then.  `staged` moves the data through host
+    memory (gloo cannot transport device tensors) and completes before returning."""
     world = dist.get_world_size(group)
-    assert send.shape[0] == world and len(counts) == world
+    assert len(counts) == world
     coll_dev = torch.device('cpu') if staged else send.device
     mine = torch.tensor(counts, dtype=torch.int64, device=coll_dev)
     table = torch.empty(world * world, dtype=torch.int64, device=coll_dev)
@@ -60,8 +60,8 @@ def exchange_rows_async(send, counts, group=None, staged=False):
     table = table.view(world, world).cpu()
     rank = dist.get_rank(group)
     recv_counts = [int(table[src, rank]) for src in range(world)]
-    packed = torch.cat([send[d, :counts[d]] for d in range(world)], dim=0)
-    recv = torch.empty((sum(recv_counts),) + tuple(send.shape[2:]), dtype=send.dtype, device=send.device)
+    packed = send[:sum(counts)]
+    recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
     if staged:
         src_host = packed.cpu()
         dst_host = torch.empty(recv.shape, dtype=recv.dtype)
@@ -70,9 +70,8 @@ def exchange_rows_async(send, counts, group=None, staged=False):
         if recv.is_cuda:
             torch.cuda.synchronize()
         return _Exchange(None, recv, recv_counts, None)
-    torch.cuda.current_stream().synchronize()      # packed is complete: the caller may overwrite `send`
     work = dist.all_to_all_single(recv, packed, recv_counts, list(counts), group=group, async_op=True)
-    return _Exchange(work, recv, recv_counts, packed)
+    return _Exchange(work, recv, recv_counts, send)
 
 
 def exchange_rows(send, counts, group=None, staged=False):
@@ -119,29 +118,30 @@ class ShardedTrio(object):
         backend = dist.get_backend(group)
         self.staged = (backend != 'nccl') if staged is None else bool(staged)
         self.device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
-        self._send = {}          # words per item -> send buffer [world, cap, words]
+        self._send = {}          # words per item -> free send buffers [cap, words] (one per exchange in flight)
         self.case_items = None   # (hash, tag) pairs of the case k-mers this rank owns
         self.timing = {'route': 0.0, 'exchange': 0.0, 'count': 0.0, 'scan': 0.0, 'gather': 0.0}
 
     def _send_buffer(self, cap, words):
-        buf = self._send.get(words)
-        if buf is None or buf.shape[1] < cap:
-            self._send[words] = None
-            buf = torch.empty((self.world, cap, words), dtype=torch.int64, device=self.device)
-            self._send[words] = buf
-        return buf
+        """A send buffer nobody is using: an exchange in flight keeps its own until finish()."""
+        free = self._send.setdefault(words, [])
+        for i, buf in enumerate(free):
+            if buf.shape[0] >= cap:
+                return free.pop(i)
+        return torch.empty((cap, words), dtype=torch.int64, device=self.device)
 
     def start(self, batch, read_index_base, with_tags):
         """Hash this rank's shard of a sample and start delivering every hash to its band's owner.
         Returns a handle for finish(); the next sample's start() may run while the exchange flies."""
         words = 2 if with_tags else 1
-        cap = max(batch.num_kmers(self.ksize), 1)       # worst case: every k-mer of the shard in one band
+        cap = max(batch.num_kmers(self.ksize), 1)
         send = self._send_buffer(cap, words)
         t0 = time.perf_counter()
         counts = hk.route_hashes(batch, self.sketch_cls, self.ksize, self.world, read_index_base, with_tags,
-                                 send.data_ptr(), send.shape[1])
+                                 send.data_ptr(), send.shape[0])
         t1 = time.perf_counter()
         ex = exchange_rows_async(send, counts, self.group, self.staged)
+        ex.send_buffer = send
         self.timing['route'] += t1 - t0
         self.timing['exchange'] += time.perf_counter() - t1
         return ex
@@ -152,6 +152,7 @@ class ShardedTrio(object):
         number of k-mers counted on this rank."""
         t0 = time.perf_counter()
         recv = ex.wait()
+        self._send[ex.send_buffer.shape[1]].append(ex.send_buffer)     # delivered: the buffer is free again
         t1 = time.perf_counter()
         n = recv.shape[0]
         if n:

@@ -25,16 +25,16 @@ for N in (8, 4, 2):
         for c in range(8):
             part = hk.ReadBatch.from_packed(packed[n][c * CH:(c + 1) * CH if c < 7 else n_reads], L)
             nk = part.num_kmers(k)
-            send = torch.empty((N, nk, w), dtype=torch.int64, device='cuda')
-            counts = hk.route_hashes(part, hk.Counttable, k, N, c * CH, w == 2, send.data_ptr(), send.shape[1])
-            parts.append(send[0, :counts[0]].clone())
+            send = torch.empty((nk, w), dtype=torch.int64, device='cuda')
+            counts = hk.route_hashes(part, hk.Counttable, k, N, c * CH, w == 2, send.data_ptr(), send.shape[0])
+            parts.append(send[:counts[0]].clone())
             del send, part
         recv[n] = torch.cat(parts)
         del parts
     torch.cuda.synchronize()
     shard = {n: hk.ReadBatch.from_packed(packed[n][:n_reads // N], L) for n in names}
     nk_s = shard['proband'].num_kmers(k)
-    sendbuf = {w: torch.empty((N, nk_s, w), dtype=torch.int64, device='cuda') for w in (1, 2)}
+    sendbuf = {w: torch.empty((nk_s, w), dtype=torch.int64, device='cuda') for w in (1, 2)}
     sk = {n: hk.Counttable(k, 2e9 / N / 4, 4) for n in names}
     tags = torch.empty(1 << 24, dtype=torch.int64, device='cuda'); abund = torch.empty((1 << 24, 3), dtype=torch.uint8, device='cuda')
     def step():

@@ -39,12 +39,11 @@ def worker(rank, world, port, result_file):
     for r in range(lo, hi):
         for i, h in enumerate(hasher.get_kmer_hashes(reads[r])):
             blocks[min(int(h) // bs, world - 1)].append((int(h), (r << 16) | i))
-    cap = max(1, max(len(b) for b in blocks))
-    send = torch.zeros((world, cap, 2), dtype=torch.int64)
-    for d, b in enumerate(blocks):
-        if b:
-            send[d, :len(b)] = torch.from_numpy(np.array(b, dtype=np.uint64).view(np.int64).reshape(len(b), 2))
     counts = [len(b) for b in blocks]
+    flat = [item for b in blocks for item in b]          # destination 0's items, then destination 1's, ...
+    send = torch.zeros((max(1, len(flat)), 2), dtype=torch.int64)
+    if flat:
+        send[:len(flat)] = torch.from_numpy(np.array(flat, dtype=np.uint64).view(np.int64).reshape(len(flat), 2))
     recv, recv_counts = shardrun.exchange_rows(send, counts, staged=True)
     assert recv.shape == (sum(recv_counts), 2)
     got = recv.numpy().view(np.uint64)
