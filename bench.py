@@ -52,7 +52,7 @@ def parse_args():
                    help='N>1: exchange = shard the reads, hash once, all-to-all the hashes by band (kevlar_amd/shardrun.py); '
                         'banded = every rank hashes all reads and keeps its band; auto = exchange from 4 GPUs up')
     p.add_argument('--count-streams', type=int, default=1,
-                   help='N=1: count the three samples concurrently on this many HIP streams.  3 is ~4 %% faster (the '
+                   help='N=1: count the three samples concurrently on this many HIP streams.  3 is ~6 %% faster (the '
                         'hashing stage of one sample overlaps the LDS/HBM-bound stages of another) but per-kernel HIP-event '
                         'durations then include time sharing, so the default keeps the launches back to back')
     p.add_argument('--backend', default='nccl', help='nccl (= RCCL) is what the driver runs; gloo lets two ranks share one GPU in tests')
@@ -183,6 +183,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if exchange:
+        # the exchange path has only ever run its RCCL transport with one rank (a one-GPU pool): try one step and,
+        # if any rank fails, let every rank fall back to the banded layout instead of losing the measurement
+        ok = 1
+        try:
+            step()
+        except Exception as exc:   # noqa: BLE001
+            ok = 0
+            print('[bench] rank {}: exchange mode failed ({}: {}); falling back to banded'.format(
+                rank, type(exc).__name__, exc), file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int64, device=coll_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            exchange = False
+            multi = 'banded'
+            run = None
+            batches = {n: hk.ReadBatch.from_packed(packed[n], L) for n in names}
+            step = step_banded
     for _ in range(args.warmup):
         step()
     lib.kv_prof_reset()
