@@ -1,0 +1,82 @@
+// kv_binned.h -- geometry and host entry points of the partitioned count (kv_binned.hip), shared with the
+// super-k-mer front end (kv_skm.hip), which feeds the same coarse buckets with (bin, count) items.
+#pragma once
+#include <map>
+#include <mutex>
+
+#include "kv_internal.h"
+
+#define BIN_C 64            // most coarse buckets per table
+#define BIN_MAX_T 4         // tables handled by the partitioned path
+#define BIN_MAX_F 512       // slices per coarse bucket (9 bits of a coarse item)
+
+// A coarse item (stage A -> stage B) is one u32:
+//   bits  0..15  offset of the bin inside its 65536-bin slice
+//   bits 16..24  slice inside the coarse bucket (< F <= 512)
+//   bits 25..31  weighted items only: increment - 1 (one item adds 1..128 to its bin; saturating adds commute,
+//                so a k-mer seen c times in a batch is one item of weight c instead of c items)
+// A fine item (stage B -> stage C) is the u16 offset, or for weighted items offset | increment << 16.
+#define BIN_W_SHIFT 25
+#define BIN_W_MAX 128u
+
+struct BinGeom {
+    int T, F, C;                     // tables, slices per coarse bucket, coarse buckets in use (<= BIN_C)
+    uint32_t ringA, ringB;           // LDS ring entries per stream in stages A / B (powers of two)
+    uint32_t recipF;                 // floor(2^32 / F) + 1: slice / F by multiply-high
+    uint32_t nslices[BIN_MAX_T];
+    uint32_t tile_lds;               // bytes of dynamic LDS in front of the stage-A rings
+    uint32_t nwgA, nwgB;             // writers per coarse bucket (stage-A workgroups) / per slice (stage-B workgroups of the bucket)
+    uint32_t quotaA;                 // work units (tiles / list chunks) one stage-A workgroup may take: bounds its segments' fill
+    uint64_t cap1, cap2, spill_cap;  // items per PRIVATE segment: every writer owns its own region of every stream,
+                                     // so appending needs no global atomic (and no round trip) at all
+    uint32_t *gbuf1;                 // [T*C][nwgA][cap1] coarse items
+    uint16_t *gbuf2;                 // [T*C*F][nwgB][cap2] fine items (u16, or u32 when weighted)
+    uint32_t *gcnt1, *gcnt2;         // [T*C][nwgA] / [T*C*F][nwgB] items written per segment
+    unsigned long long *spill;       // bin | table << 32 | (increment - 1) << 40
+    unsigned long long *ctr;         // [0] spill count, [1] overflow flag, [2] k-mers added, [3] occupancy delta, [4] work ticket
+};
+
+// host-side description of one partitioned count in flight
+struct BinPlan {
+    BinGeom g;
+    int cmax;                // bucket budget the geometry was chosen for (<= 32: 512-thread stage A, else 1024)
+    uint32_t threadsA;
+    uint32_t maxsl;          // most slices of any table
+    bool weighted;
+};
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void spill_item(const BinGeom &g, int t, uint64_t bin, uint32_t weight = 1u)
+{
+    const unsigned long long pos = atomicAdd(&g.ctr[0], 1ull);
+    if (pos < g.spill_cap) g.spill[pos] = ((unsigned long long)(weight - 1u) << 40) | ((unsigned long long)t << 32) | bin;
+    else g.ctr[1] = 1;
+}
+#endif
+
+// grow-only device scratch; one arena per stream so host threads counting different samples do not share buffers
+struct KvArena {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t need(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+};
+
+int kv_device_cus();
+static inline uint64_t kv_round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+// Geometry + scratch for a count of at most `n_items_max` k-mers into `s` on the calling thread's stream.
+// work_units / threads: the stage-A front end's units of work and workgroup size (0 threads: pick by geometry);
+// nwgA_fixed != 0 pins the number of stage-A writers (the super-k-mer front end brings its own grid).
+int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, uint64_t work_units, uint32_t lds_front,
+                uint32_t nwgA_fixed, bool weighted, BinPlan *plan);
+// stages B, C, spill + bookkeeping (n_occupied, n_unique estimate); synchronises the stream.
+// n_added_fixed: the caller knows the number of k-mers added (hash lists), else it is read from ctr[2].
+int kv_bin_finish(kv_sketch *s, BinPlan &plan, bool added_from_ctr, uint64_t n_added_fixed, uint64_t *n_added);

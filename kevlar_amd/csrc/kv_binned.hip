@@ -29,45 +29,20 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <type_traits>
 
+#include "kv_binned.h"
 #include "kv_device.h"
 
 namespace {
 
-#define BIN_C 64            // most coarse buckets per table
-#define BIN_MAX_T 4         // tables handled by the partitioned path
 #define BIN_RING_MIN 64
 #define BIN_RING_MAX 4096   // a round appends at most 4096 items to one stream
 #define BIN_B_THREADS 512   // 8 waves: one lane per slice stream for F <= 512
 #define BIN_B_ITEMS 8       // items per thread per round in stage B
-#define BIN_B_BUDGET 16384  // LDS ring entries (u16) per stage-B workgroup
+#define BIN_B_BUDGET 16384  // LDS ring entries per stage-B workgroup
 #define BIN_C_THREADS 1024
-#define BIN_MAX_F 512
 #define BIN_MAX_SEG 512      // stage-B writers per slice (nwgB)
-
-struct BinGeom {
-    int T, F, C;                     // tables, slices per coarse bucket, coarse buckets in use (<= BIN_C)
-    uint32_t ringA, ringB;           // LDS ring entries per stream in stages A / B (powers of two)
-    uint32_t recipF;                 // floor(2^32 / F) + 1: slice / F by multiply-high
-    uint32_t nslices[BIN_MAX_T];
-    uint32_t tile_lds;               // bytes of dynamic LDS in front of the stage-A rings
-    uint32_t nwgA, nwgB;             // writers per coarse bucket (stage-A workgroups) / per slice (stage-B workgroups of the bucket)
-    uint32_t quotaA;                 // work units (tiles / list chunks) one stage-A workgroup may take: bounds its segments' fill
-    uint64_t cap1, cap2, spill_cap;  // items per PRIVATE segment: every writer owns its own region of every stream,
-                                     // so appending needs no global atomic (and no round trip) at all
-    uint32_t *gbuf1;                 // [T*C][nwgA][cap1] coarse items: (slice-in-bucket << 16) | offset
-    uint16_t *gbuf2;                 // [T*C*F][nwgB][cap2] offsets inside a slice
-    uint32_t *gcnt1, *gcnt2;         // [T*C][nwgA] / [T*C*F][nwgB] items written per segment
-    unsigned long long *spill;       // (table << 32) | bin
-    unsigned long long *ctr;         // [0] spill count, [1] overflow flag, [2] k-mers added, [3] occupancy delta
-};
-
-__device__ __forceinline__ void spill_item(const BinGeom &g, int t, uint64_t bin)
-{
-    const unsigned long long pos = atomicAdd(&g.ctr[0], 1ull);
-    if (pos < g.spill_cap) g.spill[pos] = ((unsigned long long)t << 32) | bin;
-    else g.ctr[1] = 1;
-}
 
 // ---- LDS write-combining rings ------------------------------------------------------------
 // ns streams, each a ring of R items (R a power of two) plus an append counter and a flushed
@@ -145,14 +120,15 @@ __device__ __forceinline__ void rings_flush(const Rings<ItemT> &rs, uint32_t ns,
 
 // Stage B's flush between rounds: the flush phase of rings_flush is instruction-bound (PMC: ~600 VALU
 // wave-instructions per wave and round, 4/5 of them broadcasting per-burst parameters and looping), so here
-// every lane that owns a ready stream copies its own burst: 32 (or R) u16 items as 16-byte vectors, LDS read ->
+// every lane that owns a ready stream copies its own burst: 32 (or R) items as 16-byte vectors, LDS read ->
 // global store, all streams of the wave in parallel.  Bursts are multiples of 32 items and the ring skew is 8,
-// so vectors stay 16-byte aligned in LDS and 64-byte aligned in the segment.  The rare misfits (segment nearly
-// full, ring overrun that left the base unaligned) are left to rings_flush.
-template <typename Overflow>
-__device__ __forceinline__ void rings_flush_lanes16(const Rings<uint16_t> &rs, uint32_t ns, uint32_t &written, uint64_t seg_base,
-                                                    uint32_t cap, uint16_t *gbuf, Overflow overflow)
+// so vectors stay 16-byte aligned in LDS and in the segment (u16 and u32 items alike).  The rare misfits (segment
+// nearly full, ring overrun that left the base unaligned) are left to rings_flush.
+template <typename ItemT, typename Overflow>
+__device__ __forceinline__ void rings_flush_lanes(const Rings<ItemT> &rs, uint32_t ns, uint32_t &written, uint64_t seg_base,
+                                                  uint32_t cap, ItemT *gbuf, Overflow overflow)
 {
+    constexpr uint32_t VEC = 16u / sizeof(ItemT);        // items per 16-byte vector
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
     const uint32_t per_wave = (ns + nwaves - 1) / nwaves;
     const uint32_t s0 = wave * per_wave, s_end = min(ns, s0 + per_wave);
@@ -167,9 +143,9 @@ __device__ __forceinline__ void rings_flush_lanes16(const Rings<uint16_t> &rs, u
         if (n) {
             if ((base & 7u) || written + n > cap || (newbase & 7u)) misfit = true;
             else {
-                const uint16_t *ring = rs.ring + s * rs.R;
-                uint16_t *dst = gbuf + seg_base + written;
-                for (uint32_t v = 0; v < n; v += 8)
+                const ItemT *ring = rs.ring + s * rs.R;
+                ItemT *dst = gbuf + seg_base + written;
+                for (uint32_t v = 0; v < n; v += VEC)
                     *(uint4 *)(dst + v) = *(const uint4 *)(ring + ((base + v + rs.skew * s) & (rs.R - 1)));
                 written += n;
                 rs.base[s] = newbase;
@@ -177,7 +153,7 @@ __device__ __forceinline__ void rings_flush_lanes16(const Rings<uint16_t> &rs, u
         }
     }
     if (__ballot(misfit)) {
-        auto store = [&](uint64_t idx, uint16_t off) { gbuf[idx] = off; };
+        auto store = [&](uint64_t idx, ItemT off) { gbuf[idx] = off; };
         rings_flush(rs, ns, false, written, seg_base, cap, store, overflow);
     }
 }
@@ -441,17 +417,20 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_list(
 }
 
 // ---- stage B -----------------------------------------------------------------------------
+// W = weighted items (kv_binned.h): a coarse item carries its increment in bits 25..31 and leaves as offset | increment << 16
+template <bool W>
 __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
 {
+    typedef typename std::conditional<W, uint32_t, uint16_t>::type Out;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t s = blockIdx.y;                  // coarse stream = table * C + bucket
     const uint32_t t = s / (uint32_t)g.C, c = s % (uint32_t)g.C;
     const uint32_t F = (uint32_t)g.F;
-    Rings<uint16_t> rs;
+    Rings<Out> rs;
     rs.R = g.ringB;
     rs.skew = 8;
-    rs.ring = (uint16_t *)smem;
-    rs.cnt = (uint32_t *)(smem + (((size_t)F * rs.R * 2 + 15) & ~(size_t)15));
+    rs.ring = (Out *)smem;
+    rs.cnt = (uint32_t *)(smem + (((size_t)F * rs.R * sizeof(Out) + 15) & ~(size_t)15));
     rs.base = rs.cnt + F;
     for (uint32_t i = threadIdx.x; i < F; i += BIN_B_THREADS) { rs.cnt[i] = 0; rs.base[i] = 0; }
     __syncthreads();
@@ -462,8 +441,16 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
         const uint32_t mine = (threadIdx.x >> 6) * per_wave + (threadIdx.x & 63);
         if ((threadIdx.x & 63) < per_wave && mine < F) seg_base = (((uint64_t)s * F + mine) * g.nwgB + blockIdx.x) * g.cap2;
     }
-    auto store = [&](uint64_t idx, uint16_t off) { g.gbuf2[idx] = off; };
-    auto overflow = [&](uint32_t fi, uint16_t off) { spill_item(g, (int)t, (((uint64_t)c * F + fi) << 16) | off); };
+    Out *gbuf2 = (Out *)g.gbuf2;
+    auto slice_of = [](uint32_t item) { return W ? (item >> 16) & (BIN_MAX_F - 1u) : item >> 16; };
+    auto fine_of = [](uint32_t item) { return W ? (Out)((item & 0xffffu) | (((item >> BIN_W_SHIFT) + 1u) << 16)) : (Out)(item & 0xffffu); };
+    auto spill_coarse = [&](uint32_t item) {
+        spill_item(g, (int)t, (((uint64_t)c * F + slice_of(item)) << 16) | (item & 0xffffu), W ? (item >> BIN_W_SHIFT) + 1u : 1u);
+    };
+    auto store = [&](uint64_t idx, Out off) { gbuf2[idx] = off; };
+    auto overflow = [&](uint32_t fi, Out off) {
+        spill_item(g, (int)t, (((uint64_t)c * F + fi) << 16) | ((uint32_t)off & 0xffffu), W ? (uint32_t)off >> 16 : 1u);
+    };
     const uint64_t step = (uint64_t)BIN_B_THREADS * BIN_B_ITEMS;
     // this workgroup drains the private segments seg = blockIdx.x, blockIdx.x + nwgB, ... of bucket s
     for (uint32_t seg = blockIdx.x; seg < g.nwgA; seg += g.nwgB) {
@@ -493,29 +480,27 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
                 // together), then consumed; an item whose ring is full is rare and handled after the fast path
                 uint32_t pos[BIN_B_ITEMS], rbase[BIN_B_ITEMS];
 #pragma unroll
-                for (int j = 0; j < BIN_B_ITEMS; ++j) pos[j] = atomicAdd(&rs.cnt[items[j] >> 16], 1u);
+                for (int j = 0; j < BIN_B_ITEMS; ++j) pos[j] = atomicAdd(&rs.cnt[slice_of(items[j])], 1u);
 #pragma unroll
-                for (int j = 0; j < BIN_B_ITEMS; ++j) rbase[j] = rs.base[items[j] >> 16];
+                for (int j = 0; j < BIN_B_ITEMS; ++j) rbase[j] = rs.base[slice_of(items[j])];
                 uint32_t full = 0;
 #pragma unroll
                 for (int j = 0; j < BIN_B_ITEMS; ++j) {
-                    const uint32_t fi = items[j] >> 16;
-                    if (pos[j] - rbase[j] < rs.R) rs.ring[fi * rs.R + ((pos[j] + rs.skew * fi) & (rs.R - 1))] = (uint16_t)(items[j] & 0xffffu);
+                    const uint32_t fi = slice_of(items[j]);
+                    if (pos[j] - rbase[j] < rs.R) rs.ring[fi * rs.R + ((pos[j] + rs.skew * fi) & (rs.R - 1))] = fine_of(items[j]);
                     else full |= 1u << j;
                 }
                 if (full) {
 #pragma unroll
                     for (int j = 0; j < BIN_B_ITEMS; ++j)
-                        if (full & (1u << j)) spill_item(g, (int)t, (((uint64_t)c * F + (items[j] >> 16)) << 16) | (items[j] & 0xffffu));
+                        if (full & (1u << j)) spill_coarse(items[j]);
                 }
             } else {
-                for (int j = 0; j < have; ++j) {
-                    const uint32_t fi = items[j] >> 16, off = items[j] & 0xffffu;
-                    if (!ring_append(rs, fi, (uint16_t)off)) spill_item(g, (int)t, (((uint64_t)c * F + fi) << 16) | off);
-                }
+                for (int j = 0; j < have; ++j)
+                    if (!ring_append(rs, slice_of(items[j]), fine_of(items[j]))) spill_coarse(items[j]);
             }
             __syncthreads();
-            rings_flush_lanes16(rs, F, written, seg_base, (uint32_t)g.cap2, g.gbuf2, overflow);
+            rings_flush_lanes(rs, F, written, seg_base, (uint32_t)g.cap2, gbuf2, overflow);
             __syncthreads();
         }
     }
@@ -616,9 +601,73 @@ __device__ __forceinline__ uint32_t lds_inc8(uint32_t *lds, const uint32_t (&w)[
     return fresh;
 }
 
+// Four weighted saturating adds (fine items offset | increment << 16), same structure as lds_inc8: all words
+// read, all compare-and-swaps issued back to back, only lost races loop.  min(max, x + c) applied once equals c
+// single increments, so the tables come out bit-identical to the unweighted path.
 template <int STORAGE>
+__device__ __forceinline__ uint32_t lds_addw4(uint32_t *lds, const uint32_t (&w)[4], uint32_t n)
+{
+    uint32_t fresh = 0;
+    if (STORAGE == ST_BIT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t off = w[e] & 0xffffu;
+            if ((uint32_t)e < n) {
+                const uint32_t bit = 1u << (off & 31);
+                fresh += (atomicOr(&lds[off >> 5], bit) & bit) == 0 ? 1u : 0u;
+            }
+        }
+        return fresh;
+    }
+    constexpr uint32_t maxv = STORAGE == ST_BYTE ? 255u : 15u;
+    uint32_t widx[4], shift[4], add[4], old[4], prev[4];
+    bool live[4];
+    uint32_t retry = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t off = w[e] & 0xffffu;
+        add[e] = w[e] >> 16;
+        if (STORAGE == ST_BYTE) { widx[e] = off >> 2; shift[e] = (off & 3u) << 3; }
+        else { widx[e] = off >> 3; shift[e] = (((off >> 1) & 3u) << 3) + ((off & 1u) ? 0u : 4u); }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) old[e] = lds[widx[e]];               // absent items (e >= n) read a harmless word
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t field = (old[e] >> shift[e]) & maxv;
+        const uint32_t nf = min(maxv, field + add[e]);
+        live[e] = (uint32_t)e < n && nf != field;
+        prev[e] = atomicCAS(&lds[widx[e]], old[e], old[e] + (live[e] ? (nf - field) << shift[e] : 0u));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool won = prev[e] == old[e];
+        fresh += (live[e] && won && ((old[e] >> shift[e]) & maxv) == 0) ? 1u : 0u;
+        retry |= (live[e] && !won) ? (1u << e) : 0u;
+    }
+    if (retry) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (!(retry & (1u << e))) continue;
+            uint32_t cur_word = prev[e];
+            for (;;) {
+                const uint32_t field = (cur_word >> shift[e]) & maxv;
+                if (field == maxv) break;
+                const uint32_t nf = min(maxv, field + add[e]);
+                const uint32_t seen = atomicCAS(&lds[widx[e]], cur_word, cur_word + ((nf - field) << shift[e]));
+                if (seen == cur_word) { fresh += field == 0 ? 1u : 0u; break; }
+                cur_word = seen;
+            }
+        }
+    }
+    return fresh;
+}
+
+template <int STORAGE, bool W>
 __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__restrict__ sk, BinGeom g)
 {
+    typedef typename std::conditional<W, uint32_t, uint16_t>::type Item;
+    constexpr uint32_t VEC = 16u / sizeof(Item);                  // items per 16-byte vector
     __shared__ __attribute__((aligned(16))) uint32_t lds[16384];   // one slice: 65536 counters of <= 8 bits
     const int t = blockIdx.y;
     const uint32_t slice = blockIdx.x;
@@ -635,17 +684,17 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
     uint4 *tab = (uint4 *)(sk->tab[t] + byte0);
     uint4 *l4 = (uint4 *)lds;
     // the slice's items sit in nwgB private segments of cap2 slots (cap2 % 64 == 0: 128-B aligned, so a
-    // 16-byte vector never leaves its segment).  Their 8-item vectors are enumerated compactly through a
+    // 16-byte vector never leaves its segment).  Their vectors are enumerated compactly through a
     // prefix sum over the segments (LDS), so every thread has work whatever the segment fill levels.
     __shared__ uint32_t seg_cnt[BIN_MAX_SEG], vpre[BIN_MAX_SEG];
     __shared__ uint32_t wsum[BIN_C_THREADS / 64];
     __shared__ uint32_t total_vec_sh;
-    const uint16_t *items = g.gbuf2 + stream * g.nwgB * g.cap2;
+    const Item *items = (const Item *)g.gbuf2 + stream * g.nwgB * g.cap2;
     const uint32_t *counts = g.gcnt2 + stream * g.nwgB;
     {
         uint32_t myc = 0;
         if (threadIdx.x < g.nwgB) { myc = counts[threadIdx.x]; seg_cnt[threadIdx.x] = myc; }
-        const uint32_t myv = (myc + 7) >> 3;
+        const uint32_t myv = (myc + VEC - 1) / VEC;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         uint32_t incl = myv;
 #pragma unroll
@@ -663,7 +712,7 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
     }
     const uint32_t total_vec = total_vec_sh;
     if (total_vec == 0) return;                                    // untouched slice: no table traffic at all
-    // a vector: its 8 items (always loaded whole) and how many of them are real
+    // a vector: its items (always loaded whole) and how many of them are real
     struct Vec { uint4 q; uint32_t n; };
     auto fetch = [&](uint32_t v) {
         Vec r;
@@ -674,9 +723,9 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
             const uint32_t mid = (lo + hi) >> 1;
             if (vpre[mid] <= v) lo = mid; else hi = mid;
         }
-        const uint32_t j8 = (v - vpre[lo]) * 8u;
-        r.n = min(8u, seg_cnt[lo] - j8);
-        r.q = *(const uint4 *)(items + (uint64_t)lo * g.cap2 + j8);
+        const uint32_t j0 = (v - vpre[lo]) * VEC;
+        r.n = min(VEC, seg_cnt[lo] - j0);
+        r.q = *(const uint4 *)(items + (uint64_t)lo * g.cap2 + j0);
         return r;
     };
     // software pipeline, two vectors ahead: item requests fly while the slice loads and while earlier items are applied
@@ -687,7 +736,7 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
     for (uint32_t v = threadIdx.x; v < total_vec; v += BIN_C_THREADS) {
         const Vec v2 = fetch(v + 2 * BIN_C_THREADS);
         const uint32_t w[4] = {v0.q.x, v0.q.y, v0.q.z, v0.q.w};
-        fresh += lds_inc8<STORAGE>(lds, w, v0.n);
+        fresh += W ? lds_addw4<STORAGE>(lds, w, v0.n) : lds_inc8<STORAGE>(lds, w, v0.n);
         v0 = v1; v1 = v2;
     }
     __syncthreads();
@@ -698,7 +747,8 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
     }
 }
 
-__device__ __forceinline__ bool table_inc_bin(const SketchDev *s, int t, uint64_t bin)
+// saturating add of `weight` to one bin with global atomics; true if the bin was zero before
+__device__ __forceinline__ bool table_add_bin(const SketchDev *s, int t, uint64_t bin, uint32_t weight)
 {
     uint8_t *tab = s->tab[t];
     if (s->storage == ST_BIT) {
@@ -717,7 +767,8 @@ __device__ __forceinline__ bool table_inc_bin(const SketchDev *s, int t, uint64_
     for (;;) {
         const uint32_t cur = (old >> shift) & maxv;
         if (cur == maxv) return false;
-        const uint32_t prev = atomicCAS(w, old, old + (1u << shift));
+        const uint32_t nf = min(maxv, cur + weight);
+        const uint32_t prev = atomicCAS(w, old, old + ((nf - cur) << shift));
         if (prev == old) return cur == 0;
         old = prev;
     }
@@ -731,52 +782,30 @@ __global__ void k_bin_spill(const SketchDev *__restrict__ sk, BinGeom g)
     uint64_t fresh = 0;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const unsigned long long e = g.spill[i];
-        const int t = (int)(e >> 32);
-        const bool was_zero = table_inc_bin(sk, t, e & 0xffffffffull);
+        const int t = (int)((e >> 32) & 0xffu);
+        const bool was_zero = table_add_bin(sk, t, e & 0xffffffffull, (uint32_t)((e >> 40) & 0xffu) + 1u);
         fresh += (was_zero && t == 0) ? 1 : 0;
     }
     fresh = wave_sum_u64(fresh);
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&g.ctr[3], (unsigned long long)fresh);
 }
 
-// grow-only scratch shared by all calls of this process (one process per GPU)
-struct Scratch {
-    void *p = nullptr;
-    size_t bytes = 0;
-    hipError_t need(size_t n)
-    {
-        if (n <= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = 0;
-        hipError_t e = hipMalloc(&p, n);
-        if (e == hipSuccess) bytes = n;
-        return e;
-    }
-};
 // one grow-only arena per stream, so host threads counting different samples do not share buffers
-std::map<hipStream_t, Scratch> g_scratch;
+std::map<hipStream_t, KvArena> g_scratch;
 std::mutex g_scratch_mu;
 
-Scratch &scratch_for(hipStream_t st)
+KvArena &scratch_for(hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     return g_scratch[st];
 }
 
 template <typename K>
-void ensure_dynamic_lds(K kernel, size_t bytes)
-{
-    static std::mutex mu;
-    static std::map<const void *, size_t> granted;
-    std::lock_guard<std::mutex> lk(mu);
-    size_t &have = granted[(const void *)kernel];
-    if (bytes > have) {
-        (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        have = bytes;
-    }
-}
+void ensure_dynamic_lds(K kernel, size_t bytes) { kv_ensure_dynamic_lds((const void *)kernel, bytes); }
 
-int device_cus()
+}  // namespace
+
+int kv_device_cus()
 {
     static int cus = 0;
     if (cus == 0) {
@@ -787,10 +816,6 @@ int device_cus()
     }
     return cus;
 }
-
-inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
-
-}  // namespace
 
 // linear-counting estimate of the distinct k-mers behind an occupancy of table 0
 double kv_estimate_distinct(uint64_t occupied, uint64_t size)
@@ -808,23 +833,22 @@ bool kv_binned_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_km
     uint64_t pmin = UINT64_MAX, pmax = 0;
     for (int t = 0; t < s->h.ntables; ++t) { pmin = std::min(pmin, s->h.size[t]); pmax = std::max(pmax, s->h.size[t]); }
     if (pmax > (uint64_t)BIN_C * BIN_MAX_F * 65536ull) return false;      // <= 2^31 bins per table
-    if (force && strcmp(force, "binned") == 0) return reads ? reads->n_tiles > 0 : n_kmers > 0;
+    if (force && (strcmp(force, "binned") == 0 || strcmp(force, "skm") == 0)) return reads ? reads->n_tiles > 0 : n_kmers > 0;
     const uint64_t expected = nbands > 0 ? n_kmers / (uint64_t)nbands : n_kmers;
     // worth it once the batch touches the tables about as densely as streaming them costs
     return pmin >= (1ull << 20) && expected >= (1ull << 22) && expected * 8 >= pmax;
 }
 
-// returns KV_OK, or KV_ERR_CAPACITY when the spill list overflowed (tables untouched: caller falls back)
-int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_list, uint32_t list_stride,
-                      const ConsumeFilter &filter, const kv_sketch *mask, uint64_t n_kmers, int nbands, uint64_t *n_added)
+int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, uint64_t work_units, uint32_t lds_front,
+                uint32_t nwgA_fixed, bool weighted, BinPlan *plan)
 {
-    // source: the packed reads (hash in stage A) or, when reads == nullptr, n_kmers hashes at d_list[i * list_stride]
     hipStream_t st = kv_stream();
-    Scratch &scratch = scratch_for(st);
-    BinGeom g;
+    KvArena &scratch = scratch_for(st);
+    BinGeom &g = plan->g;
     memset(&g, 0, sizeof(g));
+    plan->weighted = weighted;
     g.T = s->h.ntables;
-    g.tile_lds = reads ? reads->tile_lds_bytes : 0u;
+    g.tile_lds = lds_front;
     uint64_t pmin = UINT64_MAX;
     uint32_t maxsl = 1;
     for (int t = 0; t < g.T; ++t) {
@@ -832,12 +856,14 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
         maxsl = std::max(maxsl, g.nslices[t]);
         pmin = std::min(pmin, s->h.size[t]);
     }
+    plan->maxsl = maxsl;
     // Coarse buckets per table: as few as keep stage B's fan-out F at <= 384 slices per bucket (its u16 rings then
     // fit three workgroups per CU), between 4 and 32 with 512-thread stage-A workgroups; 64 buckets / 1024 threads
     // beyond 2^30 bins.  Fewer buckets = fewer distinct lines per stage-A store instruction (that stage is bound by
     // L2 write requests): measured per 525 M k-mers into 5e8-bin tables, A/B/C = 10.5/5.0/4.0 ms with 32 buckets,
     // 8.7/4.9/4.0 with 20, 8.3/6.1/4.0 with 16 (F = 478: rings too big for three workgroups).
     const int cmax = maxsl <= 32u * BIN_MAX_F ? (int)std::min<uint32_t>(32u, std::max<uint32_t>(4u, (maxsl + 383u) / 384u)) : BIN_C;
+    plan->cmax = cmax;
     g.F = (int)((maxsl + (uint32_t)cmax - 1) / (uint32_t)cmax);
     g.C = (int)((maxsl + (uint32_t)g.F - 1) / (uint32_t)g.F);
     g.recipF = g.F == 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)g.F + 1);   // F == 1: kernels take slice as is
@@ -849,28 +875,30 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
     const uint32_t budgetA = cmax <= 32 ? 8192u : 16384u;
     g.ringA = ring_for((uint32_t)(g.T * g.C), budgetA);
     g.ringB = ring_for((uint32_t)g.F, BIN_B_BUDGET);
-    const int cus = device_cus();
-    const double expected = (double)(nbands > 0 && !filter.use_mask ? n_kmers / (uint64_t)nbands + 1 : n_kmers);
+    const int cus = kv_device_cus();
+    const double expected = (double)(nbands > 0 && !use_mask ? n_items_max / (uint64_t)nbands + 1 : n_items_max);
     const uint64_t ns = (uint64_t)g.T * g.C;
     // writers: stage A = persistent workgroups (tiles dealt round-robin, so their loads are equal
     // to within one tile); stage B = nwgB workgroups per coarse bucket, ~256 k items each
     const uint32_t threadsA = cmax <= 32 ? 512u : 1024u;
-    const uint64_t work_units = reads ? reads->n_tiles : (n_kmers + (uint64_t)threadsA * BIN_LIST_ROUNDS - 1) / ((uint64_t)threadsA * BIN_LIST_ROUNDS);
-    g.nwgA = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(work_units, 1), (cmax <= 32 ? 3u : 1u) * (uint32_t)cus);
+    plan->threadsA = threadsA;
+    if (nwgA_fixed) g.nwgA = nwgA_fixed;
+    else g.nwgA = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(work_units, 1), (cmax <= 32 ? 3u : 1u) * (uint32_t)cus);
     {
-        const uint64_t avg = (work_units + g.nwgA - 1) / g.nwgA;
+        const uint64_t avg = (std::max<uint64_t>(work_units, 1) + g.nwgA - 1) / g.nwgA;
         g.quotaA = (uint32_t)std::min<uint64_t>(avg + avg / 2 + 1, 0xffffffffull);   // matches the 1.5x slack of cap1
     }
     const double per_bucket = expected * std::min(1.0, (double)g.F * 65536.0 / (double)pmin);
     const double per_slice = expected * std::min(1.0, 65536.0 / (double)pmin);
     g.nwgB = (uint32_t)std::max(1.0, std::min((double)std::min<uint32_t>(g.nwgA, 512), std::ceil(per_bucket / 524288.0)));
     const double m1 = per_bucket / g.nwgA, m2 = per_slice / g.nwgB;
-    g.cap1 = round_up((uint64_t)(m1 * 1.5 + 8.0 * std::sqrt(m1)) + 2048, 64);   // tiles are dealt dynamically: shares are uneven
-    g.cap2 = round_up((uint64_t)(m2 * 1.05 + 8.0 * std::sqrt(m2)) + 64, 64);
+    g.cap1 = kv_round_up((uint64_t)(m1 * 1.5 + 8.0 * std::sqrt(m1)) + 2048, 64);   // tiles are dealt dynamically: shares are uneven
+    g.cap2 = kv_round_up((uint64_t)(m2 * 1.05 + 8.0 * std::sqrt(m2)) + 64, 64);
     g.spill_cap = std::max<uint64_t>(1u << 20, (uint64_t)(expected * g.T / 8));
-    const size_t b_buf1 = round_up(ns * g.nwgA * g.cap1 * 4, 256), b_buf2 = round_up(ns * g.F * g.nwgB * g.cap2 * 2, 256);
-    const size_t b_cnt1 = round_up(ns * g.nwgA * 4, 256), b_cnt2 = round_up(ns * g.F * g.nwgB * 4, 256);
-    const size_t b_spill = round_up(g.spill_cap * 8, 256), b_ctr = 256;
+    const size_t fine_bytes = weighted ? 4 : 2;
+    const size_t b_buf1 = kv_round_up(ns * g.nwgA * g.cap1 * 4, 256), b_buf2 = kv_round_up(ns * g.F * g.nwgB * g.cap2 * fine_bytes, 256);
+    const size_t b_cnt1 = kv_round_up(ns * g.nwgA * 4, 256), b_cnt2 = kv_round_up(ns * g.F * g.nwgB * 4, 256);
+    const size_t b_spill = kv_round_up(g.spill_cap * 8, 256), b_ctr = 256;
     KV_HIP(scratch.need(b_buf1 + b_buf2 + b_cnt1 + b_cnt2 + b_spill + b_ctr));
     unsigned char *base = (unsigned char *)scratch.p;
     g.gbuf1 = (uint32_t *)base; base += b_buf1;
@@ -880,7 +908,89 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
     g.spill = (unsigned long long *)base; base += b_spill;
     g.ctr = (unsigned long long *)base;
     KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));   // every segment count is written by its owner: no other memset
+    return KV_OK;
+}
 
+int kv_bin_finish(kv_sketch *s, BinPlan &plan, bool added_from_ctr, uint64_t n_added_fixed, uint64_t *n_added)
+{
+    hipStream_t st = kv_stream();
+    BinGeom &g = plan.g;
+    const uint64_t ns = (uint64_t)g.T * g.C;
+    {
+        KvProfScope prof(plan.weighted ? "k_bin_split_w" : "k_bin_split");
+        const size_t isz = plan.weighted ? 4 : 2;
+        const size_t lds = (((size_t)g.F * g.ringB * isz + 15) & ~(size_t)15) + (size_t)g.F * 2 * 4;
+        if (plan.weighted) {
+            ensure_dynamic_lds(k_bin_split<true>, lds);
+            hipLaunchKernelGGL(k_bin_split<true>, dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
+        } else {
+            ensure_dynamic_lds(k_bin_split<false>, lds);
+            hipLaunchKernelGGL(k_bin_split<false>, dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
+        }
+    }
+    {
+        KvProfScope prof(plan.weighted ? "k_bin_apply_w" : "k_bin_apply");
+        const dim3 gridC(plan.maxsl, (unsigned)g.T);
+        const SketchDev *d = (const SketchDev *)s->d_desc;
+#define KV_LAUNCH_APPLY(ST_, W_) hipLaunchKernelGGL((k_bin_apply<ST_, W_>), gridC, dim3(BIN_C_THREADS), 0, st, d, g)
+        if (plan.weighted) {
+            if (s->h.storage == ST_BYTE) KV_LAUNCH_APPLY(ST_BYTE, true);
+            else if (s->h.storage == ST_NIBBLE) KV_LAUNCH_APPLY(ST_NIBBLE, true);
+            else KV_LAUNCH_APPLY(ST_BIT, true);
+        } else {
+            if (s->h.storage == ST_BYTE) KV_LAUNCH_APPLY(ST_BYTE, false);
+            else if (s->h.storage == ST_NIBBLE) KV_LAUNCH_APPLY(ST_NIBBLE, false);
+            else KV_LAUNCH_APPLY(ST_BIT, false);
+        }
+#undef KV_LAUNCH_APPLY
+    }
+    {
+        KvProfScope prof("k_bin_spill");   // usually a handful of items; the kernels check the overflow flag themselves
+        hipLaunchKernelGGL(k_bin_spill, dim3(256), dim3(256), 0, st, (const SketchDev *)s->d_desc, g);
+    }
+    KV_HIP(hipGetLastError());
+    unsigned long long ctr[4] = {0, 0, 0, 0};
+    KV_HIP(hipMemcpyAsync(ctr, g.ctr, sizeof(ctr), hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    if (ctr[1] != 0) {
+        kv_set_error("partitioned count: spill list overflow (%llu items)", ctr[0]);
+        return KV_ERR_CAPACITY;
+    }
+    *n_added = added_from_ctr ? ctr[2] : n_added_fixed;
+    // exact occupancy bookkeeping; n_unique_kmers as a linear-counting estimate (DESIGN.md section 2)
+    if (s->occ_dirty) {
+        int rc = kv_sketch_refresh_occupancy(s);   // recount includes this batch
+        if (rc != KV_OK) return rc;
+        s->n_unique = (uint64_t)(kv_estimate_distinct(s->n_occupied, s->h.size[0]) + 0.5);
+    } else {
+        const double before = kv_estimate_distinct(s->n_occupied, s->h.size[0]);
+        s->n_occupied += ctr[3];
+        const double after = kv_estimate_distinct(s->n_occupied, s->h.size[0]);
+        s->n_unique += (uint64_t)(after - before + 0.5);
+    }
+    return KV_OK;
+}
+
+// returns KV_OK, or KV_ERR_CAPACITY when the spill list overflowed (tables untouched: caller falls back)
+int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_list, uint32_t list_stride,
+                      const ConsumeFilter &filter, const kv_sketch *mask, uint64_t n_kmers, int nbands, uint64_t *n_added)
+{
+    // source: the packed reads (hash in stage A) or, when reads == nullptr, n_kmers hashes at d_list[i * list_stride]
+    hipStream_t st = kv_stream();
+    BinPlan plan;
+    {
+        // the stage-A workgroup size depends on the geometry, which depends only on the table sizes: probe it first
+        uint32_t maxsl = 1;
+        for (int t = 0; t < s->h.ntables; ++t) maxsl = std::max(maxsl, (uint32_t)((s->h.size[t] + 65535) >> 16));
+        const uint32_t threadsA = maxsl <= 32u * BIN_MAX_F ? 512u : 1024u;
+        const uint64_t work_units = reads ? reads->n_tiles
+                                          : (n_kmers + (uint64_t)threadsA * BIN_LIST_ROUNDS - 1) / ((uint64_t)threadsA * BIN_LIST_ROUNDS);
+        const int rc = kv_bin_plan(s, n_kmers, nbands, filter.use_mask != 0, work_units, reads ? reads->tile_lds_bytes : 0u, 0u, false, &plan);
+        if (rc != KV_OK) return rc;
+    }
+    BinGeom &g = plan.g;
+    const int cmax = plan.cmax;
+    const uint64_t ns = (uint64_t)g.T * g.C;
     const SketchDev *d_mask = mask ? mask->d_desc : nullptr;
     if (reads) {
         // default: direct stores through LDS cursors (k_bin_hash_direct); KV_BIN_DIRECT=0 selects the LDS-ring
@@ -931,42 +1041,5 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
             hipLaunchKernelGGL((k_bin_list<1024>), dim3(g.nwgA), dim3(1024), 0, st, d_list, n_kmers, list_stride,
                                (const SketchDev *)s->d_desc, g);
     }
-    {
-        KvProfScope prof("k_bin_split");
-        const size_t lds = (((size_t)g.F * g.ringB * 2 + 15) & ~(size_t)15) + (size_t)g.F * 2 * 4;
-        ensure_dynamic_lds(k_bin_split, lds);
-        hipLaunchKernelGGL(k_bin_split, dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
-    }
-    {
-        KvProfScope prof("k_bin_apply");
-        const dim3 gridC(maxsl, (unsigned)g.T);
-        if (s->h.storage == ST_BYTE) hipLaunchKernelGGL(k_bin_apply<ST_BYTE>, gridC, dim3(BIN_C_THREADS), 0, st, (const SketchDev *)s->d_desc, g);
-        else if (s->h.storage == ST_NIBBLE) hipLaunchKernelGGL(k_bin_apply<ST_NIBBLE>, gridC, dim3(BIN_C_THREADS), 0, st, (const SketchDev *)s->d_desc, g);
-        else hipLaunchKernelGGL(k_bin_apply<ST_BIT>, gridC, dim3(BIN_C_THREADS), 0, st, (const SketchDev *)s->d_desc, g);
-    }
-    {
-        KvProfScope prof("k_bin_spill");   // usually a handful of items; the kernels check the overflow flag themselves
-        hipLaunchKernelGGL(k_bin_spill, dim3(256), dim3(256), 0, st, (const SketchDev *)s->d_desc, g);
-    }
-    KV_HIP(hipGetLastError());
-    unsigned long long ctr[4] = {0, 0, 0, 0};
-    KV_HIP(hipMemcpyAsync(ctr, g.ctr, sizeof(ctr), hipMemcpyDeviceToHost, st));
-    KV_HIP(hipStreamSynchronize(st));
-    if (ctr[1] != 0) {
-        kv_set_error("partitioned count: spill list overflow (%llu items)", ctr[0]);
-        return KV_ERR_CAPACITY;
-    }
-    *n_added = reads ? ctr[2] : n_kmers;
-    // exact occupancy bookkeeping; n_unique_kmers as a linear-counting estimate (DESIGN.md section 2)
-    if (s->occ_dirty) {
-        int rc = kv_sketch_refresh_occupancy(s);   // recount includes this batch
-        if (rc != KV_OK) return rc;
-        s->n_unique = (uint64_t)(kv_estimate_distinct(s->n_occupied, s->h.size[0]) + 0.5);
-    } else {
-        const double before = kv_estimate_distinct(s->n_occupied, s->h.size[0]);
-        s->n_occupied += ctr[3];
-        const double after = kv_estimate_distinct(s->n_occupied, s->h.size[0]);
-        s->n_unique += (uint64_t)(after - before + 0.5);
-    }
-    return KV_OK;
+    return kv_bin_finish(s, plan, reads != nullptr, n_kmers, n_added);
 }

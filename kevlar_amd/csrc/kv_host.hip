@@ -20,6 +20,12 @@ void kv_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+uint64_t kv_next_uid()
+{
+    static std::atomic<uint64_t> next{1};
+    return next.fetch_add(1);
+}
+
 static thread_local hipStream_t g_stream = nullptr;   // per host thread: concurrent samples use concurrent streams
 hipStream_t kv_stream() { return g_stream; }
 
@@ -633,9 +639,11 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
     {
         const uint32_t budget = KV_TILE_LDS_BYTES - 64;
         uint32_t used = 0, count = 0, first = 0;
+        uint32_t run_bases = 0, most_bases = 0;
         auto close_run = [&](uint32_t next_first) {
             if (count) tiles.push_back(TileDesc{first, count, 0u, 0u});
-            used = 0; count = 0; first = next_first;
+            most_bases = std::max(most_bases, run_bases);
+            used = 0; count = 0; first = next_first; run_bases = 0;
         };
         for (uint64_t i = 0; i < n_reads; ++i) {
             const uint32_t need = 2 * ((r->h_len[i] + KV_READ_PAD + 3) & ~3u);
@@ -643,13 +651,15 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
                 close_run((uint32_t)i + 1);
                 for (uint32_t start = 0; start < r->h_len[i]; start += KV_SEG_BASES)
                     tiles.push_back(TileDesc{(uint32_t)i, 1u, start, 1u});
+                most_bases = std::max<uint32_t>(most_bases, std::min<uint32_t>(r->h_len[i], KV_SEG_BASES + KV_MAX_K));
                 continue;
             }
             if (count > 0 && (count == KV_TILE_MAX_READS || used + need > budget)) close_run((uint32_t)i);
             if (count == 0) first = (uint32_t)i;
-            used += need; count += 1;
+            used += need; count += 1; run_bases += r->h_len[i];
         }
         close_run((uint32_t)n_reads);
+        r->tile_max_bases = most_bases;
         r->n_tiles = (uint32_t)tiles.size();
         r->tile_lds_bytes = KV_TILE_LDS_BYTES + 256;   // + rolling-window over-read
         if (tiles.empty()) tiles.push_back(TileDesc{0u, 0u, 0u, 0u});
@@ -711,6 +721,7 @@ extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, u
     for (uint64_t i = 0; i < n_reads; i += per_tile)
         tiles.push_back(TileDesc{(uint32_t)i, (uint32_t)std::min<uint64_t>(per_tile, n_reads - i), 0u, 0u});
     r->n_tiles = (uint32_t)tiles.size();
+    r->tile_max_bases = (uint32_t)std::min<uint64_t>(per_tile, n_reads) * read_len;
     if (tiles.empty()) tiles.push_back(TileDesc{0u, 0u, 0u, 0u});
     r->tile_lds_bytes = KV_TILE_LDS_BYTES + 256;
     hipError_t e = hipMalloc((void **)&r->d_words, (r->n_words + 4) * 4);   // + slack: k-mer extraction reads up to two words ahead

@@ -62,7 +62,10 @@ struct TileDesc {
 
 // Packed read batch.  Read r occupies words [woff[r], woff[r+1]) of `words`; base j sits in
 // word woff[r] + j/16 at bits 2*(j%16), code A=0 C=1 G=2 T=3.
+uint64_t kv_next_uid();   // process-wide, never reused (device pointers are)
+
 struct kv_reads {
+    uint64_t uid = kv_next_uid();
     uint64_t n_reads, n_bases, n_words;
     uint32_t *d_words;
     uint64_t *d_woff;   // n_reads + 1
@@ -72,6 +75,7 @@ struct kv_reads {
     uint32_t n_tiles;
     uint32_t tile_lds_bytes;  // dynamic LDS the tile kernels need for this batch (>= KV_TILE_LDS_BYTES)
     uint32_t max_len;
+    uint32_t tile_max_bases = 0;    // most bases any tile stages (a segment tile: KV_SEG_BASES + KV_MAX_K); 0 = not computed
     std::vector<uint32_t> h_len;    // host copies (k-mer counting, hit bookkeeping)
     int nk_cached_k = -1;           // kv_reads_num_kmers memo (the length vector can hold 1e7+ entries)
     uint64_t nk_cached = 0;
@@ -131,6 +135,15 @@ bool kv_binned_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_km
 int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_list, uint32_t list_stride,
                       const ConsumeFilter &filter, const kv_sketch *mask, uint64_t n_kmers, int nbands, uint64_t *n_added);
 double kv_estimate_distinct(uint64_t occupied, uint64_t size);
+
+// super-k-mer front end (kv_skm.hip): the batch is deduplicated in minimizer buckets and each DISTINCT k-mer is
+// hashed, filtered and counted (or evaluated by the novel scan) once
+struct NovelParams;
+bool kv_skm_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_kmers, bool for_scan);
+int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &filter, const kv_sketch *mask,
+                   uint64_t n_kmers, int nbands, uint64_t *n_added);
+// sets the mask bit of every interesting k-mer of reads[first_read:] (p.mask / p.mask_stride) and p.tile_count
+int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_kmers);
 
 // tile geometry of the hashing kernels
 #define KV_TILE_THREADS 256

@@ -199,6 +199,16 @@ extern "C" int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int b
     kv_reads_num_kmers(reads, s->h.ksize, &n_kmers);
     if (kv_binned_eligible(s, reads, n_kmers, nbands)) {
         uint64_t added = 0;
+        // large batches of short k: count every distinct k-mer once with its multiplicity (kv_skm.hip); the
+        // one-item-per-k-mer partition is its fallback, the atomic kernel the fallback of both
+        if (kv_skm_eligible(s, reads, n_kmers, false)) {
+            const int rc = kv_consume_skm(s, reads, p, mask, n_kmers, nbands, &added);
+            if (rc == KV_OK) {
+                if (n_kmers_out) *n_kmers_out = added;
+                return KV_OK;
+            }
+            if (rc != KV_ERR_CAPACITY) return rc;
+        }
         const int rc = kv_consume_binned(s, reads, nullptr, 1, p, mask, n_kmers, nbands, &added);
         if (rc == KV_OK) {
             if (n_kmers_out) *n_kmers_out = added;

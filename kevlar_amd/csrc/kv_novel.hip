@@ -14,72 +14,9 @@
 #include <algorithm>
 #include <map>
 
-#include "kv_device.h"
+#include "kv_novel_device.h"
 
 namespace {
-
-struct NovelParams {
-    HashParams hp;
-    int ncase, nctrl;
-    const SketchDev *sk[KV_MAX_SAMPLES];  // cases first, then controls
-    int case_min, ctrl_max, screen;
-    int band_mode, nbands, band;
-    uint64_t band_lo, band_hi;
-    uint64_t first_read;
-    uint8_t *disc_flag;     // per read: dropped by the abundance screen (NULL when screen is off)
-    uint32_t *mask;         // bit (read * mask_stride + offset)
-    uint64_t mask_stride;
-    uint32_t *tile_count;   // hits per tile
-    const uint64_t *tile_base;
-    uint32_t *hit_read, *hit_off;
-    uint8_t *hit_abund;
-    unsigned long long *vcache;   // hashes proven rejected by a control (NULL = off)
-    int vcache_shift;             // slot = h >> shift
-    int vcache_sets;              // k_novel_mark: 8-entry sets indexed by the k-mer's minimizer (0 = direct-mapped by hash)
-    uint32_t vcache_set_mask;     // number of sets - 1
-    int vcache_window;            // m-mers per k-mer considered for the minimizer
-};
-
-__device__ __forceinline__ bool band_pass(const NovelParams &p, uint64_t h)
-{
-    if (p.band_mode == KV_BAND_RANGE) return h >= p.band_lo && h < p.band_hi;
-    if (p.band_mode == KV_BAND_REFQUIRK) return (h & (uint64_t)(p.nbands - 1)) == (uint64_t)(int64_t)(p.band - 1);
-    return true;
-}
-
-// Table descriptors of every sample, copied to LDS once per workgroup: the probe loops then read
-// sizes / reciprocals / base pointers with broadcast LDS loads instead of three dependent global
-// loads per probe (which is what the compiler emits for `p.sk[c]->size[t]` inside a divergent loop).
-struct ProbeDesc {
-    uint64_t size, magic;
-    const uint8_t *tab;
-};
-struct NovelShared {
-    ProbeDesc d[KV_MAX_SAMPLES * KV_MAX_TABLES];
-    int ntab[KV_MAX_SAMPLES];
-    int storage[KV_MAX_SAMPLES];
-};
-
-__device__ __forceinline__ void load_descs(NovelShared &ns, const NovelParams &p)
-{
-    const int S = p.ncase + p.nctrl;
-    for (int i = threadIdx.x; i < S * KV_MAX_TABLES; i += blockDim.x) {
-        const int c = i / KV_MAX_TABLES, t = i % KV_MAX_TABLES;
-        const SketchDev *s = p.sk[c];
-        if (t < s->ntables) { ns.d[i].size = s->size[t]; ns.d[i].magic = s->magic[t]; ns.d[i].tab = s->tab[t]; }
-        if (t == 0) { ns.ntab[c] = s->ntables; ns.storage[c] = s->storage; }
-    }
-}
-
-__device__ __forceinline__ uint32_t probe(const NovelShared &ns, int c, int t, uint64_t h)
-{
-    const ProbeDesc &d = ns.d[c * KV_MAX_TABLES + t];
-    const uint64_t bin = fastmod(h, d.size, d.magic);
-    const int st = ns.storage[c];
-    if (st == ST_BYTE) return d.tab[bin];
-    if (st == ST_NIBBLE) return (d.tab[bin >> 1] >> ((bin & 1) ? 0 : 4)) & 15u;
-    return (d.tab[bin >> 3] >> (bin & 7)) & 1u;
-}
 
 // Set index of the verdict cache for k_novel_mark (16 <= k <= 32): a hash of the k-mer's minimizer -- the
 // smallest canonical (k-2)-mer among its three.  It is a pure function of the k-mer and strand-symmetric like
@@ -118,41 +55,6 @@ __device__ __forceinline__ uint32_t kmer_minimizer_key(const uint32_t *__restric
         best = v < best ? v : best;
     }
     return best;
-}
-
-// The abundance test (screen off).  Same predicate as kmer_is_interesting(), cheapest evidence first:
-// a control passes as soon as ONE table is <= ctrl_max (its Count-Min minimum is then <= ctrl_max) and
-// rejects only after all T exceed it; a case fails as soon as ONE table is < case_min.  Measured: the
-// scan is bound by the rate of random 64-B requests (~55 G/s), so probes are spent one at a time --
-// issuing a control's T probes together was slower.
-//
-// Verdict cache: whether a k-mer is rejected by the controls is a pure function of its 64-bit hash
-// (every bin derives from it), and an inherited k-mer recurs once per unit of coverage.  A direct-
-// mapped table of hashes already proven "rejected by a control" turns its T probes into one.  Entries
-// are single 8-byte words, races only cost a re-evaluation, a wrong answer is impossible: a slot
-// either holds exactly this hash (proven) or it does not.
-__device__ __forceinline__ bool novel_test_fast(const NovelShared &ns, const NovelParams &p, uint64_t h,
-                                                unsigned long long *slot, unsigned long long cached)
-{
-    if (slot && cached == h) return false;
-    // table 0 of every case first: a sequencing-error k-mer (case count 1) leaves here after one probe
-    for (int c = 0; c < p.ncase; ++c)
-        if ((int)probe(ns, c, 0, h) < p.case_min) return false;
-    for (int c = p.ncase; c < p.ncase + p.nctrl; ++c) {
-        const int T = ns.ntab[c];
-        bool pass = false;
-        for (int t = 0; t < T && !pass; ++t) pass = (int)probe(ns, c, t, h) <= p.ctrl_max;
-        if (!pass) {
-            if (slot) __hip_atomic_store(slot, (unsigned long long)h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-    }
-    for (int c = 0; c < p.ncase; ++c) {
-        const int T = ns.ntab[c];
-        for (int t = 1; t < T; ++t)
-            if ((int)probe(ns, c, t, h) < p.case_min) return false;
-    }
-    return true;
 }
 
 // With --abund-screen the reference order is kept (cases in order with full minima, novel.py:36-44)
@@ -544,12 +446,20 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     hipStream_t st = kv_stream();
     uint64_t n_kmers = 0;
     kv_reads_num_kmers(reads, k, &n_kmers);
-    { const int rc = attach_vcache(p, ctrls, ncase, nctrl, ctrl_max, n_kmers, st); if (rc != KV_OK) return rc; }
-    if (p.vcache && k >= 16 && k <= 32 && !(vc_sets_env() == 0)) {
-        p.vcache_sets = 1;
-        p.vcache_window = VC_WINDOW;
-        p.vcache_set_mask = (uint32_t)((1ull << (64 - p.vcache_shift - 3)) - 1ull);   // entries / 8 sets
-    }
+    // large batches: evaluate every DISTINCT k-mer once over the batch's super-k-mer buckets (kv_skm.hip); otherwise
+    // (and as the fallback) every k-mer of every read, with the verdict cache absorbing the repeats
+    bool use_skm = p.screen == 0 && kv_skm_eligible(cases[0], reads, n_kmers, true);
+    auto prepare_tile_scan = [&]() -> int {
+        const int rc = attach_vcache(p, ctrls, ncase, nctrl, ctrl_max, n_kmers, st);
+        if (rc != KV_OK) return rc;
+        if (p.vcache && k >= 16 && k <= 32 && !(vc_sets_env() == 0)) {
+            p.vcache_sets = 1;
+            p.vcache_window = VC_WINDOW;
+            p.vcache_set_mask = (uint32_t)((1ull << (64 - p.vcache_shift - 3)) - 1ull);   // entries / 8 sets
+        }
+        return KV_OK;
+    };
+    if (!use_skm) { const int rc = prepare_tile_scan(); if (rc != KV_OK) return rc; }
 
     kv_hits *hits = new kv_hits();
     hits->nsamples = S;
@@ -596,8 +506,21 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     uint64_t *d_tbase_p = (uint64_t *)wp;
     p.tile_base = d_tbase_p;
     uint64_t nhits = 0;
+    if (e == hipSuccess && use_skm) {
+        const int rc = kv_skm_novel_mark(reads, p, n_kmers);
+        if (rc == KV_ERR_CAPACITY) {
+            // every bit set so far is a true hit, so the tile scan can simply run on top of the same mask
+            use_skm = false;
+            const int rc2 = prepare_tile_scan();
+            if (rc2 != KV_OK) { delete hits; *out = nullptr; return rc2; }
+        } else if (rc != KV_OK) {
+            delete hits;
+            *out = nullptr;
+            return rc;
+        }
+    }
     if (e == hipSuccess) {
-        {
+        if (!use_skm) {
             KvProfScope prof("k_novel_mark");
             kv_ensure_dynamic_lds((const void *)k_novel_mark, reads->tile_lds_bytes);
             hipLaunchKernelGGL(k_novel_mark, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, st, reads_dev(reads), p);

@@ -1,0 +1,107 @@
+// kv_novel_device.h -- the abundance test of the novel scan, kmer_is_interesting() (kevlar/novel.py:21-53), shared by
+// the tile scan (kv_novel.hip) and the per-distinct-k-mer scan over super-k-mer buckets (kv_skm.hip).
+#pragma once
+#include "kv_device.h"
+
+struct NovelParams {
+    HashParams hp;
+    int ncase, nctrl;
+    const SketchDev *sk[KV_MAX_SAMPLES];  // cases first, then controls
+    int case_min, ctrl_max, screen;
+    int band_mode, nbands, band;
+    uint64_t band_lo, band_hi;
+    uint64_t first_read;
+    uint8_t *disc_flag;     // per read: dropped by the abundance screen (NULL when screen is off)
+    uint32_t *mask;         // bit (read * mask_stride + offset)
+    uint64_t mask_stride;
+    uint32_t *tile_count;   // hits per tile
+    const uint64_t *tile_base;
+    uint32_t *hit_read, *hit_off;
+    uint8_t *hit_abund;
+    unsigned long long *vcache;   // hashes proven rejected by a control (NULL = off)
+    int vcache_shift;             // slot = h >> shift
+    int vcache_sets;              // k_novel_mark: 8-entry sets indexed by the k-mer's minimizer (0 = direct-mapped by hash)
+    uint32_t vcache_set_mask;     // number of sets - 1
+    int vcache_window;            // m-mers per k-mer considered for the minimizer
+};
+
+// Table descriptors of every sample, copied to LDS once per workgroup: the probe loops then read
+// sizes / reciprocals / base pointers with broadcast LDS loads instead of three dependent global
+// loads per probe (which is what the compiler emits for `p.sk[c]->size[t]` inside a divergent loop).
+struct ProbeDesc {
+    uint64_t size, magic;
+    const uint8_t *tab;
+};
+struct NovelShared {
+    ProbeDesc d[KV_MAX_SAMPLES * KV_MAX_TABLES];
+    int ntab[KV_MAX_SAMPLES];
+    int storage[KV_MAX_SAMPLES];
+};
+
+namespace {
+
+__device__ __forceinline__ bool band_pass(const NovelParams &p, uint64_t h)
+{
+    if (p.band_mode == KV_BAND_RANGE) return h >= p.band_lo && h < p.band_hi;
+    if (p.band_mode == KV_BAND_REFQUIRK) return (h & (uint64_t)(p.nbands - 1)) == (uint64_t)(int64_t)(p.band - 1);
+    return true;
+}
+
+__device__ __forceinline__ void load_descs(NovelShared &ns, const NovelParams &p)
+{
+    const int S = p.ncase + p.nctrl;
+    for (int i = threadIdx.x; i < S * KV_MAX_TABLES; i += blockDim.x) {
+        const int c = i / KV_MAX_TABLES, t = i % KV_MAX_TABLES;
+        const SketchDev *s = p.sk[c];
+        if (t < s->ntables) { ns.d[i].size = s->size[t]; ns.d[i].magic = s->magic[t]; ns.d[i].tab = s->tab[t]; }
+        if (t == 0) { ns.ntab[c] = s->ntables; ns.storage[c] = s->storage; }
+    }
+}
+
+__device__ __forceinline__ uint32_t probe(const NovelShared &ns, int c, int t, uint64_t h)
+{
+    const ProbeDesc &d = ns.d[c * KV_MAX_TABLES + t];
+    const uint64_t bin = fastmod(h, d.size, d.magic);
+    const int st = ns.storage[c];
+    if (st == ST_BYTE) return d.tab[bin];
+    if (st == ST_NIBBLE) return (d.tab[bin >> 1] >> ((bin & 1) ? 0 : 4)) & 15u;
+    return (d.tab[bin >> 3] >> (bin & 7)) & 1u;
+}
+
+// The abundance test (screen off).  Same predicate as kmer_is_interesting(), cheapest evidence first:
+// a control passes as soon as ONE table is <= ctrl_max (its Count-Min minimum is then <= ctrl_max) and
+// rejects only after all T exceed it; a case fails as soon as ONE table is < case_min.  Measured: the
+// scan is bound by the rate of random 64-B requests (~55 G/s), so probes are spent one at a time --
+// issuing a control's T probes together was slower.
+//
+// Verdict cache: whether a k-mer is rejected by the controls is a pure function of its 64-bit hash
+// (every bin derives from it), and an inherited k-mer recurs once per unit of coverage.  A direct-
+// mapped table of hashes already proven "rejected by a control" turns its T probes into one.  Entries
+// are single 8-byte words, races only cost a re-evaluation, a wrong answer is impossible: a slot
+// either holds exactly this hash (proven) or it does not (0 = empty; hash 0 itself is never cached).
+__device__ __forceinline__ bool novel_test_fast(const NovelShared &ns, const NovelParams &p, uint64_t h,
+                                                unsigned long long *slot, unsigned long long cached)
+{
+    // 0 marks an empty cache entry, so the (one) k-mer hash 0 is never cached: it is always evaluated
+    if (slot && h != 0 && cached == h) return false;
+    // table 0 of every case first: a sequencing-error k-mer (case count 1) leaves here after one probe
+    for (int c = 0; c < p.ncase; ++c)
+        if ((int)probe(ns, c, 0, h) < p.case_min) return false;
+    for (int c = p.ncase; c < p.ncase + p.nctrl; ++c) {
+        const int T = ns.ntab[c];
+        bool pass = false;
+        for (int t = 0; t < T && !pass; ++t) pass = (int)probe(ns, c, t, h) <= p.ctrl_max;
+        if (!pass) {
+            if (slot && h != 0) __hip_atomic_store(slot, (unsigned long long)h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    for (int c = 0; c < p.ncase; ++c) {
+        const int T = ns.ntab[c];
+        for (int t = 1; t < T; ++t)
+            if ((int)probe(ns, c, t, h) < p.case_min) return false;
+    }
+    return true;
+}
+
+}  // namespace

@@ -1,0 +1,821 @@
+// kv_skm.hip -- super-k-mer front end of count and novel: every DISTINCT k-mer of a batch is hashed, filtered,
+// counted and evaluated once, however many reads contain it (kv_skm_device.h says why that is bit-identical).
+//
+//   S1  k_skm_emit    a workgroup per tile: the minimizer value of every k-mer (smallest mixed canonical m-mer
+//                     among its w = k - m + 1, by log-step window minima in LDS), the reads cut into runs of
+//                     consecutive k-mers of one minimizer bucket, each run stored as a record of 2-bit bases in
+//                     the coarse bucket's stream (private segment per workgroup, cursor in LDS, direct stores).
+//   S2  k_skm_split   every coarse stream is split into its F2 fine buckets (again private segments, direct stores);
+//                     a fine bucket holds ~8 k k-mer instances, all occurrences of ~2 k distinct k-mers.
+//   S3  k_skm_count   persistent workgroups take fine buckets: the canonical 2-bit k-mers are combined in an LDS hash
+//                     table (key -> count), then each distinct k-mer is expanded to ASCII (both strands), hashed
+//                     with the two murmurs, band/mask filtered, reduced modulo the T table sizes and appended as T
+//                     WEIGHTED items to the coarse buckets of the partitioned count (kv_binned.hip stages B and C).
+//   S6  k_skm_novel   same buckets of the case sample: combine, evaluate kmer_is_interesting() once per distinct
+//                     k-mer, then walk the records again and set the hit-mask bit of every occurrence of an
+//                     interesting k-mer; k_tile_hits + the ordinary emit kernels do the rest.
+//
+// Nothing here can lose a k-mer: a full segment, a full LDS table or an uncacheable key diverts single records to a
+// "loose" list that is processed one occurrence at a time (k_skm_loose_*); if that list overflows too, a flag makes
+// the apply stage leave the tables untouched and the caller falls back to the one-k-mer-at-a-time kernels.
+#include <algorithm>
+#include <cmath>
+
+#include "kv_binned.h"
+#include "kv_novel_device.h"
+#include "kv_skm_device.h"
+
+struct SkmGeom {
+    int k, m, w, wpow;               // wpow: largest power of two <= w
+    int kw, nbw, recw, ncap;         // key words, base words and total words of a record, most k-mers of a record
+    uint32_t C1, F2, fbits;          // coarse buckets, fine buckets per coarse bucket (2^fbits)
+    uint32_t nwg1, nwg2, quota1;     // writers of S1 (persistent workgroups) and S2 (workgroups per coarse bucket)
+    uint32_t cap1, cap2;             // records per private segment
+    uint32_t np_max;                 // most bases any tile stages
+    uint64_t stride;                 // record position = read * stride + offset
+    uint64_t *seg1; uint32_t *cnt1;  // [C1][nwg1][cap1] records / [C1][nwg1]
+    uint64_t *seg2; uint32_t *cnt2;  // [C1 * F2][nwg2][cap2] / [C1 * F2][nwg2]
+    uint64_t *loose; uint64_t loose_cap;
+    unsigned long long *ctr;         // [0] loose records, [1] failure, [2] S1 tile ticket, [3] count ticket, [4] scan ticket,
+                                     // [5] records emitted, [6] loose records after S1 + S2
+    uint32_t n_buckets, quota3;
+};
+
+namespace {
+
+#define SKM_THREADS1 512
+#define SKM_THREADS3 512
+#define SKM_MAXPROBE 24
+
+__device__ __forceinline__ void skm_store_record(uint64_t *dst, uint64_t hdr, const uint64_t *bw, int nbw)
+{
+    dst[0] = hdr;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < nbw) dst[1 + t] = bw[t];
+}
+
+__device__ __forceinline__ void skm_loose_push(const SkmGeom &sg, uint64_t hdr, const uint64_t *bw)
+{
+    const unsigned long long idx = atomicAdd(&sg.ctr[0], 1ull);
+    if (idx < sg.loose_cap) skm_store_record(sg.loose + idx * (uint64_t)sg.recw, hdr, bw, sg.nbw);
+    else sg.ctr[1] = 1;
+}
+
+// ---- S1 ------------------------------------------------------------------------------------------------
+struct SkmTile {
+    uint32_t len[KV_TILE_MAX_READS], nk[KV_TILE_MAX_READS];
+    uint32_t bpre[KV_TILE_MAX_READS + 1];      // staged-base prefix: flat position of a read's first base
+    uint32_t wpre[KV_TILE_MAX_READS + 1];      // packed-word prefix inside the tile
+    uint32_t uni;                              // bases per read if all reads of the tile have the same length, else 0
+    float uni_inv;
+    uint32_t seg_start, read0, nstart, next_tile;
+};
+
+__device__ __forceinline__ void skm_locate(const SkmTile &sh, uint32_t nr, uint32_t q, uint32_t &r, uint32_t &j)
+{
+    if (sh.uni) {
+        uint32_t rr = (uint32_t)((float)q * sh.uni_inv);
+        if (rr * sh.uni > q) rr -= 1;
+        else if ((rr + 1) * sh.uni <= q) rr += 1;
+        r = rr; j = q - rr * sh.uni;
+        return;
+    }
+    uint32_t lo = 0, hi = nr;     // largest r with bpre[r] <= q (empty reads share their successor's prefix)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sh.bpre[mid] <= q) lo = mid; else hi = mid;
+    }
+    r = lo; j = q - sh.bpre[lo];
+}
+
+__global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t n_tiles, SkmGeom sg)
+{
+    __shared__ SkmTile sh;
+    __shared__ uint32_t cur[256];
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t nwl = sg.np_max / 16u + KV_TILE_MAX_READS + 8u;     // every read starts on a word: up to one partial word each
+    uint32_t *wl = smem;                                              // the tile's packed words
+    uint32_t *bufA = smem + nwl, *bufB = bufA + sg.np_max + 64u;
+    const int k = sg.k, m = sg.m, w = sg.w;
+    for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_THREADS1) cur[c] = 0;
+    uint64_t n_rec = 0;
+    for (uint32_t taken = 0; taken < sg.quota1; ++taken) {
+        __syncthreads();
+        if (threadIdx.x == 0) sh.next_tile = (uint32_t)atomicAdd(&sg.ctr[2], 1ull);
+        __syncthreads();
+        const uint32_t tile = sh.next_tile;
+        if (tile >= n_tiles) break;
+        const TileDesc td = rd.tile[tile];
+        const uint32_t r0 = td.first, nr = td.count;
+        const uint32_t seg_start = td.seg ? td.seg_start : 0u;
+        const uint64_t w0 = rd.woff[r0] + (seg_start >> 4);
+        if (threadIdx.x < 64) {
+            const uint32_t i0 = 2 * threadIdx.x, i1 = i0 + 1;
+            uint32_t l0 = 0, l1 = 0;
+            if (i0 < nr) {
+                l0 = rd.len[r0 + i0];
+                if (td.seg) {
+                    const uint32_t rest = l0 - seg_start, want = (uint32_t)KV_SEG_BASES + (uint32_t)k - 1u;
+                    l0 = rest < want ? rest : want;
+                }
+            }
+            if (i1 < nr) l1 = rd.len[r0 + i1];
+            uint32_t eb, tot;
+            const uint32_t ea = wave_excl_scan2(l0, l1, eb, tot);
+            if (i0 < nr) { sh.len[i0] = l0; sh.nk[i0] = l0 >= (uint32_t)k ? l0 - (uint32_t)k + 1u : 0u; sh.bpre[i0] = ea; }
+            if (i1 < nr) { sh.len[i1] = l1; sh.nk[i1] = l1 >= (uint32_t)k ? l1 - (uint32_t)k + 1u : 0u; sh.bpre[i1] = eb; }
+            if (threadIdx.x == 0) { sh.bpre[nr] = tot; sh.seg_start = seg_start; sh.read0 = r0; sh.nstart = 0; }
+            const uint32_t ref = __shfl(l0, 0);
+            const bool same = (i0 >= nr || l0 == ref) && (i1 >= nr || l1 == ref);
+            const bool uniform = __all(same) && ref > 0;
+            if (threadIdx.x == 0) { sh.uni = uniform ? ref : 0u; sh.uni_inv = uniform ? 1.0f / (float)ref : 0.0f; }
+            if (td.seg) {
+                if (threadIdx.x == 0) { sh.wpre[0] = 0; sh.wpre[1] = (l0 + 15) >> 4; }
+            } else {
+                if (i0 < nr) sh.wpre[i0] = (uint32_t)(rd.woff[r0 + i0] - w0);
+                if (i1 < nr) sh.wpre[i1] = (uint32_t)(rd.woff[r0 + i1] - w0);
+                if (threadIdx.x == 0) sh.wpre[nr] = (uint32_t)(rd.woff[r0 + nr] - w0);
+            }
+        }
+        __syncthreads();
+        const uint32_t nwords = sh.wpre[nr], NB = sh.bpre[nr];
+        for (uint32_t i = threadIdx.x; i < nwords + 8u; i += SKM_THREADS1) wl[i] = i < nwords ? rd.words[w0 + i] : 0u;
+        if (threadIdx.x < 64) { bufA[NB + threadIdx.x] = 0xffffffffu; bufB[NB + threadIdx.x] = 0xffffffffu; }
+        __syncthreads();
+        // P1: order value of the m-mer starting at every base
+        const uint32_t mmask = m == 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
+        for (uint32_t q = threadIdx.x; q < NB; q += SKM_THREADS1) {
+            uint32_t r, j;
+            skm_locate(sh, nr, q, r, j);
+            uint32_t v = 0xffffffffu;
+            if (j + (uint32_t)m <= sh.len[r]) {
+                const uint32_t a = sh.wpre[r] + (j >> 4), s2 = 2u * (j & 15u);
+                const uint64_t win = (uint64_t)wl[a] | ((uint64_t)wl[a + 1] << 32);
+                v = skm_mmer_value((uint32_t)(win >> s2) & mmask, m);
+            }
+            bufA[q] = v;
+        }
+        __syncthreads();
+        // P2: minimum over the w m-mers of every k-mer: windows of 1, 2, 4 .. wpow by doubling, then two overlapping windows
+        uint32_t *src = bufA, *dst = bufB;
+        for (int s = 1; 2 * s <= w; s <<= 1) {
+            for (uint32_t q = threadIdx.x; q < NB; q += SKM_THREADS1) dst[q] = min(src[q], src[q + (uint32_t)s]);
+            __syncthreads();
+            uint32_t *t = src; src = dst; dst = t;
+        }
+        const uint32_t tail = (uint32_t)(w - sg.wpow);
+        for (uint32_t q = threadIdx.x; q < NB; q += SKM_THREADS1) {
+            uint32_t r, j;
+            skm_locate(sh, nr, q, r, j);
+            uint32_t id = 0xffffffffu;                       // bucket id coarse << 16 | fine of the k-mer starting here
+            if (j < sh.nk[r]) {
+                uint32_t coarse, fine;
+                skm_bucket_of(min(src[q], src[q + tail]), sg.C1, sg.fbits, coarse, fine);
+                id = (coarse << 16) | fine;
+            }
+            dst[q] = id;
+        }
+        __syncthreads();
+        // P3: a run starts where a read starts or the bucket changes
+        uint32_t *ids = dst, *starts = src;
+        for (uint32_t q0 = 0; q0 < NB; q0 += SKM_THREADS1) {
+            const uint32_t q = q0 + threadIdx.x;
+            bool is_start = false;
+            if (q < NB) {
+                const uint32_t id = ids[q];
+                if (id != 0xffffffffu) {
+                    uint32_t r, j;
+                    skm_locate(sh, nr, q, r, j);
+                    is_start = j == 0 || ids[q - 1] != id;
+                }
+            }
+            const unsigned long long ballot = __ballot(is_start);
+            if (ballot) {
+                const int lane = threadIdx.x & 63;
+                uint32_t first = 0;
+                if (lane == 0) first = atomicAdd(&sh.nstart, (uint32_t)__popcll(ballot));
+                first = __shfl(first, 0);
+                if (is_start) starts[first + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull))] = q;
+            }
+        }
+        __syncthreads();
+        // P4: one thread per run: measure it, cut it into records of <= ncap k-mers, store them
+        const uint32_t nstart = sh.nstart;
+        for (uint32_t i = threadIdx.x; i < nstart; i += SKM_THREADS1) {
+            const uint32_t q = starts[i];
+            uint32_t r, j;
+            skm_locate(sh, nr, q, r, j);
+            const uint32_t id = ids[q];
+            const uint32_t limit = q - j + sh.nk[r];          // flat position one past the read's last k-mer
+            uint32_t e = q + 1;
+            while (e < limit && ids[e] == id) ++e;
+            uint32_t left = e - q;
+            const uint32_t coarse = id >> 16, fine = id & 0xffffu;
+            uint64_t pos = (uint64_t)(sh.read0 + r) * sg.stride + sh.seg_start + j;
+            uint32_t b = sh.wpre[r] * 16u + j;                // base index inside wl
+            while (left) {
+                const uint32_t n = min(left, (uint32_t)sg.ncap);
+                uint64_t bw[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? skm_bases32(wl, b + 32u * t) : 0ull;
+                const uint64_t hdr = skm_header(pos, n, fine);
+                const uint32_t p = atomicAdd(&cur[coarse], 1u);
+                if (p < sg.cap1) skm_store_record(sg.seg1 + (((uint64_t)coarse * sg.nwg1 + blockIdx.x) * sg.cap1 + p) * (uint64_t)sg.recw, hdr, bw, sg.nbw);
+                else skm_loose_push(sg, hdr, bw);
+                n_rec += 1;
+                left -= n; pos += n; b += n;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_THREADS1) sg.cnt1[(uint64_t)c * sg.nwg1 + blockIdx.x] = min(cur[c], sg.cap1);
+    n_rec = wave_sum_u64(n_rec);
+    if ((threadIdx.x & 63) == 0 && n_rec) atomicAdd(&sg.ctr[5], (unsigned long long)n_rec);
+}
+
+// ---- S2 ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_skm_split(SkmGeom sg)
+{
+    __shared__ uint32_t cur[512];
+    const uint32_t c = blockIdx.y;
+    for (uint32_t f = threadIdx.x; f < sg.F2; f += 256) cur[f] = 0;
+    __syncthreads();
+    const int recw = sg.recw;
+    for (uint32_t seg = blockIdx.x; seg < sg.nwg1; seg += sg.nwg2) {
+        const uint32_t n = sg.cnt1[(uint64_t)c * sg.nwg1 + seg];
+        const uint64_t *src = sg.seg1 + ((uint64_t)c * sg.nwg1 + seg) * sg.cap1 * (uint64_t)recw;
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint64_t *rec = src + (uint64_t)i * recw;
+            const uint64_t hdr = rec[0];
+            uint64_t bw[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
+            const uint32_t fine = skm_hdr_fine(hdr);
+            const uint32_t p = atomicAdd(&cur[fine], 1u);
+            if (p < sg.cap2)
+                skm_store_record(sg.seg2 + ((((uint64_t)c * sg.F2 + fine) * sg.nwg2 + blockIdx.x) * sg.cap2 + p) * (uint64_t)recw, hdr, bw, sg.nbw);
+            else skm_loose_push(sg, hdr, bw);
+        }
+    }
+    __syncthreads();
+    for (uint32_t f = threadIdx.x; f < sg.F2; f += 256)
+        sg.cnt2[((uint64_t)c * sg.F2 + f) * sg.nwg2 + blockIdx.x] = min(cur[f], sg.cap2);
+}
+
+// ---- LDS combining table -------------------------------------------------------------------------------
+template <int KW, int TS>
+struct SkmTable {
+    unsigned long long key[KW][TS];
+};
+
+template <int KW, int TS>
+__device__ __forceinline__ void skm_table_clear(SkmTable<KW, TS> &tb)
+{
+    for (uint32_t i = threadIdx.x; i < TS; i += blockDim.x) {
+        tb.key[0][i] = SKM_EMPTY;
+        if (KW == 2) tb.key[KW - 1][i] = SKM_EMPTY;
+    }
+}
+
+// slot of the key, claiming a free slot if it is new; -1 when SKM_MAXPROBE slots are all taken by other keys.  With
+// two key words a slot is identified word by word: whoever sets word 0 (or finds it equal) goes on to set or
+// compare word 1, and moves to the next slot if another k-mer with the same first 32 bases got there first.
+template <int KW, int TS>
+__device__ __forceinline__ int skm_table_insert(SkmTable<KW, TS> &tb, const SkmKey<KW> &c)
+{
+    uint32_t slot = skm_slot_hash<KW>(c) & (TS - 1);
+    for (int probe = 0; probe < SKM_MAXPROBE; ++probe) {
+        const unsigned long long old0 = atomicCAS(&tb.key[0][slot], SKM_EMPTY, (unsigned long long)c.w[0]);
+        if (old0 == SKM_EMPTY || old0 == c.w[0]) {
+            if (KW == 1) return (int)slot;
+            const unsigned long long old1 = atomicCAS(&tb.key[KW - 1][slot], SKM_EMPTY, (unsigned long long)c.w[KW - 1]);
+            if (old1 == SKM_EMPTY || old1 == c.w[KW - 1]) return (int)slot;
+        }
+        slot = (slot + 1) & (TS - 1);
+    }
+    return -1;
+}
+
+template <int KW, int TS>
+__device__ __forceinline__ int skm_table_find(const SkmTable<KW, TS> &tb, const SkmKey<KW> &c)
+{
+    uint32_t slot = skm_slot_hash<KW>(c) & (TS - 1);
+    for (int probe = 0; probe < SKM_MAXPROBE; ++probe) {
+        const unsigned long long k0 = tb.key[0][slot];
+        if (k0 == SKM_EMPTY) return -1;
+        if (k0 == c.w[0] && (KW == 1 || tb.key[KW - 1][slot] == c.w[KW - 1])) return (int)slot;
+        slot = (slot + 1) & (TS - 1);
+    }
+    return -1;
+}
+
+// the two murmur hashes of a canonical k-mer: both strands expanded to ASCII register windows through the
+// 256-entry byte -> 4 characters table in LDS
+template <int KW>
+__device__ __forceinline__ uint64_t skm_key_hash(const SkmKey<KW> &c, const uint32_t *lut, const HashParams &hp)
+{
+    constexpr int NW = 8 * KW;
+    const SkmKey<KW> r = skm_revcomp<KW>(c, hp.k);
+    uint32_t wf[NW], wr[NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        wf[q] = lut[(uint32_t)(c.w[q >> 3] >> (8 * (q & 7))) & 0xffu];
+        wr[q] = lut[(uint32_t)(r.w[q >> 3] >> (8 * (q & 7))) & 0xffu];
+    }
+    return murmur_regs<NW>(wf, hp) ^ murmur_regs<NW>(wr, hp);
+}
+
+// count side of one distinct k-mer seen `count` times: filter, then T weighted items through `emit(table, bin, weight)`
+template <typename Emit>
+__device__ __forceinline__ uint32_t skm_count_kmer(uint64_t h, uint32_t count, const SketchDev *__restrict__ sk,
+                                                   const SketchDev *__restrict__ mask, const ConsumeFilter &f, int T, Emit emit)
+{
+    if (!consume_filter_pass(f, mask, h)) return 0;
+    uint32_t left = min(count, 255u);                  // no counter holds more than 255
+    while (left) {
+        const uint32_t wgt = min(left, BIN_W_MAX);
+#pragma unroll
+        for (int t = 0; t < BIN_MAX_T; ++t)
+            if (t < T) emit(t, fastmod(h, sk->size[t], sk->magic[t]), wgt);
+        left -= wgt;
+    }
+    return count;
+}
+
+// every wave walks its share of the table and hands the occupied slots to `body` 64 at a time (all lanes busy):
+// occupied slots are queued in LDS and drained whenever a full wave of them is ready
+template <int TS, typename Body>
+__device__ __forceinline__ void skm_for_occupied(const unsigned long long *key0, uint16_t *queue_all, Body body)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    volatile uint16_t *queue = queue_all + wave * 128u;
+    const uint32_t per_wave = TS / nwaves;
+    const uint32_t s_end = (wave + 1) * per_wave;
+    uint32_t qn = 0;                                    // < 64 between iterations
+    for (uint32_t s0 = wave * per_wave;; s0 += 64) {
+        const bool last = s0 >= s_end;
+        if (!last) {
+            const uint32_t slot = s0 + lane;
+            const bool occ = key0[slot] != SKM_EMPTY;
+            const unsigned long long ballot = __ballot(occ);
+            if (occ) queue[qn + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull))] = (uint16_t)slot;
+            qn += (uint32_t)__popcll(ballot);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (qn >= 64 || (last && qn > 0)) {
+            const uint32_t take = min(qn, 64u);
+            qn -= take;
+            if (lane < take) body((uint32_t)queue[qn + lane]);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (last) break;
+    }
+}
+
+// ---- S3: count ------------------------------------------------------------------------------------------
+template <int KW, int TS>
+__global__ __launch_bounds__(SKM_THREADS3) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
+                                                           const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
+{
+    __shared__ SkmTable<KW, TS> tb;
+    __shared__ uint32_t cnt[TS];                 // occurrences of the key in the same slot
+    __shared__ uint32_t lut[256];
+    __shared__ uint32_t cur[BIN_MAX_T * BIN_C];
+    __shared__ uint16_t queue[(SKM_THREADS3 / 64) * 128];
+    __shared__ uint32_t next_bucket;
+    const uint32_t ns = (uint32_t)(g.T * g.C);
+    for (uint32_t s = threadIdx.x; s < ns; s += SKM_THREADS3) cur[s] = 0;
+    if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    const int k = sg.k, recw = sg.recw;
+    uint64_t n_added = 0;
+    auto emit = [&](int t, uint64_t bin, uint32_t wgt) {
+        const uint32_t slice = (uint32_t)(bin >> 16);
+        const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
+        const uint32_t sidx = (uint32_t)t * (uint32_t)g.C + c;
+        const uint32_t item = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu) | ((wgt - 1u) << BIN_W_SHIFT);
+        const uint32_t pos = atomicAdd(&cur[sidx], 1u);
+        if (pos < g.cap1) g.gbuf1[((uint64_t)sidx * g.nwgA + blockIdx.x) * g.cap1 + pos] = item;
+        else spill_item(g, t, bin, wgt);
+    };
+    for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
+        __syncthreads();
+        if (threadIdx.x == 0) next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull);
+        skm_table_clear(tb);
+        for (uint32_t i = threadIdx.x; i < TS; i += SKM_THREADS3) cnt[i] = 0;
+        __syncthreads();
+        const uint32_t b = next_bucket;
+        if (b >= sg.n_buckets) break;
+        // combine: one thread per record, rolling along its k-mers
+        for (uint32_t s = 0; s < sg.nwg2; ++s) {
+            const uint32_t n = sg.cnt2[(uint64_t)b * sg.nwg2 + s];
+            const uint64_t *src = sg.seg2 + ((uint64_t)b * sg.nwg2 + s) * sg.cap2 * (uint64_t)recw;
+            for (uint32_t i = threadIdx.x; i < n; i += SKM_THREADS3) {
+                const uint64_t *rec = src + (uint64_t)i * recw;
+                const uint64_t hdr = rec[0];
+                uint64_t bw[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
+                const uint32_t nk = skm_hdr_n(hdr);
+                SkmKey<KW> fw = skm_first_kmer<KW>(bw, k);
+                SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
+                for (uint32_t j = 0; j < nk; ++j) {
+                    if (j) skm_roll<KW>(fw, rc, skm_base_at(bw, j + (uint32_t)k - 1u), k);
+                    const SkmKey<KW> c = skm_canonical<KW>(fw, rc);
+                    const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
+                    if (slot >= 0) atomicAdd(&cnt[slot], 1u);
+                    else {   // table region full (or unstorable key): this occurrence travels alone
+                        uint64_t one[3] = {fw.w[0], KW == 2 ? fw.w[KW - 1] : 0ull, 0ull};
+                        skm_loose_push(sg, skm_header(skm_hdr_pos(hdr) + j, 1u, 0u), one);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // every distinct k-mer once
+        skm_for_occupied<TS>(tb.key[0], queue, [&](uint32_t slot) {
+            SkmKey<KW> c;
+            c.w[0] = tb.key[0][slot];
+            if (KW == 2) c.w[KW - 1] = tb.key[KW - 1][slot];
+            const uint64_t h = skm_key_hash<KW>(c, lut, f.hp);
+            n_added += skm_count_kmer(h, cnt[slot], sk, mask, f, g.T, emit);
+        });
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < ns; s += SKM_THREADS3)
+        g.gcnt1[(uint64_t)s * g.nwgA + blockIdx.x] = (uint32_t)min((uint64_t)cur[s], g.cap1);
+    n_added = wave_sum_u64(n_added);
+    if ((threadIdx.x & 63) == 0 && n_added) atomicAdd(&g.ctr[2], (unsigned long long)n_added);
+}
+
+// loose records: every k-mer occurrence on its own, increments through the spill list (global atomics)
+template <int KW>
+__global__ __launch_bounds__(256) void k_skm_loose_count(SkmGeom sg, const SketchDev *__restrict__ sk,
+                                                         const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
+{
+    __shared__ uint32_t lut[256];
+    lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    __syncthreads();
+    unsigned long long n = sg.ctr[0];
+    if (n > sg.loose_cap) n = sg.loose_cap;
+    const int k = sg.k, recw = sg.recw;
+    uint64_t n_added = 0;
+    auto emit = [&](int t, uint64_t bin, uint32_t wgt) { spill_item(g, t, bin, wgt); };
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t *rec = sg.loose + i * (uint64_t)recw;
+        uint64_t bw[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
+        const uint32_t nk = skm_hdr_n(rec[0]);
+        SkmKey<KW> fw = skm_first_kmer<KW>(bw, k);
+        SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
+        for (uint32_t j = 0; j < nk; ++j) {
+            if (j) skm_roll<KW>(fw, rc, skm_base_at(bw, j + (uint32_t)k - 1u), k);
+            const uint64_t h = skm_key_hash<KW>(skm_canonical<KW>(fw, rc), lut, f.hp);
+            n_added += skm_count_kmer(h, 1u, sk, mask, f, g.T, emit);
+        }
+    }
+    n_added = wave_sum_u64(n_added);
+    if ((threadIdx.x & 63) == 0 && n_added) atomicAdd(&g.ctr[2], (unsigned long long)n_added);
+}
+
+// ---- S6: novel ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void skm_mark(const NovelParams &p, const ReadsDev &rd, uint64_t pos, uint64_t stride)
+{
+    const uint64_t read = pos / stride;
+    const uint64_t off = pos - read * stride;
+    if ((rd.flags[read] & 1) || read < p.first_read) return;     // the scan skips these reads (kevlar/novel.py:134-139)
+    const uint64_t bit = read * p.mask_stride + off;
+    atomicOr(&p.mask[bit >> 5], 1u << (bit & 31));
+}
+
+template <int KW, int TS>
+__global__ __launch_bounds__(SKM_THREADS3) void k_skm_novel(SkmGeom sg, ReadsDev rd, NovelParams p)
+{
+    __shared__ SkmTable<KW, TS> tb;
+    __shared__ uint32_t flag[TS / 32];           // bit per slot: the key is interesting
+    __shared__ uint32_t lut[256];
+    __shared__ uint16_t queue[(SKM_THREADS3 / 64) * 128];
+    __shared__ NovelShared ns;
+    __shared__ uint32_t next_bucket, any_hit;
+    if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    load_descs(ns, p);
+    const int k = sg.k, recw = sg.recw;
+    for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
+        __syncthreads();
+        if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull); any_hit = 0; }
+        skm_table_clear(tb);
+        if (threadIdx.x < TS / 32) flag[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t b = next_bucket;
+        if (b >= sg.n_buckets) break;
+        for (int pass = 0; pass < 2; ++pass) {
+            // pass 0: collect the distinct k-mers; pass 1 (after they have been evaluated): mark the occurrences
+            if (pass == 1 && any_hit == 0) break;
+            for (uint32_t s = 0; s < sg.nwg2; ++s) {
+                const uint32_t n = sg.cnt2[(uint64_t)b * sg.nwg2 + s];
+                const uint64_t *src = sg.seg2 + ((uint64_t)b * sg.nwg2 + s) * sg.cap2 * (uint64_t)recw;
+                for (uint32_t i = threadIdx.x; i < n; i += SKM_THREADS3) {
+                    const uint64_t *rec = src + (uint64_t)i * recw;
+                    const uint64_t hdr = rec[0];
+                    uint64_t bw[3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
+                    const uint32_t nk = skm_hdr_n(hdr);
+                    SkmKey<KW> fw = skm_first_kmer<KW>(bw, k);
+                    SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
+                    for (uint32_t j = 0; j < nk; ++j) {
+                        if (j) skm_roll<KW>(fw, rc, skm_base_at(bw, j + (uint32_t)k - 1u), k);
+                        const SkmKey<KW> c = skm_canonical<KW>(fw, rc);
+                        if (pass == 0) {
+                            const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
+                            if (slot < 0) {
+                                uint64_t one[3] = {fw.w[0], KW == 2 ? fw.w[KW - 1] : 0ull, 0ull};
+                                skm_loose_push(sg, skm_header(skm_hdr_pos(hdr) + j, 1u, 0u), one);
+                            }
+                        } else if (skm_cacheable<KW>(c)) {
+                            const int slot = skm_table_find(tb, c);      // absent: that occurrence went to the loose list
+                            if (slot >= 0 && ((flag[slot >> 5] >> (slot & 31)) & 1u)) skm_mark(p, rd, skm_hdr_pos(hdr) + j, sg.stride);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (pass == 0) {
+                skm_for_occupied<TS>(tb.key[0], queue, [&](uint32_t slot) {
+                    SkmKey<KW> c;
+                    c.w[0] = tb.key[0][slot];
+                    if (KW == 2) c.w[KW - 1] = tb.key[KW - 1][slot];
+                    const uint64_t h = skm_key_hash<KW>(c, lut, p.hp);
+                    if (band_pass(p, h) && novel_test_fast(ns, p, h, nullptr, 0ull)) { atomicOr(&flag[slot >> 5], 1u << (slot & 31)); any_hit = 1; }
+                });
+                __syncthreads();
+            }
+        }
+    }
+}
+
+template <int KW>
+__global__ __launch_bounds__(256) void k_skm_loose_novel(SkmGeom sg, ReadsDev rd, NovelParams p)
+{
+    __shared__ uint32_t lut[256];
+    __shared__ NovelShared ns;
+    lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    load_descs(ns, p);
+    __syncthreads();
+    unsigned long long n = sg.ctr[0];
+    if (n > sg.loose_cap) n = sg.loose_cap;
+    const int k = sg.k, recw = sg.recw;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t *rec = sg.loose + i * (uint64_t)recw;
+        uint64_t bw[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
+        const uint64_t hdr = rec[0];
+        const uint32_t nk = skm_hdr_n(hdr);
+        SkmKey<KW> fw = skm_first_kmer<KW>(bw, k);
+        SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
+        for (uint32_t j = 0; j < nk; ++j) {
+            if (j) skm_roll<KW>(fw, rc, skm_base_at(bw, j + (uint32_t)k - 1u), k);
+            const uint64_t h = skm_key_hash<KW>(skm_canonical<KW>(fw, rc), lut, p.hp);
+            if (band_pass(p, h) && novel_test_fast(ns, p, h, nullptr, 0ull)) skm_mark(p, rd, skm_hdr_pos(hdr) + j, sg.stride);
+        }
+    }
+}
+
+__global__ void k_skm_forward_flag(const unsigned long long *skm_ctr, unsigned long long *bin_ctr)
+{
+    if (skm_ctr[1] != 0) bin_ctr[1] = 1;
+}
+
+// hits per tile = set bits of the tile's range of the mask (what k_novel_mark counts while it marks)
+__global__ __launch_bounds__(64) void k_tile_hits(ReadsDev rd, NovelParams p)
+{
+    const TileDesc td = rd.tile[blockIdx.x];
+    uint64_t b0, b1;
+    if (td.seg) {
+        b0 = (uint64_t)td.first * p.mask_stride + td.seg_start;
+        b1 = min(b0 + (uint64_t)KV_SEG_BASES, ((uint64_t)td.first + 1) * p.mask_stride);
+    } else {
+        b0 = (uint64_t)td.first * p.mask_stride;
+        b1 = ((uint64_t)td.first + td.count) * p.mask_stride;
+    }
+    uint64_t n = 0;
+    for (uint64_t w = (b0 >> 5) + threadIdx.x; w < ((b1 + 31) >> 5); w += 64) {
+        uint32_t bits = p.mask[w];
+        const uint64_t wlo = w << 5;
+        if (wlo < b0) bits &= ~0u << (uint32_t)(b0 - wlo);
+        if (wlo + 32 > b1) bits &= b1 > wlo ? (~0u >> (uint32_t)(wlo + 32 - b1)) : 0u;
+        n += (uint32_t)__popc(bits);
+    }
+    n = wave_sum_u64(n);
+    if (threadIdx.x == 0) p.tile_count[blockIdx.x] = (uint32_t)n;
+}
+
+// ---- host ----------------------------------------------------------------------------------------------
+// The bucketed form of the last batch consumed on a stream stays in that stream's arena, so a scan of the same
+// batch (the case sample: count, then novel) does not cut its reads again.
+struct SkmIndex {
+    KvArena arena;
+    uint64_t reads_uid = 0;
+    int k = 0;
+    bool valid = false;
+    SkmGeom g;
+    std::mutex mu;
+};
+std::map<hipStream_t, SkmIndex> g_skm;
+std::mutex g_skm_mu;
+
+SkmIndex &skm_index_for(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_skm_mu);
+    return g_skm[st];
+}
+
+inline uint32_t pow2_ceil(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+int skm_minimizer_len(int k) { return k >= 24 ? 12 : k / 2; }
+
+// cut `reads` into super-k-mers and bucket them (S1 + S2); idx.mu held by the caller
+int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hipStream_t st)
+{
+    SkmGeom &g = idx.g;
+    memset(&g, 0, sizeof(g));
+    idx.valid = false;
+    g.k = k;
+    g.m = skm_minimizer_len(k);
+    g.w = k - g.m + 1;
+    g.wpow = 1;
+    while (g.wpow * 2 <= g.w) g.wpow *= 2;
+    g.kw = k <= 32 ? 1 : 2;
+    g.nbw = g.kw + 1;
+    g.recw = 1 + g.nbw;
+    g.ncap = 32 * g.nbw - k + 1;
+    const uint32_t table_slots = g.kw == 1 ? 4096u : 2048u;
+    const char *tgt_env = getenv("KV_SKM_BUCKET_KMERS");      // tests shrink the buckets to exercise many of them on small inputs
+    const uint64_t target = tgt_env ? std::max<uint64_t>(64, strtoull(tgt_env, nullptr, 10)) : 2ull * table_slots;
+    const uint64_t nfine = std::max<uint64_t>(1, (n_kmers + target - 1) / target);
+    g.F2 = std::min<uint32_t>(512u, pow2_ceil((uint64_t)std::ceil(std::sqrt((double)nfine))));
+    if (nfine > 256ull * g.F2) g.F2 = std::min<uint32_t>(512u, pow2_ceil((nfine + 255) / 256));
+    g.fbits = 0;
+    while ((1u << g.fbits) < g.F2) ++g.fbits;
+    g.C1 = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(1, (nfine + g.F2 - 1) / g.F2));
+    g.n_buckets = g.C1 * g.F2;
+    const int cus = kv_device_cus();
+    g.nwg1 = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(reads->n_tiles, 1u), 2u * (uint32_t)cus);
+    {
+        const uint64_t avg = (reads->n_tiles + g.nwg1 - 1) / g.nwg1;
+        g.quota1 = (uint32_t)std::min<uint64_t>(avg + avg / 2 + 1, 0xffffffffull);
+    }
+    g.nwg2 = std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / g.C1));
+    g.nwg2 = std::min<uint32_t>(g.nwg2, g.nwg1);
+    g.np_max = std::max<uint32_t>(reads->tile_max_bases, 64u);
+    const uint64_t min_stride = reads->max_len >= (uint32_t)k ? reads->max_len - (uint32_t)k + 1 : 1;
+    g.stride = min_stride;
+    // records: one run per ~ (w + 1) / 2 k-mers, one more per read, a few cuts at ncap
+    const double rec_est = (double)n_kmers * 2.2 / (double)(g.w + 1) + (double)reads->n_reads + 1024.0;
+    const double m1 = rec_est / ((double)g.C1 * g.nwg1), m2 = rec_est / ((double)g.n_buckets * g.nwg2);
+    g.cap1 = (uint32_t)kv_round_up((uint64_t)(m1 * 1.5 + 8.0 * std::sqrt(m1)) + 64, 16);
+    g.cap2 = (uint32_t)kv_round_up((uint64_t)(m2 * 1.3 + 8.0 * std::sqrt(m2)) + 32, 16);
+    g.loose_cap = (uint64_t)(rec_est / 8.0) + (1u << 20);
+    if (const char *pct = getenv("KV_SKM_CAP_PCT")) {       // tests: undersized segments push records through the loose list
+        g.cap1 = std::max<uint32_t>(16u, (uint32_t)((uint64_t)g.cap1 * (uint64_t)atoi(pct) / 100));
+        g.cap2 = std::max<uint32_t>(16u, (uint32_t)((uint64_t)g.cap2 * (uint64_t)atoi(pct) / 100));
+    }
+    if (const char *lc = getenv("KV_SKM_LOOSE_CAP")) g.loose_cap = strtoull(lc, nullptr, 10);
+    const size_t rb = (size_t)g.recw * 8;
+    const size_t b_seg1 = kv_round_up((uint64_t)g.C1 * g.nwg1 * g.cap1 * rb, 256), b_cnt1 = kv_round_up((uint64_t)g.C1 * g.nwg1 * 4, 256);
+    const size_t b_seg2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * g.cap2 * rb, 256), b_cnt2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * 4, 256);
+    const size_t b_loose = kv_round_up(g.loose_cap * rb, 256), b_ctr = 256;
+    KV_HIP(idx.arena.need(b_seg1 + b_cnt1 + b_seg2 + b_cnt2 + b_loose + b_ctr));
+    unsigned char *base = (unsigned char *)idx.arena.p;
+    g.seg1 = (uint64_t *)base; base += b_seg1;
+    g.cnt1 = (uint32_t *)base; base += b_cnt1;
+    g.seg2 = (uint64_t *)base; base += b_seg2;
+    g.cnt2 = (uint32_t *)base; base += b_cnt2;
+    g.loose = (uint64_t *)base; base += b_loose;
+    g.ctr = (unsigned long long *)base;
+    KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));
+    {
+        KvProfScope prof("k_skm_emit");
+        const size_t lds = ((size_t)g.np_max / 16 + KV_TILE_MAX_READS + 8 + 2 * ((size_t)g.np_max + 64)) * 4;
+        kv_ensure_dynamic_lds((const void *)k_skm_emit, lds);
+        hipLaunchKernelGGL(k_skm_emit, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), reads->n_tiles, g);
+    }
+    {
+        KvProfScope prof("k_skm_split");
+        hipLaunchKernelGGL(k_skm_split, dim3(g.nwg2, g.C1), dim3(256), 0, st, g);
+    }
+    KV_HIP(hipGetLastError());
+    KV_HIP(hipMemcpyAsync(&g.ctr[6], &g.ctr[0], 8, hipMemcpyDeviceToDevice, st));   // loose records S1/S2 left behind
+    const uint32_t nwg3 = (uint32_t)std::min<uint64_t>(g.n_buckets, 3u * (uint32_t)cus);
+    {
+        const uint64_t avg = (g.n_buckets + nwg3 - 1) / nwg3;
+        g.quota3 = (uint32_t)(avg + avg / 2 + 1);
+    }
+    idx.reads_uid = reads->uid;
+    idx.k = k;
+    idx.valid = true;
+    return KV_OK;
+}
+
+inline uint32_t skm_nwg3(const SkmGeom &g) { return (uint32_t)std::min<uint64_t>(g.n_buckets, 3u * (uint32_t)kv_device_cus()); }
+
+}  // namespace
+
+bool kv_skm_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_kmers, bool for_scan)
+{
+    const char *force = getenv(for_scan ? "KV_NOVEL_PATH" : "KV_COUNT_PATH");
+    if (force && strcmp(force, "skm") != 0) return false;        // another path was asked for by name
+    if (s->h.hashfam != HF_MURMUR || s->h.ksize < SKM_MIN_K || s->h.ksize > SKM_MAX_K) return false;
+    if (reads->n_tiles == 0 || n_kmers == 0) return false;
+    const uint64_t min_stride = reads->max_len >= (uint32_t)s->h.ksize ? reads->max_len - (uint32_t)s->h.ksize + 1 : 1;
+    if ((double)reads->n_reads * (double)min_stride >= (double)(1ull << SKM_POS_BITS)) return false;
+    if (reads->tile_max_bases == 0 || reads->tile_max_bases > 8192u) return false;
+    if (force) return true;
+    return n_kmers >= (1ull << 22);
+}
+
+int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &filter, const kv_sketch *mask,
+                   uint64_t n_kmers, int nbands, uint64_t *n_added)
+{
+    hipStream_t st = kv_stream();
+    SkmIndex &idx = skm_index_for(st);
+    std::lock_guard<std::mutex> lk(idx.mu);
+    const int k = s->h.ksize;
+    { const int rc = skm_build(idx, reads, k, n_kmers, st); if (rc != KV_OK) return rc; }
+    SkmGeom &sg = idx.g;
+    const uint32_t nwg3 = skm_nwg3(sg);
+    BinPlan plan;
+    { const int rc = kv_bin_plan(s, n_kmers, nbands, filter.use_mask != 0, sg.n_buckets, 0u, nwg3, true, &plan); if (rc != KV_OK) return rc; }
+    const SketchDev *d_mask = mask ? mask->d_desc : nullptr;
+    {
+        KvProfScope prof("k_skm_count");
+        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_count<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
+        else hipLaunchKernelGGL((k_skm_count<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
+    }
+    {
+        KvProfScope prof("k_skm_loose_count");
+        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_count<1>, dim3(512), dim3(256), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
+        else hipLaunchKernelGGL(k_skm_loose_count<2>, dim3(512), dim3(256), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
+    }
+    KV_HIP(hipGetLastError());
+    // a lost record (loose list overflow) must stop the apply stage, which looks at the partition's own flag
+    hipLaunchKernelGGL(k_skm_forward_flag, dim3(1), dim3(1), 0, st, sg.ctr, plan.g.ctr);
+    KV_HIP(hipGetLastError());
+    const int rc = kv_bin_finish(s, plan, true, 0, n_added);     // synchronises the stream
+    if (rc != KV_OK) idx.valid = false;
+    return rc;
+}
+
+int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_kmers)
+{
+    hipStream_t st = kv_stream();
+    const int k = p.hp.k;
+    // the bucketed batch may sit in the arena of whichever stream counted it
+    SkmIndex *idx = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_skm_mu);
+        for (auto &kv : g_skm)
+            if (kv.second.valid && kv.second.reads_uid == reads->uid && kv.second.k == k) { idx = &kv.second; break; }
+        if (!idx) idx = &g_skm[st];
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    const bool reuse = idx->valid && idx->reads_uid == reads->uid && idx->k == k && !getenv("KV_SKM_NO_REUSE");
+    if (!reuse) { const int rc = skm_build(*idx, reads, k, n_kmers, st); if (rc != KV_OK) return rc; }
+    SkmGeom &sg = idx->g;
+    if (reuse) {
+        // records that did not fit their S1/S2 segment are the first ctr[6] entries of the loose list; the entries the
+        // count pass added behind them (single occurrences that missed its LDS tables) are re-created by the scan's
+        // own pass 0, so the list is cut back to what S1/S2 left
+        KV_HIP(hipMemcpyAsync(&sg.ctr[0], &sg.ctr[6], 8, hipMemcpyDeviceToDevice, st));
+        KV_HIP(hipMemsetAsync(&sg.ctr[4], 0, 8, st));
+    }
+    const uint32_t nwg3 = skm_nwg3(sg);
+    const ReadsDev rd = reads_dev(reads);
+    {
+        KvProfScope prof("k_skm_novel");
+        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_novel<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), 0, st, sg, rd, p);
+        else hipLaunchKernelGGL((k_skm_novel<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), 0, st, sg, rd, p);
+    }
+    {
+        KvProfScope prof("k_skm_loose_novel");
+        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_novel<1>, dim3(512), dim3(256), 0, st, sg, rd, p);
+        else hipLaunchKernelGGL(k_skm_loose_novel<2>, dim3(512), dim3(256), 0, st, sg, rd, p);
+    }
+    {
+        KvProfScope prof("k_tile_hits");
+        hipLaunchKernelGGL(k_tile_hits, dim3(reads->n_tiles), dim3(64), 0, st, rd, p);
+    }
+    KV_HIP(hipGetLastError());
+    unsigned long long sctr[2] = {0, 0};
+    KV_HIP(hipMemcpyAsync(sctr, sg.ctr, sizeof(sctr), hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    idx->valid = false;     // one scan per build: the loose list now holds this scan's entries
+    if (sctr[1] != 0) {
+        kv_set_error("super-k-mer scan: loose record list overflow (%llu records)", sctr[0]);
+        return KV_ERR_CAPACITY;
+    }
+    return KV_OK;
+}

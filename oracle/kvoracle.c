@@ -509,3 +509,134 @@ int64_t kvo_novel_scan(kvo_sketch *const *cases, int ncase, kvo_sketch *const *c
     }
     return nhits;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* Multi-threaded legs for the "all host cores" CPU baseline (bench.py cpu_baseline), the way */
+/* kevlar runs khmer (kevlar/count.py:41-76: numthreads threads pull reads from one parser   */
+/* and add to ONE sketch with atomic saturating increments).  Saturating adds commute, so the */
+/* tables and n_occupied equal the single-thread result; n_unique is order dependent, as in   */
+/* khmer.                                                                                     */
+/* ------------------------------------------------------------------------------------ */
+#include <pthread.h>
+
+static int add_hash_atomic(kvo_sketch *s, uint64_t h)
+{
+    int is_new = 0;
+    for (int i = 0; i < s->ntables; ++i) {
+        const uint64_t bin = h % s->sizes[i];
+        uint8_t *t = s->tables[i];
+        if (s->storage == ST_BYTE) {
+            uint8_t cur = __atomic_load_n(&t[bin], __ATOMIC_RELAXED);
+            while (cur < 255 && !__atomic_compare_exchange_n(&t[bin], &cur, (uint8_t)(cur + 1), 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+            if (cur == 0) { is_new = 1; if (i == 0) __atomic_fetch_add(&s->n_occupied, 1, __ATOMIC_RELAXED); }
+        } else if (s->storage == ST_NIBBLE) {
+            const int shift = (bin & 1) ? 0 : 4;
+            uint8_t old = __atomic_load_n(&t[bin >> 1], __ATOMIC_RELAXED);
+            for (;;) {
+                const uint8_t cur = (uint8_t)((old >> shift) & 15);
+                if (cur == 15) break;
+                const uint8_t neu = (uint8_t)((old & ~(15 << shift)) | ((cur + 1) << shift));
+                if (__atomic_compare_exchange_n(&t[bin >> 1], &old, neu, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+                    if (cur == 0) { is_new = 1; if (i == 0) __atomic_fetch_add(&s->n_occupied, 1, __ATOMIC_RELAXED); }
+                    break;
+                }
+            }
+        } else {
+            const uint8_t bit = (uint8_t)(1u << (bin & 7));
+            const uint8_t old = __atomic_fetch_or(&t[bin >> 3], bit, __ATOMIC_RELAXED);
+            if (!(old & bit)) { is_new = 1; if (i == 0) __atomic_fetch_add(&s->n_occupied, 1, __ATOMIC_RELAXED); }
+        }
+    }
+    if (is_new) __atomic_fetch_add(&s->n_unique, 1, __ATOMIC_RELAXED);
+    return is_new;
+}
+
+typedef struct {
+    kvo_sketch *s;
+    const char *bases;
+    const uint64_t *offs;
+    uint64_t n_reads, chunk;
+    uint64_t *next;             /* shared cursor: threads pull chunks of reads, like khmer's parser */
+    uint64_t n_added;
+} mt_count_job;
+
+static void *mt_count_worker(void *arg)
+{
+    mt_count_job *j = (mt_count_job *)arg;
+    const int k = j->s->ksize;
+    char *clean = NULL;
+    size_t cap = 0;
+    for (;;) {
+        const uint64_t r0 = __atomic_fetch_add(j->next, j->chunk, __ATOMIC_RELAXED);
+        if (r0 >= j->n_reads) break;
+        const uint64_t r1 = r0 + j->chunk < j->n_reads ? r0 + j->chunk : j->n_reads;
+        for (uint64_t r = r0; r < r1; ++r) {
+            const char *seq = j->bases + j->offs[r];
+            const size_t len = (size_t)(j->offs[r + 1] - j->offs[r]);
+            if (len < (size_t)k || k > KVO_MAXK) continue;
+            if (len > cap) { free(clean); clean = (char *)malloc(len); cap = len; }
+            for (size_t i = 0; i < len; ++i) clean[i] = clean_base(seq[i]);
+            for (size_t i = 0; i + (size_t)k <= len; ++i) {
+                add_hash_atomic(j->s, kvo_hash(j->s->kind, clean + i, k));
+                j->n_added++;
+            }
+        }
+    }
+    free(clean);
+    return NULL;
+}
+
+uint64_t kvo_consume_reads_mt(kvo_sketch *s, const char *bases, const uint64_t *offs, uint64_t n_reads, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    mt_count_job jobs[256];
+    uint64_t next = 0, total = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        jobs[t].s = s; jobs[t].bases = bases; jobs[t].offs = offs; jobs[t].n_reads = n_reads;
+        jobs[t].chunk = 1024; jobs[t].next = &next; jobs[t].n_added = 0;
+        pthread_create(&th[t], NULL, mt_count_worker, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); total += jobs[t].n_added; }
+    return total;
+}
+
+typedef struct {
+    kvo_sketch *const *cases; int ncase;
+    kvo_sketch *const *ctrls; int nctrl;
+    const char *bases; const uint64_t *offs;
+    uint64_t r0, r1;
+    int ksize, case_min, ctrl_max;
+    int64_t nhits;
+} mt_scan_job;
+
+static void *mt_scan_worker(void *arg)
+{
+    mt_scan_job *j = (mt_scan_job *)arg;
+    /* the scan of a contiguous range of reads; hits are only counted here (cap 0) -- the baseline times the
+     * evaluation, the ordered output is what tests check through kvo_novel_scan                          */
+    j->nhits = kvo_novel_scan(j->cases, j->ncase, j->ctrls, j->nctrl, j->bases, j->offs + j->r0, j->r1 - j->r0,
+                              j->ksize, j->case_min, j->ctrl_max, 0, 0, 0, 0, NULL, NULL, NULL, 0, NULL);
+    return NULL;
+}
+
+int64_t kvo_novel_scan_count_mt(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl,
+                                const char *bases, const uint64_t *offs, uint64_t n_reads, int ksize,
+                                int case_min, int ctrl_max, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    mt_scan_job jobs[256];
+    int64_t total = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        mt_scan_job *j = &jobs[t];
+        j->cases = cases; j->ncase = ncase; j->ctrls = ctrls; j->nctrl = nctrl; j->bases = bases; j->offs = offs;
+        j->r0 = n_reads * (uint64_t)t / (uint64_t)nthreads; j->r1 = n_reads * (uint64_t)(t + 1) / (uint64_t)nthreads;
+        j->ksize = ksize; j->case_min = case_min; j->ctrl_max = ctrl_max; j->nhits = 0;
+        pthread_create(&th[t], NULL, mt_scan_worker, j);
+    }
+    for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); total += jobs[t].nhits; }
+    return total;
+}

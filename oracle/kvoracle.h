@@ -95,6 +95,13 @@ int64_t kvo_novel_scan(kvo_sketch *const *cases, int ncase, kvo_sketch *const *c
                        int band, uint32_t *hit_read, uint16_t *hit_off, uint8_t *hit_abund,
                        int64_t cap, uint8_t *read_status);
 
+/* --- multi-threaded legs of bench.py's cpu_baseline (kevlar/count.py:41-76: threads share one sketch, atomic
+ * saturating adds).  Tables and n_occupied equal the single-thread result; the scan leg only counts its hits. */
+uint64_t kvo_consume_reads_mt(kvo_sketch *s, const char *bases, const uint64_t *offs, uint64_t n_reads, int nthreads);
+int64_t kvo_novel_scan_count_mt(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl,
+                                const char *bases, const uint64_t *offs, uint64_t n_reads, int ksize,
+                                int case_min, int ctrl_max, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

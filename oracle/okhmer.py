@@ -65,6 +65,9 @@ def _load():
         'kvo_consume': (u64, [vp, cp, ctypes.c_size_t, i32, i32, vp, i32, i32]),
         'kvo_consume_reads': (u64, [vp, cp, pu64, u64, i32, i32, vp, i32, i32]),
         'kvo_band_bounds': (None, [i32, i32, pu64, pu64]),
+        'kvo_consume_reads_mt': (u64, [vp, cp, pu64, u64, i32]),
+        'kvo_novel_scan_count_mt': (ctypes.c_int64, [ctypes.POINTER(vp), i32, ctypes.POINTER(vp), i32, cp, pu64, u64,
+                                                     i32, i32, i32, i32]),
         'kvo_abundance_distribution': (u64, [vp, vp, cp, ctypes.c_size_t, pu64]),
         'kvo_novel_scan': (ctypes.c_int64, [
             ctypes.POINTER(vp), i32, ctypes.POINTER(vp), i32, cp, pu64, u64, i32, i32, i32, i32,
@@ -369,6 +372,20 @@ def consume_reads(sketch, bases, offs, n_reads, nbands=0, band=0, mask=None, thr
     mh = mask._h if mask is not None else None
     return int(lib.kvo_consume_reads(sketch._h, bases, offs, n_reads, nbands, band, mh,
                                      threshold, 1 if consume_masked else 0))
+
+
+def consume_reads_mt(sketch, bases, offs, n_reads, nthreads):
+    """khmer-style threaded consume (kevlar/count.py:41-76): nthreads threads, one sketch, atomic saturating adds"""
+    return int(lib.kvo_consume_reads_mt(sketch._h, bases, offs, n_reads, int(nthreads)))
+
+
+def novel_scan_count_mt(cases, ctrls, bases, offs, n_reads, ksize, case_min, ctrl_max, nthreads):
+    """number of interesting k-mer instances, the reads split over nthreads threads (timing leg of bench.py)"""
+    vp = ctypes.c_void_p
+    ca = (vp * len(cases))(*[c._h for c in cases])
+    cb = (vp * max(1, len(ctrls)))(*[c._h for c in ctrls])
+    return int(lib.kvo_novel_scan_count_mt(ca, len(cases), cb, len(ctrls), bases, offs, n_reads, ksize, case_min,
+                                           ctrl_max, int(nthreads)))
 
 
 def novel_scan(cases, ctrls, bases, offs, n_reads, ksize, case_min, ctrl_max, screen=0,

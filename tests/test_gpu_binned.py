@@ -24,7 +24,8 @@ def profiled():
     lib = _lib.load()
     lib.kv_prof_reset()
     lib.kv_prof_enable(1)
-    yield
+    os.environ['KV_COUNT_PATH'] = 'binned'      # this file is about the one-item-per-k-mer partition (the super-k-mer
+    yield                                       # front end that large batches take by default: tests/test_gpu_skm.py)
     lib.kv_prof_enable(0)
     os.environ.pop('KV_COUNT_PATH', None)
 

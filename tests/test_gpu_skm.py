@@ -1,0 +1,260 @@
+"""The super-k-mer front end (kv_skm.hip): reads cut into minimizer-bucketed super-k-mers, every distinct k-mer
+of a bucket counted once with its multiplicity and evaluated once by the novel scan.  It must give the same
+table bytes, occupancy, k-mer totals and hits as the scalar oracle (which adds and evaluates k-mer by k-mer, as
+khmer / kevlar/novel.py:123-169 do) -- for every k it accepts, every storage, with bands and masks, on ragged,
+long and non-ACGT reads, on skewed input, and when its segments or LDS tables overflow into the loose list."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = ('KV_COUNT_PATH', 'KV_NOVEL_PATH', 'KV_SKM_BUCKET_KMERS', 'KV_SKM_CAP_PCT', 'KV_SKM_LOOSE_CAP', 'KV_SKM_NO_REUSE')
+
+
+def launches(name):
+    from kevlar_amd import _lib
+    ms, n = ctypes.c_double(), ctypes.c_uint64()
+    _lib.load().kv_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(n))
+    return n.value
+
+
+@pytest.fixture
+def skm():
+    """Force the super-k-mer path (it is the default only from 4 M k-mers up) and record which kernels ran."""
+    from kevlar_amd import _lib
+    lib = _lib.load()
+    lib.kv_prof_reset()
+    lib.kv_prof_enable(1)
+    os.environ['KV_COUNT_PATH'] = 'skm'
+    os.environ['KV_NOVEL_PATH'] = 'skm'
+    yield lib
+    lib.kv_prof_enable(0)
+    for name in KNOBS:
+        os.environ.pop(name, None)
+
+
+def trio_reads(genome_len, n, seed, read_len=100):
+    from kevlar_amd import synth
+    trio = synth.make_trio(genome_len, seed, inherited_per_mb=400, denovo_per_mb=400)
+    out = {}
+    for i, name in enumerate(('proband', 'mother', 'father')):
+        words = synth.sample_reads_packed(trio[name], n, read_len, 0.005, seed + 1 + i)
+        out[name] = synth.unpack_reads(words, read_len)
+    return out
+
+
+def count_both(hk, ok, kind, k, tablesize, reads):
+    dev, ref = getattr(hk, kind)(k, tablesize, 4), getattr(ok, kind)(k, tablesize, 4)
+    n_dev = dev.consume_batch(hk.ReadBatch(reads))
+    bases, offs = ok.concat_reads(reads)
+    n_ref = ok.consume_reads(ref, bases, offs, len(reads))
+    return dev, ref, n_dev, n_ref
+
+
+def assert_same_tables(dev, ref):
+    for t in range(len(ref.hashsizes())):
+        assert dev.table_bytes(t) == ref.table_bytes(t), 'table {} differs from the oracle'.format(t)
+    assert dev.n_occupied() == ref.n_occupied()
+
+
+@pytest.mark.parametrize('kind,k,tablesize', [('Counttable', 31, 1.5e6), ('SmallCounttable', 31, 1.2e6), ('Nodetable', 31, 4e6),
+                                              ('Counttable', 21, 1.5e6), ('Counttable', 16, 8e5), ('Counttable', 32, 1.5e6),
+                                              ('Counttable', 33, 1.5e6), ('Counttable', 51, 1.5e6), ('Counttable', 64, 1.5e6)])
+def test_skm_count_matches_oracle(hk, ok, skm, kind, k, tablesize):
+    os.environ['KV_SKM_BUCKET_KMERS'] = '2048'      # ~600 fine buckets on this input
+    reads = trio_reads(150000, 18000, 5)['proband']
+    dev, ref, n_dev, n_ref = count_both(hk, ok, kind, k, tablesize, reads)
+    assert launches('k_skm_count') == 1 and launches('k_bin_apply_w') == 1 and launches('k_consume') == 0
+    assert n_dev == n_ref == 18000 * (100 - k + 1)
+    assert_same_tables(dev, ref)
+    assert abs(dev.n_unique_kmers() - ref.n_unique_kmers()) < 0.03 * ref.n_unique_kmers()
+    # a second batch lands on top of the first
+    more = trio_reads(150000, 9000, 8)['mother']
+    dev.consume_batch(hk.ReadBatch(more))
+    bases, offs = ok.concat_reads(more)
+    ok.consume_reads(ref, bases, offs, len(more))
+    assert_same_tables(dev, ref)
+
+
+def test_skm_single_bucket_and_default_geometry(hk, ok, skm):
+    """one coarse x one fine bucket (everything in one LDS table, most of it overflowing into the loose list), and
+    the geometry the library picks by itself"""
+    reads = trio_reads(60000, 2500, 3)['proband']
+    for target in ('100000000', None):
+        if target:
+            os.environ['KV_SKM_BUCKET_KMERS'] = target
+        else:
+            os.environ.pop('KV_SKM_BUCKET_KMERS', None)
+        dev, ref, n_dev, n_ref = count_both(hk, ok, 'Counttable', 31, 9e5, reads)
+        assert n_dev == n_ref
+        assert_same_tables(dev, ref)
+    assert launches('k_skm_count') == 2
+
+
+def test_skm_ragged_short_long_and_non_acgt_reads(hk, ok, skm):
+    rng = np.random.default_rng(12)
+    letters = np.array(list('ACGT'))
+
+    def rnd(n):
+        return ''.join(letters[rng.integers(0, 4, size=n)])
+    chrom = rnd(60011)
+    reads = [rnd(int(rng.integers(10, 260))) for _ in range(3000)]
+    reads += ['', 'ACG', rnd(30), rnd(31), rnd(32), chrom, rnd(7680), rnd(7681 + 30), rnd(8200), 'A' * 150, 'ACGT' * 40]
+    reads += [chrom[100:400], chrom[100:400], chrom[30000:30300]]
+    bad = list(rnd(140)); bad[70] = 'N'
+    low = rnd(50) + 'acgtn' + rnd(50)
+    reads += [''.join(bad), low]
+    os.environ['KV_SKM_BUCKET_KMERS'] = '1024'
+    for kind, k in (('Counttable', 31), ('Counttable', 45), ('SmallCounttable', 19)):
+        dev, ref, n_dev, n_ref = count_both(hk, ok, kind, k, 7e5, reads)
+        assert n_dev == n_ref
+        assert_same_tables(dev, ref)
+    assert launches('k_skm_count') == 3 and launches('k_consume') == 0
+
+
+def test_skm_skew_saturation_and_overflow_paths(hk, ok, skm):
+    """thousands of copies of a few k-mers (weights above 128 are split, counters saturate at 255 / 15), segments
+    sized at a fraction of what they need (records travel through the loose list), then a loose list that is too
+    small: the library must notice, leave the tables alone and fall back"""
+    base = trio_reads(100000, 9000, 21)['proband']
+    reads = base + ['A' * 100] * 700 + ['ACGT' * 25] * 300 + [base[0]] * 400
+    os.environ['KV_SKM_BUCKET_KMERS'] = '4096'
+    for kind in ('Counttable', 'SmallCounttable'):
+        dev, ref, n_dev, n_ref = count_both(hk, ok, kind, 31, 1e6, reads)
+        assert n_dev == n_ref
+        assert_same_tables(dev, ref)
+        assert dev.get('A' * 31) == ref.get('A' * 31) == (255 if kind == 'Counttable' else 15)
+    os.environ['KV_SKM_CAP_PCT'] = '30'
+    dev, ref, n_dev, n_ref = count_both(hk, ok, 'Counttable', 31, 1e6, reads)
+    assert n_dev == n_ref
+    assert_same_tables(dev, ref)
+    assert launches('k_skm_count') == 3 and launches('k_bin_hash_direct') == 0
+    os.environ['KV_SKM_LOOSE_CAP'] = '64'
+    dev, ref, n_dev, n_ref = count_both(hk, ok, 'Counttable', 31, 1e6, reads)
+    assert n_dev == n_ref
+    assert_same_tables(dev, ref)
+    assert launches('k_bin_hash_direct') + launches('k_consume') >= 1      # the fallback ran
+
+
+def test_skm_band_and_mask(hk, ok, skm):
+    reads = trio_reads(120000, 12000, 31)['proband']
+    dmask, rmask = hk.Nodetable(31, 1e6, 4), ok.Nodetable(31, 1e6, 4)
+    dmask.consume_batch(hk.ReadBatch(reads[:4000]))
+    bases, offs = ok.concat_reads(reads[:4000])
+    ok.consume_reads(rmask, bases, offs, 4000)
+    bases, offs = ok.concat_reads(reads)
+    os.environ['KV_SKM_BUCKET_KMERS'] = '2048'
+    for nbands, band, mask_args in [(4, 3, None), (4, 0, None), (0, 0, (0, False)), (2, 0, (1, True))]:
+        dev, ref = hk.Counttable(31, 9e5, 4), ok.Counttable(31, 9e5, 4)
+        if mask_args is None:
+            n_dev = dev.consume_batch(hk.ReadBatch(reads), nbands, band)
+            n_ref = ok.consume_reads(ref, bases, offs, len(reads), nbands, band)
+        else:
+            n_dev = dev.consume_batch(hk.ReadBatch(reads), nbands, band, dmask, mask_args[0], mask_args[1])
+            n_ref = ok.consume_reads(ref, bases, offs, len(reads), nbands, band, rmask, mask_args[0], mask_args[1])
+        assert n_dev == n_ref and n_dev > 0
+        assert_same_tables(dev, ref)
+    assert launches('k_skm_count') >= 4
+
+
+def scan_both(hk, ok, reads, k, mem, case_min=6, ctrl_max=1, nctrl=2, order=('mother', 'father', 'proband'), **kw):
+    names = ('proband', 'mother', 'father')[:1 + nctrl]
+    dev = {n: hk.Counttable(k, mem / 4, 4) for n in names}
+    ref = {n: ok.Counttable(k, mem / 4, 4) for n in names}
+    batches = {n: hk.ReadBatch(reads[n]) for n in names}
+    for n in [x for x in order if x in names]:                  # the case sample last: the scan can reuse its buckets
+        dev[n].consume_batch(batches[n])
+    for n in names:
+        bases, offs = ok.concat_reads(reads[n])
+        ok.consume_reads(ref[n], bases, offs, len(reads[n]))
+        assert_same_tables(dev[n], ref[n])
+    r, o, a, _ = hk.novel_scan([dev['proband']], [dev[n] for n in names[1:]], batches['proband'], case_min, ctrl_max, **kw)
+    bases, offs = ok.concat_reads(reads['proband'])
+    hits, _ = ok.novel_scan([ref['proband']], [ref[n] for n in names[1:]], bases, offs, len(reads['proband']), k,
+                            case_min, ctrl_max, 0, kw.get('band_mode', 0), kw.get('nbands', 0), kw.get('band', 0))
+    got = [(int(r[i]), int(o[i]), tuple(int(x) for x in a[i])) for i in range(len(r))]
+    return got, hits
+
+
+@pytest.mark.parametrize('k', [31, 25, 51])
+def test_skm_novel_scan_matches_oracle(hk, ok, skm, k):
+    os.environ['KV_SKM_BUCKET_KMERS'] = '2048'
+    reads = trio_reads(100000, 30000, 41)           # 30x: inherited k-mers well above case-min
+    got, hits = scan_both(hk, ok, reads, k, 6e6)
+    assert len(hits) > 50
+    assert got == hits
+    assert launches('k_skm_novel') == 1 and launches('k_novel_mark') == 0
+    assert launches('k_skm_emit') == 3              # the scan reused the buckets the case count had built
+
+
+def test_skm_novel_scan_rebuilds_when_the_case_was_counted_first_and_honours_skips(hk, ok, skm):
+    os.environ['KV_SKM_BUCKET_KMERS'] = '2048'
+    reads = trio_reads(80000, 24000, 43)
+    bad = list(reads['proband'][5]); bad[40] = 'N'
+    reads['proband'][5] = ''.join(bad)              # flagged: the scan skips it, the count keeps it
+    got, hits = scan_both(hk, ok, reads, 31, 5e6, order=('proband', 'mother', 'father'))
+    assert got == hits and len(hits) > 20
+    assert launches('k_skm_emit') == 4              # case buckets were overwritten by the controls: cut again
+    # first_read: reads in front of it are not scanned (--skip-until)
+    names = ('proband', 'mother', 'father')
+    dev = {n: hk.Counttable(31, 5e6 / 4, 4) for n in names}
+    batch = hk.ReadBatch(reads['proband'])
+    for n in ('mother', 'father'):
+        dev[n].consume_batch(hk.ReadBatch(reads[n]))
+    dev['proband'].consume_batch(batch)
+    r, o, a, _ = hk.novel_scan([dev['proband']], [dev['mother'], dev['father']], batch, 6, 1, first_read=9000)
+    want = [h for h in hits if h[0] >= 9000]
+    assert [(int(r[i]), int(o[i]), tuple(int(x) for x in a[i])) for i in range(len(r))] == want
+
+
+def test_skm_novel_scan_bands_multi_control_and_overflow(hk, ok, skm):
+    os.environ['KV_SKM_BUCKET_KMERS'] = '4096'
+    reads = trio_reads(80000, 24000, 47)
+    union = []
+    for band in range(3):
+        got, hits = scan_both(hk, ok, reads, 31, 5e6, band_mode=1, nbands=3, band=band)
+        assert got == hits
+        union += got
+    whole, hits = scan_both(hk, ok, reads, 31, 5e6)
+    assert sorted(union) == whole == hits
+    got, hits = scan_both(hk, ok, reads, 31, 5e6, band_mode=2, nbands=4, band=2)       # the reference's literal rule
+    assert got == hits
+    os.environ['KV_SKM_CAP_PCT'] = '30'             # loose records in the scan as well
+    got, hits = scan_both(hk, ok, reads, 31, 5e6, case_min=5, ctrl_max=2)
+    assert got == hits and len(hits) > 20
+    assert launches('k_novel_mark') == 0
+
+
+def test_default_paths_on_a_large_batch_agree_with_the_other_implementations(hk, skm):
+    """no knobs: 4.9 M k-mers take the super-k-mer path by default; tables equal those of the partitioned and the
+    atomic paths, hits equal those of the tile scan"""
+    for name in KNOBS:
+        os.environ.pop(name, None)
+    reads = trio_reads(400000, 70000, 51)
+    batches = {n: hk.ReadBatch(reads[n]) for n in reads}
+    sk = {}
+    for path in (None, 'binned', 'atomic'):
+        if path:
+            os.environ['KV_COUNT_PATH'] = path
+        else:
+            os.environ.pop('KV_COUNT_PATH', None)
+        sk[path] = {n: hk.Counttable(31, 2e7 / 4, 4) for n in ('mother', 'father', 'proband')}
+        for n in ('mother', 'father', 'proband'):
+            assert sk[path][n].consume_batch(batches[n]) == 70000 * 70
+    os.environ.pop('KV_COUNT_PATH', None)
+    assert launches('k_skm_count') == 3 and launches('k_bin_hash_direct') == 3 and launches('k_consume') == 3
+    for n in reads:
+        for t in range(4):
+            assert sk[None][n].table_bytes(t) == sk['binned'][n].table_bytes(t) == sk['atomic'][n].table_bytes(t)
+        assert sk[None][n].n_occupied() == sk['atomic'][n].n_occupied()
+    res = {}
+    for path in (None, 'tiles'):
+        if path:
+            os.environ['KV_NOVEL_PATH'] = path
+        r, o, a, _ = hk.novel_scan([sk[None]['proband']], [sk[None]['mother'], sk[None]['father']], batches['proband'], 6, 1)
+        res[path] = (r.tolist(), o.tolist(), a.tolist())
+    assert res[None] == res['tiles'] and len(res[None][0]) > 100
+    assert launches('k_skm_novel') == 1 and launches('k_novel_mark') == 1

@@ -388,3 +388,26 @@ AGGTCTTCGATGCTAGCATTTTTACGACAGACAAAAACAAGATTACATTCCAAAATACATACCGCGCC
                  ATTTTTACGAC          8 0 0#
                     TTTACGACAGA          11 0 0#
                       TACGACAGACA          9 0 0#"""
+
+
+def test_oracle_threaded_consume_equals_single_thread(ok):
+    """bench.py's all-cores CPU baseline (khmer-style: threads share one sketch, atomic saturating adds,
+    kevlar/count.py:41-76) must build the same tables as the scalar loop it is compared with"""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    letters = np.array(list('ACGT'))
+    genome = ''.join(letters[rng.integers(0, 4, size=5000)])
+    reads = [genome[s:s + 80] for s in rng.integers(0, 4920, size=3000)] + ['A' * 80] * 300 + ['ACG', '']
+    bases, offs = ok.concat_reads(reads)
+    for kind in ('Counttable', 'SmallCounttable', 'Nodetable'):
+        one, many = getattr(ok, kind)(21, 3e4, 4), getattr(ok, kind)(21, 3e4, 4)
+        n1 = ok.consume_reads(one, bases, offs, len(reads))
+        n4 = ok.consume_reads_mt(many, bases, offs, len(reads), 4)
+        assert n1 == n4 > 0
+        for t in range(4):
+            assert one.table_bytes(t) == many.table_bytes(t)
+        assert one.n_occupied() == many.n_occupied()
+    kid, mom = ok.Counttable(21, 3e4, 4), ok.Counttable(21, 3e4, 4)
+    ok.consume_reads(kid, bases, offs, len(reads))
+    hits, _ = ok.novel_scan([kid], [mom], bases, offs, len(reads), 21, 5, 0)
+    assert ok.novel_scan_count_mt([kid], [mom], bases, offs, len(reads), 21, 5, 0, 3) == len(hits) > 0

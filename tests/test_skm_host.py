@@ -1,0 +1,132 @@
+"""CPU checks of the bit-level helpers behind the super-k-mer front end (kevlar_amd/csrc/kv_skm_device.h).
+
+The header compiles for the host too; tests/harness/skm_host.cpp wraps it in a C ABI and this file compares it
+with string-level restatements (reverse complement, canonical form, rolling, packing).  No GPU involved."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, 'tests', 'harness', 'skm_host.cpp')
+HDR = os.path.join(ROOT, 'kevlar_amd', 'csrc', 'kv_skm_device.h')
+SO = os.path.join(ROOT, 'tests', 'harness', 'libskm_host.so')
+CODE = {'A': 0, 'C': 1, 'G': 2, 'T': 3}
+COMP = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A'}
+
+
+@pytest.fixture(scope='module')
+def lib():
+    clang = '/opt/rocm/lib/llvm/bin/clang++'
+    if not os.path.exists(clang):
+        pytest.skip('clang++ of the ROCm toolchain not found')
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.check_call([clang, '-x', 'c++', '-std=c++17', '-O1', '-fPIC', '-shared', '-o', SO, SRC])
+    L = ctypes.CDLL(SO)
+    L.h_mmer_value.restype = ctypes.c_uint32
+    L.h_bases32.restype = ctypes.c_uint64
+    L.h_ascii4.restype = ctypes.c_uint32
+    L.h_header.restype = ctypes.c_uint64
+    L.h_header.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]
+    L.h_hdr_pos.restype = ctypes.c_uint64
+    L.h_hdr_pos.argtypes = [ctypes.c_uint64]
+    L.h_hdr_n.argtypes = [ctypes.c_uint64]
+    L.h_hdr_fine.argtypes = [ctypes.c_uint64]
+    return L
+
+
+def pack(seq):
+    """2 bits per base, base p in bits 2p.. (the kv_reads layout), as a Python int"""
+    v = 0
+    for p, ch in enumerate(seq):
+        v |= CODE[ch] << (2 * p)
+    return v
+
+
+def revcomp(seq):
+    return ''.join(COMP[c] for c in reversed(seq))
+
+
+def words64(v, n):
+    return (ctypes.c_uint64 * n)(*[(v >> (64 * i)) & (2**64 - 1) for i in range(n)])
+
+
+def test_revcomp_matches_strings(lib):
+    rng = random.Random(1)
+    for k in list(range(16, 65)) * 3:
+        seq = ''.join(rng.choice('ACGT') for _ in range(k))
+        kw = 1 if k <= 32 else 2
+        out = (ctypes.c_uint64 * 2)()
+        lib.h_revcomp(kw, words64(pack(seq), 2), k, out)
+        assert out[0] | (out[1] << 64) == pack(revcomp(seq)), (k, seq)
+
+
+def test_rolling_gives_the_canonical_kmers_of_a_record(lib):
+    rng = random.Random(2)
+    for k in (16, 21, 31, 32, 33, 47, 51, 63, 64):
+        kw = 1 if k <= 32 else 2
+        nbw = kw + 1
+        ncap = 32 * nbw - k + 1
+        for n in (1, 2, ncap // 2, ncap):
+            seq = ''.join(rng.choice('ACGT') for _ in range(n + k - 1))
+            out = (ctypes.c_uint64 * (2 * n))()
+            lib.h_roll(kw, words64(pack(seq), 3), k, n, out)
+            for j in range(n):
+                kmer = seq[j:j + k]
+                want = min(pack(kmer), pack(revcomp(kmer)))
+                assert out[2 * j] | (out[2 * j + 1] << 64) == want, (k, n, j)
+
+
+def test_canonical_form_is_strand_symmetric(lib):
+    rng = random.Random(3)
+    for k in (31, 51):
+        kw = 1 if k <= 32 else 2
+        seq = ''.join(rng.choice('ACGT') for _ in range(k))
+        a = (ctypes.c_uint64 * 2)()
+        b = (ctypes.c_uint64 * 2)()
+        lib.h_roll(kw, words64(pack(seq), 3), k, 1, a)
+        lib.h_roll(kw, words64(pack(revcomp(seq)), 3), k, 1, b)
+        assert list(a) == list(b)
+
+
+def test_mmer_value_is_strand_symmetric_and_spreads(lib):
+    rng = random.Random(4)
+    seen = set()
+    for m in (8, 10, 12, 16):
+        for _ in range(200):
+            seq = ''.join(rng.choice('ACGT') for _ in range(m))
+            v = lib.h_mmer_value(pack(seq), m)
+            assert v == lib.h_mmer_value(pack(revcomp(seq)), m)
+            seen.add(v)
+    assert len(seen) > 700
+
+
+def test_bases32_and_ascii4(lib):
+    rng = random.Random(5)
+    seq = ''.join(rng.choice('ACGT') for _ in range(200))
+    v = pack(seq)
+    words = (ctypes.c_uint32 * 16)(*[(v >> (32 * i)) & 0xffffffff for i in range(16)])
+    for b in (0, 1, 15, 16, 17, 31, 33, 100):
+        assert lib.h_bases32(words, b) == pack(seq[b:b + 32])
+    for byte in range(256):
+        s = ''.join('ACGT'[(byte >> (2 * i)) & 3] for i in range(4))
+        assert lib.h_ascii4(byte) == int.from_bytes(s.encode(), 'little')
+
+
+def test_header_fields_and_bucket_ranges(lib):
+    h = lib.h_header(2**40 - 7, 46, 511)
+    assert (lib.h_hdr_pos(h), lib.h_hdr_n(h), lib.h_hdr_fine(h)) == (2**40 - 7, 46, 511)
+    rng = random.Random(6)
+    c, f = ctypes.c_uint32(), ctypes.c_uint32()
+    counts = {}
+    for _ in range(20000):
+        # minimizer values are minima of ~20 uniform draws: concentrated near zero
+        minv = min(rng.getrandbits(32) for _ in range(20))
+        lib.h_bucket_of(minv, 251, 8, ctypes.byref(c), ctypes.byref(f))
+        assert c.value < 251 and f.value < 256
+        counts[c.value] = counts.get(c.value, 0) + 1
+    assert len(counts) == 251 and max(counts.values()) < 4 * 20000 / 251
+    lib.h_bucket_of(12345, 1, 0, ctypes.byref(c), ctypes.byref(f))
+    assert (c.value, f.value) == (0, 0)
