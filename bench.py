@@ -155,7 +155,8 @@ def main():
             for lo in range(0, len(names), args.count_streams):
                 kmers += sum(hk.run_concurrently([job(n) for n in names[lo:lo + args.count_streams]]))
         else:
-            for n in names:
+            # controls first, the case sample last: its super-k-mer buckets are still in place when the scan starts
+            for n in names[1:] + names[:1]:
                 sketches[n].clear()
                 kmers += sketches[n].consume_batch(batches[n], nbands, band)
         t_b = time.perf_counter()
@@ -243,8 +244,10 @@ def main():
     lib.kv_prof_names(buf, 4096)
     times = {name: prof(lib, name) for name in buf.value.decode().split(',') if name}
     # the count is one logical kernel split over k_bin_* launches (or k_consume on the atomic path)
-    groups = {'count': [n_ for n_ in times if n_.startswith('k_bin_') or n_.startswith('k_route_') or n_ == 'k_consume'],
-              'novel': [n_ for n_ in times if n_.startswith('k_novel_') or n_ == 'k_tile_scan']}
+    count_prefixes = ('k_bin_', 'k_route_', 'k_skm_emit', 'k_skm_split', 'k_skm_count', 'k_skm_loose_count')
+    novel_prefixes = ('k_novel_', 'k_skm_novel', 'k_skm_loose_novel', 'k_tile_')
+    groups = {'count': [n_ for n_ in times if n_.startswith(count_prefixes) or n_ == 'k_consume'],
+              'novel': [n_ for n_ in times if n_.startswith(novel_prefixes)]}
     alg = {}
     for name in groups['count']:
         alg[name] = a_count

@@ -39,6 +39,7 @@ struct SkmGeom {
     unsigned long long *ctr;         // [0] loose records, [1] failure, [2] S1 tile ticket, [3] count ticket, [4] scan ticket,
                                      // [5] records emitted, [6] loose records after S1 + S2
     uint32_t n_buckets, quota3;
+    uint32_t sbw;                    // words of record-start bits per wave in the bucket walk
 };
 
 namespace {
@@ -67,28 +68,33 @@ struct SkmTile {
     uint32_t len[KV_TILE_MAX_READS], nk[KV_TILE_MAX_READS];
     uint32_t bpre[KV_TILE_MAX_READS + 1];      // staged-base prefix: flat position of a read's first base
     uint32_t wpre[KV_TILE_MAX_READS + 1];      // packed-word prefix inside the tile
-    uint32_t uni;                              // bases per read if all reads of the tile have the same length, else 0
-    float uni_inv;
+    uint32_t cpre[KV_TILE_MAX_READS + 1];      // chunk prefix (a chunk = CH consecutive k-mer starts of one read)
+    uint32_t uni_wpr, uni_cpr;                 // words / chunks per read if all reads of the tile have the same length, else 0
+    float inv_wpr, inv_cpr;
     uint32_t seg_start, read0, nstart, next_tile;
 };
 
-__device__ __forceinline__ void skm_locate(const SkmTile &sh, uint32_t nr, uint32_t q, uint32_t &r, uint32_t &j)
+// q / d for q < 2^16 with the precomputed float reciprocal (off by at most one before the fix-up)
+__device__ __forceinline__ uint32_t skm_div(uint32_t q, uint32_t d, float inv)
 {
-    if (sh.uni) {
-        uint32_t rr = (uint32_t)((float)q * sh.uni_inv);
-        if (rr * sh.uni > q) rr -= 1;
-        else if ((rr + 1) * sh.uni <= q) rr += 1;
-        r = rr; j = q - rr * sh.uni;
-        return;
-    }
-    uint32_t lo = 0, hi = nr;     // largest r with bpre[r] <= q (empty reads share their successor's prefix)
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (sh.bpre[mid] <= q) lo = mid; else hi = mid;
-    }
-    r = lo; j = q - sh.bpre[lo];
+    uint32_t r = (uint32_t)((float)q * inv);
+    if (r * d > q) r -= 1;
+    else if ((r + 1) * d <= q) r += 1;
+    return r;
 }
 
+__device__ __forceinline__ uint32_t skm_search(const uint32_t *pre, uint32_t n, uint32_t q)
+{
+    uint32_t lo = 0, hi = n;      // largest r with pre[r] <= q (empty entries share their successor's prefix)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pre[mid] <= q) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// CH consecutive k-mer starts per thread in the window-minimum pass; needs w > CH
+template <int CH>
 __global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t n_tiles, SkmGeom sg)
 {
     __shared__ SkmTile sh;
@@ -96,20 +102,29 @@ __global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t nwl = sg.np_max / 16u + KV_TILE_MAX_READS + 8u;     // every read starts on a word: up to one partial word each
     uint32_t *wl = smem;                                              // the tile's packed words
-    uint32_t *bufA = smem + nwl, *bufB = bufA + sg.np_max + 64u;
+    uint32_t *mh = smem + nwl;                                        // order value of the m-mer starting at every base
+    uint16_t *ids = (uint16_t *)(mh + sg.np_max + 96u);               // bucket (coarse << 8 | fine) of the k-mer starting at every base
+    uint32_t *starts = mh;                                            // run starts: reuses mh once the minima are taken
     const int k = sg.k, m = sg.m, w = sg.w;
+    const int lane = threadIdx.x & 63;
     for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_THREADS1) cur[c] = 0;
+    if (threadIdx.x == 0) sh.next_tile = (uint32_t)atomicAdd(&sg.ctr[2], 1ull);
     uint64_t n_rec = 0;
     for (uint32_t taken = 0; taken < sg.quota1; ++taken) {
-        __syncthreads();
-        if (threadIdx.x == 0) sh.next_tile = (uint32_t)atomicAdd(&sg.ctr[2], 1ull);
-        __syncthreads();
+        __syncthreads();                                   // previous tile finished, ticket visible
         const uint32_t tile = sh.next_tile;
         if (tile >= n_tiles) break;
         const TileDesc td = rd.tile[tile];
         const uint32_t r0 = td.first, nr = td.count;
         const uint32_t seg_start = td.seg ? td.seg_start : 0u;
         const uint64_t w0 = rd.woff[r0] + (seg_start >> 4);
+        uint32_t nwords;
+        if (td.seg) {
+            const uint32_t rest = rd.len[r0] - seg_start, want = (uint32_t)KV_SEG_BASES + (uint32_t)k - 1u;
+            nwords = ((rest < want ? rest : want) + 15u) >> 4;
+        } else {
+            nwords = (uint32_t)(rd.woff[r0 + nr] - w0);
+        }
         if (threadIdx.x < 64) {
             const uint32_t i0 = 2 * threadIdx.x, i1 = i0 + 1;
             uint32_t l0 = 0, l1 = 0;
@@ -121,15 +136,22 @@ __global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t
                 }
             }
             if (i1 < nr) l1 = rd.len[r0 + i1];
-            uint32_t eb, tot;
+            const uint32_t k0 = l0 >= (uint32_t)k ? l0 - (uint32_t)k + 1u : 0u, k1 = l1 >= (uint32_t)k ? l1 - (uint32_t)k + 1u : 0u;
+            const uint32_t c0 = (k0 + CH - 1) / CH, c1 = (k1 + CH - 1) / CH;
+            uint32_t eb, tot, ecb, ctot;
             const uint32_t ea = wave_excl_scan2(l0, l1, eb, tot);
-            if (i0 < nr) { sh.len[i0] = l0; sh.nk[i0] = l0 >= (uint32_t)k ? l0 - (uint32_t)k + 1u : 0u; sh.bpre[i0] = ea; }
-            if (i1 < nr) { sh.len[i1] = l1; sh.nk[i1] = l1 >= (uint32_t)k ? l1 - (uint32_t)k + 1u : 0u; sh.bpre[i1] = eb; }
-            if (threadIdx.x == 0) { sh.bpre[nr] = tot; sh.seg_start = seg_start; sh.read0 = r0; sh.nstart = 0; }
+            const uint32_t eca = wave_excl_scan2(c0, c1, ecb, ctot);
+            if (i0 < nr) { sh.len[i0] = l0; sh.nk[i0] = k0; sh.bpre[i0] = ea; sh.cpre[i0] = eca; }
+            if (i1 < nr) { sh.len[i1] = l1; sh.nk[i1] = k1; sh.bpre[i1] = eb; sh.cpre[i1] = ecb; }
+            if (threadIdx.x == 0) { sh.bpre[nr] = tot; sh.cpre[nr] = ctot; sh.seg_start = seg_start; sh.read0 = r0; sh.nstart = 0; }
             const uint32_t ref = __shfl(l0, 0);
             const bool same = (i0 >= nr || l0 == ref) && (i1 >= nr || l1 == ref);
-            const bool uniform = __all(same) && ref > 0;
-            if (threadIdx.x == 0) { sh.uni = uniform ? ref : 0u; sh.uni_inv = uniform ? 1.0f / (float)ref : 0.0f; }
+            const bool uniform = __all(same) && ref >= (uint32_t)k;
+            if (threadIdx.x == 0) {
+                const uint32_t wpr = (ref + 15u) >> 4, cpr = (ref - (uint32_t)k + 1u + CH - 1) / CH;
+                sh.uni_wpr = uniform ? wpr : 0u; sh.uni_cpr = uniform ? cpr : 0u;
+                sh.inv_wpr = uniform ? 1.0f / (float)wpr : 0.0f; sh.inv_cpr = uniform ? 1.0f / (float)cpr : 0.0f;
+            }
             if (td.seg) {
                 if (threadIdx.x == 0) { sh.wpre[0] = 0; sh.wpre[1] = (l0 + 15) >> 4; }
             } else {
@@ -138,65 +160,82 @@ __global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t
                 if (threadIdx.x == 0) sh.wpre[nr] = (uint32_t)(rd.woff[r0 + nr] - w0);
             }
         }
-        __syncthreads();
-        const uint32_t nwords = sh.wpre[nr], NB = sh.bpre[nr];
         for (uint32_t i = threadIdx.x; i < nwords + 8u; i += SKM_THREADS1) wl[i] = i < nwords ? rd.words[w0 + i] : 0u;
-        if (threadIdx.x < 64) { bufA[NB + threadIdx.x] = 0xffffffffu; bufB[NB + threadIdx.x] = 0xffffffffu; }
         __syncthreads();
-        // P1: order value of the m-mer starting at every base
+        // the next ticket is fetched while this tile is processed (everybody has read the current one by now)
+        if (threadIdx.x == 0) sh.next_tile = taken + 1 < sg.quota1 ? (uint32_t)atomicAdd(&sg.ctr[2], 1ull) : 0xffffffffu;
+        const uint32_t NB = sh.bpre[nr];
+        // P1: one thread per packed word: the order values of the m-mers starting at its 16 bases
         const uint32_t mmask = m == 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
-        for (uint32_t q = threadIdx.x; q < NB; q += SKM_THREADS1) {
-            uint32_t r, j;
-            skm_locate(sh, nr, q, r, j);
-            uint32_t v = 0xffffffffu;
-            if (j + (uint32_t)m <= sh.len[r]) {
-                const uint32_t a = sh.wpre[r] + (j >> 4), s2 = 2u * (j & 15u);
-                const uint64_t win = (uint64_t)wl[a] | ((uint64_t)wl[a + 1] << 32);
-                v = skm_mmer_value((uint32_t)(win >> s2) & mmask, m);
+        for (uint32_t wi = threadIdx.x; wi < nwords; wi += SKM_THREADS1) {
+            const uint32_t r = sh.uni_wpr ? skm_div(wi, sh.uni_wpr, sh.inv_wpr) : skm_search(sh.wpre, nr, wi);
+            const uint32_t j0 = (wi - sh.wpre[r]) * 16u, L = sh.len[r];
+            const uint32_t q0 = sh.bpre[r] + j0;
+            const uint64_t win = (uint64_t)wl[wi] | ((uint64_t)wl[wi + 1] << 32);
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const uint32_t j = j0 + (uint32_t)jj;
+                if (j < L) mh[q0 + jj] = j + (uint32_t)m <= L ? skm_mmer_value((uint32_t)(win >> (2 * jj)) & mmask, m) : 0xffffffffu;
             }
-            bufA[q] = v;
         }
+        if (threadIdx.x < 96) mh[NB + threadIdx.x] = 0xffffffffu;
         __syncthreads();
-        // P2: minimum over the w m-mers of every k-mer: windows of 1, 2, 4 .. wpow by doubling, then two overlapping windows
-        uint32_t *src = bufA, *dst = bufB;
-        for (int s = 1; 2 * s <= w; s <<= 1) {
-            for (uint32_t q = threadIdx.x; q < NB; q += SKM_THREADS1) dst[q] = min(src[q], src[q + (uint32_t)s]);
-            __syncthreads();
-            uint32_t *t = src; src = dst; dst = t;
-        }
-        const uint32_t tail = (uint32_t)(w - sg.wpow);
-        for (uint32_t q = threadIdx.x; q < NB; q += SKM_THREADS1) {
-            uint32_t r, j;
-            skm_locate(sh, nr, q, r, j);
-            uint32_t id = 0xffffffffu;                       // bucket id coarse << 16 | fine of the k-mer starting here
-            if (j < sh.nk[r]) {
+        // P2: one thread per chunk of CH k-mer starts: the minimum over the w m-mers of each (shared suffix of the
+        // chunk + the w - 1 - CH values every window contains + a growing prefix), its bucket, and where runs start
+        const uint32_t nchunks = sh.cpre[nr];             // <= 8192 / CH + 64 < 3 * SKM_THREADS1
+        uint32_t my_q[3], my_starts[3];
+#pragma unroll
+        for (int round = 0; round < 3; ++round) {
+            const uint32_t ci = (uint32_t)round * SKM_THREADS1 + threadIdx.x;
+            uint32_t startmask = 0, q = 0;
+            if (ci < nchunks) {
+                const uint32_t r = sh.uni_cpr ? skm_div(ci, sh.uni_cpr, sh.inv_cpr) : skm_search(sh.cpre, nr, ci);
+                const uint32_t j = (ci - sh.cpre[r]) * CH, nkr = sh.nk[r];
+                q = sh.bpre[r] + j;
+                uint32_t suf[CH + 1];                     // suf[i + 1] = min(mh[q + i .. q + CH - 1]), i = -1 .. CH - 1
+                uint32_t run = 0xffffffffu;
+#pragma unroll
+                for (int i = CH - 1; i >= 0; --i) { run = min(run, mh[q + i]); suf[i + 1] = run; }
+                suf[0] = j > 0 ? min(run, mh[q - 1]) : run;
+                uint32_t mid = 0xffffffffu;
+                for (uint32_t t = CH; t + 2 <= (uint32_t)w; ++t) mid = min(mid, mh[q + t]);     // mh[q + CH .. q + w - 2]
                 uint32_t coarse, fine;
-                skm_bucket_of(min(src[q], src[q + tail]), sg.C1, sg.fbits, coarse, fine);
-                id = (coarse << 16) | fine;
-            }
-            dst[q] = id;
-        }
-        __syncthreads();
-        // P3: a run starts where a read starts or the bucket changes
-        uint32_t *ids = dst, *starts = src;
-        for (uint32_t q0 = 0; q0 < NB; q0 += SKM_THREADS1) {
-            const uint32_t q = q0 + threadIdx.x;
-            bool is_start = false;
-            if (q < NB) {
-                const uint32_t id = ids[q];
-                if (id != 0xffffffffu) {
-                    uint32_t r, j;
-                    skm_locate(sh, nr, q, r, j);
-                    is_start = j == 0 || ids[q - 1] != id;
+                skm_bucket_of(min(suf[0], mid), sg.C1, sg.fbits, coarse, fine);
+                uint32_t prev = (coarse << 8) | fine;     // bucket of the k-mer in front of the chunk (unused when j == 0)
+                run = 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    run = min(run, mh[q + (uint32_t)w - 1u + i]);
+                    skm_bucket_of(min(min(suf[i + 1], mid), run), sg.C1, sg.fbits, coarse, fine);
+                    const uint32_t id = (coarse << 8) | fine;
+                    if (j + (uint32_t)i < nkr) {
+                        ids[q + i] = (uint16_t)id;
+                        if (j + (uint32_t)i == 0 || id != prev) startmask |= 1u << i;
+                    }
+                    prev = id;
                 }
             }
-            const unsigned long long ballot = __ballot(is_start);
-            if (ballot) {
-                const int lane = threadIdx.x & 63;
-                uint32_t first = 0;
-                if (lane == 0) first = atomicAdd(&sh.nstart, (uint32_t)__popcll(ballot));
-                first = __shfl(first, 0);
-                if (is_start) starts[first + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull))] = q;
+            my_q[round] = q; my_starts[round] = startmask;
+        }
+        __syncthreads();                                  // every window minimum is taken: the run starts may overwrite mh
+#pragma unroll
+        for (int round = 0; round < 3; ++round) {
+            if ((uint32_t)round * SKM_THREADS1 >= nchunks) break;
+            const uint32_t cnt = (uint32_t)__popc(my_starts[round]);
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            uint32_t base = 0;
+            if (lane == 63 && incl) base = atomicAdd(&sh.nstart, incl);
+            base = __shfl(base, 63) + incl - cnt;
+            uint32_t bits = my_starts[round];
+            while (bits) {
+                const int i = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                starts[base++] = my_q[round] + (uint32_t)i;
             }
         }
         __syncthreads();
@@ -204,14 +243,13 @@ __global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t
         const uint32_t nstart = sh.nstart;
         for (uint32_t i = threadIdx.x; i < nstart; i += SKM_THREADS1) {
             const uint32_t q = starts[i];
-            uint32_t r, j;
-            skm_locate(sh, nr, q, r, j);
+            const uint32_t r = skm_search(sh.bpre, nr, q), j = q - sh.bpre[r];
             const uint32_t id = ids[q];
             const uint32_t limit = q - j + sh.nk[r];          // flat position one past the read's last k-mer
             uint32_t e = q + 1;
             while (e < limit && ids[e] == id) ++e;
             uint32_t left = e - q;
-            const uint32_t coarse = id >> 16, fine = id & 0xffffu;
+            const uint32_t coarse = id >> 8, fine = id & 0xffu;
             uint64_t pos = (uint64_t)(sh.read0 + r) * sg.stride + sh.seg_start + j;
             uint32_t b = sh.wpre[r] * 16u + j;                // base index inside wl
             while (left) {
@@ -235,31 +273,41 @@ __global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t
 }
 
 // ---- S2 ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_skm_split(SkmGeom sg)
+#define SKM_THREADS2 512
+__global__ __launch_bounds__(SKM_THREADS2) void k_skm_split(SkmGeom sg)
 {
-    __shared__ uint32_t cur[512];
+    __shared__ uint32_t cur[256];
+    __shared__ uint32_t spre[769];                    // record prefix over the coarse segments this workgroup drains
     const uint32_t c = blockIdx.y;
-    for (uint32_t f = threadIdx.x; f < sg.F2; f += 256) cur[f] = 0;
+    for (uint32_t f = threadIdx.x; f < sg.F2; f += SKM_THREADS2) cur[f] = 0;
+    // segments seg = blockIdx.x, blockIdx.x + nwg2, ...: their records are enumerated flat, so every thread has work
+    const uint32_t nmine = (sg.nwg1 - blockIdx.x + sg.nwg2 - 1) / sg.nwg2;       // <= 768
+    for (uint32_t i = threadIdx.x; i < nmine; i += SKM_THREADS2) spre[i + 1] = sg.cnt1[(uint64_t)c * sg.nwg1 + blockIdx.x + i * sg.nwg2];
     __syncthreads();
-    const int recw = sg.recw;
-    for (uint32_t seg = blockIdx.x; seg < sg.nwg1; seg += sg.nwg2) {
-        const uint32_t n = sg.cnt1[(uint64_t)c * sg.nwg1 + seg];
-        const uint64_t *src = sg.seg1 + ((uint64_t)c * sg.nwg1 + seg) * sg.cap1 * (uint64_t)recw;
-        for (uint32_t i = threadIdx.x; i < n; i += 256) {
-            const uint64_t *rec = src + (uint64_t)i * recw;
-            const uint64_t hdr = rec[0];
-            uint64_t bw[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
-            const uint32_t fine = skm_hdr_fine(hdr);
-            const uint32_t p = atomicAdd(&cur[fine], 1u);
-            if (p < sg.cap2)
-                skm_store_record(sg.seg2 + ((((uint64_t)c * sg.F2 + fine) * sg.nwg2 + blockIdx.x) * sg.cap2 + p) * (uint64_t)recw, hdr, bw, sg.nbw);
-            else skm_loose_push(sg, hdr, bw);
-        }
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < nmine; ++i) { const uint32_t n = spre[i + 1]; spre[i] = acc; acc += n; }
+        spre[nmine] = acc;
     }
     __syncthreads();
-    for (uint32_t f = threadIdx.x; f < sg.F2; f += 256)
+    const uint32_t total = spre[nmine];
+    const int recw = sg.recw;
+    for (uint32_t i = threadIdx.x; i < total; i += SKM_THREADS2) {
+        const uint32_t si = skm_search(spre, nmine, i);
+        const uint32_t seg = blockIdx.x + si * sg.nwg2;
+        const uint64_t *rec = sg.seg1 + (((uint64_t)c * sg.nwg1 + seg) * sg.cap1 + (i - spre[si])) * (uint64_t)recw;
+        const uint64_t hdr = rec[0];
+        uint64_t bw[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
+        const uint32_t fine = skm_hdr_fine(hdr);
+        const uint32_t p = atomicAdd(&cur[fine], 1u);
+        if (p < sg.cap2)
+            skm_store_record(sg.seg2 + ((((uint64_t)c * sg.F2 + fine) * sg.nwg2 + blockIdx.x) * sg.cap2 + p) * (uint64_t)recw, hdr, bw, sg.nbw);
+        else skm_loose_push(sg, hdr, bw);
+    }
+    __syncthreads();
+    for (uint32_t f = threadIdx.x; f < sg.F2; f += SKM_THREADS2)
         sg.cnt2[((uint64_t)c * sg.F2 + f) * sg.nwg2 + blockIdx.x] = min(cur[f], sg.cap2);
 }
 
@@ -346,10 +394,10 @@ __device__ __forceinline__ uint32_t skm_count_kmer(uint64_t h, uint32_t count, c
 // every wave walks its share of the table and hands the occupied slots to `body` 64 at a time (all lanes busy):
 // occupied slots are queued in LDS and drained whenever a full wave of them is ready
 template <int TS, typename Body>
-__device__ __forceinline__ void skm_for_occupied(const unsigned long long *key0, uint16_t *queue_all, Body body)
+__device__ __forceinline__ void skm_for_occupied(const unsigned long long *key0, uint16_t *queue_all, uint32_t queue_stride, Body body)
 {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    volatile uint16_t *queue = queue_all + wave * 128u;
+    volatile uint16_t *queue = queue_all + wave * queue_stride;      // >= 128 entries
     const uint32_t per_wave = TS / nwaves;
     const uint32_t s_end = (wave + 1) * per_wave;
     uint32_t qn = 0;                                    // < 64 between iterations
@@ -374,21 +422,114 @@ __device__ __forceinline__ void skm_for_occupied(const unsigned long long *key0,
     }
 }
 
+// ---- balanced walk over the k-mer occurrences of a fine bucket ------------------------------------------------
+// Records hold 1..ncap k-mers, so a thread per record would leave most lanes waiting for the longest one.  Instead
+// each wave takes 64 records at a time (one per lane, in registers), numbers their k-mers with a prefix sum and
+// walks the occurrences 64 at a time: lane p of block t0 handles occurrence t0 + p, finds the record that owns it
+// from a bit mask of record starts (one LDS word pair per block, popcounts) and fetches that record's words from
+// the owning lane with ds_bpermute.  The k-mer is cut straight out of the record at its offset.
+
+__device__ __forceinline__ uint64_t skm_shfl64(uint64_t v, uint32_t src)
+{
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, (int)src), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// bases j .. j + k - 1 of a record's base words
+template <int KW>
+__device__ __forceinline__ SkmKey<KW> skm_kmer_at(uint64_t b0, uint64_t b1, uint64_t b2, uint32_t j, int k)
+{
+    uint32_t sh = 2u * j;
+    SkmKey<KW> f;
+    if (KW == 1) {
+        uint64_t v;
+        if (sh >= 64) v = b1 >> (sh - 64);
+        else v = (b0 >> sh) | (sh ? b1 << (64 - sh) : 0ull);
+        f.w[0] = v & skm_topmask<1>(k);
+    } else {
+        uint64_t x0 = b0, x1 = b1, x2 = b2;
+        if (sh >= 64) { x0 = b1; x1 = b2; x2 = 0; sh -= 64; }
+        f.w[0] = (x0 >> sh) | (sh ? x1 << (64 - sh) : 0ull);
+        f.w[KW - 1] = ((x1 >> sh) | (sh ? x2 << (64 - sh) : 0ull)) & skm_topmask<2>(k);
+    }
+    return f;
+}
+
+// body(forward k-mer, position of the occurrence); WANT_POS = false skips fetching the header (count pass)
+template <int KW, bool WANT_POS, typename Body>
+__device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, uint32_t *sbits_all, Body body)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    uint32_t *sbits = sbits_all + wave * sg.sbw;       // sbw words: 64 records x ncap k-mers, + the word a 64-bit read may straddle into
+    const int k = sg.k, recw = sg.recw;
+    uint32_t NR = 0;
+    for (uint32_t s = 0; s < sg.nwg2; ++s) NR += sg.cnt2[(uint64_t)b * sg.nwg2 + s];
+    for (uint32_t g0 = wave * 64u; g0 < NR; g0 += nwaves * 64u) {
+        const uint32_t i = g0 + lane;
+        uint64_t hdr = 0, b0 = 0, b1 = 0, b2 = 0;
+        if (i < NR) {
+            uint32_t s = 0, off = i;                    // segment of record i (at most 16 of them)
+            for (;;) {
+                const uint32_t n = sg.cnt2[(uint64_t)b * sg.nwg2 + s];
+                if (off < n) break;
+                off -= n; ++s;
+            }
+            const uint64_t *rec = sg.seg2 + (((uint64_t)b * sg.nwg2 + s) * sg.cap2 + off) * (uint64_t)recw;
+            hdr = rec[0]; b0 = rec[1]; b1 = rec[2];
+            if (KW == 2) b2 = rec[3];
+        }
+        const uint32_t nk = i < NR ? skm_hdr_n(hdr) : 0u;
+        uint32_t incl = nk;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63), excl = incl - nk;
+        const uint32_t nwords = (total >> 5) + 2u;
+        for (uint32_t wd = lane; wd < nwords; wd += 64) sbits[wd] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (nk) atomicOr(&sbits[excl >> 5], 1u << (excl & 31));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t before = 0;                            // records that start in front of this block
+        for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+            const uint64_t starts = (uint64_t)((volatile uint32_t *)sbits)[t0 >> 5] | ((uint64_t)((volatile uint32_t *)sbits)[(t0 >> 5) + 1] << 32);
+            const uint32_t t = t0 + lane;
+            const uint32_t owner = (before + (uint32_t)__popcll(starts & ((2ull << lane) - 1ull)) - 1u) & 63u;
+            before += (uint32_t)__popcll(starts);
+            const uint32_t ex = (uint32_t)__shfl((int)excl, (int)owner);
+            const uint64_t o0 = skm_shfl64(b0, owner), o1 = skm_shfl64(b1, owner);
+            const uint64_t o2 = KW == 2 ? skm_shfl64(b2, owner) : 0ull;
+            const uint64_t oh = WANT_POS ? skm_shfl64(hdr, owner) : 0ull;
+            if (t < total) {
+                const uint32_t j = t - ex;
+                body(skm_kmer_at<KW>(o0, o1, o2, j, k), skm_hdr_pos(oh) + j);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                // the next group clears the mask
+    }
+}
+
 // ---- S3: count ------------------------------------------------------------------------------------------
+// dynamic LDS of the bucket kernels: [256] byte -> ASCII table, [T * C] bin cursors (count only), then the per-wave
+// scratch: record-start bits of the walk, reused as the queue of occupied slots
+__host__ __device__ inline uint32_t skm_wave_scratch_words(uint32_t sbw) { return sbw > 64u ? sbw : 64u; }
+
 template <int KW, int TS>
 __global__ __launch_bounds__(SKM_THREADS3) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
                                                            const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
     __shared__ SkmTable<KW, TS> tb;
     __shared__ uint32_t cnt[TS];                 // occurrences of the key in the same slot
-    __shared__ uint32_t lut[256];
-    __shared__ uint32_t cur[BIN_MAX_T * BIN_C];
-    __shared__ uint16_t queue[(SKM_THREADS3 / 64) * 128];
     __shared__ uint32_t next_bucket;
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
     const uint32_t ns = (uint32_t)(g.T * g.C);
+    uint32_t *lut = dyn, *cur = dyn + 256, *scratch = cur + ((ns + 3u) & ~3u);
     for (uint32_t s = threadIdx.x; s < ns; s += SKM_THREADS3) cur[s] = 0;
     if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
-    const int k = sg.k, recw = sg.recw;
+    const int k = sg.k;
     uint64_t n_added = 0;
     auto emit = [&](int t, uint64_t bin, uint32_t wgt) {
         const uint32_t slice = (uint32_t)(bin >> 16);
@@ -407,34 +548,19 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_count(SkmGeom sg, const Sk
         __syncthreads();
         const uint32_t b = next_bucket;
         if (b >= sg.n_buckets) break;
-        // combine: one thread per record, rolling along its k-mers
-        for (uint32_t s = 0; s < sg.nwg2; ++s) {
-            const uint32_t n = sg.cnt2[(uint64_t)b * sg.nwg2 + s];
-            const uint64_t *src = sg.seg2 + ((uint64_t)b * sg.nwg2 + s) * sg.cap2 * (uint64_t)recw;
-            for (uint32_t i = threadIdx.x; i < n; i += SKM_THREADS3) {
-                const uint64_t *rec = src + (uint64_t)i * recw;
-                const uint64_t hdr = rec[0];
-                uint64_t bw[3];
-#pragma unroll
-                for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
-                const uint32_t nk = skm_hdr_n(hdr);
-                SkmKey<KW> fw = skm_first_kmer<KW>(bw, k);
-                SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
-                for (uint32_t j = 0; j < nk; ++j) {
-                    if (j) skm_roll<KW>(fw, rc, skm_base_at(bw, j + (uint32_t)k - 1u), k);
-                    const SkmKey<KW> c = skm_canonical<KW>(fw, rc);
-                    const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
-                    if (slot >= 0) atomicAdd(&cnt[slot], 1u);
-                    else {   // table region full (or unstorable key): this occurrence travels alone
-                        uint64_t one[3] = {fw.w[0], KW == 2 ? fw.w[KW - 1] : 0ull, 0ull};
-                        skm_loose_push(sg, skm_header(skm_hdr_pos(hdr) + j, 1u, 0u), one);
-                    }
-                }
+        // combine the occurrences of the bucket
+        skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t) {
+            const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
+            const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
+            if (slot >= 0) atomicAdd(&cnt[slot], 1u);
+            else {   // table region full (or unstorable key): this occurrence travels alone
+                uint64_t one[3] = {fw.w[0], KW == 2 ? fw.w[KW - 1] : 0ull, 0ull};
+                skm_loose_push(sg, skm_header(0, 1u, 0u), one);
             }
-        }
+        });
         __syncthreads();
         // every distinct k-mer once
-        skm_for_occupied<TS>(tb.key[0], queue, [&](uint32_t slot) {
+        skm_for_occupied<TS>(tb.key[0], (uint16_t *)scratch, skm_wave_scratch_words(sg.sbw) * 2u, [&](uint32_t slot) {
             SkmKey<KW> c;
             c.w[0] = tb.key[0][slot];
             if (KW == 2) c.w[KW - 1] = tb.key[KW - 1][slot];
@@ -495,13 +621,13 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_novel(SkmGeom sg, ReadsDev
 {
     __shared__ SkmTable<KW, TS> tb;
     __shared__ uint32_t flag[TS / 32];           // bit per slot: the key is interesting
-    __shared__ uint32_t lut[256];
-    __shared__ uint16_t queue[(SKM_THREADS3 / 64) * 128];
     __shared__ NovelShared ns;
     __shared__ uint32_t next_bucket, any_hit;
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
+    uint32_t *lut = dyn, *scratch = dyn + 256;
     if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
     load_descs(ns, p);
-    const int k = sg.k, recw = sg.recw;
+    const int k = sg.k;
     for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
         __syncthreads();
         if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull); any_hit = 0; }
@@ -510,49 +636,33 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_novel(SkmGeom sg, ReadsDev
         __syncthreads();
         const uint32_t b = next_bucket;
         if (b >= sg.n_buckets) break;
-        for (int pass = 0; pass < 2; ++pass) {
-            // pass 0: collect the distinct k-mers; pass 1 (after they have been evaluated): mark the occurrences
-            if (pass == 1 && any_hit == 0) break;
-            for (uint32_t s = 0; s < sg.nwg2; ++s) {
-                const uint32_t n = sg.cnt2[(uint64_t)b * sg.nwg2 + s];
-                const uint64_t *src = sg.seg2 + ((uint64_t)b * sg.nwg2 + s) * sg.cap2 * (uint64_t)recw;
-                for (uint32_t i = threadIdx.x; i < n; i += SKM_THREADS3) {
-                    const uint64_t *rec = src + (uint64_t)i * recw;
-                    const uint64_t hdr = rec[0];
-                    uint64_t bw[3];
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
-                    const uint32_t nk = skm_hdr_n(hdr);
-                    SkmKey<KW> fw = skm_first_kmer<KW>(bw, k);
-                    SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
-                    for (uint32_t j = 0; j < nk; ++j) {
-                        if (j) skm_roll<KW>(fw, rc, skm_base_at(bw, j + (uint32_t)k - 1u), k);
-                        const SkmKey<KW> c = skm_canonical<KW>(fw, rc);
-                        if (pass == 0) {
-                            const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
-                            if (slot < 0) {
-                                uint64_t one[3] = {fw.w[0], KW == 2 ? fw.w[KW - 1] : 0ull, 0ull};
-                                skm_loose_push(sg, skm_header(skm_hdr_pos(hdr) + j, 1u, 0u), one);
-                            }
-                        } else if (skm_cacheable<KW>(c)) {
-                            const int slot = skm_table_find(tb, c);      // absent: that occurrence went to the loose list
-                            if (slot >= 0 && ((flag[slot >> 5] >> (slot & 31)) & 1u)) skm_mark(p, rd, skm_hdr_pos(hdr) + j, sg.stride);
-                        }
-                    }
-                }
+        // collect the distinct k-mers
+        skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t pos) {
+            const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
+            const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
+            if (slot < 0) {
+                uint64_t one[3] = {fw.w[0], KW == 2 ? fw.w[KW - 1] : 0ull, 0ull};
+                skm_loose_push(sg, skm_header(pos, 1u, 0u), one);
             }
-            __syncthreads();
-            if (pass == 0) {
-                skm_for_occupied<TS>(tb.key[0], queue, [&](uint32_t slot) {
-                    SkmKey<KW> c;
-                    c.w[0] = tb.key[0][slot];
-                    if (KW == 2) c.w[KW - 1] = tb.key[KW - 1][slot];
-                    const uint64_t h = skm_key_hash<KW>(c, lut, p.hp);
-                    if (band_pass(p, h) && novel_test_fast(ns, p, h, nullptr, 0ull)) { atomicOr(&flag[slot >> 5], 1u << (slot & 31)); any_hit = 1; }
-                });
-                __syncthreads();
-            }
-        }
+        });
+        __syncthreads();
+        // evaluate each of them once
+        skm_for_occupied<TS>(tb.key[0], (uint16_t *)scratch, skm_wave_scratch_words(sg.sbw) * 2u, [&](uint32_t slot) {
+            SkmKey<KW> c;
+            c.w[0] = tb.key[0][slot];
+            if (KW == 2) c.w[KW - 1] = tb.key[KW - 1][slot];
+            const uint64_t h = skm_key_hash<KW>(c, lut, p.hp);
+            if (band_pass(p, h) && novel_test_fast(ns, p, h, nullptr, 0ull)) { atomicOr(&flag[slot >> 5], 1u << (slot & 31)); any_hit = 1; }
+        });
+        __syncthreads();
+        if (any_hit == 0) continue;
+        // mark every occurrence of an interesting k-mer (an occurrence whose key is absent went to the loose list)
+        skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t pos) {
+            const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
+            if (!skm_cacheable<KW>(c)) return;
+            const int slot = skm_table_find(tb, c);
+            if (slot >= 0 && ((flag[slot >> 5] >> (slot & 31)) & 1u)) skm_mark(p, rd, pos, sg.stride);
+        });
     }
 }
 
@@ -656,14 +766,16 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     const char *tgt_env = getenv("KV_SKM_BUCKET_KMERS");      // tests shrink the buckets to exercise many of them on small inputs
     const uint64_t target = tgt_env ? std::max<uint64_t>(64, strtoull(tgt_env, nullptr, 10)) : 2ull * table_slots;
     const uint64_t nfine = std::max<uint64_t>(1, (n_kmers + target - 1) / target);
-    g.F2 = std::min<uint32_t>(512u, pow2_ceil((uint64_t)std::ceil(std::sqrt((double)nfine))));
-    if (nfine > 256ull * g.F2) g.F2 = std::min<uint32_t>(512u, pow2_ceil((nfine + 255) / 256));
+    // at most 255 x 256 buckets (a bucket id travels as 16 bits through S1); bigger batches get bigger buckets, which
+    // only costs deduplication efficiency
+    g.F2 = std::min<uint32_t>(256u, pow2_ceil((uint64_t)std::ceil(std::sqrt((double)nfine))));
+    if (nfine > 255ull * g.F2) g.F2 = std::min<uint32_t>(256u, pow2_ceil((nfine + 254) / 255));
     g.fbits = 0;
     while ((1u << g.fbits) < g.F2) ++g.fbits;
-    g.C1 = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(1, (nfine + g.F2 - 1) / g.F2));
+    g.C1 = (uint32_t)std::min<uint64_t>(255, std::max<uint64_t>(1, (nfine + g.F2 - 1) / g.F2));
     g.n_buckets = g.C1 * g.F2;
     const int cus = kv_device_cus();
-    g.nwg1 = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(reads->n_tiles, 1u), 2u * (uint32_t)cus);
+    g.nwg1 = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(reads->n_tiles, 1u), std::min<uint32_t>(768u, 3u * (uint32_t)cus));
     {
         const uint64_t avg = (reads->n_tiles + g.nwg1 - 1) / g.nwg1;
         g.quota1 = (uint32_t)std::min<uint64_t>(avg + avg / 2 + 1, 0xffffffffull);
@@ -699,13 +811,18 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));
     {
         KvProfScope prof("k_skm_emit");
-        const size_t lds = ((size_t)g.np_max / 16 + KV_TILE_MAX_READS + 8 + 2 * ((size_t)g.np_max + 64)) * 4;
-        kv_ensure_dynamic_lds((const void *)k_skm_emit, lds);
-        hipLaunchKernelGGL(k_skm_emit, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), reads->n_tiles, g);
+        const size_t lds = ((size_t)g.np_max / 16 + KV_TILE_MAX_READS + 8 + (size_t)g.np_max + 96) * 4 + ((size_t)g.np_max + 96) * 2;
+        if (g.w > 16) {
+            kv_ensure_dynamic_lds((const void *)k_skm_emit<16>, lds);
+            hipLaunchKernelGGL(k_skm_emit<16>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), reads->n_tiles, g);
+        } else {
+            kv_ensure_dynamic_lds((const void *)k_skm_emit<8>, lds);
+            hipLaunchKernelGGL(k_skm_emit<8>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), reads->n_tiles, g);
+        }
     }
     {
         KvProfScope prof("k_skm_split");
-        hipLaunchKernelGGL(k_skm_split, dim3(g.nwg2, g.C1), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(k_skm_split, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), 0, st, g);
     }
     KV_HIP(hipGetLastError());
     KV_HIP(hipMemcpyAsync(&g.ctr[6], &g.ctr[0], 8, hipMemcpyDeviceToDevice, st));   // loose records S1/S2 left behind
@@ -714,6 +831,7 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
         const uint64_t avg = (g.n_buckets + nwg3 - 1) / nwg3;
         g.quota3 = (uint32_t)(avg + avg / 2 + 1);
     }
+    g.sbw = ((64u * (uint32_t)g.ncap) >> 5) + 2u;
     idx.reads_uid = reads->uid;
     idx.k = k;
     idx.valid = true;
@@ -752,8 +870,10 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     const SketchDev *d_mask = mask ? mask->d_desc : nullptr;
     {
         KvProfScope prof("k_skm_count");
-        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_count<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
-        else hipLaunchKernelGGL((k_skm_count<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
+        const uint32_t ns = (uint32_t)(plan.g.T * plan.g.C);
+        const size_t lds = (256 + ((ns + 3u) & ~3u) + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw)) * 4;
+        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_count<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
+        else hipLaunchKernelGGL((k_skm_count<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
     }
     {
         KvProfScope prof("k_skm_loose_count");
@@ -796,8 +916,9 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
     const ReadsDev rd = reads_dev(reads);
     {
         KvProfScope prof("k_skm_novel");
-        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_novel<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), 0, st, sg, rd, p);
-        else hipLaunchKernelGGL((k_skm_novel<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), 0, st, sg, rd, p);
+        const size_t lds = (256 + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw)) * 4;
+        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_novel<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p);
+        else hipLaunchKernelGGL((k_skm_novel<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p);
     }
     {
         KvProfScope prof("k_skm_loose_novel");
