@@ -75,7 +75,7 @@ __device__ __forceinline__ bool ring_append(const Rings<ItemT> &rs, uint32_t s, 
 // per-burst parameters travel by v_readlane: the flush phase is instruction-bound, not bandwidth-bound.
 template <typename ItemT, typename Store, typename Overflow>
 __device__ __forceinline__ void rings_flush(const Rings<ItemT> &rs, uint32_t ns, bool final, uint32_t &written,
-                                            uint64_t seg_base, uint32_t cap, Store store, Overflow overflow)
+                                            uint64_t seg_base, uint32_t cap, Store store, Overflow overflow, uint32_t quantum = 32u)
 {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
     const uint32_t per_wave = (ns + nwaves - 1) / nwaves;             // <= 64
@@ -88,7 +88,7 @@ __device__ __forceinline__ void rings_flush(const Rings<ItemT> &rs, uint32_t ns,
         uint32_t newbase = base;
         if (avail > rs.R) { n = rs.R; newbase = base + avail; }   // overran: the excess was diverted at append time
         else if (final) { n = avail; newbase = base + n; }
-        else if (avail >= rs.R / 2) { n = avail & ~31u; newbase = base + n; }   // whole half-wave bursts: one copy iteration, all lanes busy
+        else if (avail >= rs.R / 2) { n = avail & ~(quantum - 1u); newbase = base + n; }   // whole half-wave bursts: one copy iteration, all lanes busy
         if (n) { pos = written; written += n; rs.base[s] = newbase; }
     }
     const uint32_t seg_lo = (uint32_t)seg_base, seg_hi = (uint32_t)(seg_base >> 32);
@@ -129,6 +129,7 @@ __device__ __forceinline__ void rings_flush_lanes(const Rings<ItemT> &rs, uint32
                                                   uint32_t cap, ItemT *gbuf, Overflow overflow)
 {
     constexpr uint32_t VEC = 16u / sizeof(ItemT);        // items per 16-byte vector
+    constexpr uint32_t QUANTUM = 64u / sizeof(ItemT);    // bursts are whole 64-byte sectors
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
     const uint32_t per_wave = (ns + nwaves - 1) / nwaves;
     const uint32_t s0 = wave * per_wave, s_end = min(ns, s0 + per_wave);
@@ -139,7 +140,7 @@ __device__ __forceinline__ void rings_flush_lanes(const Rings<ItemT> &rs, uint32
         const uint32_t avail = rs.cnt[s] - base;
         uint32_t n = 0, newbase = base;
         if (avail > rs.R) { n = rs.R; newbase = base + avail; }
-        else if (avail >= rs.R / 2) { n = avail & ~31u; newbase = base + n; }
+        else if (avail >= rs.R / 2) { n = avail & ~(QUANTUM - 1u); newbase = base + n; }
         if (n) {
             if ((base & 7u) || written + n > cap || (newbase & 7u)) misfit = true;
             else {
@@ -154,7 +155,7 @@ __device__ __forceinline__ void rings_flush_lanes(const Rings<ItemT> &rs, uint32
     }
     if (__ballot(misfit)) {
         auto store = [&](uint64_t idx, ItemT off) { gbuf[idx] = off; };
-        rings_flush(rs, ns, false, written, seg_base, cap, store, overflow);
+        rings_flush(rs, ns, false, written, seg_base, cap, store, overflow, QUANTUM);
     }
 }
 
@@ -451,7 +452,10 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
     auto overflow = [&](uint32_t fi, Out off) {
         spill_item(g, (int)t, (((uint64_t)c * F + fi) << 16) | ((uint32_t)off & 0xffffu), W ? (uint32_t)off >> 16 : 1u);
     };
-    const uint64_t step = (uint64_t)BIN_B_THREADS * BIN_B_ITEMS;
+    // Weighted items are u32: rings of 32 entries (64 would leave room for one workgroup per CU only) and half as many
+    // items per round, so that a round cannot overrun a ring that was below its flush threshold
+    constexpr int ITEMS = W ? 4 : BIN_B_ITEMS;
+    const uint64_t step = (uint64_t)BIN_B_THREADS * ITEMS;
     // this workgroup drains the private segments seg = blockIdx.x, blockIdx.x + nwgB, ... of bucket s
     for (uint32_t seg = blockIdx.x; seg < g.nwgA; seg += g.nwgB) {
         uint64_t end = g.gcnt1[(uint64_t)s * g.nwgA + seg];
@@ -459,40 +463,40 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
         const uint32_t *src = g.gbuf1 + ((uint64_t)s * g.nwgA + seg) * g.cap1;
         uint4 va = make_uint4(0, 0, 0, 0), vb = va;
         auto fetch = [&](uint64_t r0, uint4 &a, uint4 &b) {
-            const uint64_t i0 = r0 + (uint64_t)threadIdx.x * BIN_B_ITEMS;
-            if (i0 + BIN_B_ITEMS <= end) { a = *(const uint4 *)(src + i0); b = *(const uint4 *)(src + i0 + 4); }
+            const uint64_t i0 = r0 + (uint64_t)threadIdx.x * ITEMS;
+            if (i0 + ITEMS <= end) { a = *(const uint4 *)(src + i0); if (ITEMS == 8) b = *(const uint4 *)(src + i0 + 4); }
         };
         fetch(0, va, vb);
         for (uint64_t r0 = 0; r0 < end; r0 += step) {
-            const uint64_t i0 = r0 + (uint64_t)threadIdx.x * BIN_B_ITEMS;
-            uint32_t items[BIN_B_ITEMS];
+            const uint64_t i0 = r0 + (uint64_t)threadIdx.x * ITEMS;
+            uint32_t items[ITEMS];
             int have = 0;
-            if (i0 + BIN_B_ITEMS <= end) {
+            if (i0 + ITEMS <= end) {
                 items[0] = va.x; items[1] = va.y; items[2] = va.z; items[3] = va.w;
-                items[4] = vb.x; items[5] = vb.y; items[6] = vb.z; items[7] = vb.w;
-                have = BIN_B_ITEMS;
+                if (ITEMS == 8) { items[ITEMS - 4] = vb.x; items[ITEMS - 3] = vb.y; items[ITEMS - 2] = vb.z; items[ITEMS - 1] = vb.w; }
+                have = ITEMS;
             } else {
                 for (uint64_t i = i0; i < end; ++i) items[have++] = src[i];
             }
             if (r0 + step < end) fetch(r0 + step, va, vb);          // next round's items fly during this round
-            if (have == BIN_B_ITEMS) {
+            if (have == ITEMS) {
                 // full vector: all ring positions are requested back to back (independent LDS atomics in flight
                 // together), then consumed; an item whose ring is full is rare and handled after the fast path
-                uint32_t pos[BIN_B_ITEMS], rbase[BIN_B_ITEMS];
+                uint32_t pos[ITEMS], rbase[ITEMS];
 #pragma unroll
-                for (int j = 0; j < BIN_B_ITEMS; ++j) pos[j] = atomicAdd(&rs.cnt[slice_of(items[j])], 1u);
+                for (int j = 0; j < ITEMS; ++j) pos[j] = atomicAdd(&rs.cnt[slice_of(items[j])], 1u);
 #pragma unroll
-                for (int j = 0; j < BIN_B_ITEMS; ++j) rbase[j] = rs.base[slice_of(items[j])];
+                for (int j = 0; j < ITEMS; ++j) rbase[j] = rs.base[slice_of(items[j])];
                 uint32_t full = 0;
 #pragma unroll
-                for (int j = 0; j < BIN_B_ITEMS; ++j) {
+                for (int j = 0; j < ITEMS; ++j) {
                     const uint32_t fi = slice_of(items[j]);
                     if (pos[j] - rbase[j] < rs.R) rs.ring[fi * rs.R + ((pos[j] + rs.skew * fi) & (rs.R - 1))] = fine_of(items[j]);
                     else full |= 1u << j;
                 }
                 if (full) {
 #pragma unroll
-                    for (int j = 0; j < BIN_B_ITEMS; ++j)
+                    for (int j = 0; j < ITEMS; ++j)
                         if (full & (1u << j)) spill_coarse(items[j]);
                 }
             } else {
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
             __syncthreads();
         }
     }
-    rings_flush(rs, F, true, written, seg_base, (uint32_t)g.cap2, store, overflow);
+    rings_flush(rs, F, true, written, seg_base, (uint32_t)g.cap2, store, overflow, 64u / (uint32_t)sizeof(Out));
     rings_store_counts(F, written, (uint32_t)g.cap2, g.gcnt2 + (uint64_t)s * F * g.nwgB, g.nwgB, blockIdx.x);
 }
 
@@ -867,14 +871,15 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
     g.F = (int)((maxsl + (uint32_t)cmax - 1) / (uint32_t)cmax);
     g.C = (int)((maxsl + (uint32_t)g.F - 1) / (uint32_t)g.F);
     g.recipF = g.F == 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)g.F + 1);   // F == 1: kernels take slice as is
-    auto ring_for = [](uint32_t streams, uint32_t budget) {
-        uint32_t r = BIN_RING_MIN;
+    auto ring_for = [&](uint32_t streams, uint32_t budget) {
+        uint32_t r = weighted && budget == BIN_B_BUDGET ? 32u : BIN_RING_MIN;
         while (r * 2 <= BIN_RING_MAX && (uint64_t)r * 2 * streams <= budget) r *= 2;
         return r;
     };
     const uint32_t budgetA = cmax <= 32 ? 8192u : 16384u;
     g.ringA = ring_for((uint32_t)(g.T * g.C), budgetA);
-    g.ringB = ring_for((uint32_t)g.F, BIN_B_BUDGET);
+    g.ringB = ring_for((uint32_t)g.F, BIN_B_BUDGET);       // budget in entries: u32 rings get half the entries per byte
+    if (weighted) while (g.ringB > 32u && (uint64_t)g.ringB * g.F * 4 > 2u * BIN_B_BUDGET) g.ringB /= 2;
     const int cus = kv_device_cus();
     const double expected = (double)(nbands > 0 && !use_mask ? n_items_max / (uint64_t)nbands + 1 : n_items_max);
     const uint64_t ns = (uint64_t)g.T * g.C;
@@ -894,7 +899,7 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
     const double m1 = per_bucket / g.nwgA, m2 = per_slice / g.nwgB;
     g.cap1 = kv_round_up((uint64_t)(m1 * 1.5 + 8.0 * std::sqrt(m1)) + 2048, 64);   // tiles are dealt dynamically: shares are uneven
     g.cap2 = kv_round_up((uint64_t)(m2 * 1.05 + 8.0 * std::sqrt(m2)) + 64, 64);
-    g.spill_cap = std::max<uint64_t>(1u << 20, (uint64_t)(expected * g.T / 8));
+    g.spill_cap = std::max<uint64_t>(1u << 22, (uint64_t)(expected * g.T / 8));
     const size_t fine_bytes = weighted ? 4 : 2;
     const size_t b_buf1 = kv_round_up(ns * g.nwgA * g.cap1 * 4, 256), b_buf2 = kv_round_up(ns * g.F * g.nwgB * g.cap2 * fine_bytes, 256);
     const size_t b_cnt1 = kv_round_up(ns * g.nwgA * 4, 256), b_cnt2 = kv_round_up(ns * g.F * g.nwgB * 4, 256);

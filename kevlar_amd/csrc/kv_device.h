@@ -41,7 +41,8 @@ __device__ __forceinline__ uint64_t fastmod(uint64_t h, uint64_t size, uint64_t 
 {
     uint64_t q = __umul64hi(h, magic);
     uint64_t r = h - q * size;
-    while (r >= size) r -= size;
+    r -= r >= size ? size : 0;       // twice, branch-free: the quotient is at most 2 short
+    r -= r >= size ? size : 0;
     return r;
 }
 

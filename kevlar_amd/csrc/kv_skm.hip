@@ -40,6 +40,7 @@ struct SkmGeom {
                                      // [5] records emitted, [6] loose records after S1 + S2
     uint32_t n_buckets, quota3;
     uint32_t sbw;                    // words of record-start bits per wave in the bucket walk
+    uint32_t dbg;                    // KV_SKM_DEBUG: timing experiments that skip parts of kernels (results are then wrong)
 };
 
 namespace {
@@ -47,6 +48,11 @@ namespace {
 #define SKM_THREADS1 512
 #define SKM_THREADS3 512
 #define SKM_MAXPROBE 24
+// One global counter hands out work; a returning atomic on one word saturates at ~90 per microsecond on this chip
+// (MI355X_MICROARCH.md, "dequeue"), i.e. 1.3 ms for the 117 k tiles of a 7.5 M-read sample if every tile were a
+// ticket.  A ticket therefore covers several units of work.
+#define SKM_TILES_PER_TICKET 8u
+#define SKM_BUCKETS_PER_TICKET 8u
 
 __device__ __forceinline__ void skm_store_record(uint64_t *dst, uint64_t hdr, const uint64_t *bw, int nbw)
 {
@@ -71,7 +77,8 @@ struct SkmTile {
     uint32_t cpre[KV_TILE_MAX_READS + 1];      // chunk prefix (a chunk = CH consecutive k-mer starts of one read)
     uint32_t uni_wpr, uni_cpr;                 // words / chunks per read if all reads of the tile have the same length, else 0
     float inv_wpr, inv_cpr;
-    uint32_t seg_start, read0, nstart, next_tile;
+    uint32_t seg_start, read0, next_tile;
+    uint32_t wtot[3][SKM_THREADS1 / 64];       // run starts per (round, wave)
 };
 
 // q / d for q < 2^16 with the precomputed float reciprocal (off by at most one before the fix-up)
@@ -95,7 +102,7 @@ __device__ __forceinline__ uint32_t skm_search(const uint32_t *pre, uint32_t n, 
 
 // CH consecutive k-mer starts per thread in the window-minimum pass; needs w > CH
 template <int CH>
-__global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t n_tiles, SkmGeom sg)
+__global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint32_t n_tiles, SkmGeom sg)   // 6 waves per SIMD: three workgroups per CU
 {
     __shared__ SkmTile sh;
     __shared__ uint32_t cur[256];
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t
     const int k = sg.k, m = sg.m, w = sg.w;
     const int lane = threadIdx.x & 63;
     for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_THREADS1) cur[c] = 0;
-    if (threadIdx.x == 0) sh.next_tile = (uint32_t)atomicAdd(&sg.ctr[2], 1ull);
+    if (threadIdx.x == 0) sh.next_tile = (uint32_t)atomicAdd(&sg.ctr[2], 1ull) * SKM_TILES_PER_TICKET;
     uint64_t n_rec = 0;
     for (uint32_t taken = 0; taken < sg.quota1; ++taken) {
         __syncthreads();                                   // previous tile finished, ticket visible
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t
             const uint32_t eca = wave_excl_scan2(c0, c1, ecb, ctot);
             if (i0 < nr) { sh.len[i0] = l0; sh.nk[i0] = k0; sh.bpre[i0] = ea; sh.cpre[i0] = eca; }
             if (i1 < nr) { sh.len[i1] = l1; sh.nk[i1] = k1; sh.bpre[i1] = eb; sh.cpre[i1] = ecb; }
-            if (threadIdx.x == 0) { sh.bpre[nr] = tot; sh.cpre[nr] = ctot; sh.seg_start = seg_start; sh.read0 = r0; sh.nstart = 0; }
+            if (threadIdx.x == 0) { sh.bpre[nr] = tot; sh.cpre[nr] = ctot; sh.seg_start = seg_start; sh.read0 = r0; }
             const uint32_t ref = __shfl(l0, 0);
             const bool same = (i0 >= nr || l0 == ref) && (i1 >= nr || l1 == ref);
             const bool uniform = __all(same) && ref >= (uint32_t)k;
@@ -163,7 +170,10 @@ __global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t
         for (uint32_t i = threadIdx.x; i < nwords + 8u; i += SKM_THREADS1) wl[i] = i < nwords ? rd.words[w0 + i] : 0u;
         __syncthreads();
         // the next ticket is fetched while this tile is processed (everybody has read the current one by now)
-        if (threadIdx.x == 0) sh.next_tile = taken + 1 < sg.quota1 ? (uint32_t)atomicAdd(&sg.ctr[2], 1ull) : 0xffffffffu;
+        if (threadIdx.x == 0) {
+            if ((tile + 1u) % SKM_TILES_PER_TICKET) sh.next_tile = tile + 1u;       // same ticket
+            else sh.next_tile = taken + 1 < sg.quota1 ? (uint32_t)atomicAdd(&sg.ctr[2], 1ull) * SKM_TILES_PER_TICKET : 0xffffffffu;
+        }
         const uint32_t NB = sh.bpre[nr];
         // P1: one thread per packed word: the order values of the m-mers starting at its 16 bases
         const uint32_t mmask = m == 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
@@ -172,17 +182,18 @@ __global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t
             const uint32_t j0 = (wi - sh.wpre[r]) * 16u, L = sh.len[r];
             const uint32_t q0 = sh.bpre[r] + j0;
             const uint64_t win = (uint64_t)wl[wi] | ((uint64_t)wl[wi + 1] << 32);
+            // lane l starts at base l mod 16 of its word: the 64 stores of one instruction then fall into different banks
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                const uint32_t j = j0 + (uint32_t)jj;
-                if (j < L) mh[q0 + jj] = j + (uint32_t)m <= L ? skm_mmer_value((uint32_t)(win >> (2 * jj)) & mmask, m) : 0xffffffffu;
+            for (int step = 0; step < 16; ++step) {
+                const uint32_t jj = ((uint32_t)step + (uint32_t)lane) & 15u, j = j0 + jj;
+                if (j < L) mh[q0 + jj] = j + (uint32_t)m <= L ? skm_mmer_value((uint32_t)(win >> (2u * jj)) & mmask, m) : 0xffffffffu;
             }
         }
         if (threadIdx.x < 96) mh[NB + threadIdx.x] = 0xffffffffu;
         __syncthreads();
         // P2: one thread per chunk of CH k-mer starts: the minimum over the w m-mers of each (shared suffix of the
         // chunk + the w - 1 - CH values every window contains + a growing prefix), its bucket, and where runs start
-        const uint32_t nchunks = sh.cpre[nr];             // <= 8192 / CH + 64 < 3 * SKM_THREADS1
+        const uint32_t nchunks = (sg.dbg & 32u) ? 0u : sh.cpre[nr];             // <= 8192 / CH + 64 < 3 * SKM_THREADS1
         uint32_t my_q[3], my_starts[3];
 #pragma unroll
         for (int round = 0; round < 3; ++round) {
@@ -217,20 +228,30 @@ __global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t
             }
             my_q[round] = q; my_starts[round] = startmask;
         }
-        __syncthreads();                                  // every window minimum is taken: the run starts may overwrite mh
+        // run starts in position order (chunks are numbered in position order): prefix over lanes, waves, rounds
+        uint32_t incl[3];
 #pragma unroll
         for (int round = 0; round < 3; ++round) {
-            if ((uint32_t)round * SKM_THREADS1 >= nchunks) break;
-            const uint32_t cnt = (uint32_t)__popc(my_starts[round]);
-            uint32_t incl = cnt;
+            uint32_t v = (uint32_t)__popc(my_starts[round]);
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(incl, d);
-                if (lane >= d) incl += up;
+                const uint32_t up = __shfl_up(v, d);
+                if (lane >= d) v += up;
             }
-            uint32_t base = 0;
-            if (lane == 63 && incl) base = atomicAdd(&sh.nstart, incl);
-            base = __shfl(base, 63) + incl - cnt;
+            incl[round] = v;
+            if (lane == 63) sh.wtot[round][threadIdx.x >> 6] = v;
+        }
+        __syncthreads();                                  // every window minimum is taken: the run starts may overwrite mh
+        uint32_t nstart = 0;
+#pragma unroll
+        for (int round = 0; round < 3; ++round) {
+            uint32_t before = nstart;
+            for (uint32_t wv = 0; wv < SKM_THREADS1 / 64; ++wv) {
+                const uint32_t n = sh.wtot[round][wv];
+                if (wv < (threadIdx.x >> 6)) before += n;
+                nstart += n;
+            }
+            uint32_t base = before + incl[round] - (uint32_t)__popc(my_starts[round]);
             uint32_t bits = my_starts[round];
             while (bits) {
                 const int i = __ffs((int)bits) - 1;
@@ -238,17 +259,16 @@ __global__ __launch_bounds__(SKM_THREADS1) void k_skm_emit(ReadsDev rd, uint32_t
                 starts[base++] = my_q[round] + (uint32_t)i;
             }
         }
+        if (sg.dbg & 16u) nstart = 0;
         __syncthreads();
         // P4: one thread per run: measure it, cut it into records of <= ncap k-mers, store them
-        const uint32_t nstart = sh.nstart;
         for (uint32_t i = threadIdx.x; i < nstart; i += SKM_THREADS1) {
             const uint32_t q = starts[i];
             const uint32_t r = skm_search(sh.bpre, nr, q), j = q - sh.bpre[r];
             const uint32_t id = ids[q];
             const uint32_t limit = q - j + sh.nk[r];          // flat position one past the read's last k-mer
-            uint32_t e = q + 1;
-            while (e < limit && ids[e] == id) ++e;
-            uint32_t left = e - q;
+            const uint32_t nxt = i + 1 < nstart ? starts[i + 1] : limit;       // the next run (of this read or a later one)
+            uint32_t left = (nxt < limit ? nxt : limit) - q;
             const uint32_t coarse = id >> 8, fine = id & 0xffu;
             uint64_t pos = (uint64_t)(sh.read0 + r) * sg.stride + sh.seg_start + j;
             uint32_t b = sh.wpre[r] * 16u + j;                // base index inside wl
@@ -531,25 +551,34 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_count(SkmGeom sg, const Sk
     if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
     const int k = sg.k;
     uint64_t n_added = 0;
+    const uint32_t cap1 = (uint32_t)g.cap1;
+    uint32_t *my_seg = g.gbuf1 + (uint64_t)blockIdx.x * g.cap1;          // + stream * seg_stride: this workgroup's segment of a stream
+    const uint64_t seg_stride = (uint64_t)g.nwgA * g.cap1;
     auto emit = [&](int t, uint64_t bin, uint32_t wgt) {
         const uint32_t slice = (uint32_t)(bin >> 16);
         const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
         const uint32_t sidx = (uint32_t)t * (uint32_t)g.C + c;
         const uint32_t item = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu) | ((wgt - 1u) << BIN_W_SHIFT);
         const uint32_t pos = atomicAdd(&cur[sidx], 1u);
-        if (pos < g.cap1) g.gbuf1[((uint64_t)sidx * g.nwgA + blockIdx.x) * g.cap1 + pos] = item;
+        if (pos < cap1) my_seg[sidx * seg_stride + pos] = item;
         else spill_item(g, t, bin, wgt);
     };
+    // the table is emptied as it is read (below), so it is cleared only once; the next bucket's ticket is fetched
+    // while the current bucket is processed
+    skm_table_clear(tb);
+    for (uint32_t i = threadIdx.x; i < TS; i += SKM_THREADS3) cnt[i] = 0;
+    if (threadIdx.x == 0) next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET;
     for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
-        __syncthreads();
-        if (threadIdx.x == 0) next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull);
-        skm_table_clear(tb);
-        for (uint32_t i = threadIdx.x; i < TS; i += SKM_THREADS3) cnt[i] = 0;
         __syncthreads();
         const uint32_t b = next_bucket;
         if (b >= sg.n_buckets) break;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
+            else next_bucket = taken + 1 < sg.quota3 ? (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET : 0xffffffffu;
+        }
         // combine the occurrences of the bucket
-        skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t) {
+        if (!(sg.dbg & 2u)) skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t) {
             const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
             const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
             if (slot >= 0) atomicAdd(&cnt[slot], 1u);
@@ -563,9 +592,14 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_count(SkmGeom sg, const Sk
         skm_for_occupied<TS>(tb.key[0], (uint16_t *)scratch, skm_wave_scratch_words(sg.sbw) * 2u, [&](uint32_t slot) {
             SkmKey<KW> c;
             c.w[0] = tb.key[0][slot];
-            if (KW == 2) c.w[KW - 1] = tb.key[KW - 1][slot];
+            tb.key[0][slot] = SKM_EMPTY;
+            if (KW == 2) { c.w[KW - 1] = tb.key[KW - 1][slot]; tb.key[KW - 1][slot] = SKM_EMPTY; }
+            const uint32_t seen = cnt[slot];
+            cnt[slot] = 0;
+            if (sg.dbg & 1u) return;
             const uint64_t h = skm_key_hash<KW>(c, lut, f.hp);
-            n_added += skm_count_kmer(h, cnt[slot], sk, mask, f, g.T, emit);
+            if (sg.dbg & 64u) { n_added += h & 1; return; }
+            n_added += skm_count_kmer(h, seen, sk, mask, f, g.T, emit);
         });
     }
     __syncthreads();
@@ -628,14 +662,19 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_novel(SkmGeom sg, ReadsDev
     if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
     load_descs(ns, p);
     const int k = sg.k;
+    if (threadIdx.x == 0) next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET;
     for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
-        __syncthreads();
-        if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull); any_hit = 0; }
-        skm_table_clear(tb);
-        if (threadIdx.x < TS / 32) flag[threadIdx.x] = 0;
         __syncthreads();
         const uint32_t b = next_bucket;
         if (b >= sg.n_buckets) break;
+        skm_table_clear(tb);
+        if (threadIdx.x < TS / 32) flag[threadIdx.x] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
+            else next_bucket = taken + 1 < sg.quota3 ? (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET : 0xffffffffu;
+            any_hit = 0;
+        }
         // collect the distinct k-mers
         skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t pos) {
             const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
@@ -647,7 +686,7 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_novel(SkmGeom sg, ReadsDev
         });
         __syncthreads();
         // evaluate each of them once
-        skm_for_occupied<TS>(tb.key[0], (uint16_t *)scratch, skm_wave_scratch_words(sg.sbw) * 2u, [&](uint32_t slot) {
+        if (!(sg.dbg & 4u)) skm_for_occupied<TS>(tb.key[0], (uint16_t *)scratch, skm_wave_scratch_words(sg.sbw) * 2u, [&](uint32_t slot) {
             SkmKey<KW> c;
             c.w[0] = tb.key[0][slot];
             if (KW == 2) c.w[KW - 1] = tb.key[KW - 1][slot];
@@ -655,7 +694,7 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_novel(SkmGeom sg, ReadsDev
             if (band_pass(p, h) && novel_test_fast(ns, p, h, nullptr, 0ull)) { atomicOr(&flag[slot >> 5], 1u << (slot & 31)); any_hit = 1; }
         });
         __syncthreads();
-        if (any_hit == 0) continue;
+        if (any_hit == 0 || (sg.dbg & 8u)) continue;
         // mark every occurrence of an interesting k-mer (an occurrence whose key is absent went to the loose list)
         skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t pos) {
             const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
@@ -743,6 +782,11 @@ SkmIndex &skm_index_for(hipStream_t st)
     return g_skm[st];
 }
 
+inline uint32_t skm_nwg3(const SkmGeom &g)
+{
+    return (uint32_t)std::min<uint64_t>((g.n_buckets + SKM_BUCKETS_PER_TICKET - 1) / SKM_BUCKETS_PER_TICKET, 3u * (uint32_t)kv_device_cus());
+}
+
 inline uint32_t pow2_ceil(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
 int skm_minimizer_len(int k) { return k >= 24 ? 12 : k / 2; }
@@ -775,10 +819,12 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.C1 = (uint32_t)std::min<uint64_t>(255, std::max<uint64_t>(1, (nfine + g.F2 - 1) / g.F2));
     g.n_buckets = g.C1 * g.F2;
     const int cus = kv_device_cus();
-    g.nwg1 = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(reads->n_tiles, 1u), std::min<uint32_t>(768u, 3u * (uint32_t)cus));
+    // at least one whole ticket per workgroup: the per-writer capacities below assume even shares
+    g.nwg1 = (uint32_t)std::min<uint64_t>((std::max<uint32_t>(reads->n_tiles, 1u) + SKM_TILES_PER_TICKET - 1) / SKM_TILES_PER_TICKET,
+                                          std::min<uint32_t>(768u, 3u * (uint32_t)cus));
     {
         const uint64_t avg = (reads->n_tiles + g.nwg1 - 1) / g.nwg1;
-        g.quota1 = (uint32_t)std::min<uint64_t>(avg + avg / 2 + 1, 0xffffffffull);
+        g.quota1 = (uint32_t)std::min<uint64_t>(kv_round_up(avg + avg / 2 + 1, SKM_TILES_PER_TICKET), 0xfffffff0ull);
     }
     g.nwg2 = std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / g.C1));
     g.nwg2 = std::min<uint32_t>(g.nwg2, g.nwg1);
@@ -809,6 +855,8 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.loose = (uint64_t *)base; base += b_loose;
     g.ctr = (unsigned long long *)base;
     KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));
+    g.sbw = ((64u * (uint32_t)g.ncap) >> 5) + 2u;
+    g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
     {
         KvProfScope prof("k_skm_emit");
         const size_t lds = ((size_t)g.np_max / 16 + KV_TILE_MAX_READS + 8 + (size_t)g.np_max + 96) * 4 + ((size_t)g.np_max + 96) * 2;
@@ -826,19 +874,16 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     }
     KV_HIP(hipGetLastError());
     KV_HIP(hipMemcpyAsync(&g.ctr[6], &g.ctr[0], 8, hipMemcpyDeviceToDevice, st));   // loose records S1/S2 left behind
-    const uint32_t nwg3 = (uint32_t)std::min<uint64_t>(g.n_buckets, 3u * (uint32_t)cus);
+    const uint32_t nwg3 = skm_nwg3(g);
     {
         const uint64_t avg = (g.n_buckets + nwg3 - 1) / nwg3;
-        g.quota3 = (uint32_t)(avg + avg / 2 + 1);
+        g.quota3 = (uint32_t)kv_round_up(avg + avg / 2 + 1, SKM_BUCKETS_PER_TICKET);
     }
-    g.sbw = ((64u * (uint32_t)g.ncap) >> 5) + 2u;
     idx.reads_uid = reads->uid;
     idx.k = k;
     idx.valid = true;
     return KV_OK;
 }
-
-inline uint32_t skm_nwg3(const SkmGeom &g) { return (uint32_t)std::min<uint64_t>(g.n_buckets, 3u * (uint32_t)kv_device_cus()); }
 
 }  // namespace
 
@@ -885,7 +930,17 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     hipLaunchKernelGGL(k_skm_forward_flag, dim3(1), dim3(1), 0, st, sg.ctr, plan.g.ctr);
     KV_HIP(hipGetLastError());
     const int rc = kv_bin_finish(s, plan, true, 0, n_added);     // synchronises the stream
-    if (rc != KV_OK) idx.valid = false;
+    if (rc != KV_OK) {
+        idx.valid = false;
+        if (getenv("KV_SKM_VERBOSE")) {
+            unsigned long long sc[8] = {0}, bc[4] = {0};
+            (void)hipMemcpy(sc, sg.ctr, sizeof(sc), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(bc, plan.g.ctr, sizeof(bc), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[kv_skm] count fell back: rc %d, loose %llu of %llu (flag %llu), records %llu, spill %llu of %llu (flag %llu); C1 %u F2 %u nwg1 %u nwg2 %u cap1 %u cap2 %u\n",
+                    rc, sc[0], (unsigned long long)sg.loose_cap, sc[1], sc[5], bc[0], (unsigned long long)plan.g.spill_cap, bc[1],
+                    sg.C1, sg.F2, sg.nwg1, sg.nwg2, sg.cap1, sg.cap2);
+        }
+    }
     return rc;
 }
 
