@@ -1,28 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- reads/sec through count + novel on a synthetic trio (BASELINE.json metric).
+"""bench.py -- reads/sec through count + novel on a synthetic family (BASELINE.json metric).
 
-A "step" is one full pass of the hot path over one synthetic trio already resident in HBM
-as 2-bit packed reads: zero the three sketches, `count` all three samples (kv_consume), then
-the fused `novel` scan of the proband against both parents (kv_novel_scan).
-    value = (reads of all three samples) / (time per step), whole job.
+A "step" is one full pass of the hot path over one synthetic family already resident in HBM as
+2-bit packed reads: zero the sketches, `count` every sample (kv_consume), then the fused `novel`
+scan of the proband against its controls (kv_novel_scan).
+    value = (reads of all samples) / (time per step), whole job.
 
-N = 1 : workload = BASELINE.json configs[1] (25 Mb genome, 30x, k=31, 2 GB sketch per sample).
-N > 1 : configs[2]: the same trio, kevlar's k-mer banding with band b on GPU b (1/N of the hash
-        space and of the table memory per GPU).  Total work is fixed -> "scaling": "strong".
-        --multi banded   : the reference's layout -- every GPU streams and hashes all reads, keeps
-                           its band; then one RCCL all-gather of the per-band hits, sorted on the
-                           device.
-        --multi exchange : every GPU hashes 1/N of the reads once and one RCCL all-to-all delivers
-                           each hash to its band's owner (kevlar_amd/shardrun.py); sketches and
-                           hits are identical to the banded run's.  Default from 4 GPUs up (with 2
-                           GPUs the single xGMI link between them makes the exchange slower than
-                           the replicated hashing).
+--workload (BASELINE.json configs):
+    cfg2        25 Mb trio, 30x, k=31, 2 GB sketch per sample  (the configuration the metric is quoted on; default)
+    cfg5        proband + 3 controls, k=51, 30x, 25 Mb          (multi-control test, 128-bit keys / three murmur blocks)
+    cfg1        50 kb trio, 10x, k=31, 1 MB sketch              (the reference's own CPU-runnable case: plumbing)
+    cfg4-proxy  250 Mb trio, 30x, k=31, 8 GB sketch per sample, reads in batches of 7.5 M: one band's share of
+                config 4 (3 Gb, 8 bands) on one GPU -- proves the batching and the HBM budget, not the 8-GPU run
+N > 1 : configs[2]: the same trio, kevlar's k-mer banding with band b on GPU b (1/N of the hash space and of
+        the table memory per GPU).  Total work is fixed -> "scaling": "strong".
+        --multi banded   : the reference's layout -- every GPU streams all reads and keeps its band; then one RCCL
+                           all-gather of the per-band hits, sorted on the device.
+        --multi exchange : every GPU hashes 1/N of the reads once and one RCCL all-to-all delivers each hash to its
+                           band's owner (kevlar_amd/shardrun.py); sketches and hits are identical to the banded
+                           run's.  Default from 4 GPUs up.  A failure in either layout ends the job non-zero:
+                           there is no silent switch of layouts.
+        A multi-GPU line validates itself: `ranks_seen` and `kmers_per_rank` come from RCCL collectives, and
+        `hits_checksum` (the merged hits) must equal `replay_checksum` -- rank 0 replaying the N bands one after
+        the other on its own GPU after the timed region -- which is also what a single-GPU run prints as
+        `banded_checksums[N]`.  (A banded run is not bit-identical to the unbanded one: every band has its own
+        Count-Min tables, hence its own collisions; it is bit-identical to kevlar run band by band.)
 
-Also reported: `roofline` for the dominant kernel (algorithmic bytes / live HIP-event time,
-see DESIGN.md) and `cpu_baseline` (the C oracle on one host core, bounded sample).
+Also on the line: `roofline` (algorithmic bytes / live HIP-event time of the dominant stage), `cpu_baseline`
+(the C oracle on the host cores: one core and all cores), `end_to_end` (FASTQ files on disk -> annotated reads
+through the CLI drivers, host parse and PCIe included).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -33,28 +43,45 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+WORKLOADS = {
+    'cfg2': dict(genome_mb=25.0, coverage=30.0, ksize=31, memory=2e9, controls=2, batch_reads=0,
+                 label='BASELINE.json configs[1]: synthetic 25 Mb trio, 30x, k=31, single band'),
+    'cfg5': dict(genome_mb=25.0, coverage=30.0, ksize=51, memory=2e9, controls=3, batch_reads=0,
+                 label='BASELINE.json configs[4]: proband + 3 controls, k=51, 30x, 25 Mb'),
+    'cfg1': dict(genome_mb=0.05, coverage=10.0, ksize=31, memory=1e6, controls=2, batch_reads=0,
+                 label='BASELINE.json configs[0]: 50 kb trio, 10x, k=31 (reference CPU plumbing case)'),
+    'cfg4-proxy': dict(genome_mb=250.0, coverage=30.0, ksize=31, memory=8e9, controls=2, batch_reads=7_500_000,
+                       label='one band\'s share of BASELINE.json configs[3] on one GPU: 250 Mb trio, 30x, k=31, 8 GB sketch '
+                             'per sample, reads streamed in batches of 7.5 M'),
+}
+
 
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=3)
     p.add_argument('--warmup', type=int, default=1)
-    p.add_argument('--genome-mb', type=float, default=25.0)
-    p.add_argument('--coverage', type=float, default=30.0)
+    p.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+    p.add_argument('--genome-mb', type=float, default=None)
+    p.add_argument('--coverage', type=float, default=None)
     p.add_argument('--read-len', type=int, default=100)
-    p.add_argument('--ksize', type=int, default=31)
-    p.add_argument('--memory', type=float, default=2e9, help='sketch bytes per sample (all bands together)')
+    p.add_argument('--ksize', type=int, default=None)
+    p.add_argument('--memory', type=float, default=None, help='sketch bytes per sample (all bands together)')
     p.add_argument('--case-min', type=int, default=6)
     p.add_argument('--ctrl-max', type=int, default=1)
-    p.add_argument('--cpu-reads', type=int, default=150000, help='reads per sample for the CPU baseline leg')
+    p.add_argument('--cpu-reads', type=int, default=100000, help='reads per sample for the one-core CPU baseline leg')
+    p.add_argument('--cpu-reads-mt', type=int, default=1000000, help='reads per sample for the all-cores CPU baseline leg')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--e2e-reads', type=int, default=500000, help='reads per sample written as FASTQ for the end-to-end leg')
+    p.add_argument('--no-e2e', action='store_true')
+    p.add_argument('--no-replay', action='store_true', help='skip the banded replays behind banded_checksums / replay_checksum')
     p.add_argument('--multi', default='auto', choices=['auto', 'exchange', 'banded'],
                    help='N>1: exchange = shard the reads, hash once, all-to-all the hashes by band (kevlar_amd/shardrun.py); '
-                        'banded = every rank hashes all reads and keeps its band; auto = exchange from 4 GPUs up')
+                        'banded = every rank streams all reads and keeps its band; auto = exchange from 4 GPUs up')
     p.add_argument('--count-streams', type=int, default=1,
-                   help='N=1: count the three samples concurrently on this many HIP streams.  3 is ~6 %% faster (the '
-                        'hashing stage of one sample overlaps the LDS/HBM-bound stages of another) but per-kernel HIP-event '
-                        'durations then include time sharing, so the default keeps the launches back to back')
+                   help='N=1: count the samples concurrently on this many HIP streams (~7 %% faster: kernels bound by '
+                        'different units overlap), but per-kernel HIP-event durations then include time sharing, so the '
+                        'default keeps the launches back to back and the roofline attribution clean')
     p.add_argument('--backend', default='nccl', help='nccl (= RCCL) is what the driver runs; gloo lets two ranks share one GPU in tests')
     return p.parse_args()
 
@@ -65,14 +92,28 @@ def prof(lib, name):
     return ms.value, n.value
 
 
+def hits_checksum(r, o, a):
+    import numpy as np
+    h = hashlib.sha1()
+    h.update(np.ascontiguousarray(r, dtype='<u4').tobytes())
+    h.update(np.ascontiguousarray(o, dtype='<u4').tobytes())
+    h.update(np.ascontiguousarray(a, dtype=np.uint8).tobytes())
+    return '{}:{}'.format(len(r), h.hexdigest()[:16])
+
+
 def main():
     args = parse_args()
+    wl = dict(WORKLOADS[args.workload])
+    for key in ('genome_mb', 'coverage', 'ksize', 'memory'):
+        if getattr(args, key) is not None:
+            wl[key] = getattr(args, key)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node {}'.format(args.gpus))
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -93,35 +134,87 @@ def main():
     lib = _lib.load()
     _lib.require_device()
 
-    # ---- synthetic trio (same seeds on every rank), packed on the host, uploaded once
-    L, k = args.read_len, args.ksize
-    genome_len = int(args.genome_mb * 1e6)
+    # ---- synthetic family (same seeds on every rank), packed on the host, uploaded once
+    L, k = args.read_len, int(wl['ksize'])
+    genome_len = int(wl['genome_mb'] * 1e6)
     t0 = time.time()
-    packed = synth.trio_reads_packed(genome_len, args.coverage, L)
-    upload_s = None
-    names = ('proband', 'mother', 'father')
+    packed = synth.trio_reads_packed(genome_len, wl['coverage'], L, extra_controls=wl['controls'] - 2)
+    names = tuple(packed)                           # proband first, then the controls
+    controls = names[1:]
     n_reads = packed['proband'].shape[0]
     multi = args.multi if args.multi != 'auto' else ('exchange' if world >= 4 else 'banded')
     exchange = world > 1 and multi == 'exchange'
+    per_batch = int(wl['batch_reads']) or n_reads
+    upload_s = None
     if exchange:
         from kevlar_amd import shardrun
         bounds = {n: shardrun.shard_bounds(n_reads, world, rank) for n in names}
-        batches = {n: hk.ReadBatch.from_packed(packed[n][bounds[n][0]:bounds[n][1]], L) for n in names}
+        batches = {n: [hk.ReadBatch.from_packed(packed[n][bounds[n][0]:bounds[n][1]], L)] for n in names}
         run = shardrun.ShardedTrio(k, hk.Counttable)
     else:
         t_up = time.time()
-        batches = {n: hk.ReadBatch.from_packed(packed[n], L) for n in names}
+        batches = {n: [hk.ReadBatch.from_packed(packed[n][lo:lo + per_batch], L) for lo in range(0, n_reads, per_batch)] for n in names}
         lib.kv_synchronize()
         upload_s = time.time() - t_up
+    batch_first = [lo for lo in range(0, n_reads, per_batch)]
     gen_s = time.time() - t0
     nk = L - k + 1
     T = 4
-    nbands = world if world > 1 else 0
-    band = rank
-    mem_per_gpu = args.memory / max(1, world)
-    sketches = {n: hk.Counttable(k, mem_per_gpu / T, T) for n in names}
+    S = len(names)
+    mem_per_gpu = wl['memory'] / max(1, world)
 
+    def make_sketches(memory):
+        return {n: hk.Counttable(k, memory / T, T) for n in names}
+
+    sketches = make_sketches(mem_per_gpu)
     wall = {'count': 0.0, 'novel': 0.0, 'merge': 0.0}
+
+    def scan_batches(sk, band_mode, nbands, band):
+        rs, os_, as_ = [], [], []
+        for first, batch in zip(batch_first, batches['proband']):
+            r, o, a, _ = hk.novel_scan([sk['proband']], [sk[n] for n in controls], batch, args.case_min, args.ctrl_max,
+                                       band_mode=band_mode, nbands=nbands, band=band)
+            rs.append(np.asarray(r, dtype=np.uint32) + np.uint32(first)); os_.append(o); as_.append(a)
+        if len(rs) == 1:
+            return rs[0], os_[0], as_[0]
+        return np.concatenate(rs), np.concatenate(os_), np.concatenate(as_)
+
+    def count_and_scan(sk, nbands, band):
+        """count every sample (controls first, the case sample last: its super-k-mer buckets are still in place when
+        the scan starts), then scan the case sample"""
+        kmers = 0
+        t_a = time.perf_counter()
+        order = list(controls) + ['proband']
+        if world == 1 and args.count_streams > 1:
+            def job(n):
+                def count_one():
+                    sk[n].clear()
+                    return sum(sk[n].consume_batch(b, nbands, band) for b in batches[n])
+                return count_one
+            for lo in range(0, len(order), args.count_streams):
+                kmers += sum(hk.run_concurrently([job(n) for n in order[lo:lo + args.count_streams]]))
+        else:
+            for n in order:
+                sk[n].clear()
+                for b in batches[n]:
+                    kmers += sk[n].consume_batch(b, nbands, band)
+        t_b = time.perf_counter()
+        r, o, a = scan_batches(sk, 1 if nbands else 0, nbands, band)
+        t_c = time.perf_counter()
+        wall['count'] += t_b - t_a
+        wall['novel'] += t_c - t_b
+        return kmers, (r, o, a)
+
+    def step_banded():
+        kmers, (r, o, a) = count_and_scan(sketches, world if world > 1 else 0, rank)
+        t_c = time.perf_counter()
+        if world > 1:
+            # every band's hits to every rank, sorted on the device (the per-band bit mask that `kevlar unband`
+            # would OR together carries no information beyond the hits, so it is not exchanged here)
+            from kevlar_amd import bandmerge
+            r, o, a = bandmerge.allgather_hits_device(r, o, a, torch.device('cuda', dev_index), staged=(args.backend != 'nccl'))
+        wall['merge'] += time.perf_counter() - t_c
+        return kmers, (r, o, a)
 
     def step_exchange():
         # route + exchange of sample i+1 overlap the count of sample i (RCCL runs on its own stream)
@@ -129,52 +222,17 @@ def main():
         for n in names:
             sketches[n].clear()
         kmers = 0
-        pending = run.start(batches[names[0]], bounds[names[0]][0], True)
+        pending = run.start(batches[names[0]][0], bounds[names[0]][0], True)
         for i, n in enumerate(names):
-            nxt = run.start(batches[names[i + 1]], bounds[names[i + 1]][0], False) if i + 1 < len(names) else None
+            nxt = run.start(batches[names[i + 1]][0], bounds[names[i + 1]][0], False) if i + 1 < len(names) else None
             kmers += run.finish(pending, sketches[n], keep_for_scan=(i == 0))
             pending = nxt
         t_b = time.perf_counter()
-        r, o, a = run.scan([sketches['proband']], [sketches['mother'], sketches['father']], args.case_min, args.ctrl_max)
+        r, o, a = run.scan([sketches['proband']], [sketches[n] for n in controls], args.case_min, args.ctrl_max)
         t_c = time.perf_counter()
         wall['count'] += t_b - t_a
         wall['novel'] += t_c - t_b
-        return kmers, len(r), (r, o, a)
-
-    def step_banded():
-        kmers = 0
-        t_a = time.perf_counter()
-        if world == 1 and args.count_streams > 1:
-            # the samples are independent: their counts run on separate HIP streams (host threads), so the
-            # ALU-bound hashing stage of one overlaps the LDS/HBM-bound stages of another
-            def job(n):
-                def count_one():
-                    sketches[n].clear()
-                    return sketches[n].consume_batch(batches[n], nbands, band)
-                return count_one
-            for lo in range(0, len(names), args.count_streams):
-                kmers += sum(hk.run_concurrently([job(n) for n in names[lo:lo + args.count_streams]]))
-        else:
-            # controls first, the case sample last: its super-k-mer buckets are still in place when the scan starts
-            for n in names[1:] + names[:1]:
-                sketches[n].clear()
-                kmers += sketches[n].consume_batch(batches[n], nbands, band)
-        t_b = time.perf_counter()
-        r, o, a, _ = hk.novel_scan(
-            [sketches['proband']], [sketches['mother'], sketches['father']], batches['proband'],
-            args.case_min, args.ctrl_max, band_mode=1 if world > 1 else 0, nbands=nbands, band=band)
-        nhits = len(r)
-        t_c = time.perf_counter()
-        if world > 1:
-            # every band's hits to every rank, sorted on the device (the per-band bit mask that `kevlar unband`
-            # would OR together carries no information beyond the hits, so it is not exchanged here)
-            from kevlar_amd import bandmerge
-            r, o, a = bandmerge.allgather_hits_device(r, o, a, torch.device('cuda', dev_index), staged=(args.backend != 'nccl'))
-            nhits = len(r)
-        wall['count'] += t_b - t_a
-        wall['novel'] += t_c - t_b
-        wall['merge'] += time.perf_counter() - t_c
-        return kmers, nhits, (r, o, a)
+        return kmers, (r, o, a)
 
     step = step_exchange if exchange else step_banded
 
@@ -184,24 +242,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if exchange:
-        # the exchange path has only ever run its RCCL transport with one rank (a one-GPU pool): try one step and,
-        # if any rank fails, let every rank fall back to the banded layout instead of losing the measurement
-        ok = 1
-        try:
-            step()
-        except Exception as exc:   # noqa: BLE001
-            ok = 0
-            print('[bench] rank {}: exchange mode failed ({}: {}); falling back to banded'.format(
-                rank, type(exc).__name__, exc), file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int64, device=coll_device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            exchange = False
-            multi = 'banded'
-            run = None
-            batches = {n: hk.ReadBatch.from_packed(packed[n], L) for n in names}
-            step = step_banded
     for _ in range(args.warmup):
         step()
     lib.kv_prof_reset()
@@ -211,7 +251,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        kmers, nhits, hits = step()
+        kmers, hits = step()
     fence()
     elapsed = time.perf_counter() - t0
     lib.kv_prof_enable(0)
@@ -222,112 +262,237 @@ def main():
 
     # ---- cheap end-to-end sanity on the timed result (parity proper lives in tests/)
     r, o, a = hits
-    assert nhits > 0, 'synthetic trio must yield interesting k-mers'
+    nhits = len(r)
+    assert nhits > 0, 'the synthetic family must yield interesting k-mers'
     assert (a[:, 0] >= args.case_min).all() and (a[:, 1:] <= args.ctrl_max).all()
+    selfcheck = {'hits_checksum': hits_checksum(r, o, a)}
     if world == 1:
-        assert kmers == 3 * n_reads * nk
-    elif exchange:
-        tot = torch.tensor([kmers], dtype=torch.int64, device=coll_device)
-        dist.all_reduce(tot)
-        assert int(tot.item()) == 3 * n_reads * nk, 'every k-mer of the trio must be counted by exactly one rank' 
+        assert kmers == S * n_reads * nk
+    else:
+        # every rank reports through RCCL: who took part, and how many k-mers each one counted
+        mine = torch.tensor([rank, kmers], dtype=torch.int64, device=coll_device)
+        table = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(table, mine)
+        table = [t.cpu().tolist() for t in table]
+        selfcheck['ranks_seen'] = sorted(int(t[0]) for t in table)
+        selfcheck['kmers_per_rank'] = [int(t[1]) for t in sorted(table)]
+        assert selfcheck['ranks_seen'] == list(range(world)), 'a rank is missing from the collective'
+        assert sum(selfcheck['kmers_per_rank']) == S * n_reads * nk, 'every k-mer of the family must be counted by exactly one rank'
+
+    def replay_bands(nbands):
+        """the nbands-band configuration one band after the other on this GPU: what kevlar does band by band"""
+        if exchange:
+            full = {n: [hk.ReadBatch.from_packed(packed[n], L)] for n in names}
+        else:
+            full = batches
+        sk = make_sketches(wl['memory'] / nbands)
+        parts = []
+        for band in range(nbands):
+            for n in list(controls) + ['proband']:
+                sk[n].clear()
+                for b in full[n]:
+                    sk[n].consume_batch(b, nbands, band)
+            rs = [hk.novel_scan([sk['proband']], [sk[n] for n in controls], b, args.case_min, args.ctrl_max,
+                                band_mode=1, nbands=nbands, band=band) for b in full['proband']]
+            for first, (rr, oo, aa, _) in zip(batch_first, rs):
+                parts.append((np.asarray(rr, dtype=np.uint32) + np.uint32(first), np.asarray(oo), np.asarray(aa)))
+        rr = np.concatenate([p[0] for p in parts]); oo = np.concatenate([p[1] for p in parts])
+        aa = np.concatenate([p[2] for p in parts]) if parts else np.zeros((0, S), dtype=np.uint8)
+        order = np.lexsort((oo, rr))
+        return hits_checksum(rr[order], oo[order], aa[order])
+
+    if not args.no_replay and args.workload in ('cfg2', 'cfg1', 'cfg5'):
+        saved_wall = dict(wall)
+        if world == 1:
+            selfcheck['banded_checksums'] = {str(nb): replay_bands(nb) for nb in (2, 4, 8)}
+        elif rank == 0:
+            selfcheck['replay_checksum'] = replay_bands(world)
+            selfcheck['replay_matches'] = selfcheck['replay_checksum'] == selfcheck['hits_checksum']
+            assert selfcheck['replay_matches'], 'merged multi-GPU hits differ from the band-by-band replay on one GPU'
+        wall.update(saved_wall)
 
     ms_step = elapsed / args.steps * 1e3
-    total_reads = 3 * n_reads
+    total_reads = S * n_reads
     value = total_reads / (elapsed / args.steps)
 
-    # ---- roofline of the dominant kernel: algorithmic bytes per launch / avg HIP-event time
-    # (per-read figures from SURVEY.md 8(d); with N bands only 1/N of the k-mers reach this GPU's tables)
+    # ---- roofline: algorithmic bytes (SURVEY.md 8(d): A_count = L/4 + 2 T nk, A_novel = L/4 + T S nk per read;
+    # with N bands only 1/N of the k-mers reach this GPU's tables) / live HIP-event time
     frac_band = 1.0 / max(1, world)
     a_count = n_reads * (L / 4.0 + 2 * T * nk * frac_band)
-    a_novel = n_reads * (L / 4.0 + T * 3 * nk * frac_band)
-    buf = ctypes.create_string_buffer(4096)
-    lib.kv_prof_names(buf, 4096)
+    a_novel = n_reads * (L / 4.0 + T * S * nk * frac_band)
+    buf = ctypes.create_string_buffer(8192)
+    lib.kv_prof_names(buf, 8192)
     times = {name: prof(lib, name) for name in buf.value.decode().split(',') if name}
-    # the count is one logical kernel split over k_bin_* launches (or k_consume on the atomic path)
     count_prefixes = ('k_bin_', 'k_route_', 'k_skm_emit', 'k_skm_split', 'k_skm_count', 'k_skm_loose_count')
     novel_prefixes = ('k_novel_', 'k_skm_novel', 'k_skm_loose_novel', 'k_tile_')
     groups = {'count': [n_ for n_ in times if n_.startswith(count_prefixes) or n_ == 'k_consume'],
               'novel': [n_ for n_ in times if n_.startswith(novel_prefixes)]}
-    alg = {}
-    for name in groups['count']:
-        alg[name] = a_count
-    for name in groups['novel']:
-        alg[name] = a_novel
-    dominant = max(alg, key=lambda n_: times[n_][0])
-    ms_tot, launches = times[dominant]
-    avg_ms = ms_tot / max(1, launches)
-    stage = 'count' if dominant in groups['count'] else 'novel'
-    stage_ms = sum(times[n_][0] for n_ in groups[stage]) / max(1, launches)
-    achieved = alg[dominant] / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
-    traffic = None
-    pmc_file = os.path.join(ROOT, 'profiles', 'r1_final', 'pmc_hbm_bytes.json')
-    if world == 1 and os.path.exists(pmc_file) and (args.genome_mb, args.coverage, k, args.memory) == (25.0, 30.0, 31, 2e9):
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (profiles/README.md):
-        # FETCH_SIZE doubled for the wide coalesced streams of the k_bin_* kernels, as the guide prescribes
-        pmc = json.load(open(pmc_file)).get(dominant)
-        if pmc:
-            fetch = pmc.get('FETCH_SIZE_KB_per_launch_avg', 0.0) * (2.0 if dominant.startswith('k_bin_') else 1.0)
-            traffic = int((fetch + pmc.get('WRITE_SIZE_KB_per_launch_avg', 0.0)) * 1024)
+    stage_ms = {st: sum(times[n_][0] for n_ in groups[st]) / args.steps for st in groups}       # per step
+    stage_alg = {'count': a_count * S, 'novel': a_novel}
+    stage = max(stage_ms, key=lambda st: stage_ms[st])
+    dominant = max(groups[stage], key=lambda n_: times[n_][0]) if groups[stage] else None
+    achieved = stage_alg[stage] / (stage_ms[stage] * 1e-3) / 1e9 if stage_ms[stage] > 0 else 0.0
+    traffic, traffic_source = None, None
+    pmc_file = os.path.join(ROOT, 'profiles', 'r2_final', 'pmc_hbm_bytes.json')
+    if world == 1 and os.path.exists(pmc_file) and args.workload == 'cfg2':
+        # HBM bytes from the committed rocprofv3 PMC passes of this same workload (profiles/README.md): FETCH_SIZE and
+        # WRITE_SIZE in separate passes, FETCH doubled for wide coalesced streams as the guide prescribes; summed over
+        # the launches of the stage in one step
+        pmc = json.load(open(pmc_file))
+        tot = 0.0
+        for name in groups[stage]:
+            rec = pmc.get('kernels', {}).get(name)
+            if rec:
+                tot += rec['hbm_bytes_per_step']
+        if tot:
+            traffic = int(tot)
+            traffic_source = 'profiles/r2_final/pmc_hbm_bytes.json ({})'.format(pmc.get('collected', 'rocprofv3 --pmc'))
+    dom_ms, dom_launches = times[dominant] if dominant else (0.0, 0)
     roofline = {
-        'bound': 'hbm', 'kernel': dominant, 'stage': stage,
+        'bound': 'hbm', 'stage': stage, 'kernel': dominant,
         'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
-        'avg_launch_ms': round(avg_ms, 4), 'stage_ms_per_sample': round(stage_ms, 4), 'launches': int(launches),
-        'algorithmic_bytes_per_launch': int(alg[dominant]),
-        'note': 'achieved = algorithmic bytes of one sample / summed duration of all kernels of that stage; the dominant '
-                'kernel hashes (two murmur3 per k-mer) and is VALU-issue-bound per the SQ counters (DESIGN.md 4.1), '
-                'so the HBM roofline is an upper bound it cannot approach',
+        'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_source,
+        'stage_ms_per_step': round(stage_ms[stage], 4), 'algorithmic_bytes_per_step_of_stage': int(stage_alg[stage]),
+        'kernel_avg_launch_ms': round(dom_ms / max(1, dom_launches), 4), 'kernel_launches': int(dom_launches),
+        'whole_step': {'algorithmic_bytes': int(a_count * S + a_novel),
+                       'achieved': round((a_count * S + a_novel) / (ms_step * 1e-3) / 1e9, 2),
+                       'frac': round((a_count * S + a_novel) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+        'note': 'achieved = algorithmic bytes of the stage in one step / summed HIP-event duration of its kernels; the '
+                'stage is one logical kernel split over launches (super-k-mer cut, bucket split, per-distinct-k-mer hash, '
+                'bin split, LDS-resident apply); it is bound by integer VALU issue (two murmur3 per distinct k-mer, 2-bit '
+                'k-mer extraction) and LDS atomics, not by HBM: see DESIGN.md section 4',
         'kernels_ms_per_step': {name: round(times[name][0] / args.steps, 4) for name in sorted(times)},
         'host_wall_ms_per_step': {key: round(val / args.steps * 1e3, 3) for key, val in wall.items()},
     }
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, packed, names, synth)
+    cpu = e2e = None
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, wl, packed, names, synth)
+        if not args.no_e2e:
+            e2e = end_to_end(args, wl, packed, names, synth)
 
     if rank == 0:
         out = {
-            'metric': 'reads/sec through count+novel (trio, k={})'.format(k),
+            'metric': 'reads/sec through count+novel ({} samples, k={})'.format(S, k),
             'value': round(value, 1), 'unit': 'reads/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_step, 3), 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'u64 hash / u8 counters', 'data': 'synthetic',
             'config': {
-                'workload': 'synthetic {:g} Mb trio, {:g}x, {} bp reads, k={}, {} reads/sample, '
+                'workload': '{} [{}]: {:g} Mb genome, {:g}x, {} bp reads, k={}, {} reads/sample x {} samples, '
                             '{:g} GB Count-Min sketch per sample ({} tables), case-min {}, ctrl-max {}'.format(
-                                args.genome_mb, args.coverage, L, k, n_reads, args.memory / 1e9, T,
-                                args.case_min, args.ctrl_max),
-                'parallelism': 'single band' if world == 1 else ('{} k-mer bands, 1 per GPU; reads sharded, hashes exchanged by band (all-to-all)'.format(world) if exchange else '{} k-mer bands, 1 per GPU; every rank hashes all reads'.format(world)),
+                                args.workload, wl['label'], wl['genome_mb'], wl['coverage'], L, k, n_reads, S,
+                                wl['memory'] / 1e9, T, args.case_min, args.ctrl_max),
+                'parallelism': 'single band' if world == 1 else (
+                    '{} k-mer bands, 1 per GPU; reads sharded, hashes exchanged by band (all-to-all); hits all-gathered (the '
+                    'per-band bit mask of north_star carries nothing beyond them)'.format(world) if exchange else
+                    '{} k-mer bands, 1 per GPU; every rank streams all reads; hits all-gathered (the per-band bit mask of '
+                    'north_star carries nothing beyond them)'.format(world)),
+                'read_batches_per_sample': len(batch_first), 'count_streams': args.count_streams,
                 'interesting_kmer_instances': nhits, 'host_generate_pack_upload_s': round(gen_s, 1),
                 'packed_reads_upload_s': round(upload_s, 3) if upload_s is not None else None,
                 'device': '{} ({} CUs)'.format(torch.cuda.get_device_properties(dev_index).name,
                                                torch.cuda.get_device_properties(dev_index).multi_processor_count),
             },
+            'selfcheck': selfcheck,
             'roofline': roofline,
             'cpu_baseline': cpu,
+            'end_to_end': e2e,
         }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, packed, names, synth):
-    """The C oracle (oracle/kvoracle.c, one core) on the first --cpu-reads reads of each sample,
-    with full-size sketches: count x3 then the novel scan of the proband sample."""
+def cpu_baseline(args, wl, packed, names, synth):
+    """The C oracle (oracle/kvoracle.c) on the host cores, full-size sketches, count of every sample then the novel
+    scan of the proband: (i) one core, the scalar loop; (ii) all cores the way kevlar drives khmer
+    (kevlar/count.py:41-76): threads share one sketch and add with atomic saturating increments."""
     from oracle import okhmer as ok
-    n = min(args.cpu_reads, packed['proband'].shape[0])
-    data = {}
-    for name in names:
-        seqs = synth.unpack_reads(packed[name][:n], args.read_len)
-        data[name] = ok.concat_reads(seqs)
-    sk = {name: ok.Counttable(args.ksize, args.memory / 4, 4) for name in names}
-    t0 = time.perf_counter()
-    for name in names:
-        ok.consume_reads(sk[name], data[name][0], data[name][1], n)
-    hits, _ = ok.novel_scan([sk['proband']], [sk['mother'], sk['father']], data['proband'][0], data['proband'][1],
-                            n, args.ksize, args.case_min, args.ctrl_max)
-    dt = time.perf_counter() - t0
-    return {'value': round(3 * n / dt, 1), 'unit': 'reads/s', 'cores': 1, 'kind': 'port',
-            'sample': 'first {} reads of each of the 3 samples, full-size sketches, {:.1f} s'.format(n, dt)}
+    k = int(wl['ksize'])
+    controls = names[1:]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:                                            # a container's CPU quota, not the host's core count, is what it can use
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = max(1, min(cores, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+
+    def leg(n, threads):
+        n = min(n, packed['proband'].shape[0])
+        data = {name: ok.concat_reads(synth.unpack_reads(packed[name][:n], args.read_len)) for name in names}
+        sk = {name: ok.Counttable(k, wl['memory'] / 4, 4) for name in names}
+        t0 = time.perf_counter()
+        for name in names:
+            if threads == 1:
+                ok.consume_reads(sk[name], data[name][0], data[name][1], n)
+            else:
+                ok.consume_reads_mt(sk[name], data[name][0], data[name][1], n, threads)
+        if threads == 1:
+            ok.novel_scan([sk['proband']], [sk[c] for c in controls], data['proband'][0], data['proband'][1], n, k,
+                          args.case_min, args.ctrl_max)
+        else:
+            ok.novel_scan_count_mt([sk['proband']], [sk[c] for c in controls], data['proband'][0], data['proband'][1], n, k,
+                                   args.case_min, args.ctrl_max, threads)
+        dt = time.perf_counter() - t0
+        return len(names) * n / dt, n, dt
+
+    one_v, one_n, one_dt = leg(args.cpu_reads, 1)
+    out = {'value': round(one_v, 1), 'unit': 'reads/s', 'cores': 1, 'kind': 'port', 'nproc': cores,
+           'sample': 'first {} reads of each of the {} samples, full-size sketches, {:.1f} s'.format(one_n, len(names), one_dt)}
+    if cores > 1:
+        # a short calibration leg first, then a sample sized to ~20 s of wall clock (at most --cpu-reads-mt reads per
+        # sample): large enough that the full-size sketches are not empty, bounded so that the default run stays short
+        mt_v, mt_n, mt_dt = leg(args.cpu_reads, cores)
+        n_big = int(min(args.cpu_reads_mt, mt_v * 20.0 / len(names)))
+        if n_big >= 2 * mt_n:
+            mt_v, mt_n, mt_dt = leg(n_big, cores)
+        out = {'value': round(mt_v, 1), 'unit': 'reads/s', 'cores': cores, 'kind': 'port', 'nproc': cores,
+               'sample': 'first {} reads of each of the {} samples, full-size sketches, {} threads on one sketch with atomic '
+                         'saturating adds (kevlar/count.py:41-76), {:.1f} s'.format(mt_n, len(names), cores, mt_dt),
+               'one_core': out}
+    return out
+
+
+def end_to_end(args, wl, packed, names, synth):
+    """FASTQ files on local disk -> `kevlar count` per sample -> `kevlar novel` (annotated reads written), through
+    the CLI drivers of kevlar_amd: host parse, 2-bit packing, PCIe, kernels and text output all inside the clock."""
+    import io
+    import shutil
+    import tempfile
+    import kevlar_amd
+    n = min(args.e2e_reads, packed['proband'].shape[0])
+    k = int(wl['ksize'])
+    tmp = tempfile.mkdtemp(prefix='kv_e2e_')
+    try:
+        qual = 'I' * args.read_len
+        for name in names:
+            seqs = synth.unpack_reads(packed[name][:n], args.read_len)
+            with open(os.path.join(tmp, name + '.fq'), 'w') as fh:
+                fh.write(''.join('@{}_{}\n{}\n+\n{}\n'.format(name, i, s, qual) for i, s in enumerate(seqs)))
+        saved, kevlar_amd.logstream = kevlar_amd.logstream, io.StringIO()
+        mem = '{:d}'.format(int(wl['memory']))
+
+        def run(argv):
+            a = kevlar_amd.cli.parser().parse_args(argv)
+            kevlar_amd.cli.mains[a.cmd](a)
+        t0 = time.perf_counter()
+        argv = ['novel', '--ksize', str(k), '--memory', mem, '--threads', '2', '--case', os.path.join(tmp, 'proband.fq')]
+        for c in names[1:]:
+            argv += ['--control', os.path.join(tmp, c + '.fq')]
+        run(argv + ['--case-min', str(args.case_min), '--ctrl-max', str(args.ctrl_max), '-o', os.path.join(tmp, 'novel.augfastq')])
+        t1 = time.perf_counter()
+        kevlar_amd.logstream = saved
+        return {'value': round(len(names) * n / (t1 - t0), 1), 'unit': 'reads/s',
+                'sample': '{} reads per sample as FASTQ on local disk ({} MB each); one `kevlar novel --case ... --control ...` run: '
+                          'every sample parsed, packed, uploaded and counted, the case sample parsed again and scanned, annotated '
+                          'reads written: {:.2f} s'.format(n, os.path.getsize(os.path.join(tmp, 'proband.fq')) >> 20, t1 - t0)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == '__main__':

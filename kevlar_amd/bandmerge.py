@@ -70,6 +70,14 @@ def allgather_hits_device(read, offset, abund, device, group=None, staged=False)
     from kevlar_amd import shardrun
     S = abund.shape[1]
     n = len(read)
+    # the tag packs a 16-bit offset under the read index, and kv_hits_from_tagged returns the read as u32: hits that
+    # do not fit (reads of 64 kb and more, batches beyond 2^32 reads) take the host merge instead of aliasing
+    # (decided together: every rank must take the same sequence of collectives)
+    wide = torch.tensor([1 if n and (int(np.max(offset)) >= 1 << 16 or int(np.max(read)) >= 1 << 32) else 0],
+                        dtype=torch.int64, device=torch.device('cpu') if staged else device)
+    dist.all_reduce(wide, op=dist.ReduceOp.MAX, group=group)
+    if int(wide.item()):
+        return allgather_hits(read, offset, abund, torch.device('cpu') if staged else device, group)
     tags = (np.asarray(read).astype(np.int64) << 16) | np.asarray(offset).astype(np.int64)
     d_tags = torch.from_numpy(tags).to(device)
     d_abund = torch.from_numpy(np.ascontiguousarray(abund)).to(device) if n else torch.zeros((0, S), dtype=torch.uint8, device=device)

@@ -241,7 +241,7 @@ extern "C" int kv_route_hashes(const kv_reads *reads, int kind, int ksize, int n
     KV_REQUIRE(ndest >= 1 && ndest <= ROUTE_MAX_DEST, KV_ERR_ARG, "kv_route_hashes: 1..%d destinations, got %d",
                ROUTE_MAX_DEST, ndest);
     KV_REQUIRE(ksize >= 1 && reads->max_len < 65536, KV_ERR_ARG, "kv_route_hashes: bad k or read longer than a tag can address");
-    KV_REQUIRE(read_index_base + reads->n_reads < (1ull << 46), KV_ERR_ARG, "kv_route_hashes: read index does not fit the tag");
+    KV_REQUIRE(read_index_base + reads->n_reads <= (1ull << 32), KV_ERR_ARG, "kv_route_hashes: read index does not fit the u32 read field of kv_hits");
     uint64_t n_kmers = 0;
     kv_reads_num_kmers(reads, ksize, &n_kmers);
     KV_REQUIRE(cap_items >= n_kmers, KV_ERR_CAPACITY, "kv_route_hashes: the output needs room for the %llu k-mers of the shard",

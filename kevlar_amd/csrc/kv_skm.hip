@@ -47,7 +47,7 @@ namespace {
 
 #define SKM_THREADS1 512
 #define SKM_THREADS3 512
-#define SKM_MAXPROBE 24
+#define SKM_MAXPROBE 48
 // One global counter hands out work; a returning atomic on one word saturates at ~90 per microsecond on this chip
 // (MI355X_MICROARCH.md, "dequeue"), i.e. 1.3 ms for the 117 k tiles of a 7.5 M-read sample if every tile were a
 // ticket.  A ticket therefore covers several units of work.
@@ -110,7 +110,8 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
     const uint32_t nwl = sg.np_max / 16u + KV_TILE_MAX_READS + 8u;     // every read starts on a word: up to one partial word each
     uint32_t *wl = smem;                                              // the tile's packed words
     uint32_t *mh = smem + nwl;                                        // order value of the m-mer starting at every base
-    uint16_t *ids = (uint16_t *)(mh + sg.np_max + 96u);               // bucket (coarse << 8 | fine) of the k-mer starting at every base
+    uint16_t *ids = (uint16_t *)(mh + sg.np_max + 96u);               // bucket of the k-mer starting at every base: coarse << 8 | (fine & 255) ...
+    uint32_t *idhi = (uint32_t *)(ids + ((sg.np_max + 96u + 1u) & ~1u)); // ... and bit 8 of fine (up to 512 fine buckets), one bit per base
     uint32_t *starts = mh;                                            // run starts: reuses mh once the minima are taken
     const int k = sg.k, m = sg.m, w = sg.w;
     const int lane = threadIdx.x & 63;
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
             }
         }
         if (threadIdx.x < 96) mh[NB + threadIdx.x] = 0xffffffffu;
+        for (uint32_t i = threadIdx.x; i < (NB >> 5) + 2u; i += SKM_THREADS1) idhi[i] = 0;
         __syncthreads();
         // P2: one thread per chunk of CH k-mer starts: the minimum over the w m-mers of each (shared suffix of the
         // chunk + the w - 1 - CH values every window contains + a growing prefix), its bucket, and where runs start
@@ -212,18 +214,25 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
                 for (uint32_t t = CH; t + 2 <= (uint32_t)w; ++t) mid = min(mid, mh[q + t]);     // mh[q + CH .. q + w - 2]
                 uint32_t coarse, fine;
                 skm_bucket_of(min(suf[0], mid), sg.C1, sg.fbits, coarse, fine);
-                uint32_t prev = (coarse << 8) | fine;     // bucket of the k-mer in front of the chunk (unused when j == 0)
+                uint32_t prev = (coarse << 9) | fine;     // bucket of the k-mer in front of the chunk (unused when j == 0)
+                uint32_t himask = 0;
                 run = 0xffffffffu;
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
                     run = min(run, mh[q + (uint32_t)w - 1u + i]);
                     skm_bucket_of(min(min(suf[i + 1], mid), run), sg.C1, sg.fbits, coarse, fine);
-                    const uint32_t id = (coarse << 8) | fine;
+                    const uint32_t id = (coarse << 9) | fine;
                     if (j + (uint32_t)i < nkr) {
-                        ids[q + i] = (uint16_t)id;
+                        ids[q + i] = (uint16_t)((coarse << 8) | (fine & 0xffu));
+                        himask |= (fine >> 8) << i;
                         if (j + (uint32_t)i == 0 || id != prev) startmask |= 1u << i;
                     }
                     prev = id;
+                }
+                if (himask) {                             // CH <= 16 bits starting at bit q: at most two words
+                    const uint64_t bits = (uint64_t)himask << (q & 31u);
+                    atomicOr(&idhi[q >> 5], (uint32_t)bits);
+                    if (bits >> 32) atomicOr(&idhi[(q >> 5) + 1u], (uint32_t)(bits >> 32));
                 }
             }
             my_q[round] = q; my_starts[round] = startmask;
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
             const uint32_t limit = q - j + sh.nk[r];          // flat position one past the read's last k-mer
             const uint32_t nxt = i + 1 < nstart ? starts[i + 1] : limit;       // the next run (of this read or a later one)
             uint32_t left = (nxt < limit ? nxt : limit) - q;
-            const uint32_t coarse = id >> 8, fine = id & 0xffu;
+            const uint32_t coarse = id >> 8, fine = (id & 0xffu) | (((idhi[q >> 5] >> (q & 31u)) & 1u) << 8);
             uint64_t pos = (uint64_t)(sh.read0 + r) * sg.stride + sh.seg_start + j;
             uint32_t b = sh.wpre[r] * 16u + j;                // base index inside wl
             while (left) {
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
 #define SKM_THREADS2 512
 __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split(SkmGeom sg)
 {
-    __shared__ uint32_t cur[256];
+    __shared__ uint32_t cur[512];
     __shared__ uint32_t spre[769];                    // record prefix over the coarse segments this workgroup drains
     const uint32_t c = blockIdx.y;
     for (uint32_t f = threadIdx.x; f < sg.F2; f += SKM_THREADS2) cur[f] = 0;
@@ -808,12 +817,15 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.ncap = 32 * g.nbw - k + 1;
     const uint32_t table_slots = g.kw == 1 ? 4096u : 2048u;
     const char *tgt_env = getenv("KV_SKM_BUCKET_KMERS");      // tests shrink the buckets to exercise many of them on small inputs
-    const uint64_t target = tgt_env ? std::max<uint64_t>(64, strtoull(tgt_env, nullptr, 10)) : 2ull * table_slots;
+    // k-mers per fine bucket: 2 x slots for one-word keys (a bucket then holds ~0.4 x slots distinct k-mers at 30x);
+    // 1.5 x for two-word keys, whose longer windows put fewer, bigger minimizer loci into a bucket (more variance)
+    const uint64_t target = tgt_env ? std::max<uint64_t>(64, strtoull(tgt_env, nullptr, 10))
+                                    : (g.kw == 1 ? 2ull * table_slots : table_slots + table_slots / 2);
     const uint64_t nfine = std::max<uint64_t>(1, (n_kmers + target - 1) / target);
-    // at most 255 x 256 buckets (a bucket id travels as 16 bits through S1); bigger batches get bigger buckets, which
+    // at most 255 x 512 buckets (a bucket id travels as 17 bits through S1); bigger batches get bigger buckets, which
     // only costs deduplication efficiency
-    g.F2 = std::min<uint32_t>(256u, pow2_ceil((uint64_t)std::ceil(std::sqrt((double)nfine))));
-    if (nfine > 255ull * g.F2) g.F2 = std::min<uint32_t>(256u, pow2_ceil((nfine + 254) / 255));
+    g.F2 = std::min<uint32_t>(512u, pow2_ceil((uint64_t)std::ceil(std::sqrt((double)nfine))));
+    if (nfine > 255ull * g.F2) g.F2 = std::min<uint32_t>(512u, pow2_ceil((nfine + 254) / 255));
     g.fbits = 0;
     while ((1u << g.fbits) < g.F2) ++g.fbits;
     g.C1 = (uint32_t)std::min<uint64_t>(255, std::max<uint64_t>(1, (nfine + g.F2 - 1) / g.F2));
@@ -836,7 +848,8 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     const double m1 = rec_est / ((double)g.C1 * g.nwg1), m2 = rec_est / ((double)g.n_buckets * g.nwg2);
     g.cap1 = (uint32_t)kv_round_up((uint64_t)(m1 * 1.5 + 8.0 * std::sqrt(m1)) + 64, 16);
     g.cap2 = (uint32_t)kv_round_up((uint64_t)(m2 * 1.3 + 8.0 * std::sqrt(m2)) + 32, 16);
-    g.loose_cap = (uint64_t)(rec_est / 8.0) + (1u << 20);
+    // loose records: segment overflow (whole records) and occurrences that missed a full LDS table (one k-mer each)
+    g.loose_cap = (uint64_t)(rec_est / 8.0) + n_kmers / 16 + (1u << 20);
     if (const char *pct = getenv("KV_SKM_CAP_PCT")) {       // tests: undersized segments push records through the loose list
         g.cap1 = std::max<uint32_t>(16u, (uint32_t)((uint64_t)g.cap1 * (uint64_t)atoi(pct) / 100));
         g.cap2 = std::max<uint32_t>(16u, (uint32_t)((uint64_t)g.cap2 * (uint64_t)atoi(pct) / 100));
@@ -859,7 +872,8 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
     {
         KvProfScope prof("k_skm_emit");
-        const size_t lds = ((size_t)g.np_max / 16 + KV_TILE_MAX_READS + 8 + (size_t)g.np_max + 96) * 4 + ((size_t)g.np_max + 96) * 2;
+        const size_t lds = ((size_t)g.np_max / 16 + KV_TILE_MAX_READS + 8 + (size_t)g.np_max + 96) * 4 + (((size_t)g.np_max + 96 + 1) & ~(size_t)1) * 2 +
+                           ((size_t)g.np_max / 32 + 4) * 4;
         if (g.w > 16) {
             kv_ensure_dynamic_lds((const void *)k_skm_emit<16>, lds);
             hipLaunchKernelGGL(k_skm_emit<16>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), reads->n_tiles, g);
@@ -922,8 +936,8 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     }
     {
         KvProfScope prof("k_skm_loose_count");
-        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_count<1>, dim3(512), dim3(256), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
-        else hipLaunchKernelGGL(k_skm_loose_count<2>, dim3(512), dim3(256), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
+        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_count<1>, dim3(4096), dim3(256), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
+        else hipLaunchKernelGGL(k_skm_loose_count<2>, dim3(4096), dim3(256), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
     }
     KV_HIP(hipGetLastError());
     // a lost record (loose list overflow) must stop the apply stage, which looks at the partition's own flag
@@ -977,8 +991,8 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
     }
     {
         KvProfScope prof("k_skm_loose_novel");
-        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_novel<1>, dim3(512), dim3(256), 0, st, sg, rd, p);
-        else hipLaunchKernelGGL(k_skm_loose_novel<2>, dim3(512), dim3(256), 0, st, sg, rd, p);
+        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_novel<1>, dim3(4096), dim3(256), 0, st, sg, rd, p);
+        else hipLaunchKernelGGL(k_skm_loose_novel<2>, dim3(4096), dim3(256), 0, st, sg, rd, p);
     }
     {
         KvProfScope prof("k_tile_hits");

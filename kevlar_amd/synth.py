@@ -42,7 +42,7 @@ def _apply_variants(genome, positions, kinds, rng):
     return np.concatenate(pieces)
 
 
-def make_trio(genome_len, seed=42, inherited_per_mb=400, denovo_per_mb=200, weights=(0.8, 0.1, 0.1)):
+def make_trio(genome_len, seed=42, inherited_per_mb=400, denovo_per_mb=200, weights=(0.8, 0.1, 0.1), extra_controls=0):
     """Returns {'proband': (hap1, hap2), 'mother': ..., 'father': ...} of uint8 code arrays.
 
     Defaults reproduce gentrio's -i 20 -d 10 on a 50 kb genome (cli/gentrio.py:17-36) and scale
@@ -66,7 +66,12 @@ def make_trio(genome_len, seed=42, inherited_per_mb=400, denovo_per_mb=200, weig
         p = np.concatenate((inh_pos[sel_inh], dn_pos[dn_hap == h]))
         k = np.concatenate((inh_kind[sel_inh], dn_kind[dn_hap == h]))
         kid.append(_apply_variants(genome, p, k, rng))
-    return {'father': (parents[0], parents[1]), 'mother': (parents[2], parents[3]), 'proband': tuple(kid)}
+    fam = {'father': (parents[0], parents[1]), 'mother': (parents[2], parents[3]), 'proband': tuple(kid)}
+    # further controls (BASELINE.json config 5: proband + 3 controls): siblings that inherited other haplotype pairs
+    # and carry no de novo variant; derived without touching the generator, so the trio itself is unchanged
+    for i, (fh, mh) in enumerate(((1, 3), (0, 3), (1, 2))[:max(0, extra_controls)]):
+        fam['sibling{}'.format(i + 1)] = (parents[fh], parents[mh])
+    return fam
 
 
 def sample_reads_packed(haps, n_reads, read_len=100, error_rate=0.005, seed=1001, chunk=1 << 20):
@@ -110,10 +115,9 @@ def unpack_reads(words, read_len):
     return [row.tobytes().decode('ascii') for row in ascii_]
 
 
-def trio_reads_packed(genome_len, coverage, read_len=100, seed=42, error_rate=0.005):
-    """{'proband': words, 'mother': words, 'father': words}; seeds 1001/1002/1003 per sample."""
-    trio = make_trio(genome_len, seed)
+def trio_reads_packed(genome_len, coverage, read_len=100, seed=42, error_rate=0.005, extra_controls=0):
+    """{'proband': words, 'mother': words, 'father': words[, 'sibling1': ...]}; seeds 1001/1002/1003(/1004...) per sample."""
+    trio = make_trio(genome_len, seed, extra_controls=extra_controls)
     n_reads = int(genome_len * coverage / read_len)
-    seeds = {'proband': 1001, 'mother': 1002, 'father': 1003}
-    return {name: sample_reads_packed(trio[name], n_reads, read_len, error_rate, seeds[name])
-            for name in ('proband', 'mother', 'father')}
+    names = ['proband', 'mother', 'father'] + ['sibling{}'.format(i + 1) for i in range(extra_controls)]
+    return {name: sample_reads_packed(trio[name], n_reads, read_len, error_rate, 1001 + i) for i, name in enumerate(names)}

@@ -519,7 +519,9 @@ int64_t kvo_novel_scan(kvo_sketch *const *cases, int ncase, kvo_sketch *const *c
 /* ------------------------------------------------------------------------------------ */
 #include <pthread.h>
 
-static int add_hash_atomic(kvo_sketch *s, uint64_t h)
+/* n_occupied / n_unique are accumulated per thread (occ, uniq) and added once at the end: a shared counter bumped
+ * on every new k-mer would turn into the hottest cache line of the machine with many threads */
+static int add_hash_atomic(kvo_sketch *s, uint64_t h, uint64_t *occ, uint64_t *uniq)
 {
     int is_new = 0;
     for (int i = 0; i < s->ntables; ++i) {
@@ -528,7 +530,7 @@ static int add_hash_atomic(kvo_sketch *s, uint64_t h)
         if (s->storage == ST_BYTE) {
             uint8_t cur = __atomic_load_n(&t[bin], __ATOMIC_RELAXED);
             while (cur < 255 && !__atomic_compare_exchange_n(&t[bin], &cur, (uint8_t)(cur + 1), 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
-            if (cur == 0) { is_new = 1; if (i == 0) __atomic_fetch_add(&s->n_occupied, 1, __ATOMIC_RELAXED); }
+            if (cur == 0) { is_new = 1; if (i == 0) ++*occ; }
         } else if (s->storage == ST_NIBBLE) {
             const int shift = (bin & 1) ? 0 : 4;
             uint8_t old = __atomic_load_n(&t[bin >> 1], __ATOMIC_RELAXED);
@@ -537,17 +539,17 @@ static int add_hash_atomic(kvo_sketch *s, uint64_t h)
                 if (cur == 15) break;
                 const uint8_t neu = (uint8_t)((old & ~(15 << shift)) | ((cur + 1) << shift));
                 if (__atomic_compare_exchange_n(&t[bin >> 1], &old, neu, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
-                    if (cur == 0) { is_new = 1; if (i == 0) __atomic_fetch_add(&s->n_occupied, 1, __ATOMIC_RELAXED); }
+                    if (cur == 0) { is_new = 1; if (i == 0) ++*occ; }
                     break;
                 }
             }
         } else {
             const uint8_t bit = (uint8_t)(1u << (bin & 7));
             const uint8_t old = __atomic_fetch_or(&t[bin >> 3], bit, __ATOMIC_RELAXED);
-            if (!(old & bit)) { is_new = 1; if (i == 0) __atomic_fetch_add(&s->n_occupied, 1, __ATOMIC_RELAXED); }
+            if (!(old & bit)) { is_new = 1; if (i == 0) ++*occ; }
         }
     }
-    if (is_new) __atomic_fetch_add(&s->n_unique, 1, __ATOMIC_RELAXED);
+    if (is_new) ++*uniq;
     return is_new;
 }
 
@@ -566,6 +568,7 @@ static void *mt_count_worker(void *arg)
     const int k = j->s->ksize;
     char *clean = NULL;
     size_t cap = 0;
+    uint64_t occ = 0, uniq = 0;
     for (;;) {
         const uint64_t r0 = __atomic_fetch_add(j->next, j->chunk, __ATOMIC_RELAXED);
         if (r0 >= j->n_reads) break;
@@ -577,12 +580,14 @@ static void *mt_count_worker(void *arg)
             if (len > cap) { free(clean); clean = (char *)malloc(len); cap = len; }
             for (size_t i = 0; i < len; ++i) clean[i] = clean_base(seq[i]);
             for (size_t i = 0; i + (size_t)k <= len; ++i) {
-                add_hash_atomic(j->s, kvo_hash(j->s->kind, clean + i, k));
+                add_hash_atomic(j->s, kvo_hash(j->s->kind, clean + i, k), &occ, &uniq);
                 j->n_added++;
             }
         }
     }
     free(clean);
+    __atomic_fetch_add(&j->s->n_occupied, occ, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&j->s->n_unique, uniq, __ATOMIC_RELAXED);
     return NULL;
 }
 
