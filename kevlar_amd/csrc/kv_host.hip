@@ -421,6 +421,7 @@ extern "C" int kv_sketch_clear(kv_sketch *s)
     s->n_occupied = 0;
     s->n_unique = 0;
     s->occ_dirty = false;
+    s->skm_off = false;
     return KV_OK;
 }
 

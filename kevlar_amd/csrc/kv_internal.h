@@ -49,6 +49,7 @@ struct kv_sketch {
     uint64_t uid = 0;      // unique per allocation (pointers get recycled)
     uint64_t version = 0;  // bumped by everything that changes a table (invalidates cached scan verdicts)
     uint64_t *d_counters; // [0] n_kmers, [1] n_unique (device accumulators)
+    bool skm_off = false;  // the last batch counted through the super-k-mer front end did not deduplicate: skip it until cleared
     std::mutex mu;
 };
 

@@ -37,9 +37,10 @@ struct SkmGeom {
     uint64_t *seg2; uint32_t *cnt2;  // [C1 * F2][nwg2][cap2] / [C1 * F2][nwg2]
     uint64_t *loose; uint64_t loose_cap;
     unsigned long long *ctr;         // [0] loose records, [1] failure, [2] S1 tile ticket, [3] count ticket, [4] scan ticket,
-                                     // [5] records emitted, [6] loose records after S1 + S2
+                                     // [5] records emitted, [6] loose records after S1 + S2, [7] distinct k-mers the count pass found in its LDS tables
     uint32_t n_buckets, quota3;
     uint32_t sbw;                    // words of record-start bits per wave in the bucket walk
+    uint64_t bucket_kmers;           // average k-mers per fine bucket
     uint32_t dbg;                    // KV_SKM_DEBUG: timing experiments that skip parts of kernels (results are then wrong)
 };
 
@@ -484,7 +485,8 @@ __device__ __forceinline__ SkmKey<KW> skm_kmer_at(uint64_t b0, uint64_t b1, uint
     return f;
 }
 
-// body(forward k-mer, position of the occurrence); WANT_POS = false skips fetching the header (count pass)
+// body(forward k-mer, position of the occurrence) -> true if the occurrence could not be combined and must travel
+// alone through the loose list; WANT_POS = false skips fetching the header (count pass)
 template <int KW, bool WANT_POS, typename Body>
 __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, uint32_t *sbits_all, Body body)
 {
@@ -532,9 +534,29 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
             const uint64_t o0 = skm_shfl64(b0, owner), o1 = skm_shfl64(b1, owner);
             const uint64_t o2 = KW == 2 ? skm_shfl64(b2, owner) : 0ull;
             const uint64_t oh = WANT_POS ? skm_shfl64(hdr, owner) : 0ull;
+            bool alone = false;
+            SkmKey<KW> fw;
+            fw.w[0] = 0;
+            if (KW == 2) fw.w[KW - 1] = 0;
+            uint64_t pos = 0;
             if (t < total) {
                 const uint32_t j = t - ex;
-                body(skm_kmer_at<KW>(o0, o1, o2, j, k), skm_hdr_pos(oh) + j);
+                fw = skm_kmer_at<KW>(o0, o1, o2, j, k);
+                pos = skm_hdr_pos(oh) + j;
+                alone = body(fw, pos);
+            }
+            // occurrences that found no room in the LDS table leave as one-k-mer records: one atomic per wave
+            const unsigned long long need = __ballot(alone);
+            if (need) {
+                unsigned long long first = 0;
+                if (lane == 0) first = atomicAdd(&sg.ctr[0], (unsigned long long)__popcll(need));
+                first = skm_shfl64(first, 0);
+                if (alone) {
+                    const unsigned long long idx = first + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
+                    uint64_t one[3] = {fw.w[0], KW == 2 ? fw.w[KW - 1] : 0ull, 0ull};
+                    if (idx < sg.loose_cap) skm_store_record(sg.loose + idx * (uint64_t)recw, skm_header(pos, 1u, 0u), one, sg.nbw);
+                    else sg.ctr[1] = 1;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();                // the next group clears the mask
@@ -559,7 +581,7 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_count(SkmGeom sg, const Sk
     for (uint32_t s = threadIdx.x; s < ns; s += SKM_THREADS3) cur[s] = 0;
     if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
     const int k = sg.k;
-    uint64_t n_added = 0;
+    uint64_t n_added = 0, n_distinct = 0;
     const uint32_t cap1 = (uint32_t)g.cap1;
     uint32_t *my_seg = g.gbuf1 + (uint64_t)blockIdx.x * g.cap1;          // + stream * seg_stride: this workgroup's segment of a stream
     const uint64_t seg_stride = (uint64_t)g.nwgA * g.cap1;
@@ -584,17 +606,25 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_count(SkmGeom sg, const Sk
         __syncthreads();
         if (threadIdx.x == 0) {
             if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
-            else next_bucket = taken + 1 < sg.quota3 ? (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET : 0xffffffffu;
+            else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
+            else {
+                const unsigned long long ticket = atomicAdd(&sg.ctr[3], 1ull);
+                next_bucket = (uint32_t)ticket * SKM_BUCKETS_PER_TICKET;     // (a raised flag ends the pass: the caller redoes the batch)
+                // a batch that does not fit the LDS tables (low coverage per batch: nearly every k-mer distinct) is given up
+                // early: once 2 % of the buckets are done, more than 4 % of their k-mers outside the tables raise the flag
+                const unsigned long long done = ticket * SKM_BUCKETS_PER_TICKET;
+                if (done * 50ull >= sg.n_buckets) {
+                    const unsigned long long now = __hip_atomic_load(&sg.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), start = sg.ctr[6];
+                    if (now > start && (now - start) * 25ull > done * sg.bucket_kmers) sg.ctr[1] = 1;
+                }
+            }
         }
         // combine the occurrences of the bucket
         if (!(sg.dbg & 2u)) skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t) {
             const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
             const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
             if (slot >= 0) atomicAdd(&cnt[slot], 1u);
-            else {   // table region full (or unstorable key): this occurrence travels alone
-                uint64_t one[3] = {fw.w[0], KW == 2 ? fw.w[KW - 1] : 0ull, 0ull};
-                skm_loose_push(sg, skm_header(0, 1u, 0u), one);
-            }
+            return slot < 0;         // table region full (or unstorable key): this occurrence travels alone
         });
         __syncthreads();
         // every distinct k-mer once
@@ -605,6 +635,7 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_count(SkmGeom sg, const Sk
             if (KW == 2) { c.w[KW - 1] = tb.key[KW - 1][slot]; tb.key[KW - 1][slot] = SKM_EMPTY; }
             const uint32_t seen = cnt[slot];
             cnt[slot] = 0;
+            n_distinct += 1;
             if (sg.dbg & 1u) return;
             const uint64_t h = skm_key_hash<KW>(c, lut, f.hp);
             if (sg.dbg & 64u) { n_added += h & 1; return; }
@@ -615,7 +646,9 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_count(SkmGeom sg, const Sk
     for (uint32_t s = threadIdx.x; s < ns; s += SKM_THREADS3)
         g.gcnt1[(uint64_t)s * g.nwgA + blockIdx.x] = (uint32_t)min((uint64_t)cur[s], g.cap1);
     n_added = wave_sum_u64(n_added);
+    n_distinct = wave_sum_u64(n_distinct);
     if ((threadIdx.x & 63) == 0 && n_added) atomicAdd(&g.ctr[2], (unsigned long long)n_added);
+    if ((threadIdx.x & 63) == 0 && n_distinct) atomicAdd(&sg.ctr[7], (unsigned long long)n_distinct);
 }
 
 // loose records: every k-mer occurrence on its own, increments through the spill list (global atomics)
@@ -624,6 +657,7 @@ __global__ __launch_bounds__(256) void k_skm_loose_count(SkmGeom sg, const Sketc
                                                          const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
     __shared__ uint32_t lut[256];
+    if (sg.ctr[1] != 0) return;                  // the pass was given up: the caller redoes the batch another way
     lut[threadIdx.x] = skm_ascii4(threadIdx.x);
     __syncthreads();
     unsigned long long n = sg.ctr[0];
@@ -681,17 +715,15 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_novel(SkmGeom sg, ReadsDev
         __syncthreads();
         if (threadIdx.x == 0) {
             if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
-            else next_bucket = taken + 1 < sg.quota3 ? (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET : 0xffffffffu;
+            else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
+            else next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET;
             any_hit = 0;
         }
         // collect the distinct k-mers
         skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t pos) {
             const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
             const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
-            if (slot < 0) {
-                uint64_t one[3] = {fw.w[0], KW == 2 ? fw.w[KW - 1] : 0ull, 0ull};
-                skm_loose_push(sg, skm_header(pos, 1u, 0u), one);
-            }
+            return slot < 0;
         });
         __syncthreads();
         // evaluate each of them once
@@ -707,9 +739,10 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_novel(SkmGeom sg, ReadsDev
         // mark every occurrence of an interesting k-mer (an occurrence whose key is absent went to the loose list)
         skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t pos) {
             const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
-            if (!skm_cacheable<KW>(c)) return;
+            if (!skm_cacheable<KW>(c)) return false;
             const int slot = skm_table_find(tb, c);
             if (slot >= 0 && ((flag[slot >> 5] >> (slot & 31)) & 1u)) skm_mark(p, rd, pos, sg.stride);
+            return false;
         });
     }
 }
@@ -869,6 +902,7 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.ctr = (unsigned long long *)base;
     KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));
     g.sbw = ((64u * (uint32_t)g.ncap) >> 5) + 2u;
+    g.bucket_kmers = std::max<uint64_t>(1, n_kmers / g.n_buckets);
     g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
     {
         KvProfScope prof("k_skm_emit");
@@ -911,6 +945,7 @@ bool kv_skm_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_kmers
     if ((double)reads->n_reads * (double)min_stride >= (double)(1ull << SKM_POS_BITS)) return false;
     if (reads->tile_max_bases == 0 || reads->tile_max_bases > 8192u) return false;
     if (force) return true;
+    if (s->skm_off) return false;          // the previous batch into this sketch did not deduplicate (kv_consume_skm)
     return n_kmers >= (1ull << 22);
 }
 
@@ -944,6 +979,20 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     hipLaunchKernelGGL(k_skm_forward_flag, dim3(1), dim3(1), 0, st, sg.ctr, plan.g.ctr);
     KV_HIP(hipGetLastError());
     const int rc = kv_bin_finish(s, plan, true, 0, n_added);     // synchronises the stream
+    {
+        // what the batch looked like: if most k-mers are distinct (low coverage per batch) cutting and bucketing the
+        // reads buys nothing, and if many occurrences missed the LDS tables the buckets were too full; either way
+        // the next batches into this sketch take the one-item-per-k-mer partition (until the sketch is cleared)
+        unsigned long long sc[8] = {0};
+        if (hipMemcpy(sc, sg.ctr, sizeof(sc), hipMemcpyDeviceToHost) == hipSuccess && n_kmers) {
+            const double alone = (double)(sc[0] > sc[6] ? sc[0] - sc[6] : 0) / (double)n_kmers;
+            const double distinct = (double)sc[7] / (double)n_kmers + alone;
+            s->skm_off = rc != KV_OK || alone > 0.03 || distinct > 0.45;
+            if (getenv("KV_SKM_VERBOSE"))
+                fprintf(stderr, "[kv_skm] batch of %llu k-mers: %.1f%% distinct, %.2f%% outside the LDS tables%s\n",
+                        (unsigned long long)n_kmers, 100 * distinct, 100 * alone, s->skm_off ? " -> next batches take the plain partition" : "");
+        }
+    }
     if (rc != KV_OK) {
         idx.valid = false;
         if (getenv("KV_SKM_VERBOSE")) {
