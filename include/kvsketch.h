@@ -161,6 +161,11 @@ int kv_unique_exact(kv_sketch *s, const kv_reads *const *batches, int n_batches,
 /* ---- point queries: .get / .add on many k-mers (kevlar/filter.py:32-34,67) ------------ */
 /* hash n k-mers of length k stored back to back in `kmers` (device kernel)                */
 int kv_hash_kmers(int kind, const char *kmers, int k, uint64_t n, uint64_t *hashes_out);
+/* the same hashes for k-mers given by position: k-mer i is reads[ann_read[i]][ann_offset[i] : + ksize].  What
+ * kevlar/filter.py:32-34,67 and kevlar/readgraph.py:60-66 obtain by slicing record.ikmerseq() and calling the
+ * sketch once per k-mer; here the annotated reads stay packed in HBM and only (read, offset) pairs travel.      */
+int kv_hash_positions(const kv_reads *reads, int kind, int ksize, const uint32_t *ann_read, const uint32_t *ann_offset,
+                      uint64_t n, uint64_t *hashes_out);
 int kv_get_hashes(kv_sketch *s, const uint64_t *hashes, uint64_t n, uint8_t *counts_out);
 /* adds in array order semantics are order-free (saturating); is_new_out may be NULL       */
 int kv_add_hashes(kv_sketch *s, const uint64_t *hashes, uint64_t n, uint8_t *is_new_out);
@@ -192,6 +197,10 @@ int kv_hits_fetch(const kv_hits *h, uint32_t *read, uint32_t *offset, uint8_t *a
  * kv_hits_destroy; sizes as reported by kv_hits_count                                              */
 int kv_hits_view(const kv_hits *h, const uint32_t **read, const uint32_t **offset, const uint8_t **abund,
                  const uint32_t **discarded_reads);
+/* --abund-screen only: interesting k-mers of DISCARDED reads that lie in front of the k-mer that tripped the screen.
+ * The reference has already added them to its tally of unique novel k-mers when it drops the read
+ * (kevlar/novel.py:152-164), so the summary line needs them although the reads are not reported.             */
+int kv_hits_shadow(const kv_hits *h, const uint32_t **read, const uint32_t **offset, uint64_t *n);
 int kv_hits_destroy(kv_hits *h);
 
 /* ---- read-sharded multi-GPU count / scan (kevlar's banding, docs/banding.rst,

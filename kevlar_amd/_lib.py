@@ -76,12 +76,14 @@ SIGNATURES = {
     'kv_unique_exact': (i32, [vp, vpp, i32, i32, i32, vp, i32, i32, u64p]),
     'kv_abundance_distribution': (i32, [vp, vp, vpp, i32, u64p]),
     'kv_hash_kmers': (i32, [i32, cstr, i32, u64, u64p]),
+    'kv_hash_positions': (i32, [vp, i32, i32, u32p, u32p, u64, u64p]),
     'kv_get_hashes': (i32, [vp, u64p, u64, u8p]),
     'kv_add_hashes': (i32, [vp, u64p, u64, u8p]),
     'kv_novel_scan': (i32, [vpp, i32, vpp, i32, vp, u64, i32, i32, i32, i32, i32, i32, vp, u64, vpp]),
     'kv_hits_count': (i32, [vp, u64p, u64p]),
     'kv_hits_fetch': (i32, [vp, u32p, u32p, u8p, u64, u32p, u64]),
     'kv_hits_view': (i32, [vp, ctypes.POINTER(u32p), ctypes.POINTER(u32p), ctypes.POINTER(u8p), ctypes.POINTER(u32p)]),
+    'kv_hits_shadow': (i32, [vp, ctypes.POINTER(u32p), ctypes.POINTER(u32p), u64p]),
     'kv_hits_destroy': (i32, [vp]),
     'kv_route_hashes': (i32, [vp, i32, i32, i32, u64, i32, vp, u64, u64p]),
     'kv_consume_hashes': (i32, [vp, vp, u64, ctypes.c_uint32, u64p]),

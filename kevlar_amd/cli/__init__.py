@@ -178,3 +178,18 @@ def parse_args(arglist=None):
         kevlar_amd.logstream = kevlar_amd.open(args.logfile, 'w')
     kevlar_amd.teelog = args.tee
     return args
+
+
+def run(arglist=None):
+    """The command line: parse, announce the version ("[kevlar] running version ...", asserted by the reference's
+    tests), dispatch to the subcommand's driver.  `python -m kevlar_amd` and the console entry point both come here;
+    tests pass an argument list."""
+    top = parser()
+    args = parse_args(arglist)
+    driver = mains.get(args.cmd)
+    if driver is None:
+        top.print_help()
+        raise SystemExit(0 if args.cmd is None else 2)
+    kevlar_amd.plog('[kevlar] running version {}'.format(kevlar_amd.__version__))
+    return driver(args)
+

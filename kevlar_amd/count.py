@@ -1,118 +1,107 @@
-"""`kevlar count` driver (the reference's kevlar/count.py:18-140) over the HIP sketch engine."""
+"""`kevlar count`: the k-mers of one sample into one sketch in HBM (kevlar/count.py:18-140).
+
+The reference starts `numthreads` Python threads that all call khmer's consume_seqfile* on one parser and one
+sketch.  Here the unit of work is explicit: a worker pulls the next batch of reads from the shared native parser
+(parsed, 2-bit packed and uploaded in one call), hands it to kv_consume with the sample's band / mask policy, and
+lets it go.  With one thread the batches are kept (within a memory budget) so that "distinct k-mers stored" can be
+the exact single-thread figure."""
+from collections import namedtuple
 import threading
 
 import kevlar_amd
 from kevlar_amd import khmer
-from kevlar_amd.sketch import allocate, get_extension
+from kevlar_amd.sketch import KevlarUnsuitableFPRError, allocate, estimate_fpr, get_extension
+
+_Policy = namedtuple('_Policy', 'nbands band mask threshold consume_masked')
 
 
-def load_sample_seqfile(seqfiles, ksize, memory, maxfpr=0.2, count=True, smallcount=False,
-                        mask=None, maskmaxabund=0, consume_masked=False, numbands=None,
-                        band=None, outfile=None, numthreads=1, log=None):
-    """Count the k-mers of one sample (one or more FASTA/FASTQ files) into a fresh sketch.
+def _drain(parser, sketch, policy):
+    """worker loop: batches off the shared parser into the sketch until the file is exhausted"""
+    while True:
+        batch = parser.take_batch(khmer.BATCH_READS)
+        if batch is None:
+            return
+        sketch.consume_batch(batch, policy.nbands, policy.band, policy.mask, policy.threshold, policy.consume_masked)
+        if not sketch.retains(batch):
+            batch.close()
 
-    tablesize = memory / 4 * buckets-per-byte, four tables (kevlar/count.py:29-35); the hot
-    loop is kv_consume.  `numthreads` host threads pull read batches from one shared parser,
-    as the reference's threads do; with one thread the "distinct k-mers stored" figure is the
-    exact single-thread value.
-    """
+
+def _count_file(path, sketch, policy, nthreads):
+    """all reads of one file, by `nthreads` workers; returns the number of reads"""
+    parser = khmer.ReadParser(path)
+    failures = []
+
+    def guarded():
+        try:
+            _drain(parser, sketch, policy)
+        except BaseException as exc:        # re-raised on the calling thread
+            failures.append(exc)
+    crew = [threading.Thread(target=guarded) for _ in range(max(1, nthreads))]
+    for worker in crew:
+        worker.start()
+    for worker in crew:
+        worker.join()
+    if failures:
+        raise failures[0]
+    return parser.num_reads
+
+
+def load_sample_seqfile(seqfiles, ksize, memory, maxfpr=0.2, count=True, smallcount=False, mask=None, maskmaxabund=0,
+                        consume_masked=False, numbands=None, band=None, outfile=None, numthreads=1, log=None):
+    """Count one sample (one or more FASTA/FASTQ files) into a fresh sketch of `memory` bytes: four tables of
+    memory / 4 bytes each, i.e. memory / 4 x {1, 2, 8} bins for byte / nibble / bit counters.  Returns the sketch;
+    raises KevlarUnsuitableFPRError if its estimated false positive rate exceeds `maxfpr`; saves it to `outfile`
+    (extension appended if missing)."""
     log = log or kevlar_amd.plog
-    numtables = 4
-    sketchtype = 'nodegraph'
-    if count:
-        sketchtype = 'smallcountgraph' if smallcount else 'countgraph'
-    tablesize = memory / numtables * khmer._buckets_per_byte[sketchtype]
-    sketch = allocate(ksize, tablesize, num_tables=numtables, count=count, smallcount=smallcount)
-    if numthreads == 1:
-        sketch.track_exact_unique(True)
-    numreads = 0
-    for seqfile in seqfiles:
-        log('[kevlar::count]', '- processing "{}"'.format(seqfile))
-        parser = khmer.ReadParser(seqfile)
-        if mask:
-            kwargs = {'consume_masked': consume_masked,
-                      'threshold': 1 if consume_masked else maskmaxabund}
-            if numbands:
-                target, args = sketch.consume_seqfile_banding_with_mask, (parser, numbands, band, mask)
-            else:
-                target, args = sketch.consume_seqfile_with_mask, (parser, mask)
-        else:
-            kwargs = {}
-            if numbands:
-                target, args = sketch.consume_seqfile_banding, (parser, numbands, band)
-            else:
-                target, args = sketch.consume_seqfile, (parser,)
-        errors = []
-
-        def work():
-            try:
-                target(*args, **kwargs)
-            except BaseException as exc:  # surfaced after join
-                errors.append(exc)
-
-        threads = [threading.Thread(target=work) for _ in range(numthreads)]
-        for thread in threads:
-            thread.start()
-        for thread in threads:
-            thread.join()
-        if errors:
-            raise errors[0]
-        numreads += parser.num_reads
-
-    message = 'Done loading k-mers'
-    if numbands:
-        message += ' (band {:d}/{:d})'.format(band + 1, numbands)
-    fpr = kevlar_amd.sketch.estimate_fpr(sketch)
+    flavour = ('smallcountgraph' if smallcount else 'countgraph') if count else 'nodegraph'
+    sketch = allocate(ksize, memory / 4 * khmer._buckets_per_byte[flavour], num_tables=4, count=count, smallcount=smallcount)
+    if mask is None:
+        policy = _Policy(numbands or 0, band or 0, None, 0, False)
+    else:           # skip k-mers the mask holds more than maskmaxabund times -- or, inverted, keep only k-mers it holds
+        policy = _Policy(numbands or 0, band or 0, mask, 1 if consume_masked else maskmaxabund, consume_masked)
+    sketch.track_exact_unique(numthreads == 1)
+    nreads = 0
+    for path in seqfiles:
+        log('[kevlar::count]', '- processing "{}"'.format(path))
+        nreads += _count_file(path, sketch, policy, numthreads)
     try:
         distinct = sketch.n_unique_kmers()
     except (kevlar_amd._lib.KvError, ValueError):
-        # first-touch scratch did not fit: fall back to the multi-thread figure
-        sketch.track_exact_unique(False)
+        sketch.track_exact_unique(False)        # the exact pass did not fit: report the estimate
         distinct = sketch.n_unique_kmers()
-    message += ';\n    {:d} reads processed'.format(numreads)
-    message += ', {:d} distinct k-mers stored'.format(distinct)
-    message += ';\n    estimated false positive rate is {:1.3f}'.format(fpr)
+    sketch.track_exact_unique(False)            # let the retained batches go
+    fpr = estimate_fpr(sketch)
+    lines = ['Done loading k-mers' + (' (band {:d}/{:d})'.format(band + 1, numbands) if numbands else ''),
+             '{:d} reads processed, {:d} distinct k-mers stored'.format(nreads, distinct),
+             'estimated false positive rate is {:1.3f}'.format(fpr)]
     if fpr > maxfpr:
-        message += ' (FPR too high, bailing out!!!)'
-        raise kevlar_amd.sketch.KevlarUnsuitableFPRError('[kevlar::count] ' + message)
-    sketch.track_exact_unique(False)  # release the packed batches
-
+        lines[-1] += ' (FPR too high, bailing out!!!)'
+        raise KevlarUnsuitableFPRError('[kevlar::count] ' + ';\n    '.join(lines))
     if outfile:
-        extensions = get_extension(count=count, smallcount=smallcount)
-        if not outfile.endswith(extensions):
-            outfile += extensions[1]
+        if not outfile.endswith(get_extension(count=count, smallcount=smallcount)):
+            outfile += get_extension(count=count, smallcount=smallcount)[1]
         sketch.save(outfile)
-        message += ';\n    saved to "{:s}"'.format(outfile)
-    log('[kevlar::count]', message)
+        lines.append('saved to "{:s}"'.format(outfile))
+    log('[kevlar::count]', ';\n    '.join(lines))
     return sketch
 
 
-def print_config(args):
-    tabletype = {1: 'node', 4: 'small count', 8: 'count'}[args.counter_size]
-    message = 'Storing k-mers in a {} table'.format(tabletype)
-    if args.counter_size == 1:
-        message += ' (Bloom filter) for k-mer presence/absence queries'
-    else:
-        maxcount = {4: 15, 8: 255}[args.counter_size]
-        message += ', a CountMin sketch with a counter size of {} bits'.format(args.counter_size)
-        message += ', for k-mer abundance queries (max abundance {})'.format(maxcount)
-    kevlar_amd.plog('[kevlar::count]', message)
+_TABLE_BLURB = {
+    1: 'Storing k-mers in a node table (Bloom filter) for k-mer presence/absence queries',
+    4: 'Storing k-mers in a small count table, a CountMin sketch with a counter size of 4 bits, for k-mer abundance queries (max abundance 15)',
+    8: 'Storing k-mers in a count table, a CountMin sketch with a counter size of 8 bits, for k-mer abundance queries (max abundance 255)',
+}
 
 
 def main(args):
-    if (args.num_bands is None) is not (args.band is None):
+    if (args.num_bands is None) != (args.band is None):
         raise ValueError('Must specify --num-bands and --band together')
-    myband = args.band - 1 if args.band else None
-    if args.mask:
-        args.mask = kevlar_amd.sketch.load(args.mask)
-    print_config(args)
-
-    timer = kevlar_amd.Timer()
-    timer.start()
-    load_sample_seqfile(
-        args.seqfile, args.ksize, args.memory, args.max_fpr, count=args.counter_size > 1,
-        smallcount=args.counter_size == 4, mask=args.mask, consume_masked=args.count_masked,
-        numbands=args.num_bands, band=myband, numthreads=args.threads, outfile=args.counttable,
-    )
-    total = timer.stop()
-    kevlar_amd.plog('[kevlar::count] Total time: {:.2f} seconds'.format(total))
+    mask = kevlar_amd.sketch.load(args.mask) if args.mask else None
+    kevlar_amd.plog('[kevlar::count]', _TABLE_BLURB[args.counter_size])
+    clock = kevlar_amd.Timer()
+    clock.start()
+    load_sample_seqfile(args.seqfile, args.ksize, args.memory, args.max_fpr, count=args.counter_size > 1,
+                        smallcount=args.counter_size == 4, mask=mask, consume_masked=args.count_masked,
+                        numbands=args.num_bands, band=args.band - 1 if args.band else None, numthreads=args.threads,
+                        outfile=args.counttable)
+    kevlar_amd.plog('[kevlar::count] Total time: {:.2f} seconds'.format(clock.stop()))

@@ -115,6 +115,7 @@ struct kv_hits {
     PinnedVec<uint32_t> read, offset;
     PinnedVec<uint8_t> abund;
     std::vector<uint32_t> discarded;
+    std::vector<uint32_t> shadow_read, shadow_offset;   // interesting k-mers of discarded reads in front of the screen trip
 };
 
 struct HashParams {

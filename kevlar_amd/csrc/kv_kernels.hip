@@ -10,7 +10,9 @@
 //
 // No MFMA anywhere: this is 64-bit integer hashing plus random byte-granular table access.
 #include <algorithm>
+#include <map>
 
+#include "kv_binned.h"
 #include "kv_device.h"
 
 namespace {
@@ -89,55 +91,73 @@ __global__ void k_add_hashes(const SketchDev *__restrict__ sk, const uint64_t *h
     if ((threadIdx.x & 63) == 0 && n_new) atomicAdd((unsigned long long *)&counters[1], (unsigned long long)n_new);
 }
 
-template <bool RC>
-__device__ __forceinline__ uint32_t kmer_byte(const uint8_t *km, int k, int j)
-{
-    if (!RC) return km[j];
-    const uint32_t c = km[k - 1 - j];
-    return c == 'A' ? 'T' : (c == 'C' ? 'G' : (c == 'G' ? 'C' : (c == 'T' ? 'A' : 'N')));
-}
-
-template <bool RC>
-__device__ uint64_t murmur_global(const uint8_t *km, int k)
+// MurmurHash3_x64_128 (low word) of k characters produced one at a time by `at(j)`
+template <typename At>
+__device__ uint64_t murmur_chars(At at, int k)
 {
     uint64_t h1 = 0, h2 = 0;
     const int nblocks = k / 16, rem = k & 15;
     for (int b = 0; b < nblocks; ++b) {
         uint64_t k1 = 0, k2 = 0;
         for (int j = 7; j >= 0; --j) {
-            k1 = (k1 << 8) | kmer_byte<RC>(km, k, 16 * b + j);
-            k2 = (k2 << 8) | kmer_byte<RC>(km, k, 16 * b + 8 + j);
+            k1 = (k1 << 8) | at(16 * b + j);
+            k2 = (k2 << 8) | at(16 * b + 8 + j);
         }
         mm_block(h1, h2, k1, k2);
     }
     uint64_t k1 = 0, k2 = 0;
-    for (int j = rem - 1; j >= 8; --j) k2 = (k2 << 8) | kmer_byte<RC>(km, k, 16 * nblocks + j);
+    for (int j = rem - 1; j >= 8; --j) k2 = (k2 << 8) | at(16 * nblocks + j);
     if (rem > 8) { k2 *= MM_C2; k2 = rotl64(k2, 33); k2 *= MM_C1; h2 ^= k2; }
-    for (int j = (rem > 8 ? 8 : rem) - 1; j >= 0; --j) k1 = (k1 << 8) | kmer_byte<RC>(km, k, 16 * nblocks + j);
+    for (int j = (rem > 8 ? 8 : rem) - 1; j >= 0; --j) k1 = (k1 << 8) | at(16 * nblocks + j);
     if (rem > 0) { k1 *= MM_C1; k1 = rotl64(k1, 31); k1 *= MM_C2; h1 ^= k1; }
     return mm_final(h1, h2, k);
+}
+
+// khmer's hash of a k-mer given as characters at(j) (forward) and rc(j) (reverse complement)
+template <typename Fwd, typename Rev>
+__device__ __forceinline__ uint64_t kmer_hash_chars(Fwd fwd, Rev rev, int k, int hashfam)
+{
+    if (hashfam == HF_TWOBIT) {
+        uint64_t f = 0, r = 0;
+        for (int j = 0; j < k; ++j) {
+            uint32_t x = (fwd(j) >> 1) & 3u;
+            x ^= ((x ^ (x >> 1)) & 1u) * 3u;
+            f = (f << 2) | x;
+            uint32_t y = (rev(j) >> 1) & 3u;
+            y ^= ((y ^ (y >> 1)) & 1u) * 3u;
+            r = (r << 2) | y;
+        }
+        return f < r ? f : r;
+    }
+    return murmur_chars(fwd, k) ^ murmur_chars(rev, k);
+}
+
+__device__ __forceinline__ uint32_t complement_char(uint32_t c)
+{
+    return c == 'A' ? 'T' : (c == 'C' ? 'G' : (c == 'G' ? 'C' : (c == 'T' ? 'A' : 'N')));
 }
 
 __global__ void k_hash_kmers(const uint8_t *kmers, int k, uint64_t n, int hashfam, uint64_t *out)
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint8_t *km = kmers + i * (uint64_t)k;
-        uint64_t h;
-        if (hashfam == HF_TWOBIT) {
-            uint64_t f = 0, r = 0;
-            for (int j = 0; j < k; ++j) {
-                uint32_t x = (kmer_byte<false>(km, k, j) >> 1) & 3u;
-                x ^= ((x ^ (x >> 1)) & 1u) * 3u;
-                f = (f << 2) | x;
-                uint32_t y = (kmer_byte<true>(km, k, j) >> 1) & 3u;
-                y ^= ((y ^ (y >> 1)) & 1u) * 3u;
-                r = (r << 2) | y;
-            }
-            h = f < r ? f : r;
-        } else {
-            h = murmur_global<false>(km, k) ^ murmur_global<true>(km, k);
-        }
-        out[i] = h;
+        out[i] = kmer_hash_chars([&](int j) { return (uint32_t)km[j]; },
+                                 [&](int j) { return complement_char(km[k - 1 - j]); }, k, hashfam);
+    }
+}
+
+// hashes of the k-mers at (read, offset) positions of a packed batch: the annotated k-mers of filter and partition
+// never leave the device as text
+__global__ void k_hash_positions(const uint32_t *words, const uint64_t *woff, const uint32_t *ann_read, const uint32_t *ann_off,
+                                 uint64_t n, int k, int hashfam, uint64_t *out)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t *w = words + woff[ann_read[i]];
+        const uint32_t off = ann_off[i];
+        auto base = [&](uint32_t p) { return (w[p >> 4] >> (2u * (p & 15u))) & 3u; };
+        out[i] = kmer_hash_chars([&](int j) { return (0x54474341u >> (8u * base(off + (uint32_t)j))) & 0xffu; },                    // "ACGT"
+                                 [&](int j) { return (0x41434754u >> (8u * base(off + (uint32_t)(k - 1 - j)))) & 0xffu; },          // "TGCA"
+                                 k, hashfam);
     }
 }
 
@@ -243,6 +263,53 @@ extern "C" int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int b
     return KV_OK;
 }
 
+namespace {
+// grow-only device scratch of the point-query entry points, one per stream (hipMalloc + hipFree per call cost more
+// than the kernels they wrap when filter / simlike issue thousands of small queries)
+struct PointScratch { KvArena arena; std::mutex mu; };
+std::map<hipStream_t, PointScratch> g_point_scratch;
+std::mutex g_point_scratch_mu;
+PointScratch &point_scratch()
+{
+    std::lock_guard<std::mutex> lk(g_point_scratch_mu);
+    return g_point_scratch[kv_stream()];
+}
+inline size_t pad256(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace
+
+extern "C" int kv_hash_positions(const kv_reads *reads, int kind, int ksize, const uint32_t *ann_read, const uint32_t *ann_offset,
+                                 uint64_t n, uint64_t *hashes_out)
+{
+    KV_REQUIRE(reads && ((ann_read && ann_offset && hashes_out) || n == 0), KV_ERR_ARG, "kv_hash_positions: null argument");
+    KV_REQUIRE(ksize >= 1 && ksize <= KV_MAX_K, KV_ERR_ARG, "k=%d out of range", ksize);
+    const int fam = kv_hashfam_of(kind);
+    KV_REQUIRE(fam != HF_TWOBIT || ksize <= 32, KV_ERR_ARG, "graph sketches need k <= 32 (got %d)", ksize);
+    if (n == 0) return KV_OK;
+    for (uint64_t i = 0; i < n; ++i) {
+        KV_REQUIRE(ann_read[i] < reads->n_reads && (uint64_t)ann_offset[i] + (uint64_t)ksize <= reads->h_len[ann_read[i]], KV_ERR_ARG,
+                   "kv_hash_positions: annotation %llu (read %u, offset %u) does not lie inside its read", (unsigned long long)i,
+                   ann_read[i], ann_offset[i]);
+    }
+    PointScratch &ps = point_scratch();
+    std::lock_guard<std::mutex> lk(ps.mu);
+    hipStream_t st = kv_stream();
+    KV_HIP(ps.arena.need(2 * pad256(n * 4) + pad256(n * 8)));
+    uint32_t *d_r = (uint32_t *)ps.arena.p, *d_o = (uint32_t *)((char *)ps.arena.p + pad256(n * 4));
+    uint64_t *d_h = (uint64_t *)((char *)ps.arena.p + 2 * pad256(n * 4));
+    KV_HIP(hipMemcpyAsync(d_r, ann_read, n * 4, hipMemcpyHostToDevice, st));
+    KV_HIP(hipMemcpyAsync(d_o, ann_offset, n * 4, hipMemcpyHostToDevice, st));
+    {
+        KvProfScope prof("k_hash_positions");
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_hash_positions, dim3(grid), dim3(256), 0, st, (const uint32_t *)reads->d_words, (const uint64_t *)reads->d_woff,
+                           (const uint32_t *)d_r, (const uint32_t *)d_o, n, ksize, fam, d_h);
+    }
+    KV_HIP(hipGetLastError());
+    KV_HIP(hipMemcpyAsync(hashes_out, d_h, n * 8, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    return KV_OK;
+}
+
 extern "C" int kv_hash_kmers(int kind, const char *kmers, int k, uint64_t n, uint64_t *hashes_out)
 {
     KV_REQUIRE((kmers && hashes_out) || n == 0, KV_ERR_ARG, "kv_hash_kmers: null argument");
@@ -250,22 +317,21 @@ extern "C" int kv_hash_kmers(int kind, const char *kmers, int k, uint64_t n, uin
     const int fam = kv_hashfam_of(kind);
     KV_REQUIRE(fam != HF_TWOBIT || k <= 32, KV_ERR_ARG, "graph sketches need k <= 32 (got %d)", k);
     if (n == 0) return KV_OK;
-    uint8_t *d_km = nullptr;
-    uint64_t *d_h = nullptr;
-    KV_HIP(hipMalloc((void **)&d_km, n * (uint64_t)k));
-    hipError_t e = hipMalloc((void **)&d_h, n * 8);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_km, kmers, n * (uint64_t)k, hipMemcpyHostToDevice, kv_stream());
-    if (e == hipSuccess) {
+    PointScratch &ps = point_scratch();
+    std::lock_guard<std::mutex> lk(ps.mu);
+    hipStream_t st = kv_stream();
+    KV_HIP(ps.arena.need(pad256(n * (uint64_t)k) + pad256(n * 8)));
+    uint8_t *d_km = (uint8_t *)ps.arena.p;
+    uint64_t *d_h = (uint64_t *)((char *)ps.arena.p + pad256(n * (uint64_t)k));
+    KV_HIP(hipMemcpyAsync(d_km, kmers, n * (uint64_t)k, hipMemcpyHostToDevice, st));
+    {
         KvProfScope prof("k_hash_kmers");
         const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
-        hipLaunchKernelGGL(k_hash_kmers, dim3(grid), dim3(256), 0, kv_stream(), d_km, k, n, fam, d_h);
-        e = hipGetLastError();
+        hipLaunchKernelGGL(k_hash_kmers, dim3(grid), dim3(256), 0, st, (const uint8_t *)d_km, k, n, fam, d_h);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(hashes_out, d_h, n * 8, hipMemcpyDeviceToHost, kv_stream());
-    if (e == hipSuccess) e = hipStreamSynchronize(kv_stream());
-    (void)hipFree(d_km);
-    if (d_h) (void)hipFree(d_h);
-    KV_REQUIRE(e == hipSuccess, KV_ERR_HIP, "kv_hash_kmers failed: %s", hipGetErrorString(e));
+    KV_HIP(hipGetLastError());
+    KV_HIP(hipMemcpyAsync(hashes_out, d_h, n * 8, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
     return KV_OK;
 }
 
@@ -274,22 +340,21 @@ extern "C" int kv_get_hashes(kv_sketch *s, const uint64_t *hashes, uint64_t n, u
     KV_REQUIRE(s && ((hashes && counts_out) || n == 0), KV_ERR_ARG, "kv_get_hashes: null argument");
     if (n == 0) return KV_OK;
     std::lock_guard<std::mutex> lk(s->mu);
-    uint64_t *d_h = nullptr;
-    uint8_t *d_o = nullptr;
-    KV_HIP(hipMalloc((void **)&d_h, n * 8));
-    hipError_t e = hipMalloc((void **)&d_o, n);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_h, hashes, n * 8, hipMemcpyHostToDevice, kv_stream());
-    if (e == hipSuccess) {
+    PointScratch &ps = point_scratch();
+    std::lock_guard<std::mutex> slk(ps.mu);
+    hipStream_t st = kv_stream();
+    KV_HIP(ps.arena.need(pad256(n * 8) + pad256(n)));
+    uint64_t *d_h = (uint64_t *)ps.arena.p;
+    uint8_t *d_o = (uint8_t *)ps.arena.p + pad256(n * 8);
+    KV_HIP(hipMemcpyAsync(d_h, hashes, n * 8, hipMemcpyHostToDevice, st));
+    {
         KvProfScope prof("k_get_hashes");
         const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
-        hipLaunchKernelGGL(k_get_hashes, dim3(grid), dim3(256), 0, kv_stream(), (const SketchDev *)s->d_desc, d_h, n, d_o);
-        e = hipGetLastError();
+        hipLaunchKernelGGL(k_get_hashes, dim3(grid), dim3(256), 0, st, (const SketchDev *)s->d_desc, (const uint64_t *)d_h, n, d_o);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(counts_out, d_o, n, hipMemcpyDeviceToHost, kv_stream());
-    if (e == hipSuccess) e = hipStreamSynchronize(kv_stream());
-    (void)hipFree(d_h);
-    if (d_o) (void)hipFree(d_o);
-    KV_REQUIRE(e == hipSuccess, KV_ERR_HIP, "kv_get_hashes failed: %s", hipGetErrorString(e));
+    KV_HIP(hipGetLastError());
+    KV_HIP(hipMemcpyAsync(counts_out, d_o, n, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
     return KV_OK;
 }
 
@@ -299,27 +364,25 @@ extern "C" int kv_add_hashes(kv_sketch *s, const uint64_t *hashes, uint64_t n, u
     if (n == 0) return KV_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     s->version++;
-    uint64_t *d_h = nullptr;
-    uint8_t *d_o = nullptr;
-    KV_HIP(hipMalloc((void **)&d_h, n * 8));
-    hipError_t e = hipSuccess;
-    if (is_new_out) e = hipMalloc((void **)&d_o, n);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_h, hashes, n * 8, hipMemcpyHostToDevice, kv_stream());
-    if (e == hipSuccess) e = hipMemsetAsync(s->d_counters, 0, 2 * sizeof(uint64_t), kv_stream());
-    if (e == hipSuccess) {
+    PointScratch &ps = point_scratch();
+    std::lock_guard<std::mutex> slk(ps.mu);
+    hipStream_t st = kv_stream();
+    KV_HIP(ps.arena.need(pad256(n * 8) + pad256(n)));
+    uint64_t *d_h = (uint64_t *)ps.arena.p;
+    uint8_t *d_o = is_new_out ? (uint8_t *)ps.arena.p + pad256(n * 8) : nullptr;
+    KV_HIP(hipMemcpyAsync(d_h, hashes, n * 8, hipMemcpyHostToDevice, st));
+    KV_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(uint64_t), st));
+    {
         KvProfScope prof("k_add_hashes");
         const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
-        hipLaunchKernelGGL(k_add_hashes, dim3(grid), dim3(256), 0, kv_stream(), (const SketchDev *)s->d_desc, d_h, n, 1u, d_o,
+        hipLaunchKernelGGL(k_add_hashes, dim3(grid), dim3(256), 0, st, (const SketchDev *)s->d_desc, (const uint64_t *)d_h, n, 1u, d_o,
                            s->d_counters);
-        e = hipGetLastError();
     }
+    KV_HIP(hipGetLastError());
     uint64_t c[2] = {0, 0};
-    if (e == hipSuccess) e = hipMemcpyAsync(c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost, kv_stream());
-    if (e == hipSuccess && is_new_out) e = hipMemcpyAsync(is_new_out, d_o, n, hipMemcpyDeviceToHost, kv_stream());
-    if (e == hipSuccess) e = hipStreamSynchronize(kv_stream());
-    (void)hipFree(d_h);
-    if (d_o) (void)hipFree(d_o);
-    KV_REQUIRE(e == hipSuccess, KV_ERR_HIP, "kv_add_hashes failed: %s", hipGetErrorString(e));
+    KV_HIP(hipMemcpyAsync(c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost, st));
+    if (is_new_out) KV_HIP(hipMemcpyAsync(is_new_out, d_o, n, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
     s->n_unique += c[1];
     s->occ_dirty = true;
     return KV_OK;

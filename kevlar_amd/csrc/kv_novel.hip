@@ -137,7 +137,7 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_mark(ReadsDev rd, Nov
             const bool interesting = p.screen > 0 ? novel_test_screen(p, cur.h, discard)
                                                   : novel_test_fast(ns, p, cur.h, cur.slot, cur.cached);
             const uint32_t gread = read0 + cur.r;
-            if (discard) p.disc_flag[gread] = 1;   // several k-mers may flag one read: plain store
+            if (discard) atomicMin(&p.disc_first[gread], sh.seg_start + cur.i);   // the reference stops reading the read there
             if (interesting) {
                 const uint64_t bit = (uint64_t)gread * p.mask_stride + sh.seg_start + cur.i;
                 atomicOr(&p.mask[bit >> 5], 1u << (bit & 31));
@@ -483,7 +483,7 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         *out = nullptr;
         return KV_ERR_CAPACITY;
     }
-    const size_t b_mask = up256(mask_words * 4), b_flags = p.screen > 0 ? up256(reads->n_reads) : 0;
+    const size_t b_mask = up256(mask_words * 4), b_flags = p.screen > 0 ? up256(reads->n_reads * 4) : 0;
     const size_t b_tcount = up256((uint64_t)reads->n_tiles * 4), b_tbase = up256(((uint64_t)reads->n_tiles + 1) * 8);
     e = arenas->work.need(b_mask + b_flags + b_tcount + b_tbase + 256);
     unsigned char *wp = (unsigned char *)arenas->work.p;
@@ -498,8 +498,8 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         wp += b_mask;
     }
     if (e == hipSuccess && p.screen > 0) {
-        p.disc_flag = (uint8_t *)wp;
-        e = hipMemsetAsync(p.disc_flag, 0, reads->n_reads, st);
+        p.disc_first = (uint32_t *)wp;
+        e = hipMemsetAsync(p.disc_first, 0xFF, reads->n_reads * 4, st);
     }
     wp += b_flags;
     p.tile_count = (uint32_t *)wp; wp += b_tcount;
@@ -559,11 +559,12 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         if (e == hipSuccess) e = hipMemcpyAsync(hits->abund.data(), p.hit_abund, nhits * (uint64_t)S, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
-    if (e == hipSuccess && p.disc_flag) {
-        std::vector<uint8_t> flags(reads->n_reads);
-        e = hipMemcpy(flags.data(), p.disc_flag, reads->n_reads, hipMemcpyDeviceToHost);
+    std::vector<uint32_t> first_trip;
+    if (e == hipSuccess && p.disc_first) {
+        first_trip.resize(reads->n_reads);
+        e = hipMemcpy(first_trip.data(), p.disc_first, reads->n_reads * 4, hipMemcpyDeviceToHost);
         for (uint64_t i = 0; i < reads->n_reads; ++i)
-            if (flags[i]) hits->discarded.push_back((uint32_t)i);
+            if (first_trip[i] != 0xffffffffu) hits->discarded.push_back((uint32_t)i);
     }
     if (e != hipSuccess) {
         delete hits;
@@ -571,12 +572,17 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         kv_set_error("kv_novel_scan failed: %s", hipGetErrorString(e));
         return KV_ERR_HIP;
     }
-    // a read dropped by the abundance screen loses all of its hits (novel.py:152-154,164)
+    // a read dropped by the abundance screen loses all of its hits (novel.py:152-154,164); the interesting k-mers in
+    // front of the k-mer that tripped the screen had already been tallied by the reference's loop (novel.py:160-162),
+    // so they are kept aside for the "unique novel kmers" figure
     if (!hits->discarded.empty()) {
-        const std::vector<uint32_t> &disc = hits->discarded;
         uint64_t w = 0;
         for (uint64_t i = 0; i < hits->read.size(); ++i) {
-            if (std::binary_search(disc.begin(), disc.end(), hits->read[i])) continue;
+            const uint32_t trip = first_trip[hits->read[i]];
+            if (trip != 0xffffffffu) {
+                if (hits->offset[i] < trip) { hits->shadow_read.push_back(hits->read[i]); hits->shadow_offset.push_back(hits->offset[i]); }
+                continue;
+            }
             hits->read[w] = hits->read[i];
             hits->offset[w] = hits->offset[i];
             if (w != i) memmove(&hits->abund[w * (uint64_t)S], &hits->abund[i * (uint64_t)S], (size_t)S);
@@ -584,6 +590,15 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         }
         hits->read.n = w; hits->offset.n = w; hits->abund.n = w * (uint64_t)S;   // shrink in place
     }
+    return KV_OK;
+}
+
+extern "C" int kv_hits_shadow(const kv_hits *h, const uint32_t **read, const uint32_t **offset, uint64_t *n)
+{
+    KV_REQUIRE(h && n, KV_ERR_ARG, "kv_hits_shadow: null argument");
+    *n = h->shadow_read.size();
+    if (read) *read = h->shadow_read.data();
+    if (offset) *offset = h->shadow_offset.data();
     return KV_OK;
 }
 

@@ -11,7 +11,7 @@ struct NovelParams {
     int band_mode, nbands, band;
     uint64_t band_lo, band_hi;
     uint64_t first_read;
-    uint8_t *disc_flag;     // per read: dropped by the abundance screen (NULL when screen is off)
+    uint32_t *disc_first;   // per read: offset of its first k-mer that trips the abundance screen, else ~0 (NULL: screen off)
     uint32_t *mask;         // bit (read * mask_stride + offset)
     uint64_t mask_stride;
     uint32_t *tile_count;   // hits per tile

@@ -1,14 +1,13 @@
-"""`kevlar dist` driver (the reference's kevlar/dist.py:25-125): k-mer abundance distribution of a
-sample over the k-mers of a mask (e.g. single-copy exonic k-mers) -> mean and standard deviation of
-k-mer coverage, which `simlike --mu/--sigma` consumes.
+"""`kevlar dist`: how deeply was a sample sequenced?  The abundance distribution of its k-mers over a mask of
+single-copy k-mers (exons of a reference), and from it the mean and standard deviation of k-mer coverage that
+`kevlar simlike --mu/--sigma` consumes (kevlar/dist.py:25-125).
 
-Two passes over the reads, both on the GPU: count only masked k-mers into a Counttable
-(consume_seqfile_with_mask, threshold 1, consume_masked), then `abundance_distribution` with a
-tracking Nodetable so that every k-mer contributes once.  The reference fans each file out over T
-Python threads sharing one parser; here one pass per file feeds the device and `--threads` is
-accepted for command-line compatibility."""
+Both passes over the reads run on the device: the masked count (only k-mers the mask holds are counted) and khmer's
+abundance_distribution with a tracking Nodetable so that every distinct k-mer contributes once.  The histogram is a
+numpy vector end to end; `--threads` is accepted for command-line compatibility (the device takes whole batches)."""
 import json
-import math
+
+import numpy as np
 
 import kevlar_amd
 from kevlar_amd import khmer
@@ -18,55 +17,60 @@ class KevlarZeroAbundanceDistError(ValueError):
     pass
 
 
+def _each_file(infiles):
+    for path in infiles:
+        kevlar_amd.plog('    -', path)
+        yield khmer.ReadParser(path)
+
+
 def count_first_pass(infiles, counts, mask, nthreads=1):
+    """count, into `counts`, the k-mers of the files that `mask` contains"""
     kevlar_amd.plog('[kevlar::dist]', 'Processing input with {:d} threads'.format(nthreads))
-    for filename in infiles:
-        kevlar_amd.plog('    -', filename)
-        counts.consume_seqfile_with_mask(khmer.ReadParser(filename), mask, threshold=1, consume_masked=True)
+    for parser in _each_file(infiles):
+        counts.consume_seqfile_with_mask(parser, mask, threshold=1, consume_masked=True)
     kevlar_amd.plog('[kevlar::dist] Done processing input!')
 
 
+def _histogram(infiles, counts):
+    """hist[c] = distinct k-mers of the files whose count in `counts` is c (0 <= c < 65536)"""
+    seen = khmer.Nodetable(counts.ksize(), 1, 1, primes=counts.hashsizes())
+    hist = np.zeros(65536, dtype=np.int64)
+    for parser in _each_file(infiles):
+        hist += np.asarray(counts.abundance_distribution(parser, seen), dtype=np.int64)
+    return hist
+
+
 def count_second_pass(infiles, counts, nthreads=1):
+    """{abundance: number of distinct k-mers with that abundance}, abundance 0 left out"""
     kevlar_amd.plog('[kevlar::dist] Second pass over the data')
-    tracking = khmer.Nodetable(counts.ksize(), 1, 1, primes=counts.hashsizes())
-    abundance = {}
-    for filename in infiles:
-        kevlar_amd.plog('    -', filename)
-        abund = counts.abundance_distribution(khmer.ReadParser(filename), tracking)
-        for i, count in enumerate(abund):
-            if i > 0 and count > 0:
-                abundance[i] = abundance.get(i, 0) + count
+    hist = _histogram(infiles, counts)
     kevlar_amd.plog('[kevlar::dist] Done second pass over input!')
-    return abundance
+    present = np.flatnonzero(hist[1:]) + 1
+    return dict(zip(present.tolist(), hist[present].tolist()))
 
 
 def weighted_mean_std_dev(values, weights):
-    total = float(sum(weights))
-    mu = sum(v * w for v, w in zip(values, weights)) / total
-    sigma = math.sqrt(sum(w * (v - mu) ** 2 for v, w in zip(values, weights)) / total)
-    return mu, sigma
+    v, w = np.asarray(values, dtype=np.float64), np.asarray(weights, dtype=np.float64)
+    mu = float(np.average(v, weights=w))
+    return mu, float(np.sqrt(np.average((v - mu) ** 2, weights=w)))
 
 
 def calc_mu_sigma(abundance):
-    total = sum(abundance.values())
-    if total == 0:
+    if sum(abundance.values()) == 0:
         raise KevlarZeroAbundanceDistError('all k-mer abundances are 0, please check input files')
-    return weighted_mean_std_dev(list(abundance.keys()), list(abundance.values()))
+    return weighted_mean_std_dev(list(abundance), list(abundance.values()))
 
 
 def compute_dist(abundance):
-    """Rows of the distribution table: Abundance, Count, CumulativeCount, CumulativeFraction (a pandas
-    DataFrame of floats, as the reference builds it row by row)."""
+    """The distribution as a table: Abundance, Count, CumulativeCount, CumulativeFraction (floats, as the reference's
+    row-by-row DataFrame has them)."""
     import pandas
-    total = sum(abundance.values())
-    rows = []
-    cuml = 0
-    for abund, count in sorted(abundance.items()):
-        assert count > 0, (abund, count)
-        cuml += count
-        rows.append({'Abundance': float(abund), 'Count': float(count), 'CumulativeCount': float(cuml),
-                     'CumulativeFraction': cuml / total})
-    return pandas.DataFrame(rows, columns=['Abundance', 'Count', 'CumulativeCount', 'CumulativeFraction'])
+    levels = np.array(sorted(abundance), dtype=np.float64)
+    counts = np.array([abundance[int(a)] for a in levels], dtype=np.float64)
+    assert (counts > 0).all(), abundance
+    running = np.cumsum(counts)
+    return pandas.DataFrame({'Abundance': levels, 'Count': counts, 'CumulativeCount': running,
+                             'CumulativeFraction': running / counts.sum()})
 
 
 def dist(infiles, mask, ksize=31, memory=1e6, threads=1):
@@ -74,34 +78,35 @@ def dist(infiles, mask, ksize=31, memory=1e6, threads=1):
     count_first_pass(infiles, counts, mask, nthreads=threads)
     abundance = count_second_pass(infiles, counts, nthreads=threads)
     mu, sigma = calc_mu_sigma(abundance)
-    data = compute_dist(abundance)
-    return mu, sigma, data
+    return mu, sigma, compute_dist(abundance)
+
+
+def _plot(data, mu, sigma, path, xlim):
+    try:
+        import matplotlib
+        matplotlib.use('Agg')
+        from matplotlib import pyplot
+    except ImportError:
+        raise RuntimeError('--plot needs matplotlib, which is not installed')
+    matplotlib.rcParams['figure.figsize'] = [12, 6]
+    pyplot.plot(data['Abundance'], data['Count'], color='blue')
+    for x, colour, style in ((mu, 'blue', '--'), (mu - sigma, 'red', ':'), (mu + sigma, 'red', ':')):
+        pyplot.axvline(x=x, color=colour, linestyle=style)
+    pyplot.xlim(xlim)
+    pyplot.xlabel('K-mer abundance')
+    pyplot.ylabel('Frequency')
+    pyplot.savefig(path, dpi=300)
 
 
 def main(args):
-    mask = khmer.Nodetable.load(args.mask)
-    mu, sigma, data = dist(args.infiles, mask, ksize=args.ksize, memory=args.memory, threads=args.threads)
-    out = {'mu': mu, 'sigma': sigma}
+    mu, sigma, data = dist(args.infiles, khmer.Nodetable.load(args.mask), ksize=args.ksize, memory=args.memory, threads=args.threads)
+    summary = json.dumps({'mu': mu, 'sigma': sigma})
     if getattr(args, 'out', None):
-        with open(args.out, 'w') as fh:
-            print(json.dumps(out), file=fh)
+        with open(args.out, 'w') as sink:
+            print(summary, file=sink)
     else:
-        print(json.dumps(out))
+        print(summary)
     if args.tsv:
         data.to_csv(args.tsv, sep='\t', index=False)
     if args.plot:
-        try:
-            import matplotlib
-            matplotlib.use('Agg')
-            from matplotlib import pyplot as plt
-        except ImportError:
-            raise RuntimeError('--plot needs matplotlib, which is not installed')
-        matplotlib.rcParams['figure.figsize'] = [12, 6]
-        plt.plot(data['Abundance'], data['Count'], color='blue')
-        plt.axvline(x=mu, color='blue', linestyle='--')
-        plt.axvline(x=mu - sigma, color='red', linestyle=':')
-        plt.axvline(x=mu + sigma, color='red', linestyle=':')
-        plt.xlim(args.plot_xlim)
-        plt.xlabel('K-mer abundance')
-        plt.ylabel('Frequency')
-        plt.savefig(args.plot, dpi=300)
+        _plot(data, mu, sigma, args.plot, args.plot_xlim)

@@ -1,106 +1,95 @@
-"""`kevlar filter` driver (the reference's kevlar/filter.py:15-107).
+"""`kevlar filter`: second opinion on the interesting k-mers of `novel` (kevlar/filter.py:15-107).  Every annotated
+k-mer occurrence that the mask (reference genome, contaminants) does not contain is counted again into a small fresh
+Counttable -- one whose false positive rate is far below that of the big per-sample sketches -- and annotations whose
+recount falls below the case threshold, or whose control abundances exceed theirs, are dropped; reads left without
+annotations disappear.
 
-Two passes over an augmented FASTQ: re-count every annotated k-mer that the mask does not
-contain into a fresh Counttable, then re-threshold.  The k-mer instances (<= ~1e6) are hashed,
-mask-tested, added and queried as device batches (kv_hash_kmers / kv_get_hashes /
-kv_add_hashes) instead of one Python->sketch call per k-mer.
-"""
+The annotated stream is held as an AnnotatedReads (kevlar_amd/annotated.py): k-mers are hashed on the device from
+their (read, offset) positions, masked / added / looked up as whole arrays, and the thresholds are numpy comparisons."""
+import numpy as np
+
 import kevlar_amd
 from kevlar_amd import khmer
-from kevlar_amd.sequence import KmerOfInterest
+from kevlar_amd.annotated import AnnotatedReads
+from kevlar_amd.sketch import KevlarUnsuitableFPRError, estimate_fpr
+
+_TICK = '[kevlar::filter]     processed {counter} reads'
 
 
-def first_pass(reads, mask, memory, timer):
-    """Returns (counts sketch or None, list of records, per-annotation recount array)."""
-    kevlar_amd.plog('[kevlar::filter] First pass: re-counting k-mers')
-    timer.start('firstpass')
-    progress = kevlar_amd.ProgressIndicator('[kevlar::filter]     processed {counter} reads',
-                                            interval=1e5, breaks=[1e6, 1e7])
-    records, kmers = [], []
-    n = 0
-    for n, read in enumerate(reads, 1):
-        progress.update()
-        if read is None:
-            continue
-        records.append(read)
-        for ikmer in read.annotations:
-            kmers.append(read.ikmerseq(ikmer))
-    counts, hashes = None, None
-    if kmers:
-        ksize = len(kmers[0])
-        counts = khmer.Counttable(ksize, memory / 4, 4)
-        hashes = counts.hash_kmers(kmers)
-        keep = hashes
-        if mask:
-            mhashes = hashes if mask._kind < 3 else mask.hash_kmers(kmers)   # mask hashes with its own function
-            keep = hashes[mask.get_hashes(mhashes) == 0]   # `if mask.get(ikseq) > 0: continue`
-        counts.add_hashes(keep)
-    elapsed = timer.stop('firstpass')
-    message = 'First pass complete! Processed {:d} reads in {:.2f} seconds!'.format(n, elapsed)
-    kevlar_amd.plog('[kevlar::filter]', message)
-    return counts, records, hashes
+class Recount(object):
+    """The two passes over one annotated stream.  After recount(): `table` holds the fresh counts (None if the
+    stream carries no annotation), `nreads` the reads seen; survivors() yields what passes the thresholds."""
 
+    def __init__(self, readstream, mask=None, memory=1e6):
+        self.mask, self.memory = mask, memory
+        self.nreads = 0
+        self._stream = readstream
+        self.annotated = self.table = self._hashes = None
 
-def check_fpr(counts, maxfpr):
-    fpr = kevlar_amd.sketch.estimate_fpr(counts)
-    message = 'FPR for re-computed k-mer counts: {:1.3f}'.format(fpr)
-    kevlar_amd.plog('[kevlar::filter]', message)
-    if fpr > maxfpr:
-        message += 'FPR too high, bailing out!!!'
-        raise kevlar_amd.sketch.KevlarUnsuitableFPRError(message)
+    def _counted(self, stream):
+        ticker = kevlar_amd.ProgressIndicator(_TICK, interval=1e5, breaks=[1e6, 1e7])
+        for read in stream:
+            self.nreads += 1
+            ticker.update()
+            yield read
 
+    def recount(self):
+        self.annotated = AnnotatedReads(self._counted(self._stream))
+        if not len(self.annotated):
+            return
+        self.table = khmer.Counttable(self.annotated.ksize, self.memory / 4, 4)
+        self._hashes = self.annotated.hashes(self.table)
+        fresh = self._hashes
+        if self.mask:
+            # a mask of another hash family (a *graph sketch) has to hash the k-mers itself
+            seen_by_mask = self.mask.get_hashes(fresh if self.mask._kind < 3 else self.annotated.hashes(self.mask))
+            fresh = fresh[seen_by_mask == 0]
+        self.table.add_hashes(fresh)
 
-def second_pass(reads, counts, casemin, ctrlmax, timer, hashes=None):
-    kevlar_amd.plog('[kevlar::filter] Second pass: discarding k-mers/reads')
-    timer.start('secondpass')
-    progress = kevlar_amd.ProgressIndicator('[kevlar::filter]     processed {counter} reads',
-                                            interval=1e5, breaks=[1e6, 1e7])
-    reads = list(reads)
-    if hashes is None:
-        kmers = [read.ikmerseq(ikmer) for read in reads for ikmer in read.annotations]
-        hashes = counts.hash_kmers(kmers)
-    recount = counts.get_hashes(hashes) if len(hashes) else []
-    kept = 0
-    cursor = 0
-    for read in reads:
-        progress.update()
-        validated = []
-        for ikmer in read.annotations:
-            newcount = int(recount[cursor])
-            cursor += 1
-            if any(a > ctrlmax for a in ikmer.abund[1:]):
-                continue
-            if newcount < casemin:
-                continue
-            newabund = tuple([newcount] + list(ikmer.abund[1:]))
-            validated.append(KmerOfInterest(ikmer.ksize, ikmer.offset, newabund))
-        if not validated:
-            continue
-        read.annotations = validated
-        yield read
-        kept += 1
-    elapsed = timer.stop('secondpass')
-    message = 'Second pass complete! Validated {:d} reads in {:.2f} seconds!'.format(kept, elapsed)
-    kevlar_amd.plog('[kevlar::filter]', message)
+    def survivors(self, casemin, ctrlmax):
+        """reads that keep an annotation with recount >= casemin and every control abundance <= ctrlmax; the kept
+        annotations carry the recount as their case abundance"""
+        again = self.table.get_hashes(self._hashes).astype(np.int64)
+        verdict = again >= casemin
+        if self.annotated.nsamples > 1:
+            verdict &= (self.annotated.abund[:, 1:] <= ctrlmax).all(axis=1)
+        ticker = kevlar_amd.ProgressIndicator(_TICK, interval=1e5, breaks=[1e6, 1e7])
+        for read in self.annotated.select(verdict, case_abund=again):
+            ticker.update()
+            yield read
 
 
 def filter(readfile, mask=None, memory=1e6, maxfpr=0.01, casemin=6, ctrlmax=1):
+    """Generator over the validated reads of the augmented FASTQ `readfile`."""
     timer = kevlar_amd.Timer()
     timer.start()
-    reader = kevlar_amd.parse_augmented_fastx(kevlar_amd.open(readfile, 'r'))
-    counts, records, hashes = first_pass(reader, mask, memory, timer)
-    if counts is not None:
-        check_fpr(counts, maxfpr)
-        for read in second_pass(records, counts, casemin, ctrlmax, timer, hashes=hashes):
+    work = Recount(kevlar_amd.parse_augmented_fastx(kevlar_amd.open(readfile, 'r')), mask, memory)
+
+    kevlar_amd.plog('[kevlar::filter] First pass: re-counting k-mers')
+    timer.start('firstpass')
+    work.recount()
+    kevlar_amd.plog('[kevlar::filter]', 'First pass complete! Processed {:d} reads in {:.2f} seconds!'.format(
+        work.nreads, timer.stop('firstpass')))
+
+    if work.table is not None:
+        fpr = estimate_fpr(work.table)
+        verdict = 'FPR for re-computed k-mer counts: {:1.3f}'.format(fpr)
+        kevlar_amd.plog('[kevlar::filter]', verdict)
+        if fpr > maxfpr:
+            raise KevlarUnsuitableFPRError(verdict + 'FPR too high, bailing out!!!')
+        kevlar_amd.plog('[kevlar::filter] Second pass: discarding k-mers/reads')
+        timer.start('secondpass')
+        nkept = 0
+        for nkept, read in enumerate(work.survivors(casemin, ctrlmax), 1):
             yield read
-    total = timer.stop()
-    kevlar_amd.plog('[kevlar::filter]', 'Total time: {:.2f} seconds'.format(total))
+        kevlar_amd.plog('[kevlar::filter]', 'Second pass complete! Validated {:d} reads in {:.2f} seconds!'.format(
+            nkept, timer.stop('secondpass')))
+    work.annotated.close()
+    kevlar_amd.plog('[kevlar::filter]', 'Total time: {:.2f} seconds'.format(timer.stop()))
 
 
 def main(args):
-    mask = kevlar_amd.sketch.load(args.mask) if args.mask else None
-    outstream = kevlar_amd.open(args.out, 'w')
-    filterstream = filter(args.augfastq, mask=mask, memory=args.memory, maxfpr=args.max_fpr,
-                          casemin=args.case_min, ctrlmax=args.ctrl_max)
-    for record in filterstream:
-        kevlar_amd.print_augmented_fastx(record, outstream)
+    sink = kevlar_amd.open(args.out, 'w')
+    validated = filter(args.augfastq, mask=kevlar_amd.sketch.load(args.mask) if args.mask else None, memory=args.memory,
+                       maxfpr=args.max_fpr, casemin=args.case_min, ctrlmax=args.ctrl_max)
+    sink.write(''.join(map(kevlar_amd.sequence.format_augmented_fastx, validated)))

@@ -339,6 +339,12 @@ class ReadBatch(object):
         check(_lib.load().kv_reads_num_kmers(self._h, ksize, ctypes.byref(n)))
         return n.value
 
+    def device_bytes(self):
+        """HBM the packed batch occupies, to within rounding: 2 bits per base plus 17 bytes of index per read."""
+        nreads, nbases = ctypes.c_uint64(), ctypes.c_uint64()
+        check(_lib.load().kv_reads_count(self._h, ctypes.byref(nreads), ctypes.byref(nbases)))
+        return nbases.value // 4 + 17 * nreads.value
+
     def close(self):
         h, self._h = getattr(self, '_h', None), None
         if h:
@@ -368,6 +374,7 @@ class _Sketch(object):
         self._lock = threading.Lock()
         self._exact = None      # when tracking: list of (ReadBatch, filter-key) seen so far
         self._exact_cache = None
+        self._exact_bytes, self._exact_budget = 0, 4 << 30
         if _handle is not None:
             self._h = _handle
             return
@@ -443,11 +450,13 @@ class _Sketch(object):
             return self._exact_cache
         return int(self._info().n_unique)
 
-    def track_exact_unique(self, on=True):
-        """Keep the packed read batches of subsequent consume_seqfile* calls in HBM so that
+    def track_exact_unique(self, on=True, budget_bytes=4 << 30):
+        """Keep the packed read batches of subsequent consume_seqfile* calls in HBM (up to budget_bytes) so that
         n_unique_kmers() can be re-derived exactly (single-thread semantics)."""
         self._exact = [] if on else None
         self._exact_cache = None
+        self._exact_bytes = 0
+        self._exact_budget = int(budget_bytes)
 
     def table_bytes(self, i):
         """Raw on-disk form of table i (tests compare this against the oracle)."""
@@ -498,6 +507,16 @@ class _Sketch(object):
             return []
         return [int(c) for c in self.get_hashes(self.hash_kmers(self.get_kmers(seq)))]
 
+    def hash_positions(self, batch, ann_read, ann_offset):
+        """Hashes of the k-mers at (read, offset) positions of a packed batch (kv_hash_positions): no k-mer text."""
+        ann_read = np.ascontiguousarray(ann_read, dtype=np.uint32)
+        ann_offset = np.ascontiguousarray(ann_offset, dtype=np.uint32)
+        out = np.empty(len(ann_read), dtype=np.uint64)
+        if len(out):
+            check(_lib.load().kv_hash_positions(batch._h, self._kind, self.ksize(), _u32p(ann_read), _u32p(ann_offset),
+                                                len(out), _u64p(out)))
+        return out
+
     def get_kmer_hashes(self, seq):
         return [int(h) for h in self.hash_kmers(self.get_kmers(seq))]
 
@@ -536,12 +555,21 @@ class _Sketch(object):
         if self._exact is not None:
             with self._lock:
                 key = (nbands or 0, band or 0, mask, int(threshold), bool(consume_masked))
+                self._exact_bytes += batch.device_bytes()
                 if self._exact and self._exact[0][1] != key:
                     self._exact = None   # mixed settings: exact re-derivation not defined
+                elif self._exact_bytes > self._exact_budget:
+                    # the exact figure needs every batch of the sample resident next to the sketches; past the
+                    # budget the batches are let go and the linear-counting estimate of kv_consume is reported
+                    self._exact = None
                 else:
                     self._exact.append((batch, key))
                     self._exact_cache = None
         return n.value
+
+    def retains(self, batch):
+        """True if `batch` is being kept for the exact distinct-k-mer figure (then the caller must not close it)."""
+        return self._exact is not None and any(b is batch for b, _ in self._exact)
 
     def consume_hashes(self, hashes_ptr, n, stride_words=1):
         """Count n hashes resident in HBM (device address; element i at word i * stride_words)."""
@@ -563,6 +591,8 @@ class _Sketch(object):
                 break
             nkmers += self.consume_batch(batch, nbands, band, mask, threshold, consume_masked)
             nreads += batch.n_reads
+            if not self.retains(batch):
+                batch.close()
         return nreads, nkmers
 
     def consume_seqfile(self, parser):
@@ -665,7 +695,22 @@ def _hits_arrays(hits, S):
     offs = view(po, (n.value,), np.uint32)
     abund = view(pa, (n.value, S), np.uint8)
     disc = np.array(np.ctypeslib.as_array(pd, shape=(nd.value,)), dtype=np.uint32) if nd.value else np.empty(0, dtype=np.uint32)
+    disc = disc.view(_Discarded)
+    disc.shadow = (np.empty(0, dtype=np.uint32), np.empty(0, dtype=np.uint32))
+    if nd.value:
+        ps, pso, ns = _lib.u32p(), _lib.u32p(), ctypes.c_uint64()
+        check(lib.kv_hits_shadow(hits, ctypes.byref(ps), ctypes.byref(pso), ctypes.byref(ns)))
+        if ns.value:
+            disc.shadow = (np.array(np.ctypeslib.as_array(ps, shape=(ns.value,)), dtype=np.uint32),
+                           np.array(np.ctypeslib.as_array(pso, shape=(ns.value,)), dtype=np.uint32))
     return reads, offs, abund, disc
+
+
+class _Discarded(np.ndarray):
+    """indices of the reads the abundance screen dropped; .shadow = (read, offset) of their interesting k-mers in
+    front of the k-mer that tripped the screen (the reference tallies those as unique novel k-mers before it drops
+    the read, kevlar/novel.py:152-164)"""
+    shadow = None
 
 
 # ----------------------------------------------------------------------------------------

@@ -137,6 +137,22 @@ class ReadGraph(object):
         else:
             self._labels = result
 
+    def edge_list(self):
+        """Pairs of node names that share at least one retained interesting k-mer (relaxed mode), sorted; for
+        `partition --gml`.  Enumerated on the host: the device path only ever needs their number."""
+        from itertools import combinations
+        holders = {}
+        for record in self._reads:
+            for ikmer in record.annotations:
+                holders.setdefault(kevlar_amd.revcommin(record.ikmerseq(ikmer)), set()).add(record.name)
+        pairs = set()
+        for names in holders.values():
+            n = len(names)
+            if (self._minabund and n < self._minabund) or (self._maxabund and n > self._maxabund):
+                continue
+            pairs.update(combinations(sorted(names), 2))
+        return sorted(pairs)
+
     def connected_components(self):
         """List of sets of node names."""
         if self._labels is None:

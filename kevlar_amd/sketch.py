@@ -1,23 +1,25 @@
-"""Sketch convenience functions (the reference's kevlar/sketch.py:14-170) over the HIP sketches."""
+"""Choosing, allocating, loading and vetting sketches for the drivers.
+
+One registry describes the six sketch kinds (what they store, how they hash, their file extensions); everything the
+drivers need -- class by flags, loader by file name, the extensions `count` appends -- is read off it.  Names,
+arguments, messages and exceptions follow the reference's kevlar.sketch (call sites: kevlar/count.py:29-35,91-95,
+kevlar/novel.py:62-93, kevlar/filter.py:100)."""
+from collections import namedtuple
+import os
+
 import kevlar_amd
 from kevlar_amd import khmer
 
-sketch_loader_by_filename_extension = {
-    '.nt': khmer.Nodetable.load, '.ng': khmer.Nodegraph.load,
-    '.ct': khmer.Counttable.load, '.cg': khmer.Countgraph.load,
-    '.sct': khmer.SmallCounttable.load, '.scg': khmer.SmallCountgraph.load,
-    '.nodetable': khmer.Nodetable.load, '.nodegraph': khmer.Nodegraph.load,
-    '.counttable': khmer.Counttable.load, '.countgraph': khmer.Countgraph.load,
-    '.smallcounttable': khmer.SmallCounttable.load, '.smallcountgraph': khmer.SmallCountgraph.load,
-}
-
-# (count, graph, smallcount) -> extensions
-_EXTENSIONS = {
-    (True, True, True): ('.scg', '.smallcountgraph'), (True, True, False): ('.cg', '.countgraph'),
-    (True, False, True): ('.sct', '.smallcounttable'), (True, False, False): ('.ct', '.counttable'),
-    (False, True, True): ('.ng', '.nodegraph'), (False, True, False): ('.ng', '.nodegraph'),
-    (False, False, True): ('.nt', '.nodetable'), (False, False, False): ('.nt', '.nodetable'),
-}
+_Kind = namedtuple('_Kind', 'cls counts graph small short long')
+_KINDS = (
+    _Kind(khmer.Nodetable, False, False, False, '.nt', '.nodetable'),
+    _Kind(khmer.Nodegraph, False, True, False, '.ng', '.nodegraph'),
+    _Kind(khmer.Counttable, True, False, False, '.ct', '.counttable'),
+    _Kind(khmer.Countgraph, True, True, False, '.cg', '.countgraph'),
+    _Kind(khmer.SmallCounttable, True, False, True, '.sct', '.smallcounttable'),
+    _Kind(khmer.SmallCountgraph, True, True, True, '.scg', '.smallcountgraph'),
+)
+sketch_loader_by_filename_extension = {ext: kind.cls.load for kind in _KINDS for ext in (kind.short, kind.long)}
 
 
 class KevlarSketchTypeError(ValueError):
@@ -28,60 +30,58 @@ class KevlarUnsuitableFPRError(SystemExit):
     pass
 
 
-def estimate_fpr(sketch):
-    """(occupied bins of table 0 / smallest table) ** number of tables."""
-    sizes = sketch.hashsizes()
-    return (float(sketch.n_occupied()) / min(sizes)) ** float(len(sizes))
-
-
-def load(filename):
-    """Pick the sketch class from the file extension and load it into HBM."""
-    if not filename.endswith(tuple(sketch_loader_by_filename_extension)):
-        raise KevlarSketchTypeError('unable to determine sketch type from filename ' + filename)
-    ext = '.' + filename.split('.')[-1]
-    return sketch_loader_by_filename_extension[ext](filename)
+def _kind_for(count, graph, smallcount):
+    """presence/absence sketches have no small variant: the flag is ignored for them"""
+    small = bool(smallcount) and bool(count)
+    return next(kind for kind in _KINDS if (kind.counts, kind.graph, kind.small) == (bool(count), bool(graph), small))
 
 
 def get_extension(count=False, graph=False, smallcount=False):
-    return _EXTENSIONS[(bool(count), bool(graph), bool(smallcount))]
+    kind = _kind_for(count, graph, smallcount)
+    return kind.short, kind.long
 
 
 def allocate(ksize, target_tablesize, num_tables=4, count=False, graph=False, smallcount=False):
-    if count:
-        if graph:
-            cls = khmer.SmallCountgraph if smallcount else khmer.Countgraph
-        else:
-            cls = khmer.SmallCounttable if smallcount else khmer.Counttable
-    else:
-        cls = khmer.Nodegraph if graph else khmer.Nodetable
-    return cls(ksize, target_tablesize, num_tables)
+    return _kind_for(count, graph, smallcount).cls(ksize, target_tablesize, num_tables)
 
 
-def autoload(infile, count=True, graph=False, ksize=31, table_size=1e4, num_tables=4,
-             num_bands=None, band=None):
-    """Load a saved sketch by extension, else count the file as FASTA/FASTQ."""
-    try:
+def load(filename):
+    """A saved sketch, its kind taken from the file extension, resident in HBM."""
+    loader = sketch_loader_by_filename_extension.get(os.path.splitext(filename)[1])
+    if loader is None:
+        raise KevlarSketchTypeError('unable to determine sketch type from filename ' + filename)
+    return loader(filename)
+
+
+def estimate_fpr(sketch):
+    """Chance that a k-mer never added reads as present: the fill of table 0 (measured against the smallest
+    table) to the power of the number of tables."""
+    sizes = sketch.hashsizes()
+    return (sketch.n_occupied() / min(sizes)) ** len(sizes)
+
+
+def autoload(infile, count=True, graph=False, ksize=31, table_size=1e4, num_tables=4, num_bands=None, band=None):
+    """`infile` is either a saved sketch (by extension) or sequences to count into a fresh one."""
+    if os.path.splitext(infile)[1] in sketch_loader_by_filename_extension:
         return load(infile)
-    except KevlarSketchTypeError:
-        sketch = allocate(ksize, table_size, num_tables, count=count, graph=graph, smallcount=False)
-        if num_bands:
-            assert band >= 0 and band < num_bands
-            sketch.consume_seqfile_banding(infile, num_bands, band)
-        else:
-            sketch.consume_seqfile(infile)
-        return sketch
+    sketch = allocate(ksize, table_size, num_tables, count=count, graph=graph)
+    if not num_bands:
+        sketch.consume_seqfile(infile)
+    else:
+        assert 0 <= band < num_bands
+        sketch.consume_seqfile_banding(infile, num_bands, band)
+    return sketch
 
 
 def load_sketchfiles(sketchfiles, maxfpr=0.2):
-    sketches = []
-    for sketchfile in sketchfiles:
-        kevlar_amd.plog('[kevlar::sketch]    ', 'loading sketchfile "{}"...'.format(sketchfile), end='')
-        sketch = autoload(sketchfile)
-        fpr = estimate_fpr(sketch)
-        message = 'done! estimated false positive rate is {:1.3f}'.format(fpr)
-        if fpr > maxfpr:
-            message += ' (FPR too high, bailing out!!!)'
-            raise KevlarUnsuitableFPRError(message)
-        kevlar_amd.plog(message)
-        sketches.append(sketch)
-    return sketches
+    """Load (or count) every file; a sketch whose estimated false positive rate exceeds `maxfpr` stops the run."""
+    loaded = []
+    for path in sketchfiles:
+        kevlar_amd.plog('[kevlar::sketch]    ', 'loading sketchfile "{}"...'.format(path), end='')
+        sketch = autoload(path)
+        verdict = 'done! estimated false positive rate is {:1.3f}'.format(estimate_fpr(sketch))
+        if estimate_fpr(sketch) > maxfpr:
+            raise KevlarUnsuitableFPRError(verdict + ' (FPR too high, bailing out!!!)')
+        kevlar_amd.plog(verdict)
+        loaded.append(sketch)
+    return loaded

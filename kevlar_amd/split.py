@@ -1,37 +1,40 @@
-"""`kevlar split` driver (the reference's kevlar/split.py:14-44): deal the partitions of a partitioned
-augmented FASTA/FASTQ file round-robin into N output files.  Host-side text plumbing, the step right
-after `partition` in the mark-I workflow (Snakefile:312-316)."""
-from itertools import cycle
+"""`kevlar split`: deal the partitions of a partitioned augmented FASTA/FASTQ file over N output files, the step
+between `partition` and the per-partition assembly jobs of the workflow (kevlar/split.py:14-44,
+workflows/mark-I/Snakefile:312-316).
 
+A partition is rendered to text once and written with one call; which file a partition goes to is its position in
+the input modulo N (an oversized partition that is discarded still uses up its turn, as in the reference)."""
 import kevlar_amd
+from kevlar_amd.sequence import format_augmented_fastx
+
+
+def _emit(text, sink):
+    try:
+        sink.write(text)
+    except TypeError:                      # binary sinks (gzip)
+        sink.write(text.encode('ascii'))
 
 
 def split(pstream, outstreams, maxreads=10000):
-    """Split the partitions across the N outstreams."""
-    progress_indicator = kevlar_amd.ProgressIndicator(
-        '[kevlar::split] processed {counter} partitions',
-        interval=100, breaks=[1000, 10000, 100000], usetimer=True,
-    )
-    for partdata, outstream in zip(pstream, cycle(outstreams)):
-        partid, partition = partdata
-        if len(partition) > maxreads:
-            kevlar_amd.plog('[kevlar::split]', 'WARNING: discarding partition with {} reads'.format(len(partition)))
+    """Round-robin the (partition id, reads) pairs of `pstream` over `outstreams`; partitions of more than
+    `maxreads` reads are dropped with a warning."""
+    progress = kevlar_amd.ProgressIndicator('[kevlar::split] processed {counter} partitions', interval=100,
+                                            breaks=[1000, 10000, 100000], usetimer=True)
+    nsinks = len(outstreams)
+    for turn, (partid, reads) in enumerate(pstream):
+        if len(reads) > maxreads:
+            kevlar_amd.plog('[kevlar::split]', 'WARNING: discarding partition with {} reads'.format(len(reads)))
             continue
-        for read in partition:
-            kevlar_amd.print_augmented_fastx(read, outstream)
-        progress_indicator.update()
+        _emit(''.join(map(format_augmented_fastx, reads)), outstreams[turn % nsinks])
+        progress.update()
 
 
 def main(args):
-    partfile = kevlar_amd.open(args.infile, 'r')
-    readstream = kevlar_amd.parse_augmented_fastx(partfile)
-    partstream = kevlar_amd.parse_partitioned_reads(readstream)
-    outstreams = list()
-    for i in range(args.numfiles):
-        outfile = '{:s}.{:d}.augfastx'.format(args.base, i)
-        if args.infile.endswith('.gz'):
-            outfile += '.gz'
-        outstreams.append(kevlar_amd.open(outfile, 'w'))
-    split(partstream, outstreams)
-    for stream in outstreams:
-        stream.close()
+    suffix = '.augfastx.gz' if args.infile.endswith('.gz') else '.augfastx'
+    sinks = [kevlar_amd.open('{:s}.{:d}{:s}'.format(args.base, i, suffix), 'w') for i in range(args.numfiles)]
+    try:
+        reads = kevlar_amd.parse_augmented_fastx(kevlar_amd.open(args.infile, 'r'))
+        split(kevlar_amd.parse_partitioned_reads(reads), sinks)
+    finally:
+        for sink in sinks:
+            sink.close()

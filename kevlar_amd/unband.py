@@ -1,69 +1,65 @@
-"""`kevlar unband` driver (the reference's kevlar/unband.py:26-84): merge the per-band outputs
-of a banded `novel` run -- union of the annotations of records that share a read name.
-Host-side text plumbing; it is also the semantic model of the multi-GPU band merge."""
+"""`kevlar unband`: merge the outputs of a banded `novel` run -- one file per k-mer band, the same read possibly
+annotated in several of them -- into one record per read carrying the union of its annotations
+(kevlar/unband.py:26-77, docs/banding.rst).  It is the file-level twin of the multi-GPU hit merge
+(kevlar_amd/bandmerge.py).
+
+Records are spilled as text into `numbatches` shard files chosen by a checksum of the read name, so that all copies
+of a read meet in one shard and only one shard is ever in memory; each shard is then folded by name."""
 from tempfile import TemporaryDirectory
+import os
 import zlib
 
 import kevlar_amd
+from kevlar_amd.sequence import format_augmented_fastx, parse_augmented_fastx
 
 
-def create_batch_files(numbatches, tempdir):
-    return [
-        kevlar_amd.open('{:s}/kevlar-unband-batch{:d}.augfastq.gz'.format(tempdir, i), 'w')
-        for i in range(numbatches)
-    ]
+class _Shards(object):
+    def __init__(self, directory, count):
+        self.paths = [os.path.join(directory, 'kevlar-unband-batch{:d}.augfastq'.format(i)) for i in range(count)]
+        self._sinks = [open(path, 'w') for path in self.paths]
 
+    def add(self, record):
+        # the reference picks the shard with Python's per-process hash(); any function of the name alone will do
+        self._sinks[zlib.crc32(record.name.encode()) % len(self._sinks)].write(format_augmented_fastx(record))
 
-def write_records_to_batches(recordstream, batchfiles):
-    numbatches = len(batchfiles)
-    kevlar_amd.plog('[kevlar::unband]', 'writing records to {:d} temp batch files'.format(numbatches))
-    progress = kevlar_amd.ProgressIndicator('[kevlar::unband]     processed {counter} reads',
-                                            interval=1e5, breaks=[1e6, 1e7])
-    for record in recordstream:
-        progress.update()
-        # the reference buckets by Python's per-process hash(name); any stable function of the
-        # name gives the same guarantee (all copies of a read meet in one batch)
-        batch = zlib.crc32(record.name.encode()) % numbatches
-        kevlar_amd.print_augmented_fastx(record, batchfiles[batch])
+    def seal(self):
+        for sink in self._sinks:
+            sink.close()
 
-
-def resolve_batch(batchfile):
-    filename = batchfile.name
-    batchfile.close()
-    reads = {}
-    with kevlar_amd.open(filename, 'r') as fh:
-        for read in kevlar_amd.parse_augmented_fastx(fh):
-            if read is None:
-                continue
-            if read.name not in reads:
-                reads[read.name] = read
-            else:
-                reads[read.name].annotations.extend(read.annotations)
-    for readname in sorted(reads):
-        read = reads[readname]
-        read.annotations.sort(key=lambda k: k.offset)
-        yield read
-
-
-def resolve_batches(batchfiles):
-    kevlar_amd.plog('[kevlar::unband]', 'resolving duplicate reads in {:d} batches'.format(len(batchfiles)))
-    for n, batchfile in enumerate(batchfiles):
-        for read in resolve_batch(batchfile):
-            yield read
-        kevlar_amd.plog('[kevlar::unband]     batch {:d} complete'.format(n))
-    kevlar_amd.plog('[kevlar::unband] Done!')
+    @staticmethod
+    def fold(path):
+        """records of one shard, one per read name (sorted), annotations united and ordered by offset"""
+        merged = {}
+        with open(path, 'r') as text:
+            for read in parse_augmented_fastx(text):
+                if read is None:
+                    continue
+                first = merged.setdefault(read.name, read)
+                if first is not read:
+                    first.annotations += read.annotations
+        for name in sorted(merged):
+            merged[name].annotations.sort(key=lambda ikmer: ikmer.offset)
+            yield merged[name]
 
 
 def unband(recordstream, numbatches=16):
-    with TemporaryDirectory() as tempdir:
-        batchfiles = create_batch_files(numbatches, tempdir)
-        write_records_to_batches(recordstream, batchfiles)
-        for read in resolve_batches(batchfiles):
-            yield read
+    """One record per read name of `recordstream`; shard by shard, names sorted inside a shard."""
+    with TemporaryDirectory() as scratch:
+        shards = _Shards(scratch, numbatches)
+        kevlar_amd.plog('[kevlar::unband]', 'writing records to {:d} temp batch files'.format(numbatches))
+        progress = kevlar_amd.ProgressIndicator('[kevlar::unband]     processed {counter} reads', interval=1e5, breaks=[1e6, 1e7])
+        for record in recordstream:
+            shards.add(record)
+            progress.update()
+        shards.seal()
+        kevlar_amd.plog('[kevlar::unband]', 'resolving duplicate reads in {:d} batches'.format(numbatches))
+        for index, path in enumerate(shards.paths):
+            yield from shards.fold(path)
+            kevlar_amd.plog('[kevlar::unband]     batch {:d} complete'.format(index))
+        kevlar_amd.plog('[kevlar::unband] Done!')
 
 
 def main(args):
-    outstream = kevlar_amd.open(args.out, 'w')
-    records = kevlar_amd.seqio.afxstream(args.infile)
-    for read in unband(records, args.n_batches):
-        kevlar_amd.print_augmented_fastx(read, outstream)
+    sink = kevlar_amd.open(args.out, 'w')
+    for read in unband(kevlar_amd.seqio.afxstream(args.infile), args.n_batches):
+        sink.write(format_augmented_fastx(read))

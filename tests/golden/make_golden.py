@@ -64,6 +64,8 @@ FIXTURES = [
     # kevlar split / augment (kevlar/tests/test_split.py, test_augment.py)
     'fiveparts.augfastq.gz', 'snorkel.augfastq', 'snorkel-contig.fasta', 'reaugment.augfastq', 'reaugment.fq',
     'reaugment.out', 'deadbeef.augfastq.gz', 'deadbeef.contig.fa', 'deadbeef.fq.gz', 'part-reads-mixed.fa',
+    # progress lines (kevlar/tests/test_progress.py:18-28)
+    'progind.txt',
 ]
 # the three trio1 files behind test_novel.py:179-207 are 1.8 MB each: stored gzipped
 GZ_FIXTURES = ['trio1/case1.fq', 'trio1/ctrl1.fq', 'trio1/ctrl2.fq']

@@ -374,3 +374,92 @@ def test_unband_golden(hk):
     for rec in reads:
         kevlar_amd.print_augmented_fastx(rec, buf)
     assert buf.getvalue() == open(expected_file('unband-helium.sorted.augfastq')).read()
+
+
+def test_novel_tally_counts_kmers_in_front_of_a_screen_trip(hk, ok, kevlar_log):
+    """With --abund-screen the reference adds an interesting k-mer to its set of unique novel k-mers as soon as it
+    finds it, and only later -- at the first k-mer of the read whose case abundance is under the screen -- drops the
+    read (kevlar/novel.py:152-164).  The closing line therefore counts k-mers of reads that are not reported."""
+    import kevlar_amd
+    from kevlar_amd import synth
+    trio = synth.make_trio(30000, 5, denovo_per_mb=2000)
+    reads = {n: synth.unpack_reads(synth.sample_reads_packed(trio[n], 9000, 100, 0.01, 77 + i), 100)
+             for i, n in enumerate(('proband', 'mother', 'father'))}
+    k, casemin, ctrlmax, screen = 25, 6, 1, 3
+    dev, ref = {}, {}
+    for n in reads:
+        dev[n], ref[n] = hk.Counttable(k, 2e5, 4), ok.Counttable(k, 2e5, 4)
+        dev[n].consume_batch(hk.ReadBatch(reads[n]))
+        bases, offs = ok.concat_reads(reads[n])
+        ok.consume_reads(ref[n], bases, offs, len(reads[n]))
+    # the reference's loop, k-mer by k-mer, over the oracle's sketches
+    unique, instances, nreads, dropped_with_kmers = set(), 0, 0, 0
+    for seq in reads['proband']:
+        found, discard = [], False
+        for i in range(len(seq) - k + 1):
+            kmer = seq[i:i + k]
+            a = ref['proband'].get(kmer)
+            if a < casemin:
+                if a < screen:
+                    discard = True
+                    break
+                continue
+            if ref['mother'].get(kmer) > ctrlmax or ref['father'].get(kmer) > ctrlmax:
+                continue
+            found.append(kmer)
+            unique.add(kevlar_amd.revcommin(kmer))
+        if discard:
+            dropped_with_kmers += 1 if found else 0
+        elif found:
+            nreads += 1
+            instances += len(found)
+    assert dropped_with_kmers > 0, 'the input must contain discarded reads that hold interesting k-mers'
+
+    class Rec(object):
+        def __init__(self, i, s):
+            self.name, self.sequence, self.quality = 'r{}'.format(i), s, None
+    stream = [Rec(i, s) for i, s in enumerate(reads['proband'])]
+    out = list(kevlar_amd.novel.novel(stream, [dev['proband']], [dev['mother'], dev['father']], ksize=k, abundscreen=screen,
+                                      casemin=casemin, ctrlmax=ctrlmax))
+    assert len(out) == nreads and sum(len(r.annotations) for r in out) == instances
+    assert 'Found {:d} instances of {:d} unique novel kmers in {:d} reads'.format(instances, len(unique), nreads) in kevlar_log.getvalue()
+
+
+def test_partition_gml(hk, tmp_path):
+    """`partition --gml`: nodes are the reads, edges the pairs that share a retained k-mer (the reference's own call
+    raises a NameError before it writes anything, kevlar/partition.py:38-39)"""
+    import networkx
+    import kevlar_amd
+    gml = str(tmp_path / 'graph.gml')
+    out, log = run_cli(['partition', '--gml', gml, data_file('connectivity-1311.augfastq')])
+    assert '[kevlar] graph written to ' + gml in log
+    graph = networkx.read_gml(gml)
+    with open(data_file('connectivity-1311.augfastq')) as fh:
+        reads = list(kevlar_amd.parse_augmented_fastx(fh))
+    assert sorted(graph.nodes) == sorted(r.name for r in reads)
+    assert graph.number_of_edges() == 30                # kevlar/tests/test_readgraph.py:20-31
+    rg = kevlar_amd.ReadGraph()
+    rg.load(reads)
+    rg.populate_edges()
+    assert graph.number_of_edges() == rg.number_of_edges()
+    assert len(list(networkx.connected_components(graph))) == len(rg.connected_components())
+
+
+def test_hash_positions_equals_hashing_the_kmer_text(hk):
+    """kv_hash_positions (k-mers addressed as (read, offset) in a packed batch) against kv_hash_kmers on the same
+    k-mers as text, for both hash families, long reads included"""
+    rng = np.random.default_rng(5)
+    letters = np.array(list('ACGT'))
+    seqs = [''.join(letters[rng.integers(0, 4, size=n)]) for n in (100, 31, 9000, 64, 250, 20000)]
+    batch = hk.ReadBatch(seqs)
+    for cls, k in ((hk.Counttable, 31), (hk.Counttable, 63), (hk.Counttable, 200), (hk.Countgraph, 25)):
+        sketch = cls(k, 1e4, 2)
+        reads, offs, kmers = [], [], []
+        for ridx, seq in enumerate(seqs):
+            if len(seq) < k:
+                continue
+            for off in sorted(set(rng.integers(0, len(seq) - k + 1, size=40).tolist() + [0, len(seq) - k])):
+                reads.append(ridx); offs.append(off); kmers.append(seq[off:off + k])
+        assert sketch.hash_positions(batch, reads, offs).tolist() == sketch.hash_kmers(kmers).tolist()
+    with pytest.raises(Exception, match='does not lie inside its read'):
+        hk.Counttable(31, 1e4, 2).hash_positions(batch, [1], [5])

@@ -411,3 +411,68 @@ def test_oracle_threaded_consume_equals_single_thread(ok):
     ok.consume_reads(kid, bases, offs, len(reads))
     hits, _ = ok.novel_scan([kid], [mom], bases, offs, len(reads), 21, 5, 0)
     assert ok.novel_scan_count_mt([kid], [mom], bases, offs, len(reads), 21, 5, 0, 3) == len(hits) > 0
+
+
+def test_progress_indicator_jumps_match_item_by_item_counting(kevlar_log):
+    """update(n) must log exactly where n single updates would (the reference ticks once per item,
+    kevlar/progress.py:30-42: widen the interval at a break point, log when the count reaches the due point)"""
+    import random
+    import kevlar_amd
+
+    def literal(interval, breaks, steps):
+        out, counter, nxt = [], 0, interval
+        for n in steps:
+            for _ in range(n):
+                if counter in breaks:
+                    interval = counter
+                if counter >= nxt:
+                    nxt += interval
+                    out.append(counter)
+                counter += 1
+        return out
+    rng = random.Random(1)
+    for trial in range(200):
+        interval = rng.choice([1, 3, 10, 100])
+        breaks = sorted(rng.sample(range(1, 5000), rng.randint(0, 4))) if trial % 2 else [100, 1000, 10000]
+        steps = [rng.choice([1, 1, 7, 64, 999, 2500]) for _ in range(rng.randint(1, 30))]
+        kevlar_log.seek(0); kevlar_log.truncate()
+        p = kevlar_amd.ProgressIndicator('n={counter}', interval=interval, breaks=breaks)
+        for n in steps:
+            p.update(n)
+        got = [int(line.rsplit('=', 1)[1]) for line in kevlar_log.getvalue().split('\n') if '=' in line]
+        assert got == literal(interval, breaks, steps)
+
+
+def test_progress_lines_match_the_reference_log(kevlar_log):
+    """kevlar/tests/test_progress.py:18-28: 12000 single updates, interval 1, breaks 10/100/1000, against the
+    reference's own expected log; and the same count in uneven batches"""
+    import kevlar_amd
+    want = open(data_file('progind.txt')).read().strip().split('\n')
+    logger = kevlar_amd.ProgressIndicator('processed {counter} partitions', interval=1, breaks=[10, 100, 1000])
+    for _ in range(12000):
+        logger.update()
+    assert kevlar_log.getvalue().strip().split('\n') == want
+    kevlar_log.seek(0); kevlar_log.truncate()
+    logger = kevlar_amd.ProgressIndicator('processed {counter} partitions', interval=1, breaks=[10, 100, 1000])
+    for n in (5, 1, 94, 4000, 7000, 900):
+        logger.update(n)
+    assert kevlar_log.getvalue().strip().split('\n') == want
+
+
+def test_timer_contract():
+    """kevlar/tests/test_timer.py:16-38"""
+    import time
+    from kevlar_amd.timer import Timer
+    t = Timer()
+    t.start()
+    t.start('task1')
+    time.sleep(0.01)
+    assert t.probe() > 0 and t.probe('task1') > 0.0
+    with pytest.raises(ValueError, match=r'No timer started for "task2"'):
+        t.probe('task2')
+    assert t.stop('task1') > 0.0
+    with pytest.raises(ValueError, match=r'No timer started for "task3"'):
+        t.stop('task3')
+    t.start('task3')
+    with pytest.raises(ValueError, match=r'Timer already started for "task3"'):
+        t.start('task3')
