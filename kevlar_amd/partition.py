@@ -59,19 +59,29 @@ def partition(readstream, strict=False, minabund=None, maxabund=None, dedup=True
     kevlar_amd.plog('[kevlar::partition]', 'Total time: {:.2f} seconds'.format(timer.stop()))
 
 
+class _Outputs(object):
+    """where partitions go: one shared stream, or with --split PREFIX one gzipped file per partition"""
+
+    def __init__(self, shared, prefix):
+        self.prefix = prefix
+        if prefix:
+            kevlar_amd.mkdirp(prefix, trim=True)
+        self.shared = None if prefix else kevlar_amd.open(shared, 'w')
+
+    def put(self, number, text):
+        if self.shared is not None:
+            self.shared.write(text)
+            return
+        with kevlar_amd.open('{:s}.cc{:d}.augfastq.gz'.format(self.prefix, number), 'w') as own:
+            own.write(text)
+
+
 def main(args):
-    if args.split:
-        kevlar_amd.mkdirp(args.split, trim=True)
-    shared_sink = None if args.split else kevlar_amd.open(args.out, 'w')
-    reads_in = kevlar_amd.parse_augmented_fastx(kevlar_amd.open(args.infile, 'r'))
-    nreads = ncomponents = 0
-    for ncomponents, reads in partition(reads_in, strict=args.strict, minabund=args.min_abund, maxabund=args.max_abund,
-                                        dedup=args.dedup, gmlfile=args.gml):
-        nreads += len(reads)
-        text = ''.join(map(format_augmented_fastx, reads))
-        if shared_sink is not None:
-            shared_sink.write(text)
-        else:
-            with kevlar_amd.open('{:s}.cc{:d}.augfastq.gz'.format(args.split, ncomponents), 'w') as sink:
-                sink.write(text)
-    kevlar_amd.plog('[kevlar::partition]', 'grouped {:d} reads into {:d} connected components'.format(nreads, ncomponents))
+    outputs = _Outputs(args.out, args.split)
+    labelled = partition(kevlar_amd.parse_augmented_fastx(kevlar_amd.open(args.infile, 'r')), strict=args.strict,
+                         minabund=args.min_abund, maxabund=args.max_abund, dedup=args.dedup, gmlfile=args.gml)
+    sizes = [0]                      # reads per component; sizes[0] pads the 1-based numbering
+    for number, reads in labelled:
+        sizes.append(len(reads))
+        outputs.put(number, ''.join(map(format_augmented_fastx, reads)))
+    kevlar_amd.plog('[kevlar::partition]', 'grouped {:d} reads into {:d} connected components'.format(sum(sizes), len(sizes) - 1))

@@ -2,7 +2,9 @@
 2 GB sketch per sample) is far beyond what the scalar oracle can replay, so parity at this size is
 checked through properties that do not depend on size:
 
-* the two count implementations (global-atomic and partitioned) produce identical tables;
+* the three count implementations (global-atomic, one-item-per-k-mer partition, super-k-mer / per-distinct-k-mer)
+  produce identical tables, and the two scans (per distinct k-mer over super-k-mer buckets, per k-mer over tiles)
+  identical hits -- at config 2 (k=31) and config 5 (proband + 3 controls, k=51);
 * saturating-add algebra: counting a batch twice gives min(255, 2 x) in every bin;
 * banding is a partition of the k-mers: the band tables sum to the unbanded tables;
 * the k-mer total matches n_reads x (L - k + 1); occupancy equals the non-zero count of table 0;
@@ -39,14 +41,18 @@ def test_fullsize_count_paths_agree_and_saturating_algebra(hk, trio):
     try:
         a = hk.Counttable(K, MEM / 4, 4)
         n_a = a.consume_batch(batches['proband'])
+        os.environ['KV_COUNT_PATH'] = 'binned'
+        c = hk.Counttable(K, MEM / 4, 4)
+        n_c = c.consume_batch(batches['proband'])
     finally:
         os.environ.pop('KV_COUNT_PATH', None)
-    b = hk.Counttable(K, MEM / 4, 4)
+    b = hk.Counttable(K, MEM / 4, 4)                      # default at this size: the super-k-mer front end
     n_b = b.consume_batch(batches['proband'])
-    assert n_a == n_b == n_reads * (L - K + 1)
+    assert n_a == n_b == n_c == n_reads * (L - K + 1)
     ta, tb = tables(a), tables(b)
-    for x, y in zip(ta, tb):
-        assert np.array_equal(x, y)
+    for x, y, z in zip(ta, tb, tables(c)):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    del c
     assert a.n_occupied() == b.n_occupied() == int(np.count_nonzero(tb[0]))
     for t in tb:                                    # every k-mer lands once in every table
         assert t.max() == 255 or int(t.sum(dtype=np.uint64)) == n_b
@@ -116,3 +122,52 @@ def test_fullsize_novel_scan_properties(hk, ok, trio):
         got[(ridx, off)] = tuple(ab)
     assert got == {(x, y): z for x, y, z in want}
     assert len(want) > 1000
+
+
+def test_fullsize_config5_k51_four_samples(hk, ok):
+    """BASELINE.json config 5: proband + 3 controls, k=51 (two-word keys, three murmur blocks + tail), 30x, 25 Mb"""
+    from kevlar_amd import synth
+    k, names = 51, ('proband', 'mother', 'father', 'sibling1')
+    packed = synth.trio_reads_packed(25_000_000, 30, L, extra_controls=1)
+    batches = {n: hk.ReadBatch.from_packed(packed[n], L) for n in names}
+    n_reads, nk = packed['proband'].shape[0], L - k + 1
+    sk = {n: hk.Counttable(k, MEM / 4, 4) for n in names}
+    for n in names[1:] + names[:1]:
+        assert sk[n].consume_batch(batches[n]) == n_reads * nk
+    os.environ['KV_COUNT_PATH'] = 'binned'
+    try:
+        other = hk.Counttable(k, MEM / 4, 4)
+        other.consume_batch(batches['sibling1'])
+    finally:
+        os.environ.pop('KV_COUNT_PATH', None)
+    for x, y in zip(tables(sk['sibling1']), tables(other)):
+        assert np.array_equal(x, y)
+    assert sk['sibling1'].n_occupied() == other.n_occupied() == int(np.count_nonzero(tables(other)[0]))
+    del other
+    cases, ctrls = [sk['proband']], [sk[n] for n in names[1:]]
+    r, o, a, _ = hk.novel_scan(cases, ctrls, batches['proband'], 6, 1)
+    os.environ['KV_NOVEL_PATH'] = 'tiles'
+    try:
+        r2, o2, a2, _ = hk.novel_scan(cases, ctrls, batches['proband'], 6, 1)
+    finally:
+        os.environ.pop('KV_NOVEL_PATH', None)
+    assert np.array_equal(r, r2) and np.array_equal(o, o2) and np.array_equal(a, a2)
+    assert len(r) > 100000 and a.shape[1] == 4
+    assert (a[:, 0] >= 6).all() and (a[:, 1:] <= 1).all()
+    assert (np.diff(r.astype(np.int64) * nk + o) > 0).all()
+    # a seeded sample of reads replayed by the oracle's hash + Count-Min minimum over the SAME table bytes
+    tabs = {n: tables(sk[n]) for n in names}
+    sizes = sk['proband'].hashsizes()
+    rng = np.random.default_rng(2)
+    sample = np.concatenate((rng.choice(np.unique(r), size=100, replace=False), rng.integers(0, n_reads, size=100)))
+    ref = ok.Counttable(k, MEM / 4, 4)
+    want = {}
+    for ridx, seq in zip(sample.tolist(), synth.unpack_reads(packed['proband'][sample], L)):
+        for i in range(nk):
+            h = ref.hash(seq[i:i + k])
+            ab = tuple(min(int(tabs[n][t][h % sizes[t]]) for t in range(4)) for n in names)
+            if ab[0] >= 6 and max(ab[1:]) <= 1:
+                want[(ridx, i)] = ab
+    sel = np.isin(r, sample)
+    got = {(x, y): tuple(z) for x, y, z in zip(r[sel].tolist(), o[sel].tolist(), a[sel].tolist())}
+    assert got == want and len(want) > 500
