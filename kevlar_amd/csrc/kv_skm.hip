@@ -55,6 +55,8 @@ namespace {
 #define SKM_TILES_PER_TICKET 8u
 #define SKM_BUCKETS_PER_TICKET 8u
 
+// (32-byte records -- one aligned sector each, two 16-byte stores -- were measured against these 24-byte ones: WRITE_SIZE
+// fell from 2.5 to 2.3 GB per sample for 1.3 / 1.7 GB stored, the readers fetched 0.4 GB more each, times did not move.)
 __device__ __forceinline__ void skm_store_record(uint64_t *dst, uint64_t hdr, const uint64_t *bw, int nbw)
 {
     dst[0] = hdr;
@@ -872,6 +874,8 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
         g.quota1 = (uint32_t)std::min<uint64_t>(kv_round_up(avg + avg / 2 + 1, SKM_TILES_PER_TICKET), 0xfffffff0ull);
     }
     g.nwg2 = std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / g.C1));
+    if (const char *e = getenv("KV_SKM_NWG1")) g.nwg1 = std::max<uint32_t>(1u, std::min<uint32_t>(g.nwg1, (uint32_t)atoi(e)));
+    if (const char *e = getenv("KV_SKM_NWG2")) g.nwg2 = std::max<uint32_t>(1u, std::min<uint32_t>(16u, (uint32_t)atoi(e)));
     g.nwg2 = std::min<uint32_t>(g.nwg2, g.nwg1);
     g.np_max = std::max<uint32_t>(reads->tile_max_bases, 64u);
     const uint64_t min_stride = reads->max_len >= (uint32_t)k ? reads->max_len - (uint32_t)k + 1 : 1;

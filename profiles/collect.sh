@@ -6,15 +6,15 @@
 # --pmc pass per counter (FETCH_SIZE and WRITE_SIZE do not fit one pass; counters are never combined
 # with trace domains other than the kernel trace).
 set -u
-ROUND=${1:-r1_final}
+ROUND=${1:-r2_final}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/$ROUND
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH_ARGS="--steps 3 --warmup 1 --no-cpu-baseline"
-python3 $REPO/bench.py --steps 4 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
+BENCH_ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-replay"
+python3 $REPO/bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $BENCH_ARGS > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-replay > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-replay > /dev/null 2> $OUT/pmc_write.err
 python3 $REPO/profiles/summarise.py $OUT $OUT/summary
 ls -la $OUT/summary
