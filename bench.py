@@ -333,7 +333,8 @@ def main():
     dominant = max(groups[stage], key=lambda n_: times[n_][0]) if groups[stage] else None
     achieved = stage_alg[stage] / (stage_ms[stage] * 1e-3) / 1e9 if stage_ms[stage] > 0 else 0.0
     traffic, traffic_source = None, None
-    pmc_file = os.path.join(ROOT, 'profiles', 'r2_final', 'pmc_hbm_bytes.json')
+    pmc_file = next((f for f in (os.path.join(ROOT, 'profiles', r, 'pmc_hbm_bytes.json') for r in ('r2_final', 'r2_mid'))
+                     if os.path.exists(f)), '')
     if world == 1 and os.path.exists(pmc_file) and args.workload == 'cfg2':
         # HBM bytes from the committed rocprofv3 PMC passes of this same workload (profiles/README.md): FETCH_SIZE and
         # WRITE_SIZE in separate passes, FETCH doubled for wide coalesced streams as the guide prescribes; summed over
@@ -346,7 +347,7 @@ def main():
                 tot += rec['hbm_bytes_per_step']
         if tot:
             traffic = int(tot)
-            traffic_source = 'profiles/r2_final/pmc_hbm_bytes.json ({})'.format(pmc.get('collected', 'rocprofv3 --pmc'))
+            traffic_source = '{} ({})'.format(os.path.relpath(pmc_file, ROOT), pmc.get('collected', 'rocprofv3 --pmc'))
     dom_ms, dom_launches = times[dominant] if dominant else (0.0, 0)
     roofline = {
         'bound': 'hbm', 'stage': stage, 'kernel': dominant,

@@ -14,7 +14,12 @@ import sys
 def short_name(kernel):
     """'void (anonymous namespace)::k_bin_hash_direct<512, 8>(...)' -> 'k_bin_hash_direct'"""
     m = re.search(r'(k_[a-z0-9_]+)', kernel)
-    return m.group(1) if m else kernel.split('(')[0].strip()
+    if not m:
+        return kernel.split('(')[0].strip()
+    name = m.group(1)
+    if name in ('k_bin_split', 'k_bin_apply') and 'true>' in kernel:       # the weighted template instances
+        name += '_w'
+    return name
 
 
 def main(src, dst):
@@ -48,8 +53,27 @@ def main(src, dst):
             d = pmc.setdefault(name, {})
             d[counter + '_KB_per_launch_avg'] = round(sum(vals) / len(vals), 1)
             d['launches_' + counter] = len(vals)
+    # HBM bytes per bench step by kernel: FETCH_SIZE x correction + WRITE_SIZE, x launches per step.  The guide
+    # (MI355X_MICROARCH.md, HBM) measured FETCH_SIZE at exactly 1/2 of the bytes of wide coalesced reads on gfx950;
+    # that holds for the streaming kernels here (checked against their known input sizes, profiles/README.md), while
+    # random single-sector reads (the scan's table probes) calibrate at 1.0.
+    streaming = ('k_skm_split', 'k_skm_count', 'k_bin_split', 'k_bin_apply', 'k_bin_hash', 'k_bin_list', 'k_skm_emit')
+    steps = 1
+    bench_line = os.path.join(src, 'bench_under_rocprof.json')
+    kernels = {}
+    for name, d in pmc.items():
+        if not name.startswith('k_'):
+            continue
+        factor = 2.0 if name.startswith(streaming) else 1.0
+        fetch_kb, write_kb = d.get('FETCH_SIZE_KB_per_launch_avg', 0.0), d.get('WRITE_SIZE_KB_per_launch_avg', 0.0)
+        launches = d.get('launches_FETCH_SIZE', d.get('launches_WRITE_SIZE', 0))      # the PMC passes run ONE step
+        kernels[name] = {'fetch_factor': factor, 'launches_per_step': launches,
+                         'hbm_bytes_per_launch': int((fetch_kb * factor + write_kb) * 1024),
+                         'hbm_bytes_per_step': int((fetch_kb * factor + write_kb) * 1024 * launches / steps)}
+    out = {'collected': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of bench.py --steps 1 --warmup 0',
+           'raw_KB_per_launch': pmc, 'kernels': kernels}
     with open(os.path.join(dst, 'pmc_hbm_bytes.json'), 'w') as fh:
-        json.dump(pmc, fh, indent=1)
+        json.dump(out, fh, indent=1)
     for name in ('bench.json', 'bench_under_rocprof.json'):
         p = os.path.join(src, name)
         if os.path.exists(p):
