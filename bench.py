@@ -488,12 +488,45 @@ def end_to_end(args, wl, packed, names, synth):
         run(argv + ['--case-min', str(args.case_min), '--ctrl-max', str(args.ctrl_max), '-o', os.path.join(tmp, 'novel.augfastq')])
         t1 = time.perf_counter()
         kevlar_amd.logstream = saved
-        return {'value': round(len(names) * n / (t1 - t0), 1), 'unit': 'reads/s',
+        ingest = ingest_rates(os.path.join(tmp, 'proband.fq'), n)
+        return {'value': round(len(names) * n / (t1 - t0), 1), 'unit': 'reads/s', 'ingest_reads_per_s': ingest,
                 'sample': '{} reads per sample as FASTQ on local disk ({} MB each); one `kevlar novel --case ... --control ...` run: '
                           'every sample parsed, packed, uploaded and counted, the case sample parsed again and scanned, annotated '
                           'reads written: {:.2f} s'.format(n, os.path.getsize(os.path.join(tmp, 'proband.fq')) >> 20, t1 - t0)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def ingest_rates(fastq, n):
+    """reads/s from a file on disk to 2-bit packed batches in HBM (the native reader alone, no kernels): plain FASTQ,
+    gzip (one zlib stream: the inflate rate of one core), and the packed-read cache a first pass leaves behind
+    (KEVLAR_PACK_CACHE=1: SURVEY.md 8(f).1)"""
+    import gzip
+    import shutil
+    from kevlar_amd import khmer as hk
+
+    def drain(path):
+        t0 = time.perf_counter()
+        parser, got = hk.ReadParser(path), 0
+        while True:
+            batch = parser.take_batch(hk.BATCH_READS)
+            if batch is None:
+                break
+            got += batch.n_reads
+            batch.close()
+        assert got == n
+        return round(n / (time.perf_counter() - t0), 1)
+    gz = fastq + '.gz'
+    with open(fastq, 'rb') as src, gzip.open(gz, 'wb', compresslevel=1) as dst:
+        shutil.copyfileobj(src, dst)
+    out = {'fastq': drain(fastq), 'fastq_gz': drain(gz)}
+    os.environ['KEVLAR_PACK_CACHE'] = '1'
+    try:
+        out['fastq_gz_first_pass_writing_cache'] = drain(gz)
+        out['fastq_gz_from_packed_cache'] = drain(gz)
+    finally:
+        os.environ.pop('KEVLAR_PACK_CACHE', None)
+    return out
 
 
 if __name__ == '__main__':

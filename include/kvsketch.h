@@ -136,6 +136,13 @@ int kv_fastx_batch_text(kv_fastx *f, const char **names, const uint64_t **name_o
                         const uint64_t **seq_offs, const char **quals, const uint64_t **qual_offs,
                         const uint8_t **is_fastq);
 int kv_fastx_num_reads(kv_fastx *f, uint64_t *n); /* khmer parser.num_reads */
+/* Packed-read cache (count and novel share one parse).  With KEVLAR_PACK_CACHE=1 in the environment a
+ * complete pass over FILE leaves FILE.kvpack beside it, and kv_fastx_open(FILE) streams from it when it matches the
+ * source's size and mtime: kv_fastx_next then uploads the stored packed words (no inflate, no parsing);
+ * kv_fastx_batch_text still gives names and all offsets, while sequences and qualities are produced per record by
+ * kv_fastx_record_text (byte for byte what the source holds).  kv_fastx_from_cache tells which mode a handle is in. */
+int kv_fastx_from_cache(kv_fastx *f, int *yes);
+int kv_fastx_record_text(kv_fastx *f, uint64_t i, char *seq_out, char *qual_out);
 int kv_fastx_close(kv_fastx *f);
 int kv_reads_count(const kv_reads *r, uint64_t *n_reads, uint64_t *n_bases);
 /* number of k-mers a consume of this batch visits at size k (sum over reads of len-k+1)   */

@@ -69,6 +69,8 @@ SIGNATURES = {
                                   ctypes.POINTER(u64p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u64p),
                                   ctypes.POINTER(u8p)]),
     'kv_fastx_num_reads': (i32, [vp, u64p]),
+    'kv_fastx_from_cache': (i32, [vp, ctypes.POINTER(ctypes.c_int)]),
+    'kv_fastx_record_text': (i32, [vp, u64, ctypes.c_char_p, ctypes.c_char_p]),
     'kv_fastx_close': (i32, [vp]),
     'kv_reads_count': (i32, [vp, u64p, u64p]),
     'kv_reads_num_kmers': (i32, [vp, i32, u64p]),

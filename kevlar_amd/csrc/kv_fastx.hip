@@ -9,11 +9,56 @@
 // Record rules (same as kevlar_amd.khmer._iter_fastx): '@name' / sequence / '+' / quality, or
 // '>name' followed by sequence lines up to the next '>'; name = the header line after its first
 // character; blank lines between records are ignored.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 
 #include "kv_internal.h"
+
+// ---------------------------------------------------------------------------------------
+// Packed-read cache: `kevlar count` parses a sample, `kevlar novel` parses the case sample again
+// (kevlar/count.py:40, kevlar/__init__.py:125-128) -- and a gzip stream inflates at ~250 MB/s on one core however fast
+// the GPU is.  With KEVLAR_PACK_CACHE=1 the first complete pass over FILE leaves FILE.kvpack next to it: per block of
+// reads the 2-bit packed words exactly as the device packed them, lengths, flags, names, qualities and the few
+// characters outside ACGT, so that a later open of FILE (same size and mtime) streams blocks from the page cache
+// straight into HBM -- no inflate, no record splitting, no packing kernel -- and can still reproduce every record's
+// text byte for byte.
+//   file  : "KVPK" u32 version  u64 src_size  u64 src_mtime_ns  u64 total_reads   then blocks, then a block with n = 0
+//   block : "KVPB" u32 n  u64 n_words  u64 names_bytes  u64 quals_bytes  u64 n_exc
+//           u32 len[n]  u32 name_len[n]  u32 qual_len[n]  u8 flags[n] (bit0 non-ACGT, bit1 FASTQ; padded to 8)
+//           u32 words[n_words] (padded to 8)  names  quals (each padded to 8)  u64 exc_pos[n_exc]  u8 exc_char[n_exc] (padded)
+// ---------------------------------------------------------------------------------------
+#define KVPK_VERSION 1u
+#define KVPK_BLOCK_READS 65536u
+
+struct PackBlock {                 // pointers into the mapped cache file
+    uint32_t n = 0;
+    uint64_t n_words = 0, names_bytes = 0, quals_bytes = 0, n_exc = 0;
+    const uint32_t *len = nullptr, *name_len = nullptr, *qual_len = nullptr, *words = nullptr;
+    const uint8_t *flags = nullptr, *exc_char = nullptr;
+    const char *names = nullptr, *quals = nullptr;
+    const uint64_t *exc_pos = nullptr;
+    std::vector<uint64_t> woff, noff, qoff, boff;   // per-read prefix sums (words, names, quals, bases), built on load
+};
+
+struct PackReader {
+    int fd = -1;
+    const uint8_t *base = nullptr;
+    size_t size = 0, pos = 0;
+    std::vector<PackBlock> batch;          // blocks of the batch last handed out
+    std::vector<uint64_t> first;           // first read of each of them inside the batch
+};
+
+struct PackWriter {
+    FILE *fh = nullptr;
+    std::string tmp, final_path;
+    uint64_t total = 0;
+    bool ok = true;
+};
 
 struct kv_fastx {
     gzFile fh = nullptr;
@@ -30,6 +75,8 @@ struct kv_fastx {
     std::vector<uint64_t> name_offs, seq_offs, qual_offs;
     std::vector<uint8_t> is_fastq;   // per record: came with a quality line
     std::mutex mu;
+    PackReader *cache = nullptr;     // serving from FILE.kvpack instead of parsing
+    PackWriter *writer = nullptr;    // leaving FILE.kvpack behind
 };
 
 static bool fx_fill(kv_fastx *f)
@@ -110,16 +157,191 @@ static inline void fx_strip(std::string &s)
     if (a > 0 || b < s.size()) s = s.substr(a, b - a);
 }
 
+static inline size_t pad8(size_t v) { return (v + 7) & ~(size_t)7; }
+
+static bool pack_source_signature(const char *path, uint64_t *size, uint64_t *mtime_ns)
+{
+    struct stat st;
+    if (stat(path, &st) != 0) return false;
+    *size = (uint64_t)st.st_size;
+    *mtime_ns = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
+    return true;
+}
+
+static PackReader *pack_open(const char *path)
+{
+    uint64_t size = 0, mtime = 0;
+    if (!pack_source_signature(path, &size, &mtime)) return nullptr;
+    const std::string cpath = std::string(path) + ".kvpack";
+    const int fd = open(cpath.c_str(), O_RDONLY);
+    if (fd < 0) return nullptr;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 40) { close(fd); return nullptr; }
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) { close(fd); return nullptr; }
+    const uint8_t *b = (const uint8_t *)m;
+    uint32_t version;
+    uint64_t hs, hm;
+    memcpy(&version, b + 4, 4); memcpy(&hs, b + 8, 8); memcpy(&hm, b + 16, 8);
+    if (memcmp(b, "KVPK", 4) != 0 || version != KVPK_VERSION || hs != size || hm != mtime) {   // stale or foreign: parse the source
+        munmap(m, (size_t)st.st_size); close(fd);
+        return nullptr;
+    }
+    PackReader *r = new PackReader();
+    r->fd = fd; r->base = b; r->size = (size_t)st.st_size; r->pos = 32;
+    (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    return r;
+}
+
+static void pack_close(PackReader *r)
+{
+    if (!r) return;
+    if (r->base) munmap((void *)r->base, r->size);
+    if (r->fd >= 0) close(r->fd);
+    delete r;
+}
+
+// next block of the cache, or false at the end marker / on a truncated file
+static bool pack_next_block(PackReader *r, PackBlock &blk)
+{
+    if (r->pos + 48 > r->size || memcmp(r->base + r->pos, "KVPB", 4) != 0) return false;
+    const uint8_t *p = r->base + r->pos;
+    memcpy(&blk.n, p + 4, 4); memcpy(&blk.n_words, p + 8, 8); memcpy(&blk.names_bytes, p + 16, 8);
+    memcpy(&blk.quals_bytes, p + 24, 8); memcpy(&blk.n_exc, p + 32, 8);
+    if (blk.n == 0) return false;
+    size_t at = r->pos + 40;
+    auto take = [&](size_t bytes) { const uint8_t *q = r->base + at; at += pad8(bytes); return q; };
+    blk.len = (const uint32_t *)take((size_t)blk.n * 4);
+    blk.name_len = (const uint32_t *)take((size_t)blk.n * 4);
+    blk.qual_len = (const uint32_t *)take((size_t)blk.n * 4);
+    blk.flags = take(blk.n);
+    blk.words = (const uint32_t *)take((size_t)blk.n_words * 4);
+    blk.names = (const char *)take(blk.names_bytes);
+    blk.quals = (const char *)take(blk.quals_bytes);
+    blk.exc_pos = (const uint64_t *)take((size_t)blk.n_exc * 8);
+    blk.exc_char = take(blk.n_exc);
+    if (at > r->size) return false;
+    r->pos = at;
+    blk.woff.resize(blk.n + 1); blk.noff.resize(blk.n + 1); blk.qoff.resize(blk.n + 1); blk.boff.resize(blk.n + 1);
+    uint64_t w = 0, nn = 0, q = 0, bb = 0;
+    for (uint32_t i = 0; i < blk.n; ++i) {
+        blk.woff[i] = w; blk.noff[i] = nn; blk.qoff[i] = q; blk.boff[i] = bb;
+        w += ((uint64_t)blk.len[i] + 15) / 16; nn += blk.name_len[i]; q += blk.qual_len[i]; bb += blk.len[i];
+    }
+    blk.woff[blk.n] = w; blk.noff[blk.n] = nn; blk.qoff[blk.n] = q; blk.boff[blk.n] = bb;
+    return w == blk.n_words && nn == blk.names_bytes && q == blk.quals_bytes;
+}
+
+static PackWriter *pack_writer_start(const char *path)
+{
+    uint64_t size = 0, mtime = 0;
+    if (!pack_source_signature(path, &size, &mtime)) return nullptr;
+    PackWriter *w = new PackWriter();
+    w->final_path = std::string(path) + ".kvpack";
+    w->tmp = w->final_path + ".tmp." + std::to_string((long)getpid());
+    w->fh = fopen(w->tmp.c_str(), "wb");
+    if (!w->fh) { delete w; return nullptr; }     // read-only directory: no cache, no error
+    const uint32_t version = KVPK_VERSION;
+    const uint64_t zero = 0;
+    w->ok = fwrite("KVPK", 1, 4, w->fh) == 4 && fwrite(&version, 4, 1, w->fh) == 1 && fwrite(&size, 8, 1, w->fh) == 1 &&
+            fwrite(&mtime, 8, 1, w->fh) == 1 && fwrite(&zero, 8, 1, w->fh) == 1;
+    return w;
+}
+
+static void pack_write_padded(PackWriter *w, const void *data, size_t bytes)
+{
+    static const char zeros[8] = {0};
+    if (bytes && fwrite(data, 1, bytes, w->fh) != bytes) w->ok = false;
+    const size_t pad = pad8(bytes) - bytes;
+    if (pad && fwrite(zeros, 1, pad, w->fh) != pad) w->ok = false;
+}
+
+// one parsed + uploaded batch -> cache blocks of at most KVPK_BLOCK_READS reads
+static void pack_write_batch(PackWriter *w, const kv_fastx *f, const kv_reads *reads, uint64_t n)
+{
+    if (!w->ok) return;
+    std::vector<uint32_t> words(reads->n_words ? reads->n_words : 1);
+    std::vector<uint8_t> dflags(n ? n : 1);
+    if (hipMemcpy(words.data(), reads->d_words, reads->n_words * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(dflags.data(), reads->d_flags, n, hipMemcpyDeviceToHost) != hipSuccess) { w->ok = false; return; }
+    uint64_t wbase = 0;
+    for (uint64_t lo = 0; lo < n; lo += KVPK_BLOCK_READS) {
+        const uint32_t m = (uint32_t)std::min<uint64_t>(KVPK_BLOCK_READS, n - lo);
+        std::vector<uint32_t> len(m), nlen(m), qlen(m);
+        std::vector<uint8_t> flags(m);
+        std::vector<uint64_t> epos;
+        std::vector<uint8_t> echar;
+        uint64_t nwords = 0, bases = 0;
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint64_t r = lo + i;
+            len[i] = (uint32_t)(f->seq_offs[r + 1] - f->seq_offs[r]);
+            nlen[i] = (uint32_t)(f->name_offs[r + 1] - f->name_offs[r]);
+            qlen[i] = (uint32_t)(f->qual_offs[r + 1] - f->qual_offs[r]);
+            flags[i] = (uint8_t)((dflags[r] & 1u) | (f->is_fastq[r] ? 2u : 0u));
+            if (dflags[r] & 1u) {            // keep what 2 bits cannot: every character that is not an upper-case A, C, G or T
+                const char *sq = f->seqs.data() + f->seq_offs[r];
+                for (uint32_t j = 0; j < len[i]; ++j)
+                    if (sq[j] != 'A' && sq[j] != 'C' && sq[j] != 'G' && sq[j] != 'T') { epos.push_back(bases + j); echar.push_back((uint8_t)sq[j]); }
+            }
+            nwords += ((uint64_t)len[i] + 15) / 16;
+            bases += len[i];
+        }
+        const uint64_t names_bytes = f->name_offs[lo + m] - f->name_offs[lo], quals_bytes = f->qual_offs[lo + m] - f->qual_offs[lo];
+        const uint64_t n_exc = epos.size();
+        if (fwrite("KVPB", 1, 4, w->fh) != 4 || fwrite(&m, 4, 1, w->fh) != 1 || fwrite(&nwords, 8, 1, w->fh) != 1 ||
+            fwrite(&names_bytes, 8, 1, w->fh) != 1 || fwrite(&quals_bytes, 8, 1, w->fh) != 1 || fwrite(&n_exc, 8, 1, w->fh) != 1) w->ok = false;
+        pack_write_padded(w, len.data(), (size_t)m * 4);
+        pack_write_padded(w, nlen.data(), (size_t)m * 4);
+        pack_write_padded(w, qlen.data(), (size_t)m * 4);
+        pack_write_padded(w, flags.data(), m);
+        pack_write_padded(w, words.data() + wbase, (size_t)nwords * 4);
+        pack_write_padded(w, f->names.data() + f->name_offs[lo], names_bytes);
+        pack_write_padded(w, f->quals.data() + f->qual_offs[lo], quals_bytes);
+        pack_write_padded(w, epos.data(), (size_t)n_exc * 8);
+        pack_write_padded(w, echar.data(), n_exc);
+        wbase += nwords;
+    }
+    w->total += n;
+}
+
+static void pack_writer_finish(PackWriter *w, bool complete)
+{
+    if (!w) return;
+    if (w->fh) {
+        if (complete && w->ok) {
+            const uint32_t zero32 = 0;
+            const uint64_t zero = 0;
+            w->ok = fwrite("KVPB", 1, 4, w->fh) == 4 && fwrite(&zero32, 4, 1, w->fh) == 1;
+            for (int i = 0; i < 4 && w->ok; ++i) w->ok = fwrite(&zero, 8, 1, w->fh) == 1;      // end marker: an empty block header
+            if (w->ok) w->ok = fseek(w->fh, 24, SEEK_SET) == 0 && fwrite(&w->total, 8, 1, w->fh) == 1;
+        }
+        if (fclose(w->fh) != 0) w->ok = false;
+        if (complete && w->ok) (void)rename(w->tmp.c_str(), w->final_path.c_str());     // appears atomically, or not at all
+        else (void)unlink(w->tmp.c_str());
+    }
+    delete w;
+}
+
 extern "C" int kv_fastx_open(const char *path, kv_fastx **out)
 {
     KV_REQUIRE(path && out, KV_ERR_ARG, "kv_fastx_open: null argument");
-    gzFile fh = gzopen(path, "rb");
-    KV_REQUIRE(fh, KV_ERR_IO, "cannot open sequence file %s", path);
-    gzbuffer(fh, 1 << 20);
+    const char *mode = getenv("KEVLAR_PACK_CACHE");          // unset or "0": never look at caches; "1": use and create them
+    const bool caching = mode && atoi(mode) != 0;
     kv_fastx *f = new kv_fastx();
-    f->fh = fh;
     f->path = path;
-    f->buf.resize(4 << 20);
+    if (caching) f->cache = pack_open(path);
+    if (!f->cache) {
+        gzFile fh = gzopen(path, "rb");
+        if (!fh) {
+            delete f;
+            kv_set_error("cannot open sequence file %s", path);
+            return KV_ERR_IO;
+        }
+        gzbuffer(fh, 1 << 20);
+        f->fh = fh;
+        f->buf.resize(4 << 20);
+        if (caching) f->writer = pack_writer_start(path);
+    }
     *out = f;
     return KV_OK;
 }
@@ -128,7 +350,17 @@ extern "C" int kv_fastx_close(kv_fastx *f)
 {
     if (!f) return KV_OK;
     if (f->fh) gzclose(f->fh);
+    pack_writer_finish(f->writer, false);       // a complete pass has already finished (and detached) its writer
+    pack_close(f->cache);
     delete f;
+    return KV_OK;
+}
+
+// 1 if this handle streams from a packed-read cache (the text of a batch is then fetched per record)
+extern "C" int kv_fastx_from_cache(kv_fastx *f, int *yes)
+{
+    KV_REQUIRE(f && yes, KV_ERR_ARG, "kv_fastx_from_cache: null argument");
+    *yes = f->cache ? 1 : 0;
     return KV_OK;
 }
 
@@ -146,6 +378,43 @@ extern "C" int kv_fastx_next(kv_fastx *f, uint64_t max_reads, int upload, kv_rea
     f->names.clear(); f->seqs.clear(); f->quals.clear();
     f->name_offs.assign(1, 0); f->seq_offs.assign(1, 0); f->qual_offs.assign(1, 0);
     f->is_fastq.clear();
+    if (f->cache) {
+        // whole blocks until max_reads would be exceeded (at least one): lengths, flags and packed words are
+        // concatenated and uploaded as they are; names are copied out (small), sequences and qualities stay in the
+        // file mapping and are produced per record on request (kv_fastx_record_text)
+        PackReader *c = f->cache;
+        c->batch.clear(); c->first.clear();
+        std::vector<uint32_t> lens, words;
+        std::vector<uint8_t> flags;
+        uint64_t n = 0;
+        for (;;) {
+            const size_t mark = c->pos;
+            PackBlock blk;
+            if (!pack_next_block(c, blk)) break;
+            if (n > 0 && n + blk.n > max_reads) { c->pos = mark; break; }
+            lens.insert(lens.end(), blk.len, blk.len + blk.n);
+            flags.insert(flags.end(), blk.flags, blk.flags + blk.n);
+            words.insert(words.end(), blk.words, blk.words + blk.n_words);
+            f->names.append(blk.names, blk.names_bytes);
+            for (uint32_t i = 0; i < blk.n; ++i) {
+                f->name_offs.push_back(f->name_offs.back() + blk.name_len[i]);
+                f->seq_offs.push_back(f->seq_offs.back() + blk.len[i]);
+                f->qual_offs.push_back(f->qual_offs.back() + blk.qual_len[i]);
+                f->is_fastq.push_back((blk.flags[i] >> 1) & 1u);
+            }
+            c->first.push_back(n);
+            n += blk.n;
+            c->batch.push_back(std::move(blk));
+        }
+        for (uint8_t &fl : flags) fl &= 1u;
+        f->num_reads += n;
+        *n_reads_out = n;
+        if (reads_out) {
+            *reads_out = nullptr;
+            if (upload && n > 0) return kv_reads_from_packed_var(words.data(), lens.data(), flags.data(), n, reads_out);
+        }
+        return KV_OK;
+    }
     std::string seq;
     uint64_t n = 0;
     const char *lp;
@@ -180,10 +449,48 @@ extern "C" int kv_fastx_next(kv_fastx *f, uint64_t max_reads, int upload, kv_rea
     }
     f->num_reads += n;
     *n_reads_out = n;
+    if (n == 0 && f->writer) {                       // the source is exhausted and every batch went through: publish the cache
+        pack_writer_finish(f->writer, true);
+        f->writer = nullptr;
+    }
     if (reads_out) {
         *reads_out = nullptr;
-        if (upload && n > 0) return kv_reads_create(f->seqs.data(), f->seq_offs.data(), n, reads_out);
+        if (upload && n > 0) {
+            const int rc = kv_reads_create(f->seqs.data(), f->seq_offs.data(), n, reads_out);
+            if (rc == KV_OK && f->writer) pack_write_batch(f->writer, f, *reads_out, n);
+            return rc;
+        }
     }
+    if (n > 0 && f->writer) {                        // a batch that was not uploaded has no packed form: give the cache up
+        pack_writer_finish(f->writer, false);
+        f->writer = nullptr;
+    }
+    return KV_OK;
+}
+
+// sequence and quality of record i of the batch last returned, reconstructed from the packed-read cache (cache-backed
+// handles only); buffers of seq_offs[i + 1] - seq_offs[i] and qual_offs[i + 1] - qual_offs[i] bytes
+extern "C" int kv_fastx_record_text(kv_fastx *f, uint64_t i, char *seq_out, char *qual_out)
+{
+    KV_REQUIRE(f && f->cache, KV_ERR_ARG, "kv_fastx_record_text: the handle does not stream from a packed-read cache");
+    std::lock_guard<std::mutex> lk(f->mu);
+    const PackReader *c = f->cache;
+    KV_REQUIRE(!c->batch.empty() && i < f->is_fastq.size(), KV_ERR_ARG, "kv_fastx_record_text: record %llu is not in the current batch",
+               (unsigned long long)i);
+    const size_t b = (size_t)(std::upper_bound(c->first.begin(), c->first.end(), i) - c->first.begin()) - 1;
+    const PackBlock &blk = c->batch[b];
+    const uint32_t r = (uint32_t)(i - c->first[b]);
+    if (seq_out) {
+        const uint32_t *w = blk.words + blk.woff[r];
+        const uint32_t len = blk.len[r];
+        for (uint32_t j = 0; j < len; ++j) seq_out[j] = "ACGT"[(w[j >> 4] >> (2 * (j & 15))) & 3u];
+        if (blk.flags[r] & 1u) {
+            const uint64_t lo = blk.boff[r], hi = lo + len;
+            for (const uint64_t *e = std::lower_bound(blk.exc_pos, blk.exc_pos + blk.n_exc, lo); e < blk.exc_pos + blk.n_exc && *e < hi; ++e)
+                seq_out[*e - lo] = (char)blk.exc_char[e - blk.exc_pos];
+        }
+    }
+    if (qual_out && blk.qual_len[r]) memcpy(qual_out, blk.quals + blk.qoff[r], blk.qual_len[r]);
     return KV_OK;
 }
 

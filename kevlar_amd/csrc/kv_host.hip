@@ -701,6 +701,79 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
     return KV_OK;
 }
 
+// reads that are already 2-bit packed on the host, any lengths: word offsets, tile table and uploads as kv_reads_create
+// builds them, minus the ASCII upload and the packing kernel (the packed-read cache of kv_fastx.hip comes through here)
+int kv_reads_from_packed_var(const uint32_t *words, const uint32_t *lens, const uint8_t *flags, uint64_t n_reads, kv_reads **out)
+{
+    KV_REQUIRE(out && ((words && lens) || n_reads == 0), KV_ERR_ARG, "kv_reads_from_packed_var: null argument");
+    KV_REQUIRE(n_reads < 0xFFFFFFF0ull, KV_ERR_ARG, "too many reads in one batch");
+    kv_reads *r = new kv_reads();
+    r->n_reads = n_reads;
+    r->d_words = nullptr; r->d_woff = nullptr; r->d_len = nullptr; r->d_flags = nullptr; r->d_tile = nullptr;
+    r->h_len.assign(lens, lens + n_reads);
+    std::vector<uint64_t> woff(n_reads + 1);
+    std::vector<TileDesc> tiles;
+    uint64_t nw = 0, nb = 0;
+    uint32_t max_len = 0;
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        woff[i] = nw;
+        nw += ((uint64_t)lens[i] + 15) / 16;
+        nb += lens[i];
+        if (lens[i] > max_len) max_len = lens[i];
+    }
+    woff[n_reads] = nw;
+    r->n_words = nw; r->n_bases = nb; r->max_len = max_len;
+    {
+        const uint32_t budget = KV_TILE_LDS_BYTES - 64;
+        uint32_t used = 0, count = 0, first = 0, run_bases = 0, most_bases = 0;
+        auto close_run = [&](uint32_t next_first) {
+            if (count) tiles.push_back(TileDesc{first, count, 0u, 0u});
+            most_bases = std::max(most_bases, run_bases);
+            used = 0; count = 0; first = next_first; run_bases = 0;
+        };
+        for (uint64_t i = 0; i < n_reads; ++i) {
+            const uint32_t need = 2 * ((r->h_len[i] + KV_READ_PAD + 3) & ~3u);
+            if (need > budget) {
+                close_run((uint32_t)i + 1);
+                for (uint32_t start = 0; start < r->h_len[i]; start += KV_SEG_BASES)
+                    tiles.push_back(TileDesc{(uint32_t)i, 1u, start, 1u});
+                most_bases = std::max<uint32_t>(most_bases, std::min<uint32_t>(r->h_len[i], KV_SEG_BASES + KV_MAX_K));
+                continue;
+            }
+            if (count > 0 && (count == KV_TILE_MAX_READS || used + need > budget)) close_run((uint32_t)i);
+            if (count == 0) first = (uint32_t)i;
+            used += need; count += 1; run_bases += r->h_len[i];
+        }
+        close_run((uint32_t)n_reads);
+        r->tile_max_bases = most_bases;
+        r->n_tiles = (uint32_t)tiles.size();
+        r->tile_lds_bytes = KV_TILE_LDS_BYTES + 256;
+        if (tiles.empty()) tiles.push_back(TileDesc{0u, 0u, 0u, 0u});
+    }
+    const uint64_t flag_bytes = ((n_reads + 3) & ~3ull) + 4;
+    hipStream_t st = kv_stream();
+    hipError_t e = hipMalloc((void **)&r->d_words, (nw + 4) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, flag_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, tiles.size() * sizeof(TileDesc));
+    if (e == hipSuccess && nw) e = hipMemcpyAsync(r->d_words, words, nw * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_words + nw, 0, 16, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_reads) e = hipMemcpyAsync(r->d_len, r->h_len.data(), n_reads * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_flags, 0, flag_bytes, st);
+    if (e == hipSuccess && n_reads && flags) e = hipMemcpyAsync(r->d_flags, flags, n_reads, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->d_tile, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        kv_set_error("read batch upload failed: %s", hipGetErrorString(e));
+        kv_reads_destroy(r);
+        return KV_ERR_HIP;
+    }
+    *out = r;
+    return KV_OK;
+}
+
 extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, uint32_t read_len, kv_reads **out)
 {
     KV_REQUIRE(out && (words || n_reads == 0), KV_ERR_ARG, "kv_reads_create_packed: null argument");

@@ -82,6 +82,8 @@ struct kv_reads {
     uint64_t nk_cached = 0;
 };
 
+int kv_reads_from_packed_var(const uint32_t *words, const uint32_t *lens, const uint8_t *flags, uint64_t n_reads, kv_reads **out);
+
 // hits of one scan in pinned host memory (fast DMA from the device; the Python side views it in place).
 // Blocks come from a small recycling pool (kv_host.hip): hipHostMalloc costs ~1 ms per call, more than
 // copying the hits of a whole scan.

@@ -155,21 +155,27 @@ class TextBatch(object):
     """One parsed batch: the packed reads in HBM (optional) plus the records' text as blobs.
     Python Read objects are only built on demand (record(i))."""
 
-    def __init__(self, n, names, name_offs, seqs, seq_offs, quals, qual_offs, is_fastq, batch):
+    def __init__(self, n, names, name_offs, seqs, seq_offs, quals, qual_offs, is_fastq, batch, fetch=None):
         self.n = n
         self._names, self._no = names, name_offs
         self._seqs, self._so = seqs, seq_offs
         self._quals, self._qo = quals, qual_offs
         self._fq = is_fastq
         self.batch = batch
+        self._fetch = fetch        # batches served from a packed-read cache: (sequence, quality) of record i on request
 
     def name(self, i):
         return self._names[self._no[i]:self._no[i + 1]].decode('latin-1')
 
     def sequence(self, i):
+        if self._fetch is not None:
+            return self._fetch(i, int(self._so[i + 1] - self._so[i]), 0)[0]
         return self._seqs[self._so[i]:self._so[i + 1]].decode('latin-1')
 
     def record(self, i):
+        if self._fetch is not None:
+            seq, qual = self._fetch(i, int(self._so[i + 1] - self._so[i]), int(self._qo[i + 1] - self._qo[i]) if self._fq[i] else 0)
+            return Read(self.name(i), seq, qual if self._fq[i] else None)
         qual = self._quals[self._qo[i]:self._qo[i + 1]].decode('latin-1') if self._fq[i] else None
         return Read(self.name(i), self.sequence(i), qual)
 
@@ -201,6 +207,14 @@ class ReadParser(object):
         self._lock = threading.Lock()
         self._pending = None
         self._cursor = 0
+        cached = ctypes.c_int()
+        check(_lib.load().kv_fastx_from_cache(handle, ctypes.byref(cached)))
+        self.from_cache = bool(cached.value)     # streaming FILE.kvpack (KEVLAR_PACK_CACHE=1) instead of parsing FILE
+
+    def _record_text(self, i, seqlen, quallen):
+        seq, qual = ctypes.create_string_buffer(seqlen + 1), ctypes.create_string_buffer(quallen + 1)
+        check(_lib.load().kv_fastx_record_text(self._h, int(i), seq, qual))
+        return seq.raw[:seqlen].decode('latin-1'), qual.raw[:quallen].decode('latin-1')
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -256,9 +270,13 @@ class ReadParser(object):
             seq_offs = np.ctypeslib.as_array(so, shape=(n + 1,)).copy()
             qual_offs = np.ctypeslib.as_array(qo, shape=(n + 1,)).copy()
             is_fastq = np.ctypeslib.as_array(fq, shape=(n,)).copy()
-            tb = TextBatch(n, ctypes.string_at(names, int(name_offs[n])), name_offs,
-                           ctypes.string_at(seqs, int(seq_offs[n])), seq_offs,
-                           ctypes.string_at(quals, int(qual_offs[n])), qual_offs, is_fastq, batch)
+            if self.from_cache:        # sequences and qualities stay in the cache file until a record is asked for
+                tb = TextBatch(n, ctypes.string_at(names, int(name_offs[n])), name_offs, None, seq_offs, None, qual_offs,
+                               is_fastq, batch, fetch=self._record_text)
+            else:
+                tb = TextBatch(n, ctypes.string_at(names, int(name_offs[n])), name_offs,
+                               ctypes.string_at(seqs, int(seq_offs[n])), seq_offs,
+                               ctypes.string_at(quals, int(qual_offs[n])), qual_offs, is_fastq, batch)
         return tb
 
     def text_batches(self, max_reads, upload=True):
