@@ -10,17 +10,20 @@
 #define BIN_MAX_T 4         // tables handled by the partitioned path
 #define BIN_MAX_F 512       // slices per coarse bucket (9 bits of a coarse item)
 
-// A coarse item (stage A -> stage B) is one u32:
-//   bits  0..15  offset of the bin inside its 65536-bin slice
-//   bits 16..24  slice inside the coarse bucket (< F <= 512)
-//   bits 25..31  weighted items only: increment - 1 (one item adds 1..128 to its bin; saturating adds commute,
-//                so a k-mer seen c times in a batch is one item of weight c instead of c items)
-// A fine item (stage B -> stage C) is the u16 offset, or for weighted items offset | increment << 16.
+// A coarse item (stage A -> stage B) is one u32.  Unweighted (one item per k-mer):
+//   bits  0..15  offset of the bin inside its 65536-bin slice        bits 16..24  slice inside the coarse bucket (< F <= 512)
+// Weighted (one item per distinct k-mer of a batch; saturating adds commute, so a k-mer seen c times is one item of
+// weight c instead of c items): the same layout plus bits 25..31 = weight - 1.  (A 32768-bin variant exists behind
+// KV_BIN_SLICE15=1 -- offset 15 bits, slice 10 bits -- it measured no faster, see kv_bin_plan.)
+// A fine item (stage B -> stage C) is the u16 offset, or for weighted items offset | weight << 16.
 #define BIN_W_SHIFT 25
 #define BIN_W_MAX 128u
+#define BIN_SLICE_BITS 16      // unweighted path
+#define BIN_SLICE_BITS_W 15    // weighted path
 
 struct BinGeom {
     int T, F, C;                     // tables, slices per coarse bucket, coarse buckets in use (<= BIN_C)
+    int sbits;                       // log2 of the bins per slice (BIN_SLICE_BITS or BIN_SLICE_BITS_W)
     uint32_t ringA, ringB;           // LDS ring entries per stream in stages A / B (powers of two)
     uint32_t recipF;                 // floor(2^32 / F) + 1: slice / F by multiply-high
     uint32_t nslices[BIN_MAX_T];

@@ -42,6 +42,7 @@ namespace {
 #define BIN_B_ITEMS 8       // items per thread per round in stage B
 #define BIN_B_BUDGET 16384  // LDS ring entries per stage-B workgroup
 #define BIN_C_THREADS 1024
+#define BIN_CW_THREADS 512   // weighted stage C: 32-KB slices, four workgroups per CU
 #define BIN_MAX_SEG 512      // stage-B writers per slice (nwgB)
 
 // ---- LDS write-combining rings ------------------------------------------------------------
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_list(
 
 // ---- stage B -----------------------------------------------------------------------------
 // W = weighted items (kv_binned.h): a coarse item carries its increment in bits 25..31 and leaves as offset | increment << 16
-template <bool W>
+template <bool W, int SBITS>
 __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
 {
     typedef typename std::conditional<W, uint32_t, uint16_t>::type Out;
@@ -443,14 +444,15 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
         if ((threadIdx.x & 63) < per_wave && mine < F) seg_base = (((uint64_t)s * F + mine) * g.nwgB + blockIdx.x) * g.cap2;
     }
     Out *gbuf2 = (Out *)g.gbuf2;
-    auto slice_of = [](uint32_t item) { return W ? (item >> 16) & (BIN_MAX_F - 1u) : item >> 16; };
-    auto fine_of = [](uint32_t item) { return W ? (Out)((item & 0xffffu) | (((item >> BIN_W_SHIFT) + 1u) << 16)) : (Out)(item & 0xffffu); };
+    constexpr uint32_t SB = SBITS, OFFMASK = (1u << SB) - 1u;
+    auto slice_of = [](uint32_t item) { return W ? (item >> SB) & ((1u << (BIN_W_SHIFT - SB)) - 1u) : item >> SB; };
+    auto fine_of = [](uint32_t item) { return W ? (Out)((item & OFFMASK) | (((item >> BIN_W_SHIFT) + 1u) << 16)) : (Out)(item & OFFMASK); };
     auto spill_coarse = [&](uint32_t item) {
-        spill_item(g, (int)t, (((uint64_t)c * F + slice_of(item)) << 16) | (item & 0xffffu), W ? (item >> BIN_W_SHIFT) + 1u : 1u);
+        spill_item(g, (int)t, (((uint64_t)c * F + slice_of(item)) << SB) | (item & OFFMASK), W ? (item >> BIN_W_SHIFT) + 1u : 1u);
     };
     auto store = [&](uint64_t idx, Out off) { gbuf2[idx] = off; };
     auto overflow = [&](uint32_t fi, Out off) {
-        spill_item(g, (int)t, (((uint64_t)c * F + fi) << 16) | ((uint32_t)off & 0xffffu), W ? (uint32_t)off >> 16 : 1u);
+        spill_item(g, (int)t, (((uint64_t)c * F + fi) << SB) | ((uint32_t)off & OFFMASK), W ? (uint32_t)off >> 16 : 1u);
     };
     // Weighted items are u32: rings of 32 entries (64 would leave room for one workgroup per CU only) and half as many
     // items per round, so that a round cannot overrun a ring that was below its flush threshold
@@ -667,20 +669,22 @@ __device__ __forceinline__ uint32_t lds_addw4(uint32_t *lds, const uint32_t (&w)
     return fresh;
 }
 
-template <int STORAGE, bool W>
-__global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__restrict__ sk, BinGeom g)
+template <int STORAGE, bool W, int SBITS>
+__global__ __launch_bounds__(SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_THREADS) void k_bin_apply(const SketchDev *__restrict__ sk, BinGeom g)
 {
     typedef typename std::conditional<W, uint32_t, uint16_t>::type Item;
     constexpr uint32_t VEC = 16u / sizeof(Item);                  // items per 16-byte vector
-    __shared__ __attribute__((aligned(16))) uint32_t lds[16384];   // one slice: 65536 counters of <= 8 bits
+    constexpr uint32_t SB = SBITS, SLICE = 1u << SB;
+    constexpr uint32_t THREADS = SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_THREADS;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[SLICE / 4];   // one slice: 65536 (32768 weighted) counters of <= 8 bits
     const int t = blockIdx.y;
     const uint32_t slice = blockIdx.x;
     if (slice >= g.nslices[t] || g.ctr[1] != 0) return;    // overflow flag: leave the tables untouched for the fallback
     const uint32_t c = slice / (uint32_t)g.F, fidx = slice % (uint32_t)g.F;
     const uint64_t stream = ((uint64_t)t * g.C + c) * g.F + fidx;
     constexpr int storage = STORAGE;
-    const uint64_t bin0 = (uint64_t)slice << 16;
-    const uint64_t left = sk->size[t] - bin0, nb = left < 65536 ? left : 65536;
+    const uint64_t bin0 = (uint64_t)slice << SB;
+    const uint64_t left = sk->size[t] - bin0, nb = left < SLICE ? left : SLICE;
     // byte range of the slice inside the table (the allocation is padded to 16 B)
     const uint64_t byte0 = storage == ST_BYTE ? bin0 : (storage == ST_NIBBLE ? bin0 >> 1 : bin0 >> 3);
     const uint64_t nbytes = storage == ST_BYTE ? nb : (storage == ST_NIBBLE ? (nb + 1) / 2 : (nb + 7) / 8);
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
     // 16-byte vector never leaves its segment).  Their vectors are enumerated compactly through a
     // prefix sum over the segments (LDS), so every thread has work whatever the segment fill levels.
     __shared__ uint32_t seg_cnt[BIN_MAX_SEG], vpre[BIN_MAX_SEG];
-    __shared__ uint32_t wsum[BIN_C_THREADS / 64];
+    __shared__ uint32_t wsum[THREADS / 64];
     __shared__ uint32_t total_vec_sh;
     const Item *items = (const Item *)g.gbuf2 + stream * g.nwgB * g.cap2;
     const uint32_t *counts = g.gcnt2 + stream * g.nwgB;
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
         uint32_t before = 0;
         for (int w = 0; w < wave; ++w) before += wsum[w];
         if (threadIdx.x < g.nwgB) vpre[threadIdx.x] = before + incl - myv;
-        if (threadIdx.x == BIN_C_THREADS - 1) total_vec_sh = before + incl;
+        if (threadIdx.x == THREADS - 1) total_vec_sh = before + incl;
         __syncthreads();
     }
     const uint32_t total_vec = total_vec_sh;
@@ -733,18 +737,18 @@ __global__ __launch_bounds__(BIN_C_THREADS) void k_bin_apply(const SketchDev *__
         return r;
     };
     // software pipeline, two vectors ahead: item requests fly while the slice loads and while earlier items are applied
-    Vec v0 = fetch(threadIdx.x), v1 = fetch(threadIdx.x + BIN_C_THREADS);
-    for (uint32_t j = threadIdx.x; j < nvec; j += BIN_C_THREADS) l4[j] = tab[j];
+    Vec v0 = fetch(threadIdx.x), v1 = fetch(threadIdx.x + THREADS);
+    for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) l4[j] = tab[j];
     __syncthreads();
     uint32_t fresh = 0;
-    for (uint32_t v = threadIdx.x; v < total_vec; v += BIN_C_THREADS) {
-        const Vec v2 = fetch(v + 2 * BIN_C_THREADS);
+    for (uint32_t v = threadIdx.x; v < total_vec; v += THREADS) {
+        const Vec v2 = fetch(v + 2 * THREADS);
         const uint32_t w[4] = {v0.q.x, v0.q.y, v0.q.z, v0.q.w};
         fresh += W ? lds_addw4<STORAGE>(lds, w, v0.n) : lds_inc8<STORAGE>(lds, w, v0.n);
         v0 = v1; v1 = v2;
     }
     __syncthreads();
-    for (uint32_t j = threadIdx.x; j < nvec; j += BIN_C_THREADS) tab[j] = l4[j];
+    for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) tab[j] = l4[j];
     if (t == 0) {
         const uint64_t tot = wave_sum_u64(fresh);
         if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&g.ctr[3], (unsigned long long)tot);
@@ -853,12 +857,16 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
     plan->weighted = weighted;
     g.T = s->h.ntables;
     g.tile_lds = lds_front;
-    uint64_t pmin = UINT64_MAX;
+    uint64_t pmin = UINT64_MAX, pmax = 0;
+    for (int t = 0; t < g.T; ++t) { pmin = std::min(pmin, s->h.size[t]); pmax = std::max(pmax, s->h.size[t]); }
+    // 32768-bin slices for weighted items (KV_BIN_SLICE15=1) were measured at config 2: stage C 2.20 instead of 2.25 ms,
+    // stage B 1.26-1.36 instead of 1.0 ms -- stage C is not held back by the overlap of its phases; the default stays 65536
+    g.sbits = weighted && getenv("KV_BIN_SLICE15") && atoi(getenv("KV_BIN_SLICE15")) && ((pmax + 32767) >> 15) <= 64ull * 384ull
+                  ? BIN_SLICE_BITS_W : BIN_SLICE_BITS;
     uint32_t maxsl = 1;
     for (int t = 0; t < g.T; ++t) {
-        g.nslices[t] = (uint32_t)((s->h.size[t] + 65535) >> 16);
+        g.nslices[t] = (uint32_t)((s->h.size[t] + (1ull << g.sbits) - 1) >> g.sbits);
         maxsl = std::max(maxsl, g.nslices[t]);
-        pmin = std::min(pmin, s->h.size[t]);
     }
     plan->maxsl = maxsl;
     // Coarse buckets per table: as few as keep stage B's fan-out F at <= 384 slices per bucket (its u16 rings then
@@ -866,7 +874,9 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
     // beyond 2^30 bins.  Fewer buckets = fewer distinct lines per stage-A store instruction (that stage is bound by
     // L2 write requests): measured per 525 M k-mers into 5e8-bin tables, A/B/C = 10.5/5.0/4.0 ms with 32 buckets,
     // 8.7/4.9/4.0 with 20, 8.3/6.1/4.0 with 16 (F = 478: rings too big for three workgroups).
-    const int cmax = maxsl <= 32u * BIN_MAX_F ? (int)std::min<uint32_t>(32u, std::max<uint32_t>(4u, (maxsl + 383u) / 384u)) : BIN_C;
+    // (weighted items: up to 64 buckets with the 512-thread front end -- its cursors are sized by T * C -- and F <= 1024)
+    const int cmax = weighted && g.sbits == BIN_SLICE_BITS_W ? (int)std::min<uint32_t>(BIN_C, std::max<uint32_t>(4u, (maxsl + 383u) / 384u))
+                              : (maxsl <= 32u * BIN_MAX_F ? (int)std::min<uint32_t>(32u, std::max<uint32_t>(4u, (maxsl + 383u) / 384u)) : BIN_C);
     plan->cmax = cmax;
     g.F = (int)((maxsl + (uint32_t)cmax - 1) / (uint32_t)cmax);
     g.C = (int)((maxsl + (uint32_t)g.F - 1) / (uint32_t)g.F);
@@ -893,8 +903,9 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
         const uint64_t avg = (std::max<uint64_t>(work_units, 1) + g.nwgA - 1) / g.nwgA;
         g.quotaA = (uint32_t)std::min<uint64_t>(avg + avg / 2 + 1, 0xffffffffull);   // matches the 1.5x slack of cap1
     }
-    const double per_bucket = expected * std::min(1.0, (double)g.F * 65536.0 / (double)pmin);
-    const double per_slice = expected * std::min(1.0, 65536.0 / (double)pmin);
+    const double slice_bins = (double)(1u << g.sbits);
+    const double per_bucket = expected * std::min(1.0, (double)g.F * slice_bins / (double)pmin);
+    const double per_slice = expected * std::min(1.0, slice_bins / (double)pmin);
     g.nwgB = (uint32_t)std::max(1.0, std::min((double)std::min<uint32_t>(g.nwgA, 512), std::ceil(per_bucket / 524288.0)));
     const double m1 = per_bucket / g.nwgA, m2 = per_slice / g.nwgB;
     g.cap1 = kv_round_up((uint64_t)(m1 * 1.5 + 8.0 * std::sqrt(m1)) + 2048, 64);   // tiles are dealt dynamically: shares are uneven
@@ -925,28 +936,33 @@ int kv_bin_finish(kv_sketch *s, BinPlan &plan, bool added_from_ctr, uint64_t n_a
         KvProfScope prof(plan.weighted ? "k_bin_split_w" : "k_bin_split");
         const size_t isz = plan.weighted ? 4 : 2;
         const size_t lds = (((size_t)g.F * g.ringB * isz + 15) & ~(size_t)15) + (size_t)g.F * 2 * 4;
-        if (plan.weighted) {
-            ensure_dynamic_lds(k_bin_split<true>, lds);
-            hipLaunchKernelGGL(k_bin_split<true>, dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
+        if (plan.weighted && g.sbits == BIN_SLICE_BITS_W) {
+            ensure_dynamic_lds((k_bin_split<true, BIN_SLICE_BITS_W>), lds);
+            hipLaunchKernelGGL((k_bin_split<true, BIN_SLICE_BITS_W>), dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
+        } else if (plan.weighted) {
+            ensure_dynamic_lds((k_bin_split<true, BIN_SLICE_BITS>), lds);
+            hipLaunchKernelGGL((k_bin_split<true, BIN_SLICE_BITS>), dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
         } else {
-            ensure_dynamic_lds(k_bin_split<false>, lds);
-            hipLaunchKernelGGL(k_bin_split<false>, dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
+            ensure_dynamic_lds((k_bin_split<false, BIN_SLICE_BITS>), lds);
+            hipLaunchKernelGGL((k_bin_split<false, BIN_SLICE_BITS>), dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
         }
     }
     {
         KvProfScope prof(plan.weighted ? "k_bin_apply_w" : "k_bin_apply");
         const dim3 gridC(plan.maxsl, (unsigned)g.T);
         const SketchDev *d = (const SketchDev *)s->d_desc;
-#define KV_LAUNCH_APPLY(ST_, W_) hipLaunchKernelGGL((k_bin_apply<ST_, W_>), gridC, dim3(BIN_C_THREADS), 0, st, d, g)
-        if (plan.weighted) {
-            if (s->h.storage == ST_BYTE) KV_LAUNCH_APPLY(ST_BYTE, true);
-            else if (s->h.storage == ST_NIBBLE) KV_LAUNCH_APPLY(ST_NIBBLE, true);
-            else KV_LAUNCH_APPLY(ST_BIT, true);
-        } else {
-            if (s->h.storage == ST_BYTE) KV_LAUNCH_APPLY(ST_BYTE, false);
-            else if (s->h.storage == ST_NIBBLE) KV_LAUNCH_APPLY(ST_NIBBLE, false);
-            else KV_LAUNCH_APPLY(ST_BIT, false);
-        }
+#define KV_LAUNCH_APPLY(ST_, W_, SB_) \
+        hipLaunchKernelGGL((k_bin_apply<ST_, W_, SB_>), gridC, dim3(SB_ == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_THREADS), 0, st, d, g)
+#define KV_LAUNCH_APPLY_ST(W_, SB_)                                               \
+        do {                                                                       \
+            if (s->h.storage == ST_BYTE) KV_LAUNCH_APPLY(ST_BYTE, W_, SB_);        \
+            else if (s->h.storage == ST_NIBBLE) KV_LAUNCH_APPLY(ST_NIBBLE, W_, SB_); \
+            else KV_LAUNCH_APPLY(ST_BIT, W_, SB_);                                 \
+        } while (0)
+        if (plan.weighted && g.sbits == BIN_SLICE_BITS_W) KV_LAUNCH_APPLY_ST(true, BIN_SLICE_BITS_W);
+        else if (plan.weighted) KV_LAUNCH_APPLY_ST(true, BIN_SLICE_BITS);
+        else KV_LAUNCH_APPLY_ST(false, BIN_SLICE_BITS);
+#undef KV_LAUNCH_APPLY_ST
 #undef KV_LAUNCH_APPLY
     }
     {

@@ -588,10 +588,10 @@ __global__ __launch_bounds__(SKM_THREADS3) void k_skm_count(SkmGeom sg, const Sk
     uint32_t *my_seg = g.gbuf1 + (uint64_t)blockIdx.x * g.cap1;          // + stream * seg_stride: this workgroup's segment of a stream
     const uint64_t seg_stride = (uint64_t)g.nwgA * g.cap1;
     auto emit = [&](int t, uint64_t bin, uint32_t wgt) {
-        const uint32_t slice = (uint32_t)(bin >> 16);
+        const uint32_t slice = (uint32_t)(bin >> g.sbits);
         const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
         const uint32_t sidx = (uint32_t)t * (uint32_t)g.C + c;
-        const uint32_t item = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu) | ((wgt - 1u) << BIN_W_SHIFT);
+        const uint32_t item = ((slice - c * (uint32_t)g.F) << g.sbits) | ((uint32_t)bin & ((1u << g.sbits) - 1u)) | ((wgt - 1u) << BIN_W_SHIFT);
         const uint32_t pos = atomicAdd(&cur[sidx], 1u);
         if (pos < cap1) my_seg[sidx * seg_stride + pos] = item;
         else spill_item(g, t, bin, wgt);
