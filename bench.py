@@ -75,6 +75,9 @@ def parse_args():
     p.add_argument('--e2e-reads', type=int, default=500000, help='reads per sample written as FASTQ for the end-to-end leg')
     p.add_argument('--no-e2e', action='store_true')
     p.add_argument('--no-replay', action='store_true', help='skip the banded replays behind banded_checksums / replay_checksum')
+    p.add_argument('--exchange-items', default='distinct', choices=['distinct', 'plain'],
+                   help='--multi exchange: what the count sends -- (hash, occurrences) pairs of each rank\'s deduplicated shard '
+                        '(kv_route_distinct), or one hash per k-mer')
     p.add_argument('--multi', default='auto', choices=['auto', 'exchange', 'banded'],
                    help='N>1: exchange = shard the reads, hash once, all-to-all the hashes by band (kevlar_amd/shardrun.py); '
                         'banded = every rank streams all reads and keeps its band; auto = exchange from 4 GPUs up')
@@ -222,11 +225,17 @@ def main():
         for n in names:
             sketches[n].clear()
         kmers = 0
-        pending = run.start(batches[names[0]][0], bounds[names[0]][0], True)
+        distinct = args.exchange_items == 'distinct'
+        # counts travel as (hash, occurrences) pairs of each rank's deduplicated shard; the case sample's
+        # (hash, tag) pairs travel besides them, for the scan only
+        tagged = run.start(batches[names[0]][0], bounds[names[0]][0], True)
+        pending = run.start(batches[names[0]][0], bounds[names[0]][0], False, distinct=True) if distinct else tagged
         for i, n in enumerate(names):
-            nxt = run.start(batches[names[i + 1]][0], bounds[names[i + 1]][0], False) if i + 1 < len(names) else None
-            kmers += run.finish(pending, sketches[n], keep_for_scan=(i == 0))
+            nxt = run.start(batches[names[i + 1]][0], bounds[names[i + 1]][0], False, distinct=distinct) if i + 1 < len(names) else None
+            kmers += run.finish(pending, sketches[n], keep_for_scan=(i == 0 and not distinct))
             pending = nxt
+        if distinct:
+            run.finish(tagged, None, keep_for_scan=True)
         t_b = time.perf_counter()
         r, o, a = run.scan([sketches['proband']], [sketches[n] for n in controls], args.case_min, args.ctrl_max)
         t_c = time.perf_counter()
@@ -385,8 +394,9 @@ def main():
                                 args.workload, wl['label'], wl['genome_mb'], wl['coverage'], L, k, n_reads, S,
                                 wl['memory'] / 1e9, T, args.case_min, args.ctrl_max),
                 'parallelism': 'single band' if world == 1 else (
-                    '{} k-mer bands, 1 per GPU; reads sharded, hashes exchanged by band (all-to-all); hits all-gathered (the '
-                    'per-band bit mask of north_star carries nothing beyond them)'.format(world) if exchange else
+                    '{} k-mer bands, 1 per GPU; reads sharded, {} exchanged by band (all-to-all); hits all-gathered (the '
+                    'per-band bit mask of north_star carries nothing beyond them)'.format(
+                        world, 'distinct (hash, occurrences) pairs' if args.exchange_items == 'distinct' else 'hashes') if exchange else
                     '{} k-mer bands, 1 per GPU; every rank streams all reads; hits all-gathered (the per-band bit mask of '
                     'north_star carries nothing beyond them)'.format(world)),
                 'read_batches_per_sample': len(batch_first), 'count_streams': args.count_streams,

@@ -222,6 +222,15 @@ int kv_hits_destroy(kv_hits *h);
  * function as in kv_hash_kmers.                                                                            */
 int kv_route_hashes(const kv_reads *reads, int kind, int ksize, int ndest, uint64_t read_index_base,
                     int with_tags, void *d_out, uint64_t cap_items, uint64_t *counts_out);
+/* kv_route_hashes for a count only, with the shard deduplicated first: an item is the pair (hash, occurrences
+ * in this shard) and there is one per distinct k-mer of a super-k-mer bucket (so at most -- and at sequencing
+ * coverage far fewer than -- one per k-mer; cap_items >= the k-mers of the shard still).  Same d_out layout
+ * and counts_out as kv_route_hashes with two-word items.                                                    */
+int kv_route_distinct(const kv_reads *reads, int kind, int ksize, int ndest, void *d_out,
+                      uint64_t cap_items, uint64_t *counts_out);
+/* count n (hash, count) items resident in HBM: each adds min(count, 255) to its bins, saturating -- the tables
+ * end up as if the hash had been counted `count` times.  *n_added_out = sum of the counts.                  */
+int kv_consume_hashes_weighted(kv_sketch *s, const void *d_items, uint64_t n, uint64_t *n_added_out);
 /* count n hashes resident in HBM, element i at ((uint64_t*)d_hashes)[i * stride_words]            */
 int kv_consume_hashes(kv_sketch *s, const void *d_hashes, uint64_t n, uint32_t stride_words,
                       uint64_t *n_added_out);
@@ -230,6 +239,16 @@ int kv_consume_hashes(kv_sketch *s, const void *d_hashes, uint64_t n, uint32_t s
 int kv_novel_scan_hashes(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl,
                          const void *d_items, uint64_t n_items, int case_min, int ctrl_max,
                          void *d_hit_tags, void *d_hit_abund, uint64_t hit_cap, uint64_t *n_hits);
+/* kv_novel_scan_hashes over the (hash, occurrences) pairs a band owner received of the case sample
+ * (kv_route_distinct): an interesting pair leaves as its hash (d_hit_hashes[i]) and abundances.    */
+int kv_novel_scan_distinct(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl,
+                           const void *d_items, uint64_t n_items, int case_min, int ctrl_max,
+                           void *d_hit_hashes, void *d_hit_abund, uint64_t hit_cap, uint64_t *n_hits);
+/* the scan of a read shard against a known set of interesting k-mers: d_hashes[n] (entries ~0 are
+ * padding) with d_abund[n * nsamples]; every k-mer of `reads` whose hash is in the set is a hit, with
+ * the set's abundances; reads with non-ACGT are skipped as in kv_novel_scan; (read, offset) order.  */
+int kv_novel_scan_set(const kv_reads *reads, int kind, int ksize, int nsamples, const void *d_hashes,
+                      const void *d_abund, uint64_t n, kv_hits **out);
 /* sort n_total gathered (tag, abundances) hits by tag; the n_valid smallest are real (padding has
  * tag ~0) and come back as an ordinary kv_hits in (read, offset) order                            */
 int kv_hits_from_tagged(const void *d_tags, const void *d_abund, uint64_t n_total, uint64_t n_valid,

@@ -89,7 +89,11 @@ SIGNATURES = {
     'kv_hits_destroy': (i32, [vp]),
     'kv_route_hashes': (i32, [vp, i32, i32, i32, u64, i32, vp, u64, u64p]),
     'kv_consume_hashes': (i32, [vp, vp, u64, ctypes.c_uint32, u64p]),
+    'kv_route_distinct': (i32, [vp, i32, i32, i32, vp, u64, u64p]),
+    'kv_consume_hashes_weighted': (i32, [vp, vp, u64, u64p]),
     'kv_novel_scan_hashes': (i32, [vpp, i32, vpp, i32, vp, u64, i32, i32, vp, vp, u64, u64p]),
+    'kv_novel_scan_distinct': (i32, [vpp, i32, vpp, i32, vp, u64, i32, i32, vp, vp, u64, u64p]),
+    'kv_novel_scan_set': (i32, [vp, i32, i32, i32, vp, vp, u64, vpp]),
     'kv_hits_from_tagged': (i32, [vp, vp, u64, u64, i32, vpp]),
     'kv_readgraph_components': (i32, [vp, i32, u32p, u32p, u64, u32p, u32, u32, u32, u32p, u64p]),
 }

@@ -366,7 +366,9 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash_
 // stage A over a list of hashes already in HBM (read-sharded multi-GPU count: the hashes of this
 // rank's band arrive from the other ranks, kv_shard.hip).  Element i sits at list[i * stride].
 #define BIN_LIST_ROUNDS 16
-template <int THREADS>
+// W: the list holds (hash, count) pairs -- element i at list[i * stride], its count at list[i * stride + 1] -- and the
+// items carry min(count, 255) as their weight (what a band owner receives from ranks that deduplicated their shards)
+template <int THREADS, bool W>
 __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_list(
     const uint64_t *__restrict__ list, uint64_t n, uint32_t stride, const SketchDev *__restrict__ sk, BinGeom g)
 {
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_list(
     const uint32_t ns = (uint32_t)(g.T * g.C);
     for (uint32_t s = threadIdx.x; s < ns; s += THREADS) cur[s] = 0;
     const uint64_t chunk = (uint64_t)THREADS * BIN_LIST_ROUNDS;
+    uint64_t n_added = 0;
     for (uint32_t taken = 0; taken < g.quotaA; ++taken) {
         __syncthreads();
         if (threadIdx.x == 0) next_chunk = (uint64_t)atomicAdd(&g.ctr[4], 1ull);
@@ -383,39 +386,52 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_list(
         const uint64_t i0 = next_chunk * chunk;
         if (i0 >= n) break;
         uint64_t idx = i0 + threadIdx.x;
-        uint64_t h_next = idx < n ? list[idx * stride] : 0;
+        uint64_t h_next = idx < n ? list[idx * stride] : 0, c_next = (W && idx < n) ? list[idx * stride + 1] : 1;
         for (int round = 0; round < BIN_LIST_ROUNDS; ++round) {
-            const uint64_t h = h_next;
+            const uint64_t h = h_next, count = c_next;
             const bool live = idx < n;
             idx += THREADS;
-            if (round + 1 < BIN_LIST_ROUNDS && idx < n) h_next = list[idx * stride];   // flies while this one is routed
-            if (!live) continue;
-            uint32_t sidx[BIN_MAX_T], item[BIN_MAX_T], pos[BIN_MAX_T];
-            uint64_t bins[BIN_MAX_T];
-#pragma unroll
-            for (int t = 0; t < BIN_MAX_T; ++t) {
-                if (t >= g.T) break;
-                const uint64_t bin = fastmod(h, sk->size[t], sk->magic[t]);
-                const uint32_t slice = (uint32_t)(bin >> 16);
-                const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
-                bins[t] = bin;
-                item[t] = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu);
-                sidx[t] = (uint32_t)t * (uint32_t)g.C + c;
+            if (round + 1 < BIN_LIST_ROUNDS && idx < n) {   // flies while this one is routed
+                h_next = list[idx * stride];
+                if (W) c_next = list[idx * stride + 1];
             }
+            if (!live) continue;
+            n_added += count;
+            uint32_t left = W ? (uint32_t)min(count, (uint64_t)255) : 1u;
+            while (left) {
+                const uint32_t wgt = W ? min(left, BIN_W_MAX) : 1u;
+                left -= wgt;
+                uint32_t sidx[BIN_MAX_T], item[BIN_MAX_T], pos[BIN_MAX_T];
+                uint64_t bins[BIN_MAX_T];
 #pragma unroll
-            for (int t = 0; t < BIN_MAX_T; ++t)
-                if (t < g.T) pos[t] = atomicAdd(&cur[sidx[t]], 1u);
+                for (int t = 0; t < BIN_MAX_T; ++t) {
+                    if (t >= g.T) break;
+                    const uint64_t bin = fastmod(h, sk->size[t], sk->magic[t]);
+                    const uint32_t slice = (uint32_t)(bin >> g.sbits);
+                    const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
+                    bins[t] = bin;
+                    item[t] = ((slice - c * (uint32_t)g.F) << g.sbits) | ((uint32_t)bin & ((1u << g.sbits) - 1u)) | (W ? (wgt - 1u) << BIN_W_SHIFT : 0u);
+                    sidx[t] = (uint32_t)t * (uint32_t)g.C + c;
+                }
 #pragma unroll
-            for (int t = 0; t < BIN_MAX_T; ++t) {
-                if (t >= g.T) break;
-                if (pos[t] < g.cap1) g.gbuf1[((uint64_t)sidx[t] * g.nwgA + blockIdx.x) * g.cap1 + pos[t]] = item[t];
-                else spill_item(g, t, bins[t]);
+                for (int t = 0; t < BIN_MAX_T; ++t)
+                    if (t < g.T) pos[t] = atomicAdd(&cur[sidx[t]], 1u);
+#pragma unroll
+                for (int t = 0; t < BIN_MAX_T; ++t) {
+                    if (t >= g.T) break;
+                    if (pos[t] < g.cap1) g.gbuf1[((uint64_t)sidx[t] * g.nwgA + blockIdx.x) * g.cap1 + pos[t]] = item[t];
+                    else spill_item(g, t, bins[t], wgt);
+                }
             }
         }
     }
     __syncthreads();
     for (uint32_t s = threadIdx.x; s < ns; s += THREADS)
         g.gcnt1[(uint64_t)s * g.nwgA + blockIdx.x] = (uint32_t)min((uint64_t)cur[s], g.cap1);
+    if (W) {
+        n_added = wave_sum_u64(n_added);
+        if ((threadIdx.x & 63) == 0 && n_added) atomicAdd(&g.ctr[2], (unsigned long long)n_added);
+    }
 }
 
 // ---- stage B -----------------------------------------------------------------------------
@@ -994,7 +1010,8 @@ int kv_bin_finish(kv_sketch *s, BinPlan &plan, bool added_from_ctr, uint64_t n_a
 
 // returns KV_OK, or KV_ERR_CAPACITY when the spill list overflowed (tables untouched: caller falls back)
 int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_list, uint32_t list_stride,
-                      const ConsumeFilter &filter, const kv_sketch *mask, uint64_t n_kmers, int nbands, uint64_t *n_added)
+                      const ConsumeFilter &filter, const kv_sketch *mask, uint64_t n_kmers, int nbands, uint64_t *n_added,
+                      bool weighted_list)
 {
     // source: the packed reads (hash in stage A) or, when reads == nullptr, n_kmers hashes at d_list[i * list_stride]
     hipStream_t st = kv_stream();
@@ -1006,7 +1023,7 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
         const uint32_t threadsA = maxsl <= 32u * BIN_MAX_F ? 512u : 1024u;
         const uint64_t work_units = reads ? reads->n_tiles
                                           : (n_kmers + (uint64_t)threadsA * BIN_LIST_ROUNDS - 1) / ((uint64_t)threadsA * BIN_LIST_ROUNDS);
-        const int rc = kv_bin_plan(s, n_kmers, nbands, filter.use_mask != 0, work_units, reads ? reads->tile_lds_bytes : 0u, 0u, false, &plan);
+        const int rc = kv_bin_plan(s, n_kmers, nbands, filter.use_mask != 0, work_units, reads ? reads->tile_lds_bytes : 0u, 0u, weighted_list, &plan);
         if (rc != KV_OK) return rc;
     }
     BinGeom &g = plan.g;
@@ -1054,13 +1071,12 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
 #undef KV_LAUNCH_BIN_DIRECT
 #undef KV_LAUNCH_BIN_HASH
     } else {
-        KvProfScope prof("k_bin_list");
-        if (cmax <= 32)
-            hipLaunchKernelGGL((k_bin_list<512>), dim3(g.nwgA), dim3(512), 0, st, d_list, n_kmers, list_stride,
-                               (const SketchDev *)s->d_desc, g);
-        else
-            hipLaunchKernelGGL((k_bin_list<1024>), dim3(g.nwgA), dim3(1024), 0, st, d_list, n_kmers, list_stride,
-                               (const SketchDev *)s->d_desc, g);
+        KvProfScope prof(weighted_list ? "k_bin_list_w" : "k_bin_list");
+        const SketchDev *d = (const SketchDev *)s->d_desc;
+        if (cmax <= 32 && weighted_list) hipLaunchKernelGGL((k_bin_list<512, true>), dim3(g.nwgA), dim3(512), 0, st, d_list, n_kmers, list_stride, d, g);
+        else if (cmax <= 32) hipLaunchKernelGGL((k_bin_list<512, false>), dim3(g.nwgA), dim3(512), 0, st, d_list, n_kmers, list_stride, d, g);
+        else if (weighted_list) hipLaunchKernelGGL((k_bin_list<1024, true>), dim3(g.nwgA), dim3(1024), 0, st, d_list, n_kmers, list_stride, d, g);
+        else hipLaunchKernelGGL((k_bin_list<1024, false>), dim3(g.nwgA), dim3(1024), 0, st, d_list, n_kmers, list_stride, d, g);
     }
-    return kv_bin_finish(s, plan, reads != nullptr, n_kmers, n_added);
+    return kv_bin_finish(s, plan, reads != nullptr || weighted_list, n_kmers, n_added);
 }

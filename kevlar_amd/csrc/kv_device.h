@@ -161,6 +161,39 @@ __device__ __forceinline__ bool table_inc(const SketchDev *s, int t, uint64_t h)
     }
 }
 
+// `weight` saturating increments of one bin in one CAS (min(max, v + weight) == weight single increments)
+__device__ __forceinline__ bool table_add(const SketchDev *s, int t, uint64_t h, uint32_t weight)
+{
+    const uint64_t bin = fastmod(h, s->size[t], s->magic[t]);
+    uint8_t *tab = s->tab[t];
+    if (s->storage == ST_BIT) {
+        const uint32_t bit = 1u << (bin & 31);
+        const uint32_t old = atomicOr((uint32_t *)tab + (bin >> 5), bit);
+        return (old & bit) == 0;
+    }
+    uint32_t *w;
+    uint32_t shift, maxv;
+    if (s->storage == ST_BYTE) {
+        w = (uint32_t *)(tab + (bin & ~3ull));
+        shift = (uint32_t)(bin & 3) * 8u;
+        maxv = 255u;
+    } else {
+        const uint64_t byte = bin >> 1;
+        w = (uint32_t *)(tab + (byte & ~3ull));
+        shift = (uint32_t)(byte & 3) * 8u + ((bin & 1) ? 0u : 4u);
+        maxv = 15u;
+    }
+    uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const uint32_t cur = (old >> shift) & maxv;
+        if (cur == maxv) return false;
+        const uint32_t next = min(maxv, cur + weight);
+        const uint32_t prev = atomicCAS(w, old, (old & ~(maxv << shift)) | (next << shift));
+        if (prev == old) return cur == 0;
+        old = prev;
+    }
+}
+
 __device__ __forceinline__ bool sketch_add(const SketchDev *s, uint64_t h)
 {
     bool is_new = false;

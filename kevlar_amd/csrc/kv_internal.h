@@ -137,17 +137,37 @@ struct ConsumeFilter {
 // partitioned count (kv_binned.hip)
 bool kv_binned_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_kmers, int nbands);
 int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_list, uint32_t list_stride,
-                      const ConsumeFilter &filter, const kv_sketch *mask, uint64_t n_kmers, int nbands, uint64_t *n_added);
+                      const ConsumeFilter &filter, const kv_sketch *mask, uint64_t n_kmers, int nbands, uint64_t *n_added,
+                      bool weighted_list = false);
 double kv_estimate_distinct(uint64_t occupied, uint64_t size);
 
 // super-k-mer front end (kv_skm.hip): the batch is deduplicated in minimizer buckets and each DISTINCT k-mer is
 // hashed, filtered and counted (or evaluated by the novel scan) once
 struct NovelParams;
 bool kv_skm_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_kmers, bool for_scan);
+bool kv_skm_eligible_kind(int hashfam, int ksize, const kv_reads *reads, uint64_t n_kmers, bool for_scan);
 int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &filter, const kv_sketch *mask,
                    uint64_t n_kmers, int nbands, uint64_t *n_added);
 // sets the mask bit of every interesting k-mer of reads[first_read:] (p.mask / p.mask_stride) and p.tile_count
 int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_kmers);
+
+// Read-sharded multi-GPU count (kv_shard.hip): where routed items go.  Every writer workgroup owns one private segment
+// per destination (= band = rank) and appends through a cursor in LDS; items that do not fit go to a shared overflow list.
+struct KvRouteSink {
+    int ndest;
+    uint32_t nwg;                // writer workgroups
+    uint64_t bs;                 // band width UINT64_MAX / ndest (kv_band_bounds)
+    uint64_t seg_cap;            // items per private segment
+    uint64_t *seg;               // [ndest][nwg][seg_cap] items of two words
+    uint32_t *seg_count;         // [ndest][nwg]
+    uint64_t *ovf;               // overflow items (two words each) and their destinations
+    uint8_t *ovf_dest;
+    uint64_t ovf_cap;
+    unsigned long long *ctr;     // kv_shard.hip RouteParams::ctr: [1] overflow items, [18 + d] overflow items of destination d
+};
+// (hash, count) of every DISTINCT k-mer of `reads` -- deduplicated in super-k-mer buckets -- routed by band.
+// `alloc(nwg, sink)` is called once the number of writers is known and must fill *sink.
+int kv_skm_route_distinct(const kv_reads *reads, int ksize, uint64_t n_kmers, int ndest, int (*alloc)(void *ctx, uint32_t nwg, KvRouteSink *sink), void *ctx);
 
 // tile geometry of the hashing kernels
 #define KV_TILE_THREADS 256

@@ -91,6 +91,27 @@ __global__ void k_add_hashes(const SketchDev *__restrict__ sk, const uint64_t *h
     if ((threadIdx.x & 63) == 0 && n_new) atomicAdd((unsigned long long *)&counters[1], (unsigned long long)n_new);
 }
 
+// items = (hash, count) pairs
+__global__ void k_add_hashes_weighted(const SketchDev *__restrict__ sk, const uint64_t *items, uint64_t n, uint64_t *counters)
+{
+    uint64_t n_new = 0, total = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = items[2 * i], count = items[2 * i + 1];
+        const uint32_t weight = (uint32_t)min(count, (uint64_t)255);
+        bool nw = false;
+        if (weight)
+            for (int t = 0; t < sk->ntables; ++t) nw |= table_add(sk, t, h, weight);
+        n_new += nw ? 1 : 0;
+        total += count;
+    }
+    n_new = wave_sum_u64(n_new);
+    total = wave_sum_u64(total);
+    if ((threadIdx.x & 63) == 0) {
+        if (n_new) atomicAdd((unsigned long long *)&counters[1], (unsigned long long)n_new);
+        if (total) atomicAdd((unsigned long long *)&counters[0], (unsigned long long)total);
+    }
+}
+
 // MurmurHash3_x64_128 (low word) of k characters produced one at a time by `at(j)`
 template <typename At>
 __device__ uint64_t murmur_chars(At at, int k)
@@ -418,5 +439,42 @@ extern "C" int kv_consume_hashes(kv_sketch *s, const void *d_hashes, uint64_t n,
     KV_HIP(hipStreamSynchronize(kv_stream()));
     s->n_unique += c[1];
     s->occ_dirty = true;
+    return KV_OK;
+}
+
+// The receive side once the sending ranks deduplicated their shards (kv_route_distinct): n items (hash, count); each adds
+// min(count, 255) to its bins in one saturating add, which leaves the tables exactly as `count` single increments do.
+// *n_added_out = sum of the counts = the k-mer occurrences the items stand for.
+extern "C" int kv_consume_hashes_weighted(kv_sketch *s, const void *d_items, uint64_t n, uint64_t *n_added_out)
+{
+    KV_REQUIRE(s && (d_items || n == 0), KV_ERR_ARG, "kv_consume_hashes_weighted: bad argument");
+    if (n_added_out) *n_added_out = 0;
+    if (n == 0) return KV_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->version++;
+    if (kv_binned_eligible(s, nullptr, n, 0)) {
+        const ConsumeFilter p = make_consume_filter(s->h.ksize, s->h.hashfam, 0, 0, false, 0, 0);
+        uint64_t added = 0;
+        const int rc = kv_consume_binned(s, nullptr, (const uint64_t *)d_items, 2, p, nullptr, n, 0, &added, true);
+        if (rc == KV_OK) {
+            if (n_added_out) *n_added_out = added;
+            return KV_OK;
+        }
+        if (rc != KV_ERR_CAPACITY) return rc;
+    }
+    KV_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(uint64_t), kv_stream()));
+    {
+        KvProfScope prof("k_add_hashes_weighted");
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 8192);
+        hipLaunchKernelGGL(k_add_hashes_weighted, dim3(grid), dim3(256), 0, kv_stream(), (const SketchDev *)s->d_desc,
+                           (const uint64_t *)d_items, n, s->d_counters);
+    }
+    KV_HIP(hipGetLastError());
+    uint64_t c[2] = {0, 0};
+    KV_HIP(hipMemcpyAsync(c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost, kv_stream()));
+    KV_HIP(hipStreamSynchronize(kv_stream()));
+    s->n_unique += c[1];
+    s->occ_dirty = true;
+    if (n_added_out) *n_added_out = c[0];
     return KV_OK;
 }

@@ -12,6 +12,7 @@
 // Hits therefore reach the host already sorted, in exactly the order the reference annotates
 // them, and the bit mask doubles as the per-band mask that the multi-GPU merge all-reduces.
 #include <algorithm>
+#include <functional>
 #include <map>
 
 #include "kv_novel_device.h"
@@ -218,7 +219,12 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_emit(ReadsDev rd, Nov
             const uint64_t h = kmer_hash_lds(sh.ascii, fwd, rc, p.hp);
             p.hit_read[slot] = read0 + r;
             p.hit_off[slot] = sh.seg_start + i;
-            for (int c = 0; c < S; ++c) p.hit_abund[slot * (uint64_t)S + c] = (uint8_t)sketch_get(p.sk[c], h);
+            if (p.set_keys) {
+                const uint64_t at = set_find(p, h);
+                for (int c = 0; c < S; ++c) p.hit_abund[slot * (uint64_t)S + c] = at != KV_SET_NONE ? p.set_abund[at * (uint64_t)S + c] : 0;
+            } else {
+                for (int c = 0; c < S; ++c) p.hit_abund[slot * (uint64_t)S + c] = (uint8_t)sketch_get(p.sk[c], h);
+            }
         }
         out += all;
         __syncthreads();
@@ -312,17 +318,7 @@ __global__ __launch_bounds__(256) void k_novel_emit_bits(ReadsDev rd, NovelParam
             const uint64_t slot = out + j;
             p.hit_read[slot] = (uint32_t)read;
             p.hit_off[slot] = off;
-            // a sample's T probes are independent loads (descriptors come from LDS): issued together, then reduced
-            for (int c2 = 0; c2 < S; ++c2) {
-                const int T = ns.ntab[c2];
-                uint32_t v[KV_MAX_TABLES];
-#pragma unroll
-                for (int t = 0; t < KV_MAX_TABLES; ++t) v[t] = t < T ? probe(ns, c2, t, h) : 255u;
-                uint32_t best = 255u;
-#pragma unroll
-                for (int t = 0; t < KV_MAX_TABLES; ++t) best = v[t] < best ? v[t] : best;
-                p.hit_abund[slot * (uint64_t)S + c2] = (uint8_t)best;
-            }
+            hit_abundances(ns, p, h, p.hit_abund + slot * (uint64_t)S);
         }
         out += chunk_hits;
         emitted += chunk_hits;
@@ -362,7 +358,7 @@ struct Arena {
         return e;
     }
 };
-struct ScanArenas { Arena work, hits; std::mutex mu; };   // mu: one scan at a time per stream
+struct ScanArenas { Arena work, hits, set; std::mutex mu; };   // mu: one scan at a time per stream
 std::map<hipStream_t, ScanArenas> g_scan_arenas;
 std::mutex g_scan_arenas_mu;
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -411,6 +407,9 @@ int attach_vcache(NovelParams &p, kv_sketch *const *ctrls, int ncase, int nctrl,
     return KV_OK;
 }
 
+int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers, bool use_skm, const std::function<int()> &prepare_tile_scan,
+               uint32_t *d_mask, uint64_t mask_stride, kv_hits **out);
+
 }  // namespace
 
 extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl,
@@ -442,13 +441,12 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     p.band_mode = band_mode; p.nbands = nbands; p.band = band;
     if (band_mode == KV_BAND_RANGE) kv_band_bounds(nbands, band, &p.band_lo, &p.band_hi);
     p.first_read = first_read;
-    const int S = ncase + nctrl;
     hipStream_t st = kv_stream();
     uint64_t n_kmers = 0;
     kv_reads_num_kmers(reads, k, &n_kmers);
     // large batches: evaluate every DISTINCT k-mer once over the batch's super-k-mer buckets (kv_skm.hip); otherwise
     // (and as the fallback) every k-mer of every read, with the verdict cache absorbing the repeats
-    bool use_skm = p.screen == 0 && kv_skm_eligible(cases[0], reads, n_kmers, true);
+    const bool use_skm = p.screen == 0 && kv_skm_eligible(cases[0], reads, n_kmers, true);
     auto prepare_tile_scan = [&]() -> int {
         const int rc = attach_vcache(p, ctrls, ncase, nctrl, ctrl_max, n_kmers, st);
         if (rc != KV_OK) return rc;
@@ -459,6 +457,18 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         }
         return KV_OK;
     };
+    return scan_reads(p, reads, fam, n_kmers, use_skm, prepare_tile_scan, d_mask, mask_stride, out);
+}
+
+namespace {
+
+// mark -> count per tile -> emit in (read, offset) order: shared by kv_novel_scan and kv_novel_scan_set
+int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers, bool use_skm, const std::function<int()> &prepare_tile_scan,
+               uint32_t *d_mask, uint64_t mask_stride, kv_hits **out)
+{
+    const int k = p.hp.k, S = p.ncase + p.nctrl;
+    const uint64_t min_stride = reads->max_len >= (uint32_t)k ? reads->max_len - (uint32_t)k + 1 : 1;
+    hipStream_t st = kv_stream();
     if (!use_skm) { const int rc = prepare_tile_scan(); if (rc != KV_OK) return rc; }
 
     kv_hits *hits = new kv_hits();
@@ -506,11 +516,12 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     uint64_t *d_tbase_p = (uint64_t *)wp;
     p.tile_base = d_tbase_p;
     uint64_t nhits = 0;
+    bool marked_by_skm = use_skm;
     if (e == hipSuccess && use_skm) {
         const int rc = kv_skm_novel_mark(reads, p, n_kmers);
         if (rc == KV_ERR_CAPACITY) {
             // every bit set so far is a true hit, so the tile scan can simply run on top of the same mask
-            use_skm = false;
+            marked_by_skm = false;
             const int rc2 = prepare_tile_scan();
             if (rc2 != KV_OK) { delete hits; *out = nullptr; return rc2; }
         } else if (rc != KV_OK) {
@@ -520,7 +531,7 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         }
     }
     if (e == hipSuccess) {
-        if (!use_skm) {
+        if (!marked_by_skm) {
             KvProfScope prof("k_novel_mark");
             kv_ensure_dynamic_lds((const void *)k_novel_mark, reads->tile_lds_bytes);
             hipLaunchKernelGGL(k_novel_mark, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, st, reads_dev(reads), p);
@@ -593,6 +604,8 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     return KV_OK;
 }
 
+}  // namespace
+
 extern "C" int kv_hits_shadow(const kv_hits *h, const uint32_t **read, const uint32_t **offset, uint64_t *n)
 {
     KV_REQUIRE(h && n, KV_ERR_ARG, "kv_hits_shadow: null argument");
@@ -655,7 +668,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void k_novel_list(NovelParams p, const uint64_t *__restrict__ items, uint64_t n,
                                                     uint64_t *hit_tag, uint8_t *hit_abund,
-                                                    unsigned long long *hit_count, uint64_t cap)
+                                                    unsigned long long *hit_count, uint64_t cap, bool want_hash)
 {
     __shared__ NovelShared ns;
     load_descs(ns, p);
@@ -709,7 +722,7 @@ __global__ __launch_bounds__(256) void k_novel_list(NovelParams p, const uint64_
             if (interesting) {
                 const uint64_t pos = first + (uint64_t)__popcll(ballot & ((1ull << lane) - 1ull));
                 if (pos < cap) {
-                    hit_tag[pos] = cur.tag;
+                    hit_tag[pos] = want_hash ? cur.h : cur.tag;
                     for (int c = 0; c < S; ++c) hit_abund[pos * (uint64_t)S + c] = (uint8_t)sketch_get(p.sk[c], cur.h);
                 }
             }
@@ -720,9 +733,32 @@ __global__ __launch_bounds__(256) void k_novel_list(NovelParams p, const uint64_
 
 }  // namespace
 
+namespace {
+int scan_items(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl, const void *d_items, uint64_t n_items,
+               int case_min, int ctrl_max, void *d_hit_tags, void *d_hit_abund, uint64_t hit_cap, uint64_t *n_hits, bool want_hash);
+}
+
 extern "C" int kv_novel_scan_hashes(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl,
                                     const void *d_items, uint64_t n_items, int case_min, int ctrl_max,
                                     void *d_hit_tags, void *d_hit_abund, uint64_t hit_cap, uint64_t *n_hits)
+{
+    return scan_items(cases, ncase, ctrls, nctrl, d_items, n_items, case_min, ctrl_max, d_hit_tags, d_hit_abund, hit_cap, n_hits, false);
+}
+
+// The same test over the (hash, occurrences) pairs a band owner received of the case sample (kv_route_distinct): every
+// interesting pair leaves as its HASH and the S abundances.  The same hash may arrive from several shards and then
+// leaves several times; kv_novel_scan_set does not mind.
+extern "C" int kv_novel_scan_distinct(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl,
+                                      const void *d_items, uint64_t n_items, int case_min, int ctrl_max,
+                                      void *d_hit_hashes, void *d_hit_abund, uint64_t hit_cap, uint64_t *n_hits)
+{
+    return scan_items(cases, ncase, ctrls, nctrl, d_items, n_items, case_min, ctrl_max, d_hit_hashes, d_hit_abund, hit_cap, n_hits, true);
+}
+
+namespace {
+
+int scan_items(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl, const void *d_items, uint64_t n_items,
+               int case_min, int ctrl_max, void *d_hit_tags, void *d_hit_abund, uint64_t hit_cap, uint64_t *n_hits, bool want_hash)
 {
     KV_REQUIRE(cases && n_hits && ncase >= 1 && nctrl >= 0 && (ctrls || nctrl == 0), KV_ERR_ARG,
                "kv_novel_scan_hashes: bad argument");
@@ -752,7 +788,7 @@ extern "C" int kv_novel_scan_hashes(kv_sketch *const *cases, int ncase, kv_sketc
         KvProfScope prof("k_novel_list");
         const unsigned grid = (unsigned)std::min<uint64_t>((n_items + 255) / 256, 256 * 16);
         hipLaunchKernelGGL(k_novel_list, dim3(grid), dim3(256), 0, st, p, (const uint64_t *)d_items, n_items,
-                           (uint64_t *)d_hit_tags, (uint8_t *)d_hit_abund, d_count.as<unsigned long long>(), hit_cap);
+                           (uint64_t *)d_hit_tags, (uint8_t *)d_hit_abund, d_count.as<unsigned long long>(), hit_cap, want_hash);
     }
     KV_HIP(hipGetLastError());
     unsigned long long cnt = 0;
@@ -762,4 +798,65 @@ extern "C" int kv_novel_scan_hashes(kv_sketch *const *cases, int ncase, kv_sketc
                (unsigned long long)hit_cap);
     *n_hits = cnt;
     return KV_OK;
+}
+
+__global__ void k_set_insert(unsigned long long *keys, uint8_t *abund, uint64_t mask, int S, const uint64_t *hashes,
+                             const uint8_t *hash_abund, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = hashes[i];
+        if (h == KV_SET_NONE) continue;            // padding of the all-gather
+        for (uint64_t slot = (h ^ (h >> 32)) & mask;; slot = (slot + 1) & mask) {
+            const unsigned long long prev = atomicCAS(&keys[slot], KV_SET_NONE, (unsigned long long)h);
+            if (prev == KV_SET_NONE) {
+                for (int c = 0; c < S; ++c) abund[slot * (uint64_t)S + c] = hash_abund[i * (uint64_t)S + c];
+                break;
+            }
+            if (prev == (unsigned long long)h) break;     // the same k-mer reported by another shard: same abundances
+        }
+    }
+}
+
+}  // namespace
+
+// The scan of a read shard once the interesting k-mers are known (read-sharded multi-GPU run): d_hashes[n] with
+// d_abund[n * nsamples] beside them -- every band owner's kv_novel_scan_distinct output, all-gathered; entries
+// ~0 are padding -- become a hash set, and every k-mer of `reads` (reads with non-ACGT skipped, as in kv_novel_scan)
+// whose hash is a member is a hit, reported with the abundances the set carries.  Hits leave in (read, offset) order.
+extern "C" int kv_novel_scan_set(const kv_reads *reads, int kind, int ksize, int nsamples, const void *d_hashes,
+                                 const void *d_abund, uint64_t n, kv_hits **out)
+{
+    KV_REQUIRE(reads && out && nsamples >= 1 && nsamples <= KV_MAX_SAMPLES && ksize >= 1, KV_ERR_ARG, "kv_novel_scan_set: bad argument");
+    KV_REQUIRE(n == 0 || (d_hashes && d_abund), KV_ERR_ARG, "kv_novel_scan_set: null buffer");
+    NovelParams p;
+    memset(&p, 0, sizeof(p));
+    const int fam = kv_hashfam_of(kind);
+    p.hp = make_hash_params(ksize, fam);
+    p.ncase = nsamples;
+    hipStream_t st = kv_stream();
+    ScanArenas *arenas;
+    {
+        std::lock_guard<std::mutex> lk(g_scan_arenas_mu);
+        arenas = &g_scan_arenas[st];
+    }
+    uint64_t slots = 1024;
+    while (slots < 2 * n + 64) slots <<= 1;
+    {
+        std::lock_guard<std::mutex> arena_lock(arenas->mu);
+        KV_HIP(arenas->set.need(up256(slots * 8) + up256(slots * (uint64_t)nsamples)));
+    }
+    unsigned long long *keys = (unsigned long long *)arenas->set.p;
+    uint8_t *abund = (uint8_t *)arenas->set.p + up256(slots * 8);
+    KV_HIP(hipMemsetAsync(keys, 0xFF, slots * 8, st));
+    if (n) {
+        KvProfScope prof("k_set_insert");
+        hipLaunchKernelGGL(k_set_insert, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, keys, abund, slots - 1,
+                           nsamples, (const uint64_t *)d_hashes, (const uint8_t *)d_abund, n);
+        KV_HIP(hipGetLastError());
+    }
+    p.set_keys = keys; p.set_abund = abund; p.set_mask = slots - 1;
+    uint64_t n_kmers = 0;
+    kv_reads_num_kmers(reads, ksize, &n_kmers);
+    const bool use_skm = kv_skm_eligible_kind(fam, ksize, reads, n_kmers, true);
+    return scan_reads(p, reads, fam, n_kmers, use_skm, []() { return KV_OK; }, nullptr, 0, out);
 }

@@ -23,7 +23,14 @@ struct NovelParams {
     int vcache_sets;              // k_novel_mark: 8-entry sets indexed by the k-mer's minimizer (0 = direct-mapped by hash)
     uint32_t vcache_set_mask;     // number of sets - 1
     int vcache_window;            // m-mers per k-mer considered for the minimizer
+    // Set mode (kv_novel_scan_set; the read-sharded multi-GPU scan): the interesting k-mers are already known -- the
+    // owners of the hash bands evaluated them -- and arrive as an open-addressing table of their hashes with the S
+    // abundances beside each; "interesting" is then membership, and no sketch is touched (sk[] unset, ncase = S).
+    const unsigned long long *set_keys;   // NULL = off; empty slots hold ~0 (no k-mer of any band hashes to it)
+    const uint8_t *set_abund;             // [slots][S]
+    uint64_t set_mask;                    // slots - 1
 };
+#define KV_SET_NONE 0xffffffffffffffffull
 
 // Table descriptors of every sample, copied to LDS once per workgroup: the probe loops then read
 // sizes / reciprocals / base pointers with broadcast LDS loads instead of three dependent global
@@ -47,8 +54,19 @@ __device__ __forceinline__ bool band_pass(const NovelParams &p, uint64_t h)
     return true;
 }
 
+// slot of hash h in the set, or KV_SET_NONE
+__device__ __forceinline__ uint64_t set_find(const NovelParams &p, uint64_t h)
+{
+    for (uint64_t slot = (h ^ (h >> 32)) & p.set_mask;; slot = (slot + 1) & p.set_mask) {
+        const unsigned long long key = p.set_keys[slot];
+        if (key == (unsigned long long)h) return slot;
+        if (key == KV_SET_NONE) return KV_SET_NONE;
+    }
+}
+
 __device__ __forceinline__ void load_descs(NovelShared &ns, const NovelParams &p)
 {
+    if (p.set_keys) return;
     const int S = p.ncase + p.nctrl;
     for (int i = threadIdx.x; i < S * KV_MAX_TABLES; i += blockDim.x) {
         const int c = i / KV_MAX_TABLES, t = i % KV_MAX_TABLES;
@@ -82,6 +100,7 @@ __device__ __forceinline__ uint32_t probe(const NovelShared &ns, int c, int t, u
 __device__ __forceinline__ bool novel_test_fast(const NovelShared &ns, const NovelParams &p, uint64_t h,
                                                 unsigned long long *slot, unsigned long long cached)
 {
+    if (p.set_keys) return h != KV_SET_NONE && set_find(p, h) != KV_SET_NONE;
     // 0 marks an empty cache entry, so the (one) k-mer hash 0 is never cached: it is always evaluated
     if (slot && h != 0 && cached == h) return false;
     // table 0 of every case first: a sequencing-error k-mer (case count 1) leaves here after one probe
@@ -102,6 +121,28 @@ __device__ __forceinline__ bool novel_test_fast(const NovelShared &ns, const Nov
             if ((int)probe(ns, c, t, h) < p.case_min) return false;
     }
     return true;
+}
+
+// the S abundances reported with a hit: Count-Min minimum of every sample, or what the set carries
+__device__ __forceinline__ void hit_abundances(const NovelShared &ns, const NovelParams &p, uint64_t h, uint8_t *out)
+{
+    const int S = p.ncase + p.nctrl;
+    if (p.set_keys) {
+        const uint64_t slot = set_find(p, h);
+        for (int c = 0; c < S; ++c) out[c] = slot != KV_SET_NONE ? p.set_abund[slot * (uint64_t)S + c] : 0;
+        return;
+    }
+    // a sample's T probes are independent loads (descriptors come from LDS): issued together, then reduced
+    for (int c = 0; c < S; ++c) {
+        const int T = ns.ntab[c];
+        uint32_t v[KV_MAX_TABLES];
+#pragma unroll
+        for (int t = 0; t < KV_MAX_TABLES; ++t) v[t] = t < T ? probe(ns, c, t, h) : 255u;
+        uint32_t best = 255u;
+#pragma unroll
+        for (int t = 0; t < KV_MAX_TABLES; ++t) best = v[t] < best ? v[t] : best;
+        out[c] = (uint8_t)best;
+    }
 }
 
 }  // namespace

@@ -22,6 +22,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include "kv_binned.h"
 #include "kv_device.h"
 
 namespace {
@@ -44,6 +45,7 @@ struct RouteParams {
     uint32_t nwg, quota;         // workgroups, tiles per workgroup at most
     uint64_t bs;                 // band width UINT64_MAX / ndest (kv_band_bounds)
     uint64_t read_base;          // global index of this shard's first read
+    int unit_tags;               // the "tag" of every item is the count 1 (kv_route_distinct's one-item-per-k-mer form)
     uint64_t seg_cap;            // items per private segment
     uint64_t *seg;               // [ndest][nwg][seg_cap] items (1 or 2 words each)
     uint32_t *seg_count;         // [ndest][nwg]
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(ROUTE_THREADS, 6) void k_route_hashes(ReadsDev rd, 
             if (TAGS) {
                 tag = ((p.read_base + read0 + r) << 16) | (uint64_t)(sh.seg_start + i);
                 if (flagged[r]) tag |= 1ull << 63;
+                if (p.unit_tags) tag = 1;
             }
             const uint32_t pos = atomicAdd(&cur[d], 1u);
             if (pos < p.seg_cap) {
@@ -208,6 +211,56 @@ std::mutex g_route_mu;
 
 inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
 
+// segments, overflow list and counters for p.nwg writers of at most n_kmers items of W words
+int route_scratch(RouteParams &p, uint64_t n_kmers, uint32_t W, hipStream_t st)
+{
+    const double m = 1.5 * (double)n_kmers / ((double)p.nwg * p.ndest);   // a full quota, spread evenly over the bands
+    p.seg_cap = round_up((uint64_t)(m * 1.1 + 8.0 * std::sqrt(m)) + 1024, 64);
+    p.ovf_cap = n_kmers;                                                    // worst case: no capacity error possible
+    const size_t b_seg = round_up((uint64_t)p.ndest * p.nwg * p.seg_cap * 8 * W, 256);
+    const size_t b_cnt = round_up((uint64_t)p.ndest * p.nwg * 4, 256), b_off = round_up((uint64_t)p.ndest * p.nwg * 8, 256);
+    const size_t b_ovf = round_up(p.ovf_cap * 8 * W, 256), b_od = round_up(p.ovf_cap, 256), b_ctr = 1024;
+    Scratch *scratch;
+    {
+        std::lock_guard<std::mutex> lk(g_route_mu);
+        scratch = &g_route_scratch[st];
+    }
+    KV_HIP(scratch->need(b_seg + b_cnt + b_off + b_ovf + b_od + b_ctr));
+    unsigned char *base = (unsigned char *)scratch->p;
+    p.seg = (uint64_t *)base; base += b_seg;
+    p.seg_count = (uint32_t *)base; base += b_cnt;
+    p.seg_off = (uint64_t *)base; base += b_off;
+    p.ovf = (uint64_t *)base; base += b_ovf;
+    p.ovf_dest = (uint8_t *)base; base += b_od;
+    p.ctr = (unsigned long long *)base;
+    KV_HIP(hipMemsetAsync(p.ctr, 0, b_ctr, st));
+    return KV_OK;
+}
+
+// pack the segments and the overflow tail into p.out, destination after destination; counts_out[d] = items of d
+int route_pack(RouteParams &p, uint32_t W, hipStream_t st, uint64_t *counts_out, unsigned long long *tiles_done)
+{
+    {
+        KvProfScope prof("k_route_compact");
+        hipLaunchKernelGGL(k_route_scan, dim3((unsigned)p.ndest), dim3(ROUTE_MAX_WG), 0, st, p);
+        hipLaunchKernelGGL(k_route_bases, dim3(1), dim3(64), 0, st, p);
+        if (W == 2) {
+            hipLaunchKernelGGL(k_route_compact<2>, dim3(p.nwg, (unsigned)p.ndest), dim3(256), 0, st, p);
+            hipLaunchKernelGGL(k_route_tail<2>, dim3(256), dim3(256), 0, st, p);
+        } else {
+            hipLaunchKernelGGL(k_route_compact<1>, dim3(p.nwg, (unsigned)p.ndest), dim3(256), 0, st, p);
+            hipLaunchKernelGGL(k_route_tail<1>, dim3(256), dim3(256), 0, st, p);
+        }
+    }
+    KV_HIP(hipGetLastError());
+    unsigned long long host[34];
+    KV_HIP(hipMemcpyAsync(host, p.ctr, sizeof(host), hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    *tiles_done = host[0];
+    for (int d = 0; d < p.ndest; ++d) counts_out[d] = host[2 + d] + host[18 + d];
+    return KV_OK;
+}
+
 __global__ void k_iota_u32(uint32_t *v, uint64_t n)
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
@@ -266,27 +319,8 @@ extern "C" int kv_route_hashes(const kv_reads *reads, int kind, int ksize, int n
     // dynamic hand-out, at most 1.5x the average share: bounds what one workgroup can put into a segment
     p.quota = (uint32_t)((reads->n_tiles + p.nwg - 1) / p.nwg);
     p.quota += p.quota / 2 + 1;
-    const double m = 1.5 * (double)n_kmers / ((double)p.nwg * ndest);   // a full quota, spread evenly over the bands
-    p.seg_cap = round_up((uint64_t)(m * 1.1 + 8.0 * std::sqrt(m)) + 1024, 64);
-    p.ovf_cap = n_kmers;                                                    // worst case: no capacity error possible
-    const size_t b_seg = round_up((uint64_t)ndest * p.nwg * p.seg_cap * 8 * W, 256);
-    const size_t b_cnt = round_up((uint64_t)ndest * p.nwg * 4, 256), b_off = round_up((uint64_t)ndest * p.nwg * 8, 256);
-    const size_t b_ovf = round_up(p.ovf_cap * 8 * W, 256), b_od = round_up(p.ovf_cap, 256), b_ctr = 1024;
     hipStream_t st = kv_stream();
-    Scratch *scratch;
-    {
-        std::lock_guard<std::mutex> lk(g_route_mu);
-        scratch = &g_route_scratch[st];
-    }
-    KV_HIP(scratch->need(b_seg + b_cnt + b_off + b_ovf + b_od + b_ctr));
-    unsigned char *base = (unsigned char *)scratch->p;
-    p.seg = (uint64_t *)base; base += b_seg;
-    p.seg_count = (uint32_t *)base; base += b_cnt;
-    p.seg_off = (uint64_t *)base; base += b_off;
-    p.ovf = (uint64_t *)base; base += b_ovf;
-    p.ovf_dest = (uint8_t *)base; base += b_od;
-    p.ctr = (unsigned long long *)base;
-    KV_HIP(hipMemsetAsync(p.ctr, 0, b_ctr, st));
+    { const int rc = route_scratch(p, n_kmers, W, st); if (rc != KV_OK) return rc; }
     {
         KvProfScope prof("k_route_hashes");
         const int nw = p.hp.hashfam == HF_MURMUR ? (ksize <= 32 ? 8 : (ksize <= 64 ? 16 : 0)) : 0;
@@ -303,25 +337,81 @@ extern "C" int kv_route_hashes(const kv_reads *reads, int kind, int ksize, int n
         }
 #undef KV_LAUNCH_ROUTE
     }
-    {
-        KvProfScope prof("k_route_compact");
-        hipLaunchKernelGGL(k_route_scan, dim3((unsigned)ndest), dim3(ROUTE_MAX_WG), 0, st, p);
-        hipLaunchKernelGGL(k_route_bases, dim3(1), dim3(64), 0, st, p);
-        if (with_tags) {
-            hipLaunchKernelGGL(k_route_compact<2>, dim3(p.nwg, (unsigned)ndest), dim3(256), 0, st, p);
-            hipLaunchKernelGGL(k_route_tail<2>, dim3(256), dim3(256), 0, st, p);
-        } else {
-            hipLaunchKernelGGL(k_route_compact<1>, dim3(p.nwg, (unsigned)ndest), dim3(256), 0, st, p);
-            hipLaunchKernelGGL(k_route_tail<1>, dim3(256), dim3(256), 0, st, p);
-        }
+    KV_HIP(hipGetLastError());
+    unsigned long long done = 0;
+    { const int rc = route_pack(p, W, st, counts_out, &done); if (rc != KV_OK) return rc; }
+    KV_REQUIRE(done >= reads->n_tiles, KV_ERR_HIP, "kv_route_hashes: %llu of %u tiles processed", done, reads->n_tiles);
+    return KV_OK;
+}
+
+// Like kv_route_hashes without tags, but the shard is deduplicated first (super-k-mer buckets, kv_skm.hip): an item
+// is the pair (hash, occurrences in this shard), one per DISTINCT k-mer of a bucket.  *n_items_out = items written.
+// Shards the bucketed path does not take (k outside 16..64, non-murmur hash, tiny or oversized inputs, or its loose
+// list overflowing) leave one (hash, 1) item per k-mer instead: the owner sees the same counts either way.
+extern "C" int kv_route_distinct(const kv_reads *reads, int kind, int ksize, int ndest, void *d_out, uint64_t cap_items,
+                                 uint64_t *counts_out)
+{
+    KV_REQUIRE(reads && d_out && counts_out, KV_ERR_ARG, "kv_route_distinct: null argument");
+    KV_REQUIRE(ndest >= 1 && ndest <= ROUTE_MAX_DEST, KV_ERR_ARG, "kv_route_distinct: 1..%d destinations, got %d", ROUTE_MAX_DEST, ndest);
+    KV_REQUIRE(ksize >= 1, KV_ERR_ARG, "kv_route_distinct: bad k");
+    uint64_t n_kmers = 0;
+    kv_reads_num_kmers(reads, ksize, &n_kmers);
+    KV_REQUIRE(cap_items >= n_kmers, KV_ERR_CAPACITY, "kv_route_distinct: the output needs room for the %llu k-mers of the shard",
+               (unsigned long long)n_kmers);
+    for (int d = 0; d < ndest; ++d) counts_out[d] = 0;
+    if (reads->n_tiles == 0 || n_kmers == 0) return KV_OK;
+    hipStream_t st = kv_stream();
+    const int hashfam = kv_hashfam_of(kind);
+    const char *force = getenv("KV_ROUTE_PATH");                 // "plain": tests pin the one-item-per-k-mer form
+    const uint64_t min_stride = reads->max_len >= (uint32_t)ksize ? reads->max_len - (uint32_t)ksize + 1 : 1;
+    bool bucketed = hashfam == HF_MURMUR && ksize >= 16 && ksize <= 64 && reads->tile_max_bases > 0 && reads->tile_max_bases <= 8192u &&
+                    (double)reads->n_reads * (double)min_stride < (double)(1ull << 40) && !(force && strcmp(force, "plain") == 0) &&
+                    (n_kmers >= (1ull << 20) || (force && strcmp(force, "skm") == 0));
+    RouteParams p;
+    if (bucketed) {
+        memset(&p, 0, sizeof(p));
+        p.ndest = ndest;
+        p.bs = UINT64_MAX / (uint64_t)ndest;
+        p.cap = cap_items;
+        p.out = (uint64_t *)d_out;
+        struct Ctx { RouteParams *p; uint64_t n_kmers; hipStream_t st; } ctx = {&p, n_kmers, st};
+        auto alloc = [](void *c, uint32_t nwg, KvRouteSink *sink) -> int {
+            Ctx *x = (Ctx *)c;
+            RouteParams &q = *x->p;
+            q.nwg = nwg;
+            const int rc = route_scratch(q, x->n_kmers, 2, x->st);
+            if (rc != KV_OK) return rc;
+            sink->ndest = q.ndest; sink->nwg = q.nwg; sink->bs = q.bs; sink->seg_cap = q.seg_cap; sink->seg = q.seg;
+            sink->seg_count = q.seg_count; sink->ovf = q.ovf; sink->ovf_dest = q.ovf_dest; sink->ovf_cap = q.ovf_cap; sink->ctr = q.ctr;
+            return KV_OK;
+        };
+        const int rc = kv_skm_route_distinct(reads, ksize, n_kmers, ndest, alloc, &ctx);
+        if (rc == KV_ERR_CAPACITY) bucketed = false;
+        else if (rc != KV_OK) return rc;
+    }
+    if (!bucketed) {
+        memset(&p, 0, sizeof(p));
+        p.hp = make_hash_params(ksize, hashfam);
+        p.ndest = ndest;
+        p.bs = UINT64_MAX / (uint64_t)ndest;
+        p.unit_tags = 1;
+        p.cap = cap_items;
+        p.out = (uint64_t *)d_out;
+        const size_t lds = reads->tile_lds_bytes;
+        const int per_cu = std::max(1, std::min(3, (int)(160 * 1024 / (lds + 2048))));
+        p.nwg = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(reads->n_tiles, (uint64_t)per_cu * (uint64_t)kv_device_cus()), ROUTE_MAX_WG);
+        p.quota = (uint32_t)((reads->n_tiles + p.nwg - 1) / p.nwg);
+        p.quota += p.quota / 2 + 1;
+        { const int rc = route_scratch(p, n_kmers, 2, st); if (rc != KV_OK) return rc; }
+        KvProfScope prof("k_route_hashes");
+        const int nw = p.hp.hashfam == HF_MURMUR ? (ksize <= 32 ? 8 : (ksize <= 64 ? 16 : 0)) : 0;
+        if (nw == 8) { kv_ensure_dynamic_lds((const void *)k_route_hashes<8, true>, lds); hipLaunchKernelGGL((k_route_hashes<8, true>), dim3(p.nwg), dim3(ROUTE_THREADS), lds, st, reads_dev(reads), reads->n_tiles, p); }
+        else if (nw == 16) { kv_ensure_dynamic_lds((const void *)k_route_hashes<16, true>, lds); hipLaunchKernelGGL((k_route_hashes<16, true>), dim3(p.nwg), dim3(ROUTE_THREADS), lds, st, reads_dev(reads), reads->n_tiles, p); }
+        else { kv_ensure_dynamic_lds((const void *)k_route_hashes<0, true>, lds); hipLaunchKernelGGL((k_route_hashes<0, true>), dim3(p.nwg), dim3(ROUTE_THREADS), lds, st, reads_dev(reads), reads->n_tiles, p); }
     }
     KV_HIP(hipGetLastError());
-    unsigned long long host[34];
-    KV_HIP(hipMemcpyAsync(host, p.ctr, sizeof(host), hipMemcpyDeviceToHost, st));
-    KV_HIP(hipStreamSynchronize(st));
-    KV_REQUIRE(host[0] >= reads->n_tiles, KV_ERR_HIP, "kv_route_hashes: %llu of %u tiles processed", host[0], reads->n_tiles);
-    for (int d = 0; d < ndest; ++d) counts_out[d] = host[2 + d] + host[18 + d];
-    return KV_OK;
+    unsigned long long done = 0;
+    return route_pack(p, 2, st, counts_out, &done);
 }
 
 // n_total gathered hits (tag, S abundance bytes each), of which the n_valid smallest tags are real

@@ -685,6 +685,109 @@ __global__ __launch_bounds__(256) void k_skm_loose_count(SkmGeom sg, const Sketc
     if ((threadIdx.x & 63) == 0 && n_added) atomicAdd(&g.ctr[2], (unsigned long long)n_added);
 }
 
+// ---- S3': route (read-sharded multi-GPU count) ---------------------------------------------------------------
+// Same walk as k_skm_count, but a distinct k-mer leaves as one (hash, count) item for the rank that owns the hash's
+// band instead of T bin items: what crosses xGMI shrinks by the shard's own coverage, and the owner adds each item
+// with one weighted saturating add per table (kv_consume_hashes_weighted).
+#define SKM_ROUTE_MAX_DEST 16
+__device__ __forceinline__ void skm_route_item(const KvRouteSink &rs, const uint64_t *lo, uint32_t *cur, uint64_t h, uint64_t count)
+{
+    if (h == UINT64_MAX) return;                 // the top hash value belongs to no band (kv_shard.hip)
+    uint32_t d = 0;
+    for (int b = 1; b < rs.ndest; ++b) d += h >= lo[b] ? 1u : 0u;
+    const uint32_t pos = cur ? atomicAdd(&cur[d], 1u) : 0xffffffffu;
+    if (pos < rs.seg_cap) {
+        *(ulonglong2 *)(rs.seg + (((uint64_t)d * rs.nwg + blockIdx.x) * rs.seg_cap + pos) * 2) = make_ulonglong2(h, count);
+    } else {
+        const unsigned long long o = atomicAdd(&rs.ctr[1], 1ull);
+        if (o < rs.ovf_cap) {
+            atomicAdd(&rs.ctr[18 + d], 1ull);
+            *(ulonglong2 *)(rs.ovf + 2 * o) = make_ulonglong2(h, count);
+            rs.ovf_dest[o] = (uint8_t)d;
+        }
+    }
+}
+
+template <int KW, int TS>
+__global__ __launch_bounds__(SKM_THREADS3) void k_skm_route(SkmGeom sg, HashParams hp, KvRouteSink rs)
+{
+    __shared__ SkmTable<KW, TS> tb;
+    __shared__ uint32_t cnt[TS];
+    __shared__ uint32_t next_bucket;
+    __shared__ uint32_t cur[SKM_ROUTE_MAX_DEST];
+    __shared__ uint64_t lo[SKM_ROUTE_MAX_DEST];
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
+    uint32_t *lut = dyn, *scratch = dyn + 256;
+    if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    if (threadIdx.x < (uint32_t)rs.ndest) { cur[threadIdx.x] = 0; lo[threadIdx.x] = rs.bs * (uint64_t)threadIdx.x; }
+    const int k = sg.k;
+    uint64_t n_distinct = 0;
+    skm_table_clear(tb);
+    for (uint32_t i = threadIdx.x; i < TS; i += SKM_THREADS3) cnt[i] = 0;
+    if (threadIdx.x == 0) next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET;
+    for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
+        __syncthreads();
+        const uint32_t b = next_bucket;
+        if (b >= sg.n_buckets) break;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
+            else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
+            else next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET;
+        }
+        skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t) {
+            const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
+            const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
+            if (slot >= 0) atomicAdd(&cnt[slot], 1u);
+            return slot < 0;
+        });
+        __syncthreads();
+        skm_for_occupied<TS>(tb.key[0], (uint16_t *)scratch, skm_wave_scratch_words(sg.sbw) * 2u, [&](uint32_t slot) {
+            SkmKey<KW> c;
+            c.w[0] = tb.key[0][slot];
+            tb.key[0][slot] = SKM_EMPTY;
+            if (KW == 2) { c.w[KW - 1] = tb.key[KW - 1][slot]; tb.key[KW - 1][slot] = SKM_EMPTY; }
+            const uint32_t seen = cnt[slot];
+            cnt[slot] = 0;
+            n_distinct += 1;
+            skm_route_item(rs, lo, cur, skm_key_hash<KW>(c, lut, hp), seen);
+        });
+    }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)rs.ndest)
+        rs.seg_count[(uint64_t)threadIdx.x * rs.nwg + blockIdx.x] = (uint32_t)min((uint64_t)cur[threadIdx.x], rs.seg_cap);
+    n_distinct = wave_sum_u64(n_distinct);
+    if ((threadIdx.x & 63) == 0 && n_distinct) atomicAdd(&sg.ctr[7], (unsigned long long)n_distinct);
+}
+
+// loose records: one item of count 1 per k-mer occurrence, through the overflow list
+template <int KW>
+__global__ __launch_bounds__(256) void k_skm_loose_route(SkmGeom sg, HashParams hp, KvRouteSink rs)
+{
+    __shared__ uint32_t lut[256];
+    __shared__ uint64_t lo[SKM_ROUTE_MAX_DEST];
+    if (sg.ctr[1] != 0) return;
+    lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    if (threadIdx.x < (uint32_t)rs.ndest) lo[threadIdx.x] = rs.bs * (uint64_t)threadIdx.x;
+    __syncthreads();
+    unsigned long long n = sg.ctr[0];
+    if (n > sg.loose_cap) n = sg.loose_cap;
+    const int k = sg.k, recw = sg.recw;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t *rec = sg.loose + i * (uint64_t)recw;
+        uint64_t bw[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
+        const uint32_t nk = skm_hdr_n(rec[0]);
+        SkmKey<KW> fw = skm_first_kmer<KW>(bw, k);
+        SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
+        for (uint32_t j = 0; j < nk; ++j) {
+            if (j) skm_roll<KW>(fw, rc, skm_base_at(bw, j + (uint32_t)k - 1u), k);
+            skm_route_item(rs, lo, nullptr, skm_key_hash<KW>(skm_canonical<KW>(fw, rc), lut, hp), 1ull);
+        }
+    }
+}
+
 // ---- S6: novel ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void skm_mark(const NovelParams &p, const ReadsDev &rd, uint64_t pos, uint64_t stride)
 {
@@ -814,6 +917,7 @@ struct SkmIndex {
     uint64_t reads_uid = 0;
     int k = 0;
     bool valid = false;
+    double distinct_hint = 0.0;     // distinct / all k-mers of the last batch routed on this stream (kv_skm_route_distinct)
     SkmGeom g;
     std::mutex mu;
 };
@@ -836,7 +940,8 @@ inline uint32_t pow2_ceil(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; r
 int skm_minimizer_len(int k) { return k >= 24 ? 12 : k / 2; }
 
 // cut `reads` into super-k-mers and bucket them (S1 + S2); idx.mu held by the caller
-int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hipStream_t st)
+// distinct_frac: the share of distinct k-mers the caller expects (0: sequencing coverage of a whole sample, ~0.3)
+int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hipStream_t st, double distinct_frac = 0.0)
 {
     SkmGeom &g = idx.g;
     memset(&g, 0, sizeof(g));
@@ -854,8 +959,12 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     const char *tgt_env = getenv("KV_SKM_BUCKET_KMERS");      // tests shrink the buckets to exercise many of them on small inputs
     // k-mers per fine bucket: 2 x slots for one-word keys (a bucket then holds ~0.4 x slots distinct k-mers at 30x);
     // 1.5 x for two-word keys, whose longer windows put fewer, bigger minimizer loci into a bucket (more variance)
-    const uint64_t target = tgt_env ? std::max<uint64_t>(64, strtoull(tgt_env, nullptr, 10))
-                                    : (g.kw == 1 ? 2ull * table_slots : table_slots + table_slots / 2);
+    uint64_t target = tgt_env ? std::max<uint64_t>(64, strtoull(tgt_env, nullptr, 10))
+                              : (g.kw == 1 ? 2ull * table_slots : table_slots + table_slots / 2);
+    // a shard of a sample (multi-GPU) has less coverage, so more of its k-mers are distinct: smaller buckets keep the
+    // same ~0.6 (0.45 for two-word keys) slots-worth of distinct k-mers in a table
+    if (!tgt_env && distinct_frac > 0.3)
+        target = std::max<uint64_t>(table_slots / 2, (uint64_t)((g.kw == 1 ? 0.6 : 0.45) * table_slots / std::min(1.0, distinct_frac)));
     const uint64_t nfine = std::max<uint64_t>(1, (n_kmers + target - 1) / target);
     // at most 255 x 512 buckets (a bucket id travels as 17 bits through S1); bigger batches get bigger buckets, which
     // only costs deduplication efficiency
@@ -939,18 +1048,30 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
 
 }  // namespace
 
-bool kv_skm_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_kmers, bool for_scan)
+// can (and should) the super-k-mer front end take this batch?  -1 no; 0 yes if the sketch agrees; 1 yes, asked for by name
+static int skm_fits(int hashfam, int ksize, const kv_reads *reads, uint64_t n_kmers, bool for_scan)
 {
     const char *force = getenv(for_scan ? "KV_NOVEL_PATH" : "KV_COUNT_PATH");
-    if (force && strcmp(force, "skm") != 0) return false;        // another path was asked for by name
-    if (s->h.hashfam != HF_MURMUR || s->h.ksize < SKM_MIN_K || s->h.ksize > SKM_MAX_K) return false;
-    if (reads->n_tiles == 0 || n_kmers == 0) return false;
-    const uint64_t min_stride = reads->max_len >= (uint32_t)s->h.ksize ? reads->max_len - (uint32_t)s->h.ksize + 1 : 1;
-    if ((double)reads->n_reads * (double)min_stride >= (double)(1ull << SKM_POS_BITS)) return false;
-    if (reads->tile_max_bases == 0 || reads->tile_max_bases > 8192u) return false;
-    if (force) return true;
-    if (s->skm_off) return false;          // the previous batch into this sketch did not deduplicate (kv_consume_skm)
-    return n_kmers >= (1ull << 22);
+    if (force && strcmp(force, "skm") != 0) return -1;        // another path was asked for by name
+    if (hashfam != HF_MURMUR || ksize < SKM_MIN_K || ksize > SKM_MAX_K) return -1;
+    if (reads->n_tiles == 0 || n_kmers == 0) return -1;
+    const uint64_t min_stride = reads->max_len >= (uint32_t)ksize ? reads->max_len - (uint32_t)ksize + 1 : 1;
+    if ((double)reads->n_reads * (double)min_stride >= (double)(1ull << SKM_POS_BITS)) return -1;
+    if (reads->tile_max_bases == 0 || reads->tile_max_bases > 8192u) return -1;
+    if (force) return 1;
+    return n_kmers >= (1ull << 22) ? 0 : -1;
+}
+
+bool kv_skm_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_kmers, bool for_scan)
+{
+    const int fits = skm_fits(s->h.hashfam, s->h.ksize, reads, n_kmers, for_scan);
+    // skm_off: the previous batch into this sketch did not deduplicate (kv_consume_skm)
+    return fits > 0 || (fits == 0 && !s->skm_off);
+}
+
+bool kv_skm_eligible_kind(int hashfam, int ksize, const kv_reads *reads, uint64_t n_kmers, bool for_scan)
+{
+    return skm_fits(hashfam, ksize, reads, n_kmers, for_scan) >= 0;
 }
 
 int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &filter, const kv_sketch *mask,
@@ -1058,6 +1179,49 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
     idx->valid = false;     // one scan per build: the loose list now holds this scan's entries
     if (sctr[1] != 0) {
         kv_set_error("super-k-mer scan: loose record list overflow (%llu records)", sctr[0]);
+        return KV_ERR_CAPACITY;
+    }
+    return KV_OK;
+}
+
+int kv_skm_route_distinct(const kv_reads *reads, int ksize, uint64_t n_kmers, int ndest,
+                          int (*alloc)(void *ctx, uint32_t nwg, KvRouteSink *sink), void *ctx)
+{
+    KV_REQUIRE(ndest >= 1 && ndest <= SKM_ROUTE_MAX_DEST, KV_ERR_ARG, "kv_skm_route_distinct: 1..%d destinations", SKM_ROUTE_MAX_DEST);
+    hipStream_t st = kv_stream();
+    SkmIndex &idx = skm_index_for(st);
+    std::lock_guard<std::mutex> lk(idx.mu);
+    { const int rc = skm_build(idx, reads, ksize, n_kmers, st, idx.distinct_hint); if (rc != KV_OK) return rc; }
+    SkmGeom &sg = idx.g;
+    const uint32_t nwg3 = skm_nwg3(sg);
+    KvRouteSink rs;
+    memset(&rs, 0, sizeof(rs));
+    { const int rc = alloc(ctx, nwg3, &rs); if (rc != KV_OK) return rc; }
+    const HashParams hp = make_hash_params(ksize, HF_MURMUR);
+    {
+        KvProfScope prof("k_skm_route");
+        const size_t lds = (256 + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw)) * 4;
+        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_route<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, hp, rs);
+        else hipLaunchKernelGGL((k_skm_route<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, hp, rs);
+    }
+    {
+        KvProfScope prof("k_skm_loose_route");
+        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_route<1>, dim3(4096), dim3(256), 0, st, sg, hp, rs);
+        else hipLaunchKernelGGL(k_skm_loose_route<2>, dim3(4096), dim3(256), 0, st, sg, hp, rs);
+    }
+    KV_HIP(hipGetLastError());
+    unsigned long long sctr[8] = {0};
+    KV_HIP(hipMemcpyAsync(sctr, sg.ctr, sizeof(sctr), hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    // the next shard routed on this stream (same sample or a sibling: same coverage) gets buckets sized for what this one held
+    const double alone = (double)(sctr[0] > sctr[6] ? sctr[0] - sctr[6] : 0) / (double)n_kmers;
+    idx.distinct_hint = std::min(1.0, (double)sctr[7] / (double)n_kmers + alone);
+    if (getenv("KV_SKM_VERBOSE"))
+        fprintf(stderr, "[kv_skm] routed %llu k-mers: %.1f%% distinct, %.2f%% outside the LDS tables, %u buckets\n",
+                (unsigned long long)n_kmers, 100 * idx.distinct_hint, 100 * alone, sg.n_buckets);
+    if (sctr[1] != 0) {
+        idx.valid = false;
+        kv_set_error("super-k-mer route: loose record list overflow (%llu records)", sctr[0]);
         return KV_ERR_CAPACITY;
     }
     return KV_OK;

@@ -596,6 +596,12 @@ class _Sketch(object):
                                             ctypes.byref(added)))
         return added.value
 
+    def consume_hashes_weighted(self, items_ptr, n):
+        """Count n (hash, occurrences) pairs resident in HBM; returns the occurrences they stand for."""
+        added = ctypes.c_uint64()
+        check(_lib.load().kv_consume_hashes_weighted(self._h, ctypes.c_void_p(items_ptr), int(n), ctypes.byref(added)))
+        return added.value
+
     def consume(self, seq):
         return self.consume_batch(ReadBatch([seq]))
 
@@ -745,6 +751,15 @@ def route_hashes(batch, sketch_cls, ksize, ndest, read_index_base, with_tags, ou
     return [int(c) for c in counts]
 
 
+def route_distinct(batch, sketch_cls, ksize, ndest, out_ptr, cap_items):
+    """route_hashes for a count, with the shard deduplicated first: the buffer receives (hash, occurrences) pairs,
+    one per distinct k-mer of a super-k-mer bucket; returns the number of pairs per destination."""
+    counts = (ctypes.c_uint64 * int(ndest))()
+    check(_lib.load().kv_route_distinct(batch._h, sketch_cls._kind, int(ksize), int(ndest), ctypes.c_void_p(out_ptr),
+                                        int(cap_items), counts))
+    return [int(c) for c in counts]
+
+
 def novel_scan_hashes(cases, controls, items_ptr, n_items, case_min, ctrl_max, hit_tags_ptr, hit_abund_ptr, hit_cap):
     """kmer_is_interesting() over (hash, tag) pairs in HBM; returns the number of hits written."""
     ca = (ctypes.c_void_p * len(cases))(*[c._h for c in cases])
@@ -754,6 +769,28 @@ def novel_scan_hashes(cases, controls, items_ptr, n_items, case_min, ctrl_max, h
                                            int(case_min), int(ctrl_max), ctypes.c_void_p(hit_tags_ptr),
                                            ctypes.c_void_p(hit_abund_ptr), int(hit_cap), ctypes.byref(n)))
     return n.value
+
+
+def novel_scan_distinct(cases, controls, items_ptr, n_items, case_min, ctrl_max, hit_hashes_ptr, hit_abund_ptr, hit_cap):
+    """kmer_is_interesting() over (hash, occurrences) pairs in HBM: the interesting ones leave as (hash, abundances);
+    returns how many."""
+    ca = (ctypes.c_void_p * len(cases))(*[c._h for c in cases])
+    cb = (ctypes.c_void_p * max(1, len(controls)))(*[c._h for c in controls])
+    n = ctypes.c_uint64()
+    check(_lib.load().kv_novel_scan_distinct(ca, len(cases), cb, len(controls), ctypes.c_void_p(items_ptr), int(n_items),
+                                             int(case_min), int(ctrl_max), ctypes.c_void_p(hit_hashes_ptr),
+                                             ctypes.c_void_p(hit_abund_ptr), int(hit_cap), ctypes.byref(n)))
+    return n.value
+
+
+def novel_scan_set(batch, sketch_cls, ksize, nsamples, hashes_ptr, abund_ptr, n):
+    """The hits of `batch` against a known set of interesting k-mers: n hashes in HBM (~0 = padding) with nsamples
+    abundances each; returns (read, offset, abund[n, S]) in (read, offset) order."""
+    hits = ctypes.c_void_p()
+    check(_lib.load().kv_novel_scan_set(batch._h, sketch_cls._kind, int(ksize), int(nsamples), ctypes.c_void_p(hashes_ptr),
+                                        ctypes.c_void_p(abund_ptr), int(n), ctypes.byref(hits)))
+    r, o, a, _ = _hits_arrays(hits, nsamples)
+    return r, o, a
 
 
 def hits_from_tagged(tags_ptr, abund_ptr, n_total, n_valid, nsamples):

@@ -4,9 +4,10 @@ kevlar's way to split a trio over N workers is k-mer banding (docs/banding.rst,
 kevlar/count.py:62-66, kevlar/novel.py:144-147): worker b owns the hash range of band b -- but
 every worker still reads and hashes every read.  On one node that replication is most of a banded
 rank's time.  Here rank r holds reads [r*n/N, (r+1)*n/N) of every sample,
-hashes them once (kv_route_hashes), and one all-to-all over RCCL/xGMI delivers each hash to the
-rank that owns its band; the owner counts what it receives (kv_consume_hashes) into the very
-sketch the banded run would have built, and scans the case k-mers it received
+hashes them once (kv_route_hashes; or kv_route_distinct, which first combines the repeats inside
+the shard into (hash, occurrences) pairs), and one all-to-all over RCCL/xGMI delivers each hash to
+the rank that owns its band; the owner counts what it receives (kv_consume_hashes[_weighted]) into
+the very sketch the banded run would have built, and scans the case k-mers it received
 (kv_novel_scan_hashes).  Hits are all-gathered and sorted back into (read, offset) order.
 
 torch is plumbing: it owns the exchange buffers and moves them; all arithmetic is in the HIP
@@ -15,6 +16,7 @@ staged through host memory.
 """
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -119,7 +121,8 @@ class ShardedTrio(object):
         self.staged = (backend != 'nccl') if staged is None else bool(staged)
         self.device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
         self._send = {}          # words per item -> free send buffers [cap, words] (one per exchange in flight)
-        self.case_items = None   # (hash, tag) pairs of the case k-mers this rank owns
+        self.case_items = None   # (hash, tag) or (hash, occurrences) pairs of the case k-mers this rank owns
+        self.case_items_weighted = False
         self.timing = {'route': 0.0, 'exchange': 0.0, 'count': 0.0, 'scan': 0.0, 'gather': 0.0}
 
     def _send_buffer(self, cap, words):
@@ -130,48 +133,64 @@ class ShardedTrio(object):
                 return free.pop(i)
         return torch.empty((cap, words), dtype=torch.int64, device=self.device)
 
-    def start(self, batch, read_index_base, with_tags):
+    def start(self, batch, read_index_base, with_tags, distinct=False):
         """Hash this rank's shard of a sample and start delivering every hash to its band's owner.
-        Returns a handle for finish(); the next sample's start() may run while the exchange flies."""
-        words = 2 if with_tags else 1
+        Returns a handle for finish(); the next sample's start() may run while the exchange flies.
+        with_tags: items are (hash, tag) pairs, what scan() needs of a case sample.
+        distinct: items are (hash, occurrences in the shard) pairs, one per distinct k-mer of a
+        super-k-mer bucket (kv_route_distinct) -- fewer items to send and to count; not with tags."""
+        assert not (with_tags and distinct)
+        words = 2 if (with_tags or distinct) else 1
         cap = max(batch.num_kmers(self.ksize), 1)
         send = self._send_buffer(cap, words)
         t0 = time.perf_counter()
-        counts = hk.route_hashes(batch, self.sketch_cls, self.ksize, self.world, read_index_base, with_tags,
-                                 send.data_ptr(), send.shape[0])
+        if distinct:
+            counts = hk.route_distinct(batch, self.sketch_cls, self.ksize, self.world, send.data_ptr(), send.shape[0])
+        else:
+            counts = hk.route_hashes(batch, self.sketch_cls, self.ksize, self.world, read_index_base, with_tags,
+                                     send.data_ptr(), send.shape[0])
         t1 = time.perf_counter()
         ex = exchange_rows_async(send, counts, self.group, self.staged)
         ex.send_buffer = send
+        ex.weighted = bool(distinct)
         self.timing['route'] += t1 - t0
         self.timing['exchange'] += time.perf_counter() - t1
         return ex
 
     def finish(self, ex, sketch, keep_for_scan=False):
-        """Wait for the exchange and count the received hashes into `sketch` (= band `rank`).
-        keep_for_scan: this is a case sample -- keep its (hash, tag) pairs for scan().  Returns the
-        number of k-mers counted on this rank."""
+        """Wait for the exchange and count what arrived into `sketch` (= band `rank`); sketch None
+        only receives.  keep_for_scan: these are the (hash, tag) pairs of a case sample -- keep them
+        for scan().  Returns the number of k-mer occurrences counted on this rank."""
         t0 = time.perf_counter()
         recv = ex.wait()
         self._send[ex.send_buffer.shape[1]].append(ex.send_buffer)     # delivered: the buffer is free again
         t1 = time.perf_counter()
         n = recv.shape[0]
-        if n:
+        if sketch is None:
+            n = 0
+        elif n and ex.weighted:
+            n = sketch.consume_hashes_weighted(recv.data_ptr(), n)
+        elif n:
             sketch.consume_hashes(recv.data_ptr(), n, recv.shape[1])
         self.timing['exchange'] += t1 - t0
         self.timing['count'] += time.perf_counter() - t1
         if keep_for_scan:
             self.case_items = recv
+            self.case_items_weighted = ex.weighted
         return n
 
-    def count_sample(self, sketch, batch, read_index_base=0, keep_for_scan=False):
+    def count_sample(self, sketch, batch, read_index_base=0, keep_for_scan=False, distinct=False):
         """start() + finish() for one sample: `batch` is this rank's shard of its reads (global index of
-        its first read = read_index_base)."""
-        return self.finish(self.start(batch, read_index_base, keep_for_scan), sketch, keep_for_scan)
+        its first read = read_index_base).  A case sample kept `distinct` is scanned with
+        scan_distinct(), a tagged one with scan()."""
+        if not distinct:
+            return self.finish(self.start(batch, read_index_base, keep_for_scan), sketch, keep_for_scan)
+        return self.finish(self.start(batch, read_index_base, False, distinct=True), sketch, keep_for_scan)
 
     def scan(self, cases, controls, case_min, ctrl_max):
         """kmer_is_interesting() over the case k-mers this rank owns, then gather: every rank returns
         the complete (read, offset, abund[n, S]) hit arrays in (read, offset) order."""
-        assert self.case_items is not None, 'count_sample(..., keep_for_scan=True) first'
+        assert self.case_items is not None and not self.case_items_weighted, 'count_sample(..., keep_for_scan=True) first'
         S = len(cases) + len(controls)
         items = self.case_items
         n = items.shape[0]
@@ -188,4 +207,36 @@ class ShardedTrio(object):
         r, o, a = hk.hits_from_tagged(all_tags.data_ptr(), all_abund.data_ptr(), all_tags.shape[0], total, S)
         self.timing['scan'] += t1 - t0
         self.timing['gather'] += time.perf_counter() - t1
+        return r, o, a
+
+    def scan_distinct(self, cases, controls, case_min, ctrl_max, batch, read_index_base):
+        """The scan when the case sample travelled as (hash, occurrences) pairs: no tag says where a k-mer came
+        from, so the answer goes back as a set.  Every band owner tests the distinct case k-mers it received, once
+        each; the interesting ones -- a few hundred thousand hashes with their abundances -- are all-gathered, and
+        every rank looks the k-mers of its own shard (`batch`, first read = read_index_base) up in that set
+        (kv_novel_scan_set).  The shards' hits, all-gathered in rank order, are the complete hit arrays in
+        (read, offset) order, as scan() returns them."""
+        from kevlar_amd import bandmerge
+        assert self.case_items is not None and self.case_items_weighted, 'count_sample(..., keep_for_scan=True, distinct=True) first'
+        S = len(cases) + len(controls)
+        items = self.case_items
+        n = items.shape[0]
+        t0 = time.perf_counter()
+        cap = max(min(n, 1 << 26), 1)
+        hashes = torch.empty(cap, dtype=torch.int64, device=self.device)
+        abund = torch.empty((cap, S), dtype=torch.uint8, device=self.device)
+        n_mine = hk.novel_scan_distinct(cases, controls, items.data_ptr(), n, case_min, ctrl_max,
+                                        hashes.data_ptr(), abund.data_ptr(), cap) if n else 0
+        t1 = time.perf_counter()
+        all_hashes, _ = gather_rows(hashes, n_mine, -1, self.group, self.staged)
+        all_abund, _ = gather_rows(abund, n_mine, 0, self.group, self.staged)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        r, o, a = hk.novel_scan_set(batch, self.sketch_cls, self.ksize, S, all_hashes.data_ptr(), all_abund.data_ptr(),
+                                    all_hashes.shape[0])
+        t3 = time.perf_counter()
+        r, o, a = bandmerge.allgather_hits_device(np.asarray(r).astype(np.int64) + int(read_index_base), o, a, self.device,
+                                                  self.group, self.staged)
+        self.timing['scan'] += (t1 - t0) + (t3 - t2)
+        self.timing['gather'] += (t2 - t1) + (time.perf_counter() - t3)
         return r, o, a

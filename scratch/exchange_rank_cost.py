@@ -1,0 +1,111 @@
+"""What ONE rank of an N-GPU exchange run computes per step of config 2, measured on this one GPU.
+
+Rank 0's work is replayed exactly: it routes its own shard of every sample (timed), and it counts / scans what
+the N shards send to band 0 -- those items are produced here by routing every shard and keeping destination 0's
+block (not timed: on the real node the other ranks do that, at the same time).  The exchange itself is not
+measured (no second GPU); its volume per rank is printed.  usage: exchange_rank_cost.py [N ...]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from kevlar_amd import _lib, khmer as hk, shardrun, synth
+
+
+def main():
+    worlds = [int(a) for a in sys.argv[1:]] or [2, 4, 8]
+    lib = _lib.load()
+    _lib.require_device()
+    k, L, mem, T = 31, 100, 2e9, 4
+    packed = synth.trio_reads_packed(25_000_000, 30, L)
+    names = tuple(packed)
+    n_reads = packed['proband'].shape[0]
+    dev = torch.device('cuda', 0)
+    for distinct in (True, False):
+        for world in worlds:
+            sk = {n: hk.Counttable(k, mem / world / T, T) for n in names}
+            shards = {n: [hk.ReadBatch.from_packed(packed[n][lo:hi], L) for lo, hi in
+                          (shardrun.shard_bounds(n_reads, world, r) for r in range(world))] for n in names}
+            nkm = shards['proband'][0].num_kmers(k)
+            words = 2
+            send = torch.empty((nkm + 1024, 2), dtype=torch.int64, device=dev)
+            recv_count, recv_tagged, sent = {}, None, 0
+
+            def route(batch, base, mode):
+                if mode == 'distinct':
+                    return hk.route_distinct(batch, hk.Counttable, k, world, send.data_ptr(), send.shape[0])
+                return hk.route_hashes(batch, hk.Counttable, k, world, base, mode == 'tagged', send.data_ptr(), send.shape[0])
+
+            # what band 0 receives (other ranks' routing: not timed)
+            for n in names:
+                blocks = []
+                for r in range(world):
+                    c = route(shards[n][r], 0, 'distinct' if distinct else 'plain')
+                    w = 2 if distinct else 1
+                    flat = send.view(-1)[:c[0] * w].clone().view(-1, w)
+                    blocks.append(flat)
+                recv_count[n] = torch.cat(blocks)
+            blocks = []
+            for r in range(world):
+                lo, _ = shardrun.shard_bounds(n_reads, world, r)
+                c = route(shards['proband'][r], lo, 'tagged')
+                blocks.append(send[:c[0]].clone())
+            recv_tagged = torch.cat(blocks)
+            torch.cuda.synchronize()
+            best = None
+            for rep in range(4):
+                lib.kv_prof_reset()
+                lib.kv_prof_enable(1 if os.environ.get('RANK_COST_PROF') else 0)
+                for n in names:
+                    sk[n].clear()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                t_route = t_count = 0.0
+                out_bytes = 0
+                for n in names:
+                    ta = time.perf_counter()
+                    c = route(shards[n][0], 0, 'distinct' if distinct else 'plain')
+                    out_bytes += (sum(c) - c[0]) * (16 if distinct else 8)
+                    if n == 'proband':
+                        c = route(shards[n][0], 0, 'tagged')
+                        out_bytes += (sum(c) - c[0]) * 16
+                    tb = time.perf_counter()
+                    items = recv_count[n]
+                    if distinct:
+                        sk[n].consume_hashes_weighted(items.data_ptr(), items.shape[0])
+                    else:
+                        sk[n].consume_hashes(items.data_ptr(), items.shape[0], 1)
+                    tc = time.perf_counter()
+                    t_route += tb - ta
+                    t_count += tc - tb
+                t1 = time.perf_counter()
+                cap = recv_tagged.shape[0]
+                tags = torch.empty(min(cap, 1 << 26), dtype=torch.int64, device=dev)
+                abund = torch.empty((min(cap, 1 << 26), 3), dtype=torch.uint8, device=dev)
+                nh = hk.novel_scan_hashes([sk['proband']], [sk[n] for n in names[1:]], recv_tagged.data_ptr(), cap, 6, 1,
+                                          tags.data_ptr(), abund.data_ptr(), tags.shape[0])
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                res = dict(route=t_route * 1e3, count=t_count * 1e3, scan=(t2 - t1) * 1e3, total=(t2 - t0) * 1e3, out_mb=out_bytes / 1e6,
+                           items=sum(int(v.shape[0]) for v in recv_count.values()), hits=nh)
+                if os.environ.get('RANK_COST_PROF') and rep == 3:
+                    import ctypes
+                    buf = ctypes.create_string_buffer(8192)
+                    lib.kv_prof_names(buf, 8192)
+                    for name in buf.value.decode().split(','):
+                        ms, nl = ctypes.c_double(), ctypes.c_uint64()
+                        lib.kv_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(nl))
+                        print('    {:24s} {:8.3f} ms {:4d} launches'.format(name, ms.value, nl.value))
+                if best is None or res['total'] < best['total']:
+                    best = res
+            print('N={} items={}: per-rank route {route:.2f} ms, count {count:.2f} ms, scan {scan:.2f} ms, total {total:.2f} ms; '
+                  'sends {out_mb:.0f} MB; counts {items} items; {hits} hits in band 0'.format(world, 'distinct' if distinct else 'plain', **best), flush=True)
+            del sk, shards, recv_count, recv_tagged, send
+            torch.cuda.empty_cache()
+
+
+if __name__ == '__main__':
+    main()

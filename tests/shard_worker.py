@@ -33,8 +33,19 @@ def main():
     sharded = {n: hk.Counttable(k, mem / world / 4, 4) for n in names}
     for n in names:
         lo, hi = shardrun.shard_bounds(len(reads[n]), world, rank)
-        run.count_sample(sharded[n], hk.ReadBatch(reads[n][lo:hi]), lo, keep_for_scan=(n == 'proband'))
-    r, o, a = run.scan([sharded['proband']], [sharded['mother'], sharded['father']], 6, 1)
+        counted = run.count_sample(sharded[n], hk.ReadBatch(reads[n][lo:hi]), lo, keep_for_scan=(n == 'proband'),
+                                   distinct=os.environ.get('SHARD_DISTINCT') == '1')
+        total = torch.tensor([counted], dtype=torch.int64)
+        if backend == 'nccl':
+            total = total.cuda()
+        dist.all_reduce(total)
+        assert int(total.item()) == sum(max(0, len(s) - k + 1) for s in reads[n]), n
+    if os.environ.get('SHARD_DISTINCT') == '1':
+        lo, hi = shardrun.shard_bounds(len(reads['proband']), world, rank)
+        r, o, a = run.scan_distinct([sharded['proband']], [sharded['mother'], sharded['father']], 6, 1,
+                                    hk.ReadBatch(reads['proband'][lo:hi]), lo)
+    else:
+        r, o, a = run.scan([sharded['proband']], [sharded['mother'], sharded['father']], 6, 1)
 
     # the banded run of the same trio, band = rank, every read hashed here
     full = {n: hk.ReadBatch(reads[n]) for n in names}

@@ -98,6 +98,56 @@ def test_consume_hashes_equals_banded_consume(hk, force):
         os.environ.pop('KV_COUNT_PATH', None)
 
 
+@pytest.mark.parametrize('kind,k,ndest,path', [('Counttable', 31, 3, 'skm'), ('SmallCounttable', 25, 2, 'skm'),
+                                                 ('Counttable', 51, 4, 'skm'), ('Nodetable', 31, 2, 'skm'),
+                                                 ('Counttable', 31, 3, 'plain'), ('Countgraph', 21, 2, None),
+                                                 ('Counttable', 12, 2, None)])
+def test_route_distinct_counts_like_banded_consume(hk, kind, k, ndest, path):
+    """(hash, occurrences) pairs of the deduplicated shard: every pair inside its band, the occurrences add up to
+    the k-mers, no hash twice from one bucket walk, and the weighted count leaves band b's tables bit for bit"""
+    import torch
+    reads = make_reads(60000, 13, with_n=False) + ['ACGT' * 30] * 400 + ['A' * 120] * 300   # saturating repeats
+    batch = hk.ReadBatch(reads)
+    nk = batch.num_kmers(k)
+    send = torch.zeros((nk, 2), dtype=torch.int64, device='cuda')
+    cls = getattr(hk, kind)
+    if path:
+        os.environ['KV_ROUTE_PATH'] = path
+    try:
+        counts = hk.route_distinct(batch, cls, k, ndest, send.data_ptr(), nk)
+    finally:
+        os.environ.pop('KV_ROUTE_PATH', None)
+    host = send.cpu().numpy().view(np.uint64)
+    starts = np.concatenate(([0], np.cumsum(counts)))
+    bs = (2 ** 64 - 1) // ndest
+    total = 0
+    for force in (None, 'binned', 'atomic'):
+        if force:
+            os.environ['KV_COUNT_PATH'] = force
+        try:
+            for b in range(ndest):
+                block = host[starts[b]:starts[b + 1]]
+                lo, hi = bs * b, (2 ** 64 - 1 if b == ndest - 1 else bs * (b + 1))
+                assert ((block[:, 0] >= lo) & (block[:, 0] < hi)).all()
+                assert (block[:, 1] >= 1).all()
+                banded = cls(k, 1.6e6, 4)
+                n_b = banded.consume_batch(batch, ndest, b)
+                assert int(block[:, 1].sum()) == n_b
+                routed = cls(k, 1.6e6, 4)
+                assert routed.consume_hashes_weighted(send[int(starts[b]):].data_ptr(), counts[b]) == n_b
+                for t in range(4):
+                    assert routed.table_bytes(t) == banded.table_bytes(t)
+                assert routed.n_occupied() == banded.n_occupied()
+                total += n_b
+        finally:
+            os.environ.pop('KV_COUNT_PATH', None)
+    assert total == 3 * nk
+    if path == 'skm':
+        assert sum(counts) < 0.6 * nk          # the shard was deduplicated
+    elif path == 'plain':
+        assert sum(counts) == nk
+
+
 def test_consume_hashes_strided_large(hk):
     """the partitioned list kernel on its natural size, reading (hash, tag) pairs"""
     import torch
@@ -148,6 +198,58 @@ def test_scan_hashes_equals_novel_scan(hk, ok):
     assert np.array_equal(r0, r1) and np.array_equal(o0, o1) and np.array_equal(a0, a1)
 
 
+@pytest.mark.parametrize('k,path', [(31, None), (31, 'skm'), (51, 'skm'), (12, None)])
+def test_scan_distinct_then_scan_set_reproduce_the_scan(hk, k, path):
+    """the two halves of the multi-GPU scan inside one process: the owner's test over (hash, occurrences) pairs
+    yields exactly the distinct interesting hashes, and looking the reads up in that set -- given twice over and
+    padded, as the all-gather delivers it -- yields exactly kv_novel_scan's hits"""
+    import torch
+    from kevlar_amd import synth
+    trio = synth.make_trio(200000, 17)
+    reads = {n: synth.unpack_reads(synth.sample_reads_packed(trio[n], 60000, 100, 0.005, 40 + i), 100)
+             for i, n in enumerate(('proband', 'mother', 'father'))}
+    reads['proband'][5] = reads['proband'][5][:50] + 'N' + reads['proband'][5][51:]
+    reads['proband'][9] = reads['proband'][9][:25]
+    batches = {n: hk.ReadBatch(reads[n]) for n in reads}
+    sk = {n: hk.Counttable(k, 2.0e6, 4) for n in reads}
+    for n in reads:
+        sk[n].consume_batch(batches[n])
+    r0, o0, a0, _ = hk.novel_scan([sk['proband']], [sk['mother'], sk['father']], batches['proband'], 6, 1)
+    assert len(r0) > 50
+    truth = sk['proband'].hash_positions(batches['proband'], r0, o0)
+    nk = batches['proband'].num_kmers(k)
+    send = torch.zeros((nk, 2), dtype=torch.int64, device='cuda')
+    env = {'KV_ROUTE_PATH': path, 'KV_NOVEL_PATH': path} if path else {}
+    os.environ.update(env)
+    try:
+        counts = hk.route_distinct(batches['proband'], hk.Counttable, k, 1, send.data_ptr(), nk)
+        hashes = torch.empty(nk, dtype=torch.int64, device='cuda')
+        abund = torch.empty((nk, 3), dtype=torch.uint8, device='cuda')
+        n_int = hk.novel_scan_distinct([sk['proband']], [sk['mother'], sk['father']], send.data_ptr(), counts[0], 6, 1,
+                                       hashes.data_ptr(), abund.data_ptr(), nk)
+        got = hashes[:n_int].cpu().numpy().view(np.uint64)
+        # N-containing reads are counted (stand-in bases) but not scanned: their k-mers may be interesting hashes that
+        # no scanned read shows, so the owner's answer is a superset of the scan's distinct hashes
+        assert set(np.unique(truth).tolist()) <= set(got.tolist())
+        if path == 'skm':
+            assert len(np.unique(got)) == len(got)
+        doubled = torch.full((2 * n_int + 77,), -1, dtype=torch.int64, device='cuda')
+        doubled[:n_int] = hashes[:n_int]
+        doubled[n_int + 50:2 * n_int + 50] = hashes[:n_int]
+        da = torch.zeros((2 * n_int + 77, 3), dtype=torch.uint8, device='cuda')
+        da[:n_int] = abund[:n_int]
+        da[n_int + 50:2 * n_int + 50] = abund[:n_int]
+        torch.cuda.synchronize()
+        r1, o1, a1 = hk.novel_scan_set(batches['proband'], hk.Counttable, k, 3, doubled.data_ptr(), da.data_ptr(), doubled.shape[0])
+    finally:
+        for key in env:
+            os.environ.pop(key, None)
+    assert np.array_equal(r0, r1) and np.array_equal(o0, o1) and np.array_equal(a0, a1)
+    # an empty set: no hits, no error
+    r2, o2, a2 = hk.novel_scan_set(batches['proband'], hk.Counttable, k, 3, 0, 0, 0)
+    assert len(r2) == 0 and a2.shape == (0, 3)
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -156,17 +258,22 @@ def free_port():
     return port
 
 
-@pytest.mark.parametrize('world,backend', [(2, 'gloo'), (3, 'gloo'), (1, 'nccl')])
-def test_sharded_trio_ranks_share_one_gpu(hk, world, backend):
+@pytest.mark.parametrize('world,backend,distinct', [(2, 'gloo', False), (3, 'gloo', False), (1, 'nccl', False),
+                                                    (2, 'gloo', 'skm'), (3, 'gloo', 'plain'), (1, 'nccl', 'skm')])
+def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     """N ranks on this one GPU (gloo, staged exchange): each rank's sketches must equal band `rank` of a
     banded count of ALL reads, and the gathered hits the merged banded scan (tests/shard_worker.py).  The
     (1, 'nccl') case drives the RCCL transport itself -- device tensors, async all-to-all -- with the one
-    rank a single-GPU box allows."""
+    rank a single-GPU box allows.  `distinct`: the count travels as (hash, occurrences) pairs of the
+    deduplicated shard (kv_route_distinct / kv_consume_hashes_weighted) and the scan goes through the set of
+    interesting k-mers (kv_novel_scan_distinct / kv_novel_scan_set)."""
     port = free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), SHARD_BACKEND=backend)
+                   MASTER_PORT=str(port), SHARD_BACKEND=backend, SHARD_DISTINCT='1' if distinct else '0')
+        if distinct:            # the bucketed kernels by name (the shards are small), or their one-item-per-k-mer stand-ins
+            env.update(KV_ROUTE_PATH=distinct, KV_NOVEL_PATH='skm' if distinct == 'skm' else 'tiles')
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'shard_worker.py')], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
