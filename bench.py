@@ -75,9 +75,12 @@ def parse_args():
     p.add_argument('--e2e-reads', type=int, default=500000, help='reads per sample written as FASTQ for the end-to-end leg')
     p.add_argument('--no-e2e', action='store_true')
     p.add_argument('--no-replay', action='store_true', help='skip the banded replays behind banded_checksums / replay_checksum')
-    p.add_argument('--exchange-items', default='distinct', choices=['distinct', 'plain'],
-                   help='--multi exchange: what the count sends -- (hash, occurrences) pairs of each rank\'s deduplicated shard '
-                        '(kv_route_distinct), or one hash per k-mer')
+    p.add_argument('--exchange-items', default='auto', choices=['auto', 'distinct', 'plain'],
+                   help='--multi exchange: distinct = (hash, occurrences) pairs of each rank\'s deduplicated shard (kv_route_distinct), '
+                        'the scan answered as an all-gathered set of interesting k-mers (kv_novel_scan_set); plain = one hash per '
+                        'k-mer, the case sample as (hash, tag) pairs scanned by the band owners; auto = distinct up to 4 GPUs '
+                        '(measured per-rank compute, scratch/exchange_rank_cost.py: 29.6 / 20.8 / 13.8 ms at 2 / 4 / 8 ranks against '
+                        '43.0 / 21.4 / 11.3 ms plain)')
     p.add_argument('--multi', default='auto', choices=['auto', 'exchange', 'banded'],
                    help='N>1: exchange = shard the reads, hash once, all-to-all the hashes by band (kevlar_amd/shardrun.py); '
                         'banded = every rank streams all reads and keeps its band; auto = exchange from 4 GPUs up')
@@ -146,6 +149,8 @@ def main():
     controls = names[1:]
     n_reads = packed['proband'].shape[0]
     multi = args.multi if args.multi != 'auto' else ('exchange' if world >= 4 else 'banded')
+    if args.exchange_items == 'auto':
+        args.exchange_items = 'distinct' if world <= 4 else 'plain'
     exchange = world > 1 and multi == 'exchange'
     per_batch = int(wl['batch_reads']) or n_reads
     upload_s = None
@@ -226,18 +231,24 @@ def main():
             sketches[n].clear()
         kmers = 0
         distinct = args.exchange_items == 'distinct'
-        # counts travel as (hash, occurrences) pairs of each rank's deduplicated shard; the case sample's
-        # (hash, tag) pairs travel besides them, for the scan only
-        tagged = run.start(batches[names[0]][0], bounds[names[0]][0], True)
-        pending = run.start(batches[names[0]][0], bounds[names[0]][0], False, distinct=True) if distinct else tagged
-        for i, n in enumerate(names):
-            nxt = run.start(batches[names[i + 1]][0], bounds[names[i + 1]][0], False, distinct=distinct) if i + 1 < len(names) else None
-            kmers += run.finish(pending, sketches[n], keep_for_scan=(i == 0 and not distinct))
-            pending = nxt
         if distinct:
-            run.finish(tagged, None, keep_for_scan=True)
+            # counts travel as (hash, occurrences) pairs of each rank's deduplicated shard; the case sample goes last, so
+            # its bucketed shard is still resident when the scan looks its k-mers up in the set of interesting ones
+            order = list(controls) + [names[0]]
+        else:
+            order = list(names)         # the case sample travels as (hash, tag) pairs, counted and scanned by the owners
+        pending = run.start(batches[order[0]][0], bounds[order[0]][0], not distinct and order[0] == names[0], distinct=distinct)
+        for i, n in enumerate(order):
+            nn = order[i + 1] if i + 1 < len(order) else None
+            nxt = run.start(batches[nn][0], bounds[nn][0], not distinct and nn == names[0], distinct=distinct) if nn else None
+            kmers += run.finish(pending, sketches[n], keep_for_scan=(n == names[0]))
+            pending = nxt
         t_b = time.perf_counter()
-        r, o, a = run.scan([sketches['proband']], [sketches[n] for n in controls], args.case_min, args.ctrl_max)
+        cases, ctrls = [sketches['proband']], [sketches[n] for n in controls]
+        if distinct:
+            r, o, a = run.scan_distinct(cases, ctrls, args.case_min, args.ctrl_max, batches[names[0]][0], bounds[names[0]][0])
+        else:
+            r, o, a = run.scan(cases, ctrls, args.case_min, args.ctrl_max)
         t_c = time.perf_counter()
         wall['count'] += t_b - t_a
         wall['novel'] += t_c - t_b

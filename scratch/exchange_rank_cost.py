@@ -40,20 +40,36 @@ def main():
                 return hk.route_hashes(batch, hk.Counttable, k, world, base, mode == 'tagged', send.data_ptr(), send.shape[0])
 
             # what band 0 receives (other ranks' routing: not timed)
+            order = list(names[1:]) + [names[0]] if distinct else list(names)
             for n in names:
                 blocks = []
                 for r in range(world):
                     c = route(shards[n][r], 0, 'distinct' if distinct else 'plain')
                     w = 2 if distinct else 1
-                    flat = send.view(-1)[:c[0] * w].clone().view(-1, w)
-                    blocks.append(flat)
+                    blocks.append(send.view(-1)[:c[0] * w].clone().view(-1, w))
                 recv_count[n] = torch.cat(blocks)
-            blocks = []
-            for r in range(world):
-                lo, _ = shardrun.shard_bounds(n_reads, world, r)
-                c = route(shards['proband'][r], lo, 'tagged')
-                blocks.append(send[:c[0]].clone())
-            recv_tagged = torch.cat(blocks)
+            if not distinct:
+                blocks = []
+                for r in range(world):
+                    lo, _ = shardrun.shard_bounds(n_reads, world, r)
+                    c = route(shards['proband'][r], lo, 'tagged')
+                    blocks.append(send[:c[0]].clone())
+                recv_tagged = torch.cat(blocks)
+            else:
+                # the interesting k-mers of the OTHER bands (their owners' work): evaluated here against full-size sketches
+                full = {n: hk.Counttable(k, mem / T, T) for n in names}
+                whole = {n: hk.ReadBatch.from_packed(packed[n], L) for n in names}
+                for n in names:
+                    full[n].consume_batch(whole[n])
+                fr, fo, fa, _ = hk.novel_scan([full['proband']], [full[n] for n in names[1:]], whole['proband'], 6, 1)
+                fh = full['proband'].hash_positions(whole['proband'], fr, fo)
+                fh, first = np.unique(fh, return_index=True)
+                bs = (2 ** 64 - 1) // world
+                other = fh >= np.uint64(bs)             # band 0's own come from this rank's scan below
+                others_hash = torch.from_numpy(fh[other].view(np.int64)).to(dev)
+                others_abund = torch.from_numpy(np.ascontiguousarray(np.asarray(fa)[first][other])).to(dev)
+                del full, whole
+                torch.cuda.empty_cache()
             torch.cuda.synchronize()
             best = None
             for rep in range(4):
@@ -65,28 +81,49 @@ def main():
                 t0 = time.perf_counter()
                 t_route = t_count = 0.0
                 out_bytes = 0
-                for n in names:
+                for n in order:
                     ta = time.perf_counter()
-                    c = route(shards[n][0], 0, 'distinct' if distinct else 'plain')
-                    out_bytes += (sum(c) - c[0]) * (16 if distinct else 8)
-                    if n == 'proband':
+                    if distinct:
+                        c = route(shards[n][0], 0, 'distinct')
+                        out_bytes += (sum(c) - c[0]) * 16
+                    elif n == 'proband':
                         c = route(shards[n][0], 0, 'tagged')
                         out_bytes += (sum(c) - c[0]) * 16
-                    tb = time.perf_counter()
-                    items = recv_count[n]
-                    if distinct:
-                        sk[n].consume_hashes_weighted(items.data_ptr(), items.shape[0])
                     else:
+                        c = route(shards[n][0], 0, 'plain')
+                        out_bytes += (sum(c) - c[0]) * 8
+                    tb = time.perf_counter()
+                    if distinct:
+                        items = recv_count[n]
+                        sk[n].consume_hashes_weighted(items.data_ptr(), items.shape[0])
+                    elif n == 'proband':
+                        sk[n].consume_hashes(recv_tagged.data_ptr(), recv_tagged.shape[0], 2)
+                    else:
+                        items = recv_count[n]
                         sk[n].consume_hashes(items.data_ptr(), items.shape[0], 1)
                     tc = time.perf_counter()
                     t_route += tb - ta
                     t_count += tc - tb
                 t1 = time.perf_counter()
-                cap = recv_tagged.shape[0]
-                tags = torch.empty(min(cap, 1 << 26), dtype=torch.int64, device=dev)
-                abund = torch.empty((min(cap, 1 << 26), 3), dtype=torch.uint8, device=dev)
-                nh = hk.novel_scan_hashes([sk['proband']], [sk[n] for n in names[1:]], recv_tagged.data_ptr(), cap, 6, 1,
-                                          tags.data_ptr(), abund.data_ptr(), tags.shape[0])
+                if distinct:
+                    items = recv_count['proband']
+                    cap = items.shape[0]
+                    tags = torch.empty(cap, dtype=torch.int64, device=dev)
+                    abund = torch.empty((cap, 3), dtype=torch.uint8, device=dev)
+                    nh = hk.novel_scan_distinct([sk['proband']], [sk[n] for n in names[1:]], items.data_ptr(), cap, 6, 1,
+                                                tags.data_ptr(), abund.data_ptr(), cap)
+                    out_bytes += nh * 11 * (world - 1)
+                    set_h = torch.cat([tags[:nh], others_hash])
+                    set_a = torch.cat([abund[:nh], others_abund])
+                    torch.cuda.synchronize()
+                    r, o, a = hk.novel_scan_set(shards['proband'][0], hk.Counttable, k, 3, set_h.data_ptr(), set_a.data_ptr(), set_h.shape[0])
+                    nh = len(r)
+                else:
+                    cap = recv_tagged.shape[0]
+                    tags = torch.empty(min(cap, 1 << 26), dtype=torch.int64, device=dev)
+                    abund = torch.empty((min(cap, 1 << 26), 3), dtype=torch.uint8, device=dev)
+                    nh = hk.novel_scan_hashes([sk['proband']], [sk[n] for n in names[1:]], recv_tagged.data_ptr(), cap, 6, 1,
+                                              tags.data_ptr(), abund.data_ptr(), tags.shape[0])
                 torch.cuda.synchronize()
                 t2 = time.perf_counter()
                 res = dict(route=t_route * 1e3, count=t_count * 1e3, scan=(t2 - t1) * 1e3, total=(t2 - t0) * 1e3, out_mb=out_bytes / 1e6,
@@ -102,7 +139,7 @@ def main():
                 if best is None or res['total'] < best['total']:
                     best = res
             print('N={} items={}: per-rank route {route:.2f} ms, count {count:.2f} ms, scan {scan:.2f} ms, total {total:.2f} ms; '
-                  'sends {out_mb:.0f} MB; counts {items} items; {hits} hits in band 0'.format(world, 'distinct' if distinct else 'plain', **best), flush=True)
+                  'sends {out_mb:.0f} MB; counts {items} items; {hits} hits (set: this shard; plain: this band)'.format(world, 'distinct' if distinct else 'plain', **best), flush=True)
             del sk, shards, recv_count, recv_tagged, send
             torch.cuda.empty_cache()
 
