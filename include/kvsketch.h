@@ -143,6 +143,15 @@ int kv_fastx_num_reads(kv_fastx *f, uint64_t *n); /* khmer parser.num_reads */
  * kv_fastx_record_text (byte for byte what the source holds).  kv_fastx_from_cache tells which mode a handle is in. */
 int kv_fastx_from_cache(kv_fastx *f, int *yes);
 int kv_fastx_record_text(kv_fastx *f, uint64_t i, char *seq_out, char *qual_out);
+/* Device ingest: a file that is blocked gzip (BGZF: bgzip, htslib, kevlar_amd.open(..., 'w')) holding four-line FASTQ
+ * and is read as packed batches (upload != 0) from the first call never has its text on the host: the compressed bytes
+ * go to HBM, one wavefront inflates one BGZF member (kv_inflate.hip), lines and records are found and the sequences
+ * packed by kernels (kv_fastq.hip).  kv_fastx_on_device tells whether a handle works that way; the text of a batch then
+ * stays in HBM, and kv_fastx_fetch(idx, n) brings the named records to the host, after which kv_fastx_batch_text
+ * describes exactly those n records.  Anything else (plain gzip, FASTA, blank lines, KV_INGEST=host) is parsed on the
+ * host as before, with identical results.                                                                        */
+int kv_fastx_on_device(kv_fastx *f, int *yes);
+int kv_fastx_fetch(kv_fastx *f, const uint64_t *idx, uint64_t n);
 int kv_fastx_close(kv_fastx *f);
 int kv_reads_count(const kv_reads *r, uint64_t *n_reads, uint64_t *n_bases);
 /* number of k-mers a consume of this batch visits at size k (sum over reads of len-k+1)   */
@@ -265,6 +274,13 @@ int kv_readgraph_components(const kv_reads *reads, int ksize, const uint32_t *an
                             const uint32_t *ann_offset, uint64_t n_ann,
                             const uint32_t *node_of_read, uint32_t n_nodes, uint32_t minabund,
                             uint32_t maxabund, uint32_t *labels_out, uint64_t *n_edges_out);
+
+/* ---- blocked gzip (BGZF) on the device (kevlar_amd/csrc/kv_inflate.hip) --------------------------------
+ * Replaces the gzip stream behind khmer.ReadParser (kevlar/__init__.py:125-128) for files whose members are
+ * independent: one wavefront inflates one member.  kv_fastx_open picks this path by itself; the two
+ * functions below take a whole file image in host memory (tests, tools).                                   */
+int kv_bgzf_text_size(const void *file, uint64_t size, uint64_t *text_bytes, uint64_t *n_members);
+int kv_bgzf_inflate_host(const void *file, uint64_t size, void *out, uint64_t out_cap, double *kernel_ms);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,9 @@ def open(filename, mode):
     if filename in ['-', None]:
         return sys.stdin if mode == 'r' else sys.stdout
     if filename.endswith('.gz'):
+        if mode == 'w':         # blocked gzip: any gzip reader takes it, and the GPU can inflate its members in parallel
+            from kevlar_amd.bgzf import BgzfWriter
+            return BgzfWriter(filename)
         return gzopen(filename, mode + 't')
     return builtins.open(filename, mode)
 

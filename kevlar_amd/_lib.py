@@ -70,6 +70,8 @@ SIGNATURES = {
                                   ctypes.POINTER(u8p)]),
     'kv_fastx_num_reads': (i32, [vp, u64p]),
     'kv_fastx_from_cache': (i32, [vp, ctypes.POINTER(ctypes.c_int)]),
+    'kv_fastx_on_device': (i32, [vp, ctypes.POINTER(ctypes.c_int)]),
+    'kv_fastx_fetch': (i32, [vp, u64p, u64]),
     'kv_fastx_record_text': (i32, [vp, u64, ctypes.c_char_p, ctypes.c_char_p]),
     'kv_fastx_close': (i32, [vp]),
     'kv_reads_count': (i32, [vp, u64p, u64p]),
@@ -89,6 +91,8 @@ SIGNATURES = {
     'kv_hits_destroy': (i32, [vp]),
     'kv_route_hashes': (i32, [vp, i32, i32, i32, u64, i32, vp, u64, u64p]),
     'kv_consume_hashes': (i32, [vp, vp, u64, ctypes.c_uint32, u64p]),
+    'kv_bgzf_text_size': (i32, [vp, u64, u64p, u64p]),
+    'kv_bgzf_inflate_host': (i32, [vp, u64, vp, u64, ctypes.POINTER(ctypes.c_double)]),
     'kv_route_distinct': (i32, [vp, i32, i32, i32, vp, u64, u64p]),
     'kv_consume_hashes_weighted': (i32, [vp, vp, u64, u64p]),
     'kv_novel_scan_hashes': (i32, [vpp, i32, vpp, i32, vp, u64, i32, i32, vp, vp, u64, u64p]),

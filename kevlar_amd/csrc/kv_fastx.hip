@@ -77,6 +77,9 @@ struct kv_fastx {
     std::mutex mu;
     PackReader *cache = nullptr;     // serving from FILE.kvpack instead of parsing
     PackWriter *writer = nullptr;    // leaving FILE.kvpack behind
+    // blocked gzip (BGZF) holding four-line FASTQ: inflated, split and packed on the device (kv_inflate.hip, kv_fastq.hip)
+    bool dev_candidate = false;      // the file starts like BGZF and nothing has been parsed on the host yet
+    KvFastqDevice *dev = nullptr;
 };
 
 static bool fx_fill(kv_fastx *f)
@@ -341,6 +344,16 @@ extern "C" int kv_fastx_open(const char *path, kv_fastx **out)
         f->fh = fh;
         f->buf.resize(4 << 20);
         if (caching) f->writer = pack_writer_start(path);
+        const char *ingest = getenv("KV_INGEST");               // "host": never parse on the device
+        if (!caching && !(ingest && strcmp(ingest, "host") == 0)) {
+            unsigned char head[18] = {0};
+            FILE *probe = fopen(path, "rb");
+            if (probe) {
+                if (fread(head, 1, sizeof(head), probe) == sizeof(head))
+                    f->dev_candidate = head[0] == 0x1f && head[1] == 0x8b && head[2] == 8 && head[3] == 4 && head[12] == 'B' && head[13] == 'C';
+                fclose(probe);
+            }
+        }
     }
     *out = f;
     return KV_OK;
@@ -350,6 +363,7 @@ extern "C" int kv_fastx_close(kv_fastx *f)
 {
     if (!f) return KV_OK;
     if (f->fh) gzclose(f->fh);
+    kv_fastq_device_close(f->dev);
     pack_writer_finish(f->writer, false);       // a complete pass has already finished (and detached) its writer
     pack_close(f->cache);
     delete f;
@@ -368,6 +382,44 @@ extern "C" int kv_fastx_num_reads(kv_fastx *f, uint64_t *n)
 {
     KV_REQUIRE(f && n, KV_ERR_ARG, "kv_fastx_num_reads: null argument");
     *n = f->num_reads;
+    return KV_OK;
+}
+
+// records parsed on the host into the handle's blobs (appended); *n_out = how many
+static int host_parse(kv_fastx *f, uint64_t max_reads, uint64_t *n_out)
+{
+    uint64_t n = 0;
+    const char *lp;
+    size_t ln;
+    while (n < max_reads && fx_view(f, lp, ln)) {
+        if (fx_blank_view(lp, ln)) continue;
+        const char first = lp[0];
+        if (first == '@') {
+            // four lines, each appended to its blob straight from the inflate buffer
+            f->names.append(lp + 1, ln - 1);
+            if (fx_view(f, lp, ln)) f->seqs.append(lp, ln);
+            (void)fx_view(f, lp, ln);                               // '+' line
+            if (fx_view(f, lp, ln)) f->quals.append(lp, ln);
+            f->is_fastq.push_back(1);
+        } else if (first == '>') {
+            f->names.append(lp + 1, ln - 1);
+            std::string piece;
+            while (fx_line(f, piece)) {
+                if (!piece.empty() && piece[0] == '>') { f->pending.swap(piece); f->have_pending = true; break; }
+                fx_strip(piece);
+                f->seqs += piece;
+            }
+            f->is_fastq.push_back(0);
+        } else {
+            kv_set_error("cannot parse sequence file %s", f->path.c_str());
+            return KV_ERR_IO;
+        }
+        f->name_offs.push_back(f->names.size());
+        f->seq_offs.push_back(f->seqs.size());
+        f->qual_offs.push_back(f->quals.size());
+        ++n;
+    }
+    *n_out = n;
     return KV_OK;
 }
 
@@ -415,38 +467,38 @@ extern "C" int kv_fastx_next(kv_fastx *f, uint64_t max_reads, int upload, kv_rea
         }
         return KV_OK;
     }
-    std::string seq;
-    uint64_t n = 0;
-    const char *lp;
-    size_t ln;
-    while (n < max_reads && fx_view(f, lp, ln)) {
-        if (fx_blank_view(lp, ln)) continue;
-        const char first = lp[0];
-        if (first == '@') {
-            // four lines, each appended to its blob straight from the inflate buffer
-            f->names.append(lp + 1, ln - 1);
-            if (fx_view(f, lp, ln)) f->seqs.append(lp, ln);
-            (void)fx_view(f, lp, ln);                               // '+' line
-            if (fx_view(f, lp, ln)) f->quals.append(lp, ln);
-            f->is_fastq.push_back(1);
-        } else if (first == '>') {
-            f->names.append(lp + 1, ln - 1);
-            std::string piece;
-            while (fx_line(f, piece)) {
-                if (!piece.empty() && piece[0] == '>') { f->pending.swap(piece); f->have_pending = true; break; }
-                fx_strip(piece);
-                f->seqs += piece;
-            }
-            f->is_fastq.push_back(0);
-        } else {
-            kv_set_error("cannot parse sequence file %s", f->path.c_str());
-            return KV_ERR_IO;
-        }
-        f->name_offs.push_back(f->names.size());
-        f->seq_offs.push_back(f->seqs.size());
-        f->qual_offs.push_back(f->quals.size());
-        ++n;
+    // ---- device path: BGZF + FASTQ, asked for as packed batches from the first call on
+    if (f->dev_candidate && !f->dev && f->num_reads == 0 && upload && reads_out) {
+        f->dev = kv_fastq_device_open(f->path.c_str());
+        if (!f->dev) f->dev_candidate = false;
     }
+    if (f->dev) {
+        int rc = upload && reads_out ? kv_fastq_device_next(f->dev, max_reads, reads_out, n_reads_out) : KV_ERR_TYPE;
+        if (rc == KV_OK) {
+            f->num_reads += *n_reads_out;
+            return KV_OK;
+        }
+        // not four-line FASTQ after all (or the caller wants host text now): the host parser takes over where the device
+        // path stopped
+        kv_fastq_device_close(f->dev);
+        f->dev = nullptr;
+        f->dev_candidate = false;
+        if (rc != KV_ERR_TYPE) return rc;
+        uint64_t left = f->num_reads;
+        while (left > 0) {
+            uint64_t got = 0;
+            rc = host_parse(f, std::min<uint64_t>(left, 65536), &got);
+            if (rc != KV_OK) return rc;
+            if (got == 0) break;
+            left -= got;
+            f->names.clear(); f->seqs.clear(); f->quals.clear();
+            f->name_offs.assign(1, 0); f->seq_offs.assign(1, 0); f->qual_offs.assign(1, 0);
+            f->is_fastq.clear();
+        }
+    }
+    f->dev_candidate = false;
+    uint64_t n = 0;
+    { const int rc = host_parse(f, max_reads, &n); if (rc != KV_OK) return rc; }
     f->num_reads += n;
     *n_reads_out = n;
     if (n == 0 && f->writer) {                       // the source is exhausted and every batch went through: publish the cache
@@ -506,5 +558,51 @@ extern "C" int kv_fastx_batch_text(kv_fastx *f, const char **names, const uint64
     if (quals) *quals = f->quals.data();
     if (qual_offs) *qual_offs = f->qual_offs.data();
     if (is_fastq) *is_fastq = f->is_fastq.data();
+    return KV_OK;
+}
+
+// 1 if the handle's batches are produced on the device (BGZF + FASTQ): a batch's text then stays in HBM and
+// kv_fastx_batch_text describes only the records kv_fastx_fetch asked for
+extern "C" int kv_fastx_on_device(kv_fastx *f, int *yes)
+{
+    KV_REQUIRE(f && yes, KV_ERR_ARG, "kv_fastx_on_device: null argument");
+    *yes = f->dev ? 1 : 0;
+    return KV_OK;
+}
+
+// text of records idx[0 .. n) of the batch last returned by a device-parsed handle, in that order: afterwards
+// kv_fastx_batch_text shows exactly these n records
+extern "C" int kv_fastx_fetch(kv_fastx *f, const uint64_t *idx, uint64_t n)
+{
+    KV_REQUIRE(f && (idx || n == 0), KV_ERR_ARG, "kv_fastx_fetch: null argument");
+    KV_REQUIRE(f->dev, KV_ERR_ARG, "kv_fastx_fetch: the handle does not parse on the device");
+    std::lock_guard<std::mutex> lk(f->mu);
+    std::string blob;
+    std::vector<uint64_t> offs;
+    { const int rc = kv_fastq_device_fetch(f->dev, idx, n, &blob, &offs); if (rc != KV_OK) return rc; }
+    f->names.clear(); f->seqs.clear(); f->quals.clear();
+    f->name_offs.assign(1, 0); f->seq_offs.assign(1, 0); f->qual_offs.assign(1, 0);
+    f->is_fastq.assign(n, 1);
+    for (uint64_t i = 0; i < n; ++i) {
+        const char *p = blob.data() + offs[i], *end = blob.data() + offs[i + 1];
+        const char *line[5];
+        line[0] = p;
+        for (int l = 1; l <= 4; ++l) {
+            const char *nl = (const char *)memchr(line[l - 1], '\n', (size_t)(end - line[l - 1]));
+            line[l] = nl ? nl + 1 : end;
+        }
+        auto text_of = [&](int l, size_t skip) {
+            size_t len = (size_t)(line[l + 1] - line[l]);
+            if (len && line[l][len - 1] == '\n') --len;
+            if (len && line[l][len - 1] == '\r') --len;
+            return std::string(line[l] + std::min(skip, len), len - std::min(skip, len));
+        };
+        f->names += text_of(0, 1);
+        f->seqs += text_of(1, 0);
+        f->quals += text_of(3, 0);
+        f->name_offs.push_back(f->names.size());
+        f->seq_offs.push_back(f->seqs.size());
+        f->qual_offs.push_back(f->quals.size());
+    }
     return KV_OK;
 }

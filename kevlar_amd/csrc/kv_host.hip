@@ -703,9 +703,28 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
 
 // reads that are already 2-bit packed on the host, any lengths: word offsets, tile table and uploads as kv_reads_create
 // builds them, minus the ASCII upload and the packing kernel (the packed-read cache of kv_fastx.hip comes through here)
+namespace {
+struct TextSource { const uint8_t *d_text; const uint64_t *d_seq_start; const uint32_t *d_seq_len; };
+int reads_from_packed(const uint32_t *words, const TextSource *text, const uint32_t *lens, const uint8_t *flags, uint64_t n_reads, kv_reads **out);
+}
+
 int kv_reads_from_packed_var(const uint32_t *words, const uint32_t *lens, const uint8_t *flags, uint64_t n_reads, kv_reads **out)
 {
     KV_REQUIRE(out && ((words && lens) || n_reads == 0), KV_ERR_ARG, "kv_reads_from_packed_var: null argument");
+    return reads_from_packed(words, nullptr, lens, flags, n_reads, out);
+}
+
+int kv_reads_from_device_text(const uint8_t *d_text, const uint64_t *d_seq_start, const uint32_t *d_seq_len, const uint32_t *lens,
+                              uint64_t n_reads, kv_reads **out)
+{
+    KV_REQUIRE(out && ((d_text && d_seq_start && d_seq_len && lens) || n_reads == 0), KV_ERR_ARG, "kv_reads_from_device_text: null argument");
+    const TextSource src = {d_text, d_seq_start, d_seq_len};
+    return reads_from_packed(nullptr, &src, lens, nullptr, n_reads, out);
+}
+
+namespace {
+int reads_from_packed(const uint32_t *words, const TextSource *text, const uint32_t *lens, const uint8_t *flags, uint64_t n_reads, kv_reads **out)
+{
     KV_REQUIRE(n_reads < 0xFFFFFFF0ull, KV_ERR_ARG, "too many reads in one batch");
     kv_reads *r = new kv_reads();
     r->n_reads = n_reads;
@@ -757,13 +776,17 @@ int kv_reads_from_packed_var(const uint32_t *words, const uint32_t *lens, const 
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, flag_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, tiles.size() * sizeof(TileDesc));
-    if (e == hipSuccess && nw) e = hipMemcpyAsync(r->d_words, words, nw * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && nw && words) e = hipMemcpyAsync(r->d_words, words, nw * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(r->d_words + nw, 0, 16, st);
     if (e == hipSuccess) e = hipMemcpyAsync(r->d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && n_reads) e = hipMemcpyAsync(r->d_len, r->h_len.data(), n_reads * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(r->d_flags, 0, flag_bytes, st);
     if (e == hipSuccess && n_reads && flags) e = hipMemcpyAsync(r->d_flags, flags, n_reads, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(r->d_tile, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && nw && text) {
+        kv_fastq_pack_launch(text->d_text, text->d_seq_start, text->d_seq_len, r->d_woff, n_reads, nw, r->d_words, (uint32_t *)r->d_flags, st);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
         kv_set_error("read batch upload failed: %s", hipGetErrorString(e));
@@ -773,6 +796,7 @@ int kv_reads_from_packed_var(const uint32_t *words, const uint32_t *lens, const 
     *out = r;
     return KV_OK;
 }
+}  // namespace
 
 extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, uint32_t read_len, kv_reads **out)
 {

@@ -1,0 +1,458 @@
+// kv_inflate.hip -- DEFLATE on the device for blocked gzip (BGZF) input (ingest).
+//
+// A plain .gz file is one DEFLATE stream: nothing can start before everything in front of it has been decoded, so it
+// inflates at the speed of one host core (~250 MB/s with zlib: ~1 M reads/s).  BGZF -- what bgzip, samtools and
+// htslib write, and what kevlar_amd.open(..., 'w') writes for *.gz -- is a series of independent gzip members of at
+// most 64 KB of text each, every member announcing its compressed size in an extra header field.  The host only hops
+// from header to header (kv_bgzf_index); the compressed bytes go to HBM as they are (a quarter of the text crosses
+// PCIe), and one wavefront inflates one member:
+//
+//   * the last 8 KB of the member's text stay in LDS, so nearly every LZ77 match is an LDS copy (the few that reach further
+//     back read the text the wave itself wrote to HBM);
+//   * the Huffman codes are walked one after the other (a serial job by nature) through 10-bit / 8-bit lookup tables in
+//     LDS, longer codes through the canonical count/symbol arrays; the walk is wave-uniform, so its arithmetic runs on the
+//     scalar unit; literals collect in a vector register, one per lane, and reach LDS 64 at a time;
+//   * a match is copied by all 64 lanes at once (an overlapping match is periodic in its distance, so every byte has a
+//     source in front of the match start);
+//   * text leaves for HBM in rows of up to 64 bytes as it is produced.
+//
+// Decoding one member is a chain of dependent lookups (a few hundred cycles per symbol whatever the code does), so the rate
+// comes from members in flight: 12 workgroups per CU, ~3000 members on the device.  The CRC-32 of a member is not checked
+// (its ISIZE is); tests compare the output with zlib's byte for byte.  Reference: the reader this replaces is
+// khmer.ReadParser's gzip stream (kevlar/__init__.py:125-128 opens every *.gz through it).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "kv_binned.h"
+#include "kv_internal.h"
+
+namespace {
+
+#define INF_FAST_LL 10          // bits of the literal/length lookup table
+#define INF_FAST_D 8            // ... of the distance table
+#define INF_MAX_OUT 65536u
+
+struct BitReader {
+    const uint32_t *words;      // aligned words of the payload
+    uint64_t next;              // index of the next word to take
+    uint64_t buf;               // bits not yet consumed, LSB first
+    uint32_t cnt;               // how many
+    uint32_t ahead;             // words[next], already loaded (hides the load behind the decode)
+};
+
+__device__ __forceinline__ void br_init(BitReader &br, const uint8_t *payload)
+{
+    const uint64_t addr = (uint64_t)payload;
+    const uint32_t mis = (uint32_t)(addr & 3u);
+    br.words = (const uint32_t *)(addr - mis);
+    br.buf = (uint64_t)(br.words[0] >> (8u * mis));
+    br.cnt = 32u - 8u * mis;
+    br.next = 1;
+    br.ahead = br.words[1];
+}
+
+__device__ __forceinline__ void br_need(BitReader &br, uint32_t n)   // n <= 32
+{
+    if (br.cnt < n) {
+        br.buf |= (uint64_t)br.ahead << br.cnt;
+        br.cnt += 32u;
+        br.next += 1;
+        br.ahead = br.words[br.next];
+    }
+}
+
+__device__ __forceinline__ uint32_t br_bits(BitReader &br, uint32_t n)   // n <= 16
+{
+    br_need(br, n);
+    const uint32_t v = (uint32_t)br.buf & ((1u << n) - 1u);
+    br.buf >>= n;
+    br.cnt -= n;
+    return v;
+}
+
+// canonical Huffman code of `n` symbols with the given lengths: count[len], symbols sorted by (len, symbol), and the
+// lookup table of the codes of at most `fast` bits (entry = symbol | len << 9; 0 = longer code).  Returns false if the
+// lengths oversubscribe the code space.
+__device__ bool build_code(const uint8_t *lengths, int n, uint16_t *count, uint16_t *symbol, uint16_t *table, int fast)
+{
+    for (int l = 0; l <= 15; ++l) count[l] = 0;
+    for (int s = 0; s < n; ++s) count[lengths[s]]++;
+    int left = 1;
+    for (int l = 1; l <= 15; ++l) {
+        left <<= 1;
+        left -= count[l];
+        if (left < 0) return false;
+    }
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + count[l];
+    for (int s = 0; s < n; ++s)
+        if (lengths[s]) symbol[offs[lengths[s]]++] = (uint16_t)s;
+    for (int i = 0; i < (1 << fast); ++i) table[i] = 0;
+    // codes in canonical order: first code of each length, then consecutive
+    uint32_t code = 0, index = 0;
+    for (int l = 1; l <= fast; ++l) {
+        for (uint32_t j = 0; j < count[l]; ++j, ++code, ++index) {
+            const uint32_t rev = __brev(code) >> (32 - l);            // the stream carries a code's bits MSB first
+            const uint16_t entry = (uint16_t)(symbol[index] | (l << 9));
+            for (uint32_t fill = rev; fill < (1u << fast); fill += 1u << l) table[fill] = entry;
+        }
+        code <<= 1;
+    }
+    return true;
+}
+
+// One symbol.  Every lane runs this with the same (wave-uniform) reader state, so the arithmetic lives on the scalar unit;
+// only the table word comes through a vector register and is made uniform again at once.
+#define INF_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+__device__ __forceinline__ int decode_sym(BitReader &br, const uint16_t *count, const uint16_t *symbol, const uint16_t *table, int fast)
+{
+    br_need(br, 15);
+    const uint32_t e = INF_UNI(table[(uint32_t)br.buf & ((1u << fast) - 1u)]);
+    if (e) {
+        const uint32_t l = e >> 9;
+        br.buf >>= l;
+        br.cnt -= l;
+        return (int)(e & 0x1ffu);
+    }
+    // a code longer than the table: bit by bit through the canonical counts
+    int code = 0, first = 0, index = 0;
+    uint64_t bits = br.buf;
+    for (int l = 1; l <= 15; ++l) {
+        code |= (int)(bits & 1u);
+        bits >>= 1;
+        const int c = (int)INF_UNI(count[l]);
+        if (code - c < first) {
+            br.buf >>= l;
+            br.cnt -= l;
+            return (int)INF_UNI(symbol[index + (code - first)]);
+        }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct InflateJob {
+    uint64_t in_off;        // deflate payload of the member, relative to the compressed buffer
+    uint32_t in_len;
+    uint32_t isize;         // bytes the member inflates to
+    uint64_t out_off;       // where they go in the text buffer
+};
+
+template <int RBITS>
+struct InflateShared {
+    uint8_t ring[1 << RBITS];      // the last 2^RBITS bytes of text (byte t of the member at t mod 2^RBITS)
+    uint16_t ll_table[1 << INF_FAST_LL];
+    uint16_t d_table[1 << INF_FAST_D];
+    uint16_t ll_count[16], d_count[16];
+    uint16_t ll_symbol[288], d_symbol[32];
+    uint8_t lengths[352];          // 19 code-length codes, then up to 286 + 30 code lengths
+};
+
+template <int RBITS>
+__global__ __launch_bounds__(64, (RBITS <= 13 ? 3 : RBITS == 14 ? 2 : 1)) void k_inflate(const uint8_t *__restrict__ comp, const InflateJob *__restrict__ jobs, uint32_t n_jobs,
+                                                 uint8_t *text, unsigned long long *ctr)
+{
+    __shared__ InflateShared<RBITS> sh;
+    constexpr uint32_t RMASK = (1u << RBITS) - 1u;
+    const uint32_t lane = threadIdx.x;
+    for (;;) {
+        uint32_t job_id = 0;
+        if (lane == 0) job_id = (uint32_t)atomicAdd(&ctr[0], 1ull);
+        job_id = INF_UNI(job_id);
+        if (job_id >= n_jobs) return;
+        const InflateJob job = jobs[job_id];
+        if (job.isize == 0) continue;                 // BGZF's end-of-file marker, or an empty member
+        BitReader br;                                 // identical in every lane
+        br_init(br, comp + job.in_off);
+        uint32_t o = 0;                               // bytes of text produced
+        uint32_t lit = 0, n_lit = 0;                  // literals not yet stored: lane i holds the i-th, n_lit of them
+        bool failed = job.isize > INF_MAX_OUT;
+        bool last_block = false;
+        uint8_t *dst = text + job.out_off;
+        // pending literals -> LDS window and HBM, one row store each for up to 64 of them
+        auto flush = [&]() {
+            if (lane < n_lit) { sh.ring[(o + lane) & RMASK] = (uint8_t)lit; dst[o + lane] = (uint8_t)lit; }
+            o += n_lit;
+            n_lit = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        while (!failed && !last_block) {
+            // ---- block header and code tables
+            last_block = br_bits(br, 1) != 0;
+            const uint32_t btype = br_bits(br, 2);
+            if (btype == 0) {
+                const uint32_t drop = br.cnt & 7u;        // to the next byte boundary
+                br.buf >>= drop; br.cnt -= drop;
+                const uint32_t stored_len = br_bits(br, 16);
+                const uint32_t inv = br_bits(br, 16);
+                if ((stored_len ^ inv) != 0xffffu || o + stored_len > job.isize) { failed = true; break; }
+                for (uint32_t j = 0; j < stored_len; ++j) {
+                    const uint32_t byte = br_bits(br, 8);
+                    lit = lane == n_lit ? byte : lit;
+                    if (++n_lit == 64) flush();
+                }
+                flush();
+                continue;
+            }
+            if (btype == 3) { failed = true; break; }
+            uint32_t ok = 1;
+            if (btype == 1) {
+                if (lane == 0) {
+                    for (int s = 0; s < 144; ++s) sh.lengths[s] = 8;
+                    for (int s = 144; s < 256; ++s) sh.lengths[s] = 9;
+                    for (int s = 256; s < 280; ++s) sh.lengths[s] = 7;
+                    for (int s = 280; s < 288; ++s) sh.lengths[s] = 8;
+                    ok = build_code(sh.lengths, 288, sh.ll_count, sh.ll_symbol, sh.ll_table, INF_FAST_LL);
+                    for (int s = 0; s < 30; ++s) sh.lengths[s] = 5;
+                    ok = ok && build_code(sh.lengths, 30, sh.d_count, sh.d_symbol, sh.d_table, INF_FAST_D);
+                }
+            } else {
+                const uint32_t nlen = br_bits(br, 5) + 257, ndist = br_bits(br, 5) + 1, ncode = br_bits(br, 4) + 4;
+                if (nlen > 286 || ndist > 30) { failed = true; break; }
+                if (lane < 19) sh.lengths[lane] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t s = 0; s < ncode; ++s) {
+                    const uint32_t v = br_bits(br, 3);
+                    if (lane == 0) sh.lengths[c_clen_order[s]] = (uint8_t)v;
+                }
+                // the code-length code lives in the distance arrays for a moment
+                if (lane == 0) ok = build_code(sh.lengths, 19, sh.d_count, sh.d_symbol, sh.d_table, 7);
+                ok = INF_UNI(ok);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                uint32_t idx = 0, prev = 0;
+                while (ok && idx < nlen + ndist) {
+                    const int sym = decode_sym(br, sh.d_count, sh.d_symbol, sh.d_table, 7);
+                    if (sym < 0) { ok = 0; break; }
+                    uint32_t rep = 1, val = (uint32_t)sym;
+                    if (sym == 16) {
+                        if (idx == 0) { ok = 0; break; }
+                        val = prev;
+                        rep = 3 + br_bits(br, 2);
+                    } else if (sym == 17) { val = 0; rep = 3 + br_bits(br, 3); }
+                    else if (sym == 18) { val = 0; rep = 11 + br_bits(br, 7); }
+                    if (idx + rep > nlen + ndist) { ok = 0; break; }
+                    if (lane < rep) sh.lengths[19 + idx + lane] = (uint8_t)val;       // rep <= 138: at most three rows
+                    if (lane + 64 < rep) sh.lengths[19 + idx + lane + 64] = (uint8_t)val;
+                    if (lane + 128 < rep) sh.lengths[19 + idx + lane + 128] = (uint8_t)val;
+                    idx += rep;
+                    prev = val;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0 && ok) {
+                    ok = sh.lengths[19 + 256] != 0;     // a block without an end code cannot end
+                    ok = ok && build_code(sh.lengths + 19, (int)nlen, sh.ll_count, sh.ll_symbol, sh.ll_table, INF_FAST_LL);
+                    ok = ok && build_code(sh.lengths + 19 + nlen, (int)ndist, sh.d_count, sh.d_symbol, sh.d_table, INF_FAST_D);
+                }
+            }
+            ok = INF_UNI(ok);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (!ok) { failed = true; break; }
+            // ---- symbols
+            for (;;) {
+                const int sym = decode_sym(br, sh.ll_count, sh.ll_symbol, sh.ll_table, INF_FAST_LL);
+                if (sym < 0) { failed = true; break; }
+                if (sym < 256) {
+                    if (o + n_lit >= job.isize) { failed = true; break; }
+                    lit = lane == n_lit ? (uint32_t)sym : lit;
+                    if (++n_lit == 64) flush();
+                    continue;
+                }
+                flush();
+                if (sym == 256) break;
+                const int ls = sym - 257;
+                if (ls >= 29) { failed = true; break; }
+                const uint32_t len = c_len_base[ls] + br_bits(br, c_len_extra[ls]);
+                const int ds = decode_sym(br, sh.d_count, sh.d_symbol, sh.d_table, INF_FAST_D);
+                if (ds < 0 || ds >= 30) { failed = true; break; }
+                const uint32_t extra = c_dist_extra[ds];
+                br_need(br, 16);
+                const uint32_t dist = c_dist_base[ds] + ((uint32_t)br.buf & ((1u << extra) - 1u));
+                br.buf >>= extra; br.cnt -= extra;
+                if (dist > o || o + len > job.isize) { failed = true; break; }
+                // all lanes copy; an overlapping match repeats its first `dist` bytes.  The source comes from the LDS window
+                // unless it lies further back than the window reaches (or where this very copy is about to write): then
+                // from the text in HBM, which this wave wrote itself -- fence, then loads that bypass the CU's L1
+                const uint32_t from = o - dist;
+                if (dist + 258u <= (1u << RBITS)) {
+                    for (uint32_t j = lane; j < len; j += 64) {
+                        const uint32_t src = dist >= len ? from + j : from + j % dist;
+                        const uint8_t v = sh.ring[src & RMASK];
+                        sh.ring[(o + j) & RMASK] = v;
+                        dst[o + j] = v;
+                    }
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    for (uint32_t j = lane; j < len; j += 64) {                        // dist > 258 >= len here: no overlap
+                        const uint8_t v = __hip_atomic_load(dst + from + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sh.ring[(o + j) & RMASK] = v;
+                        dst[o + j] = v;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                o += len;
+            }
+        }
+        if (failed || o != job.isize) {
+            if (lane == 0) { atomicAdd(&ctr[1], 1ull); atomicMin(&ctr[2], (unsigned long long)job_id); }
+            continue;
+        }
+        __builtin_amdgcn_wave_barrier();           // the next member reuses the window
+    }
+}
+
+}  // namespace
+
+// Index of a BGZF file image: for every member the deflate payload and the size it inflates to.  Returns KV_OK and
+// *is_bgzf = 0 for anything that is not BGZF from its first byte to its last (plain gzip, a truncated file, ...).
+int kv_bgzf_index(const uint8_t *file, uint64_t size, std::vector<KvBgzfMember> *members, int *is_bgzf)
+{
+    members->clear();
+    *is_bgzf = 0;
+    uint64_t pos = 0;
+    while (pos < size) {
+        if (size - pos < 18 + 8) return KV_OK;
+        const uint8_t *h = file + pos;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 4) == 0) return KV_OK;
+        if (h[3] & ~4u) return KV_OK;                           // name / comment / header CRC fields: not written by bgzip
+        const uint32_t xlen = h[10] | (h[11] << 8);
+        if (size - pos < 12 + (uint64_t)xlen + 8) return KV_OK;
+        uint32_t bsize = 0;
+        bool found = false;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            const uint8_t *sf = h + 12 + x;
+            const uint32_t slen = sf[2] | (sf[3] << 8);
+            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) { bsize = (sf[4] | (sf[5] << 8)) + 1u; found = true; }
+            x += 4 + slen;
+        }
+        if (!found || bsize < 12 + xlen + 8 || pos + bsize > size) return KV_OK;
+        KvBgzfMember m;
+        m.in_off = pos + 12 + xlen;
+        m.in_len = bsize - 12 - xlen - 8;
+        const uint8_t *t = file + pos + bsize - 4;
+        m.isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (m.isize > INF_MAX_OUT) return KV_OK;
+        members->push_back(m);
+        pos += bsize;
+    }
+    *is_bgzf = members->empty() ? 0 : 1;
+    return KV_OK;
+}
+
+// Inflate members [first, first + count) of a BGZF image whose bytes [comp_base, comp_base + comp_len) sit at d_comp (with
+// 16 readable bytes behind them): member i's text goes to d_text + text_off[i].  Runs on the calling thread's stream and
+// returns once the text is there.
+int kv_bgzf_inflate(const uint8_t *d_comp, uint64_t comp_base, const KvBgzfMember *members, uint64_t count, const uint64_t *text_off,
+                    uint8_t *d_text, KvArena &scratch)
+{
+    if (count == 0) return KV_OK;
+    KV_REQUIRE(count < (1ull << 31), KV_ERR_ARG, "kv_bgzf_inflate: too many members in one call");
+    hipStream_t st = kv_stream();
+    std::vector<InflateJob> jobs(count);
+    for (uint64_t i = 0; i < count; ++i) {
+        jobs[i].in_off = members[i].in_off - comp_base;
+        jobs[i].in_len = members[i].in_len;
+        jobs[i].isize = members[i].isize;
+        jobs[i].out_off = text_off[i];
+    }
+    const size_t b_jobs = kv_round_up(count * sizeof(InflateJob), 256);
+    KV_HIP(scratch.need(b_jobs + 256));
+    InflateJob *d_jobs = (InflateJob *)scratch.p;
+    unsigned long long *d_ctr = (unsigned long long *)((unsigned char *)scratch.p + b_jobs);
+    const unsigned long long init[3] = {0, 0, ~0ull};
+    KV_HIP(hipMemcpyAsync(d_jobs, jobs.data(), count * sizeof(InflateJob), hipMemcpyHostToDevice, st));
+    KV_HIP(hipMemcpyAsync(d_ctr, init, sizeof(init), hipMemcpyHostToDevice, st));
+    {
+        KvProfScope prof("k_inflate");
+        // the LDS window sets how many members a CU holds: 8 KB -> 12 workgroups; matches that reach further back (up to
+        // 32 KB) read the text from HBM.  KV_INFLATE_WINDOW_BITS = 13 .. 15 for experiments.
+        const char *wb = getenv("KV_INFLATE_WINDOW_BITS");
+        const int bits = wb ? atoi(wb) : 13;
+        const int per_cu = bits >= 15 ? 4 : bits == 14 ? 8 : 12;
+        const unsigned grid = (unsigned)std::min<uint64_t>(count, (uint64_t)per_cu * (uint64_t)kv_device_cus());
+        if (bits >= 15) hipLaunchKernelGGL(k_inflate<15>, dim3(grid), dim3(64), 0, st, d_comp, (const InflateJob *)d_jobs, (uint32_t)count, d_text, d_ctr);
+        else if (bits == 14) hipLaunchKernelGGL(k_inflate<14>, dim3(grid), dim3(64), 0, st, d_comp, (const InflateJob *)d_jobs, (uint32_t)count, d_text, d_ctr);
+        else hipLaunchKernelGGL(k_inflate<13>, dim3(grid), dim3(64), 0, st, d_comp, (const InflateJob *)d_jobs, (uint32_t)count, d_text, d_ctr);
+    }
+    KV_HIP(hipGetLastError());
+    unsigned long long ctr[3] = {0, 0, 0};
+    KV_HIP(hipMemcpyAsync(ctr, d_ctr, sizeof(ctr), hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    if (ctr[1] != 0) {
+        kv_set_error("corrupt BGZF data: %llu member(s) did not inflate to their stated size (first: member %llu of the batch)", ctr[1], ctr[2]);
+        return KV_ERR_IO;
+    }
+    return KV_OK;
+}
+
+// Whole-buffer form for tests and tools: inflate a BGZF image that sits in host memory; `out` must hold the sum of the
+// members' sizes (kv_bgzf_text_size).
+extern "C" int kv_bgzf_text_size(const void *file, uint64_t size, uint64_t *text_bytes, uint64_t *n_members)
+{
+    KV_REQUIRE(file && text_bytes, KV_ERR_ARG, "kv_bgzf_text_size: null argument");
+    std::vector<KvBgzfMember> members;
+    int yes = 0;
+    kv_bgzf_index((const uint8_t *)file, size, &members, &yes);
+    KV_REQUIRE(yes, KV_ERR_IO, "not a BGZF file image");
+    uint64_t total = 0;
+    for (const KvBgzfMember &m : members) total += m.isize;
+    *text_bytes = total;
+    if (n_members) *n_members = members.size();
+    return KV_OK;
+}
+
+extern "C" int kv_bgzf_inflate_host(const void *file, uint64_t size, void *out, uint64_t out_cap, double *kernel_ms)
+{
+    KV_REQUIRE(file && out, KV_ERR_ARG, "kv_bgzf_inflate_host: null argument");
+    std::vector<KvBgzfMember> members;
+    int yes = 0;
+    kv_bgzf_index((const uint8_t *)file, size, &members, &yes);
+    KV_REQUIRE(yes, KV_ERR_IO, "not a BGZF file image");
+    std::vector<uint64_t> text_off(members.size());
+    uint64_t total = 0;
+    for (size_t i = 0; i < members.size(); ++i) { text_off[i] = total; total += members[i].isize; }
+    KV_REQUIRE(total <= out_cap, KV_ERR_CAPACITY, "kv_bgzf_inflate_host: the text needs %llu bytes", (unsigned long long)total);
+    uint8_t *d_comp = nullptr, *d_text = nullptr;
+    KvArena scratch;
+    hipStream_t st = kv_stream();
+    int rc = KV_OK;
+    hipError_t e = hipMalloc((void **)&d_comp, size + 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_text, total + 64);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_comp, file, size, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_comp + size, 0, 64, st);
+    if (e == hipSuccess) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, st);
+        rc = kv_bgzf_inflate(d_comp, 0, members.data(), members.size(), text_off.data(), d_text, scratch);
+        (void)hipEventRecord(b, st);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        if (kernel_ms) *kernel_ms = ms;
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        if (rc == KV_OK) e = hipMemcpy(out, d_text, total, hipMemcpyDeviceToHost);
+    }
+    if (d_comp) (void)hipFree(d_comp);
+    if (d_text) (void)hipFree(d_text);
+    if (scratch.p) (void)hipFree(scratch.p);
+    if (rc != KV_OK) return rc;
+    if (e != hipSuccess) { kv_set_error("kv_bgzf_inflate_host: %s", hipGetErrorString(e)); return KV_ERR_HIP; }
+    return KV_OK;
+}

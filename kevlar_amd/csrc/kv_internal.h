@@ -83,6 +83,12 @@ struct kv_reads {
 };
 
 int kv_reads_from_packed_var(const uint32_t *words, const uint32_t *lens, const uint8_t *flags, uint64_t n_reads, kv_reads **out);
+// the same for sequences that sit as text in HBM (kv_fastq.hip): read r = d_seq_len[r] characters at d_text + d_seq_start[r];
+// `lens` is the host copy of d_seq_len; packing and flagging happen on the device
+int kv_reads_from_device_text(const uint8_t *d_text, const uint64_t *d_seq_start, const uint32_t *d_seq_len, const uint32_t *lens,
+                              uint64_t n_reads, kv_reads **out);
+void kv_fastq_pack_launch(const uint8_t *d_text, const uint64_t *d_seq_start, const uint32_t *d_seq_len, const uint64_t *d_woff, uint64_t n_reads,
+                          uint64_t n_words, uint32_t *d_words, uint32_t *d_flags32, hipStream_t st);
 
 // hits of one scan in pinned host memory (fast DMA from the device; the Python side views it in place).
 // Blocks come from a small recycling pool (kv_host.hip): hipHostMalloc costs ~1 ms per call, more than
@@ -210,3 +216,23 @@ uint64_t kv_host_murmur_lo(const void *data, int len, uint32_t seed);
 uint64_t kv_host_hash(int hashfam, const char *kmer, int k, bool *ok);
 int kv_sketch_alloc(int kind, int ksize, int ntables, const uint64_t *sizes, kv_sketch **out);
 int kv_sketch_refresh_occupancy(kv_sketch *s);
+
+// ---- blocked gzip (BGZF) on the device (kv_inflate.hip) ----
+struct KvBgzfMember {
+    uint64_t in_off;     // the member's deflate payload in the file
+    uint32_t in_len;
+    uint32_t isize;      // bytes it inflates to
+};
+struct KvArena;
+int kv_bgzf_index(const uint8_t *file, uint64_t size, std::vector<KvBgzfMember> *members, int *is_bgzf);
+int kv_bgzf_inflate(const uint8_t *d_comp, uint64_t comp_base, const KvBgzfMember *members, uint64_t count, const uint64_t *text_off,
+                    uint8_t *d_text, KvArena &scratch);
+
+// ---- FASTQ split and packed on the device (kv_fastq.hip) ----
+struct KvFastqDevice;
+KvFastqDevice *kv_fastq_device_open(const char *path);         // NULL unless the file is BGZF from end to end
+void kv_fastq_device_close(KvFastqDevice *d);
+// up to max_reads records as a batch in HBM (*n_out = 0 at the end of the file); KV_ERR_TYPE = not four-line FASTQ
+int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_out, uint64_t *n_out);
+// raw text (four lines each) of records idx[0 .. n) of the batch last returned: record i at blob[offs[i] .. offs[i + 1])
+int kv_fastq_device_fetch(KvFastqDevice *d, const uint64_t *idx, uint64_t n, std::string *blob, std::vector<uint64_t> *offs);

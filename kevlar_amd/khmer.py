@@ -179,6 +179,9 @@ class TextBatch(object):
         qual = self._quals[self._qo[i]:self._qo[i + 1]].decode('latin-1') if self._fq[i] else None
         return Read(self.name(i), self.sequence(i), qual)
 
+    def prefetch(self, indices):
+        """Hint that record(i) will be asked for these i (a no-op when the text is already on the host)."""
+
     def find_name(self, name):
         """Index of the first record called `name`, or -1."""
         raw = name.encode('latin-1')
@@ -191,6 +194,46 @@ class TextBatch(object):
             if self._no[i] == pos and self._no[i + 1] - pos == len(raw):
                 return i
             start = pos + 1
+
+
+class DeviceTextBatch(object):
+    """A batch whose text never left HBM (BGZF FASTQ parsed on the device, kv_fastq.hip): records come to the host
+    when asked for -- prefetch(indices) brings a set in one gather -- and are cached."""
+
+    def __init__(self, n, batch, fetch):
+        self.n = n
+        self.batch = batch
+        self._fetch = fetch          # indices -> TextBatch of exactly those records
+        self._have = {}
+
+    def prefetch(self, indices):
+        want = [int(i) for i in dict.fromkeys(int(i) for i in indices) if int(i) not in self._have]
+        if not want:
+            return
+        sub = self._fetch(want)
+        for pos, i in enumerate(want):
+            self._have[i] = sub.record(pos)
+
+    def record(self, i):
+        i = int(i)
+        if i not in self._have:
+            self.prefetch([i])
+        return self._have[i]
+
+    def name(self, i):
+        return self.record(i).name
+
+    def sequence(self, i):
+        return self.record(i).sequence
+
+    def find_name(self, name):
+        step = 1 << 18
+        for lo in range(0, self.n, step):
+            sub = self._fetch(list(range(lo, min(self.n, lo + step))))
+            at = sub.find_name(name)
+            if at >= 0:
+                return lo + at
+        return -1
 
 
 class ReadParser(object):
@@ -261,22 +304,37 @@ class ReadParser(object):
             if got is None:
                 return None
             n, batch = got
-            vp, u64p, u8p = ctypes.c_void_p, _lib.u64p, _lib.u8p
-            names, seqs, quals = vp(), vp(), vp()
-            no, so, qo, fq = u64p(), u64p(), u64p(), u8p()
-            check(lib.kv_fastx_batch_text(self._h, ctypes.byref(names), ctypes.byref(no), ctypes.byref(seqs),
-                                          ctypes.byref(so), ctypes.byref(quals), ctypes.byref(qo), ctypes.byref(fq)))
-            name_offs = np.ctypeslib.as_array(no, shape=(n + 1,)).copy()
-            seq_offs = np.ctypeslib.as_array(so, shape=(n + 1,)).copy()
-            qual_offs = np.ctypeslib.as_array(qo, shape=(n + 1,)).copy()
-            is_fastq = np.ctypeslib.as_array(fq, shape=(n,)).copy()
-            if self.from_cache:        # sequences and qualities stay in the cache file until a record is asked for
-                tb = TextBatch(n, ctypes.string_at(names, int(name_offs[n])), name_offs, None, seq_offs, None, qual_offs,
-                               is_fastq, batch, fetch=self._record_text)
-            else:
-                tb = TextBatch(n, ctypes.string_at(names, int(name_offs[n])), name_offs,
-                               ctypes.string_at(seqs, int(seq_offs[n])), seq_offs,
-                               ctypes.string_at(quals, int(qual_offs[n])), qual_offs, is_fastq, batch)
+            on_device = ctypes.c_int()
+            check(lib.kv_fastx_on_device(self._h, ctypes.byref(on_device)))
+            if on_device.value:
+                return DeviceTextBatch(n, batch, self._fetch_records)
+            return self._host_text(n, batch)
+
+    def _fetch_records(self, indices):
+        """Text of the given records of the current device-parsed batch as a TextBatch of len(indices) records."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        with self._lock:
+            check(_lib.load().kv_fastx_fetch(self._h, _u64p(idx), len(idx)))
+            return self._host_text(len(idx), None)
+
+    def _host_text(self, n, batch):
+        lib = _lib.load()
+        vp, u64p, u8p = ctypes.c_void_p, _lib.u64p, _lib.u8p
+        names, seqs, quals = vp(), vp(), vp()
+        no, so, qo, fq = u64p(), u64p(), u64p(), u8p()
+        check(lib.kv_fastx_batch_text(self._h, ctypes.byref(names), ctypes.byref(no), ctypes.byref(seqs),
+                                      ctypes.byref(so), ctypes.byref(quals), ctypes.byref(qo), ctypes.byref(fq)))
+        name_offs = np.ctypeslib.as_array(no, shape=(n + 1,)).copy()
+        seq_offs = np.ctypeslib.as_array(so, shape=(n + 1,)).copy()
+        qual_offs = np.ctypeslib.as_array(qo, shape=(n + 1,)).copy()
+        is_fastq = np.ctypeslib.as_array(fq, shape=(n,)).copy()
+        if self.from_cache:        # sequences and qualities stay in the cache file until a record is asked for
+            tb = TextBatch(n, ctypes.string_at(names, int(name_offs[n])), name_offs, None, seq_offs, None, qual_offs,
+                           is_fastq, batch, fetch=self._record_text)
+        else:
+            tb = TextBatch(n, ctypes.string_at(names, int(name_offs[n])), name_offs,
+                           ctypes.string_at(seqs, int(seq_offs[n])), seq_offs,
+                           ctypes.string_at(quals, int(qual_offs[n])), qual_offs, is_fastq, batch)
         return tb
 
     def text_batches(self, max_reads, upload=True):

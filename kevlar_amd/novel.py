@@ -73,6 +73,9 @@ class _Parsed(object):
     def record(self, i):
         return self.records[i]
 
+    def prefetch(self, indices):
+        pass
+
     def find_name(self, name):
         return next((i for i, r in enumerate(self.records) if r.name == name), -1)
 
@@ -107,6 +110,7 @@ class _Tally(object):
 def _annotate(text, hits, k, tally):
     """records for the runs of hits (read, offset, abundances; sorted by read) of one batch"""
     reads, offsets, abunds, dropped = hits
+    text.prefetch(np.concatenate((np.unique(reads), np.unique(dropped.shadow[0]))) if len(dropped) else np.unique(reads))
     if len(dropped):
         # the reference tallies the interesting k-mers in front of the k-mer that tripped the screen, then drops the read
         for ridx, off in zip(*(a.tolist() for a in dropped.shadow)):

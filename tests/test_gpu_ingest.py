@@ -1,0 +1,185 @@
+"""Device ingest (kv_inflate.hip, kv_fastq.hip): BGZF members inflated by the GPU must give zlib's bytes, and a FASTQ
+file parsed on the device the same batches, record text and counts as the host parser."""
+import ctypes
+import gzip
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def fastq_text(n, seed, read_len=100):
+    from kevlar_amd import synth
+    trio = synth.make_trio(100000, seed)
+    reads = synth.unpack_reads(synth.sample_reads_packed(trio['proband'], n, read_len, 0.01, seed + 1), read_len)
+    rng = np.random.default_rng(seed)
+    quals = rng.integers(33, 74, size=(n, read_len), dtype=np.uint8)
+    out = []
+    for i, seq in enumerate(reads):
+        out.append('@read{}/1 sample=proband\n{}\n+\n{}\n'.format(i, seq, quals[i].tobytes().decode('ascii')))
+    return ''.join(out).encode('ascii')
+
+
+def device_inflate(image):
+    from kevlar_amd import _lib
+    lib = _lib.load()
+    total, members = ctypes.c_uint64(), ctypes.c_uint64()
+    _lib.check(lib.kv_bgzf_text_size(image, len(image), ctypes.byref(total), ctypes.byref(members)))
+    out = ctypes.create_string_buffer(total.value + 1)
+    ms = ctypes.c_double()
+    _lib.check(lib.kv_bgzf_inflate_host(image, len(image), out, total.value, ctypes.byref(ms)))
+    return out.raw[:total.value], members.value, ms.value
+
+
+@pytest.mark.parametrize('level', [1, 6, 9, 0])
+def test_device_inflate_equals_zlib(hk, level, tmp_path):
+    from kevlar_amd import bgzf
+    text = fastq_text(40000, 3 + level)
+    path = str(tmp_path / 'reads.fq.gz')
+    with bgzf.BgzfWriter(path, level=level) as sink:
+        sink.write(text)
+    image = open(path, 'rb').read()
+    assert gzip.decompress(image) == text
+    got, members, ms = device_inflate(image)
+    assert members == (len(text) + bgzf.BLOCK_TEXT - 1) // bgzf.BLOCK_TEXT + 1        # + the end-of-file marker
+    assert got == text
+
+
+def test_device_inflate_odd_members(hk):
+    """fixed-Huffman members (tiny inputs), a one-byte member, long overlapping matches, incompressible bytes, empty members"""
+    from kevlar_amd import bgzf
+    rng = np.random.default_rng(5)
+    parts = [b'A', b'ACGT' * 3, b'', b'x' * 65536, bytes(rng.integers(0, 256, 65280, dtype=np.uint8)), b'ab' * 30000 + b'c',
+             bytes(rng.integers(0, 4, 60000, dtype=np.uint8)), b'\n' * 1000]
+    image = b''.join(bgzf.member(p, level=lv) for p, lv in zip(parts, (6, 6, 6, 9, 6, 1, 6, 9))) + bgzf._EOF
+    assert gzip.decompress(image) == b''.join(parts)
+    got, members, _ = device_inflate(image)
+    assert members == len(parts) + 1
+    assert got == b''.join(parts)
+
+
+def test_device_inflate_reports_corruption(hk):
+    from kevlar_amd import _lib, bgzf
+    text = fastq_text(3000, 9)
+    good = bgzf.member(text[:60000]) + bgzf.member(text[60000:120000]) + bgzf._EOF
+    bad = bytearray(good)
+    for at in range(40, 60):
+        bad[at] ^= 0x5a                     # inside the first member's deflate payload
+    with pytest.raises(Exception) as err:
+        device_inflate(bytes(bad))
+    assert 'BGZF' in str(err.value)
+    with pytest.raises(Exception):
+        device_inflate(gzip.compress(text))          # plain gzip: not BGZF
+
+
+def write_fastq(path, text, bgzf_level=6):
+    from kevlar_amd import bgzf
+    with bgzf.BgzfWriter(path, level=bgzf_level) as sink:
+        sink.write(text)
+
+
+def batches_of(hk, path, size, env=None):
+    """(per batch: count tables of k=25, lengths) + every record's text, through ReadParser.text_batches"""
+    env = env or {}
+    os.environ.update(env)
+    try:
+        parser = hk.ReadParser(path)
+        sketch = hk.Counttable(25, 4e6, 4)
+        sizes, records, modes = [], [], []
+        for tb in parser.text_batches(size):
+            sizes.append(tb.n)
+            modes.append(type(tb).__name__)
+            sketch.consume_batch(tb.batch)
+            tb.prefetch(range(0, tb.n, 7))
+            for i in range(0, tb.n, 7):
+                r = tb.record(i)
+                records.append((r.name, r.sequence, r.quality))
+            last = tb.record(tb.n - 1)
+            records.append((last.name, last.sequence, last.quality))
+            tb.batch.close()
+        return sizes, records, [sketch.table_bytes(t) for t in range(4)], modes, parser.num_reads
+    finally:
+        for key in env:
+            os.environ.pop(key, None)
+
+
+@pytest.mark.parametrize('batch,text_mb', [(100000, None), (7001, None), (100000, '1'), (2500, '1')])
+def test_device_parse_equals_host_parse(hk, tmp_path, batch, text_mb):
+    """BGZF FASTQ parsed on the device: same records, same packed reads (through the count tables they produce) as
+    the host parser; reads with N / lower case, ragged lengths, CRLF, a last line without newline"""
+    text = fastq_text(30000, 21).decode('ascii').split('\n')
+    text[4 * 5 + 1] = text[4 * 5 + 1][:30] + 'N' + text[4 * 5 + 1][31:]
+    text[4 * 9 + 1] = text[4 * 9 + 1].lower()
+    text[4 * 11 + 1] = text[4 * 11 + 1][:20]; text[4 * 11 + 3] = text[4 * 11 + 3][:20]
+    text[4 * 13 + 1] = ''; text[4 * 13 + 3] = ''
+    text[4 * 17 + 1] += 'ACGTACGTAC' * 40; text[4 * 17 + 3] += 'I' * 400
+    for line in range(4 * 20, 4 * 24):
+        text[line] += '\r'
+    blob = '\n'.join(text).rstrip('\n')              # no newline behind the last quality line
+    path = str(tmp_path / 'reads.fq.gz')
+    write_fastq(path, blob)
+    host = batches_of(hk, path, batch, {'KV_INGEST': 'host'})
+    dev = batches_of(hk, path, batch, {'KV_INGEST_TEXT_MB': text_mb} if text_mb else None)
+    assert set(host[3]) == {'TextBatch'} and set(dev[3]) == {'DeviceTextBatch'}
+    assert host[4] == dev[4] == 30000 and sum(host[0]) == sum(dev[0]) == 30000
+    assert max(dev[0]) <= batch
+    if text_mb is None:
+        assert host[0] == dev[0]
+    assert host[2] == dev[2]
+    if host[0] == dev[0]:
+        assert host[1] == dev[1]
+    # take_batch (count's way in) and find_name
+    parser = hk.ReadParser(path)
+    tb = parser.text_batch(1000)
+    assert tb.find_name('read777/1 sample=proband') == 777 and tb.find_name('nobody') == -1
+    assert tb.record(20).sequence == text[4 * 20 + 1].rstrip('\r')
+
+
+def test_device_parse_falls_back_to_host(hk, tmp_path):
+    """BGZF that is not four-line FASTQ -- FASTA, or FASTQ with a blank line in the middle -- ends up on the host parser
+    with nothing lost or repeated"""
+    lines = fastq_text(5000, 4).decode('ascii').split('\n')
+    broken = lines[:4 * 3000] + [''] + lines[4 * 3000:]
+    path = str(tmp_path / 'gap.fq.gz')
+    write_fastq(path, '\n'.join(broken))
+    host = batches_of(hk, path, 1000, {'KV_INGEST': 'host'})
+    dev = batches_of(hk, path, 1000)
+    assert dev[3][0] == 'DeviceTextBatch' and dev[3][-1] == 'TextBatch'
+    assert host[0] == dev[0] and host[1] == dev[1] and host[2] == dev[2] and dev[4] == 5000
+    fasta = ''.join('>s{}\n{}\n'.format(i, lines[4 * i + 1]) for i in range(2000))
+    path = str(tmp_path / 'seqs.fa.gz')
+    write_fastq(path, fasta)
+    host = batches_of(hk, path, 700, {'KV_INGEST': 'host'})
+    dev = batches_of(hk, path, 700)
+    assert set(dev[3]) == {'TextBatch'}
+    assert host[:3] == dev[:3] and dev[4] == 2000
+
+
+def test_novel_cli_same_output_from_bgzf_and_plain_gzip(hk, tmp_path):
+    """kevlar novel end to end: case reads as BGZF (device ingest) and as plain gzip (host) give the same augmented FASTQ"""
+    import gzip as gz
+    import subprocess
+    import sys
+    from kevlar_amd import synth
+    trio = synth.make_trio(60000, 8)
+    files = {}
+    for i, name in enumerate(('proband', 'mother', 'father')):
+        reads = synth.unpack_reads(synth.sample_reads_packed(trio[name], 12000, 100, 0.005, 50 + i), 100)
+        text = ''.join('@{}_{}\n{}\n+\n{}\n'.format(name, j, s, 'I' * len(s)) for j, s in enumerate(reads))
+        files[name] = (str(tmp_path / (name + '.bgzf.fq.gz')), str(tmp_path / (name + '.plain.fq.gz')))
+        write_fastq(files[name][0], text)
+        with gz.open(files[name][1], 'wt') as fh:
+            fh.write(text)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for which in (0, 1):
+        out = str(tmp_path / 'novel{}.augfastq'.format(which))
+        cmd = [sys.executable, '-m', 'kevlar_amd', 'novel', '--case', files['proband'][which], '--control', files['mother'][which],
+               '--control', files['father'][which], '--ksize', '25', '--memory', '2M', '--case-min', '5', '--ctrl-max', '1', '--out', out]
+        done = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+        assert done.returncode == 0, done.stderr[-2000:]
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] and outs[0].count('\n') > 100
