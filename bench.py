@@ -486,42 +486,59 @@ def end_to_end(args, wl, packed, names, synth):
     import io
     import shutil
     import tempfile
+    import numpy as np
     import kevlar_amd
     n = min(args.e2e_reads, packed['proband'].shape[0])
     k = int(wl['ksize'])
     tmp = tempfile.mkdtemp(prefix='kv_e2e_')
     try:
-        qual = 'I' * args.read_len
+        from kevlar_amd import bgzf
+        # binned qualities as current instruments write them: mostly one value, a few lower ones
+        rng = np.random.default_rng(12)
         for name in names:
             seqs = synth.unpack_reads(packed[name][:n], args.read_len)
+            quals = np.frombuffer(b'F:,#', dtype=np.uint8)[rng.choice(4, size=(n, args.read_len), p=[0.9, 0.06, 0.03, 0.01])]
+            text = ''.join('@{}_{}\n{}\n+\n{}\n'.format(name, i, s, q.tobytes().decode('ascii')) for i, (s, q) in enumerate(zip(seqs, quals)))
             with open(os.path.join(tmp, name + '.fq'), 'w') as fh:
-                fh.write(''.join('@{}_{}\n{}\n+\n{}\n'.format(name, i, s, qual) for i, s in enumerate(seqs)))
+                fh.write(text)
+            with bgzf.BgzfWriter(os.path.join(tmp, name + '.bgzf.fq.gz'), level=4) as fh:      # what kevlar_amd.open(..., 'w') writes
+                fh.write(text)
+            del text, quals, seqs
         saved, kevlar_amd.logstream = kevlar_amd.logstream, io.StringIO()
         mem = '{:d}'.format(int(wl['memory']))
 
-        def run(argv):
+        def novel_run(suffix):
+            argv = ['novel', '--ksize', str(k), '--memory', mem, '--threads', '2', '--case', os.path.join(tmp, 'proband' + suffix)]
+            for c in names[1:]:
+                argv += ['--control', os.path.join(tmp, c + suffix)]
+            argv += ['--case-min', str(args.case_min), '--ctrl-max', str(args.ctrl_max), '-o', os.path.join(tmp, 'novel' + suffix + '.augfastq')]
+            t0 = time.perf_counter()
             a = kevlar_amd.cli.parser().parse_args(argv)
             kevlar_amd.cli.mains[a.cmd](a)
-        t0 = time.perf_counter()
-        argv = ['novel', '--ksize', str(k), '--memory', mem, '--threads', '2', '--case', os.path.join(tmp, 'proband.fq')]
-        for c in names[1:]:
-            argv += ['--control', os.path.join(tmp, c + '.fq')]
-        run(argv + ['--case-min', str(args.case_min), '--ctrl-max', str(args.ctrl_max), '-o', os.path.join(tmp, 'novel.augfastq')])
-        t1 = time.perf_counter()
-        kevlar_amd.logstream = saved
-        ingest = ingest_rates(os.path.join(tmp, 'proband.fq'), n)
-        return {'value': round(len(names) * n / (t1 - t0), 1), 'unit': 'reads/s', 'ingest_reads_per_s': ingest,
-                'sample': '{} reads per sample as FASTQ on local disk ({} MB each); one `kevlar novel --case ... --control ...` run: '
-                          'every sample parsed, packed, uploaded and counted, the case sample parsed again and scanned, annotated '
-                          'reads written: {:.2f} s'.format(n, os.path.getsize(os.path.join(tmp, 'proband.fq')) >> 20, t1 - t0)}
+            return time.perf_counter() - t0
+        try:
+            dt_plain = novel_run('.fq')
+            dt_bgzf = novel_run('.bgzf.fq.gz')
+        finally:
+            kevlar_amd.logstream = saved
+        with open(os.path.join(tmp, 'novel.fq.augfastq')) as a, open(os.path.join(tmp, 'novel.bgzf.fq.gz.augfastq')) as b:
+            assert a.read() == b.read(), 'host-parsed and device-parsed input must give the same annotated reads'
+        ingest = ingest_rates(os.path.join(tmp, 'proband.fq'), os.path.join(tmp, 'proband.bgzf.fq.gz'), n)
+        return {'value': round(len(names) * n / dt_plain, 1), 'unit': 'reads/s',
+                'from_bgzf_fastq_gz': round(len(names) * n / dt_bgzf, 1), 'ingest_reads_per_s': ingest,
+                'sample': '{} reads per sample as FASTQ on local disk ({} MB each plain, {} MB blocked gzip); one `kevlar novel --case ... '
+                          '--control ...` run: every sample parsed, packed and counted, the case sample parsed again and scanned, annotated '
+                          'reads written: {:.2f} s from plain FASTQ (parsed on the host), {:.2f} s from BGZF .fq.gz (inflated and parsed on '
+                          'the GPU); identical output'.format(n, os.path.getsize(os.path.join(tmp, 'proband.fq')) >> 20,
+                                                               os.path.getsize(os.path.join(tmp, 'proband.bgzf.fq.gz')) >> 20, dt_plain, dt_bgzf)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def ingest_rates(fastq, n):
-    """reads/s from a file on disk to 2-bit packed batches in HBM (the native reader alone, no kernels): plain FASTQ,
-    gzip (one zlib stream: the inflate rate of one core), and the packed-read cache a first pass leaves behind
-    (KEVLAR_PACK_CACHE=1: SURVEY.md 8(f).1)"""
+def ingest_rates(fastq, bgzf_gz, n):
+    """reads/s from a file on disk to 2-bit packed batches in HBM (the reader alone, no count): plain FASTQ and plain gzip
+    on the host (one zlib stream: the inflate rate of one core), blocked gzip inflated and parsed on the GPU
+    (kv_inflate.hip, kv_fastq.hip), and the packed-read cache a first pass leaves behind (KEVLAR_PACK_CACHE=1)"""
     import gzip
     import shutil
     from kevlar_amd import khmer as hk
@@ -540,7 +557,7 @@ def ingest_rates(fastq, n):
     gz = fastq + '.gz'
     with open(fastq, 'rb') as src, gzip.open(gz, 'wb', compresslevel=1) as dst:
         shutil.copyfileobj(src, dst)
-    out = {'fastq': drain(fastq), 'fastq_gz': drain(gz)}
+    out = {'fastq': drain(fastq), 'fastq_gz': drain(gz), 'fastq_bgzf_gz_on_device': max(drain(bgzf_gz), drain(bgzf_gz))}
     os.environ['KEVLAR_PACK_CACHE'] = '1'
     try:
         out['fastq_gz_first_pass_writing_cache'] = drain(gz)

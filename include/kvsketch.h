@@ -275,6 +275,16 @@ int kv_readgraph_components(const kv_reads *reads, int ksize, const uint32_t *an
                             const uint32_t *node_of_read, uint32_t n_nodes, uint32_t minabund,
                             uint32_t maxabund, uint32_t *labels_out, uint64_t *n_edges_out);
 
+/* ---- augmented FASTA/FASTQ text of a batch's annotated reads (kevlar/sequence.py print_augmented_fastx) ----
+ * hits (read, offset, abund[nsamples]) sorted by (read, offset); the j-th distinct read among them is record
+ * rec_index[j] of the text blobs (kv_fastx_batch_text's layout).  *text_out is released with kv_text_free.   */
+int kv_format_augmented(const uint32_t *hit_read, const uint32_t *hit_off, const uint8_t *abund, uint64_t n_hits,
+                        int nsamples, int ksize, const uint64_t *rec_index, const char *names,
+                        const uint64_t *name_offs, const char *seqs, const uint64_t *seq_offs, const char *quals,
+                        const uint64_t *qual_offs, const uint8_t *is_fastq, char **text_out, uint64_t *bytes_out,
+                        uint64_t *n_records_out);
+int kv_text_free(char *text);
+
 /* ---- blocked gzip (BGZF) on the device (kevlar_amd/csrc/kv_inflate.hip) --------------------------------
  * Replaces the gzip stream behind khmer.ReadParser (kevlar/__init__.py:125-128) for files whose members are
  * independent: one wavefront inflates one member.  kv_fastx_open picks this path by itself; the two

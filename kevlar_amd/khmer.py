@@ -182,6 +182,35 @@ class TextBatch(object):
     def prefetch(self, indices):
         """Hint that record(i) will be asked for these i (a no-op when the text is already on the host)."""
 
+    def augmented_text(self, hits, ksize, rec_index=None):
+        """Augmented FASTA/FASTQ text (bytes) of the reads that hold `hits` = (read, offset, abund[n, S]) sorted by
+        (read, offset), formatted natively (kv_format_augmented); None if this batch keeps no text blobs."""
+        if self._fetch is not None or self._seqs is None:
+            return None
+        reads, offsets, abunds = hits[:3]
+        n = len(reads)
+        if n == 0:
+            return b''
+        reads = np.ascontiguousarray(reads, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        abunds = np.ascontiguousarray(abunds, dtype=np.uint8)
+        if rec_index is None:
+            rec_index = np.unique(reads)
+        rec_index = np.ascontiguousarray(rec_index, dtype=np.uint64)
+        no, so, qo = (np.ascontiguousarray(a, dtype=np.uint64) for a in (self._no, self._so, self._qo))
+        fq = np.ascontiguousarray(self._fq, dtype=np.uint8)
+        text, size, nrec = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64()
+        lib = _lib.load()
+        check(lib.kv_format_augmented(_u32p(reads), _u32p(offsets), _u8p(abunds), n, abunds.shape[1], int(ksize), _u64p(rec_index),
+                                      ctypes.cast(ctypes.c_char_p(self._names), ctypes.c_void_p), _u64p(no),
+                                      ctypes.cast(ctypes.c_char_p(self._seqs), ctypes.c_void_p), _u64p(so),
+                                      ctypes.cast(ctypes.c_char_p(self._quals), ctypes.c_void_p), _u64p(qo), _u8p(fq),
+                                      ctypes.byref(text), ctypes.byref(size), ctypes.byref(nrec)))
+        try:
+            return ctypes.string_at(text, size.value)
+        finally:
+            lib.kv_text_free(text)
+
     def find_name(self, name):
         """Index of the first record called `name`, or -1."""
         raw = name.encode('latin-1')
@@ -225,6 +254,15 @@ class DeviceTextBatch(object):
 
     def sequence(self, i):
         return self.record(i).sequence
+
+    def augmented_text(self, hits, ksize):
+        """see TextBatch.augmented_text: the hit reads are gathered from HBM in one piece and formatted natively"""
+        reads = hits[0]
+        if len(reads) == 0:
+            return b''
+        owners = np.unique(reads)
+        sub = self._fetch(owners.tolist())
+        return sub.augmented_text(hits, ksize, rec_index=np.arange(len(owners), dtype=np.uint64))
 
     def find_name(self, name):
         step = 1 << 18

@@ -100,11 +100,14 @@ class _Tally(object):
     def __init__(self):
         self.instances = self.reads = 0
         self.kmers = set()          # as read; reduced to one strand at the end
+        self.hashes = []            # ... or, on the text path, the k-mers' hashes (one value for both strands)
 
     def line(self, seconds):
-        unique = {kevlar_amd.revcommin(kmer) for kmer in self.kmers}
+        unique = len({kevlar_amd.revcommin(kmer) for kmer in self.kmers})
+        if self.hashes:
+            unique += len(np.unique(np.concatenate(self.hashes)))
         return 'Found {:d} instances of {:d} unique novel kmers in {:d} reads in {:.2f} seconds'.format(
-            self.instances, len(unique), self.reads, seconds)
+            self.instances, unique, self.reads, seconds)
 
 
 def _annotate(text, hits, k, tally):
@@ -134,26 +137,18 @@ def _annotate(text, hits, k, tally):
         yield fresh
 
 
-def novel(casestream, casecounts, controlcounts, ksize=31, abundscreen=None, casemin=5, ctrlmax=0, numbands=None, band=None,
-          skipuntil=None, refbandquirk=False, batchsize=SCAN_BATCH_READS):
-    """Yield the case reads that hold interesting k-mers, annotated, in input order.
-
-    Banding: a band keeps the k-mers whose hash falls in its range -- the rule the banded *count* uses
-    (kevlar/count.py:62-66) -- so the union over bands equals the unbanded result.  refbandquirk=True applies the
-    reference's literal low-bits test instead (kevlar/novel.py:144-147), which is inconsistent with range-banded
-    counts (SURVEY.md 0.4)."""
+def _scan(casestream, casecounts, controlcounts, ksize, abundscreen, casemin, ctrlmax, numbands, band, skipuntil, refbandquirk, batchsize):
+    """(batch text, hits) of every batch of the case stream; the batch's packed reads are still open"""
     if (not numbands) != (not band and band != 0):
         raise ValueError('Must specify `numbands` and `band` together')
     if band is not None and band < 0:
         raise ValueError('`band` must be a value between 0 and {:d} (`numbands` - 1), inclusive'.format(numbands - 1))
-    clock = kevlar_amd.Timer()
-    clock.start()
     ticking = '[kevlar::novel]     processed {counter} reads'
     progress = kevlar_amd.ProgressIndicator(ticking + ('; skipping reads in search of {}'.format(skipuntil) if skipuntil else ''),
                                             interval=1e6, breaks=[1e7, 1e8, 1e9], usetimer=True)
     band_mode = (KV_BAND_REFQUIRK if refbandquirk else KV_BAND_RANGE) if numbands else KV_BAND_NONE
     k = casecounts[0].ksize() if casecounts else ksize
-    tally, passed = _Tally(), 0
+    passed = 0
     for text in _batches(casestream, ksize, k, batchsize):
         progress.update(text.n)
         start = 0
@@ -168,8 +163,52 @@ def novel(casestream, casecounts, controlcounts, ksize=31, abundscreen=None, cas
         passed += text.n
         hits = khmer.novel_scan(casecounts, controlcounts, text.batch, casemin, ctrlmax, screen=abundscreen, band_mode=band_mode,
                                 nbands=numbands or 0, band=band or 0, first_read=start)
+        yield text, hits, k
+
+
+def novel(casestream, casecounts, controlcounts, ksize=31, abundscreen=None, casemin=5, ctrlmax=0, numbands=None, band=None,
+          skipuntil=None, refbandquirk=False, batchsize=SCAN_BATCH_READS):
+    """Yield the case reads that hold interesting k-mers, annotated, in input order.
+
+    Banding: a band keeps the k-mers whose hash falls in its range -- the rule the banded *count* uses
+    (kevlar/count.py:62-66) -- so the union over bands equals the unbanded result.  refbandquirk=True applies the
+    reference's literal low-bits test instead (kevlar/novel.py:144-147), which is inconsistent with range-banded
+    counts (SURVEY.md 0.4)."""
+    clock = kevlar_amd.Timer()
+    clock.start()
+    tally = _Tally()
+    for text, hits, k in _scan(casestream, casecounts, controlcounts, ksize, abundscreen, casemin, ctrlmax, numbands, band, skipuntil,
+                               refbandquirk, batchsize):
         text.batch.close()
         yield from _annotate(text, hits, k, tally)
+    kevlar_amd.plog('[kevlar::novel]', tally.line(clock.stop()))
+
+
+def novel_text(casestream, casecounts, controlcounts, ksize=31, abundscreen=None, casemin=5, ctrlmax=0, numbands=None, band=None,
+               skipuntil=None, refbandquirk=False, batchsize=SCAN_BATCH_READS):
+    """novel() for a writer: yields the augmented FASTA/FASTQ text (bytes) of each batch's annotated reads -- the same
+    bytes print_augmented_fastx would produce record by record -- formatted natively where the batch has its text in
+    one piece (every batch of the native reader), so no Python object is built per read or per k-mer."""
+    clock = kevlar_amd.Timer()
+    clock.start()
+    tally = _Tally()
+    for text, hits, k in _scan(casestream, casecounts, controlcounts, ksize, abundscreen, casemin, ctrlmax, numbands, band, skipuntil,
+                               refbandquirk, batchsize):
+        reads, offsets, _, dropped = hits
+        blob = text.augmented_text(hits, k) if hasattr(text, 'augmented_text') and hasattr(casecounts[0], 'hash_positions') else None
+        if blob is None:
+            text.batch.close()
+            blob = ''.join(kevlar_amd.sequence.format_augmented_fastx(rec) for rec in _annotate(text, hits, k, tally)).encode('latin-1')
+        else:
+            if len(reads):
+                tally.hashes.append(casecounts[0].hash_positions(text.batch, reads, offsets))
+                tally.instances += len(reads)
+                tally.reads += int(np.count_nonzero(np.diff(reads))) + 1
+            if len(dropped) and len(dropped.shadow[0]):
+                tally.hashes.append(casecounts[0].hash_positions(text.batch, dropped.shadow[0], dropped.shadow[1]))
+            text.batch.close()
+        if blob:
+            yield blob
     kevlar_amd.plog('[kevlar::novel]', tally.line(clock.stop()))
 
 
@@ -195,9 +234,14 @@ def main(args):
     kevlar_amd.plog('[kevlar::novel]', 'Iterating over reads from {:d} case sample(s)'.format(len(args.case)))
     sink = kevlar_amd.open(args.out, 'w')
     case_reads = kevlar_amd.multi_file_iter_khmer([path for files in args.case for path in files])
-    for record in novel(case_reads, cases, controls, ksize=args.ksize, abundscreen=args.abund_screen, casemin=args.case_min,
-                        ctrlmax=args.ctrl_max, numbands=args.num_bands, band=band, skipuntil=args.skip_until,
-                        refbandquirk=getattr(args, 'ref_band_quirk', False)):
-        kevlar_amd.print_augmented_fastx(record, sink)
+    for blob in novel_text(case_reads, cases, controls, ksize=args.ksize, abundscreen=args.abund_screen, casemin=args.case_min,
+                           ctrlmax=args.ctrl_max, numbands=args.num_bands, band=band, skipuntil=args.skip_until,
+                           refbandquirk=getattr(args, 'ref_band_quirk', False)):
+        try:
+            sink.write(blob)
+        except TypeError:
+            sink.write(blob.decode('latin-1'))
+    if args.out not in ('-', None):
+        sink.close()
     kevlar_amd.plog('[kevlar::novel]', 'Iterated over all case reads in {:.2f} seconds'.format(clock.stop('iter')))
     kevlar_amd.plog('[kevlar::novel]', 'Total time: {:.2f} seconds'.format(clock.stop()))
