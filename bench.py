@@ -72,7 +72,7 @@ def parse_args():
     p.add_argument('--cpu-reads', type=int, default=100000, help='reads per sample for the one-core CPU baseline leg')
     p.add_argument('--cpu-reads-mt', type=int, default=1000000, help='reads per sample for the all-cores CPU baseline leg')
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--e2e-reads', type=int, default=500000, help='reads per sample written as FASTQ for the end-to-end leg')
+    p.add_argument('--e2e-reads', type=int, default=2000000, help='reads per sample written as FASTQ for the end-to-end leg')
     p.add_argument('--no-e2e', action='store_true')
     p.add_argument('--no-replay', action='store_true', help='skip the banded replays behind banded_checksums / replay_checksum')
     p.add_argument('--exchange-items', default='auto', choices=['auto', 'distinct', 'plain'],
@@ -493,17 +493,35 @@ def end_to_end(args, wl, packed, names, synth):
     tmp = tempfile.mkdtemp(prefix='kv_e2e_')
     try:
         from kevlar_amd import bgzf
-        # binned qualities as current instruments write them: mostly one value, a few lower ones
+        # records as one byte matrix (fixed-width names), binned qualities as current instruments write them: mostly one
+        # value, a few lower ones
         rng = np.random.default_rng(12)
+        L = args.read_len
+        workers = max(1, len(os.sched_getaffinity(0)))
         for name in names:
-            seqs = synth.unpack_reads(packed[name][:n], args.read_len)
-            quals = np.frombuffer(b'F:,#', dtype=np.uint8)[rng.choice(4, size=(n, args.read_len), p=[0.9, 0.06, 0.03, 0.01])]
-            text = ''.join('@{}_{}\n{}\n+\n{}\n'.format(name, i, s, q.tobytes().decode('ascii')) for i, (s, q) in enumerate(zip(seqs, quals)))
-            with open(os.path.join(tmp, name + '.fq'), 'w') as fh:
+            tag = '@{}_'.format(name).encode('ascii')
+            rec = np.empty((n, len(tag) + 8 + 1 + L + 3 + L + 1), dtype=np.uint8)
+            col = 0
+            rec[:, :len(tag)] = np.frombuffer(tag, dtype=np.uint8); col += len(tag)
+            digits = np.arange(n, dtype=np.int64)
+            for d in range(8):
+                rec[:, col + 7 - d] = 48 + digits % 10
+                digits //= 10
+            col += 8
+            rec[:, col] = 10; col += 1
+            words = packed[name][:n]
+            for j in range(L):
+                rec[:, col + j] = np.frombuffer(b'ACGT', dtype=np.uint8)[(words[:, j >> 4] >> np.uint32(2 * (j & 15))) & np.uint32(3)]
+            col += L
+            rec[:, col:col + 3] = np.frombuffer(b'\n+\n', dtype=np.uint8); col += 3
+            rec[:, col:col + L] = np.frombuffer(b'F:,#', dtype=np.uint8)[rng.choice(4, size=(n, L), p=[0.9, 0.06, 0.03, 0.01])]; col += L
+            rec[:, col] = 10
+            text = rec.tobytes()
+            del rec
+            with open(os.path.join(tmp, name + '.fq'), 'wb') as fh:
                 fh.write(text)
-            with bgzf.BgzfWriter(os.path.join(tmp, name + '.bgzf.fq.gz'), level=4) as fh:      # what kevlar_amd.open(..., 'w') writes
-                fh.write(text)
-            del text, quals, seqs
+            bgzf.write_file(os.path.join(tmp, name + '.bgzf.fq.gz'), text, level=4, threads=workers)   # what kevlar_amd.open(..., 'w') writes
+            del text
         saved, kevlar_amd.logstream = kevlar_amd.logstream, io.StringIO()
         mem = '{:d}'.format(int(wl['memory']))
 

@@ -74,3 +74,19 @@ def is_bgzf(filename):
     with open(filename, 'rb') as fh:
         head = fh.read(18)
     return len(head) == 18 and head[:4] == b'\x1f\x8b\x08\x04' and head[12:14] == b'BC'
+
+
+def write_file(filename, data, level=6, threads=1):
+    """Write `data` (bytes) as a BGZF file; with threads > 1 the members are compressed concurrently (zlib releases
+    the interpreter lock)."""
+    pieces = [data[i:i + BLOCK_TEXT] for i in range(0, len(data), BLOCK_TEXT)]
+    with open(filename, 'wb') as fh:
+        if threads > 1 and len(pieces) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=threads) as pool:
+                for blob in pool.map(lambda piece: member(piece, level), pieces, chunksize=16):
+                    fh.write(blob)
+        else:
+            for piece in pieces:
+                fh.write(member(piece, level))
+        fh.write(_EOF)
