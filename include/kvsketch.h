@@ -285,6 +285,29 @@ int kv_format_augmented(const uint32_t *hit_read, const uint32_t *hit_off, const
                         uint64_t *n_records_out);
 int kv_text_free(char *text);
 
+/* ---- augmented FASTA/FASTQ files as flat arrays (kevlar/sequence.pyx parse_augmented_fastx / print_augmented_fastx):
+ * what `kevlar filter` (filter.py:15-82) and `kevlar partition` (readgraph.py:43-84) read and write.  A loaded file
+ * exposes its records as kv_fastx_batch_text-style blobs plus, per annotation, offset and abundances (record i owns
+ * annotations ann_first[i] .. ann_first[i + 1]); ksize = -1 if the stream mixes k.  kv_format_records writes any
+ * selection of records / annotations back as text (see kv_augfastx.hip); release it with kv_text_free.            */
+typedef struct kv_augfastx kv_augfastx;
+int kv_augfastx_load(const char *path, kv_augfastx **out);
+int kv_augfastx_info(const kv_augfastx *a, uint64_t *n_records, uint64_t *n_annotations, int *ksize, int *nsamples,
+                     uint64_t *n_mates);
+int kv_augfastx_view(const kv_augfastx *a, const char **names, const uint64_t **name_offs, const char **seqs,
+                     const uint64_t **seq_offs, const char **quals, const uint64_t **qual_offs,
+                     const uint8_t **is_fastq, const uint64_t **ann_first, const uint32_t **ann_offset,
+                     const int32_t **ann_abund, const uint32_t **mate_record, const char **mates,
+                     const uint64_t **mate_offs);
+int kv_augfastx_free(kv_augfastx *a);
+int kv_format_records(uint64_t n_out, const uint64_t *rec_index, const uint64_t *ann_lo, const uint64_t *ann_hi,
+                      const uint32_t *ann_offset, const int32_t *ann_abund, const uint8_t *keep,
+                      const int32_t *case_abund, int nsamples, int ksize, const char *names,
+                      const uint64_t *name_offs, const char *seqs, const uint64_t *seq_offs, const char *quals,
+                      const uint64_t *qual_offs, const uint8_t *is_fastq, const char *suffix,
+                      const uint64_t *suffix_offs, const uint32_t *mate_record, uint64_t n_mates, const char *mates,
+                      const uint64_t *mate_offs, char **text_out, uint64_t *bytes_out);
+
 /* ---- blocked gzip (BGZF) on the device (kevlar_amd/csrc/kv_inflate.hip) --------------------------------
  * Replaces the gzip stream behind khmer.ReadParser (kevlar/__init__.py:125-128) for files whose members are
  * independent: one wavefront inflates one member.  kv_fastx_open picks this path by itself; the two

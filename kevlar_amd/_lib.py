@@ -72,6 +72,11 @@ SIGNATURES = {
     'kv_fastx_from_cache': (i32, [vp, ctypes.POINTER(ctypes.c_int)]),
     'kv_format_augmented': (i32, [u32p, u32p, u8p, u64, i32, i32, u64p, vp, u64p, vp, u64p, vp, u64p, u8p, ctypes.POINTER(vp), u64p, u64p]),
     'kv_text_free': (i32, [vp]),
+    'kv_augfastx_load': (i32, [cstr, vpp]),
+    'kv_augfastx_info': (i32, [vp, u64p, u64p, ctypes.POINTER(i32), ctypes.POINTER(i32), u64p]),
+    'kv_augfastx_view': (i32, [vp] + [vpp] * 13),
+    'kv_augfastx_free': (i32, [vp]),
+    'kv_format_records': (i32, [u64, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, vp, vp, vpp, u64p]),
     'kv_fastx_on_device': (i32, [vp, ctypes.POINTER(ctypes.c_int)]),
     'kv_fastx_fetch': (i32, [vp, u64p, u64]),
     'kv_fastx_record_text': (i32, [vp, u64, ctypes.c_char_p, ctypes.c_char_p]),

@@ -1,47 +1,153 @@
 """AnnotatedReads: the reads of an augmented FASTA/FASTQ stream with their interesting-k-mer annotations as flat
-arrays -- read index, offset, abundances per sample -- next to the reads themselves 2-bit packed in HBM.
+arrays -- record text as blobs with offsets; per annotation the read index, offset and abundances -- next to the
+reads themselves 2-bit packed in HBM.
 
 `filter` and `partition` both start from such a stream (kevlar/filter.py:15-82, kevlar/readgraph.py:43-84).  The
-reference slices every annotated k-mer out of its read as a Python string and calls the sketch (or a dictionary) once
-per k-mer; with this container the k-mers are addressed by position: the device hashes them straight from the
-packed reads (kv_hash_positions) and everything per annotation is numpy arithmetic over whole arrays."""
-import re
+reference builds a Python object per record and per annotation, slices every annotated k-mer out of its read as a
+string and calls the sketch (or a dictionary) once per k-mer.  Here a file is parsed natively straight into the
+arrays (kv_augfastx_load), k-mers are addressed by position -- the device hashes them from the packed reads
+(kv_hash_positions) -- everything per annotation is numpy arithmetic over whole arrays, and what is written back is
+formatted natively from the same arrays (kv_format_records).  Record objects exist only for callers that ask for
+them one by one."""
+import ctypes
 
 import numpy as np
 
-from kevlar_amd import khmer
-from kevlar_amd.sequence import KmerOfInterest
+from kevlar_amd import _lib, khmer
+from kevlar_amd.sequence import KmerOfInterest, Record
 
-_NOT_ACGT = re.compile('[^ACGT]')
+_ACGT = np.zeros(256, dtype=bool)
+_ACGT[[ord(c) for c in 'ACGT']] = True
+
+
+def _offsets(lengths):
+    out = np.zeros(len(lengths) + 1, dtype=np.uint64)
+    if len(lengths):
+        np.cumsum(np.asarray(lengths, dtype=np.uint64), out=out[1:])
+    return out
 
 
 class AnnotatedReads(object):
-    def __init__(self, records):
-        self.records = [r for r in records if r is not None]
-        per_read = np.fromiter((len(r.annotations) for r in self.records), dtype=np.int64, count=len(self.records))
-        self.first = np.zeros(len(self.records) + 1, dtype=np.int64)        # annotations of read i: first[i] .. first[i + 1]
-        np.cumsum(per_read, out=self.first[1:])
+    """names / seqs / quals: bytes blobs, record i at blob[offs[i]:offs[i + 1]]; annotations of record i are entries
+    first[i] .. first[i + 1] of offset[], abund[, S]; read[] names the owner of every annotation."""
+
+    def __init__(self, records=()):
+        records = [r for r in records if r is not None]
+        self.n = len(records)
+        self.names = ''.join(r.name for r in records).encode('latin-1')
+        self.name_offs = _offsets([len(r.name) for r in records])
+        self.seqs = ''.join(r.sequence for r in records).encode('latin-1')
+        self.seq_offs = _offsets([len(r.sequence) for r in records])
+        self.quals = ''.join(r.quality or '' for r in records).encode('latin-1')
+        self.qual_offs = _offsets([len(r.quality or '') for r in records])
+        self.is_fastq = np.fromiter((r.quality is not None for r in records), dtype=np.uint8, count=self.n)
+        per_read = np.fromiter((len(r.annotations) for r in records), dtype=np.int64, count=self.n)
+        self.first = _offsets(per_read)
         total = int(self.first[-1])
-        self.read = np.repeat(np.arange(len(self.records), dtype=np.uint32), per_read)
-        self.offset = np.fromiter((k.offset for r in self.records for k in r.annotations), dtype=np.uint32, count=total)
-        ksizes = {k.ksize for r in self.records for k in r.annotations}
+        self.offset = np.fromiter((k.offset for r in records for k in r.annotations), dtype=np.uint32, count=total)
+        ksizes = {k.ksize for r in records for k in r.annotations}
         if len(ksizes) > 1:
             raise ValueError('all interesting k-mers of one stream must share k (found {})'.format(sorted(ksizes)))
         self.ksize = ksizes.pop() if ksizes else None
-        self.nsamples = len(self.records[0].annotations[0].abund) if total and per_read[0] else (
-            next((len(k.abund) for r in self.records for k in r.annotations), 0))
-        self.abund = np.fromiter((a for r in self.records for k in r.annotations for a in k.abund), dtype=np.int64,
-                                 count=total * self.nsamples).reshape(total, self.nsamples) if total else np.zeros((0, 0), dtype=np.int64)
+        self.nsamples = next((len(k.abund) for r in records for k in r.annotations), 0)
+        self.abund = np.fromiter((a for r in records for k in r.annotations for a in k.abund), dtype=np.int32,
+                                 count=total * self.nsamples).reshape(total, self.nsamples) if total else np.zeros((0, 0), dtype=np.int32)
+        mates = [(i, m) for i, r in enumerate(records) for m in r.mates]
+        self.mate_record = np.array([i for i, _ in mates], dtype=np.uint32)
+        self.mates = ''.join(m for _, m in mates).encode('latin-1')
+        self.mate_offs = _offsets([len(m) for _, m in mates])
+        self._finish()
+
+    @classmethod
+    def from_file(cls, filename):
+        """Parse an augmented FASTA/FASTQ file (plain or gzip) natively; no Python object per record."""
+        lib = _lib.load()
+        handle = ctypes.c_void_p()
+        _lib.check(lib.kv_augfastx_load(filename.encode(), ctypes.byref(handle)))
+        try:
+            n, na, nm = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+            k, S = ctypes.c_int(), ctypes.c_int()
+            _lib.check(lib.kv_augfastx_info(handle, ctypes.byref(n), ctypes.byref(na), ctypes.byref(k), ctypes.byref(S), ctypes.byref(nm)))
+            if k.value < 0:
+                raise ValueError('all interesting k-mers of one stream must share k')
+            ptr = [ctypes.c_void_p() for _ in range(13)]
+            _lib.check(lib.kv_augfastx_view(handle, *[ctypes.byref(p) for p in ptr]))
+            n, na, nm, S = n.value, na.value, nm.value, S.value
+
+            def arr(p, count, dtype):
+                if count == 0:
+                    return np.zeros(0, dtype=dtype)
+                return np.frombuffer(ctypes.string_at(p, count * np.dtype(dtype).itemsize), dtype=dtype).copy()
+            self = cls.__new__(cls)
+            self.n = n
+            self.name_offs, self.seq_offs, self.qual_offs = (arr(ptr[i], n + 1, np.uint64) for i in (1, 3, 5))
+            self.names = ctypes.string_at(ptr[0], int(self.name_offs[n]))
+            self.seqs = ctypes.string_at(ptr[2], int(self.seq_offs[n]))
+            self.quals = ctypes.string_at(ptr[4], int(self.qual_offs[n]))
+            self.is_fastq = arr(ptr[6], n, np.uint8)
+            self.first = arr(ptr[7], n + 1, np.uint64)
+            self.offset = arr(ptr[8], na, np.uint32)
+            self.abund = arr(ptr[9], na * S, np.int32).reshape(na, S) if na else np.zeros((0, 0), dtype=np.int32)
+            self.mate_record = arr(ptr[10], nm, np.uint32)
+            self.mate_offs = arr(ptr[12], nm + 1, np.uint64)
+            self.mates = ctypes.string_at(ptr[11], int(self.mate_offs[nm])) if nm else b''
+            self.ksize = k.value if na else None
+            self.nsamples = S if na else 0
+        finally:
+            lib.kv_augfastx_free(handle)
+        self._finish()
+        return self
+
+    def _finish(self):
+        self.first = self.first.astype(np.int64)
+        self.read = np.repeat(np.arange(self.n, dtype=np.uint32), np.diff(self.first))
         self._batch = None
+        self._made = {}
 
     def __len__(self):
         return int(self.first[-1])
 
+    # ---- record objects, on request ------------------------------------------------------------
+    def _text(self, blob, offs, i):
+        return blob[int(offs[i]):int(offs[i + 1])].decode('latin-1')
+
+    def name(self, i):
+        return self._text(self.names, self.name_offs, i)
+
+    def sequence(self, i):
+        return self._text(self.seqs, self.seq_offs, i)
+
+    def record(self, i, keep=None, case_abund=None):
+        """Record i with its annotations (only those where keep[...] is set; case_abund replaces the first abundance)"""
+        lo, hi = int(self.first[i]), int(self.first[i + 1])
+        notes = []
+        for j in range(lo, hi):
+            if keep is not None and not keep[j]:
+                continue
+            abund = tuple(int(a) for a in self.abund[j])
+            if case_abund is not None:
+                abund = (int(case_abund[j]),) + abund[1:]
+            notes.append(KmerOfInterest(self.ksize, int(self.offset[j]), abund))
+        mates = []
+        if len(self.mate_record):
+            for m in np.flatnonzero(self.mate_record == i).tolist():
+                mates.append(self._text(self.mates, self.mate_offs, m))
+        return Record(self.name(i), self.sequence(i), self._text(self.quals, self.qual_offs, i) if self.is_fastq[i] else None,
+                      annotations=notes, mates=mates)
+
+    @property
+    def records(self):
+        """every record as an object (built once)"""
+        if 'all' not in self._made:
+            self._made['all'] = [self.record(i) for i in range(self.n)]
+        return self._made['all']
+
+    # ---- device side -----------------------------------------------------------------------------
     @property
     def batch(self):
         """the read sequences packed in HBM (uploaded on first use)"""
         if self._batch is None:
-            self._batch = khmer.ReadBatch([r.sequence for r in self.records])
+            self._batch = khmer.ReadBatch.from_blob(self.seqs, self.seq_offs)
         return self._batch
 
     def close(self):
@@ -49,32 +155,77 @@ class AnnotatedReads(object):
             self._batch.close()
             self._batch = None
 
+    def odd_reads(self):
+        """indices of the reads with characters outside ACGT (the packed form cannot hold them)"""
+        if not self.seqs:
+            return np.zeros(0, dtype=np.int64)
+        bad = np.flatnonzero(~_ACGT[np.frombuffer(self.seqs, dtype=np.uint8)])
+        if not len(bad):
+            return bad
+        return np.unique(np.searchsorted(self.seq_offs, bad.astype(np.uint64), side='right') - 1)
+
     def hashes(self, sketch):
         """`sketch`'s hash of every annotated k-mer, in stream order.  K-mers of reads with characters outside ACGT
-        (which the packed form cannot hold) are hashed from their text instead."""
+        are hashed from their text instead."""
         if not len(self):
             return np.zeros(0, dtype=np.uint64)
         out = sketch.hash_positions(self.batch, self.read, self.offset)
-        odd = [i for i, r in enumerate(self.records) if r.annotations and _NOT_ACGT.search(r.sequence)]
-        for i in odd:
+        for i in self.odd_reads().tolist():
             lo, hi = int(self.first[i]), int(self.first[i + 1])
-            seq = self.records[i].sequence
-            out[lo:hi] = sketch.hash_kmers([seq[o:o + self.ksize] for o in self.offset[lo:hi].tolist()])
+            if hi > lo:
+                seq = self.sequence(i)
+                out[lo:hi] = sketch.hash_kmers([seq[o:o + self.ksize] for o in self.offset[lo:hi].tolist()])
         return out
+
+    # ---- selections ------------------------------------------------------------------------------
+    def _kept_reads(self, keep):
+        if not len(self):
+            return np.zeros(0, dtype=np.int64)
+        csum = np.concatenate(([0], np.cumsum(keep.astype(np.int64))))
+        return np.flatnonzero(csum[self.first[1:]] - csum[self.first[:-1]])
 
     def select(self, keep, case_abund=None):
         """Records that still have an annotation where `keep` (boolean per annotation) is set, each with only those
         annotations; case_abund (per annotation) replaces the first abundance.  Generator, stream order."""
-        kept_per_read = np.add.reduceat(keep.astype(np.int64), self.first[:-1]) if len(self) else np.zeros(0, dtype=np.int64)
-        # reduceat repeats a value for empty segments: mask those reads out
-        kept_per_read = np.where(np.diff(self.first) > 0, kept_per_read[:len(self.records)] if len(kept_per_read) else 0, 0)
-        for i in np.flatnonzero(kept_per_read).tolist():
-            record = self.records[i]
-            lo = int(self.first[i])
-            fresh = []
-            for j, ikmer in enumerate(record.annotations):
-                if keep[lo + j]:
-                    abund = ikmer.abund if case_abund is None else (int(case_abund[lo + j]),) + tuple(ikmer.abund[1:])
-                    fresh.append(KmerOfInterest(ikmer.ksize, ikmer.offset, abund))
-            record.annotations = fresh
-            yield record
+        for i in self._kept_reads(keep).tolist():
+            yield self.record(i, keep, case_abund)
+
+    def format(self, reads, keep=None, case_abund=None, suffixes=None):
+        """Augmented FASTA/FASTQ text (bytes) of the given reads (indices, in that order) with the annotations where
+        `keep` is set (None: all); suffixes: one string per read appended to its name."""
+        reads = np.ascontiguousarray(reads, dtype=np.uint64)
+        if not len(reads):
+            return b''
+        idx = reads.astype(np.int64)
+        lo = np.ascontiguousarray(self.first[idx], dtype=np.uint64)
+        hi = np.ascontiguousarray(self.first[idx + 1], dtype=np.uint64)
+        keep8 = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+        case32 = None if case_abund is None else np.ascontiguousarray(case_abund, dtype=np.int32)
+        abund = np.ascontiguousarray(self.abund, dtype=np.int32)
+        offset = np.ascontiguousarray(self.offset, dtype=np.uint32)
+        sfx_blob = sfx_offs = None
+        if suffixes is not None:
+            sfx_blob = ''.join(suffixes).encode('latin-1')
+            sfx_offs = _offsets([len(s) for s in suffixes])
+
+        def ptr(a):
+            return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+        text, size = ctypes.c_void_p(), ctypes.c_uint64()
+        lib = _lib.load()
+        _lib.check(lib.kv_format_records(
+            len(reads), ptr(reads), ptr(lo), ptr(hi), ptr(offset), ptr(abund), ptr(keep8), ptr(case32), int(self.nsamples), int(self.ksize or 1),
+            ctypes.cast(ctypes.c_char_p(self.names), ctypes.c_void_p), ptr(self.name_offs), ctypes.cast(ctypes.c_char_p(self.seqs), ctypes.c_void_p),
+            ptr(self.seq_offs), ctypes.cast(ctypes.c_char_p(self.quals), ctypes.c_void_p), ptr(self.qual_offs), ptr(self.is_fastq),
+            None if sfx_blob is None else ctypes.cast(ctypes.c_char_p(sfx_blob), ctypes.c_void_p), ptr(sfx_offs),
+            ptr(self.mate_record) if len(self.mate_record) else None, len(self.mate_record),
+            ctypes.cast(ctypes.c_char_p(self.mates), ctypes.c_void_p) if len(self.mate_record) else None,
+            ptr(self.mate_offs) if len(self.mate_record) else None, ctypes.byref(text), ctypes.byref(size)))
+        try:
+            return ctypes.string_at(text, size.value)
+        finally:
+            lib.kv_text_free(text)
+
+    def select_text(self, keep, case_abund=None):
+        """select() rendered to augmented FASTA/FASTQ text; returns (bytes, number of reads)"""
+        reads = self._kept_reads(keep)
+        return self.format(reads, keep, case_abund), len(reads)

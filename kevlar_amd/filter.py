@@ -17,8 +17,9 @@ _TICK = '[kevlar::filter]     processed {counter} reads'
 
 
 class Recount(object):
-    """The two passes over one annotated stream.  After recount(): `table` holds the fresh counts (None if the
-    stream carries no annotation), `nreads` the reads seen; survivors() yields what passes the thresholds."""
+    """The two passes over one annotated stream (a file name, or an iterable of records).  After recount(): `table`
+    holds the fresh counts (None if the stream carries no annotation), `nreads` the reads seen; survivors() yields what
+    passes the thresholds, survivors_text() the same as augmented FASTQ text."""
 
     def __init__(self, readstream, mask=None, memory=1e6):
         self.mask, self.memory = mask, memory
@@ -26,15 +27,23 @@ class Recount(object):
         self._stream = readstream
         self.annotated = self.table = self._hashes = None
 
-    def _counted(self, stream):
+    def _load(self):
         ticker = kevlar_amd.ProgressIndicator(_TICK, interval=1e5, breaks=[1e6, 1e7])
-        for read in stream:
-            self.nreads += 1
-            ticker.update()
-            yield read
+        if isinstance(self._stream, str):
+            self.annotated = AnnotatedReads.from_file(self._stream)      # parsed natively, no object per record
+            self.nreads = self.annotated.n
+            ticker.update(self.nreads)
+            return
+
+        def counted(stream):
+            for read in stream:
+                self.nreads += 1
+                ticker.update()
+                yield read
+        self.annotated = AnnotatedReads(counted(self._stream))
 
     def recount(self):
-        self.annotated = AnnotatedReads(self._counted(self._stream))
+        self._load()
         if not len(self.annotated):
             return
         self.table = khmer.Counttable(self.annotated.ksize, self.memory / 4, 4)
@@ -46,24 +55,35 @@ class Recount(object):
             fresh = fresh[seen_by_mask == 0]
         self.table.add_hashes(fresh)
 
-    def survivors(self, casemin, ctrlmax):
-        """reads that keep an annotation with recount >= casemin and every control abundance <= ctrlmax; the kept
-        annotations carry the recount as their case abundance"""
+    def _verdict(self, casemin, ctrlmax):
         again = self.table.get_hashes(self._hashes).astype(np.int64)
         verdict = again >= casemin
         if self.annotated.nsamples > 1:
             verdict &= (self.annotated.abund[:, 1:] <= ctrlmax).all(axis=1)
+        return verdict, again
+
+    def survivors(self, casemin, ctrlmax):
+        """reads that keep an annotation with recount >= casemin and every control abundance <= ctrlmax; the kept
+        annotations carry the recount as their case abundance"""
+        verdict, again = self._verdict(casemin, ctrlmax)
         ticker = kevlar_amd.ProgressIndicator(_TICK, interval=1e5, breaks=[1e6, 1e7])
         for read in self.annotated.select(verdict, case_abund=again):
             ticker.update()
             yield read
 
+    def survivors_text(self, casemin, ctrlmax):
+        """survivors() as (augmented FASTA/FASTQ bytes, number of reads), formatted natively from the arrays"""
+        verdict, again = self._verdict(casemin, ctrlmax)
+        text, n = self.annotated.select_text(verdict, case_abund=again)
+        kevlar_amd.ProgressIndicator(_TICK, interval=1e5, breaks=[1e6, 1e7]).update(n)
+        return text, n
 
-def filter(readfile, mask=None, memory=1e6, maxfpr=0.01, casemin=6, ctrlmax=1):
-    """Generator over the validated reads of the augmented FASTQ `readfile`."""
+
+def _passes(readfile, mask, memory, maxfpr, casemin, ctrlmax, as_text):
     timer = kevlar_amd.Timer()
     timer.start()
-    work = Recount(kevlar_amd.parse_augmented_fastx(kevlar_amd.open(readfile, 'r')), mask, memory)
+    stream = readfile if (isinstance(readfile, str) and readfile not in ('-',)) else kevlar_amd.parse_augmented_fastx(kevlar_amd.open(readfile, 'r'))
+    work = Recount(stream, mask, memory)
 
     kevlar_amd.plog('[kevlar::filter] First pass: re-counting k-mers')
     timer.start('firstpass')
@@ -80,16 +100,30 @@ def filter(readfile, mask=None, memory=1e6, maxfpr=0.01, casemin=6, ctrlmax=1):
         kevlar_amd.plog('[kevlar::filter] Second pass: discarding k-mers/reads')
         timer.start('secondpass')
         nkept = 0
-        for nkept, read in enumerate(work.survivors(casemin, ctrlmax), 1):
-            yield read
+        if as_text:
+            text, nkept = work.survivors_text(casemin, ctrlmax)
+            yield text
+        else:
+            for nkept, read in enumerate(work.survivors(casemin, ctrlmax), 1):
+                yield read
         kevlar_amd.plog('[kevlar::filter]', 'Second pass complete! Validated {:d} reads in {:.2f} seconds!'.format(
             nkept, timer.stop('secondpass')))
     work.annotated.close()
     kevlar_amd.plog('[kevlar::filter]', 'Total time: {:.2f} seconds'.format(timer.stop()))
 
 
+def filter(readfile, mask=None, memory=1e6, maxfpr=0.01, casemin=6, ctrlmax=1):
+    """Generator over the validated reads of the augmented FASTQ `readfile`."""
+    yield from _passes(readfile, mask, memory, maxfpr, casemin, ctrlmax, as_text=False)
+
+
 def main(args):
     sink = kevlar_amd.open(args.out, 'w')
-    validated = filter(args.augfastq, mask=kevlar_amd.sketch.load(args.mask) if args.mask else None, memory=args.memory,
-                       maxfpr=args.max_fpr, casemin=args.case_min, ctrlmax=args.ctrl_max)
-    sink.write(''.join(map(kevlar_amd.sequence.format_augmented_fastx, validated)))
+    mask = kevlar_amd.sketch.load(args.mask) if args.mask else None
+    for text in _passes(args.augfastq, mask, args.memory, args.max_fpr, args.case_min, args.ctrl_max, as_text=True):
+        try:
+            sink.write(text)
+        except TypeError:
+            sink.write(text.decode('latin-1'))
+    if args.out not in ('-', None):
+        sink.close()

@@ -437,6 +437,18 @@ class ReadBatch(object):
         return self
 
     @classmethod
+    def from_blob(cls, blob, offs):
+        """sequences given as one bytes blob with offsets (read i = blob[offs[i]:offs[i + 1]])"""
+        _lib.require_device()
+        self = cls.__new__(cls)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        handle = ctypes.c_void_p()
+        check(_lib.load().kv_reads_create(blob, _u64p(offs), len(offs) - 1, ctypes.byref(handle)))
+        self._h = handle
+        self.n_reads = len(offs) - 1
+        return self
+
+    @classmethod
     def from_packed(cls, words, read_len):
         """words: uint32 array [n_reads, ceil(read_len/16)], 2 bits per base (A0 C1 G2 T3)."""
         _lib.require_device()

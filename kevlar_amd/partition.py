@@ -59,6 +59,74 @@ def partition(readstream, strict=False, minabund=None, maxabund=None, dedup=True
     kevlar_amd.plog('[kevlar::partition]', 'Total time: {:.2f} seconds'.format(timer.stop()))
 
 
+def partition_file(infile, minabund=None, maxabund=None, dedup=True):
+    """partition() in relaxed mode for a file, on arrays: yields (N, annotated, read indices) with the reads of
+    component N in the order partition() lists them (sorted by name; with dedup the first read of every sequence, up
+    to reverse complement).  Same components, numbering and log lines; the records are parsed natively
+    (AnnotatedReads.from_file), the components come from the device union-find, and no Record object is built."""
+    import numpy as np
+    from kevlar_amd import khmer
+    from kevlar_amd.annotated import AnnotatedReads
+    timer = kevlar_amd.Timer()
+    timer.start()
+    with _phase(timer, 'loadreads', ('[kevlar::partition] Loading reads',), 'Reads loaded in {:.2f} sec'):
+        ann = AnnotatedReads.from_file(infile)
+        if ann.n and ann.ksize is None and len(ann):
+            raise ValueError('all interesting k-mers of one graph must share k')
+        blob, offs = ann.names.decode('latin-1'), ann.name_offs.tolist()
+        names = [blob[offs[i]:offs[i + 1]] for i in range(ann.n)]
+        node_id, node_names, holder = {}, [], []           # reads that share a name share a node; its record is the last of them
+        node_of_read = np.empty(ann.n, dtype=np.uint32)
+        for i, name in enumerate(names):
+            node = node_id.get(name)
+            if node is None:
+                node = node_id[name] = len(node_names)
+                node_names.append(name)
+                holder.append(i)
+            else:
+                holder[node] = i
+            node_of_read[i] = node
+    mode = ('[kevlar::partition]', 'Building read graph in relaxed mode')
+    with _phase(timer, 'buildgraph', mode, 'Graph built in {:.2f} sec'):
+        if ann.n:
+            labels = khmer.readgraph_components(ann.batch, ann.ksize or 1, ann.read, ann.offset, node_of_read, len(node_names),
+                                                minabund or 0, maxabund or 0)
+            ann.close()
+        else:
+            labels = np.zeros(0, dtype=np.uint32)
+    with _phase(timer, 'partition', ('[kevlar::partition] Partition readgraph',), 'Partitioning done in {:.2f} sec'):
+        # components, largest first; ties: by sorted read names, descending (names are unique per node, so the
+        # smallest name of a component decides)
+        order = np.argsort(labels, kind='stable')
+        cuts = np.flatnonzero(np.diff(labels[order])) + 1 if len(order) else np.zeros(0, dtype=np.int64)
+        groups = np.split(order, cuts) if len(order) else []
+        keyed = []
+        for nodes in groups:
+            if len(nodes) < 2:
+                continue                      # a read on its own is not a partition
+            members = sorted(node_names[v] for v in nodes.tolist())
+            keyed.append((len(members), members))
+        keyed.sort(reverse=True)
+        seqs, soffs = ann.seqs.decode('latin-1'), ann.seq_offs.tolist()
+        number = 0
+        for size, members in keyed:
+            reads = [holder[node_id[name]] for name in members]
+            if dedup:
+                seen, kept = set(), []
+                for r in reads:
+                    canon = kevlar_amd.revcommin(seqs[soffs[r]:soffs[r + 1]])
+                    if canon in seen:
+                        continue
+                    seen.add(canon)
+                    kept.append(r)
+                reads = kept
+                if minabund and len(reads) < minabund:
+                    continue
+            number += 1
+            yield number, ann, reads
+    kevlar_amd.plog('[kevlar::partition]', 'Total time: {:.2f} seconds'.format(timer.stop()))
+
+
 class _Outputs(object):
     """where partitions go: one shared stream, or with --split PREFIX one gzipped file per partition"""
 
@@ -70,14 +138,43 @@ class _Outputs(object):
 
     def put(self, number, text):
         if self.shared is not None:
-            self.shared.write(text)
+            try:
+                self.shared.write(text)
+            except TypeError:          # a text-mode stream offered bytes, or the other way round
+                self.shared.write(text.decode('latin-1') if isinstance(text, bytes) else text.encode('latin-1'))
             return
         with kevlar_amd.open('{:s}.cc{:d}.augfastq.gz'.format(self.prefix, number), 'w') as own:
             own.write(text)
 
+    def close(self):
+        import sys
+        if self.shared is not None and self.shared not in (sys.stdout, sys.stdin):
+            self.shared.close()
+
+
+def _main_arrays(args, outputs):
+    """relaxed mode, file input: everything on arrays, text rendered natively"""
+    sizes = [0]
+    pending_reads, pending_suffix, ann = [], [], None
+    for number, ann, reads in partition_file(args.infile, minabund=args.min_abund, maxabund=args.max_abund, dedup=args.dedup):
+        sizes.append(len(reads))
+        suffix = ' kvcc={:d}'.format(number)
+        if args.split:
+            outputs.put(number, ann.format(reads, suffixes=[suffix] * len(reads)))
+        else:
+            pending_reads.extend(reads)
+            pending_suffix.extend([suffix] * len(reads))
+    if pending_reads:
+        outputs.put(0, ann.format(pending_reads, suffixes=pending_suffix))
+    kevlar_amd.plog('[kevlar::partition]', 'grouped {:d} reads into {:d} connected components'.format(sum(sizes), len(sizes) - 1))
+
 
 def main(args):
     outputs = _Outputs(args.out, args.split)
+    if not args.strict and not args.gml and isinstance(args.infile, str) and args.infile != '-':
+        _main_arrays(args, outputs)
+        outputs.close()
+        return
     labelled = partition(kevlar_amd.parse_augmented_fastx(kevlar_amd.open(args.infile, 'r')), strict=args.strict,
                          minabund=args.min_abund, maxabund=args.max_abund, dedup=args.dedup, gmlfile=args.gml)
     sizes = [0]                      # reads per component; sizes[0] pads the 1-based numbering
