@@ -534,16 +534,33 @@ def end_to_end(args, wl, packed, names, synth):
             a = kevlar_amd.cli.parser().parse_args(argv)
             kevlar_amd.cli.mains[a.cmd](a)
             return time.perf_counter() - t0
+        def stage(argv):
+            t0 = time.perf_counter()
+            a = kevlar_amd.cli.parser().parse_args(argv)
+            kevlar_amd.cli.mains[a.cmd](a)
+            return time.perf_counter() - t0
         try:
             dt_plain = novel_run('.fq')
             dt_bgzf = novel_run('.bgzf.fq.gz')
+            novel_out = os.path.join(tmp, 'novel.bgzf.fq.gz.augfastq')
+            dt_filter = stage(['filter', '--memory', '50M', '--case-min', str(args.case_min), '--ctrl-max', str(args.ctrl_max),
+                               '-o', os.path.join(tmp, 'filtered.augfastq'), novel_out])
+            dt_partition = stage(['partition', '-o', os.path.join(tmp, 'partitioned.augfastq'), os.path.join(tmp, 'filtered.augfastq')])
         finally:
+            log_text = kevlar_amd.logstream.getvalue()
             kevlar_amd.logstream = saved
+        grouped = [line for line in log_text.split('\n') if 'grouped' in line]
         with open(os.path.join(tmp, 'novel.fq.augfastq')) as a, open(os.path.join(tmp, 'novel.bgzf.fq.gz.augfastq')) as b:
             assert a.read() == b.read(), 'host-parsed and device-parsed input must give the same annotated reads'
         ingest = ingest_rates(os.path.join(tmp, 'proband.fq'), os.path.join(tmp, 'proband.bgzf.fq.gz'), n)
         return {'value': round(len(names) * n / dt_plain, 1), 'unit': 'reads/s',
-                'from_bgzf_fastq_gz': round(len(names) * n / dt_bgzf, 1), 'ingest_reads_per_s': ingest,
+                'from_bgzf_fastq_gz': round(len(names) * n / dt_bgzf, 1),
+                'whole_path': {'reads_per_s': round(len(names) * n / (dt_bgzf + dt_filter + dt_partition), 1),
+                               'novel_s': round(dt_bgzf, 3), 'filter_s': round(dt_filter, 3), 'partition_s': round(dt_partition, 3),
+                               'result': grouped[-1].split('] ')[-1] if grouped else None,
+                               'what': 'BGZF .fq.gz files -> kevlar novel (counts the samples) -> kevlar filter -> kevlar partition, annotated '
+                                       'reads on disk between the stages'},
+                'ingest_reads_per_s': ingest,
                 'sample': '{} reads per sample as FASTQ on local disk ({} MB each plain, {} MB blocked gzip); one `kevlar novel --case ... '
                           '--control ...` run: every sample parsed, packed and counted, the case sample parsed again and scanned, annotated '
                           'reads written: {:.2f} s from plain FASTQ (parsed on the host), {:.2f} s from BGZF .fq.gz (inflated and parsed on '
