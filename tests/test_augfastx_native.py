@@ -1,0 +1,104 @@
+"""The native augmented FASTA/FASTQ codec (kv_augfastx.hip: host code, no GPU needed) against the Python one
+(kevlar_amd/sequence.py, itself pinned to the reference's files in tests/test_host_logic.py): every golden augmented
+file parses to the same records and annotations, and formats back to the same bytes; BGZF files index correctly."""
+import glob
+import gzip
+import io
+import os
+
+import numpy as np
+import pytest
+
+import kevlar_amd
+from kevlar_amd.annotated import AnnotatedReads
+from kevlar_amd.sequence import format_augmented_fastx, parse_augmented_fastx
+
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'data')
+FILES = sorted(glob.glob(os.path.join(DATA, '*.augfast*')) + glob.glob(os.path.join(DATA, '**', '*.augfast*'), recursive=True))
+
+
+def python_records(path):
+    with kevlar_amd.open(path, 'r') as stream:
+        return [r for r in parse_augmented_fastx(stream)]
+
+
+@pytest.mark.parametrize('path', FILES, ids=[os.path.basename(p) for p in FILES])
+def test_native_parse_and_format_equal_python(path):
+    want = python_records(path)
+    ksizes = {k.ksize for r in want for k in r.annotations}
+    if len(ksizes) > 1:
+        with pytest.raises(ValueError):
+            AnnotatedReads.from_file(path)
+        return
+    got = AnnotatedReads.from_file(path)
+    assert got.n == len(want)
+    assert len(got) == sum(len(r.annotations) for r in want)
+    for i, rec in enumerate(want):
+        mine = got.record(i)
+        assert (mine.name, mine.sequence, mine.quality) == (rec.name, rec.sequence, rec.quality)
+        assert [tuple(k) for k in mine.annotations] == [(k.ksize, k.offset, tuple(k.abund)) for k in rec.annotations]
+        assert mine.mates == rec.mates
+    text = ''.join(format_augmented_fastx(r) for r in want).encode('latin-1')
+    assert got.format(np.arange(got.n)) == text
+    # the container built from record objects renders the same bytes
+    assert AnnotatedReads(want).format(np.arange(len(want))) == text
+    if len(got):
+        # a selection: every second annotation, recounted case abundance, a name suffix
+        keep = np.zeros(len(got), dtype=bool)
+        keep[::2] = True
+        again = np.arange(len(got)) % 200
+        chosen = [r for r in got.select(keep, case_abund=again)]
+        body, n = got.select_text(keep, case_abund=again)
+        assert n == len(chosen)
+        assert body == ''.join(format_augmented_fastx(r) for r in chosen).encode('latin-1')
+        first = np.arange(min(3, got.n))
+        for rec, i in zip(want, first.tolist()):
+            rec.name += ' kvcc=7'
+        assert got.format(first, suffixes=[' kvcc=7'] * len(first)) == ''.join(format_augmented_fastx(r) for r in want[:len(first)]).encode('latin-1')
+
+
+def test_native_parser_rejects_what_the_python_parser_rejects(tmp_path):
+    good = '@r1\nACGTACGTAC\n+\nIIIIIIIIII\n  GTACG          7 0 1#\n'
+    bad_kmer = good.replace('  GTACG', '  GTACC')
+    stray = good + 'something else\n'
+    for name, text in (('kmer.augfastq', bad_kmer), ('stray.augfastq', stray)):
+        path = str(tmp_path / name)
+        with open(path, 'w') as fh:
+            fh.write(text)
+        with pytest.raises(Exception):
+            AnnotatedReads.from_file(path)
+        with pytest.raises(Exception):
+            python_records(path)
+    path = str(tmp_path / 'ok.augfastq')
+    with open(path, 'w') as fh:
+        fh.write('\n' + good + '\n#mateseq=TTTT#\n>r2 second\nAAAA\n')
+    got = AnnotatedReads.from_file(path)
+    assert got.n == 2 and len(got) == 1 and got.record(0).mates == ['TTTT'] and got.record(1).quality is None
+    assert got.format([0, 1]) == ''.join(format_augmented_fastx(r) for r in python_records(path)).encode('latin-1')
+
+
+def test_bgzf_writer_and_index(tmp_path):
+    """kevlar_amd.open(name.gz, 'w') writes blocked gzip that every gzip reader takes and kv_bgzf_index walks"""
+    import ctypes
+    from kevlar_amd import _lib, bgzf
+    path = str(tmp_path / 'out.augfastq.gz')
+    text = ''.join('@read{}\n{}\n+\n{}\n'.format(i, 'ACGT' * 25, 'I' * 100) for i in range(3000))
+    sink = kevlar_amd.open(path, 'w')
+    sink.write(text[:1000])
+    sink.write(text[1000:].encode('ascii'))
+    sink.close()
+    assert bgzf.is_bgzf(path)
+    assert gzip.open(path, 'rt').read() == text
+    with kevlar_amd.open(path, 'r') as stream:
+        assert stream.read() == text
+    image = open(path, 'rb').read()
+    total, members = ctypes.c_uint64(), ctypes.c_uint64()
+    _lib.check(_lib.load().kv_bgzf_text_size(image, len(image), ctypes.byref(total), ctypes.byref(members)))
+    assert total.value == len(text) and members.value == (len(text) + bgzf.BLOCK_TEXT - 1) // bgzf.BLOCK_TEXT + 1
+    plain = gzip.compress(text.encode('ascii'))
+    with pytest.raises(Exception):
+        _lib.check(_lib.load().kv_bgzf_text_size(plain, len(plain), ctypes.byref(total), ctypes.byref(members)))
+    # the multi-threaded writer produces the same members
+    other = str(tmp_path / 'mt.gz')
+    bgzf.write_file(other, text.encode('ascii'), level=6, threads=4)
+    assert open(other, 'rb').read() == image
