@@ -735,7 +735,11 @@ __global__ __launch_bounds__(SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_
         __syncthreads();
     }
     const uint32_t total_vec = total_vec_sh;
-    if (total_vec == 0) return;                                    // untouched slice: no table traffic at all
+    if (total_vec == 0) {                                          // untouched slice: no table traffic at all ...
+        if (g.zero_tables)                                         // ... unless this pass is also the table's zeroing
+            for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) tab[j] = make_uint4(0, 0, 0, 0);
+        return;
+    }
     // a vector: its items (always loaded whole) and how many of them are real
     struct Vec { uint4 q; uint32_t n; };
     auto fetch = [&](uint32_t v) {
@@ -754,7 +758,11 @@ __global__ __launch_bounds__(SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_
     };
     // software pipeline, two vectors ahead: item requests fly while the slice loads and while earlier items are applied
     Vec v0 = fetch(threadIdx.x), v1 = fetch(threadIdx.x + THREADS);
-    for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) l4[j] = tab[j];
+    if (g.zero_tables) {
+        for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) l4[j] = make_uint4(0, 0, 0, 0);
+    } else {
+        for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) l4[j] = tab[j];
+    }
     __syncthreads();
     uint32_t fresh = 0;
     for (uint32_t v = threadIdx.x; v < total_vec; v += THREADS) {
@@ -871,6 +879,7 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
     BinGeom &g = plan->g;
     memset(&g, 0, sizeof(g));
     plan->weighted = weighted;
+    g.zero_tables = s->lazy_zero ? 1 : 0;
     g.T = s->h.ntables;
     g.tile_lds = lds_front;
     uint64_t pmin = UINT64_MAX, pmax = 0;
@@ -994,6 +1003,7 @@ int kv_bin_finish(kv_sketch *s, BinPlan &plan, bool added_from_ctr, uint64_t n_a
         return KV_ERR_CAPACITY;
     }
     *n_added = added_from_ctr ? ctr[2] : n_added_fixed;
+    s->lazy_zero = false;          // stage C has written every slice
     // exact occupancy bookkeeping; n_unique_kmers as a linear-counting estimate
     if (s->occ_dirty) {
         int rc = kv_sketch_refresh_occupancy(s);   // recount includes this batch

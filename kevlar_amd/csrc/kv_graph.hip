@@ -389,7 +389,9 @@ extern "C" int kv_unique_exact(kv_sketch *s, const kv_reads *const *batches, int
     KV_REQUIRE(s && n_unique_out && (batches || n_batches == 0) && n_batches >= 0, KV_ERR_ARG, "kv_unique_exact: bad argument");
     KV_REQUIRE(nbands >= 0 && (nbands == 0 || (band >= 0 && band < nbands)), KV_ERR_ARG,
                "band %d out of range for %d bands", band, nbands);
+    { const int rc = kv_sketch_ready(mask); if (rc != KV_OK) return rc; }
     std::lock_guard<std::mutex> lk(s->mu);
+    { const int rc = kv_sketch_ready_locked(s); if (rc != KV_OK) return rc; }
     hipStream_t st = kv_stream();
     const int k = s->h.ksize;
     uint64_t total = 0;
@@ -465,6 +467,8 @@ extern "C" int kv_abundance_distribution(kv_sketch *counts, kv_sketch *tracking,
     KV_REQUIRE(counts->h.ksize == tracking->h.ksize && counts->h.hashfam == tracking->h.hashfam, KV_ERR_ARG,
                "counts and tracking sketches must share k and hash function");
     memset(hist_out, 0, 65536 * sizeof(uint64_t));
+    { const int rc = kv_sketch_ready(counts); if (rc != KV_OK) return rc; }
+    { const int rc = kv_sketch_ready(tracking); if (rc != KV_OK) return rc; }
     hipStream_t st = kv_stream();
     const int k = counts->h.ksize;
     uint64_t total = 0;

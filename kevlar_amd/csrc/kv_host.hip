@@ -371,6 +371,7 @@ extern "C" int kv_sketch_info_get(kv_sketch *s, kv_sketch_info *out)
     KV_REQUIRE(s && out, KV_ERR_ARG, "kv_sketch_info_get: null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     if (s->occ_dirty) {
+        { const int rc = kv_sketch_ready_locked(s); if (rc != KV_OK) return rc; }
         int rc = kv_sketch_refresh_occupancy(s);
         if (rc != KV_OK) return rc;
     }
@@ -393,6 +394,7 @@ extern "C" int kv_sketch_table_read(kv_sketch *s, int table, uint8_t *host_out, 
     uint64_t nb = kv_table_nbytes(s->h.storage, s->h.size[table]);
     KV_REQUIRE(nbytes >= nb, KV_ERR_CAPACITY, "table %d needs %llu bytes", table, (unsigned long long)nb);
     std::lock_guard<std::mutex> lk(s->mu);
+    { const int rc = kv_sketch_ready_locked(s); if (rc != KV_OK) return rc; }
     KV_HIP(hipMemcpyAsync(host_out, s->h.tab[table], nb, hipMemcpyDeviceToHost, kv_stream()));
     KV_HIP(hipStreamSynchronize(kv_stream()));
     return KV_OK;
@@ -405,6 +407,7 @@ extern "C" int kv_sketch_table_write(kv_sketch *s, int table, const uint8_t *hos
     KV_REQUIRE(nbytes == nb, KV_ERR_ARG, "table %d holds %llu bytes", table, (unsigned long long)nb);
     std::lock_guard<std::mutex> lk(s->mu);
     s->version++;
+    { const int rc = kv_sketch_ready_locked(s); if (rc != KV_OK) return rc; }
     KV_HIP(hipMemcpyAsync(s->h.tab[table], host_in, nb, hipMemcpyHostToDevice, kv_stream()));
     KV_HIP(hipStreamSynchronize(kv_stream()));
     s->occ_dirty = true;
@@ -416,8 +419,14 @@ extern "C" int kv_sketch_clear(kv_sketch *s)
     KV_REQUIRE(s, KV_ERR_ARG, "kv_sketch_clear: null handle");
     std::lock_guard<std::mutex> lk(s->mu);
     s->version++;
-    KvProfScope prof("memset_tables");
-    for (int i = 0; i < s->h.ntables; ++i) KV_HIP(hipMemsetAsync(s->h.tab[i], 0, s->alloc_bytes[i], kv_stream()));
+    const char *lazy = getenv("KV_LAZY_CLEAR");           // "0": zero the tables here and now
+    if (lazy && atoi(lazy) == 0) {
+        KvProfScope prof("memset_tables");
+        for (int i = 0; i < s->h.ntables; ++i) KV_HIP(hipMemsetAsync(s->h.tab[i], 0, s->alloc_bytes[i], kv_stream()));
+        s->lazy_zero = false;
+    } else {
+        s->lazy_zero = true;
+    }
     s->n_occupied = 0;
     s->n_unique = 0;
     s->occ_dirty = false;
@@ -425,9 +434,31 @@ extern "C" int kv_sketch_clear(kv_sketch *s)
     return KV_OK;
 }
 
+int kv_sketch_ready_locked(kv_sketch *s)
+{
+    if (!s->lazy_zero) return KV_OK;
+    KvProfScope prof("memset_tables");
+    for (int i = 0; i < s->h.ntables; ++i) KV_HIP(hipMemsetAsync(s->h.tab[i], 0, s->alloc_bytes[i], kv_stream()));
+    s->lazy_zero = false;
+    return KV_OK;
+}
+
+int kv_sketch_ready(const kv_sketch *cs)
+{
+    kv_sketch *s = const_cast<kv_sketch *>(cs);
+    if (!s) return KV_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->lazy_zero) return KV_OK;
+    const int rc = kv_sketch_ready_locked(s);
+    if (rc != KV_OK) return rc;
+    KV_HIP(hipStreamSynchronize(kv_stream()));      // the reader may be on another stream
+    return KV_OK;
+}
+
 extern "C" int kv_sketch_table_devptr(kv_sketch *s, int table, void **devptr, uint64_t *nbytes)
 {
     KV_REQUIRE(s && devptr && table >= 0 && table < s->h.ntables, KV_ERR_ARG, "kv_sketch_table_devptr: bad argument");
+    { const int rc = kv_sketch_ready(s); if (rc != KV_OK) return rc; }
     *devptr = s->h.tab[table];
     if (nbytes) *nbytes = kv_table_nbytes(s->h.storage, s->h.size[table]);
     return KV_OK;
@@ -491,6 +522,7 @@ extern "C" int kv_sketch_save(kv_sketch *s, const char *path)
 {
     KV_REQUIRE(s && path, KV_ERR_ARG, "kv_sketch_save: null argument");
     std::lock_guard<std::mutex> lk(s->mu);
+    { const int rc = kv_sketch_ready_locked(s); if (rc != KV_OK) return rc; }
     if (s->occ_dirty) {
         int rc = kv_sketch_refresh_occupancy(s);
         if (rc != KV_OK) return rc;

@@ -50,6 +50,10 @@ struct kv_sketch {
     uint64_t version = 0;  // bumped by everything that changes a table (invalidates cached scan verdicts)
     uint64_t *d_counters; // [0] n_kmers, [1] n_unique (device accumulators)
     bool skm_off = false;  // the last batch counted through the super-k-mer front end did not deduplicate: skip it until cleared
+    // kv_sketch_clear only notes that the tables are zero: the partitioned count's apply stage, which rewrites every
+    // slice anyway, then starts from zeroed LDS instead of loading the slice (no memset, no first read of the tables);
+    // every other reader or writer of the tables calls kv_sketch_ready first, which does the memset after all
+    bool lazy_zero = false;
     std::mutex mu;
 };
 
@@ -81,6 +85,10 @@ struct kv_reads {
     int nk_cached_k = -1;           // kv_reads_num_kmers memo (the length vector can hold 1e7+ entries)
     uint64_t nk_cached = 0;
 };
+
+// the deferred memset of kv_sketch_clear, if one is pending (s->mu held by the caller / taken here)
+int kv_sketch_ready_locked(kv_sketch *s);
+int kv_sketch_ready(const kv_sketch *s);
 
 int kv_reads_from_packed_var(const uint32_t *words, const uint32_t *lens, const uint8_t *flags, uint64_t n_reads, kv_reads **out);
 // the same for sequences that sit as text in HBM (kv_fastq.hip): read r = d_seq_len[r] characters at d_text + d_seq_start[r];

@@ -232,6 +232,7 @@ extern "C" int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int b
     KV_REQUIRE(s && reads, KV_ERR_ARG, "kv_consume: null handle");
     KV_REQUIRE(nbands >= 0 && (nbands == 0 || (band >= 0 && band < nbands)), KV_ERR_ARG,
                "band %d out of range for %d bands", band, nbands);
+    { const int rc = kv_sketch_ready(mask); if (rc != KV_OK) return rc; }
     std::lock_guard<std::mutex> lk(s->mu);
     s->version++;
     const ConsumeFilter p = make_consume_filter(s->h.ksize, s->h.hashfam, nbands, band, mask != nullptr, threshold,
@@ -257,6 +258,7 @@ extern "C" int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int b
         }
         if (rc != KV_ERR_CAPACITY) return rc;   // capacity: tables untouched, fall through to the atomic kernel
     }
+    { const int rc = kv_sketch_ready_locked(s); if (rc != KV_OK) return rc; }
     KV_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(uint64_t), kv_stream()));
     if (reads->n_tiles > 0) {
         KvProfScope prof("k_consume");
@@ -361,6 +363,7 @@ extern "C" int kv_get_hashes(kv_sketch *s, const uint64_t *hashes, uint64_t n, u
     KV_REQUIRE(s && ((hashes && counts_out) || n == 0), KV_ERR_ARG, "kv_get_hashes: null argument");
     if (n == 0) return KV_OK;
     std::lock_guard<std::mutex> lk(s->mu);
+    { const int rc = kv_sketch_ready_locked(s); if (rc != KV_OK) return rc; }
     PointScratch &ps = point_scratch();
     std::lock_guard<std::mutex> slk(ps.mu);
     hipStream_t st = kv_stream();
@@ -385,6 +388,7 @@ extern "C" int kv_add_hashes(kv_sketch *s, const uint64_t *hashes, uint64_t n, u
     if (n == 0) return KV_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     s->version++;
+    { const int rc = kv_sketch_ready_locked(s); if (rc != KV_OK) return rc; }
     PointScratch &ps = point_scratch();
     std::lock_guard<std::mutex> slk(ps.mu);
     hipStream_t st = kv_stream();
@@ -426,6 +430,7 @@ extern "C" int kv_consume_hashes(kv_sketch *s, const void *d_hashes, uint64_t n,
         if (rc == KV_OK) return KV_OK;
         if (rc != KV_ERR_CAPACITY) return rc;
     }
+    { const int rc = kv_sketch_ready_locked(s); if (rc != KV_OK) return rc; }
     KV_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(uint64_t), kv_stream()));
     {
         KvProfScope prof("k_add_hashes");
@@ -462,6 +467,7 @@ extern "C" int kv_consume_hashes_weighted(kv_sketch *s, const void *d_items, uin
         }
         if (rc != KV_ERR_CAPACITY) return rc;
     }
+    { const int rc = kv_sketch_ready_locked(s); if (rc != KV_OK) return rc; }
     KV_HIP(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(uint64_t), kv_stream()));
     {
         KvProfScope prof("k_add_hashes_weighted");

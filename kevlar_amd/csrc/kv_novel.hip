@@ -428,6 +428,7 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     for (int c = 0; c < ncase + nctrl; ++c) {
         const kv_sketch *s = c < ncase ? cases[c] : ctrls[c - ncase];
         KV_REQUIRE(s, KV_ERR_ARG, "kv_novel_scan: null sketch");
+        { const int rc = kv_sketch_ready(s); if (rc != KV_OK) return rc; }
         KV_REQUIRE(s->h.ksize == k && s->h.hashfam == fam, KV_ERR_ARG,
                    "all sketches of one scan must share k and hash function");
         p.sk[c] = s->d_desc;
@@ -772,6 +773,7 @@ int scan_items(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int 
     for (int c = 0; c < ncase + nctrl; ++c) {
         const kv_sketch *s = c < ncase ? cases[c] : ctrls[c - ncase];
         KV_REQUIRE(s, KV_ERR_ARG, "kv_novel_scan_hashes: null sketch");
+        { const int rc = kv_sketch_ready(s); if (rc != KV_OK) return rc; }
         KV_REQUIRE(s->h.ksize == k && s->h.hashfam == fam, KV_ERR_ARG,
                    "all sketches of one scan must share k and hash function");
         p.sk[c] = s->d_desc;
