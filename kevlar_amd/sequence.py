@@ -73,31 +73,41 @@ class Record(object):
 
 
 def copy_record(record):
-    quality = getattr(record, 'quality', None)
-    return Record(record.name, record.sequence, quality)
+    return Record(record.name, record.sequence, getattr(record, 'quality', None))
 
 
-def _by_offset(ikmer):
-    return ikmer[1]
+class _Renderer(object):
+    """Record -> augmented text.  One instance, reused: the pieces of a record are collected in a list and joined
+    once; the k-mer lines are produced in offset order whatever order the annotations were added in."""
+
+    GAP = ' ' * 10
+
+    def header(self, record):
+        if record.quality is None:
+            return '>{}\n{}\n'.format(record.name, record.sequence)
+        return '@{}\n{}\n+\n{}\n'.format(record.name, record.sequence, record.quality)
+
+    def kmer_line(self, sequence, note):
+        ksize, offset, abund = note
+        return ''.join((' ' * offset, sequence[offset:offset + ksize], self.GAP, ' '.join(str(a) for a in abund), '#\n'))
+
+    def __call__(self, record):
+        pieces = [self.header(record)]
+        notes = record.annotations
+        if any(notes[i][1] > notes[i + 1][1] for i in range(len(notes) - 1)):
+            notes = sorted(notes, key=lambda note: note[1])        # stable: ties keep their order
+        pieces.extend(self.kmer_line(record.sequence, note) for note in notes)
+        pieces.extend('#mateseq={}#\n'.format(mate) for mate in record.mates)
+        return ''.join(pieces)
 
 
-def format_augmented_fastx(record):
-    if record.quality is not None:
-        parts = ['@', record.name, '\n', record.sequence, '\n+\n', record.quality, '\n']
-    else:
-        parts = ['>', record.name, '\n', record.sequence, '\n']
-    seq = record.sequence
-    for ksize, offset, abund in sorted(record.annotations, key=_by_offset):
-        parts.append('{}{}          {}#\n'.format(' ' * offset, seq[offset:offset + ksize], ' '.join(map(str, abund))))
-    for mateseq in record.mates:
-        parts.append('#mateseq={}#\n'.format(mateseq))
-    return ''.join(parts)
+format_augmented_fastx = _Renderer()
 
 
 def print_augmented_fastx(record, outstream):
     text = format_augmented_fastx(record)
     try:
-        outstream.write(bytes(text, 'ascii'))
+        outstream.write(text.encode('ascii'))
     except TypeError:
         outstream.write(text)
 
@@ -105,30 +115,41 @@ def print_augmented_fastx(record, outstream):
 write_record = print_augmented_fastx
 
 
+def _classify(line):
+    """'blank', 'header', 'mate', 'kmer' or 'junk' for one line of an augmented stream"""
+    if not line.strip():
+        return 'blank'
+    if line[0] in '@>':
+        return 'header'
+    if line[-2:] == '#\n':
+        return 'mate' if line.startswith('#mateseq=') else 'kmer'
+    return 'junk'
+
+
 def parse_augmented_fastx(instream):
-    """Generator over Records of an augmented FASTA/FASTQ stream."""
-    record = None
-    for line in instream:
-        if line.strip() == '':
+    """Generator over Records of an augmented FASTA/FASTQ stream (files go through the native parser instead:
+    kevlar_amd.annotated.AnnotatedReads.from_file)."""
+    lines = iter(instream)
+    current = None
+    for line in lines:
+        kind = _classify(line)
+        if kind == 'blank':
             continue
-        first = line[0]
-        if first in ('@', '>'):
-            if record is not None:
-                yield record
-            name = line[1:].strip()
-            seq = next(instream).strip()
-            qual = None
-            if first == '@':
-                next(instream)
-                qual = next(instream).strip()
-            record = Record(name=name, sequence=seq, quality=qual)
-        elif line.endswith('#\n'):
-            if line.startswith('#mateseq='):
-                record.add_mate(_MATE_RE.search(line).group(1))
-                continue
-            body = line.lstrip()
-            fields = body[:-2].split()
-            record.annotate(fields[0], len(line) - len(body), tuple(map(int, fields[1:])))
+        if kind == 'header':
+            if current is not None:
+                yield current
+            sequence = next(lines).strip()
+            quality = None
+            if line[0] == '@':
+                next(lines)                                   # the '+' line
+                quality = next(lines).strip()
+            current = Record(name=line[1:].strip(), sequence=sequence, quality=quality)
+        elif kind == 'mate':
+            current.add_mate(_MATE_RE.search(line).group(1))
+        elif kind == 'kmer':
+            text = line.lstrip()
+            kmer, *counts = text[:-2].split()
+            current.annotate(kmer, len(line) - len(text), tuple(int(c) for c in counts))
         else:
             raise Exception(line)
-    yield record
+    yield current
