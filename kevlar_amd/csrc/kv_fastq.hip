@@ -216,6 +216,22 @@ __global__ __launch_bounds__(64) void k_record_copy(const uint8_t *__restrict__ 
 
 }  // namespace
 
+// device buffers of one reader; they outlive it in a small pool (a sample is usually read twice -- count, then novel --
+// and hipMalloc / hipFree of gigabytes cost more than parsing a few million reads)
+struct FastqBuffers {
+    KvArena text[2];                // the batch being served / the batch before it (the carried tail moves across)
+    KvArena comp, lines, recs, scratch, fetch;
+    void release()
+    {
+        for (KvArena *a : {&text[0], &text[1], &comp, &lines, &recs, &scratch, &fetch})
+            if (a->p) { (void)hipFree(a->p); a->p = nullptr; a->bytes = 0; }
+    }
+};
+namespace {
+std::vector<FastqBuffers *> g_fastq_pool;
+std::mutex g_fastq_pool_mu;
+}
+
 struct KvFastqDevice {
     std::string path;
     int fd = -1;
@@ -223,10 +239,10 @@ struct KvFastqDevice {
     size_t image_size = 0;
     std::vector<KvBgzfMember> members;
     size_t next_member = 0;
-    KvArena text[2];                // the batch being served / the batch before it (the carried tail moves across)
+    FastqBuffers *buf = nullptr;
+    KvArena *text = nullptr;        // = buf->text
     int cur = 0;
     uint64_t carry_at = 0, carry_len = 0;     // unconsumed tail of text[cur]
-    KvArena comp, lines, recs, scratch, fetch;
     uint64_t *d_line_start = nullptr;         // of the batch being served
     uint64_t n_batch = 0;
     double bytes_per_read = 0.0;
@@ -246,6 +262,12 @@ KvFastqDevice *kv_fastq_device_open(const char *path)
     int yes = 0;
     kv_bgzf_index(d->image, d->image_size, &d->members, &yes);
     if (!yes) { kv_fastq_device_close(d); return nullptr; }
+    {
+        std::lock_guard<std::mutex> lk(g_fastq_pool_mu);
+        if (!g_fastq_pool.empty()) { d->buf = g_fastq_pool.back(); g_fastq_pool.pop_back(); }
+    }
+    if (!d->buf) d->buf = new FastqBuffers();
+    d->text = d->buf->text;
     return d;
 }
 
@@ -254,8 +276,11 @@ void kv_fastq_device_close(KvFastqDevice *d)
     if (!d) return;
     if (d->image) munmap((void *)d->image, d->image_size);
     if (d->fd >= 0) close(d->fd);
-    for (KvArena *a : {&d->text[0], &d->text[1], &d->comp, &d->lines, &d->recs, &d->scratch, &d->fetch})
-        if (a->p) (void)hipFree(a->p);
+    if (d->buf) {
+        std::lock_guard<std::mutex> lk(g_fastq_pool_mu);
+        if (g_fastq_pool.size() < 4) g_fastq_pool.push_back(d->buf);
+        else { d->buf->release(); delete d->buf; }
+    }
     delete d;
 }
 
@@ -285,21 +310,21 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         if (d->carry_len) KV_HIP(hipMemcpyAsync(text, (const uint8_t *)d->text[d->cur].p + d->carry_at, d->carry_len, hipMemcpyDeviceToDevice, st));
         if (m1 > m0) {
             const uint64_t c0 = d->members[m0].in_off, c1 = d->members[m1 - 1].in_off + d->members[m1 - 1].in_len;
-            KV_HIP(d->comp.need(kv_round_up(c1 - c0 + 64, 4096)));
-            KV_HIP(hipMemcpyAsync(d->comp.p, d->image + c0, c1 - c0, hipMemcpyHostToDevice, st));
+            KV_HIP(d->buf->comp.need(kv_round_up(c1 - c0 + 64, 4096)));
+            KV_HIP(hipMemcpyAsync(d->buf->comp.p, d->image + c0, c1 - c0, hipMemcpyHostToDevice, st));
             std::vector<uint64_t> text_off(m1 - m0);
             uint64_t at = d->carry_len;
             for (size_t i = m0; i < m1; ++i) { text_off[i - m0] = at; at += d->members[i].isize; }
-            const int rc = kv_bgzf_inflate((const uint8_t *)d->comp.p, c0, d->members.data() + m0, m1 - m0, text_off.data(), text, d->scratch);
+            const int rc = kv_bgzf_inflate((const uint8_t *)d->buf->comp.p, c0, d->members.data() + m0, m1 - m0, text_off.data(), text, d->buf->scratch);
             if (rc != KV_OK) return rc;
         }
         // ---- lines
         const uint32_t n_chunks = (uint32_t)((total_in + 1 + FQ_CHUNK - 1) / FQ_CHUNK);
         const size_t b_counts = kv_round_up((uint64_t)n_chunks * 4, 256), b_base = kv_round_up(((uint64_t)n_chunks + 1) * 8, 256);
-        KV_HIP(d->scratch.need(b_counts + b_base + 256));
-        uint32_t *d_counts = (uint32_t *)d->scratch.p;
-        uint64_t *d_base = (uint64_t *)((unsigned char *)d->scratch.p + b_counts);
-        unsigned long long *d_ctr = (unsigned long long *)((unsigned char *)d->scratch.p + b_counts + b_base);
+        KV_HIP(d->buf->scratch.need(b_counts + b_base + 256));
+        uint32_t *d_counts = (uint32_t *)d->buf->scratch.p;
+        uint64_t *d_base = (uint64_t *)((unsigned char *)d->buf->scratch.p + b_counts);
+        unsigned long long *d_ctr = (unsigned long long *)((unsigned char *)d->buf->scratch.p + b_counts + b_base);
         unsigned long long total = total_in;
         if (final) {
             hipLaunchKernelGGL(k_terminate, dim3(1), dim3(1), 0, st, text, total_in, d_ctr);
@@ -331,13 +356,13 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         (void)prev;
         if (n == 0) { d->done = true; d->carry_len = 0; return KV_OK; }
         // ---- line starts, records
-        KV_HIP(d->lines.need(kv_round_up((4 * n + 2) * 8, 256)));
-        uint64_t *line_start = (uint64_t *)d->lines.p;
+        KV_HIP(d->buf->lines.need(kv_round_up((4 * n + 2) * 8, 256)));
+        uint64_t *line_start = (uint64_t *)d->buf->lines.p;
         KV_HIP(hipMemsetAsync(line_start, 0, 8, st));
-        KV_HIP(d->recs.need(kv_round_up(n * 8, 256) + kv_round_up(n * 4, 256) + 256));
-        uint64_t *d_seq_start = (uint64_t *)d->recs.p;
-        uint32_t *d_seq_len = (uint32_t *)((unsigned char *)d->recs.p + kv_round_up(n * 8, 256));
-        unsigned long long *d_bad = (unsigned long long *)((unsigned char *)d->recs.p + kv_round_up(n * 8, 256) + kv_round_up(n * 4, 256));
+        KV_HIP(d->buf->recs.need(kv_round_up(n * 8, 256) + kv_round_up(n * 4, 256) + 256));
+        uint64_t *d_seq_start = (uint64_t *)d->buf->recs.p;
+        uint32_t *d_seq_len = (uint32_t *)((unsigned char *)d->buf->recs.p + kv_round_up(n * 8, 256));
+        unsigned long long *d_bad = (unsigned long long *)((unsigned char *)d->buf->recs.p + kv_round_up(n * 8, 256) + kv_round_up(n * 4, 256));
         KV_HIP(hipMemsetAsync(d_bad, 0xFF, 8, st));
         {
             KvProfScope prof("k_line_starts");
@@ -391,10 +416,10 @@ int kv_fastq_device_fetch(KvFastqDevice *d, const uint64_t *idx, uint64_t n, std
         KV_REQUIRE(idx[i] < d->n_batch, KV_ERR_ARG, "record %llu is not in the current batch of %llu", (unsigned long long)idx[i], (unsigned long long)d->n_batch);
     hipStream_t st = kv_stream();
     const size_t b_idx = kv_round_up(n * 8, 256), b_ext = kv_round_up(n * 16, 256);
-    KV_HIP(d->fetch.need(2 * b_idx + b_ext));
-    uint64_t *d_idx = (uint64_t *)d->fetch.p;
-    uint64_t *d_ext = (uint64_t *)((unsigned char *)d->fetch.p + b_idx);
-    uint64_t *d_dst = (uint64_t *)((unsigned char *)d->fetch.p + b_idx + b_ext);
+    KV_HIP(d->buf->fetch.need(2 * b_idx + b_ext));
+    uint64_t *d_idx = (uint64_t *)d->buf->fetch.p;
+    uint64_t *d_ext = (uint64_t *)((unsigned char *)d->buf->fetch.p + b_idx);
+    uint64_t *d_dst = (uint64_t *)((unsigned char *)d->buf->fetch.p + b_idx + b_ext);
     KV_HIP(hipMemcpyAsync(d_idx, idx, n * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_record_extents, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, (const uint64_t *)d->d_line_start,
                        (const uint64_t *)d_idx, n, d_ext);

@@ -17,7 +17,7 @@ def short_name(kernel):
     if not m:
         return kernel.split('(')[0].strip()
     name = m.group(1)
-    if name in ('k_bin_split', 'k_bin_apply') and 'true>' in kernel:       # the weighted template instances
+    if name in ('k_bin_split', 'k_bin_apply') and re.search(r'<[^>]*true', kernel):       # the weighted template instances
         name += '_w'
     return name
 
@@ -70,14 +70,24 @@ def main(src, dst):
         kernels[name] = {'fetch_factor': factor, 'launches_per_step': launches,
                          'hbm_bytes_per_launch': int((fetch_kb * factor + write_kb) * 1024),
                          'hbm_bytes_per_step': int((fetch_kb * factor + write_kb) * 1024 * launches / steps)}
-    out = {'collected': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of bench.py --steps 1 --warmup 0',
+    out = {'collected': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of bench.py --steps 1 --warmup 0 --count-streams 1',
            'raw_KB_per_launch': pmc, 'kernels': kernels}
     with open(os.path.join(dst, 'pmc_hbm_bytes.json'), 'w') as fh:
         json.dump(out, fh, indent=1)
-    for name in ('bench.json', 'bench_under_rocprof.json'):
+    for name in ('bench.json', 'bench_under_rocprof.json', 'bench_one_stream.json', 'bench_under_rocprof_default.json'):
         p = os.path.join(src, name)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, name))
+    # the kernel statistics of the default command (samples counted concurrently on three streams)
+    stats = glob.glob(os.path.join(src, 'trace_default', '**', '*kernel_stats.csv'), recursive=True)
+    if stats:
+        with open(stats[0]) as fh, open(os.path.join(dst, 'kernel_stats_default_3_streams.csv'), 'w') as out:
+            rows = list(csv.reader(fh))
+            w = csv.writer(out)
+            w.writerow(rows[0])
+            for row in rows[1:]:
+                if row and ('k_' in row[0] or 'memset' in row[0].lower() or 'rocprim' in row[0]):
+                    w.writerow(row)
 
 
 if __name__ == '__main__':
