@@ -289,3 +289,53 @@ def test_long_sequences_are_cut_into_segment_tiles(hk, ok):
     hits, _ = ok.novel_scan([ref], [], bases, offs, len(reads), 31, 1, 0)
     assert [(int(x), int(y)) for x, y in zip(r, o)] == [(h[0], h[1]) for h in hits]
     assert hk.ReadBatch(['A' * 60000]).num_kmers(31) == 60000 - 30        # no length limit any more
+
+
+@pytest.mark.parametrize('path', ['skm', 'binned', 'atomic'])
+def test_clear_is_lazy_but_invisible(hk, path, tmp_path):
+    """kv_sketch_clear defers the zeroing to the next partitioned count; whatever touches the tables first -- a big
+    count, a small one, point queries, table reads, save, a scan, use as a mask -- must see zeroed tables"""
+    from kevlar_amd import synth
+    k = 25
+    trio = synth.make_trio(120000, 77)
+    reads = synth.unpack_reads(synth.sample_reads_packed(trio['proband'], 60000, 100, 0.01, 3), 100)
+    junk = synth.unpack_reads(synth.sample_reads_packed(trio['mother'], 60000, 100, 0.01, 4), 100)
+    big, small, dirty = hk.ReadBatch(reads), hk.ReadBatch(reads[:50]), hk.ReadBatch(junk)
+    fresh = hk.Counttable(k, 1.5e6, 4)
+    os.environ['KV_COUNT_PATH'] = path
+    try:
+        fresh.consume_batch(big)
+        want = [fresh.table_bytes(t) for t in range(4)]
+        used = hk.Counttable(k, 1.5e6, 4)
+        for first in ('count', 'get', 'table', 'save', 'small', 'mask', 'scan'):
+            used.consume_batch(dirty)
+            used.clear()
+            assert used.n_occupied() == 0 and used.n_unique_kmers() == 0
+            if first == 'get':
+                assert used.get(reads[0][:k]) == 0
+                assert not used.get_hashes(used.hash_kmers([r[:k] for r in junk[:500]])).any()
+            elif first == 'table':
+                assert not any(used.table_bytes(t).strip(b'\x00') for t in range(4))
+            elif first == 'save':
+                out = str(tmp_path / 'empty.ct')
+                used.save(out)
+                back = hk.Counttable.load(out)
+                assert not any(back.table_bytes(t).strip(b'\x00') for t in range(4))
+            elif first == 'small':
+                used.consume_batch(small)
+                ref = hk.Counttable(k, 1.5e6, 4)
+                ref.consume_batch(small)
+                assert [used.table_bytes(t) for t in range(4)] == [ref.table_bytes(t) for t in range(4)]
+                used.clear()
+            elif first == 'mask':
+                other = hk.Counttable(k, 1.5e6, 4)
+                other.consume_batch(big, 0, 0, used)
+                assert [other.table_bytes(t) for t in range(4)] == want          # an empty mask hides nothing
+            elif first == 'scan':
+                r, o, a, _ = hk.novel_scan([fresh], [used], hk.ReadBatch(reads[:2000]), 1, 0)
+                assert len(r) > 0 and not a[:, 1].any()                        # the cleared control holds nothing
+            used.consume_batch(big)
+            assert [used.table_bytes(t) for t in range(4)] == want, first
+            assert used.n_occupied() == fresh.n_occupied()
+    finally:
+        os.environ.pop('KV_COUNT_PATH', None)
