@@ -573,7 +573,7 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
 __host__ __device__ inline uint32_t skm_wave_scratch_words(uint32_t sbw) { return sbw > 64u ? sbw : 64u; }
 
 template <int KW, int TS>
-__global__ __launch_bounds__(SKM_THREADS3) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
+__global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
                                                            const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
     __shared__ SkmTable<KW, TS> tb;
@@ -668,19 +668,45 @@ __global__ __launch_bounds__(256) void k_skm_loose_count(SkmGeom sg, const Sketc
     if (n > sg.loose_cap) n = sg.loose_cap;
     const int k = sg.k, recw = sg.recw;
     uint64_t n_added = 0;
-    auto emit = [&](int t, uint64_t bin, uint32_t wgt) { spill_item(g, t, bin, wgt); };
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t *rec = sg.loose + i * (uint64_t)recw;
+    // wave-uniform loops (every lane votes in spill_items_wave).  A wave takes 64 records at a time: the one-k-mer records
+    // (occurrences that missed a full LDS table: nearly all of them) are handled one per lane; a record with several k-mers
+    // (it missed its segment in S1 / S2) is spread over the lanes, one k-mer each, instead of holding 63 lanes up while one
+    // lane rolls through it
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    auto count_one = [&](const SkmKey<KW> &fw, bool live) {
+        uint64_t h = 0;
+        bool pass = false;
+        if (live) {
+            h = skm_key_hash<KW>(skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k)), lut, f.hp);
+            pass = consume_filter_pass(f, mask, h);
+        }
+        n_added += pass ? 1 : 0;
+        uint64_t bins[BIN_MAX_T];
+#pragma unroll
+        for (int t = 0; t < BIN_MAX_T; ++t) bins[t] = (pass && t < g.T) ? fastmod(h, sk->size[t], sk->magic[t]) : 0ull;
+        spill_items_wave(g, bins, 1u, pass);
+    };
+    for (uint64_t i0 = blockIdx.x * (uint64_t)blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+        const uint64_t i = i0 + lane;
+        const bool have = i < n;
+        const uint64_t *rec = sg.loose + (have ? i : 0) * (uint64_t)recw;
         uint64_t bw[3];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
-        const uint32_t nk = skm_hdr_n(rec[0]);
-        SkmKey<KW> fw = skm_first_kmer<KW>(bw, k);
-        SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
-        for (uint32_t j = 0; j < nk; ++j) {
-            if (j) skm_roll<KW>(fw, rc, skm_base_at(bw, j + (uint32_t)k - 1u), k);
-            const uint64_t h = skm_key_hash<KW>(skm_canonical<KW>(fw, rc), lut, f.hp);
-            n_added += skm_count_kmer(h, 1u, sk, mask, f, g.T, emit);
+        for (int t = 0; t < 3; ++t) bw[t] = (have && t < sg.nbw) ? rec[1 + t] : 0ull;
+        const uint32_t nk = have ? skm_hdr_n(rec[0]) : 0u;
+        count_one(skm_first_kmer<KW>(bw, k), nk == 1);
+        unsigned long long longer = __ballot(nk > 1);
+        while (longer) {
+            const uint32_t src = (uint32_t)__ffsll((long long)longer) - 1u;
+            longer &= longer - 1ull;
+            const uint64_t b0 = skm_shfl64(bw[0], src), b1 = skm_shfl64(bw[1], src), b2 = skm_shfl64(bw[2], src);
+            const uint32_t nk_src = (uint32_t)__shfl((int)nk, (int)src);
+            for (uint32_t j0 = 0; j0 < nk_src; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const bool live = j < nk_src;
+                count_one(skm_kmer_at<KW>(b0, b1, b2, live ? j : 0u, k), live);
+            }
         }
     }
     n_added = wave_sum_u64(n_added);
@@ -711,7 +737,7 @@ __device__ __forceinline__ void skm_route_item(const KvRouteSink &rs, const uint
 }
 
 template <int KW, int TS>
-__global__ __launch_bounds__(SKM_THREADS3) void k_skm_route(SkmGeom sg, HashParams hp, KvRouteSink rs)
+__global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashParams hp, KvRouteSink rs)
 {
     __shared__ SkmTable<KW, TS> tb;
     __shared__ uint32_t cnt[TS];
@@ -801,7 +827,7 @@ __device__ __forceinline__ void skm_mark(const NovelParams &p, const ReadsDev &r
 }
 
 template <int KW, int TS>
-__global__ __launch_bounds__(SKM_THREADS3) void k_skm_novel(SkmGeom sg, ReadsDev rd, NovelParams p)
+__global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, ReadsDev rd, NovelParams p)
 {
     __shared__ SkmTable<KW, TS> tb;
     __shared__ uint32_t flag[TS / 32];           // bit per slot: the key is interesting
@@ -1116,8 +1142,8 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
             const double distinct = (double)sc[7] / (double)n_kmers + alone;
             s->skm_off = rc != KV_OK || alone > 0.03 || distinct > 0.45;
             if (getenv("KV_SKM_VERBOSE"))
-                fprintf(stderr, "[kv_skm] batch of %llu k-mers: %.1f%% distinct, %.2f%% outside the LDS tables%s\n",
-                        (unsigned long long)n_kmers, 100 * distinct, 100 * alone, s->skm_off ? " -> next batches take the plain partition" : "");
+                fprintf(stderr, "[kv_skm] batch of %llu k-mers: %.1f%% distinct, %.2f%% outside the LDS tables, %llu of %llu records outside their segments%s\n",
+                        (unsigned long long)n_kmers, 100 * distinct, 100 * alone, sc[6], sc[5], s->skm_off ? " -> next batches take the plain partition" : "");
         }
     }
     if (rc != KV_OK) {
