@@ -24,7 +24,7 @@ def short_name(kernel):
 
 def main(src, dst):
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True)
+    stats = sorted(glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime, reverse=True)
     if stats:
         with open(stats[0]) as fh, open(os.path.join(dst, 'kernel_stats.csv'), 'w') as out:
             rows = list(csv.reader(fh))
@@ -35,7 +35,7 @@ def main(src, dst):
                     w.writerow(row)
     pmc = {}
     for counter, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
-        files = glob.glob(os.path.join(src, sub, '**', '*counter_collection.csv'), recursive=True)
+        files = sorted(glob.glob(os.path.join(src, sub, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime, reverse=True)
         if not files:
             continue
         acc = {}
@@ -79,7 +79,7 @@ def main(src, dst):
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, name))
     # the kernel statistics of the default command (samples counted concurrently on three streams)
-    stats = glob.glob(os.path.join(src, 'trace_default', '**', '*kernel_stats.csv'), recursive=True)
+    stats = sorted(glob.glob(os.path.join(src, 'trace_default', '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime, reverse=True)
     if stats:
         with open(stats[0]) as fh, open(os.path.join(dst, 'kernel_stats_default_3_streams.csv'), 'w') as out:
             rows = list(csv.reader(fh))
