@@ -574,17 +574,18 @@ def end_to_end(args, wl, packed, names, synth):
                 'ingest_reads_per_s': ingest,
                 'sample': '{} reads per sample as FASTQ on local disk ({} MB each plain, {} MB blocked gzip); one `kevlar novel --case ... '
                           '--control ...` run: every sample parsed, packed and counted, the case sample parsed again and scanned, annotated '
-                          'reads written: {:.2f} s from plain FASTQ (parsed on the host), {:.2f} s from BGZF .fq.gz (inflated and parsed on '
-                          'the GPU); identical output'.format(n, os.path.getsize(os.path.join(tmp, 'proband.fq')) >> 20,
+                          'reads written: {:.2f} s from plain FASTQ (uploaded as text, split and packed on the GPU), {:.2f} s from BGZF .fq.gz '
+                          '(inflated, split and packed on the GPU); identical output'.format(n, os.path.getsize(os.path.join(tmp, 'proband.fq')) >> 20,
                                                                os.path.getsize(os.path.join(tmp, 'proband.bgzf.fq.gz')) >> 20, dt_plain, dt_bgzf)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
 def ingest_rates(fastq, bgzf_gz, n):
-    """reads/s from a file on disk to 2-bit packed batches in HBM (the reader alone, no count): plain FASTQ and plain gzip
-    on the host (one zlib stream: the inflate rate of one core), blocked gzip inflated and parsed on the GPU
-    (kv_inflate.hip, kv_fastq.hip), and the packed-read cache a first pass leaves behind (KEVLAR_PACK_CACHE=1)"""
+    """reads/s from a file on disk to 2-bit packed batches in HBM (the reader alone, no count): plain FASTQ (text uploaded,
+    records split and packed on the GPU: kv_fastq.hip), plain gzip on the host (one zlib stream: the inflate rate of one
+    core), blocked gzip inflated and parsed on the GPU (kv_inflate.hip), and the packed-read cache a first pass leaves
+    behind (KEVLAR_PACK_CACHE=1)"""
     import gzip
     import shutil
     from kevlar_amd import khmer as hk

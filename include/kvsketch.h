@@ -143,10 +143,10 @@ int kv_fastx_num_reads(kv_fastx *f, uint64_t *n); /* khmer parser.num_reads */
  * kv_fastx_record_text (byte for byte what the source holds).  kv_fastx_from_cache tells which mode a handle is in. */
 int kv_fastx_from_cache(kv_fastx *f, int *yes);
 int kv_fastx_record_text(kv_fastx *f, uint64_t i, char *seq_out, char *qual_out);
-/* Device ingest: a file that is blocked gzip (BGZF: bgzip, htslib, kevlar_amd.open(..., 'w')) holding four-line FASTQ
- * and is read as packed batches (upload != 0) from the first call never has its text on the host: the compressed bytes
- * go to HBM, one wavefront inflates one BGZF member (kv_inflate.hip), lines and records are found and the sequences
- * packed by kernels (kv_fastq.hip).  kv_fastx_on_device tells whether a handle works that way; the text of a batch then
+/* Device ingest: a file that holds four-line FASTQ, uncompressed or as blocked gzip (BGZF: bgzip, htslib,
+ * kevlar_amd.open(..., 'w')), and is read as packed batches (upload != 0) from the first call is never parsed on the host:
+ * its bytes go to HBM, one wavefront inflates one BGZF member (kv_inflate.hip), lines and records are found and the
+ * sequences packed by kernels (kv_fastq.hip).  kv_fastx_on_device tells whether a handle works that way; the text of a batch then
  * stays in HBM, and kv_fastx_fetch(idx, n) brings the named records to the host, after which kv_fastx_batch_text
  * describes exactly those n records.  Anything else (plain gzip, FASTA, blank lines, KV_INGEST=host) is parsed on the
  * host as before, with identical results.                                                                        */

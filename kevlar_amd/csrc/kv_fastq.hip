@@ -1,7 +1,8 @@
 // kv_fastq.hip -- FASTQ records split and 2-bit packed on the device, fed by kv_inflate.hip.
 //
 // The host path (kv_fastx.hip) inflates with zlib and splits lines with memchr on one core: ~2 M reads/s from a .gz
-// file whatever the GPU does next.  For blocked gzip (BGZF) input the text never exists on the host:
+// file, ~20 M from an uncompressed one, whatever the GPU does next.  For blocked gzip (BGZF) input the text never exists
+// on the host (an uncompressed FASTQ file takes the same route minus the inflate: its bytes are uploaded as they are):
 //
 //   file image (mmap) --H2D, compressed--> k_inflate (one wave per member) --> text in HBM
 //   k_count_lines   newlines per 16-KB chunk            \
@@ -239,6 +240,8 @@ struct KvFastqDevice {
     size_t image_size = 0;
     std::vector<KvBgzfMember> members;
     size_t next_member = 0;
+    bool plain = false;             // uncompressed FASTQ: the file's bytes are the text, uploaded as they are
+    uint64_t next_byte = 0;
     FastqBuffers *buf = nullptr;
     KvArena *text = nullptr;        // = buf->text
     int cur = 0;
@@ -260,8 +263,9 @@ KvFastqDevice *kv_fastq_device_open(const char *path)
     KvFastqDevice *d = new KvFastqDevice();
     d->path = path; d->fd = fd; d->image = (const uint8_t *)map; d->image_size = (size_t)sb.st_size;
     int yes = 0;
-    kv_bgzf_index(d->image, d->image_size, &d->members, &yes);
-    if (!yes) { kv_fastq_device_close(d); return nullptr; }
+    if (d->image[0] == '@') d->plain = true;
+    else kv_bgzf_index(d->image, d->image_size, &d->members, &yes);
+    if (!yes && !d->plain) { kv_fastq_device_close(d); return nullptr; }
     {
         std::lock_guard<std::mutex> lk(g_fastq_pool_mu);
         if (!g_fastq_pool.empty()) { d->buf = g_fastq_pool.back(); g_fastq_pool.pop_back(); }
@@ -296,18 +300,24 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
     const double per_read = d->bytes_per_read > 0 ? d->bytes_per_read : 280.0;
     uint64_t want = std::min<uint64_t>((uint64_t)((double)max_reads * per_read * 1.02) + 65536, text_cap);
     for (;;) {
-        // ---- members of this batch
+        // ---- members (or, for an uncompressed file, bytes) of this batch
         const size_t m0 = d->next_member;
         size_t m1 = m0;
         uint64_t fresh = 0;
-        while (m1 < d->members.size() && (m1 == m0 || d->carry_len + fresh + d->members[m1].isize <= want)) fresh += d->members[m1++].isize;
-        const bool final = m1 == d->members.size();
+        const uint64_t b0 = d->next_byte;
+        if (d->plain) {
+            fresh = std::min<uint64_t>(d->image_size - b0, want > d->carry_len + 65536 ? want - d->carry_len : 65536);
+        } else {
+            while (m1 < d->members.size() && (m1 == m0 || d->carry_len + fresh + d->members[m1].isize <= want)) fresh += d->members[m1++].isize;
+        }
+        const bool final = d->plain ? b0 + fresh == d->image_size : m1 == d->members.size();
         const uint64_t total_in = d->carry_len + fresh;
         if (total_in == 0) { d->done = true; return KV_OK; }
         const int nxt = d->cur ^ 1;
         KV_HIP(d->text[nxt].need(kv_round_up(total_in + 64, 4096)));
         uint8_t *text = (uint8_t *)d->text[nxt].p;
         if (d->carry_len) KV_HIP(hipMemcpyAsync(text, (const uint8_t *)d->text[d->cur].p + d->carry_at, d->carry_len, hipMemcpyDeviceToDevice, st));
+        if (d->plain && fresh) KV_HIP(hipMemcpyAsync(text + d->carry_len, d->image + b0, fresh, hipMemcpyHostToDevice, st));
         if (m1 > m0) {
             const uint64_t c0 = d->members[m0].in_off, c1 = d->members[m1 - 1].in_off + d->members[m1 - 1].in_len;
             KV_HIP(d->buf->comp.need(kv_round_up(c1 - c0 + 64, 4096)));
@@ -343,6 +353,7 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         uint64_t n = std::min<uint64_t>(n_lines / 4, max_reads);
         if (n == 0 && !final) {           // not one whole record yet (huge records or a tiny budget): take more members
             d->next_member = m0;
+            d->next_byte = b0;
             want = want * 2 + 65536;
             continue;
         }
@@ -351,6 +362,7 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
             return KV_ERR_TYPE;
         }
         d->next_member = m1;
+        d->next_byte = b0 + (d->plain ? fresh : 0);
         const int prev = d->cur;
         d->cur = nxt;
         (void)prev;

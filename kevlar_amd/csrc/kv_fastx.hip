@@ -350,7 +350,8 @@ extern "C" int kv_fastx_open(const char *path, kv_fastx **out)
             FILE *probe = fopen(path, "rb");
             if (probe) {
                 if (fread(head, 1, sizeof(head), probe) == sizeof(head))
-                    f->dev_candidate = head[0] == 0x1f && head[1] == 0x8b && head[2] == 8 && head[3] == 4 && head[12] == 'B' && head[13] == 'C';
+                    f->dev_candidate = (head[0] == 0x1f && head[1] == 0x8b && head[2] == 8 && head[3] == 4 && head[12] == 'B' && head[13] == 'C') ||
+                                       head[0] == '@';                 // BGZF, or uncompressed FASTQ
                 fclose(probe);
             }
         }

@@ -106,8 +106,9 @@ def batches_of(hk, path, size, env=None):
             os.environ.pop(key, None)
 
 
-@pytest.mark.parametrize('batch,text_mb', [(100000, None), (7001, None), (100000, '1'), (2500, '1')])
-def test_device_parse_equals_host_parse(hk, tmp_path, batch, text_mb):
+@pytest.mark.parametrize('batch,text_mb,kind', [(100000, None, 'bgzf'), (7001, None, 'bgzf'), (100000, '1', 'bgzf'), (2500, '1', 'bgzf'),
+                                                (100000, None, 'plain'), (7001, '1', 'plain')])
+def test_device_parse_equals_host_parse(hk, tmp_path, batch, text_mb, kind):
     """BGZF FASTQ parsed on the device: same records, same packed reads (through the count tables they produce) as
     the host parser; reads with N / lower case, ragged lengths, CRLF, a last line without newline"""
     text = fastq_text(30000, 21).decode('ascii').split('\n')
@@ -119,8 +120,13 @@ def test_device_parse_equals_host_parse(hk, tmp_path, batch, text_mb):
     for line in range(4 * 20, 4 * 24):
         text[line] += '\r'
     blob = '\n'.join(text).rstrip('\n')              # no newline behind the last quality line
-    path = str(tmp_path / 'reads.fq.gz')
-    write_fastq(path, blob)
+    if kind == 'bgzf':
+        path = str(tmp_path / 'reads.fq.gz')
+        write_fastq(path, blob)
+    else:                                            # an uncompressed file takes the same kernels, minus the inflate
+        path = str(tmp_path / 'reads.fq')
+        with open(path, 'w') as fh:
+            fh.write(blob)
     host = batches_of(hk, path, batch, {'KV_INGEST': 'host'})
     dev = batches_of(hk, path, batch, {'KV_INGEST_TEXT_MB': text_mb} if text_mb else None)
     assert set(host[3]) == {'TextBatch'} and set(dev[3]) == {'DeviceTextBatch'}
@@ -145,6 +151,13 @@ def test_device_parse_falls_back_to_host(hk, tmp_path):
     broken = lines[:4 * 3000] + [''] + lines[4 * 3000:]
     path = str(tmp_path / 'gap.fq.gz')
     write_fastq(path, '\n'.join(broken))
+    host = batches_of(hk, path, 1000, {'KV_INGEST': 'host'})
+    dev = batches_of(hk, path, 1000)
+    assert dev[3][0] == 'DeviceTextBatch' and dev[3][-1] == 'TextBatch'
+    assert host[0] == dev[0] and host[1] == dev[1] and host[2] == dev[2] and dev[4] == 5000
+    path = str(tmp_path / 'gap.fq')                  # the same, uncompressed
+    with open(path, 'w') as fh:
+        fh.write('\n'.join(broken))
     host = batches_of(hk, path, 1000, {'KV_INGEST': 'host'})
     dev = batches_of(hk, path, 1000)
     assert dev[3][0] == 'DeviceTextBatch' and dev[3][-1] == 'TextBatch'
