@@ -32,7 +32,7 @@ KIND = {'Counttable': 0, 'SmallCounttable': 1, 'Nodetable': 2,
 _buckets_per_byte = {'countgraph': 1, 'smallcountgraph': 2, 'nodegraph': 8}
 
 # reads handed to the device per kv_consume call when streaming a file
-BATCH_READS = 1 << 20
+BATCH_READS = 1 << 23
 
 
 def _u64p(arr):

@@ -14,7 +14,7 @@ import kevlar_amd
 from kevlar_amd import khmer
 from kevlar_amd._lib import KV_BAND_NONE, KV_BAND_RANGE, KV_BAND_REFQUIRK
 
-SCAN_BATCH_READS = 1 << 19
+SCAN_BATCH_READS = 1 << 23
 
 
 class KevlarCaseSampleMismatchError(ValueError):
