@@ -13,6 +13,14 @@ the very sketch the banded run would have built, and scans the case k-mers it re
 torch is plumbing: it owns the exchange buffers and moves them; all arithmetic is in the HIP
 library.  With the gloo backend (CPU tests, or several ranks sharing one GPU) the buffers are
 staged through host memory.
+
+Stream invariant: the library works on its own HIP stream, torch and RCCL on theirs, and the
+buffers come from torch's caching allocator without record_stream.  That is safe because every
+hand-over is fenced by the HOST: each kv_* entry point used here returns only after
+hipStreamSynchronize on the library stream (see include/kvsketch.h), and _Exchange.wait()
+synchronises torch's stream before the library reads a received buffer.  A buffer is therefore
+never in use on one stream while the other side (or the allocator) touches it.  Anyone making a
+kv_* call asynchronous must add record_stream / wait_stream here first.
 """
 import time
 
