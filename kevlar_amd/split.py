@@ -11,8 +11,8 @@ from kevlar_amd.sequence import format_augmented_fastx
 def _emit(text, sink):
     try:
         sink.write(text)
-    except TypeError:                      # binary sinks (gzip)
-        sink.write(text.encode('ascii'))
+    except TypeError:                      # a binary sink offered text, or a text sink offered bytes
+        sink.write(text.encode('ascii') if isinstance(text, str) else text.decode('latin-1'))
 
 
 def split(pstream, outstreams, maxreads=10000):
@@ -29,12 +29,54 @@ def split(pstream, outstreams, maxreads=10000):
         progress.update()
 
 
+def split_file(infile, outstreams, maxreads=10000):
+    """split() for a file, on arrays: the records are parsed natively (AnnotatedReads.from_file), grouped by their
+    `kvcc` labels exactly as parse_partitioned_reads groups them, and each output file's partitions are rendered
+    natively in one piece."""
+    from kevlar_amd.annotated import AnnotatedReads
+    from kevlar_amd.seqio import KevlarPartitionLabelError, partition_id
+    ann = AnnotatedReads.from_file(infile)
+    blob, offs = ann.names.decode('latin-1'), ann.name_offs.tolist()
+    labels = [partition_id(blob[offs[i]:offs[i + 1]]) for i in range(ann.n)]
+    # runs of equal labels; unlabelled reads join the partition in front of them, which then loses its id
+    partitions, held, unlabelled = [], [], False
+    previous = object()
+    for i, label in enumerate(labels):
+        if label is None:
+            unlabelled = True
+        elif unlabelled:
+            raise KevlarPartitionLabelError('reads with and without partition labels (kvcc=#)')
+        elif label != previous and held:
+            partitions.append(held)
+            held = []
+        held.append(i)
+        previous = label
+    if held or not partitions:
+        partitions.append(held)
+    progress = kevlar_amd.ProgressIndicator('[kevlar::split] processed {counter} partitions', interval=100,
+                                            breaks=[1000, 10000, 100000], usetimer=True)
+    nsinks = len(outstreams)
+    per_sink = [[] for _ in outstreams]
+    for turn, reads in enumerate(partitions):
+        if len(reads) > maxreads:
+            kevlar_amd.plog('[kevlar::split]', 'WARNING: discarding partition with {} reads'.format(len(reads)))
+            continue
+        per_sink[turn % nsinks].extend(reads)
+        progress.update()
+    for reads, sink in zip(per_sink, outstreams):
+        if reads:
+            _emit(ann.format(reads), sink)
+
+
 def main(args):
     suffix = '.augfastx.gz' if args.infile.endswith('.gz') else '.augfastx'
     sinks = [kevlar_amd.open('{:s}.{:d}{:s}'.format(args.base, i, suffix), 'w') for i in range(args.numfiles)]
     try:
-        reads = kevlar_amd.parse_augmented_fastx(kevlar_amd.open(args.infile, 'r'))
-        split(kevlar_amd.parse_partitioned_reads(reads), sinks)
+        if isinstance(args.infile, str) and args.infile != '-':
+            split_file(args.infile, sinks)
+        else:
+            reads = kevlar_amd.parse_augmented_fastx(kevlar_amd.open(args.infile, 'r'))
+            split(kevlar_amd.parse_partitioned_reads(reads), sinks)
     finally:
         for sink in sinks:
             sink.close()

@@ -102,3 +102,22 @@ def test_bgzf_writer_and_index(tmp_path):
     other = str(tmp_path / 'mt.gz')
     bgzf.write_file(other, text.encode('ascii'), level=6, threads=4)
     assert open(other, 'rb').read() == image
+
+
+def test_split_file_equals_split_of_records(tmp_path):
+    """kevlar split on arrays (split_file) writes byte for byte what the record-stream split writes"""
+    from io import BytesIO, StringIO
+    infile = os.path.join(DATA, 'fiveparts.augfastq.gz')
+    by_records = [StringIO() for _ in range(3)]
+    stream = kevlar_amd.parse_partitioned_reads(parse_augmented_fastx(kevlar_amd.open(infile, 'r')))
+    kevlar_amd.split.split(stream, by_records, maxreads=60)           # drops the 67-read partition
+    by_arrays = [BytesIO() for _ in range(3)]
+    kevlar_amd.split.split_file(infile, by_arrays, maxreads=60)
+    assert [s.getvalue().encode('ascii') for s in by_records] == [s.getvalue() for s in by_arrays]
+    assert sum(len(s.getvalue()) for s in by_arrays) > 1000
+    # an unlabelled file is one partition
+    plain = os.path.join(DATA, 'example1.augfastq')
+    one, other = [StringIO(), StringIO()], [BytesIO(), BytesIO()]
+    kevlar_amd.split.split(kevlar_amd.parse_partitioned_reads(parse_augmented_fastx(kevlar_amd.open(plain, 'r'))), one)
+    kevlar_amd.split.split_file(plain, other)
+    assert [s.getvalue().encode('ascii') for s in one] == [s.getvalue() for s in other]
