@@ -98,6 +98,45 @@ class AnnotatedReads(object):
         self._finish()
         return self
 
+    @classmethod
+    def concat(cls, parts):
+        """the records of several containers, one after the other"""
+        parts = list(parts)
+        ksizes = {p.ksize for p in parts if p.ksize is not None}
+        if len(ksizes) > 1:
+            raise ValueError('all interesting k-mers of one stream must share k (found {})'.format(sorted(ksizes)))
+        self = cls.__new__(cls)
+        self.n = sum(p.n for p in parts)
+
+        def blobs(attr, offs):
+            blob = b''.join(getattr(p, attr) for p in parts)
+            shifted, base = [np.zeros(1, dtype=np.uint64)], 0
+            for p in parts:
+                o = getattr(p, offs)
+                shifted.append(o[1:] + np.uint64(base))
+                base += int(o[-1])
+            return blob, np.concatenate(shifted)
+        self.names, self.name_offs = blobs('names', 'name_offs')
+        self.seqs, self.seq_offs = blobs('seqs', 'seq_offs')
+        self.quals, self.qual_offs = blobs('quals', 'qual_offs')
+        self.mates, self.mate_offs = blobs('mates', 'mate_offs')
+        self.is_fastq = np.concatenate([p.is_fastq for p in parts]) if parts else np.zeros(0, dtype=np.uint8)
+        first, base, rec_base, mate_record = [np.zeros(1, dtype=np.int64)], 0, 0, []
+        for p in parts:
+            first.append(p.first[1:] + base)
+            base += int(p.first[-1])
+            mate_record.append(p.mate_record + np.uint32(rec_base))
+            rec_base += p.n
+        self.first = np.concatenate(first)
+        self.mate_record = np.concatenate(mate_record) if parts else np.zeros(0, dtype=np.uint32)
+        self.offset = np.concatenate([p.offset for p in parts]) if parts else np.zeros(0, dtype=np.uint32)
+        self.ksize = ksizes.pop() if ksizes else None
+        self.nsamples = max([p.nsamples for p in parts] or [0])
+        with_ann = [p.abund for p in parts if len(p)]
+        self.abund = np.concatenate(with_ann) if with_ann else np.zeros((0, 0), dtype=np.int32)
+        self._finish()
+        return self
+
     def _finish(self):
         self.first = self.first.astype(np.int64)
         self.read = np.repeat(np.arange(self.n, dtype=np.uint32), np.diff(self.first))
@@ -190,19 +229,26 @@ class AnnotatedReads(object):
         for i in self._kept_reads(keep).tolist():
             yield self.record(i, keep, case_abund)
 
-    def format(self, reads, keep=None, case_abund=None, suffixes=None):
+    def format(self, reads, keep=None, case_abund=None, suffixes=None, regrouped=None):
         """Augmented FASTA/FASTQ text (bytes) of the given reads (indices, in that order) with the annotations where
-        `keep` is set (None: all); suffixes: one string per read appended to its name."""
+        `keep` is set (None: all); suffixes: one string per read appended to its name.  regrouped = (lo, hi, order):
+        output read j carries annotations order[lo[j]:hi[j]] (indices into this container's annotations) instead of
+        its own -- the union over several copies of a read (unband)."""
         reads = np.ascontiguousarray(reads, dtype=np.uint64)
         if not len(reads):
             return b''
         idx = reads.astype(np.int64)
-        lo = np.ascontiguousarray(self.first[idx], dtype=np.uint64)
-        hi = np.ascontiguousarray(self.first[idx + 1], dtype=np.uint64)
-        keep8 = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
-        case32 = None if case_abund is None else np.ascontiguousarray(case_abund, dtype=np.int32)
         abund = np.ascontiguousarray(self.abund, dtype=np.int32)
         offset = np.ascontiguousarray(self.offset, dtype=np.uint32)
+        if regrouped is None:
+            lo = np.ascontiguousarray(self.first[idx], dtype=np.uint64)
+            hi = np.ascontiguousarray(self.first[idx + 1], dtype=np.uint64)
+        else:
+            lo, hi, order = regrouped
+            lo, hi = np.ascontiguousarray(lo, dtype=np.uint64), np.ascontiguousarray(hi, dtype=np.uint64)
+            abund, offset = np.ascontiguousarray(abund[order]), np.ascontiguousarray(offset[order])
+        keep8 = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+        case32 = None if case_abund is None else np.ascontiguousarray(case_abund, dtype=np.int32)
         sfx_blob = sfx_offs = None
         if suffixes is not None:
             sfx_blob = ''.join(suffixes).encode('latin-1')

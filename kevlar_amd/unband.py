@@ -59,7 +59,50 @@ def unband(recordstream, numbatches=16):
         kevlar_amd.plog('[kevlar::unband] Done!')
 
 
+def unband_files(filenames, numbatches=16):
+    """unband() for files, on arrays: the band files are parsed natively and concatenated; copies of a read are found by
+    name, their annotations gathered (copy after copy, then by offset, as unband() orders them), and the records leave
+    in unband()'s order -- shard by shard (same checksum of the name), names sorted inside a shard -- rendered natively
+    in one piece.  Returns the text (bytes)."""
+    import numpy as np
+    from kevlar_amd.annotated import AnnotatedReads
+    kevlar_amd.plog('[kevlar::unband]', 'writing records to {:d} temp batch files'.format(numbatches))
+    progress = kevlar_amd.ProgressIndicator('[kevlar::unband]     processed {counter} reads', interval=1e5, breaks=[1e6, 1e7])
+    everything = AnnotatedReads.concat(AnnotatedReads.from_file(path) for path in filenames)
+    progress.update(everything.n)
+    blob, offs = everything.names.decode('latin-1'), everything.name_offs.tolist()
+    copies = {}                                  # name -> indices of its records, in stream order
+    for i in range(everything.n):
+        copies.setdefault(blob[offs[i]:offs[i + 1]], []).append(i)
+    kevlar_amd.plog('[kevlar::unband]', 'resolving duplicate reads in {:d} batches'.format(numbatches))
+    shards = [[] for _ in range(numbatches)]
+    for name in copies:
+        shards[zlib.crc32(name.encode()) % numbatches].append(name)
+    out_reads, lo, hi, order = [], [], [], []
+    first = everything.first
+    for index, names in enumerate(shards):
+        for name in sorted(names):
+            records = copies[name]
+            out_reads.append(records[0])
+            lo.append(len(order))
+            for r in records:
+                order.extend(range(int(first[r]), int(first[r + 1])))
+            hi.append(len(order))
+        kevlar_amd.plog('[kevlar::unband]     batch {:d} complete'.format(index))
+    kevlar_amd.plog('[kevlar::unband] Done!')
+    return everything.format(out_reads, regrouped=(lo, hi, np.asarray(order, dtype=np.int64)))
+
+
 def main(args):
     sink = kevlar_amd.open(args.out, 'w')
-    for read in unband(kevlar_amd.seqio.afxstream(args.infile), args.n_batches):
-        sink.write(format_augmented_fastx(read))
+    if all(isinstance(path, str) and path != '-' for path in args.infile):
+        text = unband_files(args.infile, args.n_batches)
+        try:
+            sink.write(text)
+        except TypeError:
+            sink.write(text.decode('latin-1'))
+    else:
+        for read in unband(kevlar_amd.seqio.afxstream(args.infile), args.n_batches):
+            sink.write(format_augmented_fastx(read))
+    if args.out not in ('-', None):
+        sink.close()

@@ -121,3 +121,27 @@ def test_split_file_equals_split_of_records(tmp_path):
     kevlar_amd.split.split(kevlar_amd.parse_partitioned_reads(parse_augmented_fastx(kevlar_amd.open(plain, 'r'))), one)
     kevlar_amd.split.split_file(plain, other)
     assert [s.getvalue().encode('ascii') for s in one] == [s.getvalue() for s in other]
+
+
+def test_unband_files_equals_unband_of_records(tmp_path):
+    """kevlar unband on arrays writes byte for byte what the record-stream unband writes: a banded novel output cut into
+    band files (each copy of a read holding part of its annotations) folds back into the same text"""
+    from kevlar_amd.sequence import Record
+    src = python_records(os.path.join(DATA, 'fiveparts.augfastq.gz'))[:60] + python_records(os.path.join(DATA, 'seqs-mates.augfastq'))
+    ksizes = [k.ksize for r in src for k in r.annotations]
+    common = max(set(ksizes), key=ksizes.count)
+    src = [r for r in src if all(k.ksize == common for k in r.annotations)]
+    bands = [[], [], []]
+    for i, rec in enumerate(src):
+        for b in range(3):
+            notes = [k for j, k in enumerate(rec.annotations) if (j + i) % 3 == b]
+            if notes or b == i % 3:
+                bands[b].append(Record(rec.name, rec.sequence, rec.quality, annotations=list(reversed(notes)), mates=list(rec.mates) if b == i % 3 else []))
+    paths = []
+    for b, records in enumerate(bands):
+        paths.append(str(tmp_path / 'band{}.augfastq'.format(b)))
+        with open(paths[-1], 'w') as fh:
+            fh.write(''.join(format_augmented_fastx(r) for r in records))
+    want = ''.join(format_augmented_fastx(r) for r in kevlar_amd.unband.unband(kevlar_amd.seqio.afxstream(paths), 4)).encode('latin-1')
+    got = kevlar_amd.unband.unband_files(paths, 4)
+    assert got == want and len(got) > 5000
