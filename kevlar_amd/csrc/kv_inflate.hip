@@ -7,7 +7,7 @@
 // from header to header (kv_bgzf_index); the compressed bytes go to HBM as they are (a quarter of the text crosses
 // PCIe), and one wavefront inflates one member:
 //
-//   * the last 4 KB of the member's text stay in LDS, so the near LZ77 matches (the previous record's header, the '+' line)
+//   * the last 1 KB of the member's text stays in LDS, so the near LZ77 matches (the previous record's header, the '+' line)
 //     are LDS copies; the ones that reach further back read the text the wave itself wrote to HBM;
 //   * the Huffman codes are walked one after the other (a serial job by nature) through 10-bit / 8-bit lookup tables in
 //     LDS, longer codes through the canonical count/symbol arrays; the walk is wave-uniform, so its arithmetic runs on the
@@ -17,7 +17,7 @@
 //   * text leaves for HBM in rows of up to 64 bytes as it is produced.
 //
 // Decoding one member is a chain of dependent lookups (a few hundred cycles per symbol whatever the code does), so the rate
-// comes from members in flight: 16 workgroups per CU, ~4000 members on the device.  The CRC-32 of a member is not checked
+// comes from members in flight: 32 workgroups per CU (8 waves per SIMD), ~8000 members on the device.  The CRC-32 of a member is not checked
 // (its ISIZE is); tests compare the output with zlib's byte for byte.  Reference: the reader this replaces is
 // khmer.ReadParser's gzip stream (kevlar/__init__.py:125-128 opens every *.gz through it).
 #include <algorithm>
@@ -160,7 +160,7 @@ struct InflateShared {
 };
 
 template <int RBITS>
-__global__ __launch_bounds__(64, (RBITS <= 11 ? 5 : RBITS == 12 ? 4 : RBITS == 13 ? 3 : RBITS == 14 ? 2 : 1)) void k_inflate(const uint8_t *__restrict__ comp, const InflateJob *__restrict__ jobs, uint32_t n_jobs,
+__global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 5 : RBITS == 12 ? 4 : RBITS == 13 ? 3 : RBITS == 14 ? 2 : 1)) void k_inflate(const uint8_t *__restrict__ comp, const InflateJob *__restrict__ jobs, uint32_t n_jobs,
                                                  uint8_t *text, unsigned long long *ctr)
 {
     __shared__ InflateShared<RBITS> sh;
@@ -382,20 +382,22 @@ int kv_bgzf_inflate(const uint8_t *d_comp, uint64_t comp_base, const KvBgzfMembe
     KV_HIP(hipMemcpyAsync(d_ctr, init, sizeof(init), hipMemcpyHostToDevice, st));
     {
         KvProfScope prof("k_inflate");
-        // the LDS window sets how many members a CU holds: 4 KB -> 16 workgroups; matches that reach further back (up to
-        // 32 KB) read the text from HBM.  Measured on 846 MB of FASTQ text (4 M reads, bgzip level 4), k_inflate alone:
-        // 2 KB 42.4 ms, 4 KB 45.9 ms, 8 KB 52.1 ms, 16 KB ~78 ms, 32 KB (no HBM reads at all) ~100 ms.
-        // KV_INFLATE_WINDOW_BITS = 11 .. 15 for experiments.
+        // the LDS window sets how many members a CU holds: 1 KB -> 32 workgroups = 8 waves per SIMD, the most the hardware
+        // takes (the kernel is then held to 64 VGPRs; what spills is the table construction, not the symbol loop); matches
+        // that reach further back (up to 32 KB) read the text from HBM.  Measured on 846 MB of FASTQ text (4 M reads, bgzip
+        // level 4), k_inflate alone, one box: 1 KB 27.2 ms, 2 KB 31.4 ms, 4 KB 35.5 ms; on another box 2 KB 42.4, 4 KB 45.9,
+        // 8 KB 52.1, 16 KB ~78, 32 KB (no HBM reads at all) ~100 ms.  KV_INFLATE_WINDOW_BITS = 10 .. 15 for experiments.
         const char *wb = getenv("KV_INFLATE_WINDOW_BITS");
-        const int bits = wb ? atoi(wb) : 12;
-        const int per_cu = bits >= 15 ? 4 : bits == 14 ? 8 : bits == 13 ? 12 : bits == 12 ? 16 : 20;
+        const int bits = wb ? atoi(wb) : 10;
+        const int per_cu = bits >= 15 ? 4 : bits == 14 ? 8 : bits == 13 ? 12 : bits == 12 ? 16 : bits == 11 ? 20 : 32;
         const unsigned grid = (unsigned)std::min<uint64_t>(count, (uint64_t)per_cu * (uint64_t)kv_device_cus());
 #define KV_LAUNCH_INFLATE(B_) hipLaunchKernelGGL(k_inflate<B_>, dim3(grid), dim3(64), 0, st, d_comp, (const InflateJob *)d_jobs, (uint32_t)count, d_text, d_ctr)
         if (bits >= 15) KV_LAUNCH_INFLATE(15);
         else if (bits == 14) KV_LAUNCH_INFLATE(14);
         else if (bits == 13) KV_LAUNCH_INFLATE(13);
         else if (bits == 12) KV_LAUNCH_INFLATE(12);
-        else KV_LAUNCH_INFLATE(11);
+        else if (bits == 11) KV_LAUNCH_INFLATE(11);
+        else KV_LAUNCH_INFLATE(10);
 #undef KV_LAUNCH_INFLATE
     }
     KV_HIP(hipGetLastError());
