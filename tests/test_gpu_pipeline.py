@@ -3,6 +3,7 @@ reference's own drivers (tests/golden/make_golden.py) and vs the oracle."""
 import contextlib
 import io
 import json
+import os
 import re
 
 import numpy as np
@@ -463,3 +464,14 @@ def test_hash_positions_equals_hashing_the_kmer_text(hk):
         assert sketch.hash_positions(batch, reads, offs).tolist() == sketch.hash_kmers(kmers).tolist()
     with pytest.raises(Exception, match='does not lie inside its read'):
         hk.Counttable(31, 1e4, 2).hash_positions(batch, [1], [5])
+
+
+def test_randomised_parity_against_the_oracle(hk):
+    """scratch/fuzz_parity.py, a short fixed-seed run: random sketch kinds, k, read shapes, bands, count and scan paths;
+    tables byte for byte and hits identical to the oracle"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    done = subprocess.run([sys.executable, os.path.join(root, 'scratch', 'fuzz_parity.py'), '24', '5'], cwd=root, capture_output=True, text=True, timeout=900)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-2000:]
+    assert '24 trials, 0 failures' in done.stdout
