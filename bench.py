@@ -10,7 +10,7 @@ scan of the proband against its controls (kv_novel_scan).
     cfg2        25 Mb trio, 30x, k=31, 2 GB sketch per sample  (the configuration the metric is quoted on; default)
     cfg5        proband + 3 controls, k=51, 30x, 25 Mb          (multi-control test, 128-bit keys / three murmur blocks)
     cfg1        50 kb trio, 10x, k=31, 1 MB sketch              (the reference's own CPU-runnable case: plumbing)
-    cfg4-proxy  250 Mb trio, 30x, k=31, 8 GB sketch per sample, reads in batches of 7.5 M: one band's share of
+    cfg4-proxy  250 Mb trio, 30x, k=31, 8 GB sketch per sample, reads in batches of 18.75 M: one band's share of
                 config 4 (3 Gb, 8 bands) on one GPU -- proves the batching and the HBM budget, not the 8-GPU run
 N > 1 : configs[2]: the same trio, kevlar's k-mer banding with band b on GPU b (1/N of the hash space and of
         the table memory per GPU).  Total work is fixed -> "scaling": "strong".
@@ -50,9 +50,9 @@ WORKLOADS = {
                  label='BASELINE.json configs[4]: proband + 3 controls, k=51, 30x, 25 Mb'),
     'cfg1': dict(genome_mb=0.05, coverage=10.0, ksize=31, memory=1e6, controls=2, batch_reads=0,
                  label='BASELINE.json configs[0]: 50 kb trio, 10x, k=31 (reference CPU plumbing case)'),
-    'cfg4-proxy': dict(genome_mb=250.0, coverage=30.0, ksize=31, memory=8e9, controls=2, batch_reads=7_500_000,
+    'cfg4-proxy': dict(genome_mb=250.0, coverage=30.0, ksize=31, memory=8e9, controls=2, batch_reads=18_750_000,
                        label='one band\'s share of BASELINE.json configs[3] on one GPU: 250 Mb trio, 30x, k=31, 8 GB sketch '
-                             'per sample, reads streamed in batches of 7.5 M'),
+                             'per sample, reads streamed in batches of 18.75 M (four per sample)'),
 }
 
 
@@ -62,6 +62,7 @@ def parse_args():
     p.add_argument('--steps', type=int, default=3)
     p.add_argument('--warmup', type=int, default=1)
     p.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+    p.add_argument('--batch-reads', type=int, default=None, help='reads per batch (default: the workload\'s; 0 = whole samples)')
     p.add_argument('--genome-mb', type=float, default=None)
     p.add_argument('--coverage', type=float, default=None)
     p.add_argument('--read-len', type=int, default=100)
@@ -111,7 +112,7 @@ def hits_checksum(r, o, a):
 def main():
     args = parse_args()
     wl = dict(WORKLOADS[args.workload])
-    for key in ('genome_mb', 'coverage', 'ksize', 'memory'):
+    for key in ('genome_mb', 'coverage', 'ksize', 'memory', 'batch_reads'):
         if getattr(args, key) is not None:
             wl[key] = getattr(args, key)
     rank = int(os.environ.get('RANK', '0'))

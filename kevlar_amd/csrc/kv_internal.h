@@ -50,6 +50,7 @@ struct kv_sketch {
     uint64_t version = 0;  // bumped by everything that changes a table (invalidates cached scan verdicts)
     uint64_t *d_counters; // [0] n_kmers, [1] n_unique (device accumulators)
     bool skm_off = false;  // the last batch counted through the super-k-mer front end did not deduplicate: skip it until cleared
+    double skm_distinct = 0.0;   // distinct / all k-mers of that batch (0: none yet): sizes the buckets of the next one
     // kv_sketch_clear only notes that the tables are zero: the partitioned count's apply stage, which rewrites every
     // slice anyway, then starts from zeroed LDS instead of loading the slice (no memset, no first read of the tables);
     // every other reader or writer of the tables calls kv_sketch_ready first, which does the memset after all

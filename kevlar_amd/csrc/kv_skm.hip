@@ -114,7 +114,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
     uint32_t *wl = smem;                                              // the tile's packed words
     uint32_t *mh = smem + nwl;                                        // order value of the m-mer starting at every base
     uint16_t *ids = (uint16_t *)(mh + sg.np_max + 96u);               // bucket of the k-mer starting at every base: coarse << 8 | (fine & 255) ...
-    uint32_t *idhi = (uint32_t *)(ids + ((sg.np_max + 96u + 1u) & ~1u)); // ... and bit 8 of fine (up to 512 fine buckets), one bit per base
+    uint32_t *idhi = (uint32_t *)(ids + ((sg.np_max + 96u + 1u) & ~1u)); // ... and bits 8..11 of fine (up to 4096 fine buckets), a nibble per base
     uint32_t *starts = mh;                                            // run starts: reuses mh once the minima are taken
     const int k = sg.k, m = sg.m, w = sg.w;
     const int lane = threadIdx.x & 63;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
             }
         }
         if (threadIdx.x < 96) mh[NB + threadIdx.x] = 0xffffffffu;
-        for (uint32_t i = threadIdx.x; i < (NB >> 5) + 2u; i += SKM_THREADS1) idhi[i] = 0;
+        for (uint32_t i = threadIdx.x; i < (NB >> 3) + 4u; i += SKM_THREADS1) idhi[i] = 0;
         __syncthreads();
         // P2: one thread per chunk of CH k-mer starts: the minimum over the w m-mers of each (shared suffix of the
         // chunk + the w - 1 - CH values every window contains + a growing prefix), its bucket, and where runs start
@@ -217,25 +217,28 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
                 for (uint32_t t = CH; t + 2 <= (uint32_t)w; ++t) mid = min(mid, mh[q + t]);     // mh[q + CH .. q + w - 2]
                 uint32_t coarse, fine;
                 skm_bucket_of(min(suf[0], mid), sg.C1, sg.fbits, coarse, fine);
-                uint32_t prev = (coarse << 9) | fine;     // bucket of the k-mer in front of the chunk (unused when j == 0)
-                uint32_t himask = 0;
+                uint32_t prev = (coarse << 12) | fine;    // bucket of the k-mer in front of the chunk (unused when j == 0)
+                uint64_t himask = 0;                      // CH <= 16 nibbles
                 run = 0xffffffffu;
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
                     run = min(run, mh[q + (uint32_t)w - 1u + i]);
                     skm_bucket_of(min(min(suf[i + 1], mid), run), sg.C1, sg.fbits, coarse, fine);
-                    const uint32_t id = (coarse << 9) | fine;
+                    const uint32_t id = (coarse << 12) | fine;
                     if (j + (uint32_t)i < nkr) {
                         ids[q + i] = (uint16_t)((coarse << 8) | (fine & 0xffu));
-                        himask |= (fine >> 8) << i;
+                        himask |= (uint64_t)(fine >> 8) << (4 * i);
                         if (j + (uint32_t)i == 0 || id != prev) startmask |= 1u << i;
                     }
                     prev = id;
                 }
-                if (himask) {                             // CH <= 16 bits starting at bit q: at most two words
-                    const uint64_t bits = (uint64_t)himask << (q & 31u);
-                    atomicOr(&idhi[q >> 5], (uint32_t)bits);
-                    if (bits >> 32) atomicOr(&idhi[(q >> 5) + 1u], (uint32_t)(bits >> 32));
+                if (himask) {                             // CH <= 16 nibbles starting at nibble q: at most three words
+                    const uint32_t sh4 = 4u * (q & 7u);
+                    const uint32_t w0 = (uint32_t)(himask << sh4), w1 = (uint32_t)((himask << sh4) >> 32);
+                    const uint32_t w2 = sh4 ? (uint32_t)(himask >> (64u - sh4)) : 0u;
+                    if (w0) atomicOr(&idhi[q >> 3], w0);
+                    if (w1) atomicOr(&idhi[(q >> 3) + 1u], w1);
+                    if (w2) atomicOr(&idhi[(q >> 3) + 2u], w2);
                 }
             }
             my_q[round] = q; my_starts[round] = startmask;
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
             const uint32_t limit = q - j + sh.nk[r];          // flat position one past the read's last k-mer
             const uint32_t nxt = i + 1 < nstart ? starts[i + 1] : limit;       // the next run (of this read or a later one)
             uint32_t left = (nxt < limit ? nxt : limit) - q;
-            const uint32_t coarse = id >> 8, fine = (id & 0xffu) | (((idhi[q >> 5] >> (q & 31u)) & 1u) << 8);
+            const uint32_t coarse = id >> 8, fine = (id & 0xffu) | (((idhi[q >> 3] >> (4u * (q & 7u))) & 15u) << 8);
             uint64_t pos = (uint64_t)(sh.read0 + r) * sg.stride + sh.seg_start + j;
             uint32_t b = sh.wpre[r] * 16u + j;                // base index inside wl
             while (left) {
@@ -306,9 +309,10 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
 
 // ---- S2 ------------------------------------------------------------------------------------------------
 #define SKM_THREADS2 512
+#define SKM_MAX_F2 4096u          // fine buckets per coarse bucket (12 bits of a k-mer's bucket id in S1; 16 in a record header)
 __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split(SkmGeom sg)
 {
-    __shared__ uint32_t cur[512];
+    __shared__ uint32_t cur[SKM_MAX_F2];
     __shared__ uint32_t spre[769];                    // record prefix over the coarse segments this workgroup drains
     const uint32_t c = blockIdx.y;
     for (uint32_t f = threadIdx.x; f < sg.F2; f += SKM_THREADS2) cur[f] = 0;
@@ -951,6 +955,8 @@ struct SkmIndex {
 };
 std::map<hipStream_t, SkmIndex> g_skm;
 std::mutex g_skm_mu;
+double g_skm_last_distinct = 0.0;        // distinct share of the batch counted last on any stream (guarded by g_skm_mu): a scan
+                                          // that has to bucket its batch itself sizes the buckets by it
 
 SkmIndex &skm_index_for(hipStream_t st)
 {
@@ -985,19 +991,20 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.ncap = 32 * g.nbw - k + 1;
     const uint32_t table_slots = g.kw == 1 ? 4096u : 2048u;
     const char *tgt_env = getenv("KV_SKM_BUCKET_KMERS");      // tests shrink the buckets to exercise many of them on small inputs
-    // k-mers per fine bucket: 2 x slots for one-word keys (a bucket then holds ~0.4 x slots distinct k-mers at 30x);
-    // 1.5 x for two-word keys, whose longer windows put fewer, bigger minimizer loci into a bucket (more variance)
-    uint64_t target = tgt_env ? std::max<uint64_t>(64, strtoull(tgt_env, nullptr, 10))
-                              : (g.kw == 1 ? 2ull * table_slots : table_slots + table_slots / 2);
-    // a shard of a sample (multi-GPU) has less coverage, so more of its k-mers are distinct: smaller buckets keep the
-    // same ~0.6 (0.45 for two-word keys) slots-worth of distinct k-mers in a table
-    if (!tgt_env && distinct_frac > 0.3)
-        target = std::max<uint64_t>(table_slots / 2, (uint64_t)((g.kw == 1 ? 0.6 : 0.45) * table_slots / std::min(1.0, distinct_frac)));
+    // k-mers per fine bucket: as many as leave the LDS table ~0.4 full (0.35 for two-word keys, whose longer windows put
+    // fewer, bigger minimizer loci into a bucket: more variance) given the share of distinct k-mers the previous batch
+    // into the same sketch -- or routed on the same stream -- showed; without one, a whole 30x sample is assumed
+    // (~0.2 distinct).  Fuller tables overflow in the larger buckets: 34 % distinct k-mers in 8192-k-mer buckets (a
+    // quarter of a 30x sample per batch) put 2.1 % of the occurrences on the slow path.
+    const double frac = std::min(1.0, std::max(0.05, distinct_frac > 0.0 ? distinct_frac : 0.2));
+    uint64_t target = (uint64_t)((g.kw == 1 ? 0.4 : 0.35) * table_slots / frac);
+    target = std::max<uint64_t>(table_slots / 2, std::min<uint64_t>(target, g.kw == 1 ? 2ull * table_slots : table_slots + table_slots / 2));
+    if (tgt_env) target = std::max<uint64_t>(64, strtoull(tgt_env, nullptr, 10));
     const uint64_t nfine = std::max<uint64_t>(1, (n_kmers + target - 1) / target);
-    // at most 255 x 512 buckets (a bucket id travels as 17 bits through S1); bigger batches get bigger buckets, which
-    // only costs deduplication efficiency
+    // at most 255 x 4096 buckets (a bucket id travels as 20 bits through S1): 8.5 G k-mers at 8192 per bucket; bigger
+    // batches get bigger buckets, which only costs deduplication efficiency
     g.F2 = std::min<uint32_t>(512u, pow2_ceil((uint64_t)std::ceil(std::sqrt((double)nfine))));
-    if (nfine > 255ull * g.F2) g.F2 = std::min<uint32_t>(512u, pow2_ceil((nfine + 254) / 255));
+    if (nfine > 255ull * g.F2) g.F2 = std::min<uint32_t>(SKM_MAX_F2, pow2_ceil((nfine + 254) / 255));
     g.fbits = 0;
     while ((1u << g.fbits) < g.F2) ++g.fbits;
     g.C1 = (uint32_t)std::min<uint64_t>(255, std::max<uint64_t>(1, (nfine + g.F2 - 1) / g.F2));
@@ -1048,7 +1055,7 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     {
         KvProfScope prof("k_skm_emit");
         const size_t lds = ((size_t)g.np_max / 16 + KV_TILE_MAX_READS + 8 + (size_t)g.np_max + 96) * 4 + (((size_t)g.np_max + 96 + 1) & ~(size_t)1) * 2 +
-                           ((size_t)g.np_max / 32 + 4) * 4;
+                           ((size_t)g.np_max / 8 + 8) * 4;
         if (g.w > 16) {
             kv_ensure_dynamic_lds((const void *)k_skm_emit<16>, lds);
             hipLaunchKernelGGL(k_skm_emit<16>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), reads->n_tiles, g);
@@ -1109,11 +1116,15 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     SkmIndex &idx = skm_index_for(st);
     std::lock_guard<std::mutex> lk(idx.mu);
     const int k = s->h.ksize;
-    { const int rc = skm_build(idx, reads, k, n_kmers, st); if (rc != KV_OK) return rc; }
+    { const int rc = skm_build(idx, reads, k, n_kmers, st, s->skm_distinct); if (rc != KV_OK) return rc; }
     SkmGeom &sg = idx.g;
     const uint32_t nwg3 = skm_nwg3(sg);
     BinPlan plan;
-    { const int rc = kv_bin_plan(s, n_kmers, nbands, filter.use_mask != 0, sg.n_buckets, 0u, nwg3, true, &plan); if (rc != KV_OK) return rc; }
+    // the bin stages receive one item per DISTINCT k-mer and table: their buffers are sized for 60 % of the k-mers being
+    // distinct (sequencing coverage leaves 20-35 %); a batch with more spills over, raises the flag, and is redone by
+    // the one-item-per-k-mer partition -- which is where a batch that does not deduplicate belongs anyway
+    const uint64_t n_items = std::max<uint64_t>(n_kmers * 3 / 5, std::min<uint64_t>(n_kmers, 1u << 22));
+    { const int rc = kv_bin_plan(s, n_items, nbands, filter.use_mask != 0, sg.n_buckets, 0u, nwg3, true, &plan); if (rc != KV_OK) return rc; }
     const SketchDev *d_mask = mask ? mask->d_desc : nullptr;
     {
         KvProfScope prof("k_skm_count");
@@ -1141,6 +1152,8 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
             const double alone = (double)(sc[0] > sc[6] ? sc[0] - sc[6] : 0) / (double)n_kmers;
             const double distinct = (double)sc[7] / (double)n_kmers + alone;
             s->skm_off = rc != KV_OK || alone > 0.03 || distinct > 0.45;
+            s->skm_distinct = distinct;
+            { std::lock_guard<std::mutex> glk(g_skm_mu); g_skm_last_distinct = distinct; }
             if (getenv("KV_SKM_VERBOSE"))
                 fprintf(stderr, "[kv_skm] batch of %llu k-mers: %.1f%% distinct, %.2f%% outside the LDS tables, %llu of %llu records outside their segments%s\n",
                         (unsigned long long)n_kmers, 100 * distinct, 100 * alone, sc[6], sc[5], s->skm_off ? " -> next batches take the plain partition" : "");
@@ -1174,7 +1187,12 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
     }
     std::lock_guard<std::mutex> lk(idx->mu);
     const bool reuse = idx->valid && idx->reads_uid == reads->uid && idx->k == k && !getenv("KV_SKM_NO_REUSE");
-    if (!reuse) { const int rc = skm_build(*idx, reads, k, n_kmers, st); if (rc != KV_OK) return rc; }
+    if (!reuse) {
+        double hint;
+        { std::lock_guard<std::mutex> glk(g_skm_mu); hint = g_skm_last_distinct; }
+        const int rc = skm_build(*idx, reads, k, n_kmers, st, hint);
+        if (rc != KV_OK) return rc;
+    }
     SkmGeom &sg = idx->g;
     if (reuse) {
         // records that did not fit their S1/S2 segment are the first ctr[6] entries of the loose list; the entries the
