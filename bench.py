@@ -288,6 +288,8 @@ def main():
     assert nhits > 0, 'the synthetic family must yield interesting k-mers'
     assert (a[:, 0] >= args.case_min).all() and (a[:, 1:] <= args.ctrl_max).all()
     selfcheck = {'hits_checksum': hits_checksum(r, o, a)}
+    if os.environ.get('BENCH_DUMP_HITS') and rank == 0:
+        np.savez_compressed(os.path.join(os.environ['BENCH_DUMP_HITS'], 'step_world{}.npz'.format(world)), r=np.asarray(r), o=np.asarray(o), a=np.asarray(a))
     if world == 1:
         assert kmers == S * n_reads * nk
     else:
@@ -321,6 +323,9 @@ def main():
         rr = np.concatenate([p[0] for p in parts]); oo = np.concatenate([p[1] for p in parts])
         aa = np.concatenate([p[2] for p in parts]) if parts else np.zeros((0, S), dtype=np.uint8)
         order = np.lexsort((oo, rr))
+        if os.environ.get('BENCH_DUMP_HITS'):          # debugging aid: the arrays behind a checksum
+            np.savez_compressed(os.path.join(os.environ['BENCH_DUMP_HITS'], 'replay_{}_of_{}.npz'.format(nbands, world)),
+                                r=rr[order], o=oo[order], a=aa[order])
         return hits_checksum(rr[order], oo[order], aa[order])
 
     if not args.no_replay and args.workload in ('cfg2', 'cfg1', 'cfg5'):
@@ -330,7 +335,8 @@ def main():
         elif rank == 0:
             selfcheck['replay_checksum'] = replay_bands(world)
             selfcheck['replay_matches'] = selfcheck['replay_checksum'] == selfcheck['hits_checksum']
-            assert selfcheck['replay_matches'], 'merged multi-GPU hits differ from the band-by-band replay on one GPU'
+            assert selfcheck['replay_matches'], 'merged multi-GPU hits {} differ from the band-by-band replay on one GPU {}'.format(
+                selfcheck['hits_checksum'], selfcheck['replay_checksum'])
         wall.update(saved_wall)
 
     ms_step = elapsed / args.steps * 1e3

@@ -821,8 +821,9 @@ def _hits_arrays(hits, S):
     def view(ptr, shape, dtype):
         if int(np.prod(shape)) == 0:
             return np.empty(shape, dtype=dtype)
-        arr = np.ctypeslib.as_array(ptr, shape=shape)
-        return _Owned(arr, holder)
+        # the array's memory belongs to the kv_hits handle (pinned, recycled when the handle goes): numpy keeps the
+        # object that exposes the memory alive for every view derived from it, np.asarray() included
+        return np.asarray(_HitsMemory(ctypes.addressof(ptr.contents), shape, dtype, holder))
     reads = view(pr, (n.value,), np.uint32)
     offs = view(po, (n.value,), np.uint32)
     abund = view(pa, (n.value, S), np.uint8)
@@ -921,6 +922,15 @@ class _HitsHandle(object):
                 _lib.load().kv_hits_destroy(h)
             except Exception:
                 pass
+
+
+class _HitsMemory(object):
+    """a block of a kv_hits handle's pinned memory, exposed through the array interface together with its owner"""
+
+    def __init__(self, address, shape, dtype, owner):
+        self._owner = owner
+        self.__array_interface__ = {'data': (int(address), False), 'shape': tuple(int(d) for d in shape),
+                                    'typestr': np.dtype(dtype).str, 'version': 3}
 
 
 class _Owned(np.ndarray):

@@ -475,3 +475,27 @@ def test_randomised_parity_against_the_oracle(hk):
     done = subprocess.run([sys.executable, os.path.join(root, 'scratch', 'fuzz_parity.py'), '24', '5'], cwd=root, capture_output=True, text=True, timeout=900)
     assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-2000:]
     assert '24 trials, 0 failures' in done.stdout
+
+
+def test_hit_arrays_outlive_their_handle(hk):
+    """the hit arrays are views into pinned memory that is recycled when the kv_hits handle goes: every view derived
+    from them -- np.asarray() included -- must keep the handle alive (bench.py's band replay once read recycled memory)"""
+    import gc
+    from kevlar_amd import synth
+    trio = synth.make_trio(150000, 5)
+    reads = {n: synth.unpack_reads(synth.sample_reads_packed(trio[n], 40000, 100, 0.005, 9 + i), 100)
+             for i, n in enumerate(('proband', 'mother', 'father'))}
+    sk = {n: hk.Counttable(31, 1.5e6, 4) for n in reads}
+    for n in reads:
+        sk[n].consume_batch(hk.ReadBatch(reads[n]))
+    batch = hk.ReadBatch(reads['proband'])
+    r, o, a, _ = hk.novel_scan([sk['proband']], [sk['mother'], sk['father']], batch, 6, 1)
+    keep = (np.array(r), np.array(o), np.array(a))                  # real copies
+    views = (np.asarray(r), np.asarray(o)[::1], np.asarray(a).reshape(-1, 3))
+    del r, o, a
+    gc.collect()
+    for _ in range(6):                                               # later scans take blocks from the same pool
+        hk.novel_scan([sk['proband']], [sk['mother'], sk['father']], batch, 1 + _, 2)
+    assert len(keep[0]) > 100
+    for got, want in zip(views, keep):
+        assert np.array_equal(got, want)
