@@ -82,7 +82,12 @@ class Recount(object):
 def _passes(readfile, mask, memory, maxfpr, casemin, ctrlmax, as_text):
     timer = kevlar_amd.Timer()
     timer.start()
-    stream = readfile if (isinstance(readfile, str) and readfile not in ('-',)) else kevlar_amd.parse_augmented_fastx(kevlar_amd.open(readfile, 'r'))
+    if isinstance(readfile, str) and readfile != '-':
+        stream = readfile                       # a file: parsed natively
+    elif isinstance(readfile, str) or readfile is None:
+        stream = kevlar_amd.parse_augmented_fastx(kevlar_amd.open(readfile, 'r'))      # standard input
+    else:
+        stream = readfile                       # records handed over by the caller
     work = Recount(stream, mask, memory)
 
     kevlar_amd.plog('[kevlar::filter] First pass: re-counting k-mers')
@@ -113,7 +118,8 @@ def _passes(readfile, mask, memory, maxfpr, casemin, ctrlmax, as_text):
 
 
 def filter(readfile, mask=None, memory=1e6, maxfpr=0.01, casemin=6, ctrlmax=1):
-    """Generator over the validated reads of the augmented FASTQ `readfile`."""
+    """Generator over the validated reads of the augmented FASTQ `readfile` (a file name as in the reference, '-', or an
+    iterable of records)."""
     yield from _passes(readfile, mask, memory, maxfpr, casemin, ctrlmax, as_text=False)
 
 
