@@ -68,6 +68,7 @@ def parse_partitioned_reads(readstream):
     reverse (a labelled stream that ends in unlabelled reads) is tolerated the way the reference tolerates it: the
     tail joins the last partition, which is then reported with id None."""
     held_id, held_reads, unlabelled = None, [], False
+    readstream = (read for read in readstream if read is not None)      # an empty augmented stream yields one None
     for label, run in groupby(readstream, key=_label_of):
         if label is None:
             held_reads.extend(run)
