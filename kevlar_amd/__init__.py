@@ -36,6 +36,42 @@ def open(filename, mode):
     return builtins.open(filename, mode)
 
 
+class _Sink(object):
+    """where a driver writes: takes bytes or str, whatever the stream underneath wants"""
+
+    def __init__(self, stream, binary, close):
+        self._stream, self._binary, self._close = stream, binary, close
+
+    def write(self, data):
+        if self._binary:
+            self._stream.write(data.encode('latin-1') if isinstance(data, str) else data)
+        else:
+            self._stream.write(data.decode('latin-1') if isinstance(data, (bytes, bytearray, memoryview)) else data)
+
+    def close(self):
+        if self._close:
+            self._stream.close()
+            self._close = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def open_sink(filename):
+    """Output of a driver: '-' / None = standard output, *.gz = blocked gzip, else a plain file; written as bytes, so text
+    rendered natively goes out without being decoded and encoded again."""
+    if filename in ['-', None]:
+        raw = getattr(sys.stdout, 'buffer', None)
+        return _Sink(raw if raw is not None else sys.stdout, raw is not None, False)
+    if filename.endswith('.gz'):
+        from kevlar_amd.bgzf import BgzfWriter
+        return _Sink(BgzfWriter(filename), True, True)
+    return _Sink(builtins.open(filename, 'wb'), True, True)
+
+
 def mkdirp(path, trim=False):
     outdir = dirname(path) if trim else path
     makedirs(outdir, exist_ok=True)

@@ -202,60 +202,63 @@ extern "C" int kv_format_records(uint64_t n_out, const uint64_t *rec_index, cons
 {
     KV_REQUIRE(text_out && bytes_out && (n_out == 0 || (rec_index && ann_lo && ann_hi && names && name_offs && seqs && seq_offs)), KV_ERR_ARG,
                "kv_format_records: null argument");
-    std::string out;
+    KvTextOut out;
+    {
+        uint64_t notes = 0;
+        for (uint64_t j = 0; j < n_out; ++j) notes += ann_hi[j] - ann_lo[j];
+        out.room((size_t)notes * (size_t)(ksize + 48) + (size_t)n_out * 320 + 4096);
+    }
     std::vector<uint64_t> order;
-    char num[16];
     for (uint64_t j = 0; j < n_out; ++j) {
         const uint64_t r = rec_index[j];
         const char *seq = seqs + seq_offs[r];
         const size_t seq_len = (size_t)(seq_offs[r + 1] - seq_offs[r]);
         const bool fq = is_fastq ? is_fastq[r] != 0 : false;
-        out.push_back(fq ? '@' : '>');
-        out.append(names + name_offs[r], (size_t)(name_offs[r + 1] - name_offs[r]));
-        if (suffix && suffix_offs) out.append(suffix + suffix_offs[j], (size_t)(suffix_offs[j + 1] - suffix_offs[j]));
-        out.push_back('\n');
-        out.append(seq, seq_len);
+        out.put(fq ? '@' : '>');
+        out.put(names + name_offs[r], (size_t)(name_offs[r + 1] - name_offs[r]));
+        if (suffix && suffix_offs) out.put(suffix + suffix_offs[j], (size_t)(suffix_offs[j + 1] - suffix_offs[j]));
+        out.put('\n');
+        out.put(seq, seq_len);
         if (fq) {
-            out.append("\n+\n");
-            out.append(quals + qual_offs[r], (size_t)(qual_offs[r + 1] - qual_offs[r]));
+            out.put("\n+\n", 3);
+            out.put(quals + qual_offs[r], (size_t)(qual_offs[r + 1] - qual_offs[r]));
         }
-        out.push_back('\n');
-        order.clear();
-        for (uint64_t i = ann_lo[j]; i < ann_hi[j]; ++i)
-            if (!keep || keep[i]) order.push_back(i);
+        out.put('\n');
+        // the kept annotations in offset order (stable); nearly always they already are
         bool sorted = true;
-        for (size_t q = 1; q < order.size(); ++q) sorted = sorted && ann_offset[order[q - 1]] <= ann_offset[order[q]];
-        if (!sorted) std::stable_sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return ann_offset[x] < ann_offset[y]; });
-        for (const uint64_t i : order) {
+        uint32_t last = 0;
+        for (uint64_t i = ann_lo[j]; i < ann_hi[j] && sorted; ++i)
+            if (!keep || keep[i]) { sorted = ann_offset[i] >= last; last = ann_offset[i]; }
+        auto line = [&](uint64_t i) {
             const uint32_t off = ann_offset[i];
-            KV_REQUIRE((size_t)off + (size_t)ksize <= seq_len, KV_ERR_ARG, "kv_format_records: an annotation at offset %u does not fit its read of %llu bases",
-                       off, (unsigned long long)seq_len);
-            out.append((size_t)off, ' ');
-            out.append(seq + off, (size_t)ksize);
-            out.append("          ");
-            for (int c = 0; c < nsamples; ++c) {
-                if (c) out.push_back(' ');
-                const int32_t v = (c == 0 && case_abund) ? case_abund[i] : ann_abund[i * (uint64_t)nsamples + c];
-                const int len = snprintf(num, sizeof(num), "%d", v);
-                out.append(num, (size_t)len);
-            }
-            out.append("#\n");
+            if ((size_t)off + (size_t)ksize > seq_len) { out.ok = false; return; }
+            const int32_t *row = ann_abund + i * (uint64_t)nsamples;
+            out.kmer_line(seq, off, ksize, nsamples, [&](int c) { return (int64_t)((c == 0 && case_abund) ? case_abund[i] : row[c]); });
+        };
+        if (sorted) {
+            for (uint64_t i = ann_lo[j]; i < ann_hi[j]; ++i)
+                if (!keep || keep[i]) line(i);
+        } else {
+            order.clear();
+            for (uint64_t i = ann_lo[j]; i < ann_hi[j]; ++i)
+                if (!keep || keep[i]) order.push_back(i);
+            std::stable_sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return ann_offset[x] < ann_offset[y]; });
+            for (const uint64_t i : order) line(i);
         }
+        KV_REQUIRE(out.ok, KV_ERR_ARG, "kv_format_records: an annotation does not fit its read (record %llu), or out of memory", (unsigned long long)r);
         if (n_mates) {
             const uint32_t *m = std::lower_bound(mate_record, mate_record + n_mates, (uint32_t)r);
             for (; m < mate_record + n_mates && *m == (uint32_t)r; ++m) {
                 const uint64_t mi = (uint64_t)(m - mate_record);
-                out.append("#mateseq=");
-                out.append(mates + mate_offs[mi], (size_t)(mate_offs[mi + 1] - mate_offs[mi]));
-                out.append("#\n");
+                out.put("#mateseq=", 9);
+                out.put(mates + mate_offs[mi], (size_t)(mate_offs[mi + 1] - mate_offs[mi]));
+                out.put("#\n", 2);
             }
         }
     }
-    char *buf = (char *)malloc(out.size() + 1);
-    KV_REQUIRE(buf, KV_ERR_HIP, "kv_format_records: out of memory");
-    memcpy(buf, out.data(), out.size());
-    buf[out.size()] = 0;
-    *text_out = buf;
-    *bytes_out = out.size();
+    KV_REQUIRE(out.ok, KV_ERR_HIP, "kv_format_records: out of memory");
+    *bytes_out = out.len;
+    *text_out = out.release();
+    KV_REQUIRE(*text_out, KV_ERR_HIP, "kv_format_records: out of memory");
     return KV_OK;
 }

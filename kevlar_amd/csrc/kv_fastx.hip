@@ -623,50 +623,36 @@ extern "C" int kv_format_augmented(const uint32_t *hit_read, const uint32_t *hit
     KV_REQUIRE(text_out && bytes_out && (n_hits == 0 || (hit_read && hit_off && abund && rec_index && names && name_offs && seqs && seq_offs)),
                KV_ERR_ARG, "kv_format_augmented: null argument");
     KV_REQUIRE(nsamples >= 1 && ksize >= 1, KV_ERR_ARG, "kv_format_augmented: bad argument");
-    std::string out;
-    out.reserve((size_t)n_hits * (size_t)(ksize + 64) + 1024);
+    KvTextOut out;
+    out.room((size_t)n_hits * (size_t)(ksize + 48) + 4096);
     uint64_t j = 0;         // distinct reads so far
-    char num[8];
     for (uint64_t i = 0; i < n_hits;) {
         const uint64_t r = rec_index[j++];
         const char *seq = seqs + seq_offs[r];
         const size_t seq_len = (size_t)(seq_offs[r + 1] - seq_offs[r]);
         const bool fq = is_fastq ? is_fastq[r] != 0 : false;
-        out.push_back(fq ? '@' : '>');
-        out.append(names + name_offs[r], (size_t)(name_offs[r + 1] - name_offs[r]));
-        out.push_back('\n');
-        out.append(seq, seq_len);
+        out.put(fq ? '@' : '>');
+        out.put(names + name_offs[r], (size_t)(name_offs[r + 1] - name_offs[r]));
+        out.put('\n');
+        out.put(seq, seq_len);
         if (fq) {
-            out.append("\n+\n");
-            out.append(quals + qual_offs[r], (size_t)(qual_offs[r + 1] - qual_offs[r]));
+            out.put("\n+\n", 3);
+            out.put(quals + qual_offs[r], (size_t)(qual_offs[r + 1] - qual_offs[r]));
         }
-        out.push_back('\n');
+        out.put('\n');
         const uint32_t read = hit_read[i];
         for (; i < n_hits && hit_read[i] == read; ++i) {
             const uint32_t off = hit_off[i];
             KV_REQUIRE((size_t)off + (size_t)ksize <= seq_len, KV_ERR_ARG, "kv_format_augmented: a hit at offset %u does not fit its read of %llu bases",
                        off, (unsigned long long)seq_len);
-            out.append((size_t)off, ' ');
-            out.append(seq + off, (size_t)ksize);
-            out.append("          ");
-            for (int c = 0; c < nsamples; ++c) {
-                if (c) out.push_back(' ');
-                const unsigned v = abund[i * (uint64_t)nsamples + c];
-                int len = 0;
-                if (v >= 100) num[len++] = (char)('0' + v / 100);
-                if (v >= 10) num[len++] = (char)('0' + (v / 10) % 10);
-                num[len++] = (char)('0' + v % 10);
-                out.append(num, (size_t)len);
-            }
-            out.append("#\n");
+            const uint8_t *row = abund + i * (uint64_t)nsamples;
+            out.kmer_line(seq, off, ksize, nsamples, [&](int c) { return (int64_t)row[c]; });
         }
     }
-    char *buf = (char *)malloc(out.size() + 1);
-    KV_REQUIRE(buf, KV_ERR_HIP, "kv_format_augmented: out of memory");
-    memcpy(buf, out.data(), out.size());
-    buf[out.size()] = 0;
-    *text_out = buf;
-    *bytes_out = out.size();
+    KV_REQUIRE(out.ok, KV_ERR_HIP, "kv_format_augmented: out of memory");
+    *bytes_out = out.len;
+    *text_out = out.release();
+    KV_REQUIRE(*text_out, KV_ERR_HIP, "kv_format_augmented: out of memory");
     if (n_records_out) *n_records_out = j;
     return KV_OK;
 }

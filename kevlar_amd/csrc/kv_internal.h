@@ -245,3 +245,47 @@ void kv_fastq_device_close(KvFastqDevice *d);
 int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_out, uint64_t *n_out);
 // raw text (four lines each) of records idx[0 .. n) of the batch last returned: record i at blob[offs[i] .. offs[i + 1])
 int kv_fastq_device_fetch(KvFastqDevice *d, const uint64_t *idx, uint64_t n, std::string *blob, std::vector<uint64_t> *offs);
+
+// growing text buffer of the native writers (kv_format_augmented, kv_format_records): malloc'ed, handed to the caller as it is
+struct KvTextOut {
+    char *buf = nullptr;
+    size_t len = 0, cap = 0;
+    bool ok = true;
+    ~KvTextOut() { free(buf); }
+    inline bool room(size_t n)
+    {
+        if (len + n <= cap) return true;
+        size_t want = cap ? cap : (1u << 16);
+        while (want < len + n) want += want / 2 + 4096;
+        char *grown = (char *)realloc(buf, want);
+        if (!grown) { ok = false; return false; }
+        buf = grown; cap = want;
+        return true;
+    }
+    inline void put(char c) { if (room(1)) buf[len++] = c; }
+    inline void put(const char *p, size_t n) { if (room(n)) { memcpy(buf + len, p, n); len += n; } }
+    inline void fill(char c, size_t n) { if (room(n)) { memset(buf + len, c, n); len += n; } }
+    inline void number(uint32_t v)
+    {
+        char tmp[12];
+        int n = 0;
+        do { tmp[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
+        if (room((size_t)n)) while (n) buf[len++] = tmp[--n];
+    }
+    // one annotation line: `off` blanks, the k-mer, ten blanks, the abundances, '#'
+    template <typename Abund>
+    inline void kmer_line(const char *seq, uint32_t off, int ksize, int nsamples, Abund abund_of)
+    {
+        if (!room((size_t)off + (size_t)ksize + 12 + 12u * (size_t)nsamples)) return;
+        memset(buf + len, ' ', off); len += off;
+        memcpy(buf + len, seq + off, (size_t)ksize); len += (size_t)ksize;
+        memset(buf + len, ' ', 10); len += 10;
+        for (int c = 0; c < nsamples; ++c) {
+            if (c) buf[len++] = ' ';
+            const int64_t v = abund_of(c);
+            if (v < 0) { buf[len++] = '-'; number((uint32_t)(-v)); } else number((uint32_t)v);
+        }
+        buf[len++] = '#'; buf[len++] = '\n';
+    }
+    char *release() { if (room(1)) buf[len] = 0; char *p = buf; buf = nullptr; cap = 0; return p; }
+};

@@ -124,12 +124,8 @@ def filter(readfile, mask=None, memory=1e6, maxfpr=0.01, casemin=6, ctrlmax=1):
 
 
 def main(args):
-    sink = kevlar_amd.open(args.out, 'w')
+    sink = kevlar_amd.open_sink(args.out)
     mask = kevlar_amd.sketch.load(args.mask) if args.mask else None
     for text in _passes(args.augfastq, mask, args.memory, args.max_fpr, args.case_min, args.ctrl_max, as_text=True):
-        try:
-            sink.write(text)
-        except TypeError:
-            sink.write(text.decode('latin-1'))
-    if args.out not in ('-', None):
-        sink.close()
+        sink.write(text)
+    sink.close()

@@ -232,16 +232,12 @@ def main(args):
 
     clock.start('iter')
     kevlar_amd.plog('[kevlar::novel]', 'Iterating over reads from {:d} case sample(s)'.format(len(args.case)))
-    sink = kevlar_amd.open(args.out, 'w')
+    sink = kevlar_amd.open_sink(args.out)
     case_reads = kevlar_amd.multi_file_iter_khmer([path for files in args.case for path in files])
     for blob in novel_text(case_reads, cases, controls, ksize=args.ksize, abundscreen=args.abund_screen, casemin=args.case_min,
                            ctrlmax=args.ctrl_max, numbands=args.num_bands, band=band, skipuntil=args.skip_until,
                            refbandquirk=getattr(args, 'ref_band_quirk', False)):
-        try:
-            sink.write(blob)
-        except TypeError:
-            sink.write(blob.decode('latin-1'))
-    if args.out not in ('-', None):
-        sink.close()
+        sink.write(blob)
+    sink.close()
     kevlar_amd.plog('[kevlar::novel]', 'Iterated over all case reads in {:.2f} seconds'.format(clock.stop('iter')))
     kevlar_amd.plog('[kevlar::novel]', 'Total time: {:.2f} seconds'.format(clock.stop()))

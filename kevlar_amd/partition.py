@@ -134,21 +134,17 @@ class _Outputs(object):
         self.prefix = prefix
         if prefix:
             kevlar_amd.mkdirp(prefix, trim=True)
-        self.shared = None if prefix else kevlar_amd.open(shared, 'w')
+        self.shared = None if prefix else kevlar_amd.open_sink(shared)
 
     def put(self, number, text):
         if self.shared is not None:
-            try:
-                self.shared.write(text)
-            except TypeError:          # a text-mode stream offered bytes, or the other way round
-                self.shared.write(text.decode('latin-1') if isinstance(text, bytes) else text.encode('latin-1'))
+            self.shared.write(text)
             return
-        with kevlar_amd.open('{:s}.cc{:d}.augfastq.gz'.format(self.prefix, number), 'w') as own:
+        with kevlar_amd.open_sink('{:s}.cc{:d}.augfastq.gz'.format(self.prefix, number)) as own:
             own.write(text)
 
     def close(self):
-        import sys
-        if self.shared is not None and self.shared not in (sys.stdout, sys.stdin):
+        if self.shared is not None:
             self.shared.close()
 
 
@@ -181,4 +177,5 @@ def main(args):
     for number, reads in labelled:
         sizes.append(len(reads))
         outputs.put(number, ''.join(map(format_augmented_fastx, reads)))
+    outputs.close()
     kevlar_amd.plog('[kevlar::partition]', 'grouped {:d} reads into {:d} connected components'.format(sum(sizes), len(sizes) - 1))

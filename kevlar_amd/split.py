@@ -70,7 +70,7 @@ def split_file(infile, outstreams, maxreads=10000):
 
 def main(args):
     suffix = '.augfastx.gz' if args.infile.endswith('.gz') else '.augfastx'
-    sinks = [kevlar_amd.open('{:s}.{:d}{:s}'.format(args.base, i, suffix), 'w') for i in range(args.numfiles)]
+    sinks = [kevlar_amd.open_sink('{:s}.{:d}{:s}'.format(args.base, i, suffix)) for i in range(args.numfiles)]
     try:
         if isinstance(args.infile, str) and args.infile != '-':
             split_file(args.infile, sinks)

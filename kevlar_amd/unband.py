@@ -94,15 +94,10 @@ def unband_files(filenames, numbatches=16):
 
 
 def main(args):
-    sink = kevlar_amd.open(args.out, 'w')
+    sink = kevlar_amd.open_sink(args.out)
     if all(isinstance(path, str) and path != '-' for path in args.infile):
-        text = unband_files(args.infile, args.n_batches)
-        try:
-            sink.write(text)
-        except TypeError:
-            sink.write(text.decode('latin-1'))
+        sink.write(unband_files(args.infile, args.n_batches))
     else:
         for read in unband(kevlar_amd.seqio.afxstream(args.infile), args.n_batches):
             sink.write(format_augmented_fastx(read))
-    if args.out not in ('-', None):
-        sink.close()
+    sink.close()
