@@ -755,6 +755,57 @@ int kv_reads_from_device_text(const uint8_t *d_text, const uint64_t *d_seq_start
 }
 
 namespace {
+// word offsets and tile table of a batch whose reads all have the same length: nothing per read crosses PCIe
+__global__ void k_uniform_layout(uint64_t *woff, TileDesc *tiles, uint64_t n_reads, uint64_t wpr, uint32_t per_tile, uint32_t n_tiles)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= n_reads; i += stride) woff[i] = i * wpr;
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < n_tiles; t += stride) {
+        const uint64_t first = t * per_tile;
+        tiles[t] = TileDesc{(uint32_t)first, (uint32_t)min((uint64_t)per_tile, n_reads - first), 0u, 0u};
+    }
+}
+
+// the same layout reads_from_packed builds read by read, in closed form; false if the batch is not uniform (or its reads
+// need segment tiles)
+bool uniform_reads(kv_reads *r, const TextSource *text, const uint32_t *lens, uint64_t n_reads, int *rc)
+{
+    if (!text || n_reads == 0) return false;
+    const uint32_t L = lens[0];
+    if (L == 0) return false;
+    for (uint64_t i = 1; i < n_reads; ++i)
+        if (lens[i] != L) return false;
+    const uint32_t budget = KV_TILE_LDS_BYTES - 64, need = 2 * ((L + KV_READ_PAD + 3) & ~3u);
+    if (need > budget) return false;
+    const uint32_t per_tile = std::min<uint32_t>(KV_TILE_MAX_READS, budget / need);
+    const uint64_t wpr = ((uint64_t)L + 15) / 16, nw = n_reads * wpr;
+    r->n_words = nw; r->n_bases = n_reads * (uint64_t)L; r->max_len = L;
+    r->tile_max_bases = (uint32_t)std::min<uint64_t>(per_tile, n_reads) * L;
+    r->n_tiles = (uint32_t)((n_reads + per_tile - 1) / per_tile);
+    r->tile_lds_bytes = KV_TILE_LDS_BYTES + 256;
+    const uint64_t flag_bytes = ((n_reads + 3) & ~3ull) + 4;
+    hipStream_t st = kv_stream();
+    hipError_t e = hipMalloc((void **)&r->d_words, (nw + 4) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, (n_reads + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, n_reads * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, flag_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, (size_t)r->n_tiles * sizeof(TileDesc));
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_words + nw, 0, 16, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->d_len, text->d_seq_len, n_reads * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_flags, 0, flag_bytes, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_uniform_layout, dim3(1024), dim3(256), 0, st, r->d_woff, r->d_tile, n_reads, wpr, per_tile, r->n_tiles);
+        kv_fastq_pack_launch(text->d_text, text->d_seq_start, text->d_seq_len, r->d_woff, n_reads, nw, r->d_words, (uint32_t *)r->d_flags, st);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        kv_set_error("read batch upload failed: %s", hipGetErrorString(e));
+        *rc = KV_ERR_HIP;
+    }
+    return true;
+}
+
 int reads_from_packed(const uint32_t *words, const TextSource *text, const uint32_t *lens, const uint8_t *flags, uint64_t n_reads, kv_reads **out)
 {
     KV_REQUIRE(n_reads < 0xFFFFFFF0ull, KV_ERR_ARG, "too many reads in one batch");
@@ -762,6 +813,14 @@ int reads_from_packed(const uint32_t *words, const TextSource *text, const uint3
     r->n_reads = n_reads;
     r->d_words = nullptr; r->d_woff = nullptr; r->d_len = nullptr; r->d_flags = nullptr; r->d_tile = nullptr;
     r->h_len.assign(lens, lens + n_reads);
+    {
+        int rc = KV_OK;
+        if (uniform_reads(r, text, lens, n_reads, &rc)) {
+            if (rc != KV_OK) { kv_reads_destroy(r); return rc; }
+            *out = r;
+            return KV_OK;
+        }
+    }
     std::vector<uint64_t> woff(n_reads + 1);
     std::vector<TileDesc> tiles;
     uint64_t nw = 0, nb = 0;
