@@ -476,3 +476,36 @@ def test_timer_contract():
     t.start('task3')
     with pytest.raises(ValueError, match=r'Timer already started for "task3"'):
         t.start('task3')
+
+
+def test_hit_memory_keeps_its_owner_alive_through_derived_views():
+    """arrays over a kv_hits handle's pinned memory (khmer._HitsMemory) must pin the handle for as long as ANY view of them
+    lives -- np.asarray() and slices included; a dropped owner means recycled memory under a live array"""
+    import ctypes
+    import gc
+    import numpy as np
+    from kevlar_amd import khmer
+
+    class Holder(object):
+        alive = 0
+
+        def __init__(self):
+            Holder.alive += 1
+
+        def __del__(self):
+            Holder.alive -= 1
+    block = (ctypes.c_uint32 * 16)(*range(16))
+    holder = Holder()
+    arr = np.asarray(khmer._HitsMemory(ctypes.addressof(block), (4, 4), np.uint32, holder))
+    del holder
+    assert arr.shape == (4, 4) and arr[2, 1] == 9
+    plain, part, flat = np.asarray(arr), arr[1:3], arr.reshape(-1)[5:]
+    del arr
+    gc.collect()
+    assert Holder.alive == 1
+    del plain, part
+    gc.collect()
+    assert Holder.alive == 1 and flat[0] == 5
+    del flat
+    gc.collect()
+    assert Holder.alive == 0
