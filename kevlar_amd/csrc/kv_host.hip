@@ -899,30 +899,33 @@ extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, u
     r->n_reads = n_reads; r->n_bases = n_reads * read_len; r->n_words = n_reads * wpr; r->max_len = read_len;
     r->d_words = nullptr; r->d_woff = nullptr; r->d_len = nullptr; r->d_flags = nullptr; r->d_tile = nullptr;
     r->h_len.assign(n_reads, read_len);
-    std::vector<uint64_t> woff(n_reads + 1);
-    for (uint64_t i = 0; i <= n_reads; ++i) woff[i] = i * wpr;
     const uint32_t need = 2 * ((read_len + KV_READ_PAD + 3) & ~3u);
     uint32_t per_tile = (KV_TILE_LDS_BYTES - 64) / need;
     if (per_tile > KV_TILE_MAX_READS) per_tile = KV_TILE_MAX_READS;
     if (per_tile < 1) per_tile = 1;
     KV_REQUIRE(need <= KV_TILE_LDS_BYTES - 64, KV_ERR_ARG, "kv_reads_create_packed: read length %u needs kv_reads_create", read_len);
-    std::vector<TileDesc> tiles;
-    for (uint64_t i = 0; i < n_reads; i += per_tile)
-        tiles.push_back(TileDesc{(uint32_t)i, (uint32_t)std::min<uint64_t>(per_tile, n_reads - i), 0u, 0u});
-    r->n_tiles = (uint32_t)tiles.size();
+    r->n_tiles = (uint32_t)((n_reads + per_tile - 1) / per_tile);
     r->tile_max_bases = (uint32_t)std::min<uint64_t>(per_tile, n_reads) * read_len;
-    if (tiles.empty()) tiles.push_back(TileDesc{0u, 0u, 0u, 0u});
     r->tile_lds_bytes = KV_TILE_LDS_BYTES + 256;
+    // only the packed words cross PCIe: word offsets, lengths and the tile table of equal-length reads are written on
+    // the device in closed form
+    hipStream_t st = kv_stream();
+    const uint32_t tiles_alloc = std::max<uint32_t>(r->n_tiles, 1u);
     hipError_t e = hipMalloc((void **)&r->d_words, (r->n_words + 4) * 4);   // + slack: k-mer extraction reads up to two words ahead
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, (n_reads + 1) * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, n_reads ? n_reads : 1);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, tiles.size() * sizeof(TileDesc));
-    if (e == hipSuccess && r->n_words) e = hipMemcpy(r->d_words, words, r->n_words * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(r->d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess && n_reads) e = hipMemcpy(r->d_len, r->h_len.data(), n_reads * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(r->d_flags, 0, n_reads ? n_reads : 1);
-    if (e == hipSuccess) e = hipMemcpy(r->d_tile, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, (size_t)tiles_alloc * sizeof(TileDesc));
+    if (e == hipSuccess && r->n_words) e = hipMemcpyAsync(r->d_words, words, r->n_words * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_words + r->n_words, 0, 16, st);
+    if (e == hipSuccess && n_reads) e = hipMemsetD32Async((hipDeviceptr_t)r->d_len, (int)read_len, n_reads, st);
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_flags, 0, n_reads ? n_reads : 1, st);
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_tile, 0, (size_t)tiles_alloc * sizeof(TileDesc), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_uniform_layout, dim3(1024), dim3(256), 0, st, r->d_woff, r->d_tile, n_reads, wpr, per_tile, r->n_tiles);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
         kv_set_error("read batch upload failed: %s", hipGetErrorString(e));
         kv_reads_destroy(r);
