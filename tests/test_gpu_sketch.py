@@ -291,8 +291,10 @@ def test_long_sequences_are_cut_into_segment_tiles(hk, ok):
     assert hk.ReadBatch(['A' * 60000]).num_kmers(31) == 60000 - 30        # no length limit any more
 
 
-@pytest.mark.parametrize('path', ['skm', 'binned', 'atomic'])
-def test_clear_is_lazy_but_invisible(hk, path, tmp_path):
+@pytest.mark.parametrize('kind,path', [('Counttable', 'skm'), ('Counttable', 'binned'), ('Counttable', 'atomic'),
+                                       ('SmallCounttable', 'skm'), ('SmallCounttable', 'binned'), ('Nodetable', 'binned'),
+                                       ('Nodetable', 'skm'), ('Countgraph', 'binned')])
+def test_clear_is_lazy_but_invisible(hk, kind, path, tmp_path):
     """kv_sketch_clear defers the zeroing to the next partitioned count; whatever touches the tables first -- a big
     count, a small one, point queries, table reads, save, a scan, use as a mask -- must see zeroed tables"""
     from kevlar_amd import synth
@@ -301,12 +303,12 @@ def test_clear_is_lazy_but_invisible(hk, path, tmp_path):
     reads = synth.unpack_reads(synth.sample_reads_packed(trio['proband'], 60000, 100, 0.01, 3), 100)
     junk = synth.unpack_reads(synth.sample_reads_packed(trio['mother'], 60000, 100, 0.01, 4), 100)
     big, small, dirty = hk.ReadBatch(reads), hk.ReadBatch(reads[:50]), hk.ReadBatch(junk)
-    fresh = hk.Counttable(k, 1.5e6, 4)
+    fresh = getattr(hk, kind)(k, 1.5e6, 4)
     os.environ['KV_COUNT_PATH'] = path
     try:
         fresh.consume_batch(big)
         want = [fresh.table_bytes(t) for t in range(4)]
-        used = hk.Counttable(k, 1.5e6, 4)
+        used = getattr(hk, kind)(k, 1.5e6, 4)
         for first in ('count', 'get', 'table', 'save', 'small', 'mask', 'scan'):
             used.consume_batch(dirty)
             used.clear()
@@ -319,16 +321,16 @@ def test_clear_is_lazy_but_invisible(hk, path, tmp_path):
             elif first == 'save':
                 out = str(tmp_path / 'empty.ct')
                 used.save(out)
-                back = hk.Counttable.load(out)
+                back = getattr(hk, kind).load(out)
                 assert not any(back.table_bytes(t).strip(b'\x00') for t in range(4))
             elif first == 'small':
                 used.consume_batch(small)
-                ref = hk.Counttable(k, 1.5e6, 4)
+                ref = getattr(hk, kind)(k, 1.5e6, 4)
                 ref.consume_batch(small)
                 assert [used.table_bytes(t) for t in range(4)] == [ref.table_bytes(t) for t in range(4)]
                 used.clear()
             elif first == 'mask':
-                other = hk.Counttable(k, 1.5e6, 4)
+                other = getattr(hk, kind)(k, 1.5e6, 4)
                 other.consume_batch(big, 0, 0, used)
                 assert [other.table_bytes(t) for t in range(4)] == want          # an empty mask hides nothing
             elif first == 'scan':
