@@ -90,7 +90,13 @@ struct KvArena {
         if (n <= bytes) return hipSuccess;
         if (p) (void)hipFree(p);
         p = nullptr; bytes = 0;
-        hipError_t e = hipMalloc(&p, n);
+        // an eighth of headroom: the geometry of the next batch (bucket sizes follow the previous batch's statistics) may
+        // ask for a little more, and releasing and allocating gigabytes costs a hundred milliseconds
+        const size_t roomy = n + n / 8;
+        hipError_t e = hipMalloc(&p, roomy);
+        if (e == hipSuccess) { bytes = roomy; return e; }
+        (void)hipGetLastError();
+        e = hipMalloc(&p, n);
         if (e == hipSuccess) bytes = n;
         return e;
     }
