@@ -315,6 +315,17 @@ int kv_format_records(uint64_t n_out, const uint64_t *rec_index, const uint64_t 
 int kv_bgzf_text_size(const void *file, uint64_t size, uint64_t *text_bytes, uint64_t *n_members);
 int kv_bgzf_inflate_host(const void *file, uint64_t size, void *out, uint64_t out_cap, double *kernel_ms);
 
+/* ---- ordinary gzip on the device (kevlar_amd/csrc/kv_gunzip.hip) ----------------------------------------
+ * The same reader (khmer.ReadParser over a *.gz, kevlar/__init__.py:125-128) for a file that is ONE deflate
+ * stream (gzip, pigz): block starts are searched for in parallel, every stretch between two starts is decoded
+ * by one wavefront with the unknown 32 KB in front of it as markers, the markers are resolved by pointer
+ * doubling.  kv_fastx_open picks this path by itself; this function takes a whole file image in host memory
+ * and returns its text (tests, tools).  segment_text: bytes of text per pass over the device (0: 1 GB);
+ * stats[4]: passes, stretches decoded, stretches dropped (false starts), stretches decoded again.
+ * KV_ERR_TYPE: the stream needs the host's zlib (kv_fastx_next falls back by itself).                      */
+int kv_gunzip_host(const void *file, uint64_t size, void *out, uint64_t out_cap, uint64_t segment_text,
+                   uint64_t *text_bytes, uint64_t *stats, double *device_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,7 @@ SIGNATURES = {
     'kv_consume_hashes': (i32, [vp, vp, u64, ctypes.c_uint32, u64p]),
     'kv_bgzf_text_size': (i32, [vp, u64, u64p, u64p]),
     'kv_bgzf_inflate_host': (i32, [vp, u64, vp, u64, ctypes.POINTER(ctypes.c_double)]),
+    'kv_gunzip_host': (i32, [vp, u64, vp, u64, u64, u64p, u64p, ctypes.POINTER(ctypes.c_double)]),
     'kv_route_distinct': (i32, [vp, i32, i32, i32, vp, u64, u64p]),
     'kv_consume_hashes_weighted': (i32, [vp, vp, u64, u64p]),
     'kv_novel_scan_hashes': (i32, [vpp, i32, vpp, i32, vp, u64, i32, i32, vp, vp, u64, u64p]),

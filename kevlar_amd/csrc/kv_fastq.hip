@@ -241,6 +241,7 @@ struct KvFastqDevice {
     std::vector<KvBgzfMember> members;
     size_t next_member = 0;
     bool plain = false;             // uncompressed FASTQ: the file's bytes are the text, uploaded as they are
+    KvGunzip *gz = nullptr;         // an ordinary gzip stream (not BGZF): inflated a segment at a time (kv_gunzip.hip)
     uint64_t next_byte = 0;
     FastqBuffers *buf = nullptr;
     KvArena *text = nullptr;        // = buf->text
@@ -265,7 +266,11 @@ KvFastqDevice *kv_fastq_device_open(const char *path)
     int yes = 0;
     if (d->image[0] == '@') d->plain = true;
     else kv_bgzf_index(d->image, d->image_size, &d->members, &yes);
-    if (!yes && !d->plain) { kv_fastq_device_close(d); return nullptr; }
+    if (!yes && !d->plain) {
+        const char *off = getenv("KV_GUNZIP");
+        if (!(off && !strcmp(off, "host"))) d->gz = kv_gunzip_open(d->image, d->image_size);
+        if (!d->gz) { kv_fastq_device_close(d); return nullptr; }
+    }
     {
         std::lock_guard<std::mutex> lk(g_fastq_pool_mu);
         if (!g_fastq_pool.empty()) { d->buf = g_fastq_pool.back(); g_fastq_pool.pop_back(); }
@@ -278,6 +283,7 @@ KvFastqDevice *kv_fastq_device_open(const char *path)
 void kv_fastq_device_close(KvFastqDevice *d)
 {
     if (!d) return;
+    kv_gunzip_close(d->gz);
     if (d->image) munmap((void *)d->image, d->image_size);
     if (d->fd >= 0) close(d->fd);
     if (d->buf) {
@@ -305,12 +311,16 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         size_t m1 = m0;
         uint64_t fresh = 0;
         const uint64_t b0 = d->next_byte;
-        if (d->plain) {
+        bool gz_last = false;
+        if (d->gz) {
+            const int rc = kv_gunzip_decode(d->gz, want > d->carry_len + (1u << 20) ? want - d->carry_len : (1u << 20), &fresh, &gz_last);
+            if (rc != KV_OK) return rc;
+        } else if (d->plain) {
             fresh = std::min<uint64_t>(d->image_size - b0, want > d->carry_len + 65536 ? want - d->carry_len : 65536);
         } else {
             while (m1 < d->members.size() && (m1 == m0 || d->carry_len + fresh + d->members[m1].isize <= want)) fresh += d->members[m1++].isize;
         }
-        const bool final = d->plain ? b0 + fresh == d->image_size : m1 == d->members.size();
+        const bool final = d->gz ? gz_last : d->plain ? b0 + fresh == d->image_size : m1 == d->members.size();
         const uint64_t total_in = d->carry_len + fresh;
         if (total_in == 0) { d->done = true; return KV_OK; }
         const int nxt = d->cur ^ 1;
@@ -318,6 +328,7 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         uint8_t *text = (uint8_t *)d->text[nxt].p;
         if (d->carry_len) KV_HIP(hipMemcpyAsync(text, (const uint8_t *)d->text[d->cur].p + d->carry_at, d->carry_len, hipMemcpyDeviceToDevice, st));
         if (d->plain && fresh) KV_HIP(hipMemcpyAsync(text + d->carry_len, d->image + b0, fresh, hipMemcpyHostToDevice, st));
+        if (d->gz && fresh) { const int rc = kv_gunzip_emit(d->gz, text + d->carry_len); if (rc != KV_OK) return rc; }
         if (m1 > m0) {
             const uint64_t c0 = d->members[m0].in_off, c1 = d->members[m1 - 1].in_off + d->members[m1 - 1].in_len;
             KV_HIP(d->buf->comp.need(kv_round_up(c1 - c0 + 64, 4096)));
@@ -351,6 +362,13 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         KV_HIP(hipMemcpyAsync(&n_lines, d_base + n_chunks, 8, hipMemcpyDeviceToHost, st));
         KV_HIP(hipStreamSynchronize(st));
         uint64_t n = std::min<uint64_t>(n_lines / 4, max_reads);
+        if (n == 0 && !final && d->gz) {  // not one whole record yet: what has been inflated waits as the carry
+            d->cur = nxt;
+            d->carry_at = 0;
+            d->carry_len = total_in;
+            want = want * 2 + 65536;
+            continue;
+        }
         if (n == 0 && !final) {           // not one whole record yet (huge records or a tiny budget): take more members
             d->next_member = m0;
             d->next_byte = b0;

@@ -350,9 +350,13 @@ extern "C" int kv_fastx_open(const char *path, kv_fastx **out)
             FILE *probe = fopen(path, "rb");
             if (probe) {
                 if (fread(head, 1, sizeof(head), probe) == sizeof(head))
-                    f->dev_candidate = (head[0] == 0x1f && head[1] == 0x8b && head[2] == 8 && head[3] == 4 && head[12] == 'B' && head[13] == 'C') ||
-                                       head[0] == '@';                 // BGZF, or uncompressed FASTQ
+                    f->dev_candidate = (head[0] == 0x1f && head[1] == 0x8b && head[2] == 8) || head[0] == '@';      // BGZF, gzip, or uncompressed FASTQ
                 fclose(probe);
+            }
+            if (f->dev_candidate && head[0] == 0x1f) {              // compressed: only FASTQ is worth the device's while
+                char first = 0;
+                f->dev_candidate = gzread(fh, &first, 1) == 1 && first == '@';
+                gzrewind(fh);
             }
         }
     }

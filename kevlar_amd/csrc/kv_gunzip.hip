@@ -1,0 +1,810 @@
+// kv_gunzip.hip -- an ORDINARY gzip stream inflated on the device, in parallel (ingest).
+//
+// What `gzip`, `pigz` and most sequencers write is one long DEFLATE stream: a block can only be decoded by whoever knows
+// where it starts (blocks end on arbitrary bits) and what the 32 KB of text in front of it were (matches point back into
+// them).  zlib on one host core manages ~1.7 M reads/s of FASTQ that way.  Both obstacles have known ways round them
+// (Kerbiriou & Chikhi, "Parallel decompression of gzip-compressed files and random access to DNA sequences", 2019;
+// Knespel & Brunst, "Rapidgzip", 2023), restated here for wavefronts:
+//
+//   1. k_gz_find    the stream is cut into chunks of 16 KB; one workgroup per chunk tries every bit offset as the start
+//                   of a dynamic-Huffman block: 3 header bits, the two code counts, a COMPLETE code-length code (all 64
+//                   lanes x 4 waves, one offset each), then for the few survivors the full set of literal/length and
+//                   distance code lengths, which must form complete codes with an end-of-block symbol.  First hit wins.
+//   2. k_gz_decode  one wavefront per found start decodes until it lands exactly on a later start (kv_inflate.hip's
+//                   wave-uniform Huffman walk).  Text goes out as 16-bit symbols: a byte, or -- for a match that reaches
+//                   back beyond the wave's own start -- a MARKER naming the position in the unknown 32 KB window.
+//                   The host checks the chain (start 0 is exact; a start is good iff a good decoder lands on it; a
+//                   start that was skipped over was a false positive and its output is dropped; a gap is decoded again).
+//   3. k_gz_tails / k_gz_scan   every stretch leaves a 32 K-symbol tail (its own last symbols, or markers passed
+//                   through); substituting a tail's markers from the tail before it is associative, so log2(n) rounds of
+//                   pointer doubling resolve all tails at once.
+//   4. k_gz_resolve every stretch replaces its markers from the (now plain) tail in front of it and stores bytes, packed to
+//                   the text offset the prefix sum of the lengths gives it.
+//
+// The file is taken a segment of compressed bytes at a time; the last tail and the exact bit position travel to the next
+// segment.  Concatenated members are followed inside k_gz_decode.  CRC-32 and ISIZE are not checked; tests compare with
+// zlib byte for byte.  Anything unexpected (no block found for megabytes, trailing garbage, corrupt codes) is reported as
+// KV_ERR_TYPE and the caller's host parser (zlib) takes the file.  Reference: the reader this replaces is
+// khmer.ReadParser's gzip stream (kevlar/__init__.py:125-128 opens every *.gz through it).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "kv_binned.h"
+#include "kv_internal.h"
+#include "kv_inflate_device.h"
+
+namespace {
+
+#define GZ_WIN 32768u
+#define GZ_MARK 0x8000u
+#define GZ_RBITS 10                  // the decoder's LDS window: the last 1024 symbols
+#define GZ_FAST_LL 9                 // bits of the literal/length lookup table (9: 32 workgroups of LDS per CU)
+#define GZ_SLACK 2048u               // readable zero bytes behind the compressed buffer
+#define GZ_FIND_THREADS 256
+#define GZ_FIND_SPAN 8192u           // bit offsets tried per pass of a workgroup
+#define GZ_FIND_LIST 256u
+
+enum { GZ_LANDED = 0, GZ_END = 1, GZ_BAD = 2, GZ_FULL = 3, GZ_SHORT = 4 };
+
+struct GzJob {
+    uint64_t start_bit;              // relative to the compressed buffer
+    uint64_t target_bit;             // stop at the first block boundary at or behind this one
+    uint64_t out_off;                // symbols
+    uint32_t out_cap;
+    uint32_t pad;
+};
+struct GzResult {
+    uint64_t end_bit;
+    uint32_t n_out;
+    uint32_t status;
+};
+
+__device__ __forceinline__ void br_seek(BitReader &br, const uint32_t *words, uint64_t bit)
+{
+    const uint64_t w = bit >> 5;
+    const uint32_t s = (uint32_t)(bit & 31u);
+    br.words = words;
+    br.buf = (uint64_t)(words[w] >> s);
+    br.cnt = 32u - s;
+    br.next = (uint32_t)w + 1;
+    br.ahead = words[w + 1];
+}
+__device__ __forceinline__ uint64_t br_pos(const BitReader &br) { return (uint64_t)br.next * 32ull - br.cnt; }
+
+// ---------------------------------------------------------------- 1. block starts
+__device__ __forceinline__ uint32_t lds_bits(const uint32_t *w, uint32_t bit, uint32_t n)     // n <= 25
+{
+    const uint32_t i = bit >> 5, s = bit & 31u;
+    const uint64_t v = ((uint64_t)w[i + 1] << 32) | w[i];
+    return (uint32_t)(v >> s) & ((1u << n) - 1u);
+}
+
+// bits [p, ...) of the staged chunk: BFINAL = 0, BTYPE = dynamic, plausible counts and a complete code-length code
+__device__ __forceinline__ bool gz_header_quick(const uint32_t *w, uint32_t p)
+{
+    const uint32_t head = lds_bits(w, p, 17);
+    if ((head & 7u) != 4u) return false;
+    if (((head >> 3) & 31u) > 29u || ((head >> 8) & 31u) > 29u) return false;
+    const uint32_t ncode = ((head >> 13) & 15u) + 4u;
+    uint32_t kraft = 0, q = p + 17;
+    for (uint32_t s = 0; s < ncode; s += 8) {
+        uint32_t v = lds_bits(w, q, 24);
+        q += 24;
+        const uint32_t m = min(8u, ncode - s);
+        for (uint32_t i = 0; i < m; ++i, v >>= 3) {
+            const uint32_t l = v & 7u;
+            kraft += l ? (128u >> l) : 0u;
+        }
+    }
+    return kraft == 128u;
+}
+
+// ... and the code lengths it spells: no overrun, an end-of-block code, complete literal/length and distance codes
+__device__ bool gz_header_full(const uint32_t *w, uint32_t p, uint32_t limit_bits)
+{
+    uint32_t q = p + 3;
+    const uint32_t nlen = lds_bits(w, q, 5) + 257u; q += 5;
+    const uint32_t ndist = lds_bits(w, q, 5) + 1u; q += 5;
+    const uint32_t ncode = lds_bits(w, q, 4) + 4u; q += 4;
+    uint64_t cl = 0;                                   // 19 lengths of 3 bits
+    for (uint32_t s = 0; s < ncode; ++s, q += 3) cl |= (uint64_t)lds_bits(w, q, 3) << (3u * c_clen_order[s]);
+    uint64_t cnt = 0;                                  // symbols per length, 8 bits each
+    uint64_t sorted_lo = 0, sorted_hi = 0;             // the symbols by (length, symbol), 5 bits each, 12 per word
+    uint32_t filled = 0;
+    for (uint32_t l = 1; l <= 7; ++l)
+        for (uint32_t s = 0; s < 19; ++s)
+            if (((cl >> (3u * s)) & 7u) == l) {
+                cnt += 1ull << (8u * l);
+                if (filled < 12) sorted_lo |= (uint64_t)s << (5u * filled);
+                else sorted_hi |= (uint64_t)s << (5u * (filled - 12));
+                ++filled;
+            }
+    const uint32_t total = nlen + ndist;
+    uint32_t kraft_ll = 0, kraft_d = 0, used_d = 0, idx = 0, prev = 0;
+    bool eob = false;
+    while (idx < total) {
+        if (q + 16 > limit_bits) return false;
+        uint32_t window = lds_bits(w, q, 7);
+        int code = 0, first = 0, index = 0, sym = -1;
+        for (uint32_t l = 1; l <= 7; ++l) {
+            code |= (int)(window & 1u);
+            window >>= 1;
+            const int c = (int)((cnt >> (8u * l)) & 255u);
+            if (code - c < first) {
+                const uint32_t at = (uint32_t)(index + (code - first));
+                sym = (int)(at < 12 ? (sorted_lo >> (5u * at)) & 31u : (sorted_hi >> (5u * (at - 12))) & 31u);
+                q += l;
+                break;
+            }
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+        if (sym < 0) return false;
+        uint32_t rep = 1, val = (uint32_t)sym;
+        if (sym == 16) {
+            if (idx == 0) return false;
+            val = prev;
+            rep = 3 + lds_bits(w, q, 2); q += 2;
+        } else if (sym == 17) { val = 0; rep = 3 + lds_bits(w, q, 3); q += 3; }
+        else if (sym == 18) { val = 0; rep = 11 + lds_bits(w, q, 7); q += 7; }
+        if (idx + rep > total) return false;
+        if (val) {
+            const uint32_t in_ll = idx < nlen ? min(rep, nlen - idx) : 0u;
+            kraft_ll += in_ll << (15u - val);
+            kraft_d += (rep - in_ll) << (15u - val);
+            used_d += rep - in_ll;
+            if (idx <= 256u && 256u < idx + rep) eob = true;
+        }
+        idx += rep;
+        prev = val;
+    }
+    return eob && kraft_ll == 32768u && (kraft_d == 32768u || used_d == 0 || (used_d == 1 && kraft_d == 16384u));
+}
+
+// cand[c] = bit position (relative to `comp`) of the first plausible block start in chunk c, or ~0
+__global__ __launch_bounds__(GZ_FIND_THREADS) void k_gz_find(const uint8_t *__restrict__ comp, uint64_t n_bytes, uint32_t chunk_bytes, uint32_t n_chunks,
+                                                             unsigned long long *__restrict__ cand)
+{
+    extern __shared__ uint32_t sh_words[];             // chunk_bytes + GZ_SLACK bytes of the stream
+    __shared__ uint32_t sh_list[GZ_FIND_LIST];
+    __shared__ uint32_t sh_n, sh_best;
+    const uint32_t c = blockIdx.x;
+    if (c >= n_chunks) return;
+    const uint64_t base = (uint64_t)c * chunk_bytes;
+    const uint32_t staged = chunk_bytes + GZ_SLACK;
+    const uint32_t *src = (const uint32_t *)(comp + base);          // comp is 256-aligned, chunk_bytes a multiple of 4
+    for (uint32_t i = threadIdx.x; i < staged / 4; i += GZ_FIND_THREADS) sh_words[i] = src[i];     // the buffer has GZ_SLACK zero bytes behind n_bytes
+    if (threadIdx.x == 0) sh_best = ~0u;
+    __syncthreads();
+    const uint64_t left = n_bytes > base ? n_bytes - base : 0;
+    const uint32_t limit_bits = (uint32_t)(left < staged ? left : staged) * 8u;
+    const uint32_t chunk_bits = chunk_bytes * 8u < limit_bits ? chunk_bytes * 8u : limit_bits;
+    for (uint32_t span = 0; span < chunk_bits; span += GZ_FIND_SPAN) {
+        if (threadIdx.x == 0) sh_n = 0;
+        __syncthreads();
+        for (uint32_t p = span + threadIdx.x; p < min(span + GZ_FIND_SPAN, chunk_bits); p += GZ_FIND_THREADS)
+            if (gz_header_quick(sh_words, p)) {
+                const uint32_t at = atomicAdd(&sh_n, 1u);
+                if (at < GZ_FIND_LIST) sh_list[at] = p;
+            }
+        __syncthreads();
+        const uint32_t n = min(sh_n, GZ_FIND_LIST);
+        for (uint32_t i = threadIdx.x; i < n; i += GZ_FIND_THREADS)
+            if (gz_header_full(sh_words, sh_list[i], limit_bits)) atomicMin(&sh_best, sh_list[i]);
+        __syncthreads();
+        if (sh_best != ~0u) break;
+    }
+    if (threadIdx.x == 0) cand[c] = sh_best == ~0u ? ~0ull : base * 8ull + sh_best;
+}
+
+// ---------------------------------------------------------------- 2. decode into symbols
+__device__ __forceinline__ bool gz_build_code(const uint8_t *lengths, int n, uint16_t *count, uint16_t *symbol, uint16_t *table, int fast)
+{
+    return build_code(lengths, n, count, symbol, table, fast);
+}
+
+struct GunzipShared {
+    uint16_t ring[1 << GZ_RBITS];
+    uint16_t ll_table[1 << GZ_FAST_LL];
+    uint16_t d_table[1 << INF_FAST_D];
+    uint16_t ll_count[16], d_count[16];
+    uint16_t ll_symbol[288], d_symbol[32];
+    uint8_t lengths[352];
+};
+
+// gzip member header at byte `at` of the buffer: returns the byte its deflate data start at, 0 if this is no header,
+// ~0 if the buffer ends inside it
+__device__ __attribute__((noinline)) uint64_t gz_member_header(const uint8_t *comp, uint64_t at, uint64_t n_bytes)
+{
+    if (at + 18 > n_bytes) return ~0ull;
+    if (comp[at] != 0x1f || comp[at + 1] != 0x8b || comp[at + 2] != 8 || (comp[at + 3] & 0xe0)) return 0;
+    const uint32_t flags = comp[at + 3];
+    uint64_t p = at + 10;
+    if (flags & 4) {
+        const uint32_t xlen = comp[p] | (comp[p + 1] << 8);
+        p += 2 + xlen;
+    }
+    for (int field = 0; field < 2; ++field)              // name, comment: zero-terminated
+        if (flags & (field == 0 ? 8 : 16)) {
+            while (p < n_bytes && comp[p]) ++p;
+            ++p;
+        }
+    if (flags & 2) p += 2;
+    return p + 8 <= n_bytes ? p : ~0ull;
+}
+
+__global__ __launch_bounds__(64, 8) void k_gz_decode(const uint8_t *__restrict__ comp, uint64_t n_bytes, int is_file_end, const GzJob *__restrict__ jobs,
+                                                      uint32_t n_jobs, uint16_t *syms, GzResult *__restrict__ results, unsigned long long *ctr)
+{
+    __shared__ GunzipShared sh;
+    constexpr uint32_t RMASK = (1u << GZ_RBITS) - 1u;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *words = (const uint32_t *)comp;
+    const uint64_t limit_words = (n_bytes + 3) / 4 + 2;        // the reader may be this far without having left the data
+    for (;;) {
+        uint32_t job_id = 0;
+        if (lane == 0) job_id = (uint32_t)atomicAdd(&ctr[0], 1ull);
+        job_id = INF_UNI(job_id);
+        if (job_id >= n_jobs) return;
+        const GzJob job = jobs[job_id];
+        BitReader br;
+        br_seek(br, words, job.start_bit);
+        uint16_t *dst = syms + job.out_off;
+        const uint32_t cap = job.out_cap;
+        uint32_t o = 0, lit = 0, n_lit = 0;
+        int status = -1;
+        uint64_t end_bit = job.start_bit;
+        auto flush = [&]() {
+            if (lane < n_lit) { sh.ring[(o + lane) & RMASK] = (uint16_t)lit; dst[o + lane] = (uint16_t)lit; }
+            o += n_lit;
+            n_lit = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        bool first_block = true;
+        while (status < 0) {
+            // ---- at a block boundary
+            end_bit = br_pos(br);
+            if (!first_block && end_bit >= job.target_bit) { status = GZ_LANDED; break; }
+            first_block = false;
+            if (br.next > limit_words) { status = GZ_SHORT; break; }
+            const bool last_block = br_bits(br, 1) != 0;
+            const uint32_t btype = br_bits(br, 2);
+            if (btype == 3) { status = GZ_BAD; break; }
+            if (btype == 0) {
+                const uint32_t drop = br.cnt & 7u;
+                br.buf >>= drop; br.cnt -= drop;
+                const uint32_t stored_len = br_bits(br, 16);
+                const uint32_t inv = br_bits(br, 16);
+                if ((stored_len ^ inv) != 0xffffu) { status = GZ_BAD; break; }
+                if (br_pos(br) + 8ull * stored_len > n_bytes * 8ull) { status = GZ_SHORT; break; }
+                if (o + stored_len > cap) { status = GZ_FULL; break; }
+                flush();
+                const uint64_t from_byte = br_pos(br) >> 3;                          // a byte boundary
+                for (uint32_t j = lane; j < stored_len; j += 64) {
+                    const uint16_t v = comp[from_byte + j];
+                    dst[o + j] = v;
+                    if (j + (1u << GZ_RBITS) >= stored_len) sh.ring[(o + j) & RMASK] = v;
+                }
+                o += stored_len;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                br_seek(br, words, (from_byte + stored_len) * 8);
+            } else {
+                uint32_t ok = 1;
+                if (btype == 1) {
+                    if (lane == 0) {
+                        for (int s = 0; s < 144; ++s) sh.lengths[s] = 8;
+                        for (int s = 144; s < 256; ++s) sh.lengths[s] = 9;
+                        for (int s = 256; s < 280; ++s) sh.lengths[s] = 7;
+                        for (int s = 280; s < 288; ++s) sh.lengths[s] = 8;
+                        ok = gz_build_code(sh.lengths, 288, sh.ll_count, sh.ll_symbol, sh.ll_table, GZ_FAST_LL);
+                        for (int s = 0; s < 30; ++s) sh.lengths[s] = 5;
+                        ok = ok && gz_build_code(sh.lengths, 30, sh.d_count, sh.d_symbol, sh.d_table, INF_FAST_D);
+                    }
+                } else {
+                    const uint32_t nlen = br_bits(br, 5) + 257, ndist = br_bits(br, 5) + 1, ncode = br_bits(br, 4) + 4;
+                    if (nlen > 286 || ndist > 30) { status = GZ_BAD; break; }
+                    if (lane < 19) sh.lengths[lane] = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t s = 0; s < ncode; ++s) {
+                        const uint32_t v = br_bits(br, 3);
+                        if (lane == 0) sh.lengths[c_clen_order[s]] = (uint8_t)v;
+                    }
+                    if (lane == 0) ok = gz_build_code(sh.lengths, 19, sh.d_count, sh.d_symbol, sh.d_table, 7);
+                    ok = INF_UNI(ok);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t idx = 0, prev = 0;
+                    while (ok && idx < nlen + ndist) {
+                        const int sym = decode_sym(br, sh.d_count, sh.d_symbol, sh.d_table, 7);
+                        if (sym < 0) { ok = 0; break; }
+                        uint32_t rep = 1, val = (uint32_t)sym;
+                        if (sym == 16) {
+                            if (idx == 0) { ok = 0; break; }
+                            val = prev;
+                            rep = 3 + br_bits(br, 2);
+                        } else if (sym == 17) { val = 0; rep = 3 + br_bits(br, 3); }
+                        else if (sym == 18) { val = 0; rep = 11 + br_bits(br, 7); }
+                        if (idx + rep > nlen + ndist) { ok = 0; break; }
+                        if (lane < rep) sh.lengths[19 + idx + lane] = (uint8_t)val;
+                        if (lane + 64 < rep) sh.lengths[19 + idx + lane + 64] = (uint8_t)val;
+                        if (lane + 128 < rep) sh.lengths[19 + idx + lane + 128] = (uint8_t)val;
+                        idx += rep;
+                        prev = val;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0 && ok) {
+                        ok = sh.lengths[19 + 256] != 0;
+                        ok = ok && gz_build_code(sh.lengths + 19, (int)nlen, sh.ll_count, sh.ll_symbol, sh.ll_table, GZ_FAST_LL);
+                        ok = ok && gz_build_code(sh.lengths + 19 + nlen, (int)ndist, sh.d_count, sh.d_symbol, sh.d_table, INF_FAST_D);
+                    }
+                }
+                ok = INF_UNI(ok);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (!ok) { status = GZ_BAD; break; }
+                // ---- symbols
+                for (;;) {
+                    if (br.next > limit_words) { status = GZ_SHORT; break; }
+                    const int sym = decode_sym(br, sh.ll_count, sh.ll_symbol, sh.ll_table, GZ_FAST_LL);
+                    if (sym < 0) { status = GZ_BAD; break; }
+                    if (sym < 256) {
+                        if (o + n_lit >= cap) { status = GZ_FULL; break; }
+                        lit = lane == n_lit ? (uint32_t)sym : lit;
+                        if (++n_lit == 64) flush();
+                        continue;
+                    }
+                    flush();
+                    if (sym == 256) break;
+                    const int ls = sym - 257;
+                    if (ls >= 29) { status = GZ_BAD; break; }
+                    const uint32_t len = c_len_base[ls] + br_bits(br, c_len_extra[ls]);
+                    const int ds = decode_sym(br, sh.d_count, sh.d_symbol, sh.d_table, INF_FAST_D);
+                    if (ds < 0 || ds >= 30) { status = GZ_BAD; break; }
+                    const uint32_t extra = c_dist_extra[ds];
+                    br_need(br, 16);
+                    const uint32_t dist = c_dist_base[ds] + ((uint32_t)br.buf & ((1u << extra) - 1u));
+                    br.buf >>= extra; br.cnt -= extra;
+                    if (o + len > cap) { status = GZ_FULL; break; }
+                    // a source in front of this wave's first symbol is text somebody else decodes: a marker for position
+                    // 32768 + src of the window in front of the stretch stands in for it
+                    const int32_t from = (int32_t)o - (int32_t)dist;             // (a stretch holds fewer than 2^31 symbols)
+                    if (dist + 258u <= (1u << GZ_RBITS)) {
+                        for (uint32_t j = lane; j < len; j += 64) {
+                            const int32_t src = dist >= len ? from + (int32_t)j : from + (int32_t)(j % dist);
+                            const uint16_t v = src < 0 ? (uint16_t)(GZ_MARK | (uint32_t)((int32_t)GZ_WIN + src)) : sh.ring[(uint32_t)src & RMASK];
+                            sh.ring[(o + j) & RMASK] = v;
+                            dst[o + j] = v;
+                        }
+                    } else {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        for (uint32_t j = lane; j < len; j += 64) {                    // dist > 258 >= len here: no overlap
+                            const int32_t src = from + (int32_t)j;
+                            const uint16_t v = src < 0 ? (uint16_t)(GZ_MARK | (uint32_t)((int32_t)GZ_WIN + src))
+                                                       : __hip_atomic_load(dst + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            sh.ring[(o + j) & RMASK] = v;
+                            dst[o + j] = v;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    o += len;
+                }
+                if (status >= 0) break;
+            }
+            if (last_block) {
+                // the member's trailer (CRC-32, ISIZE), then the end of the file or another member
+                uint64_t at = ((br_pos(br) + 7) >> 3) + 8;
+                if (at > n_bytes) { status = GZ_SHORT; break; }
+                if (at == n_bytes) {
+                    end_bit = at * 8;
+                    status = is_file_end ? GZ_END : GZ_SHORT;
+                    break;
+                }
+                uint64_t data = 0;
+                if (lane == 0) data = gz_member_header(comp, at, n_bytes);
+                data = ((uint64_t)INF_UNI((uint32_t)(data >> 32)) << 32) | INF_UNI((uint32_t)data);
+                if (data == ~0ull) { status = is_file_end ? GZ_BAD : GZ_SHORT; break; }
+                if (data == 0) { status = GZ_BAD; break; }
+                br_seek(br, words, data * 8);
+            }
+        }
+        if (lane == 0) {
+            GzResult r;
+            r.end_bit = end_bit;
+            r.n_out = o;
+            r.status = (uint32_t)status;
+            results[job_id] = r;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------- 3. tails
+// tail q (q = 0: the window the segment starts with, as bytes; q > 0: stretch q - 1): the 32 K symbols in front of
+// stretch q.  A stretch shorter than the window passes the rest of the tail before it through as markers.
+__global__ void k_gz_tails(const uint16_t *__restrict__ syms, const uint64_t *__restrict__ out_off, const uint32_t *__restrict__ n_out,
+                           const uint8_t *__restrict__ window_in, uint16_t *__restrict__ tails)
+{
+    const uint32_t q = blockIdx.x;
+    uint16_t *t = tails + (size_t)q * GZ_WIN;
+    if (q == 0) {
+        for (uint32_t i = threadIdx.x; i < GZ_WIN; i += blockDim.x) t[i] = window_in[i];
+        return;
+    }
+    const uint32_t n = n_out[q - 1];
+    const uint16_t *src = syms + out_off[q - 1];
+    for (uint32_t i = threadIdx.x; i < GZ_WIN; i += blockDim.x) {
+        const int64_t rel = (int64_t)n - (int64_t)GZ_WIN + i;
+        t[i] = rel >= 0 ? src[rel] : (uint16_t)(GZ_MARK | (uint32_t)(GZ_WIN + rel));
+    }
+}
+
+// one round of pointer doubling: the markers of tail q name positions of tail q - d
+__global__ void k_gz_scan(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, uint32_t d)
+{
+    const uint32_t q = blockIdx.x;
+    const uint16_t *t = in + (size_t)q * GZ_WIN;
+    uint16_t *o = out + (size_t)q * GZ_WIN;
+    if (q < d) {
+        for (uint32_t i = threadIdx.x; i < GZ_WIN / 4; i += blockDim.x) ((uint64_t *)o)[i] = ((const uint64_t *)t)[i];
+        return;
+    }
+    const uint16_t *before = in + (size_t)(q - d) * GZ_WIN;
+    for (uint32_t i = threadIdx.x; i < GZ_WIN; i += blockDim.x) {
+        uint16_t v = t[i];
+        if (v & GZ_MARK) v = before[v & (GZ_WIN - 1u)];
+        o[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- 4. bytes
+#define GZ_RESOLVE_SPLIT 8u
+__global__ void k_gz_resolve(const uint16_t *__restrict__ syms, const uint64_t *__restrict__ out_off, const uint32_t *__restrict__ n_out,
+                             const uint64_t *__restrict__ text_base, const uint16_t *__restrict__ tails, uint8_t *__restrict__ text)
+{
+    const uint32_t q = blockIdx.x / GZ_RESOLVE_SPLIT, part = blockIdx.x % GZ_RESOLVE_SPLIT;
+    const uint16_t *t = tails + (size_t)q * GZ_WIN;             // the window in front of stretch q
+    const uint16_t *src = syms + out_off[q];
+    uint8_t *dst = text + text_base[q];
+    const uint32_t n = n_out[q];
+    for (uint32_t i = part * blockDim.x + threadIdx.x; i < n; i += GZ_RESOLVE_SPLIT * blockDim.x) {
+        uint16_t v = src[i];
+        if (v & GZ_MARK) v = t[v & (GZ_WIN - 1u)];
+        dst[i] = (uint8_t)v;
+    }
+}
+
+__global__ void k_gz_window_out(const uint16_t *__restrict__ tail, uint8_t *__restrict__ window)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < GZ_WIN; i += gridDim.x * blockDim.x) window[i] = (uint8_t)tail[i];
+}
+
+// start of the deflate data of the gzip member at byte `at` of a host image; 0 if there is no member header there
+uint64_t host_member_header(const uint8_t *file, uint64_t size, uint64_t at)
+{
+    if (at + 18 > size) return 0;
+    if (file[at] != 0x1f || file[at + 1] != 0x8b || file[at + 2] != 8 || (file[at + 3] & 0xe0)) return 0;
+    const uint32_t flags = file[at + 3];
+    uint64_t p = at + 10;
+    if (flags & 4) {
+        const uint32_t xlen = file[p] | (file[p + 1] << 8);
+        p += 2 + xlen;
+    }
+    for (int field = 0; field < 2; ++field)
+        if (flags & (field == 0 ? 8 : 16)) {
+            while (p < size && file[p]) ++p;
+            ++p;
+        }
+    if (flags & 2) p += 2;
+    return p + 8 <= size ? p : 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- host side
+struct KvGunzip {
+    const uint8_t *image = nullptr;
+    uint64_t size = 0;
+    uint64_t pos_bit = 0;             // of the next block, in the file
+    bool done = false;
+    double ratio = 4.0;               // text bytes per compressed byte so far
+    uint64_t seen_comp = 0, seen_text = 0;
+    uint32_t chunk_bytes = 16384;
+    KvArena comp, syms, tails, meta, window, small;
+    // the segment decoded by kv_gunzip_decode and not yet emitted
+    std::vector<uint64_t> v_off, v_base;
+    std::vector<uint32_t> v_n;
+    uint64_t pending_text = 0, pending_pos = 0;
+    bool pending_done = false, pending = false, window_ready = false;
+    const uint64_t *d_off = nullptr, *d_base = nullptr;           // device copies of v_off / v_base / v_n
+    const uint32_t *d_n = nullptr;
+    const uint16_t *d_tails = nullptr;                            // the resolved tails of the pending segment
+    uint64_t stat_jobs = 0, stat_dropped = 0, stat_repairs = 0, stat_segments = 0;
+    ~KvGunzip()
+    {
+        for (KvArena *a : {&comp, &syms, &tails, &meta, &window, &small})
+            if (a->p) (void)hipFree(a->p);
+    }
+};
+
+KvGunzip *kv_gunzip_open(const uint8_t *image, uint64_t size)
+{
+    const uint64_t data = host_member_header(image, size, 0);
+    if (!data) return nullptr;
+    KvGunzip *g = new KvGunzip();
+    g->image = image;
+    g->size = size;
+    g->pos_bit = data * 8;
+    const char *cb = getenv("KV_GUNZIP_CHUNK_KB");
+    if (cb && atoi(cb) >= 1 && atoi(cb) <= 64) g->chunk_bytes = (uint32_t)atoi(cb) * 1024u;
+    return g;
+}
+
+void kv_gunzip_close(KvGunzip *g) { delete g; }
+bool kv_gunzip_done(const KvGunzip *g) { return g->done; }
+double kv_gunzip_ratio(const KvGunzip *g) { return g->ratio; }
+void kv_gunzip_stats(const KvGunzip *g, uint64_t out[4])
+{
+    out[0] = g->stat_segments; out[1] = g->stat_jobs; out[2] = g->stat_dropped; out[3] = g->stat_repairs;
+}
+
+static int gz_run_jobs(KvGunzip *g, const uint8_t *d_comp, uint64_t n_bytes, bool is_file_end, const GzJob *jobs, size_t n, GzJob *d_jobs,
+                       GzResult *d_results, unsigned long long *d_ctr, uint16_t *d_syms, GzResult *results)
+{
+    hipStream_t st = kv_stream();
+    KV_HIP(hipMemcpyAsync(d_jobs, jobs, n * sizeof(GzJob), hipMemcpyHostToDevice, st));
+    KV_HIP(hipMemsetAsync(d_ctr, 0, 8, st));
+    {
+        KvProfScope prof("k_gz_decode");
+        const unsigned grid = (unsigned)std::min<uint64_t>(n, 32ull * (uint64_t)kv_device_cus());       // 8 waves per SIMD: LDS and VGPRs allow it
+        hipLaunchKernelGGL(k_gz_decode, dim3(grid), dim3(64), 0, st, d_comp, n_bytes, is_file_end ? 1 : 0, (const GzJob *)d_jobs, (uint32_t)n, d_syms, d_results, d_ctr);
+    }
+    KV_HIP(hipGetLastError());
+    KV_HIP(hipMemcpyAsync(results, d_results, n * sizeof(GzResult), hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    (void)g;
+    return KV_OK;
+}
+
+// Decode the next segment: about `want_text` bytes of text (at least one chunk).  *text_bytes = what kv_gunzip_emit will
+// deliver.  KV_ERR_TYPE: the stream is not something this decoder handles (the caller falls back to zlib).
+int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool *last)
+{
+    *text_bytes = 0;
+    *last = g->done;
+    KV_REQUIRE(!g->pending, KV_ERR_ARG, "kv_gunzip_decode: the previous segment has not been emitted");
+    if (g->done) return KV_OK;
+    hipStream_t st = kv_stream();
+    const uint32_t CH = g->chunk_bytes;
+    const uint64_t margin = 4ull << 20;
+    // ---- the compressed bytes of the segment, and behind them a margin in which the next segment's first block is looked for
+    const uint64_t first_byte = (g->pos_bit >> 3) & ~255ull;
+    const uint64_t seg = std::max<uint64_t>((uint64_t)((double)want_text / g->ratio), 4ull * CH);
+    const uint64_t seg_end = std::min<uint64_t>(kv_round_up(first_byte + seg, CH), g->size);
+    const uint64_t upto = std::min<uint64_t>(seg_end + margin, g->size);
+    const bool to_file_end = seg_end == g->size, is_file_end = upto == g->size;
+    const uint64_t n_bytes = upto - first_byte;
+    const uint32_t n_chunks = (uint32_t)((n_bytes + CH - 1) / CH);
+    KV_HIP(g->comp.need(kv_round_up((uint64_t)n_chunks * CH + 2 * GZ_SLACK, 4096)));
+    uint8_t *d_comp = (uint8_t *)g->comp.p;
+    KV_HIP(hipMemcpyAsync(d_comp, g->image + first_byte, n_bytes, hipMemcpyHostToDevice, st));
+    KV_HIP(hipMemsetAsync(d_comp + n_bytes, 0, (uint64_t)n_chunks * CH + 2 * GZ_SLACK - n_bytes, st));
+    KV_HIP(g->small.need(kv_round_up((uint64_t)n_chunks * 8, 256) + 256));
+    unsigned long long *d_cand = (unsigned long long *)g->small.p;
+    unsigned long long *d_ctr = (unsigned long long *)((unsigned char *)g->small.p + kv_round_up((uint64_t)n_chunks * 8, 256));
+    {
+        KvProfScope prof("k_gz_find");
+        hipLaunchKernelGGL(k_gz_find, dim3(n_chunks), dim3(GZ_FIND_THREADS), CH + GZ_SLACK + 8, st, (const uint8_t *)d_comp, n_bytes, CH, n_chunks, d_cand);
+    }
+    KV_HIP(hipGetLastError());
+    std::vector<unsigned long long> cand(n_chunks);
+    KV_HIP(hipMemcpyAsync(cand.data(), d_cand, (uint64_t)n_chunks * 8, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    // ---- stretches: from the exact position the last segment ended at, then from every found start up to the first one
+    // behind the segment
+    const uint64_t start_rel = g->pos_bit - first_byte * 8, seg_end_rel = (seg_end - first_byte) * 8;
+    std::vector<uint64_t> starts(1, start_rel);
+    bool have_terminal = false;
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        if (cand[c] == ~0ull || cand[c] <= start_rel) continue;
+        starts.push_back(cand[c]);
+        if (!to_file_end && cand[c] >= seg_end_rel) { have_terminal = true; break; }
+    }
+    if (!to_file_end && !have_terminal && !is_file_end) {
+        kv_set_error("no DEFLATE block start within %llu MB behind byte %llu", (unsigned long long)(margin >> 20), (unsigned long long)seg_end);
+        return KV_ERR_TYPE;
+    }                                                  // (none before the end of the file: the last stretch runs to the end)
+    const size_t n_first = have_terminal ? starts.size() - 1 : starts.size();
+    const uint64_t stop_rel = have_terminal ? starts.back() : ~0ull;             // reaching it ends the segment
+    const double factor = std::min(std::max(2.5 * g->ratio, 8.0), 64.0);
+    std::vector<GzJob> jobs(n_first);
+    uint64_t total_cap = 0;
+    for (size_t j = 0; j < n_first; ++j) {
+        const uint64_t next = j + 1 < starts.size() ? starts[j + 1] : n_bytes * 8;
+        jobs[j].start_bit = starts[j];
+        jobs[j].target_bit = j + 1 < starts.size() ? starts[j + 1] : ~0ull;
+        jobs[j].out_off = total_cap;
+        jobs[j].out_cap = (uint32_t)std::min<uint64_t>((uint64_t)((double)((next - starts[j]) / 8 + 1) * factor) + 16384, 0x7ffffff0u);
+        jobs[j].pad = 0;
+        total_cap += kv_round_up(jobs[j].out_cap, 64);
+    }
+    const uint64_t repair_room = std::max<uint64_t>(64ull << 20, total_cap / 8);
+    const size_t max_jobs = n_first + 256;
+    KV_HIP(g->syms.need((total_cap + repair_room) * 2 + 256));
+    KV_HIP(g->meta.need(kv_round_up(max_jobs * sizeof(GzJob), 256) + kv_round_up(max_jobs * sizeof(GzResult), 256) + kv_round_up(max_jobs * 8, 256) * 2 +
+                        kv_round_up(max_jobs * 4, 256)));
+    GzJob *d_jobs = (GzJob *)g->meta.p;
+    GzResult *d_results = (GzResult *)((unsigned char *)d_jobs + kv_round_up(max_jobs * sizeof(GzJob), 256));
+    uint64_t *d_off = (uint64_t *)((unsigned char *)d_results + kv_round_up(max_jobs * sizeof(GzResult), 256));
+    uint64_t *d_base = (uint64_t *)((unsigned char *)d_off + kv_round_up(max_jobs * 8, 256));
+    uint32_t *d_n = (uint32_t *)((unsigned char *)d_base + kv_round_up(max_jobs * 8, 256));
+    uint16_t *d_syms = (uint16_t *)g->syms.p;
+    std::vector<GzResult> results(n_first);
+    { const int rc = gz_run_jobs(g, d_comp, n_bytes, is_file_end, jobs.data(), n_first, d_jobs, d_results, d_ctr, d_syms, results.data()); if (rc != KV_OK) return rc; }
+    // ---- the chain: stretch 0 starts at a known block; a later one counts iff a good stretch ends exactly on its start
+    g->v_off.clear(); g->v_n.clear(); g->v_base.clear();
+    uint64_t repair_used = 0, text = 0, end_rel = 0;
+    uint32_t repairs = 0;
+    bool ended = false;
+    GzJob cur_job = jobs[0];
+    GzResult cur = results[0];
+    for (;;) {
+        if (cur.status == GZ_FULL || (cur.status == GZ_LANDED && cur.end_bit < stop_rel && !std::binary_search(starts.begin() + 1, starts.end(), cur.end_bit))) {
+            // out of room, or the stretch ran over a false start and stopped at a block nobody began at: decode again, from
+            // this stretch's start (for room) or from where it stopped, as a stretch of its own
+            GzJob again;
+            if (cur.status == GZ_FULL) {
+                again = cur_job;
+                again.out_cap = (uint32_t)std::min<uint64_t>((uint64_t)cur_job.out_cap * 8, 0x7ffffff0u);
+            } else {
+                g->v_off.push_back(cur_job.out_off); g->v_n.push_back(cur.n_out); g->v_base.push_back(text);
+                text += cur.n_out;
+                again.start_bit = cur.end_bit;
+                const auto nx = std::upper_bound(starts.begin() + 1, starts.end(), cur.end_bit);
+                again.target_bit = nx == starts.end() ? ~0ull : *nx;
+                const uint64_t next = nx == starts.end() ? n_bytes * 8 : *nx;
+                again.out_cap = (uint32_t)std::min<uint64_t>((uint64_t)((double)((next - again.start_bit) / 8 + 1) * factor) + 16384, 0x7ffffff0u);
+            }
+            again.pad = 0;
+            again.out_off = total_cap + repair_used;
+            repair_used += kv_round_up(again.out_cap, 64);
+            if (++repairs > 200 || repair_used > repair_room || (cur.status == GZ_FULL && cur_job.out_cap >= 0x7ffffff0u)) {
+                kv_set_error("gzip stream at byte %llu: too many stretches needed decoding again", (unsigned long long)(first_byte + cur_job.start_bit / 8));
+                return KV_ERR_TYPE;
+            }
+            GzResult r;
+            { const int rc = gz_run_jobs(g, d_comp, n_bytes, is_file_end, &again, 1, d_jobs, d_results, d_ctr, d_syms, &r); if (rc != KV_OK) return rc; }
+            cur_job = again;
+            cur = r;
+            continue;
+        }
+        if (cur.status == GZ_BAD || cur.status == GZ_SHORT) {
+            kv_set_error("gzip stream: %s near byte %llu", cur.status == GZ_BAD ? "invalid DEFLATE data" : "data end inside a block",
+                         (unsigned long long)(first_byte + cur.end_bit / 8));
+            return KV_ERR_TYPE;
+        }
+        g->v_off.push_back(cur_job.out_off); g->v_n.push_back(cur.n_out); g->v_base.push_back(text);
+        text += cur.n_out;
+        end_rel = cur.end_bit;
+        if (cur.status == GZ_END) { ended = true; break; }
+        if (cur.end_bit >= stop_rel) break;
+        const size_t k = (size_t)(std::lower_bound(starts.begin() + 1, starts.end(), cur.end_bit) - starts.begin());     // exists: checked above
+        cur_job = jobs[k];
+        cur = results[k];
+    }
+    const size_t nv = g->v_off.size();
+    g->stat_segments += 1;
+    g->stat_jobs += n_first;
+    g->stat_dropped += n_first + repairs - nv;
+    g->stat_repairs += repairs;
+    // ---- tails, resolved by pointer doubling
+    if (!g->window_ready) {
+        KV_HIP(g->window.need(GZ_WIN));
+        KV_HIP(hipMemsetAsync(g->window.p, 0, GZ_WIN, st));         // nothing valid points in front of the first byte
+        g->window_ready = true;
+    }
+    KV_HIP(g->tails.need((uint64_t)(nv + 1) * GZ_WIN * 2 * 2));
+    uint16_t *t0 = (uint16_t *)g->tails.p, *t1 = t0 + (uint64_t)(nv + 1) * GZ_WIN;
+    KV_HIP(hipMemcpyAsync(d_off, g->v_off.data(), nv * 8, hipMemcpyHostToDevice, st));
+    KV_HIP(hipMemcpyAsync(d_base, g->v_base.data(), nv * 8, hipMemcpyHostToDevice, st));
+    KV_HIP(hipMemcpyAsync(d_n, g->v_n.data(), nv * 4, hipMemcpyHostToDevice, st));
+    {
+        KvProfScope prof("k_gz_tails");
+        hipLaunchKernelGGL(k_gz_tails, dim3((unsigned)(nv + 1)), dim3(256), 0, st, (const uint16_t *)d_syms, (const uint64_t *)d_off, (const uint32_t *)d_n,
+                           (const uint8_t *)g->window.p, t0);
+    }
+    {
+        KvProfScope prof("k_gz_scan");
+        for (uint64_t d = 1; d < nv + 1; d <<= 1) {
+            hipLaunchKernelGGL(k_gz_scan, dim3((unsigned)(nv + 1)), dim3(256), 0, st, (const uint16_t *)t0, t1, (uint32_t)d);
+            std::swap(t0, t1);
+        }
+    }
+    KV_HIP(hipGetLastError());
+    g->d_tails = t0;                          // plain text now
+    g->d_off = d_off; g->d_base = d_base; g->d_n = d_n;
+    g->pending = true;
+    g->pending_text = text;
+    g->pending_pos = first_byte * 8 + end_rel;
+    g->pending_done = ended;
+    *text_bytes = text;
+    *last = ended;
+    if (text == 0) {                          // nothing to emit (an empty member at the end of the file)
+        g->pending = false;
+        g->pos_bit = g->pending_pos;
+        g->done = ended;
+    }
+    return KV_OK;
+}
+
+// The text of the decoded segment -> d_text (device, *text_bytes of kv_gunzip_decode), on the calling thread's stream.
+int kv_gunzip_emit(KvGunzip *g, uint8_t *d_text)
+{
+    KV_REQUIRE(g->pending, KV_ERR_ARG, "kv_gunzip_emit: nothing decoded");
+    hipStream_t st = kv_stream();
+    const size_t nv = g->v_off.size();
+    const uint16_t *tails = g->d_tails;
+    {
+        KvProfScope prof("k_gz_resolve");
+        hipLaunchKernelGGL(k_gz_resolve, dim3((unsigned)(nv * GZ_RESOLVE_SPLIT)), dim3(256), 0, st, (const uint16_t *)g->syms.p, g->d_off, g->d_n, g->d_base, tails, d_text);
+        hipLaunchKernelGGL(k_gz_window_out, dim3(16), dim3(256), 0, st, tails + (uint64_t)nv * GZ_WIN, (uint8_t *)g->window.p);
+    }
+    KV_HIP(hipGetLastError());
+    g->seen_comp += (g->pending_pos - g->pos_bit) / 8;
+    g->seen_text += g->pending_text;
+    if (g->seen_comp > 0) g->ratio = std::max(1.0, (double)g->seen_text / (double)g->seen_comp);
+    g->pos_bit = g->pending_pos;
+    g->done = g->pending_done;
+    g->pending = false;
+    return KV_OK;
+}
+
+// Whole-buffer form for tests and tools: a gzip image in host memory -> its text in host memory, `segment_text` bytes of
+// text (roughly) per segment.  stats: segments, stretches decoded, dropped, decoded again.
+extern "C" int kv_gunzip_host(const void *file, uint64_t size, void *out, uint64_t out_cap, uint64_t segment_text, uint64_t *text_bytes,
+                              uint64_t *stats, double *device_ms)
+{
+    KV_REQUIRE(file && out && text_bytes, KV_ERR_ARG, "kv_gunzip_host: null argument");
+    KvGunzip *g = kv_gunzip_open((const uint8_t *)file, size);
+    KV_REQUIRE(g, KV_ERR_TYPE, "not a gzip file image");
+    hipStream_t st = kv_stream();
+    KvArena text;
+    uint64_t total = 0;
+    int rc = KV_OK;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    float ms_sum = 0;
+    while (rc == KV_OK && !kv_gunzip_done(g)) {
+        uint64_t n = 0;
+        (void)hipEventRecord(a, st);
+        bool last = false;
+        rc = kv_gunzip_decode(g, segment_text ? segment_text : (1ull << 30), &n, &last);
+        if (rc != KV_OK) break;
+        if (n == 0) continue;
+        if (text.need(n + 256) != hipSuccess) { kv_set_error("kv_gunzip_host: out of device memory"); rc = KV_ERR_HIP; break; }
+        rc = kv_gunzip_emit(g, (uint8_t *)text.p);
+        if (rc != KV_OK) break;
+        (void)hipEventRecord(b, st);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        ms_sum += ms;
+        if (total + n > out_cap) { kv_set_error("kv_gunzip_host: the text needs more than %llu bytes", (unsigned long long)out_cap); rc = KV_ERR_CAPACITY; break; }
+        if (n && hipMemcpy((uint8_t *)out + total, text.p, n, hipMemcpyDeviceToHost) != hipSuccess) { kv_set_error("kv_gunzip_host: copy failed"); rc = KV_ERR_HIP; break; }
+        total += n;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (stats) kv_gunzip_stats(g, stats);
+    if (device_ms) *device_ms = ms_sum;
+    if (text.p) (void)hipFree(text.p);
+    kv_gunzip_close(g);
+    *text_bytes = total;
+    return rc;
+}

@@ -237,9 +237,20 @@ int kv_bgzf_index(const uint8_t *file, uint64_t size, std::vector<KvBgzfMember> 
 int kv_bgzf_inflate(const uint8_t *d_comp, uint64_t comp_base, const KvBgzfMember *members, uint64_t count, const uint64_t *text_off,
                     uint8_t *d_text, KvArena &scratch);
 
+// ---- ordinary gzip on the device (kv_gunzip.hip): a segment of the stream per decode/emit pair ----
+struct KvGunzip;
+KvGunzip *kv_gunzip_open(const uint8_t *image, uint64_t size);  // NULL unless the image starts with a gzip member header
+void kv_gunzip_close(KvGunzip *g);
+bool kv_gunzip_done(const KvGunzip *g);
+// decode about want_text bytes of text; *text_bytes = how many kv_gunzip_emit will store, *last = the stream ends with them.
+// KV_ERR_TYPE: not for this decoder
+int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool *last);
+int kv_gunzip_emit(KvGunzip *g, uint8_t *d_text);
+void kv_gunzip_stats(const KvGunzip *g, uint64_t out[4]);       // segments, stretches decoded, dropped, decoded again
+
 // ---- FASTQ split and packed on the device (kv_fastq.hip) ----
 struct KvFastqDevice;
-KvFastqDevice *kv_fastq_device_open(const char *path);         // NULL unless the file is BGZF from end to end
+KvFastqDevice *kv_fastq_device_open(const char *path);         // NULL unless the file is BGZF, gzip or starts with '@'
 void kv_fastq_device_close(KvFastqDevice *d);
 // up to max_reads records as a batch in HBM (*n_out = 0 at the end of the file); KV_ERR_TYPE = not four-line FASTQ
 int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_out, uint64_t *n_out);
