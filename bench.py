@@ -539,6 +539,7 @@ def end_to_end(args, wl, packed, names, synth):
             with open(os.path.join(tmp, name + '.fq'), 'wb') as fh:
                 fh.write(text)
             bgzf.write_file(os.path.join(tmp, name + '.bgzf.fq.gz'), text, level=4, threads=workers)   # what kevlar_amd.open(..., 'w') writes
+            write_gzip(os.path.join(tmp, name + '.fq.gz'), text, level=4, threads=workers)             # what gzip / pigz write
             del text
         saved, kevlar_amd.logstream = kevlar_amd.logstream, io.StringIO()
         mem = '{:d}'.format(int(wl['memory']))
@@ -562,6 +563,7 @@ def end_to_end(args, wl, packed, names, synth):
             # loaded kernels
             dt_plain = min(novel_run('.fq'), novel_run('.fq'))
             dt_bgzf = min(novel_run('.bgzf.fq.gz'), novel_run('.bgzf.fq.gz'))
+            dt_gzip = min(novel_run('.fq.gz'), novel_run('.fq.gz'))
             novel_out = os.path.join(tmp, 'novel.bgzf.fq.gz.augfastq')
             dt_filter = stage(['filter', '--memory', '50M', '--case-min', str(args.case_min), '--ctrl-max', str(args.ctrl_max),
                                '-o', os.path.join(tmp, 'filtered.augfastq'), novel_out])
@@ -571,10 +573,13 @@ def end_to_end(args, wl, packed, names, synth):
             kevlar_amd.logstream = saved
         grouped = [line for line in log_text.split('\n') if 'grouped' in line]
         with open(os.path.join(tmp, 'novel.fq.augfastq')) as a, open(os.path.join(tmp, 'novel.bgzf.fq.gz.augfastq')) as b:
-            assert a.read() == b.read(), 'host-parsed and device-parsed input must give the same annotated reads'
+            assert a.read() == b.read(), 'plain and blocked-gzip input must give the same annotated reads'
+        with open(os.path.join(tmp, 'novel.fq.augfastq')) as a, open(os.path.join(tmp, 'novel.fq.gz.augfastq')) as b:
+            assert a.read() == b.read(), 'plain and gzip input must give the same annotated reads'
         ingest = ingest_rates(os.path.join(tmp, 'proband.fq'), os.path.join(tmp, 'proband.bgzf.fq.gz'), n)
         return {'value': round(len(names) * n / dt_plain, 1), 'unit': 'reads/s',
                 'from_bgzf_fastq_gz': round(len(names) * n / dt_bgzf, 1),
+                'from_gzip_fastq_gz': round(len(names) * n / dt_gzip, 1),
                 'whole_path': {'reads_per_s': round(len(names) * n / (dt_bgzf + dt_filter + dt_partition), 1),
                                'novel_s': round(dt_bgzf, 3), 'filter_s': round(dt_filter, 3), 'partition_s': round(dt_partition, 3),
                                'result': grouped[-1].split('] ')[-1] if grouped else None,
@@ -584,19 +589,41 @@ def end_to_end(args, wl, packed, names, synth):
                 'sample': '{} reads per sample as FASTQ on local disk ({} MB each plain, {} MB blocked gzip); one `kevlar novel --case ... '
                           '--control ...` run: every sample parsed, packed and counted, the case sample parsed again and scanned, annotated '
                           'reads written (better of two runs): {:.2f} s from plain FASTQ (uploaded as text, split and packed on the GPU), {:.2f} s from BGZF .fq.gz '
-                          '(inflated, split and packed on the GPU); identical output'.format(n, os.path.getsize(os.path.join(tmp, 'proband.fq')) >> 20,
-                                                               os.path.getsize(os.path.join(tmp, 'proband.bgzf.fq.gz')) >> 20, dt_plain, dt_bgzf)}
+                          '(inflated, split and packed on the GPU), {:.2f} s from ordinary gzip (one DEFLATE stream per file, {} MB, inflated on the '
+                          'GPU in parallel stretches); identical output'.format(n, os.path.getsize(os.path.join(tmp, 'proband.fq')) >> 20,
+                                                               os.path.getsize(os.path.join(tmp, 'proband.bgzf.fq.gz')) >> 20, dt_plain, dt_bgzf,
+                                                               dt_gzip, os.path.getsize(os.path.join(tmp, 'proband.fq.gz')) >> 20)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def write_gzip(path, text, level=4, threads=1, piece=1 << 20):
+    """`text` as ONE gzip member holding one DEFLATE stream, compressed on `threads` cores the way pigz does it: pieces
+    deflated independently, all but the last ended by a sync flush, joined end to end (what most pipelines hand over
+    as .fq.gz; kevlar_amd.open(..., 'w') writes BGZF instead)"""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    view = memoryview(text)
+    cuts = list(range(0, len(view), piece)) or [0]
+
+    def deflate(at):
+        z = zlib.compressobj(level, zlib.DEFLATED, -15)
+        last = at + piece >= len(view)
+        return z.compress(view[at:at + piece]) + z.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH)
+    with ThreadPoolExecutor(max(1, threads)) as pool, open(path, 'wb') as out:
+        out.write(b'\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03')
+        for part in pool.map(deflate, cuts):
+            out.write(part)
+        out.write(struct.pack('<II', zlib.crc32(view) & 0xffffffff, len(view) & 0xffffffff))
+
+
 def ingest_rates(fastq, bgzf_gz, n):
     """reads/s from a file on disk to 2-bit packed batches in HBM (the reader alone, no count): plain FASTQ (text uploaded,
-    records split and packed on the GPU: kv_fastq.hip), plain gzip on the host (one zlib stream: the inflate rate of one
-    core), blocked gzip inflated and parsed on the GPU (kv_inflate.hip), and the packed-read cache a first pass leaves
-    behind (KEVLAR_PACK_CACHE=1)"""
-    import gzip
-    import shutil
+    records split and packed on the GPU: kv_fastq.hip), ordinary gzip -- one DEFLATE stream -- inflated on the GPU in
+    parallel stretches (kv_gunzip.hip) and, for comparison, by zlib on one host core (KV_GUNZIP=host), blocked gzip
+    inflated on the GPU one member per wavefront (kv_inflate.hip), and the packed-read cache a first pass leaves behind
+    (KEVLAR_PACK_CACHE=1)"""
     from kevlar_amd import khmer as hk
 
     def drain(path):
@@ -610,10 +637,13 @@ def ingest_rates(fastq, bgzf_gz, n):
             batch.close()
         assert got == n
         return round(n / (time.perf_counter() - t0), 1)
-    gz = fastq + '.gz'
-    with open(fastq, 'rb') as src, gzip.open(gz, 'wb', compresslevel=1) as dst:
-        shutil.copyfileobj(src, dst)
-    out = {'fastq': drain(fastq), 'fastq_gz': drain(gz), 'fastq_bgzf_gz_on_device': max(drain(bgzf_gz), drain(bgzf_gz))}
+    gz = fastq + '.gz'                   # written by end_to_end: one gzip stream
+    out = {'fastq': drain(fastq), 'fastq_gz_on_device': max(drain(gz), drain(gz)), 'fastq_bgzf_gz_on_device': max(drain(bgzf_gz), drain(bgzf_gz))}
+    os.environ['KV_GUNZIP'] = 'host'
+    try:
+        out['fastq_gz_host_zlib'] = drain(gz)
+    finally:
+        os.environ.pop('KV_GUNZIP', None)
     os.environ['KEVLAR_PACK_CACHE'] = '1'
     try:
         out['fastq_gz_first_pass_writing_cache'] = drain(gz)

@@ -313,7 +313,8 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         const uint64_t b0 = d->next_byte;
         bool gz_last = false;
         if (d->gz) {
-            const int rc = kv_gunzip_decode(d->gz, want > d->carry_len + (1u << 20) ? want - d->carry_len : (1u << 20), &fresh, &gz_last);
+            const uint64_t ask = want > d->carry_len + (1u << 20) ? want - d->carry_len : (1u << 20);
+            const int rc = kv_gunzip_decode(d->gz, ask + ask / 20, &fresh, &gz_last);
             if (rc != KV_OK) return rc;
         } else if (d->plain) {
             fresh = std::min<uint64_t>(d->image_size - b0, want > d->carry_len + 65536 ? want - d->carry_len : 65536);
@@ -362,11 +363,15 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         KV_HIP(hipMemcpyAsync(&n_lines, d_base + n_chunks, 8, hipMemcpyDeviceToHost, st));
         KV_HIP(hipStreamSynchronize(st));
         uint64_t n = std::min<uint64_t>(n_lines / 4, max_reads);
-        if (n == 0 && !final && d->gz) {  // not one whole record yet: what has been inflated waits as the carry
+        if (d->gz && !final && n_lines / 4 < max_reads && (total_in < text_cap || n_lines < 4)) {
+            // the segment held fewer records than asked for (its size is a guess from the compression ratio so far) and the text
+            // budget is not spent: what has been inflated waits as the carry and another segment joins it
+            const uint64_t have = n_lines / 4;
+            const double each = have ? (double)total_in / (double)have : per_read;
             d->cur = nxt;
             d->carry_at = 0;
             d->carry_len = total_in;
-            want = want * 2 + 65536;
+            want = std::min<uint64_t>(total_in + (uint64_t)((double)(max_reads - have) * each * 1.05) + (1u << 20), std::max<uint64_t>(text_cap, total_in + (1u << 20)));
             continue;
         }
         if (n == 0 && !final) {           // not one whole record yet (huge records or a tiny budget): take more members

@@ -38,12 +38,10 @@ namespace {
 
 #define GZ_WIN 32768u
 #define GZ_MARK 0x8000u
-#define GZ_RBITS 10                  // the decoder's LDS window: the last 1024 symbols
 #define GZ_FAST_LL 9                 // bits of the literal/length lookup table (9: 32 workgroups of LDS per CU)
 #define GZ_SLACK 2048u               // readable zero bytes behind the compressed buffer
 #define GZ_FIND_THREADS 256
-#define GZ_FIND_SPAN 8192u           // bit offsets tried per pass of a workgroup
-#define GZ_FIND_LIST 256u
+#define GZ_FIND_LIST 1024u           // survivors of the cheap test a chunk may have (more: the later ones are not looked at)
 
 enum { GZ_LANDED = 0, GZ_END = 1, GZ_BAD = 2, GZ_FULL = 3, GZ_SHORT = 4 };
 
@@ -57,7 +55,10 @@ struct GzJob {
 struct GzResult {
     uint64_t end_bit;
     uint32_t n_out;
-    uint32_t status;
+    uint16_t status;
+    uint16_t members;                // member trailers the stretch passed,
+    uint32_t isize_sum;              // ... and the sum of their ISIZE fields
+    uint32_t pad;
 };
 
 __device__ __forceinline__ void br_seek(BitReader &br, const uint32_t *words, uint64_t bit)
@@ -108,7 +109,7 @@ __device__ bool gz_header_full(const uint32_t *w, uint32_t p, uint32_t limit_bit
     const uint32_t ndist = lds_bits(w, q, 5) + 1u; q += 5;
     const uint32_t ncode = lds_bits(w, q, 4) + 4u; q += 4;
     uint64_t cl = 0;                                   // 19 lengths of 3 bits
-    for (uint32_t s = 0; s < ncode; ++s, q += 3) cl |= (uint64_t)lds_bits(w, q, 3) << (3u * c_clen_order[s]);
+    for (uint32_t s = 0; s < ncode; ++s, q += 3) cl |= (uint64_t)lds_bits(w, q, 3) << (3u * inf_clen_order(s));
     uint64_t cnt = 0;                                  // symbols per length, 8 bits each
     uint64_t sorted_lo = 0, sorted_hi = 0;             // the symbols by (length, symbol), 5 bits each, 12 per word
     uint32_t filled = 0;
@@ -182,21 +183,20 @@ __global__ __launch_bounds__(GZ_FIND_THREADS) void k_gz_find(const uint8_t *__re
     const uint64_t left = n_bytes > base ? n_bytes - base : 0;
     const uint32_t limit_bits = (uint32_t)(left < staged ? left : staged) * 8u;
     const uint32_t chunk_bits = chunk_bytes * 8u < limit_bits ? chunk_bytes * 8u : limit_bits;
-    for (uint32_t span = 0; span < chunk_bits; span += GZ_FIND_SPAN) {
-        if (threadIdx.x == 0) sh_n = 0;
-        __syncthreads();
-        for (uint32_t p = span + threadIdx.x; p < min(span + GZ_FIND_SPAN, chunk_bits); p += GZ_FIND_THREADS)
-            if (gz_header_quick(sh_words, p)) {
-                const uint32_t at = atomicAdd(&sh_n, 1u);
-                if (at < GZ_FIND_LIST) sh_list[at] = p;
-            }
-        __syncthreads();
-        const uint32_t n = min(sh_n, GZ_FIND_LIST);
-        for (uint32_t i = threadIdx.x; i < n; i += GZ_FIND_THREADS)
-            if (gz_header_full(sh_words, sh_list[i], limit_bits)) atomicMin(&sh_best, sh_list[i]);
-        __syncthreads();
-        if (sh_best != ~0u) break;
-    }
+    // every offset through the cheap test (about one in 600 passes), then the survivors through the full one, all at once:
+    // a survivor costs ~300 dependent code-length decodes, so they must not queue up behind each other
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < chunk_bits; p += GZ_FIND_THREADS)
+        if (gz_header_quick(sh_words, p)) {
+            const uint32_t at = atomicAdd(&sh_n, 1u);
+            if (at < GZ_FIND_LIST) sh_list[at] = p;
+        }
+    __syncthreads();
+    const uint32_t n = min(sh_n, GZ_FIND_LIST);
+    for (uint32_t i = threadIdx.x; i < n; i += GZ_FIND_THREADS)
+        if (gz_header_full(sh_words, sh_list[i], limit_bits)) atomicMin(&sh_best, sh_list[i]);
+    __syncthreads();
     if (threadIdx.x == 0) cand[c] = sh_best == ~0u ? ~0ull : base * 8ull + sh_best;
 }
 
@@ -206,8 +206,9 @@ __device__ __forceinline__ bool gz_build_code(const uint8_t *lengths, int n, uin
     return build_code(lengths, n, count, symbol, table, fast);
 }
 
+template <int RBITS>                 // the decoder's LDS window: the last 2^RBITS symbols
 struct GunzipShared {
-    uint16_t ring[1 << GZ_RBITS];
+    uint16_t ring[1 << RBITS];
     uint16_t ll_table[1 << GZ_FAST_LL];
     uint16_t d_table[1 << INF_FAST_D];
     uint16_t ll_count[16], d_count[16];
@@ -236,11 +237,12 @@ __device__ __attribute__((noinline)) uint64_t gz_member_header(const uint8_t *co
     return p + 8 <= n_bytes ? p : ~0ull;
 }
 
-__global__ __launch_bounds__(64, 8) void k_gz_decode(const uint8_t *__restrict__ comp, uint64_t n_bytes, int is_file_end, const GzJob *__restrict__ jobs,
+template <int RBITS>
+__global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 6 : RBITS == 12 ? 3 : RBITS == 13 ? 2 : 1)) void k_gz_decode(const uint8_t *__restrict__ comp, uint64_t n_bytes, int is_file_end, const GzJob *__restrict__ jobs,
                                                       uint32_t n_jobs, uint16_t *syms, GzResult *__restrict__ results, unsigned long long *ctr)
 {
-    __shared__ GunzipShared sh;
-    constexpr uint32_t RMASK = (1u << GZ_RBITS) - 1u;
+    __shared__ GunzipShared<RBITS> sh;
+    constexpr uint32_t RMASK = (1u << RBITS) - 1u;
     const uint32_t lane = threadIdx.x;
     const uint32_t *words = (const uint32_t *)comp;
     const uint64_t limit_words = (n_bytes + 3) / 4 + 2;        // the reader may be this far without having left the data
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(64, 8) void k_gz_decode(const uint8_t *__restrict__
         br_seek(br, words, job.start_bit);
         uint16_t *dst = syms + job.out_off;
         const uint32_t cap = job.out_cap;
-        uint32_t o = 0, lit = 0, n_lit = 0;
+        uint32_t o = 0, lit = 0, n_lit = 0, isize_sum = 0, members = 0;
         int status = -1;
         uint64_t end_bit = job.start_bit;
         auto flush = [&]() {
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(64, 8) void k_gz_decode(const uint8_t *__restrict__
                 for (uint32_t j = lane; j < stored_len; j += 64) {
                     const uint16_t v = comp[from_byte + j];
                     dst[o + j] = v;
-                    if (j + (1u << GZ_RBITS) >= stored_len) sh.ring[(o + j) & RMASK] = v;
+                    if (j + (1u << RBITS) >= stored_len) sh.ring[(o + j) & RMASK] = v;
                 }
                 o += stored_len;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(64, 8) void k_gz_decode(const uint8_t *__restrict__
                     __builtin_amdgcn_wave_barrier();
                     for (uint32_t s = 0; s < ncode; ++s) {
                         const uint32_t v = br_bits(br, 3);
-                        if (lane == 0) sh.lengths[c_clen_order[s]] = (uint8_t)v;
+                        if (lane == 0) sh.lengths[inf_clen_order(s)] = (uint8_t)v;
                     }
                     if (lane == 0) ok = gz_build_code(sh.lengths, 19, sh.d_count, sh.d_symbol, sh.d_table, 7);
                     ok = INF_UNI(ok);
@@ -364,18 +366,18 @@ __global__ __launch_bounds__(64, 8) void k_gz_decode(const uint8_t *__restrict__
                     if (sym == 256) break;
                     const int ls = sym - 257;
                     if (ls >= 29) { status = GZ_BAD; break; }
-                    const uint32_t len = c_len_base[ls] + br_bits(br, c_len_extra[ls]);
+                    const uint32_t len = inf_len_base((uint32_t)ls) + br_bits(br, inf_len_extra((uint32_t)ls));
                     const int ds = decode_sym(br, sh.d_count, sh.d_symbol, sh.d_table, INF_FAST_D);
                     if (ds < 0 || ds >= 30) { status = GZ_BAD; break; }
-                    const uint32_t extra = c_dist_extra[ds];
+                    const uint32_t extra = inf_dist_extra((uint32_t)ds);
                     br_need(br, 16);
-                    const uint32_t dist = c_dist_base[ds] + ((uint32_t)br.buf & ((1u << extra) - 1u));
+                    const uint32_t dist = inf_dist_base((uint32_t)ds) + ((uint32_t)br.buf & ((1u << extra) - 1u));
                     br.buf >>= extra; br.cnt -= extra;
                     if (o + len > cap) { status = GZ_FULL; break; }
                     // a source in front of this wave's first symbol is text somebody else decodes: a marker for position
                     // 32768 + src of the window in front of the stretch stands in for it
                     const int32_t from = (int32_t)o - (int32_t)dist;             // (a stretch holds fewer than 2^31 symbols)
-                    if (dist + 258u <= (1u << GZ_RBITS)) {
+                    if (dist + 258u <= (1u << RBITS)) {
                         for (uint32_t j = lane; j < len; j += 64) {
                             const int32_t src = dist >= len ? from + (int32_t)j : from + (int32_t)(j % dist);
                             const uint16_t v = src < 0 ? (uint16_t)(GZ_MARK | (uint32_t)((int32_t)GZ_WIN + src)) : sh.ring[(uint32_t)src & RMASK];
@@ -402,6 +404,8 @@ __global__ __launch_bounds__(64, 8) void k_gz_decode(const uint8_t *__restrict__
                 // the member's trailer (CRC-32, ISIZE), then the end of the file or another member
                 uint64_t at = ((br_pos(br) + 7) >> 3) + 8;
                 if (at > n_bytes) { status = GZ_SHORT; break; }
+                isize_sum += INF_UNI(comp[at - 4] | (comp[at - 3] << 8) | (comp[at - 2] << 16) | ((uint32_t)comp[at - 1] << 24));
+                members += 1;
                 if (at == n_bytes) {
                     end_bit = at * 8;
                     status = is_file_end ? GZ_END : GZ_SHORT;
@@ -419,7 +423,10 @@ __global__ __launch_bounds__(64, 8) void k_gz_decode(const uint8_t *__restrict__
             GzResult r;
             r.end_bit = end_bit;
             r.n_out = o;
-            r.status = (uint32_t)status;
+            r.status = (uint16_t)status;
+            r.members = (uint16_t)min(members, 65535u);
+            r.isize_sum = isize_sum;
+            r.pad = 0;
             results[job_id] = r;
         }
         __builtin_amdgcn_wave_barrier();
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(64, 8) void k_gz_decode(const uint8_t *__restrict__
 // tail q (q = 0: the window the segment starts with, as bytes; q > 0: stretch q - 1): the 32 K symbols in front of
 // stretch q.  A stretch shorter than the window passes the rest of the tail before it through as markers.
 __global__ void k_gz_tails(const uint16_t *__restrict__ syms, const uint64_t *__restrict__ out_off, const uint32_t *__restrict__ n_out,
-                           const uint8_t *__restrict__ window_in, uint16_t *__restrict__ tails)
+                           const uint8_t *__restrict__ window_in, uint16_t *__restrict__ tails, unsigned long long *__restrict__ n_markers)
 {
     const uint32_t q = blockIdx.x;
     uint16_t *t = tails + (size_t)q * GZ_WIN;
@@ -440,14 +447,18 @@ __global__ void k_gz_tails(const uint16_t *__restrict__ syms, const uint64_t *__
     }
     const uint32_t n = n_out[q - 1];
     const uint16_t *src = syms + out_off[q - 1];
+    uint32_t marked = 0;
     for (uint32_t i = threadIdx.x; i < GZ_WIN; i += blockDim.x) {
         const int64_t rel = (int64_t)n - (int64_t)GZ_WIN + i;
-        t[i] = rel >= 0 ? src[rel] : (uint16_t)(GZ_MARK | (uint32_t)(GZ_WIN + rel));
+        const uint16_t v = rel >= 0 ? src[rel] : (uint16_t)(GZ_MARK | (uint32_t)(GZ_WIN + rel));
+        marked += v >> 15;
+        t[i] = v;
     }
+    if (marked) atomicAdd(n_markers, (unsigned long long)marked);
 }
 
-// one round of pointer doubling: the markers of tail q name positions of tail q - d
-__global__ void k_gz_scan(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, uint32_t d)
+// one round of pointer doubling: the markers of tail q name positions of tail q - d.  *n_markers: how many are left.
+__global__ void k_gz_scan(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, uint32_t d, unsigned long long *__restrict__ n_markers)
 {
     const uint32_t q = blockIdx.x;
     const uint16_t *t = in + (size_t)q * GZ_WIN;
@@ -457,11 +468,14 @@ __global__ void k_gz_scan(const uint16_t *__restrict__ in, uint16_t *__restrict_
         return;
     }
     const uint16_t *before = in + (size_t)(q - d) * GZ_WIN;
+    uint32_t marked = 0;
     for (uint32_t i = threadIdx.x; i < GZ_WIN; i += blockDim.x) {
         uint16_t v = t[i];
         if (v & GZ_MARK) v = before[v & (GZ_WIN - 1u)];
+        marked += v >> 15;
         o[i] = v;
     }
+    if (marked) atomicAdd(n_markers, (unsigned long long)marked);
 }
 
 // ---------------------------------------------------------------- 4. bytes
@@ -516,17 +530,19 @@ struct KvGunzip {
     bool done = false;
     double ratio = 4.0;               // text bytes per compressed byte so far
     uint64_t seen_comp = 0, seen_text = 0;
+    uint32_t isize_total = 0;         // of the members that have ended so far (mod 2^32, as the field is)
     uint32_t chunk_bytes = 16384;
     KvArena comp, syms, tails, meta, window, small;
     // the segment decoded by kv_gunzip_decode and not yet emitted
     std::vector<uint64_t> v_off, v_base;
     std::vector<uint32_t> v_n;
     uint64_t pending_text = 0, pending_pos = 0;
+    uint32_t pending_isize = 0;
     bool pending_done = false, pending = false, window_ready = false;
     const uint64_t *d_off = nullptr, *d_base = nullptr;           // device copies of v_off / v_base / v_n
     const uint32_t *d_n = nullptr;
     const uint16_t *d_tails = nullptr;                            // the resolved tails of the pending segment
-    uint64_t stat_jobs = 0, stat_dropped = 0, stat_repairs = 0, stat_segments = 0;
+    uint64_t stat_jobs = 0, stat_dropped = 0, stat_repairs = 0, stat_segments = 0, stat_rounds = 0;
     ~KvGunzip()
     {
         for (KvArena *a : {&comp, &syms, &tails, &meta, &window, &small})
@@ -563,8 +579,19 @@ static int gz_run_jobs(KvGunzip *g, const uint8_t *d_comp, uint64_t n_bytes, boo
     KV_HIP(hipMemsetAsync(d_ctr, 0, 8, st));
     {
         KvProfScope prof("k_gz_decode");
-        const unsigned grid = (unsigned)std::min<uint64_t>(n, 32ull * (uint64_t)kv_device_cus());       // 8 waves per SIMD: LDS and VGPRs allow it
-        hipLaunchKernelGGL(k_gz_decode, dim3(grid), dim3(64), 0, st, d_comp, n_bytes, is_file_end ? 1 : 0, (const GzJob *)d_jobs, (uint32_t)n, d_syms, d_results, d_ctr);
+        // the LDS window sets how many stretches a CU holds (1 K symbols: 32 = 8 waves per SIMD); a match that reaches further
+        // back reads the symbols the wave itself stored to HBM, behind a workgroup-scope release
+        const char *rb = getenv("KV_GUNZIP_RING_BITS");
+        const int bits = rb ? atoi(rb) : 10;
+        const int per_cu = bits >= 14 ? 4 : bits == 13 ? 8 : bits == 12 ? 12 : bits == 11 ? 24 : 32;
+        const unsigned grid = (unsigned)std::min<uint64_t>(n, (uint64_t)per_cu * (uint64_t)kv_device_cus());
+#define KV_LAUNCH_GZ(B_) hipLaunchKernelGGL(k_gz_decode<B_>, dim3(grid), dim3(64), 0, st, d_comp, n_bytes, is_file_end ? 1 : 0, (const GzJob *)d_jobs, (uint32_t)n, d_syms, d_results, d_ctr)
+        if (bits >= 14) KV_LAUNCH_GZ(14);
+        else if (bits == 13) KV_LAUNCH_GZ(13);
+        else if (bits == 12) KV_LAUNCH_GZ(12);
+        else if (bits == 11) KV_LAUNCH_GZ(11);
+        else KV_LAUNCH_GZ(10);
+#undef KV_LAUNCH_GZ
     }
     KV_HIP(hipGetLastError());
     KV_HIP(hipMemcpyAsync(results, d_results, n * sizeof(GzResult), hipMemcpyDeviceToHost, st));
@@ -651,7 +678,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     // ---- the chain: stretch 0 starts at a known block; a later one counts iff a good stretch ends exactly on its start
     g->v_off.clear(); g->v_n.clear(); g->v_base.clear();
     uint64_t repair_used = 0, text = 0, end_rel = 0;
-    uint32_t repairs = 0;
+    uint32_t repairs = 0, isize_seg = 0;
     bool ended = false;
     GzJob cur_job = jobs[0];
     GzResult cur = results[0];
@@ -666,6 +693,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
             } else {
                 g->v_off.push_back(cur_job.out_off); g->v_n.push_back(cur.n_out); g->v_base.push_back(text);
                 text += cur.n_out;
+                isize_seg += cur.isize_sum;
                 again.start_bit = cur.end_bit;
                 const auto nx = std::upper_bound(starts.begin() + 1, starts.end(), cur.end_bit);
                 again.target_bit = nx == starts.end() ? ~0ull : *nx;
@@ -692,6 +720,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
         }
         g->v_off.push_back(cur_job.out_off); g->v_n.push_back(cur.n_out); g->v_base.push_back(text);
         text += cur.n_out;
+        isize_seg += cur.isize_sum;
         end_rel = cur.end_bit;
         if (cur.status == GZ_END) { ended = true; break; }
         if (cur.end_bit >= stop_rel) break;
@@ -699,6 +728,13 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
         cur_job = jobs[k];
         cur = results[k];
     }
+    if (ended && (uint32_t)(g->seen_text + text) != (uint32_t)(g->isize_total + isize_seg)) {
+        // (the CRC-32 is not computed; a stream damaged so that it still decodes to the right length goes through, as it would
+        // through any reader that does not check it)
+        kv_set_error("gzip stream: %llu bytes of text, but the member trailers announce another length (damaged file?)", (unsigned long long)(g->seen_text + text));
+        return KV_ERR_TYPE;
+    }
+    g->pending_isize = isize_seg;
     const size_t nv = g->v_off.size();
     g->stat_segments += 1;
     g->stat_jobs += n_first;
@@ -715,17 +751,26 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     KV_HIP(hipMemcpyAsync(d_off, g->v_off.data(), nv * 8, hipMemcpyHostToDevice, st));
     KV_HIP(hipMemcpyAsync(d_base, g->v_base.data(), nv * 8, hipMemcpyHostToDevice, st));
     KV_HIP(hipMemcpyAsync(d_n, g->v_n.data(), nv * 4, hipMemcpyHostToDevice, st));
+    unsigned long long *d_markers = d_ctr + 1;
+    unsigned long long markers = 0;
+    KV_HIP(hipMemsetAsync(d_markers, 0, 8, st));
     {
         KvProfScope prof("k_gz_tails");
         hipLaunchKernelGGL(k_gz_tails, dim3((unsigned)(nv + 1)), dim3(256), 0, st, (const uint16_t *)d_syms, (const uint64_t *)d_off, (const uint32_t *)d_n,
-                           (const uint8_t *)g->window.p, t0);
+                           (const uint8_t *)g->window.p, t0, d_markers);
     }
-    {
+    KV_HIP(hipMemcpyAsync(&markers, d_markers, 8, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    // (markers die out fast -- a chain of copies has to lead back through a whole stretch to survive a round -- so the
+    // rounds stop as soon as none is left, usually after two or three)
+    for (uint64_t d = 1; d < nv + 1 && markers; d <<= 1) {
         KvProfScope prof("k_gz_scan");
-        for (uint64_t d = 1; d < nv + 1; d <<= 1) {
-            hipLaunchKernelGGL(k_gz_scan, dim3((unsigned)(nv + 1)), dim3(256), 0, st, (const uint16_t *)t0, t1, (uint32_t)d);
-            std::swap(t0, t1);
-        }
+        KV_HIP(hipMemsetAsync(d_markers, 0, 8, st));
+        hipLaunchKernelGGL(k_gz_scan, dim3((unsigned)(nv + 1)), dim3(256), 0, st, (const uint16_t *)t0, t1, (uint32_t)d, d_markers);
+        KV_HIP(hipMemcpyAsync(&markers, d_markers, 8, hipMemcpyDeviceToHost, st));
+        KV_HIP(hipStreamSynchronize(st));
+        std::swap(t0, t1);
+        g->stat_rounds += 1;
     }
     KV_HIP(hipGetLastError());
     g->d_tails = t0;                          // plain text now
@@ -738,6 +783,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     *last = ended;
     if (text == 0) {                          // nothing to emit (an empty member at the end of the file)
         g->pending = false;
+        g->isize_total += isize_seg;
         g->pos_bit = g->pending_pos;
         g->done = ended;
     }
@@ -759,6 +805,7 @@ int kv_gunzip_emit(KvGunzip *g, uint8_t *d_text)
     KV_HIP(hipGetLastError());
     g->seen_comp += (g->pending_pos - g->pos_bit) / 8;
     g->seen_text += g->pending_text;
+    g->isize_total += g->pending_isize;
     if (g->seen_comp > 0) g->ratio = std::max(1.0, (double)g->seen_text / (double)g->seen_comp);
     g->pos_bit = g->pending_pos;
     g->done = g->pending_done;

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 5 : RBITS == 1
                 __builtin_amdgcn_wave_barrier();
                 for (uint32_t s = 0; s < ncode; ++s) {
                     const uint32_t v = br_bits(br, 3);
-                    if (lane == 0) sh.lengths[c_clen_order[s]] = (uint8_t)v;
+                    if (lane == 0) sh.lengths[inf_clen_order(s)] = (uint8_t)v;
                 }
                 // the code-length code lives in the distance arrays for a moment
                 if (lane == 0) ok = build_code(sh.lengths, 19, sh.d_count, sh.d_symbol, sh.d_table, 7);
@@ -165,12 +165,12 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 5 : RBITS == 1
                 if (sym == 256) break;
                 const int ls = sym - 257;
                 if (ls >= 29) { failed = true; break; }
-                const uint32_t len = c_len_base[ls] + br_bits(br, c_len_extra[ls]);
+                const uint32_t len = inf_len_base((uint32_t)ls) + br_bits(br, inf_len_extra((uint32_t)ls));
                 const int ds = decode_sym(br, sh.d_count, sh.d_symbol, sh.d_table, INF_FAST_D);
                 if (ds < 0 || ds >= 30) { failed = true; break; }
-                const uint32_t extra = c_dist_extra[ds];
+                const uint32_t extra = inf_dist_extra((uint32_t)ds);
                 br_need(br, 16);
-                const uint32_t dist = c_dist_base[ds] + ((uint32_t)br.buf & ((1u << extra) - 1u));
+                const uint32_t dist = inf_dist_base((uint32_t)ds) + ((uint32_t)br.buf & ((1u << extra) - 1u));
                 br.buf >>= extra; br.cnt -= extra;
                 if (dist > o || o + len > job.isize) { failed = true; break; }
                 // all lanes copy; an overlapping match repeats its first `dist` bytes.  The source comes from the LDS window

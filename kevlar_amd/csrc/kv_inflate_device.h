@@ -114,11 +114,22 @@ __device__ __forceinline__ int decode_sym(BitReader &br, const uint16_t *count, 
     return -1;
 }
 
-__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-__constant__ uint8_t c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-
+// The length / distance code tables of RFC 1951 section 3.2.5 as arithmetic: a table in constant memory is a vector load
+// here, and the s_waitcnt vmcnt(0) behind it also waits for every text store the wave still has in flight -- a
+// microsecond per match.  (tests/test_gpu_ingest.py compares the text with zlib over every length and distance code.)
+__device__ __forceinline__ uint32_t inf_len_extra(uint32_t ls) { return ls < 8u || ls == 28u ? 0u : (ls - 4u) >> 2; }
+__device__ __forceinline__ uint32_t inf_len_base(uint32_t ls)
+{
+    return ls < 8u ? 3u + ls : ls == 28u ? 258u : 3u + ((4u + (ls & 3u)) << ((ls - 4u) >> 2));
+}
+__device__ __forceinline__ uint32_t inf_dist_extra(uint32_t ds) { return ds < 4u ? 0u : (ds >> 1) - 1u; }
+__device__ __forceinline__ uint32_t inf_dist_base(uint32_t ds) { return ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << ((ds >> 1) - 1u)); }
+// the order the code-length code's own lengths arrive in: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+__device__ __forceinline__ uint32_t inf_clen_order(uint32_t s)
+{
+    const uint64_t lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
+    const uint64_t hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+    return (uint32_t)((s < 12u ? lo >> (5u * s) : hi >> (5u * (s - 12u))) & 31u);
+}
 
 }  // namespace

@@ -1,5 +1,5 @@
-"""Device ingest (kv_inflate.hip, kv_fastq.hip): BGZF members inflated by the GPU must give zlib's bytes, and a FASTQ
-file parsed on the device the same batches, record text and counts as the host parser."""
+"""Device ingest (kv_inflate.hip, kv_gunzip.hip, kv_fastq.hip): BGZF members and ordinary gzip streams inflated by the GPU
+must give zlib's bytes, and a FASTQ file parsed on the device the same batches, record text and counts as the host parser."""
 import ctypes
 import gzip
 import os
@@ -75,8 +75,84 @@ def test_device_inflate_reports_corruption(hk):
         device_inflate(gzip.compress(text))          # plain gzip: not BGZF
 
 
-def write_fastq(path, text, bgzf_level=6):
+def device_gunzip(image, segment=0, cap=None):
+    """(text, [passes, stretches decoded, dropped, decoded again]) of a gzip image through kv_gunzip_host"""
+    from kevlar_amd import _lib
+    lib = _lib.load()
+    cap = cap if cap is not None else len(gzip.decompress(image)) + 64
+    out = ctypes.create_string_buffer(cap + 1)
+    n, ms, stats = ctypes.c_uint64(), ctypes.c_double(), (ctypes.c_uint64 * 4)()
+    _lib.check(lib.kv_gunzip_host(image, len(image), out, cap, segment, ctypes.byref(n), stats, ctypes.byref(ms)))
+    return out.raw[:n.value], list(stats)
+
+
+@pytest.mark.parametrize('level', [1, 6, 9])
+@pytest.mark.parametrize('segment', [0, 1 << 20, 150000])
+def test_device_gunzip_equals_zlib(hk, level, segment):
+    """one DEFLATE stream (what gzip writes), whole and a segment at a time: window and bit position carried across"""
+    text = fastq_text(40000, 30 + level)
+    image = gzip.compress(text, compresslevel=level)
+    got, stats = device_gunzip(image, segment)
+    assert got == text
+    assert stats[1] > 100                             # found and used block starts inside the stream
+    if segment:
+        assert stats[0] > 1
+
+
+def test_device_gunzip_odd_streams(hk):
+    """several members, every optional header field, stored and fixed-Huffman blocks, a 1000:1 stream (stretches run out
+    of room and are decoded again), incompressible bytes, matches at the longest distance, tiny and empty inputs"""
+    import io
+    rng = np.random.default_rng(12)
+    text = fastq_text(20000, 41)
+    cut = len(text) // 3
+    cases = {'members': gzip.compress(text[:cut], 6) + gzip.compress(text[cut:2 * cut], 1) + gzip.compress(b'', 6) + gzip.compress(text[2 * cut:], 9)}
+    named = io.BytesIO()
+    with gzip.GzipFile('reads of sample 1.fq', 'wb', 6, named, mtime=12345) as fh:
+        fh.write(text[:700000])
+    cases['name'] = named.getvalue()
+    plain = gzip.compress(text[:500000], 6)
+    # FEXTRA + FNAME + FCOMMENT + FHCRC written by hand around the same deflate data
+    cases['all header fields'] = (plain[:3] + bytes([4 | 8 | 16 | 2]) + plain[4:10] + b'\x05\x00hello' + b'a name\x00' + b'a comment\x00' + b'\x12\x34' + plain[10:])
+    cases['stored'] = gzip.compress(text[:300000], 0)
+    cases['all A'] = gzip.compress(b'A' * 6000000, 6)
+    cases['random'] = gzip.compress(bytes(rng.integers(0, 256, 1500000, dtype=np.uint8)), 6)
+    far = bytes(rng.integers(65, 91, 32768, dtype=np.uint8))
+    cases['far matches'] = gzip.compress(far * 40, 9)
+    cases['tiny'] = gzip.compress(b'@r\nACGT\n+\nIIII\n', 6)
+    cases['one byte'] = gzip.compress(b'x', 9)
+    cases['empty'] = gzip.compress(b'', 6)
+    for name, image in cases.items():
+        want = gzip.decompress(image)
+        for segment in (0, 1 << 19):
+            got, stats = device_gunzip(image, segment)
+            assert got == want, (name, segment, stats)
+    assert device_gunzip(cases['all A'])[1][3] > 0             # ... decoded again with more room
+
+
+def test_device_gunzip_refuses_what_it_cannot_read(hk):
+    """trailing garbage, a truncated stream, damaged codes: an error (the reader then falls back to zlib), never wrong text"""
+    from kevlar_amd import _lib
+    text = fastq_text(20000, 43)
+    image = gzip.compress(text, 6)
+    bad = bytearray(image)
+    for at in range(len(bad) // 2, len(bad) // 2 + 64):
+        bad[at] ^= 0xa5
+    for broken in (image + b'garbage behind the stream' * 3, image[:len(image) * 2 // 3], bytes(bad), b'\x1f\x8b\x08' + bytes(40)):
+        try:
+            got, _ = device_gunzip(broken, 0, cap=len(text) + 64)
+        except (ValueError, OSError, _lib.KvError):
+            continue
+        # (a flipped bit inside a literal run decodes: that is what the CRC is for, which this decoder does not check)
+        assert broken is not image and len(got) == len(text)
+
+
+def write_fastq(path, text, bgzf_level=6, kind='bgzf'):
     from kevlar_amd import bgzf
+    if kind == 'gzip':
+        with gzip.open(path, 'wb', compresslevel=bgzf_level) as sink:
+            sink.write(text.encode('ascii') if isinstance(text, str) else text)
+        return
     with bgzf.BgzfWriter(path, level=bgzf_level) as sink:
         sink.write(text)
 
@@ -107,7 +183,8 @@ def batches_of(hk, path, size, env=None):
 
 
 @pytest.mark.parametrize('batch,text_mb,kind', [(100000, None, 'bgzf'), (7001, None, 'bgzf'), (100000, '1', 'bgzf'), (2500, '1', 'bgzf'),
-                                                (100000, None, 'plain'), (7001, '1', 'plain')])
+                                                (100000, None, 'plain'), (7001, '1', 'plain'),
+                                                (100000, None, 'gzip'), (7001, None, 'gzip'), (100000, '1', 'gzip'), (2500, '1', 'gzip')])
 def test_device_parse_equals_host_parse(hk, tmp_path, batch, text_mb, kind):
     """BGZF FASTQ parsed on the device: same records, same packed reads (through the count tables they produce) as
     the host parser; reads with N / lower case, ragged lengths, CRLF, a last line without newline"""
@@ -120,9 +197,9 @@ def test_device_parse_equals_host_parse(hk, tmp_path, batch, text_mb, kind):
     for line in range(4 * 20, 4 * 24):
         text[line] += '\r'
     blob = '\n'.join(text).rstrip('\n')              # no newline behind the last quality line
-    if kind == 'bgzf':
+    if kind in ('bgzf', 'gzip'):                     # gzip: one DEFLATE stream, inflated a segment at a time (kv_gunzip.hip)
         path = str(tmp_path / 'reads.fq.gz')
-        write_fastq(path, blob)
+        write_fastq(path, blob, kind=kind)
     else:                                            # an uncompressed file takes the same kernels, minus the inflate
         path = str(tmp_path / 'reads.fq')
         with open(path, 'w') as fh:
@@ -155,6 +232,12 @@ def test_device_parse_falls_back_to_host(hk, tmp_path):
     dev = batches_of(hk, path, 1000)
     assert dev[3][0] == 'DeviceTextBatch' and dev[3][-1] == 'TextBatch'
     assert host[0] == dev[0] and host[1] == dev[1] and host[2] == dev[2] and dev[4] == 5000
+    path = str(tmp_path / 'gap.plain.fq.gz')         # the same as one gzip stream
+    write_fastq(path, '\n'.join(broken), kind='gzip')
+    host = batches_of(hk, path, 1000, {'KV_INGEST': 'host'})
+    dev = batches_of(hk, path, 1000)
+    assert dev[3][0] == 'DeviceTextBatch' and dev[3][-1] == 'TextBatch'
+    assert host[0] == dev[0] and host[1] == dev[1] and host[2] == dev[2] and dev[4] == 5000
     path = str(tmp_path / 'gap.fq')                  # the same, uncompressed
     with open(path, 'w') as fh:
         fh.write('\n'.join(broken))
@@ -172,7 +255,8 @@ def test_device_parse_falls_back_to_host(hk, tmp_path):
 
 
 def test_novel_cli_same_output_from_bgzf_and_plain_gzip(hk, tmp_path):
-    """kevlar novel end to end: case reads as BGZF (device ingest) and as plain gzip (host) give the same augmented FASTQ"""
+    """kevlar novel end to end: reads as BGZF (one wavefront per member) and as plain gzip (one stream, inflated in
+    parallel stretches) give the same augmented FASTQ as the host's zlib reader"""
     import gzip as gz
     import subprocess
     import sys
@@ -188,11 +272,11 @@ def test_novel_cli_same_output_from_bgzf_and_plain_gzip(hk, tmp_path):
             fh.write(text)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for which in (0, 1):
-        out = str(tmp_path / 'novel{}.augfastq'.format(which))
+    for which, env in ((0, {}), (1, {}), (1, {'KV_INGEST': 'host'})):
+        out = str(tmp_path / 'novel{}{}.augfastq'.format(which, len(env)))
         cmd = [sys.executable, '-m', 'kevlar_amd', 'novel', '--case', files['proband'][which], '--control', files['mother'][which],
                '--control', files['father'][which], '--ksize', '25', '--memory', '2M', '--case-min', '5', '--ctrl-max', '1', '--out', out]
-        done = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+        done = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert done.returncode == 0, done.stderr[-2000:]
         outs.append(open(out).read())
-    assert outs[0] == outs[1] and outs[0].count('\n') > 100
+    assert outs[0] == outs[1] == outs[2] and outs[0].count('\n') > 100
