@@ -81,24 +81,25 @@ __device__ __forceinline__ uint32_t lds_bits(const uint32_t *w, uint32_t bit, ui
     return (uint32_t)(v >> s) & ((1u << n) - 1u);
 }
 
-// bits [p, ...) of the staged chunk: BFINAL = 0, BTYPE = dynamic, plausible counts and a complete code-length code
-__device__ __forceinline__ bool gz_header_quick(const uint32_t *w, uint32_t p)
+// the 17 header bits at some offset: BFINAL = 0, BTYPE = dynamic, no more than 286 / 30 codes announced
+__device__ __forceinline__ bool gz_header_counts(uint32_t head)
 {
-    const uint32_t head = lds_bits(w, p, 17);
-    if ((head & 7u) != 4u) return false;
-    if (((head >> 3) & 31u) > 29u || ((head >> 8) & 31u) > 29u) return false;
-    const uint32_t ncode = ((head >> 13) & 15u) + 4u;
+    return (head & 7u) == 4u && ((head >> 3) & 31u) <= 29u && ((head >> 8) & 31u) <= 29u;
+}
+
+// ... and a COMPLETE code-length code behind them (bits [p + 17, ...) of the staged chunk)
+__device__ __forceinline__ bool gz_header_precode(const uint32_t *w, uint32_t p)
+{
+    const uint32_t ncode = lds_bits(w, p + 13, 4) + 4u;
     uint32_t kraft = 0, q = p + 17;
     for (uint32_t s = 0; s < ncode; s += 8) {
         uint32_t v = lds_bits(w, q, 24);
         q += 24;
         const uint32_t m = min(8u, ncode - s);
-        for (uint32_t i = 0; i < m; ++i, v >>= 3) {
-            const uint32_t l = v & 7u;
-            kraft += l ? (128u >> l) : 0u;
-        }
+        v &= (1u << (3u * m)) - 1u;
+        for (uint32_t i = 0; i < 8; ++i, v >>= 3) kraft += (256u >> (v & 7u)) & 0xffu;        // length l > 0 weighs 2^(8 - l), l = 0 nothing
     }
-    return kraft == 128u;
+    return kraft == 256u;
 }
 
 // ... and the code lengths it spells: no overrun, an end-of-block code, complete literal/length and distance codes
@@ -183,15 +184,27 @@ __global__ __launch_bounds__(GZ_FIND_THREADS) void k_gz_find(const uint8_t *__re
     const uint64_t left = n_bytes > base ? n_bytes - base : 0;
     const uint32_t limit_bits = (uint32_t)(left < staged ? left : staged) * 8u;
     const uint32_t chunk_bits = chunk_bytes * 8u < limit_bits ? chunk_bytes * 8u : limit_bits;
-    // every offset through the cheap test (about one in 600 passes), then the survivors through the full one, all at once:
-    // a survivor costs ~300 dependent code-length decodes, so they must not queue up behind each other
+    // Every bit offset is a candidate.  A lane takes 32 consecutive ones (one word of the stream and the next): the 13 bits of
+    // block type and code counts are tested from registers and leave about one offset in nine; those go through the
+    // code-length code's completeness (one in 250 passes), lane by lane as they come; what is left (~60 of a chunk's
+    // 131072) is collected and put through the full test all at once: a survivor costs ~300 dependent code-length
+    // decodes, so they must not queue up behind each other.
     if (threadIdx.x == 0) sh_n = 0;
     __syncthreads();
-    for (uint32_t p = threadIdx.x; p < chunk_bits; p += GZ_FIND_THREADS)
-        if (gz_header_quick(sh_words, p)) {
-            const uint32_t at = atomicAdd(&sh_n, 1u);
-            if (at < GZ_FIND_LIST) sh_list[at] = p;
+    for (uint32_t word = threadIdx.x; word * 32u < chunk_bits; word += GZ_FIND_THREADS) {
+        const uint64_t v = ((uint64_t)sh_words[word + 1] << 32) | sh_words[word];
+        uint32_t some = 0;
+        for (uint32_t s = 0; s < 32; ++s) some |= gz_header_counts((uint32_t)(v >> s)) ? 1u << s : 0u;
+        if (word * 32u + 32u > chunk_bits) some &= (1u << (chunk_bits - word * 32u)) - 1u;
+        while (some) {
+            const uint32_t p = word * 32u + (uint32_t)__builtin_ctz(some);
+            some &= some - 1u;
+            if (gz_header_precode(sh_words, p)) {
+                const uint32_t at = atomicAdd(&sh_n, 1u);
+                if (at < GZ_FIND_LIST) sh_list[at] = p;
+            }
         }
+    }
     __syncthreads();
     const uint32_t n = min(sh_n, GZ_FIND_LIST);
     for (uint32_t i = threadIdx.x; i < n; i += GZ_FIND_THREADS)
@@ -662,7 +675,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
         jobs[j].pad = 0;
         total_cap += kv_round_up(jobs[j].out_cap, 64);
     }
-    const uint64_t repair_room = std::max<uint64_t>(64ull << 20, total_cap / 8);
+    const uint64_t repair_room = std::max<uint64_t>(256ull << 20, total_cap / 4);
     const size_t max_jobs = n_first + 256;
     KV_HIP(g->syms.need((total_cap + repair_room) * 2 + 256));
     KV_HIP(g->meta.need(kv_round_up(max_jobs * sizeof(GzJob), 256) + kv_round_up(max_jobs * sizeof(GzResult), 256) + kv_round_up(max_jobs * 8, 256) * 2 +
@@ -688,6 +701,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
             // this stretch's start (for room) or from where it stopped, as a stretch of its own
             GzJob again;
             if (cur.status == GZ_FULL) {
+                if (cur_job.out_off >= total_cap) repair_used = cur_job.out_off - total_cap;        // the failed attempt's room is free again
                 again = cur_job;
                 again.out_cap = (uint32_t)std::min<uint64_t>((uint64_t)cur_job.out_cap * 8, 0x7ffffff0u);
             } else {

@@ -1,5 +1,5 @@
 """Randomised device-vs-host ingest parity: random record shapes (lengths 0..2000, names, CRLF, missing final newline,
-non-ACGT characters), uncompressed or BGZF at random levels, random batch sizes and text budgets; batches, record
+non-ACGT characters), uncompressed, BGZF or ordinary gzip (one or several members, random chunk size of the block search) at random levels, random batch sizes and text budgets; batches, record
 text and count tables must agree.  python scratch/fuzz_ingest.py [trials] [seed]"""
 import os, sys, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,14 +29,23 @@ with tempfile.TemporaryDirectory() as tmp:
         text = ''.join(recs)
         if rng.random() < 0.3:
             text = text.rstrip('\r\n')
-        kind = 'plain' if rng.random() < 0.4 else 'bgzf'
+        kind = str(rng.choice(['plain', 'bgzf', 'gzip', 'gzip']))
         path = os.path.join(tmp, 't{}.fq'.format(trial) + ('' if kind == 'plain' else '.gz'))
         if kind == 'plain':
             with open(path, 'w', newline='') as fh: fh.write(text)
+        elif kind == 'gzip':
+            import gzip
+            raw = text.encode('latin-1')
+            cuts = sorted(set([0, len(raw)] + [int(c) for c in rng.integers(0, len(raw) + 1, int(rng.integers(0, 3)))]))
+            with open(path, 'wb') as fh:
+                for a, b in zip(cuts, cuts[1:]):
+                    fh.write(gzip.compress(raw[a:b], int(rng.choice([1, 4, 6, 9]))))
         else:
             with bgzf.BgzfWriter(path, level=int(rng.choice([0, 1, 6, 9]))) as fh: fh.write(text)
         batch = int(rng.choice([1, 3, 1000, 100000]))
         env = {'KV_INGEST_TEXT_MB': '1'} if rng.random() < 0.5 else {}
+        if kind == 'gzip' and rng.random() < 0.5:
+            env['KV_GUNZIP_CHUNK_KB'] = str(rng.choice([1, 2, 4, 64]))
         desc = 'trial {} {} n={} style={} batch={} {}'.format(trial, kind, n, style, batch, env)
         try:
             host = batches_of(hk, path, batch, {'KV_INGEST': 'host'})
