@@ -102,6 +102,16 @@ struct KvArena {
     }
 };
 
+// device buffers of the gzip inflater (kv_gunzip.hip); gigabytes for a big file, so the FASTQ reader pools them with its own
+struct KvGunzipArenas {
+    KvArena comp, syms, tails, meta, window, small, crc;
+    void release()
+    {
+        for (KvArena *a : {&comp, &syms, &tails, &meta, &window, &small, &crc})
+            if (a->p) { (void)hipFree(a->p); a->p = nullptr; a->bytes = 0; }
+    }
+};
+
 int kv_device_cus();
 static inline uint64_t kv_round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
 

@@ -222,10 +222,12 @@ __global__ __launch_bounds__(64) void k_record_copy(const uint8_t *__restrict__ 
 struct FastqBuffers {
     KvArena text[2];                // the batch being served / the batch before it (the carried tail moves across)
     KvArena comp, lines, recs, scratch, fetch;
+    KvGunzipArenas gz;
     void release()
     {
         for (KvArena *a : {&text[0], &text[1], &comp, &lines, &recs, &scratch, &fetch})
             if (a->p) { (void)hipFree(a->p); a->p = nullptr; a->bytes = 0; }
+        gz.release();
     }
 };
 namespace {
@@ -268,8 +270,7 @@ KvFastqDevice *kv_fastq_device_open(const char *path)
     else kv_bgzf_index(d->image, d->image_size, &d->members, &yes);
     if (!yes && !d->plain) {
         const char *off = getenv("KV_GUNZIP");
-        if (!(off && !strcmp(off, "host"))) d->gz = kv_gunzip_open(d->image, d->image_size);
-        if (!d->gz) { kv_fastq_device_close(d); return nullptr; }
+        if (off && !strcmp(off, "host")) { kv_fastq_device_close(d); return nullptr; }
     }
     {
         std::lock_guard<std::mutex> lk(g_fastq_pool_mu);
@@ -277,6 +278,10 @@ KvFastqDevice *kv_fastq_device_open(const char *path)
     }
     if (!d->buf) d->buf = new FastqBuffers();
     d->text = d->buf->text;
+    if (!yes && !d->plain) {
+        d->gz = kv_gunzip_open(d->image, d->image_size, &d->buf->gz);
+        if (!d->gz) { kv_fastq_device_close(d); return nullptr; }
+    }
     return d;
 }
 

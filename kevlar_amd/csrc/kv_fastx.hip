@@ -66,6 +66,7 @@ struct kv_fastx {
     std::vector<char> buf;
     size_t pos = 0, end = 0;
     bool eof = false;
+    std::string io_error;         // what zlib said when the stream turned out damaged or cut short
     std::string pending;          // a header line read ahead while scanning a FASTA record
     std::string pending_view;     // backing store of the view handed out for it
     bool have_pending = false;
@@ -90,7 +91,14 @@ static bool fx_fill(kv_fastx *f)
     f->pos = 0;
     if (f->end == f->buf.size()) f->buf.resize(f->buf.size() * 2);
     const int got = gzread(f->fh, f->buf.data() + f->end, (unsigned)(f->buf.size() - f->end));
-    if (got <= 0) { f->eof = true; return false; }
+    if (got <= 0) {
+        // the end of the file -- or of what can be read of it: a damaged or truncated gzip stream is an error, not a short file
+        f->eof = true;
+        int errnum = Z_OK;
+        const char *msg = gzerror(f->fh, &errnum);
+        if (got < 0 || (errnum != Z_OK && errnum != Z_STREAM_END)) f->io_error = msg && *msg ? msg : "read error";
+        return false;
+    }
     f->end += (size_t)got;
     return true;
 }
@@ -423,6 +431,10 @@ static int host_parse(kv_fastx *f, uint64_t max_reads, uint64_t *n_out)
         f->seq_offs.push_back(f->seqs.size());
         f->qual_offs.push_back(f->quals.size());
         ++n;
+    }
+    if (!f->io_error.empty()) {
+        kv_set_error("%s: %s", f->path.c_str(), f->io_error.c_str());
+        return KV_ERR_IO;
     }
     *n_out = n;
     return KV_OK;

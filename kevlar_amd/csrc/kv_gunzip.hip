@@ -30,6 +30,8 @@
 #include <cstring>
 #include <vector>
 
+#include <zlib.h>
+
 #include "kv_binned.h"
 #include "kv_internal.h"
 #include "kv_inflate_device.h"
@@ -40,6 +42,7 @@ namespace {
 #define GZ_MARK 0x8000u
 #define GZ_FAST_LL 9                 // bits of the literal/length lookup table (9: 32 workgroups of LDS per CU)
 #define GZ_SLACK 2048u               // readable zero bytes behind the compressed buffer
+#define GZ_CRC_SLICE 8192u            // bytes of text per thread of k_gz_crc
 #define GZ_FIND_THREADS 256
 #define GZ_FIND_LIST 1024u           // survivors of the cheap test a chunk may have (more: the later ones are not looked at)
 
@@ -57,7 +60,9 @@ struct GzResult {
     uint32_t n_out;
     uint16_t status;
     uint16_t members;                // member trailers the stretch passed,
-    uint32_t isize_sum;              // ... and the sum of their ISIZE fields
+    uint32_t isize_sum;              // ... the sum of their ISIZE fields,
+    uint32_t trailer_at;             // ... how many symbols the stretch had produced at the first one
+    uint32_t trailer_crc;            // ... and the CRC-32 that one announces
     uint32_t pad;
 };
 
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 6 : RBITS == 1
         br_seek(br, words, job.start_bit);
         uint16_t *dst = syms + job.out_off;
         const uint32_t cap = job.out_cap;
-        uint32_t o = 0, lit = 0, n_lit = 0, isize_sum = 0, members = 0;
+        uint32_t o = 0, lit = 0, n_lit = 0, isize_sum = 0, members = 0, trailer_at = 0, trailer_crc = 0;
         int status = -1;
         uint64_t end_bit = job.start_bit;
         auto flush = [&]() {
@@ -418,6 +423,10 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 6 : RBITS == 1
                 uint64_t at = ((br_pos(br) + 7) >> 3) + 8;
                 if (at > n_bytes) { status = GZ_SHORT; break; }
                 isize_sum += INF_UNI(comp[at - 4] | (comp[at - 3] << 8) | (comp[at - 2] << 16) | ((uint32_t)comp[at - 1] << 24));
+                if (members == 0) {
+                    trailer_at = o;
+                    trailer_crc = INF_UNI(comp[at - 8] | (comp[at - 7] << 8) | (comp[at - 6] << 16) | ((uint32_t)comp[at - 5] << 24));
+                }
                 members += 1;
                 if (at == n_bytes) {
                     end_bit = at * 8;
@@ -439,6 +448,8 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 6 : RBITS == 1
             r.status = (uint16_t)status;
             r.members = (uint16_t)min(members, 65535u);
             r.isize_sum = isize_sum;
+            r.trailer_at = trailer_at;
+            r.trailer_crc = trailer_crc;
             r.pad = 0;
             results[job_id] = r;
         }
@@ -513,6 +524,43 @@ __global__ void k_gz_window_out(const uint16_t *__restrict__ tail, uint8_t *__re
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < GZ_WIN; i += gridDim.x * blockDim.x) window[i] = (uint8_t)tail[i];
 }
 
+// ---------------------------------------------------------------- 5. CRC-32
+// out[r] = CRC-32 (the gzip one: reflected 0xEDB88320) of text[start[r], start[r] + len[r]): a thread per range, four table
+// lookups per four bytes (slicing by 4, tables built in LDS); the host joins the ranges of a member (crc32_combine)
+__global__ __launch_bounds__(256) void k_gz_crc(const uint8_t *__restrict__ text, const uint64_t *__restrict__ start, const uint32_t *__restrict__ len, uint32_t n,
+                                                uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t T[4][256];
+    {
+        uint32_t c = threadIdx.x;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+        T[0][threadIdx.x] = c;
+        __syncthreads();
+        uint32_t v = c;
+        for (int t = 1; t < 4; ++t) {
+            v = T[0][v & 0xffu] ^ (v >> 8);
+            T[t][threadIdx.x] = v;
+        }
+        __syncthreads();
+    }
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint8_t *p = text + start[r];
+    uint32_t left = len[r], c = 0xffffffffu;
+    while (left && ((uint64_t)p & 15u)) { c = T[0][(c ^ *p++) & 0xffu] ^ (c >> 8); --left; }
+    for (; left >= 16; left -= 16, p += 16) {
+        const uint4 q = *(const uint4 *)p;
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            c ^= w[i];
+            c = T[3][c & 0xffu] ^ T[2][(c >> 8) & 0xffu] ^ T[1][(c >> 16) & 0xffu] ^ T[0][c >> 24];
+        }
+    }
+    for (; left; --left) c = T[0][(c ^ *p++) & 0xffu] ^ (c >> 8);
+    out[r] = c ^ 0xffffffffu;
+}
+
 // start of the deflate data of the gzip member at byte `at` of a host image; 0 if there is no member header there
 uint64_t host_member_header(const uint8_t *file, uint64_t size, uint64_t at)
 {
@@ -544,8 +592,13 @@ struct KvGunzip {
     double ratio = 4.0;               // text bytes per compressed byte so far
     uint64_t seen_comp = 0, seen_text = 0;
     uint32_t isize_total = 0;         // of the members that have ended so far (mod 2^32, as the field is)
+    uint32_t crc_run = 0;             // CRC-32 of the text of the member that is open at pos_bit
+    bool crc_on = true;               // off: KV_GUNZIP_CRC=0, or a stretch passed more than one member end (their starts in the text are not recorded)
+    uint32_t slice_op[32];            // crc32_combine(x, 0, GZ_CRC_SLICE) as a GF(2) matrix
+    std::vector<std::pair<uint64_t, uint32_t>> pending_ends;      // of the pending segment: (text offset a member ends at, the CRC-32 its trailer holds)
+
     uint32_t chunk_bytes = 16384;
-    KvArena comp, syms, tails, meta, window, small;
+    KvGunzipArenas own, *a = &own;    // device buffers: the caller's (pooled across files) or this object's
     // the segment decoded by kv_gunzip_decode and not yet emitted
     std::vector<uint64_t> v_off, v_base;
     std::vector<uint32_t> v_n;
@@ -556,23 +609,23 @@ struct KvGunzip {
     const uint32_t *d_n = nullptr;
     const uint16_t *d_tails = nullptr;                            // the resolved tails of the pending segment
     uint64_t stat_jobs = 0, stat_dropped = 0, stat_repairs = 0, stat_segments = 0, stat_rounds = 0;
-    ~KvGunzip()
-    {
-        for (KvArena *a : {&comp, &syms, &tails, &meta, &window, &small})
-            if (a->p) (void)hipFree(a->p);
-    }
+    ~KvGunzip() { own.release(); }
 };
 
-KvGunzip *kv_gunzip_open(const uint8_t *image, uint64_t size)
+KvGunzip *kv_gunzip_open(const uint8_t *image, uint64_t size, KvGunzipArenas *arenas)
 {
     const uint64_t data = host_member_header(image, size, 0);
     if (!data) return nullptr;
     KvGunzip *g = new KvGunzip();
     g->image = image;
     g->size = size;
+    if (arenas) g->a = arenas;
     g->pos_bit = data * 8;
     const char *cb = getenv("KV_GUNZIP_CHUNK_KB");
     if (cb && atoi(cb) >= 1 && atoi(cb) <= 64) g->chunk_bytes = (uint32_t)atoi(cb) * 1024u;
+    const char *cc = getenv("KV_GUNZIP_CRC");
+    g->crc_on = !(cc && !strcmp(cc, "0"));
+    for (int b = 0; b < 32; ++b) g->slice_op[b] = (uint32_t)crc32_combine(1ul << b, 0, GZ_CRC_SLICE);
     return g;
 }
 
@@ -632,13 +685,13 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     const bool to_file_end = seg_end == g->size, is_file_end = upto == g->size;
     const uint64_t n_bytes = upto - first_byte;
     const uint32_t n_chunks = (uint32_t)((n_bytes + CH - 1) / CH);
-    KV_HIP(g->comp.need(kv_round_up((uint64_t)n_chunks * CH + 2 * GZ_SLACK, 4096)));
-    uint8_t *d_comp = (uint8_t *)g->comp.p;
+    KV_HIP(g->a->comp.need(kv_round_up((uint64_t)n_chunks * CH + 2 * GZ_SLACK, 4096)));
+    uint8_t *d_comp = (uint8_t *)g->a->comp.p;
     KV_HIP(hipMemcpyAsync(d_comp, g->image + first_byte, n_bytes, hipMemcpyHostToDevice, st));
     KV_HIP(hipMemsetAsync(d_comp + n_bytes, 0, (uint64_t)n_chunks * CH + 2 * GZ_SLACK - n_bytes, st));
-    KV_HIP(g->small.need(kv_round_up((uint64_t)n_chunks * 8, 256) + 256));
-    unsigned long long *d_cand = (unsigned long long *)g->small.p;
-    unsigned long long *d_ctr = (unsigned long long *)((unsigned char *)g->small.p + kv_round_up((uint64_t)n_chunks * 8, 256));
+    KV_HIP(g->a->small.need(kv_round_up((uint64_t)n_chunks * 8, 256) + 256));
+    unsigned long long *d_cand = (unsigned long long *)g->a->small.p;
+    unsigned long long *d_ctr = (unsigned long long *)((unsigned char *)g->a->small.p + kv_round_up((uint64_t)n_chunks * 8, 256));
     {
         KvProfScope prof("k_gz_find");
         hipLaunchKernelGGL(k_gz_find, dim3(n_chunks), dim3(GZ_FIND_THREADS), CH + GZ_SLACK + 8, st, (const uint8_t *)d_comp, n_bytes, CH, n_chunks, d_cand);
@@ -677,19 +730,24 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     }
     const uint64_t repair_room = std::max<uint64_t>(256ull << 20, total_cap / 4);
     const size_t max_jobs = n_first + 256;
-    KV_HIP(g->syms.need((total_cap + repair_room) * 2 + 256));
-    KV_HIP(g->meta.need(kv_round_up(max_jobs * sizeof(GzJob), 256) + kv_round_up(max_jobs * sizeof(GzResult), 256) + kv_round_up(max_jobs * 8, 256) * 2 +
+    KV_HIP(g->a->syms.need((total_cap + repair_room) * 2 + 256));
+    KV_HIP(g->a->meta.need(kv_round_up(max_jobs * sizeof(GzJob), 256) + kv_round_up(max_jobs * sizeof(GzResult), 256) + kv_round_up(max_jobs * 8, 256) * 2 +
                         kv_round_up(max_jobs * 4, 256)));
-    GzJob *d_jobs = (GzJob *)g->meta.p;
+    GzJob *d_jobs = (GzJob *)g->a->meta.p;
     GzResult *d_results = (GzResult *)((unsigned char *)d_jobs + kv_round_up(max_jobs * sizeof(GzJob), 256));
     uint64_t *d_off = (uint64_t *)((unsigned char *)d_results + kv_round_up(max_jobs * sizeof(GzResult), 256));
     uint64_t *d_base = (uint64_t *)((unsigned char *)d_off + kv_round_up(max_jobs * 8, 256));
     uint32_t *d_n = (uint32_t *)((unsigned char *)d_base + kv_round_up(max_jobs * 8, 256));
-    uint16_t *d_syms = (uint16_t *)g->syms.p;
+    uint16_t *d_syms = (uint16_t *)g->a->syms.p;
     std::vector<GzResult> results(n_first);
     { const int rc = gz_run_jobs(g, d_comp, n_bytes, is_file_end, jobs.data(), n_first, d_jobs, d_results, d_ctr, d_syms, results.data()); if (rc != KV_OK) return rc; }
     // ---- the chain: stretch 0 starts at a known block; a later one counts iff a good stretch ends exactly on its start
-    g->v_off.clear(); g->v_n.clear(); g->v_base.clear();
+    g->v_off.clear(); g->v_n.clear(); g->v_base.clear(); g->pending_ends.clear();
+    bool crc_lost = false;
+    auto note_ends = [&](const GzResult &r, uint64_t base) {
+        if (r.members >= 1) g->pending_ends.emplace_back(base + r.trailer_at, r.trailer_crc);
+        if (r.members > 1) crc_lost = true;
+    };
     uint64_t repair_used = 0, text = 0, end_rel = 0;
     uint32_t repairs = 0, isize_seg = 0;
     bool ended = false;
@@ -706,6 +764,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
                 again.out_cap = (uint32_t)std::min<uint64_t>((uint64_t)cur_job.out_cap * 8, 0x7ffffff0u);
             } else {
                 g->v_off.push_back(cur_job.out_off); g->v_n.push_back(cur.n_out); g->v_base.push_back(text);
+                note_ends(cur, text);
                 text += cur.n_out;
                 isize_seg += cur.isize_sum;
                 again.start_bit = cur.end_bit;
@@ -733,6 +792,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
             return KV_ERR_TYPE;
         }
         g->v_off.push_back(cur_job.out_off); g->v_n.push_back(cur.n_out); g->v_base.push_back(text);
+        note_ends(cur, text);
         text += cur.n_out;
         isize_seg += cur.isize_sum;
         end_rel = cur.end_bit;
@@ -749,6 +809,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
         return KV_ERR_TYPE;
     }
     g->pending_isize = isize_seg;
+    if (crc_lost) g->crc_on = false;
     const size_t nv = g->v_off.size();
     g->stat_segments += 1;
     g->stat_jobs += n_first;
@@ -756,12 +817,12 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     g->stat_repairs += repairs;
     // ---- tails, resolved by pointer doubling
     if (!g->window_ready) {
-        KV_HIP(g->window.need(GZ_WIN));
-        KV_HIP(hipMemsetAsync(g->window.p, 0, GZ_WIN, st));         // nothing valid points in front of the first byte
+        KV_HIP(g->a->window.need(GZ_WIN));
+        KV_HIP(hipMemsetAsync(g->a->window.p, 0, GZ_WIN, st));         // nothing valid points in front of the first byte
         g->window_ready = true;
     }
-    KV_HIP(g->tails.need((uint64_t)(nv + 1) * GZ_WIN * 2 * 2));
-    uint16_t *t0 = (uint16_t *)g->tails.p, *t1 = t0 + (uint64_t)(nv + 1) * GZ_WIN;
+    KV_HIP(g->a->tails.need((uint64_t)(nv + 1) * GZ_WIN * 2 * 2));
+    uint16_t *t0 = (uint16_t *)g->a->tails.p, *t1 = t0 + (uint64_t)(nv + 1) * GZ_WIN;
     KV_HIP(hipMemcpyAsync(d_off, g->v_off.data(), nv * 8, hipMemcpyHostToDevice, st));
     KV_HIP(hipMemcpyAsync(d_base, g->v_base.data(), nv * 8, hipMemcpyHostToDevice, st));
     KV_HIP(hipMemcpyAsync(d_n, g->v_n.data(), nv * 4, hipMemcpyHostToDevice, st));
@@ -771,7 +832,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     {
         KvProfScope prof("k_gz_tails");
         hipLaunchKernelGGL(k_gz_tails, dim3((unsigned)(nv + 1)), dim3(256), 0, st, (const uint16_t *)d_syms, (const uint64_t *)d_off, (const uint32_t *)d_n,
-                           (const uint8_t *)g->window.p, t0, d_markers);
+                           (const uint8_t *)g->a->window.p, t0, d_markers);
     }
     KV_HIP(hipMemcpyAsync(&markers, d_markers, 8, hipMemcpyDeviceToHost, st));
     KV_HIP(hipStreamSynchronize(st));
@@ -798,6 +859,10 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     if (text == 0) {                          // nothing to emit (an empty member at the end of the file)
         g->pending = false;
         g->isize_total += isize_seg;
+        for (const auto &end : g->pending_ends) {
+            if (g->crc_on && g->crc_run != end.second) { kv_set_error("gzip stream: CRC-32 of a member does not match its text (damaged file)"); return KV_ERR_TYPE; }
+            g->crc_run = 0;
+        }
         g->pos_bit = g->pending_pos;
         g->done = ended;
     }
@@ -813,10 +878,67 @@ int kv_gunzip_emit(KvGunzip *g, uint8_t *d_text)
     const uint16_t *tails = g->d_tails;
     {
         KvProfScope prof("k_gz_resolve");
-        hipLaunchKernelGGL(k_gz_resolve, dim3((unsigned)(nv * GZ_RESOLVE_SPLIT)), dim3(256), 0, st, (const uint16_t *)g->syms.p, g->d_off, g->d_n, g->d_base, tails, d_text);
-        hipLaunchKernelGGL(k_gz_window_out, dim3(16), dim3(256), 0, st, tails + (uint64_t)nv * GZ_WIN, (uint8_t *)g->window.p);
+        hipLaunchKernelGGL(k_gz_resolve, dim3((unsigned)(nv * GZ_RESOLVE_SPLIT)), dim3(256), 0, st, (const uint16_t *)g->a->syms.p, g->d_off, g->d_n, g->d_base, tails, d_text);
+        hipLaunchKernelGGL(k_gz_window_out, dim3(16), dim3(256), 0, st, tails + (uint64_t)nv * GZ_WIN, (uint8_t *)g->a->window.p);
     }
     KV_HIP(hipGetLastError());
+    if (g->crc_on) {
+        // the text member by member (ends from the decoders), every member in slices of 8 KB: one thread each, joined here
+        std::vector<uint64_t> r_start;
+        std::vector<uint32_t> r_len;
+        std::vector<uint32_t> r_closes;                // index into pending_ends + 1 for the range that ends a member, else 0
+        uint64_t at = 0;
+        size_t e = 0;
+        while (at < g->pending_text || e < g->pending_ends.size()) {
+            const uint64_t stop = e < g->pending_ends.size() ? g->pending_ends[e].first : g->pending_text;
+            if (at == stop) {                          // a member that ends here without (more) text: an empty range closes it
+                if (e >= g->pending_ends.size()) break;
+                r_start.push_back(at); r_len.push_back(0); r_closes.push_back((uint32_t)++e);
+                continue;
+            }
+            const uint32_t n = (uint32_t)std::min<uint64_t>(stop - at, GZ_CRC_SLICE);
+            r_start.push_back(at); r_len.push_back(n);
+            at += n;
+            r_closes.push_back(at == stop && e < g->pending_ends.size() ? (uint32_t)++e : 0u);
+        }
+        const size_t nr = r_start.size();
+        if (nr) {
+            const size_t b_start = kv_round_up(nr * 8, 256), b_len = kv_round_up(nr * 4, 256);
+            KV_HIP(g->a->crc.need(b_start + 2 * b_len));
+            uint64_t *d_start = (uint64_t *)g->a->crc.p;
+            uint32_t *d_len = (uint32_t *)((unsigned char *)g->a->crc.p + b_start), *d_out = (uint32_t *)((unsigned char *)g->a->crc.p + b_start + b_len);
+            KV_HIP(hipMemcpyAsync(d_start, r_start.data(), nr * 8, hipMemcpyHostToDevice, st));
+            KV_HIP(hipMemcpyAsync(d_len, r_len.data(), nr * 4, hipMemcpyHostToDevice, st));
+            {
+                KvProfScope prof("k_gz_crc");
+                hipLaunchKernelGGL(k_gz_crc, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_text, (const uint64_t *)d_start, (const uint32_t *)d_len,
+                                   (uint32_t)nr, d_out);
+            }
+            KV_HIP(hipGetLastError());
+            std::vector<uint32_t> crcs(nr);
+            KV_HIP(hipMemcpyAsync(crcs.data(), d_out, nr * 4, hipMemcpyDeviceToHost, st));
+            KV_HIP(hipStreamSynchronize(st));
+            uint32_t run = g->crc_run;
+            for (size_t r = 0; r < nr; ++r) {
+                if (r_len[r] == GZ_CRC_SLICE) {
+                    uint32_t moved = 0;
+                    for (uint32_t v = run, b = 0; v; v >>= 1, ++b)
+                        if (v & 1u) moved ^= g->slice_op[b];
+                    run = moved ^ crcs[r];
+                } else if (r_len[r]) {
+                    run = (uint32_t)crc32_combine(run, crcs[r], r_len[r]);
+                }
+                if (r_closes[r]) {
+                    if (run != g->pending_ends[r_closes[r] - 1].second) {
+                        kv_set_error("gzip stream: the CRC-32 of a member does not match its text (damaged file)");
+                        return KV_ERR_TYPE;
+                    }
+                    run = 0;
+                }
+            }
+            g->crc_run = run;
+        }
+    }
     g->seen_comp += (g->pending_pos - g->pos_bit) / 8;
     g->seen_text += g->pending_text;
     g->isize_total += g->pending_isize;
@@ -833,7 +955,7 @@ extern "C" int kv_gunzip_host(const void *file, uint64_t size, void *out, uint64
                               uint64_t *stats, double *device_ms)
 {
     KV_REQUIRE(file && out && text_bytes, KV_ERR_ARG, "kv_gunzip_host: null argument");
-    KvGunzip *g = kv_gunzip_open((const uint8_t *)file, size);
+    KvGunzip *g = kv_gunzip_open((const uint8_t *)file, size, nullptr);
     KV_REQUIRE(g, KV_ERR_TYPE, "not a gzip file image");
     hipStream_t st = kv_stream();
     KvArena text;

@@ -239,7 +239,9 @@ int kv_bgzf_inflate(const uint8_t *d_comp, uint64_t comp_base, const KvBgzfMembe
 
 // ---- ordinary gzip on the device (kv_gunzip.hip): a segment of the stream per decode/emit pair ----
 struct KvGunzip;
-KvGunzip *kv_gunzip_open(const uint8_t *image, uint64_t size);  // NULL unless the image starts with a gzip member header
+struct KvGunzipArenas;                                          // its device buffers (kv_binned.h has the definition)
+// NULL unless the image starts with a gzip member header; arenas: buffers to work in (kept by the caller across files), or NULL
+KvGunzip *kv_gunzip_open(const uint8_t *image, uint64_t size, KvGunzipArenas *arenas);
 void kv_gunzip_close(KvGunzip *g);
 bool kv_gunzip_done(const KvGunzip *g);
 // decode about want_text bytes of text; *text_bytes = how many kv_gunzip_emit will store, *last = the stream ends with them.

@@ -45,7 +45,7 @@ for binned in (False, True):
         _lib.check(lib.kv_gunzip_host(image, len(image), out, len(text) + 64, 0, ctypes.byref(nb), stats, ctypes.byref(ms)))
         assert out.raw[:nb.value] == text
         per = {}
-        for name in ('k_gz_find', 'k_gz_decode', 'k_gz_tails', 'k_gz_scan', 'k_gz_resolve'):
+        for name in ('k_gz_find', 'k_gz_decode', 'k_gz_tails', 'k_gz_scan', 'k_gz_resolve', 'k_gz_crc'):
             kms, cnt = ctypes.c_double(), ctypes.c_uint64()
             lib.kv_prof_get(name.encode(), ctypes.byref(kms), ctypes.byref(cnt))
             per[name] = round(kms.value, 2)

@@ -147,6 +147,29 @@ def test_device_gunzip_refuses_what_it_cannot_read(hk):
         assert broken is not image and len(got) == len(text)
 
 
+def test_damaged_gzip_is_an_error_on_both_paths(hk, tmp_path):
+    """a truncated stream, and one with a byte changed where only the CRC-32 can tell (inside a stored block): the device
+    path declines, zlib reports, and the reader raises instead of delivering a short or altered file"""
+    text = fastq_text(20000, 44)
+    whole = gzip.compress(text, 6)
+    stored = bytearray(gzip.compress(text, 0))
+    stored[len(stored) // 2] ^= 0x01
+    with pytest.raises(ValueError) as err:
+        device_gunzip(bytes(stored), 0, cap=len(text) + 64)
+    assert 'CRC-32' in str(err.value)
+    for name, image in (('cut.fq.gz', whole[:len(whole) * 2 // 3]), ('flipped.fq.gz', bytes(stored))):
+        path = str(tmp_path / name)
+        with open(path, 'wb') as fh:
+            fh.write(image)
+        for env in ({}, {'KV_INGEST': 'host'}):
+            with pytest.raises((OSError, ValueError)):
+                batches_of(hk, path, 100000, dict(env))
+    good = str(tmp_path / 'good.fq.gz')
+    with open(good, 'wb') as fh:
+        fh.write(whole)
+    assert batches_of(hk, good, 100000)[4] == 20000
+
+
 def write_fastq(path, text, bgzf_level=6, kind='bgzf'):
     from kevlar_amd import bgzf
     if kind == 'gzip':
