@@ -337,7 +337,7 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         if (d->gz && fresh) { const int rc = kv_gunzip_emit(d->gz, text + d->carry_len); if (rc != KV_OK) return rc; }
         if (m1 > m0) {
             const uint64_t c0 = d->members[m0].in_off, c1 = d->members[m1 - 1].in_off + d->members[m1 - 1].in_len;
-            KV_HIP(d->buf->comp.need(kv_round_up(c1 - c0 + 64, 4096)));
+            KV_HIP(d->buf->comp.need(kv_round_up(c1 - c0 + 512, 4096)));          // (a damaged member may be read ~150 bytes past its end before it is caught)
             KV_HIP(hipMemcpyAsync(d->buf->comp.p, d->image + c0, c1 - c0, hipMemcpyHostToDevice, st));
             std::vector<uint64_t> text_off(m1 - m0);
             uint64_t at = d->carry_len;

@@ -43,6 +43,7 @@ namespace {
 #define GZ_FAST_LL 9                 // bits of the literal/length lookup table (9: 32 workgroups of LDS per CU)
 #define GZ_SLACK 2048u               // readable zero bytes behind the compressed buffer
 #define GZ_CRC_SLICE 8192u            // bytes of text per thread of k_gz_crc
+#define GZ_FIND_KEEP 4u                // block starts kept per chunk
 #define GZ_FIND_THREADS 256
 #define GZ_FIND_LIST 1024u           // survivors of the cheap test a chunk may have (more: the later ones are not looked at)
 
@@ -171,20 +172,23 @@ __device__ bool gz_header_full(const uint32_t *w, uint32_t p, uint32_t limit_bit
     return eob && kraft_ll == 32768u && (kraft_d == 32768u || used_d == 0 || (used_d == 1 && kraft_d == 16384u));
 }
 
-// cand[c] = bit position (relative to `comp`) of the first plausible block start in chunk c, or ~0
+// cand[c * GZ_FIND_KEEP ...] = bit positions (relative to `comp`) of the first plausible block starts in chunk c, ascending, ~0
+// where there are no more.  (All of them, not only the first: a false positive in front of a true start would otherwise hide
+// it, and the stretch that runs over the false one would end where nobody began -- a gap the host has to have decoded again,
+// one stretch's latency, ~10 ms, on its own.)
 __global__ __launch_bounds__(GZ_FIND_THREADS) void k_gz_find(const uint8_t *__restrict__ comp, uint64_t n_bytes, uint32_t chunk_bytes, uint32_t n_chunks,
                                                              unsigned long long *__restrict__ cand)
 {
     extern __shared__ uint32_t sh_words[];             // chunk_bytes + GZ_SLACK bytes of the stream
     __shared__ uint32_t sh_list[GZ_FIND_LIST];
-    __shared__ uint32_t sh_n, sh_best;
+    __shared__ uint32_t sh_n, sh_n_good, sh_good[16];
     const uint32_t c = blockIdx.x;
     if (c >= n_chunks) return;
     const uint64_t base = (uint64_t)c * chunk_bytes;
     const uint32_t staged = chunk_bytes + GZ_SLACK;
     const uint32_t *src = (const uint32_t *)(comp + base);          // comp is 256-aligned, chunk_bytes a multiple of 4
     for (uint32_t i = threadIdx.x; i < staged / 4; i += GZ_FIND_THREADS) sh_words[i] = src[i];     // the buffer has GZ_SLACK zero bytes behind n_bytes
-    if (threadIdx.x == 0) sh_best = ~0u;
+    if (threadIdx.x == 0) sh_n_good = 0;
     __syncthreads();
     const uint64_t left = n_bytes > base ? n_bytes - base : 0;
     const uint32_t limit_bits = (uint32_t)(left < staged ? left : staged) * 8u;
@@ -213,9 +217,17 @@ __global__ __launch_bounds__(GZ_FIND_THREADS) void k_gz_find(const uint8_t *__re
     __syncthreads();
     const uint32_t n = min(sh_n, GZ_FIND_LIST);
     for (uint32_t i = threadIdx.x; i < n; i += GZ_FIND_THREADS)
-        if (gz_header_full(sh_words, sh_list[i], limit_bits)) atomicMin(&sh_best, sh_list[i]);
+        if (gz_header_full(sh_words, sh_list[i], limit_bits)) {
+            const uint32_t at = atomicAdd(&sh_n_good, 1u);
+            if (at < 16) sh_good[at] = sh_list[i];
+        }
     __syncthreads();
-    if (threadIdx.x == 0) cand[c] = sh_best == ~0u ? ~0ull : base * 8ull + sh_best;
+    if (threadIdx.x == 0) {
+        const uint32_t good = min(sh_n_good, 16u);
+        for (uint32_t i = 1; i < good; ++i)               // a handful: insertion sort
+            for (uint32_t j = i; j > 0 && sh_good[j] < sh_good[j - 1]; --j) { const uint32_t t = sh_good[j]; sh_good[j] = sh_good[j - 1]; sh_good[j - 1] = t; }
+        for (uint32_t i = 0; i < GZ_FIND_KEEP; ++i) cand[(uint64_t)c * GZ_FIND_KEEP + i] = i < good ? base * 8ull + sh_good[i] : ~0ull;
+    }
 }
 
 // ---------------------------------------------------------------- 2. decode into symbols
@@ -370,16 +382,23 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 6 : RBITS == 1
                 __builtin_amdgcn_wave_barrier();
                 if (!ok) { status = GZ_BAD; break; }
                 // ---- symbols
+                // (room and the end of the input are checked when text is stored -- at least every 64 symbols, i.e. every 120
+                // bytes of input, which the zeroed slack behind the buffer covers -- not per literal: the loop is bound by the
+                // number of instructions it issues)
                 for (;;) {
-                    if (br.next > limit_words) { status = GZ_SHORT; break; }
                     const int sym = decode_sym(br, sh.ll_count, sh.ll_symbol, sh.ll_table, GZ_FAST_LL);
-                    if (sym < 0) { status = GZ_BAD; break; }
-                    if (sym < 256) {
-                        if (o + n_lit >= cap) { status = GZ_FULL; break; }
+                    if ((uint32_t)sym < 256u) {
                         lit = lane == n_lit ? (uint32_t)sym : lit;
-                        if (++n_lit == 64) flush();
+                        if (++n_lit == 64) {
+                            if (br.next > limit_words) { status = GZ_SHORT; break; }
+                            if (o + 64 > cap) { status = GZ_FULL; break; }
+                            flush();
+                        }
                         continue;
                     }
+                    if (sym < 0) { status = GZ_BAD; break; }
+                    if (br.next > limit_words) { status = GZ_SHORT; break; }
+                    if (o + n_lit > cap) { status = GZ_FULL; break; }
                     flush();
                     if (sym == 256) break;
                     const int ls = sym - 257;
@@ -460,43 +479,128 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 6 : RBITS == 1
 // ---------------------------------------------------------------- 3. tails
 // tail q (q = 0: the window the segment starts with, as bytes; q > 0: stretch q - 1): the 32 K symbols in front of
 // stretch q.  A stretch shorter than the window passes the rest of the tail before it through as markers.
-__global__ void k_gz_tails(const uint16_t *__restrict__ syms, const uint64_t *__restrict__ out_off, const uint32_t *__restrict__ n_out,
-                           const uint8_t *__restrict__ window_in, uint16_t *__restrict__ tails, unsigned long long *__restrict__ n_markers)
+__device__ __forceinline__ uint32_t lanes_below(uint64_t ballot)       // set bits of `ballot` in lanes below this one
 {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+}
+
+__global__ __launch_bounds__(256) void k_gz_tails(const uint16_t *__restrict__ syms, const uint64_t *__restrict__ out_off, const uint32_t *__restrict__ n_out,
+                                                  const uint8_t *__restrict__ window_in, uint16_t *__restrict__ tails, uint16_t *__restrict__ tails_b,
+                                                  uint32_t *__restrict__ list, uint64_t list_cap, unsigned long long *__restrict__ n_markers)
+{
+    __shared__ uint32_t sh_wave[4];
+    __shared__ unsigned long long sh_base;
     const uint32_t q = blockIdx.x;
-    uint16_t *t = tails + (size_t)q * GZ_WIN;
+    uint16_t *t = tails + (size_t)q * GZ_WIN, *tb = tails_b + (size_t)q * GZ_WIN;
     if (q == 0) {
-        for (uint32_t i = threadIdx.x; i < GZ_WIN; i += blockDim.x) t[i] = window_in[i];
+        for (uint32_t i = threadIdx.x; i < GZ_WIN; i += blockDim.x) { const uint16_t v = window_in[i]; t[i] = v; tb[i] = v; }
         return;
     }
     const uint32_t n = n_out[q - 1];
     const uint16_t *src = syms + out_off[q - 1];
-    uint32_t marked = 0;
-    for (uint32_t i = threadIdx.x; i < GZ_WIN; i += blockDim.x) {
+    // a wave takes a quarter of the tail, 64 consecutive positions at a time, so that the markers' places can be listed in
+    // the order of the positions: the rounds of pointer doubling then touch neighbouring symbols from neighbouring lanes
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, first = wave * (GZ_WIN / 4);
+    uint64_t flags[2] = {0, 0};                        // this lane's markers: bit k for position first + 64 k + lane
+    uint32_t total = 0;
+    for (uint32_t k = 0; k < GZ_WIN / 256; ++k) {
+        const uint32_t i = first + 64u * k + lane;
         const int64_t rel = (int64_t)n - (int64_t)GZ_WIN + i;
         const uint16_t v = rel >= 0 ? src[rel] : (uint16_t)(GZ_MARK | (uint32_t)(GZ_WIN + rel));
-        marked += v >> 15;
+        const bool is_marker = (v & GZ_MARK) != 0;
+        if (is_marker) flags[k >> 6] |= 1ull << (k & 63u);
+        total += (uint32_t)__popcll(__ballot(is_marker));
         t[i] = v;
+        tb[i] = v;
     }
-    if (marked) atomicAdd(n_markers, (unsigned long long)marked);
+    if (lane == 0) sh_wave[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t sum = sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3];
+        sh_base = sum ? atomicAdd(n_markers, (unsigned long long)sum) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long at = sh_base;
+    for (uint32_t w = 0; w < wave; ++w) at += sh_wave[w];
+    for (uint32_t k = 0; k < GZ_WIN / 256 && total; ++k) {
+        const bool is_marker = (flags[k >> 6] >> (k & 63u)) & 1ull;
+        const uint64_t ballot = __ballot(is_marker);
+        const unsigned long long mine = at + lanes_below(ballot);
+        if (is_marker && mine < list_cap) list[mine] = (q << 15) | (first + 64u * k + lane);
+        at += (uint32_t)__popcll(ballot);
+    }
 }
 
-// one round of pointer doubling: the markers of tail q name positions of tail q - d.  *n_markers: how many are left.
-__global__ void k_gz_scan(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, uint32_t d, unsigned long long *__restrict__ n_markers)
+// One round of pointer doubling over the list of markers: entry (q, i) names position i of tail q, whose marker (in `src`)
+// names a position of tail q - d.  The new value goes to `dst`; a byte (the end of the chain) goes to BOTH copies, so
+// that whichever one a later reader looks at is right, and leaves the list; a marker stays on it, in the same order,
+// for the next round.
+__global__ __launch_bounds__(256) void k_gz_scan_list(uint16_t *__restrict__ src, uint16_t *__restrict__ dst, const uint32_t *__restrict__ list, uint64_t n_list,
+                                                      uint32_t *__restrict__ list_out, uint32_t d, unsigned long long *__restrict__ n_out)
+{
+    __shared__ uint32_t sh_wave[4];
+    __shared__ unsigned long long sh_base;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t first = (uint64_t)blockIdx.x * 4096u + wave * 1024u;        // 16 rows of 64 entries per wave
+    uint32_t keep = 0, total = 0;
+    for (uint32_t k = 0; k < 16; ++k) {
+        const uint64_t at = first + 64u * k + lane;
+        bool stays = false;
+        if (at < n_list) {
+            const uint32_t e = list[at], q = e >> 15, i = e & (GZ_WIN - 1u);
+            if (q >= d) {                              // (always: the tails in front of the stride are plain)
+                const uint16_t v = src[(size_t)q * GZ_WIN + i];
+                const uint16_t w = (v & GZ_MARK) ? src[(size_t)(q - d) * GZ_WIN + (v & (GZ_WIN - 1u))] : v;
+                dst[(size_t)q * GZ_WIN + i] = w;
+                stays = (w & GZ_MARK) != 0;
+                if (!stays) src[(size_t)q * GZ_WIN + i] = w;
+            }
+        }
+        if (stays) keep |= 1u << k;
+        total += (uint32_t)__popcll(__ballot(stays));
+    }
+    if (lane == 0) sh_wave[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t sum = sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3];
+        sh_base = sum ? atomicAdd(n_out, (unsigned long long)sum) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long out = sh_base;
+    for (uint32_t w = 0; w < wave; ++w) out += sh_wave[w];
+    for (uint32_t k = 0; k < 16 && total; ++k) {
+        const bool stays = (keep >> k) & 1u;
+        const uint64_t ballot = __ballot(stays);
+        if (stays) list_out[out + lanes_below(ballot)] = list[first + 64u * k + lane];
+        out += (uint32_t)__popcll(ballot);
+    }
+}
+
+// the same round over whole tails (when the list of markers would not fit its buffer): the markers of tail q name
+// positions of tail q - d.  *n_markers: how many are left.
+__global__ __launch_bounds__(256) void k_gz_scan(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, uint32_t d, unsigned long long *__restrict__ n_markers)
 {
     const uint32_t q = blockIdx.x;
-    const uint16_t *t = in + (size_t)q * GZ_WIN;
-    uint16_t *o = out + (size_t)q * GZ_WIN;
+    const uint2 *t = (const uint2 *)(in + (size_t)q * GZ_WIN);
+    uint2 *o = (uint2 *)(out + (size_t)q * GZ_WIN);
     if (q < d) {
-        for (uint32_t i = threadIdx.x; i < GZ_WIN / 4; i += blockDim.x) ((uint64_t *)o)[i] = ((const uint64_t *)t)[i];
+        for (uint32_t i = threadIdx.x; i < GZ_WIN / 4; i += blockDim.x) o[i] = t[i];
         return;
     }
     const uint16_t *before = in + (size_t)(q - d) * GZ_WIN;
     uint32_t marked = 0;
-    for (uint32_t i = threadIdx.x; i < GZ_WIN; i += blockDim.x) {
-        uint16_t v = t[i];
-        if (v & GZ_MARK) v = before[v & (GZ_WIN - 1u)];
-        marked += v >> 15;
+    for (uint32_t i = threadIdx.x; i < GZ_WIN / 4; i += blockDim.x) {          // four symbols per thread and step
+        uint2 v = t[i];
+        uint32_t s0 = v.x & 0xffffu, s1 = v.x >> 16, s2 = v.y & 0xffffu, s3 = v.y >> 16;
+        if ((v.x | v.y) & 0x80008000u) {
+            if (s0 & GZ_MARK) s0 = before[s0 & (GZ_WIN - 1u)];
+            if (s1 & GZ_MARK) s1 = before[s1 & (GZ_WIN - 1u)];
+            if (s2 & GZ_MARK) s2 = before[s2 & (GZ_WIN - 1u)];
+            if (s3 & GZ_MARK) s3 = before[s3 & (GZ_WIN - 1u)];
+            v.x = s0 | (s1 << 16);
+            v.y = s2 | (s3 << 16);
+            marked += (uint32_t)__popc((v.x | 0u) & 0x80008000u) + (uint32_t)__popc(v.y & 0x80008000u);
+        }
         o[i] = v;
     }
     if (marked) atomicAdd(n_markers, (unsigned long long)marked);
@@ -689,26 +793,26 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     uint8_t *d_comp = (uint8_t *)g->a->comp.p;
     KV_HIP(hipMemcpyAsync(d_comp, g->image + first_byte, n_bytes, hipMemcpyHostToDevice, st));
     KV_HIP(hipMemsetAsync(d_comp + n_bytes, 0, (uint64_t)n_chunks * CH + 2 * GZ_SLACK - n_bytes, st));
-    KV_HIP(g->a->small.need(kv_round_up((uint64_t)n_chunks * 8, 256) + 256));
+    KV_HIP(g->a->small.need(kv_round_up((uint64_t)n_chunks * GZ_FIND_KEEP * 8, 256) + 256));
     unsigned long long *d_cand = (unsigned long long *)g->a->small.p;
-    unsigned long long *d_ctr = (unsigned long long *)((unsigned char *)g->a->small.p + kv_round_up((uint64_t)n_chunks * 8, 256));
+    unsigned long long *d_ctr = (unsigned long long *)((unsigned char *)g->a->small.p + kv_round_up((uint64_t)n_chunks * GZ_FIND_KEEP * 8, 256));
     {
         KvProfScope prof("k_gz_find");
         hipLaunchKernelGGL(k_gz_find, dim3(n_chunks), dim3(GZ_FIND_THREADS), CH + GZ_SLACK + 8, st, (const uint8_t *)d_comp, n_bytes, CH, n_chunks, d_cand);
     }
     KV_HIP(hipGetLastError());
-    std::vector<unsigned long long> cand(n_chunks);
-    KV_HIP(hipMemcpyAsync(cand.data(), d_cand, (uint64_t)n_chunks * 8, hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> cand((uint64_t)n_chunks * GZ_FIND_KEEP);
+    KV_HIP(hipMemcpyAsync(cand.data(), d_cand, (uint64_t)n_chunks * GZ_FIND_KEEP * 8, hipMemcpyDeviceToHost, st));
     KV_HIP(hipStreamSynchronize(st));
     // ---- stretches: from the exact position the last segment ended at, then from every found start up to the first one
     // behind the segment
     const uint64_t start_rel = g->pos_bit - first_byte * 8, seg_end_rel = (seg_end - first_byte) * 8;
     std::vector<uint64_t> starts(1, start_rel);
     bool have_terminal = false;
-    for (uint32_t c = 0; c < n_chunks; ++c) {
+    for (uint64_t c = 0; c < (uint64_t)n_chunks * GZ_FIND_KEEP && !have_terminal; ++c) {
         if (cand[c] == ~0ull || cand[c] <= start_rel) continue;
         starts.push_back(cand[c]);
-        if (!to_file_end && cand[c] >= seg_end_rel) { have_terminal = true; break; }
+        if (!to_file_end && cand[c] >= seg_end_rel) have_terminal = true;
     }
     if (!to_file_end && !have_terminal && !is_file_end) {
         kv_set_error("no DEFLATE block start within %llu MB behind byte %llu", (unsigned long long)(margin >> 20), (unsigned long long)seg_end);
@@ -821,8 +925,14 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
         KV_HIP(hipMemsetAsync(g->a->window.p, 0, GZ_WIN, st));         // nothing valid points in front of the first byte
         g->window_ready = true;
     }
-    KV_HIP(g->a->tails.need((uint64_t)(nv + 1) * GZ_WIN * 2 * 2));
-    uint16_t *t0 = (uint16_t *)g->a->tails.p, *t1 = t0 + (uint64_t)(nv + 1) * GZ_WIN;
+    // two copies of the tails (source and destination of a round) and two lists of marker places, room for an eighth of all
+    // places (with more markers than that -- DNA: zlib codes the bases as short matches all over the window, half of a tail is
+    // markers -- going over the whole tails moves fewer bytes than a list would)
+    const uint64_t tail_syms = (uint64_t)(nv + 1) * GZ_WIN;
+    const uint64_t list_cap = nv + 1 <= (1u << 17) ? tail_syms / 8 : 0;
+    KV_HIP(g->a->tails.need(tail_syms * 2 * 2 + list_cap * 4 * 2 + 256));
+    uint16_t *t0 = (uint16_t *)g->a->tails.p, *t1 = t0 + tail_syms;
+    uint32_t *l0 = (uint32_t *)(t1 + tail_syms), *l1 = l0 + list_cap;
     KV_HIP(hipMemcpyAsync(d_off, g->v_off.data(), nv * 8, hipMemcpyHostToDevice, st));
     KV_HIP(hipMemcpyAsync(d_base, g->v_base.data(), nv * 8, hipMemcpyHostToDevice, st));
     KV_HIP(hipMemcpyAsync(d_n, g->v_n.data(), nv * 4, hipMemcpyHostToDevice, st));
@@ -832,16 +942,23 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     {
         KvProfScope prof("k_gz_tails");
         hipLaunchKernelGGL(k_gz_tails, dim3((unsigned)(nv + 1)), dim3(256), 0, st, (const uint16_t *)d_syms, (const uint64_t *)d_off, (const uint32_t *)d_n,
-                           (const uint8_t *)g->a->window.p, t0, d_markers);
+                           (const uint8_t *)g->a->window.p, t0, t1, l0, list_cap, d_markers);
     }
     KV_HIP(hipMemcpyAsync(&markers, d_markers, 8, hipMemcpyDeviceToHost, st));
     KV_HIP(hipStreamSynchronize(st));
-    // (markers die out fast -- a chain of copies has to lead back through a whole stretch to survive a round -- so the
-    // rounds stop as soon as none is left, usually after two or three)
+    // FASTQ needs nearly every round (each read's header is a copy of the one before it: a chain as long as the file)
+    const bool listed = markers <= list_cap;
+    if (getenv("KV_GUNZIP_VERBOSE"))
+        fprintf(stderr, "[kv_gunzip] %zu stretches, %llu of %llu tail symbols are markers (%s)\n", nv, markers, (unsigned long long)tail_syms, listed ? "listed" : "whole tails");
     for (uint64_t d = 1; d < nv + 1 && markers; d <<= 1) {
         KvProfScope prof("k_gz_scan");
         KV_HIP(hipMemsetAsync(d_markers, 0, 8, st));
-        hipLaunchKernelGGL(k_gz_scan, dim3((unsigned)(nv + 1)), dim3(256), 0, st, (const uint16_t *)t0, t1, (uint32_t)d, d_markers);
+        if (listed) {
+            hipLaunchKernelGGL(k_gz_scan_list, dim3((unsigned)((markers + 4095) / 4096)), dim3(256), 0, st, t0, t1, (const uint32_t *)l0, (uint64_t)markers, l1, (uint32_t)d, d_markers);
+            std::swap(l0, l1);
+        } else {
+            hipLaunchKernelGGL(k_gz_scan, dim3((unsigned)(nv + 1)), dim3(256), 0, st, (const uint16_t *)t0, t1, (uint32_t)d, d_markers);
+        }
         KV_HIP(hipMemcpyAsync(&markers, d_markers, 8, hipMemcpyDeviceToHost, st));
         KV_HIP(hipStreamSynchronize(st));
         std::swap(t0, t1);

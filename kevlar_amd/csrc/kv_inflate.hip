@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 5 : RBITS == 1
         if (job.isize == 0) continue;                 // BGZF's end-of-file marker, or an empty member
         BitReader br;                                 // identical in every lane
         br_init(br, comp + job.in_off);
+        const uint32_t limit_words = (job.in_len + 3u) / 4u + 4u;     // a reader further than this has left the payload (damaged data)
         uint32_t o = 0;                               // bytes of text produced
         uint32_t lit = 0, n_lit = 0;                  // literals not yet stored: lane i holds the i-th, n_lit of them
         bool failed = job.isize > INF_MAX_OUT;
@@ -152,15 +153,19 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 5 : RBITS == 1
             __builtin_amdgcn_wave_barrier();
             if (!ok) { failed = true; break; }
             // ---- symbols
+            // (the size and the end of the payload are checked when text is stored, not per literal: the loop is bound by the
+            // number of instructions it issues)
             for (;;) {
                 const int sym = decode_sym(br, sh.ll_count, sh.ll_symbol, sh.ll_table, INF_FAST_LL);
-                if (sym < 0) { failed = true; break; }
-                if (sym < 256) {
-                    if (o + n_lit >= job.isize) { failed = true; break; }
+                if ((uint32_t)sym < 256u) {
                     lit = lane == n_lit ? (uint32_t)sym : lit;
-                    if (++n_lit == 64) flush();
+                    if (++n_lit == 64) {
+                        if (o + 64 > job.isize || br.next > limit_words) { failed = true; break; }
+                        flush();
+                    }
                     continue;
                 }
+                if (sym < 0 || o + n_lit > job.isize || br.next > limit_words) { failed = true; break; }
                 flush();
                 if (sym == 256) break;
                 const int ls = sym - 257;
@@ -246,7 +251,7 @@ int kv_bgzf_index(const uint8_t *file, uint64_t size, std::vector<KvBgzfMember> 
 }
 
 // Inflate members [first, first + count) of a BGZF image whose bytes [comp_base, comp_base + comp_len) sit at d_comp (with
-// 16 readable bytes behind them): member i's text goes to d_text + text_off[i].  Runs on the calling thread's stream and
+// 512 readable bytes behind them): member i's text goes to d_text + text_off[i].  Runs on the calling thread's stream and
 // returns once the text is there.
 int kv_bgzf_inflate(const uint8_t *d_comp, uint64_t comp_base, const KvBgzfMember *members, uint64_t count, const uint64_t *text_off,
                     uint8_t *d_text, KvArena &scratch)
@@ -330,10 +335,10 @@ extern "C" int kv_bgzf_inflate_host(const void *file, uint64_t size, void *out, 
     KvArena scratch;
     hipStream_t st = kv_stream();
     int rc = KV_OK;
-    hipError_t e = hipMalloc((void **)&d_comp, size + 64);
+    hipError_t e = hipMalloc((void **)&d_comp, size + 512);
     if (e == hipSuccess) e = hipMalloc((void **)&d_text, total + 64);
     if (e == hipSuccess) e = hipMemcpyAsync(d_comp, file, size, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemsetAsync(d_comp + size, 0, 64, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_comp + size, 0, 512, st);
     if (e == hipSuccess) {
         hipEvent_t a, b;
         (void)hipEventCreate(&a); (void)hipEventCreate(&b);
