@@ -8,8 +8,9 @@
 //
 //   1. k_gz_find    the stream is cut into chunks of 16 KB; one workgroup per chunk tries every bit offset as the start
 //                   of a dynamic-Huffman block: 3 header bits, the two code counts, a COMPLETE code-length code (all 64
-//                   lanes x 4 waves, one offset each), then for the few survivors the full set of literal/length and
-//                   distance code lengths, which must form complete codes with an end-of-block symbol.  First hit wins.
+//                   lanes x 4 waves, 32 offsets each from registers), then for the few survivors the full set of
+//                   literal/length and distance code lengths, which must form complete codes with an end-of-block symbol.
+//                   The first four hits of a chunk are kept.
 //   2. k_gz_decode  one wavefront per found start decodes until it lands exactly on a later start (kv_inflate.hip's
 //                   wave-uniform Huffman walk).  Text goes out as 16-bit symbols: a byte, or -- for a match that reaches
 //                   back beyond the wave's own start -- a MARKER naming the position in the unknown 32 KB window.
@@ -20,11 +21,13 @@
 //                   pointer doubling resolve all tails at once.
 //   4. k_gz_resolve every stretch replaces its markers from the (now plain) tail in front of it and stores bytes, packed to
 //                   the text offset the prefix sum of the lengths gives it.
+//   5. k_gz_crc     CRC-32 of the text in slices of 8 KB, cut at the member ends the decoders saw; the host joins the slices
+//                   of a member and compares with its trailer (ISIZE too).
 //
-// The file is taken a segment of compressed bytes at a time; the last tail and the exact bit position travel to the next
-// segment.  Concatenated members are followed inside k_gz_decode.  CRC-32 and ISIZE are not checked; tests compare with
-// zlib byte for byte.  Anything unexpected (no block found for megabytes, trailing garbage, corrupt codes) is reported as
-// KV_ERR_TYPE and the caller's host parser (zlib) takes the file.  Reference: the reader this replaces is
+// The file is taken a segment of compressed bytes at a time; the last tail, the running CRC and the exact bit position
+// travel to the next segment.  Concatenated members are followed inside k_gz_decode.  Tests compare with zlib byte for
+// byte.  Anything unexpected (no block found for megabytes, trailing garbage, corrupt codes, a CRC or length that does not
+// match) is reported as KV_ERR_TYPE and the caller's host parser (zlib) takes the file.  Reference: the reader this replaces is
 // khmer.ReadParser's gzip stream (kevlar/__init__.py:125-128 opens every *.gz through it).
 #include <algorithm>
 #include <cstring>

@@ -20,5 +20,8 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-replay > $OUT/bench_under_rocprof_default.json 2> $OUT/trace_default.err
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 > /dev/null 2> $OUT/pmc_fetch.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 > /dev/null 2> $OUT/pmc_write.err
+# ingest: one ordinary gzip stream / one BGZF file of 2 M reads through the device inflaters
+(cd $REPO && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_gunzip -- python3 scratch/gunzip_rate.py 2000000 6 > $OUT/gunzip_rate.log 2> $OUT/trace_gunzip.err)
+(cd $REPO && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bgzf -- python3 scratch/inflate_rate.py 2000000 > $OUT/inflate_rate.log 2> $OUT/trace_bgzf.err)
 python3 $REPO/profiles/summarise.py $OUT $OUT/summary
 ls -la $OUT/summary

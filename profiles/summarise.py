@@ -88,6 +88,21 @@ def main(src, dst):
             for row in rows[1:]:
                 if row and ('k_' in row[0] or 'memset' in row[0].lower() or 'rocprim' in row[0]):
                     w.writerow(row)
+    # the ingest kernels: one gzip stream and one BGZF file of 2 M reads inflated on the device (scratch/gunzip_rate.py,
+    # scratch/inflate_rate.py under the profiler)
+    for sub, name in (('trace_gunzip', 'ingest_gzip_kernel_stats.csv'), ('trace_bgzf', 'ingest_bgzf_kernel_stats.csv')):
+        stats = sorted(glob.glob(os.path.join(src, sub, '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime, reverse=True)
+        if stats:
+            with open(stats[0]) as fh, open(os.path.join(dst, name), 'w') as out:
+                rows = list(csv.reader(fh))
+                w = csv.writer(out)
+                w.writerow(rows[0])
+                for row in rows[1:]:
+                    if row and 'k_' in row[0]:
+                        w.writerow(row)
+    for log in ('gunzip_rate.log', 'inflate_rate.log'):
+        if os.path.exists(os.path.join(src, log)):
+            shutil.copy(os.path.join(src, log), os.path.join(dst, log))
 
 
 if __name__ == '__main__':
