@@ -21,7 +21,7 @@
 //                   pointer doubling resolve all tails at once.
 //   4. k_gz_resolve every stretch replaces its markers from the (now plain) tail in front of it and stores bytes, packed to
 //                   the text offset the prefix sum of the lengths gives it.
-//   5. k_gz_crc     CRC-32 of the text in slices of 8 KB, cut at the member ends the decoders saw; the host joins the slices
+//   5. k_gz_crc     CRC-32 of the text in slices of 16 KB, cut at the member ends the decoders saw; the host joins the slices
 //                   of a member and compares with its trailer (ISIZE too).
 //
 // The file is taken a segment of compressed bytes at a time; the last tail, the running CRC and the exact bit position
@@ -31,6 +31,7 @@
 // khmer.ReadParser's gzip stream (kevlar/__init__.py:125-128 opens every *.gz through it).
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include <zlib.h>
@@ -45,7 +46,6 @@ namespace {
 #define GZ_MARK 0x8000u
 #define GZ_FAST_LL 9                 // bits of the literal/length lookup table (9: 32 workgroups of LDS per CU)
 #define GZ_SLACK 2048u               // readable zero bytes behind the compressed buffer
-#define GZ_CRC_SLICE 8192u            // bytes of text per thread of k_gz_crc
 #define GZ_FIND_KEEP 4u                // block starts kept per chunk
 #define GZ_FIND_THREADS 256
 #define GZ_FIND_LIST 1024u           // survivors of the cheap test a chunk may have (more: the later ones are not looked at)
@@ -690,6 +690,56 @@ uint64_t host_member_header(const uint8_t *file, uint64_t size, uint64_t at)
 
 }  // namespace
 
+// CRC-32 of ranges of text that sits on the device: out[r] for d_text[start[r], start[r] + len[r]); returns when they are there
+int kv_crc32_ranges(const uint8_t *d_text, const uint64_t *start, const uint32_t *len, size_t n, uint32_t *out, KvArena &scratch)
+{
+    if (n == 0) return KV_OK;
+    hipStream_t st = kv_stream();
+    const size_t b_start = kv_round_up(n * 8, 256), b_len = kv_round_up(n * 4, 256);
+    KV_HIP(scratch.need(b_start + 2 * b_len));
+    uint64_t *d_start = (uint64_t *)scratch.p;
+    uint32_t *d_len = (uint32_t *)((unsigned char *)scratch.p + b_start), *d_out = (uint32_t *)((unsigned char *)scratch.p + b_start + b_len);
+    KV_HIP(hipMemcpyAsync(d_start, start, n * 8, hipMemcpyHostToDevice, st));
+    KV_HIP(hipMemcpyAsync(d_len, len, n * 4, hipMemcpyHostToDevice, st));
+    {
+        KvProfScope prof("k_gz_crc");
+        hipLaunchKernelGGL(k_gz_crc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_text, (const uint64_t *)d_start, (const uint32_t *)d_len, (uint32_t)n, d_out);
+    }
+    KV_HIP(hipGetLastError());
+    KV_HIP(hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    return KV_OK;
+}
+
+// CRC-32 of A followed by B from the CRC-32 of each and the length of B (zlib's crc32_combine).  Appending len_b zero bytes is
+// a linear map of the CRC: for the lengths that keep coming back (the slice length; the last slice of a full BGZF member) it
+// is kept as a GF(2) matrix, 32 XORs instead of zlib's chain of matrix squarings (~3 us a call).
+uint32_t kv_crc32_join(uint32_t crc_a, uint32_t crc_b, uint32_t len_b)
+{
+    struct Op { uint32_t len = 0; uint32_t col[32]; };
+    static thread_local Op ops[3];                     // [0]: the slice length; [1], [2]: other lengths that came up twice in a row
+    static thread_local uint32_t last_miss = 0, victim = 1;
+    if (len_b == 0) return crc_a;
+    if (crc_a == 0) return crc_b;                      // A is empty
+    Op *op = nullptr;
+    for (Op &o : ops)
+        if (o.len == len_b) { op = &o; break; }
+    if (!op) {
+        if (len_b != KV_CRC_SLICE && len_b != last_miss) {           // a length seen once is not worth the 32 calls that build its matrix
+            last_miss = len_b;
+            return (uint32_t)crc32_combine(crc_a, crc_b, len_b);
+        }
+        op = len_b == KV_CRC_SLICE ? &ops[0] : &ops[victim];
+        if (len_b != KV_CRC_SLICE) victim = 3 - victim;
+        op->len = len_b;
+        for (int b = 0; b < 32; ++b) op->col[b] = (uint32_t)crc32_combine(1ul << b, 0, len_b);
+    }
+    uint32_t moved = 0;
+    for (uint32_t v = crc_a, b = 0; v; v >>= 1, ++b)
+        if (v & 1u) moved ^= op->col[b];
+    return moved ^ crc_b;
+}
+
 // ---------------------------------------------------------------- host side
 struct KvGunzip {
     const uint8_t *image = nullptr;
@@ -701,7 +751,6 @@ struct KvGunzip {
     uint32_t isize_total = 0;         // of the members that have ended so far (mod 2^32, as the field is)
     uint32_t crc_run = 0;             // CRC-32 of the text of the member that is open at pos_bit
     bool crc_on = true;               // off: KV_GUNZIP_CRC=0, or a stretch passed more than one member end (their starts in the text are not recorded)
-    uint32_t slice_op[32];            // crc32_combine(x, 0, GZ_CRC_SLICE) as a GF(2) matrix
     std::vector<std::pair<uint64_t, uint32_t>> pending_ends;      // of the pending segment: (text offset a member ends at, the CRC-32 its trailer holds)
 
     uint32_t chunk_bytes = 16384;
@@ -732,7 +781,6 @@ KvGunzip *kv_gunzip_open(const uint8_t *image, uint64_t size, KvGunzipArenas *ar
     if (cb && atoi(cb) >= 1 && atoi(cb) <= 64) g->chunk_bytes = (uint32_t)atoi(cb) * 1024u;
     const char *cc = getenv("KV_GUNZIP_CRC");
     g->crc_on = !(cc && !strcmp(cc, "0"));
-    for (int b = 0; b < 32; ++b) g->slice_op[b] = (uint32_t)crc32_combine(1ul << b, 0, GZ_CRC_SLICE);
     return g;
 }
 
@@ -1003,7 +1051,7 @@ int kv_gunzip_emit(KvGunzip *g, uint8_t *d_text)
     }
     KV_HIP(hipGetLastError());
     if (g->crc_on) {
-        // the text member by member (ends from the decoders), every member in slices of 8 KB: one thread each, joined here
+        // the text member by member (ends from the decoders), every member in slices of 16 KB: one thread each, joined here
         std::vector<uint64_t> r_start;
         std::vector<uint32_t> r_len;
         std::vector<uint32_t> r_closes;                // index into pending_ends + 1 for the range that ends a member, else 0
@@ -1016,38 +1064,18 @@ int kv_gunzip_emit(KvGunzip *g, uint8_t *d_text)
                 r_start.push_back(at); r_len.push_back(0); r_closes.push_back((uint32_t)++e);
                 continue;
             }
-            const uint32_t n = (uint32_t)std::min<uint64_t>(stop - at, GZ_CRC_SLICE);
+            const uint32_t n = (uint32_t)std::min<uint64_t>(stop - at, KV_CRC_SLICE);
             r_start.push_back(at); r_len.push_back(n);
             at += n;
             r_closes.push_back(at == stop && e < g->pending_ends.size() ? (uint32_t)++e : 0u);
         }
         const size_t nr = r_start.size();
         if (nr) {
-            const size_t b_start = kv_round_up(nr * 8, 256), b_len = kv_round_up(nr * 4, 256);
-            KV_HIP(g->a->crc.need(b_start + 2 * b_len));
-            uint64_t *d_start = (uint64_t *)g->a->crc.p;
-            uint32_t *d_len = (uint32_t *)((unsigned char *)g->a->crc.p + b_start), *d_out = (uint32_t *)((unsigned char *)g->a->crc.p + b_start + b_len);
-            KV_HIP(hipMemcpyAsync(d_start, r_start.data(), nr * 8, hipMemcpyHostToDevice, st));
-            KV_HIP(hipMemcpyAsync(d_len, r_len.data(), nr * 4, hipMemcpyHostToDevice, st));
-            {
-                KvProfScope prof("k_gz_crc");
-                hipLaunchKernelGGL(k_gz_crc, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_text, (const uint64_t *)d_start, (const uint32_t *)d_len,
-                                   (uint32_t)nr, d_out);
-            }
-            KV_HIP(hipGetLastError());
             std::vector<uint32_t> crcs(nr);
-            KV_HIP(hipMemcpyAsync(crcs.data(), d_out, nr * 4, hipMemcpyDeviceToHost, st));
-            KV_HIP(hipStreamSynchronize(st));
+            { const int rc = kv_crc32_ranges(d_text, r_start.data(), r_len.data(), nr, crcs.data(), g->a->crc); if (rc != KV_OK) return rc; }
             uint32_t run = g->crc_run;
             for (size_t r = 0; r < nr; ++r) {
-                if (r_len[r] == GZ_CRC_SLICE) {
-                    uint32_t moved = 0;
-                    for (uint32_t v = run, b = 0; v; v >>= 1, ++b)
-                        if (v & 1u) moved ^= g->slice_op[b];
-                    run = moved ^ crcs[r];
-                } else if (r_len[r]) {
-                    run = (uint32_t)crc32_combine(run, crcs[r], r_len[r]);
-                }
+                run = kv_crc32_join(run, crcs[r], r_len[r]);
                 if (r_closes[r]) {
                     if (run != g->pending_ends[r_closes[r] - 1].second) {
                         kv_set_error("gzip stream: the CRC-32 of a member does not match its text (damaged file)");

@@ -17,8 +17,8 @@
 //   * text leaves for HBM in rows of up to 64 bytes as it is produced.
 //
 // Decoding one member is a chain of dependent lookups (a few hundred cycles per symbol whatever the code does), so the rate
-// comes from members in flight: 32 workgroups per CU (8 waves per SIMD), ~8000 members on the device.  The CRC-32 of a member is not checked
-// (its ISIZE is); tests compare the output with zlib's byte for byte.  Reference: the reader this replaces is
+// comes from members in flight: 32 workgroups per CU (8 waves per SIMD), ~8000 members on the device.  ISIZE and CRC-32 of every
+// member are checked (k_gz_crc of kv_gunzip.hip over the text); tests compare the output with zlib's byte for byte.  Reference: the reader this replaces is
 // khmer.ReadParser's gzip stream (kevlar/__init__.py:125-128 opens every *.gz through it).
 #include <algorithm>
 #include <cstring>
@@ -242,6 +242,8 @@ int kv_bgzf_index(const uint8_t *file, uint64_t size, std::vector<KvBgzfMember> 
         m.in_len = bsize - 12 - xlen - 8;
         const uint8_t *t = file + pos + bsize - 4;
         m.isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+        m.crc = t[-4] | (t[-3] << 8) | (t[-2] << 16) | ((uint32_t)t[-1] << 24);
+        m.pad = 0;
         if (m.isize > INF_MAX_OUT) return KV_OK;
         members->push_back(m);
         pos += bsize;
@@ -300,6 +302,29 @@ int kv_bgzf_inflate(const uint8_t *d_comp, uint64_t comp_base, const KvBgzfMembe
     if (ctr[1] != 0) {
         kv_set_error("corrupt BGZF data: %llu member(s) did not inflate to their stated size (first: member %llu of the batch)", ctr[1], ctr[2]);
         return KV_ERR_IO;
+    }
+    // the members' CRC-32, as zlib / htslib would check it: slices of 16 KB of every member's text, joined per member
+    const char *crc_env = getenv("KV_GUNZIP_CRC");
+    if (!(crc_env && !strcmp(crc_env, "0"))) {
+        std::vector<uint64_t> r_start;
+        std::vector<uint32_t> r_len;
+        r_start.reserve(count * 8); r_len.reserve(count * 8);
+        for (uint64_t i = 0; i < count; ++i)
+            for (uint32_t at = 0; at < members[i].isize; at += KV_CRC_SLICE) {
+                r_start.push_back(text_off[i] + at);
+                r_len.push_back(std::min<uint32_t>(KV_CRC_SLICE, members[i].isize - at));
+            }
+        std::vector<uint32_t> crcs(r_start.size());
+        { const int rc = kv_crc32_ranges(d_text, r_start.data(), r_len.data(), r_start.size(), crcs.data(), scratch); if (rc != KV_OK) return rc; }
+        size_t r = 0;
+        for (uint64_t i = 0; i < count; ++i) {
+            uint32_t run = 0;
+            for (uint32_t at = 0; at < members[i].isize; at += KV_CRC_SLICE, ++r) run = kv_crc32_join(run, crcs[r], r_len[r]);
+            if (run != members[i].crc) {
+                kv_set_error("corrupt BGZF data: the CRC-32 of member %llu of the batch does not match its text", (unsigned long long)i);
+                return KV_ERR_IO;
+            }
+        }
     }
     return KV_OK;
 }

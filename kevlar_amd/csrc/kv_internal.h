@@ -231,11 +231,18 @@ struct KvBgzfMember {
     uint64_t in_off;     // the member's deflate payload in the file
     uint32_t in_len;
     uint32_t isize;      // bytes it inflates to
+    uint32_t crc;        // CRC-32 of them, as the member's trailer has it
+    uint32_t pad;
 };
 struct KvArena;
 int kv_bgzf_index(const uint8_t *file, uint64_t size, std::vector<KvBgzfMember> *members, int *is_bgzf);
 int kv_bgzf_inflate(const uint8_t *d_comp, uint64_t comp_base, const KvBgzfMember *members, uint64_t count, const uint64_t *text_off,
                     uint8_t *d_text, KvArena &scratch);
+
+// CRC-32 of text on the device, a thread per range (kv_gunzip.hip); ranges of KV_CRC_SLICE bytes join fastest
+#define KV_CRC_SLICE 16384u
+int kv_crc32_ranges(const uint8_t *d_text, const uint64_t *start, const uint32_t *len, size_t n, uint32_t *out, KvArena &scratch);
+uint32_t kv_crc32_join(uint32_t crc_a, uint32_t crc_b, uint32_t len_b);
 
 // ---- ordinary gzip on the device (kv_gunzip.hip): a segment of the stream per decode/emit pair ----
 struct KvGunzip;

@@ -73,6 +73,11 @@ def test_device_inflate_reports_corruption(hk):
     assert 'BGZF' in str(err.value)
     with pytest.raises(Exception):
         device_inflate(gzip.compress(text))          # plain gzip: not BGZF
+    stored = bytearray(bgzf.member(text[:60000], level=0) + bgzf._EOF)
+    stored[30000] ^= 0x01                   # inside a stored block: only the CRC-32 can tell
+    with pytest.raises(Exception) as err:
+        device_inflate(bytes(stored))
+    assert 'CRC-32' in str(err.value)
 
 
 def device_gunzip(image, segment=0, cap=None):
