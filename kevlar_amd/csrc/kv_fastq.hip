@@ -24,6 +24,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -306,6 +307,15 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
     d->n_batch = 0;
     if (d->done) return KV_OK;
     hipStream_t st = kv_stream();
+    const bool verbose = getenv("KV_INGEST_VERBOSE") != nullptr;   // wall time of the steps of a batch on stderr
+    auto t_mark = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!verbose) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[kv_ingest] %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_mark).count());
+        t_mark = now;
+    };
     const char *cap_env = getenv("KV_INGEST_TEXT_MB");            // tests shrink the batches
     const uint64_t text_cap = (cap_env ? strtoull(cap_env, nullptr, 10) : 4096ull) << 20;
     const double per_read = d->bytes_per_read > 0 ? d->bytes_per_read : 280.0;
@@ -326,6 +336,8 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         } else {
             while (m1 < d->members.size() && (m1 == m0 || d->carry_len + fresh + d->members[m1].isize <= want)) fresh += d->members[m1++].isize;
         }
+        lap(d->gz ? "gunzip: decode" : "select");
+        lap(d->gz ? "gunzip: decode" : "select");
         const bool final = d->gz ? gz_last : d->plain ? b0 + fresh == d->image_size : m1 == d->members.size();
         const uint64_t total_in = d->carry_len + fresh;
         if (total_in == 0) { d->done = true; return KV_OK; }
@@ -345,6 +357,7 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
             const int rc = kv_bgzf_inflate((const uint8_t *)d->buf->comp.p, c0, d->members.data() + m0, m1 - m0, text_off.data(), text, d->buf->scratch);
             if (rc != KV_OK) return rc;
         }
+        lap("text on the device");
         // ---- lines
         const uint32_t n_chunks = (uint32_t)((total_in + 1 + FQ_CHUNK - 1) / FQ_CHUNK);
         const size_t b_counts = kv_round_up((uint64_t)n_chunks * 4, 256), b_base = kv_round_up(((uint64_t)n_chunks + 1) * 8, 256);
@@ -431,8 +444,10 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         d->bytes_per_read = (double)consumed / (double)n;
         d->d_line_start = line_start;
         d->n_batch = n;
+        lap("lines and records");
         const int rc = kv_reads_from_device_text(text, d_seq_start, d_seq_len, lens.data(), n, reads_out);
         if (rc != KV_OK) return rc;
+        lap("packed batch");
         *n_out = n;
         return KV_OK;
     }

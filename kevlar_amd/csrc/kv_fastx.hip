@@ -354,17 +354,26 @@ extern "C" int kv_fastx_open(const char *path, kv_fastx **out)
         if (caching) f->writer = pack_writer_start(path);
         const char *ingest = getenv("KV_INGEST");               // "host": never parse on the device
         if (!caching && !(ingest && strcmp(ingest, "host") == 0)) {
-            unsigned char head[18] = {0};
+            // the device takes four-line FASTQ, uncompressed ('@' first) or gzip of either kind: for a compressed file the first
+            // byte of TEXT is looked at (a few KB of the file through zlib; nothing of the stream handle is touched)
+            unsigned char head[8192];
             FILE *probe = fopen(path, "rb");
             if (probe) {
-                if (fread(head, 1, sizeof(head), probe) == sizeof(head))
-                    f->dev_candidate = (head[0] == 0x1f && head[1] == 0x8b && head[2] == 8) || head[0] == '@';      // BGZF, gzip, or uncompressed FASTQ
+                const size_t got = fread(head, 1, sizeof(head), probe);
                 fclose(probe);
-            }
-            if (f->dev_candidate && head[0] == 0x1f) {              // compressed: only FASTQ is worth the device's while
-                char first = 0;
-                f->dev_candidate = gzread(fh, &first, 1) == 1 && first == '@';
-                gzrewind(fh);
+                if (got >= 18 && head[0] == '@') f->dev_candidate = true;
+                else if (got >= 18 && head[0] == 0x1f && head[1] == 0x8b && head[2] == 8) {
+                    z_stream zs;
+                    memset(&zs, 0, sizeof(zs));
+                    if (inflateInit2(&zs, 15 + 16) == Z_OK) {
+                        unsigned char first = 0;
+                        zs.next_in = head; zs.avail_in = (uInt)got;
+                        zs.next_out = &first; zs.avail_out = 1;
+                        const int rc = inflate(&zs, Z_SYNC_FLUSH);
+                        f->dev_candidate = (rc == Z_OK || rc == Z_STREAM_END || rc == Z_BUF_ERROR) && zs.avail_out == 0 && first == '@';
+                        inflateEnd(&zs);
+                    }
+                }
             }
         }
     }

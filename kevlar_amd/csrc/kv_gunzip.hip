@@ -30,6 +30,7 @@
 // match) is reported as KV_ERR_TYPE and the caller's host parser (zlib) takes the file.  Reference: the reader this replaces is
 // khmer.ReadParser's gzip stream (kevlar/__init__.py:125-128 opens every *.gz through it).
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -830,6 +831,15 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     KV_REQUIRE(!g->pending, KV_ERR_ARG, "kv_gunzip_decode: the previous segment has not been emitted");
     if (g->done) return KV_OK;
     hipStream_t st = kv_stream();
+    const bool verbose = getenv("KV_INGEST_VERBOSE") != nullptr;
+    auto t_mark = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!verbose) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[kv_gunzip]   %-20s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_mark).count());
+        t_mark = now;
+    };
     const uint32_t CH = g->chunk_bytes;
     const uint64_t margin = 4ull << 20;
     // ---- the compressed bytes of the segment, and behind them a margin in which the next segment's first block is looked for
@@ -844,6 +854,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     uint8_t *d_comp = (uint8_t *)g->a->comp.p;
     KV_HIP(hipMemcpyAsync(d_comp, g->image + first_byte, n_bytes, hipMemcpyHostToDevice, st));
     KV_HIP(hipMemsetAsync(d_comp + n_bytes, 0, (uint64_t)n_chunks * CH + 2 * GZ_SLACK - n_bytes, st));
+    lap("upload");
     KV_HIP(g->a->small.need(kv_round_up((uint64_t)n_chunks * GZ_FIND_KEEP * 8, 256) + 256));
     unsigned long long *d_cand = (unsigned long long *)g->a->small.p;
     unsigned long long *d_ctr = (unsigned long long *)((unsigned char *)g->a->small.p + kv_round_up((uint64_t)n_chunks * GZ_FIND_KEEP * 8, 256));
@@ -855,6 +866,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     std::vector<unsigned long long> cand((uint64_t)n_chunks * GZ_FIND_KEEP);
     KV_HIP(hipMemcpyAsync(cand.data(), d_cand, (uint64_t)n_chunks * GZ_FIND_KEEP * 8, hipMemcpyDeviceToHost, st));
     KV_HIP(hipStreamSynchronize(st));
+    lap("find");
     // ---- stretches: from the exact position the last segment ended at, then from every found start up to the first one
     // behind the segment
     const uint64_t start_rel = g->pos_bit - first_byte * 8, seg_end_rel = (seg_end - first_byte) * 8;
@@ -896,6 +908,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     uint16_t *d_syms = (uint16_t *)g->a->syms.p;
     std::vector<GzResult> results(n_first);
     { const int rc = gz_run_jobs(g, d_comp, n_bytes, is_file_end, jobs.data(), n_first, d_jobs, d_results, d_ctr, d_syms, results.data()); if (rc != KV_OK) return rc; }
+    lap("jobs + decode");
     // ---- the chain: stretch 0 starts at a known block; a later one counts iff a good stretch ends exactly on its start
     g->v_off.clear(); g->v_n.clear(); g->v_base.clear(); g->pending_ends.clear();
     bool crc_lost = false;
@@ -957,6 +970,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
         cur_job = jobs[k];
         cur = results[k];
     }
+    lap("chain");
     if (ended && (uint32_t)(g->seen_text + text) != (uint32_t)(g->isize_total + isize_seg)) {
         // (the CRC-32 is not computed; a stream damaged so that it still decodes to the right length goes through, as it would
         // through any reader that does not check it)
@@ -1016,6 +1030,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
         g->stat_rounds += 1;
     }
     KV_HIP(hipGetLastError());
+    lap("tails + scan");
     g->d_tails = t0;                          // plain text now
     g->d_off = d_off; g->d_base = d_base; g->d_n = d_n;
     g->pending = true;

@@ -1,4 +1,4 @@
-"""kernel times of the device ingest on a BGZF FASTQ file: python scratch/ingest_phases.py [reads]"""
+"""kernel times of the device ingest on a FASTQ file: python scratch/ingest_phases.py [reads] [bgzf|gzip|plain]"""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,8 +23,16 @@ col += L
 rec[:, col:col + 3] = np.frombuffer(b'\n+\n', dtype=np.uint8); col += 3
 rec[:, col:col + L] = np.frombuffer(b'F:,#', dtype=np.uint8)[rng.choice(4, size=(n, L), p=[0.9, 0.06, 0.03, 0.01])]; col += L
 rec[:, col] = 10
-path = '/tmp/phases.fq.gz'
-bgzf.write_file(path, rec.tobytes(), level=int(os.environ.get('BGZF_LEVEL', '4')), threads=16)
+kind = sys.argv[2] if len(sys.argv) > 2 else 'bgzf'
+path = '/tmp/phases.fq' if kind == 'plain' else '/tmp/phases.fq.gz'
+if kind == 'bgzf':
+    bgzf.write_file(path, rec.tobytes(), level=int(os.environ.get('BGZF_LEVEL', '4')), threads=16)
+elif kind == 'gzip':
+    import bench
+    bench.write_gzip(path, rec.tobytes(), level=4, threads=16)
+else:
+    with open(path, 'wb') as fh:
+        fh.write(rec.tobytes())
 print('file', os.path.getsize(path) >> 20, 'MB for', rec.nbytes >> 20, 'MB of text')
 for rep in range(3):
     lib.kv_prof_reset(); lib.kv_prof_enable(1)
