@@ -11,6 +11,8 @@
 //                   lanes x 4 waves, 32 offsets each from registers), then for the few survivors the full set of
 //                   literal/length and distance code lengths, which must form complete codes with an end-of-block symbol.
 //                   The first four hits of a chunk are kept.
+//   1b. k_gz_sync   (streams with few, long blocks) symbol boundaries INSIDE a block: 64 decoders from 64 neighbouring bit
+//                   offsets fall into step with the true symbols; where 24 agree a stretch of its own begins.
 //   2. k_gz_decode  one wavefront per found start decodes until it lands exactly on a later start (kv_inflate.hip's
 //                   wave-uniform Huffman walk).  Text goes out as 16-bit symbols: a byte, or -- for a match that reaches
 //                   back beyond the wave's own start -- a MARKER naming the position in the unknown 32 KB window.
@@ -54,11 +56,16 @@ namespace {
 enum { GZ_LANDED = 0, GZ_END = 1, GZ_BAD = 2, GZ_FULL = 3, GZ_SHORT = 4 };
 
 struct GzJob {
-    uint64_t start_bit;              // relative to the compressed buffer
-    uint64_t target_bit;             // stop at the first block boundary at or behind this one
+    uint64_t start_bit;              // first symbol (or block header) to decode, relative to the compressed buffer
+    uint64_t target_idx;             // starts[target_idx]: the first start behind start_bit; the stretch stops ON the first start it meets
     uint64_t out_off;                // symbols
+    uint64_t header_bit;             // header of the block start_bit lies in (== start_bit for a stretch that begins with a block)
     uint32_t out_cap;
     uint32_t pad;
+};
+struct GzGuess {
+    uint64_t header_bit;             // a found block start ...
+    uint64_t guess_bit;              // ... and a place inside that block near which a symbol boundary is wanted
 };
 struct GzResult {
     uint64_t end_bit;
@@ -248,6 +255,9 @@ struct GunzipShared {
     uint16_t ll_count[16], d_count[16];
     uint16_t ll_symbol[288], d_symbol[32];
     uint8_t lengths[352];
+    // where the stretch is to stop (kept here, not in registers: looked at once per block and when the target comes near)
+    unsigned long long target, cur_header;
+    uint32_t target_idx, pad;
 };
 
 // gzip member header at byte `at` of the buffer: returns the byte its deflate data start at, 0 if this is no header,
@@ -271,9 +281,195 @@ __device__ __attribute__((noinline)) uint64_t gz_member_header(const uint8_t *co
     return p + 8 <= n_bytes ? p : ~0ull;
 }
 
+// The Huffman codes of a block whose 3 header bits have been read (btype 1: the fixed ones, 2: the ones the block spells
+// out) -> lookup tables in LDS.  All lanes take part; returns 0 for an invalid description.
 template <int RBITS>
+__device__ uint32_t gz_block_codes(BitReader &br, GunzipShared<RBITS> &sh, uint32_t lane, uint32_t btype)
+{
+    uint32_t ok = 1;
+    if (btype == 1) {
+        if (lane == 0) {
+            for (int s = 0; s < 144; ++s) sh.lengths[s] = 8;
+            for (int s = 144; s < 256; ++s) sh.lengths[s] = 9;
+            for (int s = 256; s < 280; ++s) sh.lengths[s] = 7;
+            for (int s = 280; s < 288; ++s) sh.lengths[s] = 8;
+            ok = gz_build_code(sh.lengths, 288, sh.ll_count, sh.ll_symbol, sh.ll_table, GZ_FAST_LL);
+            for (int s = 0; s < 30; ++s) sh.lengths[s] = 5;
+            ok = ok && gz_build_code(sh.lengths, 30, sh.d_count, sh.d_symbol, sh.d_table, INF_FAST_D);
+        }
+    } else {
+        const uint32_t nlen = br_bits(br, 5) + 257, ndist = br_bits(br, 5) + 1, ncode = br_bits(br, 4) + 4;
+        if (nlen > 286 || ndist > 30) return 0;
+        if (lane < 19) sh.lengths[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t s = 0; s < ncode; ++s) {
+            const uint32_t v = br_bits(br, 3);
+            if (lane == 0) sh.lengths[inf_clen_order(s)] = (uint8_t)v;
+        }
+        if (lane == 0) ok = gz_build_code(sh.lengths, 19, sh.d_count, sh.d_symbol, sh.d_table, 7);
+        ok = INF_UNI(ok);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t idx = 0, prev = 0;
+        while (ok && idx < nlen + ndist) {
+            const int sym = decode_sym(br, sh.d_count, sh.d_symbol, sh.d_table, 7);
+            if (sym < 0) { ok = 0; break; }
+            uint32_t rep = 1, val = (uint32_t)sym;
+            if (sym == 16) {
+                if (idx == 0) { ok = 0; break; }
+                val = prev;
+                rep = 3 + br_bits(br, 2);
+            } else if (sym == 17) { val = 0; rep = 3 + br_bits(br, 3); }
+            else if (sym == 18) { val = 0; rep = 11 + br_bits(br, 7); }
+            if (idx + rep > nlen + ndist) { ok = 0; break; }
+            if (lane < rep) sh.lengths[19 + idx + lane] = (uint8_t)val;
+            if (lane + 64 < rep) sh.lengths[19 + idx + lane + 64] = (uint8_t)val;
+            if (lane + 128 < rep) sh.lengths[19 + idx + lane + 128] = (uint8_t)val;
+            idx += rep;
+            prev = val;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0 && ok) {
+            ok = sh.lengths[19 + 256] != 0;
+            ok = ok && gz_build_code(sh.lengths + 19, (int)nlen, sh.ll_count, sh.ll_symbol, sh.ll_table, GZ_FAST_LL);
+            ok = ok && gz_build_code(sh.lengths + 19 + nlen, (int)ndist, sh.d_count, sh.d_symbol, sh.d_table, INF_FAST_D);
+        }
+    }
+    ok = INF_UNI(ok);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return ok;
+}
+
+// ---------------------------------------------------------------- 1b. symbol boundaries inside a block
+// A block of 100 KB of text is one stretch, one wavefront, 10 ms.  To cut it, a symbol boundary in its middle is needed, and
+// Huffman codes synchronise by themselves: decoding from a WRONG bit offset falls into step with the true sequence of
+// symbols after a few codes.  One wavefront per guess: the block's codes are read from its header, then every lane decodes
+// (without output) from its own bit offset guess + lane until it has passed a common horizon 4 Kbit further on; the
+// lanes that have fallen into step stop on the same bit.  If 24 of them agree, that bit starts a stretch of its own
+// (the decoder of the stretch before must still stop exactly ON it for it to count).
+struct LaneBits {
+    uint64_t buf;
+    uint32_t cnt, next;
+};
+__device__ __forceinline__ void lane_need(LaneBits &b, const uint32_t *words)
+{
+    if (b.cnt <= 32) { b.buf |= (uint64_t)words[b.next++] << b.cnt; b.cnt += 32; }
+}
+__device__ __forceinline__ int lane_symbol(LaneBits &b, const uint32_t *words, const uint16_t *count, const uint16_t *symbol, const uint16_t *table, int fast)
+{
+    lane_need(b, words);                               // 33 bits or more
+    const uint32_t e = table[(uint32_t)b.buf & ((1u << fast) - 1u)];
+    if (e) {
+        const uint32_t l = e >> 9;
+        b.buf >>= l; b.cnt -= l;
+        return (int)(e & 0x1ffu);
+    }
+    int code = 0, first = 0, index = 0;
+    uint64_t bits = b.buf;
+    for (int l = 1; l <= 15; ++l) {
+        code |= (int)(bits & 1u);
+        bits >>= 1;
+        const int c = (int)count[l];
+        if (code - c < first) {
+            b.buf >>= l; b.cnt -= l;
+            return (int)symbol[index + (code - first)];
+        }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(64) void k_gz_sync(const uint8_t *__restrict__ comp, uint64_t n_bytes, const GzGuess *__restrict__ guesses, uint32_t n_guesses,
+                                                unsigned long long *__restrict__ found)
+{
+    __shared__ GunzipShared<10> sh;
+    const uint32_t lane = threadIdx.x, g = blockIdx.x;
+    if (g >= n_guesses) return;
+    const uint32_t *words = (const uint32_t *)comp;
+    const GzGuess guess = guesses[g];
+    if (lane == 0) found[g] = ~0ull;
+    BitReader br;
+    br_seek(br, words, guess.header_bit);
+    (void)br_bits(br, 1);
+    const uint32_t btype = br_bits(br, 2);
+    if (btype != 1 && btype != 2) return;
+    if (!gz_block_codes(br, sh, lane, btype)) return;
+    const uint64_t limit = n_bytes * 8ull;
+    const uint64_t horizon = guess.guess_bit + 64 + 4096;
+    if (horizon + 4096 > limit) return;
+    const uint64_t mine = guess.guess_bit + lane;
+    LaneBits b;
+    b.next = (uint32_t)(mine >> 5);
+    b.buf = (uint64_t)(words[b.next++] >> (mine & 31u));
+    b.cnt = 32u - (uint32_t)(mine & 31u);
+    bool ok = true;
+    uint64_t pos = mine;
+    for (int steps = 0; ok && pos < horizon && steps < 4096; ++steps) {
+        const int sym = lane_symbol(b, words, sh.ll_count, sh.ll_symbol, sh.ll_table, GZ_FAST_LL);
+        if (sym < 0 || sym == 256) ok = false;          // no code, or the block would end: not a place to start from
+        else if (sym > 256) {
+            const uint32_t ls = (uint32_t)sym - 257u;
+            if (ls >= 29u) { ok = false; break; }
+            lane_need(b, words);
+            const uint32_t le = inf_len_extra(ls);
+            b.buf >>= le; b.cnt -= le;
+            const int ds = lane_symbol(b, words, sh.d_count, sh.d_symbol, sh.d_table, INF_FAST_D);
+            if (ds < 0 || ds >= 30) { ok = false; break; }
+            lane_need(b, words);
+            const uint32_t de = inf_dist_extra((uint32_t)ds);
+            b.buf >>= de; b.cnt -= de;
+        }
+        pos = (uint64_t)b.next * 32ull - b.cnt;
+    }
+    ok = ok && pos >= horizon;
+    // the bit most lanes stopped on
+    uint64_t best = ~0ull;
+    uint32_t best_votes = 0;
+    for (uint32_t i = 0; i < 64; ++i) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pos, i), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos >> 32), i);
+        const uint64_t candidate = ((uint64_t)hi << 32) | lo;
+        const bool lane_ok = __builtin_amdgcn_readlane((int)ok, i) != 0;
+        const uint32_t votes = (uint32_t)__popcll(__ballot(ok && pos == candidate));
+        if (lane_ok && votes > best_votes) { best_votes = votes; best = candidate; }
+    }
+    if (lane == 0 && best_votes >= 24) found[g] = best;
+}
+
+// Has the stretch met the start it is to stop on?  pos: where the reader is; at_boundary: in front of a block header (else
+// between two symbols).  Moves the target on over starts that were run over or are of the wrong kind.  All lanes call it.
+template <int RBITS>
+__device__ __forceinline__ bool gz_met_start(GunzipShared<RBITS> &sh, const unsigned long long *starts, const unsigned long long *headers, uint64_t pos,
+                                                       bool at_boundary, uint32_t *target_word)
+{
+    uint32_t idx = INF_UNI(sh.target_idx);
+    uint64_t target = starts[idx];
+    bool met = false;
+    for (;;) {
+        while (pos > target) target = starts[++idx];
+        if (pos != target) break;
+        const uint64_t header = headers[idx];
+        const uint64_t cur = ((uint64_t)INF_UNI((uint32_t)(sh.cur_header >> 32)) << 32) | INF_UNI((uint32_t)sh.cur_header);
+        if (header == (at_boundary ? pos : cur)) { met = true; break; }
+        target = starts[++idx];                        // a start of the other kind, or of another block, on this very bit: not this stretch's
+    }
+    if (threadIdx.x == 0) { sh.target_idx = idx; sh.target = target; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    *target_word = (uint32_t)(target >> 5 > 0xffffffffull ? 0xffffffffull : target >> 5);
+    return met;
+}
+
+template <int RBITS, bool EXACT>      // EXACT: the segment has stretches that begin inside a block (the target is looked for between symbols too)
 __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 6 : RBITS == 12 ? 3 : RBITS == 13 ? 2 : 1)) void k_gz_decode(const uint8_t *__restrict__ comp, uint64_t n_bytes, int is_file_end, const GzJob *__restrict__ jobs,
-                                                      uint32_t n_jobs, uint16_t *syms, GzResult *__restrict__ results, unsigned long long *ctr)
+                                                      uint32_t n_jobs, const unsigned long long *__restrict__ starts, const unsigned long long *__restrict__ headers,
+                                                      uint64_t terminal_bit, uint16_t *syms,
+                                                      GzResult *__restrict__ results, unsigned long long *ctr)
 {
     __shared__ GunzipShared<RBITS> sh;
     constexpr uint32_t RMASK = (1u << RBITS) - 1u;
@@ -287,7 +483,17 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 6 : RBITS == 1
         if (job_id >= n_jobs) return;
         const GzJob job = jobs[job_id];
         BitReader br;
-        br_seek(br, words, job.start_bit);
+        br_seek(br, words, job.header_bit);
+        bool mid_block = job.header_bit != job.start_bit;        // the codes come from header_bit, the symbols from start_bit
+        // starts[]: every place a stretch begins at, ascending, ~0 behind the last; headers[]: the block header each takes its
+        // codes from (itself, for a stretch that begins with a block).  The stretch ends ON the first start it meets that is
+        // of its kind -- a block start at a block boundary, a start inside a block between two symbols of THAT block; one it
+        // runs over, or meets in another block, was not a start (a false positive of the block search, a symbol boundary
+        // of a parse with the wrong codes) and the one after it becomes the target.
+        if (lane == 0) { sh.target_idx = (uint32_t)job.target_idx; sh.target = starts[job.target_idx]; sh.cur_header = job.header_bit; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t target_word = (uint32_t)std::min<uint64_t>(starts[job.target_idx] >> 5, 0xffffffffull);
         uint16_t *dst = syms + job.out_off;
         const uint32_t cap = job.out_cap;
         uint32_t o = 0, lit = 0, n_lit = 0, isize_sum = 0, members = 0, trailer_at = 0, trailer_crc = 0;
@@ -304,12 +510,14 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 6 : RBITS == 1
         while (status < 0) {
             // ---- at a block boundary
             end_bit = br_pos(br);
-            if (!first_block && end_bit >= job.target_bit) { status = GZ_LANDED; break; }
+            if (!first_block && (gz_met_start(sh, starts, headers, end_bit, true, &target_word) || end_bit >= terminal_bit)) { status = GZ_LANDED; break; }
+            if (lane == 0) sh.cur_header = end_bit;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             first_block = false;
             if (br.next > limit_words) { status = GZ_SHORT; break; }
             const bool last_block = br_bits(br, 1) != 0;
             const uint32_t btype = br_bits(br, 2);
-            if (btype == 3) { status = GZ_BAD; break; }
+            if (btype == 3 || (btype == 0 && mid_block)) { status = GZ_BAD; break; }
             if (btype == 0) {
                 const uint32_t drop = br.cnt & 7u;
                 br.buf >>= drop; br.cnt -= drop;
@@ -330,66 +538,21 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 6 : RBITS == 1
                 __builtin_amdgcn_wave_barrier();
                 br_seek(br, words, (from_byte + stored_len) * 8);
             } else {
-                uint32_t ok = 1;
-                if (btype == 1) {
-                    if (lane == 0) {
-                        for (int s = 0; s < 144; ++s) sh.lengths[s] = 8;
-                        for (int s = 144; s < 256; ++s) sh.lengths[s] = 9;
-                        for (int s = 256; s < 280; ++s) sh.lengths[s] = 7;
-                        for (int s = 280; s < 288; ++s) sh.lengths[s] = 8;
-                        ok = gz_build_code(sh.lengths, 288, sh.ll_count, sh.ll_symbol, sh.ll_table, GZ_FAST_LL);
-                        for (int s = 0; s < 30; ++s) sh.lengths[s] = 5;
-                        ok = ok && gz_build_code(sh.lengths, 30, sh.d_count, sh.d_symbol, sh.d_table, INF_FAST_D);
-                    }
-                } else {
-                    const uint32_t nlen = br_bits(br, 5) + 257, ndist = br_bits(br, 5) + 1, ncode = br_bits(br, 4) + 4;
-                    if (nlen > 286 || ndist > 30) { status = GZ_BAD; break; }
-                    if (lane < 19) sh.lengths[lane] = 0;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    for (uint32_t s = 0; s < ncode; ++s) {
-                        const uint32_t v = br_bits(br, 3);
-                        if (lane == 0) sh.lengths[inf_clen_order(s)] = (uint8_t)v;
-                    }
-                    if (lane == 0) ok = gz_build_code(sh.lengths, 19, sh.d_count, sh.d_symbol, sh.d_table, 7);
-                    ok = INF_UNI(ok);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    uint32_t idx = 0, prev = 0;
-                    while (ok && idx < nlen + ndist) {
-                        const int sym = decode_sym(br, sh.d_count, sh.d_symbol, sh.d_table, 7);
-                        if (sym < 0) { ok = 0; break; }
-                        uint32_t rep = 1, val = (uint32_t)sym;
-                        if (sym == 16) {
-                            if (idx == 0) { ok = 0; break; }
-                            val = prev;
-                            rep = 3 + br_bits(br, 2);
-                        } else if (sym == 17) { val = 0; rep = 3 + br_bits(br, 3); }
-                        else if (sym == 18) { val = 0; rep = 11 + br_bits(br, 7); }
-                        if (idx + rep > nlen + ndist) { ok = 0; break; }
-                        if (lane < rep) sh.lengths[19 + idx + lane] = (uint8_t)val;
-                        if (lane + 64 < rep) sh.lengths[19 + idx + lane + 64] = (uint8_t)val;
-                        if (lane + 128 < rep) sh.lengths[19 + idx + lane + 128] = (uint8_t)val;
-                        idx += rep;
-                        prev = val;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0 && ok) {
-                        ok = sh.lengths[19 + 256] != 0;
-                        ok = ok && gz_build_code(sh.lengths + 19, (int)nlen, sh.ll_count, sh.ll_symbol, sh.ll_table, GZ_FAST_LL);
-                        ok = ok && gz_build_code(sh.lengths + 19 + nlen, (int)ndist, sh.d_count, sh.d_symbol, sh.d_table, INF_FAST_D);
-                    }
-                }
-                ok = INF_UNI(ok);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                const uint32_t ok = gz_block_codes(br, sh, lane, btype);
                 if (!ok) { status = GZ_BAD; break; }
+                if (mid_block) { br_seek(br, words, job.start_bit); mid_block = false; }
                 // ---- symbols
                 // (room and the end of the input are checked when text is stored -- at least every 64 symbols, i.e. every 120
                 // bytes of input, which the zeroed slack behind the buffer covers -- not per literal: the loop is bound by the
                 // number of instructions it issues)
                 for (;;) {
+                    if (EXACT && br.next >= target_word && gz_met_start(sh, starts, headers, br_pos(br), false, &target_word)) {        // the next stretch starts here, inside the block
+                        if (o + n_lit > cap) { status = GZ_FULL; break; }
+                        flush();
+                        end_bit = br_pos(br);
+                        status = GZ_LANDED;
+                        break;
+                    }
                     const int sym = decode_sym(br, sh.ll_count, sh.ll_symbol, sh.ll_table, GZ_FAST_LL);
                     if ((uint32_t)sym < 256u) {
                         lit = lane == n_lit ? (uint32_t)sym : lit;
@@ -765,7 +928,7 @@ struct KvGunzip {
     const uint64_t *d_off = nullptr, *d_base = nullptr;           // device copies of v_off / v_base / v_n
     const uint32_t *d_n = nullptr;
     const uint16_t *d_tails = nullptr;                            // the resolved tails of the pending segment
-    uint64_t stat_jobs = 0, stat_dropped = 0, stat_repairs = 0, stat_segments = 0, stat_rounds = 0;
+    uint64_t stat_jobs = 0, stat_dropped = 0, stat_repairs = 0, stat_segments = 0, stat_rounds = 0, stat_cuts = 0;
     ~KvGunzip() { own.release(); }
 };
 
@@ -794,7 +957,8 @@ void kv_gunzip_stats(const KvGunzip *g, uint64_t out[4])
 }
 
 static int gz_run_jobs(KvGunzip *g, const uint8_t *d_comp, uint64_t n_bytes, bool is_file_end, const GzJob *jobs, size_t n, GzJob *d_jobs,
-                       GzResult *d_results, unsigned long long *d_ctr, uint16_t *d_syms, GzResult *results)
+                       const unsigned long long *d_starts, const unsigned long long *d_headers, uint64_t terminal_bit, bool exact, GzResult *d_results, unsigned long long *d_ctr, uint16_t *d_syms,
+                       GzResult *results)
 {
     hipStream_t st = kv_stream();
     KV_HIP(hipMemcpyAsync(d_jobs, jobs, n * sizeof(GzJob), hipMemcpyHostToDevice, st));
@@ -807,12 +971,13 @@ static int gz_run_jobs(KvGunzip *g, const uint8_t *d_comp, uint64_t n_bytes, boo
         const int bits = rb ? atoi(rb) : 10;
         const int per_cu = bits >= 14 ? 4 : bits == 13 ? 8 : bits == 12 ? 12 : bits == 11 ? 24 : 32;
         const unsigned grid = (unsigned)std::min<uint64_t>(n, (uint64_t)per_cu * (uint64_t)kv_device_cus());
-#define KV_LAUNCH_GZ(B_) hipLaunchKernelGGL(k_gz_decode<B_>, dim3(grid), dim3(64), 0, st, d_comp, n_bytes, is_file_end ? 1 : 0, (const GzJob *)d_jobs, (uint32_t)n, d_syms, d_results, d_ctr)
-        if (bits >= 14) KV_LAUNCH_GZ(14);
-        else if (bits == 13) KV_LAUNCH_GZ(13);
-        else if (bits == 12) KV_LAUNCH_GZ(12);
-        else if (bits == 11) KV_LAUNCH_GZ(11);
-        else KV_LAUNCH_GZ(10);
+#define KV_LAUNCH_GZ(B_, E_) hipLaunchKernelGGL((k_gz_decode<B_, E_>), dim3(grid), dim3(64), 0, st, d_comp, n_bytes, is_file_end ? 1 : 0, (const GzJob *)d_jobs, (uint32_t)n, d_starts, d_headers, terminal_bit, d_syms, d_results, d_ctr)
+        if (exact) KV_LAUNCH_GZ(10, true);
+        else if (bits >= 14) KV_LAUNCH_GZ(14, false);
+        else if (bits == 13) KV_LAUNCH_GZ(13, false);
+        else if (bits == 12) KV_LAUNCH_GZ(12, false);
+        else if (bits == 11) KV_LAUNCH_GZ(11, false);
+        else KV_LAUNCH_GZ(10, false);
 #undef KV_LAUNCH_GZ
     }
     KV_HIP(hipGetLastError());
@@ -855,9 +1020,13 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     KV_HIP(hipMemcpyAsync(d_comp, g->image + first_byte, n_bytes, hipMemcpyHostToDevice, st));
     KV_HIP(hipMemsetAsync(d_comp + n_bytes, 0, (uint64_t)n_chunks * CH + 2 * GZ_SLACK - n_bytes, st));
     lap("upload");
-    KV_HIP(g->a->small.need(kv_round_up((uint64_t)n_chunks * GZ_FIND_KEEP * 8, 256) + 256));
+    const uint64_t b_cand = kv_round_up((uint64_t)n_chunks * GZ_FIND_KEEP * 8, 256);
+    const uint64_t max_guesses = (uint64_t)n_chunks * GZ_FIND_KEEP * 7 + 8;          // seven cuts per stretch at most
+    KV_HIP(g->a->small.need(b_cand + 256 + kv_round_up(max_guesses * sizeof(GzGuess), 256) + kv_round_up(max_guesses * 8, 256)));
     unsigned long long *d_cand = (unsigned long long *)g->a->small.p;
-    unsigned long long *d_ctr = (unsigned long long *)((unsigned char *)g->a->small.p + kv_round_up((uint64_t)n_chunks * GZ_FIND_KEEP * 8, 256));
+    unsigned long long *d_ctr = (unsigned long long *)((unsigned char *)g->a->small.p + b_cand);
+    GzGuess *d_guesses = (GzGuess *)((unsigned char *)g->a->small.p + b_cand + 256);
+    unsigned long long *d_found = (unsigned long long *)((unsigned char *)d_guesses + kv_round_up(max_guesses * sizeof(GzGuess), 256));
     {
         KvProfScope prof("k_gz_find");
         hipLaunchKernelGGL(k_gz_find, dim3(n_chunks), dim3(GZ_FIND_THREADS), CH + GZ_SLACK + 8, st, (const uint8_t *)d_comp, n_bytes, CH, n_chunks, d_cand);
@@ -881,15 +1050,74 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
         kv_set_error("no DEFLATE block start within %llu MB behind byte %llu", (unsigned long long)(margin >> 20), (unsigned long long)seg_end);
         return KV_ERR_TYPE;
     }                                                  // (none before the end of the file: the last stretch runs to the end)
-    const size_t n_first = have_terminal ? starts.size() - 1 : starts.size();
     const uint64_t stop_rel = have_terminal ? starts.back() : ~0ull;             // reaching it ends the segment
+    // ---- long stretches are cut: symbol boundaries inside their first block, found by letting 64 decoders per cut fall
+    // into step (k_gz_sync).  KV_GUNZIP_SPLIT_KB: compressed bytes a piece should have (0: no cutting)
+    std::vector<uint64_t> headers(starts);              // headers[i]: the block header stretch i takes its codes from
+    {
+        const char *sk = getenv("KV_GUNZIP_SPLIT_KB");
+        // default: only when the block starts alone leave the device short of work (fewer than 24 stretches per CU), and
+        // then as many pieces as make 32 per CU: every cut costs a header to parse, a tail to resolve and a decoder that
+        // looks for its target between symbols too (k_gz_decode<.., true>, ~15 % more instructions per symbol)
+        const uint64_t wanted = 32ull * (uint64_t)kv_device_cus();
+        const uint64_t piece = sk ? strtoull(sk, nullptr, 10) * 1024ull * 8ull
+                                  : starts.size() * 4 >= wanted * 3 ? 0 : std::max<uint64_t>(4096ull * 8ull, (seg_end_rel - start_rel) / wanted);
+        std::vector<GzGuess> guesses;
+        const size_t n_blocks = have_terminal ? starts.size() - 1 : starts.size();
+        for (size_t j = 0; j < n_blocks && piece; ++j) {
+            const uint64_t next = j + 1 < starts.size() ? starts[j + 1] : n_bytes * 8;
+            const uint64_t span = next - starts[j];
+            const uint64_t cuts = std::min<uint64_t>(8, span / piece);
+            for (uint64_t i = 1; i < cuts; ++i) {
+                GzGuess gs;
+                gs.header_bit = starts[j];
+                gs.guess_bit = starts[j] + i * (span / cuts);
+                if (guesses.size() < max_guesses) guesses.push_back(gs);
+            }
+        }
+        if (!guesses.empty()) {
+            KV_HIP(hipMemcpyAsync(d_guesses, guesses.data(), guesses.size() * sizeof(GzGuess), hipMemcpyHostToDevice, st));
+            {
+                KvProfScope prof("k_gz_sync");
+                hipLaunchKernelGGL(k_gz_sync, dim3((unsigned)guesses.size()), dim3(64), 0, st, (const uint8_t *)d_comp, n_bytes, (const GzGuess *)d_guesses,
+                                   (uint32_t)guesses.size(), d_found);
+            }
+            KV_HIP(hipGetLastError());
+            std::vector<unsigned long long> found(guesses.size());
+            KV_HIP(hipMemcpyAsync(found.data(), d_found, guesses.size() * 8, hipMemcpyDeviceToHost, st));
+            KV_HIP(hipStreamSynchronize(st));
+            std::vector<std::pair<uint64_t, uint64_t>> all;             // (start, header)
+            for (size_t i = 0; i < starts.size(); ++i) all.emplace_back(starts[i], starts[i]);
+            for (size_t i = 0; i < guesses.size(); ++i) {
+                if (found[i] == ~0ull || found[i] <= guesses[i].header_bit || found[i] >= stop_rel) continue;
+                // (a boundary behind the next block start is of no use: the stretch before it stops at that start)
+                const auto nx = std::upper_bound(starts.begin(), starts.end(), guesses[i].header_bit);
+                if (nx != starts.end() && found[i] >= *nx) continue;
+                all.emplace_back(found[i], guesses[i].header_bit);
+                g->stat_cuts += 1;
+            }
+            std::sort(all.begin(), all.end());
+            starts.clear(); headers.clear();
+            for (const auto &a : all)
+                if (starts.empty() || a.first != starts.back()) { starts.push_back(a.first); headers.push_back(a.second); }
+        }
+        lap("cuts");
+    }
+    const size_t n_first = have_terminal ? starts.size() - 1 : starts.size();
+    bool exact = false;                                 // does any stretch begin inside a block?
+    for (size_t i = 0; i < starts.size() && !exact; ++i) exact = headers[i] != starts[i];
     const double factor = std::min(std::max(2.5 * g->ratio, 8.0), 64.0);
     std::vector<GzJob> jobs(n_first);
     uint64_t total_cap = 0;
     for (size_t j = 0; j < n_first; ++j) {
-        const uint64_t next = j + 1 < starts.size() ? starts[j + 1] : n_bytes * 8;
+        // room: up to the next stretch that begins with a block (the starts inside this block may turn out not to be any, and
+        // the stretch then runs on over them)
+        size_t nb = j + 1;
+        while (nb < starts.size() && headers[nb] != starts[nb]) ++nb;
+        const uint64_t next = nb < starts.size() ? starts[nb] : n_bytes * 8;
         jobs[j].start_bit = starts[j];
-        jobs[j].target_bit = j + 1 < starts.size() ? starts[j + 1] : ~0ull;
+        jobs[j].header_bit = headers[j];
+        jobs[j].target_idx = j + 1;                     // (starts[] on the device ends with ~0)
         jobs[j].out_off = total_cap;
         jobs[j].out_cap = (uint32_t)std::min<uint64_t>((uint64_t)((double)((next - starts[j]) / 8 + 1) * factor) + 16384, 0x7ffffff0u);
         jobs[j].pad = 0;
@@ -899,15 +1127,25 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     const size_t max_jobs = n_first + 256;
     KV_HIP(g->a->syms.need((total_cap + repair_room) * 2 + 256));
     KV_HIP(g->a->meta.need(kv_round_up(max_jobs * sizeof(GzJob), 256) + kv_round_up(max_jobs * sizeof(GzResult), 256) + kv_round_up(max_jobs * 8, 256) * 2 +
-                        kv_round_up(max_jobs * 4, 256)));
+                        kv_round_up(max_jobs * 4, 256) + 2 * kv_round_up((starts.size() + 1) * 8, 256)));
     GzJob *d_jobs = (GzJob *)g->a->meta.p;
     GzResult *d_results = (GzResult *)((unsigned char *)d_jobs + kv_round_up(max_jobs * sizeof(GzJob), 256));
     uint64_t *d_off = (uint64_t *)((unsigned char *)d_results + kv_round_up(max_jobs * sizeof(GzResult), 256));
     uint64_t *d_base = (uint64_t *)((unsigned char *)d_off + kv_round_up(max_jobs * 8, 256));
     uint32_t *d_n = (uint32_t *)((unsigned char *)d_base + kv_round_up(max_jobs * 8, 256));
+    unsigned long long *d_starts = (unsigned long long *)((unsigned char *)d_n + kv_round_up(max_jobs * 4, 256));
+    unsigned long long *d_headers = (unsigned long long *)((unsigned char *)d_starts + kv_round_up((starts.size() + 1) * 8, 256));
+    {
+        std::vector<unsigned long long> with_end(starts.begin(), starts.end()), kinds(headers.begin(), headers.end());
+        with_end.push_back(~0ull);
+        kinds.push_back(~0ull);
+        KV_HIP(hipMemcpyAsync(d_starts, with_end.data(), with_end.size() * 8, hipMemcpyHostToDevice, st));
+        KV_HIP(hipMemcpyAsync(d_headers, kinds.data(), kinds.size() * 8, hipMemcpyHostToDevice, st));
+        KV_HIP(hipStreamSynchronize(st));               // (the vectors go out of scope)
+    }
     uint16_t *d_syms = (uint16_t *)g->a->syms.p;
     std::vector<GzResult> results(n_first);
-    { const int rc = gz_run_jobs(g, d_comp, n_bytes, is_file_end, jobs.data(), n_first, d_jobs, d_results, d_ctr, d_syms, results.data()); if (rc != KV_OK) return rc; }
+    { const int rc = gz_run_jobs(g, d_comp, n_bytes, is_file_end, jobs.data(), n_first, d_jobs, d_starts, d_headers, stop_rel, exact, d_results, d_ctr, d_syms, results.data()); if (rc != KV_OK) return rc; }
     lap("jobs + decode");
     // ---- the chain: stretch 0 starts at a known block; a later one counts iff a good stretch ends exactly on its start
     g->v_off.clear(); g->v_n.clear(); g->v_base.clear(); g->pending_ends.clear();
@@ -929,15 +1167,16 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
             if (cur.status == GZ_FULL) {
                 if (cur_job.out_off >= total_cap) repair_used = cur_job.out_off - total_cap;        // the failed attempt's room is free again
                 again = cur_job;
-                again.out_cap = (uint32_t)std::min<uint64_t>((uint64_t)cur_job.out_cap * 8, 0x7ffffff0u);
+                again.out_cap = (uint32_t)std::min<uint64_t>((uint64_t)cur_job.out_cap * 32, 0x7ffffff0u);
             } else {
                 g->v_off.push_back(cur_job.out_off); g->v_n.push_back(cur.n_out); g->v_base.push_back(text);
                 note_ends(cur, text);
                 text += cur.n_out;
                 isize_seg += cur.isize_sum;
                 again.start_bit = cur.end_bit;
+                again.header_bit = cur.end_bit;
                 const auto nx = std::upper_bound(starts.begin() + 1, starts.end(), cur.end_bit);
-                again.target_bit = nx == starts.end() ? ~0ull : *nx;
+                again.target_idx = (uint64_t)(nx - starts.begin());
                 const uint64_t next = nx == starts.end() ? n_bytes * 8 : *nx;
                 again.out_cap = (uint32_t)std::min<uint64_t>((uint64_t)((double)((next - again.start_bit) / 8 + 1) * factor) + 16384, 0x7ffffff0u);
             }
@@ -949,7 +1188,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
                 return KV_ERR_TYPE;
             }
             GzResult r;
-            { const int rc = gz_run_jobs(g, d_comp, n_bytes, is_file_end, &again, 1, d_jobs, d_results, d_ctr, d_syms, &r); if (rc != KV_OK) return rc; }
+            { const int rc = gz_run_jobs(g, d_comp, n_bytes, is_file_end, &again, 1, d_jobs, d_starts, d_headers, stop_rel, exact, d_results, d_ctr, d_syms, &r); if (rc != KV_OK) return rc; }
             cur_job = again;
             cur = r;
             continue;
@@ -1014,7 +1253,8 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     // FASTQ needs nearly every round (each read's header is a copy of the one before it: a chain as long as the file)
     const bool listed = markers <= list_cap;
     if (getenv("KV_GUNZIP_VERBOSE"))
-        fprintf(stderr, "[kv_gunzip] %zu stretches, %llu of %llu tail symbols are markers (%s)\n", nv, markers, (unsigned long long)tail_syms, listed ? "listed" : "whole tails");
+        fprintf(stderr, "[kv_gunzip] %zu stretches (%llu of them begin inside a block), %llu of %llu tail symbols are markers (%s)\n", nv,
+                (unsigned long long)g->stat_cuts, markers, (unsigned long long)tail_syms, listed ? "listed" : "whole tails");
     for (uint64_t d = 1; d < nv + 1 && markers; d <<= 1) {
         KvProfScope prof("k_gz_scan");
         KV_HIP(hipMemsetAsync(d_markers, 0, 8, st));
