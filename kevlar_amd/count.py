@@ -30,12 +30,18 @@ def _count_file(path, sketch, policy, nthreads):
     """all reads of one file, by `nthreads` workers; returns the number of reads"""
     parser = khmer.ReadParser(path)
     failures = []
+    stream = khmer.bound_stream()           # the workers stay on the caller's stream (samples loaded side by side each have their own)
 
     def guarded():
         try:
+            if stream is not None:
+                stream.bind()
             _drain(parser, sketch, policy)
         except BaseException as exc:        # re-raised on the calling thread
             failures.append(exc)
+        finally:
+            if stream is not None:
+                kevlar_amd._lib.load().kv_set_stream(None)
     crew = [threading.Thread(target=guarded) for _ in range(max(1, nthreads))]
     for worker in crew:
         worker.start()

@@ -294,7 +294,7 @@ void kv_fastq_device_close(KvFastqDevice *d)
     if (d->fd >= 0) close(d->fd);
     if (d->buf) {
         std::lock_guard<std::mutex> lk(g_fastq_pool_mu);
-        if (g_fastq_pool.size() >= 2) d->buf->gz.release();            // (the gzip inflater's buffers are gigabytes: two sets are kept)
+        if (g_fastq_pool.size() >= 3) d->buf->gz.release();            // (the gzip inflater's buffers are gigabytes: three sets are kept, a trio read side by side)
         if (g_fastq_pool.size() < 4) g_fastq_pool.push_back(d->buf);
         else { d->buf->release(); delete d->buf; }
     }

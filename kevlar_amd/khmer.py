@@ -60,6 +60,7 @@ class Stream(object):
     def bind(self):
         """Make this the stream of the calling host thread."""
         check(_lib.load().kv_set_stream(self._h))
+        _bound.stream = self
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -72,17 +73,24 @@ class Stream(object):
 
 _pool_lock = threading.Lock()
 _pool_streams = []
+_bound = threading.local()
+
+
+def bound_stream():
+    """The Stream the calling host thread was bound to (None: the library's default stream).  Worker threads a job
+    starts bind it too, so that the whole job stays on one stream."""
+    return getattr(_bound, 'stream', None)
+
 
 
 def run_concurrently(jobs):
     """Run zero-argument callables on separate host threads, each bound to its own HIP stream;
-    returns their results in order.  Kernels of different jobs overlap on the GPU."""
+    returns their results in order.  Kernels of different jobs overlap on the GPU.  May be nested (a job that runs
+    jobs of its own): every job at every level gets a stream nobody else is using."""
     if len(jobs) <= 1:
         return [job() for job in jobs]
     with _pool_lock:
-        while len(_pool_streams) < len(jobs):
-            _pool_streams.append(Stream())
-        streams = _pool_streams[:len(jobs)]
+        streams = [_pool_streams.pop() if _pool_streams else Stream() for _ in jobs]
     results, errors = [None] * len(jobs), []
 
     def work(i):
@@ -93,12 +101,15 @@ def run_concurrently(jobs):
             errors.append(exc)
         finally:
             _lib.load().kv_set_stream(None)
+            _bound.stream = None
 
     threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
     for t in threads:
         t.start()
     for t in threads:
         t.join()
+    with _pool_lock:
+        _pool_streams.extend(streams)
     if errors:
         raise errors[0]
     return results

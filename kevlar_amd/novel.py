@@ -37,29 +37,42 @@ def kmer_is_interesting(kmer, casecounts, controlcounts, case_min=5, ctrl_max=1,
     return True, False, observed[:len(casecounts)], observed[len(casecounts):]
 
 
-def save_counts(filelist, tablelist):
+def save_counts(filelist, tablelist, log=None):
+    log = log or kevlar_amd.plog
     if len(filelist) != len(tablelist):
-        kevlar_amd.plog('[kevlar::novel] WARNING:', 'number of filenames provided ({:d})does not match the number of samples '
+        log('[kevlar::novel] WARNING:', 'number of filenames provided ({:d})does not match the number of samples '
                         'provided ({:d}); stubbornly refusing to save k-mer counts'.format(len(filelist), len(tablelist)))
         return
     for path, sketch in zip(filelist, tablelist):
         path += '' if path.endswith(('.ct', '.counttable')) else '.counttable'
-        kevlar_amd.plog('    saved to "{}"'.format(os.path.abspath(path)))
+        log('    saved to "{}"'.format(os.path.abspath(path)))
         sketch.save(path)
 
 
 def load_samples(counttables=None, filelists=None, ksize=31, memory=1e6, maxfpr=0.2, numbands=None, band=None, numthreads=1,
-                 outfilelist=None):
+                 outfilelist=None, log=None):
     """One sketch per sample: loaded from saved count tables if given, else counted from the sample's files."""
     assert counttables or filelists
+    log = log or kevlar_amd.plog
     if counttables:
-        kevlar_amd.plog('[kevlar::novel]    INFO:', 'counttables for {:d} sample(s) provided, any corresponding FASTA/FASTQ input '
+        log('[kevlar::novel]    INFO:', 'counttables for {:d} sample(s) provided, any corresponding FASTA/FASTQ input '
                         'will be ignored for computing k-mer abundances'.format(len(counttables)))
         return kevlar_amd.sketch.load_sketchfiles(counttables, maxfpr)
-    sketches = [kevlar_amd.count.load_sample_seqfile(files, ksize, memory, maxfpr=maxfpr, numbands=numbands, band=band,
-                                                     numthreads=numthreads) for files in filelists]
+    # the samples are counted side by side, each on its own HIP stream (reading one file overlaps with counting another);
+    # what each has to say is held back and printed sample by sample, as a one-after-the-other run prints it
+    said = [[] for _ in filelists]
+
+    def one(i):
+        return kevlar_amd.count.load_sample_seqfile(filelists[i], ksize, memory, maxfpr=maxfpr, numbands=numbands, band=band,
+                                                    numthreads=numthreads, log=lambda *words: said[i].append(words))
+    try:
+        sketches = khmer.run_concurrently([lambda i=i: one(i) for i in range(len(filelists))])
+    finally:
+        for lines in said:
+            for words in lines:
+                log(*words)
     if outfilelist:
-        save_counts(outfilelist, sketches)
+        save_counts(outfilelist, sketches, log)
     return sketches
 
 
@@ -219,15 +232,33 @@ def main(args):
     clock = kevlar_amd.Timer()
     for key in (None, 'loadall', 'loadctrl'):
         clock.start(key)
-    kevlar_amd.plog('[kevlar::novel] Loading control samples')
-    controls = load_samples(args.control_counts, args.control, args.ksize, args.memory, args.max_fpr, args.num_bands, band,
-                            args.threads, args.save_ctrl_counts)
-    kevlar_amd.plog('[kevlar::novel]', 'Control samples loaded in {:.2f} sec'.format(clock.stop('loadctrl')))
-    kevlar_amd.plog('[kevlar::novel] Loading case samples')
-    clock.start('loadcases')
-    cases = load_samples(args.case_counts, args.case, args.ksize, args.memory, args.max_fpr, args.num_bands, band,
-                         args.threads, args.save_case_counts)
-    kevlar_amd.plog('[kevlar::novel] Case samples loaded in {:.2f} sec'.format(clock.stop('loadcases')))
+    # controls and cases are loaded side by side (each sample on its own HIP stream); what they have to say is printed in the
+    # order of a one-after-the-other run
+    said = {'ctrl': [], 'case': []}
+    took = {}
+
+    def load(which, counts, files, save):
+        watch = kevlar_amd.Timer()
+        watch.start()
+        sketches = load_samples(counts, files, args.ksize, args.memory, args.max_fpr, args.num_bands, band, args.threads, save,
+                                log=lambda *words: said[which].append(words))
+        took[which] = watch.stop()
+        return sketches
+    try:
+        controls, cases = khmer.run_concurrently([lambda: load('ctrl', args.control_counts, args.control, args.save_ctrl_counts),
+                                                  lambda: load('case', args.case_counts, args.case, args.save_case_counts)])
+    finally:
+        kevlar_amd.plog('[kevlar::novel] Loading control samples')
+        for words in said['ctrl']:
+            kevlar_amd.plog(*words)
+        if 'ctrl' in took:
+            kevlar_amd.plog('[kevlar::novel]', 'Control samples loaded in {:.2f} sec'.format(took['ctrl']))
+        kevlar_amd.plog('[kevlar::novel] Loading case samples')
+        for words in said['case']:
+            kevlar_amd.plog(*words)
+        if 'case' in took:
+            kevlar_amd.plog('[kevlar::novel] Case samples loaded in {:.2f} sec'.format(took['case']))
+    clock.stop('loadctrl')
     kevlar_amd.plog('[kevlar::novel] All samples loaded in {:.2f} sec'.format(clock.stop('loadall')))
 
     clock.start('iter')
