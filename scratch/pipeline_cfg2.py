@@ -41,7 +41,15 @@ tn = run(['novel', '--ksize', '31', '--memory', '2G', '--threads', '2', '--case'
 print('novel (count 3 samples + scan + write): {:.2f} s = {:.1f} M reads/s; output {} MB'.format(tn, 3 * n / tn / 1e6, os.path.getsize(out + '/novel.augfastq') >> 20), flush=True)
 tf = run(['filter', '--memory', '200M', '-o', out + '/filtered.augfastq', out + '/novel.augfastq'])
 print('filter: {:.2f} s; output {} MB'.format(tf, os.path.getsize(out + '/filtered.augfastq') >> 20), flush=True)
+if os.environ.get('PROFILE'):
+    import cProfile, pstats
+    prof = cProfile.Profile(); prof.enable()
 tp = run(['partition', '-o', out + '/part.augfastq', out + '/filtered.augfastq'])
+if os.environ.get('PROFILE'):
+    prof.disable(); st = io.StringIO(); pstats.Stats(prof, stream=st).sort_stats('tottime').print_stats(14); print(st.getvalue()[:3500])
+    prof = cProfile.Profile(); prof.enable()
+    run(['filter', '--memory', '200M', '-o', out + '/filtered2.augfastq', out + '/novel.augfastq'])
+    prof.disable(); st = io.StringIO(); pstats.Stats(prof, stream=st).sort_stats('tottime').print_stats(12); print(st.getvalue()[:3000])
 print('partition: {:.2f} s'.format(tp))
 log = kevlar_amd.logstream.getvalue()
 print('\n'.join(l for l in log.split('\n') if 'Found' in l or 'grouped' in l or 'Validated' in l or 'reads' in l.lower())[-1500:])
