@@ -7,6 +7,10 @@
 // the same blobs + offsets a kv_fastx batch exposes, plus per-annotation arrays (offset, abundances) and the
 // annotations' extent per record, so the drivers can work on whole arrays and hand positions -- not k-mer strings --
 // to the device (kv_hash_positions, kv_readgraph_components).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -14,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kv_internal.h"
@@ -38,39 +43,29 @@ inline const char *trim(const char *p, const char *&end)
     return p;
 }
 
-}  // namespace
-
-extern "C" int kv_augfastx_load(const char *path, kv_augfastx **out)
+// records and annotations of the lines in [begin, end) -> a; begin is the start of a record (or of the file)
+int parse_range(const char *begin, const char *end, const char *path, kv_augfastx *a, std::string *err)
 {
-    KV_REQUIRE(path && out, KV_ERR_ARG, "kv_augfastx_load: null argument");
-    gzFile fh = gzopen(path, "rb");
-    if (!fh) { kv_set_error("cannot open %s", path); return KV_ERR_IO; }
-    gzbuffer(fh, 1 << 20);
-    std::string text;
-    {
-        std::vector<char> buf(8 << 20);
-        for (;;) {
-            const int got = gzread(fh, buf.data(), (unsigned)buf.size());
-            if (got < 0) { gzclose(fh); kv_set_error("cannot read %s", path); return KV_ERR_IO; }
-            if (got == 0) break;
-            text.append(buf.data(), (size_t)got);
-        }
-        gzclose(fh);
-    }
-    kv_augfastx *a = new kv_augfastx();
-    const char *p = text.data(), *const end = text.data() + text.size();
-    auto next_line = [&](const char *&lo, const char *&hi) -> bool {      // [lo, hi) without the newline; hi_nl = had one
+    const char *p = begin;
+    auto fail = [&](const char *fmt, auto... args) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), fmt, args...);
+        *err = buf;
+        return KV_ERR_IO;
+    };
+    bool had_nl = false;
+    auto next_line = [&](const char *&lo, const char *&hi) -> bool {      // [lo, hi) without the newline
         if (p >= end) return false;
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
         lo = p;
         hi = nl ? nl : end;
         p = nl ? nl + 1 : end;
+        had_nl = nl != nullptr;
         return true;
     };
     bool have_record = false;
-    int rc = KV_OK;
     const char *lo, *hi;
-    while (rc == KV_OK && next_line(lo, hi)) {
+    while (next_line(lo, hi)) {
         const char *t_hi = hi;
         const char *t_lo = trim(lo, t_hi);
         if (t_lo == t_hi) continue;                          // blank line
@@ -95,11 +90,8 @@ extern "C" int kv_augfastx_load(const char *path, kv_augfastx **out)
             continue;
         }
         // an annotation or mate line ends in '#' + newline
-        if (!(hi > lo && hi[-1] == '#' && hi < end) || !have_record) {
-            kv_set_error("%s: unexpected line in an augmented FASTA/FASTQ stream: %.60s", path, std::string(lo, (size_t)(hi - lo)).c_str());
-            rc = KV_ERR_IO;
-            break;
-        }
+        if (!(hi > lo && hi[-1] == '#' && had_nl) || !have_record)
+            return fail("%s: unexpected line in an augmented FASTA/FASTQ stream: %.60s", path, std::string(lo, (size_t)(hi - lo)).c_str());
         const uint64_t rec = a->is_fastq.size() - 1;
         if ((size_t)(hi - lo) > 9 && memcmp(lo, "#mateseq=", 9) == 0) {
             a->mates.append(lo + 9, (size_t)(hi - 1 - (lo + 9)));
@@ -115,11 +107,8 @@ extern "C" int kv_augfastx_load(const char *path, kv_augfastx **out)
         const int k = (int)(q - kmer);
         if (a->ksize == 0) a->ksize = k;
         const uint64_t s0 = a->seq_offs[rec], slen = a->seq_offs[rec + 1] - s0;
-        if (k <= 0 || (uint64_t)offset + (uint64_t)k > slen || memcmp(a->seqs.data() + s0 + offset, kmer, (size_t)k) != 0) {
-            kv_set_error("%s: the k-mer of an annotation does not match its read at offset %u (record %llu)", path, offset, (unsigned long long)rec);
-            rc = KV_ERR_IO;
-            break;
-        }
+        if (k <= 0 || (uint64_t)offset + (uint64_t)k > slen || memcmp(a->seqs.data() + s0 + offset, kmer, (size_t)k) != 0)
+            return fail("%s: the k-mer of an annotation does not match its read at offset %u (record %llu)", path, offset, (unsigned long long)rec);
         if (k != a->ksize) { a->ksize = -1; }               // mixed k: the caller decides (filter / partition reject it)
         int count = 0;
         while (q < hi - 1) {
@@ -128,21 +117,163 @@ extern "C" int kv_augfastx_load(const char *path, kv_augfastx **out)
             int32_t v = 0;
             bool digits = false;
             while (q < hi - 1 && *q >= '0' && *q <= '9') { v = v * 10 + (*q - '0'); ++q; digits = true; }
-            if (!digits) { kv_set_error("%s: bad abundance in an annotation of record %llu", path, (unsigned long long)rec); rc = KV_ERR_IO; break; }
+            if (!digits) return fail("%s: bad abundance in an annotation of record %llu", path, (unsigned long long)rec);
             a->ann_abund.push_back(v);
             ++count;
         }
-        if (rc != KV_OK) break;
         if (a->nsamples == 0 && a->ann_offset.empty()) a->nsamples = count;
-        if (count != a->nsamples) {
-            kv_set_error("%s: annotations with %d and %d abundances in one stream", path, a->nsamples, count);
-            rc = KV_ERR_IO;
-            break;
-        }
+        if (count != a->nsamples) return fail("%s: annotations with %d and %d abundances in one stream", path, a->nsamples, count);
         a->ann_offset.push_back(offset);
         a->ann_first.back() = a->ann_offset.size();
     }
-    if (rc != KV_OK) { delete a; return rc; }
+    return KV_OK;
+}
+
+// `pieces` + 1 places to cut [begin, end) at, each the start of a record: the first, the end, and in between the first
+// record start behind every i / pieces of the way.  A record starts with a line that begins with '>' in a FASTA stream; in a
+// FASTQ stream with one that begins with '@' AND has a '+' line two lines on (a quality line may begin with '@', but what
+// follows a quality line two lines on is an annotation, a header or a sequence).  Fewer places come back if no start is found
+// within 4 MB of where one is wanted (the caller then parses in one piece).
+std::vector<const char *> record_starts(const char *begin, const char *end, size_t pieces)
+{
+    std::vector<const char *> cuts(1, begin);
+    const char *p = begin;
+    while (p < end && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n')) ++p;
+    if (p >= end || (*p != '@' && *p != '>')) return cuts;
+    const bool fastq = *p == '@';
+    auto line_after = [&](const char *q) -> const char * {
+        const char *nl = (const char *)memchr(q, '\n', (size_t)(end - q));
+        return nl ? nl + 1 : end;
+    };
+    for (size_t i = 1; i < pieces; ++i) {
+        const char *q = begin + (size_t)((double)(end - begin) * (double)i / (double)pieces);
+        if (q <= cuts.back()) continue;
+        q = line_after(q);                              // the start of a line
+        const char *limit = std::min(end, q + (4u << 20));
+        const char *found = nullptr;
+        while (q < limit) {
+            if (!fastq && *q == '>') { found = q; break; }
+            if (fastq && *q == '@') {
+                const char *two_on = line_after(line_after(q));
+                if (two_on < end && *two_on == '+') { found = q; break; }
+            }
+            q = line_after(q);
+        }
+        if (!found) return std::vector<const char *>(1, begin);
+        if (found > cuts.back()) cuts.push_back(found);
+    }
+    cuts.push_back(end);
+    return cuts;
+}
+
+// the pieces one behind the other; false if they cannot be one stream (different numbers of abundance columns)
+bool join_parts(std::vector<kv_augfastx> &part, kv_augfastx *a)
+{
+    size_t names = 0, seqs = 0, quals = 0, mates = 0, recs = 0, anns = 0, abund = 0, n_mates = 0;
+    for (const kv_augfastx &b : part) {
+        names += b.names.size(); seqs += b.seqs.size(); quals += b.quals.size(); mates += b.mates.size();
+        recs += b.is_fastq.size(); anns += b.ann_offset.size(); abund += b.ann_abund.size(); n_mates += b.mate_record.size();
+        if (b.ann_offset.empty()) continue;
+        if (a->nsamples == 0) a->nsamples = b.nsamples;
+        else if (b.nsamples != a->nsamples) return false;
+        if (a->ksize == 0) a->ksize = b.ksize;
+        else if (b.ksize != a->ksize) a->ksize = -1;
+    }
+    a->names.reserve(names); a->seqs.reserve(seqs); a->quals.reserve(quals); a->mates.reserve(mates);
+    a->name_offs.reserve(recs + 1); a->seq_offs.reserve(recs + 1); a->qual_offs.reserve(recs + 1); a->ann_first.reserve(recs + 1);
+    a->is_fastq.reserve(recs); a->ann_offset.reserve(anns); a->ann_abund.reserve(abund);
+    a->mate_record.reserve(n_mates); a->mate_offs.reserve(n_mates + 1);
+    for (kv_augfastx &b : part) {
+        const uint64_t base_n = a->names.size(), base_s = a->seqs.size(), base_q = a->quals.size(), base_m = a->mates.size();
+        const uint64_t base_r = a->is_fastq.size(), base_a = a->ann_offset.size();
+        a->names += b.names; a->seqs += b.seqs; a->quals += b.quals; a->mates += b.mates;
+        for (size_t i = 1; i < b.name_offs.size(); ++i) {
+            a->name_offs.push_back(base_n + b.name_offs[i]);
+            a->seq_offs.push_back(base_s + b.seq_offs[i]);
+            a->qual_offs.push_back(base_q + b.qual_offs[i]);
+            a->ann_first.push_back(base_a + b.ann_first[i]);
+        }
+        a->is_fastq.insert(a->is_fastq.end(), b.is_fastq.begin(), b.is_fastq.end());
+        a->ann_offset.insert(a->ann_offset.end(), b.ann_offset.begin(), b.ann_offset.end());
+        a->ann_abund.insert(a->ann_abund.end(), b.ann_abund.begin(), b.ann_abund.end());
+        for (size_t i = 1; i < b.mate_offs.size(); ++i) a->mate_offs.push_back(base_m + b.mate_offs[i]);
+        for (uint32_t r : b.mate_record) a->mate_record.push_back((uint32_t)(base_r + r));
+        b = kv_augfastx();                               // let the piece go
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" int kv_augfastx_load(const char *path, kv_augfastx **out)
+{
+    KV_REQUIRE(path && out, KV_ERR_ARG, "kv_augfastx_load: null argument");
+    // an uncompressed file is parsed where the page cache has it (going through zlib's transparent read copied it twice:
+    // half of the load time); a compressed one is inflated into a buffer first
+    std::string text;
+    const char *image = nullptr;
+    size_t image_size = 0;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) { kv_set_error("cannot open %s", path); return KV_ERR_IO; }
+    {
+        struct stat sb;
+        unsigned char magic[2] = {0, 0};
+        const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0;
+        const bool gz = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (regular && !gz) {
+            void *map = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (map != MAP_FAILED) { image = (const char *)map; image_size = (size_t)sb.st_size; }
+        }
+    }
+    struct Unmap {
+        const char *p; size_t n; int fd;
+        ~Unmap() { if (p) munmap((void *)p, n); if (fd >= 0) close(fd); }
+    } unmap{image, image_size, fd};
+    if (!image) {
+        gzFile fh = gzopen(path, "rb");
+        if (!fh) { kv_set_error("cannot open %s", path); return KV_ERR_IO; }
+        gzbuffer(fh, 1 << 20);
+        std::vector<char> buf(8 << 20);
+        for (;;) {
+            const int got = gzread(fh, buf.data(), (unsigned)buf.size());
+            if (got < 0) { gzclose(fh); kv_set_error("cannot read %s", path); return KV_ERR_IO; }
+            if (got == 0) break;
+            text.append(buf.data(), (size_t)got);
+        }
+        gzclose(fh);
+        image = text.data();
+        image_size = text.size();
+    }
+    // ---- big files are cut at record starts and the pieces parsed side by side
+    kv_augfastx *a = nullptr;
+    const char *forced = getenv("KV_AUGFASTX_THREADS");             // 1: one pass, for comparison
+    const unsigned hw = forced ? (unsigned)std::max(1, atoi(forced)) : std::max(1u, std::thread::hardware_concurrency());
+    const size_t pieces = std::min<size_t>(std::min<size_t>(hw, 16), image_size / (4u << 20));
+    if (pieces >= 2) {
+        const std::vector<const char *> cuts = record_starts(image, image + image_size, pieces);
+        if (cuts.size() >= 3) {
+            const size_t n = cuts.size() - 1;
+            std::vector<kv_augfastx> part(n);
+            std::vector<int> rcs(n, KV_OK);
+            std::vector<std::string> errs(n);
+            std::vector<std::thread> crew;
+            for (size_t i = 0; i < n; ++i)
+                crew.emplace_back([&, i] { rcs[i] = parse_range(cuts[i], cuts[i + 1], path, &part[i], &errs[i]); });
+            for (std::thread &t : crew) t.join();
+            bool ok = true;
+            for (size_t i = 0; i < n; ++i) ok = ok && rcs[i] == KV_OK;
+            if (ok) {
+                a = new kv_augfastx();
+                if (!join_parts(part, a)) { delete a; a = nullptr; }        // (pieces that disagree on the columns: the plain pass below says so)
+            }
+        }
+    }
+    if (!a) {                                          // one pass over the whole file (small files; and whatever the pieces stumbled over,
+        a = new kv_augfastx();                         // for the message with the record's true number)
+        std::string err;
+        const int rc = parse_range(image, image + image_size, path, a, &err);
+        if (rc != KV_OK) { delete a; kv_set_error("%s", err.c_str()); return rc; }
+    }
     *out = a;
     return KV_OK;
 }

@@ -145,3 +145,68 @@ def test_unband_files_equals_unband_of_records(tmp_path):
     want = ''.join(format_augmented_fastx(r) for r in kevlar_amd.unband.unband(kevlar_amd.seqio.afxstream(paths), 4)).encode('latin-1')
     got = kevlar_amd.unband.unband_files(paths, 4)
     assert got == want and len(got) > 5000
+
+
+def _big_augfastq(n, fastq, seed):
+    """~100 bytes of record + annotations per read; quality lines that begin with '@' and '>', mates, blank lines"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        seq = ''.join('ACGT'[c] for c in rng.integers(0, 4, 60))
+        if fastq:
+            qual = ''.join(chr(c) for c in rng.integers(33, 74, 60))
+            if i % 3 == 0:
+                qual = '@' + qual[1:]
+            if i % 5 == 0:
+                qual = '>' + qual[1:]
+            out.append('@read{} x\n{}\n+\n{}\n'.format(i, seq, qual))
+        else:
+            out.append('>read{} x\n{}\n'.format(i, seq))
+        start = int(rng.integers(0, 20))
+        for o in range(start, start + int(rng.integers(0, 4))):
+            out.append(' ' * o + seq[o:o + 21] + ' ' * 10 + '{} 0 1#\n'.format(int(rng.integers(1, 99))))
+        if i % 7 == 0:
+            out.append('#mateseq={}#\n'.format(seq[::-1]))
+        if i % 1000 == 0:
+            out.append('\n')
+    return ''.join(out)
+
+
+@pytest.mark.parametrize('fastq', [True, False])
+def test_native_parse_in_pieces_equals_one_pass(tmp_path, fastq):
+    """a file big enough to be cut at record starts and parsed side by side gives the arrays of the one-pass parse; a damaged
+    line in the middle is reported as the one-pass parse reports it"""
+    text = _big_augfastq(60000, fastq, 5)
+    assert len(text) > (9 << 20)
+    path = str(tmp_path / ('big.augfastq' if fastq else 'big.augfasta'))
+    with open(path, 'w') as fh:
+        fh.write(text)
+    loaded = {}
+    for threads in ('1', '2', '7'):
+        os.environ['KV_AUGFASTX_THREADS'] = threads
+        try:
+            loaded[threads] = AnnotatedReads.from_file(path)
+        finally:
+            os.environ.pop('KV_AUGFASTX_THREADS', None)
+    one = loaded['1']
+    assert one.n == 60000 and len(one.mate_record) == 60000 // 7 + 1
+    for threads in ('2', '7'):
+        got = loaded[threads]
+        assert got.n == one.n and got.ksize == one.ksize and got.nsamples == one.nsamples
+        for field in ('names', 'seqs', 'quals', 'mates'):
+            assert getattr(got, field) == getattr(one, field), field
+        for field in ('name_offs', 'seq_offs', 'qual_offs', 'is_fastq', 'first', 'offset', 'abund', 'mate_record', 'mate_offs'):
+            assert np.array_equal(getattr(got, field), getattr(one, field)), field
+    middle = text.index('\n', len(text) // 2) + 1
+    with open(path, 'w') as fh:
+        fh.write(text[:middle] + 'something else\n' + text[middle:])
+    messages = []
+    for threads in ('1', '7'):
+        os.environ['KV_AUGFASTX_THREADS'] = threads
+        try:
+            with pytest.raises(Exception) as err:
+                AnnotatedReads.from_file(path)
+            messages.append(str(err.value))
+        finally:
+            os.environ.pop('KV_AUGFASTX_THREADS', None)
+    assert messages[0] == messages[1] and 'unexpected line' in messages[0]
