@@ -19,6 +19,7 @@ C ABI in include/kvsketch.h.  There is no CPU implementation behind these classe
 """
 import ctypes
 import gzip
+import os
 import threading
 
 import numpy as np

@@ -49,6 +49,10 @@ def save_counts(filelist, tablelist, log=None):
         sketch.save(path)
 
 
+def _side_by_side():
+    return bool(os.environ.get('KV_PARALLEL_SAMPLES'))
+
+
 def load_samples(counttables=None, filelists=None, ksize=31, memory=1e6, maxfpr=0.2, numbands=None, band=None, numthreads=1,
                  outfilelist=None, log=None):
     """One sketch per sample: loaded from saved count tables if given, else counted from the sample's files."""
@@ -58,8 +62,17 @@ def load_samples(counttables=None, filelists=None, ksize=31, memory=1e6, maxfpr=
         log('[kevlar::novel]    INFO:', 'counttables for {:d} sample(s) provided, any corresponding FASTA/FASTQ input '
                         'will be ignored for computing k-mer abundances'.format(len(counttables)))
         return kevlar_amd.sketch.load_sketchfiles(counttables, maxfpr)
-    # the samples are counted side by side, each on its own HIP stream (reading one file overlaps with counting another);
-    # what each has to say is held back and printed sample by sample, as a one-after-the-other run prints it
+    # KV_PARALLEL_SAMPLES=1: the samples are counted side by side, each on its own HIP stream (reading one file overlaps with
+    # counting another); what each has to say is held back and printed sample by sample, as a one-after-the-other run prints
+    # it.  Not the default: every stream brings its own scratch buffers, and in a process that counts each sample once their
+    # first allocation (gigabytes at config 2) costs more than the overlap gains (7.5 M reads per sample, cold: 1.09 s side by
+    # side against 0.76 s one after the other; 2 M reads, buffers warm: 0.115 against 0.134 s).
+    if not _side_by_side():
+        sketches = [kevlar_amd.count.load_sample_seqfile(files, ksize, memory, maxfpr=maxfpr, numbands=numbands, band=band,
+                                                         numthreads=numthreads, log=log) for files in filelists]
+        if outfilelist:
+            save_counts(outfilelist, sketches, log)
+        return sketches
     said = [[] for _ in filelists]
 
     def one(i):
@@ -225,15 +238,9 @@ def novel_text(casestream, casecounts, controlcounts, ksize=31, abundscreen=None
     kevlar_amd.plog('[kevlar::novel]', tally.line(clock.stop()))
 
 
-def main(args):
-    if (not args.num_bands) != (not args.band):
-        raise ValueError('Must specify --num-bands and --band together')
-    band = args.band - 1 if args.band else None
-    clock = kevlar_amd.Timer()
-    for key in (None, 'loadall', 'loadctrl'):
-        clock.start(key)
-    # controls and cases are loaded side by side (each sample on its own HIP stream); what they have to say is printed in the
-    # order of a one-after-the-other run
+def _load_side_by_side(args, band):
+    """KV_PARALLEL_SAMPLES=1: controls and cases loaded side by side, each sample on its own HIP stream; what they have to say
+    is printed in the order of a one-after-the-other run"""
     said = {'ctrl': [], 'case': []}
     took = {}
 
@@ -245,8 +252,8 @@ def main(args):
         took[which] = watch.stop()
         return sketches
     try:
-        controls, cases = khmer.run_concurrently([lambda: load('ctrl', args.control_counts, args.control, args.save_ctrl_counts),
-                                                  lambda: load('case', args.case_counts, args.case, args.save_case_counts)])
+        return khmer.run_concurrently([lambda: load('ctrl', args.control_counts, args.control, args.save_ctrl_counts),
+                                       lambda: load('case', args.case_counts, args.case, args.save_case_counts)])
     finally:
         kevlar_amd.plog('[kevlar::novel] Loading control samples')
         for words in said['ctrl']:
@@ -258,7 +265,28 @@ def main(args):
             kevlar_amd.plog(*words)
         if 'case' in took:
             kevlar_amd.plog('[kevlar::novel] Case samples loaded in {:.2f} sec'.format(took['case']))
-    clock.stop('loadctrl')
+
+
+def main(args):
+    if (not args.num_bands) != (not args.band):
+        raise ValueError('Must specify --num-bands and --band together')
+    band = args.band - 1 if args.band else None
+    clock = kevlar_amd.Timer()
+    for key in (None, 'loadall', 'loadctrl'):
+        clock.start(key)
+    if not _side_by_side():
+        kevlar_amd.plog('[kevlar::novel] Loading control samples')
+        controls = load_samples(args.control_counts, args.control, args.ksize, args.memory, args.max_fpr, args.num_bands, band,
+                                args.threads, args.save_ctrl_counts)
+        kevlar_amd.plog('[kevlar::novel]', 'Control samples loaded in {:.2f} sec'.format(clock.stop('loadctrl')))
+        kevlar_amd.plog('[kevlar::novel] Loading case samples')
+        clock.start('loadcases')
+        cases = load_samples(args.case_counts, args.case, args.ksize, args.memory, args.max_fpr, args.num_bands, band,
+                             args.threads, args.save_case_counts)
+        kevlar_amd.plog('[kevlar::novel] Case samples loaded in {:.2f} sec'.format(clock.stop('loadcases')))
+    else:
+        controls, cases = _load_side_by_side(args, band)
+        clock.stop('loadctrl')
     kevlar_amd.plog('[kevlar::novel] All samples loaded in {:.2f} sec'.format(clock.stop('loadall')))
 
     clock.start('iter')
