@@ -299,12 +299,19 @@ def test_novel_cli_same_output_from_bgzf_and_plain_gzip(hk, tmp_path):
         with gz.open(files[name][1], 'wt') as fh:
             fh.write(text)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for which, env in ((0, {}), (1, {}), (1, {'KV_INGEST': 'host'})):
-        out = str(tmp_path / 'novel{}{}.augfastq'.format(which, len(env)))
+    outs, logs = [], []
+    for which, env in ((0, {}), (1, {}), (1, {'KV_INGEST': 'host'}), (0, {'KV_PARALLEL_SAMPLES': '1'})):
+        out = str(tmp_path / 'novel{}{}.augfastq'.format(which, ''.join(env)))
         cmd = [sys.executable, '-m', 'kevlar_amd', 'novel', '--case', files['proband'][which], '--control', files['mother'][which],
                '--control', files['father'][which], '--ksize', '25', '--memory', '2M', '--case-min', '5', '--ctrl-max', '1', '--out', out]
         done = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert done.returncode == 0, done.stderr[-2000:]
         outs.append(open(out).read())
-    assert outs[0] == outs[1] == outs[2] and outs[0].count('\n') > 100
+        logs.append([line for line in done.stderr.split('\n') if line.startswith('[kevlar')])
+    assert outs[0] == outs[1] == outs[2] == outs[3] and outs[0].count('\n') > 100
+    # the samples counted side by side (KV_PARALLEL_SAMPLES=1) say what they say in the order of the one-after-the-other run
+
+    def untimed(lines):
+        import re
+        return [re.sub(r'[0-9.]+ sec(onds)?', 'T sec', line) for line in lines]
+    assert len(logs[0]) > 8 and untimed(logs[3]) == untimed(logs[0])
