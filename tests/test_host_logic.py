@@ -509,3 +509,29 @@ def test_hit_memory_keeps_its_owner_alive_through_derived_views():
     del flat
     gc.collect()
     assert Holder.alive == 0
+
+
+def test_bench_write_gzip_is_one_valid_member(tmp_path):
+    """bench.write_gzip (the pigz-style writer of the end-to-end leg): pieces deflated on several threads make ONE gzip member
+    that any reader inflates to the text, CRC-32 and length in the trailer included"""
+    import gzip
+    import struct
+    import sys
+    import zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        import bench
+    finally:
+        sys.path.remove(root)
+    rng = np.random.default_rng(3)
+    text = bytes(rng.choice(np.frombuffer(b'ACGT\n', dtype=np.uint8), 700000)) + b'@tail\n'
+    for piece, threads in ((1 << 16, 4), (1 << 20, 1), (123457, 3)):
+        path = str(tmp_path / 'w{}.gz'.format(piece))
+        bench.write_gzip(path, text, level=4, threads=threads, piece=piece)
+        image = open(path, 'rb').read()
+        assert gzip.decompress(image) == text
+        assert zlib.decompressobj(31).decompress(image) == text                       # one member: nothing left over
+        assert struct.unpack('<II', image[-8:]) == (zlib.crc32(text) & 0xffffffff, len(text))
+    bench.write_gzip(str(tmp_path / 'empty.gz'), b'', threads=2)
+    assert gzip.decompress(open(str(tmp_path / 'empty.gz'), 'rb').read()) == b''
