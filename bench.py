@@ -90,8 +90,46 @@ def parse_args():
                         'independent; kernels bound by different units overlap and no stream waits for another\'s host round '
                         'trips: 39-40 ms against 43-46 ms per step at config 2).  Per-kernel HIP-event durations then include '
                         'time sharing; 1 keeps the launches back to back for a clean per-kernel attribution')
+    p.add_argument('--launch-check', action='store_true', help='only start the ranks and let them meet (no GPU work)')
     p.add_argument('--backend', default='nccl', help='nccl (= RCCL) is what the driver runs; gloo lets two ranks share one GPU in tests')
     return p.parse_args()
+
+
+def self_launch(n):
+    """Run this very command under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free
+    port) and return its exit code.  The children are new processes: this one never initialises HIP."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL between processes needs it on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env)
+    try:
+        return proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        return proc.wait()
+
+
+def launch_check(args, rank, world):
+    """--launch-check: the ranks meet, exchange their ids over the chosen backend and leave; no GPU work (the CPU
+    test of the launcher, tests/test_bench_launcher.py)."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(args.backend if args.backend != 'nccl' or torch.cuda.is_available() else 'gloo')
+    mine = torch.tensor([rank], dtype=torch.int64)
+    if dist.get_backend() == 'nccl':
+        mine = mine.cuda(int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count()))
+    seen = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(seen, mine)
+    if rank == 0:
+        print(json.dumps({'launch_check': True, 'n_gpus': world, 'backend': dist.get_backend(),
+                          'ranks_seen': sorted(int(t.item()) for t in seen)}))
+    dist.destroy_process_group()
 
 
 def prof(lib, name):
@@ -118,9 +156,14 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world == 1 and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes, BEFORE this process
+        # has touched the GPU (nothing above imports torch or the library); relay rank 0's line and the exit code
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node {}'.format(args.gpus))
+        raise SystemExit('bench.py --gpus {} was started with WORLD_SIZE={}'.format(args.gpus, world))
+    if args.launch_check:
+        return launch_check(args, rank, world)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -270,6 +313,9 @@ def main():
     lib.kv_prof_enable(1)
     for key in wall:
         wall[key] = 0.0
+    if exchange:
+        for key in run.timing:
+            run.timing[key] = 0.0
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -277,10 +323,23 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     lib.kv_prof_enable(0)
+    phases = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # where a rank's step goes, host clock around each phase, slowest rank per phase (a bad scaling point then says
+        # whether routing, the all-to-all, the owner's count, the scan or the gather is to blame).  exchange: route =
+        # hashing / deduplicating the shard, exchange = issuing the all-to-all + waiting for it, count = the owner's
+        # adds, scan = evaluating (and, with distinct items, the set lookup), gather = the collectives behind the hits
+        mine = dict(run.timing) if exchange else {'count': wall['count'], 'scan': wall['novel'], 'gather': wall['merge']}
+        keys = sorted(mine)
+        both = torch.tensor([mine[key] for key in keys] + [-mine[key] for key in keys], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)
+        both = [float(v) for v in both.cpu()]
+        phases = {'max_over_ranks': {key: round(both[i] / args.steps * 1e3, 3) for i, key in enumerate(keys)},
+                  'min_over_ranks': {key: round(-both[len(keys) + i] / args.steps * 1e3, 3) for i, key in enumerate(keys)},
+                  'unit': 'ms per step'}
 
     # ---- cheap end-to-end sanity on the timed result (parity proper lives in tests/)
     r, o, a = hits
@@ -435,6 +494,7 @@ def main():
                                                torch.cuda.get_device_properties(dev_index).multi_processor_count),
             },
             'selfcheck': selfcheck,
+            'phases': phases,
             'roofline': roofline,
             'cpu_baseline': cpu,
             'end_to_end': e2e,

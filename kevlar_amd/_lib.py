@@ -8,7 +8,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIBNAME = 'libkvsketch_hip.so'
-LIBPATH = os.path.join(_HERE, LIBNAME)
+# KV_LIB_PATH: another build of the same library (the A/B variants scratch/ab_build.py makes); same ABI, same checks
+LIBPATH = os.environ.get('KV_LIB_PATH') or os.path.join(_HERE, LIBNAME)
 
 KV_OK = 0
 KV_ERR_ARG, KV_ERR_IO, KV_ERR_TYPE, KV_ERR_HIP, KV_ERR_NOTIMPL, KV_ERR_CAPACITY = -1, -2, -3, -4, -5, -6

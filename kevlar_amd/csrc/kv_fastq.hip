@@ -338,7 +338,6 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
             while (m1 < d->members.size() && (m1 == m0 || d->carry_len + fresh + d->members[m1].isize <= want)) fresh += d->members[m1++].isize;
         }
         lap(d->gz ? "gunzip: decode" : "select");
-        lap(d->gz ? "gunzip: decode" : "select");
         const bool final = d->gz ? gz_last : d->plain ? b0 + fresh == d->image_size : m1 == d->members.size();
         const uint64_t total_in = d->carry_len + fresh;
         if (total_in == 0) { d->done = true; return KV_OK; }
@@ -350,8 +349,11 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         if (d->gz && fresh) { const int rc = kv_gunzip_emit(d->gz, text + d->carry_len); if (rc != KV_OK) return rc; }
         if (m1 > m0) {
             const uint64_t c0 = d->members[m0].in_off, c1 = d->members[m1 - 1].in_off + d->members[m1 - 1].in_len;
-            KV_HIP(d->buf->comp.need(kv_round_up(c1 - c0 + 512, 4096)));          // (a damaged member may be read ~150 bytes past its end before it is caught)
+            // (a damaged member is read at most ~600 bytes past its end before k_inflate catches it: one dynamic block
+            // header, or one row of a stored block; the slack is zeroed so that what it decodes there is an error, not noise)
+            KV_HIP(d->buf->comp.need(kv_round_up(c1 - c0 + KV_INFLATE_SLACK, 4096)));
             KV_HIP(hipMemcpyAsync(d->buf->comp.p, d->image + c0, c1 - c0, hipMemcpyHostToDevice, st));
+            KV_HIP(hipMemsetAsync((uint8_t *)d->buf->comp.p + (c1 - c0), 0, KV_INFLATE_SLACK, st));
             std::vector<uint64_t> text_off(m1 - m0);
             uint64_t at = d->carry_len;
             for (size_t i = m0; i < m1; ++i) { text_off[i - m0] = at; at += d->members[i].isize; }

@@ -87,11 +87,18 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 5 : RBITS == 1
                 const uint32_t stored_len = br_bits(br, 16);
                 const uint32_t inv = br_bits(br, 16);
                 if ((stored_len ^ inv) != 0xffffu || o + stored_len > job.isize) { failed = true; break; }
+                // (a stored block that claims more bytes than the member holds -- damaged or crafted input -- must not walk
+                // the reader out of the buffer: the position is checked once per row of 64 bytes, and the caller's buffer
+                // has KV_INFLATE_SLACK readable bytes behind the last member)
                 for (uint32_t j = 0; j < stored_len; ++j) {
                     const uint32_t byte = br_bits(br, 8);
                     lit = lane == n_lit ? byte : lit;
-                    if (++n_lit == 64) flush();
+                    if (++n_lit == 64) {
+                        if (br.next > limit_words) { failed = true; break; }
+                        flush();
+                    }
                 }
+                if (failed || br.next > limit_words) { failed = true; break; }
                 flush();
                 continue;
             }
@@ -140,6 +147,7 @@ __global__ __launch_bounds__(64, (RBITS <= 10 ? 8 : RBITS == 11 ? 5 : RBITS == 1
                     idx += rep;
                     prev = val;
                 }
+                if (br.next > limit_words) ok = 0;      // the header alone can be ~560 bytes: a truncated member ends here
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0 && ok) {
@@ -360,10 +368,10 @@ extern "C" int kv_bgzf_inflate_host(const void *file, uint64_t size, void *out, 
     KvArena scratch;
     hipStream_t st = kv_stream();
     int rc = KV_OK;
-    hipError_t e = hipMalloc((void **)&d_comp, size + 512);
+    hipError_t e = hipMalloc((void **)&d_comp, size + KV_INFLATE_SLACK);
     if (e == hipSuccess) e = hipMalloc((void **)&d_text, total + 64);
     if (e == hipSuccess) e = hipMemcpyAsync(d_comp, file, size, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemsetAsync(d_comp + size, 0, 512, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_comp + size, 0, KV_INFLATE_SLACK, st);
     if (e == hipSuccess) {
         hipEvent_t a, b;
         (void)hipEventCreate(&a); (void)hipEventCreate(&b);

@@ -236,6 +236,8 @@ struct KvBgzfMember {
 };
 struct KvArena;
 int kv_bgzf_index(const uint8_t *file, uint64_t size, std::vector<KvBgzfMember> *members, int *is_bgzf);
+// readable (and zeroed) bytes the caller keeps behind the compressed image it hands to kv_bgzf_inflate
+#define KV_INFLATE_SLACK 2048
 int kv_bgzf_inflate(const uint8_t *d_comp, uint64_t comp_base, const KvBgzfMember *members, uint64_t count, const uint64_t *text_off,
                     uint8_t *d_text, KvArena &scratch);
 

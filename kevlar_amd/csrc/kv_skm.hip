@@ -347,6 +347,120 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split(SkmGeom sg)
         sg.cnt2[((uint64_t)c * sg.F2 + f) * sg.nwg2 + blockIdx.x] = min(cur[f], sg.cap2);
 }
 
+// S2 with the scatter sorted in LDS first.  The plain kernel above stores every record where it falls: 64 lanes, 64
+// different cache lines per store instruction, 8-byte pieces of 24-byte records that straddle 32-byte sectors -- PMC:
+// 2.5 GB written for 1.36 GB of records, 68 % of the wave cycles stalled on the memory pipe.  Here a workgroup takes
+// SKM_S2_CHUNK records at a time, ranks them by fine bucket (LDS atomics: rank inside the chunk's share of the bucket),
+// lays them out bucket by bucket in LDS and copies that image out with consecutive lanes on consecutive words: a bucket's
+// records of one chunk leave as one contiguous run.  Used while a chunk holds at least ~2 records per bucket.
+#define SKM_S2_CHUNK 2048u
+#define SKM_S2_MAXF 1024u
+template <int RECW>
+__global__ __launch_bounds__(SKM_THREADS2) void k_skm_split_sorted(SkmGeom sg)
+{
+    __shared__ uint32_t cur[SKM_S2_MAXF];            // records this workgroup has stored per fine bucket
+    __shared__ uint32_t hist[SKM_S2_MAXF];           // the chunk's records per bucket, then slot of sorted position 0 minus that position
+    __shared__ uint32_t off[SKM_S2_MAXF];            // sorted position of the bucket's first record of the chunk
+    __shared__ uint32_t spre[769];
+    __shared__ uint32_t wsum[SKM_THREADS2 / 64];
+    extern __shared__ __attribute__((aligned(16))) uint64_t img[];     // [SKM_S2_CHUNK][RECW]
+    const uint32_t c = blockIdx.y, F2 = sg.F2;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t f = threadIdx.x; f < F2; f += SKM_THREADS2) { cur[f] = 0; hist[f] = 0; }
+    const uint32_t nmine = (sg.nwg1 - blockIdx.x + sg.nwg2 - 1) / sg.nwg2;       // <= 768
+    for (uint32_t i = threadIdx.x; i < nmine; i += SKM_THREADS2) spre[i + 1] = sg.cnt1[(uint64_t)c * sg.nwg1 + blockIdx.x + i * sg.nwg2];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < nmine; ++i) { const uint32_t n = spre[i + 1]; spre[i] = acc; acc += n; }
+        spre[nmine] = acc;
+    }
+    __syncthreads();
+    const uint32_t total = spre[nmine];
+    constexpr uint32_t PER = SKM_S2_CHUNK / SKM_THREADS2;             // records per thread and chunk
+    const uint32_t fper = (F2 + SKM_THREADS2 - 1) / SKM_THREADS2;     // buckets per thread in the scan (1 or 2)
+    uint64_t *const out = sg.seg2 + ((uint64_t)c * F2 * sg.nwg2 + blockIdx.x) * sg.cap2 * RECW;      // + fine * nwg2 * cap2 * RECW
+    const uint64_t fstride = (uint64_t)sg.nwg2 * sg.cap2 * RECW;
+    for (uint32_t c0 = 0; c0 < total; c0 += SKM_S2_CHUNK) {
+        const uint32_t n = min(SKM_S2_CHUNK, total - c0);
+        uint64_t hdr[PER], w0[PER], w1[PER], w2[PER];
+        uint32_t rank[PER];
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            const uint32_t i = r * SKM_THREADS2 + threadIdx.x;
+            hdr[r] = 0; w0[r] = 0; w1[r] = 0; w2[r] = 0; rank[r] = 0;
+            if (i < n) {
+                const uint32_t gi = c0 + i, si = skm_search(spre, nmine, gi);
+                const uint32_t seg = blockIdx.x + si * sg.nwg2;
+                const uint64_t *rec = sg.seg1 + (((uint64_t)c * sg.nwg1 + seg) * sg.cap1 + (gi - spre[si])) * (uint64_t)RECW;
+                hdr[r] = rec[0]; w0[r] = rec[1]; w1[r] = rec[2];
+                if (RECW == 4) w2[r] = rec[3];
+            }
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r)
+            if (r * SKM_THREADS2 + threadIdx.x < n) rank[r] = atomicAdd(&hist[skm_hdr_fine(hdr[r])], 1u);
+        __syncthreads();
+        // exclusive scan of the chunk's histogram; the bucket's run then starts at slot cur[f] of the private segment
+        {
+            uint32_t h[2] = {0, 0}, sum = 0;
+            for (uint32_t j = 0; j < fper; ++j) {
+                const uint32_t f = threadIdx.x * fper + j;
+                h[j] = f < F2 ? hist[f] : 0u;
+                sum += h[j];
+            }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d);
+                if (lane >= (uint32_t)d) incl += up;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t before = incl - sum;
+            for (uint32_t wv = 0; wv < wave; ++wv) before += wsum[wv];
+            for (uint32_t j = 0; j < fper; ++j) {
+                const uint32_t f = threadIdx.x * fper + j;
+                if (f < F2) {
+                    off[f] = before;
+                    const uint32_t at = cur[f];
+                    cur[f] = at + h[j];
+                    hist[f] = at - before;              // slot = sorted position + this (mod 2^32)
+                    before += h[j];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            if (r * SKM_THREADS2 + threadIdx.x < n) {
+                uint64_t *dst = img + (uint64_t)(off[skm_hdr_fine(hdr[r])] + rank[r]) * RECW;
+                dst[0] = hdr[r]; dst[1] = w0[r]; dst[2] = w1[r];
+                if (RECW == 4) dst[3] = w2[r];
+            }
+        }
+        __syncthreads();
+        for (uint32_t wd = threadIdx.x; wd < n * RECW; wd += SKM_THREADS2) {
+            const uint32_t q = wd / RECW, part = wd - q * RECW;
+            const uint64_t h0 = img[(uint64_t)q * RECW];
+            const uint32_t f = skm_hdr_fine(h0);
+            const uint32_t slot = q + hist[f];
+            if (slot < sg.cap2) out[(uint64_t)f * fstride + (uint64_t)slot * RECW + part] = img[wd];
+            else if (part == 0) {
+                uint64_t bw[3] = {img[(uint64_t)q * RECW + 1], img[(uint64_t)q * RECW + 2], RECW == 4 ? img[(uint64_t)q * RECW + 3] : 0ull};
+                skm_loose_push(sg, h0, bw);
+            }
+        }
+        __syncthreads();
+        for (uint32_t f = threadIdx.x; f < F2; f += SKM_THREADS2) hist[f] = 0;
+        // (the next chunk's atomics on hist come after its loads and after the barrier below at the latest: the loop's
+        // first barrier orders them behind this reset only if every thread passes it, so reset before a barrier)
+        __syncthreads();
+    }
+    for (uint32_t f = threadIdx.x; f < F2; f += SKM_THREADS2)
+        sg.cnt2[((uint64_t)c * F2 + f) * sg.nwg2 + blockIdx.x] = min(cur[f], sg.cap2);
+}
+
 // ---- LDS combining table -------------------------------------------------------------------------------
 template <int KW, int TS>
 struct SkmTable {
@@ -461,11 +575,15 @@ __device__ __forceinline__ void skm_for_occupied(const unsigned long long *key0,
 }
 
 // ---- balanced walk over the k-mer occurrences of a fine bucket ------------------------------------------------
-// Records hold 1..ncap k-mers, so a thread per record would leave most lanes waiting for the longest one.  Instead
-// each wave takes 64 records at a time (one per lane, in registers), numbers their k-mers with a prefix sum and
-// walks the occurrences 64 at a time: lane p of block t0 handles occurrence t0 + p, finds the record that owns it
-// from a bit mask of record starts (one LDS word pair per block, popcounts) and fetches that record's words from
-// the owning lane with ds_bpermute.  The k-mer is cut straight out of the record at its offset.
+// Records hold 1..ncap k-mers, so a thread per record would leave most lanes waiting for the longest one, and a
+// thread per occurrence cuts every k-mer out of its record from scratch (round 2: 115 VALU instructions per
+// occurrence, the largest item of the count kernel).  The walk therefore deals UNITS: SKM_UNIT consecutive k-mers
+// of one record.  Each wave takes 64 records (one per lane, in registers), numbers their units with a prefix sum and
+// walks them 64 at a time: lane p of block t0 handles unit t0 + p, finds the record that owns it from a bit mask of
+// record starts (one LDS word pair per block, popcounts), fetches that record's words from the owning lane with
+// ds_bpermute, cuts the unit's first k-mer out, takes its reverse complement once and ROLLS both strands through
+// the unit's other k-mers (two shifts each).  Records average ~9 k-mers: units of 4 are 85 % full.
+#define SKM_UNIT 4
 
 __device__ __forceinline__ uint64_t skm_shfl64(uint64_t v, uint32_t src)
 {
@@ -477,29 +595,17 @@ __device__ __forceinline__ uint64_t skm_shfl64(uint64_t v, uint32_t src)
 template <int KW>
 __device__ __forceinline__ SkmKey<KW> skm_kmer_at(uint64_t b0, uint64_t b1, uint64_t b2, uint32_t j, int k)
 {
-    uint32_t sh = 2u * j;
-    SkmKey<KW> f;
-    if (KW == 1) {
-        uint64_t v;
-        if (sh >= 64) v = b1 >> (sh - 64);
-        else v = (b0 >> sh) | (sh ? b1 << (64 - sh) : 0ull);
-        f.w[0] = v & skm_topmask<1>(k);
-    } else {
-        uint64_t x0 = b0, x1 = b1, x2 = b2;
-        if (sh >= 64) { x0 = b1; x1 = b2; x2 = 0; sh -= 64; }
-        f.w[0] = (x0 >> sh) | (sh ? x1 << (64 - sh) : 0ull);
-        f.w[KW - 1] = ((x1 >> sh) | (sh ? x2 << (64 - sh) : 0ull)) & skm_topmask<2>(k);
-    }
-    return f;
+    return skm_kmer_of<KW>(b0, b1, b2, j, k);
 }
 
-// body(forward k-mer, position of the occurrence) -> true if the occurrence could not be combined and must travel
-// alone through the loose list; WANT_POS = false skips fetching the header (count pass)
+// body(canonical k-mer, forward k-mer, position of the occurrence) -> true if the occurrence could not be combined and
+// must travel alone through the loose list; WANT_POS = false skips fetching the header (count pass)
 template <int KW, bool WANT_POS, typename Body>
 __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, uint32_t *sbits_all, Body body)
 {
+    constexpr uint32_t G = SKM_UNIT;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    uint32_t *sbits = sbits_all + wave * sg.sbw;       // sbw words: 64 records x ncap k-mers, + the word a 64-bit read may straddle into
+    uint32_t *sbits = sbits_all + wave * sg.sbw;       // sbw words: 64 records x ncap k-mers (units need fewer), + the word a 64-bit read may straddle into
     const int k = sg.k, recw = sg.recw;
     uint32_t NR = 0;
     for (uint32_t s = 0; s < sg.nwg2; ++s) NR += sg.cnt2[(uint64_t)b * sg.nwg2 + s];
@@ -518,18 +624,20 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
             if (KW == 2) b2 = rec[3];
         }
         const uint32_t nk = i < NR ? skm_hdr_n(hdr) : 0u;
-        uint32_t incl = nk;
+        const uint32_t nu = (nk + G - 1u) / G;          // units of this record
+        uint32_t incl = nu;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t up = __shfl_up(incl, d);
             if (lane >= d) incl += up;
         }
-        const uint32_t total = __shfl(incl, 63), excl = incl - nk;
+        const uint32_t total = __shfl(incl, 63), excl = incl - nu;
+        const uint32_t exnk = excl | (nk << 16);        // < 64 * ncap units: 16 bits are plenty
         const uint32_t nwords = (total >> 5) + 2u;
         for (uint32_t wd = lane; wd < nwords; wd += 64) sbits[wd] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (nk) atomicOr(&sbits[excl >> 5], 1u << (excl & 31));
+        if (nu) atomicOr(&sbits[excl >> 5], 1u << (excl & 31));
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint32_t before = 0;                            // records that start in front of this block
@@ -538,32 +646,33 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
             const uint32_t t = t0 + lane;
             const uint32_t owner = (before + (uint32_t)__popcll(starts & ((2ull << lane) - 1ull)) - 1u) & 63u;
             before += (uint32_t)__popcll(starts);
-            const uint32_t ex = (uint32_t)__shfl((int)excl, (int)owner);
+            const uint32_t oe = (uint32_t)__shfl((int)exnk, (int)owner);
             const uint64_t o0 = skm_shfl64(b0, owner), o1 = skm_shfl64(b1, owner);
             const uint64_t o2 = KW == 2 ? skm_shfl64(b2, owner) : 0ull;
             const uint64_t oh = WANT_POS ? skm_shfl64(hdr, owner) : 0ull;
-            bool alone = false;
-            SkmKey<KW> fw;
-            fw.w[0] = 0;
-            if (KW == 2) fw.w[KW - 1] = 0;
-            uint64_t pos = 0;
-            if (t < total) {
-                const uint32_t j = t - ex;
-                fw = skm_kmer_at<KW>(o0, o1, o2, j, k);
-                pos = skm_hdr_pos(oh) + j;
-                alone = body(fw, pos);
-            }
-            // occurrences that found no room in the LDS table leave as one-k-mer records: one atomic per wave
-            const unsigned long long need = __ballot(alone);
-            if (need) {
-                unsigned long long first = 0;
-                if (lane == 0) first = atomicAdd(&sg.ctr[0], (unsigned long long)__popcll(need));
-                first = skm_shfl64(first, 0);
-                if (alone) {
-                    const unsigned long long idx = first + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
-                    uint64_t one[3] = {fw.w[0], KW == 2 ? fw.w[KW - 1] : 0ull, 0ull};
-                    if (idx < sg.loose_cap) skm_store_record(sg.loose + idx * (uint64_t)recw, skm_header(pos, 1u, 0u), one, sg.nbw);
-                    else sg.ctr[1] = 1;
+            const uint32_t j0 = t < total ? (t - (oe & 0xffffu)) * G : 0u;
+            const uint32_t cnt = t < total ? min(G, (oe >> 16) - j0) : 0u;     // k-mers of this unit: 1..G (0: no unit)
+            SkmKey<KW> fw = skm_kmer_of<KW>(o0, o1, o2, j0, k);
+            SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
+            const uint32_t tail = (uint32_t)skm_window64(o0, o1, o2, j0 + (uint32_t)k);   // the bases that enter k-mers 1 .. G - 1
+            const uint64_t pos0 = skm_hdr_pos(oh) + j0;
+#pragma unroll
+            for (uint32_t u = 0; u < G; ++u) {
+                if (u) skm_roll<KW>(fw, rc, (tail >> (2u * (u - 1u))) & 3u, k);
+                bool alone = false;
+                if (u < cnt) alone = body(skm_canonical<KW>(fw, rc), fw, pos0 + u);
+                // occurrences that found no room in the LDS table leave as one-k-mer records: one atomic per wave
+                const unsigned long long need = __ballot(alone);
+                if (need) {
+                    unsigned long long first = 0;
+                    if (lane == 0) first = atomicAdd(&sg.ctr[0], (unsigned long long)__popcll(need));
+                    first = skm_shfl64(first, 0);
+                    if (alone) {
+                        const unsigned long long idx = first + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
+                        uint64_t one[3] = {fw.w[0], KW == 2 ? fw.w[KW - 1] : 0ull, 0ull};
+                        if (idx < sg.loose_cap) skm_store_record(sg.loose + idx * (uint64_t)recw, skm_header(pos0 + u, 1u, 0u), one, sg.nbw);
+                        else sg.ctr[1] = 1;
+                    }
                 }
             }
         }
@@ -628,10 +737,10 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
             }
         }
         // combine the occurrences of the bucket
-        if (!(sg.dbg & 2u)) skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t) {
-            const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
+        if (!(sg.dbg & 2u)) skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
+            if (sg.dbg & 128u) { n_added += c.w[0] & 1; return false; }
             const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
-            if (slot >= 0) atomicAdd(&cnt[slot], 1u);
+            if (slot >= 0 && !(sg.dbg & 256u)) atomicAdd(&cnt[slot], 1u);
             return slot < 0;         // table region full (or unstorable key): this occurrence travels alone
         });
         __syncthreads();
@@ -767,8 +876,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
             else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
             else next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET;
         }
-        skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t) {
-            const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
+        skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
             const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
             if (slot >= 0) atomicAdd(&cnt[slot], 1u);
             return slot < 0;
@@ -857,8 +965,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
             any_hit = 0;
         }
         // collect the distinct k-mers
-        skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t pos) {
-            const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
+        skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
             const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
             return slot < 0;
         });
@@ -874,8 +981,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
         __syncthreads();
         if (any_hit == 0 || (sg.dbg & 8u)) continue;
         // mark every occurrence of an interesting k-mer (an occurrence whose key is absent went to the loose list)
-        skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &fw, uint64_t pos) {
-            const SkmKey<KW> c = skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k));
+        skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t pos) {
             if (!skm_cacheable<KW>(c)) return false;
             const int slot = skm_table_find(tb, c);
             if (slot >= 0 && ((flag[slot >> 5] >> (slot & 31)) & 1u)) skm_mark(p, rd, pos, sg.stride);
@@ -1066,7 +1172,21 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     }
     {
         KvProfScope prof("k_skm_split");
-        hipLaunchKernelGGL(k_skm_split, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), 0, st, g);
+        // sorted scatter while a chunk holds ~2 records per fine bucket or more (KV_SKM_S2=plain|sorted overrides)
+        const char *s2 = getenv("KV_SKM_S2");
+        const bool sorted = s2 ? strcmp(s2, "sorted") == 0 && g.F2 <= SKM_S2_MAXF : g.F2 <= SKM_S2_MAXF;
+        if (sorted) {
+            const size_t lds = (size_t)SKM_S2_CHUNK * g.recw * 8;
+            if (g.recw == 3) {
+                kv_ensure_dynamic_lds((const void *)k_skm_split_sorted<3>, lds);
+                hipLaunchKernelGGL(k_skm_split_sorted<3>, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), lds, st, g);
+            } else {
+                kv_ensure_dynamic_lds((const void *)k_skm_split_sorted<4>, lds);
+                hipLaunchKernelGGL(k_skm_split_sorted<4>, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), lds, st, g);
+            }
+        } else {
+            hipLaunchKernelGGL(k_skm_split, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), 0, st, g);
+        }
     }
     KV_HIP(hipGetLastError());
     KV_HIP(hipMemcpyAsync(&g.ctr[6], &g.ctr[0], 8, hipMemcpyDeviceToDevice, st));   // loose records S1/S2 left behind

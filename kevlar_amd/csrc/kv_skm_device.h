@@ -158,6 +158,30 @@ KV_HD uint32_t skm_base_at(const uint64_t *bw, uint32_t p)
     return (uint32_t)(w >> (2u * (p & 31u))) & 3u;
 }
 
+// 64 bits starting at base p of a record's base words (zeros beyond word 2): the window every k-mer, tail and unit of the
+// bucket walk is cut from
+KV_HD uint64_t skm_window64(uint64_t b0, uint64_t b1, uint64_t b2, uint32_t p)
+{
+    const uint32_t ws = p >> 5, sh = 2u * (p & 31u);
+    const uint64_t x0 = ws == 0 ? b0 : (ws == 1 ? b1 : (ws == 2 ? b2 : 0ull));
+    const uint64_t x1 = ws == 0 ? b1 : (ws == 1 ? b2 : 0ull);
+    return sh ? (x0 >> sh) | (x1 << (64u - sh)) : x0;
+}
+
+// the k-mer starting at base j of a record
+template <int KW>
+KV_HD SkmKey<KW> skm_kmer_of(uint64_t b0, uint64_t b1, uint64_t b2, uint32_t j, int k)
+{
+    SkmKey<KW> f;
+    if (KW == 1) {
+        f.w[0] = skm_window64(b0, b1, b2, j) & skm_topmask<1>(k);
+    } else {
+        f.w[0] = skm_window64(b0, b1, b2, j);
+        f.w[KW - 1] = skm_window64(b0, b1, b2, j + 32u) & skm_topmask<2>(k);
+    }
+    return f;
+}
+
 template <int KW>
 KV_HD SkmKey<KW> skm_canonical(const SkmKey<KW> &f, const SkmKey<KW> &r) { return skm_key_less<KW>(r, f) ? r : f; }
 

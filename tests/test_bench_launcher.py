@@ -1,0 +1,50 @@
+"""bench.py --gpus N without a launcher around it starts its own ranks: the parent spawns
+`python -m torch.distributed.run` as a child before anything touches a GPU and relays rank 0's line and the exit code."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def run_bench(*args, timeout=600):
+    env = dict(os.environ)
+    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(key, None)
+    return subprocess.run([sys.executable, BENCH] + list(args), cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=timeout, universal_newlines=True)
+
+
+def last_json(text):
+    lines = [ln for ln in text.strip().splitlines() if ln.startswith('{')]
+    assert lines, 'no JSON line in: ' + text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_self_launch_two_ranks_meet_over_gloo():
+    res = run_bench('--gpus', '2', '--backend', 'gloo', '--launch-check')
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = last_json(res.stdout)
+    assert out['launch_check'] and out['n_gpus'] == 2 and out['ranks_seen'] == [0, 1]
+
+
+def test_self_launch_relays_a_failing_rank():
+    # a backend nobody knows passes the parent's argument parser and fails in every rank: the parent must come back
+    # non-zero, not hang
+    res = run_bench('--gpus', '2', '--backend', 'no-such-backend', '--launch-check', timeout=300)
+    assert res.returncode != 0
+
+
+@pytest.mark.gpu
+def test_self_launch_runs_config_1_on_two_ranks_sharing_the_gpu():
+    res = run_bench('--gpus', '2', '--backend', 'gloo', '--workload', 'cfg1', '--steps', '1', '--warmup', '1',
+                    '--no-cpu-baseline', '--no-e2e')
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = last_json(res.stdout)
+    assert out['n_gpus'] == 2 and out['selfcheck']['ranks_seen'] == [0, 1]
+    assert out['selfcheck']['replay_matches']
+    assert set(out['phases']['max_over_ranks']) >= {'count', 'scan', 'gather'}
