@@ -223,6 +223,8 @@ struct ReadsDev {
     const uint32_t *len;
     const uint8_t *flags;
     const TileDesc *tile;
+    uint32_t uni_len, uni_per_tile;     // kv_reads::uni_len / uni_per_tile (0: look the layout up)
+    uint64_t n_reads;
 };
 
 // exclusive prefix sums over <= 128 reads by wave 0 (two entries per lane)
@@ -368,6 +370,7 @@ inline ReadsDev reads_dev(const kv_reads *r)
 {
     ReadsDev d;
     d.words = r->d_words; d.woff = r->d_woff; d.len = r->d_len; d.flags = r->d_flags; d.tile = r->d_tile;
+    d.uni_len = r->uni_len; d.uni_per_tile = r->uni_per_tile; d.n_reads = r->n_reads;
     return d;
 }
 

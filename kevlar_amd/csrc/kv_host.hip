@@ -782,6 +782,7 @@ bool uniform_reads(kv_reads *r, const TextSource *text, const uint32_t *lens, ui
     r->n_words = nw; r->n_bases = n_reads * (uint64_t)L; r->max_len = L;
     r->tile_max_bases = (uint32_t)std::min<uint64_t>(per_tile, n_reads) * L;
     r->n_tiles = (uint32_t)((n_reads + per_tile - 1) / per_tile);
+    r->uni_len = L; r->uni_per_tile = per_tile;
     r->tile_lds_bytes = KV_TILE_LDS_BYTES + 256;
     const uint64_t flag_bytes = ((n_reads + 3) & ~3ull) + 4;
     hipStream_t st = kv_stream();
@@ -906,6 +907,7 @@ extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, u
     KV_REQUIRE(need <= KV_TILE_LDS_BYTES - 64, KV_ERR_ARG, "kv_reads_create_packed: read length %u needs kv_reads_create", read_len);
     r->n_tiles = (uint32_t)((n_reads + per_tile - 1) / per_tile);
     r->tile_max_bases = (uint32_t)std::min<uint64_t>(per_tile, n_reads) * read_len;
+    r->uni_len = read_len; r->uni_per_tile = per_tile;
     r->tile_lds_bytes = KV_TILE_LDS_BYTES + 256;
     // only the packed words cross PCIe: word offsets, lengths and the tile table of equal-length reads are written on
     // the device in closed form

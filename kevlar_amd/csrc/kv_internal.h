@@ -82,6 +82,8 @@ struct kv_reads {
     uint32_t tile_lds_bytes;  // dynamic LDS the tile kernels need for this batch (>= KV_TILE_LDS_BYTES)
     uint32_t max_len;
     uint32_t tile_max_bases = 0;    // most bases any tile stages (a segment tile: KV_SEG_BASES + KV_MAX_K); 0 = not computed
+    uint32_t uni_len = 0, uni_per_tile = 0;   // all reads have this length and tile t holds reads [t * uni_per_tile, ...): the layout is
+                                              // arithmetic, and a kernel can fetch the next tile's words while it works on this one
     std::vector<uint32_t> h_len;    // host copies (k-mer counting, hit bookkeeping)
     int nk_cached_k = -1;           // kv_reads_num_kmers memo (the length vector can hold 1e7+ entries)
     uint64_t nk_cached = 0;

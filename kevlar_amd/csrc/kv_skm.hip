@@ -121,22 +121,58 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
     for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_THREADS1) cur[c] = 0;
     if (threadIdx.x == 0) sh.next_tile = (uint32_t)atomicAdd(&sg.ctr[2], 1ull) * SKM_TILES_PER_TICKET;
     uint64_t n_rec = 0;
+    // Batches of equal-length reads (rd.uni_len): the layout of a tile is arithmetic, so the packed words of the NEXT
+    // tile are requested while this one is processed (two registers per thread) and the per-tile chain of dependent loads
+    // -- tile descriptor, word offsets, lengths, words: half of this kernel's time went there -- disappears.
+    const bool uni = rd.uni_len != 0;
+    const uint32_t uni_wpr = (rd.uni_len + 15u) >> 4;
+    uint32_t pf0 = 0, pf1 = 0, pf_tile = 0xffffffffu;
+    auto prefetch = [&](uint32_t tile) {
+        pf_tile = tile;
+        if (tile >= n_tiles) return;
+        const uint64_t r0 = (uint64_t)tile * rd.uni_per_tile;
+        const uint32_t nr = (uint32_t)min((uint64_t)rd.uni_per_tile, rd.n_reads - r0), nw = nr * uni_wpr;
+        const uint32_t *src = rd.words + r0 * uni_wpr;
+        pf0 = threadIdx.x < nw ? src[threadIdx.x] : 0u;
+        pf1 = threadIdx.x + SKM_THREADS1 < nw ? src[threadIdx.x + SKM_THREADS1] : 0u;
+    };
+    if (uni) {
+        __syncthreads();
+        prefetch(sh.next_tile);
+    }
     for (uint32_t taken = 0; taken < sg.quota1; ++taken) {
         __syncthreads();                                   // previous tile finished, ticket visible
         const uint32_t tile = sh.next_tile;
         if (tile >= n_tiles) break;
-        const TileDesc td = rd.tile[tile];
+        TileDesc td;
+        if (uni) { td.first = tile * rd.uni_per_tile; td.count = (uint32_t)min((uint64_t)rd.uni_per_tile, rd.n_reads - td.first); td.seg_start = 0; td.seg = 0; }
+        else td = rd.tile[tile];
         const uint32_t r0 = td.first, nr = td.count;
         const uint32_t seg_start = td.seg ? td.seg_start : 0u;
-        const uint64_t w0 = rd.woff[r0] + (seg_start >> 4);
+        const uint64_t w0 = uni ? (uint64_t)r0 * uni_wpr : rd.woff[r0] + (seg_start >> 4);
         uint32_t nwords;
-        if (td.seg) {
+        if (uni) {
+            nwords = nr * uni_wpr;
+        } else if (td.seg) {
             const uint32_t rest = rd.len[r0] - seg_start, want = (uint32_t)KV_SEG_BASES + (uint32_t)k - 1u;
             nwords = ((rest < want ? rest : want) + 15u) >> 4;
         } else {
             nwords = (uint32_t)(rd.woff[r0 + nr] - w0);
         }
-        if (threadIdx.x < 64) {
+        if (uni) {
+            if (threadIdx.x < 64) {
+                const uint32_t i0 = 2 * threadIdx.x, i1 = i0 + 1, L = rd.uni_len;
+                const uint32_t kk = L >= (uint32_t)k ? L - (uint32_t)k + 1u : 0u, cc = (kk + CH - 1) / CH;
+                if (i0 < nr) { sh.len[i0] = L; sh.nk[i0] = kk; sh.bpre[i0] = i0 * L; sh.cpre[i0] = i0 * cc; sh.wpre[i0] = i0 * uni_wpr; }
+                if (i1 < nr) { sh.len[i1] = L; sh.nk[i1] = kk; sh.bpre[i1] = i1 * L; sh.cpre[i1] = i1 * cc; sh.wpre[i1] = i1 * uni_wpr; }
+                if (threadIdx.x == 0) {
+                    sh.bpre[nr] = nr * L; sh.cpre[nr] = nr * cc; sh.wpre[nr] = nr * uni_wpr; sh.seg_start = 0; sh.read0 = r0;
+                    const bool okk = L >= (uint32_t)k;
+                    sh.uni_wpr = okk ? uni_wpr : 0u; sh.uni_cpr = okk ? cc : 0u;
+                    sh.inv_wpr = okk ? 1.0f / (float)uni_wpr : 0.0f; sh.inv_cpr = okk ? 1.0f / (float)cc : 0.0f;
+                }
+            }
+        } else if (threadIdx.x < 64) {
             const uint32_t i0 = 2 * threadIdx.x, i1 = i0 + 1;
             uint32_t l0 = 0, l1 = 0;
             if (i0 < nr) {
@@ -171,7 +207,12 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
                 if (threadIdx.x == 0) sh.wpre[nr] = (uint32_t)(rd.woff[r0 + nr] - w0);
             }
         }
-        for (uint32_t i = threadIdx.x; i < nwords + 8u; i += SKM_THREADS1) wl[i] = i < nwords ? rd.words[w0 + i] : 0u;
+        if (uni && pf_tile == tile && nwords + 8u <= 2u * SKM_THREADS1) {
+            wl[threadIdx.x] = pf0;                                             // (zero beyond the tile's words)
+            if (threadIdx.x + SKM_THREADS1 < nwords + 8u) wl[threadIdx.x + SKM_THREADS1] = pf1;
+        } else {
+            for (uint32_t i = threadIdx.x; i < nwords + 8u; i += SKM_THREADS1) wl[i] = i < nwords ? rd.words[w0 + i] : 0u;
+        }
         __syncthreads();
         // the next ticket is fetched while this tile is processed (everybody has read the current one by now)
         if (threadIdx.x == 0) {
@@ -196,6 +237,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
         if (threadIdx.x < 96) mh[NB + threadIdx.x] = 0xffffffffu;
         for (uint32_t i = threadIdx.x; i < (NB >> 3) + 4u; i += SKM_THREADS1) idhi[i] = 0;
         __syncthreads();
+        if (uni) prefetch(sh.next_tile);                   // written before this barrier; lands during P2 .. P4
         // P2: one thread per chunk of CH k-mer starts: the minimum over the w m-mers of each (shared suffix of the
         // chunk + the w - 1 - CH values every window contains + a growing prefix), its bucket, and where runs start
         const uint32_t nchunks = (sg.dbg & 32u) ? 0u : sh.cpre[nr];             // <= 8192 / CH + 64 < 3 * SKM_THREADS1
