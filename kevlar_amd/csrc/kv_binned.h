@@ -37,6 +37,9 @@ struct BinGeom {
     uint32_t *gcnt1, *gcnt2;         // [T*C][nwgA] / [T*C*F][nwgB] items written per segment
     unsigned long long *spill;       // bin | table << 32 | (increment - 1) << 40
     unsigned long long *ctr;         // [0] spill count, [1] overflow flag, [2] k-mers added, [3] occupancy delta, [4] work ticket
+    uint64_t tsize[BIN_MAX_T];       // table sizes and base pointers by value: stage C starts without a round trip to the descriptor
+    uint8_t *ttab[BIN_MAX_T];
+    uint32_t dbg;                    // KV_BIN_DEBUG: timing experiments that skip parts of stage C (results are then wrong)
     int zero_tables;                 // the tables are all zero by decree (kv_sketch::lazy_zero): stage C writes every slice without loading it
 };
 

@@ -685,6 +685,11 @@ __device__ __forceinline__ uint32_t lds_addw4(uint32_t *lds, const uint32_t (&w)
     return fresh;
 }
 
+// A workgroup lives for a few dependent round trips to HBM and little else (PMC: 73 % of its wave cycles parked), and a
+// CU holds two of them, so the kernel's time is (round trips per workgroup) x (latency under load): the chain is kept
+// short.  Table sizes and pointers come by value; the segment counts, the overflow flag and -- unless the tables are
+// zero by decree -- the slice itself are requested together; every thread then requests ALL its item vectors at once
+// (up to MAXV; slices with more fall back to the pipelined loop for the rest) before it applies the first.
 template <int STORAGE, bool W, int SBITS>
 __global__ __launch_bounds__(SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_THREADS) void k_bin_apply(const SketchDev *__restrict__ sk, BinGeom g)
 {
@@ -692,32 +697,38 @@ __global__ __launch_bounds__(SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_
     constexpr uint32_t VEC = 16u / sizeof(Item);                  // items per 16-byte vector
     constexpr uint32_t SB = SBITS, SLICE = 1u << SB;
     constexpr uint32_t THREADS = SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_THREADS;
+    constexpr int MAXV = W ? 4 : 3;
     __shared__ __attribute__((aligned(16))) uint32_t lds[SLICE / 4];   // one slice: 65536 (32768 weighted) counters of <= 8 bits
     const int t = blockIdx.y;
     const uint32_t slice = blockIdx.x;
-    if (slice >= g.nslices[t] || g.ctr[1] != 0) return;    // overflow flag: leave the tables untouched for the fallback
+    if (slice >= g.nslices[t]) return;
     const uint32_t c = slice / (uint32_t)g.F, fidx = slice % (uint32_t)g.F;
     const uint64_t stream = ((uint64_t)t * g.C + c) * g.F + fidx;
     constexpr int storage = STORAGE;
     const uint64_t bin0 = (uint64_t)slice << SB;
-    const uint64_t left = sk->size[t] - bin0, nb = left < SLICE ? left : SLICE;
+    const uint64_t left = g.tsize[t] - bin0, nb = left < SLICE ? left : SLICE;
     // byte range of the slice inside the table (the allocation is padded to 16 B)
     const uint64_t byte0 = storage == ST_BYTE ? bin0 : (storage == ST_NIBBLE ? bin0 >> 1 : bin0 >> 3);
     const uint64_t nbytes = storage == ST_BYTE ? nb : (storage == ST_NIBBLE ? (nb + 1) / 2 : (nb + 7) / 8);
     const uint32_t nvec = (uint32_t)((nbytes + 15) / 16);
-    uint4 *tab = (uint4 *)(sk->tab[t] + byte0);
+    uint4 *tab = (uint4 *)(g.ttab[t] + byte0);
     uint4 *l4 = (uint4 *)lds;
     // the slice's items sit in nwgB private segments of cap2 slots (cap2 % 64 == 0: 128-B aligned, so a
     // 16-byte vector never leaves its segment).  Their vectors are enumerated compactly through a
     // prefix sum over the segments (LDS), so every thread has work whatever the segment fill levels.
     __shared__ uint32_t seg_cnt[BIN_MAX_SEG], vpre[BIN_MAX_SEG];
     __shared__ uint32_t wsum[THREADS / 64];
-    __shared__ uint32_t total_vec_sh;
+    __shared__ uint32_t total_vec_sh, flag_sh, fresh_sh;
     const Item *items = (const Item *)g.gbuf2 + stream * g.nwgB * g.cap2;
     const uint32_t *counts = g.gcnt2 + stream * g.nwgB;
     {
         uint32_t myc = 0;
-        if (threadIdx.x < g.nwgB) { myc = counts[threadIdx.x]; seg_cnt[threadIdx.x] = myc; }
+        if (threadIdx.x < g.nwgB) myc = (g.dbg & 16u) ? 4u : counts[threadIdx.x];
+        unsigned long long flag = 0;
+        if (threadIdx.x == THREADS - 1 && !(g.dbg & 8u)) flag = g.ctr[1];          // overflow flag: leave the tables untouched for the fallback
+        if (!g.zero_tables)
+            for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) l4[j] = tab[j];
+        if (threadIdx.x < g.nwgB) seg_cnt[threadIdx.x] = myc;
         const uint32_t myv = (myc + VEC - 1) / VEC;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         uint32_t incl = myv;
@@ -727,6 +738,7 @@ __global__ __launch_bounds__(SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_
             if (lane >= d) incl += up;
         }
         if (lane == 63) wsum[wave] = incl;
+        if (threadIdx.x == THREADS - 1) { flag_sh = flag != 0 ? 1u : 0u; fresh_sh = 0; }
         __syncthreads();
         uint32_t before = 0;
         for (int w = 0; w < wave; ++w) before += wsum[w];
@@ -734,6 +746,7 @@ __global__ __launch_bounds__(SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_
         if (threadIdx.x == THREADS - 1) total_vec_sh = before + incl;
         __syncthreads();
     }
+    if (flag_sh) return;
     const uint32_t total_vec = total_vec_sh;
     if (total_vec == 0) {                                          // untouched slice: no table traffic at all ...
         if (g.zero_tables)                                         // ... unless this pass is also the table's zeroing
@@ -746,6 +759,7 @@ __global__ __launch_bounds__(SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_
         Vec r;
         r.q = make_uint4(0, 0, 0, 0); r.n = 0;
         if (v >= total_vec) return r;
+        if (g.dbg & 32u) { r.n = VEC; r.q = *(const uint4 *)(items + (uint64_t)v * VEC); return r; }     // same bytes, one contiguous run
         uint32_t lo = 0, hi = g.nwgB;      // largest segment with vpre[seg] <= v (empty segments share their successor's prefix)
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -756,27 +770,42 @@ __global__ __launch_bounds__(SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_
         r.q = *(const uint4 *)(items + (uint64_t)lo * g.cap2 + j0);
         return r;
     };
-    // software pipeline, two vectors ahead: item requests fly while the slice loads and while earlier items are applied
-    Vec v0 = fetch(threadIdx.x), v1 = fetch(threadIdx.x + THREADS);
-    if (g.zero_tables) {
+    Vec first[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) first[i] = (g.dbg & 2u) ? Vec{make_uint4(0, 0, 0, 0), 0u} : fetch(threadIdx.x + (uint32_t)i * THREADS);
+    if (g.zero_tables)
         for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) l4[j] = make_uint4(0, 0, 0, 0);
-    } else {
-        for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) l4[j] = tab[j];
-    }
     __syncthreads();
     uint32_t fresh = 0;
-    for (uint32_t v = threadIdx.x; v < total_vec; v += THREADS) {
-        const Vec v2 = fetch(v + 2 * THREADS);
-        const uint32_t w[4] = {v0.q.x, v0.q.y, v0.q.z, v0.q.w};
-        fresh += W ? lds_addw4<STORAGE>(lds, w, v0.n) : lds_inc8<STORAGE>(lds, w, v0.n);
-        v0 = v1; v1 = v2;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const uint32_t w[4] = {first[i].q.x, first[i].q.y, first[i].q.z, first[i].q.w};
+        if (g.dbg & 1u) { fresh += w[0] ^ w[1] ^ w[2] ^ w[3]; continue; }
+        // (an absent vector would still issue its compare-and-swaps, all on word 0: same-address LDS atomics serialise)
+        if (first[i].n) fresh += W ? lds_addw4<STORAGE>(lds, w, first[i].n) : lds_inc8<STORAGE>(lds, w, first[i].n);
+    }
+    if (total_vec > (uint32_t)MAXV * THREADS && !(g.dbg & 3u)) {
+        // a fuller slice: the rest through a software pipeline, two vectors ahead
+        const uint32_t v_start = (uint32_t)MAXV * THREADS + threadIdx.x;
+        Vec v0 = fetch(v_start), v1 = fetch(v_start + THREADS);
+        for (uint32_t v = v_start; v < total_vec; v += THREADS) {
+            const Vec v2 = fetch(v + 2 * THREADS);
+            const uint32_t w[4] = {v0.q.x, v0.q.y, v0.q.z, v0.q.w};
+            fresh += W ? lds_addw4<STORAGE>(lds, w, v0.n) : lds_inc8<STORAGE>(lds, w, v0.n);
+            v0 = v1; v1 = v2;
+        }
+    }
+    // table 0's newly occupied bins: ONE update of the device-wide counter per workgroup.  (It is one address for the whole
+    // chip and takes ~90 updates per microsecond however they are issued: an update per wave -- 16 x 7630 of them for a
+    // 2 GB sketch -- held this kernel at 1.4 ms whatever else it did.)
+    if (t == 0) {
+        const uint32_t tot = (uint32_t)wave_sum_u64(fresh);
+        if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&fresh_sh, tot);
     }
     __syncthreads();
-    for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) tab[j] = l4[j];
-    if (t == 0) {
-        const uint64_t tot = wave_sum_u64(fresh);
-        if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&g.ctr[3], (unsigned long long)tot);
-    }
+    if (!(g.dbg & 4u))
+        for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) tab[j] = l4[j];
+    if (t == 0 && threadIdx.x == 0 && fresh_sh) atomicAdd(&g.ctr[3], (unsigned long long)fresh_sh);
 }
 
 // saturating add of `weight` to one bin with global atomics; true if the bin was zero before
@@ -881,7 +910,9 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
     plan->weighted = weighted;
     g.zero_tables = s->lazy_zero ? 1 : 0;
     g.T = s->h.ntables;
+    for (int t = 0; t < g.T && t < BIN_MAX_T; ++t) { g.tsize[t] = s->h.size[t]; g.ttab[t] = s->h.tab[t]; }
     g.tile_lds = lds_front;
+    g.dbg = getenv("KV_BIN_DEBUG") ? (uint32_t)atoi(getenv("KV_BIN_DEBUG")) : 0u;
     uint64_t pmin = UINT64_MAX, pmax = 0;
     for (int t = 0; t < g.T; ++t) { pmin = std::min(pmin, s->h.size[t]); pmax = std::max(pmax, s->h.size[t]); }
     // 32768-bin slices for weighted items (KV_BIN_SLICE15=1) were measured at config 2: stage C 2.20 instead of 2.25 ms,

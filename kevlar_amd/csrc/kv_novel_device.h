@@ -81,9 +81,12 @@ __device__ __forceinline__ uint32_t probe(const NovelShared &ns, int c, int t, u
     const ProbeDesc &d = ns.d[c * KV_MAX_TABLES + t];
     const uint64_t bin = fastmod(h, d.size, d.magic);
     const int st = ns.storage[c];
-    if (st == ST_BYTE) return d.tab[bin];
-    if (st == ST_NIBBLE) return (d.tab[bin >> 1] >> ((bin & 1) ? 0 : 4)) & 15u;
-    return (d.tab[bin >> 3] >> (bin & 7)) & 1u;
+    // the pointer comes out of LDS as a generic one: say that it is global, or every probe is a FLAT load that also
+    // waits for the LDS counter
+    const __attribute__((address_space(1))) uint8_t *tab = (const __attribute__((address_space(1))) uint8_t *)d.tab;
+    if (st == ST_BYTE) return tab[bin];
+    if (st == ST_NIBBLE) return (tab[bin >> 1] >> ((bin & 1) ? 0 : 4)) & 15u;
+    return (tab[bin >> 3] >> (bin & 7)) & 1u;
 }
 
 // The abundance test (screen off).  Same predicate as kmer_is_interesting(), cheapest evidence first:

@@ -17,7 +17,6 @@
 //
 // Nothing here can lose a k-mer: a full segment, a full LDS table or an uncacheable key diverts single records to a
 // "loose" list that is processed one occurrence at a time (k_skm_loose_*); if that list overflows too, a flag makes
-// the apply stage leave the tables untouched and the caller falls back to the one-k-mer-at-a-time kernels.
 #include <algorithm>
 #include <cmath>
 
@@ -591,7 +590,7 @@ template <int TS, typename Body>
 __device__ __forceinline__ void skm_for_occupied(const unsigned long long *key0, uint16_t *queue_all, uint32_t queue_stride, Body body)
 {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    volatile uint16_t *queue = queue_all + wave * queue_stride;      // >= 128 entries
+    uint16_t *queue = queue_all + wave * queue_stride;               // >= 128 entries; wave-private, ordered by the fences below
     const uint32_t per_wave = TS / nwaves;
     const uint32_t s_end = (wave + 1) * per_wave;
     uint32_t qn = 0;                                    // < 64 between iterations
@@ -601,7 +600,7 @@ __device__ __forceinline__ void skm_for_occupied(const unsigned long long *key0,
             const uint32_t slot = s0 + lane;
             const bool occ = key0[slot] != SKM_EMPTY;
             const unsigned long long ballot = __ballot(occ);
-            if (occ) queue[qn + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull))] = (uint16_t)slot;
+            if (occ) __hip_atomic_store(&queue[qn + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull))], (uint16_t)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             qn += (uint32_t)__popcll(ballot);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -609,7 +608,8 @@ __device__ __forceinline__ void skm_for_occupied(const unsigned long long *key0,
         if (qn >= 64 || (last && qn > 0)) {
             const uint32_t take = min(qn, 64u);
             qn -= take;
-            if (lane < take) body((uint32_t)queue[qn + lane]);
+            if (lane < take) body((uint32_t)__hip_atomic_load(&queue[qn + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
         if (last) break;
@@ -649,22 +649,24 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     uint32_t *sbits = sbits_all + wave * sg.sbw;       // sbw words: 64 records x ncap k-mers (units need fewer), + the word a 64-bit read may straddle into
     const int k = sg.k, recw = sg.recw;
-    uint32_t NR = 0;
-    for (uint32_t s = 0; s < sg.nwg2; ++s) NR += sg.cnt2[(uint64_t)b * sg.nwg2 + s];
-    for (uint32_t g0 = wave * 64u; g0 < NR; g0 += nwaves * 64u) {
-        const uint32_t i = g0 + lane;
-        uint64_t hdr = 0, b0 = 0, b1 = 0, b2 = 0;
-        if (i < NR) {
-            uint32_t s = 0, off = i;                    // segment of record i (at most 16 of them)
-            for (;;) {
-                const uint32_t n = sg.cnt2[(uint64_t)b * sg.nwg2 + s];
-                if (off < n) break;
-                off -= n; ++s;
-            }
-            const uint64_t *rec = sg.seg2 + (((uint64_t)b * sg.nwg2 + s) * sg.cap2 + off) * (uint64_t)recw;
-            hdr = rec[0]; b0 = rec[1]; b1 = rec[2];
-            if (KW == 2) b2 = rec[3];
-        }
+    // Which records a wave takes does not depend on how full the bucket's segments are: pair p = wave, wave + nwaves, ...
+    // is records [64 g, 64 g + 64) of segment s = p mod nwg2, g = p / nwg2.  The records are therefore requested together
+    // with the segment counts (which only mask them afterwards) instead of behind them, and the same addresses of the
+    const uint32_t *cnt2 = sg.cnt2 + (uint64_t)b * sg.nwg2;
+    uint32_t p = wave;
+    uint32_t g = p / sg.nwg2, sgm = p - g * sg.nwg2;
+    uint64_t hdr = 0, b0 = 0, b1 = 0, b2 = 0;
+    {
+        const uint32_t at = min(g * 64u + lane, sg.cap2 - 1u);
+        const uint64_t *rec = sg.seg2 + (((uint64_t)b * sg.nwg2 + sgm) * sg.cap2 + at) * (uint64_t)recw;
+        hdr = rec[0]; b0 = rec[1]; b1 = rec[2];
+        if (KW == 2) b2 = rec[3];
+    }
+    uint32_t maxc = 0;
+    for (uint32_t s2 = 0; s2 < sg.nwg2; ++s2) maxc = max(maxc, cnt2[s2]);
+    for (;;) {
+        if (g * 64u >= maxc) break;
+        const uint32_t NR = cnt2[sgm], i = g * 64u + lane;      // (the name the code below knows the bound by)
         const uint32_t nk = i < NR ? skm_hdr_n(hdr) : 0u;
         const uint32_t nu = (nk + G - 1u) / G;          // units of this record
         uint32_t incl = nu;
@@ -684,7 +686,10 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
         __builtin_amdgcn_wave_barrier();
         uint32_t before = 0;                            // records that start in front of this block
         for (uint32_t t0 = 0; t0 < total; t0 += 64) {
-            const uint64_t starts = (uint64_t)((volatile uint32_t *)sbits)[t0 >> 5] | ((uint64_t)((volatile uint32_t *)sbits)[(t0 >> 5) + 1] << 32);
+            // (relaxed wave-scope loads: a volatile access through the generic pointer became a system-scope FLAT load
+            // with its own s_waitcnt vmcnt(0), two in a row per block)
+            const uint64_t starts = (uint64_t)__hip_atomic_load(&sbits[t0 >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) |
+                                    ((uint64_t)__hip_atomic_load(&sbits[(t0 >> 5) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) << 32);
             const uint32_t t = t0 + lane;
             const uint32_t owner = (before + (uint32_t)__popcll(starts & ((2ull << lane) - 1ull)) - 1u) & 63u;
             before += (uint32_t)__popcll(starts);
@@ -719,6 +724,14 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
             }
         }
         __builtin_amdgcn_wave_barrier();                // the next group clears the mask
+        p += nwaves;
+        g = p / sg.nwg2; sgm = p - g * sg.nwg2;
+        if (g * 64u >= maxc) break;
+        if (g * 64u + lane < cnt2[sgm]) {
+            const uint64_t *rec = sg.seg2 + (((uint64_t)b * sg.nwg2 + sgm) * sg.cap2 + g * 64u + lane) * (uint64_t)recw;
+            hdr = rec[0]; b0 = rec[1]; b1 = rec[2];
+            if (KW == 2) b2 = rec[3];
+        }
     }
 }
 
