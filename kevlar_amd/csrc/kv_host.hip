@@ -362,6 +362,7 @@ extern "C" int kv_sketch_destroy(kv_sketch *s)
         if (s->h.tab[i]) (void)hipFree(s->h.tab[i]);
     if (s->d_desc) (void)hipFree(s->d_desc);
     if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->abl.mem) (void)hipFree(s->abl.mem);
     delete s;
     return KV_OK;
 }
@@ -407,6 +408,7 @@ extern "C" int kv_sketch_table_write(kv_sketch *s, int table, const uint8_t *hos
     KV_REQUIRE(nbytes == nb, KV_ERR_ARG, "table %d holds %llu bytes", table, (unsigned long long)nb);
     std::lock_guard<std::mutex> lk(s->mu);
     s->version++;
+    s->abl.valid = false;
     { const int rc = kv_sketch_ready_locked(s); if (rc != KV_OK) return rc; }
     KV_HIP(hipMemcpyAsync(s->h.tab[table], host_in, nb, hipMemcpyHostToDevice, kv_stream()));
     KV_HIP(hipStreamSynchronize(kv_stream()));
@@ -431,6 +433,7 @@ extern "C" int kv_sketch_clear(kv_sketch *s)
     s->n_unique = 0;
     s->occ_dirty = false;
     s->skm_off = false;
+    s->abl.valid = false;
     return KV_OK;
 }
 

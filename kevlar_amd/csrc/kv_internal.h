@@ -38,6 +38,24 @@ struct SketchDev {
     int32_t ntables, storage, hashfam, ksize;
 };
 
+// Certificates of abundance (kv_skm.hip): the distinct k-mers ONE super-k-mer count added to a sketch at least twice, with
+// how often (capped at 255), listed bucket by bucket in the bucket geometry of that count.  Counters never decrease, so
+// an entry stays a valid lower bound of get(k-mer) until the sketch is cleared or overwritten; the novel scan uses the
+// controls' lists to reject inherited k-mers without probing the controls' tables (Count-Min never under-counts, so
+// "added c > ctrl_max times" already decides kmer_is_interesting(), kevlar/novel.py:43-50).
+struct KvAbundList {
+    void *mem = nullptr;
+    size_t bytes = 0;
+    uint64_t *keys = nullptr;      // [cap_total][kw]
+    uint8_t *cnts = nullptr;       // [cap_total]
+    uint32_t *bstart = nullptr;    // [n_buckets] first entry of the bucket
+    uint32_t *bcount = nullptr;    // [n_buckets] entries (0: none, or the writer ran out of room: the scan then just probes)
+    int k = 0, m = 0, kw = 0;
+    uint32_t C1 = 0, F2 = 0, fbits = 0, n_buckets = 0, nwg = 0;
+    uint64_t cap_total = 0, cap_wg = 0;
+    bool valid = false;
+};
+
 struct kv_sketch {
     int kind;
     SketchDev h;          // host copy
@@ -55,6 +73,7 @@ struct kv_sketch {
     // slice anyway, then starts from zeroed LDS instead of loading the slice (no memset, no first read of the tables);
     // every other reader or writer of the tables calls kv_sketch_ready first, which does the memset after all
     bool lazy_zero = false;
+    KvAbundList abl;       // see above; valid = false whenever the tables may hold less than it says
     std::mutex mu;
 };
 

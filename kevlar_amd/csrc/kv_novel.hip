@@ -442,6 +442,7 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     p.band_mode = band_mode; p.nbands = nbands; p.band = band;
     if (band_mode == KV_BAND_RANGE) kv_band_bounds(nbands, band, &p.band_lo, &p.band_hi);
     p.first_read = first_read;
+    p.host_ctrls = (const void *)ctrls; p.host_nctrl = nctrl;
     hipStream_t st = kv_stream();
     uint64_t n_kmers = 0;
     kv_reads_num_kmers(reads, k, &n_kmers);

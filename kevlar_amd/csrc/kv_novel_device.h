@@ -29,6 +29,8 @@ struct NovelParams {
     const unsigned long long *set_keys;   // NULL = off; empty slots hold ~0 (no k-mer of any band hashes to it)
     const uint8_t *set_abund;             // [slots][S]
     uint64_t set_mask;                    // slots - 1
+    const void *host_ctrls;               // host side only: the control sketches (kv_sketch *const *) behind sk[ncase..], for their
+    int host_nctrl;                       // abundance lists (kv_skm_novel_mark)
 };
 #define KV_SET_NONE 0xffffffffffffffffull
 

@@ -41,6 +41,19 @@ struct SkmGeom {
     uint32_t sbw;                    // words of record-start bits per wave in the bucket walk
     uint64_t bucket_kmers;           // average k-mers per fine bucket
     uint32_t dbg;                    // KV_SKM_DEBUG: timing experiments that skip parts of kernels (results are then wrong)
+    // abundance list the count pass writes (KvAbundList; abl_keys == nullptr: off): every workgroup appends to its own
+    // stretch of abl_cap_wg entries and notes where each bucket's entries start
+    uint64_t *abl_keys; uint8_t *abl_cnts; uint32_t *abl_bstart, *abl_bcount; uint32_t abl_cap_wg;
+};
+
+// the controls' abundance lists a scan may use (same bucket geometry as the case sample's buckets)
+#define SKM_MAX_ABL 8
+struct SkmAblSet {
+    int n, ctrl_max;
+    const uint64_t *keys[SKM_MAX_ABL];
+    const uint8_t *cnts[SKM_MAX_ABL];
+    const uint32_t *bstart[SKM_MAX_ABL], *bcount[SKM_MAX_ABL];
+    uint32_t maxv[SKM_MAX_ABL];      // what a counter of that control can hold: an entry rejects if min(count, maxv) > ctrl_max
 };
 
 namespace {
@@ -747,6 +760,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
     __shared__ SkmTable<KW, TS> tb;
     __shared__ uint32_t cnt[TS];                 // occurrences of the key in the same slot
     __shared__ uint32_t next_bucket;
+    __shared__ uint32_t abl_cur, abl_b0, abl_prev;      // abundance list: entries appended so far, ... when the bucket began, the bucket
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
     const uint32_t ns = (uint32_t)(g.T * g.C);
     uint32_t *lut = dyn, *cur = dyn + 256, *scratch = cur + ((ns + 3u) & ~3u);
@@ -770,13 +784,23 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
     // while the current bucket is processed
     skm_table_clear(tb);
     for (uint32_t i = threadIdx.x; i < TS; i += SKM_THREADS3) cnt[i] = 0;
-    if (threadIdx.x == 0) next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET;
+    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET; abl_cur = 0; abl_b0 = 0; abl_prev = 0xffffffffu; }
+    // where the finished bucket's entries of the abundance list lie (nothing if the workgroup's stretch ran out)
+    auto abl_close = [&]() {
+        if (sg.abl_keys && abl_prev != 0xffffffffu) {
+            const bool fits = abl_cur <= sg.abl_cap_wg;
+            sg.abl_bstart[abl_prev] = blockIdx.x * sg.abl_cap_wg + abl_b0;
+            sg.abl_bcount[abl_prev] = fits ? abl_cur - abl_b0 : 0u;
+        }
+    };
     for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
         __syncthreads();
         const uint32_t b = next_bucket;
         if (b >= sg.n_buckets) break;
         __syncthreads();
         if (threadIdx.x == 0) {
+            abl_close();
+            abl_prev = b; abl_b0 = abl_cur;
             if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
             else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
             else {
@@ -811,10 +835,30 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
             if (sg.dbg & 1u) return;
             const uint64_t h = skm_key_hash<KW>(c, lut, f.hp);
             if (sg.dbg & 64u) { n_added += h & 1; return; }
-            n_added += skm_count_kmer(h, seen, sk, mask, f, g.T, emit);
+            const uint32_t added = skm_count_kmer(h, seen, sk, mask, f, g.T, emit);
+            n_added += added;
+            // abundance list: a k-mer this batch adds at least twice (the lanes of the wave that are in here vote)
+            if (sg.abl_keys) {
+                const bool want = added >= 2u;
+                const unsigned long long here = __ballot(true), vote = __ballot(want);
+                if (vote) {
+                    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)here) - 1u;
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(&abl_cur, (uint32_t)__popcll(vote));
+                    base = (uint32_t)__shfl((int)base, (int)leader);
+                    const uint32_t at = base + (uint32_t)__popcll(vote & ((1ull << lane) - 1ull));
+                    if (want && at < sg.abl_cap_wg) {
+                        const uint64_t e = (uint64_t)blockIdx.x * sg.abl_cap_wg + at;
+                        sg.abl_keys[e * KW] = c.w[0];
+                        if (KW == 2) sg.abl_keys[e * KW + (KW - 1)] = c.w[KW - 1];
+                        sg.abl_cnts[e] = (uint8_t)min(added, 255u);
+                    }
+                }
+            }
         });
     }
     __syncthreads();
+    if (threadIdx.x == 0) abl_close();
     for (uint32_t s = threadIdx.x; s < ns; s += SKM_THREADS3)
         g.gcnt1[(uint64_t)s * g.nwgA + blockIdx.x] = (uint32_t)min((uint64_t)cur[s], g.cap1);
     n_added = wave_sum_u64(n_added);
@@ -994,10 +1038,11 @@ __device__ __forceinline__ void skm_mark(const NovelParams &p, const ReadsDev &r
 }
 
 template <int KW, int TS>
-__global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, ReadsDev rd, NovelParams p)
+__global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, ReadsDev rd, NovelParams p, SkmAblSet abls)
 {
     __shared__ SkmTable<KW, TS> tb;
     __shared__ uint32_t flag[TS / 32];           // bit per slot: the key is interesting
+    __shared__ uint32_t rej[TS / 32];            // bit per slot: a control's abundance list rejects the key (no probe needed)
     __shared__ NovelShared ns;
     __shared__ uint32_t next_bucket, any_hit;
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
@@ -1011,7 +1056,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
         const uint32_t b = next_bucket;
         if (b >= sg.n_buckets) break;
         skm_table_clear(tb);
-        if (threadIdx.x < TS / 32) flag[threadIdx.x] = 0;
+        if (threadIdx.x < TS / 32) { flag[threadIdx.x] = 0; rej[threadIdx.x] = 0; }
         __syncthreads();
         if (threadIdx.x == 0) {
             if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
@@ -1024,9 +1069,24 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
             const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
             return slot < 0;
         });
+        // the k-mers of this bucket that a control is known to hold more than ctrl_max times (KvAbundList): they go into the
+        // same table, marked; whichever of them the case sample has too is then skipped by the evaluation.  A full table
+        // only costs the shortcut for that key.
+        for (int a = 0; a < abls.n; ++a) {
+            const uint32_t e0 = abls.bstart[a][b], en = abls.bcount[a][b];
+            for (uint32_t i = threadIdx.x; i < en; i += SKM_THREADS3) {
+                if ((int)min((uint32_t)abls.cnts[a][e0 + i], abls.maxv[a]) <= abls.ctrl_max) continue;
+                SkmKey<KW> c;
+                c.w[0] = abls.keys[a][(uint64_t)(e0 + i) * KW];
+                if (KW == 2) c.w[KW - 1] = abls.keys[a][(uint64_t)(e0 + i) * KW + (KW - 1)];
+                const int slot = skm_table_insert(tb, c);
+                if (slot >= 0) atomicOr(&rej[slot >> 5], 1u << (slot & 31));
+            }
+        }
         __syncthreads();
         // evaluate each of them once
         if (!(sg.dbg & 4u)) skm_for_occupied<TS>(tb.key[0], (uint16_t *)scratch, skm_wave_scratch_words(sg.sbw) * 2u, [&](uint32_t slot) {
+            if ((rej[slot >> 5] >> (slot & 31)) & 1u) return;
             SkmKey<KW> c;
             c.w[0] = tb.key[0][slot];
             if (KW == 2) c.w[KW - 1] = tb.key[KW - 1][slot];
@@ -1116,6 +1176,8 @@ struct SkmIndex {
 };
 std::map<hipStream_t, SkmIndex> g_skm;
 std::mutex g_skm_mu;
+int g_skm_pref_k = 0;                    // bucket count of the last build that chose its own (guarded by g_skm_mu), see skm_build
+uint64_t g_skm_pref_nfine = 0;
 double g_skm_last_distinct = 0.0;        // distinct share of the batch counted last on any stream (guarded by g_skm_mu): a scan
                                           // that has to bucket its batch itself sizes the buckets by it
 
@@ -1161,7 +1223,15 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     uint64_t target = (uint64_t)((g.kw == 1 ? 0.4 : 0.35) * table_slots / frac);
     target = std::max<uint64_t>(table_slots / 2, std::min<uint64_t>(target, g.kw == 1 ? 2ull * table_slots : table_slots + table_slots / 2));
     if (tgt_env) target = std::max<uint64_t>(64, strtoull(tgt_env, nullptr, 10));
-    const uint64_t nfine = std::max<uint64_t>(1, (n_kmers + target - 1) / target);
+    uint64_t nfine = std::max<uint64_t>(1, (n_kmers + target - 1) / target);
+    {
+        // samples of one family are about the same size but not exactly: a batch whose own bucket count lies within a
+        // quarter of the previous build's takes that one, so that the buckets of the controls and of the case sample
+        // are the same buckets (the scan can then use the controls' abundance lists, KvAbundList)
+        std::lock_guard<std::mutex> glk(g_skm_mu);
+        if (g_skm_pref_k == k && g_skm_pref_nfine && nfine * 4 >= g_skm_pref_nfine * 3 && nfine * 4 <= g_skm_pref_nfine * 5) nfine = g_skm_pref_nfine;
+        else { g_skm_pref_k = k; g_skm_pref_nfine = nfine; }
+    }
     // at most 255 x 4096 buckets (a bucket id travels as 20 bits through S1): 8.5 G k-mers at 8192 per bucket; bigger
     // batches get bigger buckets, which only costs deduplication efficiency
     g.F2 = std::min<uint32_t>(512u, pow2_ceil((uint64_t)std::ceil(std::sqrt((double)nfine))));
@@ -1301,6 +1371,37 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     const uint64_t n_items = std::max<uint64_t>(n_kmers * 3 / 5, std::min<uint64_t>(n_kmers, 1u << 22));
     { const int rc = kv_bin_plan(s, n_items, nbands, filter.use_mask != 0, sg.n_buckets, 0u, nwg3, true, &plan); if (rc != KV_OK) return rc; }
     const SketchDev *d_mask = mask ? mask->d_desc : nullptr;
+    // abundance list of this batch (KvAbundList): the first super-k-mer count after a clear writes one, unless KV_SKM_ABL=0
+    bool abl_new = false;
+    {
+        const char *e = getenv("KV_SKM_ABL");
+        KvAbundList &al = s->abl;
+        if (!(e && atoi(e) == 0) && !al.valid) {
+            const uint64_t cap_total = std::min<uint64_t>(std::max<uint64_t>(n_kmers / 8, 1u << 16), 0xfffffff0ull);
+            const uint64_t cap_wg = std::max<uint64_t>(64, cap_total / nwg3);
+            const size_t b_keys = kv_round_up(cap_wg * nwg3 * 8 * sg.kw, 256), b_cnts = kv_round_up(cap_wg * nwg3, 256);
+            const size_t b_idx = kv_round_up((uint64_t)sg.n_buckets * 4, 256);
+            const size_t need = b_keys + b_cnts + 2 * b_idx;
+            if (al.bytes < need) {
+                if (al.mem) (void)hipFree(al.mem);
+                al.mem = nullptr; al.bytes = 0;
+                if (hipMalloc(&al.mem, need) == hipSuccess) al.bytes = need;
+                else (void)hipGetLastError();              // no room: no list, nothing else changes
+            }
+            if (al.mem) {
+                unsigned char *base = (unsigned char *)al.mem;
+                al.keys = (uint64_t *)base; base += b_keys;
+                al.cnts = (uint8_t *)base; base += b_cnts;
+                al.bstart = (uint32_t *)base; base += b_idx;
+                al.bcount = (uint32_t *)base;
+                KV_HIP(hipMemsetAsync(al.bstart, 0, 2 * b_idx, st));
+                al.k = k; al.m = sg.m; al.kw = sg.kw; al.C1 = sg.C1; al.F2 = sg.F2; al.fbits = sg.fbits; al.n_buckets = sg.n_buckets;
+                al.nwg = nwg3; al.cap_wg = cap_wg; al.cap_total = cap_wg * nwg3;
+                sg.abl_keys = al.keys; sg.abl_cnts = al.cnts; sg.abl_bstart = al.bstart; sg.abl_bcount = al.bcount; sg.abl_cap_wg = (uint32_t)cap_wg;
+                abl_new = true;
+            }
+        }
+    }
     {
         KvProfScope prof("k_skm_count");
         const uint32_t ns = (uint32_t)(plan.g.T * plan.g.C);
@@ -1317,7 +1418,9 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     // a lost record (loose list overflow) must stop the apply stage, which looks at the partition's own flag
     hipLaunchKernelGGL(k_skm_forward_flag, dim3(1), dim3(1), 0, st, sg.ctr, plan.g.ctr);
     KV_HIP(hipGetLastError());
+    sg.abl_keys = nullptr; sg.abl_cnts = nullptr; sg.abl_bstart = nullptr; sg.abl_bcount = nullptr;
     const int rc = kv_bin_finish(s, plan, true, 0, n_added);     // synchronises the stream
+    if (abl_new) s->abl.valid = rc == KV_OK;
     {
         // what the batch looked like: if most k-mers are distinct (low coverage per batch) cutting and bucketing the
         // reads buys nothing, and if many occurrences missed the LDS tables the buckets were too full; either way
@@ -1378,11 +1481,25 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
     }
     const uint32_t nwg3 = skm_nwg3(sg);
     const ReadsDev rd = reads_dev(reads);
+    SkmAblSet abls;
+    memset(&abls, 0, sizeof(abls));
+    abls.ctrl_max = p.ctrl_max;
+    if (p.host_ctrls && !p.set_keys && !(getenv("KV_SKM_ABL") && atoi(getenv("KV_SKM_ABL")) == 0)) {
+        const kv_sketch *const *ctrls = (const kv_sketch *const *)p.host_ctrls;
+        for (int c = 0; c < p.host_nctrl && abls.n < SKM_MAX_ABL; ++c) {
+            const KvAbundList &al = ctrls[c]->abl;
+            if (!al.valid || al.k != k || al.m != sg.m || al.C1 != sg.C1 || al.F2 != sg.F2 || al.n_buckets != sg.n_buckets) continue;
+            const int a = abls.n++;
+            abls.keys[a] = al.keys; abls.cnts[a] = al.cnts; abls.bstart[a] = al.bstart; abls.bcount[a] = al.bcount;
+            abls.maxv[a] = ctrls[c]->h.storage == ST_BYTE ? 255u : (ctrls[c]->h.storage == ST_NIBBLE ? 15u : 1u);
+        }
+    }
+    if (getenv("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] scan: %d of %d controls bring an abundance list in this bucket geometry\n", abls.n, p.host_nctrl);
     {
         KvProfScope prof("k_skm_novel");
         const size_t lds = (256 + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw)) * 4;
-        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_novel<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p);
-        else hipLaunchKernelGGL((k_skm_novel<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p);
+        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_novel<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
+        else hipLaunchKernelGGL((k_skm_novel<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
     }
     {
         KvProfScope prof("k_skm_loose_novel");
