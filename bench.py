@@ -85,6 +85,9 @@ def parse_args():
     p.add_argument('--multi', default='auto', choices=['auto', 'exchange', 'banded'],
                    help='N>1: exchange = shard the reads, hash once, all-to-all the hashes by band (kevlar_amd/shardrun.py); '
                         'banded = every rank streams all reads and keeps its band; auto = exchange from 4 GPUs up')
+    p.add_argument('--merge', default='hits', choices=['hits', 'mask'],
+                   help='banded multi-GPU merge: hits = all-gather of the per-band hits (default); mask = north_star\'s all-reduce of the '
+                        'per-band interesting-k-mer bit masks as well, inside the timed step, asserted equal to the gathered hits')
     p.add_argument('--count-streams', type=int, default=3,
                    help='N=1: count the samples concurrently on this many HIP streams, one host thread each (the samples are '
                         'independent; kernels bound by different units overlap and no stream waits for another\'s host round '
@@ -222,11 +225,22 @@ def main():
     sketches = make_sketches(mem_per_gpu)
     wall = {'count': 0.0, 'novel': 0.0, 'merge': 0.0}
 
+    # --merge mask: one bit per (read, k-mer offset) of the proband, set by this rank's scan for the k-mers of its band
+    band_mask = None
+    if args.merge == 'mask' and world > 1 and not exchange:
+        assert len(batch_first) == 1, '--merge mask takes whole samples (one batch)'
+        band_mask = torch.zeros((n_reads * nk + 31) // 32, dtype=torch.int32, device=torch.device('cuda', dev_index))
+
     def scan_batches(sk, band_mode, nbands, band):
         rs, os_, as_ = [], [], []
         for first, batch in zip(batch_first, batches['proband']):
+            extra = {}
+            if band_mask is not None and sk is sketches:
+                band_mask.zero_()
+                torch.cuda.synchronize()
+                extra = dict(mask_ptr=band_mask.data_ptr(), mask_stride=nk)
             r, o, a, _ = hk.novel_scan([sk['proband']], [sk[n] for n in controls], batch, args.case_min, args.ctrl_max,
-                                       band_mode=band_mode, nbands=nbands, band=band)
+                                       band_mode=band_mode, nbands=nbands, band=band, **extra)
             rs.append(np.asarray(r, dtype=np.uint32) + np.uint32(first)); os_.append(o); as_.append(a)
         if len(rs) == 1:
             return rs[0], os_[0], as_[0]
@@ -265,6 +279,16 @@ def main():
             # every band's hits to every rank, sorted on the device (the per-band bit mask that `kevlar unband`
             # would OR together carries no information beyond the hits, so it is not exchanged here)
             from kevlar_amd import bandmerge
+            if band_mask is not None:
+                # bands are disjoint: the sum of the 0/1 words is their OR (docs/banding.rst; kevlar/unband.py:41-77)
+                torch.cuda.synchronize()
+                if args.backend == 'nccl':
+                    bandmerge.allreduce_mask(band_mask)
+                else:
+                    staged_mask = band_mask.cpu()
+                    bandmerge.allreduce_mask(staged_mask)
+                    band_mask.copy_(staged_mask)
+                torch.cuda.synchronize()
             r, o, a = bandmerge.allgather_hits_device(r, o, a, torch.device('cuda', dev_index), staged=(args.backend != 'nccl'))
         wall['merge'] += time.perf_counter() - t_c
         return kmers, (r, o, a)
@@ -349,6 +373,12 @@ def main():
     selfcheck = {'hits_checksum': hits_checksum(r, o, a)}
     if os.environ.get('BENCH_DUMP_HITS') and rank == 0:
         np.savez_compressed(os.path.join(os.environ['BENCH_DUMP_HITS'], 'step_world{}.npz'.format(world)), r=np.asarray(r), o=np.asarray(o), a=np.asarray(a))
+    if band_mask is not None:
+        from kevlar_amd import bandmerge
+        mr, mo = bandmerge.mask_to_hits(band_mask, nk)
+        selfcheck['mask_allreduce_equals_gathered_hits'] = bool(np.array_equal(mr, np.asarray(r, dtype=np.uint32)) and
+                                                                np.array_equal(mo, np.asarray(o, dtype=np.uint32)))
+        assert selfcheck['mask_allreduce_equals_gathered_hits'], 'the all-reduced band masks and the gathered hits disagree'
     if world == 1:
         assert kmers == S * n_reads * nk
     else:
@@ -485,8 +515,10 @@ def main():
                     '{} k-mer bands, 1 per GPU; reads sharded, {} exchanged by band (all-to-all); hits all-gathered (the '
                     'per-band bit mask of north_star carries nothing beyond them)'.format(
                         world, 'distinct (hash, occurrences) pairs' if args.exchange_items == 'distinct' else 'hashes') if exchange else
-                    '{} k-mer bands, 1 per GPU; every rank streams all reads; hits all-gathered (the per-band bit mask of '
-                    'north_star carries nothing beyond them)'.format(world)),
+                    ('{} k-mer bands, 1 per GPU; every rank streams all reads; per-band bit masks all-reduced (asserted equal to the '
+                     'gathered hits), hits all-gathered for their abundances' if band_mask is not None else
+                     '{} k-mer bands, 1 per GPU; every rank streams all reads; hits all-gathered (the per-band bit mask of '
+                     'north_star carries nothing beyond them; --merge mask adds its all-reduce)').format(world)),
                 'read_batches_per_sample': len(batch_first), 'count_streams': args.count_streams,
                 'interesting_kmer_instances': nhits, 'host_generate_pack_upload_s': round(gen_s, 1),
                 'packed_reads_upload_s': round(upload_s, 3) if upload_s is not None else None,

@@ -123,15 +123,24 @@ def _batches(stream, ksize, sketch_k, size):
 class _Tally(object):
     """what the closing log line reports"""
 
-    def __init__(self):
+    def __init__(self, hasher=None):
         self.instances = self.reads = 0
         self.kmers = set()          # as read; reduced to one strand at the end
         self.hashes = []            # ... or, on the text path, the k-mers' hashes (one value for both strands)
+        self.hasher = hasher        # the sketch whose hash function the text path used
 
     def line(self, seconds):
-        unique = len({kevlar_amd.revcommin(kmer) for kmer in self.kmers})
-        if self.hashes:
-            unique += len(np.unique(np.concatenate(self.hashes)))
+        """`unique novel kmers` counts canonical k-mers (kevlar/novel.py:161-162).  One run can tally through both paths
+        (a batch of parsed records next to native batches): the k-mers then meet in ONE set -- the strings are hashed
+        with the same strand-symmetric function -- so that a k-mer seen on both paths counts once."""
+        canonical = {kevlar_amd.revcommin(kmer) for kmer in self.kmers}
+        if not self.hashes:
+            unique = len(canonical)
+        else:
+            parts = list(self.hashes)
+            if canonical:
+                parts.append(self.hasher.hash_kmers(sorted(canonical)))
+            unique = len(np.unique(np.concatenate(parts)))
         return 'Found {:d} instances of {:d} unique novel kmers in {:d} reads in {:.2f} seconds'.format(
             self.instances, unique, self.reads, seconds)
 
@@ -217,7 +226,7 @@ def novel_text(casestream, casecounts, controlcounts, ksize=31, abundscreen=None
     one piece (every batch of the native reader), so no Python object is built per read or per k-mer."""
     clock = kevlar_amd.Timer()
     clock.start()
-    tally = _Tally()
+    tally = _Tally(casecounts[0] if casecounts else None)
     for text, hits, k in _scan(casestream, casecounts, controlcounts, ksize, abundscreen, casemin, ctrlmax, numbands, band, skipuntil,
                                refbandquirk, batchsize):
         reads, offsets, _, dropped = hits

@@ -42,9 +42,10 @@ def test_self_launch_relays_a_failing_rank():
 @pytest.mark.gpu
 def test_self_launch_runs_config_1_on_two_ranks_sharing_the_gpu():
     res = run_bench('--gpus', '2', '--backend', 'gloo', '--workload', 'cfg1', '--steps', '1', '--warmup', '1',
-                    '--no-cpu-baseline', '--no-e2e')
+                    '--no-cpu-baseline', '--no-e2e', '--merge', 'mask')
     assert res.returncode == 0, res.stderr[-3000:]
     out = last_json(res.stdout)
     assert out['n_gpus'] == 2 and out['selfcheck']['ranks_seen'] == [0, 1]
     assert out['selfcheck']['replay_matches']
+    assert out['selfcheck']['mask_allreduce_equals_gathered_hits']       # north_star's all-reduce of the per-band bit masks
     assert set(out['phases']['max_over_ranks']) >= {'count', 'scan', 'gather'}

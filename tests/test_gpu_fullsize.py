@@ -171,3 +171,86 @@ def test_fullsize_config5_k51_four_samples(hk, ok):
     sel = np.isin(r, sample)
     got = {(x, y): tuple(z) for x, y, z in zip(r[sel].tolist(), o[sel].tolist(), a[sel].tolist())}
     assert got == want and len(want) > 500
+
+
+# ---- full size against the ORACLE itself (not against another device path) ------------------------------------------
+# kvo_consume_reads_mt counts with atomic saturating adds, so its tables (and n_occupied: "was the bin zero" comes out of
+# the same atomic) do not depend on the thread schedule: all host cores, one sample in well under a minute.
+
+def host_cores():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = max(1, min(cores, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def ascii_block(words, read_len, chunk=500_000):
+    """packed words -> (bytes of all reads back to back, c_uint64 offsets): the oracle's input, without a Python string per read"""
+    import ctypes
+    from kevlar_amd import synth
+    n = words.shape[0]
+    out = np.empty(n * read_len, dtype=np.uint8)
+    shifts = (2 * np.arange(16, dtype=np.uint32))[None, None, :]
+    for lo in range(0, n, chunk):
+        w = words[lo:lo + chunk]
+        codes = ((w[:, :, None] >> shifts) & 3).reshape(w.shape[0], -1)[:, :read_len].astype(np.uint8)
+        out[lo * read_len:(lo + w.shape[0]) * read_len] = synth.ALPHABET[codes].reshape(-1).view(np.uint8)
+    offs = (np.arange(n + 1, dtype=np.uint64) * np.uint64(read_len))
+    return out.tobytes(), offs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), offs
+
+
+def assert_same_sketch(dev, ref):
+    assert dev.hashsizes() == ref.hashsizes()
+    for t in range(4):
+        got = np.frombuffer(dev.table_bytes(t), dtype=np.uint8)
+        want = np.frombuffer(ref.table_bytes(t), dtype=np.uint8)
+        assert got.shape == want.shape and np.array_equal(got, want), 'table {} differs from the oracle'.format(t)
+    assert dev.n_occupied() == ref.n_occupied()
+
+
+def test_fullsize_config2_tables_and_scan_equal_the_oracle(hk, ok, trio):
+    """every table byte of all three 7.5 M-read samples (2 GB sketches) against the oracle's count, n_occupied, and the
+    oracle's own scan loop (kevlar/novel.py:123-169 restated) over 120 000 consecutive reads of the proband"""
+    packed, batches = trio
+    names = ('mother', 'father', 'proband')
+    cores = host_cores()
+    n_reads = packed['proband'].shape[0]
+    dev, ref, keep = {}, {}, {}
+    for n in names:
+        dev[n] = hk.Counttable(K, MEM / 4, 4)
+        assert dev[n].consume_batch(batches[n]) == n_reads * (L - K + 1)
+        bases, offs_p, offs = ascii_block(packed[n], L)
+        ref[n] = ok.Counttable(K, MEM / 4, 4)
+        assert ok.consume_reads_mt(ref[n], bases, offs_p, n_reads, cores) == n_reads * (L - K + 1)
+        assert_same_sketch(dev[n], ref[n])
+        if n == 'proband':
+            keep = (bases, offs_p, offs)
+    r, o, a, _ = hk.novel_scan([dev['proband']], [dev['mother'], dev['father']], batches['proband'], 6, 1)
+    n_replay = 120_000
+    hits, _ = ok.novel_scan([ref['proband']], [ref['mother'], ref['father']], keep[0], keep[1], n_replay, K, 6, 1, cap=1 << 18)
+    sel = r < n_replay
+    got = list(zip(r[sel].tolist(), o[sel].tolist(), (tuple(x) for x in a[sel].tolist())))
+    assert got == hits
+    assert len(hits) > 10000
+
+
+def test_fullsize_config5_one_sample_equals_the_oracle(hk, ok):
+    """config 5's k = 51 (two-word keys, three murmur blocks + tail): one whole 7.5 M-read sample, every table byte"""
+    from kevlar_amd import synth
+    k = 51
+    packed = synth.trio_reads_packed(25_000_000, 30, L, extra_controls=1)
+    words = packed['sibling1']
+    n_reads = words.shape[0]
+    dev = hk.Counttable(k, MEM / 4, 4)
+    assert dev.consume_batch(hk.ReadBatch.from_packed(words, L)) == n_reads * (L - k + 1)
+    bases, offs_p, _offs = ascii_block(words, L)
+    ref = ok.Counttable(k, MEM / 4, 4)
+    assert ok.consume_reads_mt(ref, bases, offs_p, n_reads, host_cores()) == n_reads * (L - k + 1)
+    assert_same_sketch(dev, ref)

@@ -499,3 +499,23 @@ def test_hit_arrays_outlive_their_handle(hk):
     assert len(keep[0]) > 100
     for got, want in zip(views, keep):
         assert np.array_equal(got, want)
+
+
+def test_novel_tally_counts_a_kmer_seen_on_both_paths_once(hk):
+    """`N unique novel kmers` (kevlar/novel.py:161-162) when one run tallies through the record path and the native
+    text path: a k-mer (either strand) that both paths saw is one k-mer"""
+    import kevlar_amd
+    from kevlar_amd.novel import _Tally
+    sketch = hk.Counttable(21, 1e5, 4)
+    a, b, c = 'GATTACAGATTACAGATTACA', 'CCTGATATCCGGAATCTTAGC', 'ACGTACGTACGTACGTACGTT'
+    tally = _Tally(sketch)
+    tally.kmers.update([a, kevlar_amd.revcom(a), b])
+    tally.hashes.append(sketch.hash_kmers([kevlar_amd.revcom(b), c]))
+    tally.instances, tally.reads = 5, 2
+    assert 'Found 5 instances of 3 unique novel kmers in 2 reads' in tally.line(0.0)
+    only_text = _Tally(sketch)
+    only_text.hashes.append(sketch.hash_kmers([a, kevlar_amd.revcom(a), c]))
+    assert 'of 2 unique novel kmers' in only_text.line(0.0)
+    only_records = _Tally()
+    only_records.kmers.update([a, kevlar_amd.revcom(a), c])
+    assert 'of 2 unique novel kmers' in only_records.line(0.0)
