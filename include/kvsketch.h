@@ -120,6 +120,14 @@ int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t n_reads, k
  * r in word r*words_per_read + j/16 at bits 2*(j%16)), all of length read_len, ACGT only.
  * Used by synthetic-read generators that never materialise ASCII.                        */
 int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, uint32_t read_len, kv_reads **out);
+/* Equal-length reads of a synthetic family generated ON the device (kv_synth.hip): reads [first_read, first_read +
+ * n_reads) of sample 0 = proband, 1 = mother, 2 = father over an iid-uniform genome of genome_len bases; pure
+ * function of (seed, sample, read index).  No reference counterpart (kevlar's test reads came from wgsim,
+ * kevlar/tests/data/microtrios/README): it stands where BASELINE.json's config 4 needs 900 M reads per sample.       */
+int kv_reads_generate(uint64_t genome_len, uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads,
+                      uint32_t read_len, double error_rate, kv_reads **out);
+/* packed words [first_word, first_word + n_words) of a batch back to the host (tests; kv_reads_create_packed's layout)   */
+int kv_reads_words_read(const kv_reads *r, uint64_t first_word, uint64_t n_words, uint32_t *host_out);
 int kv_reads_destroy(kv_reads *r);
 
 /* Native FASTA/FASTQ reader (gzip transparent) = khmer.ReadParser (kevlar/count.py:40,

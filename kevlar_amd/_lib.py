@@ -63,6 +63,8 @@ SIGNATURES = {
     'kv_sketch_clear': (i32, [vp]),
     'kv_reads_create': (i32, [cstr, u64p, u64, vpp]),
     'kv_reads_create_packed': (i32, [u32p, u64, u32, vpp]),
+    'kv_reads_generate': (i32, [u64, u64, i32, u64, u64, u32, ctypes.c_double, vpp]),
+    'kv_reads_words_read': (i32, [vp, u64, u64, u32p]),
     'kv_reads_destroy': (i32, [vp]),
     'kv_fastx_open': (i32, [cstr, vpp]),
     'kv_fastx_next': (i32, [vp, u64, i32, vpp, u64p]),

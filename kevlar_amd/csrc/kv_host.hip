@@ -1,6 +1,7 @@
 // kv_host.hip -- host side of libkvsketch_hip: handles, OXLI v4 file I/O, table sizing,
 // read packing and the live profiler.  All table memory is HBM (hipMalloc).
 #include <algorithm>
+#include <functional>
 #include <atomic>
 #include <cstdarg>
 #include <map>
@@ -893,9 +894,11 @@ int reads_from_packed(const uint32_t *words, const TextSource *text, const uint3
 }
 }  // namespace
 
-extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, uint32_t read_len, kv_reads **out)
+// equal-length reads from packed words on the host, or (words == nullptr) written on the device by `fill(d_words, stream)`
+static int reads_packed_uniform(const uint32_t *words, const std::function<void(uint32_t *, hipStream_t)> *fill, uint64_t n_reads,
+                                uint32_t read_len, kv_reads **out)
 {
-    KV_REQUIRE(out && (words || n_reads == 0), KV_ERR_ARG, "kv_reads_create_packed: null argument");
+    KV_REQUIRE(out && (words || fill || n_reads == 0), KV_ERR_ARG, "kv_reads_create_packed: null argument");
     KV_REQUIRE(n_reads < 0xFFFFFFF0ull, KV_ERR_ARG, "too many reads in one batch");
     KV_REQUIRE(read_len >= 1 && read_len <= KV_MAX_READ_LEN, KV_ERR_ARG, "read length %u out of range", read_len);
     kv_reads *r = new kv_reads();
@@ -921,7 +924,8 @@ extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, u
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, n_reads ? n_reads : 1);
     if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, (size_t)tiles_alloc * sizeof(TileDesc));
-    if (e == hipSuccess && r->n_words) e = hipMemcpyAsync(r->d_words, words, r->n_words * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && r->n_words && words) e = hipMemcpyAsync(r->d_words, words, r->n_words * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && r->n_words && !words) { (*fill)(r->d_words, st); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipMemsetAsync(r->d_words + r->n_words, 0, 16, st);
     if (e == hipSuccess && n_reads) e = hipMemsetD32Async((hipDeviceptr_t)r->d_len, (int)read_len, n_reads, st);
     if (e == hipSuccess) e = hipMemsetAsync(r->d_flags, 0, n_reads ? n_reads : 1, st);
@@ -938,6 +942,36 @@ extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, u
     }
     *out = r;
     return KV_OK;
+}
+
+extern "C" int kv_reads_create_packed(const uint32_t *words, uint64_t n_reads, uint32_t read_len, kv_reads **out)
+{
+    KV_REQUIRE(out && (words || n_reads == 0), KV_ERR_ARG, "kv_reads_create_packed: null argument");
+    return reads_packed_uniform(words, nullptr, n_reads, read_len, out);
+}
+
+extern "C" int kv_reads_words_read(const kv_reads *r, uint64_t first_word, uint64_t n_words, uint32_t *host_out)
+{
+    KV_REQUIRE(r && (host_out || n_words == 0) && first_word + n_words <= r->n_words, KV_ERR_ARG, "kv_reads_words_read: bad range");
+    if (n_words == 0) return KV_OK;
+    KV_HIP(hipMemcpyAsync(host_out, r->d_words + first_word, n_words * 4, hipMemcpyDeviceToHost, kv_stream()));
+    KV_HIP(hipStreamSynchronize(kv_stream()));
+    return KV_OK;
+}
+
+// kv_synth.hip
+void kv_synth_fill(uint32_t *d_words, uint64_t genome_len, uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads,
+                   uint32_t read_len, double error_rate, hipStream_t st);
+
+extern "C" int kv_reads_generate(uint64_t genome_len, uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads,
+                                 uint32_t read_len, double error_rate, kv_reads **out)
+{
+    KV_REQUIRE(out && sample >= 0 && sample <= 2 && read_len >= 1 && genome_len >= (uint64_t)read_len + 1 && error_rate >= 0.0 && error_rate < 1.0,
+               KV_ERR_ARG, "kv_reads_generate: bad argument");
+    const std::function<void(uint32_t *, hipStream_t)> fill = [&](uint32_t *d_words, hipStream_t st) {
+        kv_synth_fill(d_words, genome_len, seed, sample, first_read, n_reads, read_len, error_rate, st);
+    };
+    return reads_packed_uniform(nullptr, &fill, n_reads, read_len, out);
 }
 
 extern "C" int kv_reads_destroy(kv_reads *r)

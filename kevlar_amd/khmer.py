@@ -472,6 +472,25 @@ class ReadBatch(object):
         self.n_reads = int(words.shape[0])
         return self
 
+    @classmethod
+    def generate(cls, genome_len, seed, sample, first_read, n_reads, read_len=100, error_rate=0.005):
+        """reads [first_read, first_read + n_reads) of the device-generated family (kv_reads_generate; sample 0 proband,
+        1 mother, 2 father): nothing crosses PCIe.  kevlar_amd.synth.device_family_reads is the numpy restatement."""
+        _lib.require_device()
+        self = cls.__new__(cls)
+        handle = ctypes.c_void_p()
+        check(_lib.load().kv_reads_generate(int(genome_len), int(seed), int(sample), int(first_read), int(n_reads), int(read_len),
+                                            float(error_rate), ctypes.byref(handle)))
+        self._h = handle
+        self.n_reads = int(n_reads)
+        return self
+
+    def packed_words(self, first_word, n_words):
+        """words [first_word, first_word + n_words) of the packed batch, from the device"""
+        out = np.empty(int(n_words), dtype=np.uint32)
+        check(_lib.load().kv_reads_words_read(self._h, int(first_word), int(n_words), _u32p(out)))
+        return out
+
     def num_kmers(self, ksize):
         n = ctypes.c_uint64()
         check(_lib.load().kv_reads_num_kmers(self._h, ksize, ctypes.byref(n)))

@@ -121,3 +121,58 @@ def trio_reads_packed(genome_len, coverage, read_len=100, seed=42, error_rate=0.
     n_reads = int(genome_len * coverage / read_len)
     names = ['proband', 'mother', 'father'] + ['sibling{}'.format(i + 1) for i in range(extra_controls)]
     return {name: sample_reads_packed(trio[name], n_reads, read_len, error_rate, 1001 + i) for i, name in enumerate(names)}
+
+
+# ---- the family kv_synth.hip generates on the device (kv_reads_generate), restated with numpy -------------------------
+_M = np.uint64(0xffffffffffffffff)
+
+
+def _mix(x):
+    x = (x + np.uint64(0x9e3779b97f4a7c15)) & _M
+    x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)) & _M
+    x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)) & _M
+    return x ^ (x >> np.uint64(31))
+
+
+def device_family_bases(seed, pos, hap):
+    """2-bit codes at positions `pos` (uint64 array) of haplotypes `hap` (same shape; 0..3 parental, 4 / 5 the proband's)"""
+    with np.errstate(over='ignore'):
+        seed = np.uint64(seed)
+        pos = pos.astype(np.uint64)
+        b = (_mix(seed ^ (pos * np.uint64(0x2545f4914f6cdd1d))) & np.uint64(3)).astype(np.uint32)
+        parental = np.where(hap < 4, hap, np.where(hap == 4, 0, 2)).astype(np.uint64)
+        hi = _mix((seed + np.uint64(1)) ^ (pos * np.uint64(0x9fb21c651e98df25)))
+        inh = (hi % np.uint64(2500) == 0) & (((hi // np.uint64(2500)) & np.uint64(3)) == parental)
+        b = np.where(inh, (b + 1 + ((hi >> np.uint64(40)) % np.uint64(3)).astype(np.uint32)) & 3, b)
+        hd = _mix((seed + np.uint64(2)) ^ (pos * np.uint64(0xd6e8feb86659fd93)))
+        dn = (hap >= 4) & (hd % np.uint64(5000) == 0) & (((hd // np.uint64(5000)) & np.uint64(1)) == (hap.astype(np.int64) - 4).astype(np.uint64))
+        return np.where(dn, (b + 1 + ((hd >> np.uint64(40)) % np.uint64(3)).astype(np.uint32)) & 3, b).astype(np.uint8)
+
+
+def device_family_reads(genome_len, seed, sample, read_index, read_len=100, error_rate=0.005):
+    """codes [len(read_index), read_len] (uint8) of the given reads (global indices) of sample 0 proband / 1 mother / 2 father"""
+    with np.errstate(over='ignore'):
+        i = np.asarray(read_index, dtype=np.uint64)
+        sseed = np.uint64(seed) + np.uint64(16 + 8 * sample)
+        rr = _mix(sseed ^ (i * np.uint64(0xa0761d6478bd642f)))
+        which = (rr & np.uint64(1)).astype(np.int64)
+        flip = ((rr >> np.uint64(1)) & np.uint64(1)).astype(bool)
+        start = (rr >> np.uint64(8)) % np.uint64(genome_len - read_len + 1)
+        hap = 4 + which if sample == 0 else (which if sample == 2 else 2 + which)
+        j = np.arange(read_len, dtype=np.uint64)[None, :]
+        src = np.where(flip[:, None], start[:, None] + (np.uint64(read_len - 1) - j), start[:, None] + j)
+        codes = device_family_bases(seed, src, np.broadcast_to(hap[:, None], src.shape))
+        codes = np.where(flip[:, None], 3 - codes, codes).astype(np.uint32)
+        e = _mix((sseed + np.uint64(1)) ^ ((i[:, None] * np.uint64(4096) + j) * np.uint64(0xe7037ed1a0b428db)))
+        bad = (e & np.uint64(0xffffffff)) < np.uint64(int(error_rate * 4294967296.0))
+        return np.where(bad, (codes + 1 + ((e >> np.uint64(32)) % np.uint64(3)).astype(np.uint32)) & 3, codes).astype(np.uint8)
+
+
+def pack_codes(codes):
+    """[n, L] codes -> uint32 [n, ceil(L / 16)] in the kv_reads layout"""
+    n, L = codes.shape
+    wpr = (L + 15) // 16
+    padded = np.zeros((n, wpr * 16), dtype=np.uint32)
+    padded[:, :L] = codes
+    shifts = (2 * np.arange(16, dtype=np.uint32))[None, None, :]
+    return (padded.reshape(n, wpr, 16) << shifts).sum(axis=2, dtype=np.uint32)

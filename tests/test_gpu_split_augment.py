@@ -49,17 +49,13 @@ def test_split_reference_fixture_on_the_gpu_box(hk, tmp_path):
 
 
 def test_split_deals_the_device_pipeline_s_partitions(hk, tmp_path):
-    """novel (count + scan on the device) -> partition (device read graph) -> split: every partition arrives whole, in
-    input order, partition i in file i mod N"""
-    novel = str(tmp_path / 'novel.augfastq')
-    run_cli(['novel', '--case', data_file('microtrios/trio-li-proband.fq.gz'), '--ksize', '25', '--case-min', '7', '--ctrl-max', '0',
-             '--memory', '500K', '--control', data_file('microtrios/trio-li-father.fq.gz'),
-             '--control', data_file('microtrios/trio-li-mother.fq.gz'), '--out', novel])
+    """partition (read graph and components on the device) -> split: every partition arrives whole, in input order,
+    partition i in file i mod N"""
     parted = str(tmp_path / 'parted.augfastq')
-    run_cli(['partition', '--out', parted, novel])
+    run_cli(['partition', '--out', parted, data_file('pico-filtered.fq.gz')])
     whole = partitions(parted)
-    assert len(whole) >= 2
-    nfiles = 2
+    assert len(whole) >= 5
+    nfiles = 3
     run_cli(['split', parted, str(nfiles), str(tmp_path / 'deal')])
     dealt = [partitions(str(tmp_path / 'deal.{}.augfastx'.format(i))) for i in range(nfiles)]
     for i in range(nfiles):
