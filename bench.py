@@ -12,6 +12,9 @@ scan of the proband against its controls (kv_novel_scan).
     cfg1        50 kb trio, 10x, k=31, 1 MB sketch              (the reference's own CPU-runnable case: plumbing)
     cfg4-proxy  250 Mb trio, 30x, k=31, 8 GB sketch per sample, reads in batches of 18.75 M: one band's share of
                 config 4 (3 Gb, 8 bands) on one GPU -- proves the batching and the HBM budget, not the 8-GPU run
+    cfg4-band   config 4 at true scale as one of its eight GPUs sees it: 3 Gb genome, 900 M reads per sample (written into
+                HBM by kv_reads_generate: 25 GB per sample), band 0 of 8 with 8 GB sketches, count + novel, then `filter` and
+                `partition` of the band's annotated reads; per-stage seconds and peak HBM on the line
 N > 1 : configs[2]: the same trio, kevlar's k-mer banding with band b on GPU b (1/N of the hash space and of
         the table memory per GPU).  Total work is fixed -> "scaling": "strong".
         --multi banded   : the reference's layout -- every GPU streams all reads and keeps its band; then one RCCL
@@ -53,6 +56,11 @@ WORKLOADS = {
     'cfg4-proxy': dict(genome_mb=250.0, coverage=30.0, ksize=31, memory=8e9, controls=2, batch_reads=18_750_000,
                        label='one band\'s share of BASELINE.json configs[3] on one GPU: 250 Mb trio, 30x, k=31, 8 GB sketch '
                              'per sample, reads streamed in batches of 18.75 M (four per sample)'),
+    'cfg4-band': dict(genome_mb=3000.0, coverage=30.0, ksize=31, memory=64e9, controls=2, batch_reads=18_750_000, bands=8, band=0,
+                      device_generated=True,
+                      label='BASELINE.json configs[3] as ONE of its 8 GPUs sees it: 3 Gb trio, 30x, k=31, band 0 of 8 (8 GB sketch per '
+                            'sample on this GPU), all 900 M reads of every sample streamed in batches of 18.75 M (generated on the '
+                            'device, resident in HBM), then filter and partition of the band\'s annotated reads'),
 }
 
 
@@ -93,9 +101,47 @@ def parse_args():
                         'independent; kernels bound by different units overlap and no stream waits for another\'s host round '
                         'trips: 39-40 ms against 43-46 ms per step at config 2).  Per-kernel HIP-event durations then include '
                         'time sharing; 1 keeps the launches back to back for a clean per-kernel attribution')
+    p.add_argument('--traffic', default='live', choices=['live', 'file', 'none'],
+                   help='roofline.traffic (HBM bytes of the dominant stage): live = measured by two rocprofv3 --pmc child passes of this '
+                        'command before the timed run (cfg2, one GPU; ~1.5 min); file = the committed profiles/r*_final file if it '
+                        'measured these kernel sources; none')
     p.add_argument('--launch-check', action='store_true', help='only start the ranks and let them meet (no GPU work)')
     p.add_argument('--backend', default='nccl', help='nccl (= RCCL) is what the driver runs; gloo lets two ranks share one GPU in tests')
     return p.parse_args()
+
+
+LIVE_PMC = None      # per-kernel HBM bytes of one step, measured by live_traffic() of this very run
+
+
+def live_traffic(args):
+    """Two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass), one
+    step each with the samples back to back, BEFORE this process initialises the GPU; returns the reduced counters or
+    None (no rocprofv3, a failing pass, a time-out: the bench line then says so and goes on)."""
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if not rocprof:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, 'profiles'))
+    import summarise
+    tmp = tempfile.mkdtemp(prefix='kv_pmc_')
+    env = dict(os.environ, TMPDIR=tmp)
+    child = [sys.executable, os.path.abspath(__file__), '--workload', args.workload, '--steps', '1', '--warmup', '0', '--no-cpu-baseline',
+             '--no-e2e', '--no-replay', '--count-streams', '1', '--traffic', 'none']
+    try:
+        for counter, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
+            res = subprocess.run([rocprof, '--pmc', counter, '--output-format', 'csv', '-d', os.path.join(tmp, sub), '--'] + child,
+                                 cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420)
+            if res.returncode != 0:
+                return None
+        rec = summarise.reduce_pmc(tmp)
+        rec['source'] = 'live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two passes of one step of this command on this GPU, before the timed run'
+        return rec if rec['kernels'] else None
+    except (subprocess.TimeoutExpired, OSError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def self_launch(n):
@@ -167,6 +213,9 @@ def main():
         raise SystemExit('bench.py --gpus {} was started with WORLD_SIZE={}'.format(args.gpus, world))
     if args.launch_check:
         return launch_check(args, rank, world)
+    global LIVE_PMC
+    if world == 1 and args.gpus == 1 and args.traffic == 'live' and args.workload == 'cfg2':
+        LIVE_PMC = live_traffic(args)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -192,10 +241,18 @@ def main():
     L, k = args.read_len, int(wl['ksize'])
     genome_len = int(wl['genome_mb'] * 1e6)
     t0 = time.time()
-    packed = synth.trio_reads_packed(genome_len, wl['coverage'], L, extra_controls=wl['controls'] - 2)
-    names = tuple(packed)                           # proband first, then the controls
+    on_device = bool(wl.get('device_generated'))
+    GEN_SEED = 42
+    if on_device:
+        assert world == 1, '{} is a one-GPU workload'.format(args.workload)
+        packed = None
+        names = ('proband', 'mother', 'father')
+        n_reads = int(genome_len * wl['coverage'] / L)
+    else:
+        packed = synth.trio_reads_packed(genome_len, wl['coverage'], L, extra_controls=wl['controls'] - 2)
+        names = tuple(packed)                           # proband first, then the controls
+        n_reads = packed['proband'].shape[0]
     controls = names[1:]
-    n_reads = packed['proband'].shape[0]
     multi = args.multi if args.multi != 'auto' else ('exchange' if world >= 4 else 'banded')
     if args.exchange_items == 'auto':
         args.exchange_items = 'distinct' if world <= 4 else 'plain'
@@ -207,6 +264,12 @@ def main():
         bounds = {n: shardrun.shard_bounds(n_reads, world, rank) for n in names}
         batches = {n: [hk.ReadBatch.from_packed(packed[n][bounds[n][0]:bounds[n][1]], L)] for n in names}
         run = shardrun.ShardedTrio(k, hk.Counttable)
+    elif on_device:
+        t_up = time.time()
+        batches = {n: [hk.ReadBatch.generate(genome_len, GEN_SEED, si, lo, min(per_batch, n_reads - lo), L) for lo in range(0, n_reads, per_batch)]
+                   for si, n in enumerate(names)}
+        lib.kv_synchronize()
+        upload_s = time.time() - t_up
     else:
         t_up = time.time()
         batches = {n: [hk.ReadBatch.from_packed(packed[n][lo:lo + per_batch], L) for lo in range(0, n_reads, per_batch)] for n in names}
@@ -217,7 +280,12 @@ def main():
     nk = L - k + 1
     T = 4
     S = len(names)
-    mem_per_gpu = wl['memory'] / max(1, world)
+    solo_bands, solo_band = int(wl.get('bands', 0)), int(wl.get('band', 0))       # a single GPU playing one band of a banded run
+    mem_per_gpu = wl['memory'] / max(1, world) / max(1, solo_bands)
+    hbm_low = [torch.cuda.mem_get_info(dev_index)[0]]
+
+    def note_hbm():
+        hbm_low[0] = min(hbm_low[0], torch.cuda.mem_get_info(dev_index)[0])
 
     def make_sketches(memory):
         return {n: hk.Counttable(k, memory / T, T) for n in names}
@@ -273,7 +341,8 @@ def main():
         return kmers, (r, o, a)
 
     def step_banded():
-        kmers, (r, o, a) = count_and_scan(sketches, world if world > 1 else 0, rank)
+        kmers, (r, o, a) = count_and_scan(sketches, world if world > 1 else solo_bands, rank if world > 1 else solo_band)
+        note_hbm()
         t_c = time.perf_counter()
         if world > 1:
             # every band's hits to every rank, sorted on the device (the per-band bit mask that `kevlar unband`
@@ -379,7 +448,11 @@ def main():
         selfcheck['mask_allreduce_equals_gathered_hits'] = bool(np.array_equal(mr, np.asarray(r, dtype=np.uint32)) and
                                                                 np.array_equal(mo, np.asarray(o, dtype=np.uint32)))
         assert selfcheck['mask_allreduce_equals_gathered_hits'], 'the all-reduced band masks and the gathered hits disagree'
-    if world == 1:
+    if world == 1 and solo_bands:
+        selfcheck['kmers_in_band'] = int(kmers)
+        selfcheck['kmers_in_band_share'] = round(kmers / float(S * n_reads * nk), 5)
+        assert abs(selfcheck['kmers_in_band_share'] * solo_bands - 1.0) < 0.01, 'a band holds 1/N of the hash space'
+    elif world == 1:
         assert kmers == S * n_reads * nk
     else:
         # every rank reports through RCCL: who took part, and how many k-mers each one counted
@@ -434,7 +507,7 @@ def main():
 
     # ---- roofline: algorithmic bytes (A_count = L/4 + 2 T nk, A_novel = L/4 + T S nk per read;
     # with N bands only 1/N of the k-mers reach this GPU's tables) / live HIP-event time
-    frac_band = 1.0 / max(1, world)
+    frac_band = 1.0 / max(1, world) / max(1, solo_bands)
     a_count = n_reads * (L / 4.0 + 2 * T * nk * frac_band)
     a_novel = n_reads * (L / 4.0 + T * S * nk * frac_band)
     buf = ctypes.create_string_buffer(8192)
@@ -455,22 +528,29 @@ def main():
     stage = max(stage_ms, key=lambda st: stage_ms[st])
     dominant = max(groups[stage], key=lambda n_: times[n_][0]) if groups[stage] else None
     achieved = stage_alg[stage] / (stage_ms[stage] * 1e-3) / 1e9 if stage_ms[stage] > 0 else 0.0
+    # HBM bytes of the stage from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, separate passes, FETCH doubled for the wide
+    # coalesced streams as the guide prescribes, profiles/summarise.py): measured by THIS run before it touched the GPU
+    # (live_traffic, below), else from a committed file -- but only one that measured these very kernel sources
     traffic, traffic_source = None, None
-    pmc_file = next((f for f in (os.path.join(ROOT, 'profiles', r, 'pmc_hbm_bytes.json') for r in ('r2_final', 'r2_mid'))
-                     if os.path.exists(f)), '')
-    if world == 1 and os.path.exists(pmc_file) and args.workload == 'cfg2':
-        # HBM bytes from the committed rocprofv3 PMC passes of this same workload (profiles/README.md): FETCH_SIZE and
-        # WRITE_SIZE in separate passes, FETCH doubled for wide coalesced streams as the guide prescribes; summed over
-        # the launches of the stage in one step
-        pmc = json.load(open(pmc_file))
-        tot = 0.0
-        for name in groups[stage]:
-            rec = pmc.get('kernels', {}).get(name)
-            if rec:
-                tot += rec['hbm_bytes_per_step']
+    pmc = LIVE_PMC
+    if pmc is None and world == 1 and args.workload == 'cfg2' and args.traffic != 'none':
+        sys.path.insert(0, os.path.join(ROOT, 'profiles'))
+        import summarise
+        for round_dir in sorted((d for d in os.listdir(os.path.join(ROOT, 'profiles')) if d.endswith('_final')), reverse=True):
+            f = os.path.join(ROOT, 'profiles', round_dir, 'pmc_hbm_bytes.json')
+            if os.path.exists(f):
+                rec = json.load(open(f))
+                if rec.get('kernel_sources_sha16') == summarise.kernel_sources_sha(ROOT):
+                    pmc = rec
+                    pmc['source'] = '{} ({})'.format(os.path.relpath(f, ROOT), rec.get('collected', 'rocprofv3 --pmc'))
+                else:
+                    traffic_source = 'none: {} measured other kernel sources than this checkout'.format(os.path.relpath(f, ROOT))
+                break
+    if pmc is not None:
+        tot = sum(pmc['kernels'][name]['hbm_bytes_per_step'] for name in groups[stage] if name in pmc.get('kernels', {}))
         if tot:
             traffic = int(tot)
-            traffic_source = '{} ({})'.format(os.path.relpath(pmc_file, ROOT), pmc.get('collected', 'rocprofv3 --pmc'))
+            traffic_source = pmc.get('source')
     dom_ms, dom_launches = times[dominant] if dominant else (0.0, 0)
     roofline = {
         'bound': 'hbm', 'stage': stage, 'kernel': dominant,
@@ -494,7 +574,14 @@ def main():
     }
 
     cpu = e2e = None
-    if rank == 0 and world == 1:
+    downstream = None
+    if on_device:
+        downstream = band_downstream(args, wl, hits, genome_len, GEN_SEED, L, k, S, synth)
+        note_hbm()
+        props = torch.cuda.get_device_properties(dev_index)
+        downstream['hbm_peak_gb'] = round((props.total_memory - hbm_low[0]) / 1e9, 1)
+        downstream['hbm_resident_reads_gb'] = round(sum(b.device_bytes() for n in names for b in batches[n]) / 1e9, 1)
+    if rank == 0 and world == 1 and not on_device:
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args, wl, packed, names, synth)
         if not args.no_e2e:
@@ -526,6 +613,7 @@ def main():
                                                torch.cuda.get_device_properties(dev_index).multi_processor_count),
             },
             'selfcheck': selfcheck,
+            'downstream': downstream,
             'phases': phases,
             'roofline': roofline,
             'cpu_baseline': cpu,
@@ -534,6 +622,72 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def band_downstream(args, wl, hits, genome_len, seed, L, k, S, synth):
+    """What follows the scan in the workflow (kevlar/workflows/mark-I/Snakefile:236-309), on the band's hits: the annotated
+    reads written as an augmented FASTQ file, `kevlar filter` on it, `kevlar partition` on what survives.  The reads' text
+    comes from the generator's numpy restatement (only reads with hits: the 2.7 G reads themselves never leave HBM)."""
+    import io
+    import tempfile
+    import numpy as np
+    import kevlar_amd
+    from kevlar_amd.annotated import AnnotatedReads
+    r, o, a = (np.asarray(x) for x in hits)
+    t0 = time.perf_counter()
+    ur, first = np.unique(r, return_index=True)
+    n = len(ur)
+    seqs = np.empty((n, L), dtype=np.uint8)
+    for lo in range(0, n, 200000):
+        seqs[lo:lo + 200000] = synth.ALPHABET[synth.device_family_reads(genome_len, seed, 0, ur[lo:lo + 200000], L)]
+    name_w = 14
+    names = np.empty((n, name_w), dtype=np.uint8)
+    names[:, :4] = np.frombuffer(b'read', dtype=np.uint8)
+    digits = ur.astype(np.int64)
+    for d in range(name_w - 4):
+        names[:, name_w - 1 - d] = 48 + digits % 10
+        digits //= 10
+    ann = AnnotatedReads.__new__(AnnotatedReads)
+    ann.n = n
+    ann.names, ann.name_offs = names.tobytes(), np.arange(n + 1, dtype=np.uint64) * np.uint64(name_w)
+    ann.seqs, ann.seq_offs = seqs.tobytes(), np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    ann.quals, ann.qual_offs = b'I' * (n * L), np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    ann.is_fastq = np.ones(n, dtype=np.uint8)
+    ann.first = np.concatenate((first, [len(r)])).astype(np.uint64)
+    ann.offset = o.astype(np.uint32)
+    ann.abund = a.astype(np.int32).reshape(len(r), S)
+    ann.mate_record = np.zeros(0, dtype=np.uint32)
+    ann.mates, ann.mate_offs = b'', np.zeros(1, dtype=np.uint64)
+    ann.ksize, ann.nsamples = k, S
+    ann._finish()
+    tmp = tempfile.mkdtemp(prefix='kv_band_')
+    novel_file, filtered_file, part_file = (os.path.join(tmp, f) for f in ('band.novel.augfastq', 'band.filtered.augfastq', 'band.part.augfastq'))
+    with open(novel_file, 'wb') as fh:
+        for lo in range(0, n, 400000):                     # (one call's text must stay below 2 GB)
+            fh.write(ann.format(np.arange(lo, min(n, lo + 400000), dtype=np.uint64)))
+    t1 = time.perf_counter()
+    log = io.StringIO()
+    old_log, kevlar_amd.logstream = kevlar_amd.logstream, log
+
+    def run(argv):
+        a_ = kevlar_amd.cli.parser().parse_args(argv)
+        t = time.perf_counter()
+        kevlar_amd.cli.mains[a_.cmd](a_)
+        return time.perf_counter() - t
+    try:
+        t_filter = run(['filter', '--memory', '2G', '--case-min', str(args.case_min), '--ctrl-max', str(args.ctrl_max), '-o', filtered_file, novel_file])
+        t_part = run(['partition', '-o', part_file, filtered_file])
+    finally:
+        kevlar_amd.logstream = old_log
+    said = [ln.split('] ', 1)[-1] for ln in log.getvalue().splitlines() if 'Validated' in ln or 'grouped' in ln or 'Processed' in ln]
+    out = {'annotated_reads': int(n), 'interesting_kmer_instances': int(len(r)), 'write_annotated_reads_s': round(t1 - t0, 2),
+           'annotated_reads_mb': os.path.getsize(novel_file) >> 20, 'filter_s': round(t_filter, 2), 'partition_s': round(t_part, 2),
+           'log': said[-4:]}
+    for f in (novel_file, filtered_file, part_file):
+        if os.path.exists(f):
+            os.remove(f)
+    os.rmdir(tmp)
+    return out
 
 
 def cpu_baseline(args, wl, packed, names, synth):

@@ -20,6 +20,15 @@ _ACGT = np.zeros(256, dtype=bool)
 _ACGT[[ord(c) for c in 'ACGT']] = True
 
 
+def _bytes_at(ptr, n):
+    """ctypes.string_at for any size (its length argument is a C int: 2 GB of annotated reads overflow it)"""
+    n = int(n)
+    if n < (1 << 31) - 1:
+        return ctypes.string_at(ptr, n)
+    address = ptr.value if hasattr(ptr, 'value') else int(ptr)
+    return bytes((ctypes.c_ubyte * n).from_address(address))
+
+
 def _offsets(lengths):
     out = np.zeros(len(lengths) + 1, dtype=np.uint64)
     if len(lengths):
@@ -77,20 +86,20 @@ class AnnotatedReads(object):
             def arr(p, count, dtype):
                 if count == 0:
                     return np.zeros(0, dtype=dtype)
-                return np.frombuffer(ctypes.string_at(p, count * np.dtype(dtype).itemsize), dtype=dtype).copy()
+                return np.frombuffer(_bytes_at(p, count * np.dtype(dtype).itemsize), dtype=dtype).copy()
             self = cls.__new__(cls)
             self.n = n
             self.name_offs, self.seq_offs, self.qual_offs = (arr(ptr[i], n + 1, np.uint64) for i in (1, 3, 5))
-            self.names = ctypes.string_at(ptr[0], int(self.name_offs[n]))
-            self.seqs = ctypes.string_at(ptr[2], int(self.seq_offs[n]))
-            self.quals = ctypes.string_at(ptr[4], int(self.qual_offs[n]))
+            self.names = _bytes_at(ptr[0], int(self.name_offs[n]))
+            self.seqs = _bytes_at(ptr[2], int(self.seq_offs[n]))
+            self.quals = _bytes_at(ptr[4], int(self.qual_offs[n]))
             self.is_fastq = arr(ptr[6], n, np.uint8)
             self.first = arr(ptr[7], n + 1, np.uint64)
             self.offset = arr(ptr[8], na, np.uint32)
             self.abund = arr(ptr[9], na * S, np.int32).reshape(na, S) if na else np.zeros((0, 0), dtype=np.int32)
             self.mate_record = arr(ptr[10], nm, np.uint32)
             self.mate_offs = arr(ptr[12], nm + 1, np.uint64)
-            self.mates = ctypes.string_at(ptr[11], int(self.mate_offs[nm])) if nm else b''
+            self.mates = _bytes_at(ptr[11], int(self.mate_offs[nm])) if nm else b''
             self.ksize = k.value if na else None
             self.nsamples = S if na else 0
         finally:
@@ -267,7 +276,7 @@ class AnnotatedReads(object):
             ctypes.cast(ctypes.c_char_p(self.mates), ctypes.c_void_p) if len(self.mate_record) else None,
             ptr(self.mate_offs) if len(self.mate_record) else None, ctypes.byref(text), ctypes.byref(size)))
         try:
-            return ctypes.string_at(text, size.value)
+            return _bytes_at(text, size.value)
         finally:
             lib.kv_text_free(text)
 

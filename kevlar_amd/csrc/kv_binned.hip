@@ -931,8 +931,9 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
     // L2 write requests): measured per 525 M k-mers into 5e8-bin tables, A/B/C = 10.5/5.0/4.0 ms with 32 buckets,
     // 8.7/4.9/4.0 with 20, 8.3/6.1/4.0 with 16 (F = 478: rings too big for three workgroups).
     // (weighted items: up to 64 buckets with the 512-thread front end -- its cursors are sized by T * C -- and F <= 1024)
-    const int cmax = weighted && g.sbits == BIN_SLICE_BITS_W ? (int)std::min<uint32_t>(BIN_C, std::max<uint32_t>(4u, (maxsl + 383u) / 384u))
+    int cmax = weighted && g.sbits == BIN_SLICE_BITS_W ? (int)std::min<uint32_t>(BIN_C, std::max<uint32_t>(4u, (maxsl + 383u) / 384u))
                               : (maxsl <= 32u * BIN_MAX_F ? (int)std::min<uint32_t>(32u, std::max<uint32_t>(4u, (maxsl + 383u) / 384u)) : BIN_C);
+    if (const char *e = getenv("KV_BIN_C")) cmax = std::max(1, std::min<int>(BIN_C, atoi(e)));      // experiments: coarse buckets per table
     plan->cmax = cmax;
     g.F = (int)((maxsl + (uint32_t)cmax - 1) / (uint32_t)cmax);
     g.C = (int)((maxsl + (uint32_t)g.F - 1) / (uint32_t)g.F);

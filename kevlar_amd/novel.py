@@ -49,8 +49,21 @@ def save_counts(filelist, tablelist, log=None):
         sketch.save(path)
 
 
-def _side_by_side():
-    return bool(os.environ.get('KV_PARALLEL_SAMPLES'))
+def _side_by_side(filelists=None):
+    """Samples counted side by side (each on its own HIP stream and with its own scratch buffers) or one after the other?
+    KV_PARALLEL_SAMPLES=1 / 0 says; otherwise side by side while the input is small enough (under 3 GB of files: reading
+    one file then overlaps inflating and counting another), one after the other beyond (the first allocation of three
+    sets of multi-gigabyte scratch buffers costs a cold one-shot run more than the overlap gains)."""
+    env = os.environ.get('KV_PARALLEL_SAMPLES')
+    if env is not None and env != '':
+        return env not in ('0', 'no', 'false')
+    if not filelists:
+        return False
+    try:
+        total = sum(os.path.getsize(path) for files in filelists for path in files if isinstance(path, str))
+    except OSError:
+        return False
+    return 0 < total < 3e9
 
 
 def load_samples(counttables=None, filelists=None, ksize=31, memory=1e6, maxfpr=0.2, numbands=None, band=None, numthreads=1,
@@ -67,7 +80,7 @@ def load_samples(counttables=None, filelists=None, ksize=31, memory=1e6, maxfpr=
     # it.  Not the default: every stream brings its own scratch buffers, and in a process that counts each sample once their
     # first allocation (gigabytes at config 2) costs more than the overlap gains (7.5 M reads per sample, cold: 1.09 s side by
     # side against 0.76 s one after the other; 2 M reads, buffers warm: 0.115 against 0.134 s).
-    if not _side_by_side():
+    if not _side_by_side(filelists):
         sketches = [kevlar_amd.count.load_sample_seqfile(files, ksize, memory, maxfpr=maxfpr, numbands=numbands, band=band,
                                                          numthreads=numthreads, log=log) for files in filelists]
         if outfilelist:
@@ -283,7 +296,7 @@ def main(args):
     clock = kevlar_amd.Timer()
     for key in (None, 'loadall', 'loadctrl'):
         clock.start(key)
-    if not _side_by_side():
+    if not _side_by_side((args.control or []) + (args.case or [])) or args.control_counts or args.case_counts:
         kevlar_amd.plog('[kevlar::novel] Loading control samples')
         controls = load_samples(args.control_counts, args.control, args.ksize, args.memory, args.max_fpr, args.num_bands, band,
                                 args.threads, args.save_ctrl_counts)

@@ -13,13 +13,13 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # the default bench counts the three samples concurrently on three streams; the trace and the counter passes run them
 # back to back (--count-streams 1) so that a kernel's duration and counters are its own
-BENCH_ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-replay --count-streams 1"
+BENCH_ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 --traffic none"
 timeout 900 python3 $REPO/bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
-timeout 600 python3 $REPO/bench.py --steps 10 --warmup 3 --count-streams 1 --no-cpu-baseline --no-e2e --no-replay > $OUT/bench_one_stream.json 2> $OUT/bench_one_stream.err
+timeout 600 python3 $REPO/bench.py --steps 10 --warmup 3 --count-streams 1 --no-cpu-baseline --no-e2e --no-replay --traffic none > $OUT/bench_one_stream.json 2> $OUT/bench_one_stream.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $BENCH_ARGS > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-replay > $OUT/bench_under_rocprof_default.json 2> $OUT/trace_default.err
-timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 > /dev/null 2> $OUT/pmc_fetch.err
-timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 > /dev/null 2> $OUT/pmc_write.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-replay --traffic none > $OUT/bench_under_rocprof_default.json 2> $OUT/trace_default.err
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 --traffic none > /dev/null 2> $OUT/pmc_fetch.err
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 --traffic none > /dev/null 2> $OUT/pmc_write.err
 # ingest: one ordinary gzip stream / one BGZF file of 2 M reads through the device inflaters
 (cd $REPO && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_gunzip -- python3 scratch/gunzip_rate.py 2000000 6 > $OUT/gunzip_rate.log 2> $OUT/trace_gunzip.err)
 (cd $REPO && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bgzf -- python3 scratch/inflate_rate.py 2000000 > $OUT/inflate_rate.log 2> $OUT/trace_bgzf.err)

@@ -22,17 +22,21 @@ def short_name(kernel):
     return name
 
 
-def main(src, dst):
-    os.makedirs(dst, exist_ok=True)
-    stats = sorted(glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime, reverse=True)
-    if stats:
-        with open(stats[0]) as fh, open(os.path.join(dst, 'kernel_stats.csv'), 'w') as out:
-            rows = list(csv.reader(fh))
-            w = csv.writer(out)
-            w.writerow(rows[0])
-            for row in rows[1:]:
-                if row and ('k_' in row[0] or 'memset' in row[0].lower() or 'rocprim' in row[0]):
-                    w.writerow(row)
+def kernel_sources_sha(root):
+    """sha256 over the kernel sources: a PMC file says which kernels it measured"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(root, 'kevlar_amd', 'csrc')
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(('.hip', '.h')):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def reduce_pmc(src):
+    """{'raw_KB_per_launch': ..., 'kernels': {name: {fetch_factor, launches_per_step, hbm_bytes_per_launch, hbm_bytes_per_step}}} from
+    the counter CSVs under src/pmc_fetch and src/pmc_write (one bench step each)"""
     pmc = {}
     for counter, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
         files = sorted(glob.glob(os.path.join(src, sub, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime, reverse=True)
@@ -58,8 +62,6 @@ def main(src, dst):
     # that holds for the streaming kernels here (checked against their known input sizes, profiles/README.md), while
     # random single-sector reads (the scan's table probes) calibrate at 1.0.
     streaming = ('k_skm_split', 'k_skm_count', 'k_bin_split', 'k_bin_apply', 'k_bin_hash', 'k_bin_list', 'k_skm_emit')
-    steps = 1
-    bench_line = os.path.join(src, 'bench_under_rocprof.json')
     kernels = {}
     for name, d in pmc.items():
         if not name.startswith('k_'):
@@ -69,9 +71,24 @@ def main(src, dst):
         launches = d.get('launches_FETCH_SIZE', d.get('launches_WRITE_SIZE', 0))      # the PMC passes run ONE step
         kernels[name] = {'fetch_factor': factor, 'launches_per_step': launches,
                          'hbm_bytes_per_launch': int((fetch_kb * factor + write_kb) * 1024),
-                         'hbm_bytes_per_step': int((fetch_kb * factor + write_kb) * 1024 * launches / steps)}
+                         'hbm_bytes_per_step': int((fetch_kb * factor + write_kb) * 1024 * launches)}
+    return {'raw_KB_per_launch': pmc, 'kernels': kernels}
+
+
+def main(src, dst):
+    os.makedirs(dst, exist_ok=True)
+    stats = sorted(glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime, reverse=True)
+    if stats:
+        with open(stats[0]) as fh, open(os.path.join(dst, 'kernel_stats.csv'), 'w') as out:
+            rows = list(csv.reader(fh))
+            w = csv.writer(out)
+            w.writerow(rows[0])
+            for row in rows[1:]:
+                if row and ('k_' in row[0] or 'memset' in row[0].lower() or 'rocprim' in row[0]):
+                    w.writerow(row)
     out = {'collected': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of bench.py --steps 1 --warmup 0 --count-streams 1',
-           'raw_KB_per_launch': pmc, 'kernels': kernels}
+           'kernel_sources_sha16': kernel_sources_sha(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))}
+    out.update(reduce_pmc(src))
     with open(os.path.join(dst, 'pmc_hbm_bytes.json'), 'w') as fh:
         json.dump(out, fh, indent=1)
     for name in ('bench.json', 'bench_under_rocprof.json', 'bench_one_stream.json', 'bench_under_rocprof_default.json'):

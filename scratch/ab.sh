@@ -15,7 +15,7 @@ for spec in "$@"; do
         export KV_LIB_PATH=$REPO/$lib
         IFS=',' read -ra kv <<< "$envs"
         for e in "${kv[@]}"; do [ -n "$e" ] && export "$e"; done
-        timeout 600 python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e --no-replay "${ARGS[@]}" > $OUT/$name.json 2> $OUT/$name.err
+        timeout 600 python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e --no-replay --traffic none "${ARGS[@]}" > $OUT/$name.json 2> $OUT/$name.err
     )
     python3 - "$OUT/$name.json" "$name" <<'PY'
 import json, sys
