@@ -587,20 +587,14 @@ __device__ __forceinline__ uint32_t skm_count_kmer(uint64_t h, uint32_t count, c
 {
     if (!consume_filter_pass(f, mask, h)) return 0;
     uint32_t left = min(count, 255u);                  // no counter holds more than 255
-    uint64_t bins[BIN_MAX_T];
-#pragma unroll
-    for (int t = 0; t < BIN_MAX_T; ++t) bins[t] = t < T ? fastmod(h, sk->size[t], sk->magic[t]) : 0ull;
-    // lane l starts with table l mod 4: one emit instruction of the wave then spreads over the cursors of all tables
-    // instead of 64 lanes sharing the ~20 cursors of one (same-address LDS atomics serialise)
-    const uint32_t rot = threadIdx.x & 3u;
+    // (tried: lane l starting with table l mod 4, so that one emit instruction spreads over the cursors of all tables instead
+    // of 64 lanes sharing the ~20 cursors of one -- 3.6 -> 4.2 ms: what costs is the number of distinct segments, i.e. cache
+    // lines, one store instruction touches, not the same-address LDS atomics; more coarse buckets cost the same way)
     while (left) {
         const uint32_t wgt = min(left, BIN_W_MAX);
 #pragma unroll
-        for (int i = 0; i < BIN_MAX_T; ++i) {
-            const uint32_t t = ((uint32_t)i + rot) & 3u;
-            const uint64_t bin = t == 0 ? bins[0] : (t == 1 ? bins[1] : (t == 2 ? bins[2] : bins[3]));
-            if ((int)t < T) emit((int)t, bin, wgt);
-        }
+        for (int t = 0; t < BIN_MAX_T; ++t)
+            if (t < T) emit(t, fastmod(h, sk->size[t], sk->magic[t]), wgt);
         left -= wgt;
     }
     return count;
