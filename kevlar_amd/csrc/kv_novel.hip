@@ -236,7 +236,7 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_emit(ReadsDev rd, Nov
 // set bits with a prefix sum and hands one hit to each lane; the lane rebuilds the k-mer and its reverse
 // complement in registers from the packed words and reads the S abundances.  Murmur kinds with k <= 64 (the
 // register windows of KmerRoll); other cases use k_novel_emit.
-template <int NW>
+template <int NW, bool ABUND>
 __global__ __launch_bounds__(256) void k_novel_emit_bits(ReadsDev rd, NovelParams p)
 {
     __shared__ uint32_t wcnt[256];      // set bits per word of the current chunk, then their exclusive prefix
@@ -297,6 +297,11 @@ __global__ __launch_bounds__(256) void k_novel_emit_bits(ReadsDev rd, NovelParam
             const uint64_t bit = ((w0 + lo) << 5) + (uint32_t)(__ffs((int)word) - 1);
             const uint64_t read = bit / p.mask_stride;
             const uint32_t off = (uint32_t)(bit - read * p.mask_stride);
+            if (!ABUND) {                               // positions only: k_hit_abund fills in the abundances, a thread per hit
+                p.hit_read[out + j] = (uint32_t)read;
+                p.hit_off[out + j] = off;
+                continue;
+            }
             // the k-mer and its reverse complement as ASCII register windows (byte 0 = first base)
             uint32_t wf[NW], wr[NW];
 #pragma unroll
@@ -323,6 +328,29 @@ __global__ __launch_bounds__(256) void k_novel_emit_bits(ReadsDev rd, NovelParam
         out += chunk_hits;
         emitted += chunk_hits;
         __syncthreads();
+    }
+}
+
+// The S abundances of every hit, a thread per hit.  (k_novel_emit_bits<.., true> does this inside the tile that found the
+// hit: ~20 of a workgroup's 256 threads then walk a chain of dependent loads -- word offset, words, twelve probes -- while
+// the others wait; with the hits listed first the same work runs at full occupancy.)
+template <int KW>
+__global__ __launch_bounds__(256) void k_hit_abund(ReadsDev rd, NovelParams p, uint64_t nhits)
+{
+    __shared__ uint32_t lut[256];
+    __shared__ NovelShared ns;
+    lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    load_descs(ns, p);
+    __syncthreads();
+    const int S = p.ncase + p.nctrl, k = p.hp.k;
+    const uint32_t uni_wpr = (rd.uni_len + 15u) >> 4;
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nhits; i += (uint64_t)gridDim.x * 256ull) {
+        const uint32_t read = p.hit_read[i], off = p.hit_off[i];
+        const uint32_t *words = rd.words + (rd.uni_len ? (uint64_t)read * uni_wpr : rd.woff[read]);
+        uint64_t bw[2] = {skm_bases32(words, off), KW == 2 ? skm_bases32(words, off + 32u) : 0ull};
+        const SkmKey<KW> f = skm_first_kmer<KW>(bw, k);
+        const uint64_t h = skm_key_hash<KW>(f, lut, p.hp);        // murmur(k-mer) ^ murmur(reverse complement): either strand
+        hit_abundances(ns, p, h, p.hit_abund + i * (uint64_t)S);
     }
 }
 
@@ -554,10 +582,18 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
         if (e == hipSuccess) {
             KvProfScope prof("k_novel_emit");
             const bool from_bits = fam == HF_MURMUR && k <= 64 && !getenv("KV_NOVEL_EMIT_TILES");
-            if (from_bits && k <= 32) {
-                hipLaunchKernelGGL(k_novel_emit_bits<8>, dim3(reads->n_tiles), dim3(256), 0, st, reads_dev(reads), p);
+            const bool dense = from_bits && k >= SKM_MIN_K && !getenv("KV_NOVEL_EMIT_FUSED");
+            const unsigned grid_hits = (unsigned)std::min<uint64_t>((nhits + 255) / 256, 1u << 16);
+            if (dense && k <= 32) {
+                hipLaunchKernelGGL((k_novel_emit_bits<8, false>), dim3(reads->n_tiles), dim3(256), 0, st, reads_dev(reads), p);
+                hipLaunchKernelGGL(k_hit_abund<1>, dim3(grid_hits), dim3(256), 0, st, reads_dev(reads), p, nhits);
+            } else if (dense) {
+                hipLaunchKernelGGL((k_novel_emit_bits<16, false>), dim3(reads->n_tiles), dim3(256), 0, st, reads_dev(reads), p);
+                hipLaunchKernelGGL(k_hit_abund<2>, dim3(grid_hits), dim3(256), 0, st, reads_dev(reads), p, nhits);
+            } else if (from_bits && k <= 32) {
+                hipLaunchKernelGGL((k_novel_emit_bits<8, true>), dim3(reads->n_tiles), dim3(256), 0, st, reads_dev(reads), p);
             } else if (from_bits) {
-                hipLaunchKernelGGL(k_novel_emit_bits<16>, dim3(reads->n_tiles), dim3(256), 0, st, reads_dev(reads), p);
+                hipLaunchKernelGGL((k_novel_emit_bits<16, true>), dim3(reads->n_tiles), dim3(256), 0, st, reads_dev(reads), p);
             } else {
                 kv_ensure_dynamic_lds((const void *)k_novel_emit, reads->tile_lds_bytes);
                 hipLaunchKernelGGL(k_novel_emit, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, st, reads_dev(reads), p);

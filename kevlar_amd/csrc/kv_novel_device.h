@@ -2,6 +2,7 @@
 // the tile scan (kv_novel.hip) and the per-distinct-k-mer scan over super-k-mer buckets (kv_skm.hip).
 #pragma once
 #include "kv_device.h"
+#include "kv_skm_device.h"
 
 struct NovelParams {
     HashParams hp;
@@ -48,6 +49,23 @@ struct NovelShared {
 };
 
 namespace {
+
+// (shared by the super-k-mer kernels of kv_skm.hip and the hit kernels of kv_novel.hip)
+// the two murmur hashes of a canonical k-mer: both strands expanded to ASCII register windows through the
+// 256-entry byte -> 4 characters table in LDS
+template <int KW>
+__device__ __forceinline__ uint64_t skm_key_hash(const SkmKey<KW> &c, const uint32_t *lut, const HashParams &hp)
+{
+    constexpr int NW = 8 * KW;
+    const SkmKey<KW> r = skm_revcomp<KW>(c, hp.k);
+    uint32_t wf[NW], wr[NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        wf[q] = lut[(uint32_t)(c.w[q >> 3] >> (8 * (q & 7))) & 0xffu];
+        wr[q] = lut[(uint32_t)(r.w[q >> 3] >> (8 * (q & 7))) & 0xffu];
+    }
+    return murmur_regs<NW>(wf, hp) ^ murmur_regs<NW>(wr, hp);
+}
 
 __device__ __forceinline__ bool band_pass(const NovelParams &p, uint64_t h)
 {

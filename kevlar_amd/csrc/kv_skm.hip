@@ -564,22 +564,6 @@ __device__ __forceinline__ int skm_table_find(const SkmTable<KW, TS> &tb, const 
     return -1;
 }
 
-// the two murmur hashes of a canonical k-mer: both strands expanded to ASCII register windows through the
-// 256-entry byte -> 4 characters table in LDS
-template <int KW>
-__device__ __forceinline__ uint64_t skm_key_hash(const SkmKey<KW> &c, const uint32_t *lut, const HashParams &hp)
-{
-    constexpr int NW = 8 * KW;
-    const SkmKey<KW> r = skm_revcomp<KW>(c, hp.k);
-    uint32_t wf[NW], wr[NW];
-#pragma unroll
-    for (int q = 0; q < NW; ++q) {
-        wf[q] = lut[(uint32_t)(c.w[q >> 3] >> (8 * (q & 7))) & 0xffu];
-        wr[q] = lut[(uint32_t)(r.w[q >> 3] >> (8 * (q & 7))) & 0xffu];
-    }
-    return murmur_regs<NW>(wf, hp) ^ murmur_regs<NW>(wr, hp);
-}
-
 // count side of one distinct k-mer seen `count` times: filter, then T weighted items through `emit(table, bin, weight)`
 template <typename Emit>
 __device__ __forceinline__ uint32_t skm_count_kmer(uint64_t h, uint32_t count, const SketchDev *__restrict__ sk,

@@ -6,7 +6,7 @@
 # --pmc pass per counter (FETCH_SIZE and WRITE_SIZE do not fit one pass; counters are never combined
 # with trace domains other than the kernel trace).
 set -u
-ROUND=${1:-r2_final}
+ROUND=${1:-r3_final}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/$ROUND
 mkdir -p "$OUT"
@@ -23,5 +23,12 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- 
 # ingest: one ordinary gzip stream / one BGZF file of 2 M reads through the device inflaters
 (cd $REPO && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_gunzip -- python3 scratch/gunzip_rate.py 2000000 6 > $OUT/gunzip_rate.log 2> $OUT/trace_gunzip.err)
 (cd $REPO && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bgzf -- python3 scratch/inflate_rate.py 2000000 > $OUT/inflate_rate.log 2> $OUT/trace_bgzf.err)
+# SQ counters of the count / scan kernels at their current shape (two --pmc passes of eight counters over one count of
+# each sample + one scan)
+(cd $REPO && bash scratch/pmc_skm.sh > $OUT/pmc_skm.log 2>&1)
+# config 5 (proband + 3 controls, k = 51): bench line and the profiler's kernel statistics
+timeout 900 python3 $REPO/bench.py --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-replay > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg5 -- python3 $REPO/bench.py --workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 > $OUT/bench_cfg5_under_rocprof.json 2> $OUT/trace_cfg5.err
 python3 $REPO/profiles/summarise.py $OUT $OUT/summary
+cp $REPO/gpurun_out/pmc_skm/summary.txt $OUT/summary/sq_counters.txt 2>/dev/null
 ls -la $OUT/summary

@@ -117,6 +117,18 @@ def main(src, dst):
                 for row in rows[1:]:
                     if row and 'k_' in row[0]:
                         w.writerow(row)
+    stats = sorted(glob.glob(os.path.join(src, 'trace_cfg5', '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime, reverse=True)
+    if stats:
+        with open(stats[0]) as fh, open(os.path.join(dst, 'cfg5_kernel_stats.csv'), 'w') as out:
+            rows = list(csv.reader(fh))
+            w = csv.writer(out)
+            w.writerow(rows[0])
+            for row in rows[1:]:
+                if row and ('k_' in row[0] or 'memset' in row[0].lower() or 'rocprim' in row[0]):
+                    w.writerow(row)
+    for name in ('bench_cfg5.json', 'bench_cfg5_under_rocprof.json'):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, name))
     for log in ('gunzip_rate.log', 'inflate_rate.log'):
         if os.path.exists(os.path.join(src, log)):
             shutil.copy(os.path.join(src, log), os.path.join(dst, log))
