@@ -84,7 +84,7 @@ def parse_args():
     p.add_argument('--e2e-reads', type=int, default=2000000, help='reads per sample written as FASTQ for the end-to-end leg')
     p.add_argument('--no-e2e', action='store_true')
     p.add_argument('--no-replay', action='store_true', help='skip the banded replays behind banded_checksums / replay_checksum')
-    p.add_argument('--exchange-items', default='auto', choices=['auto', 'distinct', 'plain'],
+    p.add_argument('--exchange-items', default='auto', choices=['auto', 'minimizer', 'distinct', 'plain'],
                    help='--multi exchange: distinct = (hash, occurrences) pairs of each rank\'s deduplicated shard (kv_route_distinct), '
                         'the scan answered as an all-gathered set of interesting k-mers (kv_novel_scan_set); plain = one hash per '
                         'k-mer, the case sample as (hash, tag) pairs scanned by the band owners; auto = distinct up to 4 GPUs '
@@ -255,7 +255,10 @@ def main():
     controls = names[1:]
     multi = args.multi if args.multi != 'auto' else ('exchange' if world >= 4 else 'banded')
     if args.exchange_items == 'auto':
-        args.exchange_items = 'distinct' if world <= 4 else 'plain'
+        # minimizer: super-k-mer records go to the owner of their minimizer bucket, who deduplicates at the sample's full
+        # coverage (needs 16 <= k <= 64); distinct: every rank deduplicates its own shard (little to combine at 1/8 of the
+        # coverage); plain: one hash per k-mer
+        args.exchange_items = 'minimizer' if 16 <= k <= 64 else ('distinct' if world <= 4 else 'plain')
     exchange = world > 1 and multi == 'exchange'
     per_batch = int(wl['batch_reads']) or n_reads
     upload_s = None
@@ -368,17 +371,23 @@ def main():
         for n in names:
             sketches[n].clear()
         kmers = 0
-        distinct = args.exchange_items == 'distinct'
+        distinct = args.exchange_items in ('distinct', 'minimizer')
+        by_minimizer = args.exchange_items == 'minimizer'
+
+        def begin(n_):
+            if by_minimizer:
+                return run.start_minimizer(batches[n_][0], bounds[n_][0], n_reads, L)
+            return run.start(batches[n_][0], bounds[n_][0], not distinct and n_ == names[0], distinct=distinct)
         if distinct:
             # counts travel as (hash, occurrences) pairs of each rank's deduplicated shard; the case sample goes last, so
             # its bucketed shard is still resident when the scan looks its k-mers up in the set of interesting ones
             order = list(controls) + [names[0]]
         else:
             order = list(names)         # the case sample travels as (hash, tag) pairs, counted and scanned by the owners
-        pending = run.start(batches[order[0]][0], bounds[order[0]][0], not distinct and order[0] == names[0], distinct=distinct)
+        pending = begin(order[0])
         for i, n in enumerate(order):
             nn = order[i + 1] if i + 1 < len(order) else None
-            nxt = run.start(batches[nn][0], bounds[nn][0], not distinct and nn == names[0], distinct=distinct) if nn else None
+            nxt = begin(nn) if nn else None
             kmers += run.finish(pending, sketches[n], keep_for_scan=(n == names[0]))
             pending = nxt
         t_b = time.perf_counter()
@@ -601,7 +610,9 @@ def main():
                 'parallelism': 'single band' if world == 1 else (
                     '{} k-mer bands, 1 per GPU; reads sharded, {} exchanged by band (all-to-all); hits all-gathered (the '
                     'per-band bit mask of north_star carries nothing beyond them)'.format(
-                        world, 'distinct (hash, occurrences) pairs' if args.exchange_items == 'distinct' else 'hashes') if exchange else
+                        world, {'distinct': 'distinct (hash, occurrences) pairs of each shard',
+                                'minimizer': 'super-k-mer records first exchanged by minimizer bucket, then the bucket owners\' distinct '
+                                             '(hash, occurrences) pairs'}.get(args.exchange_items, 'hashes')) if exchange else
                     ('{} k-mer bands, 1 per GPU; every rank streams all reads; per-band bit masks all-reduced (asserted equal to the '
                      'gathered hits), hits all-gathered for their abundances' if band_mask is not None else
                      '{} k-mer bands, 1 per GPU; every rank streams all reads; hits all-gathered (the per-band bit mask of '

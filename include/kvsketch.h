@@ -334,6 +334,29 @@ int kv_bgzf_inflate_host(const void *file, uint64_t size, void *out, uint64_t ou
 int kv_gunzip_host(const void *file, uint64_t size, void *out, uint64_t out_cap, uint64_t segment_text,
                    uint64_t *text_bytes, uint64_t *stats, double *device_ms);
 
+/* ---- minimizer-sharded exchange (multi-GPU count; no reference counterpart beyond banding itself, docs/banding.rst) ------
+ * kevlar splits a trio over workers by k-mer band, and every worker reads every read (kevlar/count.py:62-66).  On one node
+ * rank r instead holds reads [r n/N, (r+1) n/N) of every sample.  kv_mex_emit cuts its shard into super-k-mer records and
+ * leaves them grouped by minimizer bucket in the caller's exchange buffer (records: plan->seg_words u64 words laid out
+ * [C1][nwg1][cap1][recw]; counts: plan->cnt_entries u32, [C1][nwg1]); bucket range [c_lo[d], c_lo[d+1]) is rank d's, so one
+ * all-to-all with those split points delivers every occurrence of a k-mer -- whichever shard it came from -- to one rank.
+ * kv_mex_route combines what n_src ranks sent (the slabs one after the other, as all_to_all_single leaves them) at the
+ * sample's full coverage and writes one (hash, occurrences) pair per distinct k-mer for the hash band's owner: the output
+ * of kv_route_distinct, which the band owners add with kv_consume_hashes_weighted.  Every rank derives the same plan from
+ * the sample's global size.                                                                                              */
+typedef struct kv_mex_plan {
+    int32_t ksize, ndest;
+    uint32_t C1, F2, fbits, nwg1, cap1, recw, m, read_len;
+    uint64_t seg_words, cnt_entries;
+    uint64_t n_kmers_global, n_reads_global;
+    uint32_t c_lo[17];
+    uint32_t pad;
+} kv_mex_plan;
+int kv_mex_plan_make(int kind, int ksize, uint64_t n_reads_global, uint32_t read_len, int ndest, kv_mex_plan *plan);
+int kv_mex_emit(const kv_reads *shard, const kv_mex_plan *plan, uint64_t read_base, void *d_seg, void *d_cnt);
+int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_recv_seg, const void *d_recv_cnt, int n_src,
+                 void *d_out, uint64_t cap_items, uint64_t *counts_out, uint64_t *n_kmers_in);
+
 #ifdef __cplusplus
 }
 #endif

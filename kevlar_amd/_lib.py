@@ -110,8 +110,18 @@ SIGNATURES = {
     'kv_novel_scan_distinct': (i32, [vpp, i32, vpp, i32, vp, u64, i32, i32, vp, vp, u64, u64p]),
     'kv_novel_scan_set': (i32, [vp, i32, i32, i32, vp, vp, u64, vpp]),
     'kv_hits_from_tagged': (i32, [vp, vp, u64, u64, i32, vpp]),
+    'kv_mex_plan_make': (i32, [i32, i32, u64, u32, i32, vp]),
+    'kv_mex_emit': (i32, [vp, vp, u64, vp, vp]),
+    'kv_mex_route': (i32, [vp, i32, vp, vp, i32, vp, u64, u64p, u64p]),
     'kv_readgraph_components': (i32, [vp, i32, u32p, u32p, u64, u32p, u32, u32, u32, u32p, u64p]),
 }
+
+
+class MexPlan(ctypes.Structure):
+    """kv_mex_plan of include/kvsketch.h"""
+    _fields_ = [('ksize', ctypes.c_int32), ('ndest', ctypes.c_int32), ('C1', u32), ('F2', u32), ('fbits', u32), ('nwg1', u32),
+                ('cap1', u32), ('recw', u32), ('m', u32), ('read_len', u32), ('seg_words', u64), ('cnt_entries', u64),
+                ('n_kmers_global', u64), ('n_reads_global', u64), ('c_lo', u32 * 17), ('pad', u32)]
 
 
 class KvError(RuntimeError):

@@ -204,6 +204,12 @@ struct KvRouteSink {
 // (hash, count) of every DISTINCT k-mer of `reads` -- deduplicated in super-k-mer buckets -- routed by band.
 // `alloc(nwg, sink)` is called once the number of writers is known and must fill *sink.
 int kv_skm_route_distinct(const kv_reads *reads, int ksize, uint64_t n_kmers, int ndest, int (*alloc)(void *ctx, uint32_t nwg, KvRouteSink *sink), void *ctx);
+// minimizer-sharded exchange (kv_skm.hip): the plan every rank derives from the sample's global size, S1 into the caller's
+// exchange buffers, S2 + distinct route over what arrived
+int kv_skm_mex_plan(int ksize, uint64_t n_reads_global, uint32_t read_len, int ndest, kv_mex_plan *plan);
+int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t read_base, uint64_t *d_seg, uint32_t *d_cnt);
+int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_recv_seg, const uint32_t *d_recv_cnt, int n_src,
+                     int (*alloc)(void *ctx, uint32_t nwg, KvRouteSink *sink), void *ctx, uint64_t *n_kmers_in);
 
 // tile geometry of the hashing kernels
 #define KV_TILE_THREADS 256

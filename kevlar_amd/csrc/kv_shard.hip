@@ -414,6 +414,53 @@ extern "C" int kv_route_distinct(const kv_reads *reads, int kind, int ksize, int
     return route_pack(p, 2, st, counts_out, &done);
 }
 
+extern "C" int kv_mex_plan_make(int kind, int ksize, uint64_t n_reads_global, uint32_t read_len, int ndest, kv_mex_plan *plan)
+{
+    KV_REQUIRE(kv_hashfam_of(kind) == HF_MURMUR, KV_ERR_ARG, "kv_mex_plan_make: the super-k-mer front end takes the murmur sketch kinds");
+    return kv_skm_mex_plan(ksize, n_reads_global, read_len, ndest, plan);
+}
+
+extern "C" int kv_mex_emit(const kv_reads *shard, const kv_mex_plan *plan, uint64_t read_base, void *d_seg, void *d_cnt)
+{
+    KV_REQUIRE(shard && plan && d_seg && d_cnt, KV_ERR_ARG, "kv_mex_emit: null argument");
+    return kv_skm_mex_emit(shard, plan, read_base, (uint64_t *)d_seg, (uint32_t *)d_cnt);
+}
+
+extern "C" int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_recv_seg, const void *d_recv_cnt, int n_src,
+                            void *d_out, uint64_t cap_items, uint64_t *counts_out, uint64_t *n_kmers_in)
+{
+    KV_REQUIRE(plan && d_recv_seg && d_recv_cnt && d_out && counts_out && n_kmers_in, KV_ERR_ARG, "kv_mex_route: null argument");
+    const int ndest = plan->ndest;
+    for (int d = 0; d < ndest; ++d) counts_out[d] = 0;
+    hipStream_t st = kv_stream();
+    RouteParams p;
+    memset(&p, 0, sizeof(p));
+    p.ndest = ndest;
+    p.bs = UINT64_MAX / (uint64_t)ndest;
+    p.cap = cap_items;
+    p.out = (uint64_t *)d_out;
+    // every k-mer occurrence that arrived could be a pair of its own: the sink is sized for this rank's expected share
+    // with slack, and the caller's buffer must hold what actually arrived (checked below, before anything is packed)
+    const uint64_t expect = plan->n_kmers_global / (uint64_t)ndest;
+    struct Ctx { RouteParams *p; uint64_t n_kmers; hipStream_t st; } ctx = {&p, expect + expect / 4 + (1u << 20), st};
+    auto alloc = [](void *c, uint32_t nwg, KvRouteSink *sink) -> int {
+        Ctx *x = (Ctx *)c;
+        RouteParams &q = *x->p;
+        q.nwg = nwg;
+        const int rc = route_scratch(q, x->n_kmers, 2, x->st);
+        if (rc != KV_OK) return rc;
+        sink->ndest = q.ndest; sink->nwg = q.nwg; sink->bs = q.bs; sink->seg_cap = q.seg_cap; sink->seg = q.seg;
+        sink->seg_count = q.seg_count; sink->ovf = q.ovf; sink->ovf_dest = q.ovf_dest; sink->ovf_cap = q.ovf_cap; sink->ctr = q.ctr;
+        return KV_OK;
+    };
+    { const int rc = kv_skm_mex_route(plan, my_dest, (const uint64_t *)d_recv_seg, (const uint32_t *)d_recv_cnt, n_src, alloc, &ctx, n_kmers_in); if (rc != KV_OK) return rc; }
+    KV_REQUIRE(*n_kmers_in <= cap_items, KV_ERR_CAPACITY, "kv_mex_route: %llu k-mers arrived, the output holds %llu pairs",
+               (unsigned long long)*n_kmers_in, (unsigned long long)cap_items);
+    if (p.nwg == 0 || p.seg == nullptr) return KV_OK;
+    unsigned long long done = 0;
+    return route_pack(p, 2, st, counts_out, &done);
+}
+
 // n_total gathered hits (tag, S abundance bytes each), of which the n_valid smallest tags are real
 // (padding carries tag ~0): sort by tag = (read, offset) and hand back an ordinary kv_hits.
 extern "C" int kv_hits_from_tagged(const void *d_tags, const void *d_abund, uint64_t n_total, uint64_t n_valid,

@@ -44,7 +44,20 @@ struct SkmGeom {
     // abundance list the count pass writes (KvAbundList; abl_keys == nullptr: off): every workgroup appends to its own
     // stretch of abl_cap_wg entries and notes where each bucket's entries start
     uint64_t *abl_keys; uint8_t *abl_cnts; uint32_t *abl_bstart, *abl_bcount; uint32_t abl_cap_wg;
+    // S2 over records that several ranks emitted (minimizer-sharded exchange, kv_skm_mex_route): seg1 / cnt1 then hold n_src
+    // slabs of [C1][nwg1] segments one after the other, and a coarse bucket has n_src * nwg1 segments (0 / 1: the usual one slab)
+    uint32_t n_src;
+    uint64_t read_base;              // global index of the batch's first read (record positions of a read shard; 0 otherwise)
 };
+
+// segment `seg` of coarse bucket c in seg1 / cnt1, counted in segments
+__device__ __forceinline__ uint64_t skm_seg1_slot(const SkmGeom &sg, uint32_t c, uint32_t seg)
+{
+    if (sg.n_src <= 1u) return (uint64_t)c * sg.nwg1 + seg;
+    const uint32_t src = seg / sg.nwg1, w = seg - src * sg.nwg1;
+    return ((uint64_t)src * sg.C1 + c) * sg.nwg1 + w;
+}
+__device__ __forceinline__ uint32_t skm_seg1_count(const SkmGeom &sg) { return sg.nwg1 * (sg.n_src > 1u ? sg.n_src : 1u); }
 
 // the controls' abundance lists a scan may use (same bucket geometry as the case sample's buckets)
 #define SKM_MAX_ABL 8
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
             const uint32_t nxt = i + 1 < nstart ? starts[i + 1] : limit;       // the next run (of this read or a later one)
             uint32_t left = (nxt < limit ? nxt : limit) - q;
             const uint32_t coarse = id >> 8, fine = (id & 0xffu) | (((idhi[q >> 3] >> (4u * (q & 7u))) & 15u) << 8);
-            uint64_t pos = (uint64_t)(sh.read0 + r) * sg.stride + sh.seg_start + j;
+            uint64_t pos = (sg.read_base + sh.read0 + r) * sg.stride + sh.seg_start + j;
             uint32_t b = sh.wpre[r] * 16u + j;                // base index inside wl
             while (left) {
                 const uint32_t n = min(left, (uint32_t)sg.ncap);
@@ -371,8 +384,8 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split(SkmGeom sg)
     const uint32_t c = blockIdx.y;
     for (uint32_t f = threadIdx.x; f < sg.F2; f += SKM_THREADS2) cur[f] = 0;
     // segments seg = blockIdx.x, blockIdx.x + nwg2, ...: their records are enumerated flat, so every thread has work
-    const uint32_t nmine = (sg.nwg1 - blockIdx.x + sg.nwg2 - 1) / sg.nwg2;       // <= 768
-    for (uint32_t i = threadIdx.x; i < nmine; i += SKM_THREADS2) spre[i + 1] = sg.cnt1[(uint64_t)c * sg.nwg1 + blockIdx.x + i * sg.nwg2];
+    const uint32_t nmine = (skm_seg1_count(sg) - blockIdx.x + sg.nwg2 - 1) / sg.nwg2;       // <= 768
+    for (uint32_t i = threadIdx.x; i < nmine; i += SKM_THREADS2) spre[i + 1] = sg.cnt1[skm_seg1_slot(sg, c, blockIdx.x + i * sg.nwg2)];
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t acc = 0;
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split(SkmGeom sg)
     for (uint32_t i = threadIdx.x; i < total; i += SKM_THREADS2) {
         const uint32_t si = skm_search(spre, nmine, i);
         const uint32_t seg = blockIdx.x + si * sg.nwg2;
-        const uint64_t *rec = sg.seg1 + (((uint64_t)c * sg.nwg1 + seg) * sg.cap1 + (i - spre[si])) * (uint64_t)recw;
+        const uint64_t *rec = sg.seg1 + (skm_seg1_slot(sg, c, seg) * sg.cap1 + (i - spre[si])) * (uint64_t)recw;
         const uint64_t hdr = rec[0];
         uint64_t bw[3];
 #pragma unroll
@@ -421,8 +434,8 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split_sorted(SkmGeom sg)
     const uint32_t c = blockIdx.y, F2 = sg.F2;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t f = threadIdx.x; f < F2; f += SKM_THREADS2) { cur[f] = 0; hist[f] = 0; }
-    const uint32_t nmine = (sg.nwg1 - blockIdx.x + sg.nwg2 - 1) / sg.nwg2;       // <= 768
-    for (uint32_t i = threadIdx.x; i < nmine; i += SKM_THREADS2) spre[i + 1] = sg.cnt1[(uint64_t)c * sg.nwg1 + blockIdx.x + i * sg.nwg2];
+    const uint32_t nmine = (skm_seg1_count(sg) - blockIdx.x + sg.nwg2 - 1) / sg.nwg2;       // <= 768
+    for (uint32_t i = threadIdx.x; i < nmine; i += SKM_THREADS2) spre[i + 1] = sg.cnt1[skm_seg1_slot(sg, c, blockIdx.x + i * sg.nwg2)];
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t acc = 0;
@@ -446,7 +459,7 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split_sorted(SkmGeom sg)
             if (i < n) {
                 const uint32_t gi = c0 + i, si = skm_search(spre, nmine, gi);
                 const uint32_t seg = blockIdx.x + si * sg.nwg2;
-                const uint64_t *rec = sg.seg1 + (((uint64_t)c * sg.nwg1 + seg) * sg.cap1 + (gi - spre[si])) * (uint64_t)RECW;
+                const uint64_t *rec = sg.seg1 + (skm_seg1_slot(sg, c, seg) * sg.cap1 + (gi - spre[si])) * (uint64_t)RECW;
                 hdr[r] = rec[0]; w0[r] = rec[1]; w1[r] = rec[2];
                 if (RECW == 4) w2[r] = rec[3];
             }
@@ -1183,6 +1196,69 @@ inline uint32_t pow2_ceil(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; r
 
 int skm_minimizer_len(int k) { return k >= 24 ? 12 : k / 2; }
 
+void skm_launch_emit(const SkmGeom &g, const kv_reads *reads, hipStream_t st)
+{
+    KvProfScope prof("k_skm_emit");
+    const size_t lds = ((size_t)g.np_max / 16 + KV_TILE_MAX_READS + 8 + (size_t)g.np_max + 96) * 4 + (((size_t)g.np_max + 96 + 1) & ~(size_t)1) * 2 +
+                       ((size_t)g.np_max / 8 + 8) * 4;
+    if (g.w > 16) {
+        kv_ensure_dynamic_lds((const void *)k_skm_emit<16>, lds);
+        hipLaunchKernelGGL(k_skm_emit<16>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), reads->n_tiles, g);
+    } else {
+        kv_ensure_dynamic_lds((const void *)k_skm_emit<8>, lds);
+        hipLaunchKernelGGL(k_skm_emit<8>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), reads->n_tiles, g);
+    }
+}
+
+void skm_launch_split(const SkmGeom &g, hipStream_t st)
+{
+    KvProfScope prof("k_skm_split");
+    // sorted scatter while a chunk holds ~2 records per fine bucket or more (KV_SKM_S2=plain|sorted overrides)
+    const char *s2 = getenv("KV_SKM_S2");
+    const bool sorted = s2 ? strcmp(s2, "sorted") == 0 && g.F2 <= SKM_S2_MAXF : g.F2 <= SKM_S2_MAXF;
+    if (sorted) {
+        const size_t lds = (size_t)SKM_S2_CHUNK * g.recw * 8;
+        if (g.recw == 3) {
+            kv_ensure_dynamic_lds((const void *)k_skm_split_sorted<3>, lds);
+            hipLaunchKernelGGL(k_skm_split_sorted<3>, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), lds, st, g);
+        } else {
+            kv_ensure_dynamic_lds((const void *)k_skm_split_sorted<4>, lds);
+            hipLaunchKernelGGL(k_skm_split_sorted<4>, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), lds, st, g);
+        }
+    } else {
+        hipLaunchKernelGGL(k_skm_split, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), 0, st, g);
+    }
+}
+
+// k-dependent part of the geometry
+void skm_geom_k(SkmGeom &g, int k)
+{
+    memset(&g, 0, sizeof(g));
+    g.k = k;
+    g.m = skm_minimizer_len(k);
+    g.w = k - g.m + 1;
+    g.wpow = 1;
+    while (g.wpow * 2 <= g.w) g.wpow *= 2;
+    g.kw = k <= 32 ? 1 : 2;
+    g.nbw = g.kw + 1;
+    g.recw = 1 + g.nbw;
+    g.ncap = 32 * g.nbw - k + 1;
+    g.sbw = ((64u * (uint32_t)g.ncap) >> 5) + 2u;
+    g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
+}
+
+__global__ void k_mex_sum_kmers(const uint64_t *seg, const uint32_t *cnt, uint64_t n_segments, uint32_t cap1, uint32_t recw, unsigned long long *out)
+{
+    unsigned long long mine = 0;
+    for (uint64_t sgi = blockIdx.x; sgi < n_segments; sgi += gridDim.x) {
+        const uint32_t n = min(cnt[sgi], cap1);
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) mine += skm_hdr_n(seg[(sgi * cap1 + i) * recw]);
+    }
+    mine = wave_sum_u64(mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+
+
 // cut `reads` into super-k-mers and bucket them (S1 + S2); idx.mu held by the caller
 // distinct_frac: the share of distinct k-mers the caller expects (0: sequencing coverage of a whole sample, ~0.3)
 int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hipStream_t st, double distinct_frac = 0.0)
@@ -1270,36 +1346,8 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.sbw = ((64u * (uint32_t)g.ncap) >> 5) + 2u;
     g.bucket_kmers = std::max<uint64_t>(1, n_kmers / g.n_buckets);
     g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
-    {
-        KvProfScope prof("k_skm_emit");
-        const size_t lds = ((size_t)g.np_max / 16 + KV_TILE_MAX_READS + 8 + (size_t)g.np_max + 96) * 4 + (((size_t)g.np_max + 96 + 1) & ~(size_t)1) * 2 +
-                           ((size_t)g.np_max / 8 + 8) * 4;
-        if (g.w > 16) {
-            kv_ensure_dynamic_lds((const void *)k_skm_emit<16>, lds);
-            hipLaunchKernelGGL(k_skm_emit<16>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), reads->n_tiles, g);
-        } else {
-            kv_ensure_dynamic_lds((const void *)k_skm_emit<8>, lds);
-            hipLaunchKernelGGL(k_skm_emit<8>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), reads->n_tiles, g);
-        }
-    }
-    {
-        KvProfScope prof("k_skm_split");
-        // sorted scatter while a chunk holds ~2 records per fine bucket or more (KV_SKM_S2=plain|sorted overrides)
-        const char *s2 = getenv("KV_SKM_S2");
-        const bool sorted = s2 ? strcmp(s2, "sorted") == 0 && g.F2 <= SKM_S2_MAXF : g.F2 <= SKM_S2_MAXF;
-        if (sorted) {
-            const size_t lds = (size_t)SKM_S2_CHUNK * g.recw * 8;
-            if (g.recw == 3) {
-                kv_ensure_dynamic_lds((const void *)k_skm_split_sorted<3>, lds);
-                hipLaunchKernelGGL(k_skm_split_sorted<3>, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), lds, st, g);
-            } else {
-                kv_ensure_dynamic_lds((const void *)k_skm_split_sorted<4>, lds);
-                hipLaunchKernelGGL(k_skm_split_sorted<4>, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), lds, st, g);
-            }
-        } else {
-            hipLaunchKernelGGL(k_skm_split, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), 0, st, g);
-        }
-    }
+    skm_launch_emit(g, reads, st);
+    skm_launch_split(g, st);
     KV_HIP(hipGetLastError());
     KV_HIP(hipMemcpyAsync(&g.ctr[6], &g.ctr[0], 8, hipMemcpyDeviceToDevice, st));   // loose records S1/S2 left behind
     const uint32_t nwg3 = skm_nwg3(g);
@@ -1312,6 +1360,7 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     idx.valid = true;
     return KV_OK;
 }
+
 
 }  // namespace
 
@@ -1547,6 +1596,169 @@ int kv_skm_route_distinct(const kv_reads *reads, int ksize, uint64_t n_kmers, in
     if (sctr[1] != 0) {
         idx.valid = false;
         kv_set_error("super-k-mer route: loose record list overflow (%llu records)", sctr[0]);
+        return KV_ERR_CAPACITY;
+    }
+    return KV_OK;
+}
+
+
+// ---- minimizer-sharded exchange (kevlar_amd/shardrun.py) ------------------------------------------------
+// N ranks each hold 1/N of a sample's reads.  Deduplicating a shard on its own finds little to combine at 1/8 of the
+// coverage, so the shards are cut into super-k-mers first (S1, here), the RECORDS travel to the rank that owns their
+// minimizer bucket -- every occurrence of a k-mer, from whichever shard, meets there -- and that rank combines them at the
+// sample's full coverage (S2 + the distinct route below) before (hash, occurrences) pairs go on to the band owners.
+int kv_skm_mex_plan(int ksize, uint64_t n_reads_global, uint32_t read_len, int ndest, kv_mex_plan *plan)
+{
+    KV_REQUIRE(plan && ndest >= 1 && ndest <= SKM_ROUTE_MAX_DEST && ksize >= SKM_MIN_K && ksize <= SKM_MAX_K && read_len >= (uint32_t)ksize,
+               KV_ERR_ARG, "kv_mex_plan: k in %d..%d, 1..%d destinations, reads of at least k bases", SKM_MIN_K, SKM_MAX_K, SKM_ROUTE_MAX_DEST);
+    memset(plan, 0, sizeof(*plan));
+    SkmGeom g;
+    skm_geom_k(g, ksize);
+    const uint64_t nk_read = read_len - (uint32_t)ksize + 1u;
+    const uint64_t n_kmers = n_reads_global * nk_read;
+    const uint32_t table_slots = g.kw == 1 ? 4096u : 2048u;
+    const uint64_t target = g.kw == 1 ? 2ull * table_slots : table_slots + table_slots / 2;       // a whole sample at sequencing coverage (~0.2 distinct)
+    const uint64_t nfine = std::max<uint64_t>(1, (n_kmers + target - 1) / target);
+    uint32_t F2 = std::min<uint32_t>(512u, pow2_ceil((uint64_t)std::ceil(std::sqrt((double)nfine))));
+    if (nfine > 255ull * F2) F2 = std::min<uint32_t>(SKM_MAX_F2, pow2_ceil((nfine + 254) / 255));
+    uint32_t C1 = (uint32_t)std::min<uint64_t>(255, std::max<uint64_t>(1, (nfine + F2 - 1) / F2));
+    C1 = (uint32_t)kv_round_up(C1, (uint64_t)ndest);
+    if (C1 > 255u) C1 = 255u / (uint32_t)ndest * (uint32_t)ndest;
+    uint32_t fbits = 0;
+    while ((1u << fbits) < F2) ++fbits;
+    const uint64_t shard_reads = (n_reads_global + ndest - 1) / ndest;
+    const uint64_t tiles = (shard_reads + KV_TILE_MAX_READS - 1) / KV_TILE_MAX_READS;
+    const uint32_t nwg1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((tiles + SKM_TILES_PER_TICKET - 1) / SKM_TILES_PER_TICKET, 768));
+    const double rec_est = (double)(shard_reads * nk_read) * 2.2 / (double)(g.w + 1) + (double)shard_reads + 1024.0;
+    const double m1 = rec_est / ((double)C1 * nwg1);
+    const uint32_t cap1 = (uint32_t)kv_round_up((uint64_t)(m1 * 2.0 + 8.0 * std::sqrt(m1)) + 64, 16);
+    plan->ksize = ksize; plan->ndest = ndest; plan->C1 = C1; plan->F2 = F2; plan->fbits = fbits; plan->nwg1 = nwg1; plan->cap1 = cap1;
+    plan->recw = (uint32_t)g.recw; plan->m = (uint32_t)g.m;
+    plan->seg_words = (uint64_t)C1 * nwg1 * cap1 * g.recw;
+    plan->cnt_entries = (uint64_t)C1 * nwg1;
+    for (int d = 0; d <= ndest; ++d) plan->c_lo[d] = (uint32_t)((uint64_t)C1 * d / ndest);
+    plan->n_kmers_global = n_kmers; plan->n_reads_global = n_reads_global; plan->read_len = read_len;
+    return KV_OK;
+}
+
+// S1 of one shard into the caller's buffers ([C1][nwg1][cap1] records, [C1][nwg1] counts: what the plan says)
+int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t read_base, uint64_t *d_seg, uint32_t *d_cnt)
+{
+    hipStream_t st = kv_stream();
+    SkmIndex &idx = skm_index_for(st);
+    std::lock_guard<std::mutex> lk(idx.mu);
+    idx.valid = false;
+    SkmGeom &g = idx.g;
+    skm_geom_k(g, plan->ksize);
+    g.C1 = plan->C1; g.F2 = plan->F2; g.fbits = plan->fbits; g.n_buckets = g.C1 * g.F2;
+    g.nwg1 = plan->nwg1; g.cap1 = plan->cap1;
+    g.quota1 = 0xfffffff0u;                                   // tiles are dealt dynamically; the plan's capacity has the slack
+    g.np_max = std::max<uint32_t>(reads->tile_max_bases, 64u);
+    g.stride = plan->read_len - (uint32_t)plan->ksize + 1u;
+    KV_REQUIRE(reads->max_len <= plan->read_len, KV_ERR_ARG, "kv_mex_emit: a read of %u bases in a plan for %u", reads->max_len, plan->read_len);
+    KV_REQUIRE(reads->tile_max_bases > 0 && reads->tile_max_bases <= 8192u, KV_ERR_ARG, "kv_mex_emit: reads too long for the super-k-mer front end");
+    g.read_base = read_base;
+    g.seg1 = d_seg; g.cnt1 = d_cnt;
+    g.loose_cap = 1u << 16;
+    const size_t b_loose = kv_round_up(g.loose_cap * (size_t)g.recw * 8, 256), b_ctr = 256;
+    KV_HIP(idx.arena.need(b_loose + b_ctr));
+    g.loose = (uint64_t *)idx.arena.p;
+    g.ctr = (unsigned long long *)((unsigned char *)idx.arena.p + b_loose);
+    KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));
+    // a workgroup that takes no tile still writes its counts; workgroups beyond the grid never run: zero them
+    KV_HIP(hipMemsetAsync(d_cnt, 0, plan->cnt_entries * 4, st));
+    if (reads->n_tiles) {
+        g.nwg1 = plan->nwg1;
+        skm_launch_emit(g, reads, st);
+    }
+    KV_HIP(hipGetLastError());
+    unsigned long long ctr[2] = {0, 0};
+    KV_HIP(hipMemcpyAsync(ctr, g.ctr, sizeof(ctr), hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    // records that miss their segment have nowhere to travel in: the plan's capacity is twice the expected fill, so this
+    // means a pathological input (one minimizer everywhere); no silent change of layout
+    KV_REQUIRE(ctr[0] == 0 && ctr[1] == 0, KV_ERR_CAPACITY, "kv_mex_emit: %llu records did not fit their exchange segment", ctr[0]);
+    return KV_OK;
+}
+
+// the records n_src ranks sent for this rank's Cl coarse buckets -> S2 -> every distinct k-mer once as a (hash, occurrences)
+// pair for its band's owner (the callback allocates the sink, as for kv_skm_route_distinct)
+int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_recv_seg, const uint32_t *d_recv_cnt, int n_src,
+                     int (*alloc)(void *ctx, uint32_t nwg, KvRouteSink *sink), void *ctx, uint64_t *n_kmers_in)
+{
+    KV_REQUIRE(plan && my_dest >= 0 && my_dest < plan->ndest && n_src >= 1, KV_ERR_ARG, "kv_mex_route: bad argument");
+    hipStream_t st = kv_stream();
+    SkmIndex &idx = skm_index_for(st);
+    std::lock_guard<std::mutex> lk(idx.mu);
+    idx.valid = false;
+    SkmGeom &g = idx.g;
+    skm_geom_k(g, plan->ksize);
+    const uint32_t Cl = plan->c_lo[my_dest + 1] - plan->c_lo[my_dest];
+    g.C1 = Cl; g.F2 = plan->F2; g.fbits = plan->fbits; g.n_buckets = Cl * g.F2;
+    g.nwg1 = plan->nwg1; g.cap1 = plan->cap1; g.n_src = (uint32_t)n_src;
+    g.seg1 = const_cast<uint64_t *>(d_recv_seg); g.cnt1 = const_cast<uint32_t *>(d_recv_cnt);
+    g.stride = plan->read_len - (uint32_t)plan->ksize + 1u;
+    if (Cl == 0) { *n_kmers_in = 0; KvRouteSink rs; memset(&rs, 0, sizeof(rs)); return alloc(ctx, 1, &rs); }
+    const uint32_t nseg = g.nwg1 * g.n_src;
+    g.nwg2 = std::max<uint32_t>(std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / Cl)), (nseg + 767u) / 768u);
+    g.nwg2 = std::min<uint32_t>(g.nwg2, nseg);
+    KV_REQUIRE((nseg + g.nwg2 - 1) / g.nwg2 <= 768u, KV_ERR_ARG, "kv_mex_route: %u segments per bucket", nseg);
+    // this rank's share of the sample: its buckets hold 1 / ndest of the k-mers, give or take the hash's evenness
+    const uint64_t n_kmers_exp = plan->n_kmers_global / (uint64_t)plan->ndest + 1;
+    const double rec_est = (double)n_kmers_exp * 2.2 / (double)(g.w + 1) + (double)plan->n_reads_global / plan->ndest + 1024.0;
+    const double m2 = rec_est / ((double)g.n_buckets * g.nwg2);
+    g.cap2 = (uint32_t)kv_round_up((uint64_t)(m2 * 1.4 + 8.0 * std::sqrt(m2)) + 32, 16);
+    g.loose_cap = (uint64_t)(rec_est / 8.0) + n_kmers_exp / 16 + (1u << 20);
+    const size_t rb = (size_t)g.recw * 8;
+    const size_t b_seg2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * g.cap2 * rb, 256), b_cnt2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * 4, 256);
+    const size_t b_loose = kv_round_up(g.loose_cap * rb, 256), b_ctr = 256;
+    KV_HIP(idx.arena.need(b_seg2 + b_cnt2 + b_loose + b_ctr));
+    unsigned char *base = (unsigned char *)idx.arena.p;
+    g.seg2 = (uint64_t *)base; base += b_seg2;
+    g.cnt2 = (uint32_t *)base; base += b_cnt2;
+    g.loose = (uint64_t *)base; base += b_loose;
+    g.ctr = (unsigned long long *)base;
+    KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));
+    g.bucket_kmers = std::max<uint64_t>(1, n_kmers_exp / g.n_buckets);
+    // how many k-mer occurrences arrived (the caller's buffer must hold a pair for each in the worst case)
+    hipLaunchKernelGGL(k_mex_sum_kmers, dim3(1024), dim3(256), 0, st, g.seg1, g.cnt1, (uint64_t)Cl * nseg, g.cap1, (uint32_t)g.recw, &g.ctr[8]);
+    skm_launch_split(g, st);
+    KV_HIP(hipGetLastError());
+    KV_HIP(hipMemcpyAsync(&g.ctr[6], &g.ctr[0], 8, hipMemcpyDeviceToDevice, st));
+    unsigned long long arrived = 0;
+    KV_HIP(hipMemcpyAsync(&arrived, &g.ctr[8], 8, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    *n_kmers_in = arrived;
+    const uint32_t nwg3 = skm_nwg3(g);
+    {
+        const uint64_t avg = (g.n_buckets + nwg3 - 1) / nwg3;
+        g.quota3 = (uint32_t)kv_round_up(avg + avg / 2 + 1, SKM_BUCKETS_PER_TICKET);
+    }
+    KvRouteSink rs;
+    memset(&rs, 0, sizeof(rs));
+    { const int rc = alloc(ctx, nwg3, &rs); if (rc != KV_OK) return rc; }
+    const HashParams hp = make_hash_params(plan->ksize, HF_MURMUR);
+    {
+        KvProfScope prof("k_skm_route");
+        const size_t lds = (256 + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(g.sbw)) * 4;
+        if (g.kw == 1) hipLaunchKernelGGL((k_skm_route<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, g, hp, rs);
+        else hipLaunchKernelGGL((k_skm_route<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, g, hp, rs);
+    }
+    {
+        KvProfScope prof("k_skm_loose_route");
+        if (g.kw == 1) hipLaunchKernelGGL(k_skm_loose_route<1>, dim3(4096), dim3(256), 0, st, g, hp, rs);
+        else hipLaunchKernelGGL(k_skm_loose_route<2>, dim3(4096), dim3(256), 0, st, g, hp, rs);
+    }
+    KV_HIP(hipGetLastError());
+    unsigned long long sctr[8] = {0};
+    KV_HIP(hipMemcpyAsync(sctr, g.ctr, sizeof(sctr), hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    if (getenv("KV_SKM_VERBOSE"))
+        fprintf(stderr, "[kv_skm] exchange owner: %llu k-mers arrived in %u buckets, %.1f%% distinct, %.2f%% outside the LDS tables\n",
+                arrived, g.n_buckets, arrived ? 100.0 * (double)sctr[7] / (double)arrived : 0.0,
+                arrived ? 100.0 * (double)(sctr[0] > sctr[6] ? sctr[0] - sctr[6] : 0) / (double)arrived : 0.0);
+    if (sctr[1] != 0) {
+        kv_set_error("kv_mex_route: loose record list overflow (%llu records)", sctr[0]);
         return KV_ERR_CAPACITY;
     }
     return KV_OK;

@@ -900,6 +900,29 @@ def route_distinct(batch, sketch_cls, ksize, ndest, out_ptr, cap_items):
     return [int(c) for c in counts]
 
 
+def mex_plan(sketch_cls, ksize, n_reads_global, read_len, ndest):
+    """The geometry of a minimizer-sharded exchange of one sample (kv_mex_plan_make): the same on every rank, because it
+    depends on the sample's global size only."""
+    plan = _lib.MexPlan()
+    check(_lib.load().kv_mex_plan_make(sketch_cls._kind, int(ksize), int(n_reads_global), int(read_len), int(ndest), ctypes.byref(plan)))
+    return plan
+
+
+def mex_emit(batch, plan, read_base, seg_ptr, cnt_ptr):
+    """Cut this rank's shard into super-k-mer records, grouped by minimizer bucket, in the exchange buffers (kv_mex_emit)."""
+    check(_lib.load().kv_mex_emit(batch._h, ctypes.byref(plan), int(read_base), ctypes.c_void_p(seg_ptr), ctypes.c_void_p(cnt_ptr)))
+
+
+def mex_route(plan, my_dest, recv_seg_ptr, recv_cnt_ptr, n_src, out_ptr, cap_items):
+    """Combine the records n_src ranks sent for this rank's buckets and write one (hash, occurrences) pair per distinct
+    k-mer, grouped by band owner (kv_mex_route); returns (pairs per destination, k-mer occurrences that arrived)."""
+    counts = (ctypes.c_uint64 * int(plan.ndest))()
+    arrived = ctypes.c_uint64()
+    check(_lib.load().kv_mex_route(ctypes.byref(plan), int(my_dest), ctypes.c_void_p(recv_seg_ptr), ctypes.c_void_p(recv_cnt_ptr), int(n_src),
+                                   ctypes.c_void_p(out_ptr), int(cap_items), counts, ctypes.byref(arrived)))
+    return [int(c) for c in counts], arrived.value
+
+
 def novel_scan_hashes(cases, controls, items_ptr, n_items, case_min, ctrl_max, hit_tags_ptr, hit_abund_ptr, hit_cap):
     """kmer_is_interesting() over (hash, tag) pairs in HBM; returns the number of hits written."""
     ca = (ctypes.c_void_p * len(cases))(*[c._h for c in cases])

@@ -90,6 +90,22 @@ def exchange_rows(send, counts, group=None, staged=False):
     return ex.wait(), ex.recv_counts
 
 
+def exchange_slabs(send, in_splits, out_splits, group=None, staged=False):
+    """All-to-all of a flat tensor cut at fixed split points known to every rank (no size exchange): returns what arrived,
+    source after source.  Blocking."""
+    recv = torch.empty(sum(out_splits), dtype=send.dtype, device=send.device)
+    if staged:
+        host = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(host, send.cpu(), list(out_splits), list(in_splits), group=group)
+        recv.copy_(host)
+        if recv.is_cuda:
+            torch.cuda.synchronize()
+    else:
+        dist.all_to_all_single(recv, send, list(out_splits), list(in_splits), group=group)
+        torch.cuda.current_stream().synchronize()
+    return recv
+
+
 def gather_rows(rows, n_valid, fill, group=None, staged=False):
     """All-gather of each rank's first n_valid rows, padded with `fill` to the longest; returns
     (gathered [world * longest, ...], total valid)."""
@@ -141,6 +157,39 @@ class ShardedTrio(object):
                 return free.pop(i)
         return torch.empty((cap, words), dtype=torch.int64, device=self.device)
 
+    def start_minimizer(self, batch, read_index_base, n_reads_global, read_len):
+        """start() for the minimizer-sharded layout: the shard is cut into super-k-mer records (kv_mex_emit), the records go
+        to the rank that owns their minimizer bucket (first all-to-all; fixed split points, so no sizes are exchanged), that
+        rank combines every occurrence of a k-mer -- from whichever shard -- at the sample's full coverage (kv_mex_route),
+        and the (hash, occurrences) pairs go on to the band owners exactly as start(distinct=True) sends them.  A shard of
+        1/8 of the reads has little to combine on its own (49 % of its k-mers are distinct against 20 % of the sample's); this
+        way a rank hashes 1/N of the sample's DISTINCT k-mers."""
+        t0 = time.perf_counter()
+        plan = hk.mex_plan(self.sketch_cls, self.ksize, n_reads_global, read_len, self.world)
+        seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
+        cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device=self.device)
+        hk.mex_emit(batch, plan, read_index_base, seg.data_ptr(), cnt.data_ptr())
+        t1 = time.perf_counter()
+        per_bucket = int(plan.nwg1) * int(plan.cap1) * int(plan.recw)
+        width = [int(plan.c_lo[d + 1]) - int(plan.c_lo[d]) for d in range(self.world)]
+        mine = width[self.rank]
+        got_seg = exchange_slabs(seg, [w * per_bucket for w in width], [mine * per_bucket] * self.world, self.group, self.staged)
+        got_cnt = exchange_slabs(cnt, [w * int(plan.nwg1) for w in width], [mine * int(plan.nwg1)] * self.world, self.group, self.staged)
+        del seg, cnt
+        t2 = time.perf_counter()
+        share = int(plan.n_kmers_global) // self.world
+        cap = share + share // 4 + (1 << 20)
+        send = self._send_buffer(cap, 2)
+        counts, _ = hk.mex_route(plan, self.rank, got_seg.data_ptr(), got_cnt.data_ptr(), self.world, send.data_ptr(), send.shape[0])
+        del got_seg, got_cnt
+        t3 = time.perf_counter()
+        ex = exchange_rows_async(send, counts, self.group, self.staged)
+        ex.send_buffer = send
+        ex.weighted = True
+        self.timing['route'] += (t1 - t0) + (t3 - t2)
+        self.timing['exchange'] += (t2 - t1) + (time.perf_counter() - t3)
+        return ex
+
     def start(self, batch, read_index_base, with_tags, distinct=False):
         """Hash this rank's shard of a sample and start delivering every hash to its band's owner.
         Returns a handle for finish(); the next sample's start() may run while the exchange flies.
@@ -187,10 +236,13 @@ class ShardedTrio(object):
             self.case_items_weighted = ex.weighted
         return n
 
-    def count_sample(self, sketch, batch, read_index_base=0, keep_for_scan=False, distinct=False):
+    def count_sample(self, sketch, batch, read_index_base=0, keep_for_scan=False, distinct=False, minimizer=None):
         """start() + finish() for one sample: `batch` is this rank's shard of its reads (global index of
         its first read = read_index_base).  A case sample kept `distinct` is scanned with
-        scan_distinct(), a tagged one with scan()."""
+        scan_distinct(), a tagged one with scan().  minimizer = (reads of the whole sample, read length): the
+        minimizer-sharded layout (start_minimizer); what arrives is what `distinct` delivers."""
+        if minimizer is not None:
+            return self.finish(self.start_minimizer(batch, read_index_base, int(minimizer[0]), int(minimizer[1])), sketch, keep_for_scan)
         if not distinct:
             return self.finish(self.start(batch, read_index_base, keep_for_scan), sketch, keep_for_scan)
         return self.finish(self.start(batch, read_index_base, False, distinct=True), sketch, keep_for_scan)

@@ -24,7 +24,10 @@ def main():
     names = tuple(packed)
     n_reads = packed['proband'].shape[0]
     dev = torch.device('cuda', 0)
-    for distinct in (True, False):
+    modes = [m for m in os.environ.get('RANK_COST_MODES', 'minimizer,distinct,plain').split(',') if m]
+    for mode_name in modes:
+        distinct = mode_name in ('distinct', 'minimizer')
+        minimizer = mode_name == 'minimizer'
         for world in worlds:
             sk = {n: hk.Counttable(k, mem / world / T, T) for n in names}
             shards = {n: [hk.ReadBatch.from_packed(packed[n][lo:hi], L) for lo, hi in
@@ -41,7 +44,34 @@ def main():
 
             # what band 0 receives (other ranks' routing: not timed)
             order = list(names[1:]) + [names[0]] if distinct else list(names)
-            for n in names:
+            mex_recv0 = {}
+            if minimizer:
+                # every shard cut into records; bucket owner d combines what the N shards hold of its buckets; band 0 receives
+                # the owners' pairs of band 0.  Rank 0's own part (its shard's emit, its buckets' combine) is timed below.
+                plan = hk.mex_plan(hk.Counttable, k, n_reads, L, world)
+                per_bucket = int(plan.nwg1) * int(plan.cap1) * int(plan.recw)
+                for n in names:
+                    segs, cnts = [], []
+                    for r in range(world):
+                        lo, _ = shardrun.shard_bounds(n_reads, world, r)
+                        seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device=dev)
+                        cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device=dev)
+                        hk.mex_emit(shards[n][r], plan, lo, seg.data_ptr(), cnt.data_ptr())
+                        segs.append(seg); cnts.append(cnt)
+                    blocks = []
+                    for d in range(world):
+                        c0, c1 = int(plan.c_lo[d]), int(plan.c_lo[d + 1])
+                        rs = torch.cat([sg_[c0 * per_bucket:c1 * per_bucket] for sg_ in segs])
+                        rc = torch.cat([cn[c0 * int(plan.nwg1):c1 * int(plan.nwg1)] for cn in cnts])
+                        if d == 0:
+                            mex_recv0[n] = (rs, rc)
+                        c, _ = hk.mex_route(plan, d, rs.data_ptr(), rc.data_ptr(), world, send.data_ptr(), send.shape[0])
+                        blocks.append(send.view(-1)[:c[0] * 2].clone().view(-1, 2))
+                    recv_count[n] = torch.cat(blocks)
+                    del segs, cnts
+                my_seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device=dev)
+                my_cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device=dev)
+            for n in ([] if minimizer else names):
                 blocks = []
                 for r in range(world):
                     c = route(shards[n][r], 0, 'distinct' if distinct else 'plain')
@@ -83,7 +113,12 @@ def main():
                 out_bytes = 0
                 for n in order:
                     ta = time.perf_counter()
-                    if distinct:
+                    if minimizer:
+                        hk.mex_emit(shards[n][0], plan, 0, my_seg.data_ptr(), my_cnt.data_ptr())
+                        rs, rc = mex_recv0[n]
+                        c, _ = hk.mex_route(plan, 0, rs.data_ptr(), rc.data_ptr(), world, send.data_ptr(), send.shape[0])
+                        out_bytes += (sum(c) - c[0]) * 16 + (int(plan.seg_words) * 8 + int(plan.cnt_entries) * 4) * (world - 1) // world
+                    elif distinct:
                         c = route(shards[n][0], 0, 'distinct')
                         out_bytes += (sum(c) - c[0]) * 16
                     elif n == 'proband':
@@ -139,8 +174,8 @@ def main():
                 if best is None or res['total'] < best['total']:
                     best = res
             print('N={} items={}: per-rank route {route:.2f} ms, count {count:.2f} ms, scan {scan:.2f} ms, total {total:.2f} ms; '
-                  'sends {out_mb:.0f} MB; counts {items} items; {hits} hits (set: this shard; plain: this band)'.format(world, 'distinct' if distinct else 'plain', **best), flush=True)
-            del sk, shards, recv_count, recv_tagged, send
+                  'sends {out_mb:.0f} MB; counts {items} items; {hits} hits (set: this shard; plain: this band)'.format(world, mode_name, **best), flush=True)
+            del sk, shards, recv_count, recv_tagged, send, mex_recv0
             torch.cuda.empty_cache()
 
 

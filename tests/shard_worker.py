@@ -34,13 +34,14 @@ def main():
     for n in names:
         lo, hi = shardrun.shard_bounds(len(reads[n]), world, rank)
         counted = run.count_sample(sharded[n], hk.ReadBatch(reads[n][lo:hi]), lo, keep_for_scan=(n == 'proband'),
-                                   distinct=os.environ.get('SHARD_DISTINCT') == '1')
+                                   distinct=os.environ.get('SHARD_DISTINCT') == '1',
+                                   minimizer=(len(reads[n]), 100) if os.environ.get('SHARD_MINIMIZER') == '1' else None)
         total = torch.tensor([counted], dtype=torch.int64)
         if backend == 'nccl':
             total = total.cuda()
         dist.all_reduce(total)
         assert int(total.item()) == sum(max(0, len(s) - k + 1) for s in reads[n]), n
-    if os.environ.get('SHARD_DISTINCT') == '1':
+    if os.environ.get('SHARD_DISTINCT') == '1' or os.environ.get('SHARD_MINIMIZER') == '1':
         lo, hi = shardrun.shard_bounds(len(reads['proband']), world, rank)
         r, o, a = run.scan_distinct([sharded['proband']], [sharded['mother'], sharded['father']], 6, 1,
                                     hk.ReadBatch(reads['proband'][lo:hi]), lo)

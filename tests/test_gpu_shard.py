@@ -259,20 +259,26 @@ def free_port():
 
 
 @pytest.mark.parametrize('world,backend,distinct', [(2, 'gloo', False), (3, 'gloo', False), (1, 'nccl', False),
-                                                    (2, 'gloo', 'skm'), (3, 'gloo', 'plain'), (1, 'nccl', 'skm')])
+                                                    (2, 'gloo', 'skm'), (3, 'gloo', 'plain'), (1, 'nccl', 'skm'),
+                                                    (2, 'gloo', 'minimizer'), (3, 'gloo', 'minimizer'), (1, 'nccl', 'minimizer')])
 def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     """N ranks on this one GPU (gloo, staged exchange): each rank's sketches must equal band `rank` of a
     banded count of ALL reads, and the gathered hits the merged banded scan (tests/shard_worker.py).  The
     (1, 'nccl') case drives the RCCL transport itself -- device tensors, async all-to-all -- with the one
     rank a single-GPU box allows.  `distinct`: the count travels as (hash, occurrences) pairs of the
     deduplicated shard (kv_route_distinct / kv_consume_hashes_weighted) and the scan goes through the set of
-    interesting k-mers (kv_novel_scan_distinct / kv_novel_scan_set)."""
+    interesting k-mers (kv_novel_scan_distinct / kv_novel_scan_set); 'minimizer': the shards' super-k-mer records go to the
+    owners of their minimizer buckets first (kv_mex_emit / kv_mex_route)."""
     port = free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), SHARD_BACKEND=backend, SHARD_DISTINCT='1' if distinct else '0')
-        if distinct:            # the bucketed kernels by name (the shards are small), or their one-item-per-k-mer stand-ins
+        if distinct == 'minimizer':
+            # the minimizer-sharded layout: super-k-mer records travel to their bucket's owner, which deduplicates at the
+            # sample's full coverage (kv_mex_emit / kv_mex_route); the scan goes through the set, as for `distinct`
+            env.update(SHARD_DISTINCT='0', SHARD_MINIMIZER='1', KV_NOVEL_PATH='skm')
+        elif distinct:          # the bucketed kernels by name (the shards are small), or their one-item-per-k-mer stand-ins
             env.update(KV_ROUTE_PATH=distinct, KV_NOVEL_PATH='skm' if distinct == 'skm' else 'tiles')
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'shard_worker.py')], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
