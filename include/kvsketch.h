@@ -354,7 +354,11 @@ typedef struct kv_mex_plan {
 } kv_mex_plan;
 int kv_mex_plan_make(int kind, int ksize, uint64_t n_reads_global, uint32_t read_len, int ndest, kv_mex_plan *plan);
 int kv_mex_emit(const kv_reads *shard, const kv_mex_plan *plan, uint64_t read_base, void *d_seg, void *d_cnt);
-int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_recv_seg, const void *d_recv_cnt, int n_src,
+/* kv_mex_pack: only the filled part of the segments travels -- d_out receives it, destination after destination, and
+ * records_per_dest[d] says how many records rank d gets; the counts slab travels whole, so the receiver (compact != 0 in
+ * kv_mex_route) knows where every segment of every source starts.                                                        */
+int kv_mex_pack(const kv_mex_plan *plan, const void *d_seg, const void *d_cnt, void *d_out, uint64_t *records_per_dest);
+int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_recv_seg, const void *d_recv_cnt, int n_src, int compact,
                  void *d_out, uint64_t cap_items, uint64_t *counts_out, uint64_t *n_kmers_in);
 
 #ifdef __cplusplus

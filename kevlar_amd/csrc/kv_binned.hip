@@ -964,6 +964,9 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
     const double per_bucket = expected * std::min(1.0, (double)g.F * slice_bins / (double)pmin);
     const double per_slice = expected * std::min(1.0, slice_bins / (double)pmin);
     g.nwgB = (uint32_t)std::max(1.0, std::min((double)std::min<uint32_t>(g.nwgA, 512), std::ceil(per_bucket / 524288.0)));
+    // a stage-B workgroup drains its segments one after the other, a dependent round trip or two each: with few items per
+    // segment (a shard of a multi-GPU run, a small batch) that chain is the stage's whole time -- at most 32 segments each
+    g.nwgB = std::max<uint32_t>(g.nwgB, std::min<uint32_t>(std::min<uint32_t>(g.nwgA, 512), (g.nwgA + 31u) / 32u));
     const double m1 = per_bucket / g.nwgA, m2 = per_slice / g.nwgB;
     g.cap1 = kv_round_up((uint64_t)(m1 * 1.5 + 8.0 * std::sqrt(m1)) + 2048, 64);   // tiles are dealt dynamically: shares are uneven
     g.cap2 = kv_round_up((uint64_t)(m2 * 1.05 + 8.0 * std::sqrt(m2)) + 64, 64);

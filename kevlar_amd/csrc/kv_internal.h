@@ -208,8 +208,9 @@ int kv_skm_route_distinct(const kv_reads *reads, int ksize, uint64_t n_kmers, in
 // exchange buffers, S2 + distinct route over what arrived
 int kv_skm_mex_plan(int ksize, uint64_t n_reads_global, uint32_t read_len, int ndest, kv_mex_plan *plan);
 int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t read_base, uint64_t *d_seg, uint32_t *d_cnt);
-int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_recv_seg, const uint32_t *d_recv_cnt, int n_src,
+int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_recv_seg, const uint32_t *d_recv_cnt, int n_src, int compact,
                      int (*alloc)(void *ctx, uint32_t nwg, KvRouteSink *sink), void *ctx, uint64_t *n_kmers_in);
+int kv_skm_mex_pack(const kv_mex_plan *plan, const uint64_t *d_seg, const uint32_t *d_cnt, uint64_t *d_out, uint64_t *records_per_dest);
 
 // tile geometry of the hashing kernels
 #define KV_TILE_THREADS 256

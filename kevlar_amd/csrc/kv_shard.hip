@@ -426,7 +426,13 @@ extern "C" int kv_mex_emit(const kv_reads *shard, const kv_mex_plan *plan, uint6
     return kv_skm_mex_emit(shard, plan, read_base, (uint64_t *)d_seg, (uint32_t *)d_cnt);
 }
 
-extern "C" int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_recv_seg, const void *d_recv_cnt, int n_src,
+extern "C" int kv_mex_pack(const kv_mex_plan *plan, const void *d_seg, const void *d_cnt, void *d_out, uint64_t *records_per_dest)
+{
+    KV_REQUIRE(plan && d_seg && d_cnt && d_out && records_per_dest, KV_ERR_ARG, "kv_mex_pack: null argument");
+    return kv_skm_mex_pack(plan, (const uint64_t *)d_seg, (const uint32_t *)d_cnt, (uint64_t *)d_out, records_per_dest);
+}
+
+extern "C" int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_recv_seg, const void *d_recv_cnt, int n_src, int compact,
                             void *d_out, uint64_t cap_items, uint64_t *counts_out, uint64_t *n_kmers_in)
 {
     KV_REQUIRE(plan && d_recv_seg && d_recv_cnt && d_out && counts_out && n_kmers_in, KV_ERR_ARG, "kv_mex_route: null argument");
@@ -453,7 +459,7 @@ extern "C" int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_
         sink->seg_count = q.seg_count; sink->ovf = q.ovf; sink->ovf_dest = q.ovf_dest; sink->ovf_cap = q.ovf_cap; sink->ctr = q.ctr;
         return KV_OK;
     };
-    { const int rc = kv_skm_mex_route(plan, my_dest, (const uint64_t *)d_recv_seg, (const uint32_t *)d_recv_cnt, n_src, alloc, &ctx, n_kmers_in); if (rc != KV_OK) return rc; }
+    { const int rc = kv_skm_mex_route(plan, my_dest, (const uint64_t *)d_recv_seg, (const uint32_t *)d_recv_cnt, n_src, compact, alloc, &ctx, n_kmers_in); if (rc != KV_OK) return rc; }
     KV_REQUIRE(*n_kmers_in <= cap_items, KV_ERR_CAPACITY, "kv_mex_route: %llu k-mers arrived, the output holds %llu pairs",
                (unsigned long long)*n_kmers_in, (unsigned long long)cap_items);
     if (p.nwg == 0 || p.seg == nullptr) return KV_OK;

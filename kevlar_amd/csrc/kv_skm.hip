@@ -47,6 +47,7 @@ struct SkmGeom {
     // S2 over records that several ranks emitted (minimizer-sharded exchange, kv_skm_mex_route): seg1 / cnt1 then hold n_src
     // slabs of [C1][nwg1] segments one after the other, and a coarse bucket has n_src * nwg1 segments (0 / 1: the usual one slab)
     uint32_t n_src;
+    const uint64_t *seg1_off;        // non-null: segment `slot` starts at record seg1_off[slot] (compacted records) instead of slot * cap1
     uint64_t read_base;              // global index of the batch's first read (record positions of a read shard; 0 otherwise)
 };
 
@@ -58,6 +59,8 @@ __device__ __forceinline__ uint64_t skm_seg1_slot(const SkmGeom &sg, uint32_t c,
     return ((uint64_t)src * sg.C1 + c) * sg.nwg1 + w;
 }
 __device__ __forceinline__ uint32_t skm_seg1_count(const SkmGeom &sg) { return sg.nwg1 * (sg.n_src > 1u ? sg.n_src : 1u); }
+// first record of segment `slot`
+__device__ __forceinline__ uint64_t skm_seg1_first(const SkmGeom &sg, uint64_t slot) { return sg.seg1_off ? sg.seg1_off[slot] : slot * sg.cap1; }
 
 // the controls' abundance lists a scan may use (same bucket geometry as the case sample's buckets)
 #define SKM_MAX_ABL 8
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split(SkmGeom sg)
     for (uint32_t i = threadIdx.x; i < total; i += SKM_THREADS2) {
         const uint32_t si = skm_search(spre, nmine, i);
         const uint32_t seg = blockIdx.x + si * sg.nwg2;
-        const uint64_t *rec = sg.seg1 + (skm_seg1_slot(sg, c, seg) * sg.cap1 + (i - spre[si])) * (uint64_t)recw;
+        const uint64_t *rec = sg.seg1 + (skm_seg1_first(sg, skm_seg1_slot(sg, c, seg)) + (i - spre[si])) * (uint64_t)recw;
         const uint64_t hdr = rec[0];
         uint64_t bw[3];
 #pragma unroll
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split_sorted(SkmGeom sg)
             if (i < n) {
                 const uint32_t gi = c0 + i, si = skm_search(spre, nmine, gi);
                 const uint32_t seg = blockIdx.x + si * sg.nwg2;
-                const uint64_t *rec = sg.seg1 + (skm_seg1_slot(sg, c, seg) * sg.cap1 + (gi - spre[si])) * (uint64_t)RECW;
+                const uint64_t *rec = sg.seg1 + (skm_seg1_first(sg, skm_seg1_slot(sg, c, seg)) + (gi - spre[si])) * (uint64_t)RECW;
                 hdr[r] = rec[0]; w0[r] = rec[1]; w1[r] = rec[2];
                 if (RECW == 4) w2[r] = rec[3];
             }
@@ -1230,6 +1233,47 @@ void skm_launch_split(const SkmGeom &g, hipStream_t st)
     }
 }
 
+// exclusive prefix of n counts (one workgroup; n is a few hundred thousand at most); off[n] = total
+__global__ __launch_bounds__(1024) void k_mex_scan(const uint32_t *cnt, uint64_t n, uint32_t cap1, uint64_t *off)
+{
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry_sh;
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint64_t base = 0; base < n; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < n ? (uint64_t)min(cnt[i], cap1) : 0ull;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, d), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), d);
+            if (lane >= (uint32_t)d) incl += (uint64_t)lo | ((uint64_t)hi << 32);
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint64_t before = carry_sh;
+        for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
+        if (i < n) off[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_sh = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[n] = carry_sh;
+}
+
+// the filled part of every segment, one after the other: a workgroup per segment
+__global__ __launch_bounds__(256) void k_mex_gather(const uint64_t *seg, const uint32_t *cnt, const uint64_t *off, uint64_t n_segments, uint32_t cap1,
+                                                    uint32_t recw, uint64_t *out)
+{
+    for (uint64_t sgi = blockIdx.x; sgi < n_segments; sgi += gridDim.x) {
+        const uint64_t words = (uint64_t)min(cnt[sgi], cap1) * recw;
+        const uint64_t *src = seg + sgi * cap1 * recw;
+        uint64_t *dst = out + off[sgi] * recw;
+        for (uint64_t i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+    }
+}
+
 // k-dependent part of the geometry
 void skm_geom_k(SkmGeom &g, int k)
 {
@@ -1247,12 +1291,14 @@ void skm_geom_k(SkmGeom &g, int k)
     g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
 }
 
-__global__ void k_mex_sum_kmers(const uint64_t *seg, const uint32_t *cnt, uint64_t n_segments, uint32_t cap1, uint32_t recw, unsigned long long *out)
+__global__ void k_mex_sum_kmers(const uint64_t *seg, const uint32_t *cnt, const uint64_t *off, uint64_t n_segments, uint32_t cap1, uint32_t recw,
+                                unsigned long long *out)
 {
     unsigned long long mine = 0;
     for (uint64_t sgi = blockIdx.x; sgi < n_segments; sgi += gridDim.x) {
         const uint32_t n = min(cnt[sgi], cap1);
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) mine += skm_hdr_n(seg[(sgi * cap1 + i) * recw]);
+        const uint64_t first = off ? off[sgi] : sgi * cap1;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) mine += skm_hdr_n(seg[(first + i) * recw]);
     }
     mine = wave_sum_u64(mine);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
@@ -1678,12 +1724,15 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
     // records that miss their segment have nowhere to travel in: the plan's capacity is twice the expected fill, so this
     // means a pathological input (one minimizer everywhere); no silent change of layout
     KV_REQUIRE(ctr[0] == 0 && ctr[1] == 0, KV_ERR_CAPACITY, "kv_mex_emit: %llu records did not fit their exchange segment", ctr[0]);
+    // a later scan of this shard against the set of interesting k-mers buckets the shard on its own: 1 / ndest of the coverage
+    // leaves more of its k-mers distinct than the sample's ~20 % (measured: 30 / 33 / 49 % at 1/2, 1/4, 1/8 of 30x)
+    { std::lock_guard<std::mutex> glk(g_skm_mu); g_skm_last_distinct = std::min(0.9, 0.2 * std::sqrt((double)plan->ndest)); }
     return KV_OK;
 }
 
 // the records n_src ranks sent for this rank's Cl coarse buckets -> S2 -> every distinct k-mer once as a (hash, occurrences)
 // pair for its band's owner (the callback allocates the sink, as for kv_skm_route_distinct)
-int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_recv_seg, const uint32_t *d_recv_cnt, int n_src,
+int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_recv_seg, const uint32_t *d_recv_cnt, int n_src, int compact,
                      int (*alloc)(void *ctx, uint32_t nwg, KvRouteSink *sink), void *ctx, uint64_t *n_kmers_in)
 {
     KV_REQUIRE(plan && my_dest >= 0 && my_dest < plan->ndest && n_src >= 1, KV_ERR_ARG, "kv_mex_route: bad argument");
@@ -1712,16 +1761,24 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     const size_t rb = (size_t)g.recw * 8;
     const size_t b_seg2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * g.cap2 * rb, 256), b_cnt2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * 4, 256);
     const size_t b_loose = kv_round_up(g.loose_cap * rb, 256), b_ctr = 256;
-    KV_HIP(idx.arena.need(b_seg2 + b_cnt2 + b_loose + b_ctr));
+    const size_t b_off = compact ? kv_round_up(((uint64_t)Cl * nseg + 1) * 8, 256) : 0;
+    KV_HIP(idx.arena.need(b_seg2 + b_cnt2 + b_loose + b_off + b_ctr));
     unsigned char *base = (unsigned char *)idx.arena.p;
     g.seg2 = (uint64_t *)base; base += b_seg2;
     g.cnt2 = (uint32_t *)base; base += b_cnt2;
     g.loose = (uint64_t *)base; base += b_loose;
+    uint64_t *d_off = compact ? (uint64_t *)base : nullptr; base += b_off;
     g.ctr = (unsigned long long *)base;
     KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));
     g.bucket_kmers = std::max<uint64_t>(1, n_kmers_exp / g.n_buckets);
+    if (compact) {
+        // the sources sent only the filled part of their segments, in segment order: a segment starts where the counts in
+        // front of it end
+        hipLaunchKernelGGL(k_mex_scan, dim3(1), dim3(1024), 0, st, g.cnt1, (uint64_t)Cl * nseg, g.cap1, d_off);
+        g.seg1_off = d_off;
+    }
     // how many k-mer occurrences arrived (the caller's buffer must hold a pair for each in the worst case)
-    hipLaunchKernelGGL(k_mex_sum_kmers, dim3(1024), dim3(256), 0, st, g.seg1, g.cnt1, (uint64_t)Cl * nseg, g.cap1, (uint32_t)g.recw, &g.ctr[8]);
+    hipLaunchKernelGGL(k_mex_sum_kmers, dim3(1024), dim3(256), 0, st, g.seg1, g.cnt1, g.seg1_off, (uint64_t)Cl * nseg, g.cap1, (uint32_t)g.recw, &g.ctr[8]);
     skm_launch_split(g, st);
     KV_HIP(hipGetLastError());
     KV_HIP(hipMemcpyAsync(&g.ctr[6], &g.ctr[0], 8, hipMemcpyDeviceToDevice, st));
@@ -1761,5 +1818,28 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
         kv_set_error("kv_mex_route: loose record list overflow (%llu records)", sctr[0]);
         return KV_ERR_CAPACITY;
     }
+    return KV_OK;
+}
+
+
+// the filled part of a shard's exchange segments, destination after destination (what actually travels): d_out receives the
+// records, records_per_dest[d] how many go to rank d.  The counts slab travels as it is.
+int kv_skm_mex_pack(const kv_mex_plan *plan, const uint64_t *d_seg, const uint32_t *d_cnt, uint64_t *d_out, uint64_t *records_per_dest)
+{
+    hipStream_t st = kv_stream();
+    SkmIndex &idx = skm_index_for(st);
+    std::lock_guard<std::mutex> lk(idx.mu);
+    const uint64_t n_seg = plan->cnt_entries;
+    KV_HIP(idx.arena.need(kv_round_up((n_seg + 1) * 8, 256)));
+    uint64_t *d_off = (uint64_t *)idx.arena.p;
+    hipLaunchKernelGGL(k_mex_scan, dim3(1), dim3(1024), 0, st, d_cnt, n_seg, plan->cap1, d_off);
+    hipLaunchKernelGGL(k_mex_gather, dim3((unsigned)std::min<uint64_t>(n_seg, 65536)), dim3(256), 0, st, d_seg, d_cnt, d_off, n_seg, plan->cap1,
+                       plan->recw, d_out);
+    KV_HIP(hipGetLastError());
+    std::vector<uint64_t> bounds(plan->ndest + 1);
+    for (int d = 0; d <= plan->ndest; ++d)
+        KV_HIP(hipMemcpyAsync(&bounds[d], d_off + (uint64_t)plan->c_lo[d] * plan->nwg1, 8, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    for (int d = 0; d < plan->ndest; ++d) records_per_dest[d] = bounds[d + 1] - bounds[d];
     return KV_OK;
 }

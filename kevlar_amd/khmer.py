@@ -913,13 +913,20 @@ def mex_emit(batch, plan, read_base, seg_ptr, cnt_ptr):
     check(_lib.load().kv_mex_emit(batch._h, ctypes.byref(plan), int(read_base), ctypes.c_void_p(seg_ptr), ctypes.c_void_p(cnt_ptr)))
 
 
-def mex_route(plan, my_dest, recv_seg_ptr, recv_cnt_ptr, n_src, out_ptr, cap_items):
+def mex_pack(plan, seg_ptr, cnt_ptr, out_ptr):
+    """The filled part of the exchange segments, destination after destination (kv_mex_pack); returns records per destination."""
+    counts = (ctypes.c_uint64 * int(plan.ndest))()
+    check(_lib.load().kv_mex_pack(ctypes.byref(plan), ctypes.c_void_p(seg_ptr), ctypes.c_void_p(cnt_ptr), ctypes.c_void_p(out_ptr), counts))
+    return [int(c) for c in counts]
+
+
+def mex_route(plan, my_dest, recv_seg_ptr, recv_cnt_ptr, n_src, out_ptr, cap_items, compact=False):
     """Combine the records n_src ranks sent for this rank's buckets and write one (hash, occurrences) pair per distinct
     k-mer, grouped by band owner (kv_mex_route); returns (pairs per destination, k-mer occurrences that arrived)."""
     counts = (ctypes.c_uint64 * int(plan.ndest))()
     arrived = ctypes.c_uint64()
     check(_lib.load().kv_mex_route(ctypes.byref(plan), int(my_dest), ctypes.c_void_p(recv_seg_ptr), ctypes.c_void_p(recv_cnt_ptr), int(n_src),
-                                   ctypes.c_void_p(out_ptr), int(cap_items), counts, ctypes.byref(arrived)))
+                                   1 if compact else 0, ctypes.c_void_p(out_ptr), int(cap_items), counts, ctypes.byref(arrived)))
     return [int(c) for c in counts], arrived.value
 
 

@@ -157,6 +157,11 @@ class ShardedTrio(object):
                 return free.pop(i)
         return torch.empty((cap, words), dtype=torch.int64, device=self.device)
 
+    @staticmethod
+    def _fits(plan, cnt, packed):
+        """do the filled parts of the segments fit the half-size send buffer?  (one device reduction)"""
+        return int(cnt.clamp(max=int(plan.cap1)).sum(dtype=torch.int64).item()) * int(plan.recw) <= packed.shape[0]
+
     def start_minimizer(self, batch, read_index_base, n_reads_global, read_len):
         """start() for the minimizer-sharded layout: the shard is cut into super-k-mer records (kv_mex_emit), the records go
         to the rank that owns their minimizer bucket (first all-to-all; fixed split points, so no sizes are exchanged), that
@@ -169,18 +174,30 @@ class ShardedTrio(object):
         seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
         cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device=self.device)
         hk.mex_emit(batch, plan, read_index_base, seg.data_ptr(), cnt.data_ptr())
+        # only the filled part of the segments travels: the counts go first (fixed split points), and say how many records
+        # every source will send
+        packed = torch.empty(int(plan.seg_words) // 2 + 1024, dtype=torch.int64, device=self.device)     # capacity is twice the expected fill
+        try:
+            per_dest = hk.mex_pack(plan, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr()) if self._fits(plan, cnt, packed) else None
+        except ValueError:
+            per_dest = None
+        if per_dest is None:                                # fuller than expected: a buffer of the segments' full size always fits
+            packed = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
+            per_dest = hk.mex_pack(plan, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr())
         t1 = time.perf_counter()
-        per_bucket = int(plan.nwg1) * int(plan.cap1) * int(plan.recw)
+        recw = int(plan.recw)
         width = [int(plan.c_lo[d + 1]) - int(plan.c_lo[d]) for d in range(self.world)]
-        mine = width[self.rank]
-        got_seg = exchange_slabs(seg, [w * per_bucket for w in width], [mine * per_bucket] * self.world, self.group, self.staged)
-        got_cnt = exchange_slabs(cnt, [w * int(plan.nwg1) for w in width], [mine * int(plan.nwg1)] * self.world, self.group, self.staged)
-        del seg, cnt
+        mine = width[self.rank] * int(plan.nwg1)
+        got_cnt = exchange_slabs(cnt, [w * int(plan.nwg1) for w in width], [mine] * self.world, self.group, self.staged)
+        from_src = [int(v) for v in got_cnt.view(self.world, mine).clamp(max=int(plan.cap1)).sum(dim=1, dtype=torch.int64).cpu()]
+        got_seg = exchange_slabs(packed[:sum(per_dest) * recw], [n * recw for n in per_dest], [n * recw for n in from_src], self.group, self.staged)
+        self.sent_bytes = getattr(self, 'sent_bytes', 0) + (sum(per_dest) - per_dest[self.rank]) * recw * 8 + (len(cnt) - mine) * 4
+        del seg, cnt, packed
         t2 = time.perf_counter()
         share = int(plan.n_kmers_global) // self.world
         cap = share + share // 4 + (1 << 20)
         send = self._send_buffer(cap, 2)
-        counts, _ = hk.mex_route(plan, self.rank, got_seg.data_ptr(), got_cnt.data_ptr(), self.world, send.data_ptr(), send.shape[0])
+        counts, _ = hk.mex_route(plan, self.rank, got_seg.data_ptr(), got_cnt.data_ptr(), self.world, send.data_ptr(), send.shape[0], compact=True)
         del got_seg, got_cnt
         t3 = time.perf_counter()
         ex = exchange_rows_async(send, counts, self.group, self.staged)

@@ -34,7 +34,7 @@ def main():
                           (shardrun.shard_bounds(n_reads, world, r) for r in range(world))] for n in names}
             nkm = shards['proband'][0].num_kmers(k)
             words = 2
-            send = torch.empty((nkm + 1024, 2), dtype=torch.int64, device=dev)
+            send = torch.empty((nkm + nkm // 4 + (1 << 20), 2), dtype=torch.int64, device=dev)
             recv_count, recv_tagged, sent = {}, None, 0
 
             def route(batch, base, mode):
@@ -71,6 +71,7 @@ def main():
                     del segs, cnts
                 my_seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device=dev)
                 my_cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device=dev)
+                my_packed = torch.empty(int(plan.seg_words), dtype=torch.int64, device=dev)
             for n in ([] if minimizer else names):
                 blocks = []
                 for r in range(world):
@@ -116,8 +117,9 @@ def main():
                     if minimizer:
                         hk.mex_emit(shards[n][0], plan, 0, my_seg.data_ptr(), my_cnt.data_ptr())
                         rs, rc = mex_recv0[n]
+                        per_dest = hk.mex_pack(plan, my_seg.data_ptr(), my_cnt.data_ptr(), my_packed.data_ptr())
                         c, _ = hk.mex_route(plan, 0, rs.data_ptr(), rc.data_ptr(), world, send.data_ptr(), send.shape[0])
-                        out_bytes += (sum(c) - c[0]) * 16 + (int(plan.seg_words) * 8 + int(plan.cnt_entries) * 4) * (world - 1) // world
+                        out_bytes += (sum(c) - c[0]) * 16 + (sum(per_dest) - per_dest[0]) * int(plan.recw) * 8 + int(plan.cnt_entries) * 4 * (world - 1) // world
                     elif distinct:
                         c = route(shards[n][0], 0, 'distinct')
                         out_bytes += (sum(c) - c[0]) * 16
