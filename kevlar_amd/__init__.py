@@ -117,8 +117,9 @@ class multi_file_iter_khmer(object):
     """Records of several sequence files, one after the other (kevlar/__init__.py:125-128).
     Iterating yields records; text_batches() hands the novel scan whole parsed batches instead."""
 
-    def __init__(self, filenames):
+    def __init__(self, filenames, kept=None):
         self.filenames = list(filenames)
+        self.kept = kept or {}          # filename -> (parser, text batch) of files whose single batch is still open (kevlar_amd.count)
 
     def __iter__(self):
         for filename in self.filenames:
@@ -127,5 +128,9 @@ class multi_file_iter_khmer(object):
 
     def text_batches(self, max_reads):
         for filename in self.filenames:
+            held = self.kept.pop(filename, None)
+            if held is not None and max_reads >= held[1].n:
+                yield held[1]
+                continue
             for tb in khmer.ReadParser(filename).text_batches(max_reads):
                 yield tb

@@ -26,9 +26,25 @@ def _drain(parser, sketch, policy):
             batch.close()
 
 
-def _count_file(path, sketch, policy, nthreads):
-    """all reads of one file, by `nthreads` workers; returns the number of reads"""
+def _count_file(path, sketch, policy, nthreads, keep=None):
+    """all reads of one file, by `nthreads` workers; returns the number of reads.  keep: a dict that receives
+    path -> (parser, text batch) if the whole file was ONE batch -- `kevlar novel` scans a case sample right after counting
+    it, and a sample of up to BATCH_READS reads need not be read, inflated and packed a second time for that."""
     parser = khmer.ReadParser(path)
+    if keep is not None and not parser.from_cache:
+        first = parser.text_batch(khmer.BATCH_READS)
+        if first is None:
+            return parser.num_reads
+        sketch.consume_batch(first.batch, policy.nbands, policy.band, policy.mask, policy.threshold, policy.consume_masked)
+        second = parser.take_batch(khmer.BATCH_READS)
+        if second is None:
+            keep[path] = (parser, first)
+            return parser.num_reads
+        if not sketch.retains(first.batch):
+            first.batch.close()
+        sketch.consume_batch(second, policy.nbands, policy.band, policy.mask, policy.threshold, policy.consume_masked)
+        if not sketch.retains(second):
+            second.close()
     failures = []
     stream = khmer.bound_stream()           # the workers stay on the caller's stream (samples loaded side by side each have their own)
 
@@ -53,7 +69,7 @@ def _count_file(path, sketch, policy, nthreads):
 
 
 def load_sample_seqfile(seqfiles, ksize, memory, maxfpr=0.2, count=True, smallcount=False, mask=None, maskmaxabund=0,
-                        consume_masked=False, numbands=None, band=None, outfile=None, numthreads=1, log=None):
+                        consume_masked=False, numbands=None, band=None, outfile=None, numthreads=1, log=None, keep=None):
     """Count one sample (one or more FASTA/FASTQ files) into a fresh sketch of `memory` bytes: four tables of
     memory / 4 bytes each, i.e. memory / 4 x {1, 2, 8} bins for byte / nibble / bit counters.  Returns the sketch;
     raises KevlarUnsuitableFPRError if its estimated false positive rate exceeds `maxfpr`; saves it to `outfile`
@@ -69,7 +85,7 @@ def load_sample_seqfile(seqfiles, ksize, memory, maxfpr=0.2, count=True, smallco
     nreads = 0
     for path in seqfiles:
         log('[kevlar::count]', '- processing "{}"'.format(path))
-        nreads += _count_file(path, sketch, policy, numthreads)
+        nreads += _count_file(path, sketch, policy, numthreads, keep)
     try:
         distinct = sketch.n_unique_kmers()
     except (kevlar_amd._lib.KvError, ValueError):

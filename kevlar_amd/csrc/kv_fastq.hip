@@ -305,8 +305,7 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
 {
     *n_out = 0;
     *reads_out = nullptr;
-    d->n_batch = 0;
-    if (d->done) return KV_OK;
+    if (d->done) return KV_OK;             // (the batch served last stays served: its records can still be fetched)
     hipStream_t st = kv_stream();
     const bool verbose = getenv("KV_INGEST_VERBOSE") != nullptr;   // wall time of the steps of a batch on stderr
     auto t_mark = std::chrono::steady_clock::now();
@@ -340,7 +339,8 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         lap(d->gz ? "gunzip: decode" : "select");
         const bool final = d->gz ? gz_last : d->plain ? b0 + fresh == d->image_size : m1 == d->members.size();
         const uint64_t total_in = d->carry_len + fresh;
-        if (total_in == 0) { d->done = true; return KV_OK; }
+        if (total_in == 0) { d->done = true; return KV_OK; }     // end of file: nothing of the previous batch has been touched
+        d->n_batch = 0;
         const int nxt = d->cur ^ 1;
         KV_HIP(d->text[nxt].need(kv_round_up(total_in + 64, 4096)));
         uint8_t *text = (uint8_t *)d->text[nxt].p;

@@ -67,7 +67,7 @@ def _side_by_side(filelists=None):
 
 
 def load_samples(counttables=None, filelists=None, ksize=31, memory=1e6, maxfpr=0.2, numbands=None, band=None, numthreads=1,
-                 outfilelist=None, log=None):
+                 outfilelist=None, log=None, keep=None):
     """One sketch per sample: loaded from saved count tables if given, else counted from the sample's files."""
     assert counttables or filelists
     log = log or kevlar_amd.plog
@@ -82,7 +82,7 @@ def load_samples(counttables=None, filelists=None, ksize=31, memory=1e6, maxfpr=
     # side against 0.76 s one after the other; 2 M reads, buffers warm: 0.115 against 0.134 s).
     if not _side_by_side(filelists):
         sketches = [kevlar_amd.count.load_sample_seqfile(files, ksize, memory, maxfpr=maxfpr, numbands=numbands, band=band,
-                                                         numthreads=numthreads, log=log) for files in filelists]
+                                                         numthreads=numthreads, log=log, keep=keep) for files in filelists]
         if outfilelist:
             save_counts(outfilelist, sketches, log)
         return sketches
@@ -90,7 +90,7 @@ def load_samples(counttables=None, filelists=None, ksize=31, memory=1e6, maxfpr=
 
     def one(i):
         return kevlar_amd.count.load_sample_seqfile(filelists[i], ksize, memory, maxfpr=maxfpr, numbands=numbands, band=band,
-                                                    numthreads=numthreads, log=lambda *words: said[i].append(words))
+                                                    numthreads=numthreads, log=lambda *words: said[i].append(words), keep=keep)
     try:
         sketches = khmer.run_concurrently([lambda i=i: one(i) for i in range(len(filelists))])
     finally:
@@ -260,7 +260,7 @@ def novel_text(casestream, casecounts, controlcounts, ksize=31, abundscreen=None
     kevlar_amd.plog('[kevlar::novel]', tally.line(clock.stop()))
 
 
-def _load_side_by_side(args, band):
+def _load_side_by_side(args, band, keep=None):
     """KV_PARALLEL_SAMPLES=1: controls and cases loaded side by side, each sample on its own HIP stream; what they have to say
     is printed in the order of a one-after-the-other run"""
     said = {'ctrl': [], 'case': []}
@@ -270,7 +270,7 @@ def _load_side_by_side(args, band):
         watch = kevlar_amd.Timer()
         watch.start()
         sketches = load_samples(counts, files, args.ksize, args.memory, args.max_fpr, args.num_bands, band, args.threads, save,
-                                log=lambda *words: said[which].append(words))
+                                log=lambda *words: said[which].append(words), keep=keep if which == 'case' else None)
         took[which] = watch.stop()
         return sketches
     try:
@@ -296,6 +296,8 @@ def main(args):
     clock = kevlar_amd.Timer()
     for key in (None, 'loadall', 'loadctrl'):
         clock.start(key)
+    # a case sample that was counted as one batch is scanned from that batch (no second pass over its file)
+    kept = {} if not os.environ.get('KV_NOVEL_REREAD') else None
     if not _side_by_side((args.control or []) + (args.case or [])) or args.control_counts or args.case_counts:
         kevlar_amd.plog('[kevlar::novel] Loading control samples')
         controls = load_samples(args.control_counts, args.control, args.ksize, args.memory, args.max_fpr, args.num_bands, band,
@@ -304,17 +306,17 @@ def main(args):
         kevlar_amd.plog('[kevlar::novel] Loading case samples')
         clock.start('loadcases')
         cases = load_samples(args.case_counts, args.case, args.ksize, args.memory, args.max_fpr, args.num_bands, band,
-                             args.threads, args.save_case_counts)
+                             args.threads, args.save_case_counts, keep=kept)
         kevlar_amd.plog('[kevlar::novel] Case samples loaded in {:.2f} sec'.format(clock.stop('loadcases')))
     else:
-        controls, cases = _load_side_by_side(args, band)
+        controls, cases = _load_side_by_side(args, band, keep=kept)
         clock.stop('loadctrl')
     kevlar_amd.plog('[kevlar::novel] All samples loaded in {:.2f} sec'.format(clock.stop('loadall')))
 
     clock.start('iter')
     kevlar_amd.plog('[kevlar::novel]', 'Iterating over reads from {:d} case sample(s)'.format(len(args.case)))
     sink = kevlar_amd.open_sink(args.out)
-    case_reads = kevlar_amd.multi_file_iter_khmer([path for files in args.case for path in files])
+    case_reads = kevlar_amd.multi_file_iter_khmer([path for files in args.case for path in files], kept=kept)
     for blob in novel_text(case_reads, cases, controls, ksize=args.ksize, abundscreen=args.abund_screen, casemin=args.case_min,
                            ctrlmax=args.ctrl_max, numbands=args.num_bands, band=band, skipuntil=args.skip_until,
                            refbandquirk=getattr(args, 'ref_band_quirk', False)):
