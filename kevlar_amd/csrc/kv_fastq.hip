@@ -402,8 +402,21 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
             continue;
         }
         if (n == 0 && final && n_lines % 4 != 0) {
-            kv_set_error("%s ends inside a FASTQ record", d->path.c_str());
-            return KV_ERR_TYPE;
+            // blank lines behind the last record (a common way for a FASTQ file to end) are not a partial record: the few
+            // bytes are looked at on the host; only a genuinely cut record sends the file to the host parser
+            bool blank = total_in <= 4096;
+            if (blank) {
+                unsigned char tail[4096];
+                KV_HIP(hipMemcpyAsync(tail, text, total_in, hipMemcpyDeviceToHost, st));
+                KV_HIP(hipStreamSynchronize(st));
+                for (uint64_t i = 0; i < total_in && blank; ++i) blank = tail[i] == '\n' || tail[i] == '\r' || tail[i] == ' ' || tail[i] == '\t';
+            }
+            if (!blank) {
+                kv_set_error("%s ends inside a FASTQ record", d->path.c_str());
+                return KV_ERR_TYPE;
+            }
+            d->done = true; d->carry_len = 0;
+            return KV_OK;
         }
         d->next_member = m1;
         d->next_byte = b0 + (d->plain ? fresh : 0);

@@ -509,7 +509,10 @@ extern "C" int kv_fastx_next(kv_fastx *f, uint64_t max_reads, int upload, kv_rea
         kv_fastq_device_close(f->dev);
         f->dev = nullptr;
         f->dev_candidate = false;
-        if (rc != KV_ERR_TYPE) return rc;
+        // (KV_ERR_HIP: the device path's scratch did not fit next to big sketches, or a smaller GPU -- the host parser reads
+        // the same file with a few megabytes; a GPU that is really gone fails the next call anyway)
+        if (rc != KV_ERR_TYPE && rc != KV_ERR_HIP) return rc;
+        (void)hipGetLastError();
         uint64_t left = f->num_reads;
         while (left > 0) {
             uint64_t got = 0;

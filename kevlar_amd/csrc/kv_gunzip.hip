@@ -1217,7 +1217,12 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
         return KV_ERR_TYPE;
     }
     g->pending_isize = isize_seg;
-    if (crc_lost) g->crc_on = false;
+    if (crc_lost && g->crc_on) {
+        // one stretch ran over several member trailers: the per-member CRC-32 chain is broken from here on (only the ISIZE
+        // sum is still checked at the end); say so once instead of going quiet
+        g->crc_on = false;
+        fprintf(stderr, "[kv_gunzip] many small gzip members in one stretch: CRC-32 of the members is not checked beyond this point (sizes are)\n");
+    }
     const size_t nv = g->v_off.size();
     g->stat_segments += 1;
     g->stat_jobs += n_first;

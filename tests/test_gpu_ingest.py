@@ -315,3 +315,18 @@ def test_novel_cli_same_output_from_bgzf_and_plain_gzip(hk, tmp_path):
         import re
         return [re.sub(r'[0-9.]+ sec(onds)?', 'T sec', line) for line in lines]
     assert len(logs[0]) > 8 and untimed(logs[3]) == untimed(logs[0])
+
+
+@pytest.mark.parametrize('tail', ['\n\n', '\n\r\n \n', '\n'])
+def test_blank_lines_behind_the_last_record_stay_on_the_device(hk, tmp_path, tail):
+    """a FASTQ file that ends in blank lines is still four-line FASTQ: the device reader finishes it (no hand-over to the host
+    parser, which would read the whole file a second time) with the same records and counts"""
+    text = fastq_text(9000, 77).decode('ascii').rstrip('\n') + tail
+    path = str(tmp_path / 'tail.fq')
+    with open(path, 'w', newline='') as fh:
+        fh.write(text)
+    host = batches_of(hk, path, 4000, {'KV_INGEST': 'host'})
+    dev = batches_of(hk, path, 4000, None)
+    assert set(dev[3]) == {'DeviceTextBatch'} and set(host[3]) == {'TextBatch'}
+    assert host[4] == dev[4] == 9000 and dev[0] == host[0]
+    assert dev[1] == host[1] and dev[2] == host[2]
