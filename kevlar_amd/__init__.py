@@ -110,6 +110,7 @@ from kevlar_amd import unband  # noqa: E402
 from kevlar_amd import dist  # noqa: E402
 from kevlar_amd import split  # noqa: E402
 from kevlar_amd import augment  # noqa: E402
+from kevlar_amd import gentrio  # noqa: E402
 from kevlar_amd import cli  # noqa: E402
 
 

@@ -133,8 +133,22 @@ def _augment(sub):
     p.add_argument('seqs', help='sequences to annotate')
 
 
+def _gentrio(sub):
+    p = sub.add_parser('gentrio', description='Apply randomly generated mutations to the genome provided.')
+    p.add_argument('-i', '--inherited', type=int, metavar='I', default=20, help='number of shared/inherited mutations to simulate')
+    p.add_argument('-d', '--de-novo', type=int, metavar='D', default=10, help='number of unique/de novo mutations to simulate')
+    p.add_argument('--vcf', metavar='FILE', help='write mutations to a VCF file')
+    p.add_argument('--prefix', metavar='PFX', default='trio', help='prefix for output fasta files; default is "trio"')
+    p.add_argument('--weights', metavar='WT', default='snv=0.8,ins=0.1,del=0.1',
+                   help='comma-separated list of key/value pairs indicating the relative frequency of different variant types; '
+                        'default is "snv=0.8,ins=0.1,del=0.1"')
+    p.add_argument('-s', '--seed', metavar='S', default=None, type=int, help='seed for random number generator')
+    p.add_argument('genome', help='genome to mutate')
+
+
 mains = {
     'augment': kevlar_amd.augment.main,
+    'gentrio': kevlar_amd.gentrio.main,
     'split': kevlar_amd.split.main,
     'count': kevlar_amd.count.main,
     'dist': kevlar_amd.dist.main,
@@ -146,6 +160,7 @@ mains = {
 
 subparser_funcs = {
     'augment': _augment,
+    'gentrio': _gentrio,
     'split': _split,
     'count': _count,
     'dist': _dist,
@@ -159,7 +174,7 @@ subparser_funcs = {
 def parser():
     top = argparse.ArgumentParser(
         prog='kevlar', formatter_class=argparse.RawDescriptionHelpFormatter,
-        description='kevlar novel-k-mer discovery on AMD MI355X (count, novel, filter, partition, unband, dist, split, augment)')
+        description='kevlar novel-k-mer discovery on AMD MI355X (count, novel, filter, partition, unband, dist, split, augment, gentrio)')
     top._positionals.title = 'Subcommands'
     top._optionals.title = 'Global arguments'
     top.add_argument('-v', '--version', action='version', version='kevlar v{}'.format(kevlar_amd.__version__))

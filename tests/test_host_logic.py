@@ -535,3 +535,39 @@ def test_bench_write_gzip_is_one_valid_member(tmp_path):
         assert struct.unpack('<II', image[-8:]) == (zlib.crc32(text) & 0xffffffff, len(text))
     bench.write_gzip(str(tmp_path / 'empty.gz'), b'', threads=2)
     assert gzip.decompress(open(str(tmp_path / 'empty.gz'), 'rb').read()) == b''
+
+
+def test_gentrio_cli_writes_a_consistent_trio(tmp_path):
+    """kevlar/cli/gentrio.py:17-36, kevlar/gentrio.py:218-257: three two-haplotype FASTA files and a VCF whose genotypes
+    explain every difference between a haplotype and the reference; de novo variants are the proband's alone"""
+    import numpy as np
+    import kevlar_amd
+    rng = np.random.default_rng(5)
+    genome = {'chr1': ''.join(rng.choice(list('ACGT'), size=20000)), 'chr2': ''.join(rng.choice(list('ACGT'), size=9000))}
+    fasta = str(tmp_path / 'genome.fa')
+    with open(fasta, 'w') as fh:
+        for name, seq in genome.items():
+            fh.write('>{} some description\n{}\n'.format(name, seq))
+    prefix = str(tmp_path / 'fam')
+    args = kevlar_amd.cli.parser().parse_args(['gentrio', '-i', '12', '-d', '5', '--seed', '42', '--prefix', prefix,
+                                               '--vcf', str(tmp_path / 'fam.vcf'), fasta])
+    kevlar_amd.gentrio.main(args)
+    haps = {}
+    for ind in ('proband', 'mother', 'father'):
+        recs = list(kevlar_amd.parse_augmented_fastx(kevlar_amd.open('{}-{}.fasta'.format(prefix, ind), 'r')))
+        assert [r.name for r in recs] == ['chr1_haplo1', 'chr1_haplo2', 'chr2_haplo1', 'chr2_haplo2']
+        haps[ind] = {r.name: r.sequence for r in recs}
+    rows = [line.rstrip('\n').split('\t') for line in open(str(tmp_path / 'fam.vcf')) if not line.startswith('#')]
+    assert len(rows) == 17
+    denovo = [r for r in rows if r[10] == '0/0' and r[11] == '0/0']
+    assert len(denovo) >= 5 and all(r[9] in ('0/1', '1/0') for r in denovo)
+    for col, ind in ((9, 'proband'), (10, 'mother'), (11, 'father')):
+        for sid, seq in genome.items():
+            for hap in (0, 1):
+                carried = sorted((int(r[1]) - 1, r[3], r[4]) for r in rows if r[0] == sid and r[col][2 * hap] == '1')
+                assert kevlar_amd.gentrio.haplotype(seq, carried) == haps[ind]['{}_haplo{}'.format(sid, hap + 1)]
+    again = str(tmp_path / 'again')
+    args = kevlar_amd.cli.parser().parse_args(['gentrio', '-i', '12', '-d', '5', '--seed', '42', '--prefix', again, fasta])
+    kevlar_amd.gentrio.main(args)
+    assert open(again + '-proband.fasta').read() == open(prefix + '-proband.fasta').read()
+    assert kevlar_amd.gentrio.parse_weights('snv=2,del=2') == {'snv': 0.5, 'del': 0.5}
