@@ -1323,13 +1323,14 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.ncap = 32 * g.nbw - k + 1;
     const uint32_t table_slots = g.kw == 1 ? 4096u : 2048u;
     const char *tgt_env = getenv("KV_SKM_BUCKET_KMERS");      // tests shrink the buckets to exercise many of them on small inputs
-    // k-mers per fine bucket: as many as leave the LDS table ~0.4 full (0.35 for two-word keys, whose longer windows put
+    // k-mers per fine bucket: as many as leave the LDS table ~0.4 full (0.29 for two-word keys, whose longer windows put
     // fewer, bigger minimizer loci into a bucket: more variance) given the share of distinct k-mers the previous batch
     // into the same sketch -- or routed on the same stream -- showed; without one, a whole 30x sample is assumed
     // (~0.2 distinct).  Fuller tables overflow in the larger buckets: 34 % distinct k-mers in 8192-k-mer buckets (a
     // quarter of a 30x sample per batch) put 2.1 % of the occurrences on the slow path.
     const double frac = std::min(1.0, std::max(0.05, distinct_frac > 0.0 ? distinct_frac : 0.2));
-    uint64_t target = (uint64_t)((g.kw == 1 ? 0.4 : 0.35) * table_slots / frac);
+    // (two-word keys at 0.35: 2.2 M occurrences per 30x sample missed the tables and took the spill path, 67 ms per step of config 5; 0.29: 62 ms)
+    uint64_t target = (uint64_t)((g.kw == 1 ? 0.4 : 0.29) * table_slots / frac);
     target = std::max<uint64_t>(table_slots / 2, std::min<uint64_t>(target, g.kw == 1 ? 2ull * table_slots : table_slots + table_slots / 2));
     if (tgt_env) target = std::max<uint64_t>(64, strtoull(tgt_env, nullptr, 10));
     uint64_t nfine = std::max<uint64_t>(1, (n_kmers + target - 1) / target);
