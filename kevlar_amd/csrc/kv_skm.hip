@@ -85,6 +85,16 @@ namespace {
 
 // (32-byte records -- one aligned sector each, two 16-byte stores -- were measured against these 24-byte ones: WRITE_SIZE
 // fell from 2.5 to 2.3 GB per sample for 1.3 / 1.7 GB stored, the readers fetched 0.4 GB more each, times did not move.)
+// a record in as few store instructions as its size allows (every lane of a scattered store is its own cache line: the memory pipe
+// takes an instruction's 64 lines one by one, so three 8-byte stores cost three passes where a 16-byte and an 8-byte one cost two)
+__device__ __forceinline__ void skm_store_record_wide(uint64_t *dst, uint64_t hdr, const uint64_t *bw, int nbw)
+{
+    typedef uint64_t u64x2 __attribute__((ext_vector_type(2), aligned(8)));
+    *(u64x2 *)dst = u64x2{hdr, bw[0]};
+    if (nbw == 2) dst[2] = bw[1];
+    else if (nbw == 3) *(u64x2 *)(dst + 2) = u64x2{bw[1], bw[2]};
+}
+
 __device__ __forceinline__ void skm_store_record(uint64_t *dst, uint64_t hdr, const uint64_t *bw, int nbw)
 {
     dst[0] = hdr;
@@ -106,8 +116,8 @@ struct SkmTile {
     uint32_t bpre[KV_TILE_MAX_READS + 1];      // staged-base prefix: flat position of a read's first base
     uint32_t wpre[KV_TILE_MAX_READS + 1];      // packed-word prefix inside the tile
     uint32_t cpre[KV_TILE_MAX_READS + 1];      // chunk prefix (a chunk = CH consecutive k-mer starts of one read)
-    uint32_t uni_wpr, uni_cpr;                 // words / chunks per read if all reads of the tile have the same length, else 0
-    float inv_wpr, inv_cpr;
+    uint32_t uni_wpr, uni_cpr, uni_len;        // words / chunks / bases per read if all reads of the tile have the same length, else 0
+    float inv_wpr, inv_cpr, inv_len;
     uint32_t seg_start, read0, next_tile;
     uint32_t wtot[3][SKM_THREADS1 / 64];       // run starts per (round, wave)
 };
@@ -141,9 +151,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
     const uint32_t nwl = sg.np_max / 16u + KV_TILE_MAX_READS + 8u;     // every read starts on a word: up to one partial word each
     uint32_t *wl = smem;                                              // the tile's packed words
     uint32_t *mh = smem + nwl;                                        // order value of the m-mer starting at every base
-    uint16_t *ids = (uint16_t *)(mh + sg.np_max + 96u);               // bucket of the k-mer starting at every base: coarse << 8 | (fine & 255) ...
-    uint32_t *idhi = (uint32_t *)(ids + ((sg.np_max + 96u + 1u) & ~1u)); // ... and bits 8..11 of fine (up to 4096 fine buckets), a nibble per base
-    uint32_t *starts = mh;                                            // run starts: reuses mh once the minima are taken
+    uint16_t *starts = (uint16_t *)(mh + sg.np_max + 96u);            // run starts (flat positions < 2^16), in position order
     const int k = sg.k, m = sg.m, w = sg.w;
     const int lane = threadIdx.x & 63;
     for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_THREADS1) cur[c] = 0;
@@ -198,6 +206,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
                     const bool okk = L >= (uint32_t)k;
                     sh.uni_wpr = okk ? uni_wpr : 0u; sh.uni_cpr = okk ? cc : 0u;
                     sh.inv_wpr = okk ? 1.0f / (float)uni_wpr : 0.0f; sh.inv_cpr = okk ? 1.0f / (float)cc : 0.0f;
+                    sh.uni_len = okk ? L : 0u; sh.inv_len = okk ? 1.0f / (float)L : 0.0f;
                 }
             }
         } else if (threadIdx.x < 64) {
@@ -226,6 +235,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
                 const uint32_t wpr = (ref + 15u) >> 4, cpr = (ref - (uint32_t)k + 1u + CH - 1) / CH;
                 sh.uni_wpr = uniform ? wpr : 0u; sh.uni_cpr = uniform ? cpr : 0u;
                 sh.inv_wpr = uniform ? 1.0f / (float)wpr : 0.0f; sh.inv_cpr = uniform ? 1.0f / (float)cpr : 0.0f;
+                sh.uni_len = uniform ? ref : 0u; sh.inv_len = uniform ? 1.0f / (float)ref : 0.0f;
             }
             if (td.seg) {
                 if (threadIdx.x == 0) { sh.wpre[0] = 0; sh.wpre[1] = (l0 + 15) >> 4; }
@@ -250,25 +260,32 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
         const uint32_t NB = sh.bpre[nr];
         // P1: one thread per packed word: the order values of the m-mers starting at its 16 bases
         const uint32_t mmask = m == 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
-        for (uint32_t wi = threadIdx.x; wi < nwords; wi += SKM_THREADS1) {
+        for (uint32_t wi = threadIdx.x; wi < ((sg.dbg & 512u) ? 0u : nwords); wi += SKM_THREADS1) {
             const uint32_t r = sh.uni_wpr ? skm_div(wi, sh.uni_wpr, sh.inv_wpr) : skm_search(sh.wpre, nr, wi);
             const uint32_t j0 = (wi - sh.wpre[r]) * 16u, L = sh.len[r];
             const uint32_t q0 = sh.bpre[r] + j0;
             const uint64_t win = (uint64_t)wl[wi] | ((uint64_t)wl[wi + 1] << 32);
+            // the reverse complement of all 32 bases once: base i of `win`, complemented, is base 31 - i of `rcw`, so the reverse
+            // complement of the m-mer at base jj is the m-mer of rcw at base 32 - m - jj (m <= 16, jj <= 15)
+            const uint64_t rcw = ~skm_rev2_64(win);
+            const uint32_t rc0 = 2u * (32u - (uint32_t)m);
             // lane l starts at base l mod 16 of its word: the 64 stores of one instruction then fall into different banks
 #pragma unroll
             for (int step = 0; step < 16; ++step) {
                 const uint32_t jj = ((uint32_t)step + (uint32_t)lane) & 15u, j = j0 + jj;
-                if (j < L) mh[q0 + jj] = j + (uint32_t)m <= L ? skm_mmer_value((uint32_t)(win >> (2u * jj)) & mmask, m) : 0xffffffffu;
+                const uint32_t f = (uint32_t)(win >> (2u * jj)) & mmask, r = (uint32_t)(rcw >> (rc0 - 2u * jj)) & mmask;
+                if (j < L) mh[q0 + jj] = j + (uint32_t)m <= L ? skm_mix32(f < r ? f : r) : 0xffffffffu;
             }
         }
         if (threadIdx.x < 96) mh[NB + threadIdx.x] = 0xffffffffu;
-        for (uint32_t i = threadIdx.x; i < (NB >> 3) + 4u; i += SKM_THREADS1) idhi[i] = 0;
         __syncthreads();
         if (uni) prefetch(sh.next_tile);                   // written before this barrier; lands during P2 .. P4
-        // P2: one thread per chunk of CH k-mer starts: the minimum over the w m-mers of each (shared suffix of the
-        // chunk + the w - 1 - CH values every window contains + a growing prefix), its bucket, and where runs start
+        // P2: one thread per chunk of CH k-mer starts: the minimum over the w m-mers of each (shared suffix of the chunk + the
+        // w - 1 - CH values every window contains + a growing prefix) and where it changes.  A run is a stretch of k-mers with the
+        // same minimizer VALUE (its bucket is a function of that value, taken once per run in P4; two values that share a bucket
+        // -- one pair in C1 x F2 -- merely give two records where one would have done).
         const uint32_t nchunks = (sg.dbg & 32u) ? 0u : sh.cpre[nr];             // <= 8192 / CH + 64 < 3 * SKM_THREADS1
+        const uint32_t nrounds = (nchunks + SKM_THREADS1 - 1u) / SKM_THREADS1;
         uint32_t my_q[3], my_starts[3];
 #pragma unroll
         for (int round = 0; round < 3; ++round) {
@@ -285,63 +302,54 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
                 suf[0] = j > 0 ? min(run, mh[q - 1]) : run;
                 uint32_t mid = 0xffffffffu;
                 for (uint32_t t = CH; t + 2 <= (uint32_t)w; ++t) mid = min(mid, mh[q + t]);     // mh[q + CH .. q + w - 2]
-                uint32_t coarse, fine;
-                skm_bucket_of(min(suf[0], mid), sg.C1, sg.fbits, coarse, fine);
-                uint32_t prev = (coarse << 12) | fine;    // bucket of the k-mer in front of the chunk (unused when j == 0)
-                uint64_t himask = 0;                      // CH <= 16 nibbles
+                uint32_t prev = min(suf[0], mid);         // minimizer of the k-mer in front of the chunk (unused when j == 0)
+                uint32_t diff = j == 0 ? 1u : 0u;
                 run = 0xffffffffu;
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
                     run = min(run, mh[q + (uint32_t)w - 1u + i]);
-                    skm_bucket_of(min(min(suf[i + 1], mid), run), sg.C1, sg.fbits, coarse, fine);
-                    const uint32_t id = (coarse << 12) | fine;
-                    if (j + (uint32_t)i < nkr) {
-                        ids[q + i] = (uint16_t)((coarse << 8) | (fine & 0xffu));
-                        himask |= (uint64_t)(fine >> 8) << (4 * i);
-                        if (j + (uint32_t)i == 0 || id != prev) startmask |= 1u << i;
-                    }
-                    prev = id;
+                    const uint32_t v = min(min(suf[i + 1], mid), run);
+                    diff |= (v != prev ? 1u : 0u) << i;
+                    prev = v;
                 }
-                if (himask) {                             // CH <= 16 nibbles starting at nibble q: at most three words
-                    const uint32_t sh4 = 4u * (q & 7u);
-                    const uint32_t w0 = (uint32_t)(himask << sh4), w1 = (uint32_t)((himask << sh4) >> 32);
-                    const uint32_t w2 = sh4 ? (uint32_t)(himask >> (64u - sh4)) : 0u;
-                    if (w0) atomicOr(&idhi[q >> 3], w0);
-                    if (w1) atomicOr(&idhi[(q >> 3) + 1u], w1);
-                    if (w2) atomicOr(&idhi[(q >> 3) + 2u], w2);
-                }
+                const uint32_t nv = min((uint32_t)CH, nkr - j);          // k-mers of the read that start in this chunk (>= 1)
+                startmask = diff & ((2u << (nv - 1u)) - 1u);
             }
             my_q[round] = q; my_starts[round] = startmask;
         }
         // run starts in position order (chunks are numbered in position order): prefix over lanes, waves, rounds
-        uint32_t incl[3];
+        uint32_t incl[3] = {0u, 0u, 0u};
 #pragma unroll
         for (int round = 0; round < 3; ++round) {
-            uint32_t v = (uint32_t)__popc(my_starts[round]);
+            if ((uint32_t)round < nrounds) {
+                uint32_t v = (uint32_t)__popc(my_starts[round]);
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(v, d);
-                if (lane >= d) v += up;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = __shfl_up(v, d);
+                    if (lane >= d) v += up;
+                }
+                incl[round] = v;
+                if (lane == 63) sh.wtot[round][threadIdx.x >> 6] = v;
             }
-            incl[round] = v;
-            if (lane == 63) sh.wtot[round][threadIdx.x >> 6] = v;
         }
-        __syncthreads();                                  // every window minimum is taken: the run starts may overwrite mh
+        __syncthreads();
         uint32_t nstart = 0;
 #pragma unroll
         for (int round = 0; round < 3; ++round) {
-            uint32_t before = nstart;
-            for (uint32_t wv = 0; wv < SKM_THREADS1 / 64; ++wv) {
-                const uint32_t n = sh.wtot[round][wv];
-                if (wv < (threadIdx.x >> 6)) before += n;
-                nstart += n;
-            }
-            uint32_t base = before + incl[round] - (uint32_t)__popc(my_starts[round]);
-            uint32_t bits = my_starts[round];
-            while (bits) {
-                const int i = __ffs((int)bits) - 1;
-                bits &= bits - 1;
-                starts[base++] = my_q[round] + (uint32_t)i;
+            if ((uint32_t)round < nrounds) {
+                uint32_t before = nstart;
+                for (uint32_t wv = 0; wv < SKM_THREADS1 / 64; ++wv) {
+                    const uint32_t n = sh.wtot[round][wv];
+                    if (wv < (threadIdx.x >> 6)) before += n;
+                    nstart += n;
+                }
+                uint32_t base = before + incl[round] - (uint32_t)__popc(my_starts[round]);
+                uint32_t bits = my_starts[round];
+                while (bits) {
+                    const int i = __ffs((int)bits) - 1;
+                    bits &= bits - 1;
+                    starts[base++] = (uint16_t)(my_q[round] + (uint32_t)i);
+                }
             }
         }
         if (sg.dbg & 16u) nstart = 0;
@@ -349,12 +357,14 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
         // P4: one thread per run: measure it, cut it into records of <= ncap k-mers, store them
         for (uint32_t i = threadIdx.x; i < nstart; i += SKM_THREADS1) {
             const uint32_t q = starts[i];
-            const uint32_t r = skm_search(sh.bpre, nr, q), j = q - sh.bpre[r];
-            const uint32_t id = ids[q];
+            const uint32_t r = sh.uni_len ? skm_div(q, sh.uni_len, sh.inv_len) : skm_search(sh.bpre, nr, q), j = q - sh.bpre[r];
             const uint32_t limit = q - j + sh.nk[r];          // flat position one past the read's last k-mer
-            const uint32_t nxt = i + 1 < nstart ? starts[i + 1] : limit;       // the next run (of this read or a later one)
+            const uint32_t nxt = i + 1 < nstart ? (uint32_t)starts[i + 1] : limit;     // the next run (of this read or a later one)
             uint32_t left = (nxt < limit ? nxt : limit) - q;
-            const uint32_t coarse = id >> 8, fine = (id & 0xffu) | (((idhi[q >> 3] >> (4u * (q & 7u))) & 15u) << 8);
+            uint32_t minv = 0xffffffffu;
+            for (uint32_t t = 0; t < (uint32_t)w; ++t) minv = min(minv, mh[q + t]);
+            uint32_t coarse, fine;
+            skm_bucket_of(minv, sg.C1, sg.fbits, coarse, fine);
             uint64_t pos = (sg.read_base + sh.read0 + r) * sg.stride + sh.seg_start + j;
             uint32_t b = sh.wpre[r] * 16u + j;                // base index inside wl
             while (left) {
@@ -364,7 +374,8 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
                 for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? skm_bases32(wl, b + 32u * t) : 0ull;
                 const uint64_t hdr = skm_header(pos, n, fine);
                 const uint32_t p = atomicAdd(&cur[coarse], 1u);
-                if (p < sg.cap1) skm_store_record(sg.seg1 + (((uint64_t)coarse * sg.nwg1 + blockIdx.x) * sg.cap1 + p) * (uint64_t)sg.recw, hdr, bw, sg.nbw);
+                if (sg.dbg & 1024u) n_rec += hdr ^ bw[0] ^ bw[1];
+                else if (p < sg.cap1) skm_store_record(sg.seg1 + (((uint64_t)coarse * sg.nwg1 + blockIdx.x) * sg.cap1 + p) * (uint64_t)sg.recw, hdr, bw, sg.nbw);
                 else skm_loose_push(sg, hdr, bw);
                 n_rec += 1;
                 left -= n; pos += n; b += n;
@@ -375,6 +386,187 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
     for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_THREADS1) sg.cnt1[(uint64_t)c * sg.nwg1 + blockIdx.x] = min(cur[c], sg.cap1);
     n_rec = wave_sum_u64(n_rec);
     if ((threadIdx.x & 63) == 0 && n_rec) atomicAdd(&sg.ctr[5], (unsigned long long)n_rec);
+}
+
+// ---- S1, batches of equal-length reads: a wave per group of reads -----------------------------------------------
+// The tile kernel above spends most of its time parked: six workgroup barriers per tile, between phases that keep 60-80 % of
+// the lanes busy, and a phase is as slow as its slowest wave (dissected: skeleton 0.37 ms, order values 0.37, minima + run
+// starts 0.43, records 0.30, their stores 0.43 per 7.5 M reads).  When every read of the batch has the same length the layout
+// is arithmetic, so a WAVE can take R consecutive reads (R x words per read <= 64: one packed word per lane) through the same
+// four phases on its own slice of LDS with no workgroup barrier at all -- only the order of its own LDS operations -- and the
+// 24 waves of a CU are in different phases at any time.  The workgroup still shares the coarse cursors and its segments.
+#define SKM_MT_PER_TICKET 64u     // 1 M groups per 7.5 M reads: one device-wide counter takes ~90 updates per microsecond (16 per ticket: 0.74 ms of the kernel)
+#define SKM_WAVE_RUNS 128u        // runs of a group listed at a time (a group has ~55; more go round again)
+// Flat position of base j of the group's read r: r * Lp + j with Lp = 16 * words per read, so a position is also the base index
+// into the staged words.  Order values live at mh[p + (p >> PS)], PS = log2(CH): a padding word per chunk, so that lanes that
+// walk consecutive chunks (P2) or consecutive words (P1) hit different banks and every offset inside a chunk is a constant.
+__host__ __device__ inline uint32_t skm_wave_slice_words(uint32_t R, uint32_t L, uint32_t nk, int ch)
+{
+    const uint32_t lp = 16u * ((L + 15u) >> 4), pmax = R * lp + 96u;
+    (void)nk;
+    return 132u + pmax + pmax / (uint32_t)ch + 2u + SKM_WAVE_RUNS + (SKM_WAVE_RUNS + 2u) / 2u;      // words (twice), order values, minimizer + start of SKM_WAVE_RUNS runs at a time
+}
+
+template <int CH>
+__global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, SkmGeom sg, uint32_t R, uint32_t n_mt, uint32_t quota_mt)
+{
+    constexpr uint32_t PS = CH == 16 ? 4u : 3u;
+    __shared__ uint32_t cur[256];
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t wave = threadIdx.x >> 6;
+    const int k = sg.k, m = sg.m, w = sg.w;
+    const uint32_t L = rd.uni_len, wpr = (L + 15u) >> 4, Lp = 16u * wpr, nk = L - (uint32_t)k + 1u, cpr = (nk + CH - 1) / CH;
+    const float inv_wpr = 1.0f / (float)wpr, inv_cpr = 1.0f / (float)cpr;
+    const uint32_t pmax = R * Lp + 96u;
+    uint32_t *wl0 = smem + wave * skm_wave_slice_words(R, L, nk, CH), *mh = wl0 + 132u;
+    uint32_t *sval = mh + pmax + pmax / CH + 2u;
+    uint16_t *starts = (uint16_t *)(sval + SKM_WAVE_RUNS);
+    for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_THREADS1) cur[c] = 0;
+    if ((threadIdx.x & 63u) < 2u) { wl0[64u + (threadIdx.x & 63u)] = 0; wl0[130u + (threadIdx.x & 63u)] = 0; }
+    __syncthreads();
+    const uint32_t mmask = m == 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
+    const uint32_t rc0 = 2u * (32u - (uint32_t)m);
+    uint64_t n_rec = 0;
+    uint32_t mt = 0, mt_end = 0, taken = 0, pf = 0, pf_mt = 0xffffffffu, parity = 0;
+    for (;;) {
+        // (everything P1 and P2 derive from the lane number alone is the same for every group; left to itself the compiler
+        // computes all of it once in front of the loop -- 16 shift pairs, 32 lane masks -- and spills it: 196 bytes of scratch
+        // per lane and two reloads per order value.  An opaque copy of the lane number keeps the arithmetic where it is used.)
+        uint32_t lane = threadIdx.x & 63u;
+        asm volatile("" : "+v"(lane));
+        auto words_of = [&](uint32_t t) -> uint32_t {
+            const uint64_t r0 = (uint64_t)t * R;
+            const uint32_t nr = (uint32_t)min((uint64_t)R, rd.n_reads - r0);
+            return lane < nr * wpr ? rd.words[r0 * wpr + lane] : 0u;
+        };
+        if (mt == mt_end) {
+            if (taken >= quota_mt) break;
+            uint32_t t = 0;
+            if (lane == 0) t = (uint32_t)atomicAdd(&sg.ctr[2], 1ull);
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            if ((uint64_t)t * SKM_MT_PER_TICKET >= n_mt) break;
+            mt = t * SKM_MT_PER_TICKET;
+            mt_end = min(mt + SKM_MT_PER_TICKET, n_mt);
+        }
+        const uint64_t r0 = (uint64_t)mt * R;
+        const uint32_t nr = (uint32_t)min((uint64_t)R, rd.n_reads - r0), nwords = nr * wpr;
+        // The next group's words are requested now and WAITED FOR in front of P4: a wait at the top of the next round would also
+        // wait for this round's record stores (one counter, in order), i.e. for a round trip to HBM per group.
+        uint32_t *wl = wl0 + 66u * parity;
+        uint32_t word;
+        if (pf_mt == mt) word = pf;                               // (already in the other buffer's place: stored below)
+        else { word = words_of(mt); wl[lane] = word; }
+        const bool more = mt + 1u < mt_end;
+        if (more) { pf = words_of(mt + 1u); pf_mt = mt + 1u; }
+        // P1: the order values of the m-mers starting at the 16 bases of this lane's word.  (Values of m-mers that run past the
+        // end of their read are garbage: no window of a k-mer of the read contains them.)
+        if (lane < nwords && !(sg.dbg & 512u)) {
+            const uint32_t up = (uint32_t)__shfl_down((int)word, 1);
+            const uint64_t win = (uint64_t)word | ((uint64_t)(lane == 63u ? 0u : up) << 32);
+            const uint64_t rcw = ~skm_rev2_64(win);
+            uint32_t *dst = mh + 16u * lane + (CH == 16 ? lane : 2u * lane);
+#pragma unroll
+            for (int step = 0; step < 16; ++step) {
+                const uint32_t f = (uint32_t)(win >> (2 * step)) & mmask, rv = (uint32_t)(rcw >> (rc0 - 2u * (uint32_t)step)) & mmask;
+                dst[step + (step >> PS)] = skm_mix32(f < rv ? f : rv);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // P2: a lane per chunk of CH k-mer starts: window minima (shared suffix of the chunk + the values every window of the chunk
+        // contains + a growing prefix) and where they change; then every run start with its minimizer, in position order
+        const uint32_t nchunks = (sg.dbg & 32u) ? 0u : nr * cpr;
+        uint32_t startmask = 0, q = 0;
+        uint32_t v[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] = 0;
+        if (lane < nchunks) {
+            const uint32_t r = skm_div(lane, cpr, inv_cpr);
+            const uint32_t j = (lane - r * cpr) * CH;
+            q = r * Lp + j;                                   // a multiple of CH
+            const uint32_t *src = mh + q + (q >> PS);
+            auto at = [&](uint32_t i) -> uint32_t { return src[i + (i >> PS)]; };       // i: constant offsets from the chunk's first value
+            uint32_t suf[CH + 1];
+            uint32_t run = 0xffffffffu;
+#pragma unroll
+            for (int i = CH - 1; i >= 0; --i) { run = min(run, at((uint32_t)i)); suf[i + 1] = run; }
+            suf[0] = j > 0 ? min(run, mh[q - 1u + ((q - 1u) >> PS)]) : run;
+            uint32_t mid = 0xffffffffu;
+            for (uint32_t t = CH; t + 2 <= (uint32_t)w; ++t) mid = min(mid, at(t));
+            uint32_t prev = min(suf[0], mid);
+            uint32_t diff = j == 0 ? 1u : 0u;
+            run = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                run = min(run, at((uint32_t)w - 1u + (uint32_t)i));
+                v[i] = min(min(suf[i + 1], mid), run);
+                diff |= (v[i] != prev ? 1u : 0u) << i;
+                prev = v[i];
+            }
+            const uint32_t nv = min((uint32_t)CH, nk - j);
+            startmask = diff & ((2u << (nv - 1u)) - 1u);
+        }
+        uint32_t incl = (uint32_t)__popc(startmask);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t upv = __shfl_up(incl, d);
+            if (lane >= (uint32_t)d) incl += upv;
+        }
+        uint32_t nstart = (uint32_t)__shfl((int)incl, 63);
+        if (sg.dbg & 16u) nstart = 0;
+        if (more) wl0[66u * (parity ^ 1u) + lane] = pf;
+        for (uint32_t lo = 0; lo < nstart; lo += SKM_WAVE_RUNS) {
+            // runs lo .. lo + SKM_WAVE_RUNS (one more than are processed: the end of the last one), listed by the lanes that found them
+            {
+                uint32_t at = incl - (uint32_t)__popc(startmask) - lo;          // wraps for runs in front of this round: fails the test below
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    if ((startmask >> i) & 1u) {
+                        if (at <= SKM_WAVE_RUNS) { starts[at] = (uint16_t)(q + (uint32_t)i); if (at < SKM_WAVE_RUNS) sval[at] = v[i]; }
+                        at += 1u;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // P4: a lane per run: its bucket, its records
+            const uint32_t here = min(SKM_WAVE_RUNS, nstart - lo);
+            for (uint32_t i = lane; i < here; i += 64u) {
+                const uint32_t qs = starts[i];
+                const uint32_t r = skm_div(qs >> 4, wpr, inv_wpr), j = qs - r * Lp;
+                const uint32_t limit = qs - j + nk;                // position one past the read's last k-mer
+                const uint32_t nxt = lo + i + 1u < nstart ? (uint32_t)starts[i + 1] : limit;
+                uint32_t left = (nxt < limit ? nxt : limit) - qs;
+                uint32_t coarse, fine;
+                skm_bucket_of(sval[i], sg.C1, sg.fbits, coarse, fine);
+                uint64_t pos = (sg.read_base + r0 + r) * sg.stride + j;
+                uint32_t b = qs;
+                while (left) {
+                    const uint32_t n = min(left, (uint32_t)sg.ncap);
+                    uint64_t bw[3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? skm_bases32(wl, b + 32u * t) : 0ull;
+                    const uint64_t hdr = skm_header(pos, n, fine);
+                    const uint32_t p = atomicAdd(&cur[coarse], 1u);
+                    if (sg.dbg & 1024u) n_rec += hdr ^ bw[0] ^ bw[1];
+                    else if (p < sg.cap1) skm_store_record_wide(sg.seg1 + (((uint64_t)coarse * sg.nwg1 + blockIdx.x) * sg.cap1 + p) * (uint64_t)sg.recw, hdr, bw, sg.nbw);
+                    else skm_loose_push(sg, hdr, bw);
+                    n_rec += 1;
+                    left -= n; pos += n; b += n;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        parity ^= 1u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        mt += 1; taken += 1;
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_THREADS1) sg.cnt1[(uint64_t)c * sg.nwg1 + blockIdx.x] = min(cur[c], sg.cap1);
+    n_rec = wave_sum_u64(n_rec);
+    if ((threadIdx.x & 63u) == 0 && n_rec) atomicAdd(&sg.ctr[5], (unsigned long long)n_rec);
 }
 
 // ---- S2 ------------------------------------------------------------------------------------------------
@@ -1199,11 +1391,51 @@ inline uint32_t pow2_ceil(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; r
 
 int skm_minimizer_len(int k) { return k >= 24 ? 12 : k / 2; }
 
+// reads per wave and chunk size of the wave kernel for batches of equal-length reads (0: use the tile kernel).  One packed
+// word and one chunk per lane, and about as many runs as lanes: a run per (w + 1) / 2 k-mers, one more per read.
+static uint32_t skm_wave_plan(const SkmGeom &g, const kv_reads *reads, int *ch)
+{
+    const uint32_t L = reads->uni_len;
+    if (!L || L < (uint32_t)g.k || g.w <= 8) return 0;
+    if (const char *e = getenv("KV_SKM_S1")) if (!strcmp(e, "tile")) return 0;
+    const uint32_t wpr = (L + 15) / 16, nk = L - (uint32_t)g.k + 1;
+    const double runs = 1.0 + (nk - 1) * 2.0 / (g.w + 1) + (double)nk / g.ncap * 0.5;
+    uint32_t best = 0;
+    for (int c : {16, 8}) {
+        if (g.w <= c) continue;
+        const uint32_t cpr = (nk + c - 1) / c;
+        uint32_t R = std::min<uint32_t>(64 / wpr, 64 / cpr);
+        R = std::min<uint32_t>(R, (uint32_t)(58.0 / runs));
+        if (const char *e = getenv("KV_SKM_R")) R = std::min<uint32_t>(std::min<uint32_t>(64 / wpr, 64 / cpr), (uint32_t)atoi(e));
+        if (R >= best && R > 0) { best = R; *ch = c; }       // equal R: the smaller chunk keeps more lanes busy
+    }
+    if (const char *e = getenv("KV_SKM_CH")) { const int c = atoi(e); if ((c == 8 || c == 16) && g.w > c) { *ch = c; best = std::min<uint32_t>(best, 64 / ((nk + c - 1) / c)); } }
+    if (best < 2) return 0;
+    if ((size_t)skm_wave_slice_words(best, L, nk, *ch) * 4 * (SKM_THREADS1 / 64) + 2048 > 54000) return 0;       // three workgroups per CU or the tile kernel
+    return best;
+}
+
 void skm_launch_emit(const SkmGeom &g, const kv_reads *reads, hipStream_t st)
 {
     KvProfScope prof("k_skm_emit");
-    const size_t lds = ((size_t)g.np_max / 16 + KV_TILE_MAX_READS + 8 + (size_t)g.np_max + 96) * 4 + (((size_t)g.np_max + 96 + 1) & ~(size_t)1) * 2 +
-                       ((size_t)g.np_max / 8 + 8) * 4;
+    int ch = 16;
+    if (const uint32_t R = skm_wave_plan(g, reads, &ch)) {
+        const uint32_t L = reads->uni_len, nk = L - (uint32_t)g.k + 1;
+        const size_t lds = (size_t)skm_wave_slice_words(R, L, nk, ch) * 4 * (SKM_THREADS1 / 64);
+        const uint64_t n_mt = (reads->n_reads + R - 1) / R;
+        // the same share of the batch per workgroup as the tile kernel's quota, dealt to its waves
+        const uint64_t per_wave = (uint64_t)g.quota1 * reads->uni_per_tile / R / (SKM_THREADS1 / 64) + SKM_MT_PER_TICKET;
+        const uint32_t quota_mt = (uint32_t)std::min<uint64_t>(kv_round_up(per_wave, SKM_MT_PER_TICKET), 0xfffffff0ull);
+        if (ch == 16) {
+            kv_ensure_dynamic_lds((const void *)k_skm_emit_wave<16>, lds);
+            hipLaunchKernelGGL(k_skm_emit_wave<16>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), g, R, (uint32_t)n_mt, quota_mt);
+        } else {
+            kv_ensure_dynamic_lds((const void *)k_skm_emit_wave<8>, lds);
+            hipLaunchKernelGGL(k_skm_emit_wave<8>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), g, R, (uint32_t)n_mt, quota_mt);
+        }
+        return;
+    }
+    const size_t lds = ((size_t)g.np_max / 16 + KV_TILE_MAX_READS + 8 + (size_t)g.np_max + 96) * 4 + (((size_t)g.np_max + 96 + 1) & ~(size_t)1) * 2;
     if (g.w > 16) {
         kv_ensure_dynamic_lds((const void *)k_skm_emit<16>, lds);
         hipLaunchKernelGGL(k_skm_emit<16>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), reads->n_tiles, g);
