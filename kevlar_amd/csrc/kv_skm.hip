@@ -274,7 +274,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
             for (int step = 0; step < 16; ++step) {
                 const uint32_t jj = ((uint32_t)step + (uint32_t)lane) & 15u, j = j0 + jj;
                 const uint32_t f = (uint32_t)(win >> (2u * jj)) & mmask, r = (uint32_t)(rcw >> (rc0 - 2u * jj)) & mmask;
-                if (j < L) mh[q0 + jj] = j + (uint32_t)m <= L ? skm_mix32(f < r ? f : r) : 0xffffffffu;
+                if (j < L) mh[q0 + jj] = j + (uint32_t)m <= L ? skm_order32(f < r ? f : r) : 0xffffffffu;
             }
         }
         if (threadIdx.x < 96) mh[NB + threadIdx.x] = 0xffffffffu;
@@ -427,6 +427,8 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, 
     const uint32_t mmask = m == 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
     const uint32_t rc0 = 2u * (32u - (uint32_t)m);
     uint64_t n_rec = 0;
+    uint64_t *const my_seg = sg.seg1 + (uint64_t)blockIdx.x * sg.cap1 * (uint64_t)sg.recw;       // + coarse * cstride: this workgroup's segment of a coarse bucket
+    const uint64_t cstride = (uint64_t)sg.nwg1 * sg.cap1 * (uint64_t)sg.recw;
     uint32_t mt = 0, mt_end = 0, taken = 0, pf = 0, pf_mt = 0xffffffffu, parity = 0;
     for (;;) {
         // (everything P1 and P2 derive from the lane number alone is the same for every group; left to itself the compiler
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, 
 #pragma unroll
             for (int step = 0; step < 16; ++step) {
                 const uint32_t f = (uint32_t)(win >> (2 * step)) & mmask, rv = (uint32_t)(rcw >> (rc0 - 2u * (uint32_t)step)) & mmask;
-                dst[step + (step >> PS)] = skm_mix32(f < rv ? f : rv);
+                dst[step + (step >> PS)] = skm_order32(f < rv ? f : rv);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, 
                     const uint64_t hdr = skm_header(pos, n, fine);
                     const uint32_t p = atomicAdd(&cur[coarse], 1u);
                     if (sg.dbg & 1024u) n_rec += hdr ^ bw[0] ^ bw[1];
-                    else if (p < sg.cap1) skm_store_record_wide(sg.seg1 + (((uint64_t)coarse * sg.nwg1 + blockIdx.x) * sg.cap1 + p) * (uint64_t)sg.recw, hdr, bw, sg.nbw);
+                    else if (p < sg.cap1) skm_store_record_wide(my_seg + coarse * cstride + p * (uint32_t)sg.recw, hdr, bw, sg.nbw);
                     else skm_loose_push(sg, hdr, bw);
                     n_rec += 1;
                     left -= n; pos += n; b += n;
@@ -795,7 +797,7 @@ __device__ __forceinline__ uint32_t skm_count_kmer(uint64_t h, uint32_t count, c
 // every wave walks its share of the table and hands the occupied slots to `body` 64 at a time (all lanes busy):
 // occupied slots are queued in LDS and drained whenever a full wave of them is ready
 template <int TS, typename Body>
-__device__ __forceinline__ void skm_for_occupied(const unsigned long long *key0, uint16_t *queue_all, uint32_t queue_stride, Body body)
+__device__ __forceinline__ void skm_for_occupied(const unsigned long long *key0, uint16_t *queue_all, uint32_t queue_stride, Body body, const uint32_t *skip = nullptr)
 {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
     uint16_t *queue = queue_all + wave * queue_stride;               // >= 128 entries; wave-private, ordered by the fences below
@@ -806,7 +808,7 @@ __device__ __forceinline__ void skm_for_occupied(const unsigned long long *key0,
         const bool last = s0 >= s_end;
         if (!last) {
             const uint32_t slot = s0 + lane;
-            const bool occ = key0[slot] != SKM_EMPTY;
+            const bool occ = key0[slot] != SKM_EMPTY && !(skip && ((skip[slot >> 5] >> (slot & 31u)) & 1u));      // skip: a bit per slot
             const unsigned long long ballot = __ballot(occ);
             if (occ) __hip_atomic_store(&queue[qn + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull))], (uint16_t)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             qn += (uint32_t)__popcll(ballot);
@@ -1281,13 +1283,12 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
         __syncthreads();
         // evaluate each of them once
         if (!(sg.dbg & 4u)) skm_for_occupied<TS>(tb.key[0], (uint16_t *)scratch, skm_wave_scratch_words(sg.sbw) * 2u, [&](uint32_t slot) {
-            if ((rej[slot >> 5] >> (slot & 31)) & 1u) return;
             SkmKey<KW> c;
             c.w[0] = tb.key[0][slot];
             if (KW == 2) c.w[KW - 1] = tb.key[KW - 1][slot];
             const uint64_t h = skm_key_hash<KW>(c, lut, p.hp);
             if (band_pass(p, h) && novel_test_fast(ns, p, h, nullptr, 0ull)) { atomicOr(&flag[slot >> 5], 1u << (slot & 31)); any_hit = 1; }
-        });
+        }, rej);            // (keys a control's list rejects are not queued: 25 M of 106 M at config 2, lanes that used to sit out their wave's hashes)
         __syncthreads();
         if (any_hit == 0 || (sg.dbg & 8u)) continue;
         // mark every occurrence of an interesting k-mer (an occurrence whose key is absent went to the loose list)

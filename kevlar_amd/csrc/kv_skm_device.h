@@ -54,12 +54,21 @@ KV_HD uint32_t skm_mix32(uint32_t x)
     return x;
 }
 
+// the order the minimizer is the minimum of: a bijection whose high bits -- the ones a comparison looks at first -- depend on every
+// bit of the code (odd multiplier), low bits folded in for the ties.  Two instructions cheaper per base than the full mixer, which S1
+// is sensitive to (one value per base); how evenly minimizers fall into buckets is skm_bucket_of's business, not this function's.
+KV_HD uint32_t skm_order32(uint32_t x)
+{
+    x *= 0x9e3779b1u;
+    return x ^ (x >> 15);
+}
+
 // order value of the m-mer (m <= 16) whose forward code is f: mix of min(forward, reverse complement)
 KV_HD uint32_t skm_mmer_value(uint32_t f, int m)
 {
     const uint32_t mmask = m == 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
     const uint32_t r = (skm_rev2_32(f) >> (32 - 2 * m)) ^ mmask;
-    return skm_mix32(f < r ? f : r);
+    return skm_order32(f < r ? f : r);
 }
 
 // minimizer value -> (coarse, fine) bucket.  The minimum of w uniform values is far from uniform, hence the second mix.
