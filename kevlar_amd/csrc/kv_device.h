@@ -36,15 +36,7 @@ __device__ __forceinline__ uint64_t mm_final(uint64_t h1, uint64_t h2, int len)
     return h1 + h2;
 }
 
-// h % size with the precomputed reciprocal magic = floor((2^64-1)/size): q is at most 2 short
-__device__ __forceinline__ uint64_t fastmod(uint64_t h, uint64_t size, uint64_t magic)
-{
-    uint64_t q = __umul64hi(h, magic);
-    uint64_t r = h - q * size;
-    r -= r >= size ? size : 0;       // twice, branch-free: the quotient is at most 2 short
-    r -= r >= size ? size : 0;
-    return r;
-}
+// h % size: fastmod(h, size, magic) of kv_fastmod.h (included at the top)
 
 // MurmurHash3_x64_128 (low word) of the k bytes at LDS byte address `a`
 __device__ __forceinline__ uint64_t murmur_lds(const uint32_t *lds, uint32_t a, const HashParams &hp)

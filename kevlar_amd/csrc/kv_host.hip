@@ -329,7 +329,7 @@ int kv_sketch_alloc(int kind, int ksize, int ntables, const uint64_t *sizes, kv_
     for (int i = 0; i < ntables; ++i) {
         if (sizes[i] == 0) { kv_set_error("table size must be positive"); delete s; return KV_ERR_ARG; }
         s->h.size[i] = sizes[i];
-        s->h.magic[i] = UINT64_MAX / sizes[i];
+        s->h.magic[i] = kv_fastmod_magic(sizes[i]);
         uint64_t nb = kv_table_nbytes(s->h.storage, sizes[i]);
         s->alloc_bytes[i] = (nb + 15) & ~15ull;  // word-granular atomics need padding
     }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/kvsketch.h"
+#include "kv_fastmod.h"
 
 enum { ST_BYTE = 0, ST_NIBBLE = 1, ST_BIT = 2 };
 enum { HF_MURMUR = 0, HF_TWOBIT = 1 };
@@ -33,7 +34,7 @@ static inline uint64_t kv_table_nbytes(int storage, uint64_t size)
 // read it through scalar loads; also kept on the host.
 struct SketchDev {
     uint64_t size[KV_MAX_TABLES];
-    uint64_t magic[KV_MAX_TABLES];  // floor((2^64-1)/size): Barrett reciprocal for h % size
+    uint64_t magic[KV_MAX_TABLES];  // kv_fastmod_magic(size): the reciprocal fastmod() wants for this size (kv_fastmod.h)
     uint8_t *tab[KV_MAX_TABLES];
     int32_t ntables, storage, hashfam, ksize;
 };

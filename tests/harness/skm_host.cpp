@@ -3,6 +3,7 @@
 // with string-level restatements.
 #include <stdint.h>
 #include "../../kevlar_amd/csrc/kv_skm_device.h"
+#include "../../kevlar_amd/csrc/kv_fastmod.h"
 
 template <int KW>
 static void t_revcomp(const uint64_t *in, int k, uint64_t *out)
@@ -40,4 +41,11 @@ uint64_t h_header(uint64_t pos, uint32_t n, uint32_t fine) { return skm_header(p
 uint64_t h_hdr_pos(uint64_t h) { return skm_hdr_pos(h); }
 uint32_t h_hdr_n(uint64_t h) { return skm_hdr_n(h); }
 uint32_t h_hdr_fine(uint64_t h) { return skm_hdr_fine(h); }
+uint64_t h_fastmod_magic(uint64_t size) { return kv_fastmod_magic(size); }
+// out[i] = fastmod(h[i], size): the device's remainder arithmetic (FP64 quotient or Barrett, by the size), on the host's IEEE doubles
+void h_fastmod(const uint64_t *h, uint64_t n, uint64_t size, uint64_t *out)
+{
+    const uint64_t magic = kv_fastmod_magic(size);
+    for (uint64_t i = 0; i < n; ++i) out[i] = fastmod(h[i], size, magic);
+}
 }

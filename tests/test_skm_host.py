@@ -12,6 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'tests', 'harness', 'skm_host.cpp')
 HDR = os.path.join(ROOT, 'kevlar_amd', 'csrc', 'kv_skm_device.h')
+HDR2 = os.path.join(ROOT, 'kevlar_amd', 'csrc', 'kv_fastmod.h')
 SO = os.path.join(ROOT, 'tests', 'harness', 'libskm_host.so')
 CODE = {'A': 0, 'C': 1, 'G': 2, 'T': 3}
 COMP = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A'}
@@ -22,8 +23,8 @@ def lib():
     clang = '/opt/rocm/lib/llvm/bin/clang++'
     if not os.path.exists(clang):
         pytest.skip('clang++ of the ROCm toolchain not found')
-    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
-        subprocess.check_call([clang, '-x', 'c++', '-std=c++17', '-O1', '-fPIC', '-shared', '-o', SO, SRC])
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR), os.path.getmtime(HDR2)):
+        subprocess.check_call([clang, '-x', 'c++', '-std=c++17', '-O1', '-ffp-contract=off', '-fPIC', '-shared', '-o', SO, SRC])
     L = ctypes.CDLL(SO)
     L.h_mmer_value.restype = ctypes.c_uint32
     L.h_bases32.restype = ctypes.c_uint64
@@ -130,3 +131,27 @@ def test_header_fields_and_bucket_ranges(lib):
     assert len(counts) == 251 and max(counts.values()) < 4 * 20000 / 251
     lib.h_bucket_of(12345, 1, 0, ctypes.byref(c), ctypes.byref(f))
     assert (c.value, f.value) == (0, 0)
+
+
+def test_fastmod_is_the_remainder(lib):
+    """h % size for sizes on both sides of the FP64 / Barrett switch, at the inputs where a quotient estimate is most
+    likely to be off: multiples of the size and their neighbours, the top of the 64-bit range, and random hashes"""
+    import numpy as np
+    lib.h_fastmod.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+    rng = np.random.default_rng(11)
+    sizes = [1, 2, 3, 97, 65521, 65535, 65536, 65537, 499999999, 499999993, 499999931, 499999909, 124999987, 1999999973,
+             2**31 - 1, 2**32 - 5, 2**32 - 1, 2**32, 2**32 + 15, 7999999967, 2**40 + 15, 2**63 + 9]
+    sizes += [int(x) for x in rng.integers(65536, 2**32, 40, dtype=np.uint64)]
+    for size in sizes:
+        q = (2**64 - 1) // size
+        edge = []
+        for mult in [0, 1, 2, q // 3, q // 2, q - 1, q] + [int(x) for x in rng.integers(0, q + 1, 2000, dtype=np.uint64)]:
+            for d in (-2, -1, 0, 1, 2):
+                v = mult * size + d
+                if 0 <= v < 2**64:
+                    edge.append(v)
+        edge += [2**64 - 1, 2**64 - 2, 2**63, 2**63 - 1, 2**53, 2**53 + 1, 2**52 - 1]
+        h = np.concatenate([np.array(edge, dtype=np.uint64), rng.integers(0, 2**64, 200000, dtype=np.uint64)])
+        out = np.empty_like(h)
+        lib.h_fastmod(h.ctypes.data, len(h), size, out.ctypes.data)
+        assert np.array_equal(out, h % np.uint64(size)), size
