@@ -408,7 +408,7 @@ __host__ __device__ inline uint32_t skm_wave_slice_words(uint32_t R, uint32_t L,
 }
 
 template <int CH>
-__global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, SkmGeom sg, uint32_t R, uint32_t n_mt, uint32_t quota_mt)
+__global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, SkmGeom sg, uint32_t R, uint32_t n_mt, uint32_t quota_mt, uint32_t per_ticket)
 {
     constexpr uint32_t PS = CH == 16 ? 4u : 3u;
     __shared__ uint32_t cur[256];
@@ -446,9 +446,9 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, 
             uint32_t t = 0;
             if (lane == 0) t = (uint32_t)atomicAdd(&sg.ctr[2], 1ull);
             t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-            if ((uint64_t)t * SKM_MT_PER_TICKET >= n_mt) break;
-            mt = t * SKM_MT_PER_TICKET;
-            mt_end = min(mt + SKM_MT_PER_TICKET, n_mt);
+            if ((uint64_t)t * per_ticket >= n_mt) break;
+            mt = t * per_ticket;
+            mt_end = min(mt + per_ticket, n_mt);
         }
         const uint64_t r0 = (uint64_t)mt * R;
         const uint32_t nr = (uint32_t)min((uint64_t)R, rd.n_reads - r0), nwords = nr * wpr;
@@ -1425,14 +1425,18 @@ void skm_launch_emit(const SkmGeom &g, const kv_reads *reads, hipStream_t st)
         const size_t lds = (size_t)skm_wave_slice_words(R, L, nk, ch) * 4 * (SKM_THREADS1 / 64);
         const uint64_t n_mt = (reads->n_reads + R - 1) / R;
         // the same share of the batch per workgroup as the tile kernel's quota, dealt to its waves
-        const uint64_t per_wave = (uint64_t)g.quota1 * reads->uni_per_tile / R / (SKM_THREADS1 / 64) + SKM_MT_PER_TICKET;
-        const uint32_t quota_mt = (uint32_t)std::min<uint64_t>(kv_round_up(per_wave, SKM_MT_PER_TICKET), 0xfffffff0ull);
+        // a ticket is SKM_MT_PER_TICKET groups for a whole sample; small batches (a shard of a sample, a test) get smaller
+        // tickets so that every wave of the grid still finds two
+        const uint64_t waves = (uint64_t)g.nwg1 * (SKM_THREADS1 / 64);
+        const uint32_t per_ticket = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(SKM_MT_PER_TICKET, n_mt / (2 * waves)));
+        const uint64_t per_wave = (uint64_t)g.quota1 * reads->uni_per_tile / R / (SKM_THREADS1 / 64) + per_ticket;
+        const uint32_t quota_mt = (uint32_t)std::min<uint64_t>(kv_round_up(per_wave, per_ticket), 0xfffffff0ull);
         if (ch == 16) {
             kv_ensure_dynamic_lds((const void *)k_skm_emit_wave<16>, lds);
-            hipLaunchKernelGGL(k_skm_emit_wave<16>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), g, R, (uint32_t)n_mt, quota_mt);
+            hipLaunchKernelGGL(k_skm_emit_wave<16>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), g, R, (uint32_t)n_mt, quota_mt, per_ticket);
         } else {
             kv_ensure_dynamic_lds((const void *)k_skm_emit_wave<8>, lds);
-            hipLaunchKernelGGL(k_skm_emit_wave<8>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), g, R, (uint32_t)n_mt, quota_mt);
+            hipLaunchKernelGGL(k_skm_emit_wave<8>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), g, R, (uint32_t)n_mt, quota_mt, per_ticket);
         }
         return;
     }
