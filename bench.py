@@ -291,7 +291,12 @@ def main():
         hbm_low[0] = min(hbm_low[0], torch.cuda.mem_get_info(dev_index)[0])
 
     def make_sketches(memory):
-        return {n: hk.Counttable(k, memory / T, T) for n in names}
+        sk = {n: hk.Counttable(k, memory / T, T) for n in names}
+        if len(batches['proband']) == 1:
+            # what `kevlar novel` does for a case sample that is one batch (kevlar_amd/count.py): the count keeps the batch's distinct
+            # k-mers with their hashes, the scan that follows evaluates from that list
+            sk['proband'].expect_scan()
+        return sk
 
     sketches = make_sketches(mem_per_gpu)
     wall = {'count': 0.0, 'novel': 0.0, 'merge': 0.0}

@@ -109,6 +109,11 @@ int kv_sketch_table_write(kv_sketch *s, int table, const uint8_t *host_in, uint6
 int kv_sketch_table_devptr(kv_sketch *s, int table, void **devptr, uint64_t *nbytes);
 /* zero every table and counter (a fresh sketch of the same geometry; asynchronous)         */
 int kv_sketch_clear(kv_sketch *s);
+/* on != 0: the batches counted into this sketch are a CASE sample's and each is scanned right after it is counted
+ * (kevlar/novel.py:92-121 loads the case samples last, then scans them).  kv_consume then also keeps, for the batch it just
+ * counted, every distinct k-mer with its hash, and a kv_novel_scan of that same batch evaluates from that list instead of
+ * combining and hashing the batch's k-mers a second time.  Purely a performance hint: results do not depend on it. */
+int kv_sketch_scan_hint(kv_sketch *s, int on);
 
 /* ---- reads --------------------------------------------------------------------------- */
 /* khmer.ReadParser stand-in (kevlar/count.py:40): the host hands over parsed sequences

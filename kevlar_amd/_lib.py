@@ -61,6 +61,7 @@ SIGNATURES = {
     'kv_sketch_table_write': (i32, [vp, i32, u8p, u64]),
     'kv_sketch_table_devptr': (i32, [vp, i32, vpp, u64p]),
     'kv_sketch_clear': (i32, [vp]),
+    'kv_sketch_scan_hint': (i32, [vp, i32]),
     'kv_reads_create': (i32, [cstr, u64p, u64, vpp]),
     'kv_reads_create_packed': (i32, [u32p, u64, u32, vpp]),
     'kv_reads_generate': (i32, [u64, u64, i32, u64, u64, u32, ctypes.c_double, vpp]),

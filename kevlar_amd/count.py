@@ -35,11 +35,13 @@ def _count_file(path, sketch, policy, nthreads, keep=None):
         first = parser.text_batch(khmer.BATCH_READS)
         if first is None:
             return parser.num_reads
+        sketch.expect_scan(True)        # a case sample: if this batch is the whole file it is scanned next, from the list this count leaves
         sketch.consume_batch(first.batch, policy.nbands, policy.band, policy.mask, policy.threshold, policy.consume_masked)
         second = parser.take_batch(khmer.BATCH_READS)
         if second is None:
             keep[path] = (parser, first)
             return parser.num_reads
+        sketch.expect_scan(False)       # several batches: they are read again for the scan, the lists would be wasted
         if not sketch.retains(first.batch):
             first.batch.close()
         sketch.consume_batch(second, policy.nbands, policy.band, policy.mask, policy.threshold, policy.consume_masked)

@@ -417,6 +417,14 @@ extern "C" int kv_sketch_table_write(kv_sketch *s, int table, const uint8_t *hos
     return KV_OK;
 }
 
+extern "C" int kv_sketch_scan_hint(kv_sketch *s, int on)
+{
+    KV_REQUIRE(s, KV_ERR_ARG, "kv_sketch_scan_hint: null handle");
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->scan_hint = on != 0;
+    return KV_OK;
+}
+
 extern "C" int kv_sketch_clear(kv_sketch *s)
 {
     KV_REQUIRE(s, KV_ERR_ARG, "kv_sketch_clear: null handle");

@@ -75,6 +75,7 @@ struct kv_sketch {
     // every other reader or writer of the tables calls kv_sketch_ready first, which does the memset after all
     bool lazy_zero = false;
     KvAbundList abl;       // see above; valid = false whenever the tables may hold less than it says
+    bool scan_hint = false; // kv_sketch_scan_hint: batches counted into this sketch are scanned next (a case sample)
     std::mutex mu;
 };
 

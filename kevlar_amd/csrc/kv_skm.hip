@@ -36,7 +36,8 @@ struct SkmGeom {
     uint64_t *seg2; uint32_t *cnt2;  // [C1 * F2][nwg2][cap2] / [C1 * F2][nwg2]
     uint64_t *loose; uint64_t loose_cap;
     unsigned long long *ctr;         // [0] loose records, [1] failure, [2] S1 tile ticket, [3] count ticket, [4] scan ticket,
-                                     // [5] records emitted, [6] loose records after S1 + S2, [7] distinct k-mers the count pass found in its LDS tables
+                                     // [5] records emitted, [6] loose records after S1 + S2, [7] distinct k-mers the count pass found in its LDS tables,
+                                     // [9] workgroups whose stretch of the distinct list ran out
     uint32_t n_buckets, quota3;
     uint32_t sbw;                    // words of record-start bits per wave in the bucket walk
     uint64_t bucket_kmers;           // average k-mers per fine bucket
@@ -46,6 +47,9 @@ struct SkmGeom {
     uint64_t *abl_keys; uint8_t *abl_cnts; uint32_t *abl_bstart, *abl_bcount; uint32_t abl_cap_wg;
     // S2 over records that several ranks emitted (minimizer-sharded exchange, kv_skm_mex_route): seg1 / cnt1 then hold n_src
     // slabs of [C1][nwg1] segments one after the other, and a coarse bucket has n_src * nwg1 segments (0 / 1: the usual one slab)
+    // distinct list the count pass writes for a batch that is going to be scanned (SkmIndex::dl; dl_keys == nullptr: off): EVERY
+    // distinct k-mer of a bucket with its hash, appended like the abundance list (a stretch per workgroup, start + count per bucket)
+    uint64_t *dl_keys, *dl_hash; uint32_t *dl_bstart, *dl_bcount; uint32_t dl_cap_wg;
     uint32_t n_src;
     const uint64_t *seg1_off;        // non-null: segment `slot` starts at record seg1_off[slot] (compacted records) instead of slot * cap1
     uint64_t read_base;              // global index of the batch's first read (record positions of a read shard; 0 otherwise)
@@ -958,6 +962,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
     __shared__ uint32_t cnt[TS];                 // occurrences of the key in the same slot
     __shared__ uint32_t next_bucket;
     __shared__ uint32_t abl_cur, abl_b0, abl_prev;      // abundance list: entries appended so far, ... when the bucket began, the bucket
+    __shared__ uint32_t dl_cur, dl_b0;                  // distinct list: the same two
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
     const uint32_t ns = (uint32_t)(g.T * g.C);
     uint32_t *lut = dyn, *cur = dyn + 256, *scratch = cur + ((ns + 3u) & ~3u);
@@ -981,13 +986,17 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
     // while the current bucket is processed
     skm_table_clear(tb);
     for (uint32_t i = threadIdx.x; i < TS; i += SKM_THREADS3) cnt[i] = 0;
-    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET; abl_cur = 0; abl_b0 = 0; abl_prev = 0xffffffffu; }
+    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET; abl_cur = 0; abl_b0 = 0; abl_prev = 0xffffffffu; dl_cur = 0; dl_b0 = 0; }
     // where the finished bucket's entries of the abundance list lie (nothing if the workgroup's stretch ran out)
     auto abl_close = [&]() {
         if (sg.abl_keys && abl_prev != 0xffffffffu) {
             const bool fits = abl_cur <= sg.abl_cap_wg;
             sg.abl_bstart[abl_prev] = blockIdx.x * sg.abl_cap_wg + abl_b0;
             sg.abl_bcount[abl_prev] = fits ? abl_cur - abl_b0 : 0u;
+        }
+        if (sg.dl_keys && abl_prev != 0xffffffffu) {
+            sg.dl_bstart[abl_prev] = blockIdx.x * sg.dl_cap_wg + dl_b0;
+            sg.dl_bcount[abl_prev] = dl_cur - dl_b0;                // (a stretch that ran out is reported through ctr[9]: the whole list is then dropped)
         }
     };
     for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
@@ -997,7 +1006,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
         __syncthreads();
         if (threadIdx.x == 0) {
             abl_close();
-            abl_prev = b; abl_b0 = abl_cur;
+            abl_prev = b; abl_b0 = abl_cur; dl_b0 = dl_cur;
             if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
             else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
             else {
@@ -1032,6 +1041,21 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
             if (sg.dbg & 1u) return;
             const uint64_t h = skm_key_hash<KW>(c, lut, f.hp);
             if (sg.dbg & 64u) { n_added += h & 1; return; }
+            // distinct list: key and hash of every k-mer in here (the scan of this batch then neither combines nor hashes again)
+            if (sg.dl_keys) {
+                const unsigned long long here = __ballot(true);
+                const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)here) - 1u;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&dl_cur, (uint32_t)__popcll(here));
+                base = (uint32_t)__shfl((int)base, (int)leader);
+                const uint32_t at = base + (uint32_t)__popcll(here & ((1ull << lane) - 1ull));
+                if (at < sg.dl_cap_wg) {
+                    const uint64_t e = (uint64_t)blockIdx.x * sg.dl_cap_wg + at;
+                    sg.dl_keys[e * KW] = c.w[0];
+                    if (KW == 2) sg.dl_keys[e * KW + (KW - 1)] = c.w[KW - 1];
+                    sg.dl_hash[e] = h;
+                }
+            }
             const uint32_t added = skm_count_kmer(h, seen, sk, mask, f, g.T, emit);
             n_added += added;
             // abundance list: a k-mer this batch adds at least twice (the lanes of the wave that are in here vote)
@@ -1055,7 +1079,10 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
         });
     }
     __syncthreads();
-    if (threadIdx.x == 0) abl_close();
+    if (threadIdx.x == 0) {
+        abl_close();
+        if (sg.dl_keys && dl_cur > sg.dl_cap_wg) atomicAdd(&sg.ctr[9], 1ull);
+    }
     for (uint32_t s = threadIdx.x; s < ns; s += SKM_THREADS3)
         g.gcnt1[(uint64_t)s * g.nwgA + blockIdx.x] = (uint32_t)min((uint64_t)cur[s], g.cap1);
     n_added = wave_sum_u64(n_added);
@@ -1301,6 +1328,110 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
     }
 }
 
+// The scan of a batch whose count pass left a distinct list (SkmGeom::dl_*): nothing is combined and nothing is hashed again.
+// Per bucket: (1) the controls' abundance-list entries that exceed ctrl_max go into one small LDS table (the k-mers no probe is
+// needed for); (2) every entry of the distinct list that is not in there gets ONE probe -- table 0 of the first case sample, where
+// a sequencing-error k-mer ends -- four entries per thread in flight and no barrier anywhere, and the few that pass are queued;
+// (3) the queue is dealt one candidate per thread for the rest of kmer_is_interesting() (a dozen dependent probes: paid once per
+// bucket, side by side, instead of once per wave and round); the interesting ones go into a second table, and (4) only if there
+// are any are the bucket's records walked, to mark their occurrences.  Occurrences that missed the count pass's LDS tables are in
+// the loose list already (k_skm_loose_novel evaluates them one by one).  A bucket's list has at most as many entries as the count
+// kernel's LDS table has slots.
+#define SKM_LIST_MAX 4096u
+template <int KW, int TSM>
+__global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, ReadsDev rd, NovelParams p, SkmAblSet abls)
+{
+    constexpr uint32_t E = 4;                    // entries a thread has in flight
+    __shared__ SkmTable<KW, TSM> rtb;            // rejected by a control's list
+    __shared__ SkmTable<KW, TSM> itb;            // interesting
+    __shared__ NovelShared ns;
+    __shared__ uint16_t cand[SKM_LIST_MAX];      // entries (relative to the bucket's first) that passed the first probe
+    __shared__ uint32_t next_bucket, n_int, n_cand;
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
+    uint32_t *scratch = dyn;
+    load_descs(ns, p);
+    skm_table_clear(itb);
+    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET; n_int = 0; n_cand = 0; }
+    auto mark_pass = [&](uint32_t b) {
+        skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t pos) {
+            if (skm_cacheable<KW>(c) && skm_table_find(itb, c) >= 0) skm_mark(p, rd, pos, sg.stride);
+            return false;
+        });
+        __syncthreads();
+        skm_table_clear(itb);
+        if (threadIdx.x == 0) n_int = 0;
+        __syncthreads();
+    };
+    for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
+        __syncthreads();
+        const uint32_t b = next_bucket;
+        if (b >= sg.n_buckets) break;
+        skm_table_clear(rtb);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
+            else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
+            else next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET;
+            n_cand = 0;
+        }
+        // the list entries are requested before the controls' lists are worked in: they arrive meanwhile
+        const uint32_t e0 = sg.dl_bstart[b], en = min(sg.dl_bcount[b], SKM_LIST_MAX);
+        for (int a = 0; a < abls.n; ++a) {
+            const uint32_t a0 = abls.bstart[a][b], an = abls.bcount[a][b];
+            for (uint32_t i = threadIdx.x; i < an; i += SKM_THREADS3) {
+                if ((int)min((uint32_t)abls.cnts[a][a0 + i], abls.maxv[a]) <= abls.ctrl_max) continue;
+                SkmKey<KW> c;
+                c.w[0] = abls.keys[a][(uint64_t)(a0 + i) * KW];
+                if (KW == 2) c.w[KW - 1] = abls.keys[a][(uint64_t)(a0 + i) * KW + (KW - 1)];
+                (void)skm_table_insert(rtb, c);              // (a full table only costs the shortcut for that key)
+            }
+        }
+        __syncthreads();
+        for (uint32_t base = 0; base < ((sg.dbg & 4u) ? 0u : en); base += E * SKM_THREADS3) {
+            SkmKey<KW> c[E];
+            uint64_t h[E];
+            bool live[E];
+#pragma unroll
+            for (uint32_t u = 0; u < E; ++u) {
+                const uint32_t i = base + u * SKM_THREADS3 + threadIdx.x;
+                live[u] = i < en;
+                c[u].w[0] = live[u] ? sg.dl_keys[(uint64_t)(e0 + i) * KW] : SKM_EMPTY;
+                if (KW == 2) c[u].w[KW - 1] = live[u] ? sg.dl_keys[(uint64_t)(e0 + i) * KW + (KW - 1)] : SKM_EMPTY;
+                h[u] = live[u] ? sg.dl_hash[e0 + i] : 0ull;
+            }
+            uint32_t v[E];
+#pragma unroll
+            for (uint32_t u = 0; u < E; ++u) {
+                live[u] = live[u] && skm_table_find(rtb, c[u]) < 0 && band_pass(p, h[u]);
+                v[u] = live[u] ? probe(ns, 0, 0, h[u]) : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < E; ++u)
+                if (live[u] && (int)v[u] >= p.case_min) cand[atomicAdd(&n_cand, 1u)] = (uint16_t)(base + u * SKM_THREADS3 + threadIdx.x);
+        }
+        __syncthreads();
+        const uint32_t nc = n_cand;
+        for (uint32_t j0 = 0; j0 < nc; j0 += SKM_THREADS3) {
+            const uint32_t j = j0 + threadIdx.x;
+            if (j < nc) {
+                const uint32_t i = cand[j];
+                SkmKey<KW> c;
+                c.w[0] = sg.dl_keys[(uint64_t)(e0 + i) * KW];
+                if (KW == 2) c.w[KW - 1] = sg.dl_keys[(uint64_t)(e0 + i) * KW + (KW - 1)];
+                if (novel_test_fast(ns, p, sg.dl_hash[e0 + i], nullptr, 0ull)) {
+                    if (skm_table_insert(itb, c) < 0) sg.ctr[1] = 1;          // (cannot happen below half full; the caller then redoes the scan the other way)
+                    atomicAdd(&n_int, 1u);
+                }
+            }
+            __syncthreads();
+            // a bucket with more interesting k-mers than a quarter of the table (a case sample without controls to speak of)
+            // marks in instalments
+            if (n_int > TSM / 4 && j0 + SKM_THREADS3 < nc) mark_pass(b);
+        }
+        if (n_int != 0 && !(sg.dbg & 8u)) mark_pass(b);
+    }
+}
+
 template <int KW>
 __global__ __launch_bounds__(256) void k_skm_loose_novel(SkmGeom sg, ReadsDev rd, NovelParams p)
 {
@@ -1368,6 +1499,12 @@ struct SkmIndex {
     bool valid = false;
     double distinct_hint = 0.0;     // distinct / all k-mers of the last batch routed on this stream (kv_skm_route_distinct)
     SkmGeom g;
+    // distinct list of the batch (kv_sketch::scan_hint): key + hash of every distinct k-mer the count pass drained, bucket by bucket
+    KvArena dl;
+    uint64_t *dl_keys = nullptr, *dl_hash = nullptr;
+    uint32_t *dl_bstart = nullptr, *dl_bcount = nullptr;
+    uint32_t dl_cap_wg = 0;
+    bool dl_valid = false;
     std::mutex mu;
 };
 std::map<hipStream_t, SkmIndex> g_skm;
@@ -1549,6 +1686,7 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     SkmGeom &g = idx.g;
     memset(&g, 0, sizeof(g));
     idx.valid = false;
+    idx.dl_valid = false;
     g.k = k;
     g.m = skm_minimizer_len(k);
     g.w = k - g.m + 1;
@@ -1722,6 +1860,29 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
             }
         }
     }
+    // distinct list (kv_sketch_scan_hint): the batch is a case sample's and will be scanned next.  A workgroup takes up to
+    // quota3 of the buckets, so its stretch holds one and a half average shares of the distinct k-mers the batch is expected
+    // to have (what the previous batch showed, or 30 %); a stretch that runs out drops the list (ctr[9]), nothing else.
+    bool dl_new = false;
+    if (s->scan_hint && !(getenv("KV_SKM_DL") && atoi(getenv("KV_SKM_DL")) == 0)) {
+        const double frac = std::min(1.0, std::max(0.3, s->skm_distinct * 1.15));
+        const uint64_t cap_wg = std::min<uint64_t>((uint64_t)((double)n_kmers * frac * 1.6 / nwg3) + 4096, 0xfffffff0ull / nwg3);
+        const size_t b_keys = kv_round_up(cap_wg * nwg3 * 8 * sg.kw, 256), b_hash = kv_round_up(cap_wg * nwg3 * 8, 256);
+        const size_t b_idx = kv_round_up((uint64_t)sg.n_buckets * 4, 256);
+        if (idx.dl.need(b_keys + b_hash + 2 * b_idx) == hipSuccess) {
+            unsigned char *base = (unsigned char *)idx.dl.p;
+            idx.dl_keys = (uint64_t *)base; base += b_keys;
+            idx.dl_hash = (uint64_t *)base; base += b_hash;
+            idx.dl_bstart = (uint32_t *)base; base += b_idx;
+            idx.dl_bcount = (uint32_t *)base;
+            idx.dl_cap_wg = (uint32_t)cap_wg;
+            KV_HIP(hipMemsetAsync(idx.dl_bstart, 0, 2 * b_idx, st));
+            sg.dl_keys = idx.dl_keys; sg.dl_hash = idx.dl_hash; sg.dl_bstart = idx.dl_bstart; sg.dl_bcount = idx.dl_bcount; sg.dl_cap_wg = idx.dl_cap_wg;
+            dl_new = true;
+        } else {
+            (void)hipGetLastError();                    // no room: no list
+        }
+    }
     {
         KvProfScope prof("k_skm_count");
         const uint32_t ns = (uint32_t)(plan.g.T * plan.g.C);
@@ -1739,14 +1900,18 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     hipLaunchKernelGGL(k_skm_forward_flag, dim3(1), dim3(1), 0, st, sg.ctr, plan.g.ctr);
     KV_HIP(hipGetLastError());
     sg.abl_keys = nullptr; sg.abl_cnts = nullptr; sg.abl_bstart = nullptr; sg.abl_bcount = nullptr;
+    sg.dl_keys = nullptr; sg.dl_hash = nullptr; sg.dl_bstart = nullptr; sg.dl_bcount = nullptr;
     const int rc = kv_bin_finish(s, plan, true, 0, n_added);     // synchronises the stream
     if (abl_new) s->abl.valid = rc == KV_OK;
     {
         // what the batch looked like: if most k-mers are distinct (low coverage per batch) cutting and bucketing the
         // reads buys nothing, and if many occurrences missed the LDS tables the buckets were too full; either way
         // the next batches into this sketch take the one-item-per-k-mer partition (until the sketch is cleared)
-        unsigned long long sc[8] = {0};
-        if (hipMemcpy(sc, sg.ctr, sizeof(sc), hipMemcpyDeviceToHost) == hipSuccess && n_kmers) {
+        unsigned long long sc[10] = {0};
+        const bool got = hipMemcpy(sc, sg.ctr, sizeof(sc), hipMemcpyDeviceToHost) == hipSuccess;
+        idx.dl_valid = dl_new && got && rc == KV_OK && sc[9] == 0;
+        if (dl_new && getenv("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] distinct list: %s (%llu workgroups ran out of %u entries)\n", idx.dl_valid ? "kept" : "dropped", sc[9], idx.dl_cap_wg);
+        if (got && n_kmers) {
             const double alone = (double)(sc[0] > sc[6] ? sc[0] - sc[6] : 0) / (double)n_kmers;
             const double distinct = (double)sc[7] / (double)n_kmers + alone;
             s->skm_off = rc != KV_OK || alone > 0.03 || distinct > 0.45;
@@ -1792,11 +1957,14 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
         if (rc != KV_OK) return rc;
     }
     SkmGeom &sg = idx->g;
+    // the count pass of this very batch left key + hash of every distinct k-mer (kv_sketch_scan_hint): scan from that list
+    const bool from_list = reuse && idx->dl_valid && !p.set_keys && !(getenv("KV_SKM_DL") && atoi(getenv("KV_SKM_DL")) == 0);
     if (reuse) {
         // records that did not fit their S1/S2 segment are the first ctr[6] entries of the loose list; the entries the
         // count pass added behind them (single occurrences that missed its LDS tables) are re-created by the scan's
-        // own pass 0, so the list is cut back to what S1/S2 left
-        KV_HIP(hipMemcpyAsync(&sg.ctr[0], &sg.ctr[6], 8, hipMemcpyDeviceToDevice, st));
+        // own pass 0, so the list is cut back to what S1/S2 left -- unless the scan goes by the distinct list, which does
+        // not hold those k-mers: then they stay, and k_skm_loose_novel evaluates them
+        if (!from_list) KV_HIP(hipMemcpyAsync(&sg.ctr[0], &sg.ctr[6], 8, hipMemcpyDeviceToDevice, st));
         KV_HIP(hipMemsetAsync(&sg.ctr[4], 0, 8, st));
     }
     const uint32_t nwg3 = skm_nwg3(sg);
@@ -1815,7 +1983,16 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
         }
     }
     if (getenv("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] scan: %d of %d controls bring an abundance list in this bucket geometry\n", abls.n, p.host_nctrl);
-    {
+    if (getenv("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] scan: %s\n", from_list ? "from the count pass's distinct list" : "by walking the buckets");
+    if (const char *e = getenv("KV_SKM_SCAN_DEBUG")) sg.dbg = (uint32_t)atoi(e);       // scratch/scan_phases.py
+    if (from_list) {
+        KvProfScope prof("k_skm_novel_list");
+        sg.dl_keys = idx->dl_keys; sg.dl_hash = idx->dl_hash; sg.dl_bstart = idx->dl_bstart; sg.dl_bcount = idx->dl_bcount; sg.dl_cap_wg = idx->dl_cap_wg;
+        const size_t lds = (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw) * 4;
+        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_novel_list<1, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
+        else hipLaunchKernelGGL((k_skm_novel_list<2, 1024>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
+        sg.dl_keys = nullptr; sg.dl_hash = nullptr; sg.dl_bstart = nullptr; sg.dl_bcount = nullptr;
+    } else {
         KvProfScope prof("k_skm_novel");
         const size_t lds = (256 + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw)) * 4;
         if (sg.kw == 1) hipLaunchKernelGGL((k_skm_novel<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
@@ -1835,6 +2012,7 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
     KV_HIP(hipMemcpyAsync(sctr, sg.ctr, sizeof(sctr), hipMemcpyDeviceToHost, st));
     KV_HIP(hipStreamSynchronize(st));
     idx->valid = false;     // one scan per build: the loose list now holds this scan's entries
+    idx->dl_valid = false;
     if (sctr[1] != 0) {
         kv_set_error("super-k-mer scan: loose record list overflow (%llu records)", sctr[0]);
         return KV_ERR_CAPACITY;

@@ -564,6 +564,13 @@ class _Sketch(object):
     def save(self, path):
         check(_lib.load().kv_sketch_save(self._h, path.encode()))
 
+    def expect_scan(self, on=True):
+        """This sketch holds a case sample: every batch counted into it is scanned next (kevlar/novel.py:92-121 loads the cases
+        last and scans them).  The count then keeps the batch's distinct k-mers with their hashes for that scan.  A
+        performance hint only (kv_sketch_scan_hint)."""
+        check(_lib.load().kv_sketch_scan_hint(self._h, 1 if on else 0))
+        return self
+
     def clear(self):
         """Zero all tables (same geometry, fresh counts)."""
         check(_lib.load().kv_sketch_clear(self._h))

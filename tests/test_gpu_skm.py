@@ -160,9 +160,11 @@ def test_skm_band_and_mask(hk, ok, skm):
     assert launches('k_skm_count') >= 4
 
 
-def scan_both(hk, ok, reads, k, mem, case_min=6, ctrl_max=1, nctrl=2, order=('mother', 'father', 'proband'), **kw):
+def scan_both(hk, ok, reads, k, mem, case_min=6, ctrl_max=1, nctrl=2, order=('mother', 'father', 'proband'), hint=False, **kw):
     names = ('proband', 'mother', 'father')[:1 + nctrl]
     dev = {n: hk.Counttable(k, mem / 4, 4) for n in names}
+    if hint:
+        dev['proband'].expect_scan()                            # the count keeps the batch's distinct k-mers with their hashes
     ref = {n: ok.Counttable(k, mem / 4, 4) for n in names}
     batches = {n: hk.ReadBatch(reads[n]) for n in names}
     for n in [x for x in order if x in names]:                  # the case sample last: the scan can reuse its buckets
@@ -226,6 +228,52 @@ def test_skm_novel_scan_bands_multi_control_and_overflow(hk, ok, skm):
     got, hits = scan_both(hk, ok, reads, 31, 5e6, case_min=5, ctrl_max=2)
     assert got == hits and len(hits) > 20
     assert launches('k_novel_mark') == 0
+
+
+@pytest.mark.parametrize('k', [31, 25, 51])
+def test_skm_scan_from_the_distinct_list_matches_oracle(hk, ok, skm, k):
+    """kv_sketch_scan_hint: the case sample's count leaves key + hash of every distinct k-mer, the scan evaluates from that list
+    (k_skm_novel_list) and walks only the buckets that hold an interesting k-mer"""
+    os.environ['KV_SKM_BUCKET_KMERS'] = '2048'
+    reads = trio_reads(100000, 30000, 41)
+    got, hits = scan_both(hk, ok, reads, k, 6e6, hint=True)
+    assert len(hits) > 50 and got == hits
+    assert launches('k_skm_novel_list') == 1 and launches('k_skm_novel') == 0 and launches('k_novel_mark') == 0
+    assert launches('k_skm_emit') == 3
+
+
+def test_skm_scan_from_the_distinct_list_bands_overflow_skips_and_crowded_buckets(hk, ok, skm):
+    os.environ['KV_SKM_BUCKET_KMERS'] = '4096'
+    reads = trio_reads(80000, 24000, 47)
+    bad = list(reads['proband'][5]); bad[40] = 'N'
+    reads['proband'][5] = ''.join(bad)              # flagged: the scan skips it, the count keeps it
+    union = []
+    for band in range(3):
+        got, hits = scan_both(hk, ok, reads, 31, 5e6, hint=True, band_mode=1, nbands=3, band=band)
+        assert got == hits
+        union += got
+    whole, hits = scan_both(hk, ok, reads, 31, 5e6, hint=True)
+    assert sorted(union) == whole == hits and len(hits) > 20
+    assert launches('k_skm_novel_list') == 4 and launches('k_skm_novel') == 0
+    # every abundant k-mer of the case sample is interesting when the controls are all but empty and may hold anything up to
+    # 255: far more than a quarter of a bucket's table, so the buckets are marked in instalments
+    thin = dict(reads, mother=reads['mother'][:200], father=reads['father'][:200])
+    got, hits = scan_both(hk, ok, thin, 31, 5e6, hint=True, case_min=2, ctrl_max=255)
+    assert got == hits and len(hits) > 200000
+    # undersized segments and a tiny loose list budget in S1 / S2: records and single k-mers travel through the loose list
+    os.environ['KV_SKM_CAP_PCT'] = '30'
+    got, hits = scan_both(hk, ok, reads, 31, 5e6, hint=True, case_min=5, ctrl_max=2)
+    assert got == hits and len(hits) > 20
+    os.environ.pop('KV_SKM_CAP_PCT')
+    # tables too small for their buckets in the count pass: those occurrences are in the loose list, not in the distinct list
+    os.environ['KV_SKM_BUCKET_KMERS'] = '12000'
+    got, hits = scan_both(hk, ok, reads, 31, 5e6, hint=True)
+    assert got == hits
+    assert launches('k_skm_novel_list') >= 6 and launches('k_novel_mark') == 0
+    before = launches('k_skm_novel')
+    # the hint without the reuse (controls counted after the case): the list is gone with the buckets, the scan walks
+    got, hits = scan_both(hk, ok, reads, 31, 5e6, hint=True, order=('proband', 'mother', 'father'))
+    assert got == hits and launches('k_skm_novel') == before + 1
 
 
 def test_default_paths_on_a_large_batch_agree_with_the_other_implementations(hk, skm):
