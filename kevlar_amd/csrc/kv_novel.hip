@@ -350,6 +350,8 @@ __global__ __launch_bounds__(256) void k_hit_abund(ReadsDev rd, NovelParams p, u
         uint64_t bw[2] = {skm_bases32(words, off), KW == 2 ? skm_bases32(words, off + 32u) : 0ull};
         const SkmKey<KW> f = skm_first_kmer<KW>(bw, k);
         const uint64_t h = skm_key_hash<KW>(f, lut, p.hp);        // murmur(k-mer) ^ murmur(reverse complement): either strand
+        // (the scan that found the k-mer interesting has left its abundances: one lookup in a table that sits in L2 for twelve probes)
+        if (p.ab_keys && ab_lookup(p, h, p.hit_abund + i * (uint64_t)S, S)) continue;
         hit_abundances(ns, p, h, p.hit_abund + i * (uint64_t)S);
     }
 }
@@ -386,7 +388,7 @@ struct Arena {
         return e;
     }
 };
-struct ScanArenas { Arena work, hits, set; std::mutex mu; };   // mu: one scan at a time per stream
+struct ScanArenas { Arena work, hits, set, abund; std::mutex mu; };   // mu: one scan at a time per stream
 std::map<hipStream_t, ScanArenas> g_scan_arenas;
 std::mutex g_scan_arenas_mu;
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -547,6 +549,20 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
     p.tile_base = d_tbase_p;
     uint64_t nhits = 0;
     bool marked_by_skm = use_skm;
+    p.ab_keys = nullptr; p.ab_vals = nullptr; p.ab_mask = 0;
+    if (e == hipSuccess && use_skm && !p.set_keys && !(getenv("KV_NOVEL_ABCACHE") && atoi(getenv("KV_NOVEL_ABCACHE")) == 0)) {
+        // room for the abundances of the interesting k-mers (a k-mer in a few thousand is one): 1 / 64 of the k-mers in slots
+        uint64_t slots = 1u << 16;
+        while (slots < n_kmers / 64 && slots < (1ull << 24)) slots <<= 1;
+        if (arenas->abund.need(up256(slots * 8) + up256(slots * (uint64_t)S)) == hipSuccess) {
+            p.ab_keys = (unsigned long long *)arenas->abund.p;
+            p.ab_vals = (uint8_t *)arenas->abund.p + up256(slots * 8);
+            p.ab_mask = slots - 1;
+            e = hipMemsetAsync(p.ab_keys, 0, slots * 8, st);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (e == hipSuccess && use_skm) {
         const int rc = kv_skm_novel_mark(reads, p, n_kmers);
         if (rc == KV_ERR_CAPACITY) {

@@ -30,6 +30,12 @@ struct NovelParams {
     const unsigned long long *set_keys;   // NULL = off; empty slots hold ~0 (no k-mer of any band hashes to it)
     const uint8_t *set_abund;             // [slots][S]
     uint64_t set_mask;                    // slots - 1
+    // Abundances of the interesting k-mers, kept by the scan that found them (k_skm_novel_list) for the kernel that reports them
+    // hit by hit (k_hit_abund): an open-addressing table of hashes (0 = empty) with the S abundances beside each.  A k-mer that is
+    // not in there -- the table was full where it wanted to go, or the scan took another path -- is simply probed again.
+    unsigned long long *ab_keys;          // NULL = off
+    uint8_t *ab_vals;                     // [slots][S]
+    uint64_t ab_mask;                     // slots - 1
     const void *host_ctrls;               // host side only: the control sketches (kv_sketch *const *) behind sk[ncase..], for their
     int host_nctrl;                       // abundance lists (kv_skm_novel_mark)
 };
@@ -166,6 +172,36 @@ __device__ __forceinline__ void hit_abundances(const NovelShared &ns, const Nove
         for (int t = 0; t < KV_MAX_TABLES; ++t) best = v[t] < best ? v[t] : best;
         out[c] = (uint8_t)best;
     }
+}
+
+#define KV_AB_PROBES 32
+__device__ __forceinline__ uint64_t ab_slot(const NovelParams &p, uint64_t h) { return (h ^ (h >> 29)) & p.ab_mask; }
+
+// the S bytes the abundances of hash h go to, or nullptr (no room near its slot)
+__device__ __forceinline__ uint8_t *ab_claim(const NovelParams &p, uint64_t h, int S)
+{
+    if (h == 0) return nullptr;
+    uint64_t slot = ab_slot(p, h);
+    for (int probe = 0; probe < KV_AB_PROBES; ++probe, slot = (slot + 1) & p.ab_mask) {
+        const unsigned long long old = atomicCAS(&p.ab_keys[slot], 0ull, (unsigned long long)h);
+        if (old == 0ull || old == (unsigned long long)h) return p.ab_vals + slot * (uint64_t)S;       // (two k-mers with one hash have one set of abundances)
+    }
+    return nullptr;
+}
+
+__device__ __forceinline__ bool ab_lookup(const NovelParams &p, uint64_t h, uint8_t *out, int S)
+{
+    if (h == 0) return false;
+    uint64_t slot = ab_slot(p, h);
+    for (int probe = 0; probe < KV_AB_PROBES; ++probe, slot = (slot + 1) & p.ab_mask) {
+        const unsigned long long key = p.ab_keys[slot];
+        if (key == (unsigned long long)h) {
+            for (int c = 0; c < S; ++c) out[c] = p.ab_vals[slot * (uint64_t)S + c];
+            return true;
+        }
+        if (key == 0ull) return false;
+    }
+    return false;
 }
 
 }  // namespace

@@ -1418,9 +1418,11 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, 
                 SkmKey<KW> c;
                 c.w[0] = sg.dl_keys[(uint64_t)(e0 + i) * KW];
                 if (KW == 2) c.w[KW - 1] = sg.dl_keys[(uint64_t)(e0 + i) * KW + (KW - 1)];
-                if (novel_test_fast(ns, p, sg.dl_hash[e0 + i], nullptr, 0ull)) {
+                const uint64_t h = sg.dl_hash[e0 + i];
+                if (novel_test_fast(ns, p, h, nullptr, 0ull)) {
                     if (skm_table_insert(itb, c) < 0) sg.ctr[1] = 1;          // (cannot happen below half full; the caller then redoes the scan the other way)
                     atomicAdd(&n_int, 1u);
+                    if (p.ab_keys) (void)ab_claim(p, h, p.ncase + p.nctrl);      // a place for its abundances (k_ab_fill), for the kernel that reports the hits
                 }
             }
             __syncthreads();
@@ -1429,6 +1431,20 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, 
             if (n_int > TSM / 4 && j0 + SKM_THREADS3 < nc) mark_pass(b);
         }
         if (n_int != 0 && !(sg.dbg & 8u)) mark_pass(b);
+    }
+}
+
+// the abundances of the k-mers k_skm_novel_list claimed a slot for (a dozen probes each, side by side, off the scan's critical path:
+// inside the scan they were a chain of round trips in front of a workgroup barrier, 0.25 ms)
+__global__ __launch_bounds__(256) void k_ab_fill(NovelParams p)
+{
+    __shared__ NovelShared ns;
+    load_descs(ns, p);
+    __syncthreads();
+    const int S = p.ncase + p.nctrl;
+    for (uint64_t slot = blockIdx.x * 256ull + threadIdx.x; slot <= p.ab_mask; slot += (uint64_t)gridDim.x * 256ull) {
+        const unsigned long long h = p.ab_keys[slot];
+        if (h != 0ull) hit_abundances(ns, p, (uint64_t)h, p.ab_vals + slot * (uint64_t)S);
     }
 }
 
@@ -1991,6 +2007,7 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
         const size_t lds = (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw) * 4;
         if (sg.kw == 1) hipLaunchKernelGGL((k_skm_novel_list<1, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
         else hipLaunchKernelGGL((k_skm_novel_list<2, 1024>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
+        if (p.ab_keys) hipLaunchKernelGGL(k_ab_fill, dim3(2048), dim3(256), 0, st, p);
         sg.dl_keys = nullptr; sg.dl_hash = nullptr; sg.dl_bstart = nullptr; sg.dl_bcount = nullptr;
     } else {
         KvProfScope prof("k_skm_novel");
