@@ -834,10 +834,16 @@ def end_to_end(args, wl, packed, names, synth):
             log_text = kevlar_amd.logstream.getvalue()
             kevlar_amd.logstream = saved
         grouped = [line for line in log_text.split('\n') if 'grouped' in line]
-        with open(os.path.join(tmp, 'novel.fq.augfastq')) as a, open(os.path.join(tmp, 'novel.bgzf.fq.gz.augfastq')) as b:
-            assert a.read() == b.read(), 'plain and blocked-gzip input must give the same annotated reads'
-        with open(os.path.join(tmp, 'novel.fq.augfastq')) as a, open(os.path.join(tmp, 'novel.fq.gz.augfastq')) as b:
-            assert a.read() == b.read(), 'plain and gzip input must give the same annotated reads'
+        def same_output(x, y, what):
+            with open(os.path.join(tmp, x)) as a, open(os.path.join(tmp, y)) as b:
+                ta, tb = a.read(), b.read()
+            if ta != tb:
+                la, lb = ta.split('\n'), tb.split('\n')
+                first = next((i for i in range(min(len(la), len(lb))) if la[i] != lb[i]), min(len(la), len(lb)))
+                raise AssertionError('{} input must give the same annotated reads: {} against {} lines, first difference at line {}: {!r} / {!r}'.format(
+                    what, len(la), len(lb), first, la[first:first + 1], lb[first:first + 1]))
+        same_output('novel.fq.augfastq', 'novel.bgzf.fq.gz.augfastq', 'plain and blocked-gzip')
+        same_output('novel.fq.augfastq', 'novel.fq.gz.augfastq', 'plain and gzip')
         ingest = ingest_rates(os.path.join(tmp, 'proband.fq'), os.path.join(tmp, 'proband.bgzf.fq.gz'), n)
         return {'value': round(len(names) * n / dt_plain, 1), 'unit': 'reads/s',
                 'from_bgzf_fastq_gz': round(len(names) * n / dt_bgzf, 1),

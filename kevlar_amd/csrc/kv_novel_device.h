@@ -152,6 +152,49 @@ __device__ __forceinline__ bool novel_test_fast(const NovelShared &ns, const Nov
     return true;
 }
 
+// The same predicate for the few k-mers that survive the first probe of the list scan (k_skm_novel_list): there the chain of
+// dependent probes novel_test_fast spends -- the case's other tables, then control after control -- is a round trip to HBM each in
+// front of a workgroup barrier, so the probes that decide nearly every k-mer are requested together: up to eight tables of the first
+// case sample and table 0 of up to eight controls.  Whatever they leave open (a control whose table 0 exceeds ctrl_max, further
+// cases, more tables than eight) is probed one at a time as before.  Over-fetching is free here: ~2 candidates per bucket.
+__device__ __forceinline__ bool novel_test_wide(const NovelShared &ns, const NovelParams &p, uint64_t h)
+{
+    constexpr int W = 8;
+    const int T0 = ns.ntab[0];
+    uint32_t cv[W], c0[W];
+#pragma unroll
+    for (int t = 0; t < W; ++t) cv[t] = t < T0 ? probe(ns, 0, t, h) : 255u;
+#pragma unroll
+    for (int c = 0; c < W; ++c) c0[c] = c < p.nctrl ? probe(ns, p.ncase + c, 0, h) : 0u;
+    bool ok = true;
+#pragma unroll
+    for (int t = 0; t < W; ++t) ok = ok && (int)cv[t] >= p.case_min;
+    if (!ok) return false;
+    for (int t = W; t < T0; ++t)
+        if ((int)probe(ns, 0, t, h) < p.case_min) return false;
+    for (int c = 1; c < p.ncase; ++c) {
+        const int T = ns.ntab[c];
+        for (int t = 0; t < T; ++t)
+            if ((int)probe(ns, c, t, h) < p.case_min) return false;
+    }
+#pragma unroll
+    for (int c = 0; c < W; ++c) {                   // (unrolled: c0[] stays in registers)
+        if (c < p.nctrl) {
+            bool pass = (int)c0[c] <= p.ctrl_max;
+            const int T = ns.ntab[p.ncase + c];
+            for (int t = 1; t < T && !pass; ++t) pass = (int)probe(ns, p.ncase + c, t, h) <= p.ctrl_max;
+            if (!pass) return false;
+        }
+    }
+    for (int c = W; c < p.nctrl; ++c) {
+        bool pass = false;
+        const int T = ns.ntab[p.ncase + c];
+        for (int t = 0; t < T && !pass; ++t) pass = (int)probe(ns, p.ncase + c, t, h) <= p.ctrl_max;
+        if (!pass) return false;
+    }
+    return true;
+}
+
 // the S abundances reported with a hit: Count-Min minimum of every sample, or what the set carries
 __device__ __forceinline__ void hit_abundances(const NovelShared &ns, const NovelParams &p, uint64_t h, uint8_t *out)
 {

@@ -925,13 +925,17 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
                 // occurrences that found no room in the LDS table leave as one-k-mer records: one atomic per wave
                 const unsigned long long need = __ballot(alone);
                 if (need) {
+                    // (the count pass does not fetch the records' headers for the walk; here -- a wave in a few hundred -- it does,
+                    // so that the loose record carries the occurrence's real position: a scan that goes by the count pass's
+                    // distinct list evaluates these records as they are)
+                    const uint64_t posu = (WANT_POS ? pos0 : skm_hdr_pos(skm_shfl64(hdr, owner)) + j0) + u;
                     unsigned long long first = 0;
                     if (lane == 0) first = atomicAdd(&sg.ctr[0], (unsigned long long)__popcll(need));
                     first = skm_shfl64(first, 0);
                     if (alone) {
                         const unsigned long long idx = first + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
                         uint64_t one[3] = {fw.w[0], KW == 2 ? fw.w[KW - 1] : 0ull, 0ull};
-                        if (idx < sg.loose_cap) skm_store_record(sg.loose + idx * (uint64_t)recw, skm_header(pos0 + u, 1u, 0u), one, sg.nbw);
+                        if (idx < sg.loose_cap) skm_store_record(sg.loose + idx * (uint64_t)recw, skm_header(posu, 1u, 0u), one, sg.nbw);
                         else sg.ctr[1] = 1;
                     }
                 }
@@ -1024,7 +1028,10 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
         // combine the occurrences of the bucket
         if (!(sg.dbg & 2u)) skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
             if (sg.dbg & 128u) { n_added += c.w[0] & 1; return false; }
-            const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
+            // (KV_SKM_FORCE_LOOSE: one key in 64 is treated like a key that found its table full -- every occurrence travels alone;
+            // results stay exact, tests use it to put single k-mers on the loose list of a batch that otherwise fits)
+            const bool forced = (sg.dbg & 4096u) && ((c.w[0] * 0x9e3779b97f4a7c15ull) >> 58) == 0;
+            const int slot = skm_cacheable<KW>(c) && !forced ? skm_table_insert(tb, c) : -1;
             if (slot >= 0 && !(sg.dbg & 256u)) atomicAdd(&cnt[slot], 1u);
             return slot < 0;         // table region full (or unstorable key): this occurrence travels alone
         });
@@ -1419,7 +1426,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, 
                 c.w[0] = sg.dl_keys[(uint64_t)(e0 + i) * KW];
                 if (KW == 2) c.w[KW - 1] = sg.dl_keys[(uint64_t)(e0 + i) * KW + (KW - 1)];
                 const uint64_t h = sg.dl_hash[e0 + i];
-                if (novel_test_fast(ns, p, h, nullptr, 0ull)) {
+                if (novel_test_wide(ns, p, h)) {
                     if (skm_table_insert(itb, c) < 0) sg.ctr[1] = 1;          // (cannot happen below half full; the caller then redoes the scan the other way)
                     atomicAdd(&n_int, 1u);
                     if (p.ab_keys) (void)ab_claim(p, h, p.ncase + p.nctrl);      // a place for its abundances (k_ab_fill), for the kernel that reports the hits
@@ -1784,6 +1791,7 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.sbw = ((64u * (uint32_t)g.ncap) >> 5) + 2u;
     g.bucket_kmers = std::max<uint64_t>(1, n_kmers / g.n_buckets);
     g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
+    if (getenv("KV_SKM_FORCE_LOOSE")) g.dbg |= 4096u;
     skm_launch_emit(g, reads, st);
     skm_launch_split(g, st);
     KV_HIP(hipGetLastError());

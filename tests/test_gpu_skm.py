@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ('KV_COUNT_PATH', 'KV_NOVEL_PATH', 'KV_SKM_BUCKET_KMERS', 'KV_SKM_CAP_PCT', 'KV_SKM_LOOSE_CAP', 'KV_SKM_NO_REUSE')
+KNOBS = ('KV_COUNT_PATH', 'KV_NOVEL_PATH', 'KV_SKM_BUCKET_KMERS', 'KV_SKM_CAP_PCT', 'KV_SKM_LOOSE_CAP', 'KV_SKM_NO_REUSE', 'KV_SKM_FORCE_LOOSE')
 
 
 def launches(name):
@@ -265,11 +265,15 @@ def test_skm_scan_from_the_distinct_list_bands_overflow_skips_and_crowded_bucket
     got, hits = scan_both(hk, ok, reads, 31, 5e6, hint=True, case_min=5, ctrl_max=2)
     assert got == hits and len(hits) > 20
     os.environ.pop('KV_SKM_CAP_PCT')
-    # tables too small for their buckets in the count pass: those occurrences are in the loose list, not in the distinct list
-    os.environ['KV_SKM_BUCKET_KMERS'] = '12000'
-    got, hits = scan_both(hk, ok, reads, 31, 5e6, hint=True)
-    assert got == hits
-    assert launches('k_skm_novel_list') >= 6 and launches('k_novel_mark') == 0
+    # k-mers that missed the count pass's LDS tables (here: one key in 64, by decree) are on the loose list, one occurrence at a
+    # time, not in the distinct list: the scan evaluates those records as the count pass left them, positions included
+    os.environ['KV_SKM_FORCE_LOOSE'] = '1'
+    before = launches('k_skm_novel_list')
+    for k in (31, 51):
+        got, hits = scan_both(hk, ok, reads, k, 5e6, hint=True)
+        assert got == hits and len(hits) > 20
+    os.environ.pop('KV_SKM_FORCE_LOOSE')
+    assert launches('k_skm_novel_list') == before + 2 and launches('k_novel_mark') == 0
     before = launches('k_skm_novel')
     # the hint without the reuse (controls counted after the case): the list is gone with the buckets, the scan walks
     got, hits = scan_both(hk, ok, reads, 31, 5e6, hint=True, order=('proband', 'mother', 'father'))
