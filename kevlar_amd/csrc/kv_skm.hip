@@ -1381,8 +1381,21 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, 
             else next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET;
             n_cand = 0;
         }
-        // the list entries are requested before the controls' lists are worked in: they arrive meanwhile
+        // the first list entries are requested before the controls' lists are worked in: they arrive meanwhile
         const uint32_t e0 = sg.dl_bstart[b], en = min(sg.dl_bcount[b], SKM_LIST_MAX);
+        SkmKey<KW> c[E];
+        uint64_t h[E];
+        auto request = [&](uint32_t base) {
+#pragma unroll
+            for (uint32_t u = 0; u < E; ++u) {
+                const uint32_t i = base + u * SKM_THREADS3 + threadIdx.x;
+                const bool in = i < en;
+                c[u].w[0] = in ? sg.dl_keys[(uint64_t)(e0 + i) * KW] : SKM_EMPTY;
+                if (KW == 2) c[u].w[KW - 1] = in ? sg.dl_keys[(uint64_t)(e0 + i) * KW + (KW - 1)] : SKM_EMPTY;
+                h[u] = in ? sg.dl_hash[e0 + i] : 0ull;
+            }
+        };
+        request(0);
         for (int a = 0; a < abls.n; ++a) {
             const uint32_t a0 = abls.bstart[a][b], an = abls.bcount[a][b];
             for (uint32_t i = threadIdx.x; i < an; i += SKM_THREADS3) {
@@ -1395,21 +1408,12 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, 
         }
         __syncthreads();
         for (uint32_t base = 0; base < ((sg.dbg & 4u) ? 0u : en); base += E * SKM_THREADS3) {
-            SkmKey<KW> c[E];
-            uint64_t h[E];
+            if (base) request(base);
             bool live[E];
-#pragma unroll
-            for (uint32_t u = 0; u < E; ++u) {
-                const uint32_t i = base + u * SKM_THREADS3 + threadIdx.x;
-                live[u] = i < en;
-                c[u].w[0] = live[u] ? sg.dl_keys[(uint64_t)(e0 + i) * KW] : SKM_EMPTY;
-                if (KW == 2) c[u].w[KW - 1] = live[u] ? sg.dl_keys[(uint64_t)(e0 + i) * KW + (KW - 1)] : SKM_EMPTY;
-                h[u] = live[u] ? sg.dl_hash[e0 + i] : 0ull;
-            }
             uint32_t v[E];
 #pragma unroll
             for (uint32_t u = 0; u < E; ++u) {
-                live[u] = live[u] && skm_table_find(rtb, c[u]) < 0 && band_pass(p, h[u]);
+                live[u] = base + u * SKM_THREADS3 + threadIdx.x < en && skm_table_find(rtb, c[u]) < 0 && band_pass(p, h[u]);
                 v[u] = live[u] ? probe(ns, 0, 0, h[u]) : 0u;
             }
 #pragma unroll
