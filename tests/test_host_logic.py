@@ -90,7 +90,7 @@ def test_memory_setting_and_cli_defaults():
     assert args.n_batches == 16 and args.infile == ['a', 'b']
     args = kevlar_amd.cli.parser().parse_args(['dist', 'mask.nt', 'a.fq', 'b.fq'])
     assert (args.ksize, args.memory, args.threads, args.plot_xlim, args.infiles) == (31, 1e6, 1, (0, 100), ['a.fq', 'b.fq'])
-    assert set(kevlar_amd.cli.mains) == {'count', 'novel', 'filter', 'partition', 'unband', 'dist', 'split', 'augment'}
+    assert set(kevlar_amd.cli.mains) == {'count', 'novel', 'filter', 'partition', 'unband', 'dist', 'split', 'augment', 'gentrio'}
     assert kevlar_amd.sketch.get_extension() == ('.nt', '.nodetable')
     assert kevlar_amd.sketch.get_extension(count=True) == ('.ct', '.counttable')
     assert kevlar_amd.sketch.get_extension(count=True, smallcount=True) == ('.sct', '.smallcounttable')
