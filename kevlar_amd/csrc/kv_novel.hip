@@ -550,7 +550,7 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
     uint64_t nhits = 0;
     bool marked_by_skm = use_skm;
     p.ab_keys = nullptr; p.ab_vals = nullptr; p.ab_mask = 0;
-    if (e == hipSuccess && use_skm && !p.set_keys && !(getenv("KV_NOVEL_ABCACHE") && atoi(getenv("KV_NOVEL_ABCACHE")) == 0)) {
+    if (e == hipSuccess && use_skm && !p.set_keys && kv_skm_list_ready(reads, k) && !(getenv("KV_NOVEL_ABCACHE") && atoi(getenv("KV_NOVEL_ABCACHE")) == 0)) {
         // room for the abundances of the interesting k-mers (a k-mer in a few thousand is one): 1 / 64 of the k-mers in slots
         uint64_t slots = 1u << 16;
         while (slots < n_kmers / 64 && slots < (1ull << 24)) slots <<= 1;

@@ -1532,6 +1532,7 @@ struct SkmIndex {
     uint32_t *dl_bstart = nullptr, *dl_bcount = nullptr;
     uint32_t dl_cap_wg = 0;
     bool dl_valid = false;
+    uint64_t builds = 0;             // batches bucketed on this stream so far
     std::mutex mu;
 };
 std::map<hipStream_t, SkmIndex> g_skm;
@@ -1714,6 +1715,7 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     memset(&g, 0, sizeof(g));
     idx.valid = false;
     idx.dl_valid = false;
+    idx.builds += 1;
     g.k = k;
     g.m = skm_minimizer_len(k);
     g.w = k - g.m + 1;
@@ -1891,13 +1893,18 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     // distinct list (kv_sketch_scan_hint): the batch is a case sample's and will be scanned next.  A workgroup takes up to
     // quota3 of the buckets, so its stretch holds one and a half average shares of the distinct k-mers the batch is expected
     // to have (what the previous batch showed, or 30 %); a stretch that runs out drops the list (ctr[9]), nothing else.
+    // The first batch a stream ever buckets gets no list unless the room is there already: allocating a gigabyte or two costs
+    // tens of milliseconds, more than the list saves once -- a one-shot `kevlar novel` is exactly that case -- while a process
+    // that counts and scans sample after sample pays it once (KV_SKM_DL=1: always, =0: never).
     bool dl_new = false;
-    if (s->scan_hint && !(getenv("KV_SKM_DL") && atoi(getenv("KV_SKM_DL")) == 0)) {
+    const char *dl_env = getenv("KV_SKM_DL");
+    if (s->scan_hint && !(dl_env && atoi(dl_env) == 0)) {
         const double frac = std::min(1.0, std::max(0.3, s->skm_distinct * 1.15));
         const uint64_t cap_wg = std::min<uint64_t>((uint64_t)((double)n_kmers * frac * 1.6 / nwg3) + 4096, 0xfffffff0ull / nwg3);
         const size_t b_keys = kv_round_up(cap_wg * nwg3 * 8 * sg.kw, 256), b_hash = kv_round_up(cap_wg * nwg3 * 8, 256);
         const size_t b_idx = kv_round_up((uint64_t)sg.n_buckets * 4, 256);
-        if (idx.dl.need(b_keys + b_hash + 2 * b_idx) == hipSuccess) {
+        const bool worth = (dl_env && atoi(dl_env) == 1) || idx.builds > 1 || idx.dl.bytes >= b_keys + b_hash + 2 * b_idx;
+        if (worth && idx.dl.need(b_keys + b_hash + 2 * b_idx) == hipSuccess) {
             unsigned char *base = (unsigned char *)idx.dl.p;
             idx.dl_keys = (uint64_t *)base; base += b_keys;
             idx.dl_hash = (uint64_t *)base; base += b_hash;
@@ -1962,6 +1969,15 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
         }
     }
     return rc;
+}
+
+bool kv_skm_list_ready(const kv_reads *reads, int ksize)
+{
+    if (getenv("KV_SKM_NO_REUSE") || (getenv("KV_SKM_DL") && atoi(getenv("KV_SKM_DL")) == 0)) return false;
+    std::lock_guard<std::mutex> lk(g_skm_mu);
+    for (auto &kv : g_skm)
+        if (kv.second.valid && kv.second.dl_valid && kv.second.reads_uid == reads->uid && kv.second.k == ksize) return true;
+    return false;
 }
 
 int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_kmers)

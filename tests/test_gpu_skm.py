@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ('KV_COUNT_PATH', 'KV_NOVEL_PATH', 'KV_SKM_BUCKET_KMERS', 'KV_SKM_CAP_PCT', 'KV_SKM_LOOSE_CAP', 'KV_SKM_NO_REUSE', 'KV_SKM_FORCE_LOOSE')
+KNOBS = ('KV_COUNT_PATH', 'KV_NOVEL_PATH', 'KV_SKM_BUCKET_KMERS', 'KV_SKM_CAP_PCT', 'KV_SKM_LOOSE_CAP', 'KV_SKM_NO_REUSE', 'KV_SKM_FORCE_LOOSE', 'KV_SKM_DL')
 
 
 def launches(name):
@@ -164,6 +164,7 @@ def scan_both(hk, ok, reads, k, mem, case_min=6, ctrl_max=1, nctrl=2, order=('mo
     names = ('proband', 'mother', 'father')[:1 + nctrl]
     dev = {n: hk.Counttable(k, mem / 4, 4) for n in names}
     if hint:
+        os.environ['KV_SKM_DL'] = '1'                           # (also for the first batch this process buckets)
         dev['proband'].expect_scan()                            # the count keeps the batch's distinct k-mers with their hashes
     ref = {n: ok.Counttable(k, mem / 4, 4) for n in names}
     batches = {n: hk.ReadBatch(reads[n]) for n in names}
