@@ -156,15 +156,21 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_mark(ReadsDev rd, Nov
 // exclusive scan of n 32-bit counts into 64-bit bases (single 1024-thread workgroup)
 __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t *counts, uint32_t n, uint64_t *base)
 {
+    // one workgroup; eight consecutive counts per thread and round (117 k tiles: 15 rounds of three barriers instead of 115, each
+    // with its own trip to memory: 0.165 -> 0.03 ms)
+    constexpr uint32_t PER = 8;
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t start = 0; start < n; start += 1024) {
-        const uint32_t i = start + threadIdx.x;
-        const uint64_t v = i < n ? counts[i] : 0;
-        uint64_t incl = v;
+    for (uint32_t start = 0; start < n; start += 1024 * PER) {
+        const uint32_t i0 = start + threadIdx.x * PER;
+        uint32_t c[PER];
+        uint64_t mine = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < PER; ++u) { c[u] = i0 + u < n ? counts[i0 + u] : 0u; mine += c[u]; }
+        uint64_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint64_t up = __shfl_up(incl, d);
@@ -174,7 +180,9 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t *counts, uint
         __syncthreads();
         uint64_t before = carry;
         for (int w = 0; w < wave; ++w) before += wsum[w];
-        if (i < n) base[i] = before + incl - v;
+        uint64_t run = before + incl - mine;
+#pragma unroll
+        for (uint32_t u = 0; u < PER; ++u) { if (i0 + u < n) base[i0 + u] = run; run += c[u]; }
         __syncthreads();
         if (threadIdx.x == 1023) carry = before + incl;
         __syncthreads();

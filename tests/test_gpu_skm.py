@@ -160,13 +160,13 @@ def test_skm_band_and_mask(hk, ok, skm):
     assert launches('k_skm_count') >= 4
 
 
-def scan_both(hk, ok, reads, k, mem, case_min=6, ctrl_max=1, nctrl=2, order=('mother', 'father', 'proband'), hint=False, **kw):
+def scan_both(hk, ok, reads, k, mem, case_min=6, ctrl_max=1, nctrl=2, order=('mother', 'father', 'proband'), hint=False, kind='Counttable', **kw):
     names = ('proband', 'mother', 'father')[:1 + nctrl]
-    dev = {n: hk.Counttable(k, mem / 4, 4) for n in names}
+    dev = {n: getattr(hk, kind)(k, mem / 4, 4) for n in names}
     if hint:
         os.environ['KV_SKM_DL'] = '1'                           # (also for the first batch this process buckets)
         dev['proband'].expect_scan()                            # the count keeps the batch's distinct k-mers with their hashes
-    ref = {n: ok.Counttable(k, mem / 4, 4) for n in names}
+    ref = {n: getattr(ok, kind)(k, mem / 4, 4) for n in names}
     batches = {n: hk.ReadBatch(reads[n]) for n in names}
     for n in [x for x in order if x in names]:                  # the case sample last: the scan can reuse its buckets
         dev[n].consume_batch(batches[n])
@@ -241,6 +241,16 @@ def test_skm_scan_from_the_distinct_list_matches_oracle(hk, ok, skm, k):
     assert len(hits) > 50 and got == hits
     assert launches('k_skm_novel_list') == 1 and launches('k_skm_novel') == 0 and launches('k_novel_mark') == 0
     assert launches('k_skm_emit') == 3
+
+
+@pytest.mark.parametrize('kind,case_min,ctrl_max', [('SmallCounttable', 6, 1), ('Nodetable', 1, 0)])
+def test_skm_scan_from_the_distinct_list_nibble_and_bit_counters(hk, ok, skm, kind, case_min, ctrl_max):
+    """four-bit counters saturate at 15, one-bit ones at 1: the controls' abundance lists reject by min(count, what a counter holds)"""
+    os.environ['KV_SKM_BUCKET_KMERS'] = '4096'
+    reads = trio_reads(80000, 24000, 53)
+    got, hits = scan_both(hk, ok, reads, 31, 8e6, hint=True, kind=kind, case_min=case_min, ctrl_max=ctrl_max)
+    assert got == hits and len(hits) > 20
+    assert launches('k_skm_novel_list') == 1 and launches('k_skm_novel') == 0
 
 
 def test_skm_scan_from_the_distinct_list_bands_overflow_skips_and_crowded_buckets(hk, ok, skm):
