@@ -86,6 +86,9 @@ namespace {
 // ticket.  A ticket therefore covers several units of work.
 #define SKM_TILES_PER_TICKET 8u
 #define SKM_BUCKETS_PER_TICKET 8u
+// workgroups of the loose-list kernels (grid-stride over a list that is all but empty when the batch fits: 4096 workgroups cost
+// 0.14 ms each launch just to start, find nothing and leave)
+#define SKM_LOOSE_WGS 1024
 
 // (32-byte records -- one aligned sector each, two 16-byte stores -- were measured against these 24-byte ones: WRITE_SIZE
 // fell from 2.5 to 2.3 GB per sample for 1.3 / 1.7 GB stored, the readers fetched 0.4 GB more each, times did not move.)
@@ -1927,8 +1930,8 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     }
     {
         KvProfScope prof("k_skm_loose_count");
-        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_count<1>, dim3(4096), dim3(256), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
-        else hipLaunchKernelGGL(k_skm_loose_count<2>, dim3(4096), dim3(256), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
+        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_count<1>, dim3(SKM_LOOSE_WGS), dim3(256), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
+        else hipLaunchKernelGGL(k_skm_loose_count<2>, dim3(SKM_LOOSE_WGS), dim3(256), 0, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
     }
     KV_HIP(hipGetLastError());
     // a lost record (loose list overflow) must stop the apply stage, which looks at the partition's own flag
@@ -2045,8 +2048,8 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
     }
     {
         KvProfScope prof("k_skm_loose_novel");
-        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_novel<1>, dim3(4096), dim3(256), 0, st, sg, rd, p);
-        else hipLaunchKernelGGL(k_skm_loose_novel<2>, dim3(4096), dim3(256), 0, st, sg, rd, p);
+        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_novel<1>, dim3(SKM_LOOSE_WGS), dim3(256), 0, st, sg, rd, p);
+        else hipLaunchKernelGGL(k_skm_loose_novel<2>, dim3(SKM_LOOSE_WGS), dim3(256), 0, st, sg, rd, p);
     }
     {
         KvProfScope prof("k_tile_hits");
@@ -2087,8 +2090,8 @@ int kv_skm_route_distinct(const kv_reads *reads, int ksize, uint64_t n_kmers, in
     }
     {
         KvProfScope prof("k_skm_loose_route");
-        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_route<1>, dim3(4096), dim3(256), 0, st, sg, hp, rs);
-        else hipLaunchKernelGGL(k_skm_loose_route<2>, dim3(4096), dim3(256), 0, st, sg, hp, rs);
+        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_route<1>, dim3(SKM_LOOSE_WGS), dim3(256), 0, st, sg, hp, rs);
+        else hipLaunchKernelGGL(k_skm_loose_route<2>, dim3(SKM_LOOSE_WGS), dim3(256), 0, st, sg, hp, rs);
     }
     KV_HIP(hipGetLastError());
     unsigned long long sctr[8] = {0};
@@ -2264,8 +2267,8 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     }
     {
         KvProfScope prof("k_skm_loose_route");
-        if (g.kw == 1) hipLaunchKernelGGL(k_skm_loose_route<1>, dim3(4096), dim3(256), 0, st, g, hp, rs);
-        else hipLaunchKernelGGL(k_skm_loose_route<2>, dim3(4096), dim3(256), 0, st, g, hp, rs);
+        if (g.kw == 1) hipLaunchKernelGGL(k_skm_loose_route<1>, dim3(SKM_LOOSE_WGS), dim3(256), 0, st, g, hp, rs);
+        else hipLaunchKernelGGL(k_skm_loose_route<2>, dim3(SKM_LOOSE_WGS), dim3(256), 0, st, g, hp, rs);
     }
     KV_HIP(hipGetLastError());
     unsigned long long sctr[8] = {0};
