@@ -101,6 +101,7 @@ def parse_args():
                         'independent; kernels bound by different units overlap and no stream waits for another\'s host round '
                         'trips: 39-40 ms against 43-46 ms per step at config 2).  Per-kernel HIP-event durations then include '
                         'time sharing; 1 keeps the launches back to back for a clean per-kernel attribution')
+    p.add_argument('--no-downstream', action='store_true', help='cfg4-band: count and scan only (no annotated reads, filter, partition)')
     p.add_argument('--traffic', default='live', choices=['live', 'file', 'none'],
                    help='roofline.traffic (HBM bytes of the dominant stage): live = measured by two rocprofv3 --pmc child passes of this '
                         'command before the timed run (cfg2, one GPU; ~1.5 min); file = the committed profiles/r*_final file if it '
@@ -596,7 +597,7 @@ def main():
 
     cpu = e2e = None
     downstream = None
-    if on_device:
+    if on_device and not args.no_downstream:
         downstream = band_downstream(args, wl, hits, genome_len, GEN_SEED, L, k, S, synth)
         note_hbm()
         props = torch.cuda.get_device_properties(dev_index)

@@ -21,7 +21,11 @@
 #define KVF_HD static inline
 #endif
 
+#if defined(KV_FASTMOD_NO_FP)          // A/B builds (scratch/ab_build.py NAME -DKV_FASTMOD_NO_FP): Barrett for every size
+KVF_HD bool kv_fastmod_fp(uint64_t) { return false; }
+#else
 KVF_HD bool kv_fastmod_fp(uint64_t size) { return size - 65536ull < 0xffff0000ull; }
+#endif
 
 // what SketchDev::magic holds for a table of `size` bins (host side)
 static inline uint64_t kv_fastmod_magic(uint64_t size)

@@ -79,6 +79,37 @@ def test_skm_count_matches_oracle(hk, ok, skm, kind, k, tablesize):
     assert_same_tables(dev, ref)
 
 
+@pytest.mark.parametrize('read_len,k', [(36, 31), (75, 25), (150, 31), (151, 51), (251, 31), (600, 31)])
+def test_skm_equal_length_reads_of_other_lengths(hk, ok, skm, read_len, k):
+    """batches of equal-length reads handed over as packed words (what the device ingest and the generators produce) take the
+    wave-per-group S1 kernel (k_skm_emit_wave): one packed word and one chunk of k-mer starts per lane, so the group size, the
+    padding of a read's last word and the chunks per read all follow the read length"""
+    from kevlar_amd import synth
+    os.environ['KV_SKM_BUCKET_KMERS'] = '4096'
+    os.environ['KV_SKM_DL'] = '1'
+    n = max(2000, 1500000 // read_len)
+    trio = synth.make_trio(60000, 61, inherited_per_mb=400, denovo_per_mb=400)
+    names = ('proband', 'mother', 'father')
+    words = {s: synth.sample_reads_packed(trio[s], n, read_len, 0.005, 62 + i) for i, s in enumerate(names)}
+    reads = {s: synth.unpack_reads(words[s], read_len) for s in names}
+    for hint in (False, True):
+        dev = {s: hk.Counttable(k, 2e6, 4) for s in names}
+        ref = {s: ok.Counttable(k, 2e6, 4) for s in names}
+        if hint:
+            dev['proband'].expect_scan()
+        batches = {s: hk.ReadBatch.from_packed(words[s], read_len) for s in names}
+        for s in ('mother', 'father', 'proband'):
+            assert dev[s].consume_batch(batches[s]) == n * (read_len - k + 1)
+            bases, offs = ok.concat_reads(reads[s])
+            ok.consume_reads(ref[s], bases, offs, n)
+            assert_same_tables(dev[s], ref[s])
+        r, o, a, _ = hk.novel_scan([dev['proband']], [dev['mother'], dev['father']], batches['proband'], 6, 1)
+        bases, offs = ok.concat_reads(reads['proband'])
+        hits, _ = ok.novel_scan([ref['proband']], [ref['mother'], ref['father']], bases, offs, n, k, 6, 1, 0, 0, 0, 0)
+        assert [(int(r[i]), int(o[i]), tuple(int(x) for x in a[i])) for i in range(len(r))] == hits and len(hits) > 10
+    assert launches('k_skm_novel_list') == 1 and launches('k_skm_novel') == 1
+
+
 def test_skm_single_bucket_and_default_geometry(hk, ok, skm):
     """one coarse x one fine bucket (everything in one LDS table, most of it overflowing into the loose list), and
     the geometry the library picks by itself"""
