@@ -624,7 +624,11 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split(SkmGeom sg)
 // SKM_S2_CHUNK records at a time, ranks them by fine bucket (LDS atomics: rank inside the chunk's share of the bucket),
 // lays them out bucket by bucket in LDS and copies that image out with consecutive lanes on consecutive words: a bucket's
 // records of one chunk leave as one contiguous run.  Used while a chunk holds at least ~2 records per bucket.
+#if defined(SKM_S2_CHUNK_OVERRIDE)
+#define SKM_S2_CHUNK SKM_S2_CHUNK_OVERRIDE
+#else
 #define SKM_S2_CHUNK 2048u
+#endif
 #define SKM_S2_MAXF 1024u
 template <int RECW>
 __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split_sorted(SkmGeom sg)
