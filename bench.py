@@ -840,6 +840,16 @@ def end_to_end(args, wl, packed, names, synth):
             dt_filter = stage(['filter', '--memory', '50M', '--case-min', str(args.case_min), '--ctrl-max', str(args.ctrl_max),
                                '-o', os.path.join(tmp, 'filtered.augfastq'), novel_out])
             dt_partition = stage(['partition', '-o', os.path.join(tmp, 'partitioned.augfastq'), os.path.join(tmp, 'filtered.augfastq')])
+            if os.environ.get('KV_E2E_PROFILE'):       # where a one-shot filter / partition spends its time (stderr)
+                import cProfile, pstats
+                for argv in (['filter', '--memory', '50M', '--case-min', str(args.case_min), '--ctrl-max', str(args.ctrl_max),
+                              '-o', os.path.join(tmp, 'filtered2.augfastq'), novel_out],
+                             ['partition', '-o', os.path.join(tmp, 'partitioned2.augfastq'), os.path.join(tmp, 'filtered.augfastq')]):
+                    prof = cProfile.Profile(); t0 = time.perf_counter()
+                    prof.enable(); stage(argv); prof.disable()
+                    st = io.StringIO(); pstats.Stats(prof, stream=st).sort_stats('tottime').print_stats(12)
+                    sys.stderr.write('[e2e profile] second {} {:.3f} s (first: filter {:.3f}, partition {:.3f})\n{}\n'.format(
+                        argv[0], time.perf_counter() - t0, dt_filter, dt_partition, st.getvalue()[:3000]))
         finally:
             log_text = kevlar_amd.logstream.getvalue()
             kevlar_amd.logstream = saved

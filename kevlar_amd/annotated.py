@@ -238,9 +238,9 @@ class AnnotatedReads(object):
         for i in self._kept_reads(keep).tolist():
             yield self.record(i, keep, case_abund)
 
-    def format(self, reads, keep=None, case_abund=None, suffixes=None, regrouped=None):
+    def format(self, reads, keep=None, case_abund=None, suffixes=None, regrouped=None, suffix_blob=None):
         """Augmented FASTA/FASTQ text (bytes) of the given reads (indices, in that order) with the annotations where
-        `keep` is set (None: all); suffixes: one string per read appended to its name.  regrouped = (lo, hi, order):
+        `keep` is set (None: all); suffixes: one string per read appended to its name (suffix_blob: the same as one blob + offsets).  regrouped = (lo, hi, order):
         output read j carries annotations order[lo[j]:hi[j]] (indices into this container's annotations) instead of
         its own -- the union over several copies of a read (unband)."""
         reads = np.ascontiguousarray(reads, dtype=np.uint64)
@@ -262,6 +262,8 @@ class AnnotatedReads(object):
         if suffixes is not None:
             sfx_blob = ''.join(suffixes).encode('latin-1')
             sfx_offs = _offsets([len(s) for s in suffixes])
+        elif suffix_blob is not None:           # the same, already joined: (bytes, offsets[len(reads) + 1])
+            sfx_blob, sfx_offs = suffix_blob[0], np.ascontiguousarray(suffix_blob[1], dtype=np.uint64)
 
         def ptr(a):
             return None if a is None else a.ctypes.data_as(ctypes.c_void_p)

@@ -59,11 +59,119 @@ def partition(readstream, strict=False, minabund=None, maxabund=None, dedup=True
     kevlar_amd.plog('[kevlar::partition]', 'Total time: {:.2f} seconds'.format(timer.stop()))
 
 
+def _fixed_width(blob, offs):
+    """the strings blob[offs[i]:offs[i + 1]] as one numpy bytes array (NUL padded): compares and sorts like the strings do"""
+    import numpy as np
+    offs = np.asarray(offs, dtype=np.int64)
+    lens = np.diff(offs)
+    width = int(lens.max()) if len(lens) else 1
+    raw = np.frombuffer(blob, dtype=np.uint8)
+    if len(raw) == 0:
+        return np.zeros(len(lens), dtype='S1')
+    cols = np.arange(max(1, width), dtype=np.int64)
+    at = np.minimum(offs[:-1, None] + cols[None, :], len(raw) - 1)
+    out = np.where(cols[None, :] < lens[:, None], raw[at], np.uint8(0)).astype(np.uint8)
+    return np.ascontiguousarray(out).view('S{:d}'.format(max(1, width))).reshape(-1)
+
+
+_COMP_LUT = None
+
+
+def _canonical_hashes(seqs, seq_offs, reads):
+    """two independent 64-bit hashes of min(sequence, reverse complement) -- kevlar_amd.revcommin(), the key partition()
+    dedups by -- for the given reads; equal-length reads are worked on together as one byte matrix"""
+    import numpy as np
+    from kevlar_amd.sequence import _COMPLEMENT
+    global _COMP_LUT
+    if _COMP_LUT is None:
+        lut = np.arange(256, dtype=np.uint8)
+        for src, dst in _COMPLEMENT.items():
+            if src < 256:
+                lut[src] = dst
+        _COMP_LUT = lut
+    raw = np.frombuffer(seqs, dtype=np.uint8)
+    offs = np.asarray(seq_offs, dtype=np.int64)
+    reads = np.asarray(reads, dtype=np.int64)
+    lens = offs[reads + 1] - offs[reads]
+    h1 = np.zeros(len(reads), dtype=np.uint64)
+    h2 = np.zeros(len(reads), dtype=np.uint64)
+    with np.errstate(over='ignore'):
+        for length in np.unique(lens).tolist():
+            sel = np.flatnonzero(lens == length)
+            a = np.full(len(sel), 0xcbf29ce484222325, dtype=np.uint64) ^ np.uint64(length)
+            c = np.full(len(sel), 0x9e3779b97f4a7c15, dtype=np.uint64) + np.uint64(length)
+            if length:
+                fwd = raw[offs[reads[sel]][:, None] + np.arange(length, dtype=np.int64)[None, :]]
+                rev = _COMP_LUT[fwd[:, ::-1]]
+                differ = fwd != rev
+                first = differ.argmax(axis=1)
+                rows = np.arange(len(sel))
+                take_rev = differ.any(axis=1) & (rev[rows, first] < fwd[rows, first])
+                canon = np.where(take_rev[:, None], rev, fwd)
+                for col in range(length):
+                    byte = canon[:, col].astype(np.uint64)
+                    a = (a ^ byte) * np.uint64(0x100000001b3)
+                    c = (c + byte) * np.uint64(0xff51afd7ed558ccd)
+                    c ^= c >> np.uint64(29)
+            h1[sel], h2[sel] = a, c
+    return h1, h2
+
+
+def assemble_partitions(names, name_offs, seqs, seq_offs, component_of, minabund=None, dedup=True):
+    """The host half of relaxed-mode partitioning on arrays.  names / seqs: the reads' names and sequences (blob + offsets);
+    component_of(node_of_read, n_nodes) -> a component label per NODE (reads that share a name share a node, whose record is
+    the last of them).  Returns (reads, number): the read indices in output order and the partition number of each --
+    partitions largest first (ties: the one whose smallest name is larger first), members by name, with dedup only the
+    first read of every sequence up to reverse complement, and a partition that dedup leaves below minabund dropped:
+    kevlar/partition.py:15-55, kevlar/readgraph.py:123-161."""
+    import numpy as np
+    n = len(name_offs) - 1
+    empty = (np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
+    if n <= 0:
+        return empty
+    fixed = _fixed_width(names, name_offs)
+    _, node_of_read = np.unique(fixed, return_inverse=True)         # node ids in name order: a node's id is its name's rank
+    node_of_read = node_of_read.astype(np.int64)
+    n_nodes = int(node_of_read.max()) + 1
+    holder = np.zeros(n_nodes, dtype=np.int64)
+    np.maximum.at(holder, node_of_read, np.arange(n, dtype=np.int64))
+    labels = np.asarray(component_of(node_of_read.astype(np.uint32), n_nodes))
+    _, comp = np.unique(labels, return_inverse=True)
+    size = np.bincount(comp)
+    smallest = np.full(len(size), n_nodes, dtype=np.int64)
+    np.minimum.at(smallest, comp, np.arange(n_nodes, dtype=np.int64))
+    keep = np.flatnonzero(size >= 2)                                # a read on its own is not a partition
+    if not len(keep):
+        return empty
+    keep = keep[np.lexsort((-smallest[keep], -size[keep]))]          # largest first; ties: the larger smallest name first
+    place = np.full(len(size), -1, dtype=np.int64)
+    place[keep] = np.arange(len(keep))
+    nodes = np.flatnonzero(place[comp] >= 0)
+    nodes = nodes[np.lexsort((nodes, place[comp[nodes]]))]          # by partition, then by name
+    reads, part = holder[nodes], place[comp[nodes]]
+    if dedup:
+        h1, h2 = _canonical_hashes(seqs, seq_offs, reads)
+        pos = np.arange(len(reads))
+        order = np.lexsort((pos, h2, h1, part))
+        first = np.ones(len(order), dtype=bool)
+        first[1:] = (part[order][1:] != part[order][:-1]) | (h1[order][1:] != h1[order][:-1]) | (h2[order][1:] != h2[order][:-1])
+        kept = np.sort(order[first])
+        reads, part = reads[kept], part[kept]
+        if minabund:
+            left = np.bincount(part, minlength=len(keep))
+            ok = left >= minabund
+            sel = ok[part]
+            reads, part = reads[sel], part[sel]
+            renumber = np.cumsum(ok) - 1
+            part = renumber[part]
+    return reads, part + 1
+
+
 def partition_file(infile, minabund=None, maxabund=None, dedup=True):
-    """partition() in relaxed mode for a file, on arrays: yields (N, annotated, read indices) with the reads of
-    component N in the order partition() lists them (sorted by name; with dedup the first read of every sequence, up
-    to reverse complement).  Same components, numbering and log lines; the records are parsed natively
-    (AnnotatedReads.from_file), the components come from the device union-find, and no Record object is built."""
+    """partition() in relaxed mode for a file, on arrays: returns (annotated, read indices in output order, partition number of
+    each).  Same components, numbering and log lines as partition(); the records are parsed natively
+    (AnnotatedReads.from_file), the components come from the device union-find, the ordering is array arithmetic
+    (assemble_partitions), and no Record object -- nor any per-read Python object -- is built."""
     import numpy as np
     from kevlar_amd import khmer
     from kevlar_amd.annotated import AnnotatedReads
@@ -73,58 +181,24 @@ def partition_file(infile, minabund=None, maxabund=None, dedup=True):
         ann = AnnotatedReads.from_file(infile)
         if ann.n and ann.ksize is None and len(ann):
             raise ValueError('all interesting k-mers of one graph must share k')
-        blob, offs = ann.names.decode('latin-1'), ann.name_offs.tolist()
-        names = [blob[offs[i]:offs[i + 1]] for i in range(ann.n)]
-        node_id, node_names, holder = {}, [], []           # reads that share a name share a node; its record is the last of them
-        node_of_read = np.empty(ann.n, dtype=np.uint32)
-        for i, name in enumerate(names):
-            node = node_id.get(name)
-            if node is None:
-                node = node_id[name] = len(node_names)
-                node_names.append(name)
-                holder.append(i)
-            else:
-                holder[node] = i
-            node_of_read[i] = node
-    mode = ('[kevlar::partition]', 'Building read graph in relaxed mode')
-    with _phase(timer, 'buildgraph', mode, 'Graph built in {:.2f} sec'):
-        if ann.n:
-            labels = khmer.readgraph_components(ann.batch, ann.ksize or 1, ann.read, ann.offset, node_of_read, len(node_names),
+
+    def component_of(node_of_read, n_nodes):
+        mode = ('[kevlar::partition]', 'Building read graph in relaxed mode')
+        with _phase(timer, 'buildgraph', mode, 'Graph built in {:.2f} sec'):
+            labels = khmer.readgraph_components(ann.batch, ann.ksize or 1, ann.read, ann.offset, node_of_read, n_nodes,
                                                 minabund or 0, maxabund or 0)
             ann.close()
-        else:
-            labels = np.zeros(0, dtype=np.uint32)
+        return labels
+    if ann.n:
+        reads, number = assemble_partitions(ann.names, ann.name_offs, ann.seqs, ann.seq_offs, component_of, minabund, dedup)
+    else:
+        with _phase(timer, 'buildgraph', ('[kevlar::partition]', 'Building read graph in relaxed mode'), 'Graph built in {:.2f} sec'):
+            pass
+        reads, number = np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
     with _phase(timer, 'partition', ('[kevlar::partition] Partition readgraph',), 'Partitioning done in {:.2f} sec'):
-        # components, largest first; ties: by sorted read names, descending (names are unique per node, so the
-        # smallest name of a component decides)
-        order = np.argsort(labels, kind='stable')
-        cuts = np.flatnonzero(np.diff(labels[order])) + 1 if len(order) else np.zeros(0, dtype=np.int64)
-        groups = np.split(order, cuts) if len(order) else []
-        keyed = []
-        for nodes in groups:
-            if len(nodes) < 2:
-                continue                      # a read on its own is not a partition
-            members = sorted(node_names[v] for v in nodes.tolist())
-            keyed.append((len(members), members))
-        keyed.sort(reverse=True)
-        seqs, soffs = ann.seqs.decode('latin-1'), ann.seq_offs.tolist()
-        number = 0
-        for size, members in keyed:
-            reads = [holder[node_id[name]] for name in members]
-            if dedup:
-                seen, kept = set(), []
-                for r in reads:
-                    canon = kevlar_amd.revcommin(seqs[soffs[r]:soffs[r + 1]])
-                    if canon in seen:
-                        continue
-                    seen.add(canon)
-                    kept.append(r)
-                reads = kept
-                if minabund and len(reads) < minabund:
-                    continue
-            number += 1
-            yield number, ann, reads
+        pass
     kevlar_amd.plog('[kevlar::partition]', 'Total time: {:.2f} seconds'.format(timer.stop()))
+    return ann, reads, number
 
 
 class _Outputs(object):
@@ -150,19 +224,24 @@ class _Outputs(object):
 
 def _main_arrays(args, outputs):
     """relaxed mode, file input: everything on arrays, text rendered natively"""
-    sizes = [0]
-    pending_reads, pending_suffix, ann = [], [], None
-    for number, ann, reads in partition_file(args.infile, minabund=args.min_abund, maxabund=args.max_abund, dedup=args.dedup):
-        sizes.append(len(reads))
-        suffix = ' kvcc={:d}'.format(number)
+    import numpy as np
+    ann, reads, number = partition_file(args.infile, minabund=args.min_abund, maxabund=args.max_abund, dedup=args.dedup)
+    count = int(number.max()) if len(number) else 0
+    if len(reads):
+        sizes = np.bincount(number, minlength=count + 1)[1:]
+        labels = [' kvcc={:d}'.format(i) for i in range(1, count + 1)]
         if args.split:
-            outputs.put(number, ann.format(reads, suffixes=[suffix] * len(reads)))
+            start = 0
+            for i, size in enumerate(sizes.tolist(), 1):
+                outputs.put(i, ann.format(reads[start:start + size], suffixes=[labels[i - 1]] * size))
+                start += size
         else:
-            pending_reads.extend(reads)
-            pending_suffix.extend([suffix] * len(reads))
-    if pending_reads:
-        outputs.put(0, ann.format(pending_reads, suffixes=pending_suffix))
-    kevlar_amd.plog('[kevlar::partition]', 'grouped {:d} reads into {:d} connected components'.format(sum(sizes), len(sizes) - 1))
+            blob = ''.join(label * size for label, size in zip(labels, sizes.tolist())).encode('latin-1')
+            lens = np.repeat(np.array([len(label) for label in labels], dtype=np.uint64), sizes)
+            offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+            np.cumsum(lens, out=offs[1:])
+            outputs.put(0, ann.format(reads, suffix_blob=(blob, offs)))
+    kevlar_amd.plog('[kevlar::partition]', 'grouped {:d} reads into {:d} connected components'.format(len(reads), count))
 
 
 def main(args):

@@ -571,3 +571,66 @@ def test_gentrio_cli_writes_a_consistent_trio(tmp_path):
     kevlar_amd.gentrio.main(args)
     assert open(again + '-proband.fasta').read() == open(prefix + '-proband.fasta').read()
     assert kevlar_amd.gentrio.parse_weights('snv=2,del=2') == {'snv': 0.5, 'del': 0.5}
+
+
+def test_assemble_partitions_matches_the_loop_it_replaced():
+    """the array form of partition()'s ordering (largest first, ties by the larger smallest name, members by name, one read per
+    sequence up to reverse complement, partitions that dedup leaves below min-abund dropped) against the plain restatement of
+    kevlar/partition.py:15-55 + readgraph.py:123-161 -- random names (some shared: the last record of a name is its node's),
+    lengths, strands and component labels"""
+    import random
+    import numpy as np
+    import kevlar_amd
+    from kevlar_amd.partition import assemble_partitions
+    rng = random.Random(9)
+    for trial in range(40):
+        n = rng.choice([0, 1, 2, 7, 60, 400])
+        pool = [''.join(rng.choice('ACGTacgtN') for _ in range(rng.choice([20, 20, 33, 50]))) for _ in range(max(1, n // 3))]
+        names, seqs = [], []
+        for i in range(n):
+            names.append('read{}'.format(rng.randrange(max(1, n))) if rng.random() < 0.15 else 'r{}/{}'.format(i, rng.randrange(3)))
+            s = rng.choice(pool)
+            seqs.append(kevlar_amd.revcom(s) if rng.random() < 0.4 else s)
+        nb = ''.join(names).encode(); no = np.cumsum([0] + [len(x) for x in names]).astype(np.uint64)
+        sb = ''.join(seqs).encode(); so = np.cumsum([0] + [len(x) for x in seqs]).astype(np.uint64)
+        ncomp = max(1, n // rng.choice([2, 5, 20]))
+        seen_nodes = {}
+
+        def component_of(node_of_read, n_nodes):
+            lab = np.array([rng.randrange(ncomp) for _ in range(n_nodes)], dtype=np.uint32)
+            seen_nodes['node_of_read'], seen_nodes['labels'] = np.asarray(node_of_read), lab
+            return lab
+        for dedup, minabund in ((True, None), (True, 2), (False, None), (True, 3)):
+            rng_state = rng.getstate()
+            reads, number = assemble_partitions(nb, no, sb, so, component_of, minabund, dedup)
+            rng.setstate(rng_state)
+            if n == 0:
+                assert len(reads) == 0
+                continue
+            # the loop: nodes by name, the record of a node is the last read with that name
+            node_of_read, labels = seen_nodes['node_of_read'], seen_nodes['labels']
+            holder = {}
+            for i, name in enumerate(names):
+                holder[name] = i
+            label_of = {names[i]: int(labels[node_of_read[i]]) for i in range(n)}
+            groups = {}
+            for name, lab in label_of.items():
+                groups.setdefault(lab, []).append(name)
+            keyed = sorted(((len(m), sorted(m)) for m in groups.values() if len(m) >= 2), reverse=True)
+            want_reads, want_number, num = [], [], 0
+            for size, members in keyed:
+                rs = [holder[name] for name in members]
+                if dedup:
+                    seen, kept = set(), []
+                    for r in rs:
+                        canon = kevlar_amd.revcommin(seqs[r])
+                        if canon not in seen:
+                            seen.add(canon)
+                            kept.append(r)
+                    rs = kept
+                    if minabund and len(rs) < minabund:
+                        continue
+                num += 1
+                want_reads += rs
+                want_number += [num] * len(rs)
+            assert reads.tolist() == want_reads and number.tolist() == want_number, (trial, dedup, minabund)
