@@ -703,6 +703,15 @@ def band_downstream(args, wl, hits, genome_len, seed, L, k, S, synth):
     try:
         t_filter = run(['filter', '--memory', '2G', '--case-min', str(args.case_min), '--ctrl-max', str(args.ctrl_max), '-o', filtered_file, novel_file])
         t_part = run(['partition', '-o', part_file, filtered_file])
+        if os.environ.get('KV_E2E_PROFILE'):           # where the seconds of filter / partition go at this scale (stderr)
+            import cProfile, pstats
+            for argv in (['filter', '--memory', '2G', '--case-min', str(args.case_min), '--ctrl-max', str(args.ctrl_max), '-o', filtered_file + '.2', novel_file],
+                         ['partition', '-o', part_file + '.2', filtered_file]):
+                prof = cProfile.Profile(); t0 = time.perf_counter()
+                prof.enable(); run(argv); prof.disable()
+                st = io.StringIO(); pstats.Stats(prof, stream=st).sort_stats('tottime').print_stats(16)
+                sys.stderr.write('[downstream profile] {} {:.2f} s\n{}\n'.format(argv[0], time.perf_counter() - t0, st.getvalue()[:4000]))
+                os.remove(argv[-2])
     finally:
         kevlar_amd.logstream = old_log
     said = [ln.split('] ', 1)[-1] for ln in log.getvalue().splitlines() if 'Validated' in ln or 'grouped' in ln or 'Processed' in ln]
