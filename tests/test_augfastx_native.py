@@ -190,6 +190,17 @@ def test_native_parse_in_pieces_equals_one_pass(tmp_path, fastq):
             os.environ.pop('KV_AUGFASTX_THREADS', None)
     one = loaded['1']
     assert one.n == 60000 and len(one.mate_record) == 60000 // 7 + 1
+    # the writer renders stretches of records side by side and joins them: the same bytes as one pass, in any selection and order
+    picks = np.random.default_rng(3).permutation(one.n)[:50000]
+    rendered = {}
+    for threads in ('1', '2', '7'):
+        os.environ['KV_AUGFASTX_THREADS'] = threads
+        try:
+            rendered[threads] = (one.format(np.arange(one.n)), one.format(picks, suffixes=[' kvcc={}'.format(i % 9) for i in range(len(picks))]))
+        finally:
+            os.environ.pop('KV_AUGFASTX_THREADS', None)
+    assert rendered['1'][0].count(b'\n') > 3 * one.n
+    assert rendered['2'] == rendered['1'] and rendered['7'] == rendered['1'] and len(rendered['1'][1]) > (5 << 20)
     for threads in ('2', '7'):
         got = loaded[threads]
         assert got.n == one.n and got.ksize == one.ksize and got.nsamples == one.nsamples
