@@ -333,105 +333,63 @@ extern "C" int kv_format_records(uint64_t n_out, const uint64_t *rec_index, cons
 {
     KV_REQUIRE(text_out && bytes_out && (n_out == 0 || (rec_index && ann_lo && ann_hi && names && name_offs && seqs && seq_offs)), KV_ERR_ARG,
                "kv_format_records: null argument");
-    // records [j0, j1) into `out`; false (and the record in *bad) if an annotation does not fit its read or memory ran out
-    auto render = [&](uint64_t j0, uint64_t j1, KvTextOut &out, uint64_t *bad) -> bool {
-        {
-            uint64_t notes = 0;
-            for (uint64_t j = j0; j < j1; ++j) notes += ann_hi[j] - ann_lo[j];
-            out.room((size_t)notes * (size_t)(ksize + 48) + (size_t)(j1 - j0) * 320 + 4096);
-        }
-        std::vector<uint64_t> order;
-        for (uint64_t j = j0; j < j1; ++j) {
-            const uint64_t r = rec_index[j];
-            const char *seq = seqs + seq_offs[r];
-            const size_t seq_len = (size_t)(seq_offs[r + 1] - seq_offs[r]);
-            const bool fq = is_fastq ? is_fastq[r] != 0 : false;
-            out.put(fq ? '@' : '>');
-            out.put(names + name_offs[r], (size_t)(name_offs[r + 1] - name_offs[r]));
-            if (suffix && suffix_offs) out.put(suffix + suffix_offs[j], (size_t)(suffix_offs[j + 1] - suffix_offs[j]));
-            out.put('\n');
-            out.put(seq, seq_len);
-            if (fq) {
-                out.put("\n+\n", 3);
-                out.put(quals + qual_offs[r], (size_t)(qual_offs[r + 1] - qual_offs[r]));
-            }
-            out.put('\n');
-            // the kept annotations in offset order (stable); nearly always they already are
-            bool sorted = true;
-            uint32_t last = 0;
-            for (uint64_t i = ann_lo[j]; i < ann_hi[j] && sorted; ++i)
-                if (!keep || keep[i]) { sorted = ann_offset[i] >= last; last = ann_offset[i]; }
-            auto line = [&](uint64_t i) {
-                const uint32_t off = ann_offset[i];
-                if ((size_t)off + (size_t)ksize > seq_len) { out.ok = false; return; }
-                const int32_t *row = ann_abund + i * (uint64_t)nsamples;
-                out.kmer_line(seq, off, ksize, nsamples, [&](int c) { return (int64_t)((c == 0 && case_abund) ? case_abund[i] : row[c]); });
-            };
-            if (sorted) {
-                for (uint64_t i = ann_lo[j]; i < ann_hi[j]; ++i)
-                    if (!keep || keep[i]) line(i);
-            } else {
-                order.clear();
-                for (uint64_t i = ann_lo[j]; i < ann_hi[j]; ++i)
-                    if (!keep || keep[i]) order.push_back(i);
-                std::stable_sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return ann_offset[x] < ann_offset[y]; });
-                for (const uint64_t i : order) line(i);
-            }
-            if (!out.ok) { *bad = r; return false; }
-            if (n_mates) {
-                const uint32_t *m = std::lower_bound(mate_record, mate_record + n_mates, (uint32_t)r);
-                for (; m < mate_record + n_mates && *m == (uint32_t)r; ++m) {
-                    const uint64_t mi = (uint64_t)(m - mate_record);
-                    out.put("#mateseq=", 9);
-                    out.put(mates + mate_offs[mi], (size_t)(mate_offs[mi + 1] - mate_offs[mi]));
-                    out.put("#\n", 2);
-                }
-            }
-        }
-        return out.ok;
-    };
-    // big outputs (a partition file of config 4 is 3 GB) are rendered by the host's cores side by side, a stretch of records each,
-    // and joined; KV_AUGFASTX_THREADS as for the loader
-    size_t nthreads = 1;
-    if (const char *e = getenv("KV_AUGFASTX_THREADS")) nthreads = std::min<size_t>(std::max<size_t>(1, (size_t)atoi(e)), (size_t)std::max<uint64_t>(1, n_out / 2));
-    else if (n_out >= 200000) nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), (size_t)(n_out / 100000));
-    if (nthreads <= 1) {
-        KvTextOut out;
-        uint64_t bad = 0;
-        const bool fine = render(0, n_out, out, &bad);
-        KV_REQUIRE(fine, KV_ERR_ARG, "kv_format_records: an annotation does not fit its read (record %llu), or out of memory", (unsigned long long)bad);
-        *bytes_out = out.len;
-        *text_out = out.release();
-        KV_REQUIRE(*text_out, KV_ERR_HIP, "kv_format_records: out of memory");
-        return KV_OK;
-    }
-    std::vector<KvTextOut> parts(nthreads);
-    std::vector<uint64_t> bad(nthreads, 0);
-    std::vector<char> fine(nthreads, 0);
+    KvTextOut out;
     {
-        std::vector<std::thread> crew;
-        for (size_t t = 0; t < nthreads; ++t)
-            crew.emplace_back([&, t] { fine[t] = render(n_out * t / nthreads, n_out * (t + 1) / nthreads, parts[t], &bad[t]) ? 1 : 0; });
-        for (std::thread &th : crew) th.join();
+        uint64_t notes = 0;
+        for (uint64_t j = 0; j < n_out; ++j) notes += ann_hi[j] - ann_lo[j];
+        out.room((size_t)notes * (size_t)(ksize + 48) + (size_t)n_out * 320 + 4096);
     }
-    size_t total = 0;
-    for (size_t t = 0; t < nthreads; ++t) {
-        KV_REQUIRE(fine[t], KV_ERR_ARG, "kv_format_records: an annotation does not fit its read (record %llu), or out of memory", (unsigned long long)bad[t]);
-        total += parts[t].len;
-    }
-    char *joined = (char *)malloc(total + 1);
-    KV_REQUIRE(joined, KV_ERR_HIP, "kv_format_records: out of memory");
-    {
-        std::vector<std::thread> crew;
-        size_t at = 0;
-        for (size_t t = 0; t < nthreads; ++t) {
-            crew.emplace_back([&, t, at] { memcpy(joined + at, parts[t].buf, parts[t].len); });
-            at += parts[t].len;
+    std::vector<uint64_t> order;
+    for (uint64_t j = 0; j < n_out; ++j) {
+        const uint64_t r = rec_index[j];
+        const char *seq = seqs + seq_offs[r];
+        const size_t seq_len = (size_t)(seq_offs[r + 1] - seq_offs[r]);
+        const bool fq = is_fastq ? is_fastq[r] != 0 : false;
+        out.put(fq ? '@' : '>');
+        out.put(names + name_offs[r], (size_t)(name_offs[r + 1] - name_offs[r]));
+        if (suffix && suffix_offs) out.put(suffix + suffix_offs[j], (size_t)(suffix_offs[j + 1] - suffix_offs[j]));
+        out.put('\n');
+        out.put(seq, seq_len);
+        if (fq) {
+            out.put("\n+\n", 3);
+            out.put(quals + qual_offs[r], (size_t)(qual_offs[r + 1] - qual_offs[r]));
         }
-        for (std::thread &th : crew) th.join();
+        out.put('\n');
+        // the kept annotations in offset order (stable); nearly always they already are
+        bool sorted = true;
+        uint32_t last = 0;
+        for (uint64_t i = ann_lo[j]; i < ann_hi[j] && sorted; ++i)
+            if (!keep || keep[i]) { sorted = ann_offset[i] >= last; last = ann_offset[i]; }
+        auto line = [&](uint64_t i) {
+            const uint32_t off = ann_offset[i];
+            if ((size_t)off + (size_t)ksize > seq_len) { out.ok = false; return; }
+            const int32_t *row = ann_abund + i * (uint64_t)nsamples;
+            out.kmer_line(seq, off, ksize, nsamples, [&](int c) { return (int64_t)((c == 0 && case_abund) ? case_abund[i] : row[c]); });
+        };
+        if (sorted) {
+            for (uint64_t i = ann_lo[j]; i < ann_hi[j]; ++i)
+                if (!keep || keep[i]) line(i);
+        } else {
+            order.clear();
+            for (uint64_t i = ann_lo[j]; i < ann_hi[j]; ++i)
+                if (!keep || keep[i]) order.push_back(i);
+            std::stable_sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return ann_offset[x] < ann_offset[y]; });
+            for (const uint64_t i : order) line(i);
+        }
+        KV_REQUIRE(out.ok, KV_ERR_ARG, "kv_format_records: an annotation does not fit its read (record %llu), or out of memory", (unsigned long long)r);
+        if (n_mates) {
+            const uint32_t *m = std::lower_bound(mate_record, mate_record + n_mates, (uint32_t)r);
+            for (; m < mate_record + n_mates && *m == (uint32_t)r; ++m) {
+                const uint64_t mi = (uint64_t)(m - mate_record);
+                out.put("#mateseq=", 9);
+                out.put(mates + mate_offs[mi], (size_t)(mate_offs[mi + 1] - mate_offs[mi]));
+                out.put("#\n", 2);
+            }
+        }
     }
-    joined[total] = 0;
-    *bytes_out = total;
-    *text_out = joined;
+    KV_REQUIRE(out.ok, KV_ERR_HIP, "kv_format_records: out of memory");
+    *bytes_out = out.len;
+    *text_out = out.release();
+    KV_REQUIRE(*text_out, KV_ERR_HIP, "kv_format_records: out of memory");
     return KV_OK;
 }

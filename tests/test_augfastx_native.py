@@ -190,7 +190,8 @@ def test_native_parse_in_pieces_equals_one_pass(tmp_path, fastq):
             os.environ.pop('KV_AUGFASTX_THREADS', None)
     one = loaded['1']
     assert one.n == 60000 and len(one.mate_record) == 60000 // 7 + 1
-    # the writer renders stretches of records side by side and joins them: the same bytes as one pass, in any selection and order
+    # the writer (one pass; rendering stretches side by side was measured: page faults of the second buffer ate the gain) gives the
+    # same bytes whatever the loader's thread count, for any selection and order of records
     picks = np.random.default_rng(3).permutation(one.n)[:50000]
     rendered = {}
     for threads in ('1', '2', '7'):
