@@ -348,6 +348,14 @@ KvFastqDevice *kv_fastq_device_open(const char *path)
     if (!yes && !d->plain) {
         d->gz = kv_gunzip_open(d->image, d->image_size, &d->buf->gz);
         if (!d->gz) { kv_fastq_device_close(d); return nullptr; }
+        {
+            const char *stage_env = getenv("KV_STAGE");
+            if (!(stage_env && atoi(stage_env) == 0)) {
+                KvStager *stage = &d->buf->stage;
+                const int fd_ = d->fd;
+                kv_gunzip_set_uploader(d->gz, [stage, fd_](uint8_t *dst, uint64_t off, uint64_t n, hipStream_t st) { return stage->upload(dst, fd_, off, n, st); });
+            }
+        }
     }
     return d;
 }

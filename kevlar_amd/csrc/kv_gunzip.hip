@@ -32,6 +32,7 @@
 // match) is reported as KV_ERR_TYPE and the caller's host parser (zlib) takes the file.  Reference: the reader this replaces is
 // khmer.ReadParser's gzip stream (kevlar/__init__.py:125-128 opens every *.gz through it).
 #include <algorithm>
+#include <functional>
 #include <chrono>
 #include <cstring>
 #include <mutex>
@@ -929,8 +930,15 @@ struct KvGunzip {
     const uint32_t *d_n = nullptr;
     const uint16_t *d_tails = nullptr;                            // the resolved tails of the pending segment
     uint64_t stat_jobs = 0, stat_dropped = 0, stat_repairs = 0, stat_segments = 0, stat_rounds = 0, stat_cuts = 0;
+    // optional: bytes [off, off + n) of the file to d_dst on the stream, through the caller's pinned staging buffers (false: not done)
+    std::function<bool(uint8_t *, uint64_t, uint64_t, hipStream_t)> upload;
     ~KvGunzip() { own.release(); }
 };
+
+void kv_gunzip_set_uploader(KvGunzip *g, std::function<bool(uint8_t *, uint64_t, uint64_t, hipStream_t)> upload)
+{
+    if (g) g->upload = std::move(upload);
+}
 
 KvGunzip *kv_gunzip_open(const uint8_t *image, uint64_t size, KvGunzipArenas *arenas)
 {
@@ -1017,7 +1025,9 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     const uint32_t n_chunks = (uint32_t)((n_bytes + CH - 1) / CH);
     KV_HIP(g->a->comp.need(kv_round_up((uint64_t)n_chunks * CH + 2 * GZ_SLACK, 4096)));
     uint8_t *d_comp = (uint8_t *)g->a->comp.p;
-    KV_HIP(hipMemcpyAsync(d_comp, g->image + first_byte, n_bytes, hipMemcpyHostToDevice, st));
+    // (big stretches through the caller's pinned staging buffers if it has any: kv_gunzip_set_uploader)
+    if (!(g->upload && n_bytes >= (64u << 20) && g->upload(d_comp, first_byte, n_bytes, st)))
+        KV_HIP(hipMemcpyAsync(d_comp, g->image + first_byte, n_bytes, hipMemcpyHostToDevice, st));
     KV_HIP(hipMemsetAsync(d_comp + n_bytes, 0, (uint64_t)n_chunks * CH + 2 * GZ_SLACK - n_bytes, st));
     lap("upload");
     const uint64_t b_cand = kv_round_up((uint64_t)n_chunks * GZ_FIND_KEEP * 8, 256);

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -284,6 +285,7 @@ struct KvGunzip;
 struct KvGunzipArenas;                                          // its device buffers (kv_binned.h has the definition)
 // NULL unless the image starts with a gzip member header; arenas: buffers to work in (kept by the caller across files), or NULL
 KvGunzip *kv_gunzip_open(const uint8_t *image, uint64_t size, KvGunzipArenas *arenas);
+void kv_gunzip_set_uploader(KvGunzip *g, std::function<bool(uint8_t *, uint64_t, uint64_t, hipStream_t)> upload);
 void kv_gunzip_close(KvGunzip *g);
 bool kv_gunzip_done(const KvGunzip *g);
 // decode about want_text bytes of text; *text_bytes = how many kv_gunzip_emit will store, *last = the stream ends with them.
