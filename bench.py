@@ -822,6 +822,7 @@ def end_to_end(args, wl, packed, names, synth):
             bgzf.write_file(os.path.join(tmp, name + '.bgzf.fq.gz'), text, level=4, threads=workers)   # what kevlar_amd.open(..., 'w') writes
             write_gzip(os.path.join(tmp, name + '.fq.gz'), text, level=4, threads=workers)             # what gzip / pigz write
             del text
+        os.sync()       # the 2.5 GB just written are on their way to the disk: let that finish before anything is timed
         saved, kevlar_amd.logstream = kevlar_amd.logstream, io.StringIO()
         mem = '{:d}'.format(int(wl['memory']))
 
