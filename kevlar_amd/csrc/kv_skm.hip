@@ -1871,7 +1871,7 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     {
         const char *e = getenv("KV_SKM_ABL");
         KvAbundList &al = s->abl;
-        if (!(e && atoi(e) == 0) && !al.valid) {
+        if (!(e && atoi(e) == 0) && !al.valid && !s->scan_hint) {            // (a case sample's list would never be asked for: it is scanned, not scanned against)
             const uint64_t cap_total = std::min<uint64_t>(std::max<uint64_t>(n_kmers / 8, 1u << 16), 0xfffffff0ull);
             const uint64_t cap_wg = std::max<uint64_t>(64, cap_total / nwg3);
             const size_t b_keys = kv_round_up(cap_wg * nwg3 * 8 * sg.kw, 256), b_cnts = kv_round_up(cap_wg * nwg3, 256);
