@@ -330,3 +330,60 @@ def test_blank_lines_behind_the_last_record_stay_on_the_device(hk, tmp_path, tai
     assert set(dev[3]) == {'DeviceTextBatch'} and set(host[3]) == {'TextBatch'}
     assert host[4] == dev[4] == 9000 and dev[0] == host[0]
     assert dev[1] == host[1] and dev[2] == host[2]
+
+
+@pytest.mark.parametrize('kind', ['plain', 'bgzf', 'gzip'])
+def test_uploads_through_the_pinned_staging_buffers_give_the_same_reads(hk, tmp_path, kind):
+    """stretches of 64 MB and more of a file reach the GPU through pinned staging buffers filled by pread threads (KvStager);
+    KV_STAGE=0 copies from the file's mapping as small stretches always do: same records, same count tables -- with one, three
+    and five reader threads, and with a last chunk that is not a whole one"""
+    rng = np.random.default_rng(77)
+    n, L = (330000, 100) if kind == 'plain' else (1300000, 100)          # 76 MB of text / ~70 MB compressed (four random bases a byte do not deflate)
+    codes = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    rec = np.empty((n, 1 + 9 + 1 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord('@')
+    digits = np.arange(n, dtype=np.int64)
+    for d in range(9):
+        rec[:, 9 - d] = 48 + digits % 10
+        digits //= 10
+    rec[:, 10] = 10
+    rec[:, 11:11 + L] = np.frombuffer(b'ACGT', dtype=np.uint8)[codes]
+    rec[:, 11 + L:14 + L] = np.frombuffer(b'\n+\n', dtype=np.uint8)
+    rec[:, 14 + L:14 + 2 * L] = rng.integers(33, 74, size=(n, L), dtype=np.uint8) if kind != 'plain' else ord('I')
+    rec[:, 14 + 2 * L] = 10
+    text = rec.tobytes()
+    if kind == 'plain':
+        path = str(tmp_path / 'big.fq')
+        with open(path, 'wb') as fh:
+            fh.write(text)
+        assert os.path.getsize(path) > (64 << 20)
+    else:
+        path = str(tmp_path / 'big.fq.gz')
+        if kind == 'bgzf':
+            from kevlar_amd import bgzf
+            bgzf.write_file(path, text, level=1, threads=8)
+        else:
+            with gzip.open(path, 'wb', compresslevel=1) as sink:
+                sink.write(text)
+        assert os.path.getsize(path) > (64 << 20), os.path.getsize(path)
+    del rec, text
+
+    def tables(env):
+        os.environ.update(env)
+        try:
+            parser = hk.ReadParser(path)
+            sketch = hk.Counttable(25, 4e6, 4)
+            names = []
+            for tb in parser.text_batches(8000000):
+                assert type(tb).__name__ == 'DeviceTextBatch'
+                sketch.consume_batch(tb.batch)
+                names.append(tb.record(tb.n - 1).name)
+                tb.batch.close()
+            return [sketch.table_bytes(t) for t in range(4)], names, parser.num_reads
+        finally:
+            for key in env:
+                os.environ.pop(key, None)
+    plain = tables({'KV_STAGE': '0'})
+    assert plain[2] == n
+    for threads in ('1', '3', '5'):
+        assert tables({'KV_STAGE_THREADS': threads}) == plain
