@@ -67,8 +67,9 @@ WORKLOADS = {
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=3)
-    p.add_argument('--warmup', type=int, default=1)
+    p.add_argument('--steps', type=int, default=None, help='timed steps (default: 20, or 2 for the config-4 workloads whose step takes seconds)')
+    p.add_argument('--warmup', type=int, default=None, help='untimed steps first (default: 5, or 1): the first steps of a process allocate the '
+                                                            'gigabyte arenas and load the kernels, a fresh box takes a few more to settle')
     p.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
     p.add_argument('--batch-reads', type=int, default=None, help='reads per batch (default: the workload\'s; 0 = whole samples)')
     p.add_argument('--genome-mb', type=float, default=None)
@@ -108,7 +109,13 @@ def parse_args():
                         'measured these kernel sources; none')
     p.add_argument('--launch-check', action='store_true', help='only start the ranks and let them meet (no GPU work)')
     p.add_argument('--backend', default='nccl', help='nccl (= RCCL) is what the driver runs; gloo lets two ranks share one GPU in tests')
-    return p.parse_args()
+    args = p.parse_args()
+    heavy = args.workload in ('cfg4-band', 'cfg4-proxy')
+    if args.steps is None:
+        args.steps = 2 if heavy else 20
+    if args.warmup is None:
+        args.warmup = 1 if heavy else 5
+    return args
 
 
 LIVE_PMC = None      # per-kernel HBM bytes of one step, measured by live_traffic() of this very run
@@ -843,9 +850,35 @@ def end_to_end(args, wl, packed, names, synth):
         try:
             # twice each, the better run counts: the first touches cold files, grows the device buffers and pays for lazily
             # loaded kernels
-            dt_plain = min(novel_run('.fq'), novel_run('.fq'))
-            dt_bgzf = min(novel_run('.bgzf.fq.gz'), novel_run('.bgzf.fq.gz'))
-            dt_gzip = min(novel_run('.fq.gz'), novel_run('.fq.gz'))
+            runs = {sfx: [novel_run(sfx), novel_run(sfx)] for sfx in ('.fq', '.bgzf.fq.gz', '.fq.gz')}
+            if os.environ.get('KV_E2E_PROFILE'):
+                sys.stderr.write('[e2e runs] {}\n'.format({sfx: [round(t, 3) for t in ts] for sfx, ts in runs.items()}))
+                import cProfile, pstats, threading, kevlar_amd.count as kc, kevlar_amd.khmer as kh
+                spans, lock = [], threading.Lock()
+
+                def timed(owner, name):
+                    inner = getattr(owner, name)
+
+                    def outer(*a, **k):
+                        t0 = time.perf_counter()
+                        try:
+                            return inner(*a, **k)
+                        finally:
+                            with lock:
+                                spans.append((name, round(time.perf_counter() - t0, 4), threading.current_thread().name))
+                    setattr(owner, name, outer)
+                    return inner
+                saved_fns = [(kc, 'allocate', timed(kc, 'allocate')), (kc, '_count_file', timed(kc, '_count_file')), (kc, 'estimate_fpr', timed(kc, 'estimate_fpr')),
+                             (kh.ReadParser, '__init__', timed(kh.ReadParser, '__init__')), (kh.ReadParser, 'text_batch', timed(kh.ReadParser, 'text_batch')),
+                             (kh.ReadParser, 'take_batch', timed(kh.ReadParser, 'take_batch')), (kh.Counttable, 'consume_batch', timed(kh.Counttable, 'consume_batch')),
+                             (kh.Counttable, 'n_unique_kmers', timed(kh.Counttable, 'n_unique_kmers'))]
+                prof = cProfile.Profile(); prof.enable(); t_third = novel_run('.fq'); prof.disable()
+                for owner, name, inner in saved_fns:
+                    setattr(owner, name, inner)
+                sys.stderr.write('[e2e spans] {}\n'.format(spans))
+                st = io.StringIO(); pstats.Stats(prof, stream=st).sort_stats('cumtime').print_stats(22)
+                sys.stderr.write('[e2e third plain run] {:.3f} s\n{}\n'.format(t_third, st.getvalue()[:4500]))
+            dt_plain, dt_bgzf, dt_gzip = min(runs['.fq']), min(runs['.bgzf.fq.gz']), min(runs['.fq.gz'])
             novel_out = os.path.join(tmp, 'novel.bgzf.fq.gz.augfastq')
             dt_filter = stage(['filter', '--memory', '50M', '--case-min', str(args.case_min), '--ctrl-max', str(args.ctrl_max),
                                '-o', os.path.join(tmp, 'filtered.augfastq'), novel_out])

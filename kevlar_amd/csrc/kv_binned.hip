@@ -858,7 +858,7 @@ std::mutex g_scratch_mu;
 KvArena &scratch_for(hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    return g_scratch[st];
+    return g_scratch[kv_stream_key(st)];
 }
 
 template <typename K>

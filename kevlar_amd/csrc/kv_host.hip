@@ -73,18 +73,51 @@ extern "C" int kv_synchronize(void)
     return KV_OK;
 }
 
+// The library keeps gigabytes of scratch per stream (bucketed batches, bin stages, scan arenas): whoever works on a stream finds its
+// buffers from the last time.  Keyed by the raw handle that only worked when the runtime happened to hand a new stream the handle of a
+// destroyed one -- `kevlar novel` makes three streams per run: otherwise every run allocated its gigabytes again (0.19 s, and the old
+// ones were never freed).  A stream made here therefore gets the lowest free SLOT, gives it back when it is destroyed, and the
+// per-stream tables are keyed by kv_stream_key(): the slot, as a pointer-sized tag, or the handle itself for streams made elsewhere.
+namespace {
+std::mutex g_slot_mu;
+std::map<hipStream_t, uintptr_t> g_stream_slot;
+std::vector<bool> g_slot_used(1, true);            // slot 0: the null stream
+}
+
+hipStream_t kv_stream_key(hipStream_t st)
+{
+    if (!st) return st;
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    auto it = g_stream_slot.find(st);
+    return it == g_stream_slot.end() ? st : (hipStream_t)it->second;
+}
+
 extern "C" int kv_stream_create(void **out)
 {
     KV_REQUIRE(out, KV_ERR_ARG, "kv_stream_create: null output");
     hipStream_t s = nullptr;
     KV_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    {
+        std::lock_guard<std::mutex> lk(g_slot_mu);
+        size_t slot = 1;
+        while (slot < g_slot_used.size() && g_slot_used[slot]) ++slot;
+        if (slot == g_slot_used.size()) g_slot_used.push_back(true); else g_slot_used[slot] = true;
+        g_stream_slot[s] = (uintptr_t)slot;           // (small integers are not addresses the runtime hands out)
+    }
     *out = (void *)s;
     return KV_OK;
 }
 
 extern "C" int kv_stream_destroy(void *s)
 {
-    if (s) KV_HIP(hipStreamDestroy((hipStream_t)s));
+    if (s) {
+        {
+            std::lock_guard<std::mutex> lk(g_slot_mu);
+            auto it = g_stream_slot.find((hipStream_t)s);
+            if (it != g_stream_slot.end()) { g_slot_used[(size_t)it->second] = false; g_stream_slot.erase(it); }
+        }
+        KV_HIP(hipStreamDestroy((hipStream_t)s));
+    }
     return KV_OK;
 }
 
@@ -303,6 +336,55 @@ extern "C" int kv_primes_below(double target, int n, uint64_t *out, int *found)
 // ---------------------------------------------------------------------------------------
 // sketch handles
 // ---------------------------------------------------------------------------------------
+// Table buffers of destroyed sketches are kept for the next sketch of the same geometry (up to KV_TABLE_CACHE_GB, default 32): on
+// some boxes -- not on others, same image -- hipMalloc of a 2 GB sketch took 0.18 s inside a process that holds tens of gigabytes
+// (`kevlar novel` after the bench's main loop: every run 0.26 s instead of 0.075), and it stalls every other thread's HIP call meanwhile.
+namespace {
+std::mutex g_tabcache_mu;
+std::multimap<uint64_t, uint8_t *> g_tabcache;
+uint64_t g_tabcache_bytes = 0;
+uint64_t tabcache_cap()
+{
+    const char *e = getenv("KV_TABLE_CACHE_GB");
+    return (uint64_t)(e ? atof(e) : 32.0) << 30;
+}
+hipError_t table_alloc(uint8_t **p, uint64_t bytes)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_tabcache_mu);
+        auto it = g_tabcache.find(bytes);
+        if (it != g_tabcache.end()) {
+            *p = it->second;
+            g_tabcache.erase(it);
+            g_tabcache_bytes -= bytes;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc((void **)p, bytes);
+    if (e != hipSuccess) {                           // out of memory: give the cache back and try once more
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(g_tabcache_mu);
+        for (auto &kv : g_tabcache) (void)hipFree(kv.second);
+        g_tabcache.clear();
+        g_tabcache_bytes = 0;
+        e = hipMalloc((void **)p, bytes);
+    }
+    return e;
+}
+void table_free(uint8_t *p, uint64_t bytes)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_tabcache_mu);
+        if (bytes >= (16u << 20) && g_tabcache_bytes + bytes <= tabcache_cap()) {
+            g_tabcache.emplace(bytes, p);
+            g_tabcache_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+}  // namespace
+
 int kv_sketch_alloc(int kind, int ksize, int ntables, const uint64_t *sizes, kv_sketch **out)
 {
     KV_REQUIRE(out && sizes, KV_ERR_ARG, "kv_sketch_create: null argument");
@@ -335,7 +417,7 @@ int kv_sketch_alloc(int kind, int ksize, int ntables, const uint64_t *sizes, kv_
     }
     hipError_t e = hipSuccess;
     for (int i = 0; i < ntables && e == hipSuccess; ++i) {
-        e = hipMalloc((void **)&s->h.tab[i], s->alloc_bytes[i]);
+        e = table_alloc(&s->h.tab[i], s->alloc_bytes[i]);
         if (e == hipSuccess) e = hipMemsetAsync(s->h.tab[i], 0, s->alloc_bytes[i], kv_stream());
     }
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_desc, sizeof(SketchDev));
@@ -359,8 +441,9 @@ extern "C" int kv_sketch_create(int kind, int ksize, int ntables, const uint64_t
 extern "C" int kv_sketch_destroy(kv_sketch *s)
 {
     if (!s) return KV_OK;
+    (void)hipDeviceSynchronize();                   // (what hipFree did implicitly: nobody is still working on these tables)
     for (int i = 0; i < KV_MAX_TABLES; ++i)
-        if (s->h.tab[i]) (void)hipFree(s->h.tab[i]);
+        if (s->h.tab[i]) table_free(s->h.tab[i], s->alloc_bytes[i]);
     if (s->d_desc) (void)hipFree(s->d_desc);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->abl.mem) (void)hipFree(s->abl.mem);

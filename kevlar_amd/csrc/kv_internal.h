@@ -243,6 +243,8 @@ void kv_set_error(const char *fmt, ...);
     } while (0)
 
 hipStream_t kv_stream();
+// the key the per-stream scratch tables go by (kv_host.hip): a recycled slot for streams made by kv_stream_create, else the handle
+hipStream_t kv_stream_key(hipStream_t st);
 void kv_ensure_dynamic_lds(const void *kernel, size_t bytes);   // hipFuncSetAttribute once per growth
 
 // profiling: RAII wrapper recording HIP events around a launch when enabled

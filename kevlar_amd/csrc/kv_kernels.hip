@@ -295,7 +295,7 @@ std::mutex g_point_scratch_mu;
 PointScratch &point_scratch()
 {
     std::lock_guard<std::mutex> lk(g_point_scratch_mu);
-    return g_point_scratch[kv_stream()];
+    return g_point_scratch[kv_stream_key(kv_stream())];
 }
 inline size_t pad256(size_t v) { return (v + 255) & ~(size_t)255; }
 }  // namespace

@@ -422,7 +422,7 @@ int attach_vcache(NovelParams &p, kv_sketch *const *ctrls, int ncase, int nctrl,
         VerdictCache *vc;
         {
             std::lock_guard<std::mutex> lk(g_vcache_mu);
-            vc = &g_vcache[st];
+            vc = &g_vcache[kv_stream_key(st)];
         }
         int want = 20;
         while (want < 28 && (1ull << want) < n_kmers / 2) ++want;   // ~2 slots per distinct inherited k-mer at 30x
@@ -519,7 +519,7 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
     ScanArenas *arenas;
     {
         std::lock_guard<std::mutex> lk(g_scan_arenas_mu);
-        arenas = &g_scan_arenas[st];
+        arenas = &g_scan_arenas[kv_stream_key(st)];
     }
     std::lock_guard<std::mutex> arena_lock(arenas->mu);
     hipError_t e = hipSuccess;
@@ -900,7 +900,7 @@ extern "C" int kv_novel_scan_set(const kv_reads *reads, int kind, int ksize, int
     ScanArenas *arenas;
     {
         std::lock_guard<std::mutex> lk(g_scan_arenas_mu);
-        arenas = &g_scan_arenas[st];
+        arenas = &g_scan_arenas[kv_stream_key(st)];
     }
     uint64_t slots = 1024;
     while (slots < 2 * n + 64) slots <<= 1;

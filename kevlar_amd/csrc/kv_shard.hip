@@ -223,7 +223,7 @@ int route_scratch(RouteParams &p, uint64_t n_kmers, uint32_t W, hipStream_t st)
     Scratch *scratch;
     {
         std::lock_guard<std::mutex> lk(g_route_mu);
-        scratch = &g_route_scratch[st];
+        scratch = &g_route_scratch[kv_stream_key(st)];
     }
     KV_HIP(scratch->need(b_seg + b_cnt + b_off + b_ovf + b_od + b_ctr));
     unsigned char *base = (unsigned char *)scratch->p;

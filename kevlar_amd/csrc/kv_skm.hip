@@ -1552,7 +1552,7 @@ double g_skm_last_distinct = 0.0;        // distinct share of the batch counted 
 SkmIndex &skm_index_for(hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(g_skm_mu);
-    return g_skm[st];
+    return g_skm[kv_stream_key(st)];
 }
 
 inline uint32_t skm_nwg3(const SkmGeom &g)
@@ -1997,7 +1997,7 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
         std::lock_guard<std::mutex> lk(g_skm_mu);
         for (auto &kv : g_skm)
             if (kv.second.valid && kv.second.reads_uid == reads->uid && kv.second.k == k) { idx = &kv.second; break; }
-        if (!idx) idx = &g_skm[st];
+        if (!idx) idx = &g_skm[kv_stream_key(st)];
     }
     std::lock_guard<std::mutex> lk(idx->mu);
     const bool reuse = idx->valid && idx->reads_uid == reads->uid && idx->k == k && !getenv("KV_SKM_NO_REUSE");
