@@ -1355,7 +1355,11 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
 template <int KW, int TSM>
 __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, ReadsDev rd, NovelParams p, SkmAblSet abls)
 {
-    constexpr uint32_t E = 4;                    // entries a thread has in flight
+#if defined(SKM_LIST_E)
+    constexpr uint32_t E = SKM_LIST_E;
+#else
+    constexpr uint32_t E = 4;                    // entries a thread has in flight (2 / 4 / 6 measured: 2.64 / 2.6-2.8 / 2.52 ms, within the spread between runs)
+#endif
     __shared__ SkmTable<KW, TSM> rtb;            // rejected by a control's list
     __shared__ SkmTable<KW, TSM> itb;            // interesting
     __shared__ NovelShared ns;
