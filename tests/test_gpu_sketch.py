@@ -341,3 +341,35 @@ def test_clear_is_lazy_but_invisible(hk, kind, path, tmp_path):
             assert used.n_occupied() == fresh.n_occupied()
     finally:
         os.environ.pop('KV_COUNT_PATH', None)
+
+
+def test_table_buffers_of_a_destroyed_sketch_serve_the_next_one_zeroed(hk):
+    """kv_sketch_destroy keeps table buffers for the next sketch of the same geometry (a 2 GB hipMalloc can take 0.2 s and stalls
+    every other thread's HIP call): the new sketch starts empty all the same, and KV_TABLE_CACHE_GB=0 gives the buffers back"""
+    import ctypes
+    import gc
+    from kevlar_amd import _lib
+    lib = _lib.load()
+
+    def pointers(sketch):
+        out = []
+        for t in range(4):
+            p, n = ctypes.c_void_p(), ctypes.c_uint64()
+            _lib.check(lib.kv_sketch_table_devptr(sketch._h, t, ctypes.byref(p), ctypes.byref(n)))
+            out.append(p.value)
+        return out
+    first = hk.Counttable(21, 3e7, 4)                 # 30 MB tables: above the 16 MB floor of the cache
+    first.add('ACGTACGTACGTACGTACGTA')
+    assert first.get('ACGTACGTACGTACGTACGTA') == 1
+    held = pointers(first)
+    del first
+    gc.collect()
+    second = hk.Counttable(21, 3e7, 4)
+    assert sorted(pointers(second)) == sorted(held)
+    assert second.get('ACGTACGTACGTACGTACGTA') == 0 and second.n_occupied() == 0
+    os.environ['KV_TABLE_CACHE_GB'] = '0'
+    try:
+        del second
+        gc.collect()
+    finally:
+        os.environ.pop('KV_TABLE_CACHE_GB')
