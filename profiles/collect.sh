@@ -14,8 +14,8 @@ cd /tmp && export TMPDIR=/tmp
 # the default bench counts the three samples concurrently on three streams; the trace and the counter passes run them
 # back to back (--count-streams 1) so that a kernel's duration and counters are its own
 BENCH_ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 --traffic none"
-timeout 900 python3 $REPO/bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
-timeout 600 python3 $REPO/bench.py --steps 10 --warmup 3 --count-streams 1 --no-cpu-baseline --no-e2e --no-replay --traffic none > $OUT/bench_one_stream.json 2> $OUT/bench_one_stream.err
+timeout 900 python3 $REPO/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err          # the driver's command
+timeout 600 python3 $REPO/bench.py --steps 20 --warmup 5 --count-streams 1 --no-cpu-baseline --no-e2e --no-replay --traffic none > $OUT/bench_one_stream.json 2> $OUT/bench_one_stream.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $BENCH_ARGS > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-replay --traffic none > $OUT/bench_under_rocprof_default.json 2> $OUT/trace_default.err
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 --traffic none > /dev/null 2> $OUT/pmc_fetch.err
