@@ -56,6 +56,10 @@ struct SkmGeom {
 };
 
 // segment `seg` of coarse bucket c in seg1 / cnt1, counted in segments
+// Phase switches of the dissection scripts (scratch/skm_phases.py, scan_phases.py) and KV_SKM_FORCE_LOOSE of the tests.  The three
+// long kernels exist twice: the instance that looks at the switches is launched only when one is set (the tests in the occurrence loop
+// of k_skm_count cost 0.07 ms per sample, 0.4 ms per step of config 2).
+#define SKM_DBG(sg) (KNOBS ? (sg).dbg : 0u)
 __device__ __forceinline__ uint64_t skm_seg1_slot(const SkmGeom &sg, uint32_t c, uint32_t seg)
 {
     if (sg.n_src <= 1u) return (uint64_t)c * sg.nwg1 + seg;
@@ -152,6 +156,7 @@ __device__ __forceinline__ uint32_t skm_search(const uint32_t *pre, uint32_t n, 
 template <int CH>
 __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint32_t n_tiles, SkmGeom sg)   // 6 waves per SIMD: three workgroups per CU
 {
+    constexpr bool KNOBS = true;
     __shared__ SkmTile sh;
     __shared__ uint32_t cur[256];
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
         const uint32_t NB = sh.bpre[nr];
         // P1: one thread per packed word: the order values of the m-mers starting at its 16 bases
         const uint32_t mmask = m == 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
-        for (uint32_t wi = threadIdx.x; wi < ((sg.dbg & 512u) ? 0u : nwords); wi += SKM_THREADS1) {
+        for (uint32_t wi = threadIdx.x; wi < ((SKM_DBG(sg) & 512u) ? 0u : nwords); wi += SKM_THREADS1) {
             const uint32_t r = sh.uni_wpr ? skm_div(wi, sh.uni_wpr, sh.inv_wpr) : skm_search(sh.wpre, nr, wi);
             const uint32_t j0 = (wi - sh.wpre[r]) * 16u, L = sh.len[r];
             const uint32_t q0 = sh.bpre[r] + j0;
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
         // w - 1 - CH values every window contains + a growing prefix) and where it changes.  A run is a stretch of k-mers with the
         // same minimizer VALUE (its bucket is a function of that value, taken once per run in P4; two values that share a bucket
         // -- one pair in C1 x F2 -- merely give two records where one would have done).
-        const uint32_t nchunks = (sg.dbg & 32u) ? 0u : sh.cpre[nr];             // <= 8192 / CH + 64 < 3 * SKM_THREADS1
+        const uint32_t nchunks = (SKM_DBG(sg) & 32u) ? 0u : sh.cpre[nr];             // <= 8192 / CH + 64 < 3 * SKM_THREADS1
         const uint32_t nrounds = (nchunks + SKM_THREADS1 - 1u) / SKM_THREADS1;
         uint32_t my_q[3], my_starts[3];
 #pragma unroll
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
                 }
             }
         }
-        if (sg.dbg & 16u) nstart = 0;
+        if (SKM_DBG(sg) & 16u) nstart = 0;
         __syncthreads();
         // P4: one thread per run: measure it, cut it into records of <= ncap k-mers, store them
         for (uint32_t i = threadIdx.x; i < nstart; i += SKM_THREADS1) {
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
                 for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? skm_bases32(wl, b + 32u * t) : 0ull;
                 const uint64_t hdr = skm_header(pos, n, fine);
                 const uint32_t p = atomicAdd(&cur[coarse], 1u);
-                if (sg.dbg & 1024u) n_rec += hdr ^ bw[0] ^ bw[1];
+                if (SKM_DBG(sg) & 1024u) n_rec += hdr ^ bw[0] ^ bw[1];
                 else if (p < sg.cap1) skm_store_record(sg.seg1 + (((uint64_t)coarse * sg.nwg1 + blockIdx.x) * sg.cap1 + p) * (uint64_t)sg.recw, hdr, bw, sg.nbw);
                 else skm_loose_push(sg, hdr, bw);
                 n_rec += 1;
@@ -414,7 +419,7 @@ __host__ __device__ inline uint32_t skm_wave_slice_words(uint32_t R, uint32_t L,
     return 132u + pmax + pmax / (uint32_t)ch + 2u + SKM_WAVE_RUNS + (SKM_WAVE_RUNS + 2u) / 2u;      // words (twice), order values, minimizer + start of SKM_WAVE_RUNS runs at a time
 }
 
-template <int CH>
+template <int CH, bool KNOBS>
 __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, SkmGeom sg, uint32_t R, uint32_t n_mt, uint32_t quota_mt, uint32_t per_ticket)
 {
     constexpr uint32_t PS = CH == 16 ? 4u : 3u;
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, 
         if (more) { pf = words_of(mt + 1u); pf_mt = mt + 1u; }
         // P1: the order values of the m-mers starting at the 16 bases of this lane's word.  (Values of m-mers that run past the
         // end of their read are garbage: no window of a k-mer of the read contains them.)
-        if (lane < nwords && !(sg.dbg & 512u)) {
+        if (lane < nwords && !(SKM_DBG(sg) & 512u)) {
             const uint32_t up = (uint32_t)__shfl_down((int)word, 1);
             const uint64_t win = (uint64_t)word | ((uint64_t)(lane == 63u ? 0u : up) << 32);
             const uint64_t rcw = ~skm_rev2_64(win);
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, 
         __builtin_amdgcn_wave_barrier();
         // P2: a lane per chunk of CH k-mer starts: window minima (shared suffix of the chunk + the values every window of the chunk
         // contains + a growing prefix) and where they change; then every run start with its minimizer, in position order
-        const uint32_t nchunks = (sg.dbg & 32u) ? 0u : nr * cpr;
+        const uint32_t nchunks = (SKM_DBG(sg) & 32u) ? 0u : nr * cpr;
         uint32_t startmask = 0, q = 0;
         uint32_t v[CH];
 #pragma unroll
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, 
             if (lane >= (uint32_t)d) incl += upv;
         }
         uint32_t nstart = (uint32_t)__shfl((int)incl, 63);
-        if (sg.dbg & 16u) nstart = 0;
+        if (SKM_DBG(sg) & 16u) nstart = 0;
         if (more) wl0[66u * (parity ^ 1u) + lane] = pf;
         for (uint32_t lo = 0; lo < nstart; lo += SKM_WAVE_RUNS) {
             // runs lo .. lo + SKM_WAVE_RUNS (one more than are processed: the end of the last one), listed by the lanes that found them
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, 
                     for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? skm_bases32(wl, b + 32u * t) : 0ull;
                     const uint64_t hdr = skm_header(pos, n, fine);
                     const uint32_t p = atomicAdd(&cur[coarse], 1u);
-                    if (sg.dbg & 1024u) n_rec += hdr ^ bw[0] ^ bw[1];
+                    if (SKM_DBG(sg) & 1024u) n_rec += hdr ^ bw[0] ^ bw[1];
                     else if (p < sg.cap1) skm_store_record_wide(my_seg + coarse * cstride + p * (uint32_t)sg.recw, hdr, bw, sg.nbw);
                     else skm_loose_push(sg, hdr, bw);
                     n_rec += 1;
@@ -965,7 +970,7 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
 // scratch: record-start bits of the walk, reused as the queue of occupied slots
 __host__ __device__ inline uint32_t skm_wave_scratch_words(uint32_t sbw) { return sbw > 64u ? sbw : 64u; }
 
-template <int KW, int TS>
+template <int KW, int TS, bool KNOBS>
 __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
                                                            const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
@@ -1033,13 +1038,13 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
             }
         }
         // combine the occurrences of the bucket
-        if (!(sg.dbg & 2u)) skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
-            if (sg.dbg & 128u) { n_added += c.w[0] & 1; return false; }
+        if (!(SKM_DBG(sg) & 2u)) skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
+            if (SKM_DBG(sg) & 128u) { n_added += c.w[0] & 1; return false; }
             // (KV_SKM_FORCE_LOOSE: one key in 64 is treated like a key that found its table full -- every occurrence travels alone;
             // results stay exact, tests use it to put single k-mers on the loose list of a batch that otherwise fits)
-            const bool forced = (sg.dbg & 4096u) && ((c.w[0] * 0x9e3779b97f4a7c15ull) >> 58) == 0;
+            const bool forced = (SKM_DBG(sg) & 4096u) && ((c.w[0] * 0x9e3779b97f4a7c15ull) >> 58) == 0;
             const int slot = skm_cacheable<KW>(c) && !forced ? skm_table_insert(tb, c) : -1;
-            if (slot >= 0 && !(sg.dbg & 256u)) atomicAdd(&cnt[slot], 1u);
+            if (slot >= 0 && !(SKM_DBG(sg) & 256u)) atomicAdd(&cnt[slot], 1u);
             return slot < 0;         // table region full (or unstorable key): this occurrence travels alone
         });
         __syncthreads();
@@ -1052,9 +1057,9 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
             const uint32_t seen = cnt[slot];
             cnt[slot] = 0;
             n_distinct += 1;
-            if (sg.dbg & 1u) return;
+            if (SKM_DBG(sg) & 1u) return;
             const uint64_t h = skm_key_hash<KW>(c, lut, f.hp);
-            if (sg.dbg & 64u) { n_added += h & 1; return; }
+            if (SKM_DBG(sg) & 64u) { n_added += h & 1; return; }
             // distinct list: key and hash of every k-mer in here (the scan of this batch then neither combines nor hashes again)
             if (sg.dl_keys) {
                 const unsigned long long here = __ballot(true);
@@ -1278,6 +1283,7 @@ __device__ __forceinline__ void skm_mark(const NovelParams &p, const ReadsDev &r
 template <int KW, int TS>
 __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, ReadsDev rd, NovelParams p, SkmAblSet abls)
 {
+    constexpr bool KNOBS = true;
     __shared__ SkmTable<KW, TS> tb;
     __shared__ uint32_t flag[TS / 32];           // bit per slot: the key is interesting
     __shared__ uint32_t rej[TS / 32];            // bit per slot: a control's abundance list rejects the key (no probe needed)
@@ -1323,7 +1329,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
         }
         __syncthreads();
         // evaluate each of them once
-        if (!(sg.dbg & 4u)) skm_for_occupied<TS>(tb.key[0], (uint16_t *)scratch, skm_wave_scratch_words(sg.sbw) * 2u, [&](uint32_t slot) {
+        if (!(SKM_DBG(sg) & 4u)) skm_for_occupied<TS>(tb.key[0], (uint16_t *)scratch, skm_wave_scratch_words(sg.sbw) * 2u, [&](uint32_t slot) {
             SkmKey<KW> c;
             c.w[0] = tb.key[0][slot];
             if (KW == 2) c.w[KW - 1] = tb.key[KW - 1][slot];
@@ -1331,7 +1337,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
             if (band_pass(p, h) && novel_test_fast(ns, p, h, nullptr, 0ull)) { atomicOr(&flag[slot >> 5], 1u << (slot & 31)); any_hit = 1; }
         }, rej);            // (keys a control's list rejects are not queued: 25 M of 106 M at config 2, lanes that used to sit out their wave's hashes)
         __syncthreads();
-        if (any_hit == 0 || (sg.dbg & 8u)) continue;
+        if (any_hit == 0 || (SKM_DBG(sg) & 8u)) continue;
         // mark every occurrence of an interesting k-mer (an occurrence whose key is absent went to the loose list)
         skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t pos) {
             if (!skm_cacheable<KW>(c)) return false;
@@ -1352,7 +1358,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
 // the loose list already (k_skm_loose_novel evaluates them one by one).  A bucket's list has at most as many entries as the count
 // kernel's LDS table has slots.
 #define SKM_LIST_MAX 4096u
-template <int KW, int TSM>
+template <int KW, int TSM, bool KNOBS>
 __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, ReadsDev rd, NovelParams p, SkmAblSet abls)
 {
 #if defined(SKM_LIST_E)
@@ -1418,7 +1424,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, 
             }
         }
         __syncthreads();
-        for (uint32_t base = 0; base < ((sg.dbg & 4u) ? 0u : en); base += E * SKM_THREADS3) {
+        for (uint32_t base = 0; base < ((SKM_DBG(sg) & 4u) ? 0u : en); base += E * SKM_THREADS3) {
             if (base) request(base);
             bool live[E];
             uint32_t v[E];
@@ -1452,7 +1458,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, 
             // marks in instalments
             if (n_int > TSM / 4 && j0 + SKM_THREADS3 < nc) mark_pass(b);
         }
-        if (n_int != 0 && !(sg.dbg & 8u)) mark_pass(b);
+        if (n_int != 0 && !(SKM_DBG(sg) & 8u)) mark_pass(b);
     }
 }
 
@@ -1607,13 +1613,10 @@ void skm_launch_emit(const SkmGeom &g, const kv_reads *reads, hipStream_t st)
         const uint32_t per_ticket = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(SKM_MT_PER_TICKET, n_mt / (2 * waves)));
         const uint64_t per_wave = (uint64_t)g.quota1 * reads->uni_per_tile / R / (SKM_THREADS1 / 64) + per_ticket;
         const uint32_t quota_mt = (uint32_t)std::min<uint64_t>(kv_round_up(per_wave, per_ticket), 0xfffffff0ull);
-        if (ch == 16) {
-            kv_ensure_dynamic_lds((const void *)k_skm_emit_wave<16>, lds);
-            hipLaunchKernelGGL(k_skm_emit_wave<16>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), g, R, (uint32_t)n_mt, quota_mt, per_ticket);
-        } else {
-            kv_ensure_dynamic_lds((const void *)k_skm_emit_wave<8>, lds);
-            hipLaunchKernelGGL(k_skm_emit_wave<8>, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), g, R, (uint32_t)n_mt, quota_mt, per_ticket);
-        }
+        void (*kernel)(ReadsDev, SkmGeom, uint32_t, uint32_t, uint32_t, uint32_t) =
+            ch == 16 ? (g.dbg ? k_skm_emit_wave<16, true> : k_skm_emit_wave<16, false>) : (g.dbg ? k_skm_emit_wave<8, true> : k_skm_emit_wave<8, false>);
+        kv_ensure_dynamic_lds((const void *)kernel, lds);
+        hipLaunchKernelGGL(kernel, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), g, R, (uint32_t)n_mt, quota_mt, per_ticket);
         return;
     }
     const size_t lds = ((size_t)g.np_max / 16 + KV_TILE_MAX_READS + 8 + (size_t)g.np_max + 96) * 4 + (((size_t)g.np_max + 96 + 1) & ~(size_t)1) * 2;
@@ -1933,8 +1936,9 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
         KvProfScope prof("k_skm_count");
         const uint32_t ns = (uint32_t)(plan.g.T * plan.g.C);
         const size_t lds = (256 + ((ns + 3u) & ~3u) + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw)) * 4;
-        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_count<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
-        else hipLaunchKernelGGL((k_skm_count<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
+        void (*kernel)(SkmGeom, const SketchDev *, const SketchDev *, ConsumeFilter, BinGeom) =
+            sg.kw == 1 ? (sg.dbg ? k_skm_count<1, 4096, true> : k_skm_count<1, 4096, false>) : (sg.dbg ? k_skm_count<2, 2048, true> : k_skm_count<2, 2048, false>);
+        hipLaunchKernelGGL(kernel, dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
     }
     {
         KvProfScope prof("k_skm_loose_count");
@@ -2044,8 +2048,9 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
         KvProfScope prof("k_skm_novel_list");
         sg.dl_keys = idx->dl_keys; sg.dl_hash = idx->dl_hash; sg.dl_bstart = idx->dl_bstart; sg.dl_bcount = idx->dl_bcount; sg.dl_cap_wg = idx->dl_cap_wg;
         const size_t lds = (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw) * 4;
-        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_novel_list<1, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
-        else hipLaunchKernelGGL((k_skm_novel_list<2, 1024>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
+        void (*kernel)(SkmGeom, ReadsDev, NovelParams, SkmAblSet) =
+            sg.kw == 1 ? (sg.dbg ? k_skm_novel_list<1, 2048, true> : k_skm_novel_list<1, 2048, false>) : (sg.dbg ? k_skm_novel_list<2, 1024, true> : k_skm_novel_list<2, 1024, false>);
+        hipLaunchKernelGGL(kernel, dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
         if (p.ab_keys) hipLaunchKernelGGL(k_ab_fill, dim3(2048), dim3(256), 0, st, p);
         sg.dl_keys = nullptr; sg.dl_hash = nullptr; sg.dl_bstart = nullptr; sg.dl_bcount = nullptr;
     } else {
