@@ -344,7 +344,7 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
     return v;
 }
 
-inline HashParams make_hash_params(int k, int hashfam)
+__host__ __device__ inline HashParams make_hash_params(int k, int hashfam)
 {
     HashParams hp;
     hp.k = k;

@@ -868,13 +868,13 @@ __device__ __forceinline__ SkmKey<KW> skm_kmer_at(uint64_t b0, uint64_t b1, uint
 
 // body(canonical k-mer, forward k-mer, position of the occurrence) -> true if the occurrence could not be combined and
 // must travel alone through the loose list; WANT_POS = false skips fetching the header (count pass)
-template <int KW, bool WANT_POS, typename Body>
+template <int KW, bool WANT_POS, int FK = 0, typename Body>
 __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, uint32_t *sbits_all, Body body)
 {
     constexpr uint32_t G = SKM_UNIT;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     uint32_t *sbits = sbits_all + wave * sg.sbw;       // sbw words: 64 records x ncap k-mers (units need fewer), + the word a 64-bit read may straddle into
-    const int k = sg.k, recw = sg.recw;
+    const int k = FK ? FK : sg.k, recw = FK ? 1 + KW + 1 : sg.recw;        // FK: k (and with it the record width) known when compiled
     // Which records a wave takes does not depend on how full the bucket's segments are: pair p = wave, wave + nwaves, ...
     // is records [64 g, 64 g + 64) of segment s = p mod nwg2, g = p / nwg2.  The records are therefore requested together
     // with the segment counts (which only mask them afterwards) instead of behind them, and the same addresses of the
@@ -970,7 +970,9 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
 // scratch: record-start bits of the walk, reused as the queue of occupied slots
 __host__ __device__ inline uint32_t skm_wave_scratch_words(uint32_t sbw) { return sbw > 64u ? sbw : 64u; }
 
-template <int KW, int TS, bool KNOBS>
+// FK: the instance for the k everybody runs (kevlar's default, 31; the host checks k and the record width): shifts, masks and the
+// murmur tail become constants -- 3 % of the kernel.  FK = 0 reads k from the geometry.
+template <int KW, int TS, bool KNOBS, int FK>
 __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
                                                            const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
@@ -984,7 +986,8 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
     uint32_t *lut = dyn, *cur = dyn + 256, *scratch = cur + ((ns + 3u) & ~3u);
     for (uint32_t s = threadIdx.x; s < ns; s += SKM_THREADS3) cur[s] = 0;
     if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
-    const int k = sg.k;
+    const int k = FK ? FK : sg.k;
+    const HashParams hp = FK ? make_hash_params(FK, f.hp.hashfam) : f.hp;
     uint64_t n_added = 0, n_distinct = 0;
     const uint32_t cap1 = (uint32_t)g.cap1;
     uint32_t *my_seg = g.gbuf1 + (uint64_t)blockIdx.x * g.cap1;          // + stream * seg_stride: this workgroup's segment of a stream
@@ -1038,7 +1041,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
             }
         }
         // combine the occurrences of the bucket
-        if (!(SKM_DBG(sg) & 2u)) skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
+        if (!(SKM_DBG(sg) & 2u)) skm_walk_bucket<KW, false, FK>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
             if (SKM_DBG(sg) & 128u) { n_added += c.w[0] & 1; return false; }
             // (KV_SKM_FORCE_LOOSE: one key in 64 is treated like a key that found its table full -- every occurrence travels alone;
             // results stay exact, tests use it to put single k-mers on the loose list of a batch that otherwise fits)
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const
             cnt[slot] = 0;
             n_distinct += 1;
             if (SKM_DBG(sg) & 1u) return;
-            const uint64_t h = skm_key_hash<KW>(c, lut, f.hp);
+            const uint64_t h = skm_key_hash<KW>(c, lut, hp);
             if (SKM_DBG(sg) & 64u) { n_added += h & 1; return; }
             // distinct list: key and hash of every k-mer in here (the scan of this batch then neither combines nor hashes again)
             if (sg.dl_keys) {
@@ -1937,7 +1940,8 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
         const uint32_t ns = (uint32_t)(plan.g.T * plan.g.C);
         const size_t lds = (256 + ((ns + 3u) & ~3u) + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw)) * 4;
         void (*kernel)(SkmGeom, const SketchDev *, const SketchDev *, ConsumeFilter, BinGeom) =
-            sg.kw == 1 ? (sg.dbg ? k_skm_count<1, 4096, true> : k_skm_count<1, 4096, false>) : (sg.dbg ? k_skm_count<2, 2048, true> : k_skm_count<2, 2048, false>);
+            sg.kw == 1 ? (sg.dbg ? k_skm_count<1, 4096, true, 0> : k_skm_count<1, 4096, false, 0>) : (sg.dbg ? k_skm_count<2, 2048, true, 0> : k_skm_count<2, 2048, false, 0>);
+        if (sg.k == 31 && sg.recw == 3 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31>;
         hipLaunchKernelGGL(kernel, dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
     }
     {

@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ('KV_COUNT_PATH', 'KV_NOVEL_PATH', 'KV_SKM_BUCKET_KMERS', 'KV_SKM_CAP_PCT', 'KV_SKM_LOOSE_CAP', 'KV_SKM_NO_REUSE', 'KV_SKM_FORCE_LOOSE', 'KV_SKM_DL')
+KNOBS = ('KV_COUNT_PATH', 'KV_NOVEL_PATH', 'KV_SKM_BUCKET_KMERS', 'KV_SKM_CAP_PCT', 'KV_SKM_LOOSE_CAP', 'KV_SKM_NO_REUSE', 'KV_SKM_FORCE_LOOSE', 'KV_SKM_DL', 'KV_SKM_ANY_K')
 
 
 def launches(name):
@@ -352,3 +352,28 @@ def test_default_paths_on_a_large_batch_agree_with_the_other_implementations(hk,
         res[path] = (r.tolist(), o.tolist(), a.tolist())
     assert res[None] == res['tiles'] and len(res[None][0]) > 100
     assert launches('k_skm_novel') == 1 and launches('k_novel_mark') == 1
+
+
+def test_count_instance_compiled_for_k31_equals_the_one_that_reads_k(hk, skm):
+    """k = 31 has its own instance of the count kernel (k, masks and the murmur tail are constants there); KV_SKM_ANY_K keeps
+    the instance that reads k from the geometry: same tables, same occupancy, and the same hits from a scan behind either"""
+    reads = trio_reads(300000, 40000, 77)
+    batches = {n: hk.ReadBatch(reads[n]) for n in reads}
+    sk = {}
+    for generic in (False, True):
+        if generic:
+            os.environ['KV_SKM_ANY_K'] = '1'
+        sk[generic] = {n: hk.Counttable(31, 1.5e7 / 4, 4) for n in ('mother', 'father', 'proband')}
+        for n in ('mother', 'father', 'proband'):
+            if n == 'proband':
+                sk[generic][n].expect_scan(True)
+            assert sk[generic][n].consume_batch(batches[n]) == 40000 * 70
+    for n in reads:
+        for t in range(4):
+            assert sk[False][n].table_bytes(t) == sk[True][n].table_bytes(t)
+        assert sk[False][n].n_occupied() == sk[True][n].n_occupied()
+    res = {}
+    for generic in (False, True):
+        r, o, a, _ = hk.novel_scan([sk[generic]['proband']], [sk[generic]['mother'], sk[generic]['father']], batches['proband'], 6, 1)
+        res[generic] = (r.tolist(), o.tolist(), a.tolist())
+    assert res[False] == res[True] and len(res[False][0]) > 50
