@@ -20,15 +20,15 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-replay --traffic none > $OUT/bench_under_rocprof_default.json 2> $OUT/trace_default.err
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 --traffic none > /dev/null 2> $OUT/pmc_fetch.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 --traffic none > /dev/null 2> $OUT/pmc_write.err
-# ingest: one ordinary gzip stream / one BGZF file of 2 M reads through the device inflaters
-(cd $REPO && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_gunzip -- python3 scratch/gunzip_rate.py 2000000 6 > $OUT/gunzip_rate.log 2> $OUT/trace_gunzip.err)
-(cd $REPO && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bgzf -- python3 scratch/inflate_rate.py 2000000 > $OUT/inflate_rate.log 2> $OUT/trace_bgzf.err)
+# ingest: one ordinary gzip stream / one BGZF file of 2 M reads through the device inflaters   (COLLECT_SKIP="ingest cfg5" leaves parts out)
+[[ " ${COLLECT_SKIP:-} " == *" ingest "* ]] || (cd $REPO && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_gunzip -- python3 scratch/gunzip_rate.py 2000000 6 > $OUT/gunzip_rate.log 2> $OUT/trace_gunzip.err)
+[[ " ${COLLECT_SKIP:-} " == *" ingest "* ]] || (cd $REPO && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bgzf -- python3 scratch/inflate_rate.py 2000000 > $OUT/inflate_rate.log 2> $OUT/trace_bgzf.err)
 # SQ counters of the count / scan kernels at their current shape (two --pmc passes of eight counters over one count of
 # each sample + one scan)
 (cd $REPO && bash scratch/pmc_skm.sh > $OUT/pmc_skm.log 2>&1)
 # config 5 (proband + 3 controls, k = 51): bench line and the profiler's kernel statistics
-timeout 900 python3 $REPO/bench.py --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-replay > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg5 -- python3 $REPO/bench.py --workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 > $OUT/bench_cfg5_under_rocprof.json 2> $OUT/trace_cfg5.err
+[[ " ${COLLECT_SKIP:-} " == *" cfg5 "* ]] || timeout 900 python3 $REPO/bench.py --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-replay > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
+[[ " ${COLLECT_SKIP:-} " == *" cfg5 "* ]] || timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg5 -- python3 $REPO/bench.py --workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 > $OUT/bench_cfg5_under_rocprof.json 2> $OUT/trace_cfg5.err
 python3 $REPO/profiles/summarise.py $OUT $OUT/summary
 cp $REPO/gpurun_out/pmc_skm/summary.txt $OUT/summary/sq_counters.txt 2>/dev/null
 ls -la $OUT/summary
