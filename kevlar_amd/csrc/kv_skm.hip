@@ -866,6 +866,28 @@ __device__ __forceinline__ SkmKey<KW> skm_kmer_at(uint64_t b0, uint64_t b1, uint
     return skm_kmer_of<KW>(b0, b1, b2, j, k);
 }
 
+// occurrences that found no room in the LDS table leave as one-k-mer records (either strand of the k-mer): one atomic per wave
+template <int KW, bool WANT_POS>
+__device__ __forceinline__ void skm_walk_loose(const SkmGeom &sg, bool alone, const SkmKey<KW> &kmer, uint64_t hdr, uint32_t owner,
+                                               uint64_t pos0, uint32_t j0, uint32_t u, uint32_t lane, int recw)
+{
+    const unsigned long long need = __ballot(alone);
+    if (!need) return;
+    // (the count pass does not fetch the records' headers for the walk; here -- a wave in a few hundred -- it does,
+    // so that the loose record carries the occurrence's real position: a scan that goes by the count pass's
+    // distinct list evaluates these records as they are)
+    const uint64_t posu = (WANT_POS ? pos0 : skm_hdr_pos(skm_shfl64(hdr, owner)) + j0) + u;
+    unsigned long long first = 0;
+    if (lane == 0) first = atomicAdd(&sg.ctr[0], (unsigned long long)__popcll(need));
+    first = skm_shfl64(first, 0);
+    if (alone) {
+        const unsigned long long idx = first + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
+        uint64_t one[3] = {kmer.w[0], KW == 2 ? kmer.w[KW - 1] : 0ull, 0ull};
+        if (idx < sg.loose_cap) skm_store_record(sg.loose + idx * (uint64_t)recw, skm_header(posu, 1u, 0u), one, sg.nbw);
+        else sg.ctr[1] = 1;
+    }
+}
+
 // body(canonical k-mer, forward k-mer, position of the occurrence) -> true if the occurrence could not be combined and
 // must travel alone through the loose list; WANT_POS = false skips fetching the header (count pass)
 template <int KW, bool WANT_POS, int FK = 0, typename Body>
@@ -934,23 +956,7 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
                 if (u) skm_roll<KW>(fw, rc, (tail >> (2u * (u - 1u))) & 3u, k);
                 bool alone = false;
                 if (u < cnt) alone = body(skm_canonical<KW>(fw, rc), fw, pos0 + u);
-                // occurrences that found no room in the LDS table leave as one-k-mer records: one atomic per wave
-                const unsigned long long need = __ballot(alone);
-                if (need) {
-                    // (the count pass does not fetch the records' headers for the walk; here -- a wave in a few hundred -- it does,
-                    // so that the loose record carries the occurrence's real position: a scan that goes by the count pass's
-                    // distinct list evaluates these records as they are)
-                    const uint64_t posu = (WANT_POS ? pos0 : skm_hdr_pos(skm_shfl64(hdr, owner)) + j0) + u;
-                    unsigned long long first = 0;
-                    if (lane == 0) first = atomicAdd(&sg.ctr[0], (unsigned long long)__popcll(need));
-                    first = skm_shfl64(first, 0);
-                    if (alone) {
-                        const unsigned long long idx = first + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
-                        uint64_t one[3] = {fw.w[0], KW == 2 ? fw.w[KW - 1] : 0ull, 0ull};
-                        if (idx < sg.loose_cap) skm_store_record(sg.loose + idx * (uint64_t)recw, skm_header(posu, 1u, 0u), one, sg.nbw);
-                        else sg.ctr[1] = 1;
-                    }
-                }
+                skm_walk_loose<KW, WANT_POS>(sg, alone, fw, hdr, owner, pos0, j0, u, lane, recw);
             }
         }
         __builtin_amdgcn_wave_barrier();                // the next group clears the mask
