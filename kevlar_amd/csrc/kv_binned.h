@@ -100,6 +100,11 @@ struct KvArena {
         if (e == hipSuccess) { bytes = roomy; return e; }
         (void)hipGetLastError();
         e = hipMalloc(&p, n);
+        if (e != hipSuccess) {                          // the table buffers kept for future sketches are worth less than this
+            (void)hipGetLastError();
+            kv_table_cache_release();
+            e = hipMalloc(&p, n);
+        }
         if (e == hipSuccess) bytes = n;
         return e;
     }

@@ -341,8 +341,9 @@ extern "C" int kv_primes_below(double target, int n, uint64_t *out, int *found)
 // (`kevlar novel` after the bench's main loop: every run 0.26 s instead of 0.075), and it stalls every other thread's HIP call meanwhile.
 namespace {
 std::mutex g_tabcache_mu;
-std::multimap<uint64_t, uint8_t *> g_tabcache;
+std::multimap<std::pair<int, uint64_t>, uint8_t *> g_tabcache;       // (device, bytes) -> buffer
 uint64_t g_tabcache_bytes = 0;
+int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 uint64_t tabcache_cap()
 {
     const char *e = getenv("KV_TABLE_CACHE_GB");
@@ -352,7 +353,7 @@ hipError_t table_alloc(uint8_t **p, uint64_t bytes)
 {
     {
         std::lock_guard<std::mutex> lk(g_tabcache_mu);
-        auto it = g_tabcache.find(bytes);
+        auto it = g_tabcache.find(std::make_pair(current_device(), bytes));
         if (it != g_tabcache.end()) {
             *p = it->second;
             g_tabcache.erase(it);
@@ -363,10 +364,7 @@ hipError_t table_alloc(uint8_t **p, uint64_t bytes)
     hipError_t e = hipMalloc((void **)p, bytes);
     if (e != hipSuccess) {                           // out of memory: give the cache back and try once more
         (void)hipGetLastError();
-        std::lock_guard<std::mutex> lk(g_tabcache_mu);
-        for (auto &kv : g_tabcache) (void)hipFree(kv.second);
-        g_tabcache.clear();
-        g_tabcache_bytes = 0;
+        kv_table_cache_release();
         e = hipMalloc((void **)p, bytes);
     }
     return e;
@@ -376,7 +374,7 @@ void table_free(uint8_t *p, uint64_t bytes)
     {
         std::lock_guard<std::mutex> lk(g_tabcache_mu);
         if (bytes >= (16u << 20) && g_tabcache_bytes + bytes <= tabcache_cap()) {
-            g_tabcache.emplace(bytes, p);
+            g_tabcache.emplace(std::make_pair(current_device(), bytes), p);
             g_tabcache_bytes += bytes;
             return;
         }
@@ -384,6 +382,14 @@ void table_free(uint8_t *p, uint64_t bytes)
     (void)hipFree(p);
 }
 }  // namespace
+
+void kv_table_cache_release()
+{
+    std::lock_guard<std::mutex> lk(g_tabcache_mu);
+    for (auto &kv : g_tabcache) (void)hipFree(kv.second);         // (hipFree takes a pointer of any device)
+    g_tabcache.clear();
+    g_tabcache_bytes = 0;
+}
 
 int kv_sketch_alloc(int kind, int ksize, int ntables, const uint64_t *sizes, kv_sketch **out)
 {

@@ -245,6 +245,8 @@ void kv_set_error(const char *fmt, ...);
 hipStream_t kv_stream();
 // the key the per-stream scratch tables go by (kv_host.hip): a recycled slot for streams made by kv_stream_create, else the handle
 hipStream_t kv_stream_key(hipStream_t st);
+// table buffers of destroyed sketches kept for the next sketch (kv_host.hip) go back to the driver: called when an allocation fails
+void kv_table_cache_release();
 void kv_ensure_dynamic_lds(const void *kernel, size_t bytes);   // hipFuncSetAttribute once per growth
 
 // profiling: RAII wrapper recording HIP events around a launch when enabled
