@@ -347,7 +347,8 @@ int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 uint64_t tabcache_cap()
 {
     const char *e = getenv("KV_TABLE_CACHE_GB");
-    return (uint64_t)(e ? atof(e) : 32.0) << 30;
+    const double gb = e ? atof(e) : 32.0;
+    return gb > 0 ? (uint64_t)(gb * (double)(1ull << 30)) : 0;       // (fractions of a gigabyte count)
 }
 hipError_t table_alloc(uint8_t **p, uint64_t bytes)
 {
