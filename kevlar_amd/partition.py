@@ -60,18 +60,24 @@ def partition(readstream, strict=False, minabund=None, maxabund=None, dedup=True
 
 
 def _fixed_width(blob, offs):
-    """the strings blob[offs[i]:offs[i + 1]] as one numpy bytes array (NUL padded): compares and sorts like the strings do"""
+    """the strings blob[offs[i]:offs[i + 1]] as one numpy bytes array (NUL padded): compares and sorts like the strings do.
+    Rows are gathered whole from a sliding window over the blob (one index per string, not one per byte) and the bytes behind
+    each string's end are zeroed; strings of one length back to back are just the blob reshaped."""
     import numpy as np
     offs = np.asarray(offs, dtype=np.int64)
     lens = np.diff(offs)
-    width = int(lens.max()) if len(lens) else 1
+    width = max(1, int(lens.max())) if len(lens) else 1
     raw = np.frombuffer(blob, dtype=np.uint8)
-    if len(raw) == 0:
+    if len(raw) == 0 or len(lens) == 0:
         return np.zeros(len(lens), dtype='S1')
-    cols = np.arange(max(1, width), dtype=np.int64)
-    at = np.minimum(offs[:-1, None] + cols[None, :], len(raw) - 1)
-    out = np.where(cols[None, :] < lens[:, None], raw[at], np.uint8(0)).astype(np.uint8)
-    return np.ascontiguousarray(out).view('S{:d}'.format(max(1, width))).reshape(-1)
+    kind = 'S{:d}'.format(width)
+    if int(lens.min()) == width and offs[0] == 0 and int(offs[-1]) == len(lens) * width and len(raw) >= len(lens) * width:
+        return np.ascontiguousarray(raw[:len(lens) * width]).view(kind).reshape(-1)
+    padded = np.concatenate((raw, np.zeros(width, dtype=np.uint8)))
+    windows = np.lib.stride_tricks.as_strided(padded, shape=(len(raw) + 1, width), strides=(1, 1), writeable=False)
+    out = windows[np.minimum(offs[:-1], len(raw))]                  # a copy: one row of `width` bytes per string
+    out[np.arange(width, dtype=np.int64)[None, :] >= lens[:, None]] = 0
+    return np.ascontiguousarray(out).view(kind).reshape(-1)
 
 
 _COMP_LUT = None
@@ -112,8 +118,9 @@ def _canonical_hashes(seqs, seq_offs, reads):
                     rev = np.zeros((len(sel), width), dtype=np.uint8)
                     if table is not None:
                         fwd[:, :length] = table[reads[sel]]
-                    else:
-                        fwd[:, :length] = raw[offs[reads[sel]][:, None] + np.arange(length, dtype=np.int64)[None, :]]
+                    else:                                   # rows gathered whole from a sliding window over the blob
+                        windows = np.lib.stride_tricks.as_strided(raw, shape=(len(raw) - length + 1, length), strides=(1, 1), writeable=False)
+                        fwd[:, :length] = windows[offs[reads[sel]]]
                     rev[:, :length] = _COMP_LUT[fwd[:, length - 1::-1] if length > 1 else fwd[:, :1]]
                     fw, rw = fwd.view('>u8'), rev.view('>u8')          # big-endian words compare like the bytes do
                     differ = fw != rw

@@ -635,3 +635,28 @@ def test_assemble_partitions_matches_the_loop_it_replaced():
                 want_reads += rs
                 want_number += [num] * len(rs)
             assert reads.tolist() == want_reads and number.tolist() == want_number, (trial, dedup, minabund)
+
+
+def test_fixed_width_rows_are_the_strings_nul_padded():
+    """partition's name matrix: one NUL-padded row per string, whatever the lengths (ragged: rows gathered from a sliding window;
+    one length back to back: the blob reshaped; offsets that start behind the blob's first byte; empty strings; no strings)"""
+    import random
+    import numpy as np
+    from kevlar_amd.partition import _fixed_width
+    rng = random.Random(4)
+    for trial in range(200):
+        n = rng.choice([0, 1, 2, 9, 50])
+        same = trial % 3 == 0
+        length = rng.randrange(0, 7)
+        strings = [bytes(rng.randrange(1, 256) for _ in range(length if same else rng.randrange(0, 9))) for _ in range(n)]
+        lead = bytes(rng.randrange(1, 256) for _ in range(rng.randrange(0, 3))) if trial % 4 == 0 else b''
+        tail = bytes(rng.randrange(1, 256) for _ in range(rng.randrange(0, 3)))
+        blob = lead + b''.join(strings) + tail
+        offs = np.cumsum([len(lead)] + [len(s) for s in strings]).astype(np.uint64)
+        rows = _fixed_width(blob, offs)
+        assert len(rows) == n
+        width = max([len(s) for s in strings] + [1])
+        if n and blob:
+            assert rows.dtype == np.dtype('S{}'.format(width))
+        assert [bytes(r) for r in rows.tolist()] == [s for s in strings]        # (numpy strips the padding again)
+        assert sorted(range(n), key=lambda i: strings[i]) == np.argsort(rows, kind='stable').tolist() if n else True
