@@ -81,6 +81,7 @@ def _fixed_width(blob, offs):
 
 
 _COMP_LUT = None
+_COMP_LUT16 = None
 
 
 def _canonical_hashes(seqs, seq_offs, reads):
@@ -96,6 +97,9 @@ def _canonical_hashes(seqs, seq_offs, reads):
             if src < 256:
                 lut[src] = dst
         _COMP_LUT = lut
+        global _COMP_LUT16                       # two bytes per look-up: numpy's take costs per element, not per byte
+        pairs = np.arange(65536)
+        _COMP_LUT16 = lut[pairs & 255].astype(np.uint16) | (lut[pairs >> 8].astype(np.uint16) << 8)
     raw = np.frombuffer(seqs, dtype=np.uint8)
     offs = np.asarray(seq_offs, dtype=np.int64)
     reads = np.asarray(reads, dtype=np.int64)
@@ -121,7 +125,8 @@ def _canonical_hashes(seqs, seq_offs, reads):
                     else:                                   # rows gathered whole from a sliding window over the blob
                         windows = np.lib.stride_tricks.as_strided(raw, shape=(len(raw) - length + 1, length), strides=(1, 1), writeable=False)
                         fwd[:, :length] = windows[offs[reads[sel]]]
-                    rev[:, :length] = _COMP_LUT[fwd[:, length - 1::-1] if length > 1 else fwd[:, :1]]
+                    comp = _COMP_LUT16[fwd.view(np.uint16)].view(np.uint8)            # (rows are whole 64-bit words)
+                    rev[:, :length] = comp[:, length - 1::-1] if length > 1 else comp[:, :1]
                     fw, rw = fwd.view('>u8'), rev.view('>u8')          # big-endian words compare like the bytes do
                     differ = fw != rw
                     first = differ.argmax(axis=1)
