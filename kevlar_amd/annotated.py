@@ -86,7 +86,9 @@ class AnnotatedReads(object):
             def arr(p, count, dtype):
                 if count == 0:
                     return np.zeros(0, dtype=dtype)
-                return np.frombuffer(_bytes_at(p, count * np.dtype(dtype).itemsize), dtype=dtype).copy()
+                # (one copy out of the handle's memory, not a bytes object first and an array from that)
+                window = (ctypes.c_ubyte * (count * np.dtype(dtype).itemsize)).from_address(p.value)
+                return np.frombuffer(window, dtype=dtype).copy()
             self = cls.__new__(cls)
             self.n = n
             self.name_offs, self.seq_offs, self.qual_offs = (arr(ptr[i], n + 1, np.uint64) for i in (1, 3, 5))
