@@ -179,27 +179,50 @@ bool join_parts(std::vector<kv_augfastx> &part, kv_augfastx *a)
         if (a->ksize == 0) a->ksize = b.ksize;
         else if (b.ksize != a->ksize) a->ksize = -1;
     }
-    a->names.reserve(names); a->seqs.reserve(seqs); a->quals.reserve(quals); a->mates.reserve(mates);
-    a->name_offs.reserve(recs + 1); a->seq_offs.reserve(recs + 1); a->qual_offs.reserve(recs + 1); a->ann_first.reserve(recs + 1);
-    a->is_fastq.reserve(recs); a->ann_offset.reserve(anns); a->ann_abund.reserve(abund);
-    a->mate_record.reserve(n_mates); a->mate_offs.reserve(n_mates + 1);
-    for (kv_augfastx &b : part) {
-        const uint64_t base_n = a->names.size(), base_s = a->seqs.size(), base_q = a->quals.size(), base_m = a->mates.size();
-        const uint64_t base_r = a->is_fastq.size(), base_a = a->ann_offset.size();
-        a->names += b.names; a->seqs += b.seqs; a->quals += b.quals; a->mates += b.mates;
-        for (size_t i = 1; i < b.name_offs.size(); ++i) {
-            a->name_offs.push_back(base_n + b.name_offs[i]);
-            a->seq_offs.push_back(base_s + b.seq_offs[i]);
-            a->qual_offs.push_back(base_q + b.qual_offs[i]);
-            a->ann_first.push_back(base_a + b.ann_first[i]);
+    // Every piece knows where it goes, so the pieces are copied side by side (one thread doing it all -- 2 GB of a 3 GB file --
+    // was a third of the load); the big blobs are sized (= zeroed, first touch) side by side too.
+    const size_t np = part.size();
+    std::vector<uint64_t> base_n(np), base_s(np), base_q(np), base_m(np), base_r(np), base_a(np), base_ab(np), base_nm(np);
+    {
+        uint64_t n_ = 0, s_ = 0, q_ = 0, m_ = 0, r_ = 0, a_ = 0, ab_ = 0, nm_ = 0;
+        for (size_t i = 0; i < np; ++i) {
+            base_n[i] = n_; base_s[i] = s_; base_q[i] = q_; base_m[i] = m_; base_r[i] = r_; base_a[i] = a_; base_ab[i] = ab_; base_nm[i] = nm_;
+            n_ += part[i].names.size(); s_ += part[i].seqs.size(); q_ += part[i].quals.size(); m_ += part[i].mates.size();
+            r_ += part[i].is_fastq.size(); a_ += part[i].ann_offset.size(); ab_ += part[i].ann_abund.size(); nm_ += part[i].mate_record.size();
         }
-        a->is_fastq.insert(a->is_fastq.end(), b.is_fastq.begin(), b.is_fastq.end());
-        a->ann_offset.insert(a->ann_offset.end(), b.ann_offset.begin(), b.ann_offset.end());
-        a->ann_abund.insert(a->ann_abund.end(), b.ann_abund.begin(), b.ann_abund.end());
-        for (size_t i = 1; i < b.mate_offs.size(); ++i) a->mate_offs.push_back(base_m + b.mate_offs[i]);
-        for (uint32_t r : b.mate_record) a->mate_record.push_back((uint32_t)(base_r + r));
-        b = kv_augfastx();                               // let the piece go
     }
+    {
+        std::thread sized_seqs([&] { a->seqs.resize(seqs); });
+        std::thread sized_quals([&] { a->quals.resize(quals); });
+        a->names.resize(names); a->mates.resize(mates);
+        a->name_offs.assign(recs + 1, 0); a->seq_offs.assign(recs + 1, 0); a->qual_offs.assign(recs + 1, 0); a->ann_first.assign(recs + 1, 0);
+        a->is_fastq.resize(recs); a->ann_offset.resize(anns); a->ann_abund.resize(abund);
+        a->mate_record.resize(n_mates); a->mate_offs.assign(n_mates + 1, 0);
+        sized_seqs.join(); sized_quals.join();
+    }
+    auto place = [&](size_t i) {
+        kv_augfastx &b = part[i];
+        if (!b.names.empty()) memcpy(&a->names[base_n[i]], b.names.data(), b.names.size());
+        if (!b.seqs.empty()) memcpy(&a->seqs[base_s[i]], b.seqs.data(), b.seqs.size());
+        if (!b.quals.empty()) memcpy(&a->quals[base_q[i]], b.quals.data(), b.quals.size());
+        if (!b.mates.empty()) memcpy(&a->mates[base_m[i]], b.mates.data(), b.mates.size());
+        for (size_t r = 1; r < b.name_offs.size(); ++r) {
+            a->name_offs[base_r[i] + r] = base_n[i] + b.name_offs[r];
+            a->seq_offs[base_r[i] + r] = base_s[i] + b.seq_offs[r];
+            a->qual_offs[base_r[i] + r] = base_q[i] + b.qual_offs[r];
+            a->ann_first[base_r[i] + r] = base_a[i] + b.ann_first[r];
+        }
+        if (!b.is_fastq.empty()) memcpy(&a->is_fastq[base_r[i]], b.is_fastq.data(), b.is_fastq.size() * sizeof(b.is_fastq[0]));
+        if (!b.ann_offset.empty()) memcpy(&a->ann_offset[base_a[i]], b.ann_offset.data(), b.ann_offset.size() * sizeof(b.ann_offset[0]));
+        if (!b.ann_abund.empty()) memcpy(&a->ann_abund[base_ab[i]], b.ann_abund.data(), b.ann_abund.size() * sizeof(b.ann_abund[0]));
+        for (size_t m = 1; m < b.mate_offs.size(); ++m) a->mate_offs[base_nm[i] + m] = base_m[i] + b.mate_offs[m];
+        for (size_t m = 0; m < b.mate_record.size(); ++m) a->mate_record[base_nm[i] + m] = (uint32_t)(base_r[i] + b.mate_record[m]);
+        b = kv_augfastx();                               // let the piece go
+    };
+    std::vector<std::thread> crew;
+    for (size_t i = 1; i < np; ++i) crew.emplace_back(place, i);
+    if (np) place(0);
+    for (std::thread &t : crew) t.join();
     return true;
 }
 
