@@ -320,6 +320,10 @@ int kv_format_records(uint64_t n_out, const uint64_t *rec_index, const uint64_t 
                       const uint64_t *qual_offs, const uint8_t *is_fastq, const char *suffix,
                       const uint64_t *suffix_offs, const uint32_t *mate_record, uint64_t n_mates, const char *mates,
                       const uint64_t *mate_offs, char **text_out, uint64_t *bytes_out);
+/* the dedup key of `kevlar partition` (kevlar/partition.py:37-47: kevlar.revcommin(read.sequence)) as two 64-bit hashes per read:
+ * of the sequence or its reverse complement (complement[256]: the byte table of revcom), whichever sorts first.  Host only.     */
+int kv_canonical_read_hashes(const char *seqs, const uint64_t *seq_offs, const uint64_t *reads, uint64_t n,
+                             const uint8_t *complement, uint64_t *h1, uint64_t *h2);
 
 /* ---- blocked gzip (BGZF) on the device (kevlar_amd/csrc/kv_inflate.hip) --------------------------------
  * Replaces the gzip stream behind khmer.ReadParser (kevlar/__init__.py:125-128) for files whose members are

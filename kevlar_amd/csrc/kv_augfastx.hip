@@ -347,6 +347,42 @@ extern "C" int kv_augfastx_free(kv_augfastx *a)
 // (optional) replaces the first abundance of every annotation; suffix (optional blob + offsets per output record) is
 // appended to the record's name (partition's " kvcc=N").
 // ---------------------------------------------------------------------------------------
+// Two independent 64-bit hashes of min(sequence, reverse complement) for the given reads: the key `kevlar partition` dedups a
+// partition's reads by (kevlar/partition.py:37-47 via kevlar.revcommin).  complement: the 256-entry byte table of the caller's
+// revcom() (IUPAC codes, both cases); order is that of the bytes, as Python compares the strings.  Host only, threads over the reads.
+extern "C" int kv_canonical_read_hashes(const char *seqs, const uint64_t *seq_offs, const uint64_t *reads, uint64_t n,
+                                        const uint8_t *complement, uint64_t *h1, uint64_t *h2)
+{
+    KV_REQUIRE(n == 0 || (seqs && seq_offs && reads && complement && h1 && h2), KV_ERR_ARG, "kv_canonical_read_hashes: null argument");
+    const char *forced = getenv("KV_AUGFASTX_THREADS");
+    const unsigned hw = forced ? (unsigned)std::max(1, atoi(forced)) : std::max(1u, std::thread::hardware_concurrency());
+    const uint64_t crew_n = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(hw, 32), n / 20000));
+    auto work = [&](uint64_t lo, uint64_t hi) {
+        std::string rc;
+        for (uint64_t j = lo; j < hi; ++j) {
+            const uint64_t r = reads[j];
+            const unsigned char *fw = (const unsigned char *)seqs + seq_offs[r];
+            const size_t len = (size_t)(seq_offs[r + 1] - seq_offs[r]);
+            rc.resize(len);
+            for (size_t i = 0; i < len; ++i) rc[i] = (char)complement[fw[len - 1 - i]];
+            const unsigned char *use = len && memcmp(rc.data(), fw, len) < 0 ? (const unsigned char *)rc.data() : fw;
+            uint64_t a = 0xcbf29ce484222325ull ^ (uint64_t)len, c = 0x9e3779b97f4a7c15ull + (uint64_t)len;
+            for (size_t i = 0; i < len; i += 8) {
+                uint64_t w = 0;
+                memcpy(&w, use + i, std::min<size_t>(8, len - i));
+                a = (a ^ w) * 0x100000001b3ull; a ^= a >> 31;
+                c = (c + w) * 0xff51afd7ed558ccdull; c ^= c >> 29;
+            }
+            h1[j] = a; h2[j] = c;
+        }
+    };
+    if (crew_n <= 1) { work(0, n); return KV_OK; }
+    std::vector<std::thread> crew;
+    for (uint64_t t = 0; t < crew_n; ++t) crew.emplace_back(work, n * t / crew_n, n * (t + 1) / crew_n);
+    for (std::thread &t : crew) t.join();
+    return KV_OK;
+}
+
 extern "C" int kv_format_records(uint64_t n_out, const uint64_t *rec_index, const uint64_t *ann_lo, const uint64_t *ann_hi,
                                  const uint32_t *ann_offset, const int32_t *ann_abund, const uint8_t *keep, const int32_t *case_abund,
                                  int nsamples, int ksize, const char *names, const uint64_t *name_offs, const char *seqs,

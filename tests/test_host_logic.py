@@ -660,3 +660,32 @@ def test_fixed_width_rows_are_the_strings_nul_padded():
             assert rows.dtype == np.dtype('S{}'.format(width))
         assert [bytes(r) for r in rows.tolist()] == [s for s in strings]        # (numpy strips the padding again)
         assert sorted(range(n), key=lambda i: strings[i]) == np.argsort(rows, kind='stable').tolist() if n else True
+
+
+def test_canonical_read_hashes_group_reads_like_revcommin():
+    """partition's dedup key: reads get the same pair of hashes exactly when kevlar.revcommin() gives the same string -- IUPAC codes,
+    both cases, lengths from 0 up, reads addressed in any order, one thread or several"""
+    import random
+    import numpy as np
+    import kevlar_amd
+    from kevlar_amd.partition import _canonical_hashes
+    rng = random.Random(12)
+    for trial, threads in enumerate((None, '1', '3')):
+        n = 30000 if threads == '3' else 1500                # (the helper starts a thread per 20 000 reads)
+        seqs = [''.join(rng.choice('ACGTNacgtRYKMBDHVu') for _ in range(rng.choice([0, 1, 2, 7, 8, 9, 31, 100]))) for _ in range(n // 3)]
+        seqs += [rng.choice(seqs) if rng.random() < 0.5 else kevlar_amd.revcom(rng.choice(seqs)) for _ in range(n - len(seqs))]
+        blob = ''.join(seqs).encode('latin-1')
+        offs = np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64)
+        order = list(range(n)); rng.shuffle(order)
+        if threads:
+            os.environ['KV_AUGFASTX_THREADS'] = threads
+        try:
+            h1, h2 = _canonical_hashes(blob, offs, order)
+        finally:
+            os.environ.pop('KV_AUGFASTX_THREADS', None)
+        by_key = {}
+        for at, i in enumerate(order):
+            by_key.setdefault(kevlar_amd.revcommin(seqs[i]), set()).add((int(h1[at]), int(h2[at])))
+        assert all(len(v) == 1 for v in by_key.values())
+        assert len({next(iter(v)) for v in by_key.values()}) == len(by_key)
+    assert len(_canonical_hashes(b'', np.zeros(1, dtype=np.uint64), [])[0]) == 0
