@@ -123,19 +123,24 @@ def assemble_partitions(names, name_offs, seqs, seq_offs, component_of, minabund
     if n <= 0:
         return empty
     fixed = _fixed_width(names, name_offs)
-    _, node_of_read = np.unique(fixed, return_inverse=True)         # node ids in name order: a node's id is its name's rank
-    node_of_read = node_of_read.astype(np.int64)
-    n_nodes = int(node_of_read.max()) + 1
-    by_node = np.argsort(node_of_read, kind='stable')
+    by_node = np.argsort(fixed, kind='stable')                      # the reads by name, equal names in read order (ONE sort gives the
+    in_order = fixed[by_node]                                       # node ids, the reads by node and each node's last read)
+    fresh = np.ones(n, dtype=bool)
+    fresh[1:] = in_order[1:] != in_order[:-1]
+    node_of_read = np.empty(n, dtype=np.int64)
+    node_of_read[by_node] = np.cumsum(fresh) - 1                    # node ids in name order: a node's id is its name's rank
+    n_nodes = int(fresh.sum())
     last = np.ones(n, dtype=bool)
-    last[:-1] = node_of_read[by_node][1:] != node_of_read[by_node][:-1]
+    last[:-1] = fresh[1:]
     holder = by_node[last]                                          # a node's record: the last read with its name
     labels = np.asarray(component_of(node_of_read.astype(np.uint32), n_nodes))
-    _, comp = np.unique(labels, return_inverse=True)
-    size = np.bincount(comp)
-    by_comp = np.argsort(comp, kind='stable')
+    by_comp = np.argsort(labels, kind='stable')                     # the nodes by component, within one by name
+    in_order = labels[by_comp]
     head = np.ones(n_nodes, dtype=bool)
-    head[1:] = comp[by_comp][1:] != comp[by_comp][:-1]
+    head[1:] = in_order[1:] != in_order[:-1]
+    comp = np.empty(n_nodes, dtype=np.int64)
+    comp[by_comp] = np.cumsum(head) - 1
+    size = np.bincount(comp)
     smallest = by_comp[head]                                        # a component's smallest name: its first node in name order
     keep = np.flatnonzero(size >= 2)                                # a read on its own is not a partition
     if not len(keep):
