@@ -322,6 +322,9 @@ int kv_format_records(uint64_t n_out, const uint64_t *rec_index, const uint64_t 
                       const uint64_t *mate_offs, char **text_out, uint64_t *bytes_out);
 /* the dedup key of `kevlar partition` (kevlar/partition.py:37-47: kevlar.revcommin(read.sequence)) as two 64-bit hashes per read:
  * of the sequence or its reverse complement (complement[256]: the byte table of revcom), whichever sorts first.  Host only.     */
+/* flags[i] = 1 if read i (seqs[seq_offs[i] .. seq_offs[i + 1])) holds a byte other than upper-case A, C, G, T: the packed form cannot
+ * hold it, and the host hashes that read's k-mers from the text (the reference hashes every k-mer from its string).  Host only. */
+int kv_reads_flag_other_bytes(const char *seqs, const uint64_t *seq_offs, uint64_t n, uint8_t *flags);
 int kv_canonical_read_hashes(const char *seqs, const uint64_t *seq_offs, const uint64_t *reads, uint64_t n,
                              const uint8_t *complement, uint64_t *h1, uint64_t *h2);
 

@@ -16,9 +16,6 @@ import numpy as np
 from kevlar_amd import _lib, khmer
 from kevlar_amd.sequence import KmerOfInterest, Record
 
-_ACGT = np.zeros(256, dtype=bool)
-_ACGT[[ord(c) for c in 'ACGT']] = True
-
 
 def _bytes_at(ptr, n):
     """ctypes.string_at for any size (its length argument is a C int: 2 GB of annotated reads overflow it)"""
@@ -209,10 +206,13 @@ class AnnotatedReads(object):
         """indices of the reads with characters outside ACGT (the packed form cannot hold them)"""
         if not self.seqs:
             return np.zeros(0, dtype=np.int64)
-        bad = np.flatnonzero(~_ACGT[np.frombuffer(self.seqs, dtype=np.uint8)])
-        if not len(bad):
-            return bad
-        return np.unique(np.searchsorted(self.seq_offs, bad.astype(np.uint64), side='right') - 1)
+        if 'odd' not in self._made:             # (a table look-up per byte in numpy took 3 ns a byte: seconds for a few million reads)
+            flags = np.zeros(self.n, dtype=np.uint8)
+            offs = np.ascontiguousarray(self.seq_offs, dtype=np.uint64)
+            _lib.check(_lib.load().kv_reads_flag_other_bytes(
+                ctypes.cast(ctypes.c_char_p(self.seqs), ctypes.c_void_p), offs.ctypes.data_as(ctypes.c_void_p), self.n, flags.ctypes.data_as(ctypes.c_void_p)))
+            self._made['odd'] = np.flatnonzero(flags)
+        return self._made['odd']
 
     def hashes(self, sketch):
         """`sketch`'s hash of every annotated k-mer, in stream order.  K-mers of reads with characters outside ACGT

@@ -347,6 +347,31 @@ extern "C" int kv_augfastx_free(kv_augfastx *a)
 // (optional) replaces the first abundance of every annotation; suffix (optional blob + offsets per output record) is
 // appended to the record's name (partition's " kvcc=N").
 // ---------------------------------------------------------------------------------------
+// flags[i] = 1 if read i holds a byte other than A, C, G, T (upper case): such reads cannot be 2-bit packed, their k-mers are
+// hashed from the text (AnnotatedReads.hashes).  Host only, threads over the reads.
+extern "C" int kv_reads_flag_other_bytes(const char *seqs, const uint64_t *seq_offs, uint64_t n, uint8_t *flags)
+{
+    KV_REQUIRE(n == 0 || (seqs && seq_offs && flags), KV_ERR_ARG, "kv_reads_flag_other_bytes: null argument");
+    const char *forced = getenv("KV_AUGFASTX_THREADS");
+    const unsigned hw = forced ? (unsigned)std::max(1, atoi(forced)) : std::max(1u, std::thread::hardware_concurrency());
+    const uint64_t crew_n = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(hw, 32), n / 20000));
+    auto work = [&](uint64_t lo, uint64_t hi) {
+        bool other[256];
+        for (int b = 0; b < 256; ++b) other[b] = !(b == 'A' || b == 'C' || b == 'G' || b == 'T');
+        for (uint64_t r = lo; r < hi; ++r) {
+            const unsigned char *p = (const unsigned char *)seqs + seq_offs[r], *end = (const unsigned char *)seqs + seq_offs[r + 1];
+            unsigned any = 0;
+            for (; p < end; ++p) any |= (unsigned)other[*p];
+            flags[r] = (uint8_t)any;
+        }
+    };
+    if (crew_n <= 1) { work(0, n); return KV_OK; }
+    std::vector<std::thread> crew;
+    for (uint64_t t = 0; t < crew_n; ++t) crew.emplace_back(work, n * t / crew_n, n * (t + 1) / crew_n);
+    for (std::thread &t : crew) t.join();
+    return KV_OK;
+}
+
 // Two independent 64-bit hashes of min(sequence, reverse complement) for the given reads: the key `kevlar partition` dedups a
 // partition's reads by (kevlar/partition.py:37-47 via kevlar.revcommin).  complement: the 256-entry byte table of the caller's
 // revcom() (IUPAC codes, both cases); order is that of the bytes, as Python compares the strings.  Host only, threads over the reads.

@@ -689,3 +689,18 @@ def test_canonical_read_hashes_group_reads_like_revcommin():
         assert all(len(v) == 1 for v in by_key.values())
         assert len({next(iter(v)) for v in by_key.values()}) == len(by_key)
     assert len(_canonical_hashes(b'', np.zeros(1, dtype=np.uint64), [])[0]) == 0
+
+
+def test_odd_reads_are_the_reads_with_bytes_outside_acgt():
+    """AnnotatedReads.odd_reads(): the reads the 2-bit form cannot hold -- anything but upper-case A, C, G, T -- found by the library's
+    host helper (threads over the reads when there are many), empty reads never among them"""
+    import random
+    from kevlar_amd.annotated import AnnotatedReads
+    from kevlar_amd.sequence import Record
+    rng = random.Random(21)
+    for n in (0, 1, 7, 400, 45000):
+        seqs = [''.join(rng.choice('ACGT' * 40 + 'Nacgt-*') for _ in range(rng.choice([0, 1, 25, 60]))) for _ in range(n)]
+        reads = AnnotatedReads([Record(name='r{}'.format(i), sequence=s) for i, s in enumerate(seqs)])
+        want = [i for i, s in enumerate(seqs) if any(c not in 'ACGT' for c in s)]
+        assert reads.odd_reads().tolist() == want
+        assert reads.odd_reads() is reads.odd_reads()              # (kept: filter and partition ask more than once)
