@@ -120,6 +120,36 @@ def parse_args():
 
 LIVE_PMC = None      # per-kernel HBM bytes of one step, measured by live_traffic() of this very run
 
+# which stage a kernel belongs to, by the start of its name.  The library's profile scopes (kv_prof_*: HIP-event times) and the
+# profiler's kernel names (rocprofv3: PMC bytes) are two name spaces -- the scope "k_skm_emit" times the kernel k_skm_emit_wave,
+# "k_skm_split" times k_skm_split_sorted -- so both are grouped by the SAME prefixes, never matched name by name.
+STAGE_PREFIXES = {
+    'count': ('k_bin_', 'k_route_', 'k_skm_emit', 'k_skm_split', 'k_skm_count', 'k_skm_loose_count', 'k_skm_forward_flag', 'k_consume'),
+    'novel': ('k_novel_', 'k_skm_novel', 'k_skm_loose_novel', 'k_tile_', 'k_ab_fill', 'k_hit_abund'),
+}
+
+
+def stage_of(name):
+    for stage, prefixes in STAGE_PREFIXES.items():
+        if name.startswith(prefixes):
+            return stage
+    return None
+
+
+def stage_traffic(pmc_kernels, stage, scope_ms=None, min_share=0.01):
+    """HBM bytes per step of one stage from a PMC table keyed by KERNEL name (profiles/summarise.reduce_pmc) -> (total, by kernel).
+    scope_ms: {profile scope: ms} of the same stage; a scope that holds more than min_share of the stage's time and has no
+    kernel of its own in the PMC table (no kernel name starts with the scope's name, nor the other way round) raises: a kernel
+    that was renamed, or that the counter pass did not see, must not drop out of the sum silently."""
+    by_kernel = {name: int(rec['hbm_bytes_per_step']) for name, rec in pmc_kernels.items() if stage_of(name) == stage}
+    if scope_ms:
+        total_ms = sum(scope_ms.values())
+        for scope, ms in scope_ms.items():
+            if total_ms > 0 and ms > min_share * total_ms and not any(k.startswith(scope) or scope.startswith(k) for k in by_kernel):
+                raise RuntimeError('roofline.traffic: the profile scope {} holds {:.1f} % of the {} stage and no kernel in the PMC table '
+                                   'matches it (kernels seen: {})'.format(scope, 100.0 * ms / total_ms, stage, sorted(by_kernel)))
+    return sum(by_kernel.values()), by_kernel
+
 
 def live_traffic(args):
     """Two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass), one
@@ -542,10 +572,7 @@ def main():
     buf = ctypes.create_string_buffer(8192)
     lib.kv_prof_names(buf, 8192)
     times = {name: prof(lib, name) for name in buf.value.decode().split(',') if name}
-    count_prefixes = ('k_bin_', 'k_route_', 'k_skm_emit', 'k_skm_split', 'k_skm_count', 'k_skm_loose_count')
-    novel_prefixes = ('k_novel_', 'k_skm_novel', 'k_skm_loose_novel', 'k_tile_')
-    groups = {'count': [n_ for n_ in times if n_.startswith(count_prefixes) or n_ == 'k_consume'],
-              'novel': [n_ for n_ in times if n_.startswith(novel_prefixes)]}
+    groups = {st: [n_ for n_ in times if stage_of(n_) == st] for st in STAGE_PREFIXES}
     stage_ms = {st: sum(times[n_][0] for n_ in groups[st]) / args.steps for st in groups}       # per step
     kernel_sum_ms = dict(stage_ms)
     concurrent = world == 1 and args.count_streams > 1
@@ -575,8 +602,9 @@ def main():
                 else:
                     traffic_source = 'none: {} measured other kernel sources than this checkout'.format(os.path.relpath(f, ROOT))
                 break
+    traffic_by_kernel = None
     if pmc is not None:
-        tot = sum(pmc['kernels'][name]['hbm_bytes_per_step'] for name in groups[stage] if name in pmc.get('kernels', {}))
+        tot, traffic_by_kernel = stage_traffic(pmc.get('kernels', {}), stage, {n_: times[n_][0] for n_ in groups[stage]})
         if tot:
             traffic = int(tot)
             traffic_source = pmc.get('source')
@@ -585,6 +613,8 @@ def main():
         'bound': 'hbm', 'stage': stage, 'kernel': dominant,
         'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_source,
+        'traffic_by_kernel': traffic_by_kernel,
+        'traffic_over_algorithmic': round(traffic / stage_alg[stage], 3) if traffic else None,
         'stage_ms_per_step': round(stage_ms[stage], 4), 'algorithmic_bytes_per_step_of_stage': int(stage_alg[stage]),
         'kernel_avg_launch_ms': round(dom_ms / max(1, dom_launches), 4), 'kernel_launches': int(dom_launches),
         'whole_step': {'algorithmic_bytes': int(a_count * S + a_novel),
