@@ -687,17 +687,13 @@ def main():
         dist.destroy_process_group()
 
 
-def band_downstream(args, wl, hits, genome_len, seed, L, k, S, synth):
-    """What follows the scan in the workflow (kevlar/workflows/mark-I/Snakefile:236-309), on the band's hits: the annotated
-    reads written as an augmented FASTQ file, `kevlar filter` on it, `kevlar partition` on what survives.  The reads' text
-    comes from the generator's numpy restatement (only reads with hits: the 2.7 G reads themselves never leave HBM)."""
-    import io
-    import tempfile
+def band_annotated_reads(hits, genome_len, seed, L, k, S, synth):
+    """The hits of a scan over device-generated proband reads as an AnnotatedReads: the text of the reads that hold a hit comes
+    from the generator's numpy restatement (kevlar_amd.synth.device_family_reads: only those reads; the others never leave HBM),
+    names are read<index>, qualities a constant."""
     import numpy as np
-    import kevlar_amd
     from kevlar_amd.annotated import AnnotatedReads
     r, o, a = (np.asarray(x) for x in hits)
-    t0 = time.perf_counter()
     ur, first = np.unique(r, return_index=True)
     n = len(ur)
     seqs = np.empty((n, L), dtype=np.uint8)
@@ -723,6 +719,20 @@ def band_downstream(args, wl, hits, genome_len, seed, L, k, S, synth):
     ann.mates, ann.mate_offs = b'', np.zeros(1, dtype=np.uint64)
     ann.ksize, ann.nsamples = k, S
     ann._finish()
+    return ann
+
+
+def band_downstream(args, wl, hits, genome_len, seed, L, k, S, synth):
+    """What follows the scan in the workflow (kevlar/workflows/mark-I/Snakefile:236-309), on the band's hits: the annotated
+    reads written as an augmented FASTQ file, `kevlar filter` on it, `kevlar partition` on what survives."""
+    import io
+    import tempfile
+    import numpy as np
+    import kevlar_amd
+    r = np.asarray(hits[0])
+    t0 = time.perf_counter()
+    ann = band_annotated_reads(hits, genome_len, seed, L, k, S, synth)
+    n = ann.n
     t_text = time.perf_counter()
     tmp = tempfile.mkdtemp(prefix='kv_band_')
     novel_file, filtered_file, part_file = (os.path.join(tmp, f) for f in ('band.novel.augfastq', 'band.filtered.augfastq', 'band.part.augfastq'))

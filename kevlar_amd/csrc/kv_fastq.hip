@@ -414,7 +414,9 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         const bool final = d->gz ? gz_last : d->plain ? b0 + fresh == d->image_size : m1 == d->members.size();
         const uint64_t total_in = d->carry_len + fresh;
         if (total_in == 0) { d->done = true; return KV_OK; }     // end of file: nothing of the previous batch has been touched
-        d->n_batch = 0;
+        // (the batch served last -- its text buffer, its line starts, n_batch -- stays fetchable until a NEW batch with records
+        // in it has been produced: a caller that kept it asks once more only to learn that the file has ended, and a file that
+        // ends in blank lines gets here with a carry of a byte or two)
         const int nxt = d->cur ^ 1;
         KV_HIP(d->text[nxt].need(kv_round_up(total_in + 64, 4096)));
         uint8_t *text = (uint8_t *)d->text[nxt].p;
@@ -472,6 +474,7 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
             // budget is not spent: what has been inflated waits as the carry and another segment joins it
             const uint64_t have = n_lines / 4;
             const double each = have ? (double)total_in / (double)have : per_read;
+            d->n_batch = 0;               // the other text buffer -- the previous batch's -- is written next
             d->cur = nxt;
             d->carry_at = 0;
             d->carry_len = total_in;
@@ -503,10 +506,9 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         }
         d->next_member = m1;
         d->next_byte = b0 + (d->plain ? fresh : 0);
-        const int prev = d->cur;
+        if (n == 0) { d->done = true; d->carry_len = 0; return KV_OK; }      // blank tail: the previous batch is still the current one
         d->cur = nxt;
-        (void)prev;
-        if (n == 0) { d->done = true; d->carry_len = 0; return KV_OK; }
+        d->n_batch = 0;
         // ---- line starts, records
         KV_HIP(d->buf->lines.need(kv_round_up((4 * n + 2) * 8, 256)));
         uint64_t *line_start = (uint64_t *)d->buf->lines.p;

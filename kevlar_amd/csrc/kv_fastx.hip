@@ -509,8 +509,10 @@ extern "C" int kv_fastx_next(kv_fastx *f, uint64_t max_reads, int upload, kv_rea
         kv_fastq_device_close(f->dev);
         f->dev = nullptr;
         f->dev_candidate = false;
-        // (KV_ERR_HIP: the device path's scratch did not fit next to big sketches, or a smaller GPU -- the host parser reads
-        // the same file with a few megabytes; a GPU that is really gone fails the next call anyway)
+        // (KV_ERR_HIP with hipErrorOutOfMemory: the device path's scratch did not fit next to big sketches, or a smaller GPU --
+        // the host parser reads the same file with a few megabytes.  Any other HIP error -- an illegal address, a lost context --
+        // is a fault of the device path, not a reason to read the file another way: it goes to the caller)
+        if (rc == KV_ERR_HIP && kv_last_hip_code != (int)hipErrorOutOfMemory) return rc;
         if (rc != KV_ERR_TYPE && rc != KV_ERR_HIP) return rc;
         (void)hipGetLastError();
         uint64_t left = f->num_reads;

@@ -12,6 +12,7 @@
 // errors / device / stream
 // ---------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
+thread_local int kv_last_hip_code = 0;
 
 void kv_set_error(const char *fmt, ...)
 {
@@ -532,6 +533,7 @@ extern "C" int kv_sketch_clear(kv_sketch *s)
     s->n_unique = 0;
     s->occ_dirty = false;
     s->skm_off = false;
+    s->skm_scan_off = false;
     s->abl.valid = false;
     return KV_OK;
 }
@@ -827,6 +829,7 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
     if (d_ascii) (void)hipFree(d_ascii);
     if (d_offs) (void)hipFree(d_offs);
     if (e != hipSuccess) {
+        kv_last_hip_code = (int)e;
         kv_set_error("read batch upload failed: %s", hipGetErrorString(e));
         kv_reads_destroy(r);
         return KV_ERR_HIP;
@@ -903,6 +906,7 @@ bool uniform_reads(kv_reads *r, const TextSource *text, const uint32_t *lens, ui
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
+        kv_last_hip_code = (int)e;
         kv_set_error("read batch upload failed: %s", hipGetErrorString(e));
         *rc = KV_ERR_HIP;
     }
@@ -983,6 +987,7 @@ int reads_from_packed(const uint32_t *words, const TextSource *text, const uint3
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
+        kv_last_hip_code = (int)e;
         kv_set_error("read batch upload failed: %s", hipGetErrorString(e));
         kv_reads_destroy(r);
         return KV_ERR_HIP;
@@ -1034,6 +1039,7 @@ static int reads_packed_uniform(const uint32_t *words, const std::function<void(
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
+        kv_last_hip_code = (int)e;
         kv_set_error("read batch upload failed: %s", hipGetErrorString(e));
         kv_reads_destroy(r);
         return KV_ERR_HIP;

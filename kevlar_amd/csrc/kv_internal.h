@@ -71,6 +71,11 @@ struct kv_sketch {
     uint64_t *d_counters; // [0] n_kmers, [1] n_unique (device accumulators)
     bool skm_off = false;  // the last batch counted through the super-k-mer front end did not deduplicate: skip it until cleared
     double skm_distinct = 0.0;   // distinct / all k-mers of that batch (0: none yet): sizes the buckets of the next one
+    // the scan's own memory (kv_novel_scan, this sketch as the first case sample): the last batch it cut into super-k-mers did not
+    // fit the tables -- nothing to deduplicate at that coverage -- and was scanned again tile by tile; batches that follow go
+    // straight to the tile scan until the sketch is cleared.  (The count cannot say: a banded count of a sparse batch never
+    // takes the super-k-mer front end, so skm_off stays unset there.)
+    bool skm_scan_off = false;
     // kv_sketch_clear only notes that the tables are zero: the partitioned count's apply stage, which rewrites every
     // slice anyway, then starts from zeroed LDS instead of loading the slice (no memset, no first read of the tables);
     // every other reader or writer of the tables calls kv_sketch_ready first, which does the memset after all
@@ -228,10 +233,14 @@ int kv_skm_mex_pack(const kv_mex_plan *plan, const uint64_t *d_seg, const uint32
 
 // error plumbing -------------------------------------------------------------------------
 void kv_set_error(const char *fmt, ...);
+// the hipError_t behind the calling thread's last KV_ERR_HIP (KV_HIP notes it): callers that can do without the GPU for a step
+// tell "out of memory" from a device fault by it
+extern thread_local int kv_last_hip_code;
 #define KV_HIP(call)                                                                        \
     do {                                                                                    \
         hipError_t e__ = (call);                                                            \
         if (e__ != hipSuccess) {                                                            \
+            kv_last_hip_code = (int)e__;                                                    \
             kv_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,  \
                          __LINE__);                                                         \
             return KV_ERR_HIP;                                                              \

@@ -446,7 +446,7 @@ int attach_vcache(NovelParams &p, kv_sketch *const *ctrls, int ncase, int nctrl,
 }
 
 int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers, bool use_skm, const std::function<int()> &prepare_tile_scan,
-               uint32_t *d_mask, uint64_t mask_stride, kv_hits **out);
+               uint32_t *d_mask, uint64_t mask_stride, kv_hits **out, bool *skm_overflowed = nullptr);
 
 }  // namespace
 
@@ -486,7 +486,24 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     kv_reads_num_kmers(reads, k, &n_kmers);
     // large batches: evaluate every DISTINCT k-mer once over the batch's super-k-mer buckets (kv_skm.hip); otherwise
     // (and as the fallback) every k-mer of every read, with the verdict cache absorbing the repeats
-    const bool use_skm = p.screen == 0 && kv_skm_eligible(cases[0], reads, n_kmers, true);
+    bool use_skm = p.screen == 0 && kv_skm_eligible(cases[0], reads, n_kmers, true);
+    const bool skm_by_name = getenv("KV_NOVEL_PATH") != nullptr;          // asked for by name: no second-guessing
+    if (use_skm && !skm_by_name) {
+        // Is there anything to deduplicate?  (i) the scan remembers: the last batch it cut for this case sample overflowed the
+        // tables and was scanned again tile by tile (config 4's batches of 0.6x coverage: 48 per sample, every one of them scanned
+        // twice before this flag existed).  (ii) before the first cut: the case sketch knows how many distinct k-mers it holds
+        // (n_unique; of its band only, if banded); a batch of a sample at sequencing coverage brings ~5 k-mers per distinct k-mer
+        // of the sample, a batch with less than one for every two distinct k-mers is below ~3x coverage, where more than half of its
+        // k-mers are distinct and the bucket tables do not hold them.
+        const double held = (double)cases[0]->n_unique * (band_mode == KV_BAND_RANGE ? (double)nbands : 1.0);
+        const bool sparse = held > 0.0 && (double)n_kmers < 0.5 * held;
+        if (cases[0]->skm_scan_off || sparse) {
+            use_skm = false;
+            if (getenv("KV_SKM_VERBOSE"))
+                fprintf(stderr, "[kv_novel] tile scan: %s\n", cases[0]->skm_scan_off ? "the previous batch of this case sample did not fit the super-k-mer tables"
+                                                                                      : "the batch is a small share of the distinct k-mers the case sketch holds");
+        }
+    }
     auto prepare_tile_scan = [&]() -> int {
         const int rc = attach_vcache(p, ctrls, ncase, nctrl, ctrl_max, n_kmers, st);
         if (rc != KV_OK) return rc;
@@ -497,14 +514,17 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         }
         return KV_OK;
     };
-    return scan_reads(p, reads, fam, n_kmers, use_skm, prepare_tile_scan, d_mask, mask_stride, out);
+    bool skm_overflowed = false;
+    const int rc = scan_reads(p, reads, fam, n_kmers, use_skm, prepare_tile_scan, d_mask, mask_stride, out, &skm_overflowed);
+    if (skm_overflowed) cases[0]->skm_scan_off = true;
+    return rc;
 }
 
 namespace {
 
 // mark -> count per tile -> emit in (read, offset) order: shared by kv_novel_scan and kv_novel_scan_set
 int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers, bool use_skm, const std::function<int()> &prepare_tile_scan,
-               uint32_t *d_mask, uint64_t mask_stride, kv_hits **out)
+               uint32_t *d_mask, uint64_t mask_stride, kv_hits **out, bool *skm_overflowed)
 {
     const int k = p.hp.k, S = p.ncase + p.nctrl;
     const uint64_t min_stride = reads->max_len >= (uint32_t)k ? reads->max_len - (uint32_t)k + 1 : 1;
@@ -576,6 +596,7 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
         if (rc == KV_ERR_CAPACITY) {
             // every bit set so far is a true hit, so the tile scan can simply run on top of the same mask
             marked_by_skm = false;
+            if (skm_overflowed) *skm_overflowed = true;
             const int rc2 = prepare_tile_scan();
             if (rc2 != KV_OK) { delete hits; *out = nullptr; return rc2; }
         } else if (rc != KV_OK) {

@@ -1314,7 +1314,18 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
         if (threadIdx.x == 0) {
             if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
             else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
-            else next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET;
+            else {
+                const unsigned long long ticket = atomicAdd(&sg.ctr[4], 1ull);
+                next_bucket = (uint32_t)ticket * SKM_BUCKETS_PER_TICKET;
+                // the count pass's early exit, for a scan that cut the batch itself: once 2 % of the buckets are done, more than
+                // 4 % of their k-mers outside the tables (a batch of low coverage: nearly every k-mer distinct) raise the flag --
+                // the caller then scans tile by tile, and remembers -- instead of pushing the whole batch through the loose list
+                const unsigned long long done = ticket * SKM_BUCKETS_PER_TICKET;
+                if (done * 50ull >= sg.n_buckets) {
+                    const unsigned long long now = __hip_atomic_load(&sg.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), start = sg.ctr[6];
+                    if (now > start && (now - start) * 25ull > done * sg.bucket_kmers) sg.ctr[1] = 1;
+                }
+            }
             any_hit = 0;
         }
         // collect the distinct k-mers

@@ -153,9 +153,21 @@ def assemble_partitions(names, name_offs, seqs, seq_offs, component_of, minabund
     reads, part = holder[nodes], place[comp[nodes]]
     if dedup:
         h1, h2 = _canonical_hashes(seqs, seq_offs, reads)
-        order = np.lexsort((h1, part))                              # stable: equal keys stay in member order
+        order = np.lexsort((h2, h1, part))                          # by partition, then by both hashes; stable: equal keys stay in member order
         first = np.ones(len(order), dtype=bool)
         first[1:] = (part[order][1:] != part[order][:-1]) | (h1[order][1:] != h1[order][:-1]) | (h2[order][1:] != h2[order][:-1])
+        # the reference compares the canonical sequences themselves (kevlar/partition.py:26-33): a read is dropped only if its
+        # sequence really is the one its run of equal hashes started with (only would-be duplicates pay for the comparison)
+        dup = np.flatnonzero(~first)
+        if len(dup):
+            head = np.maximum.accumulate(np.where(first, np.arange(len(order)), 0))
+            view = memoryview(seqs)
+            for j in dup.tolist():
+                a_, b_ = int(reads[order[j]]), int(reads[order[head[j]]])
+                sa = bytes(view[int(seq_offs[a_]):int(seq_offs[a_ + 1])]).decode('ascii', 'replace')
+                sb = bytes(view[int(seq_offs[b_]):int(seq_offs[b_ + 1])]).decode('ascii', 'replace')
+                if sa != sb and kevlar_amd.revcommin(sa) != kevlar_amd.revcommin(sb):
+                    first[j] = True                                 # two sequences, one pair of hashes: both stay
         kept = np.sort(order[first])
         reads, part = reads[kept], part[kept]
         if minabund:

@@ -560,6 +560,7 @@ typedef struct {
     uint64_t n_reads, chunk;
     uint64_t *next;             /* shared cursor: threads pull chunks of reads, like khmer's parser */
     uint64_t n_added;
+    int nbands, band;           /* hash-range banding of consume_seqfile_banding (kevlar/count.py:62-66); nbands 0: none */
 } mt_count_job;
 
 static void *mt_count_worker(void *arg)
@@ -569,6 +570,8 @@ static void *mt_count_worker(void *arg)
     char *clean = NULL;
     size_t cap = 0;
     uint64_t occ = 0, uniq = 0;
+    uint64_t lo = 0, hi = 0;
+    if (j->nbands > 0) kvo_band_bounds(j->nbands, j->band, &lo, &hi);
     for (;;) {
         const uint64_t r0 = __atomic_fetch_add(j->next, j->chunk, __ATOMIC_RELAXED);
         if (r0 >= j->n_reads) break;
@@ -580,7 +583,9 @@ static void *mt_count_worker(void *arg)
             if (len > cap) { free(clean); clean = (char *)malloc(len); cap = len; }
             for (size_t i = 0; i < len; ++i) clean[i] = clean_base(seq[i]);
             for (size_t i = 0; i + (size_t)k <= len; ++i) {
-                add_hash_atomic(j->s, kvo_hash(j->s->kind, clean + i, k), &occ, &uniq);
+                const uint64_t h = kvo_hash(j->s->kind, clean + i, k);
+                if (j->nbands > 0 && !(h >= lo && h < hi)) continue;      /* same test as kvo_consume */
+                add_hash_atomic(j->s, h, &occ, &uniq);
                 j->n_added++;
             }
         }
@@ -593,6 +598,12 @@ static void *mt_count_worker(void *arg)
 
 uint64_t kvo_consume_reads_mt(kvo_sketch *s, const char *bases, const uint64_t *offs, uint64_t n_reads, int nthreads)
 {
+    return kvo_consume_reads_mt_banded(s, bases, offs, n_reads, nthreads, 0, 0);
+}
+
+uint64_t kvo_consume_reads_mt_banded(kvo_sketch *s, const char *bases, const uint64_t *offs, uint64_t n_reads, int nthreads,
+                                     int nbands, int band)
+{
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
     pthread_t th[256];
@@ -600,7 +611,7 @@ uint64_t kvo_consume_reads_mt(kvo_sketch *s, const char *bases, const uint64_t *
     uint64_t next = 0, total = 0;
     for (int t = 0; t < nthreads; ++t) {
         jobs[t].s = s; jobs[t].bases = bases; jobs[t].offs = offs; jobs[t].n_reads = n_reads;
-        jobs[t].chunk = 1024; jobs[t].next = &next; jobs[t].n_added = 0;
+        jobs[t].chunk = 1024; jobs[t].next = &next; jobs[t].n_added = 0; jobs[t].nbands = nbands; jobs[t].band = band;
         pthread_create(&th[t], NULL, mt_count_worker, &jobs[t]);
     }
     for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); total += jobs[t].n_added; }
@@ -624,6 +635,66 @@ static void *mt_scan_worker(void *arg)
     j->nhits = kvo_novel_scan(j->cases, j->ncase, j->ctrls, j->nctrl, j->bases, j->offs + j->r0, j->r1 - j->r0,
                               j->ksize, j->case_min, j->ctrl_max, 0, 0, 0, 0, NULL, NULL, NULL, 0, NULL);
     return NULL;
+}
+
+typedef struct {
+    kvo_sketch *const *cases; int ncase;
+    kvo_sketch *const *ctrls; int nctrl;
+    const char *bases; const uint64_t *offs;
+    uint64_t r0, r1;
+    int ksize, case_min, ctrl_max, band_mode, nbands, band;
+    uint32_t *hr; uint16_t *ho; uint8_t *ha; int64_t cap;
+    int64_t nhits;
+} mt_scan_hits_job;
+
+static void *mt_scan_hits_worker(void *arg)
+{
+    mt_scan_hits_job *j = (mt_scan_hits_job *)arg;
+    j->nhits = kvo_novel_scan(j->cases, j->ncase, j->ctrls, j->nctrl, j->bases, j->offs + j->r0, j->r1 - j->r0, j->ksize, j->case_min,
+                              j->ctrl_max, 0, j->band_mode, j->nbands, j->band, j->hr, j->ho, j->ha, j->cap, NULL);
+    return NULL;
+}
+
+/* The scan loop of kvo_novel_scan (kevlar/novel.py:123-169, no abundance screen: a read's verdict then depends on that read
+ * alone) over contiguous ranges of reads on nthreads threads; the ranges' hits are concatenated in read order, so the result is
+ * kvo_novel_scan's.  Returns the number of hits (which may exceed cap: the caller retries with room), -1 without memory. */
+int64_t kvo_novel_scan_mt(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl, const char *bases,
+                          const uint64_t *offs, uint64_t n_reads, int ksize, int case_min, int ctrl_max, int band_mode, int nbands,
+                          int band, uint32_t *hit_read, uint16_t *hit_off, uint8_t *hit_abund, int64_t cap, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    const int S = ncase + nctrl;
+    pthread_t th[256];
+    mt_scan_hits_job jobs[256];
+    const int64_t each = cap / nthreads;
+    for (int t = 0; t < nthreads; ++t) {
+        mt_scan_hits_job *j = &jobs[t];
+        j->cases = cases; j->ncase = ncase; j->ctrls = ctrls; j->nctrl = nctrl; j->bases = bases; j->offs = offs;
+        j->r0 = n_reads * (uint64_t)t / (uint64_t)nthreads; j->r1 = n_reads * (uint64_t)(t + 1) / (uint64_t)nthreads;
+        j->ksize = ksize; j->case_min = case_min; j->ctrl_max = ctrl_max; j->band_mode = band_mode; j->nbands = nbands; j->band = band;
+        j->cap = each; j->nhits = 0;
+        j->hr = (uint32_t *)malloc((size_t)(each > 0 ? each : 1) * 4);
+        j->ho = (uint16_t *)malloc((size_t)(each > 0 ? each : 1) * 2);
+        j->ha = (uint8_t *)malloc((size_t)(each > 0 ? each : 1) * (size_t)S);
+        if (!j->hr || !j->ho || !j->ha) return -1;
+        pthread_create(&th[t], NULL, mt_scan_hits_worker, j);
+    }
+    int64_t total = 0, worst = 0;
+    for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); if (jobs[t].nhits > worst) worst = jobs[t].nhits; }
+    for (int t = 0; t < nthreads; ++t) {
+        mt_scan_hits_job *j = &jobs[t];
+        if (worst <= each) {
+            for (int64_t i = 0; i < j->nhits; ++i) {
+                hit_read[total + i] = j->hr[i] + (uint32_t)j->r0;        /* kvo_novel_scan numbers the reads of its range from 0 */
+                hit_off[total + i] = j->ho[i];
+                memcpy(hit_abund + (size_t)(total + i) * (size_t)S, j->ha + (size_t)i * (size_t)S, (size_t)S);
+            }
+            total += j->nhits;
+        }
+        free(j->hr); free(j->ho); free(j->ha);
+    }
+    return worst <= each ? total : worst * nthreads;
 }
 
 int64_t kvo_novel_scan_count_mt(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl,

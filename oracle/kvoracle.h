@@ -98,6 +98,13 @@ int64_t kvo_novel_scan(kvo_sketch *const *cases, int ncase, kvo_sketch *const *c
 /* --- multi-threaded legs of bench.py's cpu_baseline (kevlar/count.py:41-76: threads share one sketch, atomic
  * saturating adds).  Tables and n_occupied equal the single-thread result; the scan leg only counts its hits. */
 uint64_t kvo_consume_reads_mt(kvo_sketch *s, const char *bases, const uint64_t *offs, uint64_t n_reads, int nthreads);
+/* the same with the hash-range banding of consume_seqfile_banding (kevlar/count.py:62-66): only band `band` of `nbands` is added */
+uint64_t kvo_consume_reads_mt_banded(kvo_sketch *s, const char *bases, const uint64_t *offs, uint64_t n_reads, int nthreads,
+                                     int nbands, int band);
+/* kvo_novel_scan (no abundance screen) over contiguous ranges of reads on nthreads threads, hits concatenated in read order */
+int64_t kvo_novel_scan_mt(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl, const char *bases,
+                          const uint64_t *offs, uint64_t n_reads, int ksize, int case_min, int ctrl_max, int band_mode, int nbands,
+                          int band, uint32_t *hit_read, uint16_t *hit_off, uint8_t *hit_abund, int64_t cap, int nthreads);
 int64_t kvo_novel_scan_count_mt(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl,
                                 const char *bases, const uint64_t *offs, uint64_t n_reads, int ksize,
                                 int case_min, int ctrl_max, int nthreads);

@@ -66,6 +66,10 @@ def _load():
         'kvo_consume_reads': (u64, [vp, cp, pu64, u64, i32, i32, vp, i32, i32]),
         'kvo_band_bounds': (None, [i32, i32, pu64, pu64]),
         'kvo_consume_reads_mt': (u64, [vp, cp, pu64, u64, i32]),
+        'kvo_consume_reads_mt_banded': (u64, [vp, cp, pu64, u64, i32, i32, i32]),
+        'kvo_novel_scan_mt': (ctypes.c_int64, [
+            ctypes.POINTER(vp), i32, ctypes.POINTER(vp), i32, cp, pu64, u64, i32, i32, i32, i32, i32, i32,
+            ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint8), ctypes.c_int64, i32]),
         'kvo_novel_scan_count_mt': (ctypes.c_int64, [ctypes.POINTER(vp), i32, ctypes.POINTER(vp), i32, cp, pu64, u64,
                                                      i32, i32, i32, i32]),
         'kvo_abundance_distribution': (u64, [vp, vp, cp, ctypes.c_size_t, pu64]),
@@ -377,6 +381,30 @@ def consume_reads(sketch, bases, offs, n_reads, nbands=0, band=0, mask=None, thr
 def consume_reads_mt(sketch, bases, offs, n_reads, nthreads):
     """khmer-style threaded consume (kevlar/count.py:41-76): nthreads threads, one sketch, atomic saturating adds"""
     return int(lib.kvo_consume_reads_mt(sketch._h, bases, offs, n_reads, int(nthreads)))
+
+
+def consume_reads_mt_banded(sketch, bases, offs, n_reads, nthreads, nbands, band):
+    """consume_reads_mt keeping only hash band `band` of `nbands` (consume_seqfile_banding, kevlar/count.py:62-66)"""
+    return int(lib.kvo_consume_reads_mt_banded(sketch._h, bases, offs, n_reads, int(nthreads), int(nbands), int(band)))
+
+
+def novel_scan_mt(cases, ctrls, bases, offs, n_reads, ksize, case_min, ctrl_max, nthreads, band_mode=0, nbands=0, band=0, cap=1 << 22):
+    """novel_scan (no abundance screen) on nthreads threads -> (read u32[n], offset u16[n], abund u8[n, S]) numpy arrays in scan order"""
+    import numpy as np
+    S = len(cases) + len(ctrls)
+    vp = ctypes.c_void_p
+    ca = (vp * len(cases))(*[c._h for c in cases])
+    cb = (vp * max(1, len(ctrls)))(*[c._h for c in ctrls])
+    while True:
+        hr, ho, ha = np.empty(cap, dtype=np.uint32), np.empty(cap, dtype=np.uint16), np.empty((cap, S), dtype=np.uint8)
+        n = lib.kvo_novel_scan_mt(ca, len(cases), cb, len(ctrls), bases, offs, n_reads, ksize, case_min, ctrl_max, band_mode, nbands, band,
+                                  hr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), ho.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
+                                  ha.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), cap, int(nthreads))
+        if n < 0:
+            raise MemoryError('kvo_novel_scan_mt')
+        if n <= cap:                      # (a range that outgrew its share of the buffers comes back as a number above cap)
+            return hr[:n].copy(), ho[:n].copy(), ha[:n].copy()
+        cap = int(n) * 2
 
 
 def novel_scan_count_mt(cases, ctrls, bases, offs, n_reads, ksize, case_min, ctrl_max, nthreads):

@@ -11,6 +11,10 @@ checked through properties that do not depend on size:
 * every reported interesting k-mer satisfies the thresholds, the scan is idempotent, its bit
   mask and its hit list agree, and a seeded sample of hits re-derives bit-exactly from the oracle
   evaluated on the same table bytes.
+
+Round 3 added the oracle itself at full size for the tables; round 4 for the scans too, whole samples: the oracle's scan loop
+runs over ALL reads of the proband on the host cores (kvo_novel_scan_mt) and every hit of each of the three scan kernels --
+k_skm_novel_list (what bench.py times), k_skm_novel, k_novel_mark -- is compared with it, configs 2 and 5.
 """
 import os
 
@@ -124,53 +128,30 @@ def test_fullsize_novel_scan_properties(hk, ok, trio):
     assert len(want) > 1000
 
 
-def test_fullsize_config5_k51_four_samples(hk, ok):
-    """BASELINE.json config 5: proband + 3 controls, k=51 (two-word keys, three murmur blocks + tail), 30x, 25 Mb"""
+@pytest.fixture(scope='module')
+def quad(hk):
+    """BASELINE.json config 5's family: proband + 3 controls (30x, 25 Mb), packed"""
     from kevlar_amd import synth
-    k, names = 51, ('proband', 'mother', 'father', 'sibling1')
-    packed = synth.trio_reads_packed(25_000_000, 30, L, extra_controls=1)
-    batches = {n: hk.ReadBatch.from_packed(packed[n], L) for n in names}
-    n_reads, nk = packed['proband'].shape[0], L - k + 1
-    sk = {n: hk.Counttable(k, MEM / 4, 4) for n in names}
-    for n in names[1:] + names[:1]:
-        assert sk[n].consume_batch(batches[n]) == n_reads * nk
+    return synth.trio_reads_packed(25_000_000, 30, L, extra_controls=1)
+
+
+def test_fullsize_config5_k51_count_paths_agree(hk, quad):
+    """k = 51 (two-word keys, three murmur blocks + tail): the one-item-per-k-mer partition and the super-k-mer count give the
+    same tables and occupancy (the scans and the tables themselves meet the oracle below)"""
+    k = 51
+    batch = hk.ReadBatch.from_packed(quad['sibling1'], L)
+    n_reads, nk = quad['sibling1'].shape[0], L - k + 1
+    mine = hk.Counttable(k, MEM / 4, 4)
+    assert mine.consume_batch(batch) == n_reads * nk
     os.environ['KV_COUNT_PATH'] = 'binned'
     try:
         other = hk.Counttable(k, MEM / 4, 4)
-        other.consume_batch(batches['sibling1'])
+        other.consume_batch(batch)
     finally:
         os.environ.pop('KV_COUNT_PATH', None)
-    for x, y in zip(tables(sk['sibling1']), tables(other)):
+    for x, y in zip(tables(mine), tables(other)):
         assert np.array_equal(x, y)
-    assert sk['sibling1'].n_occupied() == other.n_occupied() == int(np.count_nonzero(tables(other)[0]))
-    del other
-    cases, ctrls = [sk['proband']], [sk[n] for n in names[1:]]
-    r, o, a, _ = hk.novel_scan(cases, ctrls, batches['proband'], 6, 1)
-    os.environ['KV_NOVEL_PATH'] = 'tiles'
-    try:
-        r2, o2, a2, _ = hk.novel_scan(cases, ctrls, batches['proband'], 6, 1)
-    finally:
-        os.environ.pop('KV_NOVEL_PATH', None)
-    assert np.array_equal(r, r2) and np.array_equal(o, o2) and np.array_equal(a, a2)
-    assert len(r) > 100000 and a.shape[1] == 4
-    assert (a[:, 0] >= 6).all() and (a[:, 1:] <= 1).all()
-    assert (np.diff(r.astype(np.int64) * nk + o) > 0).all()
-    # a seeded sample of reads replayed by the oracle's hash + Count-Min minimum over the SAME table bytes
-    tabs = {n: tables(sk[n]) for n in names}
-    sizes = sk['proband'].hashsizes()
-    rng = np.random.default_rng(2)
-    sample = np.concatenate((rng.choice(np.unique(r), size=100, replace=False), rng.integers(0, n_reads, size=100)))
-    ref = ok.Counttable(k, MEM / 4, 4)
-    want = {}
-    for ridx, seq in zip(sample.tolist(), synth.unpack_reads(packed['proband'][sample], L)):
-        for i in range(nk):
-            h = ref.hash(seq[i:i + k])
-            ab = tuple(min(int(tabs[n][t][h % sizes[t]]) for t in range(4)) for n in names)
-            if ab[0] >= 6 and max(ab[1:]) <= 1:
-                want[(ridx, i)] = ab
-    sel = np.isin(r, sample)
-    got = {(x, y): tuple(z) for x, y, z in zip(r[sel].tolist(), o[sel].tolist(), a[sel].tolist())}
-    assert got == want and len(want) > 500
+    assert mine.n_occupied() == other.n_occupied() == int(np.count_nonzero(tables(other)[0]))
 
 
 # ---- full size against the ORACLE itself (not against another device path) ------------------------------------------
@@ -215,42 +196,140 @@ def assert_same_sketch(dev, ref):
     assert dev.n_occupied() == ref.n_occupied()
 
 
+def launches(hk, scope):
+    """launches of a profile scope since kv_prof_reset"""
+    import ctypes
+    from kevlar_amd import _lib
+    ms, n = ctypes.c_double(), ctypes.c_uint64()
+    _lib.load().kv_prof_get(scope.encode(), ctypes.byref(ms), ctypes.byref(n))
+    return int(n.value)
+
+
+class Profiled(object):
+    """kernel launches by profile scope inside a with block"""
+    def __init__(self, hk):
+        from kevlar_amd import _lib
+        self.hk, self.lib = hk, _lib.load()
+
+    def __enter__(self):
+        self.lib.kv_prof_reset()
+        self.lib.kv_prof_enable(1)
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.kv_prof_enable(0)
+
+    def count(self, scope):
+        return launches(self.hk, scope)
+
+
+def scan_all_ways(hk, cases, ctrls, batch, case_min, ctrl_max, first_from_list):
+    """the hits of `batch` from every scan kernel the product has: the one that runs after a count with expect_scan()
+    (k_skm_novel_list: what bench.py times and `kevlar novel` runs for a one-batch case sample), the walk over re-built buckets
+    (k_skm_novel) and the per-k-mer tile scan (k_novel_mark); each with the launches that prove which one it was"""
+    out = {}
+    with Profiled(hk) as prof:
+        out['list'] = hk.novel_scan(cases, ctrls, batch, case_min, ctrl_max)[:3]
+        n_list, n_walk = prof.count('k_skm_novel_list'), prof.count('k_skm_novel')
+    if first_from_list:
+        assert n_list == 1 and n_walk == 0, 'the scan behind a hinted count must go by the distinct list ({} / {})'.format(n_list, n_walk)
+    with Profiled(hk) as prof:          # one scan per bucketing: the next one cuts the reads again and walks
+        out['walk'] = hk.novel_scan(cases, ctrls, batch, case_min, ctrl_max)[:3]
+        assert prof.count('k_skm_novel') == 1 and prof.count('k_skm_novel_list') == 0
+    os.environ['KV_NOVEL_PATH'] = 'tiles'
+    try:
+        with Profiled(hk) as prof:
+            out['tiles'] = hk.novel_scan(cases, ctrls, batch, case_min, ctrl_max)[:3]
+            assert prof.count('k_novel_mark') == 1 and prof.count('k_skm_novel') == 0 and prof.count('k_skm_novel_list') == 0
+    finally:
+        os.environ.pop('KV_NOVEL_PATH', None)
+    return out
+
+
+def assert_hits_equal(got, want, what):
+    r, o, a = got
+    wr, wo, wa = want
+    assert len(r) == len(wr), '{}: {} hits, the oracle has {}'.format(what, len(r), len(wr))
+    assert np.array_equal(np.asarray(r, dtype=np.uint32), wr), what
+    assert np.array_equal(np.asarray(o, dtype=np.uint32), wo.astype(np.uint32)), what
+    assert np.array_equal(np.asarray(a, dtype=np.uint8), wa), what
+
+
 def test_fullsize_config2_tables_and_scan_equal_the_oracle(hk, ok, trio):
-    """every table byte of all three 7.5 M-read samples (2 GB sketches) against the oracle's count, n_occupied, and the
-    oracle's own scan loop (kevlar/novel.py:123-169 restated) over 120 000 consecutive reads of the proband"""
+    """BASELINE.json config 2 against the oracle itself, whole samples: every table byte and n_occupied of all three 7.5 M-read
+    samples (2 GB sketches) against the oracle's threaded count, and EVERY hit of the proband -- from each of the three scan
+    kernels, first of all the one bench.py times (k_skm_novel_list behind a count with expect_scan) -- against the oracle's own
+    scan loop (kevlar/novel.py:123-169 restated) over all 7.5 M reads, split over the host cores"""
     packed, batches = trio
-    names = ('mother', 'father', 'proband')
+    names = ('mother', 'father', 'proband')               # the case sample last: its bucketed batch is what the scan finds
     cores = host_cores()
     n_reads = packed['proband'].shape[0]
-    dev, ref, keep = {}, {}, {}
+    dev, ref, keep = {}, {}, None
+    had = os.environ.get('KV_SKM_DL')
+    os.environ['KV_SKM_DL'] = '1'            # (a stream's first batch gets no list unless asked: bench.py asks the same way)
+    try:
+        for n in names:
+            dev[n] = hk.Counttable(K, MEM / 4, 4)
+            if n == 'proband':
+                dev[n].expect_scan()
+        with Profiled(hk) as prof:
+            for n in names:
+                assert dev[n].consume_batch(batches[n]) == n_reads * (L - K + 1)
+            assert prof.count('k_skm_count') == 3 and prof.count('k_consume') == 0
+        scans = scan_all_ways(hk, [dev['proband']], [dev['mother'], dev['father']], batches['proband'], 6, 1, first_from_list=True)
+    finally:
+        if had is None:
+            os.environ.pop('KV_SKM_DL', None)
+        else:
+            os.environ['KV_SKM_DL'] = had
     for n in names:
-        dev[n] = hk.Counttable(K, MEM / 4, 4)
-        assert dev[n].consume_batch(batches[n]) == n_reads * (L - K + 1)
         bases, offs_p, offs = ascii_block(packed[n], L)
         ref[n] = ok.Counttable(K, MEM / 4, 4)
         assert ok.consume_reads_mt(ref[n], bases, offs_p, n_reads, cores) == n_reads * (L - K + 1)
         assert_same_sketch(dev[n], ref[n])
         if n == 'proband':
             keep = (bases, offs_p, offs)
-    r, o, a, _ = hk.novel_scan([dev['proband']], [dev['mother'], dev['father']], batches['proband'], 6, 1)
-    n_replay = 120_000
-    hits, _ = ok.novel_scan([ref['proband']], [ref['mother'], ref['father']], keep[0], keep[1], n_replay, K, 6, 1, cap=1 << 18)
-    sel = r < n_replay
-    got = list(zip(r[sel].tolist(), o[sel].tolist(), (tuple(x) for x in a[sel].tolist())))
-    assert got == hits
-    assert len(hits) > 10000
+    want = ok.novel_scan_mt([ref['proband']], [ref['mother'], ref['father']], keep[0], keep[1], n_reads, K, 6, 1, cores)
+    assert len(want[0]) > 1_000_000
+    for way in ('list', 'walk', 'tiles'):
+        assert_hits_equal(scans[way], want, 'config 2, scan by ' + way)
 
 
-def test_fullsize_config5_one_sample_equals_the_oracle(hk, ok):
-    """config 5's k = 51 (two-word keys, three murmur blocks + tail): one whole 7.5 M-read sample, every table byte"""
-    from kevlar_amd import synth
-    k = 51
-    packed = synth.trio_reads_packed(25_000_000, 30, L, extra_controls=1)
-    words = packed['sibling1']
-    n_reads = words.shape[0]
-    dev = hk.Counttable(k, MEM / 4, 4)
-    assert dev.consume_batch(hk.ReadBatch.from_packed(words, L)) == n_reads * (L - k + 1)
-    bases, offs_p, _offs = ascii_block(words, L)
-    ref = ok.Counttable(k, MEM / 4, 4)
-    assert ok.consume_reads_mt(ref, bases, offs_p, n_reads, host_cores()) == n_reads * (L - k + 1)
-    assert_same_sketch(dev, ref)
+def test_fullsize_config5_tables_and_scan_equal_the_oracle(hk, ok, quad):
+    """BASELINE.json config 5 -- proband + 3 controls, k = 51 (two-word keys, three murmur blocks + tail), 30x, 25 Mb -- whole samples
+    against the oracle: every table byte of all four sketches, and every hit of each scan kernel against the oracle's scan loop
+    over all reads of the proband with all four oracle-counted sketches"""
+    k, names = 51, ('mother', 'father', 'sibling1', 'proband')
+    packed = quad
+    batches = {n: hk.ReadBatch.from_packed(packed[n], L) for n in names}
+    n_reads, nk = packed['proband'].shape[0], L - k + 1
+    cores = host_cores()
+    dev, ref, keep = {}, {}, None
+    had = os.environ.get('KV_SKM_DL')
+    os.environ['KV_SKM_DL'] = '1'
+    try:
+        for n in names:
+            dev[n] = hk.Counttable(k, MEM / 4, 4)
+            if n == 'proband':
+                dev[n].expect_scan()
+        with Profiled(hk) as prof:
+            for n in names:
+                assert dev[n].consume_batch(batches[n]) == n_reads * nk
+            assert prof.count('k_skm_count') == 4
+        scans = scan_all_ways(hk, [dev['proband']], [dev[n] for n in names[:3]], batches['proband'], 6, 1, first_from_list=True)
+    finally:
+        if had is None:
+            os.environ.pop('KV_SKM_DL', None)
+        else:
+            os.environ['KV_SKM_DL'] = had
+    for n in names:
+        bases, offs_p, offs = ascii_block(packed[n], L)
+        ref[n] = ok.Counttable(k, MEM / 4, 4)
+        assert ok.consume_reads_mt(ref[n], bases, offs_p, n_reads, cores) == n_reads * nk
+        assert_same_sketch(dev[n], ref[n])
+        if n == 'proband':
+            keep = (bases, offs_p, offs)
+    want = ok.novel_scan_mt([ref['proband']], [ref[n] for n in names[:3]], keep[0], keep[1], n_reads, k, 6, 1, cores)
+    assert len(want[0]) > 100_000 and want[2].shape[1] == 4
+    for way in ('list', 'walk', 'tiles'):
+        assert_hits_equal(scans[way], want, 'config 5, scan by ' + way)

@@ -317,6 +317,42 @@ def test_novel_cli_same_output_from_bgzf_and_plain_gzip(hk, tmp_path):
     assert len(logs[0]) > 8 and untimed(logs[3]) == untimed(logs[0])
 
 
+@pytest.mark.parametrize('kind', ['plain', 'gzip'])
+def test_novel_scans_a_kept_batch_of_a_case_file_that_ends_in_blank_lines(hk, tmp_path, kind):
+    """`kevlar novel` keeps the batch a one-batch case sample was counted from and scans that (kevlar_amd/count.py keep=); it
+    asks the reader once more only to learn that the file has ended.  A FASTQ file that ends in blank lines leaves a carry of a
+    byte or two behind its last record: that second call must leave the kept batch fetchable (it reset n_batch
+    and the hit records could not be fetched).  Reference run: KV_NOVEL_REREAD=1 reads the case file a second time."""
+    import gzip as gz
+    import subprocess
+    import sys
+    from kevlar_amd import synth
+    trio = synth.make_trio(60000, 8)
+    files = {}
+    for i, name in enumerate(('proband', 'mother', 'father')):
+        reads = synth.unpack_reads(synth.sample_reads_packed(trio[name], 12000, 100, 0.005, 50 + i), 100)
+        text = ''.join('@{}_{}\n{}\n+\n{}\n'.format(name, j, s, 'I' * len(s)) for j, s in enumerate(reads))
+        if name == 'proband':
+            text += '\n'                               # the file ends "\n\n"
+        files[name] = str(tmp_path / (name + ('.fq' if kind == 'plain' else '.fq.gz')))
+        if kind == 'plain':
+            with open(files[name], 'w', newline='') as fh:
+                fh.write(text)
+        else:
+            with gz.open(files[name], 'wt', newline='') as fh:
+                fh.write(text)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {'KV_NOVEL_REREAD': '1'}, {'KV_INGEST': 'host'}):
+        out = str(tmp_path / 'novel{}.augfastq'.format(''.join(env)))
+        cmd = [sys.executable, '-m', 'kevlar_amd', 'novel', '--case', files['proband'], '--control', files['mother'],
+               '--control', files['father'], '--ksize', '25', '--memory', '2M', '--case-min', '5', '--ctrl-max', '1', '--out', out]
+        done = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert done.returncode == 0, done.stderr[-2000:]
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] == outs[2] and outs[0].count('\n') > 100
+
+
 @pytest.mark.parametrize('tail', ['\n\n', '\n\r\n \n', '\n'])
 def test_blank_lines_behind_the_last_record_stay_on_the_device(hk, tmp_path, tail):
     """a FASTQ file that ends in blank lines is still four-line FASTQ: the device reader finishes it (no hand-over to the host

@@ -411,6 +411,38 @@ def test_oracle_threaded_consume_equals_single_thread(ok):
     ok.consume_reads(kid, bases, offs, len(reads))
     hits, _ = ok.novel_scan([kid], [mom], bases, offs, len(reads), 21, 5, 0)
     assert ok.novel_scan_count_mt([kid], [mom], bases, offs, len(reads), 21, 5, 0, 3) == len(hits) > 0
+    # the threaded scan that keeps its hits (whole-sample comparisons of tests/test_gpu_fullsize.py): the scalar loop's hits, in order,
+    # also when a range of reads outgrows its share of the output buffers (cap 8)
+    for cap in (1 << 16, 8):
+        r, o, a = ok.novel_scan_mt([kid], [mom], bases, offs, len(reads), 21, 5, 0, 3, cap=cap)
+        assert [(int(x), int(y), tuple(int(v) for v in z)) for x, y, z in zip(r, o, a)] == hits
+
+
+def test_oracle_threaded_banded_consume_and_scan_equal_single_thread(ok):
+    """the band legs of the cfg4-shaped GPU test: kvo_consume_reads_mt_banded against kvo_consume_reads with the same band, and the
+    threaded scan against the scalar one under the hash-range band rule"""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    letters = np.array(list('ACGT'))
+    genome = ''.join(letters[rng.integers(0, 4, size=8000)])
+    child = genome[:4000] + ('A' if genome[4000] != 'A' else 'C') + genome[4001:]
+    reads = {name: [g[s:s + 90] for s in rng.integers(0, 7910, size=3000)] for name, g in (('kid', child), ('mom', genome))}
+    for nbands, band in ((2, 1), (8, 0), (8, 7)):
+        one, many = {}, {}
+        for name, seqs in reads.items():
+            bases, offs = ok.concat_reads(seqs)
+            one[name], many[name] = ok.Counttable(25, 2e4, 4), ok.Counttable(25, 2e4, 4)
+            n1 = ok.consume_reads(one[name], bases, offs, len(seqs), nbands, band)
+            n5 = ok.consume_reads_mt_banded(many[name], bases, offs, len(seqs), 5, nbands, band)
+            assert n1 == n5 > 0
+            for t in range(4):
+                assert one[name].table_bytes(t) == many[name].table_bytes(t)
+            assert one[name].n_occupied() == many[name].n_occupied()
+        bases, offs = ok.concat_reads(reads['kid'])
+        hits, _ = ok.novel_scan([one['kid']], [one['mom']], bases, offs, 3000, 25, 5, 1, band_mode=1, nbands=nbands, band=band)
+        r, o, a = ok.novel_scan_mt([many['kid']], [many['mom']], bases, offs, 3000, 25, 5, 1, 4, band_mode=1, nbands=nbands, band=band)
+        assert [(int(x), int(y), tuple(int(v) for v in z)) for x, y, z in zip(r, o, a)] == hits
+    assert len(hits) > 0
 
 
 def test_progress_indicator_jumps_match_item_by_item_counting(kevlar_log):
