@@ -83,6 +83,9 @@ struct SkmAblSet {
 namespace {
 
 #define SKM_THREADS1 512
+#if !defined(SKM_S1_WAVE_THREADS_DEFAULT)
+#define SKM_S1_WAVE_THREADS_DEFAULT 512u      // threads per workgroup of k_skm_emit_wave (1024: one workgroup per CU, see the kernel)
+#endif
 #define SKM_THREADS3 512
 #define SKM_MAXPROBE 48
 // One global counter hands out work; a returning atomic on one word saturates at ~90 per microsecond on this chip
@@ -419,8 +422,12 @@ __host__ __device__ inline uint32_t skm_wave_slice_words(uint32_t R, uint32_t L,
     return 132u + pmax + pmax / (uint32_t)ch + 2u + SKM_WAVE_RUNS + (SKM_WAVE_RUNS + 2u) / 2u;      // words (twice), order values, minimizer + start of SKM_WAVE_RUNS runs at a time
 }
 
-template <int CH, bool KNOBS>
-__global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, SkmGeom sg, uint32_t R, uint32_t n_mt, uint32_t quota_mt, uint32_t per_ticket)
+// THREADS: 512 (three workgroups per CU, 768 writers) or 1024 (ONE workgroup of 16 waves per CU, 256 writers).  A writer keeps one
+// open cache line per coarse bucket, and the L2 of an XCD (4 MB) merges a record's 16- and 8-byte stores into whole lines only while
+// the open lines of the XCD's workgroups fit beside the rest of its traffic: 251 buckets x 96 workgroups x 128 B = 3 MB do not
+// (WRITE_SIZE 2.5-2.7 GB per 1.36 GB of records, measured with 512 and with 768 writers), 251 x 32 x 128 B = 1 MB do (1.0 x).
+template <int CH, bool KNOBS, int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : 6) void k_skm_emit_wave(ReadsDev rd, SkmGeom sg, uint32_t R, uint32_t n_mt, uint32_t quota_mt, uint32_t per_ticket)
 {
     constexpr uint32_t PS = CH == 16 ? 4u : 3u;
     __shared__ uint32_t cur[256];
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, 
     uint32_t *wl0 = smem + wave * skm_wave_slice_words(R, L, nk, CH), *mh = wl0 + 132u;
     uint32_t *sval = mh + pmax + pmax / CH + 2u;
     uint16_t *starts = (uint16_t *)(sval + SKM_WAVE_RUNS);
-    for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_THREADS1) cur[c] = 0;
+    for (uint32_t c = threadIdx.x; c < sg.C1; c += THREADS) cur[c] = 0;
     if ((threadIdx.x & 63u) < 2u) { wl0[64u + (threadIdx.x & 63u)] = 0; wl0[130u + (threadIdx.x & 63u)] = 0; }
     __syncthreads();
     const uint32_t mmask = m == 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit_wave(ReadsDev rd, 
         mt += 1; taken += 1;
     }
     __syncthreads();
-    for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_THREADS1) sg.cnt1[(uint64_t)c * sg.nwg1 + blockIdx.x] = min(cur[c], sg.cap1);
+    for (uint32_t c = threadIdx.x; c < sg.C1; c += THREADS) sg.cnt1[(uint64_t)c * sg.nwg1 + blockIdx.x] = min(cur[c], sg.cap1);
     n_rec = wave_sum_u64(n_rec);
     if ((threadIdx.x & 63u) == 0 && n_rec) atomicAdd(&sg.ctr[5], (unsigned long long)n_rec);
 }
@@ -978,8 +985,13 @@ __host__ __device__ inline uint32_t skm_wave_scratch_words(uint32_t sbw) { retur
 
 // FK: the instance for the k everybody runs (kevlar's default, 31; the host checks k and the record width): shifts, masks and the
 // murmur tail become constants -- 3 % of the kernel.  FK = 0 reads k from the geometry.
+// waves per SIMD the two-word-key instances are compiled for (6: three workgroups per CU at 80 VGPRs, 13-19 of them spilled; 4: two
+// workgroups at up to 128 VGPRs, nothing spilled)
+#if !defined(SKM_K2_WAVES)
+#define SKM_K2_WAVES 6
+#endif
 template <int KW, int TS, bool KNOBS, int FK>
-__global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
+__global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : 6) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
                                                            const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
     __shared__ SkmTable<KW, TS> tb;
@@ -1596,6 +1608,13 @@ int skm_minimizer_len(int k) { return k >= 24 ? 12 : k / 2; }
 
 // reads per wave and chunk size of the wave kernel for batches of equal-length reads (0: use the tile kernel).  One packed
 // word and one chunk per lane, and about as many runs as lanes: a run per (w + 1) / 2 k-mers, one more per read.
+// threads per workgroup of the wave kernel (KV_SKM_S1_THREADS=512|1024)
+static uint32_t skm_wave_threads()
+{
+    if (const char *e = getenv("KV_SKM_S1_THREADS")) return atoi(e) == 512 ? 512u : 1024u;
+    return SKM_S1_WAVE_THREADS_DEFAULT;
+}
+
 static uint32_t skm_wave_plan(const SkmGeom &g, const kv_reads *reads, int *ch)
 {
     const uint32_t L = reads->uni_len;
@@ -1614,7 +1633,9 @@ static uint32_t skm_wave_plan(const SkmGeom &g, const kv_reads *reads, int *ch)
     }
     if (const char *e = getenv("KV_SKM_CH")) { const int c = atoi(e); if ((c == 8 || c == 16) && g.w > c) { *ch = c; best = std::min<uint32_t>(best, 64 / ((nk + c - 1) / c)); } }
     if (best < 2) return 0;
-    if ((size_t)skm_wave_slice_words(best, L, nk, *ch) * 4 * (SKM_THREADS1 / 64) + 2048 > 54000) return 0;       // three workgroups per CU or the tile kernel
+    const uint32_t threads = skm_wave_threads();
+    // three workgroups of 512 per CU, or one of 1024 -- or the tile kernel
+    if ((size_t)skm_wave_slice_words(best, L, nk, *ch) * 4 * (threads / 64) + 2048 > (threads == 1024 ? 160000u : 54000u)) return 0;
     return best;
 }
 
@@ -1624,19 +1645,23 @@ void skm_launch_emit(const SkmGeom &g, const kv_reads *reads, hipStream_t st)
     int ch = 16;
     if (const uint32_t R = skm_wave_plan(g, reads, &ch)) {
         const uint32_t L = reads->uni_len, nk = L - (uint32_t)g.k + 1;
-        const size_t lds = (size_t)skm_wave_slice_words(R, L, nk, ch) * 4 * (SKM_THREADS1 / 64);
+        const uint32_t threads = skm_wave_threads(), nwaves = threads / 64;
+        const size_t lds = (size_t)skm_wave_slice_words(R, L, nk, ch) * 4 * nwaves;
         const uint64_t n_mt = (reads->n_reads + R - 1) / R;
         // the same share of the batch per workgroup as the tile kernel's quota, dealt to its waves
         // a ticket is SKM_MT_PER_TICKET groups for a whole sample; small batches (a shard of a sample, a test) get smaller
         // tickets so that every wave of the grid still finds two
-        const uint64_t waves = (uint64_t)g.nwg1 * (SKM_THREADS1 / 64);
+        const uint64_t waves = (uint64_t)g.nwg1 * nwaves;
         const uint32_t per_ticket = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(SKM_MT_PER_TICKET, n_mt / (2 * waves)));
-        const uint64_t per_wave = (uint64_t)g.quota1 * reads->uni_per_tile / R / (SKM_THREADS1 / 64) + per_ticket;
+        const uint64_t per_wave = (uint64_t)g.quota1 * reads->uni_per_tile / R / nwaves + per_ticket;
         const uint32_t quota_mt = (uint32_t)std::min<uint64_t>(kv_round_up(per_wave, per_ticket), 0xfffffff0ull);
-        void (*kernel)(ReadsDev, SkmGeom, uint32_t, uint32_t, uint32_t, uint32_t) =
-            ch == 16 ? (g.dbg ? k_skm_emit_wave<16, true> : k_skm_emit_wave<16, false>) : (g.dbg ? k_skm_emit_wave<8, true> : k_skm_emit_wave<8, false>);
+        void (*kernel)(ReadsDev, SkmGeom, uint32_t, uint32_t, uint32_t, uint32_t);
+        if (threads == 1024)
+            kernel = ch == 16 ? (g.dbg ? k_skm_emit_wave<16, true, 1024> : k_skm_emit_wave<16, false, 1024>) : (g.dbg ? k_skm_emit_wave<8, true, 1024> : k_skm_emit_wave<8, false, 1024>);
+        else
+            kernel = ch == 16 ? (g.dbg ? k_skm_emit_wave<16, true, 512> : k_skm_emit_wave<16, false, 512>) : (g.dbg ? k_skm_emit_wave<8, true, 512> : k_skm_emit_wave<8, false, 512>);
         kv_ensure_dynamic_lds((const void *)kernel, lds);
-        hipLaunchKernelGGL(kernel, dim3(g.nwg1), dim3(SKM_THREADS1), lds, st, reads_dev(reads), g, R, (uint32_t)n_mt, quota_mt, per_ticket);
+        hipLaunchKernelGGL(kernel, dim3(g.nwg1), dim3(threads), lds, st, reads_dev(reads), g, R, (uint32_t)n_mt, quota_mt, per_ticket);
         return;
     }
     const size_t lds = ((size_t)g.np_max / 16 + KV_TILE_MAX_READS + 8 + (size_t)g.np_max + 96) * 4 + (((size_t)g.np_max + 96 + 1) & ~(size_t)1) * 2;
@@ -1792,6 +1817,11 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     // at least one whole ticket per workgroup: the per-writer capacities below assume even shares
     g.nwg1 = (uint32_t)std::min<uint64_t>((std::max<uint32_t>(reads->n_tiles, 1u) + SKM_TILES_PER_TICKET - 1) / SKM_TILES_PER_TICKET,
                                           std::min<uint32_t>(768u, 3u * (uint32_t)cus));
+    {
+        // the wave kernel with 1024-thread workgroups runs one workgroup per CU (fewer writers: see k_skm_emit_wave)
+        int ch_unused = 16;
+        if (skm_wave_threads() == 1024 && skm_wave_plan(g, reads, &ch_unused)) g.nwg1 = std::min<uint32_t>(g.nwg1, (uint32_t)cus);
+    }
     {
         const uint64_t avg = (reads->n_tiles + g.nwg1 - 1) / g.nwg1;
         g.quota1 = (uint32_t)std::min<uint64_t>(kv_round_up(avg + avg / 2 + 1, SKM_TILES_PER_TICKET), 0xfffffff0ull);
@@ -1959,6 +1989,8 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
         void (*kernel)(SkmGeom, const SketchDev *, const SketchDev *, ConsumeFilter, BinGeom) =
             sg.kw == 1 ? (sg.dbg ? k_skm_count<1, 4096, true, 0> : k_skm_count<1, 4096, false, 0>) : (sg.dbg ? k_skm_count<2, 2048, true, 0> : k_skm_count<2, 2048, false, 0>);
         if (sg.k == 31 && sg.recw == 3 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31>;
+        // (BASELINE.json configs[4]: k = 51 -- two-word keys, 128-bit reverse complement, three murmur blocks + a 3-byte tail)
+        if (sg.k == 51 && sg.recw == 4 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<2, 2048, false, 51>;
         hipLaunchKernelGGL(kernel, dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
     }
     {

@@ -354,20 +354,22 @@ def test_default_paths_on_a_large_batch_agree_with_the_other_implementations(hk,
     assert launches('k_skm_novel') == 1 and launches('k_novel_mark') == 1
 
 
-def test_count_instance_compiled_for_k31_equals_the_one_that_reads_k(hk, skm):
-    """k = 31 has its own instance of the count kernel (k, masks and the murmur tail are constants there); KV_SKM_ANY_K keeps
-    the instance that reads k from the geometry: same tables, same occupancy, and the same hits from a scan behind either"""
+@pytest.mark.parametrize('k', [31, 51])
+def test_count_instance_compiled_for_k_equals_the_one_that_reads_k(hk, skm, k):
+    """k = 31 (kevlar's default) and k = 51 (BASELINE.json configs[4]) have their own instances of the count kernel (k, masks,
+    shifts and the murmur tail are constants there); KV_SKM_ANY_K keeps the instance that reads k from the geometry: same
+    tables, same occupancy, and the same hits from a scan behind either"""
     reads = trio_reads(300000, 40000, 77)
     batches = {n: hk.ReadBatch(reads[n]) for n in reads}
     sk = {}
     for generic in (False, True):
         if generic:
             os.environ['KV_SKM_ANY_K'] = '1'
-        sk[generic] = {n: hk.Counttable(31, 1.5e7 / 4, 4) for n in ('mother', 'father', 'proband')}
+        sk[generic] = {n: hk.Counttable(k, 1.5e7 / 4, 4) for n in ('mother', 'father', 'proband')}
         for n in ('mother', 'father', 'proband'):
             if n == 'proband':
                 sk[generic][n].expect_scan(True)
-            assert sk[generic][n].consume_batch(batches[n]) == 40000 * 70
+            assert sk[generic][n].consume_batch(batches[n]) == 40000 * (100 - k + 1)
     for n in reads:
         for t in range(4):
             assert sk[False][n].table_bytes(t) == sk[True][n].table_bytes(t)
