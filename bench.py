@@ -468,6 +468,9 @@ def main():
     if exchange:
         for key in run.timing:
             run.timing[key] = 0.0
+    if world > 1:
+        from kevlar_amd import shardrun as _sr
+        _sr.SENT['bytes'] = 0
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -492,6 +495,34 @@ def main():
         phases = {'max_over_ranks': {key: round(both[i] / args.steps * 1e3, 3) for i, key in enumerate(keys)},
                   'min_over_ranks': {key: round(-both[len(keys) + i] / args.steps * 1e3, 3) for i, key in enumerate(keys)},
                   'unit': 'ms per step'}
+        # what a scaling point is made of, so that a bad one explains itself without a second run: the kernels a rank ran per step
+        # (summed HIP-event time, slowest rank), what it handed to collectives for other ranks, and how that compares with the
+        # single-GPU step of the committed round profile (a reference from another run, named as such)
+        names_buf = ctypes.create_string_buffer(8192)
+        lib.kv_prof_names(names_buf, 8192)
+        mine_kernel_ms = sum(prof(lib, nm)[0] for nm in names_buf.value.decode().split(',') if nm) / args.steps
+        sent = float(_sr.SENT['bytes']) / args.steps
+        agg = torch.tensor([mine_kernel_ms, sent, -mine_kernel_ms], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(agg, op=dist.ReduceOp.MAX)
+        agg = [float(v) for v in agg.cpu()]
+        ref_ms, ref_src = None, None
+        for round_dir in sorted((d for d in os.listdir(os.path.join(ROOT, 'profiles')) if d.endswith('_final')), reverse=True):
+            f = os.path.join(ROOT, 'profiles', round_dir, 'bench.json')
+            if os.path.exists(f) and args.workload == 'cfg2':
+                try:
+                    ref_ms, ref_src = json.loads(open(f).read().strip().splitlines()[-1])['ms_per_step'], os.path.relpath(f, ROOT)
+                except (ValueError, KeyError, IndexError):
+                    pass
+                break
+        phases['projection'] = {
+            'per_rank_kernel_ms_per_step': {'slowest_rank': round(agg[0], 3), 'fastest_rank': round(-agg[2], 3)},
+            'per_rank_host_and_wait_ms_per_step': round(elapsed / args.steps * 1e3 - agg[0], 3),
+            'bytes_sent_per_rank_per_step_max': int(agg[1]),
+            'xgmi_ms_at_350_GBps': round(agg[1] / 350e9 * 1e3, 3),
+            'single_gpu_reference_ms_per_step': ref_ms, 'single_gpu_reference': ref_src,
+            'speedup_vs_reference': round(ref_ms / (elapsed / args.steps * 1e3), 3) if ref_ms else None,
+            'speedup_if_only_kernels_counted': round(ref_ms / agg[0], 3) if ref_ms and agg[0] > 0 else None,
+        }
 
     # ---- cheap end-to-end sanity on the timed result (parity proper lives in tests/)
     r, o, a = hits

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 
+#include "kv_binned.h"          // KvArena, KvGunzipArenas
 #include "kv_internal.h"
 
 // ---------------------------------------------------------------------------------------
@@ -60,8 +61,32 @@ struct PackWriter {
     bool ok = true;
 };
 
+// A gzip file whose text is not four-line FASTQ (FASTA: a reference genome, contigs; FASTQ with blank lines) is still
+// inflated on the device -- kv_gunzip.hip, a segment of text at a time -- and the TEXT comes back for the host's record
+// parser: zlib inflates at ~0.35 GB/s of text on one core, the device at ~10 GB/s, the copy back at PCIe speed
+// (kevlar/__init__.py:125-128 reads every sequence file through one gzip stream).  What the device decoder declines
+// (no dynamic-Huffman block for megabytes, damaged stream: KV_ERR_TYPE) goes on through zlib from the same text offset.
+struct DevTextSource {
+    int fd = -1;
+    const uint8_t *image = nullptr;
+    size_t image_size = 0;
+    KvGunzip *gz = nullptr;
+    KvGunzipArenas arenas;
+    KvArena text;
+    uint64_t delivered = 0;        // bytes of text handed to the parser so far
+    ~DevTextSource()
+    {
+        if (gz) kv_gunzip_close(gz);
+        arenas.release();
+        if (text.p) (void)hipFree(text.p);
+        if (image) munmap((void *)image, image_size);
+        if (fd >= 0) close(fd);
+    }
+};
+
 struct kv_fastx {
     gzFile fh = nullptr;
+    DevTextSource *dsrc = nullptr; // non-null: fx_fill draws the text from the device inflater instead of gzread
     std::string path;
     std::vector<char> buf;
     size_t pos = 0, end = 0;
@@ -90,6 +115,42 @@ static bool fx_fill(kv_fastx *f)
     f->end -= f->pos;
     f->pos = 0;
     if (f->end == f->buf.size()) f->buf.resize(f->buf.size() * 2);
+    if (f->dsrc) {
+        DevTextSource *d = f->dsrc;
+        const char *seg_env = getenv("KV_INGEST_TEXT_MB");            // tests shrink the segments
+        const uint64_t want = (seg_env ? strtoull(seg_env, nullptr, 10) : 256ull) << 20;
+        uint64_t n = 0;
+        bool last = false;
+        int rc = KV_OK;
+        while (rc == KV_OK && n == 0 && !kv_gunzip_done(d->gz)) rc = kv_gunzip_decode(d->gz, want, &n, &last);
+        if (rc == KV_OK && n) {
+            if (d->text.need(n + 256) != hipSuccess) { (void)hipGetLastError(); rc = KV_ERR_TYPE; }
+            else rc = kv_gunzip_emit(d->gz, (uint8_t *)d->text.p);
+        }
+        if (rc == KV_OK && n) {
+            if (f->buf.size() - f->end < n) f->buf.resize(f->end + n);
+            if (hipMemcpyAsync(f->buf.data() + f->end, d->text.p, n, hipMemcpyDeviceToHost, kv_stream()) != hipSuccess ||
+                hipStreamSynchronize(kv_stream()) != hipSuccess) { (void)hipGetLastError(); rc = KV_ERR_TYPE; }
+        }
+        if (rc == KV_OK && n) {
+            d->delivered += n;
+            f->end += (size_t)n;
+            return true;
+        }
+        if (rc == KV_OK) { f->eof = true; return false; }            // the stream has ended
+        if (rc == KV_ERR_HIP && kv_last_hip_code != (int)hipErrorOutOfMemory) {
+            // a device fault is not a reason to read the file another way: the parser reports it
+            f->eof = true;
+            f->io_error = kv_last_error();
+            return false;
+        }
+        // the device path stops here: zlib takes over at the same text offset (it reports a damaged stream itself)
+        const uint64_t skip = d->delivered;
+        delete d;
+        f->dsrc = nullptr;
+        (void)hipGetLastError();
+        if (gzseek(f->fh, (z_off_t)skip, SEEK_SET) < 0) { f->eof = true; f->io_error = "cannot resume the gzip stream on the host"; return false; }
+    }
     const int got = gzread(f->fh, f->buf.data() + f->end, (unsigned)(f->buf.size() - f->end));
     if (got <= 0) {
         // the end of the file -- or of what can be read of it: a damaged or truncated gzip stream is an error, not a short file
@@ -333,6 +394,20 @@ static void pack_writer_finish(PackWriter *w, bool complete)
     delete w;
 }
 
+// map the file and start a device inflater over it; on any failure the handle simply keeps its zlib stream
+static void fx_open_device_text(kv_fastx *f, size_t size)
+{
+    DevTextSource *d = new DevTextSource();
+    d->fd = open(f->path.c_str(), O_RDONLY);
+    if (d->fd < 0) { delete d; return; }
+    void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, d->fd, 0);
+    if (map == MAP_FAILED) { delete d; return; }
+    d->image = (const uint8_t *)map; d->image_size = size;
+    d->gz = kv_gunzip_open(d->image, size, &d->arenas);
+    if (!d->gz) { delete d; return; }
+    f->dsrc = d;
+}
+
 extern "C" int kv_fastx_open(const char *path, kv_fastx **out)
 {
     KV_REQUIRE(path && out, KV_ERR_ARG, "kv_fastx_open: null argument");
@@ -372,6 +447,15 @@ extern "C" int kv_fastx_open(const char *path, kv_fastx **out)
                         const int rc = inflate(&zs, Z_SYNC_FLUSH);
                         f->dev_candidate = (rc == Z_OK || rc == Z_STREAM_END || rc == Z_BUF_ERROR) && zs.avail_out == 0 && first == '@';
                         inflateEnd(&zs);
+                        // any other text in a gzip file of some size (FASTA): inflate on the device, parse here
+                        const char *big = getenv("KV_GUNZIP_TEXT_MIN_MB");
+                        const uint64_t min_bytes = (big ? strtoull(big, nullptr, 10) : 4ull) << 20;
+                        struct stat sb;
+                        int ndev = 0;
+                        if (!f->dev_candidate && stat(path, &sb) == 0 && (uint64_t)sb.st_size >= min_bytes &&
+                            hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0)
+                            fx_open_device_text(f, (size_t)sb.st_size);
+                        else (void)hipGetLastError();
                     }
                 }
             }
@@ -385,6 +469,7 @@ extern "C" int kv_fastx_close(kv_fastx *f)
 {
     if (!f) return KV_OK;
     if (f->fh) gzclose(f->fh);
+    delete f->dsrc;
     kv_fastq_device_close(f->dev);
     pack_writer_finish(f->writer, false);       // a complete pass has already finished (and detached) its writer
     pack_close(f->cache);

@@ -1599,7 +1599,10 @@ SkmIndex &skm_index_for(hipStream_t st)
 
 inline uint32_t skm_nwg3(const SkmGeom &g)
 {
-    return (uint32_t)std::min<uint64_t>((g.n_buckets + SKM_BUCKETS_PER_TICKET - 1) / SKM_BUCKETS_PER_TICKET, 3u * (uint32_t)kv_device_cus());
+    // persistent workgroups of the bucket kernels: three per CU fill its LDS (KV_SKM_WG3_PER_CU=2 leaves a third of it -- and of the wave
+    // slots -- to whatever another stream has queued: the experiment behind DESIGN.md section 4.1, "samples on separate streams")
+    static const uint32_t per_cu = [] { const char *e = getenv("KV_SKM_WG3_PER_CU"); const int v = e ? atoi(e) : 3; return (uint32_t)(v >= 1 && v <= 3 ? v : 3); }();
+    return (uint32_t)std::min<uint64_t>((g.n_buckets + SKM_BUCKETS_PER_TICKET - 1) / SKM_BUCKETS_PER_TICKET, per_cu * (uint32_t)kv_device_cus());
 }
 
 inline uint32_t pow2_ceil(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }

@@ -31,6 +31,10 @@ import torch.distributed as dist
 from kevlar_amd import khmer as hk
 
 
+# payload bytes this rank has handed to collectives for OTHER ranks (what crosses xGMI from here): bench.py reads and resets it
+SENT = {'bytes': 0}
+
+
 def shard_bounds(n_reads, world, rank):
     """Reads [lo, hi) of a sample that rank `rank` hashes."""
     return (n_reads * rank) // world, (n_reads * (rank + 1)) // world
@@ -71,6 +75,7 @@ def exchange_rows_async(send, counts, group=None, staged=False):
     rank = dist.get_rank(group)
     recv_counts = [int(table[src, rank]) for src in range(world)]
     packed = send[:sum(counts)]
+    SENT['bytes'] += (sum(counts) - counts[rank]) * send.element_size() * int(np.prod(send.shape[1:], dtype=np.int64)) + 8 * (world - 1)
     recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
     if staged:
         src_host = packed.cpu()
@@ -94,6 +99,7 @@ def exchange_slabs(send, in_splits, out_splits, group=None, staged=False):
     """All-to-all of a flat tensor cut at fixed split points known to every rank (no size exchange): returns what arrived,
     source after source.  Blocking."""
     recv = torch.empty(sum(out_splits), dtype=send.dtype, device=send.device)
+    SENT['bytes'] += (sum(in_splits) - in_splits[dist.get_rank(group)]) * send.element_size()
     if staged:
         host = torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_to_all_single(host, send.cpu(), list(out_splits), list(in_splits), group=group)
@@ -115,6 +121,7 @@ def gather_rows(rows, n_valid, fill, group=None, staged=False):
     sizes = torch.empty(world, dtype=torch.int64, device=coll_dev)
     dist.all_gather_into_tensor(sizes, mine, group=group)
     sizes = [int(v) for v in sizes.cpu()]
+    SENT['bytes'] += (world - 1) * (n_valid * rows.element_size() * int(np.prod(rows.shape[1:], dtype=np.int64)) + 8)
     longest = max(max(sizes), 1)
     padded = torch.full((longest,) + tuple(rows.shape[1:]), fill, dtype=rows.dtype, device=rows.device)
     padded[:n_valid] = rows[:n_valid]
@@ -191,7 +198,6 @@ class ShardedTrio(object):
         got_cnt = exchange_slabs(cnt, [w * int(plan.nwg1) for w in width], [mine] * self.world, self.group, self.staged)
         from_src = [int(v) for v in got_cnt.view(self.world, mine).clamp(max=int(plan.cap1)).sum(dim=1, dtype=torch.int64).cpu()]
         got_seg = exchange_slabs(packed[:sum(per_dest) * recw], [n * recw for n in per_dest], [n * recw for n in from_src], self.group, self.staged)
-        self.sent_bytes = getattr(self, 'sent_bytes', 0) + (sum(per_dest) - per_dest[self.rank]) * recw * 8 + (len(cnt) - mine) * 4
         del seg, cnt, packed
         t2 = time.perf_counter()
         share = int(plan.n_kmers_global) // self.world

@@ -317,6 +317,57 @@ def test_novel_cli_same_output_from_bgzf_and_plain_gzip(hk, tmp_path):
     assert len(logs[0]) > 8 and untimed(logs[3]) == untimed(logs[0])
 
 
+@pytest.mark.parametrize('kind', ['gzip', 'bgzf'])
+def test_fasta_gz_is_inflated_on_the_device_and_parsed_on_the_host(hk, tmp_path, kind):
+    """a gzip file that is not four-line FASTQ -- FASTA with wrapped sequence lines: a reference genome, contigs -- is inflated
+    by the device (kv_gunzip.hip), a segment of text at a time, and its text parsed by the host's record parser
+    (kevlar/__init__.py:125-128 reads it through one zlib stream): same records, same count tables as KV_INGEST=host, and the
+    device inflater did run.  Segments of 1 MB of text cut records and lines anywhere."""
+    import ctypes
+    import gzip as gz
+    from kevlar_amd import _lib
+    rng = np.random.default_rng(31)
+    letters = np.frombuffer(b'ACGT', dtype=np.uint8)
+    recs = []
+    for i in range(3000):
+        n = int(rng.integers(40, 4000))
+        seq = letters[rng.integers(0, 4, size=n)].tobytes().decode('ascii')
+        if i % 97 == 0:
+            seq = seq[:n // 2] + 'N' * 5 + seq[n // 2:]
+        recs.append('>contig{} len={}\n'.format(i, len(seq)) + '\n'.join(seq[j:j + 70] for j in range(0, len(seq), 70)) + '\n')
+    text = ''.join(recs)
+    assert len(text) > (5 << 20)
+    path = str(tmp_path / 'contigs.fa.gz')
+    if kind == 'gzip':
+        with gz.open(path, 'wt', compresslevel=6) as fh:
+            fh.write(text)
+    else:
+        write_fastq(path, text)
+    lib = _lib.load()
+    host = batches_of(hk, path, 700, {'KV_INGEST': 'host'})
+    lib.kv_prof_reset()
+    lib.kv_prof_enable(1)
+    try:
+        dev = batches_of(hk, path, 700, {'KV_GUNZIP_TEXT_MIN_MB': '1', 'KV_INGEST_TEXT_MB': '1'})
+        ms, n = ctypes.c_double(), ctypes.c_uint64()
+        lib.kv_prof_get(b'k_gz_decode', ctypes.byref(ms), ctypes.byref(n))
+    finally:
+        lib.kv_prof_enable(0)
+    assert n.value >= 5, 'the device inflater must have decoded the segments'
+    assert set(dev[3]) == {'TextBatch'} and dev[4] == host[4] == 3000
+    assert dev[0] == host[0] and dev[1] == host[1] and dev[2] == host[2]
+    # a damaged stream is an error on this path too (zlib takes over where the device stops and reports it)
+    blob = bytearray(open(path, 'rb').read())
+    mid = len(blob) // 2
+    blob[mid:mid + 64] = bytes(64)
+    bad = str(tmp_path / 'damaged.fa.gz')
+    with open(bad, 'wb') as fh:
+        fh.write(bytes(blob))
+    for env in ({'KV_INGEST': 'host'}, {'KV_GUNZIP_TEXT_MIN_MB': '1'}):
+        with pytest.raises(Exception):
+            batches_of(hk, bad, 700, env)
+
+
 @pytest.mark.parametrize('kind', ['plain', 'gzip'])
 def test_novel_scans_a_kept_batch_of_a_case_file_that_ends_in_blank_lines(hk, tmp_path, kind):
     """`kevlar novel` keeps the batch a one-batch case sample was counted from and scans that (kevlar_amd/count.py keep=); it
