@@ -767,9 +767,8 @@ def band_downstream(args, wl, hits, genome_len, seed, L, k, S, synth):
     t_text = time.perf_counter()
     tmp = tempfile.mkdtemp(prefix='kv_band_')
     novel_file, filtered_file, part_file = (os.path.join(tmp, f) for f in ('band.novel.augfastq', 'band.filtered.augfastq', 'band.part.augfastq'))
-    with open(novel_file, 'wb') as fh:
-        for lo in range(0, n, 400000):                     # (one call's text must stay below 2 GB)
-            fh.write(ann.format(np.arange(lo, min(n, lo + 400000), dtype=np.uint64)))
+    with kevlar_amd.open_sink(novel_file) as sink:
+        ann.format_to(sink, np.arange(n, dtype=np.uint64))          # rendered on the host cores, written as it is rendered
     t1 = time.perf_counter()
     log = io.StringIO()
     old_log, kevlar_amd.logstream = kevlar_amd.logstream, log

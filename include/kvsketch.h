@@ -62,6 +62,10 @@ typedef struct kv_sketch_info {
 
 /* ---- library / device ---------------------------------------------------------------- */
 const char *kv_last_error(void);
+/* Table buffers of destroyed sketches are kept for the next sketch of the same size (KV_TABLE_CACHE_GB, default 32); the library gives
+ * them back by itself when one of its own allocations fails.  A host program about to allocate a large buffer of its own (torch,
+ * another library) calls this first.                                                                                                */
+int kv_table_cache_trim(void);
 const char *kv_version(void);
 int kv_device_count(int *n);
 int kv_set_device(int device);       /* one process per GPU: call once with LOCAL_RANK      */
@@ -320,6 +324,16 @@ int kv_format_records(uint64_t n_out, const uint64_t *rec_index, const uint64_t 
                       const uint64_t *qual_offs, const uint8_t *is_fastq, const char *suffix,
                       const uint64_t *suffix_offs, const uint32_t *mate_record, uint64_t n_mates, const char *mates,
                       const uint64_t *mate_offs, char **text_out, uint64_t *bytes_out);
+/* kv_format_records with the text written straight to file descriptor `fd` (a regular file, a pipe): rendered a stretch of records
+ * at a time on `nthreads` host threads, written in order; *bytes_out = bytes written.  What `kevlar filter` / `kevlar partition` /
+ * `kevlar novel` do with the text of print_augmented_fastx (kevlar/sequence.pyx:93-126) when their output is a plain file.        */
+int kv_format_records_fd(uint64_t n_out, const uint64_t *rec_index, const uint64_t *ann_lo, const uint64_t *ann_hi,
+                         const uint32_t *ann_offset, const int32_t *ann_abund, const uint8_t *keep,
+                         const int32_t *case_abund, int nsamples, int ksize, const char *names,
+                         const uint64_t *name_offs, const char *seqs, const uint64_t *seq_offs, const char *quals,
+                         const uint64_t *qual_offs, const uint8_t *is_fastq, const char *suffix,
+                         const uint64_t *suffix_offs, const uint32_t *mate_record, uint64_t n_mates, const char *mates,
+                         const uint64_t *mate_offs, int fd, int nthreads, uint64_t *bytes_out);
 /* the dedup key of `kevlar partition` (kevlar/partition.py:37-47: kevlar.revcommin(read.sequence)) as two 64-bit hashes per read:
  * of the sequence or its reverse complement (complement[256]: the byte table of revcom), whichever sorts first.  Host only.     */
 /* flags[i] = 1 if read i (seqs[seq_offs[i] .. seq_offs[i + 1])) holds a byte other than upper-case A, C, G, T: the packed form cannot

@@ -48,6 +48,18 @@ class _Sink(object):
         else:
             self._stream.write(data.decode('latin-1') if isinstance(data, (bytes, bytearray, memoryview)) else data)
 
+    def raw_fd(self):
+        """file descriptor of a plain binary file underneath (flushed), for text a native formatter writes itself; None for
+        standard output, gzip writers and anything else that is not a file of bytes"""
+        import io
+        if not self._binary or not isinstance(self._stream, io.BufferedWriter):
+            return None
+        try:
+            self._stream.flush()
+            return self._stream.fileno()
+        except (OSError, ValueError):
+            return None
+
     def close(self):
         if self._close:
             self._stream.close()

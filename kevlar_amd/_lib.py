@@ -44,6 +44,7 @@ SIGNATURES = {
     'kv_synchronize': (i32, []),
     'kv_stream_create': (i32, [vpp]),
     'kv_stream_destroy': (i32, [vp]),
+    'kv_table_cache_trim': (i32, []),
     'kv_prof_enable': (i32, [i32]),
     'kv_prof_reset': (i32, []),
     'kv_prof_get': (i32, [cstr, ctypes.POINTER(ctypes.c_double), u64p]),
@@ -83,6 +84,7 @@ SIGNATURES = {
     'kv_reads_flag_other_bytes': (i32, [vp, vp, u64, vp]),
     'kv_canonical_read_hashes': (i32, [vp, vp, vp, u64, vp, vp, vp]),
     'kv_format_records': (i32, [u64, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, vp, vp, vpp, u64p]),
+    'kv_format_records_fd': (i32, [u64, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, vp, vp, i32, i32, u64p]),
     'kv_fastx_on_device': (i32, [vp, ctypes.POINTER(ctypes.c_int)]),
     'kv_fastx_fetch': (i32, [vp, u64p, u64]),
     'kv_fastx_record_text': (i32, [vp, u64, ctypes.c_char_p, ctypes.c_char_p]),

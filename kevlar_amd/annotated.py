@@ -10,11 +10,27 @@ arrays (kv_augfastx_load), k-mers are addressed by position -- the device hashes
 formatted natively from the same arrays (kv_format_records).  Record objects exist only for callers that ask for
 them one by one."""
 import ctypes
+import os
 
 import numpy as np
 
 from kevlar_amd import _lib, khmer
 from kevlar_amd.sequence import KmerOfInterest, Record
+
+
+def _host_cores():
+    """cores this process may use: the affinity mask, cut to the cgroup's CPU quota (a container on a 256-core box gets 16)"""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = max(1, min(cores, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return cores
 
 
 def _bytes_at(ptr, n):
@@ -240,7 +256,17 @@ class AnnotatedReads(object):
         for i in self._kept_reads(keep).tolist():
             yield self.record(i, keep, case_abund)
 
-    def format(self, reads, keep=None, case_abund=None, suffixes=None, regrouped=None, suffix_blob=None):
+    def format_to(self, sink, reads, keep=None, case_abund=None, suffixes=None, regrouped=None, suffix_blob=None):
+        """format() written to `sink` (kevlar_amd.open_sink): when the sink is a plain file the native formatter renders on several
+        threads and writes the file itself (kv_format_records_fd: no text buffer of the output's size, no copy into a Python
+        object); otherwise format() + write()."""
+        fd = sink.raw_fd() if hasattr(sink, 'raw_fd') else None
+        if fd is None or os.environ.get('KV_FORMAT_FD') == '0':
+            sink.write(self.format(reads, keep, case_abund, suffixes, regrouped, suffix_blob))
+            return
+        self.format(reads, keep, case_abund, suffixes, regrouped, suffix_blob, _fd=fd)
+
+    def format(self, reads, keep=None, case_abund=None, suffixes=None, regrouped=None, suffix_blob=None, _fd=None):
         """Augmented FASTA/FASTQ text (bytes) of the given reads (indices, in that order) with the annotations where
         `keep` is set (None: all); suffixes: one string per read appended to its name (suffix_blob: the same as one blob + offsets).  regrouped = (lo, hi, order):
         output read j carries annotations order[lo[j]:hi[j]] (indices into this container's annotations) instead of
@@ -271,14 +297,19 @@ class AnnotatedReads(object):
             return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
         text, size = ctypes.c_void_p(), ctypes.c_uint64()
         lib = _lib.load()
-        _lib.check(lib.kv_format_records(
+        common = (
             len(reads), ptr(reads), ptr(lo), ptr(hi), ptr(offset), ptr(abund), ptr(keep8), ptr(case32), int(self.nsamples), int(self.ksize or 1),
             ctypes.cast(ctypes.c_char_p(self.names), ctypes.c_void_p), ptr(self.name_offs), ctypes.cast(ctypes.c_char_p(self.seqs), ctypes.c_void_p),
             ptr(self.seq_offs), ctypes.cast(ctypes.c_char_p(self.quals), ctypes.c_void_p), ptr(self.qual_offs), ptr(self.is_fastq),
             None if sfx_blob is None else ctypes.cast(ctypes.c_char_p(sfx_blob), ctypes.c_void_p), ptr(sfx_offs),
             ptr(self.mate_record) if len(self.mate_record) else None, len(self.mate_record),
             ctypes.cast(ctypes.c_char_p(self.mates), ctypes.c_void_p) if len(self.mate_record) else None,
-            ptr(self.mate_offs) if len(self.mate_record) else None, ctypes.byref(text), ctypes.byref(size)))
+            ptr(self.mate_offs) if len(self.mate_record) else None)
+        if _fd is not None:
+            threads = int(os.environ.get('KV_FORMAT_THREADS', '0')) or min(16, _host_cores())
+            _lib.check(lib.kv_format_records_fd(*(common + (int(_fd), threads, ctypes.byref(size)))))
+            return size.value
+        _lib.check(lib.kv_format_records(*(common + (ctypes.byref(text), ctypes.byref(size)))))
         try:
             return _bytes_at(text, size.value)
         finally:
@@ -288,3 +319,9 @@ class AnnotatedReads(object):
         """select() rendered to augmented FASTA/FASTQ text; returns (bytes, number of reads)"""
         reads = self._kept_reads(keep)
         return self.format(reads, keep, case_abund), len(reads)
+
+    def select_to(self, sink, keep, case_abund=None):
+        """select_text() written to `sink` (format_to); returns the number of reads"""
+        reads = self._kept_reads(keep)
+        self.format_to(sink, reads, keep, case_abund)
+        return len(reads)

@@ -14,6 +14,10 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -408,6 +412,67 @@ extern "C" int kv_canonical_read_hashes(const char *seqs, const uint64_t *seq_of
     return KV_OK;
 }
 
+// what kv_format_records and kv_format_records_fd render from
+struct FormatArgs {
+    const uint64_t *rec_index, *ann_lo, *ann_hi;
+    const uint32_t *ann_offset; const int32_t *ann_abund; const uint8_t *keep; const int32_t *case_abund;
+    int nsamples, ksize;
+    const char *names; const uint64_t *name_offs; const char *seqs; const uint64_t *seq_offs; const char *quals; const uint64_t *qual_offs;
+    const uint8_t *is_fastq; const char *suffix; const uint64_t *suffix_offs;
+    const uint32_t *mate_record; uint64_t n_mates; const char *mates; const uint64_t *mate_offs;
+};
+
+// output record j as text; false if an annotation does not fit its read (out.ok stays true) or memory ran out (out.ok false)
+static bool format_one(KvTextOut &out, const FormatArgs &a, uint64_t j, std::vector<uint64_t> &order)
+{
+    const uint64_t r = a.rec_index[j];
+    const char *seq = a.seqs + a.seq_offs[r];
+    const size_t seq_len = (size_t)(a.seq_offs[r + 1] - a.seq_offs[r]);
+    const bool fq = a.is_fastq ? a.is_fastq[r] != 0 : false;
+    out.put(fq ? '@' : '>');
+    out.put(a.names + a.name_offs[r], (size_t)(a.name_offs[r + 1] - a.name_offs[r]));
+    if (a.suffix && a.suffix_offs) out.put(a.suffix + a.suffix_offs[j], (size_t)(a.suffix_offs[j + 1] - a.suffix_offs[j]));
+    out.put('\n');
+    out.put(seq, seq_len);
+    if (fq) {
+        out.put("\n+\n", 3);
+        out.put(a.quals + a.qual_offs[r], (size_t)(a.qual_offs[r + 1] - a.qual_offs[r]));
+    }
+    out.put('\n');
+    // the kept annotations in offset order (stable); nearly always they already are
+    bool sorted = true, fits = true;
+    uint32_t last = 0;
+    for (uint64_t i = a.ann_lo[j]; i < a.ann_hi[j] && sorted; ++i)
+        if (!a.keep || a.keep[i]) { sorted = a.ann_offset[i] >= last; last = a.ann_offset[i]; }
+    auto line = [&](uint64_t i) {
+        const uint32_t off = a.ann_offset[i];
+        if ((size_t)off + (size_t)a.ksize > seq_len) { fits = false; return; }
+        const int32_t *row = a.ann_abund + i * (uint64_t)a.nsamples;
+        out.kmer_line(seq, off, a.ksize, a.nsamples, [&](int c) { return (int64_t)((c == 0 && a.case_abund) ? a.case_abund[i] : row[c]); });
+    };
+    if (sorted) {
+        for (uint64_t i = a.ann_lo[j]; i < a.ann_hi[j]; ++i)
+            if (!a.keep || a.keep[i]) line(i);
+    } else {
+        order.clear();
+        for (uint64_t i = a.ann_lo[j]; i < a.ann_hi[j]; ++i)
+            if (!a.keep || a.keep[i]) order.push_back(i);
+        std::stable_sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return a.ann_offset[x] < a.ann_offset[y]; });
+        for (const uint64_t i : order) line(i);
+    }
+    if (!fits) return false;
+    if (a.n_mates) {
+        const uint32_t *m = std::lower_bound(a.mate_record, a.mate_record + a.n_mates, (uint32_t)r);
+        for (; m < a.mate_record + a.n_mates && *m == (uint32_t)r; ++m) {
+            const uint64_t mi = (uint64_t)(m - a.mate_record);
+            out.put("#mateseq=", 9);
+            out.put(a.mates + a.mate_offs[mi], (size_t)(a.mate_offs[mi + 1] - a.mate_offs[mi]));
+            out.put("#\n", 2);
+        }
+    }
+    return out.ok;
+}
+
 extern "C" int kv_format_records(uint64_t n_out, const uint64_t *rec_index, const uint64_t *ann_lo, const uint64_t *ann_hi,
                                  const uint32_t *ann_offset, const int32_t *ann_abund, const uint8_t *keep, const int32_t *case_abund,
                                  int nsamples, int ksize, const char *names, const uint64_t *name_offs, const char *seqs,
@@ -417,6 +482,8 @@ extern "C" int kv_format_records(uint64_t n_out, const uint64_t *rec_index, cons
 {
     KV_REQUIRE(text_out && bytes_out && (n_out == 0 || (rec_index && ann_lo && ann_hi && names && name_offs && seqs && seq_offs)), KV_ERR_ARG,
                "kv_format_records: null argument");
+    const FormatArgs a = {rec_index, ann_lo, ann_hi, ann_offset, ann_abund, keep, case_abund, nsamples, ksize, names, name_offs, seqs, seq_offs,
+                          quals, qual_offs, is_fastq, suffix, suffix_offs, mate_record, n_mates, mates, mate_offs};
     KvTextOut out;
     {
         uint64_t notes = 0;
@@ -425,55 +492,78 @@ extern "C" int kv_format_records(uint64_t n_out, const uint64_t *rec_index, cons
     }
     std::vector<uint64_t> order;
     for (uint64_t j = 0; j < n_out; ++j) {
-        const uint64_t r = rec_index[j];
-        const char *seq = seqs + seq_offs[r];
-        const size_t seq_len = (size_t)(seq_offs[r + 1] - seq_offs[r]);
-        const bool fq = is_fastq ? is_fastq[r] != 0 : false;
-        out.put(fq ? '@' : '>');
-        out.put(names + name_offs[r], (size_t)(name_offs[r + 1] - name_offs[r]));
-        if (suffix && suffix_offs) out.put(suffix + suffix_offs[j], (size_t)(suffix_offs[j + 1] - suffix_offs[j]));
-        out.put('\n');
-        out.put(seq, seq_len);
-        if (fq) {
-            out.put("\n+\n", 3);
-            out.put(quals + qual_offs[r], (size_t)(qual_offs[r + 1] - qual_offs[r]));
-        }
-        out.put('\n');
-        // the kept annotations in offset order (stable); nearly always they already are
-        bool sorted = true;
-        uint32_t last = 0;
-        for (uint64_t i = ann_lo[j]; i < ann_hi[j] && sorted; ++i)
-            if (!keep || keep[i]) { sorted = ann_offset[i] >= last; last = ann_offset[i]; }
-        auto line = [&](uint64_t i) {
-            const uint32_t off = ann_offset[i];
-            if ((size_t)off + (size_t)ksize > seq_len) { out.ok = false; return; }
-            const int32_t *row = ann_abund + i * (uint64_t)nsamples;
-            out.kmer_line(seq, off, ksize, nsamples, [&](int c) { return (int64_t)((c == 0 && case_abund) ? case_abund[i] : row[c]); });
-        };
-        if (sorted) {
-            for (uint64_t i = ann_lo[j]; i < ann_hi[j]; ++i)
-                if (!keep || keep[i]) line(i);
-        } else {
-            order.clear();
-            for (uint64_t i = ann_lo[j]; i < ann_hi[j]; ++i)
-                if (!keep || keep[i]) order.push_back(i);
-            std::stable_sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return ann_offset[x] < ann_offset[y]; });
-            for (const uint64_t i : order) line(i);
-        }
-        KV_REQUIRE(out.ok, KV_ERR_ARG, "kv_format_records: an annotation does not fit its read (record %llu), or out of memory", (unsigned long long)r);
-        if (n_mates) {
-            const uint32_t *m = std::lower_bound(mate_record, mate_record + n_mates, (uint32_t)r);
-            for (; m < mate_record + n_mates && *m == (uint32_t)r; ++m) {
-                const uint64_t mi = (uint64_t)(m - mate_record);
-                out.put("#mateseq=", 9);
-                out.put(mates + mate_offs[mi], (size_t)(mate_offs[mi + 1] - mate_offs[mi]));
-                out.put("#\n", 2);
-            }
-        }
+        const bool fine = format_one(out, a, j, order);
+        KV_REQUIRE(fine || !out.ok, KV_ERR_ARG, "kv_format_records: an annotation does not fit its read (record %llu)", (unsigned long long)rec_index[j]);
+        KV_REQUIRE(out.ok, KV_ERR_HIP, "kv_format_records: out of memory");
     }
-    KV_REQUIRE(out.ok, KV_ERR_HIP, "kv_format_records: out of memory");
     *bytes_out = out.len;
     *text_out = out.release();
     KV_REQUIRE(*text_out, KV_ERR_HIP, "kv_format_records: out of memory");
+    return KV_OK;
+}
+
+// The same text written straight to a file descriptor: the records are rendered a stretch at a time by `nthreads` threads, each
+// into a buffer of its own that it keeps (warm pages: a fresh 3 GB buffer costs a page fault per 4 KB, which is what the
+// single-buffer form spent most of its time on at config-4 scale), and the stretches are written in order.  Nothing of the size of
+// the output is ever resident, and the Python side neither copies nor holds the text.
+extern "C" int kv_format_records_fd(uint64_t n_out, const uint64_t *rec_index, const uint64_t *ann_lo, const uint64_t *ann_hi,
+                                    const uint32_t *ann_offset, const int32_t *ann_abund, const uint8_t *keep, const int32_t *case_abund,
+                                    int nsamples, int ksize, const char *names, const uint64_t *name_offs, const char *seqs,
+                                    const uint64_t *seq_offs, const char *quals, const uint64_t *qual_offs, const uint8_t *is_fastq,
+                                    const char *suffix, const uint64_t *suffix_offs, const uint32_t *mate_record, uint64_t n_mates,
+                                    const char *mates, const uint64_t *mate_offs, int fd, int nthreads, uint64_t *bytes_out)
+{
+    KV_REQUIRE(bytes_out && fd >= 0 && (n_out == 0 || (rec_index && ann_lo && ann_hi && names && name_offs && seqs && seq_offs)), KV_ERR_ARG,
+               "kv_format_records_fd: bad argument");
+    const FormatArgs a = {rec_index, ann_lo, ann_hi, ann_offset, ann_abund, keep, case_abund, nsamples, ksize, names, name_offs, seqs, seq_offs,
+                          quals, qual_offs, is_fastq, suffix, suffix_offs, mate_record, n_mates, mates, mate_offs};
+    *bytes_out = 0;
+    if (n_out == 0) return KV_OK;
+    const uint64_t per = 32768;                                   // records per stretch (~15 MB of 100-bp reads)
+    const uint64_t n_chunks = (n_out + per - 1) / per;
+    if (nthreads < 1) nthreads = 1;
+    if ((uint64_t)nthreads > n_chunks) nthreads = (int)n_chunks;
+    std::atomic<uint64_t> next_chunk{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t turn = 0, total = 0;                                 // guarded by mu: the stretch that may be written, bytes written
+    int failed = 0;                                               // 1 annotation out of range, 2 memory, 3 write error
+    uint64_t bad_record = 0;
+    auto work = [&]() {
+        KvTextOut out;
+        std::vector<uint64_t> order;
+        for (;;) {
+            const uint64_t c = next_chunk.fetch_add(1);
+            if (c >= n_chunks) return;
+            out.len = 0;
+            int mine = 0;
+            uint64_t bad = 0;
+            for (uint64_t j = c * per; j < std::min(n_out, (c + 1) * per) && !mine; ++j)
+                if (!format_one(out, a, j, order)) { mine = out.ok ? 1 : 2; bad = rec_index[j]; }
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return turn == c; });
+            if (!failed && mine) { failed = mine; bad_record = bad; }
+            if (!failed) {
+                size_t done = 0;
+                while (done < out.len) {
+                    const ssize_t w = write(fd, out.buf + done, out.len - done);
+                    if (w < 0) { if (errno == EINTR) continue; failed = 3; break; }
+                    done += (size_t)w;
+                }
+                total += done;
+            }
+            turn = c + 1;
+            lk.unlock();
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    *bytes_out = total;
+    KV_REQUIRE(failed != 1, KV_ERR_ARG, "kv_format_records_fd: an annotation does not fit its read (record %llu)", (unsigned long long)bad_record);
+    KV_REQUIRE(failed != 2, KV_ERR_HIP, "kv_format_records_fd: out of memory");
+    KV_REQUIRE(failed != 3, KV_ERR_IO, "kv_format_records_fd: write failed: %s", strerror(errno));
     return KV_OK;
 }

@@ -587,7 +587,7 @@ int kv_fastq_device_fetch(KvFastqDevice *d, const uint64_t *idx, uint64_t n, std
     for (uint64_t i = 0; i < n; ++i) (*offs)[i + 1] = (*offs)[i] + (ext[2 * i + 1] - ext[2 * i]);
     const uint64_t bytes = (*offs)[n];
     uint8_t *d_out = nullptr;
-    KV_HIP(hipMalloc((void **)&d_out, bytes + 16));
+    KV_HIP(kv_hip_malloc((void **)&d_out, bytes + 16));
     hipError_t e = hipMemcpyAsync(d_dst, offs->data(), n * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_record_copy, dim3((unsigned)std::min<uint64_t>(n, 16384)), dim3(64), 0, st, (const uint8_t *)d->text[d->cur].p, (const uint64_t *)d_ext,

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_abund_hist(ReadsDev rd, con
 struct DevBuf {  // frees on scope exit
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+    hipError_t alloc(size_t n) { return kv_hip_malloc(&p, n ? n : 4); }
     template <typename T> T *as() { return (T *)p; }
 };
 

@@ -371,12 +371,12 @@ hipError_t table_alloc(uint8_t **p, uint64_t bytes)
     }
     return e;
 }
-void table_free(uint8_t *p, uint64_t bytes)
+void table_free(uint8_t *p, uint64_t bytes, int device)
 {
     {
         std::lock_guard<std::mutex> lk(g_tabcache_mu);
         if (bytes >= (16u << 20) && g_tabcache_bytes + bytes <= tabcache_cap()) {
-            g_tabcache.emplace(std::make_pair(current_device(), bytes), p);
+            g_tabcache.emplace(std::make_pair(device, bytes), p);      // the device the buffer lives on, not the caller's current one
             g_tabcache_bytes += bytes;
             return;
         }
@@ -384,6 +384,23 @@ void table_free(uint8_t *p, uint64_t bytes)
     (void)hipFree(p);
 }
 }  // namespace
+
+hipError_t kv_hip_malloc(void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        kv_table_cache_release();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
+extern "C" int kv_table_cache_trim(void)
+{
+    kv_table_cache_release();
+    return KV_OK;
+}
 
 void kv_table_cache_release()
 {
@@ -405,6 +422,7 @@ int kv_sketch_alloc(int kind, int ksize, int ntables, const uint64_t *sizes, kv_
     static std::atomic<uint64_t> next_uid{1};
     kv_sketch *s = new kv_sketch();
     s->uid = next_uid.fetch_add(1);
+    s->device = current_device();
     s->kind = kind;
     memset(&s->h, 0, sizeof(s->h));
     s->h.ntables = ntables;
@@ -428,8 +446,8 @@ int kv_sketch_alloc(int kind, int ksize, int ntables, const uint64_t *sizes, kv_
         e = table_alloc(&s->h.tab[i], s->alloc_bytes[i]);
         if (e == hipSuccess) e = hipMemsetAsync(s->h.tab[i], 0, s->alloc_bytes[i], kv_stream());
     }
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_desc, sizeof(SketchDev));
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_counters, 4 * sizeof(uint64_t));
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&s->d_desc, sizeof(SketchDev));
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&s->d_counters, 4 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMemcpy(s->d_desc, &s->h, sizeof(SketchDev), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(s->d_counters, 0, 4 * sizeof(uint64_t));
     if (e != hipSuccess) {
@@ -451,7 +469,7 @@ extern "C" int kv_sketch_destroy(kv_sketch *s)
     if (!s) return KV_OK;
     (void)hipDeviceSynchronize();                   // (what hipFree did implicitly: nobody is still working on these tables)
     for (int i = 0; i < KV_MAX_TABLES; ++i)
-        if (s->h.tab[i]) table_free(s->h.tab[i], s->alloc_bytes[i]);
+        if (s->h.tab[i]) table_free(s->h.tab[i], s->alloc_bytes[i], s->device);
     if (s->d_desc) (void)hipFree(s->d_desc);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->abl.mem) (void)hipFree(s->abl.mem);
@@ -805,13 +823,13 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
     char *d_ascii = nullptr;
     uint64_t *d_offs = nullptr;
     hipStream_t st = kv_stream();
-    hipError_t e = hipMalloc((void **)&r->d_words, (nw + 4) * 4);   // + slack: k-mer extraction reads up to two words ahead
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, flag_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, tiles.size() * sizeof(TileDesc));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_ascii, r->n_bases ? r->n_bases : 1);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_offs, woff.size() * 8);
+    hipError_t e = kv_hip_malloc((void **)&r->d_words, (nw + 4) * 4);   // + slack: k-mer extraction reads up to two words ahead
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_woff, woff.size() * 8);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_flags, flag_bytes);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_tile, tiles.size() * sizeof(TileDesc));
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&d_ascii, r->n_bases ? r->n_bases : 1);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&d_offs, woff.size() * 8);
     if (e == hipSuccess && r->n_bases) e = hipMemcpyAsync(d_ascii, bases + offs[0], r->n_bases, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_offs, offs, (n_reads + 1) * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(r->d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice, st);
@@ -891,11 +909,11 @@ bool uniform_reads(kv_reads *r, const TextSource *text, const uint32_t *lens, ui
     r->tile_lds_bytes = KV_TILE_LDS_BYTES + 256;
     const uint64_t flag_bytes = ((n_reads + 3) & ~3ull) + 4;
     hipStream_t st = kv_stream();
-    hipError_t e = hipMalloc((void **)&r->d_words, (nw + 4) * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, (n_reads + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, n_reads * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, flag_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, (size_t)r->n_tiles * sizeof(TileDesc));
+    hipError_t e = kv_hip_malloc((void **)&r->d_words, (nw + 4) * 4);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_woff, (n_reads + 1) * 8);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_len, n_reads * 4);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_flags, flag_bytes);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_tile, (size_t)r->n_tiles * sizeof(TileDesc));
     if (e == hipSuccess) e = hipMemsetAsync(r->d_words + nw, 0, 16, st);
     if (e == hipSuccess) e = hipMemcpyAsync(r->d_len, text->d_seq_len, n_reads * 4, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(r->d_flags, 0, flag_bytes, st);
@@ -969,11 +987,11 @@ int reads_from_packed(const uint32_t *words, const TextSource *text, const uint3
     }
     const uint64_t flag_bytes = ((n_reads + 3) & ~3ull) + 4;
     hipStream_t st = kv_stream();
-    hipError_t e = hipMalloc((void **)&r->d_words, (nw + 4) * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, woff.size() * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, flag_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, tiles.size() * sizeof(TileDesc));
+    hipError_t e = kv_hip_malloc((void **)&r->d_words, (nw + 4) * 4);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_woff, woff.size() * 8);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_flags, flag_bytes);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_tile, tiles.size() * sizeof(TileDesc));
     if (e == hipSuccess && nw && words) e = hipMemcpyAsync(r->d_words, words, nw * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(r->d_words + nw, 0, 16, st);
     if (e == hipSuccess) e = hipMemcpyAsync(r->d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice, st);
@@ -1022,11 +1040,11 @@ static int reads_packed_uniform(const uint32_t *words, const std::function<void(
     // the device in closed form
     hipStream_t st = kv_stream();
     const uint32_t tiles_alloc = std::max<uint32_t>(r->n_tiles, 1u);
-    hipError_t e = hipMalloc((void **)&r->d_words, (r->n_words + 4) * 4);   // + slack: k-mer extraction reads up to two words ahead
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_woff, (n_reads + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_flags, n_reads ? n_reads : 1);
-    if (e == hipSuccess) e = hipMalloc((void **)&r->d_tile, (size_t)tiles_alloc * sizeof(TileDesc));
+    hipError_t e = kv_hip_malloc((void **)&r->d_words, (r->n_words + 4) * 4);   // + slack: k-mer extraction reads up to two words ahead
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_woff, (n_reads + 1) * 8);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_len, (n_reads ? n_reads : 1) * 4);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_flags, n_reads ? n_reads : 1);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&r->d_tile, (size_t)tiles_alloc * sizeof(TileDesc));
     if (e == hipSuccess && r->n_words && words) e = hipMemcpyAsync(r->d_words, words, r->n_words * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && r->n_words && !words) { (*fill)(r->d_words, st); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipMemsetAsync(r->d_words + r->n_words, 0, 16, st);

@@ -368,8 +368,8 @@ extern "C" int kv_bgzf_inflate_host(const void *file, uint64_t size, void *out, 
     KvArena scratch;
     hipStream_t st = kv_stream();
     int rc = KV_OK;
-    hipError_t e = hipMalloc((void **)&d_comp, size + KV_INFLATE_SLACK);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_text, total + 64);
+    hipError_t e = kv_hip_malloc((void **)&d_comp, size + KV_INFLATE_SLACK);
+    if (e == hipSuccess) e = kv_hip_malloc((void **)&d_text, total + 64);
     if (e == hipSuccess) e = hipMemcpyAsync(d_comp, file, size, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(d_comp + size, 0, KV_INFLATE_SLACK, st);
     if (e == hipSuccess) {

@@ -67,6 +67,7 @@ struct kv_sketch {
     bool occ_dirty;
     uint64_t n_unique;
     uint64_t uid = 0;      // unique per allocation (pointers get recycled)
+    int device = 0;        // the device the tables were allocated on (what the table cache files them under)
     uint64_t version = 0;  // bumped by everything that changes a table (invalidates cached scan verdicts)
     uint64_t *d_counters; // [0] n_kmers, [1] n_unique (device accumulators)
     bool skm_off = false;  // the last batch counted through the super-k-mer front end did not deduplicate: skip it until cleared
@@ -266,6 +267,12 @@ struct KvProfScope {
     explicit KvProfScope(const char *n);
     ~KvProfScope();
 };
+
+// hipMalloc for the library: when the device is out of memory the table buffers kept for future sketches (up to KV_TABLE_CACHE_GB of
+// them, kv_host.hip) are given back and the call is made once more -- every allocation of the library goes through here, so the
+// cache never stands between a caller and memory that is in fact free
+hipError_t kv_hip_malloc(void **p, size_t bytes);
+template <typename T> static inline hipError_t kv_hip_malloc(T **p, size_t bytes) { return kv_hip_malloc((void **)p, bytes); }
 
 // host helpers shared between files
 uint64_t kv_host_murmur_lo(const void *data, int len, uint32_t seed);

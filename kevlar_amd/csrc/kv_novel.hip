@@ -377,7 +377,7 @@ std::mutex g_vcache_mu;
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+    hipError_t alloc(size_t n) { return kv_hip_malloc(&p, n ? n : 4); }
     template <typename T> T *as() { return (T *)p; }
 };
 
@@ -391,7 +391,7 @@ struct Arena {
         if (n <= bytes) return hipSuccess;
         if (p) (void)hipFree(p);
         p = nullptr; bytes = 0;
-        hipError_t e = hipMalloc(&p, n);
+        hipError_t e = kv_hip_malloc(&p, n);
         if (e == hipSuccess) bytes = n;
         return e;
     }
@@ -429,7 +429,7 @@ int attach_vcache(NovelParams &p, kv_sketch *const *ctrls, int ncase, int nctrl,
         if (vc->p == nullptr || vc->bits < want) {
             if (vc->p) (void)hipFree(vc->p);
             vc->p = nullptr;
-            if (hipMalloc((void **)&vc->p, (size_t)8 << want) == hipSuccess) { vc->bits = want; vc->signature = 0; }
+            if (kv_hip_malloc((void **)&vc->p, (size_t)8 << want) == hipSuccess) { vc->bits = want; vc->signature = 0; }
             else { (void)hipGetLastError(); vc->bits = 0; }
         }
         if (vc->p) {

@@ -201,7 +201,7 @@ struct Scratch {
         if (n <= bytes) return hipSuccess;
         if (p) (void)hipFree(p);
         p = nullptr; bytes = 0;
-        hipError_t e = hipMalloc(&p, n);
+        hipError_t e = kv_hip_malloc(&p, n);
         if (e == hipSuccess) bytes = n;
         return e;
     }
@@ -281,7 +281,7 @@ __global__ void k_gather_hits(const uint64_t *sorted_tags, const uint32_t *sorte
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+    hipError_t alloc(size_t n) { return kv_hip_malloc(&p, n ? n : 4); }
     template <typename T> T *as() { return (T *)p; }
 };
 

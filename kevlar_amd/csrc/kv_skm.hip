@@ -1940,7 +1940,7 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
             if (al.bytes < need) {
                 if (al.mem) (void)hipFree(al.mem);
                 al.mem = nullptr; al.bytes = 0;
-                if (hipMalloc(&al.mem, need) == hipSuccess) al.bytes = need;
+                if (kv_hip_malloc(&al.mem, need) == hipSuccess) al.bytes = need;
                 else (void)hipGetLastError();              // no room: no list, nothing else changes
             }
             if (al.mem) {

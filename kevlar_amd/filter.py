@@ -71,15 +71,19 @@ class Recount(object):
             ticker.update()
             yield read
 
-    def survivors_text(self, casemin, ctrlmax):
-        """survivors() as (augmented FASTA/FASTQ bytes, number of reads), formatted natively from the arrays"""
+    def survivors_text(self, casemin, ctrlmax, sink=None):
+        """survivors() as (augmented FASTA/FASTQ bytes, number of reads), formatted natively from the arrays; with a `sink`
+        (kevlar_amd.open_sink) the text is written there as it is rendered and (b'', number of reads) comes back"""
         verdict, again = self._verdict(casemin, ctrlmax)
-        text, n = self.annotated.select_text(verdict, case_abund=again)
+        if sink is not None:
+            text, n = b'', self.annotated.select_to(sink, verdict, case_abund=again)
+        else:
+            text, n = self.annotated.select_text(verdict, case_abund=again)
         kevlar_amd.ProgressIndicator(_TICK, interval=1e5, breaks=[1e6, 1e7]).update(n)
         return text, n
 
 
-def _passes(readfile, mask, memory, maxfpr, casemin, ctrlmax, as_text):
+def _passes(readfile, mask, memory, maxfpr, casemin, ctrlmax, as_text, sink=None):
     timer = kevlar_amd.Timer()
     timer.start()
     if isinstance(readfile, str) and readfile != '-':
@@ -106,7 +110,7 @@ def _passes(readfile, mask, memory, maxfpr, casemin, ctrlmax, as_text):
         timer.start('secondpass')
         nkept = 0
         if as_text:
-            text, nkept = work.survivors_text(casemin, ctrlmax)
+            text, nkept = work.survivors_text(casemin, ctrlmax, sink)
             yield text
         else:
             for nkept, read in enumerate(work.survivors(casemin, ctrlmax), 1):
@@ -126,6 +130,7 @@ def filter(readfile, mask=None, memory=1e6, maxfpr=0.01, casemin=6, ctrlmax=1):
 def main(args):
     sink = kevlar_amd.open_sink(args.out)
     mask = kevlar_amd.sketch.load(args.mask) if args.mask else None
-    for text in _passes(args.augfastq, mask, args.memory, args.max_fpr, args.case_min, args.ctrl_max, as_text=True):
-        sink.write(text)
+    for text in _passes(args.augfastq, mask, args.memory, args.max_fpr, args.case_min, args.ctrl_max, as_text=True, sink=sink):
+        if text:
+            sink.write(text)
     sink.close()

@@ -253,7 +253,7 @@ def _main_arrays(args, outputs):
             lens = np.repeat(np.array([len(label) for label in labels], dtype=np.uint64), sizes)
             offs = np.zeros(len(reads) + 1, dtype=np.uint64)
             np.cumsum(lens, out=offs[1:])
-            outputs.put(0, ann.format(reads, suffix_blob=(blob, offs)))
+            ann.format_to(outputs.shared, reads, suffix_blob=(blob, offs))
     kevlar_amd.plog('[kevlar::partition]', 'grouped {:d} reads into {:d} connected components'.format(len(reads), count))
 
 

@@ -57,6 +57,44 @@ def test_native_parse_and_format_equal_python(path):
         assert got.format(first, suffixes=[' kvcc=7'] * len(first)) == ''.join(format_augmented_fastx(r) for r in want[:len(first)]).encode('latin-1')
 
 
+@pytest.mark.parametrize('threads', ['1', '5'])
+def test_format_written_to_a_file_by_the_library_equals_format(tmp_path, threads, monkeypatch):
+    """kv_format_records_fd (what filter / partition use when their output is a plain file: stretches of records rendered on
+    several threads into buffers they keep, written in order) gives the bytes kv_format_records returns -- over many stretches
+    (the records of a golden file repeated to 100 000 outputs), with a selection, recounted abundances and name suffixes; a
+    sink that is not a plain file (gzip) takes the old route with the same result"""
+    monkeypatch.setenv('KV_FORMAT_THREADS', threads)
+    path = os.path.join(DATA, 'trio1', 'novel_3_1,2.txt')
+    got = AnnotatedReads.from_file(path)
+    reads = np.tile(np.arange(got.n), 100000 // got.n + 1)[:100000]
+    rng = np.random.default_rng(3)
+    rng.shuffle(reads)
+    keep = rng.random(len(got)) < 0.7
+    again = (np.arange(len(got)) % 250).astype(np.int32)
+    blob = ''.join(' kvcc={}'.format(i % 977) for i in range(len(reads))).encode('latin-1')
+    offs = np.cumsum([0] + [len(' kvcc={}'.format(i % 977)) for i in range(len(reads))]).astype(np.uint64)
+    want = got.format(reads, keep, again, suffix_blob=(blob, offs))
+    assert len(want) > 40_000_000
+    out = str(tmp_path / 'out.augfastq')
+    with kevlar_amd.open_sink(out) as sink:
+        sink.write(b'# head\n')                       # what the sink already holds stays in front
+        got.format_to(sink, reads, keep, again, suffix_blob=(blob, offs))
+        sink.write(b'# tail\n')
+    assert open(out, 'rb').read() == b'# head\n' + want + b'# tail\n'
+    gz = str(tmp_path / 'out.augfastq.gz')
+    with kevlar_amd.open_sink(gz) as sink:
+        got.format_to(sink, reads[:5000], keep, again)
+    assert gzip.open(gz, 'rb').read() == got.format(reads[:5000], keep, again)
+    # an annotation that does not fit its read is an error on both routes
+    bad = AnnotatedReads.from_file(path)
+    bad.offset = bad.offset.copy()
+    bad.offset[0] = 10 ** 6
+    with pytest.raises(ValueError):
+        bad.format(np.arange(bad.n))
+    with kevlar_amd.open_sink(str(tmp_path / 'bad.augfastq')) as sink, pytest.raises(ValueError):
+        bad.format_to(sink, np.arange(bad.n))
+
+
 def test_native_parser_rejects_what_the_python_parser_rejects(tmp_path):
     good = '@r1\nACGTACGTAC\n+\nIIIIIIIIII\n  GTACG          7 0 1#\n'
     bad_kmer = good.replace('  GTACG', '  GTACC')
