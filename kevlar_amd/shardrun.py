@@ -162,6 +162,10 @@ class ShardedTrio(object):
         for i, buf in enumerate(free):
             if buf.shape[0] >= cap:
                 return free.pop(i)
+        if cap * words * 8 >= (1 << 30):
+            # torch allocates beside the library: the table buffers the library keeps for future sketches are worth less than this
+            from kevlar_amd import _lib
+            _lib.load().kv_table_cache_trim()
         return torch.empty((cap, words), dtype=torch.int64, device=self.device)
 
     @staticmethod
