@@ -785,10 +785,10 @@ def band_downstream(args, wl, hits, genome_len, seed, L, k, S, synth):
             import cProfile, pstats
             for argv in (['filter', '--memory', '2G', '--case-min', str(args.case_min), '--ctrl-max', str(args.ctrl_max), '-o', filtered_file + '.2', novel_file],
                          ['partition', '-o', part_file + '.2', filtered_file]):
-                prof = cProfile.Profile(); t0 = time.perf_counter()
+                prof = cProfile.Profile(); t_prof = time.perf_counter()
                 prof.enable(); run(argv); prof.disable()
                 st = io.StringIO(); pstats.Stats(prof, stream=st).sort_stats('tottime').print_stats(16)
-                sys.stderr.write('[downstream profile] {} {:.2f} s\n{}\n'.format(argv[0], time.perf_counter() - t0, st.getvalue()[:4000]))
+                sys.stderr.write('[downstream profile] {} {:.2f} s\n{}\n'.format(argv[0], time.perf_counter() - t_prof, st.getvalue()[:4000]))
                 os.remove(argv[-2])
     finally:
         kevlar_amd.logstream = old_log

@@ -341,6 +341,10 @@ int kv_format_records_fd(uint64_t n_out, const uint64_t *rec_index, const uint64
 int kv_reads_flag_other_bytes(const char *seqs, const uint64_t *seq_offs, uint64_t n, uint8_t *flags);
 int kv_canonical_read_hashes(const char *seqs, const uint64_t *seq_offs, const uint64_t *reads, uint64_t n,
                              const uint8_t *complement, uint64_t *h1, uint64_t *h2);
+/* same[j] = 1 if reads a[j] and b[j] have the same canonical sequence, min(sequence, reverse complement) by byte order: what
+ * kevlar/partition.py:26-33 compares; partition confirms equal-hash pairs with it.  Host only.                                   */
+int kv_canonical_reads_equal(const char *seqs, const uint64_t *seq_offs, const uint64_t *a, const uint64_t *b, uint64_t n,
+                             const uint8_t *complement, uint8_t *same);
 
 /* ---- blocked gzip (BGZF) on the device (kevlar_amd/csrc/kv_inflate.hip) --------------------------------
  * Replaces the gzip stream behind khmer.ReadParser (kevlar/__init__.py:125-128) for files whose members are

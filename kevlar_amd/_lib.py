@@ -83,6 +83,7 @@ SIGNATURES = {
     'kv_augfastx_free': (i32, [vp]),
     'kv_reads_flag_other_bytes': (i32, [vp, vp, u64, vp]),
     'kv_canonical_read_hashes': (i32, [vp, vp, vp, u64, vp, vp, vp]),
+    'kv_canonical_reads_equal': (i32, [vp, vp, vp, vp, u64, vp, vp]),
     'kv_format_records': (i32, [u64, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, vp, vp, vpp, u64p]),
     'kv_format_records_fd': (i32, [u64, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, vp, vp, i32, i32, u64p]),
     'kv_fastx_on_device': (i32, [vp, ctypes.POINTER(ctypes.c_int)]),

@@ -412,6 +412,31 @@ extern "C" int kv_canonical_read_hashes(const char *seqs, const uint64_t *seq_of
     return KV_OK;
 }
 
+// same[j] = 1 if reads a[j] and b[j] have the same canonical sequence -- min(sequence, reverse complement) by byte order, the string
+// the reference compares (kevlar/partition.py:26-33 via kevlar.revcommin).  The canonical forms themselves are built and compared:
+// revcom() is not an involution (it upper-cases what it complements), so "one is the other or the other's reverse complement"
+// would be a different relation on mixed-case reads.  partition calls this for the pairs whose two hashes agree, so that a
+// collision never drops a read.  Host only.
+extern "C" int kv_canonical_reads_equal(const char *seqs, const uint64_t *seq_offs, const uint64_t *a, const uint64_t *b, uint64_t n,
+                                        const uint8_t *complement, uint8_t *same)
+{
+    KV_REQUIRE(n == 0 || (seqs && seq_offs && a && b && complement && same), KV_ERR_ARG, "kv_canonical_reads_equal: null argument");
+    std::string ra, rb;
+    auto canonical = [&](uint64_t r, std::string &rc, size_t &len) -> const unsigned char * {
+        const unsigned char *fw = (const unsigned char *)seqs + seq_offs[r];
+        len = (size_t)(seq_offs[r + 1] - seq_offs[r]);
+        rc.resize(len);
+        for (size_t i = 0; i < len; ++i) rc[i] = (char)complement[fw[len - 1 - i]];
+        return len && memcmp(rc.data(), fw, len) < 0 ? (const unsigned char *)rc.data() : fw;      // the rule of kv_canonical_read_hashes
+    };
+    for (uint64_t j = 0; j < n; ++j) {
+        size_t la = 0, lb = 0;
+        const unsigned char *ca = canonical(a[j], ra, la), *cb = canonical(b[j], rb, lb);
+        same[j] = la == lb && (la == 0 || memcmp(ca, cb, la) == 0) ? 1 : 0;
+    }
+    return KV_OK;
+}
+
 // what kv_format_records and kv_format_records_fd render from
 struct FormatArgs {
     const uint64_t *rec_index, *ann_lo, *ann_hi;

@@ -83,13 +83,8 @@ def _fixed_width(blob, offs):
 _COMP_LUT = None
 
 
-def _canonical_hashes(seqs, seq_offs, reads):
-    """two independent 64-bit hashes of min(sequence, reverse complement) -- kevlar_amd.revcommin(), the key partition()
-    dedups by -- for the given reads: kv_canonical_read_hashes, host threads over the reads (the numpy form -- byte matrices
-    padded to 64-bit words, strands chosen and hashed by word columns -- took 1.3 s for 2 M reads of 100 bases)."""
-    import ctypes
+def _complement_lut():
     import numpy as np
-    from kevlar_amd import _lib
     from kevlar_amd.sequence import _COMPLEMENT
     global _COMP_LUT
     if _COMP_LUT is None:
@@ -98,6 +93,33 @@ def _canonical_hashes(seqs, seq_offs, reads):
             if src < 256:
                 lut[src] = dst
         _COMP_LUT = lut
+    return _COMP_LUT
+
+
+def _same_canonical(seqs, seq_offs, a, b):
+    """bool per pair: reads a[j] and b[j] have the same kevlar_amd.revcommin() (kv_canonical_reads_equal builds both canonical
+    forms and compares them)"""
+    import ctypes
+    import numpy as np
+    from kevlar_amd import _lib
+    a, b = np.ascontiguousarray(a, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint64)
+    same = np.zeros(len(a), dtype=np.uint8)
+    if len(a):
+        offs = np.ascontiguousarray(seq_offs, dtype=np.uint64)
+        blob = bytes(seqs) if not isinstance(seqs, bytes) else seqs
+        _lib.check(_lib.load().kv_canonical_reads_equal(
+            ctypes.cast(ctypes.c_char_p(blob), ctypes.c_void_p), offs.ctypes.data_as(ctypes.c_void_p), a.ctypes.data_as(ctypes.c_void_p),
+            b.ctypes.data_as(ctypes.c_void_p), len(a), _complement_lut().ctypes.data_as(ctypes.c_void_p), same.ctypes.data_as(ctypes.c_void_p)))
+    return same.astype(bool)
+
+
+def _canonical_hashes(seqs, seq_offs, reads):
+    """two independent 64-bit hashes of min(sequence, reverse complement) -- kevlar_amd.revcommin(), the key partition()
+    dedups by -- for the given reads: kv_canonical_read_hashes, host threads over the reads (the numpy form -- byte matrices
+    padded to 64-bit words, strands chosen and hashed by word columns -- took 1.3 s for 2 M reads of 100 bases)."""
+    import ctypes
+    import numpy as np
+    from kevlar_amd import _lib
     offs = np.ascontiguousarray(seq_offs, dtype=np.uint64)
     reads = np.ascontiguousarray(reads, dtype=np.uint64)
     h1 = np.zeros(len(reads), dtype=np.uint64)
@@ -106,7 +128,7 @@ def _canonical_hashes(seqs, seq_offs, reads):
         blob = bytes(seqs) if not isinstance(seqs, bytes) else seqs
         _lib.check(_lib.load().kv_canonical_read_hashes(
             ctypes.cast(ctypes.c_char_p(blob), ctypes.c_void_p), offs.ctypes.data_as(ctypes.c_void_p), reads.ctypes.data_as(ctypes.c_void_p),
-            len(reads), _COMP_LUT.ctypes.data_as(ctypes.c_void_p), h1.ctypes.data_as(ctypes.c_void_p), h2.ctypes.data_as(ctypes.c_void_p)))
+            len(reads), _complement_lut().ctypes.data_as(ctypes.c_void_p), h1.ctypes.data_as(ctypes.c_void_p), h2.ctypes.data_as(ctypes.c_void_p)))
     return h1, h2
 
 
@@ -161,13 +183,7 @@ def assemble_partitions(names, name_offs, seqs, seq_offs, component_of, minabund
         dup = np.flatnonzero(~first)
         if len(dup):
             head = np.maximum.accumulate(np.where(first, np.arange(len(order)), 0))
-            view = memoryview(seqs)
-            for j in dup.tolist():
-                a_, b_ = int(reads[order[j]]), int(reads[order[head[j]]])
-                sa = bytes(view[int(seq_offs[a_]):int(seq_offs[a_ + 1])]).decode('ascii', 'replace')
-                sb = bytes(view[int(seq_offs[b_]):int(seq_offs[b_ + 1])]).decode('ascii', 'replace')
-                if sa != sb and kevlar_amd.revcommin(sa) != kevlar_amd.revcommin(sb):
-                    first[j] = True                                 # two sequences, one pair of hashes: both stay
+            first[dup[~_same_canonical(seqs, seq_offs, reads[order[dup]], reads[order[head[dup]]])]] = True     # two sequences, one pair of hashes: both stay
         kept = np.sort(order[first])
         reads, part = reads[kept], part[kept]
         if minabund:

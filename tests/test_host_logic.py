@@ -669,6 +669,38 @@ def test_assemble_partitions_matches_the_loop_it_replaced():
             assert reads.tolist() == want_reads and number.tolist() == want_number, (trial, dedup, minabund)
 
 
+def test_dedup_survives_colliding_hashes(monkeypatch):
+    """partition's dedup goes by two 64-bit hashes of the canonical sequence and then CONFIRMS every would-be duplicate against the
+    sequence its run started with (kv_canonical_reads_equal: the reference compares the strings, kevlar/partition.py:26-33).  With
+    the hashes forced to collide for every read, what is dropped must still be exactly the reads whose canonical sequence was seen
+    before in their partition."""
+    import random
+    import numpy as np
+    import kevlar_amd
+    from kevlar_amd import partition as part_mod
+    rng = random.Random(21)
+    pool = [''.join(rng.choice('ACGTacgtN') for _ in range(rng.choice([1, 12, 30]))) for _ in range(25)]      # (revcom upper-cases: not an involution)
+    seqs = [kevlar_amd.revcom(s) if rng.random() < 0.5 else s for s in (rng.choice(pool) for _ in range(300))]
+    names = ['r{:04d}'.format(i) for i in range(300)]
+    nb = ''.join(names).encode(); no = np.cumsum([0] + [len(x) for x in names]).astype(np.uint64)
+    sb = ''.join(seqs).encode(); so = np.cumsum([0] + [len(x) for x in seqs]).astype(np.uint64)
+    pairs = part_mod._same_canonical(sb, so, np.arange(299), np.arange(1, 300))
+    assert pairs.tolist() == [kevlar_amd.revcommin(seqs[i]) == kevlar_amd.revcommin(seqs[i + 1]) for i in range(299)]
+    labels = np.array([i % 7 for i in range(300)], dtype=np.uint32)
+    want = part_mod.assemble_partitions(nb, no, sb, so, lambda node_of_read, n_nodes: labels, None, True)
+    monkeypatch.setattr(part_mod, '_canonical_hashes', lambda s_, o_, reads: (np.zeros(len(reads), dtype=np.uint64), np.zeros(len(reads), dtype=np.uint64)))
+    got = part_mod.assemble_partitions(nb, no, sb, so, lambda node_of_read, n_nodes: labels, None, True)
+    # with one hash for everybody a run is a whole partition and only its FIRST sequence is confirmed against: copies of that one go,
+    # every other read stays -- never a read whose sequence differs from the one it was compared with
+    kept = set(got[0].tolist())
+    for reads_, number in (got,):
+        for p_ in set(number.tolist()):
+            members = [r for r, q in zip(reads_.tolist(), number.tolist()) if q == p_]
+            first_seq = kevlar_amd.revcommin(seqs[members[0]])
+            assert sum(1 for r in members if kevlar_amd.revcommin(seqs[r]) == first_seq) == 1
+    assert kept >= set(want[0].tolist())              # nothing the true dedup keeps was dropped
+
+
 def test_fixed_width_rows_are_the_strings_nul_padded():
     """partition's name matrix: one NUL-padded row per string, whatever the lengths (ragged: rows gathered from a sliding window;
     one length back to back: the blob reshaped; offsets that start behind the blob's first byte; empty strings; no strings)"""
