@@ -70,12 +70,16 @@ struct DevTextSource {
     int fd = -1;
     const uint8_t *image = nullptr;
     size_t image_size = 0;
-    KvGunzip *gz = nullptr;
+    KvGunzip *gz = nullptr;        // one DEFLATE stream (gzip, pigz): parallel stretches between found block starts (kv_gunzip.hip)
+    std::vector<KvBgzfMember> members;   // blocked gzip (bgzip, this package's writer): a wavefront per member, CRC-32 checked (kv_inflate.hip)
+    size_t next_member = 0;
     KvGunzipArenas arenas;
-    KvArena text;
+    KvArena text, comp, scratch;
     uint64_t delivered = 0;        // bytes of text handed to the parser so far
     ~DevTextSource()
     {
+        for (KvArena *a : {&comp, &scratch})
+            if (a->p) (void)hipFree(a->p);
         if (gz) kv_gunzip_close(gz);
         arenas.release();
         if (text.p) (void)hipFree(text.p);
@@ -122,10 +126,29 @@ static bool fx_fill(kv_fastx *f)
         uint64_t n = 0;
         bool last = false;
         int rc = KV_OK;
-        while (rc == KV_OK && n == 0 && !kv_gunzip_done(d->gz)) rc = kv_gunzip_decode(d->gz, want, &n, &last);
-        if (rc == KV_OK && n) {
-            if (d->text.need(n + 256) != hipSuccess) { (void)hipGetLastError(); rc = KV_ERR_TYPE; }
-            else rc = kv_gunzip_emit(d->gz, (uint8_t *)d->text.p);
+        if (!d->gz) {
+            // blocked gzip: as many whole members as make up the segment
+            const size_t m0 = d->next_member;
+            size_t m1 = m0;
+            while (m1 < d->members.size() && (m1 == m0 || n + d->members[m1].isize <= want)) n += d->members[m1++].isize;
+            if (m1 > m0) {
+                hipStream_t st = kv_stream();
+                const uint64_t c0 = d->members[m0].in_off, c1 = d->members[m1 - 1].in_off + d->members[m1 - 1].in_len;
+                std::vector<uint64_t> text_off(m1 - m0);
+                uint64_t at = 0;
+                for (size_t i = m0; i < m1; ++i) { text_off[i - m0] = at; at += d->members[i].isize; }
+                if (d->comp.need(kv_round_up(c1 - c0 + KV_INFLATE_SLACK, 4096)) != hipSuccess || d->text.need(n + 256) != hipSuccess) { (void)hipGetLastError(); rc = KV_ERR_TYPE; }
+                else if (hipMemcpyAsync(d->comp.p, d->image + c0, c1 - c0, hipMemcpyHostToDevice, st) != hipSuccess ||
+                         hipMemsetAsync((uint8_t *)d->comp.p + (c1 - c0), 0, KV_INFLATE_SLACK, st) != hipSuccess) { (void)hipGetLastError(); rc = KV_ERR_TYPE; }
+                else rc = kv_bgzf_inflate((const uint8_t *)d->comp.p, c0, d->members.data() + m0, m1 - m0, text_off.data(), (uint8_t *)d->text.p, d->scratch);
+                if (rc == KV_OK) d->next_member = m1;
+            }
+        } else {
+            while (rc == KV_OK && n == 0 && !kv_gunzip_done(d->gz)) rc = kv_gunzip_decode(d->gz, want, &n, &last);
+            if (rc == KV_OK && n) {
+                if (d->text.need(n + 256) != hipSuccess) { (void)hipGetLastError(); rc = KV_ERR_TYPE; }
+                else rc = kv_gunzip_emit(d->gz, (uint8_t *)d->text.p);
+            }
         }
         if (rc == KV_OK && n) {
             if (f->buf.size() - f->end < n) f->buf.resize(f->end + n);
@@ -403,8 +426,12 @@ static void fx_open_device_text(kv_fastx *f, size_t size)
     void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, d->fd, 0);
     if (map == MAP_FAILED) { delete d; return; }
     d->image = (const uint8_t *)map; d->image_size = size;
-    d->gz = kv_gunzip_open(d->image, size, &d->arenas);
-    if (!d->gz) { delete d; return; }
+    int is_bgzf = 0;
+    if (kv_bgzf_index(d->image, size, &d->members, &is_bgzf) != KV_OK || !is_bgzf || d->members.empty()) {
+        d->members.clear();
+        d->gz = kv_gunzip_open(d->image, size, &d->arenas);
+        if (!d->gz) { delete d; return; }
+    }
     f->dsrc = d;
 }
 

@@ -350,7 +350,8 @@ def test_fasta_gz_is_inflated_on_the_device_and_parsed_on_the_host(hk, tmp_path,
     try:
         dev = batches_of(hk, path, 700, {'KV_GUNZIP_TEXT_MIN_MB': '1', 'KV_INGEST_TEXT_MB': '1'})
         ms, n = ctypes.c_double(), ctypes.c_uint64()
-        lib.kv_prof_get(b'k_gz_decode', ctypes.byref(ms), ctypes.byref(n))
+        # one DEFLATE stream: parallel stretches (kv_gunzip.hip); blocked gzip: a wavefront per member, CRC-32 checked (kv_inflate.hip)
+        lib.kv_prof_get(b'k_gz_decode' if kind == 'gzip' else b'k_inflate', ctypes.byref(ms), ctypes.byref(n))
     finally:
         lib.kv_prof_enable(0)
     assert n.value >= 5, 'the device inflater must have decoded the segments'

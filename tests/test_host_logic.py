@@ -701,6 +701,32 @@ def test_dedup_survives_colliding_hashes(monkeypatch):
     assert kept >= set(want[0].tolist())              # nothing the true dedup keeps was dropped
 
 
+def test_dedup_runs_take_the_exact_order_when_two_groups_share_a_mixed_key():
+    """partition's dedup sorts its members ONCE, by a 64-bit mix of partition number and first hash; two different (partition, h1)
+    pairs with the same mix would interleave in that order and a duplicate would be missed -- so the runs of equal keys are put into
+    the exact (partition, h1, h2, member) order themselves.  Crafted: partition 0 with h1 = X and partition 1 with h1 = X ^ MIX share a key."""
+    import numpy as np
+    from kevlar_amd.partition import _dedup_runs, _MIX
+    X = 0x1234567890abcdef
+    part = np.array([0, 1, 0, 1, 0, 2], dtype=np.int64)
+    h1 = np.array([X, X ^ _MIX, X, X ^ _MIX, X, 7], dtype=np.uint64)
+    h2 = np.array([5, 5, 5, 5, 6, 5], dtype=np.uint64)
+    dup, head = _dedup_runs(part, h1, h2)
+    assert sorted(zip(dup.tolist(), head.tolist())) == [(2, 0), (3, 1)]      # members 2 and 3 repeat members 0 and 1; member 4 differs in h2
+    rng = np.random.default_rng(2)
+    part = np.sort(rng.integers(0, 50, size=5000)).astype(np.int64)
+    h1 = rng.integers(0, 40, size=5000).astype(np.uint64)
+    h2 = rng.integers(0, 3, size=5000).astype(np.uint64)
+    dup, head = _dedup_runs(part, h1, h2)
+    seen, want = {}, []
+    for i, key in enumerate(zip(part.tolist(), h1.tolist(), h2.tolist())):
+        if key in seen:
+            want.append((i, seen[key]))
+        else:
+            seen[key] = i
+    assert sorted(zip(dup.tolist(), head.tolist())) == want
+
+
 def test_fixed_width_rows_are_the_strings_nul_padded():
     """partition's name matrix: one NUL-padded row per string, whatever the lengths (ragged: rows gathered from a sliding window;
     one length back to back: the blob reshaped; offsets that start behind the blob's first byte; empty strings; no strings)"""
