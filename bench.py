@@ -362,7 +362,8 @@ def main():
                 extra = dict(mask_ptr=band_mask.data_ptr(), mask_stride=nk)
             r, o, a, _ = hk.novel_scan([sk['proband']], [sk[n] for n in controls], batch, args.case_min, args.ctrl_max,
                                        band_mode=band_mode, nbands=nbands, band=band, **extra)
-            rs.append(np.asarray(r, dtype=np.uint32) + np.uint32(first)); os_.append(o); as_.append(a)
+            # (a sample that is one batch: its read indices are the batch's -- no 9 MB copy just to add zero, a millisecond per step)
+            rs.append(r if first == 0 else np.asarray(r, dtype=np.uint32) + np.uint32(first)); os_.append(o); as_.append(a)
         if len(rs) == 1:
             return rs[0], os_[0], as_[0]
         return np.concatenate(rs), np.concatenate(os_), np.concatenate(as_)

@@ -6,7 +6,7 @@
 # --pmc pass per counter (FETCH_SIZE and WRITE_SIZE do not fit one pass; counters are never combined
 # with trace domains other than the kernel trace).
 set -u
-ROUND=${1:-r3_final}
+ROUND=${1:-r4_final}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/$ROUND
 mkdir -p "$OUT"
@@ -26,9 +26,14 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- 
 # SQ counters of the count / scan kernels at their current shape (two --pmc passes of eight counters over one count of
 # each sample + one scan)
 (cd $REPO && bash scratch/pmc_skm.sh > $OUT/pmc_skm.log 2>&1)
+# the same for config 5 (k = 51: two-word keys) and for the kernels of config 4's band shape (k_consume under banding, k_novel_mark)
+[[ " ${COLLECT_SKIP:-} " == *" cfg5 "* ]] || (cd $REPO && PMC_K=51 PMC_TAG=cfg5 bash scratch/pmc_skm.sh > $OUT/pmc_skm_cfg5.log 2>&1)
+[[ " ${COLLECT_SKIP:-} " == *" cfg4 "* ]] || (cd $REPO && PMC_SCRIPT=scratch/pmc_band.py PMC_TAG=cfg4 bash scratch/pmc_skm.sh > $OUT/pmc_skm_cfg4.log 2>&1)
 # config 5 (proband + 3 controls, k = 51): bench line and the profiler's kernel statistics
-[[ " ${COLLECT_SKIP:-} " == *" cfg5 "* ]] || timeout 900 python3 $REPO/bench.py --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-replay > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
+[[ " ${COLLECT_SKIP:-} " == *" cfg5 "* ]] || timeout 1200 python3 $REPO/bench.py --gpus 1 --steps 20 --warmup 5 --workload cfg5 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err      # the driver's style of command
 [[ " ${COLLECT_SKIP:-} " == *" cfg5 "* ]] || timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg5 -- python3 $REPO/bench.py --workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 > $OUT/bench_cfg5_under_rocprof.json 2> $OUT/trace_cfg5.err
 python3 $REPO/profiles/summarise.py $OUT $OUT/summary
 cp $REPO/gpurun_out/pmc_skm/summary.txt $OUT/summary/sq_counters.txt 2>/dev/null
+cp $REPO/gpurun_out/pmc_skm_cfg5/summary.txt $OUT/summary/sq_counters_cfg5.txt 2>/dev/null
+cp $REPO/gpurun_out/pmc_skm_cfg4/summary.txt $OUT/summary/sq_counters_cfg4_band.txt 2>/dev/null
 ls -la $OUT/summary

@@ -1,10 +1,12 @@
 #!/bin/bash
 # SQ counters of the super-k-mer kernels at config 2 (two passes of 8 counters), per wave-instruction totals
 REPO=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$REPO/gpurun_out/pmc_skm; rm -rf $OUT; mkdir -p $OUT
+# PMC_K=51: config 5's two-word keys; PMC_SCRIPT=scratch/pmc_band.py: the kernels of config 4's band shape; PMC_TAG names the output
+SCRIPT=${PMC_SCRIPT:-scratch/pmc_count.py}
+OUT=$REPO/gpurun_out/pmc_skm${PMC_TAG:+_$PMC_TAG}; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/a -- python3 $REPO/scratch/pmc_count.py > $OUT/a.log 2>&1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/b -- python3 $REPO/scratch/pmc_count.py > $OUT/b.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/a -- python3 $REPO/$SCRIPT > $OUT/a.log 2>&1
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/b -- python3 $REPO/$SCRIPT > $OUT/b.log 2>&1
 python3 - <<PY | tee $OUT/summary.txt
 import csv, glob, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
