@@ -120,6 +120,7 @@ struct KvGunzipArenas {
     }
 };
 
+bool kv_bin_two_bit(const kv_sketch *s, const kv_reads *reads);      // stage A can hash this batch from its 2-bit form (k_bin_hash_2bit)
 int kv_device_cus();
 static inline uint64_t kv_round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
 

@@ -33,6 +33,7 @@
 
 #include "kv_binned.h"
 #include "kv_device.h"
+#include "kv_kmer2bit_device.h"
 
 namespace {
 
@@ -356,6 +357,82 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash_
             }
         }
     }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < ns; s += THREADS)
+        g.gcnt1[(uint64_t)s * g.nwgA + blockIdx.x] = (uint32_t)min((uint64_t)cur[s], g.cap1);
+    n_added = wave_sum_u64(n_added);
+    if ((threadIdx.x & 63) == 0 && n_added) atomicAdd(&g.ctr[2], (unsigned long long)n_added);
+}
+
+// Stage A for batches of equal-length reads, hashed from the 2-bit form (kv_kmer2bit_device.h): a thread takes BIN2_CH consecutive
+// k-mers of one read; what passes the band / mask filter is collected per wave and routed 64 at a time -- T reductions, T items through
+// the LDS cursors, direct stores, exactly as k_bin_hash_direct stores them.  A ticket is BIN2_TILES tiles' worth of reads.
+#define BIN2_CH 10
+#define BIN2_TILES 8u
+template <int THREADS, int KW>
+__global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash_2bit(
+    ReadsDev rd, uint32_t n_units, const SketchDev *__restrict__ sk, const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
+{
+    __shared__ uint32_t lut[256];
+    __shared__ uint32_t cur[BIN_MAX_T * BIN_C];
+    __shared__ uint32_t next_unit;
+    __shared__ unsigned long long queue[(THREADS / 64) * 128];
+    const uint32_t ns = (uint32_t)(g.T * g.C);
+    for (uint32_t s = threadIdx.x; s < ns; s += THREADS) cur[s] = 0;
+    if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    const int k = f.hp.k;
+    const uint32_t L = rd.uni_len, wpr = (L + 15u) >> 4, nk = L - (uint32_t)k + 1u, cpr = (nk + BIN2_CH - 1u) / BIN2_CH;
+    const float inv_cpr = 1.0f / (float)cpr;
+    const uint64_t reads_per_unit = (uint64_t)BIN2_TILES * rd.uni_per_tile;
+    WaveQueue wq;
+    wq.q = queue + (threadIdx.x >> 6) * 128u;
+    wq.n = 0;
+    uint64_t n_added = 0;
+    auto route = [&](bool have, uint64_t h) {
+        if (!have) return;
+        n_added += 1;
+        uint32_t sidx[BIN_MAX_T], item[BIN_MAX_T], pos[BIN_MAX_T];
+        uint64_t bins[BIN_MAX_T];
+#pragma unroll
+        for (int t = 0; t < BIN_MAX_T; ++t) {
+            if (t >= g.T) break;
+            const uint64_t bin = fastmod(h, sk->size[t], sk->magic[t]);
+            const uint32_t slice = (uint32_t)(bin >> 16);
+            const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
+            bins[t] = bin;
+            item[t] = ((slice - c * (uint32_t)g.F) << 16) | (uint32_t)(bin & 0xffffu);
+            sidx[t] = (uint32_t)t * (uint32_t)g.C + c;
+        }
+#pragma unroll
+        for (int t = 0; t < BIN_MAX_T; ++t)
+            if (t < g.T) pos[t] = atomicAdd(&cur[sidx[t]], 1u);
+#pragma unroll
+        for (int t = 0; t < BIN_MAX_T; ++t) {
+            if (t >= g.T) break;
+            if (pos[t] < g.cap1) g.gbuf1[((uint64_t)sidx[t] * g.nwgA + blockIdx.x) * g.cap1 + pos[t]] = item[t];
+            else spill_item(g, t, bins[t]);
+        }
+    };
+    for (uint32_t taken = 0; taken < g.quotaA; ++taken) {
+        __syncthreads();
+        if (threadIdx.x == 0) next_unit = (uint32_t)atomicAdd(&g.ctr[4], 1ull);
+        __syncthreads();
+        const uint32_t unit = next_unit;
+        if (unit >= n_units) break;
+        const uint64_t r0 = (uint64_t)unit * reads_per_unit;
+        const uint32_t nr = (uint32_t)min(reads_per_unit, rd.n_reads - r0), n_items = nr * cpr;
+        // (whole waves go round together: the queue's ballots want every lane there)
+        for (uint32_t i0 = (threadIdx.x & ~63u); i0 < n_items; i0 += THREADS) {
+            const uint32_t i = i0 + (threadIdx.x & 63u);
+            const bool mine = i < n_items;
+            const uint32_t r = mine ? k2_div(i, cpr, inv_cpr) : 0u, j0 = mine ? (i - r * cpr) * BIN2_CH : 0u;
+            const uint32_t cnt = mine ? min((uint32_t)BIN2_CH, nk - j0) : 0u;
+            kmer2bit_walk<KW, BIN2_CH>(rd.words + (r0 + r) * wpr, j0, cnt, k, lut, f.hp, [&](bool live, uint64_t h) {
+                wave_queue_push(wq, live && consume_filter_pass(f, mask, h), h, route);
+            });
+        }
+    }
+    wave_queue_flush(wq, route);
     __syncthreads();
     for (uint32_t s = threadIdx.x; s < ns; s += THREADS)
         g.gcnt1[(uint64_t)s * g.nwgA + blockIdx.x] = (uint32_t)min((uint64_t)cur[s], g.cap1);
@@ -885,6 +962,15 @@ double kv_estimate_distinct(uint64_t occupied, uint64_t size)
     return -(double)size * std::log1p(-(double)occupied / (double)size);
 }
 
+// can stage A hash this batch from its 2-bit form (k_bin_hash_2bit)?  Reads of one length, murmur kinds, 16 <= k <= 64.  KV_BIN_2BIT=0: never
+bool kv_bin_two_bit(const kv_sketch *s, const kv_reads *reads)
+{
+    const char *e = getenv("KV_BIN_2BIT");
+    if (e && atoi(e) == 0) return false;
+    return reads && reads->uni_len != 0 && reads->uni_per_tile != 0 && s->h.hashfam == HF_MURMUR && s->h.ksize >= SKM_MIN_K && s->h.ksize <= SKM_MAX_K &&
+           reads->uni_len >= (uint32_t)s->h.ksize && reads->n_tiles > 0;
+}
+
 bool kv_binned_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_kmers, int nbands)
 {
     // reads == nullptr: the items come from a hash list (kv_consume_hashes)
@@ -896,8 +982,12 @@ bool kv_binned_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_km
     if (pmax > (uint64_t)BIN_C * BIN_MAX_F * 65536ull) return false;      // <= 2^31 bins per table
     if (force && (strcmp(force, "binned") == 0 || strcmp(force, "skm") == 0)) return reads ? reads->n_tiles > 0 : n_kmers > 0;
     const uint64_t expected = nbands > 0 ? n_kmers / (uint64_t)nbands : n_kmers;
-    // worth it once the batch touches the tables about as densely as streaming them costs
-    return pmin >= (1ull << 20) && expected >= (1ull << 22) && expected * 8 >= pmax;
+    // worth it once the batch touches the tables about as densely as streaming them costs.  With the 2-bit stage A the hashing costs
+    // half as much, and what is left to compare is T global compare-and-swaps per k-mer that reaches the tables (~27 G/s device-wide)
+    // against streaming the tables once (read + write at ~4.7 TB/s) plus the split: even at one k-mer per 32 bins -- config 4's
+    // 0.6x batches under 8-fold banding: 164 M k-mers into 2 G bins -- the atomics cost 24 ms and the streamed tables 3.4 + 7
+    const uint64_t density = reads && kv_bin_two_bit(s, reads) ? 32 : 8;
+    return pmin >= (1ull << 20) && expected >= (1ull << 22) && expected * density >= pmax;
 }
 
 int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, uint64_t work_units, uint32_t lds_front,
@@ -1061,21 +1151,31 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
     // source: the packed reads (hash in stage A) or, when reads == nullptr, n_kmers hashes at d_list[i * list_stride]
     hipStream_t st = kv_stream();
     BinPlan plan;
+    const bool two_bit = reads && kv_bin_two_bit(s, reads);
+    const uint32_t n_units2 = two_bit ? (reads->n_tiles + BIN2_TILES - 1u) / BIN2_TILES : 0u;
     {
         // the stage-A workgroup size depends on the geometry, which depends only on the table sizes: probe it first
         uint32_t maxsl = 1;
         for (int t = 0; t < s->h.ntables; ++t) maxsl = std::max(maxsl, (uint32_t)((s->h.size[t] + 65535) >> 16));
         const uint32_t threadsA = maxsl <= 32u * BIN_MAX_F ? 512u : 1024u;
-        const uint64_t work_units = reads ? reads->n_tiles
+        const uint64_t work_units = two_bit ? n_units2 : reads ? reads->n_tiles
                                           : (n_kmers + (uint64_t)threadsA * BIN_LIST_ROUNDS - 1) / ((uint64_t)threadsA * BIN_LIST_ROUNDS);
-        const int rc = kv_bin_plan(s, n_kmers, nbands, filter.use_mask != 0, work_units, reads ? reads->tile_lds_bytes : 0u, 0u, weighted_list, &plan);
+        const int rc = kv_bin_plan(s, n_kmers, nbands, filter.use_mask != 0, work_units, reads && !two_bit ? reads->tile_lds_bytes : 0u, 0u, weighted_list, &plan);
         if (rc != KV_OK) return rc;
     }
     BinGeom &g = plan.g;
     const int cmax = plan.cmax;
     const uint64_t ns = (uint64_t)g.T * g.C;
     const SketchDev *d_mask = mask ? mask->d_desc : nullptr;
-    if (reads) {
+    if (two_bit) {
+        KvProfScope prof("k_bin_hash_2bit");
+        const SketchDev *d = (const SketchDev *)s->d_desc;
+        const bool kw2 = s->h.ksize > 32;
+        if (cmax <= 32 && !kw2) hipLaunchKernelGGL((k_bin_hash_2bit<512, 1>), dim3(g.nwgA), dim3(512), 0, st, reads_dev(reads), n_units2, d, d_mask, filter, g);
+        else if (cmax <= 32) hipLaunchKernelGGL((k_bin_hash_2bit<512, 2>), dim3(g.nwgA), dim3(512), 0, st, reads_dev(reads), n_units2, d, d_mask, filter, g);
+        else if (!kw2) hipLaunchKernelGGL((k_bin_hash_2bit<1024, 1>), dim3(g.nwgA), dim3(1024), 0, st, reads_dev(reads), n_units2, d, d_mask, filter, g);
+        else hipLaunchKernelGGL((k_bin_hash_2bit<1024, 2>), dim3(g.nwgA), dim3(1024), 0, st, reads_dev(reads), n_units2, d, d_mask, filter, g);
+    } else if (reads) {
         // default: direct stores through LDS cursors (k_bin_hash_direct); KV_BIN_DIRECT=0 selects the LDS-ring
         // variant, which measured ~10% slower on this stage (profiles/README.md)
         const bool direct = !(getenv("KV_BIN_DIRECT") && atoi(getenv("KV_BIN_DIRECT")) == 0);

@@ -195,6 +195,8 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
                    uint64_t n_kmers, int nbands, uint64_t *n_added);
 // sets the mask bit of every interesting k-mer of reads[first_read:] (p.mask / p.mask_stride) and p.tile_count
 int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_kmers);
+// hits per tile = set bits of the tile's stretch of the hit mask (p.tile_count), for scans that only mark (k_tile_hits, kv_skm.hip)
+void kv_tile_hits_launch(const kv_reads *reads, const NovelParams &p, hipStream_t st);
 // will a scan of `reads` go by the distinct list its count pass left (k_skm_novel_list)?  (the caller then sets up the table of
 // the interesting k-mers' abundances that kernel fills)
 bool kv_skm_list_ready(const kv_reads *reads, int ksize);

@@ -15,7 +15,9 @@
 #include <functional>
 #include <map>
 
+#include "kv_binned.h"          // kv_device_cus
 #include "kv_novel_device.h"
+#include "kv_kmer2bit_device.h"
 
 namespace {
 
@@ -71,6 +73,47 @@ __device__ __forceinline__ bool novel_test_screen(const NovelParams &p, uint64_t
     for (int c = 0; c < p.nctrl && interesting; ++c)
         if ((int)sketch_get(p.sk[p.ncase + c], h) > p.ctrl_max) interesting = false;
     return interesting;
+}
+
+// k_novel_mark for batches of equal-length reads, hashed from the 2-bit form (kv_kmer2bit_device.h): a thread takes NM2_CH consecutive
+// k-mers of one read; the k-mers of the band are collected per wave and evaluated 64 at a time (kmer_is_interesting(), cheapest evidence
+// first), the interesting ones set their bit of the hit mask; k_tile_hits counts the bits per tile afterwards.  No abundance screen,
+// no verdict cache (a batch that repeats its k-mers takes the super-k-mer scan instead).
+#define NM2_CH 10
+#define NM2_THREADS 512
+template <int KW>
+__global__ __launch_bounds__(NM2_THREADS, 6) void k_novel_mark_2bit(ReadsDev rd, NovelParams p)
+{
+    __shared__ uint32_t lut[256];
+    __shared__ NovelShared ns;
+    __shared__ unsigned long long queue[2 * (NM2_THREADS / 64) * 128];
+    if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    load_descs(ns, p);
+    __syncthreads();
+    const int k = p.hp.k;
+    const uint32_t L = rd.uni_len, wpr = (L + 15u) >> 4, nk = L - (uint32_t)k + 1u, cpr = (nk + NM2_CH - 1u) / NM2_CH;
+    WaveQueue2 wq;
+    wq.q = queue + (threadIdx.x >> 6) * 256u;
+    wq.q2 = wq.q + 128u;
+    wq.n = 0;
+    auto judge = [&](bool have, uint64_t h, uint64_t bit) {
+        if (have && novel_test_fast(ns, p, h, nullptr, 0ull)) atomicOr(&p.mask[bit >> 5], 1u << (bit & 31));
+    };
+    const uint64_t n_items = rd.n_reads * cpr;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * NM2_THREADS + (threadIdx.x & ~63u); i0 < n_items; i0 += (uint64_t)gridDim.x * NM2_THREADS) {
+        const uint64_t i = i0 + (threadIdx.x & 63u);
+        bool mine = i < n_items;
+        const uint64_t r = mine ? i / cpr : 0ull;
+        const uint32_t j0 = mine ? (uint32_t)(i - r * cpr) * NM2_CH : 0u;
+        if (mine && ((rd.flags[r] & 1) || r < p.first_read)) mine = false;        // the scan skips these reads (kevlar/novel.py:134-139)
+        const uint32_t cnt = mine ? min((uint32_t)NM2_CH, nk - j0) : 0u;
+        uint32_t u = 0;
+        kmer2bit_walk<KW, NM2_CH>(rd.words + r * wpr, j0, cnt, k, lut, p.hp, [&](bool live, uint64_t h) {
+            wave_queue_push2(wq, live && band_pass(p, h), h, r * p.mask_stride + j0 + u, judge);
+            u += 1;
+        });
+    }
+    wave_queue_flush2(wq, judge);
 }
 
 __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_mark(ReadsDev rd, NovelParams p)
@@ -606,7 +649,21 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
         }
     }
     if (e == hipSuccess) {
-        if (!marked_by_skm) {
+        // equal-length reads of a murmur kind, 16 <= k <= 64, no abundance screen: every k-mer hashed from its 2-bit form
+        // (k_novel_mark_2bit; KV_NOVEL_PATH=tiles, or KV_NOVEL_2BIT=0, keeps the tile kernel)
+        const char *forced = getenv("KV_NOVEL_PATH"), *nm2 = getenv("KV_NOVEL_2BIT");
+        const bool two_bit = !marked_by_skm && p.screen == 0 && fam == HF_MURMUR && k >= SKM_MIN_K && k <= SKM_MAX_K && reads->uni_len >= (uint32_t)k &&
+                             reads->uni_per_tile != 0 && !(forced && strcmp(forced, "tiles") == 0) && !(nm2 && atoi(nm2) == 0);
+        if (two_bit) {
+            {
+                KvProfScope prof("k_novel_mark_2bit");
+                const uint64_t n_items = reads->n_reads * (((uint64_t)reads->uni_len - (uint64_t)k + 1 + NM2_CH - 1) / NM2_CH);
+                const unsigned grid = (unsigned)std::min<uint64_t>((n_items + NM2_THREADS - 1) / NM2_THREADS, 3u * (unsigned)kv_device_cus() * 4u);
+                if (k <= 32) hipLaunchKernelGGL(k_novel_mark_2bit<1>, dim3(grid), dim3(NM2_THREADS), 0, st, reads_dev(reads), p);
+                else hipLaunchKernelGGL(k_novel_mark_2bit<2>, dim3(grid), dim3(NM2_THREADS), 0, st, reads_dev(reads), p);
+            }
+            kv_tile_hits_launch(reads, p, st);
+        } else if (!marked_by_skm) {
             KvProfScope prof("k_novel_mark");
             kv_ensure_dynamic_lds((const void *)k_novel_mark, reads->tile_lds_bytes);
             hipLaunchKernelGGL(k_novel_mark, dim3(reads->n_tiles), dim3(KV_TILE_THREADS), reads->tile_lds_bytes, st, reads_dev(reads), p);

@@ -2042,6 +2042,12 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     return rc;
 }
 
+void kv_tile_hits_launch(const kv_reads *reads, const NovelParams &p, hipStream_t st)
+{
+    KvProfScope prof("k_tile_hits");
+    hipLaunchKernelGGL(k_tile_hits, dim3(reads->n_tiles), dim3(64), 0, st, reads_dev(reads), p);
+}
+
 bool kv_skm_list_ready(const kv_reads *reads, int ksize)
 {
     if (getenv("KV_SKM_NO_REUSE") || (getenv("KV_SKM_DL") && atoi(getenv("KV_SKM_DL")) == 0)) return false;

@@ -64,14 +64,14 @@ def counted(hk, family):
             sk[name].clear()
             for b in batches[name]:
                 kmers += sk[name].consume_batch(b, NBANDS, BAND)
-        for scope in ('k_skm_emit', 'k_skm_count', 'k_consume', 'k_bin_hash_direct', 'k_bin_split', 'k_bin_apply'):
+        for scope in ('k_skm_emit', 'k_skm_count', 'k_consume', 'k_bin_hash_direct', 'k_bin_hash_2bit', 'k_bin_split', 'k_bin_apply'):
             seen[scope] = prof.count(scope)
     with Profiled(hk) as prof:
         rs, os_, as_ = [], [], []
         for first, b in zip(firsts, batches['proband']):
             r, o, a, _ = hk.novel_scan([sk['proband']], [sk['mother'], sk['father']], b, CASE_MIN, CTRL_MAX, band_mode=1, nbands=NBANDS, band=BAND)
             rs.append(np.asarray(r, dtype=np.uint32) + np.uint32(first)); os_.append(np.asarray(o, dtype=np.uint32)); as_.append(np.asarray(a, dtype=np.uint8))
-        for scope in ('k_skm_novel', 'k_skm_novel_list', 'k_novel_mark', 'k_skm_emit'):
+        for scope in ('k_skm_novel', 'k_skm_novel_list', 'k_novel_mark', 'k_novel_mark_2bit', 'k_skm_emit'):
             seen['scan:' + scope] = prof.count(scope)
     hits = (np.concatenate(rs), np.concatenate(os_), np.concatenate(as_))
     return sk, kmers, hits, seen
@@ -127,7 +127,7 @@ def test_band_sketches_equal_the_oracle(hk, counted, oracle_side, family):
     # a 0.6x batch has nothing to deduplicate: the super-k-mer count declines, and the sketch remembers -- it is tried at most once
     # per sketch, not 48 times
     assert seen['k_skm_emit'] <= len(NAMES), seen
-    assert seen['k_consume'] + seen['k_bin_hash_direct'] >= 3 * 48 - len(NAMES), seen
+    assert seen['k_consume'] + seen['k_bin_hash_direct'] + seen['k_bin_hash_2bit'] >= 3 * 48 - len(NAMES), seen
 
 
 def test_band_hits_equal_the_oracle(counted, oracle_side):
@@ -140,7 +140,7 @@ def test_band_hits_equal_the_oracle(counted, oracle_side):
     assert np.array_equal(r, wr) and np.array_equal(o, wo.astype(np.uint32)) and np.array_equal(a, wa)
     # the scan of a batch that cannot be deduplicated goes straight to the tile scan: cutting it into super-k-mers first, running
     # into the tables' capacity and scanning again (round 3: 48 launches of each per step) may happen once, not per batch
-    assert seen['scan:k_novel_mark'] >= 47, seen
+    assert seen['scan:k_novel_mark'] + seen['scan:k_novel_mark_2bit'] >= 47, seen
     assert seen['scan:k_skm_novel'] <= 1 and seen['scan:k_skm_emit'] <= 1, seen
 
 

@@ -11,7 +11,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ('KV_COUNT_PATH', 'KV_NOVEL_PATH', 'KV_SKM_BUCKET_KMERS', 'KV_SKM_CAP_PCT', 'KV_SKM_LOOSE_CAP', 'KV_SKM_NO_REUSE', 'KV_SKM_FORCE_LOOSE', 'KV_SKM_DL', 'KV_SKM_ANY_K')
+KNOBS = ('KV_COUNT_PATH', 'KV_NOVEL_PATH', 'KV_SKM_BUCKET_KMERS', 'KV_SKM_CAP_PCT', 'KV_SKM_LOOSE_CAP', 'KV_SKM_NO_REUSE', 'KV_SKM_FORCE_LOOSE', 'KV_SKM_DL', 'KV_SKM_ANY_K',
+         'KV_BIN_2BIT', 'KV_NOVEL_2BIT')
 
 
 def launches(name):
@@ -34,6 +35,11 @@ def skm():
     lib.kv_prof_enable(0)
     for name in KNOBS:
         os.environ.pop(name, None)
+
+
+def stage_a():
+    """launches of the partitioned count's per-k-mer front end: the tile kernel, or (reads of one length) the one that hashes from the 2-bit form"""
+    return launches('k_bin_hash_direct') + launches('k_bin_hash_2bit')
 
 
 def trio_reads(genome_len, n, seed, read_len=100):
@@ -162,12 +168,12 @@ def test_skm_skew_saturation_and_overflow_paths(hk, ok, skm):
     dev, ref, n_dev, n_ref = count_both(hk, ok, 'Counttable', 31, 1e6, reads)
     assert n_dev == n_ref
     assert_same_tables(dev, ref)
-    assert launches('k_skm_count') == 3 and launches('k_bin_hash_direct') == 0
+    assert launches('k_skm_count') == 3 and stage_a() == 0
     os.environ['KV_SKM_LOOSE_CAP'] = '64'
     dev, ref, n_dev, n_ref = count_both(hk, ok, 'Counttable', 31, 1e6, reads)
     assert n_dev == n_ref
     assert_same_tables(dev, ref)
-    assert launches('k_bin_hash_direct') + launches('k_consume') >= 1      # the fallback ran
+    assert stage_a() + launches('k_consume') >= 1      # the fallback ran
 
 
 def test_skm_band_and_mask(hk, ok, skm):
@@ -330,19 +336,24 @@ def test_default_paths_on_a_large_batch_agree_with_the_other_implementations(hk,
     reads = trio_reads(400000, 70000, 51)
     batches = {n: hk.ReadBatch(reads[n]) for n in reads}
     sk = {}
-    for path in (None, 'binned', 'atomic'):
+    for path in (None, 'binned', 'binned-tiles', 'atomic'):
         if path:
-            os.environ['KV_COUNT_PATH'] = path
+            os.environ['KV_COUNT_PATH'] = path.split('-')[0]
         else:
             os.environ.pop('KV_COUNT_PATH', None)
+        if path == 'binned-tiles':
+            os.environ['KV_BIN_2BIT'] = '0'              # the partition's tile front end (reads of one length take the 2-bit one by default)
+        else:
+            os.environ.pop('KV_BIN_2BIT', None)
         sk[path] = {n: hk.Counttable(31, 2e7 / 4, 4) for n in ('mother', 'father', 'proband')}
         for n in ('mother', 'father', 'proband'):
             assert sk[path][n].consume_batch(batches[n]) == 70000 * 70
     os.environ.pop('KV_COUNT_PATH', None)
-    assert launches('k_skm_count') == 3 and launches('k_bin_hash_direct') == 3 and launches('k_consume') == 3
+    os.environ.pop('KV_BIN_2BIT', None)
+    assert launches('k_skm_count') == 3 and launches('k_bin_hash_2bit') == 3 and launches('k_bin_hash_direct') == 3 and launches('k_consume') == 3
     for n in reads:
         for t in range(4):
-            assert sk[None][n].table_bytes(t) == sk['binned'][n].table_bytes(t) == sk['atomic'][n].table_bytes(t)
+            assert sk[None][n].table_bytes(t) == sk['binned'][n].table_bytes(t) == sk['binned-tiles'][n].table_bytes(t) == sk['atomic'][n].table_bytes(t)
         assert sk[None][n].n_occupied() == sk['atomic'][n].n_occupied()
     res = {}
     for path in (None, 'tiles'):
