@@ -33,6 +33,21 @@ def prof():
         os.environ.pop(name, None)
 
 
+class Uniform(object):
+    """a batch with the arithmetic layout the 2-bit kernels need (every read the same length), made the way real input makes it: the
+    reads as a FASTQ file, parsed and packed on the device (kv_fastq.hip) -- reads with N or lower case keep their flags that way.
+    hk.ReadBatch(list of strings) goes through the ragged constructor and never has that layout."""
+    def __init__(self, hk, tmp_path, seqs, tag):
+        path = str(tmp_path / '{}.fq'.format(tag))
+        with open(path, 'w') as fh:
+            for i, seq in enumerate(seqs):
+                fh.write('@r{}\n{}\n+\n{}\n'.format(i, seq, 'I' * len(seq)))
+        self.parser = hk.ReadParser(path)
+        self.text = self.parser.text_batch(len(seqs) + 16)
+        assert type(self.text).__name__ == 'DeviceTextBatch' and self.text.n == len(seqs)
+        self.batch = self.text.batch
+
+
 def family(genome_len, n, seed, read_len):
     from kevlar_amd import synth
     trio = synth.make_trio(genome_len, seed, inherited_per_mb=400, denovo_per_mb=600)
@@ -46,14 +61,15 @@ def family(genome_len, n, seed, read_len):
                                              ('Counttable', 16, 100), ('Counttable', 17, 37), ('Counttable', 32, 96), ('Counttable', 33, 100),
                                              ('Counttable', 47, 100), ('Counttable', 48, 64), ('Counttable', 51, 100), ('Counttable', 64, 100),
                                              ('Counttable', 31, 41), ('Counttable', 31, 31), ('Counttable', 25, 250)])
-def test_two_bit_count_equals_the_oracle_and_the_tile_front_end(hk, ok, prof, kind, k, read_len):
+def test_two_bit_count_equals_the_oracle_and_the_tile_front_end(hk, ok, prof, tmp_path, kind, k, read_len):
     reads = family(60000, 9000, 3, read_len)['proband']
+    uni = Uniform(hk, tmp_path, reads, 'count')
     os.environ['KV_COUNT_PATH'] = 'binned'
     nk = read_len - k + 1
     for nbands, band in ((0, 0), (8, 0), (8, 7), (3, 1)):
         prof.kv_prof_reset()
         dev = getattr(hk, kind)(k, 4e5, 4)
-        n_dev = dev.consume_batch(hk.ReadBatch(reads), nbands, band)
+        n_dev = dev.consume_batch(uni.batch, nbands, band)
         assert launches('k_bin_hash_2bit') == 1 and launches('k_bin_hash_direct') == 0 and launches('k_consume') == 0
         ref = getattr(ok, kind)(k, 4e5, 4)
         bases, offs = ok.concat_reads(reads)
@@ -64,13 +80,23 @@ def test_two_bit_count_equals_the_oracle_and_the_tile_front_end(hk, ok, prof, ki
         assert dev.n_occupied() == ref.n_occupied()
     os.environ['KV_BIN_2BIT'] = '0'
     old = getattr(hk, kind)(k, 4e5, 4)
-    old.consume_batch(hk.ReadBatch(reads), 3, 1)
+    old.consume_batch(uni.batch, 3, 1)
     assert launches('k_bin_hash_direct') == 1
     for t in range(4):
         assert old.table_bytes(t) == dev.table_bytes(t)
+    # the packed constructor gives the same layout (bench.py's batches)
+    from kevlar_amd import synth
+    os.environ.pop('KV_BIN_2BIT', None)
+    prof.kv_prof_reset()
+    again = getattr(hk, kind)(k, 4e5, 4)
+    codes = np.frombuffer(''.join(reads).encode(), dtype=np.uint8).reshape(len(reads), read_len)
+    again.consume_batch(hk.ReadBatch.from_packed(synth.pack_codes(np.searchsorted(np.frombuffer(b'ACGT', dtype=np.uint8), codes)), read_len), 3, 1)
+    assert launches('k_bin_hash_2bit') == 1
+    for t in range(4):
+        assert again.table_bytes(t) == dev.table_bytes(t)
 
 
-def test_two_bit_count_with_a_mask_and_reads_outside_acgt(hk, ok, prof):
+def test_two_bit_count_with_a_mask_and_reads_outside_acgt(hk, ok, prof, tmp_path):
     """consume_seqfile_with_mask / _banding_with_mask (kevlar/count.py:43-60) through the 2-bit front end; reads with N and lower case
     are counted as khmer counts them (cleaned to A / upper case)"""
     reads = family(50000, 7000, 8, 100)
@@ -83,10 +109,11 @@ def test_two_bit_count_with_a_mask_and_reads_outside_acgt(hk, ok, prof):
     bases, offs = ok.concat_reads(reads['mother'])
     ok.consume_reads(mask_ref, bases, offs, len(reads['mother']))
     bases, offs = ok.concat_reads(sample)
+    uni = Uniform(hk, tmp_path, sample, 'masked')
     for nbands, band, masked in ((0, 0, False), (0, 0, True), (4, 2, False)):
         prof.kv_prof_reset()
         dev, ref = hk.Counttable(31, 3e5, 4), ok.Counttable(31, 3e5, 4)
-        n_dev = dev.consume_batch(hk.ReadBatch(sample), nbands, band, mask=mask_dev, threshold=1 if masked else 0, consume_masked=masked)
+        n_dev = dev.consume_batch(uni.batch, nbands, band, mask=mask_dev, threshold=1 if masked else 0, consume_masked=masked)
         n_ref = ok.consume_reads(ref, bases, offs, len(sample), nbands, band, mask_ref, 1 if masked else 0, masked)
         assert launches('k_bin_hash_2bit') == 1
         assert n_dev == n_ref > 0
@@ -96,7 +123,7 @@ def test_two_bit_count_with_a_mask_and_reads_outside_acgt(hk, ok, prof):
 
 
 @pytest.mark.parametrize('k,read_len', [(31, 100), (51, 100), (16, 100), (64, 100), (32, 96), (33, 41), (25, 250)])
-def test_two_bit_scan_equals_the_oracle_and_the_tile_scan(hk, ok, prof, k, read_len):
+def test_two_bit_scan_equals_the_oracle_and_the_tile_scan(hk, ok, prof, tmp_path, k, read_len):
     reads = family(50000, 8000, 11, read_len)
     sample = list(reads['proband'])
     sample[5] = sample[5][:10] + 'N' + sample[5][11:]            # the scan skips reads with bases outside ACGT (kevlar/novel.py:134-139)
@@ -107,7 +134,8 @@ def test_two_bit_scan_equals_the_oracle_and_the_tile_scan(hk, ok, prof, k, read_
         dev[n].consume_batch(hk.ReadBatch(seqs))
         bases, offs = ok.concat_reads(seqs)
         ok.consume_reads(ref[n], bases, offs, len(seqs))
-    batch = hk.ReadBatch(sample)
+    uni = Uniform(hk, tmp_path, sample, 'scan')
+    batch = uni.batch
     bases, offs = ok.concat_reads(sample)
     for band_mode, nbands, band, first in ((0, 0, 0, 0), (1, 8, 0, 0), (1, 8, 7, 0), (2, 4, 2, 0), (0, 0, 0, 3000)):
         want, _ = ok.novel_scan([ref['proband']], [ref['mother'], ref['father']], bases, offs, len(sample), k, 5, 1, band_mode=band_mode, nbands=nbands, band=band)

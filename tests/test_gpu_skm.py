@@ -333,8 +333,12 @@ def test_default_paths_on_a_large_batch_agree_with_the_other_implementations(hk,
     atomic paths, hits equal those of the tile scan"""
     for name in KNOBS:
         os.environ.pop(name, None)
+    from kevlar_amd import synth
     reads = trio_reads(400000, 70000, 51)
-    batches = {n: hk.ReadBatch(reads[n]) for n in reads}
+    letters = np.frombuffer(b'ACGT', dtype=np.uint8)
+    # (packed batches: reads of one length with the arithmetic layout, as bench.py and the device FASTQ parser make them)
+    batches = {n: hk.ReadBatch.from_packed(synth.pack_codes(np.searchsorted(letters, np.frombuffer(''.join(reads[n]).encode(), dtype=np.uint8).reshape(len(reads[n]), 100))), 100)
+               for n in reads}
     sk = {}
     for path in (None, 'binned', 'binned-tiles', 'atomic'):
         if path:
