@@ -43,7 +43,7 @@ class Uniform(object):
             for i, seq in enumerate(seqs):
                 fh.write('@r{}\n{}\n+\n{}\n'.format(i, seq, 'I' * len(seq)))
         self.parser = hk.ReadParser(path)
-        self.text = self.parser.text_batch(len(seqs) + 16)
+        self.text = self.parser.text_batch(4 * len(seqs) + 16)        # (the first batch is sized from a guess of 280 bytes per record)
         assert type(self.text).__name__ == 'DeviceTextBatch' and self.text.n == len(seqs)
         self.batch = self.text.batch
 
