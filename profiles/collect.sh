@@ -32,6 +32,9 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- 
 # config 5 (proband + 3 controls, k = 51): bench line and the profiler's kernel statistics
 [[ " ${COLLECT_SKIP:-} " == *" cfg5 "* ]] || timeout 1200 python3 $REPO/bench.py --gpus 1 --steps 20 --warmup 5 --workload cfg5 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err      # the driver's style of command
 [[ " ${COLLECT_SKIP:-} " == *" cfg5 "* ]] || timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg5 -- python3 $REPO/bench.py --workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-replay --count-streams 1 > $OUT/bench_cfg5_under_rocprof.json 2> $OUT/trace_cfg5.err
+# config 4 as one of its eight GPUs sees it: the step with its downstream stages, and one step under the tracer
+[[ " ${COLLECT_SKIP:-} " == *" cfg4 "* ]] || timeout 1200 python3 $REPO/bench.py --workload cfg4-band > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err
+[[ " ${COLLECT_SKIP:-} " == *" cfg4 "* ]] || timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg4 -- python3 $REPO/bench.py --workload cfg4-band --steps 1 --warmup 1 --no-downstream --count-streams 1 > $OUT/bench_cfg4_under_rocprof.json 2> $OUT/trace_cfg4.err
 python3 $REPO/profiles/summarise.py $OUT $OUT/summary
 cp $REPO/gpurun_out/pmc_skm/summary.txt $OUT/summary/sq_counters.txt 2>/dev/null
 cp $REPO/gpurun_out/pmc_skm_cfg5/summary.txt $OUT/summary/sq_counters_cfg5.txt 2>/dev/null

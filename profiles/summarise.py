@@ -126,6 +126,18 @@ def main(src, dst):
             for row in rows[1:]:
                 if row and ('k_' in row[0] or 'memset' in row[0].lower() or 'rocprim' in row[0]):
                     w.writerow(row)
+    stats = sorted(glob.glob(os.path.join(src, 'trace_cfg4', '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime, reverse=True)
+    if stats:
+        with open(stats[0]) as fh, open(os.path.join(dst, 'cfg4_band_kernel_stats.csv'), 'w') as out:
+            rows = list(csv.reader(fh))
+            w = csv.writer(out)
+            w.writerow(rows[0])
+            for row in rows[1:]:
+                if row and ('k_' in row[0] or 'memset' in row[0].lower() or 'rocprim' in row[0]):
+                    w.writerow(row)
+    for name in ('bench_cfg4.json', 'bench_cfg4_under_rocprof.json'):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, name))
     for name in ('bench_cfg5.json', 'bench_cfg5_under_rocprof.json'):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, name))
