@@ -354,7 +354,20 @@ def main():
 
     def scan_batches(sk, band_mode, nbands, band):
         rs, os_, as_ = [], [], []
-        for first, batch in zip(batch_first, batches['proband']):
+        many = len(batch_first) > 1 and band_mask is None and world == 1 and args.count_streams > 1
+        if many:
+            # the batches of a case sample are independent: scanned side by side on the streams the counts used (every scan is a
+            # few kernels between host round trips -- mask, hit count, hit list -- that another batch's kernels fill)
+            def job(batch):
+                return lambda: hk.novel_scan([sk['proband']], [sk[n] for n in controls], batch, args.case_min, args.ctrl_max,
+                                             band_mode=band_mode, nbands=nbands, band=band)
+            found = []
+            todo = list(batches['proband'])
+            for lo in range(0, len(todo), args.count_streams):
+                found += hk.run_concurrently([job(b) for b in todo[lo:lo + args.count_streams]])
+            for first, (r, o, a, _) in zip(batch_first, found):
+                rs.append(r if first == 0 else np.asarray(r, dtype=np.uint32) + np.uint32(first)); os_.append(o); as_.append(a)
+        for first, batch in zip(batch_first, [] if many else batches['proband']):
             extra = {}
             if band_mask is not None and sk is sketches:
                 band_mask.zero_()
