@@ -173,3 +173,15 @@ def test_ragged_batches_keep_the_tile_kernels(hk, ok, prof):
     assert launches('k_bin_hash_direct') == 1 and launches('k_bin_hash_2bit') == 0
     for t in range(4):
         assert dev.table_bytes(t) == ref.table_bytes(t)
+
+
+def test_randomised_parity_of_the_two_bit_kernels(hk):
+    """scratch/fuzz_kmer2bit.py, a short fixed-seed run: random k (16..64), read lengths, storages, table sizes, bands (both rules), masks,
+    thresholds, reads with bases outside ACGT, a first read; tables byte for byte and hits identical to the oracle, and the 2-bit kernels are
+    the ones that ran (200 trials of seed 1 at the end of round 4: no mismatch)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    done = subprocess.run([sys.executable, os.path.join(root, 'scratch', 'fuzz_kmer2bit.py'), '30', '7'], cwd=root, capture_output=True, text=True, timeout=900)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-2000:]
+    assert 'done: 30 trials (seed 7), 0 mismatches' in done.stdout
