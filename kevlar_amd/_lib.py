@@ -166,12 +166,19 @@ def last_error():
     return load().kv_last_error().decode('utf-8', 'replace')
 
 
+class KvCapacityError(ValueError):
+    """KV_ERR_CAPACITY: a buffer the call was given (or sized for itself) did not hold the result; callers with another way to the
+    same result take it (a ValueError to everybody else, as before)"""
+
+
 def check(code):
     """Map a C return code onto the reference's exception types."""
     if code == KV_OK:
         return
     msg = last_error()
-    if code in (KV_ERR_ARG, KV_ERR_NOTIMPL, KV_ERR_CAPACITY):
+    if code == KV_ERR_CAPACITY:
+        raise KvCapacityError(msg)
+    if code in (KV_ERR_ARG, KV_ERR_NOTIMPL):
         raise ValueError(msg)
     if code == KV_ERR_IO:
         raise OSError(msg)

@@ -22,6 +22,7 @@ synchronises torch's stream before the library reads a received buffer.  A buffe
 never in use on one stream while the other side (or the allocator) touches it.  Anyone making a
 kv_* call asynchronous must add record_stream / wait_stream here first.
 """
+import os
 import time
 
 import numpy as np
@@ -38,6 +39,13 @@ SENT = {'bytes': 0}
 def shard_bounds(n_reads, world, rank):
     """Reads [lo, hi) of a sample that rank `rank` hashes."""
     return (n_reads * rank) // world, (n_reads * (rank + 1)) // world
+
+
+class PeerDeclined(Exception):
+    """A rank could not produce its part of an exchange (a buffer of the minimizer-sharded layout overflowed: bucket skew).  It says so
+    INSIDE a collective every rank takes part in anyway -- a negative count in the size exchange, a marker in its slab of segment
+    counts -- so every rank learns it at the same point and all of them take the same fallback; no rank ever waits in a collective the
+    others have left."""
 
 
 class _Exchange(object):
@@ -66,12 +74,14 @@ def exchange_rows_async(send, counts, group=None, staged=False):
     returned handle's wait(); `send` must stay untouched until then.  `staged` moves the data through host
     memory (gloo cannot transport device tensors) and completes before returning."""
     world = dist.get_world_size(group)
-    assert len(counts) == world
+    assert counts is None or len(counts) == world
     coll_dev = torch.device('cpu') if staged else send.device
-    mine = torch.tensor(counts, dtype=torch.int64, device=coll_dev)
+    mine = torch.tensor([-1] * world if counts is None else counts, dtype=torch.int64, device=coll_dev)     # None: this rank declines
     table = torch.empty(world * world, dtype=torch.int64, device=coll_dev)
     dist.all_gather_into_tensor(table, mine, group=group)
     table = table.view(world, world).cpu()
+    if bool((table < 0).any()):
+        raise PeerDeclined('ranks {} declined'.format([r for r in range(world) if bool((table[r] < 0).any())]))
     rank = dist.get_rank(group)
     recv_counts = [int(table[src, rank]) for src in range(world)]
     packed = send[:sum(counts)]
@@ -181,36 +191,68 @@ class ShardedTrio(object):
         1/8 of the reads has little to combine on its own (49 % of its k-mers are distinct against 20 % of the sample's); this
         way a rank hashes 1/N of the sample's DISTINCT k-mers."""
         t0 = time.perf_counter()
+        from kevlar_amd._lib import KvCapacityError
+        forced = os.environ.get('KV_MEX_TEST_DECLINE', '')          # tests: 'emit:RANK' / 'route:RANK' makes that rank decline there
         plan = hk.mex_plan(self.sketch_cls, self.ksize, n_reads_global, read_len, self.world)
         seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
         cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device=self.device)
-        hk.mex_emit(batch, plan, read_index_base, seg.data_ptr(), cnt.data_ptr())
+        emitted = forced != 'emit:{}'.format(self.rank)
+        if emitted:
+            try:
+                hk.mex_emit(batch, plan, read_index_base, seg.data_ptr(), cnt.data_ptr())
+            except KvCapacityError:                         # records outside their exchange segment: minimizer skew
+                emitted = False
         # only the filled part of the segments travels: the counts go first (fixed split points), and say how many records
         # every source will send
-        packed = torch.empty(int(plan.seg_words) // 2 + 1024, dtype=torch.int64, device=self.device)     # capacity is twice the expected fill
-        try:
-            per_dest = hk.mex_pack(plan, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr()) if self._fits(plan, cnt, packed) else None
-        except ValueError:
-            per_dest = None
-        if per_dest is None:                                # fuller than expected: a buffer of the segments' full size always fits
-            packed = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
-            per_dest = hk.mex_pack(plan, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr())
+        per_dest = None
+        if emitted:
+            packed = torch.empty(int(plan.seg_words) // 2 + 1024, dtype=torch.int64, device=self.device)     # capacity is twice the expected fill
+            try:
+                per_dest = hk.mex_pack(plan, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr()) if self._fits(plan, cnt, packed) else None
+            except ValueError:
+                per_dest = None
+            if per_dest is None:                            # fuller than expected: a buffer of the segments' full size always fits
+                packed = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
+                per_dest = hk.mex_pack(plan, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr())
+        else:
+            cnt.fill_(-1)                                   # the marker every destination finds in this rank's slab of counts
         t1 = time.perf_counter()
         recw = int(plan.recw)
         width = [int(plan.c_lo[d + 1]) - int(plan.c_lo[d]) for d in range(self.world)]
         mine = width[self.rank] * int(plan.nwg1)
         got_cnt = exchange_slabs(cnt, [w * int(plan.nwg1) for w in width], [mine] * self.world, self.group, self.staged)
-        from_src = [int(v) for v in got_cnt.view(self.world, mine).clamp(max=int(plan.cap1)).sum(dim=1, dtype=torch.int64).cpu()]
+        per_src = got_cnt.view(self.world, mine)
+        summary = torch.cat([per_src.clamp(min=0, max=int(plan.cap1)).sum(dim=1, dtype=torch.int64), (per_src < 0).any(dim=1).to(torch.int64)]).cpu()
+        if bool(summary[self.world:].any()):
+            # a rank's cut did not fit its exchange segments; every rank has just seen its marker: the sample travels as the
+            # (hash, occurrences) pairs of each rank's own deduplicated shard instead (what arrives at the band owners is the same)
+            del seg, cnt, got_cnt
+            self.fallbacks = getattr(self, 'fallbacks', 0) + 1
+            self.timing['route'] += time.perf_counter() - t0
+            return self.start(batch, read_index_base, False, distinct=True)
+        from_src = [int(v) for v in summary[:self.world]]
         got_seg = exchange_slabs(packed[:sum(per_dest) * recw], [n * recw for n in per_dest], [n * recw for n in from_src], self.group, self.staged)
         del seg, cnt, packed
         t2 = time.perf_counter()
         share = int(plan.n_kmers_global) // self.world
         cap = share + share // 4 + (1 << 20)
         send = self._send_buffer(cap, 2)
-        counts, _ = hk.mex_route(plan, self.rank, got_seg.data_ptr(), got_cnt.data_ptr(), self.world, send.data_ptr(), send.shape[0], compact=True)
+        counts = None
+        if forced != 'route:{}'.format(self.rank):
+            try:
+                counts, _ = hk.mex_route(plan, self.rank, got_seg.data_ptr(), got_cnt.data_ptr(), self.world, send.data_ptr(), send.shape[0], compact=True)
+            except KvCapacityError:                         # more k-mers in this rank's buckets than its pair buffer holds: bucket skew
+                counts = None
         del got_seg, got_cnt
         t3 = time.perf_counter()
-        ex = exchange_rows_async(send, counts, self.group, self.staged)
+        try:
+            ex = exchange_rows_async(send, counts, self.group, self.staged)      # counts None: this rank declines, inside the size exchange
+        except PeerDeclined:
+            self._send[2].append(send)
+            self.fallbacks = getattr(self, 'fallbacks', 0) + 1
+            self.timing['route'] += (t1 - t0) + (t3 - t2)
+            self.timing['exchange'] += (t2 - t1) + (time.perf_counter() - t3)
+            return self.start(batch, read_index_base, False, distinct=True)
         ex.send_buffer = send
         ex.weighted = True
         self.timing['route'] += (t1 - t0) + (t3 - t2)

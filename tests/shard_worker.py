@@ -66,7 +66,7 @@ def main():
     assert np.array_equal(r, mr) and np.array_equal(o, mo) and np.array_equal(a, ma)
     dist.barrier()
     dist.destroy_process_group()
-    print('shard worker ok: rank {} of {}, {} hits'.format(rank, world, len(r)))
+    print('shard worker ok: rank {} of {}, {} hits, {} fallbacks'.format(rank, world, len(r), getattr(run, 'fallbacks', 0)))
 
 
 if __name__ == '__main__':

@@ -260,7 +260,8 @@ def free_port():
 
 @pytest.mark.parametrize('world,backend,distinct', [(2, 'gloo', False), (3, 'gloo', False), (1, 'nccl', False),
                                                     (2, 'gloo', 'skm'), (3, 'gloo', 'plain'), (1, 'nccl', 'skm'),
-                                                    (2, 'gloo', 'minimizer'), (3, 'gloo', 'minimizer'), (1, 'nccl', 'minimizer')])
+                                                    (2, 'gloo', 'minimizer'), (3, 'gloo', 'minimizer'), (1, 'nccl', 'minimizer'),
+                                                    (3, 'gloo', 'minimizer/emit:1'), (3, 'gloo', 'minimizer/route:2'), (2, 'gloo', 'minimizer/route:0')])
 def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     """N ranks on this one GPU (gloo, staged exchange): each rank's sketches must equal band `rank` of a
     banded count of ALL reads, and the gathered hits the merged banded scan (tests/shard_worker.py).  The
@@ -271,9 +272,17 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     owners of their minimizer buckets first (kv_mex_emit / kv_mex_route)."""
     port = free_port()
     procs = []
+    # 'minimizer/emit:R' / 'minimizer/route:R': rank R declines at that point of the minimizer exchange (as it would when a buffer
+    # overflows: bucket skew); every rank learns it inside the collective that follows and all of them send the sample as the pairs of
+    # their own deduplicated shards instead -- same sketches, same hits, nobody left waiting
+    decline = None
+    if distinct and '/' in str(distinct):
+        distinct, decline = distinct.split('/')
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), SHARD_BACKEND=backend, SHARD_DISTINCT='1' if distinct else '0')
+        if decline:
+            env['KV_MEX_TEST_DECLINE'] = decline
         if distinct == 'minimizer':
             # the minimizer-sharded layout: super-k-mer records travel to their bucket's owner, which deduplicates at the
             # sample's full coverage (kv_mex_emit / kv_mex_route); the scan goes through the set, as for `distinct`
@@ -293,3 +302,5 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     for rank, p in enumerate(procs):
         assert p.returncode == 0, 'rank {} failed:\n{}'.format(rank, outs[rank][-3000:])
         assert 'shard worker ok' in outs[rank]
+        if decline:
+            assert '3 fallbacks' in outs[rank], outs[rank][-400:]        # one per sample, on every rank

@@ -76,6 +76,16 @@ def worker(rank, world, port, result_file):
     assert total == sum(r + 2 for r in range(world))
     valid = rows[rows != -1]
     assert valid.tolist() == [100 * r + j for r in range(world) for j in range(r + 2)]
+    # (4) a rank that cannot produce its part says so inside the size exchange: every rank raises, none is left in a collective
+    for decliner in range(world):
+        try:
+            shardrun.exchange_rows_async(send, None if rank == decliner else counts, staged=True)
+            raised = False
+        except shardrun.PeerDeclined:
+            raised = True
+        assert raised
+    recv2, recv_counts2 = shardrun.exchange_rows(send, counts, staged=True)       # and the next exchange is in step again
+    assert recv_counts2 == recv_counts and torch.equal(recv2, recv)
     dist.barrier()
     dist.destroy_process_group()
     with open(result_file + str(rank), 'w') as fh:
