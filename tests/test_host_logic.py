@@ -727,6 +727,17 @@ def test_dedup_runs_take_the_exact_order_when_two_groups_share_a_mixed_key():
     assert sorted(zip(dup.tolist(), head.tolist())) == want
 
 
+def test_the_build_knows_every_source_and_header():
+    """__graft_entry__.build() recompiles when a listed source or header is newer than the library: a file that is not on the lists
+    would change without a rebuild (kv_inflate_device.h was missing until round 4), and a stale library on the GPU box fails every
+    test that loads it"""
+    import __graft_entry__ as g
+    csrc = g.CSRC
+    assert sorted(g.HIP_SOURCES) == sorted(f for f in os.listdir(csrc) if f.endswith('.hip'))
+    assert sorted(os.path.basename(h) for h in g.HIP_HEADERS if not h.startswith('..')) == sorted(f for f in os.listdir(csrc) if f.endswith('.h'))
+    assert any(h.endswith('kvsketch.h') for h in g.HIP_HEADERS)
+
+
 def test_fixed_width_rows_are_the_strings_nul_padded():
     """partition's name matrix: one NUL-padded row per string, whatever the lengths (ragged: rows gathered from a sliding window;
     one length back to back: the blob reshaped; offsets that start behind the blob's first byte; empty strings; no strings)"""
