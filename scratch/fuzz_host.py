@@ -49,6 +49,13 @@ with tempfile.TemporaryDirectory() as tmp:
                                                                                       memory=mem, maxfpr=1.0, casemin=casemin, ctrlmax=ctrlmax))
             got = b''.join(kevlar_amd.filter._passes(novel_out, None, mem, 1.0, casemin, ctrlmax, as_text=True)).decode('latin-1')
             assert got == want, (desc, 'filter', len(got), len(want))
+            # the same through the sink the CLI hands over (a plain file: the library renders and writes it, kv_format_records_fd)
+            sunk = os.path.join(tmp, 'sunk{}.augfastq'.format(trial))
+            with kevlar_amd.open_sink(sunk) as sink:
+                for text in kevlar_amd.filter._passes(novel_out, None, mem, 1.0, casemin, ctrlmax, as_text=True, sink=sink):
+                    if text:
+                        sink.write(text)
+            assert open(sunk).read() == want, (desc, 'filter to a sink')
             filtered = os.path.join(tmp, 'filtered{}.augfastq'.format(trial))
             with open(filtered, 'w') as fh:
                 fh.write(got)
@@ -58,8 +65,19 @@ with tempfile.TemporaryDirectory() as tmp:
             parts_obj = [(num, ''.join(format_augmented_fastx(r) for r in (reads if dedup else sorted(reads, key=lambda r: r.name))))
                          for num, reads in kevlar_amd.partition.partition(parse_augmented_fastx(kevlar_amd.open(filtered, 'r')), strict=False,
                                                                          minabund=minab, maxabund=maxab, dedup=dedup)]
-            parts_arr = [(num, ann.format(reads, suffixes=[' kvcc={:d}'.format(num)] * len(reads)).decode('latin-1'))
-                         for num, ann, reads in kevlar_amd.partition.partition_file(filtered, minabund=minab, maxabund=maxab, dedup=dedup)]
+            # partition_file: (annotated reads, read indices in output order, partition number of each) -- cut into partitions here
+            ann, out_reads, numbers = kevlar_amd.partition.partition_file(filtered, minabund=minab, maxabund=maxab, dedup=dedup)
+            parts_arr = []
+            for num in sorted(set(numbers.tolist())):
+                mine = out_reads[numbers == num]
+                parts_arr.append((int(num), ann.format(mine, suffixes=[' kvcc={:d}'.format(int(num))] * len(mine)).decode('latin-1')))
+            # ... and the same text through the writer the CLI uses for a plain file (kv_format_records_fd)
+            whole = os.path.join(tmp, 'whole{}.augfastq'.format(trial))
+            with kevlar_amd.open_sink(whole) as sink:
+                for num, text in parts_arr:
+                    mine = out_reads[numbers == num]
+                    ann.format_to(sink, mine, suffixes=[' kvcc={:d}'.format(num)] * len(mine))
+            assert open(whole).read() == ''.join(text for _, text in parts_arr), (desc, 'format_to')
             assert parts_arr == parts_obj, (desc, 'partition', dedup, minab, maxab, len(parts_arr), len(parts_obj))
             parted = os.path.join(tmp, 'part{}.augfastq'.format(trial))
             with open(parted, 'w') as fh:
