@@ -1843,9 +1843,6 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.cap2 = (uint32_t)kv_round_up((uint64_t)(m2 * 1.3 + 8.0 * std::sqrt(m2)) + 32, 16);
     // loose records: segment overflow (whole records) and occurrences that missed a full LDS table (one k-mer each)
     g.loose_cap = (uint64_t)(rec_est / 8.0) + n_kmers / 16 + (1u << 20);
-    // (experiment: pad the segments, i.e. change the strides between the write frontiers of neighbouring buckets -- S2's "two speeds")
-    if (const char *e = getenv("KV_SKM_CAP1_EXTRA")) g.cap1 += (uint32_t)atoi(e);
-    if (const char *e = getenv("KV_SKM_CAP2_EXTRA")) g.cap2 += (uint32_t)atoi(e);
     if (const char *pct = getenv("KV_SKM_CAP_PCT")) {       // tests: undersized segments push records through the loose list
         g.cap1 = std::max<uint32_t>(16u, (uint32_t)((uint64_t)g.cap1 * (uint64_t)atoi(pct) / 100));
         g.cap2 = std::max<uint32_t>(16u, (uint32_t)((uint64_t)g.cap2 * (uint64_t)atoi(pct) / 100));

@@ -1,5 +1,7 @@
 #!/bin/bash
 # S2's two speeds: does the stride between the buckets' write frontiers (segment capacity) move k_skm_split_sorted?
+# (needs the two lines `if (getenv("KV_SKM_CAP1_EXTRA")) g.cap1 += ...; if (getenv("KV_SKM_CAP2_EXTRA")) g.cap2 += ...;` in skm_build, which were taken out
+# again after the sweep -- no padding moved the kernel: 2.77-2.80 ms per step in all ten runs -- so that the kernel sources stay those of profiles/r4_final)
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 cd $REPO
 L=kevlar_amd/libkvsketch_hip.so
