@@ -524,6 +524,7 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     if (band_mode == KV_BAND_RANGE) kv_band_bounds(nbands, band, &p.band_lo, &p.band_hi);
     p.first_read = first_read;
     p.host_ctrls = (const void *)ctrls; p.host_nctrl = nctrl;
+    p.host_case0 = (const void *)cases[0];
     hipStream_t st = kv_stream();
     uint64_t n_kmers = 0;
     kv_reads_num_kmers(reads, k, &n_kmers);

@@ -38,6 +38,11 @@ struct NovelParams {
     uint64_t ab_mask;                     // slots - 1
     const void *host_ctrls;               // host side only: the control sketches (kv_sketch *const *) behind sk[ncase..], for their
     int host_nctrl;                       // abundance lists (kv_skm_novel_mark)
+    const void *host_case0;               // host side only: the first case sketch (kv_sketch *), for case0_bits
+    // One bit per bin of table 0 of the first case sample: counter >= case_min (k_case_bits, a streaming pass in front of the list scan).
+    // The scan's first probe -- where a sequencing-error k-mer ends: 81 M of them at config 2 -- asks exactly that, and a bit map is an
+    // eighth of the table (62.5 MB for 500 M bins: it stays in the 256 MB Infinity Cache where the table does not).  NULL = probe the table.
+    const uint32_t *case0_bits;
 };
 #define KV_SET_NONE 0xffffffffffffffffull
 

@@ -1380,6 +1380,26 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
     }
 }
 
+// bits[w] bit j = (tab[32 w + j] >= case_min), byte counters: the first probe of the list scan as a bit map (NovelParams::case0_bits)
+__global__ __launch_bounds__(256) void k_case_bits(const uint8_t *__restrict__ tab, uint64_t size, int case_min, uint32_t *__restrict__ bits)
+{
+    const uint64_t n_words = (size + 31) >> 5;
+    for (uint64_t w = blockIdx.x * 256ull + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * 256ull) {
+        uint32_t out = 0;
+        if (w * 32 + 32 <= size) {
+            const uint4 a = ((const uint4 *)tab)[2 * w], b = ((const uint4 *)tab)[2 * w + 1];
+            const uint32_t q[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out |= ((int)((q[i] >> (8 * j)) & 0xffu) >= case_min ? 1u : 0u) << (4 * i + j);
+        } else {
+            for (uint64_t j = w * 32; j < size; ++j) out |= ((int)tab[j] >= case_min ? 1u : 0u) << (uint32_t)(j - w * 32);
+        }
+        bits[w] = out;
+    }
+}
+
 // The scan of a batch whose count pass left a distinct list (SkmGeom::dl_*): nothing is combined and nothing is hashed again.
 // Per bucket: (1) the controls' abundance-list entries that exceed ctrl_max go into one small LDS table (the k-mers no probe is
 // needed for); (2) every entry of the distinct list that is not in there gets ONE probe -- table 0 of the first case sample, where
@@ -1463,7 +1483,13 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, 
 #pragma unroll
             for (uint32_t u = 0; u < E; ++u) {
                 live[u] = base + u * SKM_THREADS3 + threadIdx.x < en && skm_table_find(rtb, c[u]) < 0 && band_pass(p, h[u]);
-                v[u] = live[u] ? probe(ns, 0, 0, h[u]) : 0u;
+                if (p.case0_bits) {
+                    const uint64_t bin = fastmod(h[u], ns.d[0].size, ns.d[0].magic);
+                    const __attribute__((address_space(1))) uint32_t *bits = (const __attribute__((address_space(1))) uint32_t *)p.case0_bits;
+                    v[u] = live[u] && ((bits[bin >> 5] >> (uint32_t)(bin & 31u)) & 1u) ? (uint32_t)p.case_min : 0u;
+                } else {
+                    v[u] = live[u] ? probe(ns, 0, 0, h[u]) : 0u;
+                }
             }
 #pragma unroll
             for (uint32_t u = 0; u < E; ++u)
@@ -1582,6 +1608,7 @@ struct SkmIndex {
     uint32_t dl_cap_wg = 0;
     bool dl_valid = false;
     uint64_t builds = 0;             // batches bucketed on this stream so far
+    KvArena bits;                    // NovelParams::case0_bits of the scan in flight
     std::mutex mu;
 };
 std::map<hipStream_t, SkmIndex> g_skm;
@@ -2106,13 +2133,25 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
     if (getenv("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] scan: %d of %d controls bring an abundance list in this bucket geometry\n", abls.n, p.host_nctrl);
     if (getenv("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] scan: %s\n", from_list ? "from the count pass's distinct list" : "by walking the buckets");
     if (const char *e = getenv("KV_SKM_SCAN_DEBUG")) sg.dbg = (uint32_t)atoi(e);       // scratch/scan_phases.py
+    NovelParams pl = p;
+    pl.case0_bits = nullptr;
+    if (from_list && p.host_case0 && getenv("KV_NOVEL_BITS") && atoi(getenv("KV_NOVEL_BITS")) != 0) {
+        const kv_sketch *c0 = (const kv_sketch *)p.host_case0;
+        if (c0->h.storage == ST_BYTE && !c0->lazy_zero && idx->bits.need(kv_round_up(((c0->h.size[0] + 31) >> 5) * 4, 256)) == hipSuccess) {
+            KvProfScope prof("k_case_bits");
+            hipLaunchKernelGGL(k_case_bits, dim3(4096), dim3(256), 0, st, (const uint8_t *)c0->h.tab[0], (uint64_t)c0->h.size[0], p.case_min, (uint32_t *)idx->bits.p);
+            pl.case0_bits = (const uint32_t *)idx->bits.p;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (from_list) {
         KvProfScope prof("k_skm_novel_list");
         sg.dl_keys = idx->dl_keys; sg.dl_hash = idx->dl_hash; sg.dl_bstart = idx->dl_bstart; sg.dl_bcount = idx->dl_bcount; sg.dl_cap_wg = idx->dl_cap_wg;
         const size_t lds = (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw) * 4;
         void (*kernel)(SkmGeom, ReadsDev, NovelParams, SkmAblSet) =
             sg.kw == 1 ? (sg.dbg ? k_skm_novel_list<1, 2048, true> : k_skm_novel_list<1, 2048, false>) : (sg.dbg ? k_skm_novel_list<2, 1024, true> : k_skm_novel_list<2, 1024, false>);
-        hipLaunchKernelGGL(kernel, dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
+        hipLaunchKernelGGL(kernel, dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, pl, abls);
         if (p.ab_keys) hipLaunchKernelGGL(k_ab_fill, dim3(2048), dim3(256), 0, st, p);
         sg.dl_keys = nullptr; sg.dl_hash = nullptr; sg.dl_bstart = nullptr; sg.dl_bcount = nullptr;
     } else {
