@@ -2135,7 +2135,8 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
     if (const char *e = getenv("KV_SKM_SCAN_DEBUG")) sg.dbg = (uint32_t)atoi(e);       // scratch/scan_phases.py
     NovelParams pl = p;
     pl.case0_bits = nullptr;
-    if (from_list && p.host_case0 && getenv("KV_NOVEL_BITS") && atoi(getenv("KV_NOVEL_BITS")) != 0) {
+    // (KV_NOVEL_BITS=0: probe the table.  Measured at config 2: the bit map costs 0.135 ms, the list scan goes from 2.57-2.77 to 2.34 ms)
+    if (from_list && p.host_case0 && !(getenv("KV_NOVEL_BITS") && atoi(getenv("KV_NOVEL_BITS")) == 0)) {
         const kv_sketch *c0 = (const kv_sketch *)p.host_case0;
         if (c0->h.storage == ST_BYTE && !c0->lazy_zero && idx->bits.need(kv_round_up(((c0->h.size[0] + 31) >> 5) * 4, 256)) == hipSuccess) {
             KvProfScope prof("k_case_bits");
