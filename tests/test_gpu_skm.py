@@ -383,7 +383,7 @@ def test_list_scan_first_probe_from_the_bit_map_equals_the_table_probe(hk, ok, s
             assert got == hits, (case_min, bits, len(got), len(hits))
             assert launches('k_skm_novel_list') == before_list + 1
             assert launches('k_case_bits') == before_bits + (1 if bits == '1' else 0)
-        assert len(hits) > (50 if case_min <= 6 else 0)
+        assert case_min > 6 or len(hits) > 50           # (at 25 nothing is left: every first probe fails, the bit map's best case)
     os.environ.pop('KV_NOVEL_BITS', None)
 
 
