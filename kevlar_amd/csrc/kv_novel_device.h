@@ -72,16 +72,8 @@ __device__ __forceinline__ uint64_t skm_key_hash(const SkmKey<KW> &c, const uint
     uint32_t wf[NW], wr[NW];
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
-#ifdef KV_ASCII_PERM
-        // A/B build (scratch/r4_exp6.sh): four 2-bit codes spread to four selector bytes by one 24-bit multiply and a mask, the characters
-        // picked out of the constant "ACGT" by v_perm_b32 -- no LDS read, one or two VALU instructions more per four bases than the table
-        const uint32_t bf = (uint32_t)(c.w[q >> 3] >> (8 * (q & 7))) & 0xffu, br = (uint32_t)(r.w[q >> 3] >> (8 * (q & 7))) & 0xffu;
-        wf[q] = __builtin_amdgcn_perm(0x54474341u, 0x54474341u, (bf * 0x41041u) & 0x03030303u);
-        wr[q] = __builtin_amdgcn_perm(0x54474341u, 0x54474341u, (br * 0x41041u) & 0x03030303u);
-#else
         wf[q] = lut[(uint32_t)(c.w[q >> 3] >> (8 * (q & 7))) & 0xffu];
         wr[q] = lut[(uint32_t)(r.w[q >> 3] >> (8 * (q & 7))) & 0xffu];
-#endif
     }
     return murmur_regs<NW>(wf, hp) ^ murmur_regs<NW>(wr, hp);
 }
