@@ -999,6 +999,13 @@ extern "C" int kv_novel_scan_set(const kv_reads *reads, int kind, int ksize, int
     p.set_keys = keys; p.set_abund = abund; p.set_mask = slots - 1;
     uint64_t n_kmers = 0;
     kv_reads_num_kmers(reads, ksize, &n_kmers);
-    const bool use_skm = kv_skm_eligible_kind(fam, ksize, reads, n_kmers, true);
+    // Membership is one read of a set that stays in the L2, so the test is nearly free and what is left is finding the hash of every
+    // k-mer: from the 2-bit form of equal-length reads that is ~305 lane-instructions per occurrence (k_novel_mark_2bit), which is what
+    // cutting, splitting and combining the shard costs per occurrence at 30x and more than it costs at a shard's 4-15x (measured per
+    // rank of config 2: 3.1 -> 1.8 ms at N = 8).  KV_SET_SCAN=skm keeps the bucketed scan; other batches take it as before.
+    const char *how = getenv("KV_SET_SCAN"), *nm2 = getenv("KV_NOVEL_2BIT"), *forced = getenv("KV_NOVEL_PATH");
+    const bool two_bit = fam == HF_MURMUR && ksize >= SKM_MIN_K && ksize <= SKM_MAX_K && reads->uni_len >= (uint32_t)ksize && reads->uni_per_tile != 0 &&
+                         !(how && strcmp(how, "skm") == 0) && !(nm2 && atoi(nm2) == 0) && !(forced && strcmp(forced, "tiles") == 0);
+    const bool use_skm = !two_bit && kv_skm_eligible_kind(fam, ksize, reads, n_kmers, true);
     return scan_reads(p, reads, fam, n_kmers, use_skm, []() { return KV_OK; }, nullptr, 0, out);
 }

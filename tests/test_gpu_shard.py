@@ -250,6 +250,53 @@ def test_scan_distinct_then_scan_set_reproduce_the_scan(hk, k, path):
     assert len(r2) == 0 and a2.shape == (0, 3)
 
 
+def test_set_scan_of_equal_length_reads_hashes_from_the_2bit_form(hk):
+    """a shard as the bench and the file readers hold it -- equal-length reads, uniform layout -- is looked up in the gathered set by
+    k_novel_mark_2bit (every k-mer hashed from its 2-bit form, membership as the test) instead of being cut and combined again; the
+    bucketed scan (KV_SET_SCAN=skm) and kv_novel_scan over the sketches give the same hits"""
+    import ctypes
+    import torch
+    from kevlar_amd import _lib, synth
+    lib = _lib.load()
+
+    def launches(name):
+        ms, n = ctypes.c_double(), ctypes.c_uint64()
+        lib.kv_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(n))
+        return n.value
+
+    k = 31
+    trio = synth.make_trio(300000, 23)
+    packed = {n: synth.sample_reads_packed(trio[n], 90000, 100, 0.005, 60 + i) for i, n in enumerate(('proband', 'mother', 'father'))}
+    batches = {n: hk.ReadBatch.from_packed(packed[n], 100) for n in packed}
+    sk = {n: hk.Counttable(k, 3.0e6, 4) for n in packed}
+    for n in packed:
+        sk[n].consume_batch(batches[n])
+    r0, o0, a0, _ = hk.novel_scan([sk['proband']], [sk['mother'], sk['father']], batches['proband'], 6, 1)
+    assert len(r0) > 50
+    nk = batches['proband'].num_kmers(k)
+    send = torch.zeros((nk, 2), dtype=torch.int64, device='cuda')
+    counts = hk.route_distinct(batches['proband'], hk.Counttable, k, 1, send.data_ptr(), nk)
+    hashes = torch.empty(nk, dtype=torch.int64, device='cuda')
+    abund = torch.empty((nk, 3), dtype=torch.uint8, device='cuda')
+    n_int = hk.novel_scan_distinct([sk['proband']], [sk['mother'], sk['father']], send.data_ptr(), counts[0], 6, 1,
+                                   hashes.data_ptr(), abund.data_ptr(), nk)
+    lib.kv_prof_enable(1)
+    try:
+        before = launches('k_novel_mark_2bit'), launches('k_skm_novel')
+        r1, o1, a1 = hk.novel_scan_set(batches['proband'], hk.Counttable, k, 3, hashes.data_ptr(), abund.data_ptr(), n_int)
+        assert (launches('k_novel_mark_2bit'), launches('k_skm_novel')) == (before[0] + 1, before[1])
+        os.environ['KV_SET_SCAN'] = 'skm'
+        os.environ['KV_NOVEL_PATH'] = 'skm'
+        r2, o2, a2 = hk.novel_scan_set(batches['proband'], hk.Counttable, k, 3, hashes.data_ptr(), abund.data_ptr(), n_int)
+        assert (launches('k_novel_mark_2bit'), launches('k_skm_novel')) == (before[0] + 1, before[1] + 1)
+    finally:
+        os.environ.pop('KV_SET_SCAN', None)
+        os.environ.pop('KV_NOVEL_PATH', None)
+        lib.kv_prof_enable(0)
+    for r, o, a in ((r1, o1, a1), (r2, o2, a2)):
+        assert np.array_equal(r0, r) and np.array_equal(o0, o) and np.array_equal(a0, a)
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
