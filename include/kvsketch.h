@@ -390,6 +390,11 @@ int kv_mex_emit(const kv_reads *shard, const kv_mex_plan *plan, uint64_t read_ba
 int kv_mex_pack(const kv_mex_plan *plan, const void *d_seg, const void *d_cnt, void *d_out, uint64_t *records_per_dest);
 int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_recv_seg, const void *d_recv_cnt, int n_src, int compact,
                  void *d_out, uint64_t cap_items, uint64_t *counts_out, uint64_t *n_kmers_in);
+/* kv_mex_emit_pack: kv_mex_emit and kv_mex_pack in one call and one stream synchronisation.  d_out holds out_cap_words u64 words;
+ * *packed = 1: the filled part fitted and sits in d_out; 0: it did not (records_per_dest is right either way), nothing was
+ * written to d_out and kv_mex_pack into a buffer of plan->seg_words words does it.                                          */
+int kv_mex_emit_pack(const kv_reads *shard, const kv_mex_plan *plan, uint64_t read_base, void *d_seg, void *d_cnt, void *d_out,
+                     uint64_t out_cap_words, uint64_t *records_per_dest, int *packed);
 
 #ifdef __cplusplus
 }

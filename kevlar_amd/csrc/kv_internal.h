@@ -157,6 +157,34 @@ struct PinnedVec {
     bool empty() const { return n == 0; }
 };
 
+// Small device -> host read-backs of one call gathered in one pinned block and waited for once.  (A hipMemcpyAsync into pageable
+// memory -- a variable on the stack -- stalls the caller until the copy is done: every such copy is a synchronisation of its own.)
+struct KvReadback {
+    unsigned char *host = nullptr;
+    size_t cap = 0, used = 0;
+    bool pinned = true;
+    KvReadback()
+    {
+        host = (unsigned char *)kv_pinned_get(4096, &cap);
+        if (!host) { host = new unsigned char[4096]; cap = 4096; pinned = false; }
+    }
+    ~KvReadback() { if (pinned) kv_pinned_put(host, cap); else delete[] host; }
+    KvReadback(const KvReadback &) = delete;
+    KvReadback &operator=(const KvReadback &) = delete;
+    // enqueue the copy of `count` values; the returned pointer is valid after wait()
+    template <typename T>
+    const T *add(const T *dev, size_t count, hipStream_t st, hipError_t *err)
+    {
+        const size_t at = (used + 7) & ~(size_t)7, bytes = count * sizeof(T);
+        if (at + bytes > cap) { *err = hipErrorOutOfMemory; return nullptr; }
+        const hipError_t e = hipMemcpyAsync(host + at, dev, bytes, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) *err = e;
+        used = at + bytes;
+        return (const T *)(host + at);
+    }
+    hipError_t wait(hipStream_t st) { return hipStreamSynchronize(st); }
+};
+
 struct kv_hits {
     int nsamples;
     PinnedVec<uint32_t> read, offset;
@@ -221,9 +249,10 @@ int kv_skm_route_distinct(const kv_reads *reads, int ksize, uint64_t n_kmers, in
 // minimizer-sharded exchange (kv_skm.hip): the plan every rank derives from the sample's global size, S1 into the caller's
 // exchange buffers, S2 + distinct route over what arrived
 int kv_skm_mex_plan(int ksize, uint64_t n_reads_global, uint32_t read_len, int ndest, kv_mex_plan *plan);
-int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t read_base, uint64_t *d_seg, uint32_t *d_cnt);
+int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t read_base, uint64_t *d_seg, uint32_t *d_cnt,
+                    uint64_t *d_out, uint64_t out_cap_words, uint64_t *records_per_dest, int *packed);
 int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_recv_seg, const uint32_t *d_recv_cnt, int n_src, int compact,
-                     int (*alloc)(void *ctx, uint32_t nwg, KvRouteSink *sink), void *ctx, uint64_t *n_kmers_in);
+                     int (*alloc)(void *ctx, uint32_t nwg, KvRouteSink *sink), int (*after)(void *ctx), void *ctx, uint64_t *n_kmers_in);
 int kv_skm_mex_pack(const kv_mex_plan *plan, const uint64_t *d_seg, const uint32_t *d_cnt, uint64_t *d_out, uint64_t *records_per_dest);
 
 // tile geometry of the hashing kernels

@@ -872,6 +872,52 @@ __global__ __launch_bounds__(256) void k_novel_list(NovelParams p, const uint64_
     }
 }
 
+// The same for (hash, occurrences) pairs -- every distinct k-mer of the case sample once (or once per shard): nothing repeats, so
+// there is no verdict cache to consult and fill (a random 64-byte line per item, for nothing), and a thread keeps E first probes in
+// flight -- table 0 of the first case sample, where a sequencing-error k-mer ends -- before the few that pass take the rest of
+// kmer_is_interesting() one by one.  (k_novel_list over the pairs of config 2: 0.91 ms per rank at N = 8, 3.66 at N = 2.)
+template <int E>
+__global__ __launch_bounds__(256) void k_novel_pairs(NovelParams p, const uint64_t *__restrict__ items, uint64_t n, uint64_t *hit_hash, uint8_t *hit_abund,
+                                                     unsigned long long *hit_count, uint64_t cap)
+{
+    __shared__ NovelShared ns;
+    load_descs(ns, p);
+    __syncthreads();
+    const int S = p.ncase + p.nctrl;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = (uint64_t)blockIdx.x * (E * 256u); base < n; base += (uint64_t)gridDim.x * (E * 256u)) {      // workgroup-uniform trip count
+        uint64_t h[E];
+        bool live[E];
+        uint32_t v[E];
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const uint64_t i = base + (uint64_t)u * 256u + threadIdx.x;
+            live[u] = i < n;
+            const ulonglong2 it = live[u] ? *(const ulonglong2 *)(items + 2 * i) : make_ulonglong2(0ull, 0ull);
+            h[u] = it.x;
+            live[u] = live[u] && (it.y >> 63) == 0;
+        }
+#pragma unroll
+        for (int u = 0; u < E; ++u) v[u] = live[u] ? probe(ns, 0, 0, h[u]) : 0u;
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const bool interesting = live[u] && (int)v[u] >= p.case_min && novel_test_fast(ns, p, h[u], nullptr, 0ull);
+            const unsigned long long ballot = __ballot(interesting);
+            if (!ballot) continue;
+            unsigned long long first = 0;
+            if (lane == 0) first = atomicAdd(hit_count, (unsigned long long)__popcll(ballot));
+            first = __shfl(first, 0);
+            if (interesting) {
+                const uint64_t pos = first + (uint64_t)__popcll(ballot & ((1ull << lane) - 1ull));
+                if (pos < cap) {
+                    hit_hash[pos] = h[u];
+                    for (int c = 0; c < S; ++c) hit_abund[pos * (uint64_t)S + c] = (uint8_t)sketch_get(p.sk[c], h[u]);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -922,20 +968,30 @@ int scan_items(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int 
     p.ncase = ncase; p.nctrl = nctrl;
     p.case_min = case_min; p.ctrl_max = ctrl_max;
     hipStream_t st = kv_stream();
-    { const int rc = attach_vcache(p, ctrls, ncase, nctrl, ctrl_max, n_items, st); if (rc != KV_OK) return rc; }
+    // pairs (want_hash): every k-mer once, no verdict cache, several first probes in flight (KV_NOVEL_PAIRS=0: the list kernel)
+    const bool pairs = want_hash && !(getenv("KV_NOVEL_PAIRS") && atoi(getenv("KV_NOVEL_PAIRS")) == 0);
+    if (!pairs) { const int rc = attach_vcache(p, ctrls, ncase, nctrl, ctrl_max, n_items, st); if (rc != KV_OK) return rc; }
     DevBuf d_count;
     KV_HIP(d_count.alloc(8));
     KV_HIP(hipMemsetAsync(d_count.p, 0, 8, st));
-    {
+    if (pairs) {
+        KvProfScope prof("k_novel_pairs");
+        const unsigned grid = (unsigned)std::min<uint64_t>((n_items + 1023) / 1024, 256 * 16);
+        hipLaunchKernelGGL(k_novel_pairs<4>, dim3(grid), dim3(256), 0, st, p, (const uint64_t *)d_items, n_items,
+                           (uint64_t *)d_hit_tags, (uint8_t *)d_hit_abund, d_count.as<unsigned long long>(), hit_cap);
+    } else {
         KvProfScope prof("k_novel_list");
         const unsigned grid = (unsigned)std::min<uint64_t>((n_items + 255) / 256, 256 * 16);
         hipLaunchKernelGGL(k_novel_list, dim3(grid), dim3(256), 0, st, p, (const uint64_t *)d_items, n_items,
                            (uint64_t *)d_hit_tags, (uint8_t *)d_hit_abund, d_count.as<unsigned long long>(), hit_cap, want_hash);
     }
     KV_HIP(hipGetLastError());
-    unsigned long long cnt = 0;
-    KV_HIP(hipMemcpyAsync(&cnt, d_count.p, 8, hipMemcpyDeviceToHost, st));
-    KV_HIP(hipStreamSynchronize(st));
+    KvReadback rb;
+    hipError_t rb_err = hipSuccess;
+    const unsigned long long *cnt_p = rb.add(d_count.as<unsigned long long>(), 1, st, &rb_err);
+    KV_HIP(rb_err);
+    KV_HIP(rb.wait(st));
+    const unsigned long long cnt = *cnt_p;
     KV_REQUIRE(cnt <= hit_cap, KV_ERR_CAPACITY, "kv_novel_scan_hashes: %llu hits exceed the buffer of %llu", cnt,
                (unsigned long long)hit_cap);
     *n_hits = cnt;

@@ -173,9 +173,12 @@ template <int W>
 __global__ __launch_bounds__(256) void k_route_compact(RouteParams p)
 {
     const uint32_t wg = blockIdx.x, d = blockIdx.y;
-    const uint64_t n = p.seg_count[(uint64_t)d * p.nwg + wg];
+    uint64_t n = p.seg_count[(uint64_t)d * p.nwg + wg];
     const uint64_t *src = p.seg + ((uint64_t)d * p.nwg + wg) * p.seg_cap * W;
-    uint64_t *dst = p.out + (p.ctr[34 + d] + p.seg_off[(uint64_t)d * p.nwg + wg]) * W;
+    const uint64_t first = p.ctr[34 + d] + p.seg_off[(uint64_t)d * p.nwg + wg];
+    if (first >= p.cap) return;                          // more items than the output holds: the host sees the totals and says so
+    n = min(n, p.cap - first);
+    uint64_t *dst = p.out + first * W;
     for (uint64_t j = threadIdx.x; j < n * W; j += 256) dst[j] = src[j];
 }
 
@@ -238,6 +241,21 @@ int route_scratch(RouteParams &p, uint64_t n_kmers, uint32_t W, hipStream_t st)
 }
 
 // pack the segments and the overflow tail into p.out, destination after destination; counts_out[d] = items of d
+// (route_pack_enqueue + a read of p.ctr[0 .. 33] by the caller: the same without a synchronisation of its own)
+void route_pack_enqueue(RouteParams &p, uint32_t W, hipStream_t st)
+{
+    KvProfScope prof("k_route_compact");
+    hipLaunchKernelGGL(k_route_scan, dim3((unsigned)p.ndest), dim3(ROUTE_MAX_WG), 0, st, p);
+    hipLaunchKernelGGL(k_route_bases, dim3(1), dim3(64), 0, st, p);
+    if (W == 2) {
+        hipLaunchKernelGGL(k_route_compact<2>, dim3(p.nwg, (unsigned)p.ndest), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(k_route_tail<2>, dim3(256), dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL(k_route_compact<1>, dim3(p.nwg, (unsigned)p.ndest), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(k_route_tail<1>, dim3(256), dim3(256), 0, st, p);
+    }
+}
+
 int route_pack(RouteParams &p, uint32_t W, hipStream_t st, uint64_t *counts_out, unsigned long long *tiles_done)
 {
     {
@@ -423,7 +441,7 @@ extern "C" int kv_mex_plan_make(int kind, int ksize, uint64_t n_reads_global, ui
 extern "C" int kv_mex_emit(const kv_reads *shard, const kv_mex_plan *plan, uint64_t read_base, void *d_seg, void *d_cnt)
 {
     KV_REQUIRE(shard && plan && d_seg && d_cnt, KV_ERR_ARG, "kv_mex_emit: null argument");
-    return kv_skm_mex_emit(shard, plan, read_base, (uint64_t *)d_seg, (uint32_t *)d_cnt);
+    return kv_skm_mex_emit(shard, plan, read_base, (uint64_t *)d_seg, (uint32_t *)d_cnt, nullptr, 0, nullptr, nullptr);
 }
 
 extern "C" int kv_mex_pack(const kv_mex_plan *plan, const void *d_seg, const void *d_cnt, void *d_out, uint64_t *records_per_dest)
@@ -448,7 +466,8 @@ extern "C" int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_
     // every k-mer occurrence that arrived could be a pair of its own: the sink is sized for this rank's expected share
     // with slack, and the caller's buffer must hold what actually arrived (checked below, before anything is packed)
     const uint64_t expect = plan->n_kmers_global / (uint64_t)ndest;
-    struct Ctx { RouteParams *p; uint64_t n_kmers; hipStream_t st; } ctx = {&p, expect + expect / 4 + (1u << 20), st};
+    KvReadback rb;
+    struct Ctx { RouteParams *p; uint64_t n_kmers; hipStream_t st; KvReadback *rb; const unsigned long long *host; } ctx = {&p, expect + expect / 4 + (1u << 20), st, &rb, nullptr};
     auto alloc = [](void *c, uint32_t nwg, KvRouteSink *sink) -> int {
         Ctx *x = (Ctx *)c;
         RouteParams &q = *x->p;
@@ -459,12 +478,31 @@ extern "C" int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_
         sink->seg_count = q.seg_count; sink->ovf = q.ovf; sink->ovf_dest = q.ovf_dest; sink->ovf_cap = q.ovf_cap; sink->ctr = q.ctr;
         return KV_OK;
     };
-    { const int rc = kv_skm_mex_route(plan, my_dest, (const uint64_t *)d_recv_seg, (const uint32_t *)d_recv_cnt, n_src, compact, alloc, &ctx, n_kmers_in); if (rc != KV_OK) return rc; }
+    // the pairs are packed behind the route kernels without waiting for them: kv_skm_mex_route waits once, for both
+    auto after = [](void *c) -> int {
+        Ctx *x = (Ctx *)c;
+        RouteParams &q = *x->p;
+        if (q.nwg == 0 || q.seg == nullptr) return KV_OK;
+        route_pack_enqueue(q, 2, x->st);
+        KV_HIP(hipGetLastError());
+        hipError_t e = hipSuccess;
+        x->host = x->rb->add(q.ctr, 34, x->st, &e);
+        KV_HIP(e);
+        return KV_OK;
+    };
+    { const int rc = kv_skm_mex_route(plan, my_dest, (const uint64_t *)d_recv_seg, (const uint32_t *)d_recv_cnt, n_src, compact, alloc, after, &ctx, n_kmers_in); if (rc != KV_OK) return rc; }
     KV_REQUIRE(*n_kmers_in <= cap_items, KV_ERR_CAPACITY, "kv_mex_route: %llu k-mers arrived, the output holds %llu pairs",
                (unsigned long long)*n_kmers_in, (unsigned long long)cap_items);
-    if (p.nwg == 0 || p.seg == nullptr) return KV_OK;
-    unsigned long long done = 0;
-    return route_pack(p, 2, st, counts_out, &done);
+    if (ctx.host)
+        for (int d = 0; d < ndest; ++d) counts_out[d] = ctx.host[2 + d] + ctx.host[18 + d];
+    return KV_OK;
+}
+
+extern "C" int kv_mex_emit_pack(const kv_reads *shard, const kv_mex_plan *plan, uint64_t read_base, void *d_seg, void *d_cnt, void *d_out,
+                                uint64_t out_cap_words, uint64_t *records_per_dest, int *packed)
+{
+    KV_REQUIRE(shard && plan && d_seg && d_cnt && d_out && records_per_dest && packed, KV_ERR_ARG, "kv_mex_emit_pack: null argument");
+    return kv_skm_mex_emit(shard, plan, read_base, (uint64_t *)d_seg, (uint32_t *)d_cnt, (uint64_t *)d_out, out_cap_words, records_per_dest, packed);
 }
 
 // n_total gathered hits (tag, S abundance bytes each), of which the n_valid smallest tags are real

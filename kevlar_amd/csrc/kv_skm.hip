@@ -1755,8 +1755,9 @@ __global__ __launch_bounds__(1024) void k_mex_scan(const uint32_t *cnt, uint64_t
 
 // the filled part of every segment, one after the other: a workgroup per segment
 __global__ __launch_bounds__(256) void k_mex_gather(const uint64_t *seg, const uint32_t *cnt, const uint64_t *off, uint64_t n_segments, uint32_t cap1,
-                                                    uint32_t recw, uint64_t *out)
+                                                    uint32_t recw, uint64_t *out, uint64_t out_cap_records)
 {
+    if (off[n_segments] > out_cap_records) return;            // does not fit: nothing is written, the caller sees the total and packs into a bigger buffer
     for (uint64_t sgi = blockIdx.x; sgi < n_segments; sgi += gridDim.x) {
         const uint64_t words = (uint64_t)min(cnt[sgi], cap1) * recw;
         const uint64_t *src = seg + sgi * cap1 * recw;
@@ -2266,8 +2267,11 @@ int kv_skm_mex_plan(int ksize, uint64_t n_reads_global, uint32_t read_len, int n
     return KV_OK;
 }
 
-// S1 of one shard into the caller's buffers ([C1][nwg1][cap1] records, [C1][nwg1] counts: what the plan says)
-int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t read_base, uint64_t *d_seg, uint32_t *d_cnt)
+// S1 of one shard into the caller's buffers ([C1][nwg1][cap1] records, [C1][nwg1] counts: what the plan says).
+// d_out != NULL: the filled part of the segments is packed into it as well, destination after destination (kv_skm_mex_pack), if it
+// holds out_cap_words; *packed says whether it did.  One stream synchronisation either way.
+int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t read_base, uint64_t *d_seg, uint32_t *d_cnt,
+                    uint64_t *d_out, uint64_t out_cap_words, uint64_t *records_per_dest, int *packed)
 {
     hipStream_t st = kv_stream();
     SkmIndex &idx = skm_index_for(st);
@@ -2286,9 +2290,12 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
     g.seg1 = d_seg; g.cnt1 = d_cnt;
     g.loose_cap = 1u << 16;
     const size_t b_loose = kv_round_up(g.loose_cap * (size_t)g.recw * 8, 256), b_ctr = 256;
-    KV_HIP(idx.arena.need(b_loose + b_ctr));
+    const uint64_t n_seg = plan->cnt_entries;
+    const size_t b_off = d_out ? kv_round_up((n_seg + 1) * 8, 256) : 0;
+    KV_HIP(idx.arena.need(b_loose + b_ctr + b_off));
     g.loose = (uint64_t *)idx.arena.p;
     g.ctr = (unsigned long long *)((unsigned char *)idx.arena.p + b_loose);
+    uint64_t *d_off = d_out ? (uint64_t *)((unsigned char *)idx.arena.p + b_loose + b_ctr) : nullptr;
     KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));
     // a workgroup that takes no tile still writes its counts; workgroups beyond the grid never run: zero them
     KV_HIP(hipMemsetAsync(d_cnt, 0, plan->cnt_entries * 4, st));
@@ -2297,9 +2304,25 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
         skm_launch_emit(g, reads, st);
     }
     KV_HIP(hipGetLastError());
-    unsigned long long ctr[2] = {0, 0};
-    KV_HIP(hipMemcpyAsync(ctr, g.ctr, sizeof(ctr), hipMemcpyDeviceToHost, st));
-    KV_HIP(hipStreamSynchronize(st));
+    if (d_out) {
+        KvProfScope prof("k_mex_pack");
+        hipLaunchKernelGGL(k_mex_scan, dim3(1), dim3(1024), 0, st, d_cnt, n_seg, plan->cap1, d_off);
+        hipLaunchKernelGGL(k_mex_gather, dim3((unsigned)std::min<uint64_t>(n_seg, 65536)), dim3(256), 0, st, d_seg, d_cnt, d_off, n_seg, plan->cap1,
+                           plan->recw, d_out, out_cap_words / plan->recw);
+        KV_HIP(hipGetLastError());
+    }
+    KvReadback rb;
+    hipError_t rb_err = hipSuccess;
+    const unsigned long long *ctr = rb.add(g.ctr, 2, st, &rb_err);
+    std::vector<const uint64_t *> bounds(plan->ndest + 1, nullptr);
+    if (d_out)
+        for (int d = 0; d <= plan->ndest; ++d) bounds[d] = rb.add(d_off + (uint64_t)plan->c_lo[d] * plan->nwg1, 1, st, &rb_err);
+    KV_HIP(rb_err);
+    KV_HIP(rb.wait(st));
+    if (d_out) {
+        for (int d = 0; d < plan->ndest; ++d) records_per_dest[d] = *bounds[d + 1] - *bounds[d];
+        *packed = (*bounds[plan->ndest] - *bounds[0]) * (uint64_t)plan->recw <= out_cap_words ? 1 : 0;
+    }
     // records that miss their segment have nowhere to travel in: the plan's capacity is twice the expected fill, so this
     // means a pathological input (one minimizer everywhere); no silent change of layout
     KV_REQUIRE(ctr[0] == 0 && ctr[1] == 0, KV_ERR_CAPACITY, "kv_mex_emit: %llu records did not fit their exchange segment", ctr[0]);
@@ -2312,7 +2335,7 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
 // the records n_src ranks sent for this rank's Cl coarse buckets -> S2 -> every distinct k-mer once as a (hash, occurrences)
 // pair for its band's owner (the callback allocates the sink, as for kv_skm_route_distinct)
 int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_recv_seg, const uint32_t *d_recv_cnt, int n_src, int compact,
-                     int (*alloc)(void *ctx, uint32_t nwg, KvRouteSink *sink), void *ctx, uint64_t *n_kmers_in)
+                     int (*alloc)(void *ctx, uint32_t nwg, KvRouteSink *sink), int (*after)(void *ctx), void *ctx, uint64_t *n_kmers_in)
 {
     KV_REQUIRE(plan && my_dest >= 0 && my_dest < plan->ndest && n_src >= 1, KV_ERR_ARG, "kv_mex_route: bad argument");
     hipStream_t st = kv_stream();
@@ -2361,10 +2384,6 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     skm_launch_split(g, st);
     KV_HIP(hipGetLastError());
     KV_HIP(hipMemcpyAsync(&g.ctr[6], &g.ctr[0], 8, hipMemcpyDeviceToDevice, st));
-    unsigned long long arrived = 0;
-    KV_HIP(hipMemcpyAsync(&arrived, &g.ctr[8], 8, hipMemcpyDeviceToHost, st));
-    KV_HIP(hipStreamSynchronize(st));
-    *n_kmers_in = arrived;
     const uint32_t nwg3 = skm_nwg3(g);
     {
         const uint64_t avg = (g.n_buckets + nwg3 - 1) / nwg3;
@@ -2386,9 +2405,16 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
         else hipLaunchKernelGGL(k_skm_loose_route<2>, dim3(SKM_LOOSE_WGS), dim3(256), 0, st, g, hp, rs);
     }
     KV_HIP(hipGetLastError());
-    unsigned long long sctr[8] = {0};
-    KV_HIP(hipMemcpyAsync(sctr, g.ctr, sizeof(sctr), hipMemcpyDeviceToHost, st));
-    KV_HIP(hipStreamSynchronize(st));
+    // the packing of the pairs (the caller's `after`) is queued behind the route kernels and everything is waited for once: its
+    // kernels bound what they write by the output's capacity, so what the counters say can be judged afterwards
+    if (after) { const int rc = after(ctx); if (rc != KV_OK) return rc; }
+    KvReadback back;
+    hipError_t rb_err = hipSuccess;
+    const unsigned long long *sctr = back.add(g.ctr, 9, st, &rb_err);
+    KV_HIP(rb_err);
+    KV_HIP(back.wait(st));
+    const unsigned long long arrived = sctr[8];
+    *n_kmers_in = arrived;
     if (getenv("KV_SKM_VERBOSE"))
         fprintf(stderr, "[kv_skm] exchange owner: %llu k-mers arrived in %u buckets, %.1f%% distinct, %.2f%% outside the LDS tables\n",
                 arrived, g.n_buckets, arrived ? 100.0 * (double)sctr[7] / (double)arrived : 0.0,
@@ -2413,12 +2439,14 @@ int kv_skm_mex_pack(const kv_mex_plan *plan, const uint64_t *d_seg, const uint32
     uint64_t *d_off = (uint64_t *)idx.arena.p;
     hipLaunchKernelGGL(k_mex_scan, dim3(1), dim3(1024), 0, st, d_cnt, n_seg, plan->cap1, d_off);
     hipLaunchKernelGGL(k_mex_gather, dim3((unsigned)std::min<uint64_t>(n_seg, 65536)), dim3(256), 0, st, d_seg, d_cnt, d_off, n_seg, plan->cap1,
-                       plan->recw, d_out);
+                       plan->recw, d_out, ~0ull);
     KV_HIP(hipGetLastError());
-    std::vector<uint64_t> bounds(plan->ndest + 1);
-    for (int d = 0; d <= plan->ndest; ++d)
-        KV_HIP(hipMemcpyAsync(&bounds[d], d_off + (uint64_t)plan->c_lo[d] * plan->nwg1, 8, hipMemcpyDeviceToHost, st));
-    KV_HIP(hipStreamSynchronize(st));
-    for (int d = 0; d < plan->ndest; ++d) records_per_dest[d] = bounds[d + 1] - bounds[d];
+    KvReadback rb;
+    hipError_t rb_err = hipSuccess;
+    std::vector<const uint64_t *> bounds(plan->ndest + 1, nullptr);
+    for (int d = 0; d <= plan->ndest; ++d) bounds[d] = rb.add(d_off + (uint64_t)plan->c_lo[d] * plan->nwg1, 1, st, &rb_err);
+    KV_HIP(rb_err);
+    KV_HIP(rb.wait(st));
+    for (int d = 0; d < plan->ndest; ++d) records_per_dest[d] = *bounds[d + 1] - *bounds[d];
     return KV_OK;
 }

@@ -927,6 +927,16 @@ def mex_pack(plan, seg_ptr, cnt_ptr, out_ptr):
     return [int(c) for c in counts]
 
 
+def mex_emit_pack(batch, plan, read_base, seg_ptr, cnt_ptr, out_ptr, out_cap_words):
+    """mex_emit + mex_pack in one call and one synchronisation (kv_mex_emit_pack); returns (records per destination, packed):
+    packed False = the filled part of the segments did not fit out_cap_words and mex_pack into a bigger buffer has to follow."""
+    counts = (ctypes.c_uint64 * int(plan.ndest))()
+    packed = ctypes.c_int(0)
+    check(_lib.load().kv_mex_emit_pack(batch._h, ctypes.byref(plan), int(read_base), ctypes.c_void_p(seg_ptr), ctypes.c_void_p(cnt_ptr),
+                                       ctypes.c_void_p(out_ptr), int(out_cap_words), counts, ctypes.byref(packed)))
+    return [int(c) for c in counts], bool(packed.value)
+
+
 def mex_route(plan, my_dest, recv_seg_ptr, recv_cnt_ptr, n_src, out_ptr, cap_items, compact=False):
     """Combine the records n_src ranks sent for this rank's buckets and write one (hash, occurrences) pair per distinct
     k-mer, grouped by band owner (kv_mex_route); returns (pairs per destination, k-mer occurrences that arrived)."""

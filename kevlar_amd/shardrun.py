@@ -178,11 +178,6 @@ class ShardedTrio(object):
             _lib.load().kv_table_cache_trim()
         return torch.empty((cap, words), dtype=torch.int64, device=self.device)
 
-    @staticmethod
-    def _fits(plan, cnt, packed):
-        """do the filled parts of the segments fit the half-size send buffer?  (one device reduction)"""
-        return int(cnt.clamp(max=int(plan.cap1)).sum(dtype=torch.int64).item()) * int(plan.recw) <= packed.shape[0]
-
     def start_minimizer(self, batch, read_index_base, n_reads_global, read_len):
         """start() for the minimizer-sharded layout: the shard is cut into super-k-mer records (kv_mex_emit), the records go
         to the rank that owns their minimizer bucket (first all-to-all; fixed split points, so no sizes are exchanged), that
@@ -197,24 +192,19 @@ class ShardedTrio(object):
         seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
         cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device=self.device)
         emitted = forced != 'emit:{}'.format(self.rank)
-        if emitted:
-            try:
-                hk.mex_emit(batch, plan, read_index_base, seg.data_ptr(), cnt.data_ptr())
-            except KvCapacityError:                         # records outside their exchange segment: minimizer skew
-                emitted = False
-        # only the filled part of the segments travels: the counts go first (fixed split points), and say how many records
-        # every source will send
+        # only the filled part of the segments travels (the segments' capacity is twice the expected fill): the cut and the
+        # packing are one call and one wait; the counts go first (fixed split points), and say how many records every source sends
         per_dest = None
         if emitted:
-            packed = torch.empty(int(plan.seg_words) // 2 + 1024, dtype=torch.int64, device=self.device)     # capacity is twice the expected fill
+            packed = torch.empty(int(plan.seg_words) // 2 + 1024, dtype=torch.int64, device=self.device)
             try:
-                per_dest = hk.mex_pack(plan, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr()) if self._fits(plan, cnt, packed) else None
-            except ValueError:
-                per_dest = None
-            if per_dest is None:                            # fuller than expected: a buffer of the segments' full size always fits
-                packed = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
-                per_dest = hk.mex_pack(plan, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr())
-        else:
+                per_dest, fitted = hk.mex_emit_pack(batch, plan, read_index_base, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr(), packed.shape[0])
+                if not fitted:                              # fuller than expected: a buffer of the segments' full size always fits
+                    packed = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
+                    per_dest = hk.mex_pack(plan, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr())
+            except KvCapacityError:                         # records outside their exchange segment: minimizer skew
+                emitted = False
+        if not emitted:
             cnt.fill_(-1)                                   # the marker every destination finds in this rank's slab of counts
         t1 = time.perf_counter()
         recw = int(plan.recw)

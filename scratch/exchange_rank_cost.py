@@ -115,9 +115,9 @@ def main():
                 for n in order:
                     ta = time.perf_counter()
                     if minimizer:
-                        hk.mex_emit(shards[n][0], plan, 0, my_seg.data_ptr(), my_cnt.data_ptr())
+                        per_dest, fitted = hk.mex_emit_pack(shards[n][0], plan, 0, my_seg.data_ptr(), my_cnt.data_ptr(), my_packed.data_ptr(), my_packed.shape[0])
+                        assert fitted
                         rs, rc = mex_recv0[n]
-                        per_dest = hk.mex_pack(plan, my_seg.data_ptr(), my_cnt.data_ptr(), my_packed.data_ptr())
                         c, _ = hk.mex_route(plan, 0, rs.data_ptr(), rc.data_ptr(), world, send.data_ptr(), send.shape[0])
                         out_bytes += (sum(c) - c[0]) * 16 + (sum(per_dest) - per_dest[0]) * int(plan.recw) * 8 + int(plan.cnt_entries) * 4 * (world - 1) // world
                     elif distinct:

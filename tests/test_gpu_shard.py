@@ -280,6 +280,22 @@ def test_set_scan_of_equal_length_reads_hashes_from_the_2bit_form(hk):
     abund = torch.empty((nk, 3), dtype=torch.uint8, device='cuda')
     n_int = hk.novel_scan_distinct([sk['proband']], [sk['mother'], sk['father']], send.data_ptr(), counts[0], 6, 1,
                                    hashes.data_ptr(), abund.data_ptr(), nk)
+    # the pairs are judged by k_novel_pairs (no verdict cache, four first probes in flight); the list kernel gives the same rows
+    os.environ['KV_NOVEL_PAIRS'] = '0'
+    try:
+        h2 = torch.empty(nk, dtype=torch.int64, device='cuda')
+        a2 = torch.empty((nk, 3), dtype=torch.uint8, device='cuda')
+        n2 = hk.novel_scan_distinct([sk['proband']], [sk['mother'], sk['father']], send.data_ptr(), counts[0], 6, 1, h2.data_ptr(), a2.data_ptr(), nk)
+    finally:
+        os.environ.pop('KV_NOVEL_PAIRS', None)
+    assert n2 == n_int and n_int > 50
+
+    def rows(h, a, n):
+        hh = h[:n].cpu().numpy().view(np.uint64)
+        order = np.argsort(hh, kind='stable')
+        return hh[order], a[:n].cpu().numpy()[order]
+    (ha, aa), (hb, ab) = rows(hashes, abund, n_int), rows(h2, a2, n2)
+    assert np.array_equal(ha, hb) and np.array_equal(aa, ab)
     lib.kv_prof_enable(1)
     try:
         before = launches('k_novel_mark_2bit'), launches('k_skm_novel')
