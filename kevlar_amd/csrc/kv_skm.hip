@@ -1724,17 +1724,39 @@ void skm_launch_split(const SkmGeom &g, hipStream_t st)
     }
 }
 
-// exclusive prefix of n counts (one workgroup; n is a few hundred thousand at most); off[n] = total
-__global__ __launch_bounds__(1024) void k_mex_scan(const uint32_t *cnt, uint64_t n, uint32_t cap1, uint64_t *off)
+// Exclusive prefix of n counts, off[n] = total -- n is the number of exchange segments, a couple of hundred thousand: chunks of 1024
+// scanned side by side (k_mex_scan_chunks), the chunk totals by one workgroup (k_mex_scan_parts), the bases added (k_mex_scan_add).
+// (One workgroup walking all of it took 0.15 ms, a third of a rank's packing at N = 8.)  `part` holds n / 1024 + 2 values.
+__global__ __launch_bounds__(1024) void k_mex_scan_chunks(const uint32_t *cnt, uint64_t n, uint32_t cap1, uint64_t *off, uint64_t *part)
+{
+    __shared__ uint64_t wsum[16];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t i = (uint64_t)blockIdx.x * 1024u + threadIdx.x;
+    const uint64_t v = i < n ? (uint64_t)min(cnt[i], cap1) : 0ull;
+    uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, d), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), d);
+        if (lane >= (uint32_t)d) incl += (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint64_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
+    if (i < n) off[i] = before + incl - v;
+    if (threadIdx.x == 1023) part[blockIdx.x] = before + incl;
+}
+
+__global__ __launch_bounds__(1024) void k_mex_scan_parts(uint64_t *part, uint64_t n_parts)
 {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry_sh;
     if (threadIdx.x == 0) carry_sh = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint64_t base = 0; base < n; base += 1024) {
+    for (uint64_t base = 0; base < n_parts; base += 1024) {
         const uint64_t i = base + threadIdx.x;
-        const uint64_t v = i < n ? (uint64_t)min(cnt[i], cap1) : 0ull;
+        const uint64_t v = i < n_parts ? part[i] : 0ull;
         uint64_t incl = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -1745,24 +1767,42 @@ __global__ __launch_bounds__(1024) void k_mex_scan(const uint32_t *cnt, uint64_t
         __syncthreads();
         uint64_t before = carry_sh;
         for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
-        if (i < n) off[i] = before + incl - v;
+        if (i < n_parts) part[i] = before + incl - v;
         __syncthreads();
         if (threadIdx.x == 1023) carry_sh = before + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) off[n] = carry_sh;
+    if (threadIdx.x == 0) part[n_parts] = carry_sh;
 }
 
-// the filled part of every segment, one after the other: a workgroup per segment
+__global__ __launch_bounds__(1024) void k_mex_scan_add(uint64_t *off, uint64_t n, const uint64_t *part, uint64_t n_parts)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 1024u + threadIdx.x;
+    if (i < n) off[i] += part[blockIdx.x];
+    if (i == 0) off[n] = part[n_parts];
+}
+
+static inline size_t mex_scan_bytes(uint64_t n) { return kv_round_up((n + 1 + n / 1024 + 3) * 8, 256); }     // off[n + 1] and the chunk totals behind it
+static void mex_scan_launch(const uint32_t *cnt, uint64_t n, uint32_t cap1, uint64_t *off, hipStream_t st)
+{
+    const uint64_t n_parts = (n + 1023) / 1024;
+    uint64_t *part = off + n + 1;
+    if (n_parts) hipLaunchKernelGGL(k_mex_scan_chunks, dim3((unsigned)n_parts), dim3(1024), 0, st, cnt, n, cap1, off, part);
+    hipLaunchKernelGGL(k_mex_scan_parts, dim3(1), dim3(1024), 0, st, part, n_parts);
+    hipLaunchKernelGGL(k_mex_scan_add, dim3((unsigned)std::max<uint64_t>(n_parts, 1)), dim3(1024), 0, st, off, n, (const uint64_t *)part, n_parts);
+}
+
+// the filled part of every segment, one after the other: a wavefront per segment (a segment of a shard at N = 8 holds ~40 records)
 __global__ __launch_bounds__(256) void k_mex_gather(const uint64_t *seg, const uint32_t *cnt, const uint64_t *off, uint64_t n_segments, uint32_t cap1,
                                                     uint32_t recw, uint64_t *out, uint64_t out_cap_records)
 {
     if (off[n_segments] > out_cap_records) return;            // does not fit: nothing is written, the caller sees the total and packs into a bigger buffer
-    for (uint64_t sgi = blockIdx.x; sgi < n_segments; sgi += gridDim.x) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t sgi = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); sgi < n_segments; sgi += (uint64_t)gridDim.x * 4u) {
         const uint64_t words = (uint64_t)min(cnt[sgi], cap1) * recw;
         const uint64_t *src = seg + sgi * cap1 * recw;
         uint64_t *dst = out + off[sgi] * recw;
-        for (uint64_t i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+        for (uint64_t i = lane; i < words; i += 64) dst[i] = src[i];
     }
 }
 
@@ -2254,7 +2294,9 @@ int kv_skm_mex_plan(int ksize, uint64_t n_reads_global, uint32_t read_len, int n
     while ((1u << fbits) < F2) ++fbits;
     const uint64_t shard_reads = (n_reads_global + ndest - 1) / ndest;
     const uint64_t tiles = (shard_reads + KV_TILE_MAX_READS - 1) / KV_TILE_MAX_READS;
-    const uint32_t nwg1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((tiles + SKM_TILES_PER_TICKET - 1) / SKM_TILES_PER_TICKET, 768));
+    // writers per shard (every one owns a segment of every coarse bucket): KV_MEX_NWG1 must be the same on every rank
+    const uint64_t nwg1_max = getenv("KV_MEX_NWG1") ? (uint64_t)std::max(1, std::min(768, atoi(getenv("KV_MEX_NWG1")))) : 768;
+    const uint32_t nwg1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((tiles + SKM_TILES_PER_TICKET - 1) / SKM_TILES_PER_TICKET, nwg1_max));
     const double rec_est = (double)(shard_reads * nk_read) * 2.2 / (double)(g.w + 1) + (double)shard_reads + 1024.0;
     const double m1 = rec_est / ((double)C1 * nwg1);
     const uint32_t cap1 = (uint32_t)kv_round_up((uint64_t)(m1 * 2.0 + 8.0 * std::sqrt(m1)) + 64, 16);
@@ -2291,7 +2333,7 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
     g.loose_cap = 1u << 16;
     const size_t b_loose = kv_round_up(g.loose_cap * (size_t)g.recw * 8, 256), b_ctr = 256;
     const uint64_t n_seg = plan->cnt_entries;
-    const size_t b_off = d_out ? kv_round_up((n_seg + 1) * 8, 256) : 0;
+    const size_t b_off = d_out ? mex_scan_bytes(n_seg) : 0;
     KV_HIP(idx.arena.need(b_loose + b_ctr + b_off));
     g.loose = (uint64_t *)idx.arena.p;
     g.ctr = (unsigned long long *)((unsigned char *)idx.arena.p + b_loose);
@@ -2306,8 +2348,8 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
     KV_HIP(hipGetLastError());
     if (d_out) {
         KvProfScope prof("k_mex_pack");
-        hipLaunchKernelGGL(k_mex_scan, dim3(1), dim3(1024), 0, st, d_cnt, n_seg, plan->cap1, d_off);
-        hipLaunchKernelGGL(k_mex_gather, dim3((unsigned)std::min<uint64_t>(n_seg, 65536)), dim3(256), 0, st, d_seg, d_cnt, d_off, n_seg, plan->cap1,
+        mex_scan_launch(d_cnt, n_seg, plan->cap1, d_off, st);
+        hipLaunchKernelGGL(k_mex_gather, dim3((unsigned)std::min<uint64_t>((n_seg + 3) / 4, 1u << 20)), dim3(256), 0, st, d_seg, d_cnt, d_off, n_seg, plan->cap1,
                            plan->recw, d_out, out_cap_words / plan->recw);
         KV_HIP(hipGetLastError());
     }
@@ -2363,7 +2405,7 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     const size_t rb = (size_t)g.recw * 8;
     const size_t b_seg2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * g.cap2 * rb, 256), b_cnt2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * 4, 256);
     const size_t b_loose = kv_round_up(g.loose_cap * rb, 256), b_ctr = 256;
-    const size_t b_off = compact ? kv_round_up(((uint64_t)Cl * nseg + 1) * 8, 256) : 0;
+    const size_t b_off = compact ? mex_scan_bytes((uint64_t)Cl * nseg) : 0;
     KV_HIP(idx.arena.need(b_seg2 + b_cnt2 + b_loose + b_off + b_ctr));
     unsigned char *base = (unsigned char *)idx.arena.p;
     g.seg2 = (uint64_t *)base; base += b_seg2;
@@ -2376,7 +2418,7 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     if (compact) {
         // the sources sent only the filled part of their segments, in segment order: a segment starts where the counts in
         // front of it end
-        hipLaunchKernelGGL(k_mex_scan, dim3(1), dim3(1024), 0, st, g.cnt1, (uint64_t)Cl * nseg, g.cap1, d_off);
+        mex_scan_launch(g.cnt1, (uint64_t)Cl * nseg, g.cap1, d_off, st);
         g.seg1_off = d_off;
     }
     // how many k-mer occurrences arrived (the caller's buffer must hold a pair for each in the worst case)
@@ -2435,10 +2477,10 @@ int kv_skm_mex_pack(const kv_mex_plan *plan, const uint64_t *d_seg, const uint32
     SkmIndex &idx = skm_index_for(st);
     std::lock_guard<std::mutex> lk(idx.mu);
     const uint64_t n_seg = plan->cnt_entries;
-    KV_HIP(idx.arena.need(kv_round_up((n_seg + 1) * 8, 256)));
+    KV_HIP(idx.arena.need(mex_scan_bytes(n_seg)));
     uint64_t *d_off = (uint64_t *)idx.arena.p;
-    hipLaunchKernelGGL(k_mex_scan, dim3(1), dim3(1024), 0, st, d_cnt, n_seg, plan->cap1, d_off);
-    hipLaunchKernelGGL(k_mex_gather, dim3((unsigned)std::min<uint64_t>(n_seg, 65536)), dim3(256), 0, st, d_seg, d_cnt, d_off, n_seg, plan->cap1,
+    mex_scan_launch(d_cnt, n_seg, plan->cap1, d_off, st);
+    hipLaunchKernelGGL(k_mex_gather, dim3((unsigned)std::min<uint64_t>((n_seg + 3) / 4, 1u << 20)), dim3(256), 0, st, d_seg, d_cnt, d_off, n_seg, plan->cap1,
                        plan->recw, d_out, ~0ull);
     KV_HIP(hipGetLastError());
     KvReadback rb;
