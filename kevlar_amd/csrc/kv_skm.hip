@@ -1639,10 +1639,11 @@ int skm_minimizer_len(int k) { return k >= 24 ? 12 : k / 2; }
 // reads per wave and chunk size of the wave kernel for batches of equal-length reads (0: use the tile kernel).  One packed
 // word and one chunk per lane, and about as many runs as lanes: a run per (w + 1) / 2 k-mers, one more per read.
 // threads per workgroup of the wave kernel (KV_SKM_S1_THREADS=512|1024)
+static thread_local uint32_t tl_s1_threads = 0;       // a caller's choice for the launch it is about to make (kv_skm_mex_emit); the variable in the environment wins
 static uint32_t skm_wave_threads()
 {
     if (const char *e = getenv("KV_SKM_S1_THREADS")) return atoi(e) == 512 ? 512u : 1024u;
-    return SKM_S1_WAVE_THREADS_DEFAULT;
+    return tl_s1_threads ? tl_s1_threads : SKM_S1_WAVE_THREADS_DEFAULT;
 }
 
 static uint32_t skm_wave_plan(const SkmGeom &g, const kv_reads *reads, int *ch)
@@ -2294,8 +2295,11 @@ int kv_skm_mex_plan(int ksize, uint64_t n_reads_global, uint32_t read_len, int n
     while ((1u << fbits) < F2) ++fbits;
     const uint64_t shard_reads = (n_reads_global + ndest - 1) / ndest;
     const uint64_t tiles = (shard_reads + KV_TILE_MAX_READS - 1) / KV_TILE_MAX_READS;
-    // writers per shard (every one owns a segment of every coarse bucket): KV_MEX_NWG1 must be the same on every rank
-    const uint64_t nwg1_max = getenv("KV_MEX_NWG1") ? (uint64_t)std::max(1, std::min(768, atoi(getenv("KV_MEX_NWG1")))) : 768;
+    // Writers per shard; every one owns a segment of every coarse bucket.  One per CU, 1024 threads each: a shard is an N-th of a
+    // sample, and with the 768 writers of a whole sample its ~190 000 segments held ~40 records each at N = 8 -- the cut, the packing
+    // and the owner's split all pay per segment (per rank of config 2, N = 8 / N = 2: 8.58 / 25.07 ms with 768 writers of 512 threads,
+    // 7.73 / 23.10 with 256 of 1024).  KV_MEX_NWG1 (the same on every rank) overrides.
+    const uint64_t nwg1_max = getenv("KV_MEX_NWG1") ? (uint64_t)std::max(1, std::min(768, atoi(getenv("KV_MEX_NWG1")))) : 256;
     const uint32_t nwg1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((tiles + SKM_TILES_PER_TICKET - 1) / SKM_TILES_PER_TICKET, nwg1_max));
     const double rec_est = (double)(shard_reads * nk_read) * 2.2 / (double)(g.w + 1) + (double)shard_reads + 1024.0;
     const double m1 = rec_est / ((double)C1 * nwg1);
@@ -2343,7 +2347,9 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
     KV_HIP(hipMemsetAsync(d_cnt, 0, plan->cnt_entries * 4, st));
     if (reads->n_tiles) {
         g.nwg1 = plan->nwg1;
+        tl_s1_threads = plan->nwg1 <= 256u ? 1024u : 0u;
         skm_launch_emit(g, reads, st);
+        tl_s1_threads = 0;
     }
     KV_HIP(hipGetLastError());
     if (d_out) {
