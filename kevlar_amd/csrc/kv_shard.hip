@@ -491,10 +491,16 @@ extern "C" int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_
         return KV_OK;
     };
     { const int rc = kv_skm_mex_route(plan, my_dest, (const uint64_t *)d_recv_seg, (const uint32_t *)d_recv_cnt, n_src, compact, alloc, after, &ctx, n_kmers_in); if (rc != KV_OK) return rc; }
-    KV_REQUIRE(*n_kmers_in <= cap_items, KV_ERR_CAPACITY, "kv_mex_route: %llu k-mers arrived, the output holds %llu pairs",
-               (unsigned long long)*n_kmers_in, (unsigned long long)cap_items);
-    if (ctx.host)
-        for (int d = 0; d < ndest; ++d) counts_out[d] = ctx.host[2 + d] + ctx.host[18 + d];
+    // what has to fit is the pairs -- one per distinct k-mer, a fifth of the occurrences at sequencing coverage -- not the occurrences:
+    // the sink's overflow list and the packing both bound what they write and count what they were asked to
+    if (ctx.host) {
+        uint64_t total = 0;
+        for (int d = 0; d < ndest; ++d) { counts_out[d] = ctx.host[2 + d] + ctx.host[18 + d]; total += counts_out[d]; }
+        KV_REQUIRE(ctx.host[1] <= p.ovf_cap, KV_ERR_CAPACITY, "kv_mex_route: %llu pairs beside their segments, the list holds %llu (%llu k-mers arrived)",
+                   (unsigned long long)ctx.host[1], (unsigned long long)p.ovf_cap, (unsigned long long)*n_kmers_in);
+        KV_REQUIRE(total <= cap_items, KV_ERR_CAPACITY, "kv_mex_route: %llu pairs for %llu k-mers that arrived, the output holds %llu",
+                   (unsigned long long)total, (unsigned long long)*n_kmers_in, (unsigned long long)cap_items);
+    }
     return KV_OK;
 }
 

@@ -313,6 +313,49 @@ def test_set_scan_of_equal_length_reads_hashes_from_the_2bit_form(hk):
         assert np.array_equal(r0, r) and np.array_equal(o0, o) and np.array_equal(a0, a)
 
 
+def test_mex_route_judges_its_output_by_the_pairs_not_by_the_occurrences(hk):
+    """the owner's output holds one pair per DISTINCT k-mer: a buffer smaller than the occurrences that arrived but large enough for
+    the pairs is fine (same pairs as with a roomy one), one smaller than the pairs is a capacity error -- said after the fact, with
+    nothing written outside the buffer (the words behind it keep their pattern)"""
+    import torch
+    from kevlar_amd import synth
+    from kevlar_amd._lib import KvCapacityError
+    k, L = 31, 100
+    trio = synth.make_trio(150000, 31)
+    packed = synth.sample_reads_packed(trio['proband'], 45000, L, 0.005, 77)          # 30x: a fifth of the k-mers distinct
+    batch = hk.ReadBatch.from_packed(packed, L)
+    plan = hk.mex_plan(hk.Counttable, k, packed.shape[0], L, 1)
+    seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device='cuda')
+    cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device='cuda')
+    hk.mex_emit(batch, plan, 0, seg.data_ptr(), cnt.data_ptr())
+    nk = batch.num_kmers(k)
+
+    def route(cap):
+        out = torch.full((cap + 64, 2), 0x5a5a5a5a, dtype=torch.int64, device='cuda')
+        counts, arrived = hk.mex_route(plan, 0, seg.data_ptr(), cnt.data_ptr(), 1, out.data_ptr(), cap)
+        torch.cuda.synchronize()
+        return counts, arrived, out
+    counts, arrived, roomy = route(nk)
+    n_pairs = counts[0]
+    assert arrived == nk and n_pairs < nk // 2
+    want = roomy[:n_pairs].cpu().numpy()
+    want = want[np.lexsort((want[:, 1], want[:, 0]))]
+    counts2, arrived2, tight = route(n_pairs + 10)                 # fewer than the occurrences, enough for the pairs
+    assert counts2 == counts and arrived2 == nk
+    got = tight[:n_pairs].cpu().numpy()
+    assert np.array_equal(got[np.lexsort((got[:, 1], got[:, 0]))], want)
+    assert bool((tight[n_pairs + 10:] == 0x5a5a5a5a).all())
+    with pytest.raises(KvCapacityError):
+        route(n_pairs // 2)
+    probe = torch.full((n_pairs // 2 + 64, 2), 0x5a5a5a5a, dtype=torch.int64, device='cuda')
+    try:
+        hk.mex_route(plan, 0, seg.data_ptr(), cnt.data_ptr(), 1, probe.data_ptr(), n_pairs // 2)
+    except KvCapacityError:
+        pass
+    torch.cuda.synchronize()
+    assert bool((probe[n_pairs // 2:] == 0x5a5a5a5a).all())
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
