@@ -102,6 +102,8 @@ def parse_args():
                         'independent; kernels bound by different units overlap and no stream waits for another\'s host round '
                         'trips: 39-40 ms against 43-46 ms per step at config 2).  Per-kernel HIP-event durations then include '
                         'time sharing; 1 keeps the launches back to back for a clean per-kernel attribution')
+    p.add_argument('--bands', type=int, default=None, help='one GPU plays ONE band of a run banded this many ways (what a rank of --multi banded computes); --band picks it')
+    p.add_argument('--band', type=int, default=0)
     p.add_argument('--no-downstream', action='store_true', help='cfg4-band: count and scan only (no annotated reads, filter, partition)')
     p.add_argument('--traffic', default='live', choices=['live', 'file', 'none'],
                    help='roofline.traffic (HBM bytes of the dominant stage): live = measured by two rocprofv3 --pmc child passes of this '
@@ -321,6 +323,8 @@ def main():
     nk = L - k + 1
     T = 4
     S = len(names)
+    if args.bands:
+        wl = dict(wl, bands=int(args.bands), band=int(args.band))
     solo_bands, solo_band = int(wl.get('bands', 0)), int(wl.get('band', 0))       # a single GPU playing one band of a banded run
     mem_per_gpu = wl['memory'] / max(1, world) / max(1, solo_bands)
     hbm_low = [torch.cuda.mem_get_info(dev_index)[0]]
