@@ -391,7 +391,7 @@ def main():
         kmers = 0
         t_a = time.perf_counter()
         order = list(controls) + ['proband']
-        if world == 1 and args.count_streams > 1:
+        if args.count_streams > 1 and not exchange:           # (a rank of a banded run counts its band of the three samples side by side as well)
             def job(n):
                 def count_one():
                     sk[n].clear()
