@@ -396,6 +396,14 @@ int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_recv_seg, c
 int kv_mex_emit_pack(const kv_reads *shard, const kv_mex_plan *plan, uint64_t read_base, void *d_seg, void *d_cnt, void *d_out,
                      uint64_t out_cap_words, uint64_t *records_per_dest, int *packed);
 
+/* ---- argsort for the host half of partition (kevlar/readgraph.py:123-161, kevlar/partition.py:15-55: sorted(cc), sorted by
+ * size; here the array form, kevlar_amd/partition.py assemble_partitions) -------------------------------------------------
+ * order[i] = index of the i-th smallest key, equal keys in index order (numpy.argsort(kind='stable')); host pointers, the
+ * sort runs on the device (rocPRIM radix sort of (key, index) pairs).  kv_argsort_rows orders n rows of `width` bytes like
+ * byte strings (numpy 'S<width>').                                                                                       */
+int kv_argsort_u64(const uint64_t *keys, uint64_t n, uint32_t *order);
+int kv_argsort_rows(const void *rows, uint64_t n, uint32_t width, uint32_t *order);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,6 +116,8 @@ SIGNATURES = {
     'kv_novel_scan_distinct': (i32, [vpp, i32, vpp, i32, vp, u64, i32, i32, vp, vp, u64, u64p]),
     'kv_novel_scan_set': (i32, [vp, i32, i32, i32, vp, vp, u64, vpp]),
     'kv_hits_from_tagged': (i32, [vp, vp, u64, u64, i32, vpp]),
+    'kv_argsort_u64': (i32, [vp, u64, vp]),
+    'kv_argsort_rows': (i32, [vp, u64, ctypes.c_uint32, vp]),
     'kv_mex_plan_make': (i32, [i32, i32, u64, u32, i32, vp]),
     'kv_mex_emit': (i32, [vp, vp, u64, vp, vp]),
     'kv_mex_pack': (i32, [vp, vp, vp, vp, u64p]),
@@ -186,6 +188,17 @@ def check(code):
     if code == KV_ERR_TYPE:
         raise ValueError(msg)
     raise KvError(code, msg)
+
+
+def device_visible():
+    """is there a GPU to hand the big sorts of the host stages to?  (never raises: host logic runs without one)"""
+    if _device_ready:
+        return True
+    try:
+        n = ctypes.c_int(0)
+        return load().kv_device_count(ctypes.byref(n)) == 0 and n.value >= 1
+    except OSError:
+        return False
 
 
 def require_device():

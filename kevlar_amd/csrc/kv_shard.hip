@@ -511,6 +511,81 @@ extern "C" int kv_mex_emit_pack(const kv_reads *shard, const kv_mex_plan *plan, 
     return kv_skm_mex_emit(shard, plan, read_base, (uint64_t *)d_seg, (uint32_t *)d_cnt, (uint64_t *)d_out, out_cap_words, records_per_dest, packed);
 }
 
+// ---- argsort for the host half of partition (kevlar_amd/partition.py assemble_partitions) ---------------------------------
+// The reads of a partition run are ordered by name, by component label and by a hash of their canonical sequence: three
+// numpy argsorts over 6.7 M reads were 0.75 s of config 4's band (a fifth of `kevlar partition` there).  The keys go to the
+// device, rocPRIM's radix sort -- stable -- orders (key, index) pairs, the indices come back: a few milliseconds.
+namespace {
+__global__ void k_row_keys(const uint8_t *rows, const uint32_t *idx, uint64_t n, uint32_t width, uint32_t at, unsigned long long *keys)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t *row = rows + (uint64_t)idx[i] * width + at;
+        unsigned long long key = 0;
+        for (uint32_t b = 0; b < 8; ++b) key = (key << 8) | (at + b < width ? (unsigned long long)row[b] : 0ull);     // big-endian: compares like the bytes
+        keys[i] = key;
+    }
+}
+
+int argsort_pairs(DevBuf &keys_in, DevBuf &idx_in, DevBuf &keys_out, DevBuf &idx_out, DevBuf &tmp, size_t &tmp_bytes, uint64_t n, hipStream_t st)
+{
+    size_t need = 0;
+    KV_HIP(rocprim::radix_sort_pairs(nullptr, need, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(), idx_in.as<uint32_t>(),
+                                     idx_out.as<uint32_t>(), (size_t)n, 0, 64, st));
+    if (need > tmp_bytes) {
+        if (tmp.p) { (void)hipFree(tmp.p); tmp.p = nullptr; }
+        KV_HIP(tmp.alloc(need));
+        tmp_bytes = need;
+    }
+    KV_HIP(rocprim::radix_sort_pairs(tmp.p, need, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(), idx_in.as<uint32_t>(),
+                                     idx_out.as<uint32_t>(), (size_t)n, 0, 64, st));
+    return KV_OK;
+}
+}  // namespace
+
+// order[i] = index of the i-th smallest key, equal keys in index order (numpy.argsort(keys, kind='stable')); host pointers
+extern "C" int kv_argsort_u64(const uint64_t *keys, uint64_t n, uint32_t *order)
+{
+    KV_REQUIRE((keys && order) || n == 0, KV_ERR_ARG, "kv_argsort_u64: null argument");
+    KV_REQUIRE(n < (1ull << 32), KV_ERR_ARG, "kv_argsort_u64: too many keys");
+    if (n == 0) return KV_OK;
+    hipStream_t st = kv_stream();
+    DevBuf k_in, k_out, v_in, v_out, tmp;
+    size_t tmp_bytes = 0;
+    KV_HIP(k_in.alloc(n * 8)); KV_HIP(k_out.alloc(n * 8)); KV_HIP(v_in.alloc(n * 4)); KV_HIP(v_out.alloc(n * 4));
+    KV_HIP(hipMemcpyAsync(k_in.p, keys, n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_iota_u32, dim3(256), dim3(256), 0, st, v_in.as<uint32_t>(), n);
+    { const int rc = argsort_pairs(k_in, v_in, k_out, v_out, tmp, tmp_bytes, n, st); if (rc != KV_OK) return rc; }
+    KV_HIP(hipMemcpyAsync(order, v_out.p, n * 4, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    return KV_OK;
+}
+
+// the same for n rows of `width` bytes compared like byte strings (numpy.argsort of an 'S<width>' array, kind='stable'):
+// least significant eight bytes first, every pass stable
+extern "C" int kv_argsort_rows(const void *rows, uint64_t n, uint32_t width, uint32_t *order)
+{
+    KV_REQUIRE((rows && order) || n == 0, KV_ERR_ARG, "kv_argsort_rows: null argument");
+    KV_REQUIRE(n < (1ull << 32) && width >= 1, KV_ERR_ARG, "kv_argsort_rows: bad size");
+    if (n == 0) return KV_OK;
+    hipStream_t st = kv_stream();
+    DevBuf d_rows, k_in, k_out, v_a, v_b, tmp;
+    size_t tmp_bytes = 0;
+    KV_HIP(d_rows.alloc(n * (uint64_t)width)); KV_HIP(k_in.alloc(n * 8)); KV_HIP(k_out.alloc(n * 8)); KV_HIP(v_a.alloc(n * 4)); KV_HIP(v_b.alloc(n * 4));
+    KV_HIP(hipMemcpyAsync(d_rows.p, rows, n * (uint64_t)width, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_iota_u32, dim3(256), dim3(256), 0, st, v_a.as<uint32_t>(), n);
+    DevBuf *cur = &v_a, *nxt = &v_b;
+    const uint32_t chunks = (width + 7u) / 8u;
+    for (uint32_t c = chunks; c-- > 0;) {
+        hipLaunchKernelGGL(k_row_keys, dim3(1024), dim3(256), 0, st, d_rows.as<uint8_t>(), cur->as<uint32_t>(), n, width, c * 8u, k_in.as<unsigned long long>());
+        KV_HIP(hipGetLastError());
+        { const int rc = argsort_pairs(k_in, *cur, k_out, *nxt, tmp, tmp_bytes, n, st); if (rc != KV_OK) return rc; }
+        std::swap(cur, nxt);
+    }
+    KV_HIP(hipMemcpyAsync(order, cur->p, n * 4, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    return KV_OK;
+}
+
 // n_total gathered hits (tag, S abundance bytes each), of which the n_valid smallest tags are real
 // (padding carries tag ~0): sort by tag = (read, offset) and hand back an ordinary kv_hits.
 extern "C" int kv_hits_from_tagged(const void *d_tags, const void *d_abund, uint64_t n_total, uint64_t n_valid,

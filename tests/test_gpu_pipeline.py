@@ -519,3 +519,59 @@ def test_novel_tally_counts_a_kmer_seen_on_both_paths_once(hk):
     only_records = _Tally()
     only_records.kmers.update([a, kevlar_amd.revcom(a), c])
     assert 'of 2 unique novel kmers' in only_records.line(0.0)
+
+
+def test_device_argsort_is_numpys_stable_argsort(hk):
+    """kv_argsort_u64 / kv_argsort_rows (the sorts of partition's host half on the device's radix sort) give numpy's stable order:
+    integer keys with many ties, names of every width around the eight-byte passes, NUL padding, bytes above 127"""
+    import ctypes
+    from kevlar_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for n, hi in ((0, 10), (1, 10), (1000, 7), (300000, 1 << 40), (300000, 50), (70000, 1 << 63)):
+        keys = rng.integers(0, hi, size=n, dtype=np.uint64) if hi < (1 << 63) else rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+        order = np.empty(n, dtype=np.uint32)
+        _lib.check(lib.kv_argsort_u64(ctypes.c_void_p(keys.ctypes.data), n, ctypes.c_void_p(order.ctypes.data)))
+        assert np.array_equal(order, np.argsort(keys, kind='stable'))
+    for width in (1, 3, 7, 8, 9, 16, 23):
+        n = 120000
+        alphabet = np.frombuffer(b'ab\x00\xfe/0', dtype=np.uint8)          # few symbols: long common prefixes, many equal names
+        raw = alphabet[rng.integers(0, len(alphabet), size=(n, width))]
+        cut = rng.integers(1, width + 1, size=n)
+        raw[np.arange(width)[None, :] >= cut[:, None]] = 0                # names of different lengths, NUL padded
+        rows = np.ascontiguousarray(raw).view('S{}'.format(width)).reshape(-1)
+        order = np.empty(n, dtype=np.uint32)
+        _lib.check(lib.kv_argsort_rows(ctypes.c_void_p(rows.ctypes.data), n, width, ctypes.c_void_p(order.ctypes.data)))
+        # numpy compares 'S' values with trailing NULs stripped, which is what NUL padding + byte order gives as well
+        assert np.array_equal(order, np.argsort(rows, kind='stable')), width
+
+
+def test_partition_orders_through_the_device_sort_exactly_as_through_numpy(hk, monkeypatch):
+    """assemble_partitions with its three sorts on the device (threshold lowered) against the same call with numpy's sorts"""
+    import random
+    import kevlar_amd
+    from kevlar_amd import partition
+    rng = random.Random(21)
+    n = 30000
+    pool = [''.join(rng.choice('ACGT') for _ in range(rng.choice([40, 40, 55]))) for _ in range(n // 3)]
+    names = ['read{}'.format(rng.randrange(n)) if rng.random() < 0.2 else 'r{}/{}'.format(i, rng.randrange(3)) for i in range(n)]
+    seqs = [kevlar_amd.revcom(s) if rng.random() < 0.4 else s for s in (rng.choice(pool) for _ in range(n))]
+    nb = ''.join(names).encode(); no = np.cumsum([0] + [len(x) for x in names]).astype(np.uint64)
+    sb = ''.join(seqs).encode(); so = np.cumsum([0] + [len(x) for x in seqs]).astype(np.uint64)
+    label_rng = np.random.default_rng(3)
+    labels_cache = {}
+
+    def component_of(node_of_read, n_nodes):
+        if n_nodes not in labels_cache:
+            labels_cache[n_nodes] = label_rng.integers(0, n // 7, size=n_nodes).astype(np.uint32)
+        return labels_cache[n_nodes]
+    monkeypatch.setenv('KV_HOST_SORT', '1')
+    want = partition.assemble_partitions(nb, no, sb, so, component_of, 2, True)
+    monkeypatch.delenv('KV_HOST_SORT')
+    monkeypatch.setattr(partition, '_DEVICE_SORT_MIN', 16)
+    calls = []
+    real = partition._argsort
+    monkeypatch.setattr(partition, '_argsort', lambda keys: (calls.append(len(keys)), real(keys))[1])
+    got = partition.assemble_partitions(nb, no, sb, so, component_of, 2, True)
+    assert len(calls) == 3 and len(want[0]) > 1000
+    assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1])
