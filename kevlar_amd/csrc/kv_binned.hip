@@ -885,179 +885,6 @@ __global__ __launch_bounds__(SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_
     if (t == 0 && threadIdx.x == 0 && fresh_sh) atomicAdd(&g.ctr[3], (unsigned long long)fresh_sh);
 }
 
-// ---- stage C for weighted items on byte counters: sums first, saturation once ----------------------------------------------
-// k_bin_apply pays a compare-and-swap loop per item because a byte that overflows would carry into its neighbour: ~30 of its 75
-// lane-instructions per item, in a kernel that runs at the chip's VALU ceiling.  Saturating adds commute, so the
-// slice is widened instead: every bin a 16-bit sum in LDS (64 KB for the 32768 bins of a slice: two workgroups per CU), initialised
-// with the counter, the items added with plain atomic adds, and the sums clamped to 255 on the way back.  A 16-bit sum can overflow
-// only when 255 + (weights of the items of ONE bin in ONE batch) passes 65535 -- a few hundred distinct k-mers of a batch on one bin;
-// every add checks the value it replaced, and a workgroup that sees it happen throws its sums away and does the slice again the slow
-// way (the table has not been touched yet), so the result is exact whatever the input.
-typedef unsigned short kv_u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t zero_bytes_of(uint32_t x)
-{
-    uint32_t t = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
-    t = ~(t | x | 0x7f7f7f7fu);
-    return (uint32_t)__popc(t);
-}
-__device__ __forceinline__ uint32_t clamp255x2(uint32_t v)
-{
-    kv_u16x2 a;
-    __builtin_memcpy(&a, &v, 4);
-    const kv_u16x2 lim = {255, 255};
-    a = __builtin_elementwise_min(a, lim);
-    uint32_t r;
-    __builtin_memcpy(&r, &a, 4);
-    return r;
-}
-
-__global__ __launch_bounds__(BIN_CW_THREADS) void k_bin_apply_w16(BinGeom g)
-{
-    constexpr uint32_t VEC = 4u, SB = BIN_SLICE_BITS_W, SLICE = 1u << SB, THREADS = BIN_CW_THREADS;
-    constexpr int MAXV = 4;
-    __shared__ __attribute__((aligned(16))) uint32_t acc[SLICE / 2];      // two 16-bit sums per word (the slow path uses the front half as bytes)
-    __shared__ uint32_t seg_cnt[BIN_MAX_SEG], vpre[BIN_MAX_SEG];
-    __shared__ uint32_t wsum[THREADS / 64];
-    __shared__ uint32_t total_vec_sh, flag_sh, fresh_sh, ovf_sh;
-    const int t = blockIdx.y;
-    const uint32_t slice = blockIdx.x;
-    if (slice >= g.nslices[t]) return;
-    const uint32_t c = slice / (uint32_t)g.F, fidx = slice % (uint32_t)g.F;
-    const uint64_t stream = ((uint64_t)t * g.C + c) * g.F + fidx;
-    const uint64_t bin0 = (uint64_t)slice << SB;
-    const uint64_t left = g.tsize[t] - bin0, nb = left < SLICE ? left : SLICE;
-    const uint32_t nvec = (uint32_t)((nb + 15) / 16);
-    uint4 *tab = (uint4 *)(g.ttab[t] + bin0);
-    uint4 *a4 = (uint4 *)acc;
-    const uint32_t *items = (const uint32_t *)g.gbuf2 + stream * g.nwgB * g.cap2;
-    const uint32_t *counts = g.gcnt2 + stream * g.nwgB;
-    uint32_t zeros_before = 0, zeros_after = 0;
-    {
-        uint32_t myc = 0;
-        if (threadIdx.x < g.nwgB) myc = counts[threadIdx.x];
-        unsigned long long flag = 0;
-        if (threadIdx.x == THREADS - 1) flag = g.ctr[1];          // overflow flag: leave the tables untouched for the fallback
-        if (!g.zero_tables) {
-            for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) {
-                const uint4 q = tab[j];
-                if (t == 0) zeros_before += zero_bytes_of(q.x) + zero_bytes_of(q.y) + zero_bytes_of(q.z) + zero_bytes_of(q.w);
-                a4[2 * j] = make_uint4(__builtin_amdgcn_perm(0u, q.x, 0x0c010c00u), __builtin_amdgcn_perm(0u, q.x, 0x0c030c02u),
-                                       __builtin_amdgcn_perm(0u, q.y, 0x0c010c00u), __builtin_amdgcn_perm(0u, q.y, 0x0c030c02u));
-                a4[2 * j + 1] = make_uint4(__builtin_amdgcn_perm(0u, q.z, 0x0c010c00u), __builtin_amdgcn_perm(0u, q.z, 0x0c030c02u),
-                                           __builtin_amdgcn_perm(0u, q.w, 0x0c010c00u), __builtin_amdgcn_perm(0u, q.w, 0x0c030c02u));
-            }
-        }
-        if (threadIdx.x < g.nwgB) seg_cnt[threadIdx.x] = myc;
-        const uint32_t myv = (myc + VEC - 1) / VEC;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        uint32_t incl = myv;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        if (threadIdx.x == THREADS - 1) { flag_sh = flag != 0 ? 1u : 0u; fresh_sh = 0; ovf_sh = (g.dbg & 64u) ? 1u : 0u; }      // KV_BIN_DEBUG=64: every slice the slow way (tests)
-        __syncthreads();
-        uint32_t before = 0;
-        for (int w = 0; w < wave; ++w) before += wsum[w];
-        if (threadIdx.x < g.nwgB) vpre[threadIdx.x] = before + incl - myv;
-        if (threadIdx.x == THREADS - 1) total_vec_sh = before + incl;
-        __syncthreads();
-    }
-    if (flag_sh) return;
-    const uint32_t total_vec = total_vec_sh;
-    if (total_vec == 0) {                                          // untouched slice: no table traffic at all ...
-        if (g.zero_tables)                                         // ... unless this pass is also the table's zeroing
-            for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) tab[j] = make_uint4(0, 0, 0, 0);
-        return;
-    }
-    struct Vec { uint4 q; uint32_t n; };
-    auto fetch = [&](uint32_t v) {
-        Vec r;
-        r.q = make_uint4(0, 0, 0, 0); r.n = 0;
-        if (v >= total_vec) return r;
-        uint32_t lo = 0, hi = g.nwgB;      // largest segment with vpre[seg] <= v (empty segments share their successor's prefix)
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (vpre[mid] <= v) lo = mid; else hi = mid;
-        }
-        const uint32_t j0 = (v - vpre[lo]) * VEC;
-        r.n = min(VEC, seg_cnt[lo] - j0);
-        r.q = *(const uint4 *)(items + (uint64_t)lo * g.cap2 + j0);
-        return r;
-    };
-    uint32_t ovf = 0;
-    auto add4 = [&](const Vec &v) {
-        const uint32_t w[4] = {v.q.x, v.q.y, v.q.z, v.q.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if ((uint32_t)e >= v.n) continue;                      // (absent items stay away from the LDS: they would all meet on one word)
-            const uint32_t off = w[e] & 0xffffu, add = w[e] >> 16, sh = (off & 1u) << 4;
-            const uint32_t old = atomicAdd(&acc[off >> 1], add << sh);
-            ovf |= (((old >> sh) & 0xffffu) + add) >> 16;
-        }
-    };
-    Vec first[MAXV];
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) first[i] = fetch(threadIdx.x + (uint32_t)i * THREADS);
-    if (g.zero_tables) {
-        for (uint32_t j = threadIdx.x; j < 2 * nvec; j += THREADS) a4[j] = make_uint4(0, 0, 0, 0);
-        if (t == 0) for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) zeros_before += 16;
-    }
-    __syncthreads();
-    if (!ovf_sh) {
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) add4(first[i]);
-        if (total_vec > (uint32_t)MAXV * THREADS) {
-            const uint32_t v_start = (uint32_t)MAXV * THREADS + threadIdx.x;
-            Vec v0 = fetch(v_start), v1 = fetch(v_start + THREADS);
-            for (uint32_t v = v_start; v < total_vec; v += THREADS) {
-                const Vec v2 = fetch(v + 2 * THREADS);
-                add4(v0);
-                v0 = v1; v1 = v2;
-            }
-        }
-        if (ovf) ovf_sh = 1;
-    }
-    __syncthreads();
-    uint32_t fresh = 0;
-    if (ovf_sh) {
-        // a sum passed 16 bits (or the test switch is on): the slice again, byte counters and saturating compare-and-swaps (k_bin_apply's way)
-        __syncthreads();
-        uint32_t *lds = acc;
-        uint4 *l4 = (uint4 *)lds;
-        for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) l4[j] = g.zero_tables ? make_uint4(0, 0, 0, 0) : tab[j];
-        __syncthreads();
-        for (uint32_t v = threadIdx.x; v < total_vec; v += THREADS) {
-            const Vec x = fetch(v);
-            const uint32_t w[4] = {x.q.x, x.q.y, x.q.z, x.q.w};
-            if (x.n) fresh += lds_addw4<ST_BYTE>(lds, w, x.n);
-        }
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) tab[j] = l4[j];
-    } else {
-        for (uint32_t j = threadIdx.x; j < nvec; j += THREADS) {
-            const uint4 lo = a4[2 * j], hi = a4[2 * j + 1];
-            uint4 q;
-            q.x = __builtin_amdgcn_perm(clamp255x2(lo.y), clamp255x2(lo.x), 0x06040200u);
-            q.y = __builtin_amdgcn_perm(clamp255x2(lo.w), clamp255x2(lo.z), 0x06040200u);
-            q.z = __builtin_amdgcn_perm(clamp255x2(hi.y), clamp255x2(hi.x), 0x06040200u);
-            q.w = __builtin_amdgcn_perm(clamp255x2(hi.w), clamp255x2(hi.z), 0x06040200u);
-            if (t == 0) zeros_after += zero_bytes_of(q.x) + zero_bytes_of(q.y) + zero_bytes_of(q.z) + zero_bytes_of(q.w);
-            tab[j] = q;
-        }
-        fresh = zeros_before - zeros_after;                        // (per thread this may wrap; the sum over the workgroup does not)
-    }
-    // table 0's newly occupied bins: ONE update of the device-wide counter per workgroup
-    if (t == 0) {
-        const uint32_t tot = (uint32_t)wave_sum_u64((uint64_t)fresh) ;
-        if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&fresh_sh, tot);
-    }
-    __syncthreads();
-    if (t == 0 && threadIdx.x == 0 && fresh_sh) atomicAdd(&g.ctr[3], (unsigned long long)fresh_sh);
-}
-
 // saturating add of `weight` to one bin with global atomics; true if the bin was zero before
 __device__ __forceinline__ bool table_add_bin(const SketchDev *s, int t, uint64_t bin, uint32_t weight)
 {
@@ -1282,10 +1109,7 @@ int kv_bin_finish(kv_sketch *s, BinPlan &plan, bool added_from_ctr, uint64_t n_a
             else if (s->h.storage == ST_NIBBLE) KV_LAUNCH_APPLY(ST_NIBBLE, W_, SB_); \
             else KV_LAUNCH_APPLY(ST_BIT, W_, SB_);                                 \
         } while (0)
-        // byte counters: sums first, saturation once (k_bin_apply_w16; KV_BIN_APPLY16=0 keeps the compare-and-swap kernel)
-        const bool sums16 = plan.weighted && g.sbits == BIN_SLICE_BITS_W && s->h.storage == ST_BYTE && !(getenv("KV_BIN_APPLY16") && atoi(getenv("KV_BIN_APPLY16")) == 0);
-        if (sums16) hipLaunchKernelGGL(k_bin_apply_w16, gridC, dim3(BIN_CW_THREADS), 0, st, g);
-        else if (plan.weighted && g.sbits == BIN_SLICE_BITS_W) KV_LAUNCH_APPLY_ST(true, BIN_SLICE_BITS_W);
+        if (plan.weighted && g.sbits == BIN_SLICE_BITS_W) KV_LAUNCH_APPLY_ST(true, BIN_SLICE_BITS_W);
         else if (plan.weighted) KV_LAUNCH_APPLY_ST(true, BIN_SLICE_BITS);
         else KV_LAUNCH_APPLY_ST(false, BIN_SLICE_BITS);
 #undef KV_LAUNCH_APPLY_ST

@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 KNOBS = ('KV_COUNT_PATH', 'KV_NOVEL_PATH', 'KV_SKM_BUCKET_KMERS', 'KV_SKM_CAP_PCT', 'KV_SKM_LOOSE_CAP', 'KV_SKM_NO_REUSE', 'KV_SKM_FORCE_LOOSE', 'KV_SKM_DL', 'KV_SKM_ANY_K',
-         'KV_BIN_2BIT', 'KV_NOVEL_2BIT', 'KV_NOVEL_BITS', 'KV_BIN_APPLY16', 'KV_BIN_DEBUG')
+         'KV_BIN_2BIT', 'KV_NOVEL_2BIT', 'KV_NOVEL_BITS')
 
 
 def launches(name):
@@ -174,35 +174,6 @@ def test_skm_skew_saturation_and_overflow_paths(hk, ok, skm):
     assert n_dev == n_ref
     assert_same_tables(dev, ref)
     assert stage_a() + launches('k_consume') >= 1      # the fallback ran
-
-
-@pytest.mark.parametrize('tablesize', [1.5e6, 3000])
-def test_weighted_items_on_byte_counters_as_sums_first_equal_the_compare_and_swap_way(hk, ok, skm, tablesize):
-    """k_bin_apply_w16 widens a slice to 16-bit sums, adds the weighted items with plain atomic adds and saturates once on the way back;
-    a workgroup whose sum passes 16 bits does its slice again with saturating compare-and-swaps.  Three ways to the same bytes and the
-    same n_occupied, all equal to the oracle's: the default, every slice the slow way (KV_BIN_DEBUG=64), the kernel it replaced
-    (KV_BIN_APPLY16=0) -- on a sketch of ordinary size, and on one of 3000 bins where hundreds of distinct k-mers share every bin and
-    the sums do pass 16 bits by themselves"""
-    base = trio_reads(100000, 30000, 27)['proband']
-    reads = base + ['A' * 100] * 700 + [base[0]] * 300
-    os.environ['KV_SKM_BUCKET_KMERS'] = '4096'
-    for knobs in ({}, {'KV_BIN_DEBUG': '64'}, {'KV_BIN_APPLY16': '0'}):
-        os.environ.update(knobs)
-        try:
-            before = launches('k_bin_apply_w')
-            dev, ref, n_dev, n_ref = count_both(hk, ok, 'Counttable', 31, tablesize, reads)
-            assert launches('k_bin_apply_w') == before + 1 and launches('k_skm_count') >= 1
-            assert n_dev == n_ref
-            assert_same_tables(dev, ref)
-            # a second batch on top of the first: the sums start from the counters that are there
-            more = trio_reads(100000, 9000, 28)['proband']
-            dev.consume_batch(hk.ReadBatch(more))
-            bases, offs = ok.concat_reads(more)
-            ok.consume_reads(ref, bases, offs, len(more))
-            assert_same_tables(dev, ref)
-        finally:
-            for key in knobs:
-                os.environ.pop(key, None)
 
 
 def test_skm_band_and_mask(hk, ok, skm):
