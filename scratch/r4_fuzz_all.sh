@@ -3,7 +3,7 @@
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 cd $REPO
 python3 -c "import __graft_entry__ as g; g.build()" >/dev/null 2>&1
-for spec in "fuzz_parity 160 401" "fuzz_list 160 402" "fuzz_shard 40 403" "fuzz_ingest 60 404" "fuzz_host 50 405" "fuzz_gunzip 80 406" "fuzz_kmer2bit 300 407"; do
+for spec in "fuzz_parity ${FUZZ_SCALE:-1}60 ${FUZZ_SEED:-4}01" "fuzz_list ${FUZZ_SCALE:-1}60 ${FUZZ_SEED:-4}02" "fuzz_shard ${FUZZ_SCALE:-}40 ${FUZZ_SEED:-4}03" "fuzz_ingest ${FUZZ_SCALE:-}60 ${FUZZ_SEED:-4}04" "fuzz_host ${FUZZ_SCALE:-}50 ${FUZZ_SEED:-4}05" "fuzz_gunzip ${FUZZ_SCALE:-}80 ${FUZZ_SEED:-4}06" "fuzz_kmer2bit ${FUZZ_SCALE:-3}00 ${FUZZ_SEED:-4}07"; do
   set -- $spec
   echo "== $1 ($2 trials, seed $3)"
   timeout 1500 python3 scratch/$1.py $2 $3 2>&1 | tail -3
