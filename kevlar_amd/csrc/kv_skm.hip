@@ -668,22 +668,32 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split_sorted(SkmGeom sg)
     const uint32_t fper = (F2 + SKM_THREADS2 - 1) / SKM_THREADS2;     // buckets per thread in the scan (1 or 2)
     uint64_t *const out = sg.seg2 + ((uint64_t)c * F2 * sg.nwg2 + blockIdx.x) * sg.cap2 * RECW;      // + fine * nwg2 * cap2 * RECW
     const uint64_t fstride = (uint64_t)sg.nwg2 * sg.cap2 * RECW;
+    // the records of the NEXT chunk are requested before this chunk is ranked, laid out and stored: a workgroup's chunk used to begin
+    // with a round trip to HBM that nothing covered (two workgroups per CU, five barriers per chunk)
+    uint64_t nh[PER], n0[PER], n1[PER], n2[PER];
+    auto request = [&](uint32_t c0) {
+        const uint32_t n = c0 < total ? min(SKM_S2_CHUNK, total - c0) : 0u;
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            const uint32_t i = r * SKM_THREADS2 + threadIdx.x;
+            nh[r] = 0; n0[r] = 0; n1[r] = 0; n2[r] = 0;
+            if (i < n) {
+                const uint32_t gi = c0 + i, si = skm_search(spre, nmine, gi);
+                const uint32_t seg = blockIdx.x + si * sg.nwg2;
+                const uint64_t *rec = sg.seg1 + (skm_seg1_first(sg, skm_seg1_slot(sg, c, seg)) + (gi - spre[si])) * (uint64_t)RECW;
+                nh[r] = rec[0]; n0[r] = rec[1]; n1[r] = rec[2];
+                if (RECW == 4) n2[r] = rec[3];
+            }
+        }
+    };
+    request(0);
     for (uint32_t c0 = 0; c0 < total; c0 += SKM_S2_CHUNK) {
         const uint32_t n = min(SKM_S2_CHUNK, total - c0);
         uint64_t hdr[PER], w0[PER], w1[PER], w2[PER];
         uint32_t rank[PER];
 #pragma unroll
-        for (uint32_t r = 0; r < PER; ++r) {
-            const uint32_t i = r * SKM_THREADS2 + threadIdx.x;
-            hdr[r] = 0; w0[r] = 0; w1[r] = 0; w2[r] = 0; rank[r] = 0;
-            if (i < n) {
-                const uint32_t gi = c0 + i, si = skm_search(spre, nmine, gi);
-                const uint32_t seg = blockIdx.x + si * sg.nwg2;
-                const uint64_t *rec = sg.seg1 + (skm_seg1_first(sg, skm_seg1_slot(sg, c, seg)) + (gi - spre[si])) * (uint64_t)RECW;
-                hdr[r] = rec[0]; w0[r] = rec[1]; w1[r] = rec[2];
-                if (RECW == 4) w2[r] = rec[3];
-            }
-        }
+        for (uint32_t r = 0; r < PER; ++r) { hdr[r] = nh[r]; w0[r] = n0[r]; w1[r] = n1[r]; w2[r] = n2[r]; rank[r] = 0; }
+        request(c0 + SKM_S2_CHUNK);
 #pragma unroll
         for (uint32_t r = 0; r < PER; ++r)
             if (r * SKM_THREADS2 + threadIdx.x < n) rank[r] = atomicAdd(&hist[skm_hdr_fine(hdr[r])], 1u);
