@@ -452,12 +452,29 @@ def main():
             order = list(controls) + [names[0]]
         else:
             order = list(names)         # the case sample travels as (hash, tag) pairs, counted and scanned by the owners
-        pending = begin(order[0])
-        for i, n in enumerate(order):
-            nn = order[i + 1] if i + 1 < len(order) else None
-            nxt = begin(nn) if nn else None
-            kmers += run.finish(pending, sketches[n], keep_for_scan=(n == names[0]))
-            pending = nxt
+        if by_minimizer:
+            # three collectives per sample -- records to the owners of their minimizer buckets, pairs to the band owners, in between the
+            # owner's combine -- interleaved so that a sample's records travel while the next sample's shard is cut, and its pairs
+            # while the next sample's records are combined (RCCL runs on its own stream; every rank keeps this order)
+            def cut(n_):
+                return run.cut_minimizer(batches[n_][0], bounds[n_][0], n_reads, L)
+            cuts = {0: cut(order[0])}
+            flying = None
+            for i, n in enumerate(order):
+                if i + 1 < len(order):
+                    cuts[i + 1] = cut(order[i + 1])
+                ex = run.combine_minimizer(cuts.pop(i))
+                if flying is not None:
+                    kmers += run.finish(flying[0], sketches[flying[1]], keep_for_scan=(flying[1] == names[0]))
+                flying = (ex, n)
+            kmers += run.finish(flying[0], sketches[flying[1]], keep_for_scan=(flying[1] == names[0]))
+        else:
+            pending = begin(order[0])
+            for i, n in enumerate(order):
+                nn = order[i + 1] if i + 1 < len(order) else None
+                nxt = begin(nn) if nn else None
+                kmers += run.finish(pending, sketches[n], keep_for_scan=(n == names[0]))
+                pending = nxt
         t_b = time.perf_counter()
         cases, ctrls = [sketches['proband']], [sketches[n] for n in controls]
         if distinct:

@@ -122,6 +122,26 @@ def exchange_slabs(send, in_splits, out_splits, group=None, staged=False):
     return recv
 
 
+def exchange_slabs_async(send, in_splits, out_splits, group=None, staged=False):
+    """exchange_slabs that returns while the slabs travel (RCCL; the staged form has delivered when it returns): wait() on the
+    handle gives what arrived.  `send` must stay untouched until then."""
+    if staged:
+        return _Exchange(None, exchange_slabs(send, in_splits, out_splits, group, True), None, None)
+    recv = torch.empty(sum(out_splits), dtype=send.dtype, device=send.device)
+    SENT['bytes'] += (sum(in_splits) - in_splits[dist.get_rank(group)]) * send.element_size()
+    work = dist.all_to_all_single(recv, send, list(out_splits), list(in_splits), group=group, async_op=True)
+    return _Exchange(work, recv, None, send)
+
+
+class _Cut(object):
+    """A sample whose shard is cut and whose records are on their way to the owners of their minimizer buckets
+    (ShardedTrio.cut_minimizer); combine_minimizer() takes it from there.  fallback: the sample travels as `distinct`
+    pairs instead (a rank declined) and this is that exchange."""
+
+    def __init__(self, plan=None, got_cnt=None, records=None, fallback=None, batch=None, base=0):
+        self.plan, self.got_cnt, self.records, self.fallback, self.batch, self.base = plan, got_cnt, records, fallback, batch, base
+
+
 def gather_rows(rows, n_valid, fill, group=None, staged=False):
     """All-gather of each rank's first n_valid rows, padded with `fill` to the longest; returns
     (gathered [world * longest, ...], total valid)."""
@@ -184,7 +204,14 @@ class ShardedTrio(object):
         rank combines every occurrence of a k-mer -- from whichever shard -- at the sample's full coverage (kv_mex_route),
         and the (hash, occurrences) pairs go on to the band owners exactly as start(distinct=True) sends them.  A shard of
         1/8 of the reads has little to combine on its own (49 % of its k-mers are distinct against 20 % of the sample's); this
-        way a rank hashes 1/N of the sample's DISTINCT k-mers."""
+        way a rank hashes 1/N of the sample's DISTINCT k-mers.  = combine_minimizer(cut_minimizer(...)); callers with several
+        samples interleave the two halves so that one sample's records travel while the next one's shard is cut."""
+        return self.combine_minimizer(self.cut_minimizer(batch, read_index_base, n_reads_global, read_len))
+
+    def cut_minimizer(self, batch, read_index_base, n_reads_global, read_len):
+        """First half of start_minimizer(): cut the shard, pack what was cut, tell every owner how much is coming (the slab of
+        segment counts: blocking, small) and START the all-to-all of the records.  Returns a _Cut for combine_minimizer().
+        Every rank calls the halves of every sample in the same order (they are collectives)."""
         t0 = time.perf_counter()
         from kevlar_amd._lib import KvCapacityError
         forced = os.environ.get('KV_MEX_TEST_DECLINE', '')          # tests: 'emit:RANK' / 'route:RANK' makes that rank decline there
@@ -219,10 +246,26 @@ class ShardedTrio(object):
             del seg, cnt, got_cnt
             self.fallbacks = getattr(self, 'fallbacks', 0) + 1
             self.timing['route'] += time.perf_counter() - t0
-            return self.start(batch, read_index_base, False, distinct=True)
+            return _Cut(fallback=self.start(batch, read_index_base, False, distinct=True))
         from_src = [int(v) for v in summary[:self.world]]
-        got_seg = exchange_slabs(packed[:sum(per_dest) * recw], [n * recw for n in per_dest], [n * recw for n in from_src], self.group, self.staged)
-        del seg, cnt, packed
+        records = exchange_slabs_async(packed[:sum(per_dest) * recw], [n * recw for n in per_dest], [n * recw for n in from_src], self.group, self.staged)
+        records.packed = packed                             # (the view above is what travels: the buffer stays until wait())
+        del seg, cnt
+        self.timing['route'] += t1 - t0
+        self.timing['exchange'] += time.perf_counter() - t1
+        return _Cut(plan, got_cnt, records, None, batch, read_index_base)
+
+    def combine_minimizer(self, cut):
+        """Second half of start_minimizer(): wait for the records, combine what the N shards hold of this rank's buckets and start
+        the exchange of the (hash, occurrences) pairs; returns the handle finish() takes."""
+        if cut.fallback is not None:
+            return cut.fallback
+        from kevlar_amd._lib import KvCapacityError
+        forced = os.environ.get('KV_MEX_TEST_DECLINE', '')
+        plan, got_cnt = cut.plan, cut.got_cnt
+        t1 = time.perf_counter()
+        got_seg = cut.records.wait()
+        cut.records = None
         t2 = time.perf_counter()
         share = int(plan.n_kmers_global) // self.world
         cap = share + share // 4 + (1 << 20)
@@ -234,18 +277,19 @@ class ShardedTrio(object):
             except KvCapacityError:                         # more k-mers in this rank's buckets than its pair buffer holds: bucket skew
                 counts = None
         del got_seg, got_cnt
+        cut.got_cnt = None
         t3 = time.perf_counter()
         try:
             ex = exchange_rows_async(send, counts, self.group, self.staged)      # counts None: this rank declines, inside the size exchange
         except PeerDeclined:
             self._send[2].append(send)
             self.fallbacks = getattr(self, 'fallbacks', 0) + 1
-            self.timing['route'] += (t1 - t0) + (t3 - t2)
+            self.timing['route'] += t3 - t2
             self.timing['exchange'] += (t2 - t1) + (time.perf_counter() - t3)
-            return self.start(batch, read_index_base, False, distinct=True)
+            return self.start(cut.batch, cut.base, False, distinct=True)
         ex.send_buffer = send
         ex.weighted = True
-        self.timing['route'] += (t1 - t0) + (t3 - t2)
+        self.timing['route'] += t3 - t2
         self.timing['exchange'] += (t2 - t1) + (time.perf_counter() - t3)
         return ex
 

@@ -49,3 +49,17 @@ def test_self_launch_runs_config_1_on_two_ranks_sharing_the_gpu():
     assert out['selfcheck']['replay_matches']
     assert out['selfcheck']['mask_allreduce_equals_gathered_hits']       # north_star's all-reduce of the per-band bit masks
     assert set(out['phases']['max_over_ranks']) >= {'count', 'scan', 'gather'}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ranks,items', [(2, 'minimizer'), (3, 'minimizer'), (3, 'distinct')])
+def test_exchange_layout_with_its_samples_interleaved_equals_the_banded_replay(ranks, items):
+    """bench.py --multi exchange: a sample's records travel while the next sample's shard is cut, its pairs while the next sample's
+    records are combined (ShardedTrio.cut_minimizer / combine_minimizer); the merged hits must equal rank 0's replay of the bands"""
+    res = run_bench('--gpus', str(ranks), '--backend', 'gloo', '--workload', 'cfg1', '--steps', '2', '--warmup', '1',
+                    '--no-cpu-baseline', '--no-e2e', '--multi', 'exchange', '--exchange-items', items)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = last_json(res.stdout)
+    assert out['n_gpus'] == ranks and out['selfcheck']['ranks_seen'] == list(range(ranks))
+    assert out['selfcheck']['replay_matches']
+    assert 'exchanged by band' in out['config']['parallelism']
