@@ -118,7 +118,8 @@ def exchange_slabs(send, in_splits, out_splits, group=None, staged=False):
             torch.cuda.synchronize()
     else:
         dist.all_to_all_single(recv, send, list(out_splits), list(in_splits), group=group)
-        torch.cuda.current_stream().synchronize()
+        if recv.is_cuda:
+            torch.cuda.current_stream().synchronize()
     return recv
 
 

@@ -86,6 +86,21 @@ def worker(rank, world, port, result_file):
         assert raised
     recv2, recv_counts2 = shardrun.exchange_rows(send, counts, staged=True)       # and the next exchange is in step again
     assert recv_counts2 == recv_counts and torch.equal(recv2, recv)
+    # (5) slabs cut at split points every rank knows (the records of the minimizer layout): source r sends (r + 1) * (d + 1) words
+    # to destination d; blocking, asynchronous (two in flight, waited for in the other order) and host-staged give the same slabs
+    def slab(src, dst, salt):
+        return [1000 * src + 10 * dst + salt + j for j in range((src + 1) * (dst + 1))]
+    in_splits = [(rank + 1) * (d + 1) for d in range(world)]
+    out_splits = [(src + 1) * (rank + 1) for src in range(world)]
+    for staged in (True, False):
+        send_a = torch.tensor([v for d in range(world) for v in slab(rank, d, 1)], dtype=torch.int64)
+        send_b = torch.tensor([v for d in range(world) for v in slab(rank, d, 2)], dtype=torch.int64)
+        want_a = [v for src in range(world) for v in slab(src, rank, 1)]
+        want_b = [v for src in range(world) for v in slab(src, rank, 2)]
+        assert shardrun.exchange_slabs(send_a, in_splits, out_splits, staged=staged).tolist() == want_a
+        first = shardrun.exchange_slabs_async(send_a, in_splits, out_splits, staged=staged)
+        second = shardrun.exchange_slabs_async(send_b, in_splits, out_splits, staged=staged)
+        assert second.wait().tolist() == want_b and first.wait().tolist() == want_a
     dist.barrier()
     dist.destroy_process_group()
     with open(result_file + str(rank), 'w') as fh:
