@@ -91,6 +91,8 @@ def parse_args():
                         'k-mer, the case sample as (hash, tag) pairs scanned by the band owners; auto = distinct up to 4 GPUs '
                         '(measured per-rank compute, scratch/exchange_rank_cost.py: 29.6 / 20.8 / 13.8 ms at 2 / 4 / 8 ranks against '
                         '43.0 / 21.4 / 11.3 ms plain)')
+    p.add_argument('--exchange-scan', default='owner', choices=['owner', 'shard'],
+                   help='minimizer layout: who answers the scan -- the owners of the minimizer buckets from their combined buckets, or every rank by hashing its shard again')
     p.add_argument('--multi', default='auto', choices=['auto', 'exchange', 'banded'],
                    help='N>1: exchange = shard the reads, hash once, all-to-all the hashes by band (kevlar_amd/shardrun.py); '
                         'banded = every rank streams all reads and keeps its band; auto = exchange from 4 GPUs up')
@@ -463,7 +465,7 @@ def main():
             for i, n in enumerate(order):
                 if i + 1 < len(order):
                     cuts[i + 1] = cut(order[i + 1])
-                ex = run.combine_minimizer(cuts.pop(i))
+                ex = run.combine_minimizer(cuts.pop(i), keep_scan=(n == names[0] and args.exchange_scan == 'owner'))
                 if flying is not None:
                     kmers += run.finish(flying[0], sketches[flying[1]], keep_for_scan=(flying[1] == names[0]))
                 flying = (ex, n)
@@ -477,7 +479,11 @@ def main():
                 pending = nxt
         t_b = time.perf_counter()
         cases, ctrls = [sketches['proband']], [sketches[n] for n in controls]
-        if distinct:
+        if by_minimizer and args.exchange_scan == 'owner':
+            # the owners of the minimizer buckets answer (they hold every occurrence with its position, and its hash); a sample that
+            # fell back to `distinct` pairs is scanned shard by shard, decided collectively inside
+            r, o, a = run.scan_minimizer(cases, ctrls, args.case_min, args.ctrl_max, batches[names[0]][0], bounds[names[0]][0])
+        elif distinct:
             r, o, a = run.scan_distinct(cases, ctrls, args.case_min, args.ctrl_max, batches[names[0]][0], bounds[names[0]][0])
         else:
             r, o, a = run.scan(cases, ctrls, args.case_min, args.ctrl_max)

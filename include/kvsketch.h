@@ -388,8 +388,20 @@ int kv_mex_emit(const kv_reads *shard, const kv_mex_plan *plan, uint64_t read_ba
  * records_per_dest[d] says how many records rank d gets; the counts slab travels whole, so the receiver (compact != 0 in
  * kv_mex_route) knows where every segment of every source starts.                                                        */
 int kv_mex_pack(const kv_mex_plan *plan, const void *d_seg, const void *d_cnt, void *d_out, uint64_t *records_per_dest);
+/* keep_scan != 0 (the case sample): the combined buckets and key + hash of every distinct k-mer stay on this stream until the next
+ * call that buckets anything, for kv_mex_scan_set.                                                                          */
 int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_recv_seg, const void *d_recv_cnt, int n_src, int compact,
-                 void *d_out, uint64_t cap_items, uint64_t *counts_out, uint64_t *n_kmers_in);
+                 int keep_scan, void *d_out, uint64_t cap_items, uint64_t *counts_out, uint64_t *n_kmers_in);
+/* kv_mex_scan_set: the scan (kevlar/novel.py:123-169) answered by the owner of the minimizer buckets.  d_hashes[n] / d_abund[n * S]:
+ * every band owner's kv_novel_scan_distinct output, all-gathered (entries ~0 are padding).  Every occurrence of a member of that
+ * set among this rank's buckets leaves as d_hit_tags[i] = read << 16 | offset (global read index) with its S abundances, in
+ * arbitrary order: gather them and sort with kv_hits_from_tagged.  Reads the scan skips (bytes outside ACGT) are NOT left out:
+ * the caller drops their hits.  KV_ERR_CAPACITY: the state kv_mex_route(keep_scan) leaves is not there (or does not suffice);
+ * scan the shard against the set instead (kv_novel_scan_set).                                                                */
+int kv_mex_scan_set(int kind, int ksize, int nsamples, const void *d_hashes, const void *d_abund, uint64_t n,
+                    void *d_hit_tags, void *d_hit_abund, uint64_t hit_cap, uint64_t *n_hits);
+/* flags[r] bit 0: read r holds a byte outside ACGT (counted with stand-in bases, skipped by the scan); host buffer of n_reads bytes */
+int kv_reads_flags(const kv_reads *reads, uint8_t *flags);
 /* kv_mex_emit_pack: kv_mex_emit and kv_mex_pack in one call and one stream synchronisation.  d_out holds out_cap_words u64 words;
  * *packed = 1: the filled part fitted and sits in d_out; 0: it did not (records_per_dest is right either way), nothing was
  * written to d_out and kv_mex_pack into a buffer of plan->seg_words words does it.                                          */

@@ -122,7 +122,9 @@ SIGNATURES = {
     'kv_mex_emit': (i32, [vp, vp, u64, vp, vp]),
     'kv_mex_pack': (i32, [vp, vp, vp, vp, u64p]),
     'kv_mex_emit_pack': (i32, [vp, vp, u64, vp, vp, vp, u64, u64p, ctypes.POINTER(ctypes.c_int)]),
-    'kv_mex_route': (i32, [vp, i32, vp, vp, i32, i32, vp, u64, u64p, u64p]),
+    'kv_mex_route': (i32, [vp, i32, vp, vp, i32, i32, i32, vp, u64, u64p, u64p]),
+    'kv_mex_scan_set': (i32, [i32, i32, i32, vp, vp, u64, vp, vp, u64, u64p]),
+    'kv_reads_flags': (i32, [vp, vp]),
     'kv_readgraph_components': (i32, [vp, i32, u32p, u32p, u64, u32p, u32, u32, u32, u32p, u64p]),
 }
 

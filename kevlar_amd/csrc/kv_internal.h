@@ -251,8 +251,10 @@ int kv_skm_route_distinct(const kv_reads *reads, int ksize, uint64_t n_kmers, in
 int kv_skm_mex_plan(int ksize, uint64_t n_reads_global, uint32_t read_len, int ndest, kv_mex_plan *plan);
 int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t read_base, uint64_t *d_seg, uint32_t *d_cnt,
                     uint64_t *d_out, uint64_t out_cap_words, uint64_t *records_per_dest, int *packed);
-int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_recv_seg, const uint32_t *d_recv_cnt, int n_src, int compact,
+int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_recv_seg, const uint32_t *d_recv_cnt, int n_src, int compact, int keep_scan,
                      int (*alloc)(void *ctx, uint32_t nwg, KvRouteSink *sink), int (*after)(void *ctx), void *ctx, uint64_t *n_kmers_in);
+struct NovelParams;
+int kv_skm_mex_scan_set(const NovelParams &p, int ksize, uint64_t *d_tags, uint8_t *d_abund, uint64_t cap, uint64_t *n_hits);
 int kv_skm_mex_pack(const kv_mex_plan *plan, const uint64_t *d_seg, const uint32_t *d_cnt, uint64_t *d_out, uint64_t *records_per_dest);
 
 // tile geometry of the hashing kernels

@@ -1021,17 +1021,14 @@ __global__ void k_set_insert(unsigned long long *keys, uint8_t *abund, uint64_t 
 // d_abund[n * nsamples] beside them -- every band owner's kv_novel_scan_distinct output, all-gathered; entries
 // ~0 are padding -- become a hash set, and every k-mer of `reads` (reads with non-ACGT skipped, as in kv_novel_scan)
 // whose hash is a member is a hit, reported with the abundances the set carries.  Hits leave in (read, offset) order.
-extern "C" int kv_novel_scan_set(const kv_reads *reads, int kind, int ksize, int nsamples, const void *d_hashes,
-                                 const void *d_abund, uint64_t n, kv_hits **out)
+namespace {
+// the gathered (hash, abundances) rows as a hash set in this stream's arena: p.set_keys / set_abund / set_mask
+int build_hit_set(NovelParams &p, int kind, int ksize, int nsamples, const void *d_hashes, const void *d_abund, uint64_t n, hipStream_t st)
 {
-    KV_REQUIRE(reads && out && nsamples >= 1 && nsamples <= KV_MAX_SAMPLES && ksize >= 1, KV_ERR_ARG, "kv_novel_scan_set: bad argument");
-    KV_REQUIRE(n == 0 || (d_hashes && d_abund), KV_ERR_ARG, "kv_novel_scan_set: null buffer");
-    NovelParams p;
     memset(&p, 0, sizeof(p));
     const int fam = kv_hashfam_of(kind);
     p.hp = make_hash_params(ksize, fam);
     p.ncase = nsamples;
-    hipStream_t st = kv_stream();
     ScanArenas *arenas;
     {
         std::lock_guard<std::mutex> lk(g_scan_arenas_mu);
@@ -1053,6 +1050,35 @@ extern "C" int kv_novel_scan_set(const kv_reads *reads, int kind, int ksize, int
         KV_HIP(hipGetLastError());
     }
     p.set_keys = keys; p.set_abund = abund; p.set_mask = slots - 1;
+    return KV_OK;
+}
+}  // namespace
+
+// The same answer from the owner of the minimizer buckets (minimizer-sharded exchange): after kv_mex_route(keep_scan) on this stream,
+// every occurrence of this rank's buckets whose hash is in the set leaves as (read << 16 | offset) with the S abundances the set
+// carries -- reads the scan must skip included: the caller drops them (kevlar/novel.py:134-139) -- in arbitrary order, for the
+// all-gather and kv_hits_from_tagged.  KV_ERR_CAPACITY: not available (see kv_skm_mex_scan_set); scan the shard instead.
+extern "C" int kv_mex_scan_set(int kind, int ksize, int nsamples, const void *d_hashes, const void *d_abund, uint64_t n,
+                               void *d_hit_tags, void *d_hit_abund, uint64_t hit_cap, uint64_t *n_hits)
+{
+    KV_REQUIRE(n_hits && nsamples >= 1 && nsamples <= KV_MAX_SAMPLES && ksize >= 1, KV_ERR_ARG, "kv_mex_scan_set: bad argument");
+    KV_REQUIRE((n == 0 || (d_hashes && d_abund)) && (hit_cap == 0 || (d_hit_tags && d_hit_abund)), KV_ERR_ARG, "kv_mex_scan_set: null buffer");
+    *n_hits = 0;
+    NovelParams p;
+    hipStream_t st = kv_stream();
+    { const int rc = build_hit_set(p, kind, ksize, nsamples, d_hashes, d_abund, n, st); if (rc != KV_OK) return rc; }
+    return kv_skm_mex_scan_set(p, ksize, (uint64_t *)d_hit_tags, (uint8_t *)d_hit_abund, hit_cap, n_hits);
+}
+
+extern "C" int kv_novel_scan_set(const kv_reads *reads, int kind, int ksize, int nsamples, const void *d_hashes,
+                                 const void *d_abund, uint64_t n, kv_hits **out)
+{
+    KV_REQUIRE(reads && out && nsamples >= 1 && nsamples <= KV_MAX_SAMPLES && ksize >= 1, KV_ERR_ARG, "kv_novel_scan_set: bad argument");
+    KV_REQUIRE(n == 0 || (d_hashes && d_abund), KV_ERR_ARG, "kv_novel_scan_set: null buffer");
+    NovelParams p;
+    const int fam = kv_hashfam_of(kind);
+    hipStream_t st = kv_stream();
+    { const int rc = build_hit_set(p, kind, ksize, nsamples, d_hashes, d_abund, n, st); if (rc != KV_OK) return rc; }
     uint64_t n_kmers = 0;
     kv_reads_num_kmers(reads, ksize, &n_kmers);
     // Membership is one read of a set that stays in the L2, so the test is nearly free and what is left is finding the hash of every

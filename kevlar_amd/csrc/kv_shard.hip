@@ -451,7 +451,7 @@ extern "C" int kv_mex_pack(const kv_mex_plan *plan, const void *d_seg, const voi
 }
 
 extern "C" int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_recv_seg, const void *d_recv_cnt, int n_src, int compact,
-                            void *d_out, uint64_t cap_items, uint64_t *counts_out, uint64_t *n_kmers_in)
+                            int keep_scan, void *d_out, uint64_t cap_items, uint64_t *counts_out, uint64_t *n_kmers_in)
 {
     KV_REQUIRE(plan && d_recv_seg && d_recv_cnt && d_out && counts_out && n_kmers_in, KV_ERR_ARG, "kv_mex_route: null argument");
     const int ndest = plan->ndest;
@@ -490,7 +490,7 @@ extern "C" int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_
         KV_HIP(e);
         return KV_OK;
     };
-    { const int rc = kv_skm_mex_route(plan, my_dest, (const uint64_t *)d_recv_seg, (const uint32_t *)d_recv_cnt, n_src, compact, alloc, after, &ctx, n_kmers_in); if (rc != KV_OK) return rc; }
+    { const int rc = kv_skm_mex_route(plan, my_dest, (const uint64_t *)d_recv_seg, (const uint32_t *)d_recv_cnt, n_src, compact, keep_scan, alloc, after, &ctx, n_kmers_in); if (rc != KV_OK) return rc; }
     // what has to fit is the pairs -- one per distinct k-mer, a fifth of the occurrences at sequencing coverage -- not the occurrences:
     // the sink's overflow list and the packing both bound what they write and count what they were asked to
     if (ctx.host) {
@@ -501,6 +501,16 @@ extern "C" int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_
         KV_REQUIRE(total <= cap_items, KV_ERR_CAPACITY, "kv_mex_route: %llu pairs for %llu k-mers that arrived, the output holds %llu",
                    (unsigned long long)total, (unsigned long long)*n_kmers_in, (unsigned long long)cap_items);
     }
+    return KV_OK;
+}
+
+extern "C" int kv_reads_flags(const kv_reads *reads, uint8_t *flags)
+{
+    KV_REQUIRE(reads && (flags || reads->n_reads == 0), KV_ERR_ARG, "kv_reads_flags: null argument");
+    if (reads->n_reads == 0) return KV_OK;
+    hipStream_t st = kv_stream();
+    KV_HIP(hipMemcpyAsync(flags, reads->d_flags, reads->n_reads, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
     return KV_OK;
 }
 

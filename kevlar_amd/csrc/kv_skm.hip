@@ -1230,6 +1230,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
     __shared__ uint32_t next_bucket;
     __shared__ uint32_t cur[SKM_ROUTE_MAX_DEST];
     __shared__ uint64_t lo[SKM_ROUTE_MAX_DEST];
+    __shared__ uint32_t dl_cur, dl_b0, dl_prev;         // distinct list (sg.dl_keys != NULL: the owner will answer the scan from it, kv_skm_mex_scan_set)
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
     uint32_t *lut = dyn, *scratch = dyn + 256;
     if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
@@ -1238,13 +1239,21 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
     uint64_t n_distinct = 0;
     skm_table_clear(tb);
     for (uint32_t i = threadIdx.x; i < TS; i += SKM_THREADS3) cnt[i] = 0;
-    if (threadIdx.x == 0) next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET;
+    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET; dl_cur = 0; dl_b0 = 0; dl_prev = 0xffffffffu; }
+    auto dl_close = [&]() {
+        if (sg.dl_keys && dl_prev != 0xffffffffu) {
+            sg.dl_bstart[dl_prev] = blockIdx.x * sg.dl_cap_wg + dl_b0;
+            sg.dl_bcount[dl_prev] = dl_cur - dl_b0;              // (a stretch that ran out is reported through ctr[9]: the whole list is then dropped)
+        }
+    };
     for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
         __syncthreads();
         const uint32_t b = next_bucket;
         if (b >= sg.n_buckets) break;
         __syncthreads();
         if (threadIdx.x == 0) {
+            dl_close();
+            dl_prev = b; dl_b0 = dl_cur;
             if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
             else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
             else next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET;
@@ -1263,10 +1272,29 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
             const uint32_t seen = cnt[slot];
             cnt[slot] = 0;
             n_distinct += 1;
-            skm_route_item(rs, lo, cur, skm_key_hash<KW>(c, lut, hp), seen);
+            const uint64_t h = skm_key_hash<KW>(c, lut, hp);
+            if (sg.dl_keys) {
+                const unsigned long long here = __ballot(true);
+                const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)here) - 1u;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&dl_cur, (uint32_t)__popcll(here));
+                base = (uint32_t)__shfl((int)base, (int)leader);
+                const uint32_t at = base + (uint32_t)__popcll(here & ((1ull << lane) - 1ull));
+                if (at < sg.dl_cap_wg) {
+                    const uint64_t e = (uint64_t)blockIdx.x * sg.dl_cap_wg + at;
+                    sg.dl_keys[e * KW] = c.w[0];
+                    if (KW == 2) sg.dl_keys[e * KW + (KW - 1)] = c.w[KW - 1];
+                    sg.dl_hash[e] = h;
+                }
+            }
+            skm_route_item(rs, lo, cur, h, seen);
         });
     }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        dl_close();
+        if (sg.dl_keys && dl_cur > sg.dl_cap_wg) atomicAdd(&sg.ctr[9], 1ull);
+    }
     if (threadIdx.x < (uint32_t)rs.ndest)
         rs.seg_count[(uint64_t)threadIdx.x * rs.nwg + blockIdx.x] = (uint32_t)min((uint64_t)cur[threadIdx.x], rs.seg_cap);
     n_distinct = wave_sum_u64(n_distinct);
@@ -1572,6 +1600,116 @@ __global__ __launch_bounds__(256) void k_skm_loose_novel(SkmGeom sg, ReadsDev rd
     }
 }
 
+// ---- the scan answered by the owner of the minimizer buckets (minimizer-sharded exchange, kv_skm_mex_scan_set) ----------------
+// After kv_skm_mex_route(keep_scan) this rank holds every occurrence of the k-mers of its buckets -- from whichever shard, with the
+// global (read, offset) of each in the record headers -- and key + hash of every distinct one (the distinct list k_skm_route left).
+// Once the band owners' verdicts have been gathered into the set of interesting hashes, the hits are these: per bucket, the list
+// entries that are members go into a small LDS table with their slot of the set; only if there are any is the bucket walked, and every
+// occurrence of a member leaves as (read << 16 | offset, the S abundances the set carries) -- the form kv_hits_from_tagged sorts.
+// Hits are staged in LDS and appended with one update of the device-wide counter per flush (that counter takes ~90 updates per
+// microsecond however they are issued); a bucket with more hits than the stage holds appends the rest one by one.
+struct SetHitSink {
+    unsigned long long *tags;
+    uint8_t *abund;
+    unsigned long long *count;
+    uint64_t cap;
+};
+__device__ __forceinline__ void set_hit_store(const NovelParams &p, const SetHitSink &out, uint64_t at, unsigned long long tag, uint64_t slot)
+{
+    if (at >= out.cap) return;
+    const int S = p.ncase + p.nctrl;
+    out.tags[at] = tag;
+    for (int c = 0; c < S; ++c) out.abund[at * (uint64_t)S + c] = p.set_abund[slot * (uint64_t)S + c];
+}
+#define SKM_HIT_STAGE 1024u
+template <int KW, int TSM>
+__global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_set_hits(SkmGeom sg, NovelParams p, SetHitSink out)
+{
+    __shared__ SkmTable<KW, TSM> itb;            // the bucket's members of the set
+    __shared__ uint32_t islot[TSM];              // their slots of the set
+    __shared__ unsigned long long htag[SKM_HIT_STAGE];
+    __shared__ uint32_t hslot[SKM_HIT_STAGE];
+    __shared__ uint32_t next_bucket, n_int, n_hit;
+    __shared__ unsigned long long flush_base;
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
+    uint32_t *scratch = dyn;
+    skm_table_clear(itb);
+    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET; n_int = 0; n_hit = 0; }
+    for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
+        __syncthreads();
+        const uint32_t b = next_bucket;
+        if (b >= sg.n_buckets) break;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
+            else if (taken + 1 >= sg.quota3) next_bucket = 0xffffffffu;
+            else next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET;
+        }
+        const uint32_t e0 = sg.dl_bstart[b], en = sg.dl_bcount[b];
+        for (uint32_t i = threadIdx.x; i < en; i += SKM_THREADS3) {
+            const uint64_t h = sg.dl_hash[e0 + i];
+            const uint64_t slot = set_find(p, h);
+            if (slot == KV_SET_NONE) continue;
+            SkmKey<KW> c;
+            c.w[0] = sg.dl_keys[(uint64_t)(e0 + i) * KW];
+            if (KW == 2) c.w[KW - 1] = sg.dl_keys[(uint64_t)(e0 + i) * KW + (KW - 1)];
+            const int at = skm_table_insert(itb, c);
+            if (at < 0) { sg.ctr[1] = 1; continue; }            // more members than the table takes: the caller scans the other way
+            islot[at] = (uint32_t)slot;
+            atomicAdd(&n_int, 1u);
+        }
+        __syncthreads();
+        if (n_int == 0) continue;
+        skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t pos) {
+            if (!skm_cacheable<KW>(c)) return false;
+            const int at = skm_table_find(itb, c);
+            if (at < 0) return false;
+            const uint64_t read = pos / sg.stride;
+            const unsigned long long tag = ((unsigned long long)read << 16) | (unsigned long long)(pos - read * sg.stride);
+            const uint32_t i = atomicAdd(&n_hit, 1u);
+            if (i < SKM_HIT_STAGE) { htag[i] = tag; hslot[i] = islot[at]; }
+            else set_hit_store(p, out, atomicAdd(out.count, 1ull), tag, islot[at]);
+            return false;
+        });
+        __syncthreads();
+        const uint32_t staged = min(n_hit, SKM_HIT_STAGE);
+        if (threadIdx.x == 0) flush_base = atomicAdd(out.count, (unsigned long long)staged);
+        skm_table_clear(itb);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < staged; i += SKM_THREADS3) set_hit_store(p, out, flush_base + i, htag[i], hslot[i]);
+        if (threadIdx.x == 0) { n_int = 0; n_hit = 0; }
+    }
+}
+
+// the occurrences that travelled alone (records of the loose list: one k-mer each from the combine, whole records from the split)
+template <int KW>
+__global__ __launch_bounds__(256) void k_skm_loose_set_hits(SkmGeom sg, NovelParams p, SetHitSink out)
+{
+    __shared__ uint32_t lut[256];
+    lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    __syncthreads();
+    unsigned long long n = sg.ctr[0];
+    if (n > sg.loose_cap) n = sg.loose_cap;
+    const int k = sg.k, recw = sg.recw;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t *rec = sg.loose + i * (uint64_t)recw;
+        uint64_t bw[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
+        const uint32_t nk = skm_hdr_n(rec[0]);
+        const uint64_t pos0 = skm_hdr_pos(rec[0]);
+        SkmKey<KW> fw = skm_first_kmer<KW>(bw, k);
+        SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
+        for (uint32_t j = 0; j < nk; ++j) {
+            if (j) skm_roll<KW>(fw, rc, skm_base_at(bw, j + (uint32_t)k - 1u), k);
+            const uint64_t slot = set_find(p, skm_key_hash<KW>(skm_canonical<KW>(fw, rc), lut, p.hp));
+            if (slot == KV_SET_NONE) continue;
+            const uint64_t pos = pos0 + j, read = pos / sg.stride;
+            set_hit_store(p, out, atomicAdd(out.count, 1ull), ((unsigned long long)read << 16) | (unsigned long long)(pos - read * sg.stride), slot);
+        }
+    }
+}
+
 __global__ void k_skm_forward_flag(const unsigned long long *skm_ctr, unsigned long long *bin_ctr)
 {
     if (skm_ctr[1] != 0) bin_ctr[1] = 1;
@@ -1617,6 +1755,7 @@ struct SkmIndex {
     uint32_t *dl_bstart = nullptr, *dl_bcount = nullptr;
     uint32_t dl_cap_wg = 0;
     bool dl_valid = false;
+    bool mex_scan_ready = false;     // the arena holds an owner's combined buckets with their distinct list (kv_skm_mex_route, keep_scan): kv_skm_mex_scan_set
     uint64_t builds = 0;             // batches bucketed on this stream so far
     KvArena bits;                    // NovelParams::case0_bits of the scan in flight
     std::mutex mu;
@@ -1855,6 +1994,7 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     SkmGeom &g = idx.g;
     memset(&g, 0, sizeof(g));
     idx.valid = false;
+    idx.mex_scan_ready = false;
     idx.dl_valid = false;
     idx.builds += 1;
     g.k = k;
@@ -2109,6 +2249,8 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     }
     if (rc != KV_OK) {
         idx.valid = false;
+        idx.mex_scan_ready = false;
+    idx.mex_scan_ready = false;
         if (getenv("KV_SKM_VERBOSE")) {
             unsigned long long sc[8] = {0}, bc[4] = {0};
             (void)hipMemcpy(sc, sg.ctr, sizeof(sc), hipMemcpyDeviceToHost);
@@ -2272,6 +2414,8 @@ int kv_skm_route_distinct(const kv_reads *reads, int ksize, uint64_t n_kmers, in
                 (unsigned long long)n_kmers, 100 * idx.distinct_hint, 100 * alone, sg.n_buckets);
     if (sctr[1] != 0) {
         idx.valid = false;
+        idx.mex_scan_ready = false;
+    idx.mex_scan_ready = false;
         kv_set_error("super-k-mer route: loose record list overflow (%llu records)", sctr[0]);
         return KV_ERR_CAPACITY;
     }
@@ -2333,6 +2477,7 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
     SkmIndex &idx = skm_index_for(st);
     std::lock_guard<std::mutex> lk(idx.mu);
     idx.valid = false;
+    idx.mex_scan_ready = false;
     SkmGeom &g = idx.g;
     skm_geom_k(g, plan->ksize);
     g.C1 = plan->C1; g.F2 = plan->F2; g.fbits = plan->fbits; g.n_buckets = g.C1 * g.F2;
@@ -2392,7 +2537,7 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
 
 // the records n_src ranks sent for this rank's Cl coarse buckets -> S2 -> every distinct k-mer once as a (hash, occurrences)
 // pair for its band's owner (the callback allocates the sink, as for kv_skm_route_distinct)
-int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_recv_seg, const uint32_t *d_recv_cnt, int n_src, int compact,
+int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_recv_seg, const uint32_t *d_recv_cnt, int n_src, int compact, int keep_scan,
                      int (*alloc)(void *ctx, uint32_t nwg, KvRouteSink *sink), int (*after)(void *ctx), void *ctx, uint64_t *n_kmers_in)
 {
     KV_REQUIRE(plan && my_dest >= 0 && my_dest < plan->ndest && n_src >= 1, KV_ERR_ARG, "kv_mex_route: bad argument");
@@ -2400,6 +2545,7 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     SkmIndex &idx = skm_index_for(st);
     std::lock_guard<std::mutex> lk(idx.mu);
     idx.valid = false;
+    idx.mex_scan_ready = false;
     SkmGeom &g = idx.g;
     skm_geom_k(g, plan->ksize);
     const uint32_t Cl = plan->c_lo[my_dest + 1] - plan->c_lo[my_dest];
@@ -2451,6 +2597,28 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     memset(&rs, 0, sizeof(rs));
     { const int rc = alloc(ctx, nwg3, &rs); if (rc != KV_OK) return rc; }
     const HashParams hp = make_hash_params(plan->ksize, HF_MURMUR);
+    // keep_scan (the case sample): key + hash of every distinct k-mer stay, bucket by bucket, and the buckets themselves stay where
+    // they are -- this rank will answer the scan for its buckets (kv_skm_mex_scan_set).  A stretch holds one and a half average shares
+    // of 0.45 distinct k-mers per occurrence; one that runs out drops the list (ctr[9]) and the scan goes the other way.
+    bool dl_new = false;
+    if (keep_scan) {
+        const uint64_t cap_wg = std::min<uint64_t>((uint64_t)((double)n_kmers_exp * 0.45 * 1.6 / nwg3) + 4096, 0xfffffff0ull / nwg3);
+        const size_t b_keys = kv_round_up(cap_wg * nwg3 * 8 * g.kw, 256), b_hash = kv_round_up(cap_wg * nwg3 * 8, 256);
+        const size_t b_idx = kv_round_up((uint64_t)g.n_buckets * 4, 256);
+        if (idx.dl.need(b_keys + b_hash + 2 * b_idx) == hipSuccess) {
+            unsigned char *dbase = (unsigned char *)idx.dl.p;
+            idx.dl_keys = (uint64_t *)dbase; dbase += b_keys;
+            idx.dl_hash = (uint64_t *)dbase; dbase += b_hash;
+            idx.dl_bstart = (uint32_t *)dbase; dbase += b_idx;
+            idx.dl_bcount = (uint32_t *)dbase;
+            idx.dl_cap_wg = (uint32_t)cap_wg;
+            KV_HIP(hipMemsetAsync(idx.dl_bstart, 0, 2 * b_idx, st));
+            g.dl_keys = idx.dl_keys; g.dl_hash = idx.dl_hash; g.dl_bstart = idx.dl_bstart; g.dl_bcount = idx.dl_bcount; g.dl_cap_wg = idx.dl_cap_wg;
+            dl_new = true;
+        } else {
+            (void)hipGetLastError();                    // no room: no list, the scan goes the other way
+        }
+    }
     {
         KvProfScope prof("k_skm_route");
         const size_t lds = (256 + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(g.sbw)) * 4;
@@ -2468,11 +2636,13 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     if (after) { const int rc = after(ctx); if (rc != KV_OK) return rc; }
     KvReadback back;
     hipError_t rb_err = hipSuccess;
-    const unsigned long long *sctr = back.add(g.ctr, 9, st, &rb_err);
+    const unsigned long long *sctr = back.add(g.ctr, 10, st, &rb_err);
     KV_HIP(rb_err);
     KV_HIP(back.wait(st));
     const unsigned long long arrived = sctr[8];
     *n_kmers_in = arrived;
+    idx.mex_scan_ready = dl_new && sctr[9] == 0 && sctr[1] == 0;
+    idx.k = plan->ksize;
     if (getenv("KV_SKM_VERBOSE"))
         fprintf(stderr, "[kv_skm] exchange owner: %llu k-mers arrived in %u buckets, %.1f%% distinct, %.2f%% outside the LDS tables\n",
                 arrived, g.n_buckets, arrived ? 100.0 * (double)sctr[7] / (double)arrived : 0.0,
@@ -2484,6 +2654,49 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     return KV_OK;
 }
 
+
+// The hits of this rank's minimizer buckets against the gathered set of interesting hashes (p.set_*): see k_skm_set_hits.  Needs the
+// state kv_skm_mex_route(keep_scan) left on this stream; KV_ERR_CAPACITY when it is not there (or a bucket holds more members than its
+// table takes, or the hits do not fit): the caller then scans its shard against the set (kv_novel_scan_set) as before.
+int kv_skm_mex_scan_set(const NovelParams &p, int ksize, uint64_t *d_tags, uint8_t *d_abund, uint64_t cap, uint64_t *n_hits)
+{
+    hipStream_t st = kv_stream();
+    SkmIndex &idx = skm_index_for(st);
+    std::lock_guard<std::mutex> lk(idx.mu);
+    if (!idx.mex_scan_ready || idx.k != ksize) {
+        kv_set_error("kv_mex_scan_set: no combined buckets with a distinct list on this stream (kv_mex_route with keep_scan, nothing bucketed since)");
+        return KV_ERR_CAPACITY;
+    }
+    SkmGeom sg = idx.g;
+    sg.dl_keys = idx.dl_keys; sg.dl_hash = idx.dl_hash; sg.dl_bstart = idx.dl_bstart; sg.dl_bcount = idx.dl_bcount; sg.dl_cap_wg = idx.dl_cap_wg;
+    KV_HIP(hipMemsetAsync(&sg.ctr[4], 0, 8, st));
+    KV_HIP(hipMemsetAsync(&sg.ctr[10], 0, 8, st));
+    SetHitSink out;
+    out.tags = (unsigned long long *)d_tags; out.abund = d_abund; out.count = &sg.ctr[10]; out.cap = cap;
+    const uint32_t nwg3 = skm_nwg3(sg);
+    {
+        KvProfScope prof("k_skm_set_hits");
+        const size_t lds = (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw) * 4;
+        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_set_hits<1, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, p, out);
+        else hipLaunchKernelGGL((k_skm_set_hits<2, 1024>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, p, out);
+        if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_set_hits<1>, dim3(SKM_LOOSE_WGS), dim3(256), 0, st, sg, p, out);
+        else hipLaunchKernelGGL(k_skm_loose_set_hits<2>, dim3(SKM_LOOSE_WGS), dim3(256), 0, st, sg, p, out);
+    }
+    KV_HIP(hipGetLastError());
+    KvReadback back;
+    hipError_t rb_err = hipSuccess;
+    const unsigned long long *c = back.add(sg.ctr, 11, st, &rb_err);
+    KV_HIP(rb_err);
+    KV_HIP(back.wait(st));
+    if (c[1] != 0) {
+        idx.mex_scan_ready = false;
+        kv_set_error("kv_mex_scan_set: a bucket holds more members of the set than its table takes");
+        return KV_ERR_CAPACITY;
+    }
+    KV_REQUIRE(c[10] <= cap, KV_ERR_CAPACITY, "kv_mex_scan_set: %llu hits exceed the buffer of %llu", c[10], (unsigned long long)cap);
+    *n_hits = c[10];
+    return KV_OK;
+}
 
 // the filled part of a shard's exchange segments, destination after destination (what actually travels): d_out receives the
 // records, records_per_dest[d] how many go to rank d.  The counts slab travels as it is.

@@ -496,6 +496,17 @@ class ReadBatch(object):
         check(_lib.load().kv_reads_num_kmers(self._h, ksize, ctypes.byref(n)))
         return n.value
 
+    def flagged_reads(self):
+        """indices of the reads with a byte outside ACGT -- counted with stand-in bases, skipped by the scan (kv_reads_flags);
+        read once per batch and kept"""
+        if getattr(self, '_flagged', None) is None:
+            nreads, nbases = ctypes.c_uint64(), ctypes.c_uint64()
+            check(_lib.load().kv_reads_count(self._h, ctypes.byref(nreads), ctypes.byref(nbases)))
+            flags = np.zeros(nreads.value, dtype=np.uint8)
+            check(_lib.load().kv_reads_flags(self._h, ctypes.c_void_p(flags.ctypes.data)))
+            self._flagged = np.flatnonzero(flags & 1).astype(np.int64)
+        return self._flagged
+
     def device_bytes(self):
         """HBM the packed batch occupies, to within rounding: 2 bits per base plus 17 bytes of index per read."""
         nreads, nbases = ctypes.c_uint64(), ctypes.c_uint64()
@@ -937,14 +948,24 @@ def mex_emit_pack(batch, plan, read_base, seg_ptr, cnt_ptr, out_ptr, out_cap_wor
     return [int(c) for c in counts], bool(packed.value)
 
 
-def mex_route(plan, my_dest, recv_seg_ptr, recv_cnt_ptr, n_src, out_ptr, cap_items, compact=False):
+def mex_route(plan, my_dest, recv_seg_ptr, recv_cnt_ptr, n_src, out_ptr, cap_items, compact=False, keep_scan=False):
     """Combine the records n_src ranks sent for this rank's buckets and write one (hash, occurrences) pair per distinct
-    k-mer, grouped by band owner (kv_mex_route); returns (pairs per destination, k-mer occurrences that arrived)."""
+    k-mer, grouped by band owner (kv_mex_route); returns (pairs per destination, k-mer occurrences that arrived).
+    keep_scan: the combined buckets stay for mex_scan_set (the case sample)."""
     counts = (ctypes.c_uint64 * int(plan.ndest))()
     arrived = ctypes.c_uint64()
     check(_lib.load().kv_mex_route(ctypes.byref(plan), int(my_dest), ctypes.c_void_p(recv_seg_ptr), ctypes.c_void_p(recv_cnt_ptr), int(n_src),
-                                   1 if compact else 0, ctypes.c_void_p(out_ptr), int(cap_items), counts, ctypes.byref(arrived)))
+                                   1 if compact else 0, 1 if keep_scan else 0, ctypes.c_void_p(out_ptr), int(cap_items), counts, ctypes.byref(arrived)))
     return [int(c) for c in counts], arrived.value
+
+
+def mex_scan_set(sketch_cls, ksize, nsamples, hashes_ptr, abund_ptr, n, hit_tags_ptr, hit_abund_ptr, hit_cap):
+    """The hits of this rank's minimizer buckets against the gathered set of interesting hashes (kv_mex_scan_set): returns how
+    many (tag, abundances) rows were written; raises KvCapacityError when the owner cannot answer (scan the shard instead)."""
+    n_hits = ctypes.c_uint64()
+    check(_lib.load().kv_mex_scan_set(sketch_cls._kind, int(ksize), int(nsamples), ctypes.c_void_p(hashes_ptr), ctypes.c_void_p(abund_ptr), int(n),
+                                      ctypes.c_void_p(hit_tags_ptr), ctypes.c_void_p(hit_abund_ptr), int(hit_cap), ctypes.byref(n_hits)))
+    return n_hits.value
 
 
 def novel_scan_hashes(cases, controls, items_ptr, n_items, case_min, ctrl_max, hit_tags_ptr, hit_abund_ptr, hit_cap):

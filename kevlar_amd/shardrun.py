@@ -199,7 +199,7 @@ class ShardedTrio(object):
             _lib.load().kv_table_cache_trim()
         return torch.empty((cap, words), dtype=torch.int64, device=self.device)
 
-    def start_minimizer(self, batch, read_index_base, n_reads_global, read_len):
+    def start_minimizer(self, batch, read_index_base, n_reads_global, read_len, keep_scan=False):
         """start() for the minimizer-sharded layout: the shard is cut into super-k-mer records (kv_mex_emit), the records go
         to the rank that owns their minimizer bucket (first all-to-all; fixed split points, so no sizes are exchanged), that
         rank combines every occurrence of a k-mer -- from whichever shard -- at the sample's full coverage (kv_mex_route),
@@ -207,7 +207,7 @@ class ShardedTrio(object):
         1/8 of the reads has little to combine on its own (49 % of its k-mers are distinct against 20 % of the sample's); this
         way a rank hashes 1/N of the sample's DISTINCT k-mers.  = combine_minimizer(cut_minimizer(...)); callers with several
         samples interleave the two halves so that one sample's records travel while the next one's shard is cut."""
-        return self.combine_minimizer(self.cut_minimizer(batch, read_index_base, n_reads_global, read_len))
+        return self.combine_minimizer(self.cut_minimizer(batch, read_index_base, n_reads_global, read_len), keep_scan)
 
     def cut_minimizer(self, batch, read_index_base, n_reads_global, read_len):
         """First half of start_minimizer(): cut the shard, pack what was cut, tell every owner how much is coming (the slab of
@@ -256,9 +256,11 @@ class ShardedTrio(object):
         self.timing['exchange'] += time.perf_counter() - t1
         return _Cut(plan, got_cnt, records, None, batch, read_index_base)
 
-    def combine_minimizer(self, cut):
+    def combine_minimizer(self, cut, keep_scan=False):
         """Second half of start_minimizer(): wait for the records, combine what the N shards hold of this rank's buckets and start
-        the exchange of the (hash, occurrences) pairs; returns the handle finish() takes."""
+        the exchange of the (hash, occurrences) pairs; returns the handle finish() takes.  keep_scan (the case sample, combined
+        last): the combined buckets stay on the device for scan_minimizer()."""
+        self.owner_can_scan = False
         if cut.fallback is not None:
             return cut.fallback
         from kevlar_amd._lib import KvCapacityError
@@ -274,7 +276,8 @@ class ShardedTrio(object):
         counts = None
         if forced != 'route:{}'.format(self.rank):
             try:
-                counts, _ = hk.mex_route(plan, self.rank, got_seg.data_ptr(), got_cnt.data_ptr(), self.world, send.data_ptr(), send.shape[0], compact=True)
+                counts, _ = hk.mex_route(plan, self.rank, got_seg.data_ptr(), got_cnt.data_ptr(), self.world, send.data_ptr(), send.shape[0], compact=True,
+                                         keep_scan=keep_scan)
             except KvCapacityError:                         # more k-mers in this rank's buckets than its pair buffer holds: bucket skew
                 counts = None
         del got_seg, got_cnt
@@ -290,6 +293,7 @@ class ShardedTrio(object):
             return self.start(cut.batch, cut.base, False, distinct=True)
         ex.send_buffer = send
         ex.weighted = True
+        self.owner_can_scan = bool(keep_scan)
         self.timing['route'] += t3 - t2
         self.timing['exchange'] += (t2 - t1) + (time.perf_counter() - t3)
         return ex
@@ -346,7 +350,7 @@ class ShardedTrio(object):
         scan_distinct(), a tagged one with scan().  minimizer = (reads of the whole sample, read length): the
         minimizer-sharded layout (start_minimizer); what arrives is what `distinct` delivers."""
         if minimizer is not None:
-            return self.finish(self.start_minimizer(batch, read_index_base, int(minimizer[0]), int(minimizer[1])), sketch, keep_for_scan)
+            return self.finish(self.start_minimizer(batch, read_index_base, int(minimizer[0]), int(minimizer[1]), keep_scan=keep_for_scan), sketch, keep_for_scan)
         if not distinct:
             return self.finish(self.start(batch, read_index_base, keep_for_scan), sketch, keep_for_scan)
         return self.finish(self.start(batch, read_index_base, False, distinct=True), sketch, keep_for_scan)
@@ -401,6 +405,81 @@ class ShardedTrio(object):
         t3 = time.perf_counter()
         r, o, a = bandmerge.allgather_hits_device(np.asarray(r).astype(np.int64) + int(read_index_base), o, a, self.device,
                                                   self.group, self.staged)
+        self.timing['scan'] += (t1 - t0) + (t3 - t2)
+        self.timing['gather'] += (t2 - t1) + (time.perf_counter() - t3)
+        return r, o, a
+
+
+    def scan_minimizer(self, cases, controls, case_min, ctrl_max, batch, read_index_base):
+        """The scan when the case sample went through the minimizer layout and was combined last with keep_scan: the band owners
+        judge the distinct k-mers they received (as in scan_distinct), the interesting hashes are all-gathered, and then the OWNERS
+        OF THE MINIMIZER BUCKETS answer -- every occurrence of a k-mer sits in their combined buckets with its global (read, offset),
+        and they kept its hash (kv_mex_scan_set) -- instead of every rank hashing its whole shard again.  The hits are gathered as
+        (tag, abundances) rows and sorted like scan()'s; hits on reads the scan skips (bytes outside ACGT: every rank contributes
+        the indices of its shard's) are dropped.  Every rank must be able to answer, or none does: the ranks agree in one small
+        all-gather and otherwise take scan_distinct()'s second half."""
+        assert self.case_items is not None and self.case_items_weighted, 'count_sample(..., keep_for_scan=True) through the minimizer layout first'
+        from kevlar_amd._lib import KvCapacityError
+        S = len(cases) + len(controls)
+        items = self.case_items
+        n = items.shape[0]
+        t0 = time.perf_counter()
+        cap = max(min(n, 1 << 26), 1)
+        hashes = torch.empty(cap, dtype=torch.int64, device=self.device)
+        abund = torch.empty((cap, S), dtype=torch.uint8, device=self.device)
+        n_mine = hk.novel_scan_distinct(cases, controls, items.data_ptr(), n, case_min, ctrl_max,
+                                        hashes.data_ptr(), abund.data_ptr(), cap) if n else 0
+        t1 = time.perf_counter()
+        all_hashes, _ = gather_rows(hashes, n_mine, -1, self.group, self.staged)
+        all_abund, _ = gather_rows(abund, n_mine, 0, self.group, self.staged)
+        flagged = batch.flagged_reads() + int(read_index_base)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        # this rank's buckets against the set; how many hits there can be is not known in advance: a buffer sized by the set, again if short
+        n_hits, tags, rows = -1, None, None
+        if getattr(self, 'owner_can_scan', False):
+            hit_cap = max(1 << 16, 64 * int(all_hashes.shape[0]) // max(1, self.world))
+            for _ in range(2):
+                tags = torch.empty(hit_cap, dtype=torch.int64, device=self.device)
+                rows = torch.empty((hit_cap, S), dtype=torch.uint8, device=self.device)
+                try:
+                    n_hits = hk.mex_scan_set(self.sketch_cls, self.ksize, S, all_hashes.data_ptr(), all_abund.data_ptr(), all_hashes.shape[0],
+                                             tags.data_ptr(), rows.data_ptr(), hit_cap)
+                    break
+                except KvCapacityError as exc:
+                    n_hits = -1
+                    if 'exceed the buffer' not in str(exc):
+                        break
+                    hit_cap *= 16
+        t3 = time.perf_counter()
+        coll_dev = torch.device('cpu') if self.staged else self.device
+        mine = torch.tensor([n_hits, len(flagged)], dtype=torch.int64, device=coll_dev)
+        table = torch.empty(2 * self.world, dtype=torch.int64, device=coll_dev)
+        dist.all_gather_into_tensor(table, mine, group=self.group)
+        table = table.view(self.world, 2).cpu()
+        if bool((table[:, 0] < 0).any()):
+            # an owner cannot answer: every rank looks its own shard up in the set, as scan_distinct() does
+            self.scan_fallbacks = getattr(self, 'scan_fallbacks', 0) + 1
+            from kevlar_amd import bandmerge
+            r, o, a = hk.novel_scan_set(batch, self.sketch_cls, self.ksize, S, all_hashes.data_ptr(), all_abund.data_ptr(), all_hashes.shape[0])
+            t4 = time.perf_counter()
+            r, o, a = bandmerge.allgather_hits_device(np.asarray(r).astype(np.int64) + int(read_index_base), o, a, self.device, self.group, self.staged)
+            self.timing['scan'] += (t1 - t0) + (t4 - t2)
+            self.timing['gather'] += (t2 - t1) + (time.perf_counter() - t4)
+            return r, o, a
+        all_tags, total = gather_rows(tags, n_hits, -1, self.group, self.staged)
+        all_rows, _ = gather_rows(rows, n_hits, 0, self.group, self.staged)
+        skip = None
+        if int(table[:, 1].sum()):
+            mine_f = torch.from_numpy(flagged).to(self.device)
+            skip, _ = gather_rows(mine_f, len(flagged), -1, self.group, self.staged)
+            skip = np.unique(skip.cpu().numpy())
+            skip = skip[skip >= 0]
+        torch.cuda.synchronize()
+        r, o, a = hk.hits_from_tagged(all_tags.data_ptr(), all_rows.data_ptr(), all_tags.shape[0], total, S)
+        if skip is not None and len(skip):
+            keep = ~np.isin(np.asarray(r), skip)
+            r, o, a = np.asarray(r)[keep], np.asarray(o)[keep], np.asarray(a)[keep]
         self.timing['scan'] += (t1 - t0) + (t3 - t2)
         self.timing['gather'] += (t2 - t1) + (time.perf_counter() - t3)
         return r, o, a

@@ -25,6 +25,7 @@ def main():
     n_reads = packed['proband'].shape[0]
     dev = torch.device('cuda', 0)
     modes = [m for m in os.environ.get('RANK_COST_MODES', 'minimizer,distinct,plain').split(',') if m]
+    owner_scan = os.environ.get('RANK_COST_SCAN', 'owner') == 'owner'      # minimizer layout: the bucket owners answer the scan (shard: every rank hashes its shard again)
     for mode_name in modes:
         distinct = mode_name in ('distinct', 'minimizer')
         minimizer = mode_name == 'minimizer'
@@ -118,7 +119,7 @@ def main():
                         per_dest, fitted = hk.mex_emit_pack(shards[n][0], plan, 0, my_seg.data_ptr(), my_cnt.data_ptr(), my_packed.data_ptr(), my_packed.shape[0])
                         assert fitted
                         rs, rc = mex_recv0[n]
-                        c, _ = hk.mex_route(plan, 0, rs.data_ptr(), rc.data_ptr(), world, send.data_ptr(), send.shape[0])
+                        c, _ = hk.mex_route(plan, 0, rs.data_ptr(), rc.data_ptr(), world, send.data_ptr(), send.shape[0], keep_scan=(owner_scan and n == 'proband'))
                         out_bytes += (sum(c) - c[0]) * 16 + (sum(per_dest) - per_dest[0]) * int(plan.recw) * 8 + int(plan.cnt_entries) * 4 * (world - 1) // world
                     elif distinct:
                         c = route(shards[n][0], 0, 'distinct')
@@ -153,8 +154,16 @@ def main():
                     set_h = torch.cat([tags[:nh], others_hash])
                     set_a = torch.cat([abund[:nh], others_abund])
                     torch.cuda.synchronize()
-                    r, o, a = hk.novel_scan_set(shards['proband'][0], hk.Counttable, k, 3, set_h.data_ptr(), set_a.data_ptr(), set_h.shape[0])
-                    nh = len(r)
+                    if minimizer and owner_scan:
+                        # this rank's minimizer buckets against the gathered set (kv_mex_scan_set); the sort of all ranks' hits that follows
+                        # the all-gather is the same work in either layout of the scan and is not timed in either
+                        hit_cap = max(1 << 16, 64 * int(set_h.shape[0]) // world)
+                        htags = torch.empty(hit_cap, dtype=torch.int64, device=dev)
+                        hrows = torch.empty((hit_cap, 3), dtype=torch.uint8, device=dev)
+                        nh = hk.mex_scan_set(hk.Counttable, k, 3, set_h.data_ptr(), set_a.data_ptr(), set_h.shape[0], htags.data_ptr(), hrows.data_ptr(), hit_cap)
+                    else:
+                        r, o, a = hk.novel_scan_set(shards['proband'][0], hk.Counttable, k, 3, set_h.data_ptr(), set_a.data_ptr(), set_h.shape[0])
+                        nh = len(r)
                 else:
                     cap = recv_tagged.shape[0]
                     tags = torch.empty(min(cap, 1 << 26), dtype=torch.int64, device=dev)

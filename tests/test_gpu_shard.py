@@ -367,6 +367,7 @@ def free_port():
 @pytest.mark.parametrize('world,backend,distinct', [(2, 'gloo', False), (3, 'gloo', False), (1, 'nccl', False),
                                                     (2, 'gloo', 'skm'), (3, 'gloo', 'plain'), (1, 'nccl', 'skm'),
                                                     (2, 'gloo', 'minimizer'), (3, 'gloo', 'minimizer'), (1, 'nccl', 'minimizer'),
+                                                    (2, 'gloo', 'minimizer-shardscan'), (1, 'nccl', 'minimizer-shardscan'),
                                                     (3, 'gloo', 'minimizer/emit:1'), (3, 'gloo', 'minimizer/route:2'), (2, 'gloo', 'minimizer/route:0')])
 def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     """N ranks on this one GPU (gloo, staged exchange): each rank's sketches must equal band `rank` of a
@@ -384,6 +385,11 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     decline = None
     if distinct and '/' in str(distinct):
         distinct, decline = distinct.split('/')
+    # 'minimizer': the owners of the minimizer buckets answer the scan from their combined buckets (ShardedTrio.scan_minimizer,
+    # kv_mex_scan_set); 'minimizer-shardscan': every rank looks its own shard up in the gathered set (scan_distinct), as before
+    shard_scan = distinct == 'minimizer-shardscan'
+    if shard_scan:
+        distinct = 'minimizer'
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), SHARD_BACKEND=backend, SHARD_DISTINCT='1' if distinct else '0')
@@ -392,7 +398,7 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
         if distinct == 'minimizer':
             # the minimizer-sharded layout: super-k-mer records travel to their bucket's owner, which deduplicates at the
             # sample's full coverage (kv_mex_emit / kv_mex_route); the scan goes through the set, as for `distinct`
-            env.update(SHARD_DISTINCT='0', SHARD_MINIMIZER='1', KV_NOVEL_PATH='skm')
+            env.update(SHARD_DISTINCT='0', SHARD_MINIMIZER='1', KV_NOVEL_PATH='skm', SHARD_SCAN='shard' if shard_scan else 'owner')
         elif distinct:          # the bucketed kernels by name (the shards are small), or their one-item-per-k-mer stand-ins
             env.update(KV_ROUTE_PATH=distinct, KV_NOVEL_PATH='skm' if distinct == 'skm' else 'tiles')
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'shard_worker.py')], env=env,
@@ -410,3 +416,6 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
         assert 'shard worker ok' in outs[rank]
         if decline:
             assert '3 fallbacks' in outs[rank], outs[rank][-400:]        # one per sample, on every rank
+            assert '1 scan fallbacks' in outs[rank], outs[rank][-400:]   # and the scan of a sample that fell back goes by the shards
+        elif distinct == 'minimizer':
+            assert '0 fallbacks, 0 scan fallbacks' in outs[rank], outs[rank][-400:]
