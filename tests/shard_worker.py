@@ -33,7 +33,8 @@ def main():
 
     run = shardrun.ShardedTrio(k, hk.Counttable)
     sharded = {n: hk.Counttable(k, mem / world / 4, 4) for n in names}
-    for n in names:
+    # (the case sample last: what its combine leaves on the device is what the owners answer the scan from)
+    for n in (names[1:] + names[:1] if os.environ.get('SHARD_MINIMIZER') == '1' else names):
         lo, hi = shardrun.shard_bounds(len(reads[n]), world, rank)
         counted = run.count_sample(sharded[n], hk.ReadBatch(reads[n][lo:hi]), lo, keep_for_scan=(n == 'proband'),
                                    distinct=os.environ.get('SHARD_DISTINCT') == '1',
