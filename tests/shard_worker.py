@@ -22,10 +22,11 @@ def main():
     from kevlar_amd import _lib, bandmerge, khmer as hk, shardrun, synth
     _lib.load()
     _lib.require_device()
-    k, mem = 31, 4.0e6
-    trio = synth.make_trio(250000, 33)
+    k, mem = int(os.environ.get('SHARD_K', '31')), 4.0e6
+    L = int(os.environ.get('SHARD_L', '100'))
+    trio = synth.make_trio(250000, 33 + k + L)
     names = ('proband', 'mother', 'father')
-    reads = {n: synth.unpack_reads(synth.sample_reads_packed(trio[n], 50001, 100, 0.005, 7 + i), 100)
+    reads = {n: synth.unpack_reads(synth.sample_reads_packed(trio[n], 5000100 // L, L, 0.005, 7 + i), L)
              for i, n in enumerate(names)}
     reads['proband'][3] = reads['proband'][3][:30] + 'N' + reads['proband'][3][31:]
     for i in range(11, len(reads['proband']), 97):         # one read in a hundred is skipped by the scan and still counted: some of them hold novel k-mers
@@ -38,7 +39,7 @@ def main():
         lo, hi = shardrun.shard_bounds(len(reads[n]), world, rank)
         counted = run.count_sample(sharded[n], hk.ReadBatch(reads[n][lo:hi]), lo, keep_for_scan=(n == 'proband'),
                                    distinct=os.environ.get('SHARD_DISTINCT') == '1',
-                                   minimizer=(len(reads[n]), 100) if os.environ.get('SHARD_MINIMIZER') == '1' else None)
+                                   minimizer=(len(reads[n]), L) if os.environ.get('SHARD_MINIMIZER') == '1' else None)
         total = torch.tensor([counted], dtype=torch.int64)
         if backend == 'nccl':
             total = total.cuda()

@@ -356,6 +356,29 @@ def test_mex_route_judges_its_output_by_the_pairs_not_by_the_occurrences(hk):
     assert bool((probe[n_pairs // 2:] == 0x5a5a5a5a).all())
 
 
+@pytest.mark.parametrize('world,k,read_len', [(2, 51, 150), (3, 64, 100), (2, 16, 100), (3, 33, 250)])
+def test_owner_scan_of_the_minimizer_layout_other_k_and_read_lengths(hk, world, k, read_len):
+    """the scan answered by the owners of the minimizer buckets with two-word keys (k > 32), the shortest k the layout takes and
+    longer reads: sketches equal the banded count's, merged hits equal the merged banded scan's (tests/shard_worker.py)"""
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   SHARD_BACKEND='gloo', SHARD_DISTINCT='0', SHARD_MINIMIZER='1', SHARD_SCAN='owner', SHARD_K=str(k), SHARD_L=str(read_len),
+                   KV_NOVEL_PATH='skm')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'shard_worker.py')], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for rank, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        out = out.decode(errors='replace')
+        assert p.returncode == 0, 'rank {} failed:\n{}'.format(rank, out[-3000:])
+        assert '0 fallbacks, 0 scan fallbacks' in out, out[-400:]
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
