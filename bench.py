@@ -302,6 +302,7 @@ def main():
         # coverage); plain: one hash per k-mer
         args.exchange_items = 'minimizer' if 16 <= k <= 64 else ('distinct' if world <= 4 else 'plain')
     exchange = world > 1 and multi == 'exchange'
+    by_minimizer_layout = exchange and args.exchange_items == 'minimizer'
     per_batch = int(wl['batch_reads']) or n_reads
     upload_s = None
     if exchange:
@@ -595,6 +596,11 @@ def main():
         selfcheck['kmers_per_rank'] = [int(t[1]) for t in sorted(table)]
         assert selfcheck['ranks_seen'] == list(range(world)), 'a rank is missing from the collective'
         assert sum(selfcheck['kmers_per_rank']) == S * n_reads * nk, 'every k-mer of the family must be counted by exactly one rank'
+        if exchange:
+            # how the exchange layout ran on rank 0 (the decisions are collective: the same on every rank): samples that fell back from the
+            # minimizer layout to `distinct` pairs, scans the bucket owners could not answer (all steps, warm-up included)
+            selfcheck['exchange'] = {'items': args.exchange_items, 'scan': args.exchange_scan if by_minimizer_layout else ('set' if args.exchange_items == 'distinct' else 'owners of the bands'),
+                                     'layout_fallbacks': int(getattr(run, 'fallbacks', 0)), 'scan_fallbacks': int(getattr(run, 'scan_fallbacks', 0))}
 
     def replay_bands(nbands):
         """the nbands-band configuration one band after the other on this GPU: what kevlar does band by band"""

@@ -63,3 +63,5 @@ def test_exchange_layout_with_its_samples_interleaved_equals_the_banded_replay(r
     assert out['n_gpus'] == ranks and out['selfcheck']['ranks_seen'] == list(range(ranks))
     assert out['selfcheck']['replay_matches']
     assert 'exchanged by band' in out['config']['parallelism']
+    assert out['selfcheck']['exchange']['layout_fallbacks'] == 0 and out['selfcheck']['exchange']['scan_fallbacks'] == 0
+    assert out['selfcheck']['exchange']['scan'] == ('owner' if items == 'minimizer' else 'set')
