@@ -446,12 +446,19 @@ fail:
 /* ------------------------------------------------------------------------------------ */
 /* H7-H9: the novel scan, kevlar/novel.py:123-169 with kmer_is_interesting :21-53        */
 /* ------------------------------------------------------------------------------------ */
-int64_t kvo_novel_scan(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl,
+/* band_mode 3 (test infrastructure for BASELINE.json config 3, no reference analogue): ALL nbands bands of a banded run in one pass.
+ * `cases` / `ctrls` then hold nbands x ncase / nbands x nctrl sketches, band-major -- the sketches kevlar would have counted in
+ * its nbands separate `--band b` jobs (docs/banding.rst) --, every k-mer is hashed once, evaluated against the sketches of the band
+ * its hash falls into (the test kvo_consume applies: bs*b <= h < bs*(b+1)) and the band is reported beside the hit, so the hits
+ * with hit_band == b are exactly what kvo_novel_scan(band_mode 1, band b) over band b's sketches returns. */
+static int64_t novel_scan_impl(kvo_sketch *const *cases_all, int ncase, kvo_sketch *const *ctrls_all, int nctrl,
                        const char *bases, const uint64_t *offs, uint64_t n_reads, int ksize,
                        int case_min, int ctrl_max, int screen_thresh, int band_mode, int nbands,
-                       int band, uint32_t *hit_read, uint16_t *hit_off, uint8_t *hit_abund,
+                       int band, uint32_t *hit_read, uint16_t *hit_off, uint8_t *hit_abund, uint8_t *hit_band,
                        int64_t cap, uint8_t *read_status)
 {
+    kvo_sketch *const *cases = cases_all, *const *ctrls = ctrls_all;
+    const uint64_t bs = nbands > 0 ? UINT64_MAX / (uint64_t)nbands : 0;
     const int S = ncase + nctrl;
     int64_t nhits = 0;
     uint64_t lo = 0, hi = 0;
@@ -471,7 +478,15 @@ int64_t kvo_novel_scan(kvo_sketch *const *cases, int ncase, kvo_sketch *const *c
         const int64_t first_hit = nhits;
         int discard_read = 0;
         for (size_t i = 0; i + (size_t)ksize <= len; ++i) { /* novel.py:143 get_kmers */
-            const uint64_t h = kvo_hash(cases[0]->kind, seq + i, ksize);
+            const uint64_t h = kvo_hash(cases_all[0]->kind, seq + i, ksize);
+            int b_of_h = 0;
+            if (band_mode == 3) {
+                if (h == UINT64_MAX) continue;                      /* in no band: the last band ends below it (kvo_band_bounds) */
+                b_of_h = (int)(h / bs);
+                if (b_of_h >= nbands) b_of_h = nbands - 1;          /* the last band also takes the remainder of 2^64 / nbands */
+                cases = cases_all + (size_t)b_of_h * (size_t)ncase;
+                ctrls = ctrls_all + (size_t)b_of_h * (size_t)nctrl;
+            }
             if (band_mode == 1 && !(h >= lo && h < hi)) continue;
             if (band_mode == 2 && (h & (uint64_t)(nbands - 1)) != (uint64_t)(int64_t)(band - 1))
                 continue;                                   /* novel.py:144-147, band is 0-based */
@@ -497,6 +512,7 @@ int64_t kvo_novel_scan(kvo_sketch *const *cases, int ncase, kvo_sketch *const *c
                 hit_read[nhits] = (uint32_t)r;
                 hit_off[nhits] = (uint16_t)i;
                 memcpy(hit_abund + (size_t)nhits * (size_t)S, abund, (size_t)S);
+                if (hit_band) hit_band[nhits] = (uint8_t)b_of_h;
             }
             ++nhits;
         }
@@ -508,6 +524,17 @@ int64_t kvo_novel_scan(kvo_sketch *const *cases, int ncase, kvo_sketch *const *c
         }
     }
     return nhits;
+}
+
+int64_t kvo_novel_scan(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl,
+                       const char *bases, const uint64_t *offs, uint64_t n_reads, int ksize,
+                       int case_min, int ctrl_max, int screen_thresh, int band_mode, int nbands,
+                       int band, uint32_t *hit_read, uint16_t *hit_off, uint8_t *hit_abund,
+                       int64_t cap, uint8_t *read_status)
+{
+    if (band_mode < 0 || band_mode > 2) return -1;
+    return novel_scan_impl(cases, ncase, ctrls, nctrl, bases, offs, n_reads, ksize, case_min, ctrl_max, screen_thresh, band_mode, nbands,
+                           band, hit_read, hit_off, hit_abund, NULL, cap, read_status);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -561,6 +588,7 @@ typedef struct {
     uint64_t *next;             /* shared cursor: threads pull chunks of reads, like khmer's parser */
     uint64_t n_added;
     int nbands, band;           /* hash-range banding of consume_seqfile_banding (kevlar/count.py:62-66); nbands 0: none */
+    kvo_sketch *const *all;     /* non-NULL: the nbands sketches of ALL bands; a k-mer is hashed once and added to its band's sketch */
 } mt_count_job;
 
 static void *mt_count_worker(void *arg)
@@ -571,6 +599,9 @@ static void *mt_count_worker(void *arg)
     size_t cap = 0;
     uint64_t occ = 0, uniq = 0;
     uint64_t lo = 0, hi = 0;
+    uint64_t occ_b[256], uniq_b[256];
+    const uint64_t bs = j->nbands > 0 ? UINT64_MAX / (uint64_t)j->nbands : 0;
+    if (j->all) { memset(occ_b, 0, sizeof(occ_b)); memset(uniq_b, 0, sizeof(uniq_b)); }
     if (j->nbands > 0) kvo_band_bounds(j->nbands, j->band, &lo, &hi);
     for (;;) {
         const uint64_t r0 = __atomic_fetch_add(j->next, j->chunk, __ATOMIC_RELAXED);
@@ -584,6 +615,15 @@ static void *mt_count_worker(void *arg)
             for (size_t i = 0; i < len; ++i) clean[i] = clean_base(seq[i]);
             for (size_t i = 0; i + (size_t)k <= len; ++i) {
                 const uint64_t h = kvo_hash(j->s->kind, clean + i, k);
+                if (j->all) {
+                    /* the band whose test (bs*b <= h < bs*(b+1), the last one up to 2^64 - 1 exclusive: kvo_band_bounds) h passes */
+                    if (h == UINT64_MAX) continue;
+                    int b = (int)(h / bs);
+                    if (b >= j->nbands) b = j->nbands - 1;
+                    add_hash_atomic(j->all[b], h, &occ_b[b], &uniq_b[b]);
+                    j->n_added++;
+                    continue;
+                }
                 if (j->nbands > 0 && !(h >= lo && h < hi)) continue;      /* same test as kvo_consume */
                 add_hash_atomic(j->s, h, &occ, &uniq);
                 j->n_added++;
@@ -591,6 +631,13 @@ static void *mt_count_worker(void *arg)
         }
     }
     free(clean);
+    if (j->all) {
+        for (int b = 0; b < j->nbands; ++b) {
+            __atomic_fetch_add(&j->all[b]->n_occupied, occ_b[b], __ATOMIC_RELAXED);
+            __atomic_fetch_add(&j->all[b]->n_unique, uniq_b[b], __ATOMIC_RELAXED);
+        }
+        return NULL;
+    }
     __atomic_fetch_add(&j->s->n_occupied, occ, __ATOMIC_RELAXED);
     __atomic_fetch_add(&j->s->n_unique, uniq, __ATOMIC_RELAXED);
     return NULL;
@@ -611,7 +658,29 @@ uint64_t kvo_consume_reads_mt_banded(kvo_sketch *s, const char *bases, const uin
     uint64_t next = 0, total = 0;
     for (int t = 0; t < nthreads; ++t) {
         jobs[t].s = s; jobs[t].bases = bases; jobs[t].offs = offs; jobs[t].n_reads = n_reads;
-        jobs[t].chunk = 1024; jobs[t].next = &next; jobs[t].n_added = 0; jobs[t].nbands = nbands; jobs[t].band = band;
+        jobs[t].chunk = 1024; jobs[t].next = &next; jobs[t].n_added = 0; jobs[t].nbands = nbands; jobs[t].band = band; jobs[t].all = NULL;
+        pthread_create(&th[t], NULL, mt_count_worker, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); total += jobs[t].n_added; }
+    return total;
+}
+
+/* All nbands bands of a banded count in ONE pass over the reads (test infrastructure for BASELINE.json config 3; kevlar itself runs
+ * `kevlar count --num-bands N --band b` once per band, docs/banding.rst): sketches[b] receives exactly the k-mers
+ * kvo_consume_reads_mt_banded(sketches[b], ..., nbands, b) would add -- the band test is a partition of the hash values below
+ * 2^64 - 1 --, so tables and n_occupied per band equal the band-by-band result; the hashing is paid once instead of nbands times. */
+uint64_t kvo_consume_reads_mt_allbands(kvo_sketch *const *sketches, int nbands, const char *bases, const uint64_t *offs, uint64_t n_reads,
+                                       int nthreads)
+{
+    if (nbands < 1 || nbands > 256) return 0;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    mt_count_job jobs[256];
+    uint64_t next = 0, total = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        jobs[t].s = sketches[0]; jobs[t].bases = bases; jobs[t].offs = offs; jobs[t].n_reads = n_reads;
+        jobs[t].chunk = 1024; jobs[t].next = &next; jobs[t].n_added = 0; jobs[t].nbands = nbands; jobs[t].band = 0; jobs[t].all = sketches;
         pthread_create(&th[t], NULL, mt_count_worker, &jobs[t]);
     }
     for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); total += jobs[t].n_added; }
@@ -643,24 +712,24 @@ typedef struct {
     const char *bases; const uint64_t *offs;
     uint64_t r0, r1;
     int ksize, case_min, ctrl_max, band_mode, nbands, band;
-    uint32_t *hr; uint16_t *ho; uint8_t *ha; int64_t cap;
+    uint32_t *hr; uint16_t *ho; uint8_t *ha; uint8_t *hb; int64_t cap;
     int64_t nhits;
 } mt_scan_hits_job;
 
 static void *mt_scan_hits_worker(void *arg)
 {
     mt_scan_hits_job *j = (mt_scan_hits_job *)arg;
-    j->nhits = kvo_novel_scan(j->cases, j->ncase, j->ctrls, j->nctrl, j->bases, j->offs + j->r0, j->r1 - j->r0, j->ksize, j->case_min,
-                              j->ctrl_max, 0, j->band_mode, j->nbands, j->band, j->hr, j->ho, j->ha, j->cap, NULL);
+    j->nhits = novel_scan_impl(j->cases, j->ncase, j->ctrls, j->nctrl, j->bases, j->offs + j->r0, j->r1 - j->r0, j->ksize, j->case_min,
+                               j->ctrl_max, 0, j->band_mode, j->nbands, j->band, j->hr, j->ho, j->ha, j->hb, j->cap, NULL);
     return NULL;
 }
 
 /* The scan loop of kvo_novel_scan (kevlar/novel.py:123-169, no abundance screen: a read's verdict then depends on that read
  * alone) over contiguous ranges of reads on nthreads threads; the ranges' hits are concatenated in read order, so the result is
  * kvo_novel_scan's.  Returns the number of hits (which may exceed cap: the caller retries with room), -1 without memory. */
-int64_t kvo_novel_scan_mt(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl, const char *bases,
+static int64_t novel_scan_mt_impl(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl, const char *bases,
                           const uint64_t *offs, uint64_t n_reads, int ksize, int case_min, int ctrl_max, int band_mode, int nbands,
-                          int band, uint32_t *hit_read, uint16_t *hit_off, uint8_t *hit_abund, int64_t cap, int nthreads)
+                          int band, uint32_t *hit_read, uint16_t *hit_off, uint8_t *hit_abund, uint8_t *hit_band, int64_t cap, int nthreads)
 {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
@@ -677,7 +746,8 @@ int64_t kvo_novel_scan_mt(kvo_sketch *const *cases, int ncase, kvo_sketch *const
         j->hr = (uint32_t *)malloc((size_t)(each > 0 ? each : 1) * 4);
         j->ho = (uint16_t *)malloc((size_t)(each > 0 ? each : 1) * 2);
         j->ha = (uint8_t *)malloc((size_t)(each > 0 ? each : 1) * (size_t)S);
-        if (!j->hr || !j->ho || !j->ha) return -1;
+        j->hb = hit_band ? (uint8_t *)malloc((size_t)(each > 0 ? each : 1)) : NULL;
+        if (!j->hr || !j->ho || !j->ha || (hit_band && !j->hb)) return -1;
         pthread_create(&th[t], NULL, mt_scan_hits_worker, j);
     }
     int64_t total = 0, worst = 0;
@@ -689,12 +759,34 @@ int64_t kvo_novel_scan_mt(kvo_sketch *const *cases, int ncase, kvo_sketch *const
                 hit_read[total + i] = j->hr[i] + (uint32_t)j->r0;        /* kvo_novel_scan numbers the reads of its range from 0 */
                 hit_off[total + i] = j->ho[i];
                 memcpy(hit_abund + (size_t)(total + i) * (size_t)S, j->ha + (size_t)i * (size_t)S, (size_t)S);
+                if (hit_band) hit_band[total + i] = j->hb[i];
             }
             total += j->nhits;
         }
-        free(j->hr); free(j->ho); free(j->ha);
+        free(j->hr); free(j->ho); free(j->ha); free(j->hb);
     }
     return worst <= each ? total : worst * nthreads;
+}
+
+int64_t kvo_novel_scan_mt(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl, const char *bases,
+                          const uint64_t *offs, uint64_t n_reads, int ksize, int case_min, int ctrl_max, int band_mode, int nbands,
+                          int band, uint32_t *hit_read, uint16_t *hit_off, uint8_t *hit_abund, int64_t cap, int nthreads)
+{
+    if (band_mode < 0 || band_mode > 2) return -1;
+    return novel_scan_mt_impl(cases, ncase, ctrls, nctrl, bases, offs, n_reads, ksize, case_min, ctrl_max, band_mode, nbands, band,
+                              hit_read, hit_off, hit_abund, NULL, cap, nthreads);
+}
+
+/* The scans of ALL nbands bands of a banded run in one pass (novel_scan_impl, band_mode 3): cases / ctrls hold nbands x ncase /
+ * nbands x nctrl sketches band-major; hit_band[i] says which band's sketches judged hit i.  The merged result of the nbands jobs
+ * kevlar runs (docs/banding.rst + kevlar/unband.py:41-77) is all hits in (read, offset) order, which is the order returned. */
+int64_t kvo_novel_scan_mt_allbands(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl, int nbands, const char *bases,
+                                   const uint64_t *offs, uint64_t n_reads, int ksize, int case_min, int ctrl_max, uint32_t *hit_read,
+                                   uint16_t *hit_off, uint8_t *hit_abund, uint8_t *hit_band, int64_t cap, int nthreads)
+{
+    if (nbands < 1 || nbands > 256 || !hit_band) return -1;
+    return novel_scan_mt_impl(cases, ncase, ctrls, nctrl, bases, offs, n_reads, ksize, case_min, ctrl_max, 3, nbands, 0,
+                              hit_read, hit_off, hit_abund, hit_band, cap, nthreads);
 }
 
 int64_t kvo_novel_scan_count_mt(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl,

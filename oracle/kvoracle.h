@@ -105,6 +105,12 @@ uint64_t kvo_consume_reads_mt_banded(kvo_sketch *s, const char *bases, const uin
 int64_t kvo_novel_scan_mt(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl, const char *bases,
                           const uint64_t *offs, uint64_t n_reads, int ksize, int case_min, int ctrl_max, int band_mode, int nbands,
                           int band, uint32_t *hit_read, uint16_t *hit_off, uint8_t *hit_abund, int64_t cap, int nthreads);
+/* test infrastructure for BASELINE.json config 3: all nbands bands of a banded count / scan in one pass over the reads */
+uint64_t kvo_consume_reads_mt_allbands(kvo_sketch *const *sketches, int nbands, const char *bases, const uint64_t *offs, uint64_t n_reads,
+                                       int nthreads);
+int64_t kvo_novel_scan_mt_allbands(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl, int nbands, const char *bases,
+                                   const uint64_t *offs, uint64_t n_reads, int ksize, int case_min, int ctrl_max, uint32_t *hit_read,
+                                   uint16_t *hit_off, uint8_t *hit_abund, uint8_t *hit_band, int64_t cap, int nthreads);
 int64_t kvo_novel_scan_count_mt(kvo_sketch *const *cases, int ncase, kvo_sketch *const *ctrls, int nctrl,
                                 const char *bases, const uint64_t *offs, uint64_t n_reads, int ksize,
                                 int case_min, int ctrl_max, int nthreads);

@@ -70,6 +70,11 @@ def _load():
         'kvo_novel_scan_mt': (ctypes.c_int64, [
             ctypes.POINTER(vp), i32, ctypes.POINTER(vp), i32, cp, pu64, u64, i32, i32, i32, i32, i32, i32,
             ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint8), ctypes.c_int64, i32]),
+        'kvo_consume_reads_mt_allbands': (u64, [ctypes.POINTER(vp), i32, cp, pu64, u64, i32]),
+        'kvo_novel_scan_mt_allbands': (ctypes.c_int64, [
+            ctypes.POINTER(vp), i32, ctypes.POINTER(vp), i32, i32, cp, pu64, u64, i32, i32, i32,
+            ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8),
+            ctypes.c_int64, i32]),
         'kvo_novel_scan_count_mt': (ctypes.c_int64, [ctypes.POINTER(vp), i32, ctypes.POINTER(vp), i32, cp, pu64, u64,
                                                      i32, i32, i32, i32]),
         'kvo_abundance_distribution': (u64, [vp, vp, cp, ctypes.c_size_t, pu64]),
@@ -404,6 +409,35 @@ def novel_scan_mt(cases, ctrls, bases, offs, n_reads, ksize, case_min, ctrl_max,
             raise MemoryError('kvo_novel_scan_mt')
         if n <= cap:                      # (a range that outgrew its share of the buffers comes back as a number above cap)
             return hr[:n].copy(), ho[:n].copy(), ha[:n].copy()
+        cap = int(n) * 2
+
+
+def consume_reads_mt_allbands(sketches, bases, offs, n_reads, nthreads):
+    """ALL bands of a banded count in one pass: sketches[b] receives what consume_reads_mt_banded(sketches[b], .., len(sketches), b) adds"""
+    arr = (ctypes.c_void_p * len(sketches))(*[s._h for s in sketches])
+    return int(lib.kvo_consume_reads_mt_allbands(arr, len(sketches), bases, offs, n_reads, int(nthreads)))
+
+
+def novel_scan_mt_allbands(cases_by_band, ctrls_by_band, bases, offs, n_reads, ksize, case_min, ctrl_max, nthreads, cap=1 << 22):
+    """the scans of ALL bands in one pass: cases_by_band[b] / ctrls_by_band[b] are band b's sketches; returns (read u32[n], offset u16[n],
+    abund u8[n, S], band u8[n]) in (read, offset) order -- the rows with band == b are novel_scan_mt(band_mode=1, band=b) over band b's sketches"""
+    import numpy as np
+    nbands, ncase, nctrl = len(cases_by_band), len(cases_by_band[0]), len(ctrls_by_band[0])
+    S = ncase + nctrl
+    vp = ctypes.c_void_p
+    ca = (vp * (nbands * ncase))(*[c._h for band in cases_by_band for c in band])
+    cb = (vp * max(1, nbands * nctrl))(*[c._h for band in ctrls_by_band for c in band])
+    while True:
+        hr, ho, ha = np.empty(cap, dtype=np.uint32), np.empty(cap, dtype=np.uint16), np.empty((cap, S), dtype=np.uint8)
+        hb = np.empty(cap, dtype=np.uint8)
+        n = lib.kvo_novel_scan_mt_allbands(ca, ncase, cb, nctrl, nbands, bases, offs, n_reads, ksize, case_min, ctrl_max,
+                                           hr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), ho.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
+                                           ha.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), hb.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                           cap, int(nthreads))
+        if n < 0:
+            raise MemoryError('kvo_novel_scan_mt_allbands')
+        if n <= cap:
+            return hr[:n].copy(), ho[:n].copy(), ha[:n].copy(), hb[:n].copy()
         cap = int(n) * 2
 
 

@@ -68,7 +68,9 @@ FIXTURES = [
     'progind.txt',
 ]
 # the three trio1 files behind test_novel.py:179-207 are 1.8 MB each: stored gzipped
-GZ_FIXTURES = ['trio1/case1.fq', 'trio1/ctrl1.fq', 'trio1/ctrl2.fq']
+GZ_FIXTURES = ['trio1/case1.fq', 'trio1/ctrl1.fq', 'trio1/ctrl2.fq',
+               # two case samples + two controls: test_novel.py:108-144
+               'trio1/case6.fq', 'trio1/case6b.fq', 'trio1/ctrl5.fq', 'trio1/ctrl6.fq']
 
 
 def copy_fixtures():
@@ -184,6 +186,31 @@ def main():
     with open(os.path.join(EXPECTED, 'novel-trio1.augfastq'), 'w') as fh:
         fh.write(out)
     manifest['cases']['novel-trio1.augfastq'] = keep_lines(log, ['Found'])
+
+    # ---- two case samples, two controls, from saved counts (test_novel.py:108-144), and -- through novel() itself, which
+    #      the CLI cannot ask for -- two cases and no control at all (novel.py:36-51: an empty control loop)
+    tables = []
+    for tag, rel in [('case1', 'trio1/case6.fq'), ('case2', 'trio1/case6b.fq'), ('ctrl1', 'trio1/ctrl5.fq'), ('ctrl2', 'trio1/ctrl6.fq')]:
+        tables.append(os.path.join(work, 'two-' + tag + '.ct'))
+        run_cli(kevlar, ['count', '--ksize', '19', '--memory', '1e7', tables[-1], d(rel)])
+    out, log = run_cli(kevlar, ['novel', '--ksize', '19', '--memory', '1e7', '--ctrl-max', '1', '--case-min', '7',
+                                '--case', d('trio1/case6.fq'), '--case', d('trio1/case6b.fq'),
+                                '--case-counts', tables[0], tables[1], '--control-counts', tables[2], tables[3]])
+    assert out.strip() != ''
+    with open(os.path.join(EXPECTED, 'novel-trio1-two-cases.augfastq'), 'w') as fh:
+        fh.write(out)
+    manifest['cases']['novel-trio1-two-cases.augfastq'] = keep_lines(log, ['Found', 'counttables'])
+    sketches = [kevlar.sketch.load(t) for t in tables[:2]]
+    buf = io.StringIO()
+    kevlar.logstream = io.StringIO()
+    stream = kevlar.multi_file_iter_khmer([d('trio1/case6.fq'), d('trio1/case6b.fq')])
+    for rec in kevlar.novel.novel(stream, sketches, [], ksize=19, casemin=12, ctrlmax=0):
+        kevlar.print_augmented_fastx(rec, buf)
+    manifest['cases']['novel-trio1-two-cases-no-control.augfastq'] = keep_lines(kevlar.logstream.getvalue(), ['Found'])
+    kevlar.logstream = None
+    assert buf.getvalue().strip() != ''
+    with open(os.path.join(EXPECTED, 'novel-trio1-two-cases-no-control.augfastq'), 'w') as fh:
+        fh.write(buf.getvalue())
 
     # ---- novel with abundance screen (test_novel.py:167-176)
     out, log = run_cli(kevlar, ['novel', '--ksize', '25', '--ctrl-max', '1', '--case-min', '8',

@@ -333,3 +333,60 @@ def test_fullsize_config5_tables_and_scan_equal_the_oracle(hk, ok, quad):
     assert len(want[0]) > 100_000 and want[2].shape[1] == 4
     for way in ('list', 'walk', 'tiles'):
         assert_hits_equal(scans[way], want, 'config 5, scan by ' + way)
+
+
+def test_fullsize_config3_eight_bands_equal_the_oracle(hk, ok, trio):
+    """BASELINE.json config 3 in its single-GPU form: the 25 Mb trio as EIGHT hash bands (what the eight GPUs of a node count and
+    scan, one band each: docs/banding.rst, kevlar/count.py:62-66; sketch memory 2 GB / 8 per band as `bench.py --gpus 8` sizes
+    it), replayed band by band on this GPU and held against the oracle, which hashes every k-mer once and sends it to its band's
+    sketch (kvo_consume_reads_mt_allbands, kvo_novel_scan_mt_allbands: equal to the band-by-band scalar legs, tests/test_host_logic.py):
+    every table byte and n_occupied of all 24 band sketches, every hit of every band, the merged hits (the all-gather +
+    sort of kevlar_amd/bandmerge.py, kevlar/unband.py:41-77), and north_star's merge of per-band bit masks: the eight masks are
+    disjoint, their sum (what the all-reduce computes) is their OR, and its set bits are the merged hits"""
+    import torch
+    from kevlar_amd import bandmerge
+    packed, batches = trio
+    NB = 8
+    names = ('mother', 'father', 'proband')
+    cores = host_cores()
+    n_reads = packed['proband'].shape[0]
+    nk = L - K + 1
+    ref = {n: [ok.Counttable(K, MEM / NB / 4, 4) for _ in range(NB)] for n in names}
+    keep = None
+    for n in names:
+        bases, offs_p, offs = ascii_block(packed[n], L)
+        assert ok.consume_reads_mt_allbands(ref[n], bases, offs_p, n_reads, cores) == n_reads * nk
+        if n == 'proband':
+            keep = (bases, offs_p, offs)
+    want = ok.novel_scan_mt_allbands([[ref['proband'][b]] for b in range(NB)], [[ref['mother'][b], ref['father'][b]] for b in range(NB)],
+                                     keep[0], keep[1], n_reads, K, 6, 1, cores)
+    del keep
+    assert len(want[0]) > 1_000_000
+    dev = {n: hk.Counttable(K, MEM / NB / 4, 4) for n in names}
+    dev['proband'].expect_scan()
+    merged = torch.zeros((n_reads * nk + 31) // 32, dtype=torch.int32, device='cuda')
+    mask = torch.zeros_like(merged)
+    parts, total = [], {n: 0 for n in names}
+    for band in range(NB):
+        for n in names:
+            dev[n].clear()
+            total[n] += dev[n].consume_batch(batches[n], NB, band)
+            assert_same_sketch(dev[n], ref[n][band])
+        mask.zero_()
+        torch.cuda.synchronize()
+        r, o, a, _ = hk.novel_scan([dev['proband']], [dev['mother'], dev['father']], batches['proband'], 6, 1, band_mode=1, nbands=NB,
+                                   band=band, mask_ptr=mask.data_ptr(), mask_stride=nk)
+        torch.cuda.synchronize()
+        sel = want[3] == band
+        assert_hits_equal((r, o, a), (want[0][sel], want[1][sel], want[2][sel]), 'config 3, band {} of {}'.format(band, NB))
+        assert int(sel.sum()) > 50_000
+        assert not bool((merged & mask).any()), 'the bands\' masks must be disjoint'
+        merged += mask                                  # what all_reduce(SUM) does with the eight ranks' masks (bandmerge.allreduce_mask)
+        parts.append((np.array(r, dtype=np.uint32), np.array(o, dtype=np.uint32), np.array(a, dtype=np.uint8)))
+    for n in names:
+        assert total[n] == n_reads * nk                 # every k-mer counted by exactly one band
+    rr, oo, aa = (np.concatenate([p[i] for p in parts]) for i in range(3))
+    order = np.lexsort((oo, rr))
+    assert_hits_equal((rr[order], oo[order], aa[order]), want[:3], 'config 3, merged hits')
+    mr, mo = bandmerge.mask_to_hits(merged, nk)
+    assert np.array_equal(mr, want[0]) and np.array_equal(mo, want[1].astype(np.uint32)), 'config 3, merged bit masks'

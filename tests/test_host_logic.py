@@ -445,6 +445,45 @@ def test_oracle_threaded_banded_consume_and_scan_equal_single_thread(ok):
     assert len(hits) > 0
 
 
+def test_oracle_all_bands_in_one_pass_equal_the_band_by_band_legs(ok):
+    """config 3's checker (tests/test_gpu_config3.py): kvo_consume_reads_mt_allbands / kvo_novel_scan_mt_allbands hash every k-mer once
+    and send it to its band's sketches; per band they must give what the scalar banded count and scan (kvo_consume_reads with a
+    band, kvo_novel_scan band_mode 1: kevlar/count.py:62-66 run once per band) give, and the union in (read, offset) order"""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    letters = np.array(list('ACGT'))
+    genome = ''.join(letters[rng.integers(0, 4, size=9000)])
+    child = genome[:3000] + ('A' if genome[3000] != 'A' else 'C') + genome[3001:6000] + ('G' if genome[6000] != 'G' else 'T') + genome[6001:]
+    reads = {name: [g[s:s + 90] for s in rng.integers(0, 8910, size=3500)] for name, g in (('kid', child), ('mom', genome), ('dad', genome))}
+    reads['kid'][17] = reads['kid'][17][:40] + 'N' + reads['kid'][17][41:]          # skipped by the scan, cleaned by the count
+    for nbands in (1, 3, 8):
+        scalar = {name: [ok.Counttable(25, 2e4, 4) for _ in range(nbands)] for name in reads}
+        once = {name: [ok.Counttable(25, 2e4, 4) for _ in range(nbands)] for name in reads}
+        for name, seqs in reads.items():
+            bases, offs = ok.concat_reads(seqs)
+            total = sum(ok.consume_reads(scalar[name][b], bases, offs, len(seqs), nbands, b) for b in range(nbands))
+            assert ok.consume_reads_mt_allbands(once[name], bases, offs, len(seqs), 5) == total == len(seqs) * 66
+            for b in range(nbands):
+                for t in range(4):
+                    assert scalar[name][b].table_bytes(t) == once[name][b].table_bytes(t)
+                assert scalar[name][b].n_occupied() == once[name][b].n_occupied()
+        bases, offs = ok.concat_reads(reads['kid'])
+        r, o, a, hb = ok.novel_scan_mt_allbands([[once['kid'][b]] for b in range(nbands)], [[once['mom'][b], once['dad'][b]] for b in range(nbands)],
+                                                bases, offs, 3500, 25, 5, 1, 4)
+        merged = []
+        for b in range(nbands):
+            hits, _ = ok.novel_scan([scalar['kid'][b]], [scalar['mom'][b], scalar['dad'][b]], bases, offs, 3500, 25, 5, 1, band_mode=1,
+                                    nbands=nbands, band=b)
+            sel = hb == b
+            assert [(int(x), int(y), tuple(int(v) for v in z)) for x, y, z in zip(r[sel], o[sel], a[sel])] == hits
+            merged += hits
+        assert [(int(x), int(y)) for x, y in zip(r, o)] == sorted((x, y) for x, y, _ in merged) and len(merged) > 0
+        # (a buffer too small for a range's share of the hits: the call says how much room it wants)
+        r2, o2, a2, hb2 = ok.novel_scan_mt_allbands([[once['kid'][b]] for b in range(nbands)], [[once['mom'][b], once['dad'][b]] for b in range(nbands)],
+                                                    bases, offs, 3500, 25, 5, 1, 3, cap=8)
+        assert np.array_equal(r, r2) and np.array_equal(o, o2) and np.array_equal(a, a2) and np.array_equal(hb, hb2)
+
+
 def test_progress_indicator_jumps_match_item_by_item_counting(kevlar_log):
     """update(n) must log exactly where n single updates would (the reference ticks once per item,
     kevlar/progress.py:30-42: widen the interval at a break point, log when the count reaches the due point)"""

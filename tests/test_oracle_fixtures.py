@@ -165,6 +165,29 @@ def test_novel_scan_reproduces_reference_output(ok):
     assert len(want) == 209 and len(set(n for n, _, _ in want)) == 18
 
 
+@pytest.mark.parametrize('golden,nctrl,case_min,ctrl_max', [('novel-trio1-two-cases.augfastq', 2, 7, 1),
+                                                            ('novel-trio1-two-cases-no-control.augfastq', 0, 12, 0)])
+def test_novel_scan_with_two_cases_reproduces_reference_output(ok, golden, nctrl, case_min, ctrl_max):
+    """the oracle's case loop over TWO case samples, with two controls and with none, == the reference's kmer_is_interesting()
+    (kevlar/novel.py:36-51) run by its own drivers over the same sketches (kevlar/tests/test_novel.py:108-144)"""
+    from kevlar_amd.sequence import parse_augmented_fastx
+    files = [data_file('trio1/{}.fq.gz'.format(n)) for n in ('case6', 'case6b', 'ctrl5', 'ctrl6')]
+    sketches = []
+    for f in files[:2 + nctrl]:
+        ct = ok.Counttable(19, 1e7 / 4, 4)
+        ct.consume_seqfile(f)
+        sketches.append(ct)
+    reads = list(ok.ReadParser(files[0])) + list(ok.ReadParser(files[1]))      # kevlar/novel.py:215-216: every case file, in order
+    bases, offs = ok.concat_reads([r.sequence for r in reads])
+    hits, status = ok.novel_scan(sketches[:2], sketches[2:], bases, offs, len(reads), 19, case_min, ctrl_max)
+    with open(expected_file(golden)) as fh:
+        records = [r for r in parse_augmented_fastx(fh)]
+    want = [(r.name, k.offset, k.abund) for r in records for k in sorted(r.annotations, key=lambda k: k.offset)]
+    got = [(reads[r].name, o, a) for r, o, a in hits]
+    assert got == want and len(want) > 0
+    assert all(len(a) == 2 + nctrl for _, _, a in want)
+
+
 # ---- kevlar dist (kevlar/tests/test_dist.py): the oracle's two passes against the reference's goldens
 def test_dist_first_pass_file_is_byte_exact(ok, tmp_path):
     import filecmp
