@@ -59,14 +59,14 @@ def run_scan(hk, cases, ctrls, batch, case_min, ctrl_max, path, **kw):
     if path in ('list', 'walk'):
         os.environ['KV_NOVEL_PATH'] = 'skm'
     else:
-        os.environ['KV_NOVEL_PATH'] = 'tiles'
-        os.environ['KV_NOVEL_2BIT'] = '1' if path == 'tiles2bit' else '0'
+        # 'tiles' keeps the tile kernel (k_novel_mark); any other name than 'skm' leaves the choice among the per-k-mer kernels to
+        # the library, which takes the 2-bit one for equal-length reads (kv_novel.hip, scan_reads)
+        os.environ['KV_NOVEL_PATH'] = 'tiles' if path == 'tiles' else 'per-kmer'
     lib.kv_prof_reset()
     try:
         r, o, a, disc = hk.novel_scan(cases, ctrls, batch, case_min, ctrl_max, **kw)
     finally:
         os.environ.pop('KV_NOVEL_PATH', None)
-        os.environ.pop('KV_NOVEL_2BIT', None)
     ran = {name: launches(name) for name in ('k_skm_novel_list', 'k_skm_novel', 'k_novel_mark', 'k_novel_mark_2bit')}
     return as_tuples(r, o, a), sorted(disc.tolist()), ran
 
