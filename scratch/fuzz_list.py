@@ -34,7 +34,12 @@ for trial in range(trials):
     try:
         dev = {s: getattr(hk, kind)(k, mem / 4, 4) for s in names}
         ref = {s: getattr(ok, kind)(k, mem / 4, 4) for s in names}
-        dev['proband'].expect_scan()
+        # one or two case samples, two / one / no controls (kevlar/novel.py:36-51); the scanned batch -- the proband's -- is counted last
+        cases, ctrls = [(['proband'], ['mother', 'father']), (['proband'], ['mother', 'father']), (['proband', 'mother'], ['father']),
+                        (['mother', 'proband'], ['father']), (['proband', 'father'], []), (['proband'], [])][rng.integers(0, 6)]
+        desc += ' cases={} ctrls={}'.format(','.join(cases), ','.join(ctrls))
+        for s in cases:
+            dev[s].expect_scan()
         batches = {s: hk.ReadBatch.from_packed(words[s], L) for s in names}
         for s in ('mother', 'father', 'proband'):
             nk = dev[s].consume_batch(batches[s], nbands, band)
@@ -43,10 +48,10 @@ for trial in range(trials):
             assert nk == nk_ref, ('k-mers counted', s, nk, nk_ref)
             for t in range(4):
                 assert dev[s].table_bytes(t) == ref[s].table_bytes(t), (s, 'table', t)
-        r, o, a, _ = hk.novel_scan([dev['proband']], [dev['mother'], dev['father']], batches['proband'], case_min, ctrl_max,
+        r, o, a, _ = hk.novel_scan([dev[s] for s in cases], [dev[s] for s in ctrls], batches['proband'], case_min, ctrl_max,
                                    band_mode=1 if nbands else 0, nbands=nbands, band=band)
         bases, offs = ok.concat_reads(reads['proband'])
-        hits, _ = ok.novel_scan([ref['proband']], [ref['mother'], ref['father']], bases, offs, n, k, case_min, ctrl_max,
+        hits, _ = ok.novel_scan([ref[s] for s in cases], [ref[s] for s in ctrls], bases, offs, n, k, case_min, ctrl_max,
                                 band_mode=1 if nbands else 0, nbands=nbands, band=band, cap=max(1 << 20, 4 * n * max(1, L - k + 1)))
         got = list(zip(r.tolist(), o.tolist(), map(tuple, a.tolist())))
         assert got == [(h[0], h[1], tuple(h[2])) for h in hits], ('hits', len(got), len(hits))

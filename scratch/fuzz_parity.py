@@ -50,11 +50,16 @@ for trial in range(trials):
                 assert dev[name].table_bytes(t) == ref[name].table_bytes(t), (desc, name, 'table', t)
             assert dev[name].n_occupied() == ref[name].n_occupied(), (desc, 'occupied')
         case_min, ctrl_max = int(rng.integers(1, 8)), int(rng.integers(0, 3))
+        # who is a case and who a control (kevlar/novel.py:36-51 loops over any number of either; the reference's own two-case run is
+        # kevlar/tests/test_novel.py:108-144): one or two cases, two / one / no controls
+        split = [(['proband'], ['mother', 'father']), (['proband'], ['mother', 'father']), (['proband', 'mother'], ['father']),
+                 (['proband', 'father'], []), (['proband'], []), (['proband'], ['father'])][rng.integers(0, 6)]
+        desc += ' cases={} ctrls={}'.format(len(split[0]), len(split[1]))
         batch = hk.ReadBatch(reads['proband'])
-        r, o, a, _ = hk.novel_scan([dev['proband']], [dev['mother'], dev['father']], batch, case_min, ctrl_max,
+        r, o, a, _ = hk.novel_scan([dev[s] for s in split[0]], [dev[s] for s in split[1]], batch, case_min, ctrl_max,
                                    band_mode=1 if nbands else 0, nbands=nbands, band=band)
         bases, offs = ok.concat_reads(reads['proband'])
-        hits, _ = ok.novel_scan([ref['proband']], [ref['mother'], ref['father']], bases, offs, len(reads['proband']), k, case_min, ctrl_max,
+        hits, _ = ok.novel_scan([ref[s] for s in split[0]], [ref[s] for s in split[1]], bases, offs, len(reads['proband']), k, case_min, ctrl_max,
                                 band_mode=1 if nbands else 0, nbands=nbands, band=band, cap=max(1 << 20, 4 * n * max(1, L - k + 1)))
         got = list(zip(r.tolist(), o.tolist(), map(tuple, a.tolist())))
         assert got == [(h[0], h[1], tuple(h[2])) for h in hits], (desc, 'hits', len(got), len(hits))
