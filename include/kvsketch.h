@@ -326,7 +326,9 @@ int kv_format_records(uint64_t n_out, const uint64_t *rec_index, const uint64_t 
                       const uint64_t *mate_offs, char **text_out, uint64_t *bytes_out);
 /* kv_format_records with the text written straight to file descriptor `fd` (a regular file, a pipe): rendered a stretch of records
  * at a time on `nthreads` host threads, written in order; *bytes_out = bytes written.  What `kevlar filter` / `kevlar partition` /
- * `kevlar novel` do with the text of print_augmented_fastx (kevlar/sequence.pyx:93-126) when their output is a plain file.        */
+ * `kevlar novel` do with the text of print_augmented_fastx (kevlar/sequence.pyx:93-126) when their output is a plain file.  On an
+ * error (an annotation outside its read, no memory, a failed write) a seekable `fd` is truncated back to where the call found it and
+ * *bytes_out = 0; a pipe keeps the stretches already written (*bytes_out says how much).                                          */
 int kv_format_records_fd(uint64_t n_out, const uint64_t *rec_index, const uint64_t *ann_lo, const uint64_t *ann_hi,
                          const uint32_t *ann_offset, const int32_t *ann_abund, const uint8_t *keep,
                          const int32_t *case_abund, int nsamples, int ksize, const char *names,

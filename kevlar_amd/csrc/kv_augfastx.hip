@@ -553,7 +553,9 @@ extern "C" int kv_format_records_fd(uint64_t n_out, const uint64_t *rec_index, c
     std::condition_variable cv;
     uint64_t turn = 0, total = 0;                                 // guarded by mu: the stretch that may be written, bytes written
     int failed = 0;                                               // 1 annotation out of range, 2 memory, 3 write error
+    int write_errno = 0;                                          // errno of the write that failed, taken where it failed
     uint64_t bad_record = 0;
+    const off_t start_at = lseek(fd, 0, SEEK_CUR);                // -1: not seekable (a pipe): nothing can be taken back
     auto work = [&]() {
         KvTextOut out;
         std::vector<uint64_t> order;
@@ -572,7 +574,7 @@ extern "C" int kv_format_records_fd(uint64_t n_out, const uint64_t *rec_index, c
                 size_t done = 0;
                 while (done < out.len) {
                     const ssize_t w = write(fd, out.buf + done, out.len - done);
-                    if (w < 0) { if (errno == EINTR) continue; failed = 3; break; }
+                    if (w < 0) { if (errno == EINTR) continue; write_errno = errno; failed = 3; break; }
                     done += (size_t)w;
                 }
                 total += done;
@@ -587,8 +589,13 @@ extern "C" int kv_format_records_fd(uint64_t n_out, const uint64_t *rec_index, c
     work();
     for (auto &th : pool) th.join();
     *bytes_out = total;
+    if (failed && start_at >= 0) {
+        // earlier stretches are in the file already: a failed call leaves a regular file as it found it (what the buffered form,
+        // which writes nothing before everything is rendered, leaves), not a truncated but plausible list of records
+        if (ftruncate(fd, start_at) == 0 && lseek(fd, start_at, SEEK_SET) == start_at) *bytes_out = 0;
+    }
     KV_REQUIRE(failed != 1, KV_ERR_ARG, "kv_format_records_fd: an annotation does not fit its read (record %llu)", (unsigned long long)bad_record);
     KV_REQUIRE(failed != 2, KV_ERR_HIP, "kv_format_records_fd: out of memory");
-    KV_REQUIRE(failed != 3, KV_ERR_IO, "kv_format_records_fd: write failed: %s", strerror(errno));
+    KV_REQUIRE(failed != 3, KV_ERR_IO, "kv_format_records_fd: write failed: %s", strerror(write_errno));
     return KV_OK;
 }

@@ -2250,7 +2250,6 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     if (rc != KV_OK) {
         idx.valid = false;
         idx.mex_scan_ready = false;
-    idx.mex_scan_ready = false;
         if (getenv("KV_SKM_VERBOSE")) {
             unsigned long long sc[8] = {0}, bc[4] = {0};
             (void)hipMemcpy(sc, sg.ctr, sizeof(sc), hipMemcpyDeviceToHost);
@@ -2415,7 +2414,6 @@ int kv_skm_route_distinct(const kv_reads *reads, int ksize, uint64_t n_kmers, in
     if (sctr[1] != 0) {
         idx.valid = false;
         idx.mex_scan_ready = false;
-    idx.mex_scan_ready = false;
         kv_set_error("super-k-mer route: loose record list overflow (%llu records)", sctr[0]);
         return KV_ERR_CAPACITY;
     }
@@ -2706,6 +2704,9 @@ int kv_skm_mex_pack(const kv_mex_plan *plan, const uint64_t *d_seg, const uint32
     SkmIndex &idx = skm_index_for(st);
     std::lock_guard<std::mutex> lk(idx.mu);
     const uint64_t n_seg = plan->cnt_entries;
+    // the offsets go where the stream's bucketed batch lies: whatever that was -- a batch a scan could reuse, an owner's combined
+    // buckets kept for kv_skm_mex_scan_set, a distinct list -- is gone after this call
+    idx.valid = false; idx.mex_scan_ready = false; idx.dl_valid = false;
     KV_HIP(idx.arena.need(mex_scan_bytes(n_seg)));
     uint64_t *d_off = (uint64_t *)idx.arena.p;
     mex_scan_launch(d_cnt, n_seg, plan->cap1, d_off, st);

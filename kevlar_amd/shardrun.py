@@ -48,6 +48,27 @@ class PeerDeclined(Exception):
     others have left."""
 
 
+def _local_failures():
+    """What a rank's own part of an exchange may raise -- a library error (a buffer too small: KvCapacityError; out of device
+    memory or any other HIP failure: KvError), torch running out of memory for an exchange buffer -- and what must therefore never
+    leave a rank between two collectives: the rank says so inside the next collective instead (PeerDeclined above)."""
+    from kevlar_amd._lib import KvCapacityError, KvError
+    return (KvCapacityError, KvError, MemoryError, torch.cuda.OutOfMemoryError)
+
+
+def _test_failure(point, rank):
+    """tests: KV_MEX_TEST_DECLINE='<point>:<rank>' makes that rank fail at that point the way the real thing would -- 'emit-oom'
+    (no memory for the packed records), 'route-hip' (the library reports a HIP error while combining), 'scan-fail' (the owner's
+    scan of its distinct case k-mers fails), 'owner-hip' (the bucket owner's look-up fails); 'emit' / 'route' are the plain
+    capacity declines handled where they occur"""
+    if os.environ.get('KV_MEX_TEST_DECLINE', '') != '{}:{}'.format(point, rank):
+        return
+    if point == 'emit-oom':
+        raise MemoryError('forced by KV_MEX_TEST_DECLINE')
+    from kevlar_amd._lib import KV_ERR_HIP, KvError
+    raise KvError(KV_ERR_HIP, 'forced by KV_MEX_TEST_DECLINE')
+
+
 class _Exchange(object):
     """An all-to-all in flight: wait() returns the received rows."""
 
@@ -152,6 +173,8 @@ def gather_rows(rows, n_valid, fill, group=None, staged=False):
     sizes = torch.empty(world, dtype=torch.int64, device=coll_dev)
     dist.all_gather_into_tensor(sizes, mine, group=group)
     sizes = [int(v) for v in sizes.cpu()]
+    if min(sizes) < 0:          # a rank could not produce its rows: every rank learns it here, nobody enters the gather
+        raise PeerDeclined('ranks {} declined'.format([r for r in range(world) if sizes[r] < 0]))
     SENT['bytes'] += (world - 1) * (n_valid * rows.element_size() * int(np.prod(rows.shape[1:], dtype=np.int64)) + 8)
     longest = max(max(sizes), 1)
     padded = torch.full((longest,) + tuple(rows.shape[1:]), fill, dtype=rows.dtype, device=rows.device)
@@ -214,7 +237,6 @@ class ShardedTrio(object):
         segment counts: blocking, small) and START the all-to-all of the records.  Returns a _Cut for combine_minimizer().
         Every rank calls the halves of every sample in the same order (they are collectives)."""
         t0 = time.perf_counter()
-        from kevlar_amd._lib import KvCapacityError
         forced = os.environ.get('KV_MEX_TEST_DECLINE', '')          # tests: 'emit:RANK' / 'route:RANK' makes that rank decline there
         plan = hk.mex_plan(self.sketch_cls, self.ksize, n_reads_global, read_len, self.world)
         seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
@@ -222,16 +244,17 @@ class ShardedTrio(object):
         emitted = forced != 'emit:{}'.format(self.rank)
         # only the filled part of the segments travels (the segments' capacity is twice the expected fill): the cut and the
         # packing are one call and one wait; the counts go first (fixed split points), and say how many records every source sends
-        per_dest = None
+        per_dest, packed = None, None
         if emitted:
-            packed = torch.empty(int(plan.seg_words) // 2 + 1024, dtype=torch.int64, device=self.device)
             try:
+                _test_failure('emit-oom', self.rank)
+                packed = torch.empty(int(plan.seg_words) // 2 + 1024, dtype=torch.int64, device=self.device)
                 per_dest, fitted = hk.mex_emit_pack(batch, plan, read_index_base, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr(), packed.shape[0])
                 if not fitted:                              # fuller than expected: a buffer of the segments' full size always fits
                     packed = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
                     per_dest = hk.mex_pack(plan, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr())
-            except KvCapacityError:                         # records outside their exchange segment: minimizer skew
-                emitted = False
+            except _local_failures():                       # records outside their exchange segment (minimizer skew), no memory for the
+                emitted, packed = False, None               # packed copy, a HIP error: the peers must hear of it, in the slab below
         if not emitted:
             cnt.fill_(-1)                                   # the marker every destination finds in this rank's slab of counts
         t1 = time.perf_counter()
@@ -263,7 +286,6 @@ class ShardedTrio(object):
         self.owner_can_scan = False
         if cut.fallback is not None:
             return cut.fallback
-        from kevlar_amd._lib import KvCapacityError
         forced = os.environ.get('KV_MEX_TEST_DECLINE', '')
         plan, got_cnt = cut.plan, cut.got_cnt
         t1 = time.perf_counter()
@@ -272,21 +294,25 @@ class ShardedTrio(object):
         t2 = time.perf_counter()
         share = int(plan.n_kmers_global) // self.world
         cap = share + share // 4 + (1 << 20)
-        send = self._send_buffer(cap, 2)
-        counts = None
+        send, counts = None, None
         if forced != 'route:{}'.format(self.rank):
             try:
+                _test_failure('route-hip', self.rank)
+                send = self._send_buffer(cap, 2)
                 counts, _ = hk.mex_route(plan, self.rank, got_seg.data_ptr(), got_cnt.data_ptr(), self.world, send.data_ptr(), send.shape[0], compact=True,
                                          keep_scan=keep_scan)
-            except KvCapacityError:                         # more k-mers in this rank's buckets than its pair buffer holds: bucket skew
-                counts = None
+            except _local_failures():                       # more k-mers in this rank's buckets than its pair buffer holds (bucket skew), the
+                counts = None                               # stream arena or the distinct list out of memory, no room for the pair buffer
         del got_seg, got_cnt
         cut.got_cnt = None
         t3 = time.perf_counter()
         try:
+            if send is None:                                # (nothing travels from a rank that declines: any tensor carries its "-1")
+                send = torch.empty((1, 2), dtype=torch.int64, device=self.device)
             ex = exchange_rows_async(send, counts, self.group, self.staged)      # counts None: this rank declines, inside the size exchange
         except PeerDeclined:
-            self._send[2].append(send)
+            if send.shape[0] > 1:
+                self._send[2].append(send)
             self.fallbacks = getattr(self, 'fallbacks', 0) + 1
             self.timing['route'] += t3 - t2
             self.timing['exchange'] += (t2 - t1) + (time.perf_counter() - t3)
@@ -355,6 +381,23 @@ class ShardedTrio(object):
             return self.finish(self.start(batch, read_index_base, keep_for_scan), sketch, keep_for_scan)
         return self.finish(self.start(batch, read_index_base, False, distinct=True), sketch, keep_for_scan)
 
+    def _owners_scan(self, what, call):
+        """A band owner's part of a scan (the library call `call`) whose rows every rank is about to gather: a failure here -- more hits
+        than the buffer holds, no memory -- must not leave this rank alone outside the gather the others are entering.  Returns
+        (rows written, None) or (-1, the error): -1 travels as this rank's row count, gather_rows() raises PeerDeclined on EVERY rank
+        at the same point, and _scan_declined() turns that into this rank's own error (or, on the others, a clear one)."""
+        try:
+            _test_failure('scan-fail', self.rank)
+            return call(), None
+        except _local_failures() as exc:
+            return -1, exc
+
+    @staticmethod
+    def _scan_declined(what, err, declined):
+        if err is not None:
+            raise err
+        raise RuntimeError('{}: {} -- its error is in that rank\'s log; every rank stops here, together'.format(what, declined))
+
     def scan(self, cases, controls, case_min, ctrl_max):
         """kmer_is_interesting() over the case k-mers this rank owns, then gather: every rank returns
         the complete (read, offset, abund[n, S]) hit arrays in (read, offset) order."""
@@ -366,10 +409,13 @@ class ShardedTrio(object):
         cap = max(min(n, 1 << 26), 1)
         tags = torch.empty(cap, dtype=torch.int64, device=self.device)
         abund = torch.empty((cap, S), dtype=torch.uint8, device=self.device)
-        n_hits = hk.novel_scan_hashes(cases, controls, items.data_ptr(), n, case_min, ctrl_max,
-                                      tags.data_ptr(), abund.data_ptr(), cap) if n else 0
+        n_hits, err = self._owners_scan('scan', lambda: hk.novel_scan_hashes(cases, controls, items.data_ptr(), n, case_min, ctrl_max,
+                                                                              tags.data_ptr(), abund.data_ptr(), cap) if n else 0)
         t1 = time.perf_counter()
-        all_tags, total = gather_rows(tags, n_hits, -1, self.group, self.staged)
+        try:
+            all_tags, total = gather_rows(tags, n_hits, -1, self.group, self.staged)
+        except PeerDeclined as declined:
+            self._scan_declined('scan', err, declined)
         all_abund, _ = gather_rows(abund, n_hits, 0, self.group, self.staged)
         torch.cuda.synchronize()
         r, o, a = hk.hits_from_tagged(all_tags.data_ptr(), all_abund.data_ptr(), all_tags.shape[0], total, S)
@@ -393,10 +439,13 @@ class ShardedTrio(object):
         cap = max(min(n, 1 << 26), 1)
         hashes = torch.empty(cap, dtype=torch.int64, device=self.device)
         abund = torch.empty((cap, S), dtype=torch.uint8, device=self.device)
-        n_mine = hk.novel_scan_distinct(cases, controls, items.data_ptr(), n, case_min, ctrl_max,
-                                        hashes.data_ptr(), abund.data_ptr(), cap) if n else 0
+        n_mine, err = self._owners_scan('scan', lambda: hk.novel_scan_distinct(cases, controls, items.data_ptr(), n, case_min, ctrl_max,
+                                                                               hashes.data_ptr(), abund.data_ptr(), cap) if n else 0)
         t1 = time.perf_counter()
-        all_hashes, _ = gather_rows(hashes, n_mine, -1, self.group, self.staged)
+        try:
+            all_hashes, _ = gather_rows(hashes, n_mine, -1, self.group, self.staged)
+        except PeerDeclined as declined:
+            self._scan_declined('scan of the distinct case k-mers', err, declined)
         all_abund, _ = gather_rows(abund, n_mine, 0, self.group, self.staged)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
@@ -427,10 +476,13 @@ class ShardedTrio(object):
         cap = max(min(n, 1 << 26), 1)
         hashes = torch.empty(cap, dtype=torch.int64, device=self.device)
         abund = torch.empty((cap, S), dtype=torch.uint8, device=self.device)
-        n_mine = hk.novel_scan_distinct(cases, controls, items.data_ptr(), n, case_min, ctrl_max,
-                                        hashes.data_ptr(), abund.data_ptr(), cap) if n else 0
+        n_mine, err = self._owners_scan('scan', lambda: hk.novel_scan_distinct(cases, controls, items.data_ptr(), n, case_min, ctrl_max,
+                                                                               hashes.data_ptr(), abund.data_ptr(), cap) if n else 0)
         t1 = time.perf_counter()
-        all_hashes, _ = gather_rows(hashes, n_mine, -1, self.group, self.staged)
+        try:
+            all_hashes, _ = gather_rows(hashes, n_mine, -1, self.group, self.staged)
+        except PeerDeclined as declined:
+            self._scan_declined('scan of the distinct case k-mers', err, declined)
         all_abund, _ = gather_rows(abund, n_mine, 0, self.group, self.staged)
         flagged = batch.flagged_reads() + int(read_index_base)
         torch.cuda.synchronize()
@@ -440,9 +492,10 @@ class ShardedTrio(object):
         if getattr(self, 'owner_can_scan', False):
             hit_cap = max(1 << 16, 64 * int(all_hashes.shape[0]) // max(1, self.world))
             for _ in range(2):
-                tags = torch.empty(hit_cap, dtype=torch.int64, device=self.device)
-                rows = torch.empty((hit_cap, S), dtype=torch.uint8, device=self.device)
                 try:
+                    _test_failure('owner-hip', self.rank)
+                    tags = torch.empty(hit_cap, dtype=torch.int64, device=self.device)
+                    rows = torch.empty((hit_cap, S), dtype=torch.uint8, device=self.device)
                     n_hits = hk.mex_scan_set(self.sketch_cls, self.ksize, S, all_hashes.data_ptr(), all_abund.data_ptr(), all_hashes.shape[0],
                                              tags.data_ptr(), rows.data_ptr(), hit_cap)
                     break
@@ -451,6 +504,9 @@ class ShardedTrio(object):
                     if 'exceed the buffer' not in str(exc):
                         break
                     hit_cap *= 16
+                except _local_failures():                   # no memory for the rows, a HIP error: this owner cannot answer; the ranks agree below
+                    n_hits = -1
+                    break
         t3 = time.perf_counter()
         coll_dev = torch.device('cpu') if self.staged else self.device
         mine = torch.tensor([n_hits, len(flagged)], dtype=torch.int64, device=coll_dev)

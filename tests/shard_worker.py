@@ -50,7 +50,8 @@ def main():
         lo, hi = shardrun.shard_bounds(len(reads['proband']), world, rank)
         r, o, a = run.scan_minimizer([sharded['proband']], [sharded['mother'], sharded['father']], 6, 1,
                                      hk.ReadBatch(reads['proband'][lo:hi]), lo)
-        assert (getattr(run, 'scan_fallbacks', 0) == 0) == (getattr(run, 'fallbacks', 0) == 0), (getattr(run, 'scan_fallbacks', 0), getattr(run, 'fallbacks', 0))
+        if not os.environ.get('KV_MEX_TEST_DECLINE', '').startswith('owner'):        # (an owner that cannot answer: the scan falls back, the layout did not)
+            assert (getattr(run, 'scan_fallbacks', 0) == 0) == (getattr(run, 'fallbacks', 0) == 0), (getattr(run, 'scan_fallbacks', 0), getattr(run, 'fallbacks', 0))
     elif os.environ.get('SHARD_DISTINCT') == '1' or os.environ.get('SHARD_MINIMIZER') == '1':
         lo, hi = shardrun.shard_bounds(len(reads['proband']), world, rank)
         r, o, a = run.scan_distinct([sharded['proband']], [sharded['mother'], sharded['father']], 6, 1,

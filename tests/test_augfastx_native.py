@@ -93,6 +93,16 @@ def test_format_written_to_a_file_by_the_library_equals_format(tmp_path, threads
         bad.format(np.arange(bad.n))
     with kevlar_amd.open_sink(str(tmp_path / 'bad.augfastq')) as sink, pytest.raises(ValueError):
         bad.format_to(sink, np.arange(bad.n))
+    # ... and when the bad record sits in a LATER stretch, the stretches already written are taken back: a failed call leaves the
+    # file as it found it (the head), not a truncated but plausible list of records
+    late = np.concatenate((reads[:70000][reads[:70000] != 0], [0]))       # record 0 (the damaged one) only at the very end: third stretch
+    tail = str(tmp_path / 'late.augfastq')
+    with kevlar_amd.open_sink(tail) as sink:
+        sink.write(b'# head\n')
+        with pytest.raises(ValueError):
+            bad.format_to(sink, late)
+        sink.write(b'# after\n')
+    assert open(tail, 'rb').read() == b'# head\n# after\n'
 
 
 def test_native_parser_rejects_what_the_python_parser_rejects(tmp_path):

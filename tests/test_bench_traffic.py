@@ -51,7 +51,8 @@ def test_every_profile_scope_of_the_library_has_a_stage_or_is_known_to_have_none
     staged = {s for s in scopes if bench.stage_of(s)}
     # what count and novel launch
     for s in ('k_skm_emit', 'k_skm_split', 'k_skm_count', 'k_skm_loose_count', 'k_bin_split_w', 'k_bin_apply_w', 'k_bin_spill', 'k_consume',
-              'k_bin_hash_direct', 'k_skm_novel_list', 'k_skm_novel', 'k_skm_loose_novel', 'k_tile_hits', 'k_tile_scan', 'k_novel_mark', 'k_novel_emit'):
+              'k_bin_hash_direct', 'k_skm_novel_list', 'k_skm_novel', 'k_skm_loose_novel', 'k_tile_hits', 'k_tile_scan', 'k_novel_mark', 'k_novel_emit',
+              'k_case_bits', 'k_skm_set_hits', 'k_skm_route', 'k_mex_pack'):
         assert s in staged, s
     # ingest, point queries, partition, exchange bookkeeping: neither stage
     for s in ('k_inflate', 'k_pack_reads', 'k_get_hashes', 'k_readgraph', 'memset_tables'):

@@ -391,7 +391,9 @@ def free_port():
                                                     (2, 'gloo', 'skm'), (3, 'gloo', 'plain'), (1, 'nccl', 'skm'),
                                                     (2, 'gloo', 'minimizer'), (3, 'gloo', 'minimizer'), (1, 'nccl', 'minimizer'),
                                                     (2, 'gloo', 'minimizer-shardscan'), (1, 'nccl', 'minimizer-shardscan'),
-                                                    (3, 'gloo', 'minimizer/emit:1'), (3, 'gloo', 'minimizer/route:2'), (2, 'gloo', 'minimizer/route:0')])
+                                                    (3, 'gloo', 'minimizer/emit:1'), (3, 'gloo', 'minimizer/route:2'), (2, 'gloo', 'minimizer/route:0'),
+                                                    (3, 'gloo', 'minimizer/emit-oom:2'), (2, 'gloo', 'minimizer/route-hip:1'),
+                                                    (2, 'gloo', 'minimizer/owner-hip:1'), (2, 'gloo', 'minimizer/scan-fail:0')])
 def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     """N ranks on this one GPU (gloo, staged exchange): each rank's sketches must equal band `rank` of a
     banded count of ALL reads, and the gathered hits the merged banded scan (tests/shard_worker.py).  The
@@ -404,7 +406,10 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     procs = []
     # 'minimizer/emit:R' / 'minimizer/route:R': rank R declines at that point of the minimizer exchange (as it would when a buffer
     # overflows: bucket skew); every rank learns it inside the collective that follows and all of them send the sample as the pairs of
-    # their own deduplicated shards instead -- same sketches, same hits, nobody left waiting
+    # their own deduplicated shards instead -- same sketches, same hits, nobody left waiting.  'emit-oom' / 'route-hip': the same for a
+    # failure that is not a capacity error (no memory for a buffer, a HIP error inside the library); 'owner-hip': a bucket owner
+    # cannot answer the scan -- all ranks scan their shards; 'scan-fail': a band owner's scan of its distinct k-mers fails, which no
+    # other layout can make up for -- EVERY rank must stop, at the same collective, with an error (none may hang in the gather)
     decline = None
     if distinct and '/' in str(distinct):
         distinct, decline = distinct.split('/')
@@ -429,15 +434,23 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     outs = []
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=600)
+            out, _ = p.communicate(timeout=300 if decline and decline.startswith('scan-fail') else 600)
         except subprocess.TimeoutExpired:
             p.kill()
             out, _ = p.communicate()
         outs.append(out.decode(errors='replace'))
+    if decline and decline.startswith('scan-fail'):
+        failing = int(decline.split(':')[1])
+        for rank, p in enumerate(procs):
+            assert p.returncode not in (0, None, -9), 'rank {} must stop with an error (killed after a timeout = it hung):\n{}'.format(rank, outs[rank][-2000:])
+            assert ('forced by KV_MEX_TEST_DECLINE' if rank == failing else 'every rank stops here') in outs[rank], outs[rank][-2000:]
+        return
     for rank, p in enumerate(procs):
         assert p.returncode == 0, 'rank {} failed:\n{}'.format(rank, outs[rank][-3000:])
         assert 'shard worker ok' in outs[rank]
-        if decline:
+        if decline and decline.startswith('owner'):
+            assert '0 fallbacks, 1 scan fallbacks' in outs[rank], outs[rank][-400:]
+        elif decline:
             assert '3 fallbacks' in outs[rank], outs[rank][-400:]        # one per sample, on every rank
             assert '1 scan fallbacks' in outs[rank], outs[rank][-400:]   # and the scan of a sample that fell back goes by the shards
         elif distinct == 'minimizer':
