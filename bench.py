@@ -265,7 +265,7 @@ def main():
     import torch.distributed as dist
 
     import __graft_entry__
-    __graft_entry__.build()
+    __graft_entry__.build_product()          # the product only: the oracle is built (and imported) by the cpu_baseline leg alone
     from kevlar_amd import _lib, khmer as hk, synth
 
     ndev = torch.cuda.device_count()

@@ -156,7 +156,7 @@ def load():
     if not os.path.exists(LIBPATH):
         raise ImportError(
             '{} not found: the HIP extension has not been built (run '
-            '`python -c "import __graft_entry__ as g; g.build()"`). kevlar_amd has no CPU '
+            '`python -c "import __graft_entry__ as g; g.build_product()"`). kevlar_amd has no CPU '
             'fallback.'.format(LIBPATH))
     lib = ctypes.CDLL(LIBPATH)
     for name, (res, args) in SIGNATURES.items():

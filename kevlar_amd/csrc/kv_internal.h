@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -76,7 +77,7 @@ struct kv_sketch {
     // fit the tables -- nothing to deduplicate at that coverage -- and was scanned again tile by tile; batches that follow go
     // straight to the tile scan until the sketch is cleared.  (The count cannot say: a banded count of a sparse batch never
     // takes the super-k-mer front end, so skm_off stays unset there.)
-    bool skm_scan_off = false;
+    std::atomic<bool> skm_scan_off{false};       // (scans of several batches of one case sample run side by side: bench.py scan_batches)
     // kv_sketch_clear only notes that the tables are zero: the partitioned count's apply stage, which rewrites every
     // slice anyway, then starts from zeroed LDS instead of loading the slice (no memset, no first read of the tables);
     // every other reader or writer of the tables calls kv_sketch_ready first, which does the memset after all

@@ -539,7 +539,16 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         // (n_unique; of its band only, if banded); a batch of a sample at sequencing coverage brings ~5 k-mers per distinct k-mer
         // of the sample, a batch with less than one for every two distinct k-mers is below ~3x coverage, where more than half of its
         // k-mers are distinct and the bucket tables do not hold them.
-        const double held = (double)cases[0]->n_unique * (band_mode == KV_BAND_RANGE ? (double)nbands : 1.0);
+        // (n_unique is kept by the counts; a sketch that was loaded from a file or filled through weighted pairs has none: there the
+        // occupancy of table 0 -- counted now if it is stale -- gives the same figure by linear counting)
+        double distinct_held = (double)cases[0]->n_unique;
+        if (distinct_held == 0.0) {
+            kv_sketch *c0 = cases[0];
+            std::lock_guard<std::mutex> lk(c0->mu);
+            if (!c0->occ_dirty || kv_sketch_refresh_occupancy(c0) == KV_OK) distinct_held = kv_estimate_distinct(c0->n_occupied, c0->h.size[0]);
+            else (void)hipGetLastError();
+        }
+        const double held = distinct_held * (band_mode == KV_BAND_RANGE ? (double)nbands : 1.0);
         const bool sparse = held > 0.0 && (double)n_kmers < 0.5 * held;
         if (cases[0]->skm_scan_off || sparse) {
             use_skm = false;

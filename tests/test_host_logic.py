@@ -844,3 +844,18 @@ def test_odd_reads_are_the_reads_with_bytes_outside_acgt():
         want = [i for i, s in enumerate(seqs) if any(c not in 'ACGT' for c in s)]
         assert reads.odd_reads().tolist() == want
         assert not reads.seqs or reads.odd_reads() is reads.odd_reads()             # (kept: filter and partition ask more than once)
+
+
+def test_console_script_is_the_reference_s():
+    """reference setup.py:69-71: console_scripts kevlar = kevlar.__main__:main -- here pyproject.toml's kevlar = kevlar_amd.__main__:main,
+    and that callable is the dispatcher `python -m kevlar_amd` runs; the product's build does not touch the oracle"""
+    import importlib
+    import inspect
+    text = open(os.path.join(ROOT, 'pyproject.toml')).read()
+    assert 'kevlar = "kevlar_amd.__main__:main"' in text
+    mod = importlib.import_module('kevlar_amd.__main__')
+    assert callable(mod.main)
+    import __graft_entry__
+    body = inspect.getsource(__graft_entry__.build_product).split('"""')[2]          # (the code, not the docstring that says so)
+    assert 'oracle' not in body and 'okhmer' not in body
+    assert 'build_product()' in open(os.path.join(ROOT, 'bench.py')).read()
