@@ -590,6 +590,198 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : 6) void k_skm_emit_w
     if ((threadIdx.x & 63u) == 0 && n_rec) atomicAdd(&sg.ctr[5], (unsigned long long)n_rec);
 }
 
+// ---- S1, batches of equal-length reads: a LANE per read (round 5) ---------------------------------------------------
+// The wave kernel above deals a group of 7 reads over the lanes three different ways (a lane per packed word, per chunk of k-mer
+// starts, per run) with the order values, the run starts and their minimizers passing through LDS between the phases: 57
+// lane-instructions per base, a third of the lanes idle in every phase (100 bases are 6.25 words; 7 reads are 49 words and 63 chunks).
+// Here a lane takes ONE READ and walks its m-mers in order, all 64 lanes at the same position -- so everything that depends on the
+// position alone (which words, which shifts, whether a k-mer ends here) is scalar -- and the window minimum is the streaming form of
+// the block decomposition: m-mers in blocks of B = 20; the k-mer whose window ENDS at m-mer p takes min(suffix minimum of the block
+// it starts in, [the whole block between, for w = 40,] prefix minimum of the block p is in); a block's values overwrite the suffix
+// minima they have just been compared with, and one backward pass turns them into the next block's suffix minima.  Per m-mer:
+// two extractions (forward and reverse complement from the block's 64-bit window, constant shifts), a minimum, the order multiply;
+// per k-mer: three minima and a compare.  A lane whose minimizer changes appends the run it has just finished -- (minimizer, read,
+// first k-mer, length) -- to the wave's list in LDS (ballot + mbcnt; one in thirteen lanes per position), and every few blocks the
+// list is turned into records a lane per RUN, all lanes busy: the record code of the kernels above, unchanged, so the records are
+// the same records.  No order value, window minimum or run start ever goes through LDS; the words do, once.
+// Work is dealt statically (group g to wave g mod waves): a wave has ~19 groups of 64 reads per 7.5 M-read sample, tickets of any
+// useful size would leave a tail of a ticket, and the device-wide counter is not in the picture.
+// Instances: w = 20 (k = 31: C = 1) and w = 40 (k = 51: C = 2), m = 12, reads of up to 16 x NW bases; everything else takes the kernels above.
+#define SKM_LANE_B 20
+#define SKM_LANE_CAP 384u         // finished runs a wave lists between two flushes (64 reads x 40 k-mers bring ~250; what does not fit is written at once)
+#define SKM_LANE_THREADS 512
+__host__ __device__ inline uint32_t skm_lane_slice_words(uint32_t wpr) { return 64u * wpr + 4u + 2u * SKM_LANE_CAP; }
+
+// one block of B m-mers for every lane's read: Sold holds the suffix minima of the block the finishing k-mers START in (C blocks
+// back) and receives this block's values; Smid (C = 2) the suffix minima of the block between, Smid[0] its minimum
+template <int C, typename Append>
+__device__ __forceinline__ void skm_lane_block(const uint32_t *wl, uint32_t rbase, uint32_t lane, uint32_t b, uint32_t npos, uint32_t nk,
+                                               uint32_t (&Sold)[SKM_LANE_B], const uint32_t (&Smid)[SKM_LANE_B], uint32_t &prev_v, uint32_t &start_prev,
+                                               uint32_t &n_ent, Append append)
+{
+    constexpr int B = SKM_LANE_B;
+    const uint32_t bit0 = 2u * B * b, w0 = bit0 >> 5, s0 = bit0 & 31u;
+    const uint32_t x0 = wl[rbase + w0], x1 = wl[rbase + w0 + 1u], x2 = wl[rbase + w0 + 2u];
+    const uint32_t xlo = __builtin_amdgcn_alignbit(x1, x0, s0), xhi = __builtin_amdgcn_alignbit(x2, x1, s0);
+    const uint64_t X = (uint64_t)xlo | ((uint64_t)xhi << 32);          // bases 20 b .. 20 b + 31 of the read
+    const uint64_t R = ~skm_rev2_64(X);                                // their reverse complement: the m-mer at base j in bits 40 - 2 j .. 63 - 2 j
+    uint32_t pre = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+        const uint32_t p = (uint32_t)B * b + (uint32_t)j;
+        if (p >= npos) break;                                          // (the same for every lane: a scalar branch)
+        const uint32_t f = (uint32_t)(X >> (2 * j)) & 0xffffffu, rv = (uint32_t)(R >> (40 - 2 * j)) & 0xffffffu;
+        const uint32_t val = skm_order32(f < rv ? f : rv);
+        pre = min(pre, val);
+        if (p + 1u >= (uint32_t)(C * B)) {
+            const uint32_t i = p + 1u - (uint32_t)(C * B);             // the k-mer whose window ends at this m-mer
+            if (i < nk) {
+                uint32_t minv;
+                if (C == 1) minv = j == B - 1 ? pre : min(Sold[j == B - 1 ? 0 : j + 1], pre);
+                else minv = j == B - 1 ? min(Smid[0], pre) : min(min(Sold[j == B - 1 ? 0 : j + 1], Smid[0]), pre);
+                if (i == 0u) {
+                    prev_v = minv; start_prev = lane;                 // lane | first k-mer << 6: the upper word of the run's entry, but for its end
+                } else {
+                    // (a lane that finds the list full keeps its run open and asks again at the next k-mer, after the flush that full
+                    // list brings about: the run is then cut a few k-mers late -- k-mers in a bucket other than their minimizer's, which
+                    // costs deduplication, never correctness: adds of a k-mer's occurrences compose whichever buckets they met in)
+                    // (lanes without a read walk words of zeros: one minimizer from end to end, no run ever finishes)
+                    const bool want = minv != prev_v;
+                    const unsigned long long bal = __ballot(want);
+                    if (want && append(bal, prev_v, start_prev, i)) { prev_v = minv; start_prev = lane | (i << 6); }
+                    n_ent += (uint32_t)__popcll(bal);
+                }
+            }
+        }
+        Sold[j] = val;
+    }
+#pragma unroll
+    for (int j = B - 2; j >= 0; --j) Sold[j] = min(Sold[j], Sold[j + 1]);
+}
+
+template <int C, int NW>
+__global__ __launch_bounds__(SKM_LANE_THREADS, 6) void k_skm_emit_lane(ReadsDev rd, SkmGeom sg, uint32_t n_groups, uint32_t flush_blocks)
+{
+    constexpr int B = SKM_LANE_B;
+    __shared__ uint32_t cur[256];
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwaves = SKM_LANE_THREADS / 64;
+    const uint32_t L = rd.uni_len, wpr = (L + 15u) >> 4, nk = L - (uint32_t)sg.k + 1u, npos = L - 12u + 1u;
+    uint32_t *wl = smem + wave * skm_lane_slice_words(wpr);
+    unsigned long long *ent = (unsigned long long *)(wl + 64u * wpr + 4u);
+    for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_LANE_THREADS) cur[c] = 0;
+    __syncthreads();
+    uint64_t n_rec = 0;
+    uint64_t *const my_seg = sg.seg1 + (uint64_t)blockIdx.x * sg.cap1 * (uint64_t)sg.recw;       // + coarse * cstride: this workgroup's segment of a coarse bucket
+    const uint64_t cstride = (uint64_t)sg.nwg1 * sg.cap1 * (uint64_t)sg.recw;
+    const uint64_t n_words = rd.n_reads * (uint64_t)wpr;
+    const uint32_t nblocks = (npos + B - 1u) / B;
+    const uint32_t gstep = gridDim.x * nwaves;
+    // words of group g as the wave loads them: word t = lane + 64 i of the group's 64 x wpr
+    // (lanes and words beyond the batch's end read as zeros)
+    auto fetch = [&](uint32_t g, uint32_t (&dst)[NW]) {
+        const uint64_t first = (uint64_t)g * 64u * wpr;
+        const uint32_t *gw = rd.words + first;
+        const uint32_t have = (uint32_t)min((uint64_t)64u * wpr, n_words - first);
+        uint32_t ln = lane;
+        asm volatile("" : "+v"(ln));              // (or the 64-bit addresses of all NW words are computed once in front of the loop, and spilled)
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const uint32_t t = ln + 64u * (uint32_t)i;
+            dst[i] = t < have ? gw[t] : 0u;
+        }
+    };
+    uint32_t pf[NW];
+    uint32_t g = blockIdx.x * nwaves + wave;
+    if (g < n_groups) fetch(g, pf);
+    for (; g < n_groups; g += gstep) {
+        const uint64_t r0 = (uint64_t)g * 64u;
+        const uint32_t nr = (uint32_t)min((uint64_t)64u, rd.n_reads - r0);
+        const bool active = lane < nr;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            if ((uint32_t)i < wpr) wl[lane + 64u * (uint32_t)i] = pf[i];
+        if (lane < 4u) wl[64u * wpr + lane] = 0u;
+        // the next group's words are requested now; they are waited for in front of the first flush (below), not at the top of the
+        // next round, where the wait would also cover this round's record stores
+        const bool more = g + gstep < n_groups;
+        if (more) fetch(g + gstep, pf);
+        bool pf_waited = !more;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // a finished run as records (a run of more than ncap k-mers is cut)
+        auto emit_run = [&](uint32_t v, uint32_t r, uint32_t j, uint32_t left) {
+            uint32_t coarse, fine;
+            skm_bucket_of(v, sg.C1, sg.fbits, coarse, fine);
+            uint64_t pos = (sg.read_base + r0 + r) * sg.stride + j;
+            uint32_t bidx = r * wpr * 16u + j;
+            while (left) {
+                const uint32_t n = min(left, (uint32_t)sg.ncap);
+                uint64_t bw[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? skm_bases32(wl, bidx + 32u * t) : 0ull;
+                const uint64_t hdr = skm_header(pos, n, fine);
+                const uint32_t p = atomicAdd(&cur[coarse], 1u);
+                if (p < sg.cap1) skm_store_record_wide(my_seg + coarse * cstride + p * (uint32_t)sg.recw, hdr, bw, sg.nbw);
+                else skm_loose_push(sg, hdr, bw);
+                n_rec += 1;
+                left -= n; pos += n; bidx += n;
+            }
+        };
+        uint32_t n_ent = 0;
+        // an entry: the run's minimizer | (lane | first k-mer << 6 | the k-mer behind its last << 18) << 32
+        auto append = [&](unsigned long long bal, uint32_t v, uint32_t lane_start, uint32_t end) -> bool {
+            const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, n_ent));
+            if (slot >= SKM_LANE_CAP) return false;                   // (a wave of reads that change minimizer at nearly every k-mer)
+            ent[slot] = (unsigned long long)v | ((unsigned long long)(lane_start | (end << 18)) << 32);
+            return true;
+        };
+        auto flush = [&]() {
+            if (!pf_waited) {
+#pragma unroll
+                for (int i = 0; i < NW; ++i) asm volatile("" : "+v"(pf[i]));          // the prefetched words have arrived from here on
+                pf_waited = true;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n = min(n_ent, SKM_LANE_CAP);
+            for (uint32_t e = lane; e < n; e += 64u) {
+                const unsigned long long en = ent[e];
+                const uint32_t hi = (uint32_t)(en >> 32), first = (hi >> 6) & 4095u;
+                emit_run((uint32_t)en, hi & 63u, first, (hi >> 18) - first);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            n_ent = 0;
+        };
+        uint32_t Sa[B], Sb[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) { Sa[j] = 0xffffffffu; Sb[j] = 0xffffffffu; }
+        uint32_t prev_v = 0, start_prev = 0;
+        const uint32_t rbase = lane * wpr;
+        uint32_t since = 0;
+        for (uint32_t b = 0; b < nblocks; b += (C == 2 ? 2u : 1u)) {
+            skm_lane_block<C>(wl, rbase, lane, b, npos, nk, Sa, Sb, prev_v, start_prev, n_ent, append);
+            if (C == 2 && b + 1u < nblocks) skm_lane_block<C>(wl, rbase, lane, b + 1u, npos, nk, Sb, Sa, prev_v, start_prev, n_ent, append);
+            since += (C == 2 ? 2u : 1u);
+            // (the last block's runs leave with the final ones; a list that is filling up is flushed whatever the count says)
+            if ((since >= flush_blocks || n_ent + 64u * B > SKM_LANE_CAP) && n_ent && b + (C == 2 ? 2u : 1u) < nblocks) { flush(); since = 0; }
+        }
+        // the run every read ends in (room for all 64: the list is emptied first if need be)
+        if (n_ent + 64u > SKM_LANE_CAP) flush();
+        {
+            const unsigned long long bal = __ballot(active);
+            if (active) (void)append(bal, prev_v, start_prev, nk);
+            n_ent += (uint32_t)__popcll(bal);
+        }
+        flush();
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_LANE_THREADS) sg.cnt1[(uint64_t)c * sg.nwg1 + blockIdx.x] = min(cur[c], sg.cap1);
+    n_rec = wave_sum_u64(n_rec);
+    if ((threadIdx.x & 63u) == 0 && n_rec) atomicAdd(&sg.ctr[5], (unsigned long long)n_rec);
+}
+
 // ---- S2 ------------------------------------------------------------------------------------------------
 #define SKM_THREADS2 512
 #define SKM_MAX_F2 4096u          // fine buckets per coarse bucket (12 bits of a k-mer's bucket id in S1; 16 in a record header)
@@ -1819,10 +2011,34 @@ static uint32_t skm_wave_plan(const SkmGeom &g, const kv_reads *reads, int *ch)
     return best;
 }
 
+// the lane-per-read kernel takes batches of equal-length reads with w = 20 or 40 (k = 31, 51: m = 12) and up to 256 bases;
+// KV_SKM_S1=wave|tile keeps the older kernels
+static bool skm_lane_fits(const SkmGeom &g, const kv_reads *reads)
+{
+    const uint32_t L = reads->uni_len;
+    if (!L || L < (uint32_t)g.k || g.m != 12 || (g.w != SKM_LANE_B && g.w != 2 * SKM_LANE_B) || L > 256u) return false;
+    if (const char *e = getenv("KV_SKM_S1")) if (strcmp(e, "lane") != 0) return false;
+    if (g.dbg & ~4096u) return false;                           // the phase switches of the dissection scripts live in the older kernels
+    return (size_t)skm_lane_slice_words((L + 15u) / 16u) * 4 * (SKM_LANE_THREADS / 64) + 1200 <= 54000u;       // three workgroups per CU
+}
+
 void skm_launch_emit(const SkmGeom &g, const kv_reads *reads, hipStream_t st)
 {
     KvProfScope prof("k_skm_emit");
     int ch = 16;
+    if (skm_lane_fits(g, reads)) {
+        const uint32_t wpr = (reads->uni_len + 15u) / 16u;
+        const size_t lds = (size_t)skm_lane_slice_words(wpr) * 4 * (SKM_LANE_THREADS / 64);
+        const uint64_t n_groups = (reads->n_reads + 63) / 64;
+        uint32_t flush_blocks = 2;
+        if (const char *e = getenv("KV_SKM_LANE_FLUSH")) flush_blocks = std::max(1, atoi(e));
+        void (*kernel)(ReadsDev, SkmGeom, uint32_t, uint32_t);
+        if (g.w == SKM_LANE_B) kernel = wpr <= 8 ? k_skm_emit_lane<1, 8> : k_skm_emit_lane<1, 16>;
+        else kernel = wpr <= 8 ? k_skm_emit_lane<2, 8> : k_skm_emit_lane<2, 16>;
+        kv_ensure_dynamic_lds((const void *)kernel, lds);
+        hipLaunchKernelGGL(kernel, dim3(g.nwg1), dim3(SKM_LANE_THREADS), lds, st, reads_dev(reads), g, (uint32_t)n_groups, flush_blocks);
+        return;
+    }
     if (const uint32_t R = skm_wave_plan(g, reads, &ch)) {
         const uint32_t L = reads->uni_len, nk = L - (uint32_t)g.k + 1;
         const uint32_t threads = skm_wave_threads(), nwaves = threads / 64;
