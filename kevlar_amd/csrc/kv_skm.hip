@@ -608,13 +608,26 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : 6) void k_skm_emit_w
 // useful size would leave a tail of a ticket, and the device-wide counter is not in the picture.
 // Instances: w = 20 (k = 31: C = 1) and w = 40 (k = 51: C = 2), m = 12, reads of up to 16 x NW bases; everything else takes the kernels above.
 #define SKM_LANE_B 20
+#if !defined(SKM_LANE_FULL)
+#define SKM_LANE_FULL 0           // 1: blocks in the middle of a read run without the per-position scalar tests (measured: slower)
+#endif
+#if !defined(SKM_LANE_BRANCHFREE)
+#define SKM_LANE_BRANCHFREE 0     // 1: every lane writes an entry at every k-mer, lanes without a finished run to a dummy slot (no exec regions)
+#endif
+#if !defined(SKM_LANE_CAP)
 #define SKM_LANE_CAP 384u         // finished runs a wave lists between two flushes (64 reads x 40 k-mers bring ~250; what does not fit is written at once)
+#endif
 #define SKM_LANE_THREADS 512
-__host__ __device__ inline uint32_t skm_lane_slice_words(uint32_t wpr) { return 64u * wpr + 4u + 2u * SKM_LANE_CAP; }
+#if !defined(SKM_LANE_WAVES)
+#define SKM_LANE_WAVES 6          // waves per SIMD the kernel is compiled for (3 workgroups per CU)
+#endif
+__host__ __device__ inline uint32_t skm_lane_slice_words(uint32_t wpr) { return 64u * wpr + 4u + 2u * SKM_LANE_CAP + 2u; }
 
 // one block of B m-mers for every lane's read: Sold holds the suffix minima of the block the finishing k-mers START in (C blocks
 // back) and receives this block's values; Smid (C = 2) the suffix minima of the block between, Smid[0] its minimum
-template <int C, typename Append>
+// FULL: every m-mer of the block exists and a k-mer > 0 of the read ends at each of them (the blocks in the middle of a read: no
+// per-position tests, which are scalar but not free -- a compare and a branch each, 13 scalar instructions per m-mer with them)
+template <int C, bool FULL, typename Append>
 __device__ __forceinline__ void skm_lane_block(const uint32_t *wl, uint32_t rbase, uint32_t lane, uint32_t b, uint32_t npos, uint32_t nk,
                                                uint32_t (&Sold)[SKM_LANE_B], const uint32_t (&Smid)[SKM_LANE_B], uint32_t &prev_v, uint32_t &start_prev,
                                                uint32_t &n_ent, Append append)
@@ -629,17 +642,17 @@ __device__ __forceinline__ void skm_lane_block(const uint32_t *wl, uint32_t rbas
 #pragma unroll
     for (int j = 0; j < B; ++j) {
         const uint32_t p = (uint32_t)B * b + (uint32_t)j;
-        if (p >= npos) break;                                          // (the same for every lane: a scalar branch)
+        if (!FULL && p >= npos) break;                                 // (the same for every lane: a scalar branch)
         const uint32_t f = (uint32_t)(X >> (2 * j)) & 0xffffffu, rv = (uint32_t)(R >> (40 - 2 * j)) & 0xffffffu;
         const uint32_t val = skm_order32(f < rv ? f : rv);
         pre = min(pre, val);
-        if (p + 1u >= (uint32_t)(C * B)) {
+        if (FULL || p + 1u >= (uint32_t)(C * B)) {
             const uint32_t i = p + 1u - (uint32_t)(C * B);             // the k-mer whose window ends at this m-mer
-            if (i < nk) {
+            if (FULL || i < nk) {
                 uint32_t minv;
                 if (C == 1) minv = j == B - 1 ? pre : min(Sold[j == B - 1 ? 0 : j + 1], pre);
                 else minv = j == B - 1 ? min(Smid[0], pre) : min(min(Sold[j == B - 1 ? 0 : j + 1], Smid[0]), pre);
-                if (i == 0u) {
+                if (!FULL && i == 0u) {
                     prev_v = minv; start_prev = lane;                 // lane | first k-mer << 6: the upper word of the run's entry, but for its end
                 } else {
                     // (a lane that finds the list full keeps its run open and asks again at the next k-mer, after the flush that full
@@ -648,7 +661,13 @@ __device__ __forceinline__ void skm_lane_block(const uint32_t *wl, uint32_t rbas
                     // (lanes without a read walk words of zeros: one minimizer from end to end, no run ever finishes)
                     const bool want = minv != prev_v;
                     const unsigned long long bal = __ballot(want);
-                    if (want && append(bal, prev_v, start_prev, i)) { prev_v = minv; start_prev = lane | (i << 6); }
+#if SKM_LANE_BRANCHFREE
+                    const bool done = append(bal, want, prev_v, start_prev, i);
+                    prev_v = done ? minv : prev_v;
+                    start_prev = done ? (lane | (i << 6)) : start_prev;
+#else
+                    if (want && append(bal, true, prev_v, start_prev, i)) { prev_v = minv; start_prev = lane | (i << 6); }
+#endif
                     n_ent += (uint32_t)__popcll(bal);
                 }
             }
@@ -660,7 +679,7 @@ __device__ __forceinline__ void skm_lane_block(const uint32_t *wl, uint32_t rbas
 }
 
 template <int C, int NW>
-__global__ __launch_bounds__(SKM_LANE_THREADS, 6) void k_skm_emit_lane(ReadsDev rd, SkmGeom sg, uint32_t n_groups, uint32_t flush_blocks)
+__global__ __launch_bounds__(SKM_LANE_THREADS, SKM_LANE_WAVES) void k_skm_emit_lane(ReadsDev rd, SkmGeom sg, uint32_t n_groups, uint32_t flush_blocks)
 {
     constexpr int B = SKM_LANE_B;
     __shared__ uint32_t cur[256];
@@ -722,7 +741,11 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, 6) void k_skm_emit_lane(ReadsDev 
                 for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? skm_bases32(wl, bidx + 32u * t) : 0ull;
                 const uint64_t hdr = skm_header(pos, n, fine);
                 const uint32_t p = atomicAdd(&cur[coarse], 1u);
+#if defined(SKM_HACK_ONESTORE)          // timing experiment only: one 16-byte store per record
+                if (p < sg.cap1) { typedef uint64_t u64x2 __attribute__((ext_vector_type(2), aligned(8))); *(u64x2 *)(my_seg + coarse * cstride + p * (uint32_t)sg.recw) = u64x2{hdr, bw[0]}; }
+#else
                 if (p < sg.cap1) skm_store_record_wide(my_seg + coarse * cstride + p * (uint32_t)sg.recw, hdr, bw, sg.nbw);
+#endif
                 else skm_loose_push(sg, hdr, bw);
                 n_rec += 1;
                 left -= n; pos += n; bidx += n;
@@ -730,11 +753,19 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, 6) void k_skm_emit_lane(ReadsDev 
         };
         uint32_t n_ent = 0;
         // an entry: the run's minimizer | (lane | first k-mer << 6 | the k-mer behind its last << 18) << 32
-        auto append = [&](unsigned long long bal, uint32_t v, uint32_t lane_start, uint32_t end) -> bool {
-            const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, n_ent));
+        auto append = [&](unsigned long long bal, bool want, uint32_t v, uint32_t lane_start, uint32_t end) -> bool {
+            uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, n_ent));
+#if SKM_LANE_BRANCHFREE
+            const bool ok = want && slot < SKM_LANE_CAP;
+            slot = ok ? slot : SKM_LANE_CAP;                          // (slot CAP: the word nobody reads)
+            ent[slot] = (unsigned long long)v | ((unsigned long long)(lane_start | (end << 18)) << 32);
+            return ok;
+#else
+            (void)want;
             if (slot >= SKM_LANE_CAP) return false;                   // (a wave of reads that change minimizer at nearly every k-mer)
             ent[slot] = (unsigned long long)v | ((unsigned long long)(lane_start | (end << 18)) << 32);
             return true;
+#endif
         };
         auto flush = [&]() {
             if (!pf_waited) {
@@ -761,17 +792,23 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, 6) void k_skm_emit_lane(ReadsDev 
         const uint32_t rbase = lane * wpr;
         uint32_t since = 0;
         for (uint32_t b = 0; b < nblocks; b += (C == 2 ? 2u : 1u)) {
-            skm_lane_block<C>(wl, rbase, lane, b, npos, nk, Sa, Sb, prev_v, start_prev, n_ent, append);
-            if (C == 2 && b + 1u < nblocks) skm_lane_block<C>(wl, rbase, lane, b + 1u, npos, nk, Sb, Sa, prev_v, start_prev, n_ent, append);
+            // block b is FULL when its first m-mer ends k-mer 1 or a later one and its last m-mer ends a k-mer of the read
+            auto full = [&](uint32_t bb) { return (uint32_t)B * bb + 1u > (uint32_t)(C * B) && (uint32_t)B * bb + (uint32_t)B <= nk + (uint32_t)(C * B) - 1u; };
+            if (SKM_LANE_FULL && full(b)) skm_lane_block<C, true>(wl, rbase, lane, b, npos, nk, Sa, Sb, prev_v, start_prev, n_ent, append);
+            else skm_lane_block<C, false>(wl, rbase, lane, b, npos, nk, Sa, Sb, prev_v, start_prev, n_ent, append);
+            if (C == 2 && b + 1u < nblocks) {
+                if (SKM_LANE_FULL && full(b + 1u)) skm_lane_block<C, true>(wl, rbase, lane, b + 1u, npos, nk, Sb, Sa, prev_v, start_prev, n_ent, append);
+                else skm_lane_block<C, false>(wl, rbase, lane, b + 1u, npos, nk, Sb, Sa, prev_v, start_prev, n_ent, append);
+            }
             since += (C == 2 ? 2u : 1u);
             // (the last block's runs leave with the final ones; a list that is filling up is flushed whatever the count says)
-            if ((since >= flush_blocks || n_ent + 64u * B > SKM_LANE_CAP) && n_ent && b + (C == 2 ? 2u : 1u) < nblocks) { flush(); since = 0; }
+            if ((since >= flush_blocks || n_ent + 192u > SKM_LANE_CAP) && n_ent && b + (C == 2 ? 2u : 1u) < nblocks) { flush(); since = 0; }
         }
         // the run every read ends in (room for all 64: the list is emptied first if need be)
         if (n_ent + 64u > SKM_LANE_CAP) flush();
         {
             const unsigned long long bal = __ballot(active);
-            if (active) (void)append(bal, prev_v, start_prev, nk);
+            if (active) (void)append(bal, true, prev_v, start_prev, nk);
             n_ent += (uint32_t)__popcll(bal);
         }
         flush();
@@ -1157,12 +1194,20 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
             const uint32_t j0 = t < total ? (t - (oe & 0xffffu)) * G : 0u;
             const uint32_t cnt = t < total ? min(G, (oe >> 16) - j0) : 0u;     // k-mers of this unit: 1..G (0: no unit)
             SkmKey<KW> fw = skm_kmer_of<KW>(o0, o1, o2, j0, k);
+#if defined(SKM_HACK_NOCANON)          // timing experiment only (results are wrong): what the walk costs without the other strand
+            SkmKey<KW> rc = fw;
+#else
             SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
+#endif
             const uint32_t tail = (uint32_t)skm_window64(o0, o1, o2, j0 + (uint32_t)k);   // the bases that enter k-mers 1 .. G - 1
             const uint64_t pos0 = skm_hdr_pos(oh) + j0;
 #pragma unroll
             for (uint32_t u = 0; u < G; ++u) {
+#if defined(SKM_HACK_NOCANON)
+                if (u) { SkmKey<KW> dummy = fw; skm_roll<KW>(fw, dummy, (tail >> (2u * (u - 1u))) & 3u, k); rc = fw; }
+#else
                 if (u) skm_roll<KW>(fw, rc, (tail >> (2u * (u - 1u))) & 3u, k);
+#endif
                 bool alone = false;
                 if (u < cnt) alone = body(skm_canonical<KW>(fw, rc), fw, pos0 + u);
                 skm_walk_loose<KW, WANT_POS>(sg, alone, fw, hdr, owner, pos0, j0, u, lane, recw);
@@ -2019,7 +2064,7 @@ static bool skm_lane_fits(const SkmGeom &g, const kv_reads *reads)
     if (!L || L < (uint32_t)g.k || g.m != 12 || (g.w != SKM_LANE_B && g.w != 2 * SKM_LANE_B) || L > 256u) return false;
     if (const char *e = getenv("KV_SKM_S1")) if (strcmp(e, "lane") != 0) return false;
     if (g.dbg & ~4096u) return false;                           // the phase switches of the dissection scripts live in the older kernels
-    return (size_t)skm_lane_slice_words((L + 15u) / 16u) * 4 * (SKM_LANE_THREADS / 64) + 1200 <= 54000u;       // three workgroups per CU
+    return (size_t)skm_lane_slice_words((L + 15u) / 16u) * 4 * (SKM_LANE_THREADS / 64) + 1200 <= 160000u / (SKM_LANE_WAVES / 2);       // three workgroups per CU
 }
 
 void skm_launch_emit(const SkmGeom &g, const kv_reads *reads, hipStream_t st)
