@@ -53,6 +53,14 @@ struct SkmGeom {
     uint32_t n_src;
     const uint64_t *seg1_off;        // non-null: segment `slot` starts at record seg1_off[slot] (compacted records) instead of slot * cap1
     uint64_t read_base;              // global index of the batch's first read (record positions of a read shard; 0 otherwise)
+    // seg1 / cnt1 laid out [nwg1][C1] instead of [C1][nwg1]: a writer's ~250 open segments then lie within a few megabytes -- two or
+    // three pages of the address translation -- instead of one every nwg1 x cap1 records (11 MB: a page each).  The exchange
+    // layouts keep bucket-major order (a destination's coarse buckets must be contiguous: kv_skm_mex_pack).
+    uint32_t seg1_wmajor;
+    // compact: the records of this batch are 16-byte records without positions (kv_skm_device.h; recw = 2) -- a count into a sketch
+    // that is not going to be scanned from this batch.  Loose records keep the classic form: lrecw = 1 + nbw words each.
+    uint32_t compact;
+    int lrecw;
 };
 
 // segment `seg` of coarse bucket c in seg1 / cnt1, counted in segments
@@ -62,6 +70,7 @@ struct SkmGeom {
 #define SKM_DBG(sg) (KNOBS ? (sg).dbg : 0u)
 __device__ __forceinline__ uint64_t skm_seg1_slot(const SkmGeom &sg, uint32_t c, uint32_t seg)
 {
+    if (sg.seg1_wmajor) return (uint64_t)seg * sg.C1 + c;
     if (sg.n_src <= 1u) return (uint64_t)c * sg.nwg1 + seg;
     const uint32_t src = seg / sg.nwg1, w = seg - src * sg.nwg1;
     return ((uint64_t)src * sg.C1 + c) * sg.nwg1 + w;
@@ -120,7 +129,7 @@ __device__ __forceinline__ void skm_store_record(uint64_t *dst, uint64_t hdr, co
 __device__ __forceinline__ void skm_loose_push(const SkmGeom &sg, uint64_t hdr, const uint64_t *bw)
 {
     const unsigned long long idx = atomicAdd(&sg.ctr[0], 1ull);
-    if (idx < sg.loose_cap) skm_store_record(sg.loose + idx * (uint64_t)sg.recw, hdr, bw, sg.nbw);
+    if (idx < sg.loose_cap) skm_store_record(sg.loose + idx * (uint64_t)sg.lrecw, hdr, bw, sg.nbw);
     else sg.ctr[1] = 1;
 }
 
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
                 const uint64_t hdr = skm_header(pos, n, fine);
                 const uint32_t p = atomicAdd(&cur[coarse], 1u);
                 if (SKM_DBG(sg) & 1024u) n_rec += hdr ^ bw[0] ^ bw[1];
-                else if (p < sg.cap1) skm_store_record(sg.seg1 + (((uint64_t)coarse * sg.nwg1 + blockIdx.x) * sg.cap1 + p) * (uint64_t)sg.recw, hdr, bw, sg.nbw);
+                else if (p < sg.cap1) skm_store_record(sg.seg1 + (skm_seg1_slot(sg, coarse, blockIdx.x) * sg.cap1 + p) * (uint64_t)sg.recw, hdr, bw, sg.nbw);
                 else skm_loose_push(sg, hdr, bw);
                 n_rec += 1;
                 left -= n; pos += n; b += n;
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
         }
     }
     __syncthreads();
-    for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_THREADS1) sg.cnt1[(uint64_t)c * sg.nwg1 + blockIdx.x] = min(cur[c], sg.cap1);
+    for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_THREADS1) sg.cnt1[skm_seg1_slot(sg, c, blockIdx.x)] = min(cur[c], sg.cap1);
     n_rec = wave_sum_u64(n_rec);
     if ((threadIdx.x & 63) == 0 && n_rec) atomicAdd(&sg.ctr[5], (unsigned long long)n_rec);
 }
@@ -446,8 +455,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : 6) void k_skm_emit_w
     const uint32_t mmask = m == 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
     const uint32_t rc0 = 2u * (32u - (uint32_t)m);
     uint64_t n_rec = 0;
-    uint64_t *const my_seg = sg.seg1 + (uint64_t)blockIdx.x * sg.cap1 * (uint64_t)sg.recw;       // + coarse * cstride: this workgroup's segment of a coarse bucket
-    const uint64_t cstride = (uint64_t)sg.nwg1 * sg.cap1 * (uint64_t)sg.recw;
+    uint64_t *const my_seg = sg.seg1 + skm_seg1_slot(sg, 0u, blockIdx.x) * sg.cap1 * (uint64_t)sg.recw;       // + coarse * cstride: this workgroup's segment of a coarse bucket
+    const uint64_t cstride = (sg.seg1_wmajor ? 1ull : (uint64_t)sg.nwg1) * sg.cap1 * (uint64_t)sg.recw;
     uint32_t mt = 0, mt_end = 0, taken = 0, pf = 0, pf_mt = 0xffffffffu, parity = 0;
     for (;;) {
         // (everything P1 and P2 derive from the lane number alone is the same for every group; left to itself the compiler
@@ -585,7 +594,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : 6) void k_skm_emit_w
         mt += 1; taken += 1;
     }
     __syncthreads();
-    for (uint32_t c = threadIdx.x; c < sg.C1; c += THREADS) sg.cnt1[(uint64_t)c * sg.nwg1 + blockIdx.x] = min(cur[c], sg.cap1);
+    for (uint32_t c = threadIdx.x; c < sg.C1; c += THREADS) sg.cnt1[skm_seg1_slot(sg, c, blockIdx.x)] = min(cur[c], sg.cap1);
     n_rec = wave_sum_u64(n_rec);
     if ((threadIdx.x & 63u) == 0 && n_rec) atomicAdd(&sg.ctr[5], (unsigned long long)n_rec);
 }
@@ -691,8 +700,8 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, SKM_LANE_WAVES) void k_skm_emit_l
     for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_LANE_THREADS) cur[c] = 0;
     __syncthreads();
     uint64_t n_rec = 0;
-    uint64_t *const my_seg = sg.seg1 + (uint64_t)blockIdx.x * sg.cap1 * (uint64_t)sg.recw;       // + coarse * cstride: this workgroup's segment of a coarse bucket
-    const uint64_t cstride = (uint64_t)sg.nwg1 * sg.cap1 * (uint64_t)sg.recw;
+    uint64_t *const my_seg = sg.seg1 + skm_seg1_slot(sg, 0u, blockIdx.x) * sg.cap1 * (uint64_t)sg.recw;       // + coarse * cstride: this workgroup's segment of a coarse bucket
+    const uint64_t cstride = (sg.seg1_wmajor ? 1ull : (uint64_t)sg.nwg1) * sg.cap1 * (uint64_t)sg.recw;
     const uint64_t n_words = rd.n_reads * (uint64_t)wpr;
     const uint32_t nblocks = (npos + B - 1u) / B;
     const uint32_t gstep = gridDim.x * nwaves;
@@ -743,8 +752,17 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, SKM_LANE_WAVES) void k_skm_emit_l
                 const uint32_t p = atomicAdd(&cur[coarse], 1u);
 #if defined(SKM_HACK_ONESTORE)          // timing experiment only: one 16-byte store per record
                 if (p < sg.cap1) { typedef uint64_t u64x2 __attribute__((ext_vector_type(2), aligned(8))); *(u64x2 *)(my_seg + coarse * cstride + p * (uint32_t)sg.recw) = u64x2{hdr, bw[0]}; }
+#elif defined(SKM_LANE_DISSECT) && SKM_LANE_DISSECT == 3
+                if (p < sg.cap1) n_rec += hdr ^ bw[0] ^ bw[1];
 #else
-                if (p < sg.cap1) skm_store_record_wide(my_seg + coarse * cstride + p * (uint32_t)sg.recw, hdr, bw, sg.nbw);
+                if (p < sg.cap1) {
+                    if (sg.compact) {                                 // one aligned 16-byte store: bases, n and the fine bucket (no position)
+                        typedef uint64_t u64x2a __attribute__((ext_vector_type(2), aligned(16)));
+                        *(u64x2a *)(my_seg + coarse * cstride + p * 2u) = u64x2a{bw[0], skm_c_pack1(bw[1], n, fine)};
+                    } else {
+                        skm_store_record_wide(my_seg + coarse * cstride + p * (uint32_t)sg.recw, hdr, bw, sg.nbw);
+                    }
+                }
 #endif
                 else skm_loose_push(sg, hdr, bw);
                 n_rec += 1;
@@ -763,7 +781,11 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, SKM_LANE_WAVES) void k_skm_emit_l
 #else
             (void)want;
             if (slot >= SKM_LANE_CAP) return false;                   // (a wave of reads that change minimizer at nearly every k-mer)
+#if defined(SKM_LANE_DISSECT) && SKM_LANE_DISSECT == 2
+            n_rec += v ^ lane_start ^ end;
+#else
             ent[slot] = (unsigned long long)v | ((unsigned long long)(lane_start | (end << 18)) << 32);
+#endif
             return true;
 #endif
         };
@@ -775,7 +797,11 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, SKM_LANE_WAVES) void k_skm_emit_l
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#if defined(SKM_LANE_DISSECT)        // timing experiments (results are wrong): 1 no records, 2 no run list either, 3 the records without their stores
+            const uint32_t n = SKM_LANE_DISSECT == 3 ? min(n_ent, SKM_LANE_CAP) : 0u;
+#else
             const uint32_t n = min(n_ent, SKM_LANE_CAP);
+#endif
             for (uint32_t e = lane; e < n; e += 64u) {
                 const unsigned long long en = ent[e];
                 const uint32_t hi = (uint32_t)(en >> 32), first = (hi >> 6) & 4095u;
@@ -814,7 +840,7 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, SKM_LANE_WAVES) void k_skm_emit_l
         flush();
     }
     __syncthreads();
-    for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_LANE_THREADS) sg.cnt1[(uint64_t)c * sg.nwg1 + blockIdx.x] = min(cur[c], sg.cap1);
+    for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_LANE_THREADS) sg.cnt1[skm_seg1_slot(sg, c, blockIdx.x)] = min(cur[c], sg.cap1);
     n_rec = wave_sum_u64(n_rec);
     if ((threadIdx.x & 63u) == 0 && n_rec) atomicAdd(&sg.ctr[5], (unsigned long long)n_rec);
 }
@@ -910,8 +936,14 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split_sorted(SkmGeom sg)
                 const uint32_t gi = c0 + i, si = skm_search(spre, nmine, gi);
                 const uint32_t seg = blockIdx.x + si * sg.nwg2;
                 const uint64_t *rec = sg.seg1 + (skm_seg1_first(sg, skm_seg1_slot(sg, c, seg)) + (gi - spre[si])) * (uint64_t)RECW;
-                nh[r] = rec[0]; n0[r] = rec[1]; n1[r] = rec[2];
-                if (RECW == 4) n2[r] = rec[3];
+                if (RECW == 2) {                                      // compact: the word that says the bucket is the second one
+                    typedef uint64_t u64x2a __attribute__((ext_vector_type(2), aligned(16)));
+                    const u64x2a both = *(const u64x2a *)rec;
+                    n0[r] = both.x; nh[r] = both.y;
+                } else {
+                    nh[r] = rec[0]; n0[r] = rec[1]; n1[r] = rec[2];
+                    if (RECW == 4) n2[r] = rec[3];
+                }
             }
         }
     };
@@ -925,7 +957,7 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split_sorted(SkmGeom sg)
         request(c0 + SKM_S2_CHUNK);
 #pragma unroll
         for (uint32_t r = 0; r < PER; ++r)
-            if (r * SKM_THREADS2 + threadIdx.x < n) rank[r] = atomicAdd(&hist[skm_hdr_fine(hdr[r])], 1u);
+            if (r * SKM_THREADS2 + threadIdx.x < n) rank[r] = atomicAdd(&hist[RECW == 2 ? skm_c_fine(hdr[r]) : skm_hdr_fine(hdr[r])], 1u);
         __syncthreads();
         // exclusive scan of the chunk's histogram; the bucket's run then starts at slot cur[f] of the private segment
         {
@@ -960,21 +992,27 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split_sorted(SkmGeom sg)
 #pragma unroll
         for (uint32_t r = 0; r < PER; ++r) {
             if (r * SKM_THREADS2 + threadIdx.x < n) {
-                uint64_t *dst = img + (uint64_t)(off[skm_hdr_fine(hdr[r])] + rank[r]) * RECW;
-                dst[0] = hdr[r]; dst[1] = w0[r]; dst[2] = w1[r];
+                uint64_t *dst = img + (uint64_t)(off[RECW == 2 ? skm_c_fine(hdr[r]) : skm_hdr_fine(hdr[r])] + rank[r]) * RECW;
+                if (RECW == 2) { dst[0] = w0[r]; dst[1] = hdr[r]; }
+                else { dst[0] = hdr[r]; dst[1] = w0[r]; dst[2] = w1[r]; }
                 if (RECW == 4) dst[3] = w2[r];
             }
         }
         __syncthreads();
         for (uint32_t wd = threadIdx.x; wd < n * RECW; wd += SKM_THREADS2) {
             const uint32_t q = wd / RECW, part = wd - q * RECW;
-            const uint64_t h0 = img[(uint64_t)q * RECW];
-            const uint32_t f = skm_hdr_fine(h0);
+            const uint64_t h0 = img[(uint64_t)q * RECW + (RECW == 2 ? 1 : 0)];
+            const uint32_t f = RECW == 2 ? skm_c_fine(h0) : skm_hdr_fine(h0);
             const uint32_t slot = q + hist[f];
             if (slot < sg.cap2) out[(uint64_t)f * fstride + (uint64_t)slot * RECW + part] = img[wd];
             else if (part == 0) {
-                uint64_t bw[3] = {img[(uint64_t)q * RECW + 1], img[(uint64_t)q * RECW + 2], RECW == 4 ? img[(uint64_t)q * RECW + 3] : 0ull};
-                skm_loose_push(sg, h0, bw);
+                if (RECW == 2) {                                      // a compact record leaves in the loose list's (classic) form, position unknown
+                    uint64_t bw[3] = {img[(uint64_t)q * RECW], skm_c_b1(h0), 0ull};
+                    skm_loose_push(sg, skm_header(0ull, skm_c_n(h0), f), bw);
+                } else {
+                    uint64_t bw[3] = {img[(uint64_t)q * RECW + 1], img[(uint64_t)q * RECW + 2], RECW == 4 ? img[(uint64_t)q * RECW + 3] : 0ull};
+                    skm_loose_push(sg, h0, bw);
+                }
             }
         }
         __syncthreads();
@@ -1136,13 +1174,25 @@ __device__ __forceinline__ void skm_walk_loose(const SkmGeom &sg, bool alone, co
 
 // body(canonical k-mer, forward k-mer, position of the occurrence) -> true if the occurrence could not be combined and
 // must travel alone through the loose list; WANT_POS = false skips fetching the header (count pass)
-template <int KW, bool WANT_POS, int FK = 0, typename Body>
+template <int KW, bool WANT_POS, int FK = 0, bool COMPACT = false, typename Body>
 __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, uint32_t *sbits_all, Body body)
 {
+    static_assert(!COMPACT || (KW == 1 && !WANT_POS), "compact records: one-word keys, no positions");
     constexpr uint32_t G = SKM_UNIT;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     uint32_t *sbits = sbits_all + wave * sg.sbw;       // sbw words: 64 records x ncap k-mers (units need fewer), + the word a 64-bit read may straddle into
-    const int k = FK ? FK : sg.k, recw = FK ? 1 + KW + 1 : sg.recw;        // FK: k (and with it the record width) known when compiled
+    const int k = FK ? FK : sg.k, recw = COMPACT ? 2 : (FK ? 1 + KW + 1 : sg.recw);        // FK: k (and with it the record width) known when compiled
+    // a compact record (16 bytes, one load) is taken apart into what the code below knows: a header without a position, two base words
+    auto load = [&](const uint64_t *rec, uint64_t &hdr, uint64_t &b0, uint64_t &b1, uint64_t &b2) {
+        if (COMPACT) {
+            typedef uint64_t u64x2a __attribute__((ext_vector_type(2), aligned(16)));
+            const u64x2a both = *(const u64x2a *)rec;
+            b0 = both.x; b1 = skm_c_b1(both.y); hdr = (uint64_t)skm_c_n(both.y) << SKM_POS_BITS;
+        } else {
+            hdr = rec[0]; b0 = rec[1]; b1 = rec[2];
+            if (KW == 2) b2 = rec[3];
+        }
+    };
     // Which records a wave takes does not depend on how full the bucket's segments are: pair p = wave, wave + nwaves, ...
     // is records [64 g, 64 g + 64) of segment s = p mod nwg2, g = p / nwg2.  The records are therefore requested together
     // with the segment counts (which only mask them afterwards) instead of behind them, and the same addresses of the
@@ -1153,8 +1203,7 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
     {
         const uint32_t at = min(g * 64u + lane, sg.cap2 - 1u);
         const uint64_t *rec = sg.seg2 + (((uint64_t)b * sg.nwg2 + sgm) * sg.cap2 + at) * (uint64_t)recw;
-        hdr = rec[0]; b0 = rec[1]; b1 = rec[2];
-        if (KW == 2) b2 = rec[3];
+        load(rec, hdr, b0, b1, b2);
     }
     uint32_t maxc = 0;
     for (uint32_t s2 = 0; s2 < sg.nwg2; ++s2) maxc = max(maxc, cnt2[s2]);
@@ -1210,7 +1259,7 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
 #endif
                 bool alone = false;
                 if (u < cnt) alone = body(skm_canonical<KW>(fw, rc), fw, pos0 + u);
-                skm_walk_loose<KW, WANT_POS>(sg, alone, fw, hdr, owner, pos0, j0, u, lane, recw);
+                skm_walk_loose<KW, WANT_POS>(sg, alone, fw, hdr, owner, pos0, j0, u, lane, sg.lrecw);
             }
         }
         __builtin_amdgcn_wave_barrier();                // the next group clears the mask
@@ -1219,8 +1268,7 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
         if (g * 64u >= maxc) break;
         if (g * 64u + lane < cnt2[sgm]) {
             const uint64_t *rec = sg.seg2 + (((uint64_t)b * sg.nwg2 + sgm) * sg.cap2 + g * 64u + lane) * (uint64_t)recw;
-            hdr = rec[0]; b0 = rec[1]; b1 = rec[2];
-            if (KW == 2) b2 = rec[3];
+            load(rec, hdr, b0, b1, b2);
         }
     }
 }
@@ -1237,7 +1285,7 @@ __host__ __device__ inline uint32_t skm_wave_scratch_words(uint32_t sbw) { retur
 #if !defined(SKM_K2_WAVES)
 #define SKM_K2_WAVES 6
 #endif
-template <int KW, int TS, bool KNOBS, int FK>
+template <int KW, int TS, bool KNOBS, int FK, bool COMPACT = false>
 __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : 6) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
                                                            const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
@@ -1306,7 +1354,7 @@ __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : 6) void k_sk
             }
         }
         // combine the occurrences of the bucket
-        if (!(SKM_DBG(sg) & 2u)) skm_walk_bucket<KW, false, FK>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
+        if (!(SKM_DBG(sg) & 2u)) skm_walk_bucket<KW, false, FK, COMPACT>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
             if (SKM_DBG(sg) & 128u) { n_added += c.w[0] & 1; return false; }
             // (KV_SKM_FORCE_LOOSE: one key in 64 is treated like a key that found its table full -- every occurrence travels alone;
             // results stay exact, tests use it to put single k-mers on the loose list of a batch that otherwise fits)
@@ -1389,7 +1437,7 @@ __global__ __launch_bounds__(256) void k_skm_loose_count(SkmGeom sg, const Sketc
     __syncthreads();
     unsigned long long n = sg.ctr[0];
     if (n > sg.loose_cap) n = sg.loose_cap;
-    const int k = sg.k, recw = sg.recw;
+    const int k = sg.k, recw = sg.lrecw;
     uint64_t n_added = 0;
     // wave-uniform loops (every lane votes in spill_items_wave).  A wave takes 64 records at a time: the one-k-mer records
     // (occurrences that missed a full LDS table: nearly all of them) are handled one per lane; a record with several k-mers
@@ -1550,7 +1598,7 @@ __global__ __launch_bounds__(256) void k_skm_loose_route(SkmGeom sg, HashParams 
     __syncthreads();
     unsigned long long n = sg.ctr[0];
     if (n > sg.loose_cap) n = sg.loose_cap;
-    const int k = sg.k, recw = sg.recw;
+    const int k = sg.k, recw = sg.lrecw;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t *rec = sg.loose + i * (uint64_t)recw;
         uint64_t bw[3];
@@ -1819,7 +1867,7 @@ __global__ __launch_bounds__(256) void k_skm_loose_novel(SkmGeom sg, ReadsDev rd
     __syncthreads();
     unsigned long long n = sg.ctr[0];
     if (n > sg.loose_cap) n = sg.loose_cap;
-    const int k = sg.k, recw = sg.recw;
+    const int k = sg.k, recw = sg.lrecw;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t *rec = sg.loose + i * (uint64_t)recw;
         uint64_t bw[3];
@@ -1927,7 +1975,7 @@ __global__ __launch_bounds__(256) void k_skm_loose_set_hits(SkmGeom sg, NovelPar
     __syncthreads();
     unsigned long long n = sg.ctr[0];
     if (n > sg.loose_cap) n = sg.loose_cap;
-    const int k = sg.k, recw = sg.recw;
+    const int k = sg.k, recw = sg.lrecw;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t *rec = sg.loose + i * (uint64_t)recw;
         uint64_t bw[3];
@@ -2123,7 +2171,10 @@ void skm_launch_split(const SkmGeom &g, hipStream_t st)
     const bool sorted = s2 ? strcmp(s2, "sorted") == 0 && g.F2 <= SKM_S2_MAXF : g.F2 <= SKM_S2_MAXF;
     if (sorted) {
         const size_t lds = (size_t)SKM_S2_CHUNK * g.recw * 8;
-        if (g.recw == 3) {
+        if (g.recw == 2) {
+            kv_ensure_dynamic_lds((const void *)k_skm_split_sorted<2>, lds);
+            hipLaunchKernelGGL(k_skm_split_sorted<2>, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), lds, st, g);
+        } else if (g.recw == 3) {
             kv_ensure_dynamic_lds((const void *)k_skm_split_sorted<3>, lds);
             hipLaunchKernelGGL(k_skm_split_sorted<3>, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), lds, st, g);
         } else {
@@ -2229,6 +2280,7 @@ void skm_geom_k(SkmGeom &g, int k)
     g.kw = k <= 32 ? 1 : 2;
     g.nbw = g.kw + 1;
     g.recw = 1 + g.nbw;
+    g.lrecw = g.recw;
     g.ncap = 32 * g.nbw - k + 1;
     g.sbw = ((64u * (uint32_t)g.ncap) >> 5) + 2u;
     g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
@@ -2250,7 +2302,7 @@ __global__ void k_mex_sum_kmers(const uint64_t *seg, const uint32_t *cnt, const 
 
 // cut `reads` into super-k-mers and bucket them (S1 + S2); idx.mu held by the caller
 // distinct_frac: the share of distinct k-mers the caller expects (0: sequencing coverage of a whole sample, ~0.3)
-int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hipStream_t st, double distinct_frac = 0.0)
+int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hipStream_t st, double distinct_frac = 0.0, bool want_pos = true)
 {
     SkmGeom &g = idx.g;
     memset(&g, 0, sizeof(g));
@@ -2266,7 +2318,10 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.kw = k <= 32 ? 1 : 2;
     g.nbw = g.kw + 1;
     g.recw = 1 + g.nbw;
+    g.lrecw = g.recw;
     g.ncap = 32 * g.nbw - k + 1;
+    g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
+    if (getenv("KV_SKM_FORCE_LOOSE")) g.dbg |= 4096u;
     const uint32_t table_slots = g.kw == 1 ? 4096u : 2048u;
     const char *tgt_env = getenv("KV_SKM_BUCKET_KMERS");      // tests shrink the buckets to exercise many of them on small inputs
     // k-mers per fine bucket: as many as leave the LDS table ~0.4 full (0.29 for two-word keys, whose longer windows put
@@ -2296,6 +2351,14 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     while ((1u << g.fbits) < g.F2) ++g.fbits;
     g.C1 = (uint32_t)std::min<uint64_t>(255, std::max<uint64_t>(1, (nfine + g.F2 - 1) / g.F2));
     g.n_buckets = g.C1 * g.F2;
+    // 16-byte records without positions (kv_skm_device.h) when nobody will ask where a k-mer was: the count of a sample that is not
+    // scanned from this very batch.  The lane-per-read S1 writes them, the sorted S2 moves them, k_skm_count reads them; KV_SKM_COMPACT=0: never
+    {
+        const char *e = getenv("KV_SKM_COMPACT"), *s2 = getenv("KV_SKM_S2");
+        g.compact = (!want_pos && g.kw == 1 && k + 1 <= SKM_C_BASES && skm_lane_fits(g, reads) && g.F2 <= SKM_S2_MAXF && !(s2 && strcmp(s2, "sorted") != 0) &&
+                     !(e && atoi(e) == 0)) ? 1u : 0u;
+        if (g.compact) { g.recw = 2; g.ncap = std::min(g.ncap, SKM_C_BASES + 1 - k); }
+    }
     const int cus = kv_device_cus();
     // at least one whole ticket per workgroup: the per-writer capacities below assume even shares
     g.nwg1 = (uint32_t)std::min<uint64_t>((std::max<uint32_t>(reads->n_tiles, 1u) + SKM_TILES_PER_TICKET - 1) / SKM_TILES_PER_TICKET,
@@ -2331,11 +2394,12 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     const size_t rb = (size_t)g.recw * 8;
     const size_t b_seg1 = kv_round_up((uint64_t)g.C1 * g.nwg1 * g.cap1 * rb, 256), b_cnt1 = kv_round_up((uint64_t)g.C1 * g.nwg1 * 4, 256);
     const size_t b_seg2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * g.cap2 * rb, 256), b_cnt2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * 4, 256);
-    const size_t b_loose = kv_round_up(g.loose_cap * rb, 256), b_ctr = 256;
+    const size_t b_loose = kv_round_up(g.loose_cap * (size_t)g.lrecw * 8, 256), b_ctr = 256;
     KV_HIP(idx.arena.need(b_seg1 + b_cnt1 + b_seg2 + b_cnt2 + b_loose + b_ctr));
     unsigned char *base = (unsigned char *)idx.arena.p;
     g.seg1 = (uint64_t *)base; base += b_seg1;
     g.cnt1 = (uint32_t *)base; base += b_cnt1;
+    { const char *e = getenv("KV_SKM_SEG1"); g.seg1_wmajor = (e && !strcmp(e, "bucket")) ? 0u : 1u; }
     g.seg2 = (uint64_t *)base; base += b_seg2;
     g.cnt2 = (uint32_t *)base; base += b_cnt2;
     g.loose = (uint64_t *)base; base += b_loose;
@@ -2343,8 +2407,6 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));
     g.sbw = ((64u * (uint32_t)g.ncap) >> 5) + 2u;
     g.bucket_kmers = std::max<uint64_t>(1, n_kmers / g.n_buckets);
-    g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
-    if (getenv("KV_SKM_FORCE_LOOSE")) g.dbg |= 4096u;
     skm_launch_emit(g, reads, st);
     skm_launch_split(g, st);
     KV_HIP(hipGetLastError());
@@ -2396,7 +2458,8 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     SkmIndex &idx = skm_index_for(st);
     std::lock_guard<std::mutex> lk(idx.mu);
     const int k = s->h.ksize;
-    { const int rc = skm_build(idx, reads, k, n_kmers, st, s->skm_distinct); if (rc != KV_OK) return rc; }
+    // (a sketch with the scan hint keeps positions: the scan that follows marks occurrences from these very buckets)
+    { const int rc = skm_build(idx, reads, k, n_kmers, st, s->skm_distinct, s->scan_hint != 0); if (rc != KV_OK) return rc; }
     SkmGeom &sg = idx.g;
     const uint32_t nwg3 = skm_nwg3(sg);
     BinPlan plan;
@@ -2472,6 +2535,10 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
         void (*kernel)(SkmGeom, const SketchDev *, const SketchDev *, ConsumeFilter, BinGeom) =
             sg.kw == 1 ? (sg.dbg ? k_skm_count<1, 4096, true, 0> : k_skm_count<1, 4096, false, 0>) : (sg.dbg ? k_skm_count<2, 2048, true, 0> : k_skm_count<2, 2048, false, 0>);
         if (sg.k == 31 && sg.recw == 3 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31>;
+        if (sg.compact) {       // 16-byte records (sg.recw == 2): their own instances
+            kernel = sg.dbg ? k_skm_count<1, 4096, true, 0, true> : k_skm_count<1, 4096, false, 0, true>;
+            if (sg.k == 31 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31, true>;
+        }
         // (BASELINE.json configs[4]: k = 51 -- two-word keys, 128-bit reverse complement, three murmur blocks + a 3-byte tail)
         if (sg.k == 51 && sg.recw == 4 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<2, 2048, false, 51>;
         hipLaunchKernelGGL(kernel, dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
@@ -2504,8 +2571,8 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
             s->skm_distinct = distinct;
             { std::lock_guard<std::mutex> glk(g_skm_mu); g_skm_last_distinct = distinct; }
             if (getenv("KV_SKM_VERBOSE"))
-                fprintf(stderr, "[kv_skm] batch of %llu k-mers: %.1f%% distinct, %.2f%% outside the LDS tables, %llu of %llu records outside their segments%s\n",
-                        (unsigned long long)n_kmers, 100 * distinct, 100 * alone, sc[6], sc[5], s->skm_off ? " -> next batches take the plain partition" : "");
+                fprintf(stderr, "[kv_skm] batch of %llu k-mers: %.1f%% distinct, %.2f%% outside the LDS tables, %llu of %llu records (%d bytes each) outside their segments%s\n",
+                        (unsigned long long)n_kmers, 100 * distinct, 100 * alone, sc[6], sc[5], 8 * sg.recw, s->skm_off ? " -> next batches take the plain partition" : "");
         }
     }
     if (rc != KV_OK) {
@@ -2551,7 +2618,7 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
         if (!idx) idx = &g_skm[kv_stream_key(st)];
     }
     std::lock_guard<std::mutex> lk(idx->mu);
-    const bool reuse = idx->valid && idx->reads_uid == reads->uid && idx->k == k && !getenv("KV_SKM_NO_REUSE");
+    const bool reuse = idx->valid && idx->reads_uid == reads->uid && idx->k == k && !idx->g.compact && !getenv("KV_SKM_NO_REUSE");
     if (!reuse) {
         double hint;
         { std::lock_guard<std::mutex> glk(g_skm_mu); hint = g_skm_last_distinct; }

@@ -85,6 +85,17 @@ KV_HD uint64_t skm_hdr_pos(uint64_t h) { return h & ((1ull << SKM_POS_BITS) - 1u
 KV_HD uint32_t skm_hdr_n(uint64_t h) { return (uint32_t)(h >> SKM_POS_BITS) & 0xffu; }
 KV_HD uint32_t skm_hdr_fine(uint64_t h) { return (uint32_t)(h >> 48); }
 
+// ---- compact records (round 5): 16 bytes, for batches nobody needs positions of (a control sample's count) -----------
+//   word 0   bases 0..31
+//   word 1   bits  0..39  bases 32..51   bits 40..45  n (n + k - 1 <= 52 bases)   bits 46..57  fine bucket
+// One aligned 16-byte store in S1 and one 16-byte load per lane in S2 / S3 instead of a 16- and an 8-byte piece of a 24-byte
+// record that straddles sectors; a third fewer bytes through S1, S2 and S3.  k <= 32 only.
+#define SKM_C_BASES 52
+KV_HD uint64_t skm_c_pack1(uint64_t b1, uint32_t n, uint32_t fine) { return (b1 & ((1ull << 40) - 1ull)) | ((uint64_t)n << 40) | ((uint64_t)fine << 46); }
+KV_HD uint32_t skm_c_n(uint64_t w1) { return (uint32_t)(w1 >> 40) & 63u; }
+KV_HD uint32_t skm_c_fine(uint64_t w1) { return (uint32_t)(w1 >> 46) & 4095u; }
+KV_HD uint64_t skm_c_b1(uint64_t w1) { return w1 & ((1ull << 40) - 1ull); }
+
 // 32 bases starting at base `b` of a packed sequence (u32 words, 16 bases each); reads three words
 KV_HD uint64_t skm_bases32(const uint32_t *words, uint32_t b)
 {
