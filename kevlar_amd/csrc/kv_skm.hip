@@ -2110,7 +2110,11 @@ static bool skm_lane_fits(const SkmGeom &g, const kv_reads *reads)
 {
     const uint32_t L = reads->uni_len;
     if (!L || L < (uint32_t)g.k || g.m != 12 || (g.w != SKM_LANE_B && g.w != 2 * SKM_LANE_B) || L > 256u) return false;
-    if (const char *e = getenv("KV_SKM_S1")) if (strcmp(e, "lane") != 0) return false;
+    const char *e1 = getenv("KV_SKM_S1");
+    if (e1 && strcmp(e1, "lane") != 0) return false;
+    // w = 40 (k = 51): two arrays of suffix minima do not fit the 80 registers six waves per SIMD leave (52-88 bytes of scratch per
+    // lane) and the kernel measured SLOWER than the wave kernel (5.5 against 4.1 ms per step of config 5): only when asked for by name
+    if (g.w != SKM_LANE_B && !e1) return false;
     if (g.dbg & ~4096u) return false;                           // the phase switches of the dissection scripts live in the older kernels
     return (size_t)skm_lane_slice_words((L + 15u) / 16u) * 4 * (SKM_LANE_THREADS / 64) + 1200 <= 160000u / (SKM_LANE_WAVES / 2);       // three workgroups per CU
 }
