@@ -61,6 +61,11 @@ struct SkmGeom {
     // that is not going to be scanned from this batch.  Loose records keep the classic form: lrecw = 1 + nbw words each.
     uint32_t compact;
     int lrecw;
+    // oriented: a record whose minimizer stands reversed in the read (strand bit of its value, skm_order_s) holds the REVERSE COMPLEMENT
+    // of the read's bases (header flag), so every k-mer of every record is stored on the strand on which its minimizer is canonical --
+    // and that strand is the k-mer's key in the bucket tables: the walk takes k-mers as they stand, no second strand, no comparison.
+    // The exchange layouts keep classic records (canonical = the smaller strand, computed by the walk).
+    uint32_t oriented;
 };
 
 // segment `seg` of coarse bucket c in seg1 / cnt1, counted in segments
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
             for (int step = 0; step < 16; ++step) {
                 const uint32_t jj = ((uint32_t)step + (uint32_t)lane) & 15u, j = j0 + jj;
                 const uint32_t f = (uint32_t)(win >> (2u * jj)) & mmask, r = (uint32_t)(rcw >> (rc0 - 2u * jj)) & mmask;
-                if (j < L) mh[q0 + jj] = j + (uint32_t)m <= L ? skm_order32(f < r ? f : r) : 0xffffffffu;
+                if (j < L) mh[q0 + jj] = j + (uint32_t)m <= L ? skm_order_s(f, r) : 0xffffffffu;
             }
         }
         if (threadIdx.x < 96) mh[NB + threadIdx.x] = 0xffffffffu;
@@ -396,7 +401,9 @@ __global__ __launch_bounds__(SKM_THREADS1, 6) void k_skm_emit(ReadsDev rd, uint3
                 uint64_t bw[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? skm_bases32(wl, b + 32u * t) : 0ull;
-                const uint64_t hdr = skm_header(pos, n, fine);
+                const uint32_t rev = sg.oriented ? (minv & 1u) : 0u;
+                if (rev) skm_rc_bases(bw, sg.nbw, n + (uint32_t)k - 1u);
+                const uint64_t hdr = skm_header(pos, n, fine, rev);
                 const uint32_t p = atomicAdd(&cur[coarse], 1u);
                 if (SKM_DBG(sg) & 1024u) n_rec += hdr ^ bw[0] ^ bw[1];
                 else if (p < sg.cap1) skm_store_record(sg.seg1 + (skm_seg1_slot(sg, coarse, blockIdx.x) * sg.cap1 + p) * (uint64_t)sg.recw, hdr, bw, sg.nbw);
@@ -498,7 +505,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : 6) void k_skm_emit_w
 #pragma unroll
             for (int step = 0; step < 16; ++step) {
                 const uint32_t f = (uint32_t)(win >> (2 * step)) & mmask, rv = (uint32_t)(rcw >> (rc0 - 2u * (uint32_t)step)) & mmask;
-                dst[step + (step >> PS)] = skm_order32(f < rv ? f : rv);
+                dst[step + (step >> PS)] = skm_order_s(f, rv);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -576,7 +583,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : 6) void k_skm_emit_w
                     uint64_t bw[3];
 #pragma unroll
                     for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? skm_bases32(wl, b + 32u * t) : 0ull;
-                    const uint64_t hdr = skm_header(pos, n, fine);
+                    const uint32_t rev = sg.oriented ? (sval[i] & 1u) : 0u;
+                    if (rev) skm_rc_bases(bw, sg.nbw, n + (uint32_t)k - 1u);
+                    const uint64_t hdr = skm_header(pos, n, fine, rev);
                     const uint32_t p = atomicAdd(&cur[coarse], 1u);
                     if (SKM_DBG(sg) & 1024u) n_rec += hdr ^ bw[0] ^ bw[1];
                     else if (p < sg.cap1) skm_store_record_wide(my_seg + coarse * cstride + p * (uint32_t)sg.recw, hdr, bw, sg.nbw);
@@ -653,7 +662,7 @@ __device__ __forceinline__ void skm_lane_block(const uint32_t *wl, uint32_t rbas
         const uint32_t p = (uint32_t)B * b + (uint32_t)j;
         if (!FULL && p >= npos) break;                                 // (the same for every lane: a scalar branch)
         const uint32_t f = (uint32_t)(X >> (2 * j)) & 0xffffffu, rv = (uint32_t)(R >> (40 - 2 * j)) & 0xffffffu;
-        const uint32_t val = skm_order32(f < rv ? f : rv);
+        const uint32_t val = skm_order_s(f, rv);
         pre = min(pre, val);
         if (FULL || p + 1u >= (uint32_t)(C * B)) {
             const uint32_t i = p + 1u - (uint32_t)(C * B);             // the k-mer whose window ends at this m-mer
@@ -748,7 +757,9 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, SKM_LANE_WAVES) void k_skm_emit_l
                 uint64_t bw[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? skm_bases32(wl, bidx + 32u * t) : 0ull;
-                const uint64_t hdr = skm_header(pos, n, fine);
+                const uint32_t rev = sg.oriented ? (v & 1u) : 0u;
+                if (rev) skm_rc_bases(bw, sg.nbw, n + (uint32_t)sg.k - 1u);
+                const uint64_t hdr = skm_header(pos, n, fine, rev);
                 const uint32_t p = atomicAdd(&cur[coarse], 1u);
 #if defined(SKM_HACK_ONESTORE)          // timing experiment only: one 16-byte store per record
                 if (p < sg.cap1) { typedef uint64_t u64x2 __attribute__((ext_vector_type(2), aligned(8))); *(u64x2 *)(my_seg + coarse * cstride + p * (uint32_t)sg.recw) = u64x2{hdr, bw[0]}; }
@@ -758,7 +769,7 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, SKM_LANE_WAVES) void k_skm_emit_l
                 if (p < sg.cap1) {
                     if (sg.compact) {                                 // one aligned 16-byte store: bases, n and the fine bucket (no position)
                         typedef uint64_t u64x2a __attribute__((ext_vector_type(2), aligned(16)));
-                        *(u64x2a *)(my_seg + coarse * cstride + p * 2u) = u64x2a{bw[0], skm_c_pack1(bw[1], n, fine)};
+                        *(u64x2a *)(my_seg + coarse * cstride + p * 2u) = u64x2a{bw[0], skm_c_pack1(bw[1], n, fine, rev)};
                     } else {
                         skm_store_record_wide(my_seg + coarse * cstride + p * (uint32_t)sg.recw, hdr, bw, sg.nbw);
                     }
@@ -1008,7 +1019,7 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split_sorted(SkmGeom sg)
             else if (part == 0) {
                 if (RECW == 2) {                                      // a compact record leaves in the loose list's (classic) form, position unknown
                     uint64_t bw[3] = {img[(uint64_t)q * RECW], skm_c_b1(h0), 0ull};
-                    skm_loose_push(sg, skm_header(0ull, skm_c_n(h0), f), bw);
+                    skm_loose_push(sg, skm_header(0ull, skm_c_n(h0), f, skm_c_rev(h0)), bw);
                 } else {
                     uint64_t bw[3] = {img[(uint64_t)q * RECW + 1], img[(uint64_t)q * RECW + 2], RECW == 4 ? img[(uint64_t)q * RECW + 3] : 0ull};
                     skm_loose_push(sg, h0, bw);
@@ -1160,7 +1171,8 @@ __device__ __forceinline__ void skm_walk_loose(const SkmGeom &sg, bool alone, co
     // (the count pass does not fetch the records' headers for the walk; here -- a wave in a few hundred -- it does,
     // so that the loose record carries the occurrence's real position: a scan that goes by the count pass's
     // distinct list evaluates these records as they are)
-    const uint64_t posu = (WANT_POS ? pos0 : skm_hdr_pos(skm_shfl64(hdr, owner)) + j0) + u;
+    // (WANT_POS: pos0 is this occurrence's position already; else it is derived here from the owner's header, orientation included)
+    const uint64_t posu = WANT_POS ? pos0 : skm_hdr_pos_of(skm_shfl64(hdr, owner), j0 + u);
     unsigned long long first = 0;
     if (lane == 0) first = atomicAdd(&sg.ctr[0], (unsigned long long)__popcll(need));
     first = skm_shfl64(first, 0);
@@ -1174,7 +1186,8 @@ __device__ __forceinline__ void skm_walk_loose(const SkmGeom &sg, bool alone, co
 
 // body(canonical k-mer, forward k-mer, position of the occurrence) -> true if the occurrence could not be combined and
 // must travel alone through the loose list; WANT_POS = false skips fetching the header (count pass)
-template <int KW, bool WANT_POS, int FK = 0, bool COMPACT = false, typename Body>
+// ORI: the bucket's records are oriented (SkmGeom::oriented): a k-mer's key is the k-mer as the record holds it
+template <int KW, bool WANT_POS, int FK = 0, bool COMPACT = false, bool ORI = false, typename Body>
 __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, uint32_t *sbits_all, Body body)
 {
     static_assert(!COMPACT || (KW == 1 && !WANT_POS), "compact records: one-word keys, no positions");
@@ -1187,7 +1200,7 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
         if (COMPACT) {
             typedef uint64_t u64x2a __attribute__((ext_vector_type(2), aligned(16)));
             const u64x2a both = *(const u64x2a *)rec;
-            b0 = both.x; b1 = skm_c_b1(both.y); hdr = (uint64_t)skm_c_n(both.y) << SKM_POS_BITS;
+            b0 = both.x; b1 = skm_c_b1(both.y); hdr = skm_header(0ull, skm_c_n(both.y), 0u, skm_c_rev(both.y));
         } else {
             hdr = rec[0]; b0 = rec[1]; b1 = rec[2];
             if (KW == 2) b2 = rec[3];
@@ -1243,23 +1256,27 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
             const uint32_t j0 = t < total ? (t - (oe & 0xffffu)) * G : 0u;
             const uint32_t cnt = t < total ? min(G, (oe >> 16) - j0) : 0u;     // k-mers of this unit: 1..G (0: no unit)
             SkmKey<KW> fw = skm_kmer_of<KW>(o0, o1, o2, j0, k);
-#if defined(SKM_HACK_NOCANON)          // timing experiment only (results are wrong): what the walk costs without the other strand
             SkmKey<KW> rc = fw;
-#else
-            SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
-#endif
+            if (!ORI) rc = skm_revcomp<KW>(fw, k);
             const uint32_t tail = (uint32_t)skm_window64(o0, o1, o2, j0 + (uint32_t)k);   // the bases that enter k-mers 1 .. G - 1
-            const uint64_t pos0 = skm_hdr_pos(oh) + j0;
+            // read position of the unit's first k-mer and the step to the next: a reversed record's k-mer j stands at pos + n - 1 - j
+            uint64_t pos0 = 0;
+            int step = 1;
+            if (WANT_POS) {
+                const bool rv = skm_hdr_rev(oh) != 0u;
+                pos0 = skm_hdr_pos(oh) + (rv ? skm_hdr_n(oh) - 1u - j0 : j0);
+                step = rv ? -1 : 1;
+            }
 #pragma unroll
             for (uint32_t u = 0; u < G; ++u) {
-#if defined(SKM_HACK_NOCANON)
-                if (u) { SkmKey<KW> dummy = fw; skm_roll<KW>(fw, dummy, (tail >> (2u * (u - 1u))) & 3u, k); rc = fw; }
-#else
-                if (u) skm_roll<KW>(fw, rc, (tail >> (2u * (u - 1u))) & 3u, k);
-#endif
+                if (u) {
+                    if (ORI) { SkmKey<KW> other = fw; skm_roll<KW>(fw, other, (tail >> (2u * (u - 1u))) & 3u, k); }      // (the other strand is dead code here)
+                    else skm_roll<KW>(fw, rc, (tail >> (2u * (u - 1u))) & 3u, k);
+                }
+                const uint64_t posu = pos0 + (uint64_t)(int64_t)(step * (int)u);
                 bool alone = false;
-                if (u < cnt) alone = body(skm_canonical<KW>(fw, rc), fw, pos0 + u);
-                skm_walk_loose<KW, WANT_POS>(sg, alone, fw, hdr, owner, pos0, j0, u, lane, sg.lrecw);
+                if (u < cnt) alone = body(ORI ? fw : skm_canonical<KW>(fw, rc), fw, posu);
+                skm_walk_loose<KW, WANT_POS>(sg, alone, fw, hdr, owner, posu, j0, u, lane, sg.lrecw);
             }
         }
         __builtin_amdgcn_wave_barrier();                // the next group clears the mask
@@ -1285,7 +1302,7 @@ __host__ __device__ inline uint32_t skm_wave_scratch_words(uint32_t sbw) { retur
 #if !defined(SKM_K2_WAVES)
 #define SKM_K2_WAVES 6
 #endif
-template <int KW, int TS, bool KNOBS, int FK, bool COMPACT = false>
+template <int KW, int TS, bool KNOBS, int FK, bool COMPACT = false, bool ORI = false>
 __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : 6) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
                                                            const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
@@ -1354,7 +1371,7 @@ __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : 6) void k_sk
             }
         }
         // combine the occurrences of the bucket
-        if (!(SKM_DBG(sg) & 2u)) skm_walk_bucket<KW, false, FK, COMPACT>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
+        if (!(SKM_DBG(sg) & 2u)) skm_walk_bucket<KW, false, FK, COMPACT, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
             if (SKM_DBG(sg) & 128u) { n_added += c.w[0] & 1; return false; }
             // (KV_SKM_FORCE_LOOSE: one key in 64 is treated like a key that found its table full -- every occurrence travels alone;
             // results stay exact, tests use it to put single k-mers on the loose list of a batch that otherwise fits)
@@ -1507,7 +1524,7 @@ __device__ __forceinline__ void skm_route_item(const KvRouteSink &rs, const uint
     }
 }
 
-template <int KW, int TS>
+template <int KW, int TS, bool ORI = false>
 __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashParams hp, KvRouteSink rs)
 {
     __shared__ SkmTable<KW, TS> tb;
@@ -1543,7 +1560,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
             else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
             else next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET;
         }
-        skm_walk_bucket<KW, false>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
+        skm_walk_bucket<KW, false, 0, false, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
             const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
             if (slot >= 0) atomicAdd(&cnt[slot], 1u);
             return slot < 0;
@@ -1624,7 +1641,7 @@ __device__ __forceinline__ void skm_mark(const NovelParams &p, const ReadsDev &r
     atomicOr(&p.mask[bit >> 5], 1u << (bit & 31));
 }
 
-template <int KW, int TS>
+template <int KW, int TS, bool ORI = false>
 __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, ReadsDev rd, NovelParams p, SkmAblSet abls)
 {
     constexpr bool KNOBS = true;
@@ -1664,7 +1681,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
             any_hit = 0;
         }
         // collect the distinct k-mers
-        skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
+        skm_walk_bucket<KW, true, 0, false, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
             const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
             return slot < 0;
         });
@@ -1694,7 +1711,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
         __syncthreads();
         if (any_hit == 0 || (SKM_DBG(sg) & 8u)) continue;
         // mark every occurrence of an interesting k-mer (an occurrence whose key is absent went to the loose list)
-        skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t pos) {
+        skm_walk_bucket<KW, true, 0, false, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t pos) {
             if (!skm_cacheable<KW>(c)) return false;
             const int slot = skm_table_find(tb, c);
             if (slot >= 0 && ((flag[slot >> 5] >> (slot & 31)) & 1u)) skm_mark(p, rd, pos, sg.stride);
@@ -1733,7 +1750,7 @@ __global__ __launch_bounds__(256) void k_case_bits(const uint8_t *__restrict__ t
 // the loose list already (k_skm_loose_novel evaluates them one by one).  A bucket's list has at most as many entries as the count
 // kernel's LDS table has slots.
 #define SKM_LIST_MAX 4096u
-template <int KW, int TSM, bool KNOBS>
+template <int KW, int TSM, bool KNOBS, bool ORI = false>
 __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, ReadsDev rd, NovelParams p, SkmAblSet abls)
 {
 #if defined(SKM_LIST_E)
@@ -1752,7 +1769,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, 
     skm_table_clear(itb);
     if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET; n_int = 0; n_cand = 0; }
     auto mark_pass = [&](uint32_t b) {
-        skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t pos) {
+        skm_walk_bucket<KW, true, 0, false, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t pos) {
             if (skm_cacheable<KW>(c) && skm_table_find(itb, c) >= 0) skm_mark(p, rd, pos, sg.stride);
             return false;
         });
@@ -1880,7 +1897,7 @@ __global__ __launch_bounds__(256) void k_skm_loose_novel(SkmGeom sg, ReadsDev rd
         for (uint32_t j = 0; j < nk; ++j) {
             if (j) skm_roll<KW>(fw, rc, skm_base_at(bw, j + (uint32_t)k - 1u), k);
             const uint64_t h = skm_key_hash<KW>(skm_canonical<KW>(fw, rc), lut, p.hp);
-            if (band_pass(p, h) && novel_test_fast(ns, p, h, nullptr, 0ull)) skm_mark(p, rd, skm_hdr_pos(hdr) + j, sg.stride);
+            if (band_pass(p, h) && novel_test_fast(ns, p, h, nullptr, 0ull)) skm_mark(p, rd, skm_hdr_pos_of(hdr, j), sg.stride);
         }
     }
 }
@@ -1907,7 +1924,7 @@ __device__ __forceinline__ void set_hit_store(const NovelParams &p, const SetHit
     for (int c = 0; c < S; ++c) out.abund[at * (uint64_t)S + c] = p.set_abund[slot * (uint64_t)S + c];
 }
 #define SKM_HIT_STAGE 1024u
-template <int KW, int TSM>
+template <int KW, int TSM, bool ORI = false>
 __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_set_hits(SkmGeom sg, NovelParams p, SetHitSink out)
 {
     __shared__ SkmTable<KW, TSM> itb;            // the bucket's members of the set
@@ -1945,7 +1962,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_set_hits(SkmGeom sg, No
         }
         __syncthreads();
         if (n_int == 0) continue;
-        skm_walk_bucket<KW, true>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t pos) {
+        skm_walk_bucket<KW, true, 0, false, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t pos) {
             if (!skm_cacheable<KW>(c)) return false;
             const int at = skm_table_find(itb, c);
             if (at < 0) return false;
@@ -1982,14 +1999,13 @@ __global__ __launch_bounds__(256) void k_skm_loose_set_hits(SkmGeom sg, NovelPar
 #pragma unroll
         for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
         const uint32_t nk = skm_hdr_n(rec[0]);
-        const uint64_t pos0 = skm_hdr_pos(rec[0]);
         SkmKey<KW> fw = skm_first_kmer<KW>(bw, k);
         SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
         for (uint32_t j = 0; j < nk; ++j) {
             if (j) skm_roll<KW>(fw, rc, skm_base_at(bw, j + (uint32_t)k - 1u), k);
             const uint64_t slot = set_find(p, skm_key_hash<KW>(skm_canonical<KW>(fw, rc), lut, p.hp));
             if (slot == KV_SET_NONE) continue;
-            const uint64_t pos = pos0 + j, read = pos / sg.stride;
+            const uint64_t pos = skm_hdr_pos_of(rec[0], j), read = pos / sg.stride;
             set_hit_store(p, out, atomicAdd(out.count, 1ull), ((unsigned long long)read << 16) | (unsigned long long)(pos - read * sg.stride), slot);
         }
     }
@@ -2404,6 +2420,7 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.seg1 = (uint64_t *)base; base += b_seg1;
     g.cnt1 = (uint32_t *)base; base += b_cnt1;
     { const char *e = getenv("KV_SKM_SEG1"); g.seg1_wmajor = (e && !strcmp(e, "bucket")) ? 0u : 1u; }
+    { const char *e = getenv("KV_SKM_ORIENT"); g.oriented = (e && atoi(e) == 0) ? 0u : 1u; }
     g.seg2 = (uint64_t *)base; base += b_seg2;
     g.cnt2 = (uint32_t *)base; base += b_cnt2;
     g.loose = (uint64_t *)base; base += b_loose;
@@ -2545,6 +2562,16 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
         }
         // (BASELINE.json configs[4]: k = 51 -- two-word keys, 128-bit reverse complement, three murmur blocks + a 3-byte tail)
         if (sg.k == 51 && sg.recw == 4 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<2, 2048, false, 51>;
+        if (sg.oriented) {      // oriented records: the same instances with the walk that takes k-mers as they stand
+            kernel = sg.kw == 1 ? (sg.dbg ? k_skm_count<1, 4096, true, 0, false, true> : k_skm_count<1, 4096, false, 0, false, true>)
+                                : (sg.dbg ? k_skm_count<2, 2048, true, 0, false, true> : k_skm_count<2, 2048, false, 0, false, true>);
+            if (sg.k == 31 && sg.recw == 3 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31, false, true>;
+            if (sg.compact) {
+                kernel = sg.dbg ? k_skm_count<1, 4096, true, 0, true, true> : k_skm_count<1, 4096, false, 0, true, true>;
+                if (sg.k == 31 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31, true, true>;
+            }
+            if (sg.k == 51 && sg.recw == 4 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<2, 2048, false, 51, false, true>;
+        }
         hipLaunchKernelGGL(kernel, dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
     }
     {
@@ -2676,14 +2703,18 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
         sg.dl_keys = idx->dl_keys; sg.dl_hash = idx->dl_hash; sg.dl_bstart = idx->dl_bstart; sg.dl_bcount = idx->dl_bcount; sg.dl_cap_wg = idx->dl_cap_wg;
         const size_t lds = (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw) * 4;
         void (*kernel)(SkmGeom, ReadsDev, NovelParams, SkmAblSet) =
-            sg.kw == 1 ? (sg.dbg ? k_skm_novel_list<1, 2048, true> : k_skm_novel_list<1, 2048, false>) : (sg.dbg ? k_skm_novel_list<2, 1024, true> : k_skm_novel_list<2, 1024, false>);
+            sg.oriented ? (sg.kw == 1 ? (sg.dbg ? k_skm_novel_list<1, 2048, true, true> : k_skm_novel_list<1, 2048, false, true>) : (sg.dbg ? k_skm_novel_list<2, 1024, true, true> : k_skm_novel_list<2, 1024, false, true>))
+                        : (sg.kw == 1 ? (sg.dbg ? k_skm_novel_list<1, 2048, true> : k_skm_novel_list<1, 2048, false>) : (sg.dbg ? k_skm_novel_list<2, 1024, true> : k_skm_novel_list<2, 1024, false>));
         hipLaunchKernelGGL(kernel, dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, pl, abls);
         if (p.ab_keys) hipLaunchKernelGGL(k_ab_fill, dim3(2048), dim3(256), 0, st, p);
         sg.dl_keys = nullptr; sg.dl_hash = nullptr; sg.dl_bstart = nullptr; sg.dl_bcount = nullptr;
     } else {
         KvProfScope prof("k_skm_novel");
         const size_t lds = (256 + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw)) * 4;
-        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_novel<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
+        if (sg.oriented) {
+            if (sg.kw == 1) hipLaunchKernelGGL((k_skm_novel<1, 4096, true>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
+            else hipLaunchKernelGGL((k_skm_novel<2, 2048, true>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
+        } else if (sg.kw == 1) hipLaunchKernelGGL((k_skm_novel<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
         else hipLaunchKernelGGL((k_skm_novel<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, p, abls);
     }
     {
@@ -2725,7 +2756,10 @@ int kv_skm_route_distinct(const kv_reads *reads, int ksize, uint64_t n_kmers, in
     {
         KvProfScope prof("k_skm_route");
         const size_t lds = (256 + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw)) * 4;
-        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_route<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, hp, rs);
+        if (sg.oriented) {
+            if (sg.kw == 1) hipLaunchKernelGGL((k_skm_route<1, 4096, true>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, hp, rs);
+            else hipLaunchKernelGGL((k_skm_route<2, 2048, true>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, hp, rs);
+        } else if (sg.kw == 1) hipLaunchKernelGGL((k_skm_route<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, hp, rs);
         else hipLaunchKernelGGL((k_skm_route<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, hp, rs);
     }
     {
@@ -3007,7 +3041,10 @@ int kv_skm_mex_scan_set(const NovelParams &p, int ksize, uint64_t *d_tags, uint8
     {
         KvProfScope prof("k_skm_set_hits");
         const size_t lds = (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw) * 4;
-        if (sg.kw == 1) hipLaunchKernelGGL((k_skm_set_hits<1, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, p, out);
+        if (sg.oriented) {
+            if (sg.kw == 1) hipLaunchKernelGGL((k_skm_set_hits<1, 2048, true>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, p, out);
+            else hipLaunchKernelGGL((k_skm_set_hits<2, 1024, true>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, p, out);
+        } else if (sg.kw == 1) hipLaunchKernelGGL((k_skm_set_hits<1, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, p, out);
         else hipLaunchKernelGGL((k_skm_set_hits<2, 1024>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, p, out);
         if (sg.kw == 1) hipLaunchKernelGGL(k_skm_loose_set_hits<1>, dim3(SKM_LOOSE_WGS), dim3(256), 0, st, sg, p, out);
         else hipLaunchKernelGGL(k_skm_loose_set_hits<2>, dim3(SKM_LOOSE_WGS), dim3(256), 0, st, sg, p, out);

@@ -63,35 +63,55 @@ KV_HD uint32_t skm_order32(uint32_t x)
     return x ^ (x >> 15);
 }
 
-// order value of the m-mer (m <= 16) whose forward code is f: mix of min(forward, reverse complement)
+// Order value of an m-mer with forward code f and reverse-complement code r: the order of the canonical one (the smaller), doubled,
+// plus a STRAND BIT -- 1 when the canonical form is the reverse complement, i.e. the m-mer stands in the read the other way round.
+// The minimum over a k-mer's window then carries the strand of the minimizer, which (round 5) decides which strand of the K-MER is
+// its key: the one on which its minimizer is canonical.  Both strands of a k-mer have the same m-mers with the strand bits flipped, so
+// they agree on that key without either of them computing the other strand (kv_skm.hip, "oriented records").  Where they do not
+// agree -- the minimal value occurs on both strands of one window, or the minimizer is its own reverse complement -- a k-mer is kept
+// under two keys, which costs a little deduplication and nothing else: adds compose, kmer_is_interesting() is a function of the hash.
+KV_HD uint32_t skm_order_s(uint32_t f, uint32_t r)
+{
+    return (skm_order32(f < r ? f : r) << 1) | (r < f ? 1u : 0u);
+}
+// order value of the m-mer (m <= 16) whose forward code is f
 KV_HD uint32_t skm_mmer_value(uint32_t f, int m)
 {
     const uint32_t mmask = m == 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
     const uint32_t r = (skm_rev2_32(f) >> (32 - 2 * m)) ^ mmask;
-    return skm_order32(f < r ? f : r);
+    return skm_order_s(f, r);
 }
 
 // minimizer value -> (coarse, fine) bucket.  The minimum of w uniform values is far from uniform, hence the second mix.
 KV_HD void skm_bucket_of(uint32_t minv, uint32_t C1, uint32_t fbits, uint32_t &coarse, uint32_t &fine)
 {
-    const uint32_t g = skm_mix32(minv + 0x9e3779b9u);
+    const uint32_t g = skm_mix32((minv | 1u) + 0x9e3779b9u);          // (the strand bit of the value is no part of the bucket: both strands of a k-mer meet)
     const uint64_t prod = (uint64_t)g * C1;
     coarse = (uint32_t)(prod >> 32);
     fine = fbits ? (uint32_t)prod >> (32 - fbits) : 0u;
 }
 
-KV_HD uint64_t skm_header(uint64_t pos, uint32_t n, uint32_t fine) { return pos | ((uint64_t)n << SKM_POS_BITS) | ((uint64_t)fine << 48); }
+// (bit 47, the top of n's byte: the record's bases are the REVERSE COMPLEMENT of the read's -- an oriented record, kv_skm.hip; its k-mer j
+// then stands at read position pos + n - 1 - j)
+KV_HD uint64_t skm_header(uint64_t pos, uint32_t n, uint32_t fine, uint32_t rev = 0u) { return pos | ((uint64_t)(n | (rev << 7)) << SKM_POS_BITS) | ((uint64_t)fine << 48); }
 KV_HD uint64_t skm_hdr_pos(uint64_t h) { return h & ((1ull << SKM_POS_BITS) - 1ull); }
-KV_HD uint32_t skm_hdr_n(uint64_t h) { return (uint32_t)(h >> SKM_POS_BITS) & 0xffu; }
+KV_HD uint32_t skm_hdr_n(uint64_t h) { return (uint32_t)(h >> SKM_POS_BITS) & 0x7fu; }
+KV_HD uint32_t skm_hdr_rev(uint64_t h) { return (uint32_t)(h >> (SKM_POS_BITS + 7)) & 1u; }
+// read position of k-mer j of a record
+KV_HD uint64_t skm_hdr_pos_of(uint64_t h, uint32_t j) { return skm_hdr_pos(h) + (skm_hdr_rev(h) ? skm_hdr_n(h) - 1u - j : j); }
 KV_HD uint32_t skm_hdr_fine(uint64_t h) { return (uint32_t)(h >> 48); }
 
 // ---- compact records (round 5): 16 bytes, for batches nobody needs positions of (a control sample's count) -----------
 //   word 0   bases 0..31
-//   word 1   bits  0..39  bases 32..51   bits 40..45  n (n + k - 1 <= 52 bases)   bits 46..57  fine bucket
+//   word 1   bits  0..39  bases 32..51   bits 40..45  n (n + k - 1 <= 52 bases)   bits 46..57  fine bucket   bit 58  reversed
 // One aligned 16-byte store in S1 and one 16-byte load per lane in S2 / S3 instead of a 16- and an 8-byte piece of a 24-byte
 // record that straddles sectors; a third fewer bytes through S1, S2 and S3.  k <= 32 only.
 #define SKM_C_BASES 52
-KV_HD uint64_t skm_c_pack1(uint64_t b1, uint32_t n, uint32_t fine) { return (b1 & ((1ull << 40) - 1ull)) | ((uint64_t)n << 40) | ((uint64_t)fine << 46); }
+KV_HD uint64_t skm_c_pack1(uint64_t b1, uint32_t n, uint32_t fine, uint32_t rev = 0u)
+{
+    return (b1 & ((1ull << 40) - 1ull)) | ((uint64_t)n << 40) | ((uint64_t)fine << 46) | ((uint64_t)rev << 58);      // (bit 58: an oriented record, reversed)
+}
+KV_HD uint32_t skm_c_rev(uint64_t w1) { return (uint32_t)(w1 >> 58) & 1u; }
 KV_HD uint32_t skm_c_n(uint64_t w1) { return (uint32_t)(w1 >> 40) & 63u; }
 KV_HD uint32_t skm_c_fine(uint64_t w1) { return (uint32_t)(w1 >> 46) & 4095u; }
 KV_HD uint64_t skm_c_b1(uint64_t w1) { return w1 & ((1ull << 40) - 1ull); }
@@ -104,6 +124,25 @@ KV_HD uint64_t skm_bases32(const uint32_t *words, uint32_t b)
     uint64_t v = lo >> sh;
     if (sh) v |= (uint64_t)words[a + 2] << (64u - sh);
     return v;
+}
+
+// reverse complement of the nb bases (1 <= nb <= 32 * nbw) held in bw[0 .. nbw), in place; bits beyond 2 nb come out zero
+KV_HD void skm_rc_bases(uint64_t *bw, int nbw, uint32_t nb)
+{
+    // reverse all 32 * nbw base slots, complement, then drop the (32 * nbw - nb) slots that came to the front
+    uint64_t r[4] = {0, 0, 0, 0};
+    for (int t = 0; t < 3; ++t)
+        if (t < nbw) r[t] = ~skm_rev2_64(bw[nbw - 1 - t]);
+    const uint32_t s = 2u * (32u * (uint32_t)nbw - nb), ws = s >> 6, bs = s & 63u;
+    for (int t = 0; t < 3; ++t) {
+        if (t >= nbw) break;
+        const uint32_t a = (uint32_t)t + ws;
+        const uint64_t lo = a == 0 ? r[0] : (a == 1 ? r[1] : (a == 2 ? r[2] : 0ull));
+        const uint64_t hi = a == 0 ? r[1] : (a == 1 ? r[2] : 0ull);
+        const uint64_t lim = (uint32_t)nbw;                       // words at and beyond nbw are not part of the string
+        const uint64_t lo_ok = a < lim ? lo : 0ull, hi_ok = a + 1u < lim ? hi : 0ull;
+        bw[t] = bs ? (lo_ok >> bs) | (hi_ok << (64u - bs)) : lo_ok;
+    }
 }
 
 // ---- k-mers in registers: KW = 1 (k <= 32) or 2 (k <= 64) words, base 0 in the low bits -----------------------

@@ -41,6 +41,15 @@ uint64_t h_header(uint64_t pos, uint32_t n, uint32_t fine) { return skm_header(p
 uint64_t h_hdr_pos(uint64_t h) { return skm_hdr_pos(h); }
 uint32_t h_hdr_n(uint64_t h) { return skm_hdr_n(h); }
 uint32_t h_hdr_fine(uint64_t h) { return skm_hdr_fine(h); }
+uint64_t h_header_rev(uint64_t pos, uint32_t n, uint32_t fine, uint32_t rev) { return skm_header(pos, n, fine, rev); }
+uint32_t h_hdr_rev(uint64_t h) { return skm_hdr_rev(h); }
+uint64_t h_hdr_pos_of(uint64_t h, uint32_t j) { return skm_hdr_pos_of(h, j); }
+void h_rc_bases(uint64_t *bw, int nbw, uint32_t nb) { skm_rc_bases(bw, nbw, nb); }
+uint64_t h_c_pack1(uint64_t b1, uint32_t n, uint32_t fine, uint32_t rev) { return skm_c_pack1(b1, n, fine, rev); }
+uint32_t h_c_n(uint64_t w1) { return skm_c_n(w1); }
+uint32_t h_c_fine(uint64_t w1) { return skm_c_fine(w1); }
+uint32_t h_c_rev(uint64_t w1) { return skm_c_rev(w1); }
+uint64_t h_c_b1(uint64_t w1) { return skm_c_b1(w1); }
 uint64_t h_fastmod_magic(uint64_t size) { return kv_fastmod_magic(size); }
 // out[i] = fastmod(h[i], size): the device's remainder arithmetic (FP64 quotient or Barrett, by the size), on the host's IEEE doubles
 void h_fastmod(const uint64_t *h, uint64_t n, uint64_t size, uint64_t *out)

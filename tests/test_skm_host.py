@@ -98,10 +98,50 @@ def test_mmer_value_is_strand_symmetric_and_spreads(lib):
     for m in (8, 10, 12, 16):
         for _ in range(200):
             seq = ''.join(rng.choice('ACGT') for _ in range(m))
-            v = lib.h_mmer_value(pack(seq), m)
-            assert v == lib.h_mmer_value(pack(revcomp(seq)), m)
-            seen.add(v)
+            v, vr = lib.h_mmer_value(pack(seq), m), lib.h_mmer_value(pack(revcomp(seq)), m)
+            # the order of the canonical m-mer is the same on both strands; bit 0 says on which strand the m-mer is NOT canonical:
+            # opposite on the two strands (unless the m-mer is its own reverse complement: then neither is "reversed")
+            assert v >> 1 == vr >> 1
+            assert (v & 1) + (vr & 1) == (0 if seq == revcomp(seq) else 1)
+            assert (v & 1) == (1 if pack(revcomp(seq)) < pack(seq) else 0)
+            seen.add(v >> 1)
     assert len(seen) > 700
+
+
+def test_oriented_record_helpers(lib):
+    """reverse complement of the bases of a record (what S1 stores for a run whose minimizer stands reversed), the header's
+    orientation flag with the position arithmetic that goes with it, and the fields of a compact record"""
+    rng = random.Random(11)
+    lib.h_rc_bases.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32]
+    for nbw in (2, 3):
+        for nb in list(range(1, 9)) + [31, 32, 33, 50, 63, 64] + ([65, 80, 95, 96] if nbw == 3 else []):
+            if nb > 32 * nbw:
+                continue
+            seq = ''.join(rng.choice('ACGT') for _ in range(nb))
+            junk = ''.join(rng.choice('ACGT') for _ in range(32 * nbw - nb))      # the read's next bases: what skm_bases32 brings along
+            v = pack(seq + junk)
+            bw = (ctypes.c_uint64 * 3)(*[(v >> (64 * i)) & (2**64 - 1) for i in range(3)])
+            lib.h_rc_bases(bw, nbw, nb)
+            got = sum(int(bw[i]) << (64 * i) for i in range(nbw))
+            assert got == pack(revcomp(seq)), (nbw, nb)
+    lib.h_header_rev.restype = ctypes.c_uint64
+    lib.h_header_rev.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    lib.h_hdr_pos_of.restype = ctypes.c_uint64
+    lib.h_hdr_pos_of.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
+    lib.h_hdr_rev.argtypes = [ctypes.c_uint64]
+    for rev in (0, 1):
+        h = lib.h_header_rev(123456789, 34, 4095, rev)
+        assert (lib.h_hdr_pos(h), lib.h_hdr_n(h), lib.h_hdr_fine(h), lib.h_hdr_rev(h)) == (123456789, 34, 4095, rev)
+        assert [lib.h_hdr_pos_of(h, j) for j in (0, 1, 33)] == ([123456789 + 33, 123456789 + 32, 123456789] if rev else [123456789, 123456790, 123456789 + 33])
+    lib.h_c_pack1.restype = ctypes.c_uint64
+    lib.h_c_pack1.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    lib.h_c_b1.restype = ctypes.c_uint64
+    for f in (lib.h_c_n, lib.h_c_fine, lib.h_c_rev, lib.h_c_b1):
+        f.argtypes = [ctypes.c_uint64]
+    w1 = lib.h_c_pack1(2**40 - 3, 22, 4095, 1)
+    assert (lib.h_c_b1(w1), lib.h_c_n(w1), lib.h_c_fine(w1), lib.h_c_rev(w1)) == (2**40 - 3, 22, 4095, 1)
+    w1 = lib.h_c_pack1(2**64 - 1, 1, 0, 0)             # (bases beyond the 52nd are cut off)
+    assert (lib.h_c_b1(w1), lib.h_c_n(w1), lib.h_c_fine(w1), lib.h_c_rev(w1)) == (2**40 - 1, 1, 0, 0)
 
 
 def test_bases32_and_ascii4(lib):
