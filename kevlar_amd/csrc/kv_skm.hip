@@ -633,13 +633,14 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : 6) void k_skm_emit_w
 #define SKM_LANE_BRANCHFREE 0     // 1: every lane writes an entry at every k-mer, lanes without a finished run to a dummy slot (no exec regions)
 #endif
 #if !defined(SKM_LANE_CAP)
-#define SKM_LANE_CAP 384u         // finished runs a wave lists between two flushes (64 reads x 40 k-mers bring ~250; what does not fit is written at once)
+#define SKM_LANE_CAP 320u         // finished runs a wave lists between two flushes (64 reads x 40 k-mers bring ~250; what does not fit is written at once)
 #endif
 #define SKM_LANE_THREADS 512
 #if !defined(SKM_LANE_WAVES)
 #define SKM_LANE_WAVES 6          // waves per SIMD the kernel is compiled for (3 workgroups per CU)
 #endif
-__host__ __device__ inline uint32_t skm_lane_slice_words(uint32_t wpr) { return 64u * wpr + 4u + 2u * SKM_LANE_CAP + 2u; }
+// a wave's slice of LDS: the group's words, their reverse complement read by read (oriented records), the run list
+__host__ __device__ inline uint32_t skm_lane_slice_words(uint32_t wpr) { return 2u * (64u * wpr + 4u) + 2u * SKM_LANE_CAP + 2u; }
 
 // one block of B m-mers for every lane's read: Sold holds the suffix minima of the block the finishing k-mers START in (C blocks
 // back) and receives this block's values; Smid (C = 2) the suffix minima of the block between, Smid[0] its minimum
@@ -705,7 +706,8 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, SKM_LANE_WAVES) void k_skm_emit_l
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwaves = SKM_LANE_THREADS / 64;
     const uint32_t L = rd.uni_len, wpr = (L + 15u) >> 4, nk = L - (uint32_t)sg.k + 1u, npos = L - 12u + 1u;
     uint32_t *wl = smem + wave * skm_lane_slice_words(wpr);
-    unsigned long long *ent = (unsigned long long *)(wl + 64u * wpr + 4u);
+    uint32_t *rcl = wl + 64u * wpr + 4u;             // read r's reverse complement: base i of it = complement of the read's base L - 1 - i
+    unsigned long long *ent = (unsigned long long *)(rcl + 64u * wpr + 4u);
     for (uint32_t c = threadIdx.x; c < sg.C1; c += SKM_LANE_THREADS) cur[c] = 0;
     __syncthreads();
     uint64_t n_rec = 0;
@@ -738,7 +740,7 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, SKM_LANE_WAVES) void k_skm_emit_l
 #pragma unroll
         for (int i = 0; i < NW; ++i)
             if ((uint32_t)i < wpr) wl[lane + 64u * (uint32_t)i] = pf[i];
-        if (lane < 4u) wl[64u * wpr + lane] = 0u;
+        if (lane < 4u) { wl[64u * wpr + lane] = 0u; rcl[64u * wpr + lane] = 0u; }
         // the next group's words are requested now; they are waited for in front of the first flush (below), not at the top of the
         // next round, where the wait would also cover this round's record stores
         const bool more = g + gstep < n_groups;
@@ -746,19 +748,35 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, SKM_LANE_WAVES) void k_skm_emit_l
         bool pf_waited = !more;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (sg.oriented) {
+            // every lane reverses and complements its own read once: the 16 wpr base slots of its words turned round (word order and
+            // the bases inside each word), complemented, and the 16 wpr - L slots of padding that came to the front shifted out.  A
+            // reversed run's bases are then read from this image exactly as a forward run's are read from the words.
+            const uint32_t sh = 2u * (16u * wpr - L);                  // < 32
+            uint32_t prev = ~skm_rev2_32(wl[lane * wpr + wpr - 1u]);
+            for (uint32_t t = 0; t < wpr; ++t) {
+                const uint32_t next = t + 1u < wpr ? ~skm_rev2_32(wl[lane * wpr + wpr - 2u - t]) : 0u;
+                rcl[lane * wpr + t] = __builtin_amdgcn_alignbit(next, prev, sh);
+                prev = next;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         // a finished run as records (a run of more than ncap k-mers is cut)
         auto emit_run = [&](uint32_t v, uint32_t r, uint32_t j, uint32_t left) {
             uint32_t coarse, fine;
             skm_bucket_of(v, sg.C1, sg.fbits, coarse, fine);
             uint64_t pos = (sg.read_base + r0 + r) * sg.stride + j;
-            uint32_t bidx = r * wpr * 16u + j;
+            const uint32_t rev = sg.oriented ? (v & 1u) : 0u;
+            const uint32_t *src = rev ? rcl : wl;
+            uint32_t bidx = r * wpr * 16u + j;                        // the piece's first base in the read (in wl)
             while (left) {
                 const uint32_t n = min(left, (uint32_t)sg.ncap);
+                // (a reversed piece: its n + k - 1 bases end at base L - j' of the reverse complement, j' its first base in the read)
+                const uint32_t from = rev ? 2u * r * wpr * 16u + L - bidx - (n + (uint32_t)sg.k - 1u) : bidx;
                 uint64_t bw[3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? skm_bases32(wl, bidx + 32u * t) : 0ull;
-                const uint32_t rev = sg.oriented ? (v & 1u) : 0u;
-                if (rev) skm_rc_bases(bw, sg.nbw, n + (uint32_t)sg.k - 1u);
+                for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? skm_bases32(src, from + 32u * t) : 0ull;
                 const uint64_t hdr = skm_header(pos, n, fine, rev);
                 const uint32_t p = atomicAdd(&cur[coarse], 1u);
 #if defined(SKM_HACK_ONESTORE)          // timing experiment only: one 16-byte store per record
@@ -1062,6 +1080,9 @@ __device__ __forceinline__ int skm_table_insert(SkmTable<KW, TS> &tb, const SkmK
         // (reading the slot first and swapping only into an empty one was measured 5 % slower: the read does not save
         // the swap's round trip, it adds one for every new key)
         const unsigned long long old0 = atomicCAS(&tb.key[0][slot], SKM_EMPTY, (unsigned long long)c.w[0]);
+#if defined(SKM_HACK_ONEPROBE)        // timing experiment only (wrong counts): what the insert costs when the first slot always answers
+        if (KW == 1) return (int)(slot | (old0 == SKM_EMPTY || old0 == c.w[0] ? 0u : 0u));
+#endif
         if (old0 == SKM_EMPTY || old0 == c.w[0]) {
             if (KW == 1) return (int)slot;
             const unsigned long long old1 = atomicCAS(&tb.key[KW - 1][slot], SKM_EMPTY, (unsigned long long)c.w[KW - 1]);
