@@ -697,8 +697,10 @@ __device__ __forceinline__ void skm_lane_block(const uint32_t *wl, uint32_t rbas
     for (int j = B - 2; j >= 0; --j) Sold[j] = min(Sold[j], Sold[j + 1]);
 }
 
+// (C = 2 keeps two arrays of suffix minima: 4 waves per SIMD -- two workgroups per CU, 128 registers -- where C = 1 runs 6; the kernel
+// is bound by instruction issue from 4 waves per SIMD up, so the lower occupancy costs nothing: measured with KV_SKM_NWG1=512 at C = 1)
 template <int C, int NW>
-__global__ __launch_bounds__(SKM_LANE_THREADS, SKM_LANE_WAVES) void k_skm_emit_lane(ReadsDev rd, SkmGeom sg, uint32_t n_groups, uint32_t flush_blocks)
+__global__ __launch_bounds__(SKM_LANE_THREADS, C == 2 ? 4 : SKM_LANE_WAVES) void k_skm_emit_lane(ReadsDev rd, SkmGeom sg, uint32_t n_groups, uint32_t flush_blocks)
 {
     constexpr int B = SKM_LANE_B;
     __shared__ uint32_t cur[256];
@@ -2149,9 +2151,9 @@ static bool skm_lane_fits(const SkmGeom &g, const kv_reads *reads)
     if (!L || L < (uint32_t)g.k || g.m != 12 || (g.w != SKM_LANE_B && g.w != 2 * SKM_LANE_B) || L > 256u) return false;
     const char *e1 = getenv("KV_SKM_S1");
     if (e1 && strcmp(e1, "lane") != 0) return false;
-    // w = 40 (k = 51): two arrays of suffix minima do not fit the 80 registers six waves per SIMD leave (52-88 bytes of scratch per
-    // lane) and the kernel measured SLOWER than the wave kernel (5.5 against 4.1 ms per step of config 5): only when asked for by name
-    if (g.w != SKM_LANE_B && !e1) return false;
+    // (w = 40, k = 51: two arrays of suffix minima; that instance is compiled for 4 waves per SIMD and skm_build starts two workgroups
+    // per CU for it -- at six waves it spilled and measured slower than the wave kernel, 5.5 against 4.1 ms per step of config 5)
+    if (g.w != SKM_LANE_B && e1 && !strcmp(e1, "lane6")) return false;
     if (g.dbg & ~4096u) return false;                           // the phase switches of the dissection scripts live in the older kernels
     return (size_t)skm_lane_slice_words((L + 15u) / 16u) * 4 * (SKM_LANE_THREADS / 64) + 1200 <= 160000u / (SKM_LANE_WAVES / 2);       // three workgroups per CU
 }
@@ -2404,6 +2406,7 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     // at least one whole ticket per workgroup: the per-writer capacities below assume even shares
     g.nwg1 = (uint32_t)std::min<uint64_t>((std::max<uint32_t>(reads->n_tiles, 1u) + SKM_TILES_PER_TICKET - 1) / SKM_TILES_PER_TICKET,
                                           std::min<uint32_t>(768u, 3u * (uint32_t)cus));
+    if (g.w == 2 * SKM_LANE_B && skm_lane_fits(g, reads)) g.nwg1 = std::min<uint32_t>(g.nwg1, 2u * (uint32_t)cus);      // (the w = 40 lane kernel: two workgroups per CU)
     {
         // the wave kernel with 1024-thread workgroups runs one workgroup per CU (fewer writers: see k_skm_emit_wave)
         int ch_unused = 16;
