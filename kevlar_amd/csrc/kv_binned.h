@@ -41,6 +41,11 @@ struct BinGeom {
     uint8_t *ttab[BIN_MAX_T];
     uint32_t dbg;                    // KV_BIN_DEBUG: timing experiments that skip parts of stage C (results are then wrong)
     int zero_tables;                 // the tables are all zero by decree (kv_sketch::lazy_zero): stage C writes every slice without loading it
+    // fast4: four tables of 2^16 <= size < 2^31 bins each and less than 2^32 coarse-item slots in all: the super-k-mer count's drain then
+    // takes h % size with the FP64 quotient and 32-bit remainders (the remainder's sign is bit 31) and appends its four items with 32-bit
+    // index arithmetic; tmagic[t] = kv_fastmod_magic(size[t]) by value (no trip to the sketch's descriptor per k-mer)
+    int fast4;
+    uint64_t tmagic[BIN_MAX_T];
 };
 
 // host-side description of one partitioned count in flight

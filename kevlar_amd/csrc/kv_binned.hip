@@ -1073,6 +1073,14 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
     g.gcnt2 = (uint32_t *)base; base += b_cnt2;
     g.spill = (unsigned long long *)base; base += b_spill;
     g.ctr = (unsigned long long *)base;
+    {
+        bool ok = g.T == 4 && ns * g.nwgA * g.cap1 < (1ull << 32) && !(getenv("KV_BIN_FAST4") && atoi(getenv("KV_BIN_FAST4")) == 0);
+        for (int t = 0; t < g.T && t < BIN_MAX_T; ++t) {
+            g.tmagic[t] = kv_fastmod_magic(s->h.size[t]);
+            ok = ok && kv_fastmod_fp(s->h.size[t]) && s->h.size[t] < (1ull << 31);
+        }
+        g.fast4 = ok ? 1 : 0;
+    }
     KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));   // every segment count is written by its owner: no other memset
     return KV_OK;
 }

@@ -1351,7 +1351,11 @@ __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : 6) void k_sk
         const uint32_t sidx = (uint32_t)t * (uint32_t)g.C + c;
         const uint32_t item = ((slice - c * (uint32_t)g.F) << g.sbits) | ((uint32_t)bin & ((1u << g.sbits) - 1u)) | ((wgt - 1u) << BIN_W_SHIFT);
         const uint32_t pos = atomicAdd(&cur[sidx], 1u);
+#if defined(SKM_HACK_NOITEMSTORE)      // timing experiment only: what the scattered 4-byte item stores cost
+        if (pos < cap1) { if (item == 0xdeadbeefu) my_seg[sidx * seg_stride + pos] = item; }
+#else
         if (pos < cap1) my_seg[sidx * seg_stride + pos] = item;
+#endif
         else spill_item(g, t, bin, wgt);
     };
     // the table is emptied as it is read (below), so it is cleared only once; the next bucket's ticket is fetched
@@ -1431,7 +1435,45 @@ __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : 6) void k_sk
                     sg.dl_hash[e] = h;
                 }
             }
-            const uint32_t added = skm_count_kmer(h, seen, sk, mask, f, g.T, emit);
+            uint32_t added;
+            if (g.fast4 && !f.use_mask) {
+                // four tables below 2^31 bins: the quotient of h / size from the FP64 pipe (kv_fastmod.h), the remainder in 32 bits --
+                // h - q size lies in [-size, size), so its low word is the remainder or the remainder + 2^32 - size, told apart by bit 31 --
+                // and the items appended with 32-bit index arithmetic: ~95 lane-instructions per k-mer for the 222 of the general form
+                // (64-bit remainders, the sizes fetched from the sketch's descriptor, scalar registers spilled around them)
+                const bool pass = !f.use_band || (h >= f.band_lo && h < f.band_hi);
+                added = pass ? seen : 0u;
+                if (pass) {
+                    const double hd = fma((double)(uint32_t)(h >> 32), 4294967296.0, (double)(uint32_t)h);
+                    uint32_t bin[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double q = fma(hd, __longlong_as_double((long long)g.tmagic[t]), 4503599627370496.0);
+                        const uint32_t psz = (uint32_t)g.tsize[t];
+                        uint32_t r = (uint32_t)h - (uint32_t)__double_as_longlong(q) * psz;
+                        r += (uint32_t)((int32_t)r >> 31) & psz;
+                        bin[t] = r;
+                    }
+                    uint32_t left = min(seen, 255u);
+                    const uint32_t omask = (1u << g.sbits) - 1u, stride32 = (uint32_t)seg_stride;
+                    while (left) {
+                        const uint32_t wgt = min(left, BIN_W_MAX), wbits = (wgt - 1u) << BIN_W_SHIFT;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const uint32_t slice = bin[t] >> g.sbits;
+                            const uint32_t c = g.F == 1 ? slice : __umulhi(slice, g.recipF);
+                            const uint32_t sidx = (uint32_t)t * (uint32_t)g.C + c;
+                            const uint32_t item = ((slice - c * (uint32_t)g.F) << g.sbits) | (bin[t] & omask) | wbits;
+                            const uint32_t pos = atomicAdd(&cur[sidx], 1u);
+                            if (pos < cap1) my_seg[sidx * stride32 + pos] = item;
+                            else spill_item(g, t, (uint64_t)bin[t], wgt);
+                        }
+                        left -= wgt;
+                    }
+                }
+            } else {
+                added = skm_count_kmer(h, seen, sk, mask, f, g.T, emit);
+            }
             n_added += added;
             // abundance list: a k-mer this batch adds at least twice (the lanes of the wave that are in here vote)
             if (sg.abl_keys) {
