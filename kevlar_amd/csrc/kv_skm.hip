@@ -1063,7 +1063,10 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split_sorted(SkmGeom sg)
 #if defined(SKM_LINEAR_PROBE)
 #define SKM_PROBE_STEP(h) 1u
 #else
-#define SKM_PROBE_STEP(h) ((((h) >> 20) & 62u) | 1u)
+#if !defined(SKM_STEP_MASK)
+#define SKM_STEP_MASK 62u
+#endif
+#define SKM_PROBE_STEP(h) ((((h) >> 20) & SKM_STEP_MASK) | 1u)
 #endif
 template <int KW, int TS>
 struct SkmTable {
