@@ -794,6 +794,7 @@ __global__ __launch_bounds__(SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_
     // 16-byte vector never leaves its segment).  Their vectors are enumerated compactly through a
     // prefix sum over the segments (LDS), so every thread has work whatever the segment fill levels.
     __shared__ uint32_t seg_cnt[BIN_MAX_SEG], vpre[BIN_MAX_SEG];
+    __shared__ uint16_t segof[MAXV * THREADS];       // the segment every one of the first MAXV x THREADS vectors lies in (below)
     __shared__ uint32_t wsum[THREADS / 64];
     __shared__ uint32_t total_vec_sh, flag_sh, fresh_sh;
     const Item *items = (const Item *)g.gbuf2 + stream * g.nwgB * g.cap2;
@@ -822,6 +823,14 @@ __global__ __launch_bounds__(SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_
         if (threadIdx.x < g.nwgB) vpre[threadIdx.x] = before + incl - myv;
         if (threadIdx.x == THREADS - 1) total_vec_sh = before + incl;
         __syncthreads();
+        // which segment a vector lies in, looked up instead of searched for: every wave writes the number of a few segments over
+        // their vectors' entries (a thread's MAXV fetches used to be MAXV binary searches over the ~30 segments, five dependent LDS
+        // reads and as many branches each: a fifth of the kernel's instructions)
+        for (uint32_t sgi = (uint32_t)wave; sgi < g.nwgB; sgi += THREADS / 64) {
+            const uint32_t first = vpre[sgi], nv = (seg_cnt[sgi] + VEC - 1) / VEC;
+            for (uint32_t i = (uint32_t)lane; i < nv && first + i < (uint32_t)MAXV * THREADS; i += 64) segof[first + i] = (uint16_t)sgi;
+        }
+        __syncthreads();
     }
     if (flag_sh) return;
     const uint32_t total_vec = total_vec_sh;
@@ -838,9 +847,13 @@ __global__ __launch_bounds__(SBITS == BIN_SLICE_BITS_W ? BIN_CW_THREADS : BIN_C_
         if (v >= total_vec) return r;
         if (g.dbg & 32u) { r.n = VEC; r.q = *(const uint4 *)(items + (uint64_t)v * VEC); return r; }     // same bytes, one contiguous run
         uint32_t lo = 0, hi = g.nwgB;      // largest segment with vpre[seg] <= v (empty segments share their successor's prefix)
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (vpre[mid] <= v) lo = mid; else hi = mid;
+        if (v < (uint32_t)MAXV * THREADS) {
+            lo = segof[v];
+        } else {
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (vpre[mid] <= v) lo = mid; else hi = mid;
+            }
         }
         const uint32_t j0 = (v - vpre[lo]) * VEC;
         r.n = min(VEC, seg_cnt[lo] - j0);
