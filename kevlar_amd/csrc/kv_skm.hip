@@ -2933,6 +2933,9 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
     KV_REQUIRE(reads->max_len <= plan->read_len, KV_ERR_ARG, "kv_mex_emit: a read of %u bases in a plan for %u", reads->max_len, plan->read_len);
     KV_REQUIRE(reads->tile_max_bases > 0 && reads->tile_max_bases <= 8192u, KV_ERR_ARG, "kv_mex_emit: reads too long for the super-k-mer front end");
     g.read_base = read_base;
+    // (the exchange's records are oriented like a single GPU's: every rank cuts with the same rule, so the owner of a bucket finds a
+    // k-mer under one key whichever shard it came from; KV_SKM_ORIENT=0 on every rank keeps the classic form)
+    { const char *e = getenv("KV_SKM_ORIENT"); g.oriented = (e && atoi(e) == 0) ? 0u : 1u; }
     g.seg1 = d_seg; g.cnt1 = d_cnt;
     g.loose_cap = 1u << 16;
     const size_t b_loose = kv_round_up(g.loose_cap * (size_t)g.recw * 8, 256), b_ctr = 256;
@@ -2996,6 +2999,7 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     const uint32_t Cl = plan->c_lo[my_dest + 1] - plan->c_lo[my_dest];
     g.C1 = Cl; g.F2 = plan->F2; g.fbits = plan->fbits; g.n_buckets = Cl * g.F2;
     g.nwg1 = plan->nwg1; g.cap1 = plan->cap1; g.n_src = (uint32_t)n_src;
+    { const char *e = getenv("KV_SKM_ORIENT"); g.oriented = (e && atoi(e) == 0) ? 0u : 1u; }       // as kv_skm_mex_emit cut them
     g.seg1 = const_cast<uint64_t *>(d_recv_seg); g.cnt1 = const_cast<uint32_t *>(d_recv_cnt);
     g.stride = plan->read_len - (uint32_t)plan->ksize + 1u;
     if (Cl == 0) { *n_kmers_in = 0; KvRouteSink rs; memset(&rs, 0, sizeof(rs)); return alloc(ctx, 1, &rs); }
@@ -3067,7 +3071,10 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     {
         KvProfScope prof("k_skm_route");
         const size_t lds = (256 + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(g.sbw)) * 4;
-        if (g.kw == 1) hipLaunchKernelGGL((k_skm_route<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, g, hp, rs);
+        if (g.oriented) {
+            if (g.kw == 1) hipLaunchKernelGGL((k_skm_route<1, 4096, true>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, g, hp, rs);
+            else hipLaunchKernelGGL((k_skm_route<2, 2048, true>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, g, hp, rs);
+        } else if (g.kw == 1) hipLaunchKernelGGL((k_skm_route<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, g, hp, rs);
         else hipLaunchKernelGGL((k_skm_route<2, 2048>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, g, hp, rs);
     }
     {
