@@ -607,6 +607,118 @@ __global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split(BinGeom g)
     rings_store_counts(F, written, (uint32_t)g.cap2, g.gcnt2 + (uint64_t)s * F * g.nwgB, g.nwgB, blockIdx.x);
 }
 
+// Stage B for weighted items, sorted in LDS (round 5).  The ring kernel above appends 2048 items per round to ~380 LDS rings and
+// then lets a lane per ring look whether its ring has a burst to flush, between two barriers: ~70 lane-instructions per item, and -- like
+// every kernel of the count stage -- bound by instruction issue, not by the 3.4 GB it moves.  Here a workgroup takes 8192 coarse items at
+// a time, ranks them by slice with LDS atomics, lays them out slice by slice in LDS (as coarse items: they carry their slice) and copies
+// that image out with consecutive lanes on consecutive items, converting to fine items on the way: a slice's items of one chunk leave
+// as one contiguous run of ~20.  The scheme of k_skm_split_sorted, for 4-byte items.  MEASURED SLOWER than the rings (1.33 against 1.08 ms
+// per sample: five barriers per 8192 items with two workgroups' worth of registers per thread) and therefore not the default.
+#define BIN_BS_CHUNK 8192u
+#define BIN_BS_MAXSEG 64u          // coarse segments one stage-B workgroup drains (nwgB >= nwgA / 32: at most 32)
+template <int SBITS>
+__global__ __launch_bounds__(BIN_B_THREADS) void k_bin_split_sorted(BinGeom g)
+{
+    __shared__ uint32_t cur[BIN_MAX_F], hist[BIN_MAX_F], off[BIN_MAX_F];
+    __shared__ uint32_t spre[BIN_BS_MAXSEG + 1], scnt[BIN_BS_MAXSEG];
+    __shared__ uint32_t wsum[BIN_B_THREADS / 64];
+    __shared__ uint32_t chunk_items;
+    extern __shared__ __attribute__((aligned(16))) uint32_t bimg[];      // [BIN_BS_CHUNK] coarse items in sorted order
+    const uint32_t s = blockIdx.y;
+    const uint32_t t = s / (uint32_t)g.C, c = s % (uint32_t)g.C, F = (uint32_t)g.F;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    constexpr uint32_t SB = SBITS, OFFMASK = (1u << SB) - 1u;
+    auto slice_of = [](uint32_t item) { return (item >> SB) & ((1u << (BIN_W_SHIFT - SB)) - 1u); };
+    auto fine_of = [](uint32_t item) { return (item & OFFMASK) | (((item >> BIN_W_SHIFT) + 1u) << 16); };
+    for (uint32_t f = threadIdx.x; f < F; f += BIN_B_THREADS) { cur[f] = 0; hist[f] = 0; }
+    // the segments seg = blockIdx.x, blockIdx.x + nwgB, ... of coarse stream s, enumerated flat; a segment's count is rounded up to whole
+    // 16-byte vectors in that enumeration (its base is 128-byte aligned, so every vector load is aligned; the padding items are masked)
+    const uint32_t nmine = min((g.nwgA - blockIdx.x + g.nwgB - 1u) / g.nwgB, BIN_BS_MAXSEG);
+    if (threadIdx.x < nmine) {
+        const uint64_t n = g.gcnt1[(uint64_t)s * g.nwgA + blockIdx.x + threadIdx.x * g.nwgB];
+        scnt[threadIdx.x] = (uint32_t)(n < g.cap1 ? n : g.cap1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < nmine; ++i) { spre[i] = acc; acc += (scnt[i] + 3u) & ~3u; }
+        spre[nmine] = acc;
+    }
+    __syncthreads();
+    const uint32_t total = spre[nmine];
+    constexpr uint32_t PER = BIN_BS_CHUNK / BIN_B_THREADS / 4u;          // 16-byte vectors per thread and chunk
+    uint32_t *const out = (uint32_t *)g.gbuf2 + ((uint64_t)s * F * g.nwgB + blockIdx.x) * g.cap2;      // + slice * fstride
+    const uint64_t fstride = (uint64_t)g.nwgB * g.cap2;
+    uint4 nv[PER];
+    uint32_t nn[PER];                                  // real items of the vector (0..4)
+    auto request = [&](uint32_t c0) {
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) {
+            const uint32_t gi = c0 + (r * BIN_B_THREADS + threadIdx.x) * 4u;
+            nv[r] = make_uint4(0, 0, 0, 0); nn[r] = 0;
+            if (gi < total) {
+                uint32_t lo = 0, hi = nmine;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (spre[mid] <= gi) lo = mid; else hi = mid; }
+                const uint32_t at = gi - spre[lo];
+                nn[r] = min(4u, scnt[lo] > at ? scnt[lo] - at : 0u);
+                const uint32_t *src = g.gbuf1 + ((uint64_t)s * g.nwgA + blockIdx.x + (uint64_t)lo * g.nwgB) * g.cap1 + at;
+                if (nn[r]) nv[r] = *(const uint4 *)src;
+            }
+        }
+    };
+    request(0);
+    for (uint32_t c0 = 0; c0 < total; c0 += BIN_BS_CHUNK) {
+        uint32_t it[PER][4], rank[PER][4], have[PER];
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r) { it[r][0] = nv[r].x; it[r][1] = nv[r].y; it[r][2] = nv[r].z; it[r][3] = nv[r].w; have[r] = nn[r]; }
+        request(c0 + BIN_BS_CHUNK);                     // the next chunk's items fly while this one is ranked, laid out and stored
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r)
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) rank[r][e] = e < have[r] ? atomicAdd(&hist[slice_of(it[r][e])], 1u) : 0u;
+        __syncthreads();
+        {   // exclusive scan of the chunk's histogram (F <= 512: one slice per thread); the slice's run starts at slot cur[f] of its segment
+            const uint32_t f = threadIdx.x;
+            const uint32_t h = f < F ? hist[f] : 0u;
+            uint32_t incl = h;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d);
+                if (lane >= (uint32_t)d) incl += up;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t before = incl - h;
+            for (uint32_t wv = 0; wv < wave; ++wv) before += wsum[wv];
+            if (f < F) {
+                off[f] = before;
+                const uint32_t at = cur[f];
+                cur[f] = at + h;
+                hist[f] = at - before;                  // slot = sorted position + this (mod 2^32)
+            }
+            if (threadIdx.x == BIN_B_THREADS - 1) chunk_items = before + h;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < PER; ++r)
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e)
+                if (e < have[r]) bimg[off[slice_of(it[r][e])] + rank[r][e]] = it[r][e];
+        __syncthreads();
+        const uint32_t n = chunk_items;
+        for (uint32_t q = threadIdx.x; q < n; q += BIN_B_THREADS) {
+            const uint32_t item = bimg[q], f = slice_of(item), slot = q + hist[f];
+            if (slot < (uint32_t)g.cap2) out[(uint64_t)f * fstride + slot] = fine_of(item);
+            else spill_item(g, (int)t, (((uint64_t)c * F + f) << SB) | (item & OFFMASK), (item >> BIN_W_SHIFT) + 1u);
+        }
+        __syncthreads();
+        for (uint32_t f = threadIdx.x; f < F; f += BIN_B_THREADS) hist[f] = 0;
+        __syncthreads();
+    }
+    for (uint32_t f = threadIdx.x; f < F; f += BIN_B_THREADS)
+        g.gcnt2[((uint64_t)s * F + f) * g.nwgB + blockIdx.x] = min(cur[f], (uint32_t)g.cap2);
+}
+
 // ---- stage C -----------------------------------------------------------------------------
 __device__ __forceinline__ bool lds_inc(uint32_t *lds, uint32_t off, int storage)
 {
@@ -1110,6 +1222,13 @@ int kv_bin_finish(kv_sketch *s, BinPlan &plan, bool added_from_ctr, uint64_t n_a
         if (plan.weighted && g.sbits == BIN_SLICE_BITS_W) {
             ensure_dynamic_lds((k_bin_split<true, BIN_SLICE_BITS_W>), lds);
             hipLaunchKernelGGL((k_bin_split<true, BIN_SLICE_BITS_W>), dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
+        } else if (plan.weighted && (g.nwgA + g.nwgB - 1) / g.nwgB <= BIN_BS_MAXSEG && (uint32_t)g.F <= BIN_B_THREADS &&
+                   getenv("KV_BIN_SPLIT") && !strcmp(getenv("KV_BIN_SPLIT"), "sorted")) {
+            // weighted items, 65536-bin slices, ranked and laid out in LDS, copied out in runs: only by name (KV_BIN_SPLIT=sorted) -- it gives
+            // the same segments and measured SLOWER than the ring kernel, 3.98 against 3.24 ms per step of config 2 (profiles/README.md)
+            const size_t lds2 = (size_t)BIN_BS_CHUNK * 4;
+            ensure_dynamic_lds((k_bin_split_sorted<BIN_SLICE_BITS>), lds2);
+            hipLaunchKernelGGL((k_bin_split_sorted<BIN_SLICE_BITS>), dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds2, st, g);
         } else if (plan.weighted) {
             ensure_dynamic_lds((k_bin_split<true, BIN_SLICE_BITS>), lds);
             hipLaunchKernelGGL((k_bin_split<true, BIN_SLICE_BITS>), dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
