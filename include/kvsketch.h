@@ -190,6 +190,12 @@ int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int band, const 
 int kv_unique_exact(kv_sketch *s, const kv_reads *const *batches, int n_batches, int nbands,
                     int band, const kv_sketch *mask, int threshold, int consume_masked,
                     uint64_t *n_unique_out);
+/* The same figure one batch at a time: *n_new_out = the k-mers of `batch` that khmer's single thread would count as new if the batch
+ * were consumed into `s` now (a bin of the k-mer is clear in the tables as they stand, and no earlier k-mer of this batch touches it
+ * first).  Call it before every kv_consume of the batch with the same band / mask arguments and add the results up: the sum is the
+ * "distinct k-mers stored" of kevlar/count.py:82-84 for a sample of any size, no batch kept resident.                                */
+int kv_unique_new(kv_sketch *s, const kv_reads *batch, int nbands, int band, const kv_sketch *mask, int threshold,
+                  int consume_masked, uint64_t *n_new_out);
 
 /* ---- point queries: .get / .add on many k-mers (kevlar/filter.py:32-34,67) ------------ */
 /* hash n k-mers of length k stored back to back in `kmers` (device kernel)                */

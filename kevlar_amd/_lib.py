@@ -94,6 +94,7 @@ SIGNATURES = {
     'kv_reads_num_kmers': (i32, [vp, i32, u64p]),
     'kv_consume': (i32, [vp, vp, i32, i32, vp, i32, i32, u64p]),
     'kv_unique_exact': (i32, [vp, vpp, i32, i32, i32, vp, i32, i32, u64p]),
+    'kv_unique_new': (i32, [vp, vp, i32, i32, vp, i32, i32, u64p]),
     'kv_abundance_distribution': (i32, [vp, vp, vpp, i32, u64p]),
     'kv_hash_kmers': (i32, [i32, cstr, i32, u64, u64p]),
     'kv_hash_positions': (i32, [vp, i32, i32, u32p, u32p, u64, u64p]),

@@ -10,7 +10,10 @@
 // (c) count distinct (k-mer, node) pairs, (d) union every node of a retained k-mer with that
 // k-mer's representative node (lock-free hooking, larger root under smaller), (e) flatten.
 #include <algorithm>
+#include <map>
+#include <mutex>
 
+#include "kv_binned.h"
 #include "kv_device.h"
 
 namespace {
@@ -449,6 +452,81 @@ extern "C" int kv_unique_exact(kv_sketch *s, const kv_reads *const *batches, int
                        d_out.as<unsigned long long>());
     KV_HIP(hipGetLastError());
     KV_HIP(hipMemcpyAsync(n_unique_out, d_out.p, 8, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    return KV_OK;
+}
+
+// kv_unique_exact one batch at a time, against the sketch AS IT STANDS: how many k-mers of `batch` khmer's single thread would call
+// new if the batch were consumed now -- some bin of the k-mer is clear in the tables (nothing counted so far touched it) and no earlier
+// k-mer of this very batch touches it first.  Called before every kv_consume of a sketch that tracks the exact figure, the sum over the
+// batches is kv_unique_exact's number without keeping any batch resident (round 5: the 4 GiB retention limit is gone; a sample of any
+// size reports the reference's "distinct k-mers stored").  The first-toucher arrays (4 bytes per bin and table) come from a per-stream
+// arena that is kept between calls.
+namespace {
+std::map<hipStream_t, KvArena> g_unique_arena;
+std::mutex g_unique_arena_mu;
+}
+extern "C" int kv_unique_new(kv_sketch *s, const kv_reads *batch, int nbands, int band, const kv_sketch *mask, int threshold,
+                             int consume_masked, uint64_t *n_new_out)
+{
+    KV_REQUIRE(s && batch && n_new_out, KV_ERR_ARG, "kv_unique_new: bad argument");
+    KV_REQUIRE(nbands >= 0 && (nbands == 0 || (band >= 0 && band < nbands)), KV_ERR_ARG, "band %d out of range for %d bands", band, nbands);
+    { const int rc = kv_sketch_ready(mask); if (rc != KV_OK) return rc; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    { const int rc = kv_sketch_ready_locked(s); if (rc != KV_OK) return rc; }
+    hipStream_t st = kv_stream();
+    const int k = s->h.ksize;
+    uint64_t total = 0;
+    kv_reads_num_kmers(batch, k, &total);
+    KV_REQUIRE(total < 0xFFFFFFF0ull, KV_ERR_CAPACITY, "exact distinct k-mer counting handles up to 4.29e9 k-mers per batch (got %llu)",
+               (unsigned long long)total);
+    *n_new_out = 0;
+    if (total == 0 || batch->n_tiles == 0) return KV_OK;
+    FirstTouchParams p;
+    memset(&p, 0, sizeof(p));
+    p.f = make_consume_filter(k, s->h.hashfam, nbands, band, mask != nullptr, threshold, consume_masked);
+    KvArena *arena;
+    {
+        std::lock_guard<std::mutex> alk(g_unique_arena_mu);
+        arena = &g_unique_arena[kv_stream_key(st)];
+    }
+    const uint64_t bm_words = (total + 31) / 32;
+    size_t need = kv_round_up(bm_words * 4, 256) + 256;
+    for (int t = 0; t < s->h.ntables; ++t) need += kv_round_up(s->h.size[t] * 4, 256);
+    {
+        const hipError_t e = arena->need(need);
+        KV_REQUIRE(e == hipSuccess, KV_ERR_HIP, "first-touch scratch (%llu bytes) allocation failed: %s", (unsigned long long)need, hipGetErrorString(e));
+    }
+    unsigned char *base = (unsigned char *)arena->p;
+    for (int t = 0; t < s->h.ntables; ++t) {
+        p.first[t] = (uint32_t *)base;
+        KV_HIP(hipMemsetAsync(base, 0xFF, s->h.size[t] * 4, st));
+        base += kv_round_up(s->h.size[t] * 4, 256);
+    }
+    uint32_t *d_bm = (uint32_t *)base; base += kv_round_up(bm_words * 4, 256);
+    unsigned long long *d_out = (unsigned long long *)base;
+    KV_HIP(hipMemsetAsync(d_bm, 0, bm_words * 4, st));
+    KV_HIP(hipMemsetAsync(d_out, 0, 8, st));
+    std::vector<uint64_t> kpre(batch->n_reads + 1, 0);
+    for (uint64_t i = 0; i < batch->n_reads; ++i)
+        kpre[i + 1] = kpre[i] + (batch->h_len[i] >= (uint32_t)k ? batch->h_len[i] - (uint32_t)k + 1 : 0);
+    DevBuf d_kpre;
+    KV_HIP(d_kpre.alloc(kpre.size() * 8));
+    KV_HIP(hipMemcpyAsync(d_kpre.p, kpre.data(), kpre.size() * 8, hipMemcpyHostToDevice, st));
+    p.ordinal_base = 0;
+    p.kprefix = d_kpre.as<uint64_t>();
+    {
+        KvProfScope prof("k_first_touch");
+        kv_ensure_dynamic_lds((const void *)k_first_touch, batch->tile_lds_bytes);
+        hipLaunchKernelGGL(k_first_touch, dim3(batch->n_tiles), dim3(KV_TILE_THREADS), batch->tile_lds_bytes, st, reads_dev(batch),
+                           (const SketchDev *)s->d_desc, (const SketchDev *)(mask ? mask->d_desc : nullptr), p);
+    }
+    // a bin's first toucher is new only if the tables had not recorded the bin before this batch
+    for (int t = 0; t < s->h.ntables; ++t)
+        hipLaunchKernelGGL(k_mark_first_untracked, dim3(grid_for(s->h.size[t])), dim3(256), 0, st, p.first[t], (const SketchDev *)s->d_desc, t, d_bm);
+    hipLaunchKernelGGL(k_popcount, dim3(grid_for(bm_words)), dim3(256), 0, st, d_bm, bm_words, d_out);
+    KV_HIP(hipGetLastError());
+    KV_HIP(hipMemcpyAsync(n_new_out, d_out, 8, hipMemcpyDeviceToHost, st));
     KV_HIP(hipStreamSynchronize(st));
     return KV_OK;
 }

@@ -540,9 +540,7 @@ class _Sketch(object):
 
     def __init__(self, k, starting_size, n_tables, primes=None, _handle=None):
         self._lock = threading.Lock()
-        self._exact = None      # when tracking: list of (ReadBatch, filter-key) seen so far
-        self._exact_cache = None
-        self._exact_bytes, self._exact_budget = 0, 4 << 30
+        self._exact = None      # when tracking the exact distinct-k-mer figure: the k-mers counted as new so far (kv_unique_new), else None
         if _handle is not None:
             self._h = _handle
             return
@@ -586,8 +584,7 @@ class _Sketch(object):
         """Zero all tables (same geometry, fresh counts)."""
         check(_lib.load().kv_sketch_clear(self._h))
         if self._exact is not None:
-            self._exact = []
-        self._exact_cache = None
+            self._exact = 0
 
     # ---- info ---------------------------------------------------------------------------
     def _info(self):
@@ -612,26 +609,16 @@ class _Sketch(object):
         """Distinct k-mers seen.  With track_exact_unique(True) this is the value one khmer
         thread reports for the same files in the same order; otherwise it carries the
         semantics of khmer's multi-threaded consume (see include/kvsketch.h kv_consume)."""
-        if self._exact:
-            if self._exact_cache is None:
-                batches, key = [b for b, _ in self._exact], self._exact[0][1]
-                nbands, band, mask, threshold, consume_masked = key
-                arr = (ctypes.c_void_p * len(batches))(*[b._h for b in batches])
-                out = ctypes.c_uint64()
-                check(_lib.load().kv_unique_exact(
-                    self._h, arr, len(batches), nbands, band, mask._h if mask is not None else None,
-                    threshold, 1 if consume_masked else 0, ctypes.byref(out)))
-                self._exact_cache = out.value
-            return self._exact_cache
+        if self._exact is not None:
+            return int(self._exact)
         return int(self._info().n_unique)
 
-    def track_exact_unique(self, on=True, budget_bytes=4 << 30):
-        """Keep the packed read batches of subsequent consume_seqfile* calls in HBM (up to budget_bytes) so that
-        n_unique_kmers() can be re-derived exactly (single-thread semantics)."""
-        self._exact = [] if on else None
-        self._exact_cache = None
-        self._exact_bytes = 0
-        self._exact_budget = int(budget_bytes)
+    def track_exact_unique(self, on=True, budget_bytes=None):
+        """From now on every consume_batch() first asks the library how many of the batch's k-mers are new to the tables as they
+        stand (kv_unique_new: khmer's single-thread rule, batch by batch), and n_unique_kmers() reports the sum: the reference's
+        "distinct k-mers stored" for one thread (kevlar/count.py:82-84), for a sample of any size -- nothing is kept resident
+        (budget_bytes: ignored, the retention limit of earlier rounds is gone)."""
+        self._exact = 0 if on else None
 
     def table_bytes(self, i):
         """Raw on-disk form of table i (tests compare this against the oracle)."""
@@ -723,28 +710,29 @@ class _Sketch(object):
 
     # ---- consume --------------------------------------------------------------------------
     def consume_batch(self, batch, nbands=0, band=0, mask=None, threshold=0, consume_masked=False):
-        n = ctypes.c_uint64()
-        check(_lib.load().kv_consume(self._h, batch._h, nbands or 0, band or 0,
-                                     mask._h if mask is not None else None, int(threshold),
-                                     1 if consume_masked else 0, ctypes.byref(n)))
+        lib = _lib.load()
         if self._exact is not None:
+            # (before the batch is counted: "new" is judged against the tables the batch is about to change)
+            fresh = ctypes.c_uint64()
+            try:
+                check(lib.kv_unique_new(self._h, batch._h, nbands or 0, band or 0, mask._h if mask is not None else None, int(threshold),
+                                        1 if consume_masked else 0, ctypes.byref(fresh)))
+            except (_lib.KvError, _lib.KvCapacityError):
+                # no room for the first-toucher arrays (4 bytes per bin) or a batch beyond 4.29e9 k-mers: the count goes on and
+                # n_unique_kmers() reports the estimate of kv_consume
+                self._exact = None
             with self._lock:
-                key = (nbands or 0, band or 0, mask, int(threshold), bool(consume_masked))
-                self._exact_bytes += batch.device_bytes()
-                if self._exact and self._exact[0][1] != key:
-                    self._exact = None   # mixed settings: exact re-derivation not defined
-                elif self._exact_bytes > self._exact_budget:
-                    # the exact figure needs every batch of the sample resident next to the sketches; past the
-                    # budget the batches are let go and the linear-counting estimate of kv_consume is reported
-                    self._exact = None
-                else:
-                    self._exact.append((batch, key))
-                    self._exact_cache = None
+                if self._exact is not None:
+                    self._exact += fresh.value
+        n = ctypes.c_uint64()
+        check(lib.kv_consume(self._h, batch._h, nbands or 0, band or 0,
+                             mask._h if mask is not None else None, int(threshold),
+                             1 if consume_masked else 0, ctypes.byref(n)))
         return n.value
 
     def retains(self, batch):
-        """True if `batch` is being kept for the exact distinct-k-mer figure (then the caller must not close it)."""
-        return self._exact is not None and any(b is batch for b, _ in self._exact)
+        """(no batch is kept for the exact distinct-k-mer figure any more: always False)"""
+        return False
 
     def consume_hashes(self, hashes_ptr, n, stride_words=1):
         """Count n hashes resident in HBM (device address; element i at word i * stride_words)."""

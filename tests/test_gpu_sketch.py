@@ -266,6 +266,35 @@ def test_exact_unique_matches_single_thread_oracle(hk, ok):
         ok.consume_reads(ref, bases, offs, len(reads), nbands, band)
         assert dev.n_unique_kmers() == ref.n_unique_kmers()
         assert dev.n_occupied() == ref.n_occupied()
+    # batch by batch against the tables as they stand (kv_unique_new: nothing is kept resident, so no size limit): many small batches,
+    # through every count path, on top of k-mers that were counted before tracking began, with a mask
+    mask_dev, mask_ref = hk.Nodetable(23, 4e4, 2), ok.Nodetable(23, 4e4, 2)
+    mseqs = random_reads(23, 200, lo=40, hi=90)
+    mask_dev.consume_batch(hk.ReadBatch(mseqs))
+    mb, mo = ok.concat_reads(mseqs)
+    ok.consume_reads(mask_ref, mb, mo, len(mseqs))
+    for path in ('atomic', 'binned', 'skm'):
+        os.environ['KV_COUNT_PATH'] = path
+        try:
+            for use_mask in (False, True):
+                dev, ref = hk.Counttable(23, 2e4, 4), ok.Counttable(23, 2e4, 4)
+                before = random_reads(24, 400, lo=30, hi=140)
+                dev.consume_batch(hk.ReadBatch(before))                         # (not tracked: the tables are not empty when tracking starts)
+                bases, offs = ok.concat_reads(before)
+                ok.consume_reads(ref, bases, offs, len(before))
+                base_unique = ref.n_unique_kmers()
+                dev.track_exact_unique(True)
+                step = 211
+                for lo in range(0, len(reads), step):
+                    part = reads[lo:lo + step]
+                    dev.consume_batch(hk.ReadBatch(part), 0, 0, mask_dev if use_mask else None, 0, False)
+                    bases, offs = ok.concat_reads(part)
+                    ok.consume_reads(ref, bases, offs, len(part), 0, 0, mask_ref if use_mask else None, 0, False)
+                assert dev.n_unique_kmers() == ref.n_unique_kmers() - base_unique, (path, use_mask)
+                for t in range(4):
+                    assert dev.table_bytes(t) == ref.table_bytes(t)
+        finally:
+            os.environ.pop('KV_COUNT_PATH', None)
 
 
 def test_long_sequences_are_cut_into_segment_tiles(hk, ok):
