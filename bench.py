@@ -462,7 +462,8 @@ def main():
             # owner's combine -- interleaved so that a sample's records travel while the next sample's shard is cut, and its pairs
             # while the next sample's records are combined (RCCL runs on its own stream; every rank keeps this order)
             def cut(n_):
-                return run.cut_minimizer(batches[n_][0], bounds[n_][0], n_reads, L)
+                # (records without read positions for every sample but the one the owners answer the scan from)
+                return run.cut_minimizer(batches[n_][0], bounds[n_][0], n_reads, L, short=not (n_ == names[0] and args.exchange_scan == 'owner'))
             cuts = {0: cut(order[0])}
             flying = None
             for i, n in enumerate(order):

@@ -120,6 +120,7 @@ SIGNATURES = {
     'kv_argsort_u64': (i32, [vp, u64, vp]),
     'kv_argsort_rows': (i32, [vp, u64, ctypes.c_uint32, vp]),
     'kv_mex_plan_make': (i32, [i32, i32, u64, u32, i32, vp]),
+    'kv_mex_plan_short': (i32, [vp]),
     'kv_mex_emit': (i32, [vp, vp, u64, vp, vp]),
     'kv_mex_pack': (i32, [vp, vp, vp, vp, u64p]),
     'kv_mex_emit_pack': (i32, [vp, vp, u64, vp, vp, vp, u64, u64p, ctypes.POINTER(ctypes.c_int)]),
@@ -134,7 +135,7 @@ class MexPlan(ctypes.Structure):
     """kv_mex_plan of include/kvsketch.h"""
     _fields_ = [('ksize', ctypes.c_int32), ('ndest', ctypes.c_int32), ('C1', u32), ('F2', u32), ('fbits', u32), ('nwg1', u32),
                 ('cap1', u32), ('recw', u32), ('m', u32), ('read_len', u32), ('seg_words', u64), ('cnt_entries', u64),
-                ('n_kmers_global', u64), ('n_reads_global', u64), ('c_lo', u32 * 17), ('pad', u32)]
+                ('n_kmers_global', u64), ('n_reads_global', u64), ('c_lo', u32 * 17), ('flags', u32)]
 
 
 class KvError(RuntimeError):

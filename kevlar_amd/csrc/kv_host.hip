@@ -816,6 +816,16 @@ extern "C" int kv_reads_create(const char *bases, const uint64_t *offs, uint64_t
         close_run((uint32_t)n_reads);
         r->tile_max_bases = most_bases;
         r->n_tiles = (uint32_t)tiles.size();
+        // reads of one length (packed on the host: uniform_reads above takes only text on the device) lie exactly as uniform_reads
+        // lays them out -- read i at word i * wpr, the same reads per tile: say so, the lane-per-read cut asks for it
+        {
+            bool same = n_reads > 0 && r->h_len[0] > 0 && 2 * ((r->h_len[0] + KV_READ_PAD + 3) & ~3u) <= budget;
+            for (uint64_t i = 1; same && i < n_reads; ++i) same = r->h_len[i] == r->h_len[0];
+            if (same) {
+                r->uni_len = r->h_len[0];
+                r->uni_per_tile = std::min<uint32_t>(KV_TILE_MAX_READS, budget / (2 * ((r->h_len[0] + KV_READ_PAD + 3) & ~3u)));
+            }
+        }
         r->tile_lds_bytes = KV_TILE_LDS_BYTES + 256;   // + rolling-window over-read
         if (tiles.empty()) tiles.push_back(TileDesc{0u, 0u, 0u, 0u});
     }

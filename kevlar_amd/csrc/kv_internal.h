@@ -250,6 +250,7 @@ int kv_skm_route_distinct(const kv_reads *reads, int ksize, uint64_t n_kmers, in
 // minimizer-sharded exchange (kv_skm.hip): the plan every rank derives from the sample's global size, S1 into the caller's
 // exchange buffers, S2 + distinct route over what arrived
 int kv_skm_mex_plan(int ksize, uint64_t n_reads_global, uint32_t read_len, int ndest, kv_mex_plan *plan);
+int kv_skm_mex_plan_short(kv_mex_plan *plan);
 int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t read_base, uint64_t *d_seg, uint32_t *d_cnt,
                     uint64_t *d_out, uint64_t out_cap_words, uint64_t *records_per_dest, int *packed);
 int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_recv_seg, const uint32_t *d_recv_cnt, int n_src, int compact, int keep_scan,

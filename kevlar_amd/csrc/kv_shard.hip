@@ -438,6 +438,12 @@ extern "C" int kv_mex_plan_make(int kind, int ksize, uint64_t n_reads_global, ui
     return kv_skm_mex_plan(ksize, n_reads_global, read_len, ndest, plan);
 }
 
+extern "C" int kv_mex_plan_short(kv_mex_plan *plan)
+{
+    KV_REQUIRE(plan, KV_ERR_ARG, "kv_mex_plan_short: null plan");
+    return kv_skm_mex_plan_short(plan);
+}
+
 extern "C" int kv_mex_emit(const kv_reads *shard, const kv_mex_plan *plan, uint64_t read_base, void *d_seg, void *d_cnt)
 {
     KV_REQUIRE(shard && plan && d_seg && d_cnt, KV_ERR_ARG, "kv_mex_emit: null argument");

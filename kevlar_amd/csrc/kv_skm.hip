@@ -1604,7 +1604,7 @@ __device__ __forceinline__ void skm_route_item(const KvRouteSink &rs, const uint
     }
 }
 
-template <int KW, int TS, bool ORI = false>
+template <int KW, int TS, bool ORI = false, bool COMPACT = false>
 __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashParams hp, KvRouteSink rs)
 {
     __shared__ SkmTable<KW, TS> tb;
@@ -1640,7 +1640,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
             else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
             else next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET;
         }
-        skm_walk_bucket<KW, false, 0, false, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
+        skm_walk_bucket<KW, false, 0, COMPACT, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
             const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
             if (slot >= 0) atomicAdd(&cnt[slot], 1u);
             return slot < 0;
@@ -2393,7 +2393,7 @@ __global__ void k_mex_sum_kmers(const uint64_t *seg, const uint32_t *cnt, const 
     for (uint64_t sgi = blockIdx.x; sgi < n_segments; sgi += gridDim.x) {
         const uint32_t n = min(cnt[sgi], cap1);
         const uint64_t first = off ? off[sgi] : sgi * cap1;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) mine += skm_hdr_n(seg[(first + i) * recw]);
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) mine += recw == 2u ? skm_c_n(seg[(first + i) * 2u + 1u]) : skm_hdr_n(seg[(first + i) * recw]);
     }
     mine = wave_sum_u64(mine);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
@@ -2912,6 +2912,28 @@ int kv_skm_mex_plan(int ksize, uint64_t n_reads_global, uint32_t read_len, int n
     return KV_OK;
 }
 
+// the plan with 16-byte records (compact: kv_skm_device.h): the lane-per-read S1 writes them, the sorted S2 moves them
+int kv_skm_mex_plan_short(kv_mex_plan *plan)
+{
+    SkmGeom g;
+    skm_geom_k(g, plan->ksize);
+    KV_REQUIRE(g.kw == 1 && g.m == 12 && g.w == SKM_LANE_B && plan->read_len <= 256u && plan->read_len >= (uint32_t)plan->ksize &&
+               plan->F2 <= SKM_S2_MAXF && !(getenv("KV_SKM_COMPACT") && atoi(getenv("KV_SKM_COMPACT")) == 0) &&
+               !(getenv("KV_SKM_S1") && strcmp(getenv("KV_SKM_S1"), "lane") != 0) && !(g.dbg & ~4096u) &&
+               !(getenv("KV_SKM_S2") && strcmp(getenv("KV_SKM_S2"), "sorted") != 0),
+               KV_ERR_NOTIMPL, "kv_mex_plan_short: no 16-byte records for k = %d, reads of %u bases, %u fine buckets", plan->ksize, plan->read_len, plan->F2);
+    if (plan->flags & 1u) return KV_OK;
+    plan->flags |= 1u;
+    plan->seg_words = plan->seg_words / plan->recw * 2u;
+    plan->recw = 2u;
+    return KV_OK;
+}
+// what the plan's flags mean for the geometry
+static void skm_mex_apply_flags(SkmGeom &g, const kv_mex_plan *plan)
+{
+    if (plan->flags & 1u) { g.compact = 1u; g.recw = 2; g.ncap = std::min(g.ncap, SKM_C_BASES + 1 - g.k); g.sbw = ((64u * (uint32_t)g.ncap) >> 5) + 2u; }
+}
+
 // S1 of one shard into the caller's buffers ([C1][nwg1][cap1] records, [C1][nwg1] counts: what the plan says).
 // d_out != NULL: the filled part of the segments is packed into it as well, destination after destination (kv_skm_mex_pack), if it
 // holds out_cap_words; *packed says whether it did.  One stream synchronisation either way.
@@ -2925,6 +2947,7 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
     idx.mex_scan_ready = false;
     SkmGeom &g = idx.g;
     skm_geom_k(g, plan->ksize);
+    skm_mex_apply_flags(g, plan);
     g.C1 = plan->C1; g.F2 = plan->F2; g.fbits = plan->fbits; g.n_buckets = g.C1 * g.F2;
     g.nwg1 = plan->nwg1; g.cap1 = plan->cap1;
     g.quota1 = 0xfffffff0u;                                   // tiles are dealt dynamically; the plan's capacity has the slack
@@ -2938,8 +2961,9 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
     { const char *e = getenv("KV_SKM_ORIENT"); g.oriented = (e && atoi(e) == 0) ? 0u : 1u; }
     g.seg1 = d_seg; g.cnt1 = d_cnt;
     g.loose_cap = 1u << 16;
-    const size_t b_loose = kv_round_up(g.loose_cap * (size_t)g.recw * 8, 256), b_ctr = 256;
+    const size_t b_loose = kv_round_up(g.loose_cap * (size_t)g.lrecw * 8, 256), b_ctr = 256;
     const uint64_t n_seg = plan->cnt_entries;
+    KV_REQUIRE(!g.compact || skm_lane_fits(g, reads), KV_ERR_NOTIMPL, "kv_mex_emit: 16-byte records need a shard of equal-length reads (the lane-per-read cut)");
     const size_t b_off = d_out ? mex_scan_bytes(n_seg) : 0;
     KV_HIP(idx.arena.need(b_loose + b_ctr + b_off));
     g.loose = (uint64_t *)idx.arena.p;
@@ -2996,6 +3020,8 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     idx.mex_scan_ready = false;
     SkmGeom &g = idx.g;
     skm_geom_k(g, plan->ksize);
+    skm_mex_apply_flags(g, plan);
+    KV_REQUIRE(!(g.compact && keep_scan), KV_ERR_ARG, "kv_mex_route: the sample the scan is answered from needs records with positions (not a short-record plan)");
     const uint32_t Cl = plan->c_lo[my_dest + 1] - plan->c_lo[my_dest];
     g.C1 = Cl; g.F2 = plan->F2; g.fbits = plan->fbits; g.n_buckets = Cl * g.F2;
     g.nwg1 = plan->nwg1; g.cap1 = plan->cap1; g.n_src = (uint32_t)n_src;
@@ -3015,7 +3041,7 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     g.loose_cap = (uint64_t)(rec_est / 8.0) + n_kmers_exp / 16 + (1u << 20);
     const size_t rb = (size_t)g.recw * 8;
     const size_t b_seg2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * g.cap2 * rb, 256), b_cnt2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * 4, 256);
-    const size_t b_loose = kv_round_up(g.loose_cap * rb, 256), b_ctr = 256;
+    const size_t b_loose = kv_round_up(g.loose_cap * (size_t)g.lrecw * 8, 256), b_ctr = 256;
     const size_t b_off = compact ? mex_scan_bytes((uint64_t)Cl * nseg) : 0;
     KV_HIP(idx.arena.need(b_seg2 + b_cnt2 + b_loose + b_off + b_ctr));
     unsigned char *base = (unsigned char *)idx.arena.p;
@@ -3071,7 +3097,10 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     {
         KvProfScope prof("k_skm_route");
         const size_t lds = (256 + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(g.sbw)) * 4;
-        if (g.oriented) {
+        if (g.compact) {
+            if (g.oriented) hipLaunchKernelGGL((k_skm_route<1, 4096, true, true>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, g, hp, rs);
+            else hipLaunchKernelGGL((k_skm_route<1, 4096, false, true>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, g, hp, rs);
+        } else if (g.oriented) {
             if (g.kw == 1) hipLaunchKernelGGL((k_skm_route<1, 4096, true>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, g, hp, rs);
             else hipLaunchKernelGGL((k_skm_route<2, 2048, true>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, g, hp, rs);
         } else if (g.kw == 1) hipLaunchKernelGGL((k_skm_route<1, 4096>), dim3(nwg3), dim3(SKM_THREADS3), lds, st, g, hp, rs);

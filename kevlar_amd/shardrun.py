@@ -230,15 +230,18 @@ class ShardedTrio(object):
         1/8 of the reads has little to combine on its own (49 % of its k-mers are distinct against 20 % of the sample's); this
         way a rank hashes 1/N of the sample's DISTINCT k-mers.  = combine_minimizer(cut_minimizer(...)); callers with several
         samples interleave the two halves so that one sample's records travel while the next one's shard is cut."""
-        return self.combine_minimizer(self.cut_minimizer(batch, read_index_base, n_reads_global, read_len), keep_scan)
+        return self.combine_minimizer(self.cut_minimizer(batch, read_index_base, n_reads_global, read_len, short=not keep_scan), keep_scan)
 
-    def cut_minimizer(self, batch, read_index_base, n_reads_global, read_len):
+    def cut_minimizer(self, batch, read_index_base, n_reads_global, read_len, short=False):
         """First half of start_minimizer(): cut the shard, pack what was cut, tell every owner how much is coming (the slab of
         segment counts: blocking, small) and START the all-to-all of the records.  Returns a _Cut for combine_minimizer().
-        Every rank calls the halves of every sample in the same order (they are collectives)."""
+        Every rank calls the halves of every sample in the same order (they are collectives).  short (every rank alike): the
+        sample is not the one combine_minimizer(keep_scan) keeps, so its records travel without read positions where the
+        plan has such records (16 bytes instead of 24: hk.mex_plan); a rank whose shard cannot be cut that way (reads of
+        unequal length) declines like one whose segments overflowed, and the sample travels as pairs."""
         t0 = time.perf_counter()
         forced = os.environ.get('KV_MEX_TEST_DECLINE', '')          # tests: 'emit:RANK' / 'route:RANK' makes that rank decline there
-        plan = hk.mex_plan(self.sketch_cls, self.ksize, n_reads_global, read_len, self.world)
+        plan = hk.mex_plan(self.sketch_cls, self.ksize, n_reads_global, read_len, self.world, short=short)
         seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
         cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device=self.device)
         emitted = forced != 'emit:{}'.format(self.rank)
@@ -253,8 +256,16 @@ class ShardedTrio(object):
                 if not fitted:                              # fuller than expected: a buffer of the segments' full size always fits
                     packed = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
                     per_dest = hk.mex_pack(plan, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr())
-            except _local_failures():                       # records outside their exchange segment (minimizer skew), no memory for the
+            except _local_failures() as e:                  # records outside their exchange segment (minimizer skew), no memory for the
                 emitted, packed = False, None               # packed copy, a HIP error: the peers must hear of it, in the slab below
+                if os.environ.get('KV_MEX_VERBOSE'):
+                    print('rank {} declines the cut: {!r}'.format(self.rank, e), flush=True)
+            except ValueError as e:                         # (a short-record plan and a shard the lane-per-read cut does not take)
+                if not (int(plan.flags) & 1 and '16-byte records' in str(e)):
+                    raise
+                emitted, packed = False, None
+                if os.environ.get('KV_MEX_VERBOSE'):
+                    print('rank {} declines the cut: {!r}'.format(self.rank, e), flush=True)
         if not emitted:
             cnt.fill_(-1)                                   # the marker every destination finds in this rank's slab of counts
         t1 = time.perf_counter()

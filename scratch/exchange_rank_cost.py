@@ -49,9 +49,12 @@ def main():
             if minimizer:
                 # every shard cut into records; bucket owner d combines what the N shards hold of its buckets; band 0 receives
                 # the owners' pairs of band 0.  Rank 0's own part (its shard's emit, its buckets' combine) is timed below.
-                plan = hk.mex_plan(hk.Counttable, k, n_reads, L, world)
-                per_bucket = int(plan.nwg1) * int(plan.cap1) * int(plan.recw)
+                # (16-byte records for the samples nobody scans from their records: RANK_COST_SHORT=0 keeps 24 bytes everywhere)
+                want_short = os.environ.get('RANK_COST_SHORT', '1') != '0'
+                plans = {n: hk.mex_plan(hk.Counttable, k, n_reads, L, world, short=want_short and not (owner_scan and n == 'proband')) for n in names}
                 for n in names:
+                    plan = plans[n]
+                    per_bucket = int(plan.nwg1) * int(plan.cap1) * int(plan.recw)
                     segs, cnts = [], []
                     for r in range(world):
                         lo, _ = shardrun.shard_bounds(n_reads, world, r)
@@ -70,9 +73,10 @@ def main():
                         blocks.append(send.view(-1)[:c[0] * 2].clone().view(-1, 2))
                     recv_count[n] = torch.cat(blocks)
                     del segs, cnts
-                my_seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device=dev)
+                big = max(int(p_.seg_words) for p_ in plans.values())
+                my_seg = torch.empty(big, dtype=torch.int64, device=dev)
                 my_cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device=dev)
-                my_packed = torch.empty(int(plan.seg_words), dtype=torch.int64, device=dev)
+                my_packed = torch.empty(big, dtype=torch.int64, device=dev)
             for n in ([] if minimizer else names):
                 blocks = []
                 for r in range(world):
@@ -116,6 +120,7 @@ def main():
                 for n in order:
                     ta = time.perf_counter()
                     if minimizer:
+                        plan = plans[n]
                         per_dest, fitted = hk.mex_emit_pack(shards[n][0], plan, 0, my_seg.data_ptr(), my_cnt.data_ptr(), my_packed.data_ptr(), my_packed.shape[0])
                         assert fitted
                         rs, rc = mex_recv0[n]

@@ -356,6 +356,50 @@ def test_mex_route_judges_its_output_by_the_pairs_not_by_the_occurrences(hk):
     assert bool((probe[n_pairs // 2:] == 0x5a5a5a5a).all())
 
 
+def test_short_exchange_records_deliver_the_same_pairs(hk):
+    """a plan with 16-byte records (hk.mex_plan(short=True), kv_mex_plan_short) cuts, packs and combines to exactly the pairs of the
+    24-byte plan, in two thirds of the words; the sample the scan is answered from cannot use it, a shape without such records keeps
+    the classic plan, and a shard of unequal reads is refused by name"""
+    import torch
+    from kevlar_amd import synth
+    k, L = 31, 100
+    trio = synth.make_trio(150000, 32)
+    packed = synth.sample_reads_packed(trio['mother'], 45000, L, 0.005, 78)
+    batch = hk.ReadBatch.from_packed(packed, L)
+    nk = batch.num_kmers(k)
+    pairs, words = {}, {}
+    for short in (False, True):
+        plan = hk.mex_plan(hk.Counttable, k, packed.shape[0], L, 1, short=short)
+        assert (int(plan.flags) & 1, int(plan.recw)) == ((1, 2) if short else (0, 3))
+        seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device='cuda')
+        cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device='cuda')
+        out = torch.empty(int(plan.seg_words), dtype=torch.int64, device='cuda')
+        per_dest, fitted = hk.mex_emit_pack(batch, plan, 0, seg.data_ptr(), cnt.data_ptr(), out.data_ptr(), out.shape[0])
+        assert fitted
+        words[short] = per_dest[0] * int(plan.recw)
+        buf = torch.empty((nk, 2), dtype=torch.int64, device='cuda')
+        for compact in (False, True):                   # the segments as cut, and their filled part as it travels
+            src = out if compact else seg
+            counts, arrived = hk.mex_route(plan, 0, src.data_ptr(), cnt.data_ptr(), 1, buf.data_ptr(), nk, compact=compact)
+            assert arrived == nk
+            got = buf[:counts[0]].cpu().numpy()
+            got = got[np.lexsort((got[:, 1], got[:, 0]))]
+            if pairs:
+                assert np.array_equal(got, pairs['want'])
+            else:
+                pairs['want'] = got
+        if short:
+            with pytest.raises(ValueError):
+                hk.mex_route(plan, 0, seg.data_ptr(), cnt.data_ptr(), 1, buf.data_ptr(), nk, keep_scan=True)
+            reads = synth.unpack_reads(packed[:2000], L)
+            reads[7] = reads[7][:-3]
+            with pytest.raises(ValueError, match='16-byte records'):
+                hk.mex_emit(hk.ReadBatch(reads), plan, 0, seg.data_ptr(), cnt.data_ptr())
+    assert int(pairs['want'][:, 1].sum()) == nk
+    assert words[True] < 0.72 * words[False]
+    assert int(hk.mex_plan(hk.Counttable, 51, packed.shape[0], 150, 1, short=True).flags) & 1 == 0
+
+
 @pytest.mark.parametrize('world,k,read_len', [(2, 51, 150), (3, 64, 100), (2, 16, 100), (3, 33, 250)])
 def test_owner_scan_of_the_minimizer_layout_other_k_and_read_lengths(hk, world, k, read_len):
     """the scan answered by the owners of the minimizer buckets with two-word keys (k > 32), the shortest k the layout takes and
@@ -393,7 +437,8 @@ def free_port():
                                                     (2, 'gloo', 'minimizer-shardscan'), (1, 'nccl', 'minimizer-shardscan'),
                                                     (3, 'gloo', 'minimizer/emit:1'), (3, 'gloo', 'minimizer/route:2'), (2, 'gloo', 'minimizer/route:0'),
                                                     (3, 'gloo', 'minimizer/emit-oom:2'), (2, 'gloo', 'minimizer/route-hip:1'),
-                                                    (2, 'gloo', 'minimizer/owner-hip:1'), (2, 'gloo', 'minimizer/scan-fail:0')])
+                                                    (2, 'gloo', 'minimizer/owner-hip:1'), (2, 'gloo', 'minimizer/scan-fail:0'),
+                                                    (2, 'gloo', 'minimizer/ragged:1')])
 def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     """N ranks on this one GPU (gloo, staged exchange): each rank's sketches must equal band `rank` of a
     banded count of ALL reads, and the gathered hits the merged banded scan (tests/shard_worker.py).  The
@@ -421,7 +466,9 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), SHARD_BACKEND=backend, SHARD_DISTINCT='1' if distinct else '0')
-        if decline:
+        if decline and decline.startswith('ragged'):        # a control sample's records travel without positions (16 bytes); a rank whose
+            env['SHARD_RAGGED'] = decline.split(':')[1]     # shard has reads of unequal length cannot cut those: that sample goes as pairs
+        elif decline:
             env['KV_MEX_TEST_DECLINE'] = decline
         if distinct == 'minimizer':
             # the minimizer-sharded layout: super-k-mer records travel to their bucket's owner, which deduplicates at the
@@ -450,6 +497,8 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
         assert 'shard worker ok' in outs[rank]
         if decline and decline.startswith('owner'):
             assert '0 fallbacks, 1 scan fallbacks' in outs[rank], outs[rank][-400:]
+        elif decline and decline.startswith('ragged'):
+            assert '1 fallbacks, 0 scan fallbacks' in outs[rank], outs[rank][-400:]
         elif decline:
             assert '3 fallbacks' in outs[rank], outs[rank][-400:]        # one per sample, on every rank
             assert '1 scan fallbacks' in outs[rank], outs[rank][-400:]   # and the scan of a sample that fell back goes by the shards

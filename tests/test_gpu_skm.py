@@ -227,7 +227,9 @@ def test_skm_novel_scan_matches_oracle(hk, ok, skm, k):
     assert len(hits) > 50
     assert got == hits
     assert launches('k_skm_novel') == 1 and launches('k_novel_mark') == 0
-    assert launches('k_skm_emit') == 3              # the scan reused the buckets the case count had built
+    # the scan reused the buckets the case count had built -- unless that count wrote 16-byte records without read positions (k = 31,
+    # reads of one length, and nobody said a scan would follow: Counttable.expect_scan), which the scan cannot answer from: it cuts again
+    assert launches('k_skm_emit') == (4 if k == 31 else 3)
 
 
 def test_skm_novel_scan_rebuilds_when_the_case_was_counted_first_and_honours_skips(hk, ok, skm):
