@@ -66,6 +66,7 @@ struct SkmGeom {
     // and that strand is the k-mer's key in the bucket tables: the walk takes k-mers as they stand, no second strand, no comparison.
     // The exchange layouts keep classic records (canonical = the smaller strand, computed by the walk).
     uint32_t oriented;
+    uint32_t dd_maxn;                // k_skm_count combines identical records first (records of up to dd_maxn k-mers; 0: it does not)
 };
 
 // segment `seg` of coarse bucket c in seg1 / cnt1, counted in segments
@@ -1068,6 +1069,19 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split_sorted(SkmGeom sg)
 #endif
 #define SKM_PROBE_STEP(h) ((((h) >> 20) & SKM_STEP_MASK) | 1u)
 #endif
+// slot a hash starts at / the slot `step` further on, for tables of 2^n slots and of any other size (3072: the count's instances that
+// share their LDS with a table of records) -- there the top bits of the hash pick the slot, so the step comes from the low ones
+template <int TS>
+__device__ __forceinline__ uint32_t skm_slot0(uint32_t sh) { return (TS & (TS - 1)) == 0 ? sh & (uint32_t)(TS - 1) : __umulhi(sh, (uint32_t)TS); }
+template <int TS>
+__device__ __forceinline__ uint32_t skm_step_of(uint32_t sh) { return (TS & (TS - 1)) == 0 ? SKM_PROBE_STEP(sh) : (((sh >> 2) & 62u) | 1u); }
+template <int TS>
+__device__ __forceinline__ uint32_t skm_slot_next(uint32_t slot, uint32_t step)
+{
+    if ((TS & (TS - 1)) == 0) return (slot + step) & (uint32_t)(TS - 1);
+    slot += step;
+    return slot >= (uint32_t)TS ? slot - (uint32_t)TS : slot;
+}
 template <int KW, int TS>
 struct SkmTable {
     unsigned long long key[KW][TS];
@@ -1089,8 +1103,8 @@ template <int KW, int TS>
 __device__ __forceinline__ int skm_table_insert(SkmTable<KW, TS> &tb, const SkmKey<KW> &c)
 {
     const uint32_t sh = skm_slot_hash<KW>(c);
-    uint32_t slot = sh & (TS - 1);
-    const uint32_t step = SKM_PROBE_STEP(sh);
+    uint32_t slot = skm_slot0<TS>(sh);
+    const uint32_t step = skm_step_of<TS>(sh);
     for (int probe = 0; probe < SKM_MAXPROBE; ++probe) {
         // (reading the slot first and swapping only into an empty one was measured 5 % slower: the read does not save
         // the swap's round trip, it adds one for every new key)
@@ -1103,7 +1117,7 @@ __device__ __forceinline__ int skm_table_insert(SkmTable<KW, TS> &tb, const SkmK
             const unsigned long long old1 = atomicCAS(&tb.key[KW - 1][slot], SKM_EMPTY, (unsigned long long)c.w[KW - 1]);
             if (old1 == SKM_EMPTY || old1 == c.w[KW - 1]) return (int)slot;
         }
-        slot = (slot + step) & (TS - 1);
+        slot = skm_slot_next<TS>(slot, step);
     }
     return -1;
 }
@@ -1112,13 +1126,13 @@ template <int KW, int TS>
 __device__ __forceinline__ int skm_table_find(const SkmTable<KW, TS> &tb, const SkmKey<KW> &c)
 {
     const uint32_t sh = skm_slot_hash<KW>(c);
-    uint32_t slot = sh & (TS - 1);
-    const uint32_t step = SKM_PROBE_STEP(sh);
+    uint32_t slot = skm_slot0<TS>(sh);
+    const uint32_t step = skm_step_of<TS>(sh);
     for (int probe = 0; probe < SKM_MAXPROBE; ++probe) {
         const unsigned long long k0 = tb.key[0][slot];
         if (k0 == SKM_EMPTY) return -1;
         if (k0 == c.w[0] && (KW == 1 || tb.key[KW - 1][slot] == c.w[KW - 1])) return (int)slot;
-        slot = (slot + step) & (TS - 1);
+        slot = skm_slot_next<TS>(slot, step);
     }
     return -1;
 }
@@ -1328,6 +1342,167 @@ __device__ __forceinline__ void skm_walk_bucket(const SkmGeom &sg, uint32_t b, u
     }
 }
 
+// ---- identical records first (the k = 31 instances of the count) ------------------------------------------------------
+// (KV_SKM_DEDUP=1 only -- an experiment that did not pay, kept for the next attempt: see the end of this comment.)
+// Reads that cover the same stretch of the genome cut the same super-k-mers out of it: at 30 x, 61 % of a bucket's records repeat
+// another record of the bucket base for base (measured on the synthetic trio; the rest were cut short by a read's end or hold an
+// error), and they hold 60 % of the k-mer occurrences.  So the count first puts the bucket's RECORDS into a small LDS table (key = the
+// bases the record's k-mers use + their number; value = how many records said the same), and only then walks every distinct record
+// once, adding its weight to each of its k-mers: 2.5 x fewer cut-outs and table inserts for one insert per record.
+// Anything irregular -- no room in the record table, a record longer than dd_maxn k-mers, a k-mer that finds the k-mer table full --
+// only raises a flag: the workgroup then empties its tables and walks the bucket the plain way (skm_walk_bucket), whose loose
+// records carry the positions of the occurrences themselves.  (Saturating adds compose in any grouping: weights are exact.)
+// Measured (config 2, one stream, ms per step for the three samples): k_skm_count 9.25 without, 10.2 with 512 record slots + 3072 k-mer
+// slots (114 k buckets instead of 64 k: S2 2.24 -> 2.65 as well), 10.15 with 1024 + 4096 slots at two workgroups per CU (64 k buckets).
+// The walk and the inserts it saves (1.5 of 3.1 ms per sample, 60 % of them) are outweighed by what it adds per bucket: a phase that
+// only waits for the records and three dependent LDS atomics, a second barrier, and a walk whose groups of 64 slots hold ~22 records.
+#define SKM_REC_MAXPROBE 16
+template <int RS>
+struct SkmRecTable {
+    unsigned long long k0[RS], k1[RS];
+    uint32_t w[RS];
+};
+
+template <int RS>
+__device__ __forceinline__ void skm_rec_table_clear(SkmRecTable<RS> &rt)
+{
+    for (uint32_t i = threadIdx.x; i < RS; i += blockDim.x) { rt.k0[i] = SKM_EMPTY; rt.k1[i] = SKM_EMPTY; rt.w[i] = 0u; }
+}
+
+// every record of bucket b into the table; true if one of this thread's records could not be put there
+template <int RS, bool COMPACT>
+__device__ __forceinline__ bool skm_rec_combine(const SkmGeom &sg, uint32_t b, SkmRecTable<RS> &rt, int k)
+{
+    static_assert((RS & (RS - 1)) == 0, "record table: 2^n slots");
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    constexpr uint32_t recw = COMPACT ? 2u : 3u;
+    const uint32_t *cnt2 = sg.cnt2 + (uint64_t)b * sg.nwg2;
+    bool failed = false;
+    uint32_t p = wave;
+    uint32_t g = p / sg.nwg2, sgm = p - g * sg.nwg2;
+    uint64_t b0 = 0, w1 = 0;
+    auto load = [&](const uint64_t *rec) {
+        if (COMPACT) {
+            typedef uint64_t u64x2a __attribute__((ext_vector_type(2), aligned(16)));
+            const u64x2a both = *(const u64x2a *)rec;
+            b0 = both.x; w1 = skm_c_b1(both.y) | ((uint64_t)skm_c_n(both.y) << 40);
+        } else {
+            const uint32_t n = skm_hdr_n(rec[0]);
+            b0 = rec[1];
+            // (more than 20 bases in the second word: not a record this table takes -- the number of k-mers says so below)
+            w1 = (rec[2] & ((1ull << 40) - 1ull)) | ((uint64_t)n << 40);
+        }
+    };
+    {   // (as in skm_walk_bucket: the first records are requested together with the segment counts)
+        const uint32_t at = min(g * 64u + lane, sg.cap2 - 1u);
+        load(sg.seg2 + (((uint64_t)b * sg.nwg2 + sgm) * sg.cap2 + at) * (uint64_t)recw);
+    }
+    uint32_t maxc = 0;
+    for (uint32_t s2 = 0; s2 < sg.nwg2; ++s2) maxc = max(maxc, cnt2[s2]);
+    for (;;) {
+        if (g * 64u >= maxc) break;
+        if (g * 64u + lane < cnt2[sgm]) {
+            const uint32_t n = (uint32_t)(w1 >> 40), nb = n + (uint32_t)k - 1u;          // the bases its k-mers use: k .. 52
+            if (n == 0u || n > sg.dd_maxn || nb > SKM_C_BASES) {
+                failed = true;
+            } else {
+                // bases behind the last k-mer are whatever followed in the read: not part of the key
+                const uint64_t key0 = nb >= 32u ? b0 : b0 & ((1ull << (2u * nb)) - 1ull);
+                const uint64_t key1 = (nb > 32u ? w1 & ((1ull << (2u * (nb - 32u))) - 1ull) : 0ull) | ((uint64_t)n << 40);
+                uint32_t y = (uint32_t)key0 * 0x9e3779b1u ^ (uint32_t)(key0 >> 32) * 0x85ebca6bu ^ (uint32_t)key1 * 0xc2b2ae35u ^ (uint32_t)(key1 >> 32) * 0x27d4eb2fu;
+                y ^= y >> 15;
+                y *= 0x2c1b3c6du;
+                uint32_t slot = y >> (32 - __builtin_ctz(RS));
+                const uint32_t step = ((y >> 3) & 30u) | 1u;
+                bool placed = false;
+                if (key0 != SKM_EMPTY) {
+                    for (int probe = 0; probe < SKM_REC_MAXPROBE; ++probe) {
+                        const unsigned long long old0 = atomicCAS(&rt.k0[slot], SKM_EMPTY, (unsigned long long)key0);
+                        if (old0 == SKM_EMPTY || old0 == key0) {
+                            const unsigned long long old1 = atomicCAS(&rt.k1[slot], SKM_EMPTY, (unsigned long long)key1);
+                            if (old1 == SKM_EMPTY || old1 == key1) { atomicAdd(&rt.w[slot], 1u); placed = true; break; }
+                        }
+                        slot = (slot + step) & (uint32_t)(RS - 1);
+                    }
+                }
+                failed = failed || !placed;
+            }
+        }
+        p += nwaves;
+        g = p / sg.nwg2; sgm = p - g * sg.nwg2;
+        if (g * 64u >= maxc) break;
+        if (g * 64u + lane < cnt2[sgm])
+            load(sg.seg2 + (((uint64_t)b * sg.nwg2 + sgm) * sg.cap2 + g * 64u + lane) * (uint64_t)recw);
+    }
+    return failed;
+}
+
+// every distinct record of the table once (the table is emptied on the way): body(k-mer as the record holds it, weight) for each of
+// its k-mers, dealt to the lanes in units of SKM_UNIT k-mers like skm_walk_bucket deals them
+template <int RS, typename Body>
+__device__ __forceinline__ void skm_rec_walk(const SkmGeom &sg, SkmRecTable<RS> &rt, uint32_t *sbits_all, int k, Body body)
+{
+    constexpr uint32_t G = SKM_UNIT;
+    __shared__ uint8_t lane_of_all[SKM_THREADS3];       // the wave's occupied slots in order: the r-th of them sits in lane lane_of[r]
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    uint32_t *sbits = sbits_all + wave * sg.sbw;
+    uint8_t *lane_of = lane_of_all + wave * 64u;
+    for (uint32_t s0 = wave * 64u; s0 < (uint32_t)RS; s0 += nwaves * 64u) {
+        const uint32_t s = s0 + lane;
+        const uint64_t b0 = rt.k0[s];
+        uint64_t b1 = 0;
+        uint32_t nk = 0, wgt = 0;
+        if (b0 != SKM_EMPTY) {
+            const uint64_t w1 = rt.k1[s];
+            wgt = rt.w[s];
+            rt.k0[s] = SKM_EMPTY; rt.k1[s] = SKM_EMPTY; rt.w[s] = 0u;
+            nk = (uint32_t)(w1 >> 40);
+            b1 = w1 & ((1ull << 40) - 1ull);
+        }
+        const unsigned long long occ = __ballot(nk != 0u);
+        if (!occ) continue;
+        if (nk) lane_of[__popcll(occ & ((1ull << lane) - 1ull))] = (uint8_t)lane;      // (ordered with the reads below by the fences around the start bits)
+        const uint32_t nu = (nk + G - 1u) / G;
+        uint32_t incl = nu;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63), excl = incl - nu;
+        const uint32_t exnk = excl | (nk << 16);
+        const uint32_t nwords = (total >> 5) + 2u;
+        for (uint32_t wd = lane; wd < nwords; wd += 64) sbits[wd] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (nu) atomicOr(&sbits[excl >> 5], 1u << (excl & 31));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t before = 0;
+        for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+            const uint64_t starts = (uint64_t)__hip_atomic_load(&sbits[t0 >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) |
+                                    ((uint64_t)__hip_atomic_load(&sbits[(t0 >> 5) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) << 32);
+            const uint32_t t = t0 + lane;
+            // (the start bits number the records that have units: empty slots lie between them here, hence the look-up)
+            const uint32_t owner = lane_of[(before + (uint32_t)__popcll(starts & ((2ull << lane) - 1ull)) - 1u) & 63u];
+            before += (uint32_t)__popcll(starts);
+            const uint32_t oe = (uint32_t)__shfl((int)exnk, (int)owner);
+            const uint32_t ow = (uint32_t)__shfl((int)wgt, (int)owner);
+            const uint64_t o0 = skm_shfl64(b0, owner), o1 = skm_shfl64(b1, owner);
+            const uint32_t j0 = t < total ? (t - (oe & 0xffffu)) * G : 0u;
+            const uint32_t cnt = t < total ? min(G, (oe >> 16) - j0) : 0u;
+            SkmKey<1> fw = skm_kmer_of<1>(o0, o1, 0ull, j0, k);
+            const uint32_t tail = (uint32_t)skm_window64(o0, o1, 0ull, j0 + (uint32_t)k);
+#pragma unroll
+            for (uint32_t u = 0; u < G; ++u) {
+                if (u) { SkmKey<1> other = fw; skm_roll<1>(fw, other, (tail >> (2u * (u - 1u))) & 3u, k); }
+                if (u < cnt) body(fw, ow);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- S3: count ------------------------------------------------------------------------------------------
 // dynamic LDS of the bucket kernels: [256] byte -> ASCII table, [T * C] bin cursors (count only), then the per-wave
 // scratch: record-start bits of the walk, reused as the queue of occupied slots
@@ -1340,12 +1515,15 @@ __host__ __device__ inline uint32_t skm_wave_scratch_words(uint32_t sbw) { retur
 #if !defined(SKM_K2_WAVES)
 #define SKM_K2_WAVES 6
 #endif
-template <int KW, int TS, bool KNOBS, int FK, bool COMPACT = false, bool ORI = false>
-__global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : 6) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
+// RS: slots of the table of records (above) the instance combines identical records in before it walks them; 0: it walks them all
+template <int KW, int TS, bool KNOBS, int FK, bool COMPACT = false, bool ORI = false, int RS = 0>
+__global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : (RS >= 1024 ? 4 : 6)) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
                                                            const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
+    static_assert(RS == 0 || (KW == 1 && ORI && !KNOBS), "records are combined in the oriented one-word instances");
     __shared__ SkmTable<KW, TS> tb;
     __shared__ uint32_t cnt[TS];                 // occurrences of the key in the same slot
+    __shared__ SkmRecTable<RS ? RS : 1> rt;
     __shared__ uint32_t next_bucket;
     __shared__ uint32_t abl_cur, abl_b0, abl_prev;      // abundance list: entries appended so far, ... when the bucket began, the bucket
     __shared__ uint32_t dl_cur, dl_b0;                  // distinct list: the same two
@@ -1377,6 +1555,7 @@ __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : 6) void k_sk
     // while the current bucket is processed
     skm_table_clear(tb);
     for (uint32_t i = threadIdx.x; i < TS; i += SKM_THREADS3) cnt[i] = 0;
+    if constexpr (RS != 0) skm_rec_table_clear(rt);
     if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET; abl_cur = 0; abl_b0 = 0; abl_prev = 0xffffffffu; dl_cur = 0; dl_b0 = 0; }
     // where the finished bucket's entries of the abundance list lie (nothing if the workgroup's stretch ran out)
     auto abl_close = [&]() {
@@ -1412,8 +1591,27 @@ __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : 6) void k_sk
                 }
             }
         }
-        // combine the occurrences of the bucket
-        if (!(SKM_DBG(sg) & 2u)) skm_walk_bucket<KW, false, FK, COMPACT, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
+        // combine the occurrences of the bucket: identical records first where the instance has the table for them
+        bool plain = true;
+        if constexpr (RS != 0) {
+            bool failed = skm_rec_combine<RS, COMPACT>(sg, b, rt, k);
+            __syncthreads();
+            skm_rec_walk<RS>(sg, rt, scratch, k, [&](const SkmKey<1> &c1, uint32_t wgt) {
+                SkmKey<KW> c;
+                c.w[0] = c1.w[0];
+                const int slot = skm_table_insert(tb, c);
+                if (slot >= 0) atomicAdd(&cnt[slot], wgt);
+                else failed = true;
+            });
+            plain = __syncthreads_or(failed ? 1 : 0) != 0;
+            if (plain) {                         // (a bucket in thousands: too many distinct records or k-mers for the tables) start over
+                skm_table_clear(tb);
+                for (uint32_t i = threadIdx.x; i < TS; i += SKM_THREADS3) cnt[i] = 0;
+                if (threadIdx.x == 0) atomicAdd(&sg.ctr[12], 1ull);
+                __syncthreads();
+            }
+        }
+        if (plain && !(SKM_DBG(sg) & 2u)) skm_walk_bucket<KW, false, FK, COMPACT, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
             if (SKM_DBG(sg) & 128u) { n_added += c.w[0] & 1; return false; }
             // (KV_SKM_FORCE_LOOSE: one key in 64 is treated like a key that found its table full -- every occurrence travels alone;
             // results stay exact, tests use it to put single k-mers on the loose list of a batch that otherwise fits)
@@ -2422,7 +2620,18 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.ncap = 32 * g.nbw - k + 1;
     g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
     if (getenv("KV_SKM_FORCE_LOOSE")) g.dbg |= 4096u;
-    const uint32_t table_slots = g.kw == 1 ? 4096u : 2048u;
+    // KV_SKM_DEDUP=1 (k = 31, oriented records): k_skm_count combines identical records before their k-mers (skm_rec_combine): a 3072-slot
+    // k-mer table beside a 512-slot table of records, or KV_SKM_DEDUP_RS=1024: 4096 beside 1024 at two workgroups per CU.  Off unless asked
+    // for: measured SLOWER (k_skm_count 9.25 -> 10.2 ms per step of config 2 either way, profiles/README.md round 5).
+    // KV_SKM_DEDUP_MAXN=n: records of more than n k-mers send their bucket down the plain walk (tests: n = 5 sends nearly every bucket there)
+    {
+        const char *eo = getenv("KV_SKM_ORIENT"), *ed = getenv("KV_SKM_DEDUP"), *em = getenv("KV_SKM_DEDUP_MAXN");
+        const bool dd = k == 31 && !(eo && atoi(eo) == 0) && (ed && atoi(ed) == 1) && !g.dbg && !getenv("KV_SKM_ANY_K");
+        g.dd_maxn = dd ? (uint32_t)(SKM_C_BASES + 1 - k) : 0u;
+        if (dd && em) g.dd_maxn = (uint32_t)std::max(0, std::min(atoi(em), SKM_C_BASES + 1 - k));
+    }
+    const bool dd_big = g.dd_maxn && getenv("KV_SKM_DEDUP_RS") && atoi(getenv("KV_SKM_DEDUP_RS")) >= 1024;      // (experiment: 1024 record slots beside 4096 k-mer slots, two workgroups per CU)
+    const uint32_t table_slots = g.kw == 1 ? (g.dd_maxn && !dd_big ? 3072u : 4096u) : 2048u;
     const char *tgt_env = getenv("KV_SKM_BUCKET_KMERS");      // tests shrink the buckets to exercise many of them on small inputs
     // k-mers per fine bucket: as many as leave the LDS table ~0.4 full (0.29 for two-word keys, whose longer windows put
     // fewer, bigger minimizer loci into a bucket: more variance) given the share of distinct k-mers the previous batch
@@ -2433,6 +2642,8 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     // (two-word keys at 0.35: 2.2 M occurrences per 30x sample missed the tables and took the spill path, 67 ms per step of config 5; 0.29: 62 ms)
     uint64_t target = (uint64_t)((g.kw == 1 ? 0.4 : 0.29) * table_slots / frac);
     target = std::max<uint64_t>(table_slots / 2, std::min<uint64_t>(target, g.kw == 1 ? 2ull * table_slots : table_slots + table_slots / 2));
+    // (the table of records: ~4 % of a 30x bucket's occurrences are distinct records -- 195 of 512 slots at 4608 occurrences)
+    if (g.dd_maxn && !dd_big) target = std::min<uint64_t>(target, 4608);
     if (tgt_env) target = std::max<uint64_t>(64, strtoull(tgt_env, nullptr, 10));
     uint64_t nfine = std::max<uint64_t>(1, (n_kmers + target - 1) / target);
     {
@@ -2652,7 +2863,14 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
                 if (sg.k == 31 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31, true, true>;
             }
             if (sg.k == 51 && sg.recw == 4 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<2, 2048, false, 51, false, true>;
+            // k = 31: identical records are combined before their k-mers are (skm_rec_combine; skm_build sized the buckets for it)
+            if (sg.dd_maxn && sg.k == 31 && (sg.compact || sg.recw == 3) && !sg.dbg) {
+                kernel = sg.compact ? k_skm_count<1, 3072, false, 31, true, true, 512> : k_skm_count<1, 3072, false, 31, false, true, 512>;
+                if (getenv("KV_SKM_DEDUP_RS") && atoi(getenv("KV_SKM_DEDUP_RS")) >= 1024)
+                    kernel = sg.compact ? k_skm_count<1, 4096, false, 31, true, true, 1024> : k_skm_count<1, 4096, false, 31, false, true, 1024>;
+            }
         }
+        if (!sg.oriented) sg.dd_maxn = 0;
         hipLaunchKernelGGL(kernel, dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
     }
     {
@@ -2672,7 +2890,7 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
         // what the batch looked like: if most k-mers are distinct (low coverage per batch) cutting and bucketing the
         // reads buys nothing, and if many occurrences missed the LDS tables the buckets were too full; either way
         // the next batches into this sketch take the one-item-per-k-mer partition (until the sketch is cleared)
-        unsigned long long sc[10] = {0};
+        unsigned long long sc[13] = {0};
         const bool got = hipMemcpy(sc, sg.ctr, sizeof(sc), hipMemcpyDeviceToHost) == hipSuccess;
         idx.dl_valid = dl_new && got && rc == KV_OK && sc[9] == 0;
         if (dl_new && getenv("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] distinct list: %s (%llu workgroups ran out of %u entries)\n", idx.dl_valid ? "kept" : "dropped", sc[9], idx.dl_cap_wg);
@@ -2683,8 +2901,9 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
             s->skm_distinct = distinct;
             { std::lock_guard<std::mutex> glk(g_skm_mu); g_skm_last_distinct = distinct; }
             if (getenv("KV_SKM_VERBOSE"))
-                fprintf(stderr, "[kv_skm] batch of %llu k-mers: %.1f%% distinct, %.2f%% outside the LDS tables, %llu of %llu records (%d bytes each) outside their segments%s\n",
-                        (unsigned long long)n_kmers, 100 * distinct, 100 * alone, sc[6], sc[5], 8 * sg.recw, s->skm_off ? " -> next batches take the plain partition" : "");
+                fprintf(stderr, "[kv_skm] batch of %llu k-mers: %.1f%% distinct, %.2f%% outside the LDS tables, %llu of %llu records (%d bytes each) outside their segments, %llu of %u buckets walked record by record%s\n",
+                        (unsigned long long)n_kmers, 100 * distinct, 100 * alone, sc[6], sc[5], 8 * sg.recw, sg.dd_maxn ? sc[12] : (unsigned long long)sg.n_buckets, sg.n_buckets,
+                        s->skm_off ? " -> next batches take the plain partition" : "");
         }
     }
     if (rc != KV_OK) {

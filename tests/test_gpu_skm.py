@@ -85,6 +85,24 @@ def test_skm_count_matches_oracle(hk, ok, skm, kind, k, tablesize):
     assert_same_tables(dev, ref)
 
 
+@pytest.mark.parametrize('rs,maxn', [('512', None), ('1024', None), ('512', '5')])
+def test_skm_count_with_identical_records_combined_first(hk, ok, skm, rs, maxn):
+    """KV_SKM_DEDUP=1 (off by default: measured slower): the count puts a bucket's records into an LDS table first and walks every distinct
+    record once with its weight -- same tables, same scan; maxn = 5 sends every bucket that holds a longer record down the plain walk"""
+    os.environ['KV_SKM_DEDUP'] = '1'
+    os.environ['KV_SKM_DEDUP_RS'] = rs
+    if maxn:
+        os.environ['KV_SKM_DEDUP_MAXN'] = maxn
+    try:
+        reads = trio_reads(100000, 30000, 43)
+        for hint in (False, True):                  # 16-byte records, and records with positions + the distinct list
+            got, hits = scan_both(hk, ok, reads, 31, 6e6, hint=hint)
+            assert len(hits) > 50 and got == hits
+    finally:
+        for name in ('KV_SKM_DEDUP', 'KV_SKM_DEDUP_RS', 'KV_SKM_DEDUP_MAXN', 'KV_SKM_DL'):
+            os.environ.pop(name, None)
+
+
 @pytest.mark.parametrize('read_len,k', [(36, 31), (75, 25), (150, 31), (151, 51), (251, 31), (600, 31)])
 def test_skm_equal_length_reads_of_other_lengths(hk, ok, skm, read_len, k):
     """batches of equal-length reads handed over as packed words (what the device ingest and the generators produce) take the
