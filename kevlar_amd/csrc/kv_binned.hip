@@ -1111,7 +1111,9 @@ bool kv_binned_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_km
     // half as much, and what is left to compare is T global compare-and-swaps per k-mer that reaches the tables (~27 G/s device-wide)
     // against streaming the tables once (read + write at ~4.7 TB/s) plus the split: even at one k-mer per 32 bins -- config 4's
     // 0.6x batches under 8-fold banding: 164 M k-mers into 2 G bins -- the atomics cost 24 ms and the streamed tables 3.4 + 7
-    const uint64_t density = reads && kv_bin_two_bit(s, reads) ? 32 : 8;
+    // (a hash list has no hashing left to pay at all: 164 M hashes into a band's 2 G-bin tables -- config 4 with every band resident,
+    // scratch/cfg4_whole.py -- took 30.9 ms through the atomics)
+    const uint64_t density = !reads || kv_bin_two_bit(s, reads) ? 32 : 8;
     return pmin >= (1ull << 20) && expected >= (1ull << 22) && expected * density >= pmax;
 }
 
