@@ -2400,9 +2400,9 @@ static uint32_t skm_wave_plan(const SkmGeom &g, const kv_reads *reads, int *ch)
 
 // the lane-per-read kernel takes batches of equal-length reads with w = 20 or 40 (k = 31, 51: m = 12) and up to 256 bases;
 // KV_SKM_S1=wave|tile keeps the older kernels
-static bool skm_lane_fits(const SkmGeom &g, const kv_reads *reads)
+// (by the read length alone: kv_mex_plan_short, which sees no reads, asks this way)
+static bool skm_lane_fits_len(const SkmGeom &g, uint32_t L)
 {
-    const uint32_t L = reads->uni_len;
     if (!L || L < (uint32_t)g.k || g.m != 12 || (g.w != SKM_LANE_B && g.w != 2 * SKM_LANE_B) || L > 256u) return false;
     const char *e1 = getenv("KV_SKM_S1");
     if (e1 && strcmp(e1, "lane") != 0) return false;
@@ -2410,8 +2410,10 @@ static bool skm_lane_fits(const SkmGeom &g, const kv_reads *reads)
     // per CU for it -- at six waves it spilled and measured slower than the wave kernel, 5.5 against 4.1 ms per step of config 5)
     if (g.w != SKM_LANE_B && e1 && !strcmp(e1, "lane6")) return false;
     if (g.dbg & ~4096u) return false;                           // the phase switches of the dissection scripts live in the older kernels
-    return (size_t)skm_lane_slice_words((L + 15u) / 16u) * 4 * (SKM_LANE_THREADS / 64) + 1200 <= 160000u / (SKM_LANE_WAVES / 2);       // three workgroups per CU
+    // three workgroups per CU: reads of up to 112 bases (seven packed words and their reverse complement per lane)
+    return (size_t)skm_lane_slice_words((L + 15u) / 16u) * 4 * (SKM_LANE_THREADS / 64) + 1200 <= 160000u / (SKM_LANE_WAVES / 2);
 }
+static bool skm_lane_fits(const SkmGeom &g, const kv_reads *reads) { return skm_lane_fits_len(g, reads->uni_len); }
 
 void skm_launch_emit(const SkmGeom &g, const kv_reads *reads, hipStream_t st)
 {
@@ -3136,9 +3138,8 @@ int kv_skm_mex_plan_short(kv_mex_plan *plan)
 {
     SkmGeom g;
     skm_geom_k(g, plan->ksize);
-    KV_REQUIRE(g.kw == 1 && g.m == 12 && g.w == SKM_LANE_B && plan->read_len <= 256u && plan->read_len >= (uint32_t)plan->ksize &&
+    KV_REQUIRE(g.kw == 1 && g.w == SKM_LANE_B && skm_lane_fits_len(g, plan->read_len) &&
                plan->F2 <= SKM_S2_MAXF && !(getenv("KV_SKM_COMPACT") && atoi(getenv("KV_SKM_COMPACT")) == 0) &&
-               !(getenv("KV_SKM_S1") && strcmp(getenv("KV_SKM_S1"), "lane") != 0) && !(g.dbg & ~4096u) &&
                !(getenv("KV_SKM_S2") && strcmp(getenv("KV_SKM_S2"), "sorted") != 0),
                KV_ERR_NOTIMPL, "kv_mex_plan_short: no 16-byte records for k = %d, reads of %u bases, %u fine buckets", plan->ksize, plan->read_len, plan->F2);
     if (plan->flags & 1u) return KV_OK;
