@@ -2400,6 +2400,15 @@ static uint32_t skm_wave_plan(const SkmGeom &g, const kv_reads *reads, int *ch)
 
 // the lane-per-read kernel takes batches of equal-length reads with w = 20 or 40 (k = 31, 51: m = 12) and up to 256 bases;
 // KV_SKM_S1=wave|tile keeps the older kernels
+// workgroups of the lane-per-read cut a CU holds at once, by their LDS (0: not even two -- other kernels cut such reads)
+static uint32_t skm_lane_wgs_per_cu(uint32_t L)
+{
+    const size_t need = (size_t)skm_lane_slice_words((L + 15u) / 16u) * 4 * (SKM_LANE_THREADS / 64) + 1200;
+    const char *e = getenv("KV_SKM_LANE_MAXWG");                // (A/B: 3 keeps the cut to the lengths that fit three times)
+    const uint32_t floor_wgs = e ? (uint32_t)std::max(2, std::min(3, atoi(e))) : 2u;
+    if (need <= 160000u / (SKM_LANE_WAVES / 2)) return 3u;
+    return (floor_wgs <= 2u && need <= 160000u / 2u) ? 2u : 0u;
+}
 // (by the read length alone: kv_mex_plan_short, which sees no reads, asks this way)
 static bool skm_lane_fits_len(const SkmGeom &g, uint32_t L)
 {
@@ -2410,8 +2419,8 @@ static bool skm_lane_fits_len(const SkmGeom &g, uint32_t L)
     // per CU for it -- at six waves it spilled and measured slower than the wave kernel, 5.5 against 4.1 ms per step of config 5)
     if (g.w != SKM_LANE_B && e1 && !strcmp(e1, "lane6")) return false;
     if (g.dbg & ~4096u) return false;                           // the phase switches of the dissection scripts live in the older kernels
-    // three workgroups per CU: reads of up to 112 bases (seven packed words and their reverse complement per lane)
-    return (size_t)skm_lane_slice_words((L + 15u) / 16u) * 4 * (SKM_LANE_THREADS / 64) + 1200 <= 160000u / (SKM_LANE_WAVES / 2);
+    // three workgroups per CU for reads of up to 112 bases (seven packed words and their reverse complement per lane), two up to 224
+    return skm_lane_wgs_per_cu(L) >= 2u;
 }
 static bool skm_lane_fits(const SkmGeom &g, const kv_reads *reads) { return skm_lane_fits_len(g, reads->uni_len); }
 
@@ -2676,7 +2685,8 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     // at least one whole ticket per workgroup: the per-writer capacities below assume even shares
     g.nwg1 = (uint32_t)std::min<uint64_t>((std::max<uint32_t>(reads->n_tiles, 1u) + SKM_TILES_PER_TICKET - 1) / SKM_TILES_PER_TICKET,
                                           std::min<uint32_t>(768u, 3u * (uint32_t)cus));
-    if (g.w == 2 * SKM_LANE_B && skm_lane_fits(g, reads)) g.nwg1 = std::min<uint32_t>(g.nwg1, 2u * (uint32_t)cus);      // (the w = 40 lane kernel: two workgroups per CU)
+    // (the w = 40 lane kernel, and reads whose LDS slices fit a CU only twice: two workgroups per CU)
+    if (skm_lane_fits(g, reads) && (g.w == 2 * SKM_LANE_B || skm_lane_wgs_per_cu(reads->uni_len) < 3u)) g.nwg1 = std::min<uint32_t>(g.nwg1, 2u * (uint32_t)cus);
     {
         // the wave kernel with 1024-thread workgroups runs one workgroup per CU (fewer writers: see k_skm_emit_wave)
         int ch_unused = 16;

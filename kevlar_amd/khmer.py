@@ -909,7 +909,7 @@ def route_distinct(batch, sketch_cls, ksize, ndest, out_ptr, cap_items):
 def mex_plan(sketch_cls, ksize, n_reads_global, read_len, ndest, short=False):
     """The geometry of a minimizer-sharded exchange of one sample (kv_mex_plan_make): the same on every rank, because it
     depends on the sample's global size only.  short: 16-byte records without read positions where the plan's shape has them
-    (kv_mex_plan_short; k = 31 and reads of up to 112 bases today) -- for a sample nobody scans from these records; a shape
+    (kv_mex_plan_short; k = 31 and reads of up to 224 bases today) -- for a sample nobody scans from these records; a shape
     without them keeps the classic plan (plan.flags & 1 says which it is)."""
     plan = _lib.MexPlan()
     check(_lib.load().kv_mex_plan_make(sketch_cls._kind, int(ksize), int(n_reads_global), int(read_len), int(ndest), ctypes.byref(plan)))

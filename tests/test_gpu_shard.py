@@ -398,7 +398,8 @@ def test_short_exchange_records_deliver_the_same_pairs(hk):
     assert int(pairs['want'][:, 1].sum()) == nk
     assert words[True] < 0.72 * words[False]
     assert int(hk.mex_plan(hk.Counttable, 51, packed.shape[0], 150, 1, short=True).flags) & 1 == 0
-    assert int(hk.mex_plan(hk.Counttable, 31, packed.shape[0], 151, 1, short=True).flags) & 1 == 0      # (the lane-per-read cut takes reads of up to 112 bases)
+    assert int(hk.mex_plan(hk.Counttable, 31, packed.shape[0], 151, 1, short=True).flags) & 1 == 1
+    assert int(hk.mex_plan(hk.Counttable, 31, packed.shape[0], 250, 1, short=True).flags) & 1 == 0      # (the lane-per-read cut takes reads of up to 224 bases)
 
 
 @pytest.mark.parametrize('world,k,read_len', [(2, 51, 150), (3, 64, 100), (2, 16, 100), (3, 33, 250)])
