@@ -67,6 +67,7 @@ struct SkmGeom {
     // The exchange layouts keep classic records (canonical = the smaller strand, computed by the walk).
     uint32_t oriented;
     uint32_t dd_maxn;                // k_skm_count combines identical records first (records of up to dd_maxn k-mers; 0: it does not)
+    uint32_t bpt;                    // buckets per ticket of the bucket kernels' work counter (a power of two)
 };
 
 // segment `seg` of coarse bucket c in seg1 / cnt1, counted in segments
@@ -1556,7 +1557,7 @@ __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : (RS >= 1024 
     skm_table_clear(tb);
     for (uint32_t i = threadIdx.x; i < TS; i += SKM_THREADS3) cnt[i] = 0;
     if constexpr (RS != 0) skm_rec_table_clear(rt);
-    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET; abl_cur = 0; abl_b0 = 0; abl_prev = 0xffffffffu; dl_cur = 0; dl_b0 = 0; }
+    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * sg.bpt; abl_cur = 0; abl_b0 = 0; abl_prev = 0xffffffffu; dl_cur = 0; dl_b0 = 0; }
     // where the finished bucket's entries of the abundance list lie (nothing if the workgroup's stretch ran out)
     auto abl_close = [&]() {
         if (sg.abl_keys && abl_prev != 0xffffffffu) {
@@ -1577,14 +1578,14 @@ __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : (RS >= 1024 
         if (threadIdx.x == 0) {
             abl_close();
             abl_prev = b; abl_b0 = abl_cur; dl_b0 = dl_cur;
-            if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
+            if ((b + 1u) & (sg.bpt - 1u)) next_bucket = b + 1u;
             else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
             else {
                 const unsigned long long ticket = atomicAdd(&sg.ctr[3], 1ull);
-                next_bucket = (uint32_t)ticket * SKM_BUCKETS_PER_TICKET;     // (a raised flag ends the pass: the caller redoes the batch)
+                next_bucket = (uint32_t)ticket * sg.bpt;     // (a raised flag ends the pass: the caller redoes the batch)
                 // a batch that does not fit the LDS tables (low coverage per batch: nearly every k-mer distinct) is given up
                 // early: once 2 % of the buckets are done, more than 4 % of their k-mers outside the tables raise the flag
-                const unsigned long long done = ticket * SKM_BUCKETS_PER_TICKET;
+                const unsigned long long done = ticket * sg.bpt;
                 if (done * 50ull >= sg.n_buckets) {
                     const unsigned long long now = __hip_atomic_load(&sg.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), start = sg.ctr[6];
                     if (now > start && (now - start) * 25ull > done * sg.bucket_kmers) sg.ctr[1] = 1;
@@ -1819,7 +1820,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
     uint64_t n_distinct = 0;
     skm_table_clear(tb);
     for (uint32_t i = threadIdx.x; i < TS; i += SKM_THREADS3) cnt[i] = 0;
-    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET; dl_cur = 0; dl_b0 = 0; dl_prev = 0xffffffffu; }
+    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * sg.bpt; dl_cur = 0; dl_b0 = 0; dl_prev = 0xffffffffu; }
     auto dl_close = [&]() {
         if (sg.dl_keys && dl_prev != 0xffffffffu) {
             sg.dl_bstart[dl_prev] = blockIdx.x * sg.dl_cap_wg + dl_b0;
@@ -1834,9 +1835,9 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
         if (threadIdx.x == 0) {
             dl_close();
             dl_prev = b; dl_b0 = dl_cur;
-            if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
+            if ((b + 1u) & (sg.bpt - 1u)) next_bucket = b + 1u;
             else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
-            else next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * SKM_BUCKETS_PER_TICKET;
+            else next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * sg.bpt;
         }
         skm_walk_bucket<KW, false, 0, COMPACT, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
             const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
@@ -1933,7 +1934,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
     if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
     load_descs(ns, p);
     const int k = sg.k;
-    if (threadIdx.x == 0) next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET;
+    if (threadIdx.x == 0) next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * sg.bpt;
     for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
         __syncthreads();
         const uint32_t b = next_bucket;
@@ -1942,15 +1943,15 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel(SkmGeom sg, Reads
         if (threadIdx.x < TS / 32) { flag[threadIdx.x] = 0; rej[threadIdx.x] = 0; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
+            if ((b + 1u) & (sg.bpt - 1u)) next_bucket = b + 1u;
             else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
             else {
                 const unsigned long long ticket = atomicAdd(&sg.ctr[4], 1ull);
-                next_bucket = (uint32_t)ticket * SKM_BUCKETS_PER_TICKET;
+                next_bucket = (uint32_t)ticket * sg.bpt;
                 // the count pass's early exit, for a scan that cut the batch itself: once 2 % of the buckets are done, more than
                 // 4 % of their k-mers outside the tables (a batch of low coverage: nearly every k-mer distinct) raise the flag --
                 // the caller then scans tile by tile, and remembers -- instead of pushing the whole batch through the loose list
-                const unsigned long long done = ticket * SKM_BUCKETS_PER_TICKET;
+                const unsigned long long done = ticket * sg.bpt;
                 if (done * 50ull >= sg.n_buckets) {
                     const unsigned long long now = __hip_atomic_load(&sg.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), start = sg.ctr[6];
                     if (now > start && (now - start) * 25ull > done * sg.bucket_kmers) sg.ctr[1] = 1;
@@ -2045,7 +2046,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, 
     uint32_t *scratch = dyn;
     load_descs(ns, p);
     skm_table_clear(itb);
-    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET; n_int = 0; n_cand = 0; }
+    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * sg.bpt; n_int = 0; n_cand = 0; }
     auto mark_pass = [&](uint32_t b) {
         skm_walk_bucket<KW, true, 0, false, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t pos) {
             if (skm_cacheable<KW>(c) && skm_table_find(itb, c) >= 0) skm_mark(p, rd, pos, sg.stride);
@@ -2063,9 +2064,9 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_novel_list(SkmGeom sg, 
         skm_table_clear(rtb);
         __syncthreads();
         if (threadIdx.x == 0) {
-            if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
+            if ((b + 1u) & (sg.bpt - 1u)) next_bucket = b + 1u;
             else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
-            else next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET;
+            else next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * sg.bpt;
             n_cand = 0;
         }
         // the first list entries are requested before the controls' lists are worked in: they arrive meanwhile
@@ -2214,16 +2215,16 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_set_hits(SkmGeom sg, No
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
     uint32_t *scratch = dyn;
     skm_table_clear(itb);
-    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET; n_int = 0; n_hit = 0; }
+    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * sg.bpt; n_int = 0; n_hit = 0; }
     for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
         __syncthreads();
         const uint32_t b = next_bucket;
         if (b >= sg.n_buckets) break;
         __syncthreads();
         if (threadIdx.x == 0) {
-            if ((b + 1u) % SKM_BUCKETS_PER_TICKET) next_bucket = b + 1u;
+            if ((b + 1u) & (sg.bpt - 1u)) next_bucket = b + 1u;
             else if (taken + 1 >= sg.quota3) next_bucket = 0xffffffffu;
-            else next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * SKM_BUCKETS_PER_TICKET;
+            else next_bucket = (uint32_t)atomicAdd(&sg.ctr[4], 1ull) * sg.bpt;
         }
         const uint32_t e0 = sg.dl_bstart[b], en = sg.dl_bcount[b];
         for (uint32_t i = threadIdx.x; i < en; i += SKM_THREADS3) {
@@ -2357,7 +2358,23 @@ inline uint32_t skm_nwg3(const SkmGeom &g)
     // persistent workgroups of the bucket kernels: three per CU fill its LDS (KV_SKM_WG3_PER_CU=2 leaves a third of it -- and of the wave
     // slots -- to whatever another stream has queued: the experiment behind DESIGN.md section 4.1, "samples on separate streams")
     static const uint32_t per_cu = [] { const char *e = getenv("KV_SKM_WG3_PER_CU"); const int v = e ? atoi(e) : 3; return (uint32_t)(v >= 1 && v <= 3 ? v : 3); }();
-    return (uint32_t)std::min<uint64_t>((g.n_buckets + SKM_BUCKETS_PER_TICKET - 1) / SKM_BUCKETS_PER_TICKET, per_cu * (uint32_t)kv_device_cus());
+    return (uint32_t)std::min<uint64_t>((g.n_buckets + g.bpt - 1) / g.bpt, per_cu * (uint32_t)kv_device_cus());
+}
+
+static uint32_t skm_default_bpt()
+{
+    if (const char *e = getenv("KV_SKM_BPT")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) return (uint32_t)v; }
+    return SKM_BUCKETS_PER_TICKET;
+}
+// Buckets per ticket of the work counter.  A ticket costs a returning atomic on a word every workgroup asks for -- ~10 per microsecond
+// device-wide, measured: a sample's 64 k buckets one per ticket took k_skm_count from 3.1 to 6.9 ms, two per ticket to 3.7 -- and a big
+// ticket leaves a tail (16: +0.08 ms, 32: +0.13).  8 for a whole sample; fewer where the buckets are few (a rank's share of the exchange:
+// 7 936 buckets for 768 workgroups -- tickets of 8 give a quarter of them two and the rest one), down to 2.  KV_SKM_BPT overrides.
+static void skm_pick_bpt(SkmGeom &g)
+{
+    g.bpt = SKM_BUCKETS_PER_TICKET;
+    while (g.bpt > 2u && g.n_buckets / g.bpt < 4u * 768u) g.bpt /= 2u;
+    if (getenv("KV_SKM_BPT")) g.bpt = skm_default_bpt();
 }
 
 inline uint32_t pow2_ceil(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
@@ -2593,6 +2610,7 @@ void skm_geom_k(SkmGeom &g, int k)
     g.ncap = 32 * g.nbw - k + 1;
     g.sbw = ((64u * (uint32_t)g.ncap) >> 5) + 2u;
     g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
+    g.bpt = skm_default_bpt();
 }
 
 __global__ void k_mex_sum_kmers(const uint64_t *seg, const uint32_t *cnt, const uint64_t *off, uint64_t n_segments, uint32_t cap1, uint32_t recw,
@@ -2631,6 +2649,7 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.ncap = 32 * g.nbw - k + 1;
     g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
     if (getenv("KV_SKM_FORCE_LOOSE")) g.dbg |= 4096u;
+    g.bpt = skm_default_bpt();
     // KV_SKM_DEDUP=1 (k = 31, oriented records): k_skm_count combines identical records before their k-mers (skm_rec_combine): a 3072-slot
     // k-mer table beside a 512-slot table of records, or KV_SKM_DEDUP_RS=1024: 4096 beside 1024 at two workgroups per CU.  Off unless asked
     // for: measured SLOWER (k_skm_count 9.25 -> 10.2 ms per step of config 2 either way, profiles/README.md round 5).
@@ -2736,10 +2755,11 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     skm_launch_split(g, st);
     KV_HIP(hipGetLastError());
     KV_HIP(hipMemcpyAsync(&g.ctr[6], &g.ctr[0], 8, hipMemcpyDeviceToDevice, st));   // loose records S1/S2 left behind
+    skm_pick_bpt(g);
     const uint32_t nwg3 = skm_nwg3(g);
     {
         const uint64_t avg = (g.n_buckets + nwg3 - 1) / nwg3;
-        g.quota3 = (uint32_t)kv_round_up(avg + avg / 2 + 1, SKM_BUCKETS_PER_TICKET);
+        g.quota3 = (uint32_t)kv_round_up(avg + avg / 2 + 1, g.bpt);
     }
     idx.reads_uid = reads->uid;
     idx.k = k;
@@ -3293,10 +3313,11 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     skm_launch_split(g, st);
     KV_HIP(hipGetLastError());
     KV_HIP(hipMemcpyAsync(&g.ctr[6], &g.ctr[0], 8, hipMemcpyDeviceToDevice, st));
+    skm_pick_bpt(g);
     const uint32_t nwg3 = skm_nwg3(g);
     {
         const uint64_t avg = (g.n_buckets + nwg3 - 1) / nwg3;
-        g.quota3 = (uint32_t)kv_round_up(avg + avg / 2 + 1, SKM_BUCKETS_PER_TICKET);
+        g.quota3 = (uint32_t)kv_round_up(avg + avg / 2 + 1, g.bpt);
     }
     KvRouteSink rs;
     memset(&rs, 0, sizeof(rs));
