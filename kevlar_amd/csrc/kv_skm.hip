@@ -3204,7 +3204,8 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
     g.np_max = std::max<uint32_t>(reads->tile_max_bases, 64u);
     g.stride = plan->read_len - (uint32_t)plan->ksize + 1u;
     KV_REQUIRE(reads->max_len <= plan->read_len, KV_ERR_ARG, "kv_mex_emit: a read of %u bases in a plan for %u", reads->max_len, plan->read_len);
-    KV_REQUIRE(reads->tile_max_bases > 0 && reads->tile_max_bases <= 8192u, KV_ERR_ARG, "kv_mex_emit: reads too long for the super-k-mer front end");
+    // (a rank whose shard holds no read -- fewer reads than ranks -- still takes part: it sends empty segments)
+    KV_REQUIRE(reads->n_tiles == 0 || (reads->tile_max_bases > 0 && reads->tile_max_bases <= 8192u), KV_ERR_ARG, "kv_mex_emit: reads too long for the super-k-mer front end");
     g.read_base = read_base;
     // (the exchange's records are oriented like a single GPU's: every rank cuts with the same rule, so the owner of a bucket finds a
     // k-mer under one key whichever shard it came from; KV_SKM_ORIENT=0 on every rank keeps the classic form)
@@ -3213,7 +3214,8 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
     g.loose_cap = 1u << 16;
     const size_t b_loose = kv_round_up(g.loose_cap * (size_t)g.lrecw * 8, 256), b_ctr = 256;
     const uint64_t n_seg = plan->cnt_entries;
-    KV_REQUIRE(!g.compact || skm_lane_fits(g, reads), KV_ERR_NOTIMPL, "kv_mex_emit: 16-byte records need a shard of equal-length reads (the lane-per-read cut)");
+    // (a shard without reads cuts nothing and fits any plan)
+    KV_REQUIRE(!g.compact || reads->n_tiles == 0 || skm_lane_fits(g, reads), KV_ERR_NOTIMPL, "kv_mex_emit: 16-byte records need a shard of equal-length reads (the lane-per-read cut)");
     const size_t b_off = d_out ? mex_scan_bytes(n_seg) : 0;
     KV_HIP(idx.arena.need(b_loose + b_ctr + b_off));
     g.loose = (uint64_t *)idx.arena.p;

@@ -18,7 +18,7 @@ for trial in range(trials):
     k = int(rng.choice([31, 31, 31, 25, 33, 51]))
     world = int(rng.choice([1, 2, 3, 5, 8]))
     L = int(rng.choice([60, 100, 100, 151, 250]))
-    n = int(rng.choice([3000, 20000, 90000]))
+    n = int(rng.choice([3000, 20000, 90000, 5]))              # (5: ranks without reads when world = 8)
     text = bool(rng.random() < 0.5)                     # shards handed over as text (with an N somewhere) or as packed words
     mem = float(rng.choice([4e5, 4e6]))
     desc = 'trial {} k={} world={} n={} L={} {}'.format(trial, k, world, n, L, 'text' if text else 'packed')
