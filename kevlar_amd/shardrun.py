@@ -50,10 +50,12 @@ class PeerDeclined(Exception):
 
 def _local_failures():
     """What a rank's own part of an exchange may raise -- a library error (a buffer too small: KvCapacityError; out of device
-    memory or any other HIP failure: KvError), torch running out of memory for an exchange buffer -- and what must therefore never
-    leave a rank between two collectives: the rank says so inside the next collective instead (PeerDeclined above)."""
+    memory or any other HIP failure: KvError; a shard the call does not take -- reads of unequal length under a short-record plan,
+    say -- which _lib.check() raises as ValueError, or OSError), torch running out of memory for an exchange buffer -- and what must
+    therefore never leave a rank between two collectives: the rank says so inside the next collective instead (PeerDeclined above).
+    (An argument that is wrong on every rank alike is refused again by the layout the ranks fall back to, on all of them.)"""
     from kevlar_amd._lib import KvCapacityError, KvError
-    return (KvCapacityError, KvError, MemoryError, torch.cuda.OutOfMemoryError)
+    return (KvCapacityError, KvError, MemoryError, torch.cuda.OutOfMemoryError, ValueError, OSError)
 
 
 def _test_failure(point, rank):
@@ -256,14 +258,8 @@ class ShardedTrio(object):
                 if not fitted:                              # fuller than expected: a buffer of the segments' full size always fits
                     packed = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
                     per_dest = hk.mex_pack(plan, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr())
-            except _local_failures() as e:                  # records outside their exchange segment (minimizer skew), no memory for the
-                emitted, packed = False, None               # packed copy, a HIP error: the peers must hear of it, in the slab below
-                if os.environ.get('KV_MEX_VERBOSE'):
-                    print('rank {} declines the cut: {!r}'.format(self.rank, e), flush=True)
-            except ValueError as e:                         # (a short-record plan and a shard the lane-per-read cut does not take)
-                if not (int(plan.flags) & 1 and '16-byte records' in str(e)):
-                    raise
-                emitted, packed = False, None
+            except _local_failures() as e:                  # records outside their exchange segment (minimizer skew), no memory for the packed
+                emitted, packed = False, None               # copy, a HIP error, a shard a short-record plan cannot cut: the peers must hear of it, in the slab below
                 if os.environ.get('KV_MEX_VERBOSE'):
                     print('rank {} declines the cut: {!r}'.format(self.rank, e), flush=True)
         if not emitted:
