@@ -67,6 +67,7 @@ struct SkmGeom {
     // The exchange layouts keep classic records (canonical = the smaller strand, computed by the walk).
     uint32_t oriented;
     uint32_t dd_maxn;                // k_skm_count combines identical records first (records of up to dd_maxn k-mers; 0: it does not)
+    uint32_t passes;                 // k_skm_route takes a bucket's k-mers in this many passes (a power of two; 0 / 1: one) -- buckets bigger than its LDS table
     uint32_t bpt;                    // buckets per ticket of the bucket kernels' work counter (a power of two)
 };
 
@@ -1839,8 +1840,16 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
             else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
             else next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * sg.bpt;
         }
+        // A sample too big for the bucket geometry (255 x 4096 buckets: beyond 8.5 G k-mers a bucket holds more distinct k-mers than the
+        // table has slots) is combined in passes: pass p walks the whole bucket and takes the k-mers whose hash says p -- the walk is paid
+        // once per pass, the inserts, the hashes and the pairs once in all (kv_skm_mex_route sets sg.passes)
+        const uint32_t passes = sg.passes > 1u ? sg.passes : 1u;
+        for (uint32_t pass = 0; pass < passes; ++pass) {
+        if (pass) __syncthreads();                       // (the drain of the pass before empties the table)
         skm_walk_bucket<KW, false, 0, COMPACT, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
-            const int slot = skm_cacheable<KW>(c) ? skm_table_insert(tb, c) : -1;
+            if (!skm_cacheable<KW>(c)) return pass == 0u;                                           // (travels alone, once)
+            if (passes > 1u && ((skm_slot_hash<KW>(c) >> 12) & (passes - 1u)) != pass) return false;
+            const int slot = skm_table_insert(tb, c);
             if (slot >= 0) atomicAdd(&cnt[slot], 1u);
             return slot < 0;
         });
@@ -1870,6 +1879,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
             }
             skm_route_item(rs, lo, cur, h, seen);
         });
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -3304,6 +3314,15 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     g.ctr = (unsigned long long *)base;
     KV_HIP(hipMemsetAsync(g.ctr, 0, b_ctr, st));
     g.bucket_kmers = std::max<uint64_t>(1, n_kmers_exp / g.n_buckets);
+    {
+        // buckets the geometry could not make small enough (plan->F2 at its limit): k_skm_route combines them in passes, each taking
+        // the k-mers of one hash class -- as many passes as bring a pass's distinct k-mers (a fifth of the occurrences at sequencing
+        // coverage) under half the LDS table.  KV_MEX_PASSES=n (tests): that many whatever the size.
+        const double distinct = (double)g.bucket_kmers * 0.2, room = 0.5 * (g.kw == 1 ? 4096.0 : 2048.0);
+        g.passes = 1;
+        while (g.passes < 16u && distinct > room * g.passes) g.passes *= 2u;
+        if (const char *e = getenv("KV_MEX_PASSES")) { const int v = atoi(e); if (v >= 1 && v <= 16 && (v & (v - 1)) == 0) g.passes = (uint32_t)v; }
+    }
     if (compact) {
         // the sources sent only the filled part of their segments, in segment order: a segment starts where the counts in
         // front of it end

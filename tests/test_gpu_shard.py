@@ -356,6 +356,39 @@ def test_mex_route_judges_its_output_by_the_pairs_not_by_the_occurrences(hk):
     assert bool((probe[n_pairs // 2:] == 0x5a5a5a5a).all())
 
 
+@pytest.mark.parametrize('passes', ['2', '8'])
+def test_owner_combines_big_buckets_in_passes(hk, passes):
+    """buckets with more distinct k-mers than the owner's LDS table holds (a sample beyond the 255 x 4096 buckets of the geometry:
+    config 4) are combined in passes, each taking the k-mers of one hash class (kv_mex_route, SkmGeom::passes): forced here on a
+    sample that would fit one pass, the pairs must be the same pairs, with and without the list the owners' scan is answered from"""
+    import torch
+    from kevlar_amd import synth
+    k, L = 31, 100
+    trio = synth.make_trio(150000, 33)
+    packed = synth.sample_reads_packed(trio['father'], 45000, L, 0.005, 79)
+    batch = hk.ReadBatch.from_packed(packed, L)
+    nk = batch.num_kmers(k)
+    plan = hk.mex_plan(hk.Counttable, k, packed.shape[0], L, 1)
+    seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device='cuda')
+    cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device='cuda')
+    hk.mex_emit(batch, plan, 0, seg.data_ptr(), cnt.data_ptr())
+    buf = torch.empty((nk, 2), dtype=torch.int64, device='cuda')
+
+    def pairs(keep_scan):
+        counts, arrived = hk.mex_route(plan, 0, seg.data_ptr(), cnt.data_ptr(), 1, buf.data_ptr(), nk, keep_scan=keep_scan)
+        assert arrived == nk
+        got = buf[:counts[0]].cpu().numpy()
+        return got[np.lexsort((got[:, 1], got[:, 0]))]
+    want = pairs(False)
+    assert int(want[:, 1].sum()) == nk           # (a k-mer kept under two keys leaves two pairs: the adds compose)
+    os.environ['KV_MEX_PASSES'] = passes
+    try:
+        for keep_scan in (False, True):
+            assert np.array_equal(pairs(keep_scan), want)
+    finally:
+        os.environ.pop('KV_MEX_PASSES', None)
+
+
 def test_short_exchange_records_deliver_the_same_pairs(hk):
     """a plan with 16-byte records (hk.mex_plan(short=True), kv_mex_plan_short) cuts, packs and combines to exactly the pairs of the
     24-byte plan, in two thirds of the words; the sample the scan is answered from cannot use it, a shape without such records keeps
