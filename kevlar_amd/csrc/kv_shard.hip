@@ -182,15 +182,31 @@ __global__ __launch_bounds__(256) void k_route_compact(RouteParams p)
     for (uint64_t j = threadIdx.x; j < n * W; j += 256) dst[j] = src[j];
 }
 
-// overflow items join the tail of their destination (after the packed segments)
+// overflow items join the tail of their destination (after the packed segments).  A workgroup counts its items per destination, takes
+// its stretch of every tail with ONE device atomic each and deals the places out through LDS cursors (a device atomic per item, then per
+// wave and destination, was most of the 8-26 ms this took for 4.5 M items); entries marked 0xff hold no item (kv_skm.hip, k_skm_loose_route)
 template <int W>
-__global__ void k_route_tail(RouteParams p)
+__global__ __launch_bounds__(256) void k_route_tail(RouteParams p)
 {
+    __shared__ uint32_t dcnt[ROUTE_MAX_DEST], dcur[ROUTE_MAX_DEST];
+    __shared__ unsigned long long dbase[ROUTE_MAX_DEST];
     unsigned long long n = p.ctr[1];
     if (n > p.ovf_cap) n = p.ovf_cap;
-    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+    if (threadIdx.x < ROUTE_MAX_DEST) { dcnt[threadIdx.x] = 0; dcur[threadIdx.x] = 0; }
+    __syncthreads();
+    // (a workgroup takes a contiguous stretch of the list: its items are read twice, the second time from cache)
+    const uint64_t per_wg = (n + gridDim.x - 1) / gridDim.x, j_lo = blockIdx.x * per_wg, j_hi = j_lo + per_wg < n ? j_lo + per_wg : n;
+    for (uint64_t j = j_lo + threadIdx.x; j < j_hi; j += blockDim.x) {
         const uint32_t d = p.ovf_dest[j];
-        const unsigned long long pos = atomicAdd(&p.ctr[50 + d], 1ull);
+        if (d < (uint32_t)p.ndest) atomicAdd(&dcnt[d], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)p.ndest) dbase[threadIdx.x] = dcnt[threadIdx.x] ? atomicAdd(&p.ctr[50 + threadIdx.x], (unsigned long long)dcnt[threadIdx.x]) : 0ull;
+    __syncthreads();
+    for (uint64_t j = j_lo + threadIdx.x; j < j_hi; j += blockDim.x) {
+        const uint32_t d = p.ovf_dest[j];
+        if (d >= (uint32_t)p.ndest) continue;
+        const unsigned long long pos = dbase[d] + atomicAdd(&dcur[d], 1u);
         if (pos < p.cap)
             for (int w = 0; w < W; ++w) p.out[pos * W + w] = p.ovf[j * W + w];
     }
