@@ -66,6 +66,11 @@ const char *kv_last_error(void);
  * them back by itself when one of its own allocations fails.  A host program about to allocate a large buffer of its own (torch,
  * another library) calls this first.                                                                                                */
 int kv_table_cache_trim(void);
+/* The library's per-stream working buffers only grow (the super-k-mer buckets of the last batch, the pair sink of an exchange owner, the
+ * staging of the partitioned add): after one very large batch -- a bucket owner of a 900 M-read sample holds ~200 GB of them -- a
+ * long-lived process gives them back with this call.  No other kv_* call may be running; whatever a later call kept in them (the
+ * buckets a scan would reuse, an owner's combined buckets) is forgotten and rebuilt.  Also trims the table cache.                     */
+int kv_scratch_trim(void);
 const char *kv_version(void);
 int kv_device_count(int *n);
 int kv_set_device(int device);       /* one process per GPU: call once with LOCAL_RANK      */

@@ -45,6 +45,7 @@ SIGNATURES = {
     'kv_stream_create': (i32, [vpp]),
     'kv_stream_destroy': (i32, [vp]),
     'kv_table_cache_trim': (i32, []),
+    'kv_scratch_trim': (i32, []),
     'kv_prof_enable': (i32, [i32]),
     'kv_prof_reset': (i32, []),
     'kv_prof_get': (i32, [cstr, ctypes.POINTER(ctypes.c_double), u64p]),

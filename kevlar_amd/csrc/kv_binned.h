@@ -93,6 +93,7 @@ __device__ __forceinline__ void spill_items_wave(const BinGeom &g, const uint64_
 struct KvArena {
     void *p = nullptr;
     size_t bytes = 0;
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
     hipError_t need(size_t n)
     {
         if (n <= bytes) return hipSuccess;

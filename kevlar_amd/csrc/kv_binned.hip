@@ -1062,6 +1062,13 @@ KvArena &scratch_for(hipStream_t st)
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     return g_scratch[kv_stream_key(st)];
 }
+}
+void kv_bin_scratch_release()
+{
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    for (auto &kv : g_scratch) kv.second.release();
+}
+namespace {
 
 template <typename K>
 void ensure_dynamic_lds(K kernel, size_t bytes) { kv_ensure_dynamic_lds((const void *)kernel, bytes); }

@@ -402,6 +402,16 @@ extern "C" int kv_table_cache_trim(void)
     return KV_OK;
 }
 
+extern "C" int kv_scratch_trim(void)
+{
+    (void)hipDeviceSynchronize();
+    kv_skm_scratch_release();
+    kv_route_scratch_release();
+    kv_bin_scratch_release();
+    kv_table_cache_release();
+    return KV_OK;
+}
+
 void kv_table_cache_release()
 {
     std::lock_guard<std::mutex> lk(g_tabcache_mu);

@@ -292,6 +292,9 @@ hipStream_t kv_stream();
 hipStream_t kv_stream_key(hipStream_t st);
 // table buffers of destroyed sketches kept for the next sketch (kv_host.hip) go back to the driver: called when an allocation fails
 void kv_table_cache_release();
+void kv_skm_scratch_release();       // kv_skm.hip: every stream's bucket arena, distinct list and bit map
+void kv_route_scratch_release();     // kv_shard.hip: every stream's pair sink
+void kv_bin_scratch_release();       // kv_binned.hip: every stream's staging of the partitioned add
 void kv_ensure_dynamic_lds(const void *kernel, size_t bytes);   // hipFuncSetAttribute once per growth
 
 // profiling: RAII wrapper recording HIP events around a launch when enabled

@@ -227,6 +227,13 @@ struct Scratch {
 };
 std::map<hipStream_t, Scratch> g_route_scratch;   // grow-only, one arena per stream
 std::mutex g_route_mu;
+}
+void kv_route_scratch_release()
+{
+    std::lock_guard<std::mutex> lk(g_route_mu);
+    for (auto &kv : g_route_scratch) { if (kv.second.p) (void)hipFree(kv.second.p); kv.second.p = nullptr; kv.second.bytes = 0; }
+}
+namespace {
 
 inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
 
@@ -235,7 +242,9 @@ int route_scratch(RouteParams &p, uint64_t n_kmers, uint32_t W, hipStream_t st)
 {
     const double m = 1.5 * (double)n_kmers / ((double)p.nwg * p.ndest);   // a full quota, spread evenly over the bands
     p.seg_cap = round_up((uint64_t)(m * 1.1 + 8.0 * std::sqrt(m)) + 1024, 64);
-    p.ovf_cap = n_kmers;                                                    // worst case: no capacity error possible
+    // worst case: no capacity error possible -- up to 2^30 items; a bigger sink takes a quarter of its items through the overflow list
+    // (what missed a segment of 1.5 x the even share: skew beyond that ends in the capacity error the callers fall back from)
+    p.ovf_cap = n_kmers <= (1ull << 30) ? n_kmers : std::max<uint64_t>(1ull << 30, n_kmers / 4);
     const size_t b_seg = round_up((uint64_t)p.ndest * p.nwg * p.seg_cap * 8 * W, 256);
     const size_t b_cnt = round_up((uint64_t)p.ndest * p.nwg * 4, 256), b_off = round_up((uint64_t)p.ndest * p.nwg * 8, 256);
     const size_t b_ovf = round_up(p.ovf_cap * 8 * W, 256), b_od = round_up(p.ovf_cap, 256), b_ctr = 1024;
@@ -487,9 +496,12 @@ extern "C" int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_
     p.out = (uint64_t *)d_out;
     // every k-mer occurrence that arrived could be a pair of its own: the sink is sized for this rank's expected share
     // with slack, and the caller's buffer must hold what actually arrived (checked below, before anything is packed)
+    // (no more than the caller's buffer takes, though: beyond it the call ends in a capacity error whatever the sink holds -- a 63 G-k-mer
+    // sample's owner expects 7.9 G occurrences and 1.5 G pairs; a sink for the occurrences would be 400 GB)
     const uint64_t expect = plan->n_kmers_global / (uint64_t)ndest;
+    const uint64_t sink_items = std::min<uint64_t>(expect + expect / 4, cap_items + cap_items / 4) + (1u << 20);
     KvReadback rb;
-    struct Ctx { RouteParams *p; uint64_t n_kmers; hipStream_t st; KvReadback *rb; const unsigned long long *host; } ctx = {&p, expect + expect / 4 + (1u << 20), st, &rb, nullptr};
+    struct Ctx { RouteParams *p; uint64_t n_kmers; hipStream_t st; KvReadback *rb; const unsigned long long *host; } ctx = {&p, sink_items, st, &rb, nullptr};
     auto alloc = [](void *c, uint32_t nwg, KvRouteSink *sink) -> int {
         Ctx *x = (Ctx *)c;
         RouteParams &q = *x->p;

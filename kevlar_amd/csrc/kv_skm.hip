@@ -1853,7 +1853,16 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
         // A sample too big for the bucket geometry (255 x 4096 buckets: beyond 8.5 G k-mers a bucket holds more distinct k-mers than the
         // table has slots) is combined in passes: pass p walks the whole bucket and takes the k-mers whose hash says p -- the walk is paid
         // once per pass, the inserts, the hashes and the pairs once in all (kv_skm_mex_route sets sg.passes)
-        const uint32_t passes = sg.passes > 1u ? sg.passes : 1u;
+        // (how many: by the bucket's own size -- with 12-base minimizers a million buckets are far from even, a popular minimizer makes
+        // its bucket several times the average -- from its record count: ~9.5 k-mers a record, a fifth of them distinct at sequencing
+        // coverage, a pass's share under 0.7 of the table; sg.passes, the estimate from the average, is the least)
+        uint32_t passes = sg.passes > 1u ? sg.passes : 1u;
+        {
+            const uint32_t *cnt2 = sg.cnt2 + (uint64_t)b * sg.nwg2;
+            uint32_t nrec = 0;
+            for (uint32_t s2 = 0; s2 < sg.nwg2; ++s2) nrec += cnt2[s2];
+            while (passes < 64u && 19u * nrec > 10u * ((uint32_t)TS * 7u / 10u) * passes) passes *= 2u;
+        }
         for (uint32_t pass = 0; pass < passes; ++pass) {
         if (pass) __syncthreads();                       // (the drain of the pass before empties the table)
         skm_walk_bucket<KW, false, 0, COMPACT, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
@@ -2399,6 +2408,19 @@ SkmIndex &skm_index_for(hipStream_t st)
     std::lock_guard<std::mutex> lk(g_skm_mu);
     return g_skm[kv_stream_key(st)];
 }
+}
+void kv_skm_scratch_release()
+{
+    std::lock_guard<std::mutex> lk(g_skm_mu);
+    for (auto &kv : g_skm) {
+        SkmIndex &idx = kv.second;
+        std::lock_guard<std::mutex> ilk(idx.mu);
+        idx.valid = false; idx.dl_valid = false; idx.mex_scan_ready = false;
+        idx.dl_keys = nullptr; idx.dl_hash = nullptr; idx.dl_bstart = nullptr; idx.dl_bcount = nullptr;
+        idx.arena.release(); idx.dl.release(); idx.bits.release();
+    }
+}
+namespace {
 
 inline uint32_t skm_nwg3(const SkmGeom &g)
 {
@@ -3336,7 +3358,11 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     const uint64_t n_kmers_exp = plan->n_kmers_global / (uint64_t)plan->ndest + 1;
     const double rec_est = (double)n_kmers_exp * 2.2 / (double)(g.w + 1) + (double)plan->n_reads_global / plan->ndest + 1024.0;
     const double m2 = rec_est / ((double)g.n_buckets * g.nwg2);
-    g.cap2 = (uint32_t)kv_round_up((uint64_t)(m2 * 1.4 + 8.0 * std::sqrt(m2)) + 32, 16);
+    // (a geometry at its limit -- 4096 fine buckets per coarse one: a handful of distinct 12-base minimizers per bucket -- has buckets of
+    // very different sizes: at 248 x 4096 buckets a tenth of the records missed segments of 2 x the even share; KV_MEX_CAP2_SLACK overrides)
+    double slack2 = plan->F2 > SKM_S2_MAXF ? 3.0 : 1.4;
+    if (const char *e = getenv("KV_MEX_CAP2_SLACK")) slack2 = std::max(1.1, atof(e));
+    g.cap2 = (uint32_t)kv_round_up((uint64_t)(m2 * slack2 + 8.0 * std::sqrt(m2)) + 32, 16);
     g.loose_cap = (uint64_t)(rec_est / 8.0) + n_kmers_exp / 16 + (1u << 20);
     const size_t rb = (size_t)g.recw * 8;
     const size_t b_seg2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * g.cap2 * rb, 256), b_cnt2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * 4, 256);
@@ -3434,9 +3460,10 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     idx.mex_scan_ready = dl_new && sctr[9] == 0 && sctr[1] == 0;
     idx.k = plan->ksize;
     if (getenv("KV_SKM_VERBOSE"))
-        fprintf(stderr, "[kv_skm] exchange owner: %llu k-mers arrived in %u buckets, %.1f%% distinct, %.2f%% outside the LDS tables\n",
-                arrived, g.n_buckets, arrived ? 100.0 * (double)sctr[7] / (double)arrived : 0.0,
-                arrived ? 100.0 * (double)(sctr[0] > sctr[6] ? sctr[0] - sctr[6] : 0) / (double)arrived : 0.0);
+        fprintf(stderr, "[kv_skm] exchange owner: %llu k-mers arrived in %u buckets (%u passes, segments of %u records), %.1f%% distinct, %.2f%% outside the LDS tables, "
+                        "%llu records outside their bucket's segments\n",
+                arrived, g.n_buckets, g.passes, g.cap2, arrived ? 100.0 * (double)sctr[7] / (double)arrived : 0.0,
+                arrived ? 100.0 * (double)(sctr[0] > sctr[6] ? sctr[0] - sctr[6] : 0) / (double)arrived : 0.0, sctr[6]);
     if (sctr[1] != 0) {
         kv_set_error("kv_mex_route: loose record list overflow (%llu records)", sctr[0]);
         return KV_ERR_CAPACITY;

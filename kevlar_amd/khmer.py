@@ -84,6 +84,12 @@ def bound_stream():
 
 
 
+def scratch_trim():
+    """Give the library's grow-only working buffers back to the device (kv_scratch_trim): after a very large batch, or before another
+    library allocates most of the HBM.  No other call may be running; buckets a later scan would have reused are cut again."""
+    check(_lib.load().kv_scratch_trim())
+
+
 def run_concurrently(jobs):
     """Run zero-argument callables on separate host threads, each bound to its own HIP stream;
     returns their results in order.  Kernels of different jobs overlap on the GPU.  May be nested (a job that runs

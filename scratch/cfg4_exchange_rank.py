@@ -44,7 +44,7 @@ def main():
         lib.kv_prof_reset(); lib.kv_prof_enable(1)
     t_cut = t_combine = t_add = 0.0
     sent_records = sent_pairs = 0
-    pairs_cap = int(n_reads * nk * 0.205 / world) + (1 << 22)      # (a fifth of the occurrences are distinct at 30x; the library sizes its own
+    pairs_cap = int(n_reads * nk * float(os.environ.get('CFG4_PAIRS_FRAC', '0.205')) / world) + (1 << 22)      # (a fifth of the occurrences are distinct at 30x; the library sizes its own
                                                                     # staging from this number, generously)
     group = int(os.environ.get('CFG4_OWNERS_AT_ONCE', '2'))      # owners whose records are held at once (every shard is cut once per group)
     for si, n in enumerate(names):
@@ -52,6 +52,7 @@ def main():
         for d0 in range(0, world, group):
             owners = list(range(d0, min(world, d0 + group)))
             # every shard's cut; what it holds for these owners is set aside
+            hk.scratch_trim()                                # (the owner's combine of a sample this size leaves ~200 GB of working buffers)
             got_rec = {d: [] for d in owners}
             got_cnt = {d: [] for d in owners}
             seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device=dev)
@@ -91,23 +92,27 @@ def main():
                 lib.kv_synchronize()
                 tb = time.perf_counter()
                 arrived_all += arrived
+                del rs, rc
+                torch.cuda.empty_cache()
                 if d == 0:
                     t_combine += tb - ta
                     sent_pairs += sum(counts) - counts[0]
                     # (a band owner receives about what a bucket owner sends: band 0 adding ALL of owner 0's pairs into a scratch sketch is
                     # the size of its real work; only the pairs of band 0 go into the sketch that is checked)
                     scratch = hk.Counttable(k, memory / world / T, T)
-                    scratch.consume_hashes_weighted(pairs.data_ptr(), sum(counts))
-                    scratch.clear()
-                    lib.kv_synchronize()
-                    tc = time.perf_counter()
-                    scratch.consume_hashes_weighted(pairs.data_ptr(), sum(counts))
-                    lib.kv_synchronize()
-                    t_add += time.perf_counter() - tc
+                    chunk = 1 << 28                            # (pairs per call: the partitioned add stages four items a pair, twice)
+                    for rep in range(2):
+                        scratch.clear()
+                        lib.kv_synchronize()
+                        tc = time.perf_counter()
+                        for c0 in range(0, sum(counts), chunk):
+                            scratch.consume_hashes_weighted(pairs.data_ptr() + c0 * 16, min(chunk, sum(counts) - c0))
+                        lib.kv_synchronize()
+                        if rep == 1:
+                            t_add += time.perf_counter() - tc
                     del scratch
-                if counts[0]:
-                    band0[n].consume_hashes_weighted(pairs.data_ptr(), counts[0])
-                del rs, rc
+                for c0 in range(0, counts[0], 1 << 29):
+                    band0[n].consume_hashes_weighted(pairs.data_ptr() + c0 * 16, min(1 << 29, counts[0] - c0))
             del pairs
             torch.cuda.empty_cache()
         assert arrived_all == n_reads * nk, (arrived_all, n_reads * nk)
@@ -123,6 +128,7 @@ def main():
             ms, nl = ctypes.c_double(), ctypes.c_uint64()
             lib.kv_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(nl))
             print('    {:24s} {:10.1f} ms {:6d} launches (all owners, all shards)'.format(name, ms.value, nl.value))
+    hk.scratch_trim()
     # band 0 the banded way
     per_batch = 18_750_000
     for si, n in enumerate(names):

@@ -85,6 +85,32 @@ def test_skm_count_matches_oracle(hk, ok, skm, kind, k, tablesize):
     assert_same_tables(dev, ref)
 
 
+def test_scratch_trim_between_count_and_scan(hk, ok, skm):
+    """kv_scratch_trim gives the per-stream working buffers back: a scan that would have reused the case sample's buckets (and its distinct
+    list) cuts them again, a later count allocates again -- same hits, same tables"""
+    reads = trio_reads(100000, 30000, 44)
+    for hint in (False, True):
+        names = ('proband', 'mother', 'father')
+        dev = {n: hk.Counttable(31, 1.5e6, 4) for n in names}
+        ref = {n: ok.Counttable(31, 1.5e6, 4) for n in names}
+        if hint:
+            dev['proband'].expect_scan()
+        batches = {n: hk.ReadBatch(reads[n]) for n in names}
+        for n in ('mother', 'father', 'proband'):
+            dev[n].consume_batch(batches[n])
+            if n == 'father':
+                hk.scratch_trim()
+            bases, offs = ok.concat_reads(reads[n])
+            ok.consume_reads(ref[n], bases, offs, len(reads[n]))
+            assert_same_tables(dev[n], ref[n])
+        hk.scratch_trim()
+        r, o, a, _ = hk.novel_scan([dev['proband']], [dev['mother'], dev['father']], batches['proband'], 6, 1)
+        bases, offs = ok.concat_reads(reads['proband'])
+        hits, _ = ok.novel_scan([ref['proband']], [ref['mother'], ref['father']], bases, offs, len(reads['proband']), 31, 6, 1, 0, 0, 0, 0)
+        assert len(hits) > 50
+        assert [(int(r[i]), int(o[i]), tuple(int(x) for x in a[i])) for i in range(len(r))] == hits
+
+
 @pytest.mark.parametrize('rs,maxn', [('512', None), ('1024', None), ('512', '5')])
 def test_skm_count_with_identical_records_combined_first(hk, ok, skm, rs, maxn):
     """KV_SKM_DEDUP=1 (off by default: measured slower): the count puts a bucket's records into an LDS table first and walks every distinct
