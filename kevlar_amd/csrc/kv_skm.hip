@@ -1786,15 +1786,11 @@ __global__ __launch_bounds__(256) void k_skm_loose_count(SkmGeom sg, const Sketc
 // band instead of T bin items: what crosses xGMI shrinks by the shard's own coverage, and the owner adds each item
 // with one weighted saturating add per table (kv_consume_hashes_weighted).
 #define SKM_ROUTE_MAX_DEST 16
-__device__ __forceinline__ void skm_route_item(const KvRouteSink &rs, const uint64_t *lo, uint32_t *cur, uint64_t h, uint64_t count)
+// (out of line: a pair that misses its segment is rare in the kernels that call this from their drain, whose registers it must not cost)
+struct SkmOverflowSink { unsigned long long *ctr; uint64_t *ovf; uint8_t *ovf_dest; uint64_t ovf_cap; int ndest; };
+__device__ __attribute__((noinline)) void skm_route_overflow(SkmOverflowSink rs, uint32_t d, uint64_t h, uint64_t count)
 {
-    if (h == UINT64_MAX) return;                 // the top hash value belongs to no band (kv_shard.hip)
-    uint32_t d = 0;
-    for (int b = 1; b < rs.ndest; ++b) d += h >= lo[b] ? 1u : 0u;
-    const uint32_t pos = cur ? atomicAdd(&cur[d], 1u) : 0xffffffffu;
-    if (pos < rs.seg_cap) {
-        *(ulonglong2 *)(rs.seg + (((uint64_t)d * rs.nwg + blockIdx.x) * rs.seg_cap + pos) * 2) = make_ulonglong2(h, count);
-    } else {
+    {
         // the overflow list: one returning atomic for the lanes of the wave that are here together, not one each (the loose kernel sends
         // every item this way: 4.5 M of them took 25 ms one by one at ~180 per microsecond), and one add per destination among them
         const unsigned long long here = __ballot(true);
@@ -1812,6 +1808,16 @@ __device__ __forceinline__ void skm_route_item(const KvRouteSink &rs, const uint
             rs.ovf_dest[o] = (uint8_t)d;
         }
     }
+}
+
+__device__ __forceinline__ void skm_route_item(const KvRouteSink &rs, const uint64_t *lo, uint32_t *cur, uint64_t h, uint64_t count)
+{
+    if (h == UINT64_MAX) return;                 // the top hash value belongs to no band (kv_shard.hip)
+    uint32_t d = 0;
+    for (int b = 1; b < rs.ndest; ++b) d += h >= lo[b] ? 1u : 0u;
+    const uint32_t pos = cur ? atomicAdd(&cur[d], 1u) : 0xffffffffu;
+    if (pos < rs.seg_cap) *(ulonglong2 *)(rs.seg + (((uint64_t)d * rs.nwg + blockIdx.x) * rs.seg_cap + pos) * 2) = make_ulonglong2(h, count);
+    else skm_route_overflow(SkmOverflowSink{rs.ctr, rs.ovf, rs.ovf_dest, rs.ovf_cap, rs.ndest}, d, h, count);
 }
 
 template <int KW, int TS, bool ORI = false, bool COMPACT = false>
