@@ -398,7 +398,7 @@ typedef struct kv_mex_plan {
 int kv_mex_plan_make(int kind, int ksize, uint64_t n_reads_global, uint32_t read_len, int ndest, kv_mex_plan *plan);
 /* The same exchange with 16-byte records without positions (two thirds of the bytes a rank sends) for a sample nobody asks "where" of:
  * a control.  Not for the sample kv_mex_route(keep_scan) / kv_mex_scan_set answer the scan from.  KV_ERR_NOTIMPL when the plan's shape
- * has no such records (k > 32, a window other than k = 31's, reads beyond 224 bases, more than 1024 fine buckets): keep the plan as it is. */
+ * has no such records (k > 32, a window other than k = 31's, reads beyond 224 bases): keep the plan as it is. */
 int kv_mex_plan_short(kv_mex_plan *plan);
 int kv_mex_emit(const kv_reads *shard, const kv_mex_plan *plan, uint64_t read_base, void *d_seg, void *d_cnt);
 /* kv_mex_pack: only the filled part of the segments travels -- d_out receives it, destination after destination, and

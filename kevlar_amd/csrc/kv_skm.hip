@@ -882,6 +882,8 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, C == 2 ? 4 : SKM_LANE_WAVES) void
 // ---- S2 ------------------------------------------------------------------------------------------------
 #define SKM_THREADS2 512
 #define SKM_MAX_F2 4096u          // fine buckets per coarse bucket (12 bits of a k-mer's bucket id in S1; 16 in a record header)
+// COMPACT: 16-byte records (kv_skm_device.h: the fine bucket sits in the second word; one 16-byte load and store each)
+template <bool COMPACT>
 __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split(SkmGeom sg)
 {
     __shared__ uint32_t cur[SKM_MAX_F2];
@@ -899,11 +901,24 @@ __global__ __launch_bounds__(SKM_THREADS2) void k_skm_split(SkmGeom sg)
     }
     __syncthreads();
     const uint32_t total = spre[nmine];
-    const int recw = sg.recw;
+    const int recw = COMPACT ? 2 : sg.recw;
     for (uint32_t i = threadIdx.x; i < total; i += SKM_THREADS2) {
         const uint32_t si = skm_search(spre, nmine, i);
         const uint32_t seg = blockIdx.x + si * sg.nwg2;
         const uint64_t *rec = sg.seg1 + (skm_seg1_first(sg, skm_seg1_slot(sg, c, seg)) + (i - spre[si])) * (uint64_t)recw;
+        if (COMPACT) {
+            typedef uint64_t u64x2a __attribute__((ext_vector_type(2), aligned(16)));
+            const u64x2a both = *(const u64x2a *)rec;
+            const uint32_t fine = skm_c_fine(both.y);
+            const uint32_t p = atomicAdd(&cur[fine], 1u);
+            if (p < sg.cap2) {
+                *(u64x2a *)(sg.seg2 + ((((uint64_t)c * sg.F2 + fine) * sg.nwg2 + blockIdx.x) * sg.cap2 + p) * 2ull) = both;
+            } else {                                         // (leaves in the loose list's classic form, position unknown)
+                uint64_t lw[3] = {both.x, skm_c_b1(both.y), 0ull};
+                skm_loose_push(sg, skm_header(0ull, skm_c_n(both.y), fine, skm_c_rev(both.y)), lw);
+            }
+            continue;
+        }
         const uint64_t hdr = rec[0];
         uint64_t bw[3];
 #pragma unroll
@@ -2583,7 +2598,8 @@ void skm_launch_split(const SkmGeom &g, hipStream_t st)
             hipLaunchKernelGGL(k_skm_split_sorted<4>, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), lds, st, g);
         }
     } else {
-        hipLaunchKernelGGL(k_skm_split, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), 0, st, g);
+        if (g.recw == 2) hipLaunchKernelGGL(k_skm_split<true>, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), 0, st, g);
+        else hipLaunchKernelGGL(k_skm_split<false>, dim3(g.nwg2, g.C1), dim3(SKM_THREADS2), 0, st, g);
     }
 }
 
@@ -3243,9 +3259,10 @@ int kv_skm_mex_plan_short(kv_mex_plan *plan)
 {
     SkmGeom g;
     skm_geom_k(g, plan->ksize);
+    // (the owner's S2 takes 16-byte records in either form: the sorted split up to 1024 fine buckets, the plain one up to 4096 -- the 12
+    // bits the record has for its fine bucket)
     KV_REQUIRE(g.kw == 1 && g.w == SKM_LANE_B && skm_lane_fits_len(g, plan->read_len) &&
-               plan->F2 <= SKM_S2_MAXF && !(getenv("KV_SKM_COMPACT") && atoi(getenv("KV_SKM_COMPACT")) == 0) &&
-               !(getenv("KV_SKM_S2") && strcmp(getenv("KV_SKM_S2"), "sorted") != 0),
+               plan->F2 <= 4096u && !(getenv("KV_SKM_COMPACT") && atoi(getenv("KV_SKM_COMPACT")) == 0),
                KV_ERR_NOTIMPL, "kv_mex_plan_short: no 16-byte records for k = %d, reads of %u bases, %u fine buckets", plan->ksize, plan->read_len, plan->F2);
     if (plan->flags & 1u) return KV_OK;
     plan->flags |= 1u;
