@@ -389,8 +389,10 @@ def test_owner_combines_big_buckets_in_passes(hk, passes):
         os.environ.pop('KV_MEX_PASSES', None)
 
 
-def test_short_exchange_records_deliver_the_same_pairs(hk):
-    """a plan with 16-byte records (hk.mex_plan(short=True), kv_mex_plan_short) cuts, packs and combines to exactly the pairs of the
+@pytest.mark.parametrize('split', [None, 'plain'])
+def test_short_exchange_records_deliver_the_same_pairs(hk, split):
+    """(split = 'plain': the owner's S2 that takes more than 1024 fine buckets per coarse one -- config 4's geometry -- on the same records)
+    a plan with 16-byte records (hk.mex_plan(short=True), kv_mex_plan_short) cuts, packs and combines to exactly the pairs of the
     24-byte plan, in two thirds of the words; the sample the scan is answered from cannot use it, a shape without such records keeps
     the classic plan, and a shard of unequal reads is refused by name"""
     import torch
@@ -401,33 +403,38 @@ def test_short_exchange_records_deliver_the_same_pairs(hk):
     batch = hk.ReadBatch.from_packed(packed, L)
     nk = batch.num_kmers(k)
     pairs, words = {}, {}
-    for short in (False, True):
-        plan = hk.mex_plan(hk.Counttable, k, packed.shape[0], L, 1, short=short)
-        assert (int(plan.flags) & 1, int(plan.recw)) == ((1, 2) if short else (0, 3))
-        seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device='cuda')
-        cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device='cuda')
-        out = torch.empty(int(plan.seg_words), dtype=torch.int64, device='cuda')
-        per_dest, fitted = hk.mex_emit_pack(batch, plan, 0, seg.data_ptr(), cnt.data_ptr(), out.data_ptr(), out.shape[0])
-        assert fitted
-        words[short] = per_dest[0] * int(plan.recw)
-        buf = torch.empty((nk, 2), dtype=torch.int64, device='cuda')
-        for compact in (False, True):                   # the segments as cut, and their filled part as it travels
-            src = out if compact else seg
-            counts, arrived = hk.mex_route(plan, 0, src.data_ptr(), cnt.data_ptr(), 1, buf.data_ptr(), nk, compact=compact)
-            assert arrived == nk
-            got = buf[:counts[0]].cpu().numpy()
-            got = got[np.lexsort((got[:, 1], got[:, 0]))]
-            if pairs:
-                assert np.array_equal(got, pairs['want'])
-            else:
-                pairs['want'] = got
-        if short:
-            with pytest.raises(ValueError):
-                hk.mex_route(plan, 0, seg.data_ptr(), cnt.data_ptr(), 1, buf.data_ptr(), nk, keep_scan=True)
-            reads = synth.unpack_reads(packed[:2000], L)
-            reads[7] = reads[7][:-3]
-            with pytest.raises(ValueError, match='16-byte records'):
-                hk.mex_emit(hk.ReadBatch(reads), plan, 0, seg.data_ptr(), cnt.data_ptr())
+    if split:
+        os.environ['KV_SKM_S2'] = split
+    try:
+        for short in (False, True):
+            plan = hk.mex_plan(hk.Counttable, k, packed.shape[0], L, 1, short=short)
+            assert (int(plan.flags) & 1, int(plan.recw)) == ((1, 2) if short else (0, 3))
+            seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device='cuda')
+            cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device='cuda')
+            out = torch.empty(int(plan.seg_words), dtype=torch.int64, device='cuda')
+            per_dest, fitted = hk.mex_emit_pack(batch, plan, 0, seg.data_ptr(), cnt.data_ptr(), out.data_ptr(), out.shape[0])
+            assert fitted
+            words[short] = per_dest[0] * int(plan.recw)
+            buf = torch.empty((nk, 2), dtype=torch.int64, device='cuda')
+            for compact in (False, True):                   # the segments as cut, and their filled part as it travels
+                src = out if compact else seg
+                counts, arrived = hk.mex_route(plan, 0, src.data_ptr(), cnt.data_ptr(), 1, buf.data_ptr(), nk, compact=compact)
+                assert arrived == nk
+                got = buf[:counts[0]].cpu().numpy()
+                got = got[np.lexsort((got[:, 1], got[:, 0]))]
+                if pairs:
+                    assert np.array_equal(got, pairs['want'])
+                else:
+                    pairs['want'] = got
+            if short:
+                with pytest.raises(ValueError):
+                    hk.mex_route(plan, 0, seg.data_ptr(), cnt.data_ptr(), 1, buf.data_ptr(), nk, keep_scan=True)
+                reads = synth.unpack_reads(packed[:2000], L)
+                reads[7] = reads[7][:-3]
+                with pytest.raises(ValueError, match='16-byte records'):
+                    hk.mex_emit(hk.ReadBatch(reads), plan, 0, seg.data_ptr(), cnt.data_ptr())
+    finally:
+        os.environ.pop('KV_SKM_S2', None)
     assert int(pairs['want'][:, 1].sum()) == nk
     assert words[True] < 0.72 * words[False]
     assert int(hk.mex_plan(hk.Counttable, 51, packed.shape[0], 150, 1, short=True).flags) & 1 == 0
