@@ -268,6 +268,15 @@ int kv_route_distinct(const kv_reads *reads, int kind, int ksize, int ndest, voi
 /* count n (hash, count) items resident in HBM: each adds min(count, 255) to its bins, saturating -- the tables
  * end up as if the hash had been counted `count` times.  *n_added_out = sum of the counts.                  */
 int kv_consume_hashes_weighted(kv_sketch *s, const void *d_items, uint64_t n, uint64_t *n_added_out);
+/* (hash, occurrences) pairs as they travel between ranks: 9 bytes instead of 16.  A block of n pairs for one destination becomes
+ * 1 + n + ceil(n / 8) 64-bit words -- the block's occurrences in all (exact: the statistic `kevlar count` prints), the n hashes, the n
+ * occurrence counts as bytes saturated at 255 (no counter of any sketch kind holds more: `Hashtable::add` saturates).
+ * kv_pairs_pack: d_pairs holds counts[0] pairs for destination 0, then counts[1] for destination 1, ...; d_out receives the blocks back
+ * to back, words_per_dest[d] words each.  kv_pairs_unpack: d_in holds nsrc received blocks of words_per_src[s] words; d_pairs receives
+ * their pairs as 16-byte (hash, count <= 255) items, pairs_per_src[s] each; *occurrences = the sum of the blocks' totals.              */
+int kv_pairs_pack(const void *d_pairs, const uint64_t *counts, int ndest, void *d_out, uint64_t out_cap_words, uint64_t *words_per_dest);
+int kv_pairs_unpack(const void *d_in, const uint64_t *words_per_src, int nsrc, void *d_pairs, uint64_t cap_pairs, uint64_t *pairs_per_src,
+                    uint64_t *occurrences);
 /* count n hashes resident in HBM, element i at ((uint64_t*)d_hashes)[i * stride_words]            */
 int kv_consume_hashes(kv_sketch *s, const void *d_hashes, uint64_t n, uint32_t stride_words,
                       uint64_t *n_added_out);

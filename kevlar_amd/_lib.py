@@ -114,6 +114,8 @@ SIGNATURES = {
     'kv_gunzip_host': (i32, [vp, u64, vp, u64, u64, u64p, u64p, ctypes.POINTER(ctypes.c_double)]),
     'kv_route_distinct': (i32, [vp, i32, i32, i32, vp, u64, u64p]),
     'kv_consume_hashes_weighted': (i32, [vp, vp, u64, u64p]),
+    'kv_pairs_pack': (i32, [vp, u64p, i32, vp, u64, u64p]),
+    'kv_pairs_unpack': (i32, [vp, u64p, i32, vp, u64, u64p, u64p]),
     'kv_novel_scan_hashes': (i32, [vpp, i32, vpp, i32, vp, u64, i32, i32, vp, vp, u64, u64p]),
     'kv_novel_scan_distinct': (i32, [vpp, i32, vpp, i32, vp, u64, i32, i32, vp, vp, u64, u64p]),
     'kv_novel_scan_set': (i32, [vp, i32, i32, i32, vp, vp, u64, vpp]),

@@ -538,6 +538,153 @@ extern "C" int kv_mex_route(const kv_mex_plan *plan, int my_dest, const void *d_
     return KV_OK;
 }
 
+// ---- (hash, occurrences) pairs in 9 bytes for the wire (include/kvsketch.h) ------------------------------------------------------------
+namespace {
+struct PairBlocks {                      // per block: first pair, pairs, first word of its packed form
+    uint64_t first[ROUTE_MAX_DEST], n[ROUTE_MAX_DEST], woff[ROUTE_MAX_DEST];
+    int nblocks;
+};
+__device__ __forceinline__ uint64_t pairs_wave_sum(uint64_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_down((int)(uint32_t)v, d), hi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), d);
+        v += (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    return v;
+}
+// the head words (occurrences, summed below) start as zero
+__global__ void k_pairs_pack_init(PairBlocks b, uint64_t *out)
+{
+    const int d = threadIdx.x;
+    if (d < b.nblocks) out[b.woff[d]] = 0;
+}
+// a workgroup takes 2048 pairs at a time, consecutive lanes on consecutive pairs (16-byte loads, 8-byte hash stores); the count bytes meet
+// in LDS and leave as 256 whole words (no byte stores to HBM; the last word's missing bytes are zero)
+#define PAIRS_CHUNK 2048u
+__global__ __launch_bounds__(256) void k_pairs_pack(PairBlocks b, const ulonglong2 *__restrict__ pairs, uint64_t *out)
+{
+    __shared__ __attribute__((aligned(8))) uint8_t cb[PAIRS_CHUNK];
+    const int d = blockIdx.y;
+    const uint64_t n = b.n[d], chunks = (n + PAIRS_CHUNK - 1) / PAIRS_CHUNK;
+    const ulonglong2 *src = pairs + b.first[d];
+    uint64_t *hashes = out + b.woff[d] + 1, *cwords = hashes + n;
+    uint64_t occ = 0;
+    for (uint64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const uint64_t base = c * PAIRS_CHUNK;
+#pragma unroll
+        for (uint32_t j = 0; j < PAIRS_CHUNK / 256u; ++j) {
+            const uint32_t at = j * 256u + threadIdx.x;
+            const uint64_t i = base + at;
+            uint8_t byte = 0;
+            if (i < n) {
+                const ulonglong2 it = src[i];
+                hashes[i] = it.x;
+                byte = (uint8_t)(it.y < 255ull ? it.y : 255ull);
+                occ += it.y;
+            }
+            cb[at] = byte;
+        }
+        __syncthreads();
+        const uint64_t w = base / 8 + threadIdx.x;
+        if (w < (n + 7) / 8) cwords[w] = ((const uint64_t *)cb)[threadIdx.x];
+        __syncthreads();
+    }
+    occ = pairs_wave_sum(occ);
+    if ((threadIdx.x & 63) == 0 && occ) atomicAdd((unsigned long long *)&out[b.woff[d]], (unsigned long long)occ);
+}
+__global__ __launch_bounds__(256) void k_pairs_unpack(PairBlocks b, const uint64_t *__restrict__ in, ulonglong2 *pairs, unsigned long long *occ_sum)
+{
+    __shared__ __attribute__((aligned(8))) uint8_t cb[PAIRS_CHUNK];
+    const int s = blockIdx.y;
+    const uint64_t n = b.n[s], chunks = (n + PAIRS_CHUNK - 1) / PAIRS_CHUNK;
+    const uint64_t *hashes = in + b.woff[s] + 1, *cwords = hashes + n;
+    ulonglong2 *dst = pairs + b.first[s];
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(occ_sum, (unsigned long long)in[b.woff[s]]);
+    for (uint64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const uint64_t base = c * PAIRS_CHUNK;
+        const uint64_t w = base / 8 + threadIdx.x;
+        ((uint64_t *)cb)[threadIdx.x] = w < (n + 7) / 8 ? cwords[w] : 0ull;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < PAIRS_CHUNK / 256u; ++j) {
+            const uint32_t at = j * 256u + threadIdx.x;
+            const uint64_t i = base + at;
+            if (i < n) dst[i] = make_ulonglong2(hashes[i], (unsigned long long)cb[at]);
+        }
+        __syncthreads();
+    }
+}
+unsigned long long *g_pairs_occ = nullptr;       // one device word for kv_pairs_unpack's total (calls are serialised by g_pairs_mu)
+std::mutex g_pairs_mu;
+}  // namespace
+
+extern "C" int kv_pairs_pack(const void *d_pairs, const uint64_t *counts, int ndest, void *d_out, uint64_t out_cap_words, uint64_t *words_per_dest)
+{
+    KV_REQUIRE(d_out && counts && words_per_dest && ndest >= 1 && ndest <= ROUTE_MAX_DEST, KV_ERR_ARG, "kv_pairs_pack: bad argument");
+    PairBlocks b;
+    memset(&b, 0, sizeof(b));
+    b.nblocks = ndest;
+    uint64_t first = 0, woff = 0, most = 0;
+    for (int d = 0; d < ndest; ++d) {
+        b.first[d] = first; b.n[d] = counts[d]; b.woff[d] = woff;
+        words_per_dest[d] = 1 + counts[d] + (counts[d] + 7) / 8;
+        first += counts[d]; woff += words_per_dest[d];
+        most = std::max(most, counts[d]);
+    }
+    KV_REQUIRE(first == 0 || d_pairs, KV_ERR_ARG, "kv_pairs_pack: null pairs");
+    KV_REQUIRE(woff <= out_cap_words, KV_ERR_CAPACITY, "kv_pairs_pack: %llu words for a buffer of %llu", (unsigned long long)woff, (unsigned long long)out_cap_words);
+    hipStream_t st = kv_stream();
+    KvProfScope prof("k_pairs_pack");
+    hipLaunchKernelGGL(k_pairs_pack_init, dim3(1), dim3(64), 0, st, b, (uint64_t *)d_out);
+    if (most) {
+        const unsigned gx = (unsigned)std::min<uint64_t>((most + PAIRS_CHUNK - 1) / PAIRS_CHUNK, 2048);
+        hipLaunchKernelGGL(k_pairs_pack, dim3(gx, (unsigned)ndest), dim3(256), 0, st, b, (const ulonglong2 *)d_pairs, (uint64_t *)d_out);
+    }
+    KV_HIP(hipGetLastError());
+    KV_HIP(hipStreamSynchronize(st));
+    return KV_OK;
+}
+
+extern "C" int kv_pairs_unpack(const void *d_in, const uint64_t *words_per_src, int nsrc, void *d_pairs, uint64_t cap_pairs, uint64_t *pairs_per_src,
+                               uint64_t *occurrences)
+{
+    KV_REQUIRE(d_in && words_per_src && pairs_per_src && occurrences && nsrc >= 1 && nsrc <= ROUTE_MAX_DEST, KV_ERR_ARG, "kv_pairs_unpack: bad argument");
+    PairBlocks b;
+    memset(&b, 0, sizeof(b));
+    b.nblocks = nsrc;
+    uint64_t first = 0, woff = 0, most = 0;
+    for (int s = 0; s < nsrc; ++s) {
+        const uint64_t w = words_per_src[s];
+        KV_REQUIRE(w >= 1, KV_ERR_ARG, "kv_pairs_unpack: block %d has no head word", s);
+        // w = 1 + n + ceil(n / 8): n = floor(8 (w - 1) / 9), the one n that gives w back (the sender only produces such w)
+        const uint64_t n = (w - 1) * 8 / 9;
+        KV_REQUIRE(1 + n + (n + 7) / 8 == w, KV_ERR_ARG, "kv_pairs_unpack: block %d of %llu words is not a packed block", s, (unsigned long long)w);
+        b.first[s] = first; b.n[s] = n; b.woff[s] = woff;
+        pairs_per_src[s] = n;
+        first += n; woff += w;
+        most = std::max(most, n);
+    }
+    KV_REQUIRE(first <= cap_pairs && (first == 0 || d_pairs), KV_ERR_CAPACITY, "kv_pairs_unpack: %llu pairs for a buffer of %llu", (unsigned long long)first,
+               (unsigned long long)cap_pairs);
+    hipStream_t st = kv_stream();
+    KvProfScope prof("k_pairs_unpack");
+    std::lock_guard<std::mutex> lk(g_pairs_mu);
+    if (!g_pairs_occ) KV_HIP(kv_hip_malloc((void **)&g_pairs_occ, 256));
+    KV_HIP(hipMemsetAsync(g_pairs_occ, 0, 8, st));
+    {
+        // (every block starts its own workgroups, an empty one too: its head still counts)
+        const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((most + PAIRS_CHUNK - 1) / PAIRS_CHUNK, 2048));
+        hipLaunchKernelGGL(k_pairs_unpack, dim3(gx, (unsigned)nsrc), dim3(256), 0, st, b, (const uint64_t *)d_in, (ulonglong2 *)d_pairs, g_pairs_occ);
+    }
+    KV_HIP(hipGetLastError());
+    unsigned long long total = 0;
+    KV_HIP(hipMemcpyAsync(&total, g_pairs_occ, 8, hipMemcpyDeviceToHost, st));
+    KV_HIP(hipStreamSynchronize(st));
+    *occurrences = total;
+    return KV_OK;
+}
+
 extern "C" int kv_reads_flags(const kv_reads *reads, uint8_t *flags)
 {
     KV_REQUIRE(reads && (flags || reads->n_reads == 0), KV_ERR_ARG, "kv_reads_flags: null argument");

@@ -959,6 +959,27 @@ def mex_route(plan, my_dest, recv_seg_ptr, recv_cnt_ptr, n_src, out_ptr, cap_ite
     return [int(c) for c in counts], arrived.value
 
 
+def pairs_pack(pairs_ptr, counts, out_ptr, out_cap_words):
+    """(hash, occurrences) pairs, counts[d] of them for destination d, into their 9-byte travelling form (kv_pairs_pack); returns the
+    64-bit words of every destination's block."""
+    nd = len(counts)
+    c = (ctypes.c_uint64 * nd)(*[int(v) for v in counts])
+    w = (ctypes.c_uint64 * nd)()
+    check(_lib.load().kv_pairs_pack(ctypes.c_void_p(pairs_ptr), c, nd, ctypes.c_void_p(out_ptr), int(out_cap_words), w))
+    return [int(v) for v in w]
+
+
+def pairs_unpack(in_ptr, words_per_src, pairs_ptr, cap_pairs):
+    """Received blocks back into 16-byte (hash, count <= 255) pairs (kv_pairs_unpack); returns (pairs per source, occurrences they stand
+    for -- exact, from the blocks' heads)."""
+    ns = len(words_per_src)
+    w = (ctypes.c_uint64 * ns)(*[int(v) for v in words_per_src])
+    n = (ctypes.c_uint64 * ns)()
+    occ = ctypes.c_uint64()
+    check(_lib.load().kv_pairs_unpack(ctypes.c_void_p(in_ptr), w, ns, ctypes.c_void_p(pairs_ptr), int(cap_pairs), n, ctypes.byref(occ)))
+    return [int(v) for v in n], int(occ.value)
+
+
 def mex_scan_set(sketch_cls, ksize, nsamples, hashes_ptr, abund_ptr, n, hit_tags_ptr, hit_abund_ptr, hit_cap):
     """The hits of this rank's minimizer buckets against the gathered set of interesting hashes (kv_mex_scan_set): returns how
     many (tag, abundances) rows were written; raises KvCapacityError when the owner cannot answer (scan the shard instead)."""

@@ -46,6 +46,8 @@ def main():
             # what band 0 receives (other ranks' routing: not timed)
             order = list(names[1:]) + [names[0]] if distinct else list(names)
             mex_recv0 = {}
+            recv_travel = {}
+            short_pairs = os.environ.get('KV_MEX_PAIRS', '16') == '9'
             if minimizer:
                 # every shard cut into records; bucket owner d combines what the N shards hold of its buckets; band 0 receives
                 # the owners' pairs of band 0.  Rank 0's own part (its shard's emit, its buckets' combine) is timed below.
@@ -72,11 +74,21 @@ def main():
                         c, _ = hk.mex_route(plan, d, rs.data_ptr(), rc.data_ptr(), world, send.data_ptr(), send.shape[0])
                         blocks.append(send.view(-1)[:c[0] * 2].clone().view(-1, 2))
                     recv_count[n] = torch.cat(blocks)
+                    # (as they arrive: every owner's block in the 9-byte travelling form, kv_pairs_pack)
+                    tw, ww = [], []
+                    for blk in blocks:
+                        nb = int(blk.shape[0])
+                        tbuf = torch.empty(nb + nb // 8 + 16, dtype=torch.int64, device=dev)
+                        w = hk.pairs_pack(blk.data_ptr() if nb else 0, [nb], tbuf.data_ptr(), tbuf.shape[0])
+                        tw.append(tbuf[:w[0]]); ww.append(w[0])
+                    recv_travel[n] = (torch.cat(tw), ww)
                     del segs, cnts
                 big = max(int(p_.seg_words) for p_ in plans.values())
                 my_seg = torch.empty(big, dtype=torch.int64, device=dev)
                 my_cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device=dev)
                 my_packed = torch.empty(big, dtype=torch.int64, device=dev)
+                travel = torch.empty(send.shape[0] + send.shape[0] // 8 + 64, dtype=torch.int64, device=dev)
+                unpacked = torch.empty((max(int(v.shape[0]) for v in recv_count.values()) + 8, 2), dtype=torch.int64, device=dev)
             for n in ([] if minimizer else names):
                 blocks = []
                 for r in range(world):
@@ -125,7 +137,12 @@ def main():
                         assert fitted
                         rs, rc = mex_recv0[n]
                         c, _ = hk.mex_route(plan, 0, rs.data_ptr(), rc.data_ptr(), world, send.data_ptr(), send.shape[0], keep_scan=(owner_scan and n == 'proband'))
-                        out_bytes += (sum(c) - c[0]) * 16 + (sum(per_dest) - per_dest[0]) * int(plan.recw) * 8 + int(plan.cnt_entries) * 4 * (world - 1) // world
+                        if short_pairs:
+                            wc = hk.pairs_pack(send.data_ptr(), c, travel.data_ptr(), travel.shape[0])
+                            out_bytes += (sum(wc) - wc[0]) * 8
+                        else:
+                            out_bytes += (sum(c) - c[0]) * 16
+                        out_bytes += (sum(per_dest) - per_dest[0]) * int(plan.recw) * 8 + int(plan.cnt_entries) * 4 * (world - 1) // world
                     elif distinct:
                         c = route(shards[n][0], 0, 'distinct')
                         out_bytes += (sum(c) - c[0]) * 16
@@ -136,7 +153,11 @@ def main():
                         c = route(shards[n][0], 0, 'plain')
                         out_bytes += (sum(c) - c[0]) * 8
                     tb = time.perf_counter()
-                    if distinct:
+                    if distinct and minimizer and short_pairs:
+                        tbuf, ww = recv_travel[n]
+                        per_src, _ = hk.pairs_unpack(tbuf.data_ptr(), ww, unpacked.data_ptr(), unpacked.shape[0])
+                        sk[n].consume_hashes_weighted(unpacked.data_ptr(), sum(per_src))
+                    elif distinct:
                         items = recv_count[n]
                         sk[n].consume_hashes_weighted(items.data_ptr(), items.shape[0])
                     elif n == 'proband':
@@ -191,7 +212,7 @@ def main():
                     best = res
             print('N={} items={}: per-rank route {route:.2f} ms, count {count:.2f} ms, scan {scan:.2f} ms, total {total:.2f} ms; '
                   'sends {out_mb:.0f} MB; counts {items} items; {hits} hits (set: this shard; plain: this band)'.format(world, mode_name, **best), flush=True)
-            del sk, shards, recv_count, recv_tagged, send, mex_recv0
+            del sk, shards, recv_count, recv_tagged, send, mex_recv0, recv_travel
             torch.cuda.empty_cache()
 
 

@@ -356,6 +356,33 @@ def test_mex_route_judges_its_output_by_the_pairs_not_by_the_occurrences(hk):
     assert bool((probe[n_pairs // 2:] == 0x5a5a5a5a).all())
 
 
+def test_pairs_travel_in_nine_bytes_and_come_back(hk):
+    """kv_pairs_pack / kv_pairs_unpack: blocks of (hash, occurrences) pairs into 1 + n + ceil(n / 8) words each and back -- same hashes,
+    counts saturated at 255, the exact occurrences in the heads; empty blocks, blocks that end inside a count word, a bad block refused"""
+    import torch
+    rng = np.random.default_rng(3)
+    counts = [0, 1, 7, 8, 9, 100003, 0, 64]
+    n = sum(counts)
+    pairs = np.empty((n, 2), dtype=np.uint64)
+    pairs[:, 0] = rng.integers(0, 2 ** 63, n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    pairs[:, 1] = rng.integers(1, 400, n, dtype=np.uint64)
+    pairs[5, 1] = 70000
+    dev = torch.from_numpy(pairs.view(np.int64)).cuda()
+    out = torch.full((n + n // 8 + 64,), -1, dtype=torch.int64, device='cuda')
+    words = hk.pairs_pack(dev.data_ptr(), counts, out.data_ptr(), out.shape[0])
+    assert words == [1 + c + (c + 7) // 8 for c in counts]
+    back = torch.zeros((n, 2), dtype=torch.int64, device='cuda')
+    per_src, occ = hk.pairs_unpack(out.data_ptr(), words, back.data_ptr(), n)
+    assert per_src == counts and occ == int(pairs[:, 1].sum())
+    got = back.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got[:, 0], pairs[:, 0]) and np.array_equal(got[:, 1], np.minimum(pairs[:, 1], 255))
+    assert bool((out[sum(words):] == -1).all())                   # nothing written behind the blocks
+    with pytest.raises(ValueError):
+        hk.pairs_unpack(out.data_ptr(), [2], back.data_ptr(), n)  # 1 + n + ceil(n / 8) is never 2
+    with pytest.raises(ValueError):
+        hk.pairs_pack(dev.data_ptr(), counts, out.data_ptr(), sum(words) - 1)
+
+
 @pytest.mark.parametrize('passes', ['2', '8'])
 def test_owner_combines_big_buckets_in_passes(hk, passes):
     """buckets with more distinct k-mers than the owner's LDS table holds (a sample beyond the 255 x 4096 buckets of the geometry:
@@ -480,7 +507,7 @@ def free_port():
                                                     (3, 'gloo', 'minimizer/emit:1'), (3, 'gloo', 'minimizer/route:2'), (2, 'gloo', 'minimizer/route:0'),
                                                     (3, 'gloo', 'minimizer/emit-oom:2'), (2, 'gloo', 'minimizer/route-hip:1'),
                                                     (2, 'gloo', 'minimizer/owner-hip:1'), (2, 'gloo', 'minimizer/scan-fail:0'),
-                                                    (2, 'gloo', 'minimizer/ragged:1')])
+                                                    (2, 'gloo', 'minimizer/ragged:1'), (3, 'gloo', 'minimizer/pairs9'), (1, 'nccl', 'minimizer/pairs9')])
 def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     """N ranks on this one GPU (gloo, staged exchange): each rank's sketches must equal band `rank` of a
     banded count of ALL reads, and the gathered hits the merged banded scan (tests/shard_worker.py).  The
@@ -508,7 +535,9 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), SHARD_BACKEND=backend, SHARD_DISTINCT='1' if distinct else '0')
-        if decline and decline.startswith('ragged'):        # a control sample's records travel without positions (16 bytes); a rank whose
+        if decline == 'pairs9':                             # (not a decline: the pairs travel in their 9-byte form, KV_MEX_PAIRS=9)
+            env['KV_MEX_PAIRS'] = '9'
+        elif decline and decline.startswith('ragged'):      # a control sample's records travel without positions (16 bytes); a rank whose
             env['SHARD_RAGGED'] = decline.split(':')[1]     # shard has reads of unequal length cannot cut those: that sample goes as pairs
         elif decline:
             env['KV_MEX_TEST_DECLINE'] = decline
@@ -541,6 +570,8 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
             assert '0 fallbacks, 1 scan fallbacks' in outs[rank], outs[rank][-400:]
         elif decline and decline.startswith('ragged'):
             assert '1 fallbacks, 0 scan fallbacks' in outs[rank], outs[rank][-400:]
+        elif decline == 'pairs9':
+            assert '0 fallbacks, 0 scan fallbacks' in outs[rank], outs[rank][-400:]
         elif decline:
             assert '3 fallbacks' in outs[rank], outs[rank][-400:]        # one per sample, on every rank
             assert '1 scan fallbacks' in outs[rank], outs[rank][-400:]   # and the scan of a sample that fell back goes by the shards
