@@ -859,3 +859,36 @@ def test_console_script_is_the_reference_s():
     body = inspect.getsource(__graft_entry__.build_product).split('"""')[2]          # (the code, not the docstring that says so)
     assert 'oracle' not in body and 'okhmer' not in body
     assert 'build_product()' in open(os.path.join(ROOT, 'bench.py')).read()
+
+
+def test_exchange_plans_are_host_arithmetic_every_rank_repeats():
+    """kv_mex_plan_make / kv_mex_plan_short need no device: the plan of a sample's minimizer-sharded exchange depends on the sample's global
+    size only, so every rank derives the same one.  Its split points cover the coarse buckets evenly; the short form (16-byte records
+    without read positions) exists for k = 31 and reads the lane-per-read cut takes, keeps the segment geometry and shrinks the words;
+    config 4's size ends at the geometry's limit (248 x 4096 buckets) and still has a short form."""
+    import ctypes
+    from kevlar_amd import _lib
+    lib = _lib.load()
+
+    def plan(k, n_reads, read_len, ndest, short=False):
+        p = _lib.MexPlan()
+        assert lib.kv_mex_plan_make(0, k, n_reads, read_len, ndest, ctypes.byref(p)) == 0, _lib.last_error()
+        rc = lib.kv_mex_plan_short(ctypes.byref(p)) if short else 0
+        return p, rc
+    for ndest in (1, 2, 3, 8):
+        p, _ = plan(31, 7_500_000, 100, ndest)
+        lo = [int(p.c_lo[d]) for d in range(ndest + 1)]
+        assert lo[0] == 0 and lo[-1] == int(p.C1) and all(b > a for a, b in zip(lo, lo[1:]))
+        assert int(p.seg_words) == int(p.C1) * int(p.nwg1) * int(p.cap1) * int(p.recw) and int(p.cnt_entries) == int(p.C1) * int(p.nwg1)
+        assert int(p.recw) == 3 and int(p.flags) == 0
+        q, rc = plan(31, 7_500_000, 100, ndest, short=True)
+        assert rc == 0 and int(q.flags) & 1 and int(q.recw) == 2 and int(q.seg_words) * 3 == int(p.seg_words) * 2
+        assert (int(q.C1), int(q.F2), int(q.nwg1), int(q.cap1)) == (int(p.C1), int(p.F2), int(p.nwg1), int(p.cap1))
+    assert plan(31, 7_500_000, 150, 8, short=True)[1] == 0              # two workgroups of the cut per CU up to 224 bases
+    for k, read_len in ((31, 250), (51, 150), (25, 100)):                # reads the cut does not take, two-word keys, another window
+        p, rc = plan(k, 7_500_000, read_len, 8, short=True)
+        assert rc == _lib.KV_ERR_NOTIMPL and int(p.flags) == 0 and int(p.recw) == (4 if k > 32 else 3)
+    big, rc = plan(31, 900_000_000, 100, 8, short=True)
+    assert rc == 0 and (int(big.C1), int(big.F2), int(big.recw)) == (248, 4096, 2)
+    p = _lib.MexPlan()
+    assert lib.kv_mex_plan_make(0, 12, 1000, 100, 8, ctypes.byref(p)) != 0          # k below the super-k-mer front end's range
