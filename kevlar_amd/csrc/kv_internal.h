@@ -292,6 +292,7 @@ hipStream_t kv_stream();
 hipStream_t kv_stream_key(hipStream_t st);
 // table buffers of destroyed sketches kept for the next sketch (kv_host.hip) go back to the driver: called when an allocation fails
 void kv_table_cache_release();
+void kv_case_bits_launch(const uint8_t *d_table, uint64_t size, int case_min, uint32_t *d_bits, hipStream_t st);      // kv_skm.hip
 void kv_skm_scratch_release();       // kv_skm.hip: every stream's bucket arena, distinct list and bit map
 void kv_route_scratch_release();     // kv_shard.hip: every stream's pair sink
 void kv_bin_scratch_release();       // kv_binned.hip: every stream's staging of the partitioned add

@@ -906,8 +906,17 @@ __global__ __launch_bounds__(256) void k_novel_pairs(NovelParams p, const uint64
             h[u] = it.x;
             live[u] = live[u] && (it.y >> 63) == 0;
         }
+        // (p.case0_bits: the bit map of "table 0 of the first case sample >= case_min" instead of the table -- an eighth of its bytes)
 #pragma unroll
-        for (int u = 0; u < E; ++u) v[u] = live[u] ? probe(ns, 0, 0, h[u]) : 0u;
+        for (int u = 0; u < E; ++u) {
+            if (p.case0_bits) {
+                const uint64_t bin = fastmod(h[u], ns.d[0].size, ns.d[0].magic);
+                const __attribute__((address_space(1))) uint32_t *bits = (const __attribute__((address_space(1))) uint32_t *)p.case0_bits;
+                v[u] = live[u] && ((bits[bin >> 5] >> (uint32_t)(bin & 31u)) & 1u) ? (uint32_t)p.case_min : 0u;
+            } else {
+                v[u] = live[u] ? probe(ns, 0, 0, h[u]) : 0u;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < E; ++u) {
             const bool interesting = live[u] && (int)v[u] >= p.case_min && novel_test_fast(ns, p, h[u], nullptr, 0ull);
@@ -983,6 +992,21 @@ int scan_items(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int 
     DevBuf d_count;
     KV_HIP(d_count.alloc(8));
     KV_HIP(hipMemsetAsync(d_count.p, 0, 8, st));
+    const uint64_t bits_from = getenv("KV_NOVEL_BITS_MIN") ? strtoull(getenv("KV_NOVEL_BITS_MIN"), nullptr, 10) : (1ull << 20);      // (tests: 1)
+    if (pairs && cases[0]->h.storage == ST_BYTE && n_items >= bits_from && !(getenv("KV_NOVEL_BITS") && atoi(getenv("KV_NOVEL_BITS")) == 0)) {
+        // the first probe -- where a sequencing-error k-mer ends -- from a bit map of table 0 (a streaming pass over the table first: worth it
+        // from a million pairs up)
+        static std::map<hipStream_t, KvArena> bits_for;
+        static std::mutex bits_mu;
+        KvArena *bits;
+        { std::lock_guard<std::mutex> lk(bits_mu); bits = &bits_for[kv_stream_key(st)]; }
+        if (bits->need(kv_round_up(((cases[0]->h.size[0] + 31) >> 5) * 4, 256)) == hipSuccess) {
+            kv_case_bits_launch((const uint8_t *)cases[0]->h.tab[0], (uint64_t)cases[0]->h.size[0], case_min, (uint32_t *)bits->p, st);
+            p.case0_bits = (const uint32_t *)bits->p;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (pairs) {
         KvProfScope prof("k_novel_pairs");
         const unsigned grid = (unsigned)std::min<uint64_t>((n_items + 1023) / 1024, 256 * 16);

@@ -3044,6 +3044,13 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     return rc;
 }
 
+// bits[w] bit j = (table[32 w + j] >= case_min) for a table of byte counters (k_case_bits): the first probe of a scan as a bit map
+void kv_case_bits_launch(const uint8_t *d_table, uint64_t size, int case_min, uint32_t *d_bits, hipStream_t st)
+{
+    KvProfScope prof("k_case_bits");
+    hipLaunchKernelGGL(k_case_bits, dim3(4096), dim3(256), 0, st, d_table, size, case_min, d_bits);
+}
+
 void kv_tile_hits_launch(const kv_reads *reads, const NovelParams &p, hipStream_t st)
 {
     KvProfScope prof("k_tile_hits");

@@ -545,6 +545,8 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
             # the minimizer-sharded layout: super-k-mer records travel to their bucket's owner, which deduplicates at the
             # sample's full coverage (kv_mex_emit / kv_mex_route); the scan goes through the set, as for `distinct`
             env.update(SHARD_DISTINCT='0', SHARD_MINIMIZER='1', KV_NOVEL_PATH='skm', SHARD_SCAN='shard' if shard_scan else 'owner')
+            if world == 3:                              # (the band owners' scan of their pairs with its first probe from the bit map, however few the pairs)
+                env['KV_NOVEL_BITS_MIN'] = '1'
         elif distinct:          # the bucketed kernels by name (the shards are small), or their one-item-per-k-mer stand-ins
             env.update(KV_ROUTE_PATH=distinct, KV_NOVEL_PATH='skm' if distinct == 'skm' else 'tiles')
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'shard_worker.py')], env=env,
