@@ -408,6 +408,7 @@ extern "C" int kv_scratch_trim(void)
     kv_skm_scratch_release();
     kv_route_scratch_release();
     kv_bin_scratch_release();
+    kv_novel_scratch_release();
     kv_table_cache_release();
     return KV_OK;
 }

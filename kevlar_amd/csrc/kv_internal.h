@@ -295,6 +295,7 @@ void kv_table_cache_release();
 void kv_case_bits_launch(const uint8_t *d_table, uint64_t size, int case_min, uint32_t *d_bits, hipStream_t st);      // kv_skm.hip
 void kv_skm_scratch_release();       // kv_skm.hip: every stream's bucket arena, distinct list and bit map
 void kv_route_scratch_release();     // kv_shard.hip: every stream's pair sink
+void kv_novel_scratch_release();     // kv_novel.hip: every stream's bit map of the pairs scan
 void kv_bin_scratch_release();       // kv_binned.hip: every stream's staging of the partitioned add
 void kv_ensure_dynamic_lds(const void *kernel, size_t bytes);   // hipFuncSetAttribute once per growth
 

@@ -941,6 +941,13 @@ __global__ __launch_bounds__(256) void k_novel_pairs(NovelParams p, const uint64
 namespace {
 int scan_items(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl, const void *d_items, uint64_t n_items,
                int case_min, int ctrl_max, void *d_hit_tags, void *d_hit_abund, uint64_t hit_cap, uint64_t *n_hits, bool want_hash);
+std::map<hipStream_t, KvArena> g_pairs_bits;     // per stream: the bit map of the pairs scan's first probe (grow-only; kv_scratch_trim)
+std::mutex g_pairs_bits_mu;
+}
+void kv_novel_scratch_release()
+{
+    std::lock_guard<std::mutex> lk(g_pairs_bits_mu);
+    for (auto &kv : g_pairs_bits) kv.second.release();
 }
 
 extern "C" int kv_novel_scan_hashes(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int nctrl,
@@ -996,10 +1003,8 @@ int scan_items(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int 
     if (pairs && cases[0]->h.storage == ST_BYTE && n_items >= bits_from && !(getenv("KV_NOVEL_BITS") && atoi(getenv("KV_NOVEL_BITS")) == 0)) {
         // the first probe -- where a sequencing-error k-mer ends -- from a bit map of table 0 (a streaming pass over the table first: worth it
         // from a million pairs up)
-        static std::map<hipStream_t, KvArena> bits_for;
-        static std::mutex bits_mu;
         KvArena *bits;
-        { std::lock_guard<std::mutex> lk(bits_mu); bits = &bits_for[kv_stream_key(st)]; }
+        { std::lock_guard<std::mutex> lk(g_pairs_bits_mu); bits = &g_pairs_bits[kv_stream_key(st)]; }
         if (bits->need(kv_round_up(((cases[0]->h.size[0] + 31) >> 5) * 4, 256)) == hipSuccess) {
             kv_case_bits_launch((const uint8_t *)cases[0]->h.tab[0], (uint64_t)cases[0]->h.size[0], case_min, (uint32_t *)bits->p, st);
             p.case0_bits = (const uint32_t *)bits->p;
