@@ -96,9 +96,10 @@ def parse_args():
     p.add_argument('--multi', default='auto', choices=['auto', 'exchange', 'banded'],
                    help='N>1: exchange = shard the reads, hash once, all-to-all the hashes by band (kevlar_amd/shardrun.py); '
                         'banded = every rank streams all reads and keeps its band; auto = exchange from 4 GPUs up')
-    p.add_argument('--merge', default='hits', choices=['hits', 'mask'],
-                   help='banded multi-GPU merge: hits = all-gather of the per-band hits (default); mask = north_star\'s all-reduce of the '
-                        'per-band interesting-k-mer bit masks as well, inside the timed step, asserted equal to the gathered hits')
+    p.add_argument('--merge', default='mask', choices=['hits', 'mask'],
+                   help='multi-GPU merge: mask (default) = north_star\'s all-reduce of the per-owner interesting-k-mer bit masks (a band, a '
+                        'set of minimizer buckets, a shard: disjoint findings, so the sum is the OR) inside the timed step, asserted equal to '
+                        'the gathered hits, besides the all-gather of the hits that carries their abundances; hits = the all-gather alone')
     p.add_argument('--count-streams', type=int, default=3,
                    help='N=1: count the samples concurrently on this many HIP streams, one host thread each (the samples are '
                         'independent; kernels bound by different units overlap and no stream waits for another\'s host round '
@@ -344,12 +345,9 @@ def main():
         if len(batches['proband']) == 1:
             # what `kevlar novel` does for a case sample that is one batch (kevlar_amd/count.py): the count keeps the batch's distinct
             # k-mers with their hashes, the scan that follows evaluates from that list
-            sk['proband'].expect_scan()
             # (a stream's first batch gets no list unless asked -- the allocation does not pay for a one-shot run; the bench measures
             # the steady state, and its one-step counter passes must take the path the timed steps take)
-            if 'KV_SKM_DL' not in os.environ:
-                os.environ['KV_SKM_DL'] = '1'
-                forced_env.append('KV_SKM_DL')
+            sk['proband'].expect_scan(steady=True)
         return sk
 
     sketches = make_sketches(mem_per_gpu)
@@ -357,9 +355,10 @@ def main():
 
     # --merge mask: one bit per (read, k-mer offset) of the proband, set by this rank's scan for the k-mers of its band
     band_mask = None
-    if args.merge == 'mask' and world > 1 and not exchange:
-        assert len(batch_first) == 1, '--merge mask takes whole samples (one batch)'
+    if args.merge == 'mask' and world > 1 and len(batch_first) == 1 and n_reads * nk < (1 << 36):      # (whole samples, one batch; up to 8 GB of mask)
         band_mask = torch.zeros((n_reads * nk + 31) // 32, dtype=torch.int32, device=torch.device('cuda', dev_index))
+        if exchange:
+            run.band_mask = (band_mask, nk)         # every scan of the exchange layout sets this rank's findings and all-reduces (ShardedTrio._merge_mask)
 
     def scan_batches(sk, band_mode, nbands, band):
         rs, os_, as_ = [], [], []
@@ -517,11 +516,13 @@ def main():
         from kevlar_amd import shardrun as _sr
         _sr.SENT['bytes'] = 0
     fence()
+    clocks = ClockWatch(dev_index) if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         kmers, hits = step()
     fence()
     elapsed = time.perf_counter() - t0
+    clocks = clocks.stop() if clocks is not None else None
     lib.kv_prof_enable(0)
     phases = None
     if world > 1:
@@ -603,7 +604,9 @@ def main():
             # how the exchange layout ran on rank 0 (the decisions are collective: the same on every rank): samples that fell back from the
             # minimizer layout to `distinct` pairs, scans the bucket owners could not answer (all steps, warm-up included)
             selfcheck['exchange'] = {'items': args.exchange_items, 'scan': args.exchange_scan if by_minimizer_layout else ('set' if args.exchange_items == 'distinct' else 'owners of the bands'),
-                                     'layout_fallbacks': int(getattr(run, 'fallbacks', 0)), 'scan_fallbacks': int(getattr(run, 'scan_fallbacks', 0))}
+                                     'layout_fallbacks': int(run.fallbacks), 'scan_fallbacks': int(run.scan_fallbacks),
+                                     # rank 0's own failures behind them, by reason; argument errors (a mis-wired call, not skew or memory) counted apart
+                                     'own_failures': dict(run.fallback_reasons), 'unexpected_failures': int(run.unexpected_failures)}
 
     def replay_bands(nbands):
         """the nbands-band configuration one band after the other on this GPU: what kevlar does band by band"""
@@ -749,11 +752,12 @@ def main():
                                 args.workload, wl['label'], wl['genome_mb'], wl['coverage'], L, k, n_reads, S,
                                 wl['memory'] / 1e9, T, args.case_min, args.ctrl_max),
                 'parallelism': 'single band' if world == 1 else (
-                    '{} k-mer bands, 1 per GPU; reads sharded, {} exchanged by band (all-to-all); hits all-gathered (the '
-                    'per-band bit mask of north_star carries nothing beyond them)'.format(
+                    '{} k-mer bands, 1 per GPU; reads sharded, {} exchanged by band (all-to-all); {}'.format(
                         world, {'distinct': 'distinct (hash, occurrences) pairs of each shard',
                                 'minimizer': 'super-k-mer records first exchanged by minimizer bucket, then the bucket owners\' distinct '
-                                             '(hash, occurrences) pairs'}.get(args.exchange_items, 'hashes')) if exchange else
+                                             '(hash, occurrences) pairs'}.get(args.exchange_items, 'hashes'),
+                        'per-owner bit masks of the interesting k-mer occurrences all-reduced (asserted equal to the gathered hits), hits '
+                        'all-gathered for their abundances' if band_mask is not None else 'hits all-gathered (--merge hits: no bit-mask all-reduce)') if exchange else
                     ('{} k-mer bands, 1 per GPU; every rank streams all reads; per-band bit masks all-reduced (asserted equal to the '
                      'gathered hits), hits all-gathered for their abundances' if band_mask is not None else
                      '{} k-mer bands, 1 per GPU; every rank streams all reads; hits all-gathered (the per-band bit mask of '
@@ -764,6 +768,10 @@ def main():
                 'device': '{} ({} CUs)'.format(torch.cuda.get_device_properties(dev_index).name,
                                                torch.cuda.get_device_properties(dev_index).multi_processor_count),
             },
+            # shader clock and socket power sampled beside the timed steps (sysfs; null where the box hides them): box-to-box spread of
+            # ms_per_step reads off these; `knobs`: every registered KV_* switch set in this run's environment (kv_knobs_describe)
+            'clocks': clocks,
+            'knobs': _knobs_active(),
             'selfcheck': selfcheck,
             'downstream': downstream,
             'phases': phases,
@@ -774,6 +782,62 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _knobs_active():
+    from kevlar_amd import _lib
+    return _lib.knobs_active()
+
+
+class ClockWatch(object):
+    """The GPU's shader clock (MHz) and power (W) while the timed steps run, read from the amdgpu hwmon files of the card every
+    20 ms on a thread of its own (what scratch/clock_watch.sh did with rocm-smi beside a long run).  stop() -> {'sclk_mhz': [min,
+    median, max], 'power_w': [...], 'samples': n} or None when the files are not there / not readable."""
+
+    def __init__(self, dev_index, period=0.02):
+        import glob
+        import threading
+        self.freq, self.power = None, None
+        cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/hwmon/hwmon*'))
+        # (one card per box on the pool; on a node, LOCAL_RANK's card by the order of the render nodes)
+        cards = [c for c in cards if os.path.exists(os.path.join(c, 'freq1_input'))]
+        if cards:
+            hw = cards[min(dev_index, len(cards) - 1)]
+            self.freq = os.path.join(hw, 'freq1_input')
+            for name in ('power1_input', 'power1_average'):
+                if os.path.exists(os.path.join(hw, name)):
+                    self.power = os.path.join(hw, name)
+                    break
+        self.samples = []
+        self.done = threading.Event()
+        self.period = period
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as fh:
+                return int(fh.read().strip())
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def _run(self):
+        while self.freq and not self.done.is_set():
+            self.samples.append((self._read(self.freq), self._read(self.power) if self.power else None))
+            self.done.wait(self.period)
+
+    def stop(self):
+        self.done.set()
+        self.thread.join()
+        f = sorted(s[0] / 1e6 for s in self.samples if s[0])
+        p = sorted(s[1] / 1e6 for s in self.samples if s[1])
+        if not f:
+            return None
+
+        def three(v):
+            return [round(v[0]), round(v[len(v) // 2]), round(v[-1])] if v else None
+        return {'sclk_mhz': three(f), 'power_w': three(p), 'samples': len(f)}
 
 
 def band_annotated_reads(hits, genome_len, seed, L, k, S, synth):

@@ -69,9 +69,19 @@ int kv_table_cache_trim(void);
 /* The library's per-stream working buffers only grow (the super-k-mer buckets of the last batch, the pair sink of an exchange owner, the
  * staging of the partitioned add): after one very large batch -- a bucket owner of a 900 M-read sample holds ~200 GB of them -- a
  * long-lived process gives them back with this call.  No other kv_* call may be running; whatever a later call kept in them (the
- * buckets a scan would reuse, an owner's combined buckets) is forgotten and rebuilt.  Also trims the table cache.                     */
+ * buckets a scan would reuse, an owner's combined buckets) is forgotten and rebuilt.  Also trims the table cache and the first-toucher
+ * arrays of kv_unique_new.                                                                                                           */
 int kv_scratch_trim(void);
 const char *kv_version(void);
+/* The environment variables the library looks at are one table (kevlar_amd/csrc/kv_knobs.h, kv_host.hip): SETTINGS a user may set
+ * (cache sizes, host threads, progress on stderr), TUNING switches that pin a path or shrink a geometry for tests and A/B runs -- same
+ * results on every path; honoured only while KV_TUNING=1 is set -- and EXPERIMENTS that skip parts of kernels (wrong results; only a
+ * library built with -DKV_EXPERIMENTS honours them).  kv_knobs_describe: whole_table = 0 writes what is set right now as
+ * "NAME=value ..." ("ignored:NAME=value" for a knob that is set but not honoured), 1 the table as "name<TAB>class<TAB>what it does"
+ * lines.  kv_knob_get: 1 and the value if `name` is set and honoured, 0 if not, KV_ERR_ARG for a name outside the table (the Python
+ * wrapper reads its own switches through this, so there is one registry).                                                           */
+int kv_knobs_describe(int whole_table, char *out, uint64_t cap);
+int kv_knob_get(const char *name, char *value_out, uint64_t cap);
 int kv_device_count(int *n);
 int kv_set_device(int device);       /* one process per GPU: call once with LOCAL_RANK      */
 int kv_set_stream(void *hip_stream); /* hipStream_t for the CALLING host thread; NULL = null stream */
@@ -121,7 +131,9 @@ int kv_sketch_clear(kv_sketch *s);
 /* on != 0: the batches counted into this sketch are a CASE sample's and each is scanned right after it is counted
  * (kevlar/novel.py:92-121 loads the case samples last, then scans them).  kv_consume then also keeps, for the batch it just
  * counted, every distinct k-mer with its hash, and a kv_novel_scan of that same batch evaluates from that list instead of
- * combining and hashing the batch's k-mers a second time.  Purely a performance hint: results do not depend on it. */
+ * combining and hashing the batch's k-mers a second time.  on = 2: the process counts and scans sample after sample (a server, the
+ * bench's steady state), so the list is kept from the stream's very first batch on -- a one-shot run skips it there because the
+ * allocation costs more than the list saves once.  Purely a performance hint: results do not depend on it. */
 int kv_sketch_scan_hint(kv_sketch *s, int on);
 
 /* ---- reads --------------------------------------------------------------------------- */
@@ -201,6 +213,10 @@ int kv_unique_exact(kv_sketch *s, const kv_reads *const *batches, int n_batches,
  * "distinct k-mers stored" of kevlar/count.py:82-84 for a sample of any size, no batch kept resident.                                */
 int kv_unique_new(kv_sketch *s, const kv_reads *batch, int nbands, int band, const kv_sketch *mask, int threshold,
                   int consume_masked, uint64_t *n_new_out);
+/* kv_unique_new keeps its first-toucher arrays (4 bytes per bin and table, ~4.5 x the sketch, one set per stream) between the batches
+ * of a sample; this gives back every set no running call holds.  The wrapper calls it when a sample is done
+ * (kevlar_amd.khmer: track_exact_unique(False)); kv_scratch_trim and an out-of-memory retry inside the library do the same.          */
+int kv_unique_release(void);
 
 /* ---- point queries: .get / .add on many k-mers (kevlar/filter.py:32-34,67) ------------ */
 /* hash n k-mers of length k stored back to back in `kmers` (device kernel)                */

@@ -46,6 +46,9 @@ SIGNATURES = {
     'kv_stream_destroy': (i32, [vp]),
     'kv_table_cache_trim': (i32, []),
     'kv_scratch_trim': (i32, []),
+    'kv_unique_release': (i32, []),
+    'kv_knobs_describe': (i32, [i32, ctypes.c_char_p, u64]),
+    'kv_knob_get': (i32, [ctypes.c_char_p, ctypes.c_char_p, u64]),
     'kv_prof_enable': (i32, [i32]),
     'kv_prof_reset': (i32, []),
     'kv_prof_get': (i32, [cstr, ctypes.POINTER(ctypes.c_double), u64p]),
@@ -181,6 +184,11 @@ class KvCapacityError(ValueError):
     same result take it (a ValueError to everybody else, as before)"""
 
 
+class KvArgError(ValueError):
+    """KV_ERR_ARG: the call was given arguments it does not take -- a mistake of the caller, not of the input.  The sharded step still
+    turns it into an agreed fallback (no rank may leave between collectives) but counts it as UNEXPECTED (shardrun.ShardedRun)."""
+
+
 def check(code):
     """Map a C return code onto the reference's exception types."""
     if code == KV_OK:
@@ -188,13 +196,32 @@ def check(code):
     msg = last_error()
     if code == KV_ERR_CAPACITY:
         raise KvCapacityError(msg)
-    if code in (KV_ERR_ARG, KV_ERR_NOTIMPL):
+    if code == KV_ERR_ARG:
+        raise KvArgError(msg)
+    if code == KV_ERR_NOTIMPL:
         raise ValueError(msg)
     if code == KV_ERR_IO:
         raise OSError(msg)
     if code == KV_ERR_TYPE:
         raise ValueError(msg)
     raise KvError(code, msg)
+
+
+def knob(name, default=None):
+    """An environment switch of the wrapper, through the library's one registry (kevlar_amd/csrc/kv_knobs.h): the value if `name` is
+    set and its class is honoured right now (tuning switches need KV_TUNING=1), else `default`.  An unregistered name raises."""
+    buf = ctypes.create_string_buffer(256)
+    rc = load().kv_knob_get(name.encode(), buf, len(buf))
+    if rc < 0:
+        check(rc)
+    return buf.value.decode() if rc == 1 else default
+
+
+def knobs_active():
+    """'NAME=value ...' of every registered switch that is set ('ignored:NAME=value' when its class is not honoured)"""
+    buf = ctypes.create_string_buffer(1 << 14)
+    check(load().kv_knobs_describe(0, buf, len(buf)))
+    return buf.value.decode()
 
 
 def device_visible():

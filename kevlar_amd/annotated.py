@@ -261,7 +261,7 @@ class AnnotatedReads(object):
         threads and writes the file itself (kv_format_records_fd: no text buffer of the output's size, no copy into a Python
         object); otherwise format() + write()."""
         fd = sink.raw_fd() if hasattr(sink, 'raw_fd') else None
-        if fd is None or os.environ.get('KV_FORMAT_FD') == '0':
+        if fd is None or _lib.knob('KV_FORMAT_FD') == '0':
             sink.write(self.format(reads, keep, case_abund, suffixes, regrouped, suffix_blob))
             return
         self.format(reads, keep, case_abund, suffixes, regrouped, suffix_blob, _fd=fd)
@@ -306,7 +306,7 @@ class AnnotatedReads(object):
             ctypes.cast(ctypes.c_char_p(self.mates), ctypes.c_void_p) if len(self.mate_record) else None,
             ptr(self.mate_offs) if len(self.mate_record) else None)
         if _fd is not None:
-            threads = int(os.environ.get('KV_FORMAT_THREADS', '0')) or min(16, _host_cores())
+            threads = int(_lib.knob('KV_FORMAT_THREADS', '0')) or min(16, _host_cores())
             _lib.check(lib.kv_format_records_fd(*(common + (int(_fd), threads, ctypes.byref(size)))))
             return size.value
         _lib.check(lib.kv_format_records(*(common + (ctypes.byref(text), ctypes.byref(size)))))

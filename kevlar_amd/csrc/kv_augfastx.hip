@@ -273,7 +273,7 @@ extern "C" int kv_augfastx_load(const char *path, kv_augfastx **out)
     }
     // ---- big files are cut at record starts and the pieces parsed side by side
     kv_augfastx *a = nullptr;
-    const char *forced = getenv("KV_AUGFASTX_THREADS");             // 1: one pass, for comparison
+    const char *forced = kv_knob("KV_AUGFASTX_THREADS");             // 1: one pass, for comparison
     const unsigned hw = forced ? (unsigned)std::max(1, atoi(forced)) : std::max(1u, std::thread::hardware_concurrency());
     const size_t pieces = std::min<size_t>(std::min<size_t>(hw, 16), image_size / (4u << 20));
     if (pieces >= 2) {
@@ -356,7 +356,7 @@ extern "C" int kv_augfastx_free(kv_augfastx *a)
 extern "C" int kv_reads_flag_other_bytes(const char *seqs, const uint64_t *seq_offs, uint64_t n, uint8_t *flags)
 {
     KV_REQUIRE(n == 0 || (seqs && seq_offs && flags), KV_ERR_ARG, "kv_reads_flag_other_bytes: null argument");
-    const char *forced = getenv("KV_AUGFASTX_THREADS");
+    const char *forced = kv_knob("KV_AUGFASTX_THREADS");
     const unsigned hw = forced ? (unsigned)std::max(1, atoi(forced)) : std::max(1u, std::thread::hardware_concurrency());
     const uint64_t crew_n = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(hw, 32), n / 20000));
     auto work = [&](uint64_t lo, uint64_t hi) {
@@ -383,7 +383,7 @@ extern "C" int kv_canonical_read_hashes(const char *seqs, const uint64_t *seq_of
                                         const uint8_t *complement, uint64_t *h1, uint64_t *h2)
 {
     KV_REQUIRE(n == 0 || (seqs && seq_offs && reads && complement && h1 && h2), KV_ERR_ARG, "kv_canonical_read_hashes: null argument");
-    const char *forced = getenv("KV_AUGFASTX_THREADS");
+    const char *forced = kv_knob("KV_AUGFASTX_THREADS");
     const unsigned hw = forced ? (unsigned)std::max(1, atoi(forced)) : std::max(1u, std::thread::hardware_concurrency());
     const uint64_t crew_n = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(hw, 32), n / 20000));
     auto work = [&](uint64_t lo, uint64_t hi) {

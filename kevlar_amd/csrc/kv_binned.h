@@ -109,6 +109,7 @@ struct KvArena {
         if (e != hipSuccess) {                          // the table buffers kept for future sketches are worth less than this
             (void)hipGetLastError();
             kv_table_cache_release();
+            kv_unique_scratch_release();                // (skips the arena of a kv_unique_new that is itself the caller)
             e = hipMalloc(&p, n);
         }
         if (e == hipSuccess) bytes = n;

@@ -1097,7 +1097,7 @@ double kv_estimate_distinct(uint64_t occupied, uint64_t size)
 // can stage A hash this batch from its 2-bit form (k_bin_hash_2bit)?  Reads of one length, murmur kinds, 16 <= k <= 64.  KV_BIN_2BIT=0: never
 bool kv_bin_two_bit(const kv_sketch *s, const kv_reads *reads)
 {
-    const char *e = getenv("KV_BIN_2BIT");
+    const char *e = kv_knob("KV_BIN_2BIT");
     if (e && atoi(e) == 0) return false;
     return reads && reads->uni_len != 0 && reads->uni_per_tile != 0 && s->h.hashfam == HF_MURMUR && s->h.ksize >= SKM_MIN_K && s->h.ksize <= SKM_MAX_K &&
            reads->uni_len >= (uint32_t)s->h.ksize && reads->n_tiles > 0;
@@ -1106,7 +1106,7 @@ bool kv_bin_two_bit(const kv_sketch *s, const kv_reads *reads)
 bool kv_binned_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_kmers, int nbands)
 {
     // reads == nullptr: the items come from a hash list (kv_consume_hashes)
-    const char *force = getenv("KV_COUNT_PATH");
+    const char *force = kv_knob("KV_COUNT_PATH");
     if (force && strcmp(force, "atomic") == 0) return false;
     if (s->h.ntables > BIN_MAX_T) return false;
     uint64_t pmin = UINT64_MAX, pmax = 0;
@@ -1136,12 +1136,12 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
     g.T = s->h.ntables;
     for (int t = 0; t < g.T && t < BIN_MAX_T; ++t) { g.tsize[t] = s->h.size[t]; g.ttab[t] = s->h.tab[t]; }
     g.tile_lds = lds_front;
-    g.dbg = getenv("KV_BIN_DEBUG") ? (uint32_t)atoi(getenv("KV_BIN_DEBUG")) : 0u;
+    g.dbg = kv_knob("KV_BIN_DEBUG") ? (uint32_t)atoi(kv_knob("KV_BIN_DEBUG")) : 0u;
     uint64_t pmin = UINT64_MAX, pmax = 0;
     for (int t = 0; t < g.T; ++t) { pmin = std::min(pmin, s->h.size[t]); pmax = std::max(pmax, s->h.size[t]); }
     // 32768-bin slices for weighted items (KV_BIN_SLICE15=1) were measured at config 2: stage C 2.20 instead of 2.25 ms,
     // stage B 1.26-1.36 instead of 1.0 ms -- stage C is not held back by the overlap of its phases; the default stays 65536
-    g.sbits = weighted && getenv("KV_BIN_SLICE15") && atoi(getenv("KV_BIN_SLICE15")) && ((pmax + 32767) >> 15) <= 64ull * 384ull
+    g.sbits = weighted && kv_knob("KV_BIN_SLICE15") && atoi(kv_knob("KV_BIN_SLICE15")) && ((pmax + 32767) >> 15) <= 64ull * 384ull
                   ? BIN_SLICE_BITS_W : BIN_SLICE_BITS;
     uint32_t maxsl = 1;
     for (int t = 0; t < g.T; ++t) {
@@ -1157,7 +1157,7 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
     // (weighted items: up to 64 buckets with the 512-thread front end -- its cursors are sized by T * C -- and F <= 1024)
     int cmax = weighted && g.sbits == BIN_SLICE_BITS_W ? (int)std::min<uint32_t>(BIN_C, std::max<uint32_t>(4u, (maxsl + 383u) / 384u))
                               : (maxsl <= 32u * BIN_MAX_F ? (int)std::min<uint32_t>(32u, std::max<uint32_t>(4u, (maxsl + 383u) / 384u)) : BIN_C);
-    if (const char *e = getenv("KV_BIN_C")) cmax = std::max(1, std::min<int>(BIN_C, atoi(e)));      // experiments: coarse buckets per table
+    if (const char *e = kv_knob("KV_BIN_C")) cmax = std::max(1, std::min<int>(BIN_C, atoi(e)));      // experiments: coarse buckets per table
     plan->cmax = cmax;
     g.F = (int)((maxsl + (uint32_t)cmax - 1) / (uint32_t)cmax);
     g.C = (int)((maxsl + (uint32_t)g.F - 1) / (uint32_t)g.F);
@@ -1208,7 +1208,7 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
     g.spill = (unsigned long long *)base; base += b_spill;
     g.ctr = (unsigned long long *)base;
     {
-        bool ok = g.T == 4 && ns * g.nwgA * g.cap1 < (1ull << 32) && !(getenv("KV_BIN_FAST4") && atoi(getenv("KV_BIN_FAST4")) == 0);
+        bool ok = g.T == 4 && ns * g.nwgA * g.cap1 < (1ull << 32) && !(kv_knob("KV_BIN_FAST4") && atoi(kv_knob("KV_BIN_FAST4")) == 0);
         for (int t = 0; t < g.T && t < BIN_MAX_T; ++t) {
             g.tmagic[t] = kv_fastmod_magic(s->h.size[t]);
             ok = ok && kv_fastmod_fp(s->h.size[t]) && s->h.size[t] < (1ull << 31);
@@ -1232,7 +1232,7 @@ int kv_bin_finish(kv_sketch *s, BinPlan &plan, bool added_from_ctr, uint64_t n_a
             ensure_dynamic_lds((k_bin_split<true, BIN_SLICE_BITS_W>), lds);
             hipLaunchKernelGGL((k_bin_split<true, BIN_SLICE_BITS_W>), dim3(g.nwgB, (unsigned)ns), dim3(BIN_B_THREADS), lds, st, g);
         } else if (plan.weighted && (g.nwgA + g.nwgB - 1) / g.nwgB <= BIN_BS_MAXSEG && (uint32_t)g.F <= BIN_B_THREADS &&
-                   getenv("KV_BIN_SPLIT") && !strcmp(getenv("KV_BIN_SPLIT"), "sorted")) {
+                   kv_knob("KV_BIN_SPLIT") && !strcmp(kv_knob("KV_BIN_SPLIT"), "sorted")) {
             // weighted items, 65536-bin slices, ranked and laid out in LDS, copied out in runs: only by name (KV_BIN_SPLIT=sorted) -- it gives
             // the same segments and measured SLOWER than the ring kernel, 3.98 against 3.24 ms per step of config 2 (profiles/README.md)
             const size_t lds2 = (size_t)BIN_BS_CHUNK * 4;
@@ -1327,12 +1327,12 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
     } else if (reads) {
         // default: direct stores through LDS cursors (k_bin_hash_direct); KV_BIN_DIRECT=0 selects the LDS-ring
         // variant, which measured ~10% slower on this stage (profiles/README.md)
-        const bool direct = !(getenv("KV_BIN_DIRECT") && atoi(getenv("KV_BIN_DIRECT")) == 0);
+        const bool direct = !(kv_knob("KV_BIN_DIRECT") && atoi(kv_knob("KV_BIN_DIRECT")) == 0);
         KvProfScope prof(direct ? "k_bin_hash_direct" : "k_bin_hash");
         const size_t lds = (size_t)g.tile_lds + ns * g.ringA * 4 + ns * 8;
         const unsigned grid = g.nwgA;
         const int k = s->h.ksize;
-        const int nw = (s->h.hashfam == HF_MURMUR && !getenv("KV_NO_ROLL")) ? (k <= 32 ? 8 : (k <= 64 ? 16 : 0)) : 0;
+        const int nw = (s->h.hashfam == HF_MURMUR && !kv_knob("KV_NO_ROLL")) ? (k <= 32 ? 8 : (k <= 64 ? 16 : 0)) : 0;
 #define KV_LAUNCH_BIN_HASH(THREADS_, NW_)                                                                         \
         do {                                                                                                      \
             ensure_dynamic_lds(k_bin_hash<THREADS_, NW_>, lds);                                                   \

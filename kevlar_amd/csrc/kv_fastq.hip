@@ -256,7 +256,7 @@ struct KvStager {
     {
         if (!init()) return false;
         int nthreads = 4;
-        if (const char *e = getenv("KV_STAGE_THREADS")) nthreads = std::max(1, std::min(16, atoi(e)));
+        if (const char *e = kv_knob("KV_STAGE_THREADS")) nthreads = std::max(1, std::min(16, atoi(e)));
         int s = 0;
         for (uint64_t done = 0; done < n; done += KV_STAGE_CHUNK, s = (s + 1) % KV_STAGE_SLOTS) {
             const uint64_t len = std::min<uint64_t>(KV_STAGE_CHUNK, n - done);
@@ -336,7 +336,7 @@ KvFastqDevice *kv_fastq_device_open(const char *path)
     if (d->image[0] == '@') d->plain = true;
     else kv_bgzf_index(d->image, d->image_size, &d->members, &yes);
     if (!yes && !d->plain) {
-        const char *off = getenv("KV_GUNZIP");
+        const char *off = kv_knob("KV_GUNZIP");
         if (off && !strcmp(off, "host")) { kv_fastq_device_close(d); return nullptr; }
     }
     {
@@ -349,7 +349,7 @@ KvFastqDevice *kv_fastq_device_open(const char *path)
         d->gz = kv_gunzip_open(d->image, d->image_size, &d->buf->gz);
         if (!d->gz) { kv_fastq_device_close(d); return nullptr; }
         {
-            const char *stage_env = getenv("KV_STAGE");
+            const char *stage_env = kv_knob("KV_STAGE");
             if (!(stage_env && atoi(stage_env) == 0)) {
                 KvStager *stage = &d->buf->stage;
                 const int fd_ = d->fd;
@@ -381,7 +381,7 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
     *reads_out = nullptr;
     if (d->done) return KV_OK;             // (the batch served last stays served: its records can still be fetched)
     hipStream_t st = kv_stream();
-    const bool verbose = getenv("KV_INGEST_VERBOSE") != nullptr;   // wall time of the steps of a batch on stderr
+    const bool verbose = kv_knob("KV_INGEST_VERBOSE") != nullptr;   // wall time of the steps of a batch on stderr
     auto t_mark = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!verbose) return;
@@ -390,7 +390,7 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         fprintf(stderr, "[kv_ingest] %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_mark).count());
         t_mark = now;
     };
-    const char *cap_env = getenv("KV_INGEST_TEXT_MB");            // tests shrink the batches
+    const char *cap_env = kv_knob("KV_INGEST_TEXT_MB");            // tests shrink the batches
     const uint64_t text_cap = (cap_env ? strtoull(cap_env, nullptr, 10) : 4096ull) << 20;
     const double per_read = d->bytes_per_read > 0 ? d->bytes_per_read : 280.0;
     uint64_t want = std::min<uint64_t>((uint64_t)((double)max_reads * per_read * 1.02) + 65536, text_cap);
@@ -423,7 +423,7 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
         if (d->carry_len) KV_HIP(hipMemcpyAsync(text, (const uint8_t *)d->text[d->cur].p + d->carry_at, d->carry_len, hipMemcpyDeviceToDevice, st));
         if (d->plain && fresh) {
             // big stretches through the pinned staging buffers (KV_STAGE=0: straight from the mapping, as small ones go)
-            const char *stage_env = getenv("KV_STAGE");
+            const char *stage_env = kv_knob("KV_STAGE");
             const bool staged = fresh >= (64u << 20) && !(stage_env && atoi(stage_env) == 0) && d->buf->stage.upload(text + d->carry_len, d->fd, b0, fresh, st);
             if (!staged) KV_HIP(hipMemcpyAsync(text + d->carry_len, d->image + b0, fresh, hipMemcpyHostToDevice, st));
         }
@@ -434,7 +434,7 @@ int kv_fastq_device_next(KvFastqDevice *d, uint64_t max_reads, kv_reads **reads_
             // header, or one row of a stored block; the slack is zeroed so that what it decodes there is an error, not noise)
             KV_HIP(d->buf->comp.need(kv_round_up(c1 - c0 + KV_INFLATE_SLACK, 4096)));
             {
-                const char *stage_env = getenv("KV_STAGE");
+                const char *stage_env = kv_knob("KV_STAGE");
                 const bool staged = c1 - c0 >= (64u << 20) && !(stage_env && atoi(stage_env) == 0) && d->buf->stage.upload((uint8_t *)d->buf->comp.p, d->fd, c0, c1 - c0, st);
                 if (!staged) KV_HIP(hipMemcpyAsync(d->buf->comp.p, d->image + c0, c1 - c0, hipMemcpyHostToDevice, st));
             }

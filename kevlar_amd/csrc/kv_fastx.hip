@@ -121,7 +121,7 @@ static bool fx_fill(kv_fastx *f)
     if (f->end == f->buf.size()) f->buf.resize(f->buf.size() * 2);
     if (f->dsrc) {
         DevTextSource *d = f->dsrc;
-        const char *seg_env = getenv("KV_INGEST_TEXT_MB");            // tests shrink the segments
+        const char *seg_env = kv_knob("KV_INGEST_TEXT_MB");            // tests shrink the segments
         const uint64_t want = (seg_env ? strtoull(seg_env, nullptr, 10) : 256ull) << 20;
         uint64_t n = 0;
         bool last = false;
@@ -438,7 +438,7 @@ static void fx_open_device_text(kv_fastx *f, size_t size)
 extern "C" int kv_fastx_open(const char *path, kv_fastx **out)
 {
     KV_REQUIRE(path && out, KV_ERR_ARG, "kv_fastx_open: null argument");
-    const char *mode = getenv("KEVLAR_PACK_CACHE");          // unset or "0": never look at caches; "1": use and create them
+    const char *mode = kv_knob("KEVLAR_PACK_CACHE");          // unset or "0": never look at caches; "1": use and create them
     const bool caching = mode && atoi(mode) != 0;
     kv_fastx *f = new kv_fastx();
     f->path = path;
@@ -454,7 +454,7 @@ extern "C" int kv_fastx_open(const char *path, kv_fastx **out)
         f->fh = fh;
         f->buf.resize(4 << 20);
         if (caching) f->writer = pack_writer_start(path);
-        const char *ingest = getenv("KV_INGEST");               // "host": never parse on the device
+        const char *ingest = kv_knob("KV_INGEST");               // "host": never parse on the device
         if (!caching && !(ingest && strcmp(ingest, "host") == 0)) {
             // the device takes four-line FASTQ, uncompressed ('@' first) or gzip of either kind: for a compressed file the first
             // byte of TEXT is looked at (a few KB of the file through zlib; nothing of the stream handle is touched)
@@ -475,7 +475,7 @@ extern "C" int kv_fastx_open(const char *path, kv_fastx **out)
                         f->dev_candidate = (rc == Z_OK || rc == Z_STREAM_END || rc == Z_BUF_ERROR) && zs.avail_out == 0 && first == '@';
                         inflateEnd(&zs);
                         // any other text in a gzip file of some size (FASTA): inflate on the device, parse here
-                        const char *big = getenv("KV_GUNZIP_TEXT_MIN_MB");
+                        const char *big = kv_knob("KV_GUNZIP_TEXT_MIN_MB");
                         const uint64_t min_bytes = (big ? strtoull(big, nullptr, 10) : 4ull) << 20;
                         struct stat sb;
                         int ndev = 0;

@@ -460,11 +460,31 @@ extern "C" int kv_unique_exact(kv_sketch *s, const kv_reads *const *batches, int
 // new if the batch were consumed now -- some bin of the k-mer is clear in the tables (nothing counted so far touched it) and no earlier
 // k-mer of this very batch touches it first.  Called before every kv_consume of a sketch that tracks the exact figure, the sum over the
 // batches is kv_unique_exact's number without keeping any batch resident (round 5: the 4 GiB retention limit is gone; a sample of any
-// size reports the reference's "distinct k-mers stored").  The first-toucher arrays (4 bytes per bin and table) come from a per-stream
-// arena that is kept between calls.
+// size reports the reference's "distinct k-mers stored").  The first-toucher arrays (4 bytes per bin and table, ~4.5 x the sketch) come
+// from a per-stream arena that is kept between the calls of one sample and given back by kv_unique_release (the wrapper calls it when
+// tracking ends), kv_scratch_trim, and any allocation of the library that runs out of memory (kv_unique_scratch_release skips an
+// arena whose call is still running).
 namespace {
-std::map<hipStream_t, KvArena> g_unique_arena;
+struct UniqueArena {
+    KvArena a;
+    std::mutex busy;            // held for the whole of a kv_unique_new call on this stream
+};
+std::map<hipStream_t, UniqueArena> g_unique_arena;
 std::mutex g_unique_arena_mu;
+}
+void kv_unique_scratch_release()
+{
+    std::lock_guard<std::mutex> alk(g_unique_arena_mu);
+    for (auto &kv : g_unique_arena) {
+        if (!kv.second.busy.try_lock()) continue;       // in use by a running call (possibly the caller's own): not ours to free
+        kv.second.a.release();
+        kv.second.busy.unlock();
+    }
+}
+extern "C" int kv_unique_release(void)
+{
+    kv_unique_scratch_release();
+    return KV_OK;
 }
 extern "C" int kv_unique_new(kv_sketch *s, const kv_reads *batch, int nbands, int band, const kv_sketch *mask, int threshold,
                              int consume_masked, uint64_t *n_new_out)
@@ -485,11 +505,13 @@ extern "C" int kv_unique_new(kv_sketch *s, const kv_reads *batch, int nbands, in
     FirstTouchParams p;
     memset(&p, 0, sizeof(p));
     p.f = make_consume_filter(k, s->h.hashfam, nbands, band, mask != nullptr, threshold, consume_masked);
-    KvArena *arena;
+    UniqueArena *ua;
     {
         std::lock_guard<std::mutex> alk(g_unique_arena_mu);
-        arena = &g_unique_arena[kv_stream_key(st)];
+        ua = &g_unique_arena[kv_stream_key(st)];
     }
+    std::lock_guard<std::mutex> busy(ua->busy);
+    KvArena *arena = &ua->a;
     const uint64_t bm_words = (total + 31) / 32;
     size_t need = kv_round_up(bm_words * 4, 256) + 256;
     for (int t = 0; t < s->h.ntables; ++t) need += kv_round_up(s->h.size[t] * 4, 256);

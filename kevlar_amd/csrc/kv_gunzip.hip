@@ -949,9 +949,9 @@ KvGunzip *kv_gunzip_open(const uint8_t *image, uint64_t size, KvGunzipArenas *ar
     g->size = size;
     if (arenas) g->a = arenas;
     g->pos_bit = data * 8;
-    const char *cb = getenv("KV_GUNZIP_CHUNK_KB");
+    const char *cb = kv_knob("KV_GUNZIP_CHUNK_KB");
     if (cb && atoi(cb) >= 1 && atoi(cb) <= 64) g->chunk_bytes = (uint32_t)atoi(cb) * 1024u;
-    const char *cc = getenv("KV_GUNZIP_CRC");
+    const char *cc = kv_knob("KV_GUNZIP_CRC");
     g->crc_on = !(cc && !strcmp(cc, "0"));
     return g;
 }
@@ -975,7 +975,7 @@ static int gz_run_jobs(KvGunzip *g, const uint8_t *d_comp, uint64_t n_bytes, boo
         KvProfScope prof("k_gz_decode");
         // the LDS window sets how many stretches a CU holds (1 K symbols: 32 = 8 waves per SIMD); a match that reaches further
         // back reads the symbols the wave itself stored to HBM, behind a workgroup-scope release
-        const char *rb = getenv("KV_GUNZIP_RING_BITS");
+        const char *rb = kv_knob("KV_GUNZIP_RING_BITS");
         const int bits = rb ? atoi(rb) : 10;
         const int per_cu = bits >= 14 ? 4 : bits == 13 ? 8 : bits == 12 ? 12 : bits == 11 ? 24 : 32;
         const unsigned grid = (unsigned)std::min<uint64_t>(n, (uint64_t)per_cu * (uint64_t)kv_device_cus());
@@ -1004,7 +1004,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     KV_REQUIRE(!g->pending, KV_ERR_ARG, "kv_gunzip_decode: the previous segment has not been emitted");
     if (g->done) return KV_OK;
     hipStream_t st = kv_stream();
-    const bool verbose = getenv("KV_INGEST_VERBOSE") != nullptr;
+    const bool verbose = kv_knob("KV_INGEST_VERBOSE") != nullptr;
     auto t_mark = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!verbose) return;
@@ -1065,7 +1065,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     // into step (k_gz_sync).  KV_GUNZIP_SPLIT_KB: compressed bytes a piece should have (0: no cutting)
     std::vector<uint64_t> headers(starts);              // headers[i]: the block header stretch i takes its codes from
     {
-        const char *sk = getenv("KV_GUNZIP_SPLIT_KB");
+        const char *sk = kv_knob("KV_GUNZIP_SPLIT_KB");
         // default: only when the block starts alone leave the device short of work (fewer than 24 stretches per CU), and
         // then as many pieces as make 32 per CU: every cut costs a header to parse, a tail to resolve and a decoder that
         // looks for its target between symbols too (k_gz_decode<.., true>, ~15 % more instructions per symbol)
@@ -1267,7 +1267,7 @@ int kv_gunzip_decode(KvGunzip *g, uint64_t want_text, uint64_t *text_bytes, bool
     KV_HIP(hipStreamSynchronize(st));
     // FASTQ needs nearly every round (each read's header is a copy of the one before it: a chain as long as the file)
     const bool listed = markers <= list_cap;
-    if (getenv("KV_GUNZIP_VERBOSE"))
+    if (kv_knob("KV_GUNZIP_VERBOSE"))
         fprintf(stderr, "[kv_gunzip] %zu stretches (%llu of them begin inside a block), %llu of %llu tail symbols are markers (%s)\n", nv,
                 (unsigned long long)g->stat_cuts, markers, (unsigned long long)tail_syms, listed ? "listed" : "whole tails");
     for (uint64_t d = 1; d < nv + 1 && markers; d <<= 1) {

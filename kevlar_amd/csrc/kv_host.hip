@@ -347,7 +347,7 @@ uint64_t g_tabcache_bytes = 0;
 int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 uint64_t tabcache_cap()
 {
-    const char *e = getenv("KV_TABLE_CACHE_GB");
+    const char *e = kv_knob("KV_TABLE_CACHE_GB");
     const double gb = e ? atof(e) : 32.0;
     return gb > 0 ? (uint64_t)(gb * (double)(1ull << 30)) : 0;       // (fractions of a gigabyte count)
 }
@@ -364,9 +364,10 @@ hipError_t table_alloc(uint8_t **p, uint64_t bytes)
         }
     }
     hipError_t e = hipMalloc((void **)p, bytes);
-    if (e != hipSuccess) {                           // out of memory: give the cache back and try once more
+    if (e != hipSuccess) {                           // out of memory: give the cache (and idle first-toucher arrays) back, try once more
         (void)hipGetLastError();
         kv_table_cache_release();
+        kv_unique_scratch_release();
         e = hipMalloc((void **)p, bytes);
     }
     return e;
@@ -391,6 +392,7 @@ hipError_t kv_hip_malloc(void **p, size_t bytes)
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
         kv_table_cache_release();
+        kv_unique_scratch_release();
         e = hipMalloc(p, bytes);
     }
     return e;
@@ -409,6 +411,7 @@ extern "C" int kv_scratch_trim(void)
     kv_route_scratch_release();
     kv_bin_scratch_release();
     kv_novel_scratch_release();
+    kv_unique_scratch_release();
     kv_table_cache_release();
     return KV_OK;
 }
@@ -542,6 +545,7 @@ extern "C" int kv_sketch_scan_hint(kv_sketch *s, int on)
     KV_REQUIRE(s, KV_ERR_ARG, "kv_sketch_scan_hint: null handle");
     std::lock_guard<std::mutex> lk(s->mu);
     s->scan_hint = on != 0;
+    s->scan_steady = on == 2;
     return KV_OK;
 }
 
@@ -550,7 +554,7 @@ extern "C" int kv_sketch_clear(kv_sketch *s)
     KV_REQUIRE(s, KV_ERR_ARG, "kv_sketch_clear: null handle");
     std::lock_guard<std::mutex> lk(s->mu);
     s->version++;
-    const char *lazy = getenv("KV_LAZY_CLEAR");           // "0": zero the tables here and now
+    const char *lazy = kv_knob("KV_LAZY_CLEAR");           // "0": zero the tables here and now
     if (lazy && atoi(lazy) == 0) {
         KvProfScope prof("memset_tables");
         for (int i = 0; i < s->h.ntables; ++i) KV_HIP(hipMemsetAsync(s->h.tab[i], 0, s->alloc_bytes[i], kv_stream()));
@@ -1149,5 +1153,155 @@ extern "C" int kv_reads_num_kmers(const kv_reads *r, int ksize, uint64_t *n_kmer
         w->nk_cached_k = ksize;
     }
     *n_kmers = r->nk_cached;
+    return KV_OK;
+}
+
+// ---- the knob registry (kv_knobs.h) --------------------------------------------------------------------------------------------
+namespace {
+#define S_ KV_KNOB_SETTING
+#define T_ KV_KNOB_TUNING
+#define X_ KV_KNOB_EXPERIMENT
+const KvKnobDef g_knobs[] = {
+    // settings: a user may set these
+    {"KV_TABLE_CACHE_GB", S_, "table buffers of destroyed sketches kept for the next sketch of the same size, in GB (default 32; 0: none)"},
+    {"KV_AUGFASTX_THREADS", S_, "host threads of the augmented FASTX reader / writer (default: by input size, up to the cores)"},
+    {"KV_FORMAT_THREADS", S_, "host threads formatting annotated reads (default: min(16, cores))"},
+    {"KV_STAGE_THREADS", S_, "host threads reading a file into the pinned staging buffers (1..16)"},
+    {"KEVLAR_PACK_CACHE", S_, "packed-read cache files beside the inputs: unset / 0 never, 1 use and create"},
+    {"KV_INGEST", S_, "host: parse every file on the host, never on the device"},
+    {"KV_GUNZIP", S_, "0: ordinary gzip through zlib on the host instead of the device inflater"},
+    {"KV_GUNZIP_CRC", S_, "0: skip the CRC-32 check of inflated members"},
+    {"KV_PARALLEL_SAMPLES", S_, "1 / 0: count the samples of `kevlar novel` side by side on their own streams / one after the other"},
+    {"KV_INGEST_VERBOSE", S_, "wall time of every ingest step on stderr"},
+    {"KV_GUNZIP_VERBOSE", S_, "statistics of the gzip inflater on stderr"},
+    {"KV_SKM_VERBOSE", S_, "what the super-k-mer front end decided (geometry, lists kept or dropped, fallbacks) on stderr"},
+    {"KV_MEX_VERBOSE", S_, "why a rank declined a step of the exchange layout, on stderr"},
+    // tuning: same results on another path / in another geometry; honoured only with KV_TUNING=1
+    {"KV_COUNT_PATH", T_, "atomic | binned | skm: pin the count path"},
+    {"KV_NOVEL_PATH", T_, "tiles | skm: pin the scan path"},
+    {"KV_ROUTE_PATH", T_, "plain: the exchange routes one item per k-mer (no combining)"},
+    {"KV_SET_SCAN", T_, "skm: a shard's set scan keeps the bucketed kernel"},
+    {"KV_LAZY_CLEAR", T_, "0: kv_sketch_clear zeroes the tables at once instead of leaving it to the apply stage"},
+    {"KV_NO_ROLL", T_, "hash every k-mer from scratch (no rolling 2-bit window)"},
+    {"KV_BIN_2BIT", T_, "0: stage A never hashes from the 2-bit form"},
+    {"KV_BIN_DIRECT", T_, "0: stage A writes items through LDS rings instead of direct stores"},
+    {"KV_BIN_FAST4", T_, "0: no FP64-quotient remainders for four tables"},
+    {"KV_BIN_SPLIT", T_, "sorted: stage B sorts a chunk in LDS before it stores"},
+    {"KV_BIN_SLICE15", T_, "1: 32 K-bin slices for weighted items"},
+    {"KV_BIN_C", T_, "coarse buckets per table"},
+    {"KV_SKM_S1", T_, "tile | wave | lane: pin the record cutter"},
+    {"KV_SKM_S2", T_, "plain | sorted: pin the fine split"},
+    {"KV_SKM_S1_THREADS", T_, "512 | 1024: workgroup size of the wave cutter"},
+    {"KV_SKM_R", T_, "reads per wave pass of the wave cutter"},
+    {"KV_SKM_CH", T_, "8 | 16: k-mers per lane chunk of the wave cutter"},
+    {"KV_SKM_LANE_MAXWG", T_, "2 | 3: workgroups per CU the lane cutter asks for"},
+    {"KV_SKM_LANE_FLUSH", T_, "blocks between two flushes of the lane cutter's run list"},
+    {"KV_SKM_SEG1", T_, "bucket: S1 segments laid out bucket-major"},
+    {"KV_SKM_ORIENT", T_, "0: records keep the read's strand (no oriented keys)"},
+    {"KV_SKM_COMPACT", T_, "0: never the 16-byte records without positions"},
+    {"KV_SKM_DEDUP", T_, "1: identical records merged before the k-mer table (k = 31)"},
+    {"KV_SKM_DEDUP_MAXN", T_, "longest record the record table takes"},
+    {"KV_SKM_DEDUP_RS", T_, "record-table slots (1024: two workgroups per CU)"},
+    {"KV_SKM_ANY_K", T_, "use the kernels with k at run time, not the k = 31 / 51 instances"},
+    {"KV_SKM_BUCKET_KMERS", T_, "k-mer occurrences aimed at per bucket (tests: many buckets on small inputs)"},
+    {"KV_SKM_CAP_PCT", T_, "segment capacity in per cent of the estimate (tests: push records through the loose list)"},
+    {"KV_SKM_LOOSE_CAP", T_, "entries of the loose list"},
+    {"KV_SKM_FORCE_LOOSE", T_, "every record through the loose list"},
+    {"KV_SKM_NWG1", T_, "S1 writers (upper bound)"},
+    {"KV_SKM_NWG2", T_, "S2 writers per coarse stream"},
+    {"KV_SKM_BPT", T_, "buckets per work ticket of stage S3"},
+    {"KV_SKM_WG3_PER_CU", T_, "1..3: S3 workgroups per CU"},
+    {"KV_SKM_ABL", T_, "0: no abundance list from a control's count"},
+    {"KV_SKM_DL", T_, "0: no distinct list from a case sample's count; 1: from the first batch on"},
+    {"KV_SKM_NO_REUSE", T_, "the scan re-buckets the batch instead of reusing the count's buckets"},
+    {"KV_NOVEL_2BIT", T_, "0: the per-k-mer scan keeps the tile kernel"},
+    {"KV_NOVEL_BITS", T_, "0: no bit map as the first probe of the scan"},
+    {"KV_NOVEL_BITS_MIN", T_, "items from which the pairs scan builds its bit map"},
+    {"KV_NOVEL_PAIRS", T_, "0: the set scan answers from hashes alone"},
+    {"KV_NOVEL_ABCACHE", T_, "0: no cache of the interesting k-mers' abundances"},
+    {"KV_NOVEL_VCACHE", T_, "0: no verdict cache in the tile scan"},
+    {"KV_NOVEL_VCSETS", T_, "0: direct-mapped verdict cache"},
+    {"KV_NOVEL_EMIT_TILES", T_, "hits listed by the tile kernel"},
+    {"KV_NOVEL_EMIT_FUSED", T_, "hits listed by the fused kernel"},
+    {"KV_NOVEL_REREAD", T_, "`kevlar novel` reads a case file again for the scan instead of keeping its batch"},
+    {"KV_HOST_SORT", T_, "partition sorts its keys on the host"},
+    {"KV_FORMAT_FD", T_, "0: annotated reads formatted into a buffer, not written to the descriptor"},
+    {"KV_STAGE", T_, "0: uploads straight from the file mapping, no pinned staging"},
+    {"KV_INGEST_TEXT_MB", T_, "text per ingest batch in MB (tests: small batches)"},
+    {"KV_GUNZIP_TEXT_MIN_MB", T_, "gzip files from this size on are inflated on the device"},
+    {"KV_GUNZIP_CHUNK_KB", T_, "1..64: compressed bytes per probe stretch"},
+    {"KV_GUNZIP_RING_BITS", T_, "10..14: LDS window of the gzip decoder"},
+    {"KV_GUNZIP_SPLIT_KB", T_, "cut DEFLATE blocks longer than this"},
+    {"KV_INFLATE_WINDOW_BITS", T_, "10..15: LDS window of the BGZF inflater"},
+    {"KV_MEX_NWG1", T_, "exchange: S1 writers of a shard (the same on every rank)"},
+    {"KV_MEX_CAP2_SLACK", T_, "exchange: S2 segment slack"},
+    {"KV_MEX_PASSES", T_, "exchange: combine passes per bucket (power of two)"},
+    {"KV_MEX_PAIRS", T_, "9: (hash, count) pairs travel in the 9-byte block form"},
+    {"KV_MEX_TEST_DECLINE", T_, "point:rank -- that rank fails at that point of the exchange (tests of the agreed fallbacks)"},
+    {"KV_ROUTE_OVF_CAP", T_, "entries of the route's overflow list (tests: force the capacity error)"},
+    // experiments: parts of kernels skipped for timing, RESULTS ARE WRONG; a -DKV_EXPERIMENTS build only
+    {"KV_SKM_DEBUG", X_, "bit mask: phases of the super-k-mer count kernels to skip"},
+    {"KV_SKM_SCAN_DEBUG", X_, "bit mask: phases of k_skm_novel_list to skip"},
+    {"KV_BIN_DEBUG", X_, "bit mask: phases of k_bin_apply to skip"},
+};
+#undef S_
+#undef T_
+#undef X_
+}  // namespace
+
+const KvKnobDef *kv_knob_table(size_t *n)
+{
+    if (n) *n = sizeof(g_knobs) / sizeof(g_knobs[0]);
+    return g_knobs;
+}
+
+static bool knob_honoured(KvKnobClass cls)
+{
+    if (cls == KV_KNOB_SETTING) return true;
+    const char *t = getenv("KV_TUNING");                 // (the registry's own switch: the one getenv of the library besides the lookup below)
+    if (!(t && atoi(t) == 1)) return false;
+#if defined(KV_EXPERIMENTS)
+    return true;
+#else
+    return cls != KV_KNOB_EXPERIMENT;
+#endif
+}
+
+const char *kv_knob(const char *name)
+{
+    for (const KvKnobDef &d : g_knobs)
+        if (!strcmp(d.name, name)) return knob_honoured(d.cls) ? getenv(name) : nullptr;
+    fprintf(stderr, "[kvsketch] kv_knob(\"%s\"): not in the registry of kv_host.hip\n", name);
+    return nullptr;
+}
+
+extern "C" int kv_knob_get(const char *name, char *value_out, uint64_t cap)
+{
+    KV_REQUIRE(name, KV_ERR_ARG, "kv_knob_get: null name");
+    bool known = false;
+    for (const KvKnobDef &d : g_knobs) known = known || !strcmp(d.name, name);
+    KV_REQUIRE(known, KV_ERR_ARG, "kv_knob_get: %s is not a registered knob", name);
+    const char *v = kv_knob(name);
+    if (!v) return 0;
+    if (value_out && cap) { strncpy(value_out, v, cap - 1); value_out[cap - 1] = 0; }
+    return 1;
+}
+
+extern "C" int kv_knobs_describe(int whole_table, char *out, uint64_t cap)
+{
+    KV_REQUIRE(out && cap > 0, KV_ERR_ARG, "kv_knobs_describe: no buffer");
+    std::string s;
+    static const char *cls_name[] = {"setting", "tuning", "experiment"};
+    for (const KvKnobDef &d : g_knobs) {
+        if (whole_table) {
+            s += d.name; s += '\t'; s += cls_name[d.cls]; s += '\t'; s += d.doc; s += '\n';
+        } else if (const char *v = getenv(d.name)) {
+            if (!s.empty()) s += ' ';
+            if (!knob_honoured(d.cls)) s += "ignored:";
+            s += d.name; s += '='; s += v;
+        }
+    }
+    KV_REQUIRE(s.size() < cap, KV_ERR_CAPACITY, "kv_knobs_describe: %llu bytes needed", (unsigned long long)s.size() + 1);
+    memcpy(out, s.c_str(), s.size() + 1);
     return KV_OK;
 }

@@ -290,7 +290,7 @@ int kv_bgzf_inflate(const uint8_t *d_comp, uint64_t comp_base, const KvBgzfMembe
         // that reach further back (up to 32 KB) read the text from HBM.  Measured on 846 MB of FASTQ text (4 M reads, bgzip
         // level 4), k_inflate alone, one box: 1 KB 27.2 ms, 2 KB 31.4 ms, 4 KB 35.5 ms; on another box 2 KB 42.4, 4 KB 45.9,
         // 8 KB 52.1, 16 KB ~78, 32 KB (no HBM reads at all) ~100 ms.  KV_INFLATE_WINDOW_BITS = 10 .. 15 for experiments.
-        const char *wb = getenv("KV_INFLATE_WINDOW_BITS");
+        const char *wb = kv_knob("KV_INFLATE_WINDOW_BITS");
         const int bits = wb ? atoi(wb) : 10;
         const int per_cu = bits >= 15 ? 4 : bits == 14 ? 8 : bits == 13 ? 12 : bits == 12 ? 16 : bits == 11 ? 20 : 32;
         const unsigned grid = (unsigned)std::min<uint64_t>(count, (uint64_t)per_cu * (uint64_t)kv_device_cus());
@@ -312,7 +312,7 @@ int kv_bgzf_inflate(const uint8_t *d_comp, uint64_t comp_base, const KvBgzfMembe
         return KV_ERR_IO;
     }
     // the members' CRC-32, as zlib / htslib would check it: slices of 16 KB of every member's text, joined per member
-    const char *crc_env = getenv("KV_GUNZIP_CRC");
+    const char *crc_env = kv_knob("KV_GUNZIP_CRC");
     if (!(crc_env && !strcmp(crc_env, "0"))) {
         std::vector<uint64_t> r_start;
         std::vector<uint32_t> r_len;

@@ -11,6 +11,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include "kv_knobs.h"
 
 #include "../../include/kvsketch.h"
 #include "kv_fastmod.h"
@@ -84,6 +85,7 @@ struct kv_sketch {
     bool lazy_zero = false;
     KvAbundList abl;       // see above; valid = false whenever the tables may hold less than it says
     bool scan_hint = false; // kv_sketch_scan_hint: batches counted into this sketch are scanned next (a case sample)
+    bool scan_steady = false; // ... and the process does so sample after sample: the distinct list pays from the first batch on
     std::mutex mu;
 };
 
@@ -297,6 +299,7 @@ void kv_skm_scratch_release();       // kv_skm.hip: every stream's bucket arena,
 void kv_route_scratch_release();     // kv_shard.hip: every stream's pair sink
 void kv_novel_scratch_release();     // kv_novel.hip: every stream's bit map of the pairs scan
 void kv_bin_scratch_release();       // kv_binned.hip: every stream's staging of the partitioned add
+void kv_unique_scratch_release();    // kv_graph.hip: every stream's first-toucher arrays of kv_unique_new that no running call holds
 void kv_ensure_dynamic_lds(const void *kernel, size_t bytes);   // hipFuncSetAttribute once per growth
 
 // profiling: RAII wrapper recording HIP events around a launch when enabled

@@ -264,7 +264,7 @@ extern "C" int kv_consume(kv_sketch *s, const kv_reads *reads, int nbands, int b
         KvProfScope prof("k_consume");
         const SketchDev *dm = mask ? mask->d_desc : nullptr;
         const unsigned lds = reads->tile_lds_bytes;
-        const bool roll = s->h.hashfam == HF_MURMUR && !getenv("KV_NO_ROLL");
+        const bool roll = s->h.hashfam == HF_MURMUR && !kv_knob("KV_NO_ROLL");
 #define KV_LAUNCH_CONSUME(NW_)                                                                                   \
         do {                                                                                                     \
             kv_ensure_dynamic_lds((const void *)k_consume<NW_>, lds);                                            \

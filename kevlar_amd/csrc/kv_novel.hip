@@ -446,14 +446,14 @@ inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 inline int vc_sets_env()
 {
-    const char *e = getenv("KV_NOVEL_VCSETS");   // 0: direct-mapped cache in k_novel_mark as well
+    const char *e = kv_knob("KV_NOVEL_VCSETS");   // 0: direct-mapped cache in k_novel_mark as well
     return e ? atoi(e) : -1;
 }
 
 // point p.vcache at this stream's verdict cache, (re)allocating or clearing it as the signature requires
 int attach_vcache(NovelParams &p, kv_sketch *const *ctrls, int ncase, int nctrl, int ctrl_max, uint64_t n_kmers, hipStream_t st)
 {
-    const char *vc_env = getenv("KV_NOVEL_VCACHE");
+    const char *vc_env = kv_knob("KV_NOVEL_VCACHE");
     if (nctrl > 0 && p.screen == 0 && !(vc_env && atoi(vc_env) == 0)) {
         // signature of everything the cached verdicts depend on
         uint64_t sig = 0x9e3779b97f4a7c15ull ^ (uint64_t)(uint32_t)ctrl_max;
@@ -531,7 +531,7 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
     // large batches: evaluate every DISTINCT k-mer once over the batch's super-k-mer buckets (kv_skm.hip); otherwise
     // (and as the fallback) every k-mer of every read, with the verdict cache absorbing the repeats
     bool use_skm = p.screen == 0 && kv_skm_eligible(cases[0], reads, n_kmers, true);
-    const bool skm_by_name = getenv("KV_NOVEL_PATH") != nullptr;          // asked for by name: no second-guessing
+    const bool skm_by_name = kv_knob("KV_NOVEL_PATH") != nullptr;          // asked for by name: no second-guessing
     if (use_skm && !skm_by_name) {
         // Is there anything to deduplicate?  (i) the scan remembers: the last batch it cut for this case sample overflowed the
         // tables and was scanned again tile by tile (config 4's batches of 0.6x coverage: 48 per sample, every one of them scanned
@@ -552,7 +552,7 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         const bool sparse = held > 0.0 && (double)n_kmers < 0.5 * held;
         if (cases[0]->skm_scan_off || sparse) {
             use_skm = false;
-            if (getenv("KV_SKM_VERBOSE"))
+            if (kv_knob("KV_SKM_VERBOSE"))
                 fprintf(stderr, "[kv_novel] tile scan: %s\n", cases[0]->skm_scan_off ? "the previous batch of this case sample did not fit the super-k-mer tables"
                                                                                       : "the batch is a small share of the distinct k-mers the case sketch holds");
         }
@@ -631,7 +631,7 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
     uint64_t nhits = 0;
     bool marked_by_skm = use_skm;
     p.ab_keys = nullptr; p.ab_vals = nullptr; p.ab_mask = 0;
-    if (e == hipSuccess && use_skm && !p.set_keys && kv_skm_list_ready(reads, k) && !(getenv("KV_NOVEL_ABCACHE") && atoi(getenv("KV_NOVEL_ABCACHE")) == 0)) {
+    if (e == hipSuccess && use_skm && !p.set_keys && kv_skm_list_ready(reads, k) && !(kv_knob("KV_NOVEL_ABCACHE") && atoi(kv_knob("KV_NOVEL_ABCACHE")) == 0)) {
         // room for the abundances of the interesting k-mers (a k-mer in a few thousand is one): 1 / 64 of the k-mers in slots
         uint64_t slots = 1u << 16;
         while (slots < n_kmers / 64 && slots < (1ull << 24)) slots <<= 1;
@@ -661,7 +661,7 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
     if (e == hipSuccess) {
         // equal-length reads of a murmur kind, 16 <= k <= 64, no abundance screen: every k-mer hashed from its 2-bit form
         // (k_novel_mark_2bit; KV_NOVEL_PATH=tiles, or KV_NOVEL_2BIT=0, keeps the tile kernel)
-        const char *forced = getenv("KV_NOVEL_PATH"), *nm2 = getenv("KV_NOVEL_2BIT");
+        const char *forced = kv_knob("KV_NOVEL_PATH"), *nm2 = kv_knob("KV_NOVEL_2BIT");
         const bool two_bit = !marked_by_skm && p.screen == 0 && fam == HF_MURMUR && k >= SKM_MIN_K && k <= SKM_MAX_K && reads->uni_len >= (uint32_t)k &&
                              reads->uni_per_tile != 0 && !(forced && strcmp(forced, "tiles") == 0) && !(nm2 && atoi(nm2) == 0);
         if (two_bit) {
@@ -693,8 +693,8 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
         p.hit_abund = (uint8_t *)arenas->hits.p + 2 * up256(nhits * 4);
         if (e == hipSuccess) {
             KvProfScope prof("k_novel_emit");
-            const bool from_bits = fam == HF_MURMUR && k <= 64 && !getenv("KV_NOVEL_EMIT_TILES");
-            const bool dense = from_bits && k >= SKM_MIN_K && !getenv("KV_NOVEL_EMIT_FUSED");
+            const bool from_bits = fam == HF_MURMUR && k <= 64 && !kv_knob("KV_NOVEL_EMIT_TILES");
+            const bool dense = from_bits && k >= SKM_MIN_K && !kv_knob("KV_NOVEL_EMIT_FUSED");
             const unsigned grid_hits = (unsigned)std::min<uint64_t>((nhits + 255) / 256, 1u << 16);
             if (dense && k <= 32) {
                 hipLaunchKernelGGL((k_novel_emit_bits<8, false>), dim3(reads->n_tiles), dim3(256), 0, st, reads_dev(reads), p);
@@ -994,13 +994,13 @@ int scan_items(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, int 
     p.case_min = case_min; p.ctrl_max = ctrl_max;
     hipStream_t st = kv_stream();
     // pairs (want_hash): every k-mer once, no verdict cache, several first probes in flight (KV_NOVEL_PAIRS=0: the list kernel)
-    const bool pairs = want_hash && !(getenv("KV_NOVEL_PAIRS") && atoi(getenv("KV_NOVEL_PAIRS")) == 0);
+    const bool pairs = want_hash && !(kv_knob("KV_NOVEL_PAIRS") && atoi(kv_knob("KV_NOVEL_PAIRS")) == 0);
     if (!pairs) { const int rc = attach_vcache(p, ctrls, ncase, nctrl, ctrl_max, n_items, st); if (rc != KV_OK) return rc; }
     DevBuf d_count;
     KV_HIP(d_count.alloc(8));
     KV_HIP(hipMemsetAsync(d_count.p, 0, 8, st));
-    const uint64_t bits_from = getenv("KV_NOVEL_BITS_MIN") ? strtoull(getenv("KV_NOVEL_BITS_MIN"), nullptr, 10) : (1ull << 20);      // (tests: 1)
-    if (pairs && cases[0]->h.storage == ST_BYTE && n_items >= bits_from && !(getenv("KV_NOVEL_BITS") && atoi(getenv("KV_NOVEL_BITS")) == 0)) {
+    const uint64_t bits_from = kv_knob("KV_NOVEL_BITS_MIN") ? strtoull(kv_knob("KV_NOVEL_BITS_MIN"), nullptr, 10) : (1ull << 20);      // (tests: 1)
+    if (pairs && cases[0]->h.storage == ST_BYTE && n_items >= bits_from && !(kv_knob("KV_NOVEL_BITS") && atoi(kv_knob("KV_NOVEL_BITS")) == 0)) {
         // the first probe -- where a sequencing-error k-mer ends -- from a bit map of table 0 (a streaming pass over the table first: worth it
         // from a million pairs up)
         KvArena *bits;
@@ -1123,7 +1123,7 @@ extern "C" int kv_novel_scan_set(const kv_reads *reads, int kind, int ksize, int
     // k-mer: from the 2-bit form of equal-length reads that is ~305 lane-instructions per occurrence (k_novel_mark_2bit), which is what
     // cutting, splitting and combining the shard costs per occurrence at 30x and more than it costs at a shard's 4-15x (measured per
     // rank of config 2: 3.1 -> 1.8 ms at N = 8).  KV_SET_SCAN=skm keeps the bucketed scan; other batches take it as before.
-    const char *how = getenv("KV_SET_SCAN"), *nm2 = getenv("KV_NOVEL_2BIT"), *forced = getenv("KV_NOVEL_PATH");
+    const char *how = kv_knob("KV_SET_SCAN"), *nm2 = kv_knob("KV_NOVEL_2BIT"), *forced = kv_knob("KV_NOVEL_PATH");
     const bool two_bit = fam == HF_MURMUR && ksize >= SKM_MIN_K && ksize <= SKM_MAX_K && reads->uni_len >= (uint32_t)ksize && reads->uni_per_tile != 0 &&
                          !(how && strcmp(how, "skm") == 0) && !(nm2 && atoi(nm2) == 0) && !(forced && strcmp(forced, "tiles") == 0);
     const bool use_skm = !two_bit && kv_skm_eligible_kind(fam, ksize, reads, n_kmers, true);

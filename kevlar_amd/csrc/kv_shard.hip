@@ -244,7 +244,9 @@ int route_scratch(RouteParams &p, uint64_t n_kmers, uint32_t W, hipStream_t st)
     p.seg_cap = round_up((uint64_t)(m * 1.1 + 8.0 * std::sqrt(m)) + 1024, 64);
     // worst case: no capacity error possible -- up to 2^30 items; a bigger sink takes a quarter of its items through the overflow list
     // (what missed a segment of 1.5 x the even share: skew beyond that ends in the capacity error the callers fall back from)
+    // (route_pack and kv_mex_route compare what was pushed with the list's size: KV_ERR_CAPACITY, never a silent loss)
     p.ovf_cap = n_kmers <= (1ull << 30) ? n_kmers : std::max<uint64_t>(1ull << 30, n_kmers / 4);
+    if (const char *e = kv_knob("KV_ROUTE_OVF_CAP")) p.ovf_cap = std::max<uint64_t>(1, std::min<uint64_t>(p.ovf_cap, strtoull(e, nullptr, 10)));      // tests: force the error
     const size_t b_seg = round_up((uint64_t)p.ndest * p.nwg * p.seg_cap * 8 * W, 256);
     const size_t b_cnt = round_up((uint64_t)p.ndest * p.nwg * 4, 256), b_off = round_up((uint64_t)p.ndest * p.nwg * 8, 256);
     const size_t b_ovf = round_up(p.ovf_cap * 8 * W, 256), b_od = round_up(p.ovf_cap, 256), b_ctr = 1024;
@@ -300,6 +302,9 @@ int route_pack(RouteParams &p, uint32_t W, hipStream_t st, uint64_t *counts_out,
     KV_HIP(hipMemcpyAsync(host, p.ctr, sizeof(host), hipMemcpyDeviceToHost, st));
     KV_HIP(hipStreamSynchronize(st));
     *tiles_done = host[0];
+    // ctr[1] counts every item that missed its segment, stored or not: past the list's end the kernels drop what they cannot store
+    KV_REQUIRE(host[1] <= p.ovf_cap, KV_ERR_CAPACITY, "route: %llu items beside their segments, the overflow list holds %llu",
+               host[1], (unsigned long long)p.ovf_cap);
     for (int d = 0; d < p.ndest; ++d) counts_out[d] = host[2 + d] + host[18 + d];
     return KV_OK;
 }
@@ -405,7 +410,7 @@ extern "C" int kv_route_distinct(const kv_reads *reads, int kind, int ksize, int
     if (reads->n_tiles == 0 || n_kmers == 0) return KV_OK;
     hipStream_t st = kv_stream();
     const int hashfam = kv_hashfam_of(kind);
-    const char *force = getenv("KV_ROUTE_PATH");                 // "plain": tests pin the one-item-per-k-mer form
+    const char *force = kv_knob("KV_ROUTE_PATH");                 // "plain": tests pin the one-item-per-k-mer form
     const uint64_t min_stride = reads->max_len >= (uint32_t)ksize ? reads->max_len - (uint32_t)ksize + 1 : 1;
     bool bucketed = hashfam == HF_MURMUR && ksize >= 16 && ksize <= 64 && reads->tile_max_bases > 0 && reads->tile_max_bases <= 8192u &&
                     (double)reads->n_reads * (double)min_stride < (double)(1ull << 40) && !(force && strcmp(force, "plain") == 0) &&

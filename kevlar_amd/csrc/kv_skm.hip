@@ -784,11 +784,6 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, C == 2 ? 4 : SKM_LANE_WAVES) void
                 for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? skm_bases32(src, from + 32u * t) : 0ull;
                 const uint64_t hdr = skm_header(pos, n, fine, rev);
                 const uint32_t p = atomicAdd(&cur[coarse], 1u);
-#if defined(SKM_HACK_ONESTORE)          // timing experiment only: one 16-byte store per record
-                if (p < sg.cap1) { typedef uint64_t u64x2 __attribute__((ext_vector_type(2), aligned(8))); *(u64x2 *)(my_seg + coarse * cstride + p * (uint32_t)sg.recw) = u64x2{hdr, bw[0]}; }
-#elif defined(SKM_LANE_DISSECT) && SKM_LANE_DISSECT == 3
-                if (p < sg.cap1) n_rec += hdr ^ bw[0] ^ bw[1];
-#else
                 if (p < sg.cap1) {
                     if (sg.compact) {                                 // one aligned 16-byte store: bases, n and the fine bucket (no position)
                         typedef uint64_t u64x2a __attribute__((ext_vector_type(2), aligned(16)));
@@ -797,7 +792,6 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, C == 2 ? 4 : SKM_LANE_WAVES) void
                         skm_store_record_wide(my_seg + coarse * cstride + p * (uint32_t)sg.recw, hdr, bw, sg.nbw);
                     }
                 }
-#endif
                 else skm_loose_push(sg, hdr, bw);
                 n_rec += 1;
                 left -= n; pos += n; bidx += n;
@@ -815,11 +809,7 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, C == 2 ? 4 : SKM_LANE_WAVES) void
 #else
             (void)want;
             if (slot >= SKM_LANE_CAP) return false;                   // (a wave of reads that change minimizer at nearly every k-mer)
-#if defined(SKM_LANE_DISSECT) && SKM_LANE_DISSECT == 2
-            n_rec += v ^ lane_start ^ end;
-#else
             ent[slot] = (unsigned long long)v | ((unsigned long long)(lane_start | (end << 18)) << 32);
-#endif
             return true;
 #endif
         };
@@ -831,11 +821,7 @@ __global__ __launch_bounds__(SKM_LANE_THREADS, C == 2 ? 4 : SKM_LANE_WAVES) void
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-#if defined(SKM_LANE_DISSECT)        // timing experiments (results are wrong): 1 no records, 2 no run list either, 3 the records without their stores
-            const uint32_t n = SKM_LANE_DISSECT == 3 ? min(n_ent, SKM_LANE_CAP) : 0u;
-#else
             const uint32_t n = min(n_ent, SKM_LANE_CAP);
-#endif
             for (uint32_t e = lane; e < n; e += 64u) {
                 const unsigned long long en = ent[e];
                 const uint32_t hi = (uint32_t)(en >> 32), first = (hi >> 6) & 4095u;
@@ -1126,9 +1112,6 @@ __device__ __forceinline__ int skm_table_insert(SkmTable<KW, TS> &tb, const SkmK
         // (reading the slot first and swapping only into an empty one was measured 5 % slower: the read does not save
         // the swap's round trip, it adds one for every new key)
         const unsigned long long old0 = atomicCAS(&tb.key[0][slot], SKM_EMPTY, (unsigned long long)c.w[0]);
-#if defined(SKM_HACK_ONEPROBE)        // timing experiment only (wrong counts): what the insert costs when the first slot always answers
-        if (KW == 1) return (int)(slot | (old0 == SKM_EMPTY || old0 == c.w[0] ? 0u : 0u));
-#endif
         if (old0 == SKM_EMPTY || old0 == c.w[0]) {
             if (KW == 1) return (int)slot;
             const unsigned long long old1 = atomicCAS(&tb.key[KW - 1][slot], SKM_EMPTY, (unsigned long long)c.w[KW - 1]);
@@ -1561,11 +1544,7 @@ __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : (RS >= 1024 
         const uint32_t sidx = (uint32_t)t * (uint32_t)g.C + c;
         const uint32_t item = ((slice - c * (uint32_t)g.F) << g.sbits) | ((uint32_t)bin & ((1u << g.sbits) - 1u)) | ((wgt - 1u) << BIN_W_SHIFT);
         const uint32_t pos = atomicAdd(&cur[sidx], 1u);
-#if defined(SKM_HACK_NOITEMSTORE)      // timing experiment only: what the scattered 4-byte item stores cost
-        if (pos < cap1) { if (item == 0xdeadbeefu) my_seg[sidx * seg_stride + pos] = item; }
-#else
         if (pos < cap1) my_seg[sidx * seg_stride + pos] = item;
-#endif
         else spill_item(g, t, bin, wgt);
     };
     // the table is emptied as it is read (below), so it is cleared only once; the next bucket's ticket is fetched
@@ -2447,13 +2426,13 @@ inline uint32_t skm_nwg3(const SkmGeom &g)
 {
     // persistent workgroups of the bucket kernels: three per CU fill its LDS (KV_SKM_WG3_PER_CU=2 leaves a third of it -- and of the wave
     // slots -- to whatever another stream has queued: the experiment behind DESIGN.md section 4.1, "samples on separate streams")
-    static const uint32_t per_cu = [] { const char *e = getenv("KV_SKM_WG3_PER_CU"); const int v = e ? atoi(e) : 3; return (uint32_t)(v >= 1 && v <= 3 ? v : 3); }();
+    static const uint32_t per_cu = [] { const char *e = kv_knob("KV_SKM_WG3_PER_CU"); const int v = e ? atoi(e) : 3; return (uint32_t)(v >= 1 && v <= 3 ? v : 3); }();
     return (uint32_t)std::min<uint64_t>((g.n_buckets + g.bpt - 1) / g.bpt, per_cu * (uint32_t)kv_device_cus());
 }
 
 static uint32_t skm_default_bpt()
 {
-    if (const char *e = getenv("KV_SKM_BPT")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) return (uint32_t)v; }
+    if (const char *e = kv_knob("KV_SKM_BPT")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) return (uint32_t)v; }
     return SKM_BUCKETS_PER_TICKET;
 }
 // Buckets per ticket of the work counter.  A ticket costs a returning atomic on a word every workgroup asks for -- ~10 per microsecond
@@ -2464,7 +2443,7 @@ static void skm_pick_bpt(SkmGeom &g)
 {
     g.bpt = SKM_BUCKETS_PER_TICKET;
     while (g.bpt > 2u && g.n_buckets / g.bpt < 4u * 768u) g.bpt /= 2u;
-    if (getenv("KV_SKM_BPT")) g.bpt = skm_default_bpt();
+    if (kv_knob("KV_SKM_BPT")) g.bpt = skm_default_bpt();
 }
 
 inline uint32_t pow2_ceil(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
@@ -2477,7 +2456,7 @@ int skm_minimizer_len(int k) { return k >= 24 ? 12 : k / 2; }
 static thread_local uint32_t tl_s1_threads = 0;       // a caller's choice for the launch it is about to make (kv_skm_mex_emit); the variable in the environment wins
 static uint32_t skm_wave_threads()
 {
-    if (const char *e = getenv("KV_SKM_S1_THREADS")) return atoi(e) == 512 ? 512u : 1024u;
+    if (const char *e = kv_knob("KV_SKM_S1_THREADS")) return atoi(e) == 512 ? 512u : 1024u;
     return tl_s1_threads ? tl_s1_threads : SKM_S1_WAVE_THREADS_DEFAULT;
 }
 
@@ -2485,7 +2464,7 @@ static uint32_t skm_wave_plan(const SkmGeom &g, const kv_reads *reads, int *ch)
 {
     const uint32_t L = reads->uni_len;
     if (!L || L < (uint32_t)g.k || g.w <= 8) return 0;
-    if (const char *e = getenv("KV_SKM_S1")) if (!strcmp(e, "tile")) return 0;
+    if (const char *e = kv_knob("KV_SKM_S1")) if (!strcmp(e, "tile")) return 0;
     const uint32_t wpr = (L + 15) / 16, nk = L - (uint32_t)g.k + 1;
     const double runs = 1.0 + (nk - 1) * 2.0 / (g.w + 1) + (double)nk / g.ncap * 0.5;
     uint32_t best = 0;
@@ -2494,10 +2473,10 @@ static uint32_t skm_wave_plan(const SkmGeom &g, const kv_reads *reads, int *ch)
         const uint32_t cpr = (nk + c - 1) / c;
         uint32_t R = std::min<uint32_t>(64 / wpr, 64 / cpr);
         R = std::min<uint32_t>(R, (uint32_t)(58.0 / runs));
-        if (const char *e = getenv("KV_SKM_R")) R = std::min<uint32_t>(std::min<uint32_t>(64 / wpr, 64 / cpr), (uint32_t)atoi(e));
+        if (const char *e = kv_knob("KV_SKM_R")) R = std::min<uint32_t>(std::min<uint32_t>(64 / wpr, 64 / cpr), (uint32_t)atoi(e));
         if (R >= best && R > 0) { best = R; *ch = c; }       // equal R: the smaller chunk keeps more lanes busy
     }
-    if (const char *e = getenv("KV_SKM_CH")) { const int c = atoi(e); if ((c == 8 || c == 16) && g.w > c) { *ch = c; best = std::min<uint32_t>(best, 64 / ((nk + c - 1) / c)); } }
+    if (const char *e = kv_knob("KV_SKM_CH")) { const int c = atoi(e); if ((c == 8 || c == 16) && g.w > c) { *ch = c; best = std::min<uint32_t>(best, 64 / ((nk + c - 1) / c)); } }
     if (best < 2) return 0;
     const uint32_t threads = skm_wave_threads();
     // three workgroups of 512 per CU, or one of 1024 -- or the tile kernel
@@ -2511,7 +2490,7 @@ static uint32_t skm_wave_plan(const SkmGeom &g, const kv_reads *reads, int *ch)
 static uint32_t skm_lane_wgs_per_cu(uint32_t L)
 {
     const size_t need = (size_t)skm_lane_slice_words((L + 15u) / 16u) * 4 * (SKM_LANE_THREADS / 64) + 1200;
-    const char *e = getenv("KV_SKM_LANE_MAXWG");                // (A/B: 3 keeps the cut to the lengths that fit three times)
+    const char *e = kv_knob("KV_SKM_LANE_MAXWG");                // (A/B: 3 keeps the cut to the lengths that fit three times)
     const uint32_t floor_wgs = e ? (uint32_t)std::max(2, std::min(3, atoi(e))) : 2u;
     if (need <= 160000u / (SKM_LANE_WAVES / 2)) return 3u;
     return (floor_wgs <= 2u && need <= 160000u / 2u) ? 2u : 0u;
@@ -2520,7 +2499,7 @@ static uint32_t skm_lane_wgs_per_cu(uint32_t L)
 static bool skm_lane_fits_len(const SkmGeom &g, uint32_t L)
 {
     if (!L || L < (uint32_t)g.k || g.m != 12 || (g.w != SKM_LANE_B && g.w != 2 * SKM_LANE_B) || L > 256u) return false;
-    const char *e1 = getenv("KV_SKM_S1");
+    const char *e1 = kv_knob("KV_SKM_S1");
     if (e1 && strcmp(e1, "lane") != 0) return false;
     // (w = 40, k = 51: two arrays of suffix minima; that instance is compiled for 4 waves per SIMD and skm_build starts two workgroups
     // per CU for it -- at six waves it spilled and measured slower than the wave kernel, 5.5 against 4.1 ms per step of config 5)
@@ -2540,7 +2519,7 @@ void skm_launch_emit(const SkmGeom &g, const kv_reads *reads, hipStream_t st)
         const size_t lds = (size_t)skm_lane_slice_words(wpr) * 4 * (SKM_LANE_THREADS / 64);
         const uint64_t n_groups = (reads->n_reads + 63) / 64;
         uint32_t flush_blocks = 2;
-        if (const char *e = getenv("KV_SKM_LANE_FLUSH")) flush_blocks = std::max(1, atoi(e));
+        if (const char *e = kv_knob("KV_SKM_LANE_FLUSH")) flush_blocks = std::max(1, atoi(e));
         void (*kernel)(ReadsDev, SkmGeom, uint32_t, uint32_t);
         if (g.w == SKM_LANE_B) kernel = wpr <= 8 ? k_skm_emit_lane<1, 8> : k_skm_emit_lane<1, 16>;
         else kernel = wpr <= 8 ? k_skm_emit_lane<2, 8> : k_skm_emit_lane<2, 16>;
@@ -2583,7 +2562,7 @@ void skm_launch_split(const SkmGeom &g, hipStream_t st)
 {
     KvProfScope prof("k_skm_split");
     // sorted scatter while a chunk holds ~2 records per fine bucket or more (KV_SKM_S2=plain|sorted overrides)
-    const char *s2 = getenv("KV_SKM_S2");
+    const char *s2 = kv_knob("KV_SKM_S2");
     const bool sorted = s2 ? strcmp(s2, "sorted") == 0 && g.F2 <= SKM_S2_MAXF : g.F2 <= SKM_S2_MAXF;
     if (sorted) {
         const size_t lds = (size_t)SKM_S2_CHUNK * g.recw * 8;
@@ -2700,7 +2679,7 @@ void skm_geom_k(SkmGeom &g, int k)
     g.lrecw = g.recw;
     g.ncap = 32 * g.nbw - k + 1;
     g.sbw = ((64u * (uint32_t)g.ncap) >> 5) + 2u;
-    g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
+    g.dbg = kv_knob("KV_SKM_DEBUG") ? (uint32_t)atoi(kv_knob("KV_SKM_DEBUG")) : 0u;
     g.bpt = skm_default_bpt();
 }
 
@@ -2738,22 +2717,22 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.recw = 1 + g.nbw;
     g.lrecw = g.recw;
     g.ncap = 32 * g.nbw - k + 1;
-    g.dbg = getenv("KV_SKM_DEBUG") ? (uint32_t)atoi(getenv("KV_SKM_DEBUG")) : 0u;
-    if (getenv("KV_SKM_FORCE_LOOSE")) g.dbg |= 4096u;
+    g.dbg = kv_knob("KV_SKM_DEBUG") ? (uint32_t)atoi(kv_knob("KV_SKM_DEBUG")) : 0u;
+    if (kv_knob("KV_SKM_FORCE_LOOSE")) g.dbg |= 4096u;
     g.bpt = skm_default_bpt();
     // KV_SKM_DEDUP=1 (k = 31, oriented records): k_skm_count combines identical records before their k-mers (skm_rec_combine): a 3072-slot
     // k-mer table beside a 512-slot table of records, or KV_SKM_DEDUP_RS=1024: 4096 beside 1024 at two workgroups per CU.  Off unless asked
     // for: measured SLOWER (k_skm_count 9.25 -> 10.2 ms per step of config 2 either way, profiles/README.md round 5).
     // KV_SKM_DEDUP_MAXN=n: records of more than n k-mers send their bucket down the plain walk (tests: n = 5 sends nearly every bucket there)
     {
-        const char *eo = getenv("KV_SKM_ORIENT"), *ed = getenv("KV_SKM_DEDUP"), *em = getenv("KV_SKM_DEDUP_MAXN");
-        const bool dd = k == 31 && !(eo && atoi(eo) == 0) && (ed && atoi(ed) == 1) && !g.dbg && !getenv("KV_SKM_ANY_K");
+        const char *eo = kv_knob("KV_SKM_ORIENT"), *ed = kv_knob("KV_SKM_DEDUP"), *em = kv_knob("KV_SKM_DEDUP_MAXN");
+        const bool dd = k == 31 && !(eo && atoi(eo) == 0) && (ed && atoi(ed) == 1) && !g.dbg && !kv_knob("KV_SKM_ANY_K");
         g.dd_maxn = dd ? (uint32_t)(SKM_C_BASES + 1 - k) : 0u;
         if (dd && em) g.dd_maxn = (uint32_t)std::max(0, std::min(atoi(em), SKM_C_BASES + 1 - k));
     }
-    const bool dd_big = g.dd_maxn && getenv("KV_SKM_DEDUP_RS") && atoi(getenv("KV_SKM_DEDUP_RS")) >= 1024;      // (experiment: 1024 record slots beside 4096 k-mer slots, two workgroups per CU)
+    const bool dd_big = g.dd_maxn && kv_knob("KV_SKM_DEDUP_RS") && atoi(kv_knob("KV_SKM_DEDUP_RS")) >= 1024;      // (experiment: 1024 record slots beside 4096 k-mer slots, two workgroups per CU)
     const uint32_t table_slots = g.kw == 1 ? (g.dd_maxn && !dd_big ? 3072u : 4096u) : 2048u;
-    const char *tgt_env = getenv("KV_SKM_BUCKET_KMERS");      // tests shrink the buckets to exercise many of them on small inputs
+    const char *tgt_env = kv_knob("KV_SKM_BUCKET_KMERS");      // tests shrink the buckets to exercise many of them on small inputs
     // k-mers per fine bucket: as many as leave the LDS table ~0.4 full (0.29 for two-word keys, whose longer windows put
     // fewer, bigger minimizer loci into a bucket: more variance) given the share of distinct k-mers the previous batch
     // into the same sketch -- or routed on the same stream -- showed; without one, a whole 30x sample is assumed
@@ -2786,7 +2765,7 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     // 16-byte records without positions (kv_skm_device.h) when nobody will ask where a k-mer was: the count of a sample that is not
     // scanned from this very batch.  The lane-per-read S1 writes them, the sorted S2 moves them, k_skm_count reads them; KV_SKM_COMPACT=0: never
     {
-        const char *e = getenv("KV_SKM_COMPACT"), *s2 = getenv("KV_SKM_S2");
+        const char *e = kv_knob("KV_SKM_COMPACT"), *s2 = kv_knob("KV_SKM_S2");
         g.compact = (!want_pos && g.kw == 1 && k + 1 <= SKM_C_BASES && skm_lane_fits(g, reads) && g.F2 <= SKM_S2_MAXF && !(s2 && strcmp(s2, "sorted") != 0) &&
                      !(e && atoi(e) == 0)) ? 1u : 0u;
         if (g.compact) { g.recw = 2; g.ncap = std::min(g.ncap, SKM_C_BASES + 1 - k); }
@@ -2807,8 +2786,8 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
         g.quota1 = (uint32_t)std::min<uint64_t>(kv_round_up(avg + avg / 2 + 1, SKM_TILES_PER_TICKET), 0xfffffff0ull);
     }
     g.nwg2 = std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / g.C1));
-    if (const char *e = getenv("KV_SKM_NWG1")) g.nwg1 = std::max<uint32_t>(1u, std::min<uint32_t>(g.nwg1, (uint32_t)atoi(e)));
-    if (const char *e = getenv("KV_SKM_NWG2")) g.nwg2 = std::max<uint32_t>(1u, std::min<uint32_t>(16u, (uint32_t)atoi(e)));
+    if (const char *e = kv_knob("KV_SKM_NWG1")) g.nwg1 = std::max<uint32_t>(1u, std::min<uint32_t>(g.nwg1, (uint32_t)atoi(e)));
+    if (const char *e = kv_knob("KV_SKM_NWG2")) g.nwg2 = std::max<uint32_t>(1u, std::min<uint32_t>(16u, (uint32_t)atoi(e)));
     g.nwg2 = std::min<uint32_t>(g.nwg2, g.nwg1);
     g.np_max = std::max<uint32_t>(reads->tile_max_bases, 64u);
     const uint64_t min_stride = reads->max_len >= (uint32_t)k ? reads->max_len - (uint32_t)k + 1 : 1;
@@ -2820,11 +2799,11 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     g.cap2 = (uint32_t)kv_round_up((uint64_t)(m2 * 1.3 + 8.0 * std::sqrt(m2)) + 32, 16);
     // loose records: segment overflow (whole records) and occurrences that missed a full LDS table (one k-mer each)
     g.loose_cap = (uint64_t)(rec_est / 8.0) + n_kmers / 16 + (1u << 20);
-    if (const char *pct = getenv("KV_SKM_CAP_PCT")) {       // tests: undersized segments push records through the loose list
+    if (const char *pct = kv_knob("KV_SKM_CAP_PCT")) {       // tests: undersized segments push records through the loose list
         g.cap1 = std::max<uint32_t>(16u, (uint32_t)((uint64_t)g.cap1 * (uint64_t)atoi(pct) / 100));
         g.cap2 = std::max<uint32_t>(16u, (uint32_t)((uint64_t)g.cap2 * (uint64_t)atoi(pct) / 100));
     }
-    if (const char *lc = getenv("KV_SKM_LOOSE_CAP")) g.loose_cap = strtoull(lc, nullptr, 10);
+    if (const char *lc = kv_knob("KV_SKM_LOOSE_CAP")) g.loose_cap = strtoull(lc, nullptr, 10);
     const size_t rb = (size_t)g.recw * 8;
     const size_t b_seg1 = kv_round_up((uint64_t)g.C1 * g.nwg1 * g.cap1 * rb, 256), b_cnt1 = kv_round_up((uint64_t)g.C1 * g.nwg1 * 4, 256);
     const size_t b_seg2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * g.cap2 * rb, 256), b_cnt2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * 4, 256);
@@ -2833,8 +2812,8 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     unsigned char *base = (unsigned char *)idx.arena.p;
     g.seg1 = (uint64_t *)base; base += b_seg1;
     g.cnt1 = (uint32_t *)base; base += b_cnt1;
-    { const char *e = getenv("KV_SKM_SEG1"); g.seg1_wmajor = (e && !strcmp(e, "bucket")) ? 0u : 1u; }
-    { const char *e = getenv("KV_SKM_ORIENT"); g.oriented = (e && atoi(e) == 0) ? 0u : 1u; }
+    { const char *e = kv_knob("KV_SKM_SEG1"); g.seg1_wmajor = (e && !strcmp(e, "bucket")) ? 0u : 1u; }
+    { const char *e = kv_knob("KV_SKM_ORIENT"); g.oriented = (e && atoi(e) == 0) ? 0u : 1u; }
     g.seg2 = (uint64_t *)base; base += b_seg2;
     g.cnt2 = (uint32_t *)base; base += b_cnt2;
     g.loose = (uint64_t *)base; base += b_loose;
@@ -2864,7 +2843,7 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
 // can (and should) the super-k-mer front end take this batch?  -1 no; 0 yes if the sketch agrees; 1 yes, asked for by name
 static int skm_fits(int hashfam, int ksize, const kv_reads *reads, uint64_t n_kmers, bool for_scan)
 {
-    const char *force = getenv(for_scan ? "KV_NOVEL_PATH" : "KV_COUNT_PATH");
+    const char *force = kv_knob(for_scan ? "KV_NOVEL_PATH" : "KV_COUNT_PATH");
     if (force && strcmp(force, "skm") != 0) return -1;        // another path was asked for by name
     if (hashfam != HF_MURMUR || ksize < SKM_MIN_K || ksize > SKM_MAX_K) return -1;
     if (reads->n_tiles == 0 || n_kmers == 0) return -1;
@@ -2908,7 +2887,7 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     // abundance list of this batch (KvAbundList): the first super-k-mer count after a clear writes one, unless KV_SKM_ABL=0
     bool abl_new = false;
     {
-        const char *e = getenv("KV_SKM_ABL");
+        const char *e = kv_knob("KV_SKM_ABL");
         KvAbundList &al = s->abl;
         if (!(e && atoi(e) == 0) && !al.valid && !s->scan_hint) {            // (a case sample's list would never be asked for: it is scanned, not scanned against)
             const uint64_t cap_total = std::min<uint64_t>(std::max<uint64_t>(n_kmers / 8, 1u << 16), 0xfffffff0ull);
@@ -2943,13 +2922,13 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     // tens of milliseconds, more than the list saves once -- a one-shot `kevlar novel` is exactly that case -- while a process
     // that counts and scans sample after sample pays it once (KV_SKM_DL=1: always, =0: never).
     bool dl_new = false;
-    const char *dl_env = getenv("KV_SKM_DL");
+    const char *dl_env = kv_knob("KV_SKM_DL");
     if (s->scan_hint && !(dl_env && atoi(dl_env) == 0)) {
         const double frac = std::min(1.0, std::max(0.3, s->skm_distinct * 1.15));
         const uint64_t cap_wg = std::min<uint64_t>((uint64_t)((double)n_kmers * frac * 1.6 / nwg3) + 4096, 0xfffffff0ull / nwg3);
         const size_t b_keys = kv_round_up(cap_wg * nwg3 * 8 * sg.kw, 256), b_hash = kv_round_up(cap_wg * nwg3 * 8, 256);
         const size_t b_idx = kv_round_up((uint64_t)sg.n_buckets * 4, 256);
-        const bool worth = (dl_env && atoi(dl_env) == 1) || idx.builds > 1 || idx.dl.bytes >= b_keys + b_hash + 2 * b_idx;
+        const bool worth = (dl_env && atoi(dl_env) == 1) || s->scan_steady || idx.builds > 1 || idx.dl.bytes >= b_keys + b_hash + 2 * b_idx;
         if (worth && idx.dl.need(b_keys + b_hash + 2 * b_idx) == hipSuccess) {
             unsigned char *base = (unsigned char *)idx.dl.p;
             idx.dl_keys = (uint64_t *)base; base += b_keys;
@@ -2970,26 +2949,26 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
         const size_t lds = (256 + ((ns + 3u) & ~3u) + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw)) * 4;
         void (*kernel)(SkmGeom, const SketchDev *, const SketchDev *, ConsumeFilter, BinGeom) =
             sg.kw == 1 ? (sg.dbg ? k_skm_count<1, 4096, true, 0> : k_skm_count<1, 4096, false, 0>) : (sg.dbg ? k_skm_count<2, 2048, true, 0> : k_skm_count<2, 2048, false, 0>);
-        if (sg.k == 31 && sg.recw == 3 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31>;
+        if (sg.k == 31 && sg.recw == 3 && !sg.dbg && !kv_knob("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31>;
         if (sg.compact) {       // 16-byte records (sg.recw == 2): their own instances
             kernel = sg.dbg ? k_skm_count<1, 4096, true, 0, true> : k_skm_count<1, 4096, false, 0, true>;
-            if (sg.k == 31 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31, true>;
+            if (sg.k == 31 && !sg.dbg && !kv_knob("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31, true>;
         }
         // (BASELINE.json configs[4]: k = 51 -- two-word keys, 128-bit reverse complement, three murmur blocks + a 3-byte tail)
-        if (sg.k == 51 && sg.recw == 4 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<2, 2048, false, 51>;
+        if (sg.k == 51 && sg.recw == 4 && !sg.dbg && !kv_knob("KV_SKM_ANY_K")) kernel = k_skm_count<2, 2048, false, 51>;
         if (sg.oriented) {      // oriented records: the same instances with the walk that takes k-mers as they stand
             kernel = sg.kw == 1 ? (sg.dbg ? k_skm_count<1, 4096, true, 0, false, true> : k_skm_count<1, 4096, false, 0, false, true>)
                                 : (sg.dbg ? k_skm_count<2, 2048, true, 0, false, true> : k_skm_count<2, 2048, false, 0, false, true>);
-            if (sg.k == 31 && sg.recw == 3 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31, false, true>;
+            if (sg.k == 31 && sg.recw == 3 && !sg.dbg && !kv_knob("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31, false, true>;
             if (sg.compact) {
                 kernel = sg.dbg ? k_skm_count<1, 4096, true, 0, true, true> : k_skm_count<1, 4096, false, 0, true, true>;
-                if (sg.k == 31 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31, true, true>;
+                if (sg.k == 31 && !sg.dbg && !kv_knob("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31, true, true>;
             }
-            if (sg.k == 51 && sg.recw == 4 && !sg.dbg && !getenv("KV_SKM_ANY_K")) kernel = k_skm_count<2, 2048, false, 51, false, true>;
+            if (sg.k == 51 && sg.recw == 4 && !sg.dbg && !kv_knob("KV_SKM_ANY_K")) kernel = k_skm_count<2, 2048, false, 51, false, true>;
             // k = 31: identical records are combined before their k-mers are (skm_rec_combine; skm_build sized the buckets for it)
             if (sg.dd_maxn && sg.k == 31 && (sg.compact || sg.recw == 3) && !sg.dbg) {
                 kernel = sg.compact ? k_skm_count<1, 3072, false, 31, true, true, 512> : k_skm_count<1, 3072, false, 31, false, true, 512>;
-                if (getenv("KV_SKM_DEDUP_RS") && atoi(getenv("KV_SKM_DEDUP_RS")) >= 1024)
+                if (kv_knob("KV_SKM_DEDUP_RS") && atoi(kv_knob("KV_SKM_DEDUP_RS")) >= 1024)
                     kernel = sg.compact ? k_skm_count<1, 4096, false, 31, true, true, 1024> : k_skm_count<1, 4096, false, 31, false, true, 1024>;
             }
         }
@@ -3016,14 +2995,14 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
         unsigned long long sc[13] = {0};
         const bool got = hipMemcpy(sc, sg.ctr, sizeof(sc), hipMemcpyDeviceToHost) == hipSuccess;
         idx.dl_valid = dl_new && got && rc == KV_OK && sc[9] == 0;
-        if (dl_new && getenv("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] distinct list: %s (%llu workgroups ran out of %u entries)\n", idx.dl_valid ? "kept" : "dropped", sc[9], idx.dl_cap_wg);
+        if (dl_new && kv_knob("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] distinct list: %s (%llu workgroups ran out of %u entries)\n", idx.dl_valid ? "kept" : "dropped", sc[9], idx.dl_cap_wg);
         if (got && n_kmers) {
             const double alone = (double)(sc[0] > sc[6] ? sc[0] - sc[6] : 0) / (double)n_kmers;
             const double distinct = (double)sc[7] / (double)n_kmers + alone;
             s->skm_off = rc != KV_OK || alone > 0.03 || distinct > 0.45;
             s->skm_distinct = distinct;
             { std::lock_guard<std::mutex> glk(g_skm_mu); g_skm_last_distinct = distinct; }
-            if (getenv("KV_SKM_VERBOSE"))
+            if (kv_knob("KV_SKM_VERBOSE"))
                 fprintf(stderr, "[kv_skm] batch of %llu k-mers: %.1f%% distinct, %.2f%% outside the LDS tables, %llu of %llu records (%d bytes each) outside their segments, %llu of %u buckets walked record by record%s\n",
                         (unsigned long long)n_kmers, 100 * distinct, 100 * alone, sc[6], sc[5], 8 * sg.recw, sg.dd_maxn ? sc[12] : (unsigned long long)sg.n_buckets, sg.n_buckets,
                         s->skm_off ? " -> next batches take the plain partition" : "");
@@ -3032,7 +3011,7 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     if (rc != KV_OK) {
         idx.valid = false;
         idx.mex_scan_ready = false;
-        if (getenv("KV_SKM_VERBOSE")) {
+        if (kv_knob("KV_SKM_VERBOSE")) {
             unsigned long long sc[8] = {0}, bc[4] = {0};
             (void)hipMemcpy(sc, sg.ctr, sizeof(sc), hipMemcpyDeviceToHost);
             (void)hipMemcpy(bc, plan.g.ctr, sizeof(bc), hipMemcpyDeviceToHost);
@@ -3059,7 +3038,7 @@ void kv_tile_hits_launch(const kv_reads *reads, const NovelParams &p, hipStream_
 
 bool kv_skm_list_ready(const kv_reads *reads, int ksize)
 {
-    if (getenv("KV_SKM_NO_REUSE") || (getenv("KV_SKM_DL") && atoi(getenv("KV_SKM_DL")) == 0)) return false;
+    if (kv_knob("KV_SKM_NO_REUSE") || (kv_knob("KV_SKM_DL") && atoi(kv_knob("KV_SKM_DL")) == 0)) return false;
     std::lock_guard<std::mutex> lk(g_skm_mu);
     for (auto &kv : g_skm)
         if (kv.second.valid && kv.second.dl_valid && kv.second.reads_uid == reads->uid && kv.second.k == ksize) return true;
@@ -3079,7 +3058,7 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
         if (!idx) idx = &g_skm[kv_stream_key(st)];
     }
     std::lock_guard<std::mutex> lk(idx->mu);
-    const bool reuse = idx->valid && idx->reads_uid == reads->uid && idx->k == k && !idx->g.compact && !getenv("KV_SKM_NO_REUSE");
+    const bool reuse = idx->valid && idx->reads_uid == reads->uid && idx->k == k && !idx->g.compact && !kv_knob("KV_SKM_NO_REUSE");
     if (!reuse) {
         double hint;
         { std::lock_guard<std::mutex> glk(g_skm_mu); hint = g_skm_last_distinct; }
@@ -3088,7 +3067,7 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
     }
     SkmGeom &sg = idx->g;
     // the count pass of this very batch left key + hash of every distinct k-mer (kv_sketch_scan_hint): scan from that list
-    const bool from_list = reuse && idx->dl_valid && !p.set_keys && !(getenv("KV_SKM_DL") && atoi(getenv("KV_SKM_DL")) == 0);
+    const bool from_list = reuse && idx->dl_valid && !p.set_keys && !(kv_knob("KV_SKM_DL") && atoi(kv_knob("KV_SKM_DL")) == 0);
     if (reuse) {
         // records that did not fit their S1/S2 segment are the first ctr[6] entries of the loose list; the entries the
         // count pass added behind them (single occurrences that missed its LDS tables) are re-created by the scan's
@@ -3102,7 +3081,7 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
     SkmAblSet abls;
     memset(&abls, 0, sizeof(abls));
     abls.ctrl_max = p.ctrl_max;
-    if (p.host_ctrls && !p.set_keys && !(getenv("KV_SKM_ABL") && atoi(getenv("KV_SKM_ABL")) == 0)) {
+    if (p.host_ctrls && !p.set_keys && !(kv_knob("KV_SKM_ABL") && atoi(kv_knob("KV_SKM_ABL")) == 0)) {
         const kv_sketch *const *ctrls = (const kv_sketch *const *)p.host_ctrls;
         for (int c = 0; c < p.host_nctrl && abls.n < SKM_MAX_ABL; ++c) {
             const KvAbundList &al = ctrls[c]->abl;
@@ -3112,13 +3091,13 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
             abls.maxv[a] = ctrls[c]->h.storage == ST_BYTE ? 255u : (ctrls[c]->h.storage == ST_NIBBLE ? 15u : 1u);
         }
     }
-    if (getenv("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] scan: %d of %d controls bring an abundance list in this bucket geometry\n", abls.n, p.host_nctrl);
-    if (getenv("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] scan: %s\n", from_list ? "from the count pass's distinct list" : "by walking the buckets");
-    if (const char *e = getenv("KV_SKM_SCAN_DEBUG")) sg.dbg = (uint32_t)atoi(e);       // scratch/scan_phases.py
+    if (kv_knob("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] scan: %d of %d controls bring an abundance list in this bucket geometry\n", abls.n, p.host_nctrl);
+    if (kv_knob("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] scan: %s\n", from_list ? "from the count pass's distinct list" : "by walking the buckets");
+    if (const char *e = kv_knob("KV_SKM_SCAN_DEBUG")) sg.dbg = (uint32_t)atoi(e);       // scratch/scan_phases.py
     NovelParams pl = p;
     pl.case0_bits = nullptr;
     // (KV_NOVEL_BITS=0: probe the table.  Measured at config 2: the bit map costs 0.135 ms, the list scan goes from 2.57-2.77 to 2.34 ms)
-    if (from_list && p.host_case0 && !(getenv("KV_NOVEL_BITS") && atoi(getenv("KV_NOVEL_BITS")) == 0)) {
+    if (from_list && p.host_case0 && !(kv_knob("KV_NOVEL_BITS") && atoi(kv_knob("KV_NOVEL_BITS")) == 0)) {
         const kv_sketch *c0 = (const kv_sketch *)p.host_case0;
         if (c0->h.storage == ST_BYTE && !c0->lazy_zero && idx->bits.need(kv_round_up(((c0->h.size[0] + 31) >> 5) * 4, 256)) == hipSuccess) {
             KvProfScope prof("k_case_bits");
@@ -3204,7 +3183,7 @@ int kv_skm_route_distinct(const kv_reads *reads, int ksize, uint64_t n_kmers, in
     // the next shard routed on this stream (same sample or a sibling: same coverage) gets buckets sized for what this one held
     const double alone = (double)(sctr[0] > sctr[6] ? sctr[0] - sctr[6] : 0) / (double)n_kmers;
     idx.distinct_hint = std::min(1.0, (double)sctr[7] / (double)n_kmers + alone);
-    if (getenv("KV_SKM_VERBOSE"))
+    if (kv_knob("KV_SKM_VERBOSE"))
         fprintf(stderr, "[kv_skm] routed %llu k-mers: %.1f%% distinct, %.2f%% outside the LDS tables, %u buckets\n",
                 (unsigned long long)n_kmers, 100 * idx.distinct_hint, 100 * alone, sg.n_buckets);
     if (sctr[1] != 0) {
@@ -3247,7 +3226,7 @@ int kv_skm_mex_plan(int ksize, uint64_t n_reads_global, uint32_t read_len, int n
     // sample, and with the 768 writers of a whole sample its ~190 000 segments held ~40 records each at N = 8 -- the cut, the packing
     // and the owner's split all pay per segment (per rank of config 2, N = 8 / N = 2: 8.58 / 25.07 ms with 768 writers of 512 threads,
     // 7.73 / 23.10 with 256 of 1024).  KV_MEX_NWG1 (the same on every rank) overrides.
-    const uint64_t nwg1_max = getenv("KV_MEX_NWG1") ? (uint64_t)std::max(1, std::min(768, atoi(getenv("KV_MEX_NWG1")))) : 256;
+    const uint64_t nwg1_max = kv_knob("KV_MEX_NWG1") ? (uint64_t)std::max(1, std::min(768, atoi(kv_knob("KV_MEX_NWG1")))) : 256;
     const uint32_t nwg1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((tiles + SKM_TILES_PER_TICKET - 1) / SKM_TILES_PER_TICKET, nwg1_max));
     const double rec_est = (double)(shard_reads * nk_read) * 2.2 / (double)(g.w + 1) + (double)shard_reads + 1024.0;
     const double m1 = rec_est / ((double)C1 * nwg1);
@@ -3269,7 +3248,7 @@ int kv_skm_mex_plan_short(kv_mex_plan *plan)
     // (the owner's S2 takes 16-byte records in either form: the sorted split up to 1024 fine buckets, the plain one up to 4096 -- the 12
     // bits the record has for its fine bucket)
     KV_REQUIRE(g.kw == 1 && g.w == SKM_LANE_B && skm_lane_fits_len(g, plan->read_len) &&
-               plan->F2 <= 4096u && !(getenv("KV_SKM_COMPACT") && atoi(getenv("KV_SKM_COMPACT")) == 0),
+               plan->F2 <= 4096u && !(kv_knob("KV_SKM_COMPACT") && atoi(kv_knob("KV_SKM_COMPACT")) == 0),
                KV_ERR_NOTIMPL, "kv_mex_plan_short: no 16-byte records for k = %d, reads of %u bases, %u fine buckets", plan->ksize, plan->read_len, plan->F2);
     if (plan->flags & 1u) return KV_OK;
     plan->flags |= 1u;
@@ -3308,7 +3287,7 @@ int kv_skm_mex_emit(const kv_reads *reads, const kv_mex_plan *plan, uint64_t rea
     g.read_base = read_base;
     // (the exchange's records are oriented like a single GPU's: every rank cuts with the same rule, so the owner of a bucket finds a
     // k-mer under one key whichever shard it came from; KV_SKM_ORIENT=0 on every rank keeps the classic form)
-    { const char *e = getenv("KV_SKM_ORIENT"); g.oriented = (e && atoi(e) == 0) ? 0u : 1u; }
+    { const char *e = kv_knob("KV_SKM_ORIENT"); g.oriented = (e && atoi(e) == 0) ? 0u : 1u; }
     g.seg1 = d_seg; g.cnt1 = d_cnt;
     g.loose_cap = 1u << 16;
     const size_t b_loose = kv_round_up(g.loose_cap * (size_t)g.lrecw * 8, 256), b_ctr = 256;
@@ -3376,7 +3355,7 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     const uint32_t Cl = plan->c_lo[my_dest + 1] - plan->c_lo[my_dest];
     g.C1 = Cl; g.F2 = plan->F2; g.fbits = plan->fbits; g.n_buckets = Cl * g.F2;
     g.nwg1 = plan->nwg1; g.cap1 = plan->cap1; g.n_src = (uint32_t)n_src;
-    { const char *e = getenv("KV_SKM_ORIENT"); g.oriented = (e && atoi(e) == 0) ? 0u : 1u; }       // as kv_skm_mex_emit cut them
+    { const char *e = kv_knob("KV_SKM_ORIENT"); g.oriented = (e && atoi(e) == 0) ? 0u : 1u; }       // as kv_skm_mex_emit cut them
     g.seg1 = const_cast<uint64_t *>(d_recv_seg); g.cnt1 = const_cast<uint32_t *>(d_recv_cnt);
     g.stride = plan->read_len - (uint32_t)plan->ksize + 1u;
     if (Cl == 0) { *n_kmers_in = 0; KvRouteSink rs; memset(&rs, 0, sizeof(rs)); return alloc(ctx, 1, &rs); }
@@ -3391,7 +3370,7 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     // (a geometry at its limit -- 4096 fine buckets per coarse one: a handful of distinct 12-base minimizers per bucket -- has buckets of
     // very different sizes: at 248 x 4096 buckets a tenth of the records missed segments of 2 x the even share; KV_MEX_CAP2_SLACK overrides)
     double slack2 = plan->F2 > SKM_S2_MAXF ? 3.0 : 1.4;
-    if (const char *e = getenv("KV_MEX_CAP2_SLACK")) slack2 = std::max(1.1, atof(e));
+    if (const char *e = kv_knob("KV_MEX_CAP2_SLACK")) slack2 = std::max(1.1, atof(e));
     g.cap2 = (uint32_t)kv_round_up((uint64_t)(m2 * slack2 + 8.0 * std::sqrt(m2)) + 32, 16);
     g.loose_cap = (uint64_t)(rec_est / 8.0) + n_kmers_exp / 16 + (1u << 20);
     const size_t rb = (size_t)g.recw * 8;
@@ -3414,7 +3393,7 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
         const double distinct = (double)g.bucket_kmers * 0.2, room = 0.5 * (g.kw == 1 ? 4096.0 : 2048.0);
         g.passes = 1;
         while (g.passes < 16u && distinct > room * g.passes) g.passes *= 2u;
-        if (const char *e = getenv("KV_MEX_PASSES")) { const int v = atoi(e); if (v >= 1 && v <= 16 && (v & (v - 1)) == 0) g.passes = (uint32_t)v; }
+        if (const char *e = kv_knob("KV_MEX_PASSES")) { const int v = atoi(e); if (v >= 1 && v <= 16 && (v & (v - 1)) == 0) g.passes = (uint32_t)v; }
     }
     if (compact) {
         // the sources sent only the filled part of their segments, in segment order: a segment starts where the counts in
@@ -3489,7 +3468,7 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     *n_kmers_in = arrived;
     idx.mex_scan_ready = dl_new && sctr[9] == 0 && sctr[1] == 0;
     idx.k = plan->ksize;
-    if (getenv("KV_SKM_VERBOSE"))
+    if (kv_knob("KV_SKM_VERBOSE"))
         fprintf(stderr, "[kv_skm] exchange owner: %llu k-mers arrived in %u buckets (%u passes, segments of %u records), %.1f%% distinct, %.2f%% outside the LDS tables, "
                         "%llu records outside their bucket's segments\n",
                 arrived, g.n_buckets, g.passes, g.cap2, arrived ? 100.0 * (double)sctr[7] / (double)arrived : 0.0,

@@ -546,6 +546,7 @@ class _Sketch(object):
 
     def __init__(self, k, starting_size, n_tables, primes=None, _handle=None):
         self._lock = threading.Lock()
+        self._consume_lock = threading.Lock()   # unique-new + consume as one step while the exact figure is tracked
         self._exact = None      # when tracking the exact distinct-k-mer figure: the k-mers counted as new so far (kv_unique_new), else None
         if _handle is not None:
             self._h = _handle
@@ -579,11 +580,12 @@ class _Sketch(object):
     def save(self, path):
         check(_lib.load().kv_sketch_save(self._h, path.encode()))
 
-    def expect_scan(self, on=True):
+    def expect_scan(self, on=True, steady=False):
         """This sketch holds a case sample: every batch counted into it is scanned next (kevlar/novel.py:92-121 loads the cases
-        last and scans them).  The count then keeps the batch's distinct k-mers with their hashes for that scan.  A
-        performance hint only (kv_sketch_scan_hint)."""
-        check(_lib.load().kv_sketch_scan_hint(self._h, 1 if on else 0))
+        last and scans them).  The count then keeps the batch's distinct k-mers with their hashes for that scan.  steady: the
+        process counts and scans sample after sample, so the list is worth its allocation from the first batch on (a one-shot
+        `kevlar novel` skips it there).  A performance hint only (kv_sketch_scan_hint)."""
+        check(_lib.load().kv_sketch_scan_hint(self._h, (2 if steady else 1) if on else 0))
         return self
 
     def clear(self):
@@ -623,8 +625,14 @@ class _Sketch(object):
         """From now on every consume_batch() first asks the library how many of the batch's k-mers are new to the tables as they
         stand (kv_unique_new: khmer's single-thread rule, batch by batch), and n_unique_kmers() reports the sum: the reference's
         "distinct k-mers stored" for one thread (kevlar/count.py:82-84), for a sample of any size -- nothing is kept resident
-        (budget_bytes: ignored, the retention limit of earlier rounds is gone)."""
-        self._exact = 0 if on else None
+        (budget_bytes: ignored, the retention limit of earlier rounds is gone).  The figure is the single-thread one, so
+        consume_batch() calls on a tracking sketch run one at a time (they take the sketch's consume lock); switching the
+        tracking off gives the library's first-toucher arrays (4.5 x the sketch) back."""
+        with self._lock:
+            was = self._exact is not None
+            self._exact = 0 if on else None
+        if was and not on:
+            check(_lib.load().kv_unique_release())
 
     def table_bytes(self, i):
         """Raw on-disk form of table i (tests compare this against the oracle)."""
@@ -717,23 +725,29 @@ class _Sketch(object):
     # ---- consume --------------------------------------------------------------------------
     def consume_batch(self, batch, nbands=0, band=0, mask=None, threshold=0, consume_masked=False):
         lib = _lib.load()
-        if self._exact is not None:
-            # (before the batch is counted: "new" is judged against the tables the batch is about to change)
-            fresh = ctypes.c_uint64()
-            try:
-                check(lib.kv_unique_new(self._h, batch._h, nbands or 0, band or 0, mask._h if mask is not None else None, int(threshold),
-                                        1 if consume_masked else 0, ctypes.byref(fresh)))
-            except (_lib.KvError, _lib.KvCapacityError):
-                # no room for the first-toucher arrays (4 bytes per bin) or a batch beyond 4.29e9 k-mers: the count goes on and
-                # n_unique_kmers() reports the estimate of kv_consume
-                self._exact = None
-            with self._lock:
-                if self._exact is not None:
-                    self._exact += fresh.value
+        args = (nbands or 0, band or 0, mask._h if mask is not None else None, int(threshold), 1 if consume_masked else 0)
         n = ctypes.c_uint64()
-        check(lib.kv_consume(self._h, batch._h, nbands or 0, band or 0,
-                             mask._h if mask is not None else None, int(threshold),
-                             1 if consume_masked else 0, ctypes.byref(n)))
+        if self._exact is None:
+            check(lib.kv_consume(self._h, batch._h, *args, ctypes.byref(n)))
+            return n.value
+        # "new" is judged against the tables the batch is about to change, so the question and the count are one step: another
+        # thread's batch between the two would be counted twice where the batches share k-mers
+        with self._consume_lock:
+            fresh = None
+            if self._exact is not None:
+                fresh = ctypes.c_uint64()
+                try:
+                    check(lib.kv_unique_new(self._h, batch._h, *args, ctypes.byref(fresh)))
+                except (_lib.KvError, _lib.KvCapacityError):
+                    # no room for the first-toucher arrays (4 bytes per bin) or a batch beyond 4.29e9 k-mers: the count goes on and
+                    # n_unique_kmers() reports the estimate of kv_consume
+                    fresh = None
+            with self._lock:
+                if fresh is None:
+                    self._exact = None
+                elif self._exact is not None:
+                    self._exact += fresh.value
+            check(lib.kv_consume(self._h, batch._h, *args, ctypes.byref(n)))
         return n.value
 
     def retains(self, batch):

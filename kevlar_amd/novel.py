@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 import kevlar_amd
-from kevlar_amd import khmer
+from kevlar_amd import _lib, khmer
 from kevlar_amd._lib import KV_BAND_NONE, KV_BAND_RANGE, KV_BAND_REFQUIRK
 
 SCAN_BATCH_READS = 1 << 23
@@ -54,7 +54,7 @@ def _side_by_side(filelists=None):
     KV_PARALLEL_SAMPLES=1 / 0 says; otherwise side by side while the input is small enough (under 3 GB of files: reading
     one file then overlaps inflating and counting another), one after the other beyond (the first allocation of three
     sets of multi-gigabyte scratch buffers costs a cold one-shot run more than the overlap gains)."""
-    env = os.environ.get('KV_PARALLEL_SAMPLES')
+    env = _lib.knob('KV_PARALLEL_SAMPLES')
     if env is not None and env != '':
         return env not in ('0', 'no', 'false')
     if not filelists:
@@ -297,7 +297,7 @@ def main(args):
     for key in (None, 'loadall', 'loadctrl'):
         clock.start(key)
     # a case sample that was counted as one batch is scanned from that batch (no second pass over its file)
-    kept = {} if not os.environ.get('KV_NOVEL_REREAD') else None
+    kept = {} if not _lib.knob('KV_NOVEL_REREAD') else None
     if not _side_by_side((args.control or []) + (args.case or [])) or args.control_counts or args.case_counts:
         kevlar_amd.plog('[kevlar::novel] Loading control samples')
         controls = load_samples(args.control_counts, args.control, args.ksize, args.memory, args.max_fpr, args.num_bands, band,

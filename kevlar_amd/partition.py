@@ -147,7 +147,7 @@ def _argsort(keys):
     import numpy as np
     from kevlar_amd import _lib
     n = len(keys)
-    if n < _DEVICE_SORT_MIN or n >= (1 << 32) or os.environ.get('KV_HOST_SORT') or not _lib.device_visible():
+    if n < _DEVICE_SORT_MIN or n >= (1 << 32) or not _lib.device_visible() or _lib.knob('KV_HOST_SORT'):
         return np.argsort(keys, kind='stable')
     _lib.require_device()
     lib = _lib.load()

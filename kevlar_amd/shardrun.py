@@ -29,7 +29,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from kevlar_amd import khmer as hk
+from kevlar_amd import _lib, khmer as hk
 
 
 # payload bytes this rank has handed to collectives for OTHER ranks (what crosses xGMI from here): bench.py reads and resets it
@@ -58,12 +58,33 @@ def _local_failures():
     return (KvCapacityError, KvError, MemoryError, torch.cuda.OutOfMemoryError, ValueError, OSError)
 
 
+_SAID = set()
+
+
+def _note_failure(run, where, exc):
+    """A rank's own part of an exchange failed and the ranks are about to agree on a fallback: keep the exception on the handle
+    (run.last_failure), count it by reason (run.fallback_reasons: tests and bench.py assert on them; run.unexpected_failures counts
+    the argument errors -- a mis-wired caller, which would otherwise only show as slower numbers) and say so on stderr once per
+    process and reason, whatever the verbosity."""
+    import sys
+    from kevlar_amd._lib import KvArgError
+    reason = '{}: {}'.format(where, type(exc).__name__)
+    run.last_failure = exc
+    run.fallback_reasons[reason] = run.fallback_reasons.get(reason, 0) + 1
+    if isinstance(exc, KvArgError):
+        run.unexpected_failures += 1
+    if reason not in _SAID or _lib.knob('KV_MEX_VERBOSE'):
+        _SAID.add(reason)
+        print('[kevlar_amd.shardrun] rank {} declines ({}{}): {}'.format(run.rank, reason, ', UNEXPECTED -- a caller\'s mistake' if isinstance(exc, KvArgError) else '', exc),
+              file=sys.stderr, flush=True)
+
+
 def _test_failure(point, rank):
     """tests: KV_MEX_TEST_DECLINE='<point>:<rank>' makes that rank fail at that point the way the real thing would -- 'emit-oom'
     (no memory for the packed records), 'route-hip' (the library reports a HIP error while combining), 'scan-fail' (the owner's
     scan of its distinct case k-mers fails), 'owner-hip' (the bucket owner's look-up fails); 'emit' / 'route' are the plain
     capacity declines handled where they occur"""
-    if os.environ.get('KV_MEX_TEST_DECLINE', '') != '{}:{}'.format(point, rank):
+    if _lib.knob('KV_MEX_TEST_DECLINE', '') != '{}:{}'.format(point, rank):
         return
     if point == 'emit-oom':
         raise MemoryError('forced by KV_MEX_TEST_DECLINE')
@@ -89,8 +110,10 @@ class _Exchange(object):
         return self.recv
 
 
-def exchange_rows_async(send, counts, group=None, staged=False):
+def exchange_rows_async(send, counts, group=None, staged=False, form=0):
     """All-to-all of variable-length row blocks.
+    form: a small number every rank must bring alike (which wire format its rows are in); it travels beside the counts, and ranks
+    that disagree raise PeerDeclined together, before anything is sent.
 
     send: tensor [rows, ...] holding the block for rank 0, then rank 1, ... back to back (counts[d] rows for
     rank d), exactly as kv_route_hashes leaves them.  The received blocks (from rank 0, 1, ...) come from the
@@ -99,12 +122,15 @@ def exchange_rows_async(send, counts, group=None, staged=False):
     world = dist.get_world_size(group)
     assert counts is None or len(counts) == world
     coll_dev = torch.device('cpu') if staged else send.device
-    mine = torch.tensor([-1] * world if counts is None else counts, dtype=torch.int64, device=coll_dev)     # None: this rank declines
-    table = torch.empty(world * world, dtype=torch.int64, device=coll_dev)
+    mine = torch.tensor(([-1] * world if counts is None else list(counts)) + [int(form)], dtype=torch.int64, device=coll_dev)     # None: this rank declines
+    table = torch.empty(world * (world + 1), dtype=torch.int64, device=coll_dev)
     dist.all_gather_into_tensor(table, mine, group=group)
-    table = table.view(world, world).cpu()
+    table = table.view(world, world + 1).cpu()
+    forms, table = table[:, world], table[:, :world]
     if bool((table < 0).any()):
         raise PeerDeclined('ranks {} declined'.format([r for r in range(world) if bool((table[r] < 0).any())]))
+    if bool((forms != forms[0]).any()):
+        raise PeerDeclined('the ranks bring different wire formats: {}'.format([int(f) for f in forms]))
     rank = dist.get_rank(group)
     recv_counts = [int(table[src, rank]) for src in range(world)]
     packed = send[:sum(counts)]
@@ -211,6 +237,15 @@ class ShardedTrio(object):
         self.case_items = None   # (hash, tag) or (hash, occurrences) pairs of the case k-mers this rank owns
         self.case_items_weighted = False
         self.timing = {'route': 0.0, 'exchange': 0.0, 'count': 0.0, 'scan': 0.0, 'gather': 0.0}
+        self.fallbacks, self.scan_fallbacks = 0, 0      # agreed fallbacks this rank took part in (its own failure or a peer's)
+        self.fallback_reasons = {}                      # this rank's OWN failures behind them: 'where: ExceptionType' -> count (_note_failure)
+        self.unexpected_failures = 0                    # ... of which argument errors (a caller's mistake, not skew or memory)
+        self.last_failure = None
+        # north_star's merge: (int32 words on the device, bits per read) or None.  When set, every scan_*() also builds this rank's
+        # bit mask of the interesting k-mer occurrences IT found -- the owners' findings are disjoint (a band, a set of minimizer
+        # buckets, a shard of the reads) -- and all-reduces it (SUM of disjoint 0/1 bits = their OR: docs/banding.rst,
+        # kevlar/unband.py:41-77); the caller holds the result against the gathered hits (bandmerge.mask_to_hits).
+        self.band_mask = None
 
     def _send_buffer(self, cap, words):
         """A send buffer nobody is using: an exchange in flight keeps its own until finish()."""
@@ -242,7 +277,7 @@ class ShardedTrio(object):
         plan has such records (16 bytes instead of 24: hk.mex_plan); a rank whose shard cannot be cut that way (reads of
         unequal length) declines like one whose segments overflowed, and the sample travels as pairs."""
         t0 = time.perf_counter()
-        forced = os.environ.get('KV_MEX_TEST_DECLINE', '')          # tests: 'emit:RANK' / 'route:RANK' makes that rank decline there
+        forced = _lib.knob('KV_MEX_TEST_DECLINE', '')          # tests: 'emit:RANK' / 'route:RANK' makes that rank decline there
         plan = hk.mex_plan(self.sketch_cls, self.ksize, n_reads_global, read_len, self.world, short=short)
         seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device=self.device)
         cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device=self.device)
@@ -260,8 +295,7 @@ class ShardedTrio(object):
                     per_dest = hk.mex_pack(plan, seg.data_ptr(), cnt.data_ptr(), packed.data_ptr())
             except _local_failures() as e:                  # records outside their exchange segment (minimizer skew), no memory for the packed
                 emitted, packed = False, None               # copy, a HIP error, a shard a short-record plan cannot cut: the peers must hear of it, in the slab below
-                if os.environ.get('KV_MEX_VERBOSE'):
-                    print('rank {} declines the cut: {!r}'.format(self.rank, e), flush=True)
+                _note_failure(self, 'cut', e)
         if not emitted:
             cnt.fill_(-1)                                   # the marker every destination finds in this rank's slab of counts
         t1 = time.perf_counter()
@@ -275,7 +309,7 @@ class ShardedTrio(object):
             # a rank's cut did not fit its exchange segments; every rank has just seen its marker: the sample travels as the
             # (hash, occurrences) pairs of each rank's own deduplicated shard instead (what arrives at the band owners is the same)
             del seg, cnt, got_cnt
-            self.fallbacks = getattr(self, 'fallbacks', 0) + 1
+            self.fallbacks += 1
             self.timing['route'] += time.perf_counter() - t0
             return _Cut(fallback=self.start(batch, read_index_base, False, distinct=True))
         from_src = [int(v) for v in summary[:self.world]]
@@ -293,7 +327,7 @@ class ShardedTrio(object):
         self.owner_can_scan = False
         if cut.fallback is not None:
             return cut.fallback
-        forced = os.environ.get('KV_MEX_TEST_DECLINE', '')
+        forced = _lib.knob('KV_MEX_TEST_DECLINE', '')
         plan, got_cnt = cut.plan, cut.got_cnt
         t1 = time.perf_counter()
         got_seg = cut.records.wait()
@@ -308,36 +342,41 @@ class ShardedTrio(object):
                 send = self._send_buffer(cap, 2)
                 counts, _ = hk.mex_route(plan, self.rank, got_seg.data_ptr(), got_cnt.data_ptr(), self.world, send.data_ptr(), send.shape[0], compact=True,
                                          keep_scan=keep_scan)
-            except _local_failures():                       # more k-mers in this rank's buckets than its pair buffer holds (bucket skew), the
+            except _local_failures() as e:                  # more k-mers in this rank's buckets than its pair buffer holds (bucket skew), the
                 counts = None                               # stream arena or the distinct list out of memory, no room for the pair buffer
+                _note_failure(self, 'combine', e)
         del got_seg, got_cnt
         cut.got_cnt = None
         # KV_MEX_PAIRS=9 (every rank alike): the pairs travel in 9 bytes each -- the hash, the occurrences as a byte saturated at 255 (no
         # counter holds more), the block's exact total in its head word (kv_pairs_pack).  A quarter fewer bytes on the links for a pass
         # over the pairs on either side: 646 instead of 875 MB and 6.56 instead of 5.88 ms per rank of config 2 at N = 8 -- which of the
         # two is cheaper is a property of the links nobody has measured, so 16 bytes stay the default
+        # The form is this rank's word in the size exchange (exchange_rows_async(form=)): ranks that disagree -- the switch set on some
+        # of them -- all learn it there and fall back together, nobody decodes one form as the other.
         travelling, wcounts = None, None
-        if counts is not None and os.environ.get('KV_MEX_PAIRS', '16') == '9':
+        form = 9 if _lib.knob('KV_MEX_PAIRS', '16') == '9' else 16
+        if counts is not None and form == 9:
             try:
                 n_pairs = sum(counts)
                 travelling = torch.empty(n_pairs + n_pairs // 8 + 2 * self.world + 8, dtype=torch.int64, device=self.device)
                 wcounts = hk.pairs_pack(send.data_ptr(), counts, travelling.data_ptr(), travelling.shape[0])
-            except _local_failures():
+            except _local_failures() as e:
                 counts, travelling, wcounts = None, None, None
+                _note_failure(self, 'pairs-pack', e)
         t3 = time.perf_counter()
         try:
             if send is None:                                # (nothing travels from a rank that declines: any tensor carries its "-1")
                 send = torch.empty((1, 2), dtype=torch.int64, device=self.device)
             if travelling is not None:
-                ex = exchange_rows_async(travelling, wcounts, self.group, self.staged)
+                ex = exchange_rows_async(travelling, wcounts, self.group, self.staged, form=form)
                 ex.travelling = travelling                  # (kept until wait())
                 ex.packed_pairs = True
             else:
-                ex = exchange_rows_async(send, counts, self.group, self.staged)      # counts None: this rank declines, inside the size exchange
+                ex = exchange_rows_async(send, counts, self.group, self.staged, form=form)      # counts None: this rank declines, inside the size exchange
         except PeerDeclined:
             if send.shape[0] > 1:
                 self._send[2].append(send)
-            self.fallbacks = getattr(self, 'fallbacks', 0) + 1
+            self.fallbacks += 1
             self.timing['route'] += t3 - t2
             self.timing['exchange'] += (t2 - t1) + (time.perf_counter() - t3)
             return self.start(cut.batch, cut.base, False, distinct=True)
@@ -383,11 +422,23 @@ class ShardedTrio(object):
         occurrences = None
         if getattr(ex, 'packed_pairs', False):
             # 9-byte pairs (combine_minimizer): back into the 16-byte form the kernels read; what they stand for comes from the blocks' heads
+            # (a failure here -- no memory for the unpacked pairs, a HIP error -- comes after the exchange, with the next collective
+            # ahead: the ranks agree right here, in one small all-reduce of this opt-in path, and stop together)
             words = list(ex.recv_counts)
-            pairs = torch.empty((max(1, sum(max(0, (w - 1) * 8 // 9) for w in words)), 2), dtype=torch.int64, device=recv.device)
-            per_src, occurrences = hk.pairs_unpack(recv.data_ptr(), words, pairs.data_ptr(), pairs.shape[0])
-            recv = pairs[:sum(per_src)]
+            failed = None
+            try:
+                _test_failure('unpack-fail', self.rank)
+                pairs = torch.empty((max(1, sum(max(0, (w - 1) * 8 // 9) for w in words)), 2), dtype=torch.int64, device=recv.device)
+                per_src, occurrences = hk.pairs_unpack(recv.data_ptr(), words, pairs.data_ptr(), pairs.shape[0])
+                recv = pairs[:sum(per_src)]
+            except _local_failures() as e:
+                failed = e
+                _note_failure(self, 'pairs-unpack', e)
             ex.travelling = None
+            flag = torch.tensor([1 if failed is not None else 0], dtype=torch.int64, device=torch.device('cpu') if self.staged else self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            if int(flag.item()):
+                self._scan_declined('unpacking the 9-byte pairs', failed, 'a rank could not unpack what it received')
         n = recv.shape[0]
         if sketch is None:
             n = 0
@@ -426,6 +477,43 @@ class ShardedTrio(object):
         except _local_failures() as exc:
             return -1, exc
 
+    def _merge_mask(self, reads_t, offs_t):
+        """this rank's findings -- device tensors of global read index and k-mer offset -- as bits of self.band_mask, then the
+        all-reduce over the ranks (RCCL on the device; gloo through the host)"""
+        if self.band_mask is None:
+            return
+        from kevlar_amd import bandmerge
+        mask, stride = self.band_mask
+        mask.zero_()
+        if reads_t.numel():
+            idx = reads_t.to(torch.int64) * int(stride) + offs_t.to(torch.int64)
+            bit = torch.bitwise_left_shift(torch.ones_like(idx), idx & 31).to(torch.int32)       # (bit 31 wraps to the sign bit: the words are bit patterns)
+            mask.index_add_(0, idx >> 5, bit)                                                    # (an occurrence is found once: distinct bits, the sum is their OR)
+        torch.cuda.synchronize()
+        if self.staged:
+            host = mask.cpu()
+            bandmerge.allreduce_mask(host, self.group)
+            mask.copy_(host)
+        else:
+            bandmerge.allreduce_mask(mask, self.group)
+        torch.cuda.synchronize()
+
+    def _merge_mask_np(self, reads, offs):
+        if self.band_mask is not None:
+            self._merge_mask(torch.from_numpy(np.ascontiguousarray(reads, dtype=np.int64)).to(self.device),
+                             torch.from_numpy(np.ascontiguousarray(offs).astype(np.int64)).to(self.device))
+
+    def _merge_mask_tags(self, tags, n, skip=None):
+        """_merge_mask for findings held as tags (read << 16 | offset), minus the reads in `skip` (numpy, sorted)"""
+        if self.band_mask is None:
+            return
+        t = tags[:max(int(n), 0)]
+        reads_t, offs_t = t >> 16, t & 0xffff
+        if skip is not None and len(skip) and reads_t.numel():
+            keep = ~torch.isin(reads_t, torch.from_numpy(np.asarray(skip, dtype=np.int64)).to(reads_t.device))
+            reads_t, offs_t = reads_t[keep], offs_t[keep]
+        self._merge_mask(reads_t, offs_t)
+
     @staticmethod
     def _scan_declined(what, err, declined):
         if err is not None:
@@ -452,6 +540,7 @@ class ShardedTrio(object):
             self._scan_declined('scan', err, declined)
         all_abund, _ = gather_rows(abund, n_hits, 0, self.group, self.staged)
         torch.cuda.synchronize()
+        self._merge_mask_tags(tags & ((1 << 63) - 1), n_hits)            # (the tag's top bit flags a read the scan skips: kv_hits_from_tagged drops those)
         r, o, a = hk.hits_from_tagged(all_tags.data_ptr(), all_abund.data_ptr(), all_tags.shape[0], total, S)
         self.timing['scan'] += t1 - t0
         self.timing['gather'] += time.perf_counter() - t1
@@ -486,6 +575,7 @@ class ShardedTrio(object):
         r, o, a = hk.novel_scan_set(batch, self.sketch_cls, self.ksize, S, all_hashes.data_ptr(), all_abund.data_ptr(),
                                     all_hashes.shape[0])
         t3 = time.perf_counter()
+        self._merge_mask_np(np.asarray(r).astype(np.int64) + int(read_index_base), o)
         r, o, a = bandmerge.allgather_hits_device(np.asarray(r).astype(np.int64) + int(read_index_base), o, a, self.device,
                                                   self.group, self.staged)
         self.timing['scan'] += (t1 - t0) + (t3 - t2)
@@ -538,8 +628,9 @@ class ShardedTrio(object):
                     if 'exceed the buffer' not in str(exc):
                         break
                     hit_cap *= 16
-                except _local_failures():                   # no memory for the rows, a HIP error: this owner cannot answer; the ranks agree below
+                except _local_failures() as exc:            # no memory for the rows, a HIP error: this owner cannot answer; the ranks agree below
                     n_hits = -1
+                    _note_failure(self, 'owner-scan', exc)
                     break
         t3 = time.perf_counter()
         coll_dev = torch.device('cpu') if self.staged else self.device
@@ -549,10 +640,11 @@ class ShardedTrio(object):
         table = table.view(self.world, 2).cpu()
         if bool((table[:, 0] < 0).any()):
             # an owner cannot answer: every rank looks its own shard up in the set, as scan_distinct() does
-            self.scan_fallbacks = getattr(self, 'scan_fallbacks', 0) + 1
+            self.scan_fallbacks += 1
             from kevlar_amd import bandmerge
             r, o, a = hk.novel_scan_set(batch, self.sketch_cls, self.ksize, S, all_hashes.data_ptr(), all_abund.data_ptr(), all_hashes.shape[0])
             t4 = time.perf_counter()
+            self._merge_mask_np(np.asarray(r).astype(np.int64) + int(read_index_base), o)
             r, o, a = bandmerge.allgather_hits_device(np.asarray(r).astype(np.int64) + int(read_index_base), o, a, self.device, self.group, self.staged)
             self.timing['scan'] += (t1 - t0) + (t4 - t2)
             self.timing['gather'] += (t2 - t1) + (time.perf_counter() - t4)
@@ -566,6 +658,7 @@ class ShardedTrio(object):
             skip = np.unique(skip.cpu().numpy())
             skip = skip[skip >= 0]
         torch.cuda.synchronize()
+        self._merge_mask_tags(tags, n_hits, skip)
         r, o, a = hk.hits_from_tagged(all_tags.data_ptr(), all_rows.data_ptr(), all_tags.shape[0], total, S)
         if skip is not None and len(skip):
             keep = ~np.isin(np.asarray(r), skip)

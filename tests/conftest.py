@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
+# The tests pin kernel paths and shrink geometries through the library's TUNING switches (kevlar_amd/csrc/kv_knobs.h), which it
+# honours only while KV_TUNING=1 is set; tests/test_host_logic.py holds the registry itself (and that without KV_TUNING a set switch
+# is ignored).
+os.environ.setdefault('KV_TUNING', '1')
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')

@@ -64,4 +64,5 @@ def test_exchange_layout_with_its_samples_interleaved_equals_the_banded_replay(r
     assert out['selfcheck']['replay_matches']
     assert 'exchanged by band' in out['config']['parallelism']
     assert out['selfcheck']['exchange']['layout_fallbacks'] == 0 and out['selfcheck']['exchange']['scan_fallbacks'] == 0
+    assert out['selfcheck']['exchange']['unexpected_failures'] == 0 and out['selfcheck']['exchange']['own_failures'] == {}
     assert out['selfcheck']['exchange']['scan'] == ('owner' if items == 'minimizer' else 'set')

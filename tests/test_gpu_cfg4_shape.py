@@ -1,18 +1,23 @@
-"""BASELINE.json config 4 as ONE of its eight GPUs sees it (bench.py --workload cfg4-band), at 1/150 of the size and
-against the oracle: a 20 Mb genome at 30x, the reads of every sample written into HBM by kv_reads_generate in 48 batches of
-0.625x coverage each (exactly the batch shape of the 3 Gb run: 18.75 M reads on 3 Gb), band 0 of 8 counted into band sketches
-of config 4's bins-per-base, the proband scanned batch by batch under the hash-range band rule -- then `kevlar filter` and
-`kevlar partition` on the band's annotated reads.
+"""BASELINE.json config 4 in the form it states -- 3 Gb gentrio, 30x, k = 31, EIGHT k-mer bands, the whole count -> novel -> (unband) ->
+filter -> partition -- at 1/150 of the size and against the oracle: a 20 Mb genome at 30x, the reads of every sample written into HBM
+by kv_reads_generate in 48 batches of 0.625x coverage each (exactly the batch shape of the 3 Gb run: 18.75 M reads on 3 Gb), EVERY
+ONE of the 8 bands counted into band sketches of config 4's bins-per-base and scanned batch by batch under the hash-range band rule
+(what each of config 4's eight GPUs does: bench.py --workload cfg4-band), the eight per-band results merged the way kevlar merges them
+(docs/banding.rst:13-47: one `kevlar novel --num-bands 8 --band b` per band, `kevlar unband` over the eight files, then `kevlar filter`
+and `kevlar partition` on the MERGED reads), and north_star's merge beside it: the per-band bit masks summed
+(kevlar_amd.bandmerge.allreduce_mask's arithmetic -- bands are disjoint, the sum is the OR).
 
 What is compared with what:
 * the reads: the packed words the device generator wrote, a spread sample of them against its independent numpy restatement
   (kevlar_amd.synth.device_family_reads; tests/test_gpu_synth.py holds the two against each other more thoroughly);
-* count: every byte of the three band sketches and n_occupied against the oracle's banded count of the same reads
-  (kvo_consume_reads_mt_banded = kvo_consume's band test, kevlar/count.py:62-66, on the host cores);
-* scan: every hit (read, offset, abundances) against the oracle's scan loop over all reads of the proband (kevlar/novel.py:123-169
-  restated, band rule of the count);
-* filter: the validated reads, their annotations and recounted abundances against a literal restatement of kevlar/filter.py:15-82
-  over an oracle Counttable;
+* count: every byte of the 24 band sketches and n_occupied against the oracle's all-band count of the same reads
+  (kvo_consume_reads_mt_allbands = kvo_consume's band test, kevlar/count.py:62-66, for every band in one pass on the host cores);
+* scan: every hit (read, offset, abundances) of every band against the oracle's scan loop over all reads of the proband
+  (kevlar/novel.py:123-169 restated, band rule of the count; kvo_novel_scan_mt_allbands says which band judged a hit);
+* merge: the summed bit masks against the merged hits, and `kevlar unband` over the eight per-band files (kevlar/unband.py:41-77)
+  against the oracle's all-band hits, read by read;
+* filter: the validated reads of the MERGED file, their annotations and recounted abundances against a literal restatement of
+  kevlar/filter.py:15-82 over an oracle Counttable;
 * partition: partition numbers and membership against a dict / set restatement of kevlar/readgraph.py:43-161 +
   kevlar/partition.py:15-55.
 It also pins what the batches' shape is there to exercise: a batch of 0.6x coverage has nothing to deduplicate, so the
@@ -27,7 +32,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 G, COVERAGE, L, K = 20_000_000, 30, 100, 31
-NBANDS, BAND = 8, 0
+NBANDS = 8
 PER_BATCH = 125_000                       # 0.625x of 20 Mb: bench.py's 18.75 M reads on 3 Gb
 MEM_BAND = 64e9 * (G / 3e9) / NBANDS      # config 4's 64 GB per sample for 3 Gb, split over 8 bands
 SEED = 42
@@ -51,35 +56,47 @@ def family(hk):
 
 @pytest.fixture(scope='module')
 def counted(hk, family):
-    """the band sketches and the band's hits, the way bench.py's cfg4-band step produces them; launches by profile scope"""
+    """the 24 band sketches and every band's hits, the way bench.py's cfg4-band step produces them on each of config 4's eight GPUs
+    (one band after the other here); launches by profile scope; the per-band bit masks of the scan, batch by batch, SUMMED over the
+    bands as the all-reduce sums them"""
+    import torch
     from test_gpu_fullsize import Profiled
     n_reads, firsts, batches = family
     assert len(firsts) == 48
-    T = 4
-    sk = {name: hk.Counttable(K, MEM_BAND / T, T) for name in NAMES}
+    T, nk = 4, L - K + 1
     seen = {}
-    with Profiled(hk) as prof:
-        kmers = 0
-        for name in ('mother', 'father', 'proband'):
-            sk[name].clear()
-            for b in batches[name]:
-                kmers += sk[name].consume_batch(b, NBANDS, BAND)
-        for scope in ('k_skm_emit', 'k_skm_count', 'k_consume', 'k_bin_hash_direct', 'k_bin_hash_2bit', 'k_bin_split', 'k_bin_apply'):
-            seen[scope] = prof.count(scope)
-    with Profiled(hk) as prof:
-        rs, os_, as_ = [], [], []
-        for first, b in zip(firsts, batches['proband']):
-            r, o, a, _ = hk.novel_scan([sk['proband']], [sk['mother'], sk['father']], b, CASE_MIN, CTRL_MAX, band_mode=1, nbands=NBANDS, band=BAND)
-            rs.append(np.asarray(r, dtype=np.uint32) + np.uint32(first)); os_.append(np.asarray(o, dtype=np.uint32)); as_.append(np.asarray(a, dtype=np.uint8))
-        for scope in ('k_skm_novel', 'k_skm_novel_list', 'k_novel_mark', 'k_novel_mark_2bit', 'k_skm_emit'):
-            seen['scan:' + scope] = prof.count(scope)
-    hits = (np.concatenate(rs), np.concatenate(os_), np.concatenate(as_))
-    return sk, kmers, hits, seen
+    sketches, hits_by_band, kmers = [], [], 0
+    summed = [torch.zeros((b.n_reads * nk + 31) // 32, dtype=torch.int32, device='cuda') for b in batches['proband']]
+    mine = [torch.zeros_like(m) for m in summed]
+    for band in range(NBANDS):
+        sk = {name: hk.Counttable(K, MEM_BAND / T, T) for name in NAMES}
+        with Profiled(hk) as prof:
+            for name in ('mother', 'father', 'proband'):
+                sk[name].clear()
+                for b in batches[name]:
+                    kmers += sk[name].consume_batch(b, NBANDS, band)
+            for scope in ('k_skm_emit', 'k_skm_count', 'k_consume', 'k_bin_hash_direct', 'k_bin_hash_2bit', 'k_bin_split', 'k_bin_apply'):
+                seen[scope] = seen.get(scope, 0) + prof.count(scope)
+        with Profiled(hk) as prof:
+            rs, os_, as_ = [], [], []
+            for i, (first, b) in enumerate(zip(firsts, batches['proband'])):
+                mine[i].zero_()
+                torch.cuda.synchronize()
+                r, o, a, _ = hk.novel_scan([sk['proband']], [sk['mother'], sk['father']], b, CASE_MIN, CTRL_MAX, band_mode=1, nbands=NBANDS, band=band,
+                                           mask_ptr=mine[i].data_ptr(), mask_stride=nk)
+                torch.cuda.synchronize()
+                summed[i] += mine[i]              # bandmerge.allreduce_mask: SUM of disjoint 0/1 words
+                rs.append(np.asarray(r, dtype=np.uint32) + np.uint32(first)); os_.append(np.asarray(o, dtype=np.uint32)); as_.append(np.asarray(a, dtype=np.uint8))
+            for scope in ('k_skm_novel', 'k_skm_novel_list', 'k_novel_mark', 'k_novel_mark_2bit', 'k_skm_emit'):
+                seen['scan:' + scope] = seen.get('scan:' + scope, 0) + prof.count(scope)
+        sketches.append(sk)
+        hits_by_band.append((np.concatenate(rs), np.concatenate(os_), np.concatenate(as_)))
+    return sketches, kmers, hits_by_band, seen, summed
 
 
 @pytest.fixture(scope='module')
 def oracle_side(ok, family):
-    """the same reads as text (unpacked from the words the device wrote), the oracle's banded count and scan of them"""
+    """the same reads as text (unpacked from the words the device wrote), the oracle's all-band count and all-band scan of them"""
     from test_gpu_fullsize import ascii_block
     n_reads, firsts, batches = family
     wpr = (L + 15) // 16
@@ -90,12 +107,12 @@ def oracle_side(ok, family):
         words = np.concatenate([b.packed_words(0, b.n_reads * wpr).reshape(b.n_reads, wpr) for b in batches[name]])
         words_of[name] = words
         bases, offs_p, offs = ascii_block(words, L)
-        ref[name] = ok.Counttable(K, MEM_BAND / 4, 4)
-        ok.consume_reads_mt_banded(ref[name], bases, offs_p, n_reads, cores, NBANDS, BAND)
+        ref[name] = [ok.Counttable(K, MEM_BAND / 4, 4) for _ in range(NBANDS)]
+        assert ok.consume_reads_mt_allbands(ref[name], bases, offs_p, n_reads, cores) == n_reads * (L - K + 1)
         if name == 'proband':
             keep = (bases, offs_p, offs)
-    want = ok.novel_scan_mt([ref['proband']], [ref['mother'], ref['father']], keep[0], keep[1], n_reads, K, CASE_MIN, CTRL_MAX, cores,
-                            band_mode=1, nbands=NBANDS, band=BAND)
+    want = ok.novel_scan_mt_allbands([[ref['proband'][b]] for b in range(NBANDS)], [[ref['mother'][b], ref['father'][b]] for b in range(NBANDS)],
+                                     keep[0], keep[1], n_reads, K, CASE_MIN, CTRL_MAX, cores)
     return ref, want, words_of
 
 
@@ -111,55 +128,87 @@ def test_generated_reads_are_the_numpy_restatement(family, oracle_side):
         assert np.array_equal(words_of[name][idx], want), name
 
 
-def test_band_sketches_equal_the_oracle(hk, counted, oracle_side, family):
-    sk, kmers, _hits, seen = counted
+def test_all_eight_bands_sketches_equal_the_oracle(hk, counted, oracle_side, family):
+    sketches, kmers, _hits, seen, _masks = counted
     ref, _want, _words = oracle_side
     n_reads = family[0]
-    share = kmers / float(3 * n_reads * (L - K + 1))
-    assert abs(share * NBANDS - 1.0) < 0.01, 'a band holds 1/N of the hash space'
-    for name in NAMES:
-        assert sk[name].hashsizes() == ref[name].hashsizes()
-        for t in range(4):
-            got = np.frombuffer(sk[name].table_bytes(t), dtype=np.uint8)
-            exp = np.frombuffer(ref[name].table_bytes(t), dtype=np.uint8)
-            assert np.array_equal(got, exp), '{} table {} differs from the oracle'.format(name, t)
-        assert sk[name].n_occupied() == ref[name].n_occupied()
+    assert kmers == 3 * n_reads * (L - K + 1), 'the eight bands hold every k-mer exactly once'
+    for band in range(NBANDS):
+        for name in NAMES:
+            sk, want = sketches[band][name], ref[name][band]
+            assert sk.hashsizes() == want.hashsizes()
+            for t in range(4):
+                got = np.frombuffer(sk.table_bytes(t), dtype=np.uint8)
+                exp = np.frombuffer(want.table_bytes(t), dtype=np.uint8)
+                assert np.array_equal(got, exp), 'band {} {} table {} differs from the oracle'.format(band, name, t)
+            assert sk.n_occupied() == want.n_occupied()
     # a 0.6x batch has nothing to deduplicate: the super-k-mer count declines, and the sketch remembers -- it is tried at most once
     # per sketch, not 48 times
-    assert seen['k_skm_emit'] <= len(NAMES), seen
-    assert seen['k_consume'] + seen['k_bin_hash_direct'] + seen['k_bin_hash_2bit'] >= 3 * 48 - len(NAMES), seen
+    assert seen['k_skm_emit'] <= NBANDS * len(NAMES), seen
+    assert seen['k_consume'] + seen['k_bin_hash_direct'] + seen['k_bin_hash_2bit'] >= NBANDS * (3 * 48 - len(NAMES)), seen
 
 
-def test_band_hits_equal_the_oracle(counted, oracle_side):
-    _sk, _kmers, hits, seen = counted
+def test_all_eight_bands_hits_equal_the_oracle(counted, oracle_side):
+    _sk, _kmers, hits_by_band, seen, _masks = counted
     _ref, want, _words = oracle_side
-    r, o, a = hits
-    wr, wo, wa = want
-    assert len(wr) > 20_000
-    assert len(r) == len(wr)
-    assert np.array_equal(r, wr) and np.array_equal(o, wo.astype(np.uint32)) and np.array_equal(a, wa)
+    wr, wo, wa, wb = want
+    assert len(wr) > 150_000
+    for band in range(NBANDS):
+        r, o, a = hits_by_band[band]
+        sel = wb == band
+        assert int(sel.sum()) > 10_000 and len(r) == int(sel.sum()), band
+        assert np.array_equal(r, wr[sel]) and np.array_equal(o, wo[sel].astype(np.uint32)) and np.array_equal(a, wa[sel]), band
     # the scan of a batch that cannot be deduplicated goes straight to the tile scan: cutting it into super-k-mers first, running
-    # into the tables' capacity and scanning again (round 3: 48 launches of each per step) may happen once, not per batch
-    assert seen['scan:k_novel_mark'] + seen['scan:k_novel_mark_2bit'] >= 47, seen
-    assert seen['scan:k_skm_novel'] <= 1 and seen['scan:k_skm_emit'] <= 1, seen
+    # into the tables' capacity and scanning again (round 3: 48 launches of each per step) may happen once per band, not per batch
+    assert seen['scan:k_novel_mark'] + seen['scan:k_novel_mark_2bit'] >= NBANDS * 47, seen
+    assert seen['scan:k_skm_novel'] <= NBANDS and seen['scan:k_skm_emit'] <= NBANDS, seen
+
+
+def merged_hits(hits_by_band):
+    """every band's hits in (read, offset) order -- what bandmerge.allgather_hits leaves on every rank"""
+    r = np.concatenate([h[0] for h in hits_by_band]); o = np.concatenate([h[1] for h in hits_by_band]); a = np.concatenate([h[2] for h in hits_by_band])
+    order = np.lexsort((o, r))
+    return r[order], o[order], a[order]
+
+
+def test_summed_band_masks_are_the_merged_hits(counted, oracle_side, family):
+    """north_star's merge: the all-reduce (SUM) of the per-band interesting-k-mer bit masks.  Bands are disjoint in hash space, so a
+    bit is set by one band at most and the summed words are the OR: the set bits are exactly the merged hits, which are the oracle's"""
+    from kevlar_amd import bandmerge
+    _sk, _kmers, hits_by_band, _seen, summed = counted
+    _ref, want, _words = oracle_side
+    _n, firsts, _b = family
+    r, o, a = merged_hits(hits_by_band)
+    assert np.array_equal(r, want[0]) and np.array_equal(o, want[1].astype(np.uint32)) and np.array_equal(a, want[2])
+    mr, mo = [], []
+    for first, mask in zip(firsts, summed):
+        br, bo = bandmerge.mask_to_hits(mask, L - K + 1)
+        mr.append(br + np.uint32(first)); mo.append(bo)
+    assert np.array_equal(np.concatenate(mr), r) and np.array_equal(np.concatenate(mo), o)
 
 
 @pytest.fixture(scope='module')
 def downstream(hk, counted, tmp_path_factory):
-    """the band's annotated reads as a file, `kevlar filter` and `kevlar partition` through the CLI"""
+    """docs/banding.rst:38-47: the eight bands' annotated reads as eight files, `kevlar unband` over them, then `kevlar filter` and
+    `kevlar partition` on the merged file -- through the CLI"""
     import kevlar_amd
     import bench
     from kevlar_amd import synth
-    _sk, _kmers, hits, _seen = counted
-    tmp = tmp_path_factory.mktemp('band')
-    ann = bench.band_annotated_reads(hits, G, SEED, L, K, 3, synth)
-    novel_file, filtered_file, part_file = (str(tmp / f) for f in ('band.novel.augfastq', 'band.filtered.augfastq', 'band.part.augfastq'))
-    with open(novel_file, 'wb') as fh:
-        fh.write(ann.format(np.arange(ann.n, dtype=np.uint64)))
+    _sk, _kmers, hits_by_band, _seen, _masks = counted
+    tmp = tmp_path_factory.mktemp('bands')
+    band_files = []
+    for band, hits in enumerate(hits_by_band):
+        ann = bench.band_annotated_reads(hits, G, SEED, L, K, 3, synth)
+        path = str(tmp / 'band{}.novel.augfastq'.format(band))
+        with open(path, 'wb') as fh:
+            fh.write(ann.format(np.arange(ann.n, dtype=np.uint64)))
+        band_files.append(path)
+    novel_file, filtered_file, part_file = (str(tmp / f) for f in ('merged.novel.augfastq', 'merged.filtered.augfastq', 'merged.part.augfastq'))
     log = io.StringIO()
     old, kevlar_amd.logstream = kevlar_amd.logstream, log
     try:
-        for argv in (['filter', '--memory', '20M', '--case-min', str(CASE_MIN), '--ctrl-max', str(CTRL_MAX), '-o', filtered_file, novel_file],
+        for argv in (['unband', '-o', novel_file] + band_files,
+                     ['filter', '--memory', '20M', '--case-min', str(CASE_MIN), '--ctrl-max', str(CTRL_MAX), '-o', filtered_file, novel_file],
                      ['partition', '-o', part_file, filtered_file]):
             args = kevlar_amd.cli.parser().parse_args(argv)
             kevlar_amd.cli.mains[args.cmd](args)
@@ -174,7 +223,21 @@ def load(path):
         return list(kevlar_amd.parse_augmented_fastx(fh))
 
 
-def test_filter_of_the_band_equals_the_reference_loop(ok, downstream):
+def test_unband_of_the_eight_files_is_the_oracles_all_band_scan(downstream, oracle_side):
+    """kevlar/unband.py:41-77: one record per read name, the union of its annotations from whichever bands found them, by offset.
+    Held against the ORACLE's hits (all bands, kvo_novel_scan_mt_allbands): the same reads, each with the same (offset, abundances)"""
+    novel_file = downstream[0]
+    _ref, want, _words = oracle_side
+    wr, wo, wa, _wb = want
+    expect = {}
+    for r, o, a in zip(wr.tolist(), wo.tolist(), wa.tolist()):
+        expect.setdefault('read{:010d}'.format(r), []).append((o, tuple(a)))
+    got = {rec.name: [(ik.offset, tuple(ik.abund)) for ik in rec.annotations] for rec in load(novel_file)}
+    assert len(got) == len(expect) > 5000
+    assert got == expect
+
+
+def test_filter_of_the_merged_reads_equals_the_reference_loop(ok, downstream):
     """kevlar/filter.py:15-82 literally, over an oracle Counttable: first pass adds every annotated k-mer occurrence, second pass keeps
     the annotations whose recount reaches case-min and whose control abundances stay within ctrl-max, with the recount as case
     abundance; reads left without annotations go; order kept"""
@@ -201,7 +264,7 @@ def test_filter_of_the_band_equals_the_reference_loop(ok, downstream):
     assert 0 < len(want) <= len(reads)
 
 
-def test_partition_of_the_band_equals_the_reference_loop(downstream):
+def test_partition_of_the_merged_reads_equals_the_reference_loop(downstream):
     """kevlar/readgraph.py:43-161 + kevlar/partition.py:15-55 as dicts and sets: reads that share an interesting k-mer (up to reverse
     complement) are connected; components largest first (ties: by their sorted names, descending), singletons dropped, one read per
     canonical sequence, numbered from 1"""

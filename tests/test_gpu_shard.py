@@ -148,6 +148,29 @@ def test_route_distinct_counts_like_banded_consume(hk, kind, k, ndest, path):
         assert sum(counts) == nk
 
 
+def test_route_overflow_beyond_its_list_is_a_capacity_error(hk, monkeypatch):
+    """a shard whose k-mers all go to one band pushes most of them past that band's segments into the overflow list; when the list is
+    too short for them (sinks beyond 2^30 items size it at a quarter) the call must end in KV_ERR_CAPACITY -- the callers fall back or
+    stop together -- and never hand back fewer k-mers than the shard holds (round 5 advice: route_pack did not look)"""
+    import torch
+    from kevlar_amd._lib import KvCapacityError
+    k, nb = 31, 4
+    reads = ['A' * 120] * 30000 + make_reads(3000, 21, with_n=False)
+    batch = hk.ReadBatch(reads)
+    nk = batch.num_kmers(k)
+    send = torch.zeros((nk, 2), dtype=torch.int64, device='cuda')
+    monkeypatch.setenv('KV_ROUTE_PATH', 'plain')
+    assert sum(hk.route_hashes(batch, hk.Counttable, k, nb, 0, False, send.data_ptr(), nk)) == nk
+    assert sum(hk.route_distinct(batch, hk.Counttable, k, nb, send.data_ptr(), nk)) == nk
+    monkeypatch.setenv('KV_ROUTE_OVF_CAP', '64')
+    with pytest.raises(KvCapacityError, match='beside their segments'):
+        hk.route_hashes(batch, hk.Counttable, k, nb, 0, False, send.data_ptr(), nk)
+    with pytest.raises(KvCapacityError, match='beside their segments'):
+        hk.route_distinct(batch, hk.Counttable, k, nb, send.data_ptr(), nk)
+    monkeypatch.delenv('KV_ROUTE_OVF_CAP')
+    assert sum(hk.route_hashes(batch, hk.Counttable, k, nb, 0, False, send.data_ptr(), nk)) == nk
+
+
 def test_consume_hashes_strided_large(hk):
     """the partitioned list kernel on its natural size, reading (hash, tag) pairs"""
     import torch
@@ -507,7 +530,8 @@ def free_port():
                                                     (3, 'gloo', 'minimizer/emit:1'), (3, 'gloo', 'minimizer/route:2'), (2, 'gloo', 'minimizer/route:0'),
                                                     (3, 'gloo', 'minimizer/emit-oom:2'), (2, 'gloo', 'minimizer/route-hip:1'),
                                                     (2, 'gloo', 'minimizer/owner-hip:1'), (2, 'gloo', 'minimizer/scan-fail:0'),
-                                                    (2, 'gloo', 'minimizer/ragged:1'), (3, 'gloo', 'minimizer/pairs9'), (1, 'nccl', 'minimizer/pairs9')])
+                                                    (2, 'gloo', 'minimizer/ragged:1'), (3, 'gloo', 'minimizer/pairs9'), (1, 'nccl', 'minimizer/pairs9'),
+                                                    (3, 'gloo', 'minimizer/passes4'), (2, 'gloo', 'minimizer/pairs-differ:1'), (2, 'gloo', 'minimizer/unpack-fail:1')])
 def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     """N ranks on this one GPU (gloo, staged exchange): each rank's sketches must equal band `rank` of a
     banded count of ALL reads, and the gathered hits the merged banded scan (tests/shard_worker.py).  The
@@ -537,6 +561,14 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
                    MASTER_PORT=str(port), SHARD_BACKEND=backend, SHARD_DISTINCT='1' if distinct else '0')
         if decline == 'pairs9':                             # (not a decline: the pairs travel in their 9-byte form, KV_MEX_PAIRS=9)
             env['KV_MEX_PAIRS'] = '9'
+        elif decline == 'passes4':                          # (nor this: the owner combines every bucket in four passes, as config 4's size makes it)
+            env['KV_MEX_PASSES'] = '4'
+        elif decline and decline.startswith('pairs-differ'):    # the 9-byte form on ONE rank only: the size exchange carries the form, every rank
+            if rank == int(decline.split(':')[1]):              # sees the disagreement there and the samples go as the shards' own pairs
+                env['KV_MEX_PAIRS'] = '9'
+        elif decline and decline.startswith('unpack-fail'):     # a rank cannot unpack the 9-byte pairs it received: after the exchange, so
+            env['KV_MEX_PAIRS'] = '9'                           # the ranks agree in one small all-reduce and ALL stop with an error
+            env['KV_MEX_TEST_DECLINE'] = decline
         elif decline and decline.startswith('ragged'):      # a control sample's records travel without positions (16 bytes); a rank whose
             env['SHARD_RAGGED'] = decline.split(':')[1]     # shard has reads of unequal length cannot cut those: that sample goes as pairs
         elif decline:
@@ -554,12 +586,12 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     outs = []
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=300 if decline and decline.startswith('scan-fail') else 600)
+            out, _ = p.communicate(timeout=300 if decline and decline.split(':')[0] in ('scan-fail', 'unpack-fail') else 600)
         except subprocess.TimeoutExpired:
             p.kill()
             out, _ = p.communicate()
         outs.append(out.decode(errors='replace'))
-    if decline and decline.startswith('scan-fail'):
+    if decline and (decline.startswith('scan-fail') or decline.startswith('unpack-fail')):
         failing = int(decline.split(':')[1])
         for rank, p in enumerate(procs):
             assert p.returncode not in (0, None, -9), 'rank {} must stop with an error (killed after a timeout = it hung):\n{}'.format(rank, outs[rank][-2000:])
@@ -572,10 +604,15 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
             assert '0 fallbacks, 1 scan fallbacks' in outs[rank], outs[rank][-400:]
         elif decline and decline.startswith('ragged'):
             assert '1 fallbacks, 0 scan fallbacks' in outs[rank], outs[rank][-400:]
-        elif decline == 'pairs9':
+        elif decline in ('pairs9', 'passes4'):
             assert '0 fallbacks, 0 scan fallbacks' in outs[rank], outs[rank][-400:]
         elif decline:
             assert '3 fallbacks' in outs[rank], outs[rank][-400:]        # one per sample, on every rank
             assert '1 scan fallbacks' in outs[rank], outs[rank][-400:]   # and the scan of a sample that fell back goes by the shards
         elif distinct == 'minimizer':
             assert '0 fallbacks, 0 scan fallbacks' in outs[rank], outs[rank][-400:]
+        # whatever was declined, nobody's own failure was an argument error (a mis-wired caller would show here, not as slower numbers);
+        # a rank that failed by itself says why
+        assert ', 0 unexpected' in outs[rank], outs[rank][-400:]
+        if decline and decline.split(':')[0] in ('emit-oom', 'route-hip', 'owner-hip') and rank == int(decline.split(':')[1]):
+            assert '[kevlar_amd.shardrun] rank {} declines'.format(rank) in outs[rank] and 'own failures []' not in outs[rank], outs[rank][-600:]

@@ -892,3 +892,59 @@ def test_exchange_plans_are_host_arithmetic_every_rank_repeats():
     assert rc == 0 and (int(big.C1), int(big.F2), int(big.recw)) == (248, 4096, 2)
     p = _lib.MexPlan()
     assert lib.kv_mex_plan_make(0, 12, 1000, 100, 8, ctypes.byref(p)) != 0          # k below the super-k-mer front end's range
+
+
+def test_every_environment_switch_is_in_the_one_registry(monkeypatch):
+    """kevlar_amd/csrc/kv_knobs.h: the library and its wrapper look at the environment through ONE table (kv_host.hip).  No source
+    calls getenv() beside the registry; every name a source asks for is registered with a class and a description; a TUNING switch is
+    ignored unless KV_TUNING=1 -- a stray KV_* in a user's shell changes nothing -- and an EXPERIMENT switch (wrong results) is never
+    honoured by the product build."""
+    import glob
+    from kevlar_amd import _lib
+    import ctypes
+    buf = ctypes.create_string_buffer(1 << 16)
+    assert _lib.load().kv_knobs_describe(1, buf, len(buf)) == 0
+    table = {}
+    for line in buf.value.decode().splitlines():
+        name, cls, doc = line.split('\t')
+        assert name not in table and cls in ('setting', 'tuning', 'experiment') and len(doc) > 10, line
+        table[name] = cls
+    asked = set()
+    csrc = os.path.join(ROOT, 'kevlar_amd', 'csrc')
+    for path in glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')):
+        text = open(path).read()
+        raw = [m.start() for m in re.finditer(r'\bgetenv\s*\(', text)]
+        if os.path.basename(path) == 'kv_host.hip':
+            # the registry's own three: the KV_TUNING switch, the lookup, the listing
+            assert len(raw) == 3 and all(text.index('// ---- the knob registry') < at for at in raw), path
+        elif os.path.basename(path) != 'kv_knobs.h':
+            assert not raw, '{} calls getenv() beside the registry'.format(path)
+        asked |= set(re.findall(r'kv_knob\(\s*"([A-Z_0-9]+)"', text))
+        asked |= set(re.findall(r'kv_knob\([^")]*\?\s*"([A-Z_0-9]+)"\s*:\s*"([A-Z_0-9]+)"', text)[0]) if 'kv_knob(for_scan' in text else set()
+    for path in glob.glob(os.path.join(ROOT, 'kevlar_amd', '*.py')) + glob.glob(os.path.join(ROOT, 'kevlar_amd', 'cli', '*.py')):
+        text = open(path).read()
+        asked |= set(re.findall(r"_lib\.knob\(\s*'([A-Z_0-9]+)'", text))
+        # the wrapper's only direct looks at the environment: where the library is, which GPU this rank takes
+        for name in re.findall(r"environ(?:\.get\(|\[)\s*'([A-Z_0-9]+)'", text):
+            assert name in ('KV_LIB_PATH', 'LOCAL_RANK'), '{} reads {} beside the registry'.format(path, name)
+    assert asked and asked <= set(table), sorted(asked - set(table))
+    assert set(table) - asked <= set(), 'registered but never asked for: {}'.format(sorted(set(table) - asked))
+
+    for name in list(os.environ):
+        if name.startswith('KV_'):
+            monkeypatch.delenv(name)
+    assert _lib.knobs_active() == ''
+    monkeypatch.setenv('KV_COUNT_PATH', 'atomic')
+    monkeypatch.setenv('KV_TABLE_CACHE_GB', '1')
+    monkeypatch.setenv('KV_SKM_DEBUG', '3')
+    assert _lib.knob('KV_COUNT_PATH') is None and _lib.knob('KV_TABLE_CACHE_GB') == '1' and _lib.knob('KV_SKM_DEBUG', 'no') == 'no'
+    assert sorted(_lib.knobs_active().split()) == ['KV_TABLE_CACHE_GB=1', 'ignored:KV_COUNT_PATH=atomic', 'ignored:KV_SKM_DEBUG=3']
+    monkeypatch.setenv('KV_TUNING', '1')
+    assert _lib.knob('KV_COUNT_PATH') == 'atomic'
+    assert _lib.knob('KV_SKM_DEBUG') is None, 'the product build must not honour the wrong-result switches'
+    assert sorted(_lib.knobs_active().split()) == ['KV_COUNT_PATH=atomic', 'KV_TABLE_CACHE_GB=1', 'ignored:KV_SKM_DEBUG=3']
+    with pytest.raises(ValueError):
+        _lib.knob('KV_NO_SUCH_SWITCH')
+    # no compile-time switch of the kernels changes results either: the timing hacks of round 5 live in scratch/patches/
+    for path in glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')):
+        assert 'SKM_HACK' not in open(path).read() and 'SKM_LANE_DISSECT' not in open(path).read(), path
