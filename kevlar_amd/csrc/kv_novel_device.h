@@ -78,6 +78,78 @@ __device__ __forceinline__ uint64_t skm_key_hash(const SkmKey<KW> &c, const uint
     return murmur_regs<NW>(wf, hp) ^ murmur_regs<NW>(wr, hp);
 }
 
+// ---- the same two murmurs without their first multiplications (k known when compiled) -----------------------------------------
+// MurmurHash3 starts on every 8 bytes of key with a multiplication by a constant (k1 *= c1, k2 *= c2).  Eight bytes of a k-mer's
+// ASCII are two BYTES of its 2-bit form, four bases each, and the product is linear in them modulo 2^64:
+//   (w0 | w1 << 32) * c  =  w0 * c  +  ((w1 * c) << 32)
+// so with two 256-entry tables in LDS -- P1[b] = ascii4(b) * c1, P2[b] = ascii4(b) * c2, 64 bits each (4 KB for both) -- the product
+// is a 64-bit and a 32-bit look-up and one addition in place of two look-ups of the ASCII table, a 64 x 64-bit multiplication (a
+// v_mad_u64_u32 and two v_mul_lo_u32: integer multiplications issue at a quarter of the rate of the other integer instructions, and
+// they are what the drain of k_skm_count is made of) and the additions that put it together: 24 of a k-mer's 88 multiplications.
+// A word of which the k-mer fills only v < 4 characters (its last) is looked up with the other bases zero, i.e. with 'A' in their
+// place, and what those 'A's contribute is a constant taken off again (murmur3 masks those bytes to zero).
+KV_HD uint64_t skm_ascii4_times(uint32_t byte, uint64_t c) { return (uint64_t)skm_ascii4(byte) * c; }
+
+template <int K> __host__ __device__ constexpr int pl_valid(int q) { return K - 4 * q >= 4 ? 4 : (K - 4 * q > 0 ? K - 4 * q : 0); }
+__host__ __device__ constexpr uint64_t pl_corr(int valid, uint64_t c)
+{
+    return valid >= 4 ? 0ull : (uint64_t)(0x41414141u & ~((1u << (8 * valid)) - 1u)) * c;
+}
+
+// (ASCII words QA and QA + 1 of the k-mer as one little-endian u64, masked to the k-mer's length) * C, from the table P of that C
+template <int KW, int K, int QA>
+__device__ __forceinline__ uint64_t pl_mul(const SkmKey<KW> &c, const uint64_t *P, uint64_t C)
+{
+    constexpr int v0 = pl_valid<K>(QA), v1 = pl_valid<K>(QA + 1);
+    static_assert(v0 > 0, "a murmur lane without a byte");
+    const uint32_t b0 = (uint32_t)(c.w[QA >> 3] >> (8 * (QA & 7))) & (v0 == 4 ? 0xffu : ((1u << (2 * v0)) - 1u));
+    uint64_t x = P[b0] - pl_corr(v0, C);
+    if (v1 > 0) {
+        const uint32_t b1 = (uint32_t)(c.w[(QA + 1) >> 3] >> (8 * ((QA + 1) & 7))) & (v1 == 4 ? 0xffu : ((1u << (2 * v1)) - 1u));
+        x += (uint64_t)((uint32_t)P[b1] - (uint32_t)pl_corr(v1, C)) << 32;
+    }
+    return x;
+}
+
+template <int KW, int K, int B>
+__device__ __forceinline__ void pl_block(const SkmKey<KW> &c, const uint64_t *P1, const uint64_t *P2, uint64_t &h1, uint64_t &h2)
+{
+    uint64_t k1 = pl_mul<KW, K, 4 * B>(c, P1, MM_C1), k2 = pl_mul<KW, K, 4 * B + 2>(c, P2, MM_C2);
+    k1 = rotl64(k1, 31); k1 *= MM_C2; h1 ^= k1;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    k2 = rotl64(k2, 33); k2 *= MM_C1; h2 ^= k2;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+}
+
+template <int KW, int K>
+__device__ __forceinline__ uint64_t murmur_pl(const SkmKey<KW> &c, const uint64_t *P1, const uint64_t *P2)
+{
+    constexpr int nb = K / 16, rem = K % 16;
+    static_assert(K >= 1 && K <= 32 * KW && nb <= 4, "k out of the key's range");
+    uint64_t h1 = 0, h2 = 0;
+    if constexpr (nb > 0) pl_block<KW, K, 0>(c, P1, P2, h1, h2);
+    if constexpr (nb > 1) pl_block<KW, K, 1>(c, P1, P2, h1, h2);
+    if constexpr (nb > 2) pl_block<KW, K, 2>(c, P1, P2, h1, h2);
+    if constexpr (nb > 3) pl_block<KW, K, 3>(c, P1, P2, h1, h2);
+    if constexpr (rem > 8) {
+        uint64_t k2 = pl_mul<KW, K, 4 * nb + 2>(c, P2, MM_C2);
+        k2 = rotl64(k2, 33); k2 *= MM_C1; h2 ^= k2;
+    }
+    if constexpr (rem > 0) {
+        uint64_t k1 = pl_mul<KW, K, 4 * nb>(c, P1, MM_C1);
+        k1 = rotl64(k1, 31); k1 *= MM_C2; h1 ^= k1;
+    }
+    return mm_final(h1, h2, K);
+}
+
+// skm_key_hash for a k known when compiled, from the product tables (P1 / P2: 256 u64 each, filled with skm_ascii4_times)
+template <int KW, int K>
+__device__ __forceinline__ uint64_t skm_key_hash_pl(const SkmKey<KW> &c, const uint64_t *P1, const uint64_t *P2)
+{
+    const SkmKey<KW> r = skm_revcomp<KW>(c, K);
+    return murmur_pl<KW, K>(c, P1, P2) ^ murmur_pl<KW, K>(r, P1, P2);
+}
+
 __device__ __forceinline__ bool band_pass(const NovelParams &p, uint64_t h)
 {
     if (p.band_mode == KV_BAND_RANGE) return h >= p.band_lo && h < p.band_hi;

@@ -1516,22 +1516,34 @@ __host__ __device__ inline uint32_t skm_wave_scratch_words(uint32_t sbw) { retur
 #define SKM_K2_WAVES 6
 #endif
 // RS: slots of the table of records (above) the instance combines identical records in before it walks them; 0: it walks them all
+// The instances for a fixed k (FK != 0, no record table) take the two murmurs from the product tables (skm_key_hash_pl: P1 / P2, 4 KB of
+// dynamic LDS in place of the 1 KB ASCII table) and keep their occurrence counters as 16-bit halves of a word -- that is where the
+// 3 KB come from with three workgroups on a CU; the host launches them only for buckets that cannot hold 65536 occurrences
+// (skm_count_pl_fits), the instances with k at run time count in 32 bits.  -DSKM_PL=0: A/B builds without either.
+#if !defined(SKM_PL)
+#define SKM_PL 1
+#endif
 template <int KW, int TS, bool KNOBS, int FK, bool COMPACT = false, bool ORI = false, int RS = 0>
 __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : (RS >= 1024 ? 4 : 6)) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
                                                            const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
     static_assert(RS == 0 || (KW == 1 && ORI && !KNOBS), "records are combined in the oriented one-word instances");
+    constexpr bool PL = SKM_PL && FK != 0 && RS == 0;
     __shared__ SkmTable<KW, TS> tb;
-    __shared__ uint32_t cnt[TS];                 // occurrences of the key in the same slot
+    __shared__ uint32_t cnt[PL ? TS / 2 : TS];   // occurrences of the key in the same slot (PL: slot s in half s & 1 of word s >> 1)
     __shared__ SkmRecTable<RS ? RS : 1> rt;
     __shared__ uint32_t next_bucket;
     __shared__ uint32_t abl_cur, abl_b0, abl_prev;      // abundance list: entries appended so far, ... when the bucket began, the bucket
     __shared__ uint32_t dl_cur, dl_b0;                  // distinct list: the same two
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
     const uint32_t ns = (uint32_t)(g.T * g.C);
-    uint32_t *lut = dyn, *cur = dyn + 256, *scratch = cur + ((ns + 3u) & ~3u);
+    uint32_t *lut = dyn, *cur = dyn + (PL ? 1024 : 256), *scratch = cur + ((ns + 3u) & ~3u);
+    uint64_t *P1 = (uint64_t *)dyn, *P2 = P1 + 256;
     for (uint32_t s = threadIdx.x; s < ns; s += SKM_THREADS3) cur[s] = 0;
-    if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    if (threadIdx.x < 256) {
+        if (PL) { P1[threadIdx.x] = skm_ascii4_times(threadIdx.x, MM_C1); P2[threadIdx.x] = skm_ascii4_times(threadIdx.x, MM_C2); }
+        else lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    }
     const int k = FK ? FK : sg.k;
     const HashParams hp = FK ? make_hash_params(FK, f.hp.hashfam) : f.hp;
     uint64_t n_added = 0, n_distinct = 0;
@@ -1550,7 +1562,7 @@ __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : (RS >= 1024 
     // the table is emptied as it is read (below), so it is cleared only once; the next bucket's ticket is fetched
     // while the current bucket is processed
     skm_table_clear(tb);
-    for (uint32_t i = threadIdx.x; i < TS; i += SKM_THREADS3) cnt[i] = 0;
+    for (uint32_t i = threadIdx.x; i < (PL ? TS / 2 : TS); i += SKM_THREADS3) cnt[i] = 0;
     if constexpr (RS != 0) skm_rec_table_clear(rt);
     if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * sg.bpt; abl_cur = 0; abl_b0 = 0; abl_prev = 0xffffffffu; dl_cur = 0; dl_b0 = 0; }
     // where the finished bucket's entries of the abundance list lie (nothing if the workgroup's stretch ran out)
@@ -1613,7 +1625,10 @@ __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : (RS >= 1024 
             // results stay exact, tests use it to put single k-mers on the loose list of a batch that otherwise fits)
             const bool forced = (SKM_DBG(sg) & 4096u) && ((c.w[0] * 0x9e3779b97f4a7c15ull) >> 58) == 0;
             const int slot = skm_cacheable<KW>(c) && !forced ? skm_table_insert(tb, c) : -1;
-            if (slot >= 0 && !(SKM_DBG(sg) & 256u)) atomicAdd(&cnt[slot], 1u);
+            if (slot >= 0 && !(SKM_DBG(sg) & 256u)) {
+                if (PL) atomicAdd(&cnt[(uint32_t)slot >> 1], 1u << (((uint32_t)slot & 1u) * 16u));
+                else atomicAdd(&cnt[slot], 1u);
+            }
             return slot < 0;         // table region full (or unstorable key): this occurrence travels alone
         });
         __syncthreads();
@@ -1623,11 +1638,20 @@ __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : (RS >= 1024 
             c.w[0] = tb.key[0][slot];
             tb.key[0][slot] = SKM_EMPTY;
             if (KW == 2) { c.w[KW - 1] = tb.key[KW - 1][slot]; tb.key[KW - 1][slot] = SKM_EMPTY; }
-            const uint32_t seen = cnt[slot];
-            cnt[slot] = 0;
+            uint32_t seen;
+            if (PL) {               // (the other half of the word is another lane's, maybe at this very moment)
+                const uint32_t sh = (slot & 1u) * 16u;
+                seen = (cnt[slot >> 1] >> sh) & 0xffffu;
+                atomicSub(&cnt[slot >> 1], seen << sh);
+            } else {
+                seen = cnt[slot];
+                cnt[slot] = 0;
+            }
             n_distinct += 1;
             if (SKM_DBG(sg) & 1u) return;
-            const uint64_t h = skm_key_hash<KW>(c, lut, hp);
+            uint64_t h;
+            if constexpr (PL) h = skm_key_hash_pl<KW, FK>(c, P1, P2);
+            else h = skm_key_hash<KW>(c, lut, hp);
             if (SKM_DBG(sg) & 64u) { n_added += h & 1; return; }
             // distinct list: key and hash of every k-mer in here (the scan of this batch then neither combines nor hashes again)
             if (sg.dl_keys) {
@@ -2946,33 +2970,40 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     {
         KvProfScope prof("k_skm_count");
         const uint32_t ns = (uint32_t)(plan.g.T * plan.g.C);
-        const size_t lds = (256 + ((ns + 3u) & ~3u) + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw)) * 4;
+        // the fixed-k instances count a key's occurrences in 16 bits (k_skm_count, PL): only for buckets that cannot hold 65536 of them
+        const bool fixed_k = !sg.dbg && !kv_knob("KV_SKM_ANY_K") && (!SKM_PL || (uint64_t)sg.nwg2 * sg.cap2 * (uint64_t)sg.ncap < 65536ull);
         void (*kernel)(SkmGeom, const SketchDev *, const SketchDev *, ConsumeFilter, BinGeom) =
             sg.kw == 1 ? (sg.dbg ? k_skm_count<1, 4096, true, 0> : k_skm_count<1, 4096, false, 0>) : (sg.dbg ? k_skm_count<2, 2048, true, 0> : k_skm_count<2, 2048, false, 0>);
-        if (sg.k == 31 && sg.recw == 3 && !sg.dbg && !kv_knob("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31>;
+        bool pl = false;         // a fixed-k instance: 4 KB of product tables where the others keep 1 KB of ASCII
+        if (sg.k == 31 && sg.recw == 3 && fixed_k) { kernel = k_skm_count<1, 4096, false, 31>; pl = true; }
         if (sg.compact) {       // 16-byte records (sg.recw == 2): their own instances
             kernel = sg.dbg ? k_skm_count<1, 4096, true, 0, true> : k_skm_count<1, 4096, false, 0, true>;
-            if (sg.k == 31 && !sg.dbg && !kv_knob("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31, true>;
+            pl = false;
+            if (sg.k == 31 && fixed_k) { kernel = k_skm_count<1, 4096, false, 31, true>; pl = true; }
         }
         // (BASELINE.json configs[4]: k = 51 -- two-word keys, 128-bit reverse complement, three murmur blocks + a 3-byte tail)
-        if (sg.k == 51 && sg.recw == 4 && !sg.dbg && !kv_knob("KV_SKM_ANY_K")) kernel = k_skm_count<2, 2048, false, 51>;
+        if (sg.k == 51 && sg.recw == 4 && fixed_k) { kernel = k_skm_count<2, 2048, false, 51>; pl = true; }
         if (sg.oriented) {      // oriented records: the same instances with the walk that takes k-mers as they stand
             kernel = sg.kw == 1 ? (sg.dbg ? k_skm_count<1, 4096, true, 0, false, true> : k_skm_count<1, 4096, false, 0, false, true>)
                                 : (sg.dbg ? k_skm_count<2, 2048, true, 0, false, true> : k_skm_count<2, 2048, false, 0, false, true>);
-            if (sg.k == 31 && sg.recw == 3 && !sg.dbg && !kv_knob("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31, false, true>;
+            pl = false;
+            if (sg.k == 31 && sg.recw == 3 && fixed_k) { kernel = k_skm_count<1, 4096, false, 31, false, true>; pl = true; }
             if (sg.compact) {
                 kernel = sg.dbg ? k_skm_count<1, 4096, true, 0, true, true> : k_skm_count<1, 4096, false, 0, true, true>;
-                if (sg.k == 31 && !sg.dbg && !kv_knob("KV_SKM_ANY_K")) kernel = k_skm_count<1, 4096, false, 31, true, true>;
+                pl = false;
+                if (sg.k == 31 && fixed_k) { kernel = k_skm_count<1, 4096, false, 31, true, true>; pl = true; }
             }
-            if (sg.k == 51 && sg.recw == 4 && !sg.dbg && !kv_knob("KV_SKM_ANY_K")) kernel = k_skm_count<2, 2048, false, 51, false, true>;
+            if (sg.k == 51 && sg.recw == 4 && fixed_k) { kernel = k_skm_count<2, 2048, false, 51, false, true>; pl = true; }
             // k = 31: identical records are combined before their k-mers are (skm_rec_combine; skm_build sized the buckets for it)
             if (sg.dd_maxn && sg.k == 31 && (sg.compact || sg.recw == 3) && !sg.dbg) {
+                pl = false;
                 kernel = sg.compact ? k_skm_count<1, 3072, false, 31, true, true, 512> : k_skm_count<1, 3072, false, 31, false, true, 512>;
                 if (kv_knob("KV_SKM_DEDUP_RS") && atoi(kv_knob("KV_SKM_DEDUP_RS")) >= 1024)
                     kernel = sg.compact ? k_skm_count<1, 4096, false, 31, true, true, 1024> : k_skm_count<1, 4096, false, 31, false, true, 1024>;
             }
         }
         if (!sg.oriented) sg.dd_maxn = 0;
+        const size_t lds = ((pl && SKM_PL ? 1024 : 256) + ((ns + 3u) & ~3u) + (size_t)(SKM_THREADS3 / 64) * skm_wave_scratch_words(sg.sbw)) * 4;
         hipLaunchKernelGGL(kernel, dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, (const SketchDev *)s->d_desc, d_mask, filter, plan.g);
     }
     {

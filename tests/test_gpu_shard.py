@@ -558,7 +558,10 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
         distinct = 'minimizer'
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), SHARD_BACKEND=backend, SHARD_DISTINCT='1' if distinct else '0')
+                   MASTER_PORT=str(port), SHARD_BACKEND=backend, SHARD_DISTINCT='1' if distinct else '0',
+                   # every layout against the oracle itself (tests/shard_worker.py: against_the_oracle); the forced declines repeat
+                   # those layouts and keep to the banded device path (which tests/test_gpu_fullsize.py holds against the oracle)
+                   SHARD_ORACLE='1' if decline in (None, 'passes4', 'pairs9') else '0')
         if decline == 'pairs9':                             # (not a decline: the pairs travel in their 9-byte form, KV_MEX_PAIRS=9)
             env['KV_MEX_PAIRS'] = '9'
         elif decline == 'passes4':                          # (nor this: the owner combines every bucket in four passes, as config 4's size makes it)
