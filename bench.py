@@ -100,6 +100,9 @@ def parse_args():
                    help='multi-GPU merge: mask (default) = north_star\'s all-reduce of the per-owner interesting-k-mer bit masks (a band, a '
                         'set of minimizer buckets, a shard: disjoint findings, so the sum is the OR) inside the timed step, asserted equal to '
                         'the gathered hits, besides the all-gather of the hits that carries their abundances; hits = the all-gather alone')
+    p.add_argument('--eager-hits', action='store_true',
+                   help='N=1: every scan waits for its hit arrays to reach the host before the step goes on (default: the copy of step i runs '
+                        'beside the counts of step i + 1; all hits are fetched either way)')
     p.add_argument('--count-streams', type=int, default=3,
                    help='N=1: count the samples concurrently on this many HIP streams, one host thread each (the samples are '
                         'independent; kernels bound by different units overlap and no stream waits for another\'s host round '
@@ -360,8 +363,23 @@ def main():
         if exchange:
             run.band_mask = (band_mask, nk)         # every scan of the exchange layout sets this rank's findings and all-reduces (ShardedTrio._merge_mask)
 
+    class PendingHits(object):
+        """the hits of a one-batch scan whose arrays are still on their way to the host (hk.novel_scan(lazy=True)): the next step's
+        counts run meanwhile; unpacks like the (read, offset, abundances) triple it stands for"""
+        def __init__(self, lazy):
+            self.lazy = lazy
+
+        def __iter__(self):
+            return iter(self.lazy.arrays()[:3])
+
     def scan_batches(sk, band_mode, nbands, band):
         rs, os_, as_ = [], [], []
+        if len(batch_first) == 1 and world == 1 and band_mask is None and sk is sketches and not args.eager_hits:
+            # one batch, one GPU: the scan returns when its kernels are done and the hit arrays (25 MB at config 2, half a millisecond of
+            # PCIe) travel while the next step counts; every step's hits are fetched all the same -- the fence that ends the timed
+            # region waits for the last copy, the checksum is taken from those arrays (--eager-hits: wait inside the step, as before)
+            return PendingHits(hk.novel_scan([sk['proband']], [sk[n] for n in controls], batches['proband'][0], args.case_min, args.ctrl_max,
+                                             band_mode=band_mode, nbands=nbands, band=band, lazy=True))
         many = len(batch_first) > 1 and band_mask is None and world == 1 and args.count_streams > 1
         if many:
             # the batches of a case sample are independent: scanned side by side on the streams the counts used (every scan is a
@@ -409,14 +427,18 @@ def main():
                 for b in batches[n]:
                     kmers += sk[n].consume_batch(b, nbands, band)
         t_b = time.perf_counter()
-        r, o, a = scan_batches(sk, 1 if nbands else 0, nbands, band)
+        found = scan_batches(sk, 1 if nbands else 0, nbands, band)
         t_c = time.perf_counter()
         wall['count'] += t_b - t_a
         wall['novel'] += t_c - t_b
-        return kmers, (r, o, a)
+        return kmers, found
 
     def step_banded():
-        kmers, (r, o, a) = count_and_scan(sketches, world if world > 1 else solo_bands, rank if world > 1 else solo_band)
+        kmers, found = count_and_scan(sketches, world if world > 1 else solo_bands, rank if world > 1 else solo_band)
+        if world == 1:
+            note_hbm()
+            return kmers, found
+        r, o, a = found
         note_hbm()
         t_c = time.perf_counter()
         if world > 1:
@@ -571,7 +593,7 @@ def main():
         }
 
     # ---- cheap end-to-end sanity on the timed result (parity proper lives in tests/)
-    r, o, a = hits
+    r, o, a = hits                      # (a PendingHits unpacks into its arrays: they arrived before the fence above returned)
     nhits = len(r)
     assert nhits > 0, 'the synthetic family must yield interesting k-mers'
     assert (a[:, 0] >= args.case_min).all() and (a[:, 1:] <= args.ctrl_max).all()

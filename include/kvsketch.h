@@ -249,6 +249,11 @@ int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *const *ctrls, i
                   const kv_reads *reads, uint64_t first_read, int case_min, int ctrl_max,
                   int screen_thresh, int band_mode, int nbands, int band, uint32_t *d_mask,
                   uint64_t mask_stride, kv_hits **out);
+/* on != 0, for the calling host thread: a kv_novel_scan (without an abundance screen) returns as soon as its kernels are done -- the
+ * sketches may be cleared and counted into again -- while the hit arrays are still being copied to the host on a stream of their own;
+ * kv_hits_view / kv_hits_fetch / kv_hits_shadow / kv_hits_destroy wait for them (kv_hits_count does not need to).  A caller that scans
+ * batch after batch reads the hits of one scan while the next count runs.                                                          */
+int kv_hits_lazy(int on);
 int kv_hits_count(const kv_hits *h, uint64_t *n_hits, uint64_t *n_discarded_reads);
 /* copies hits sorted by (read, offset); abund has n_hits * (ncase+nctrl) entries          */
 int kv_hits_fetch(const kv_hits *h, uint32_t *read, uint32_t *offset, uint8_t *abund,

@@ -47,6 +47,7 @@ SIGNATURES = {
     'kv_table_cache_trim': (i32, []),
     'kv_scratch_trim': (i32, []),
     'kv_unique_release': (i32, []),
+    'kv_hits_lazy': (i32, [i32]),
     'kv_knobs_describe': (i32, [i32, ctypes.c_char_p, u64]),
     'kv_knob_get': (i32, [ctypes.c_char_p, ctypes.c_char_p, u64]),
     'kv_prof_enable': (i32, [i32]),

@@ -194,6 +194,11 @@ struct kv_hits {
     PinnedVec<uint8_t> abund;
     std::vector<uint32_t> discarded;
     std::vector<uint32_t> shadow_read, shadow_offset;   // interesting k-mers of discarded reads in front of the screen trip
+    // kv_hits_lazy: the hit arrays are still on their way from the device (a copy stream of their own); every reader waits for this
+    // event first, and so does the destructor before the pinned arrays go back to their pool
+    hipEvent_t ready = nullptr;
+    void wait() const { if (ready) (void)hipEventSynchronize(ready); }
+    ~kv_hits() { if (ready) { (void)hipEventSynchronize(ready); (void)hipEventDestroy(ready); } }
 };
 
 struct HashParams {

@@ -199,35 +199,51 @@ __global__ __launch_bounds__(KV_TILE_THREADS) void k_novel_mark(ReadsDev rd, Nov
 // exclusive scan of n 32-bit counts into 64-bit bases (single 1024-thread workgroup)
 __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t *counts, uint32_t n, uint64_t *base)
 {
-    // one workgroup; eight consecutive counts per thread and round (117 k tiles: 15 rounds of three barriers instead of 115, each
-    // with its own trip to memory: 0.165 -> 0.03 ms)
+    // One workgroup; a wave takes 64 * PER consecutive counts per round, 64 at a time: consecutive lanes on consecutive counts, so a
+    // load is one 256-byte piece of memory and a store one of 512, and the wave's running total rides along from one 64 to the next.
+    // (A thread on PER consecutive counts -- eight 4-byte loads 32 bytes apart from its neighbour's, eight 8-byte stores 64 bytes apart --
+    // made every round ~7 us of single-CU memory pipe: 0.108 ms for the 117 k tiles of config 2.)  The next round's counts are
+    // requested before this round's barriers.
     constexpr uint32_t PER = 8;
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t nxt[PER];
+    auto request = [&](uint32_t start) {
+        const uint32_t i0 = start + wave * 64u * PER + lane;
+#pragma unroll
+        for (uint32_t u = 0; u < PER; ++u) nxt[u] = i0 + u * 64u < n ? counts[i0 + u * 64u] : 0u;
+    };
+    request(0);
     for (uint32_t start = 0; start < n; start += 1024 * PER) {
-        const uint32_t i0 = start + threadIdx.x * PER;
+        const uint32_t i0 = start + wave * 64u * PER + lane;
         uint32_t c[PER];
-        uint64_t mine = 0;
+        uint64_t excl[PER];                             // exclusive prefix inside the wave's stretch
+        uint64_t run = 0;                               // total of the pieces in front (wave-uniform)
 #pragma unroll
-        for (uint32_t u = 0; u < PER; ++u) { c[u] = i0 + u < n ? counts[i0 + u] : 0u; mine += c[u]; }
-        uint64_t incl = mine;
+        for (uint32_t u = 0; u < PER; ++u) {
+            c[u] = nxt[u];
+            uint64_t incl = c[u];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint64_t up = __shfl_up(incl, d);
+                if (lane >= (uint32_t)d) incl += up;
+            }
+            excl[u] = run + incl - c[u];
+            run += __shfl(incl, 63);
         }
-        if (lane == 63) wsum[wave] = incl;
+        if (start + 1024 * PER < n) request(start + 1024 * PER);
+        if (lane == 0) wsum[wave] = run;
         __syncthreads();
         uint64_t before = carry;
-        for (int w = 0; w < wave; ++w) before += wsum[w];
-        uint64_t run = before + incl - mine;
+        for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
 #pragma unroll
-        for (uint32_t u = 0; u < PER; ++u) { if (i0 + u < n) base[i0 + u] = run; run += c[u]; }
+        for (uint32_t u = 0; u < PER; ++u)
+            if (i0 + u * 64u < n) base[i0 + u * 64u] = before + excl[u];
         __syncthreads();
-        if (threadIdx.x == 1023) carry = before + incl;
+        if (threadIdx.x == 1023) carry = before + run;
         __syncthreads();
     }
     if (threadIdx.x == 0) base[n] = carry;
@@ -439,7 +455,16 @@ struct Arena {
         return e;
     }
 };
-struct ScanArenas { Arena work, hits, set, abund; std::mutex mu; };   // mu: one scan at a time per stream
+struct ScanArenas {
+    Arena work, hits, set, abund;
+    std::mutex mu;                                  // one scan at a time per stream
+    // kv_hits_lazy: the hit arrays leave `hits` on a copy stream of this stream's own, behind the scan's last kernel (kdone); the
+    // next scan that writes `hits` queues behind the copy (copied)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t kdone = nullptr, copied = nullptr;
+    bool copy_pending = false;
+};
+thread_local bool g_hits_lazy = false;
 std::map<hipStream_t, ScanArenas> g_scan_arenas;
 std::mutex g_scan_arenas_mu;
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -596,6 +621,10 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
     }
     std::lock_guard<std::mutex> arena_lock(arenas->mu);
     hipError_t e = hipSuccess;
+    if (arenas->copy_pending) {                     // the previous scan's hits may still be leaving the buffers this one writes
+        e = hipStreamWaitEvent(st, arenas->copied, 0);
+        arenas->copy_pending = false;
+    }
     const uint64_t mask_words = d_mask ? 0 : (reads->n_reads * min_stride + 31) / 32;
     if (mask_words * 4 > ((uint64_t)64 << 30)) {
         // one bit per (read, offset) with the stride of the longest read: a chromosome among a million reads
@@ -630,16 +659,21 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
     p.tile_base = d_tbase_p;
     uint64_t nhits = 0;
     bool marked_by_skm = use_skm;
-    p.ab_keys = nullptr; p.ab_vals = nullptr; p.ab_mask = 0;
+    p.ab_keys = nullptr; p.ab_vals = nullptr; p.ab_mask = 0; p.ab_list = nullptr; p.ab_count = nullptr; p.ab_list_cap = 0;
     if (e == hipSuccess && use_skm && !p.set_keys && kv_skm_list_ready(reads, k) && !(kv_knob("KV_NOVEL_ABCACHE") && atoi(kv_knob("KV_NOVEL_ABCACHE")) == 0)) {
         // room for the abundances of the interesting k-mers (a k-mer in a few thousand is one): 1 / 64 of the k-mers in slots
         uint64_t slots = 1u << 16;
         while (slots < n_kmers / 64 && slots < (1ull << 24)) slots <<= 1;
-        if (arenas->abund.need(up256(slots * 8) + up256(slots * (uint64_t)S)) == hipSuccess) {
+        const uint64_t list_cap = slots / 8;
+        if (arenas->abund.need(up256(slots * 8) + up256(slots * (uint64_t)S) + up256(list_cap * 4) + 256) == hipSuccess) {
             p.ab_keys = (unsigned long long *)arenas->abund.p;
             p.ab_vals = (uint8_t *)arenas->abund.p + up256(slots * 8);
             p.ab_mask = slots - 1;
+            p.ab_list = (uint32_t *)(p.ab_vals + up256(slots * (uint64_t)S));
+            p.ab_count = (unsigned int *)((unsigned char *)p.ab_list + up256(list_cap * 4));
+            p.ab_list_cap = (uint32_t)list_cap;
             e = hipMemsetAsync(p.ab_keys, 0, slots * 8, st);
+            if (e == hipSuccess) e = hipMemsetAsync(p.ab_count, 0, 4, st);
         } else {
             (void)hipGetLastError();
         }
@@ -715,10 +749,34 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
         if (e == hipSuccess) e = hits->read.resize(nhits);
         if (e == hipSuccess) e = hits->offset.resize(nhits);
         if (e == hipSuccess) e = hits->abund.resize(nhits * (uint64_t)S);
-        if (e == hipSuccess) e = hipMemcpyAsync(hits->read.data(), p.hit_read, nhits * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(hits->offset.data(), p.hit_off, nhits * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(hits->abund.data(), p.hit_abund, nhits * (uint64_t)S, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        // kv_hits_lazy (and no abundance screen, whose bookkeeping reads the hits on the host right here): the call returns when its
+        // KERNELS are done -- the sketches may change from then on -- while the arrays travel on a copy stream; whoever reads the handle
+        // waits for them (kv_hits::wait).  25 MB of hits per scan of config 2 are half a millisecond of PCIe that the next count hides.
+        hipStream_t cs = st;
+        const bool lazy = g_hits_lazy && !p.disc_first;
+        if (lazy && e == hipSuccess) {
+            if (!arenas->copy_stream) {
+                e = hipStreamCreateWithFlags(&arenas->copy_stream, hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&arenas->kdone, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&arenas->copied, hipEventDisableTiming);
+            }
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&hits->ready, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(arenas->kdone, st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(arenas->copy_stream, arenas->kdone, 0);
+            cs = arenas->copy_stream;
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(hits->read.data(), p.hit_read, nhits * 4, hipMemcpyDeviceToHost, cs);
+        if (e == hipSuccess) e = hipMemcpyAsync(hits->offset.data(), p.hit_off, nhits * 4, hipMemcpyDeviceToHost, cs);
+        if (e == hipSuccess) e = hipMemcpyAsync(hits->abund.data(), p.hit_abund, nhits * (uint64_t)S, hipMemcpyDeviceToHost, cs);
+        if (lazy) {
+            if (e == hipSuccess) e = hipEventRecord(hits->ready, cs);
+            if (e == hipSuccess) e = hipEventRecord(arenas->copied, cs);
+            if (e == hipSuccess) arenas->copy_pending = true;
+            if (e == hipSuccess) e = hipEventSynchronize(arenas->kdone);
+            else (void)hipStreamSynchronize(cs);            // (nothing may be in flight into a handle that is about to be deleted)
+        } else if (e == hipSuccess) {
+            e = hipStreamSynchronize(st);
+        }
     }
     std::vector<uint32_t> first_trip;
     if (e == hipSuccess && p.disc_first) {
@@ -756,9 +814,16 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
 
 }  // namespace
 
+extern "C" int kv_hits_lazy(int on)
+{
+    g_hits_lazy = on != 0;
+    return KV_OK;
+}
+
 extern "C" int kv_hits_shadow(const kv_hits *h, const uint32_t **read, const uint32_t **offset, uint64_t *n)
 {
     KV_REQUIRE(h && n, KV_ERR_ARG, "kv_hits_shadow: null argument");
+    h->wait();
     *n = h->shadow_read.size();
     if (read) *read = h->shadow_read.data();
     if (offset) *offset = h->shadow_offset.data();
@@ -778,6 +843,7 @@ extern "C" int kv_hits_fetch(const kv_hits *h, uint32_t *read, uint32_t *offset,
 {
     KV_REQUIRE(h, KV_ERR_ARG, "kv_hits_fetch: null handle");
     KV_REQUIRE(cap_hits >= h->read.size(), KV_ERR_CAPACITY, "hit buffer too small");
+    h->wait();
     if (!h->read.empty()) {
         KV_REQUIRE(read && offset && abund, KV_ERR_ARG, "kv_hits_fetch: null output");
         memcpy(read, h->read.data(), h->read.size() * 4);
@@ -795,6 +861,7 @@ extern "C" int kv_hits_view(const kv_hits *h, const uint32_t **read, const uint3
                             const uint32_t **discarded_reads)
 {
     KV_REQUIRE(h, KV_ERR_ARG, "kv_hits_view: null handle");
+    h->wait();
     if (read) *read = h->read.data();
     if (offset) *offset = h->offset.data();
     if (abund) *abund = h->abund.data();

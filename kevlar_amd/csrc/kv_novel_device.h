@@ -36,6 +36,9 @@ struct NovelParams {
     unsigned long long *ab_keys;          // NULL = off
     uint8_t *ab_vals;                     // [slots][S]
     uint64_t ab_mask;                     // slots - 1
+    uint32_t *ab_list;                    // the slots claimed, in the order they were (k_ab_fill visits these, not all 8 M slots); [0] of
+    unsigned int *ab_count;               // ab_count counts them, past ab_list_cap k_ab_fill walks the table after all
+    uint32_t ab_list_cap;
     const void *host_ctrls;               // host side only: the control sketches (kv_sketch *const *) behind sk[ncase..], for their
     int host_nctrl;                       // abundance lists (kv_skm_novel_mark)
     const void *host_case0;               // host side only: the first case sketch (kv_sketch *), for case0_bits
@@ -304,6 +307,10 @@ __device__ __forceinline__ uint8_t *ab_claim(const NovelParams &p, uint64_t h, i
     uint64_t slot = ab_slot(p, h);
     for (int probe = 0; probe < KV_AB_PROBES; ++probe, slot = (slot + 1) & p.ab_mask) {
         const unsigned long long old = atomicCAS(&p.ab_keys[slot], 0ull, (unsigned long long)h);
+        if (old == 0ull && p.ab_list) {
+            const unsigned int at = atomicAdd(p.ab_count, 1u);
+            if (at < p.ab_list_cap) p.ab_list[at] = (uint32_t)slot;
+        }
         if (old == 0ull || old == (unsigned long long)h) return p.ab_vals + slot * (uint64_t)S;       // (two k-mers with one hash have one set of abundances)
     }
     return nullptr;

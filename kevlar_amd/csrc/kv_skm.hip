@@ -1773,9 +1773,15 @@ __global__ __launch_bounds__(256) void k_skm_loose_count(SkmGeom sg, const Sketc
         for (int t = 0; t < BIN_MAX_T; ++t) bins[t] = (pass && t < g.T) ? fastmod(h, sk->size[t], sk->magic[t]) : 0ull;
         spill_items_wave(g, bins, 1u, pass);
     };
-    for (uint64_t i0 = blockIdx.x * (uint64_t)blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+    // records a wave takes at a time: the records with several k-mers are handled one after the other (each a round trip to the spill
+    // counter), so a short list -- 40 k records at config 2 -- is dealt a few records to every wave, not 64 to one wave in seven
+    // (0.135 -> 0.0x ms per launch; a long list -- k = 51: millions of one-k-mer records -- keeps 64)
+    const uint64_t total_waves = (uint64_t)gridDim.x * (blockDim.x >> 6), wave_id = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t per = (uint32_t)min((unsigned long long)64, max((unsigned long long)1, (n + total_waves - 1) / total_waves));
+    (void)stride;
+    for (uint64_t i0 = wave_id * per; i0 < n; i0 += total_waves * per) {
         const uint64_t i = i0 + lane;
-        const bool have = i < n;
+        const bool have = lane < per && i < n;
         const uint64_t *rec = sg.loose + (have ? i : 0) * (uint64_t)recw;
         uint64_t bw[3];
 #pragma unroll
@@ -2227,6 +2233,16 @@ __global__ __launch_bounds__(256) void k_ab_fill(NovelParams p)
     load_descs(ns, p);
     __syncthreads();
     const int S = p.ncase + p.nctrl;
+    // the slots that were claimed are on a list (ab_claim) -- some 10^5 of the table's 8 M at config 2, whose walk was 0.11 ms; a list
+    // that ran out of room sends the kernel over the whole table as before
+    const unsigned int listed = p.ab_list ? *p.ab_count : 0xffffffffu;
+    if (listed <= p.ab_list_cap) {
+        for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < listed; i += (uint64_t)gridDim.x * 256ull) {
+            const uint64_t slot = p.ab_list[i];
+            hit_abundances(ns, p, (uint64_t)p.ab_keys[slot], p.ab_vals + slot * (uint64_t)S);
+        }
+        return;
+    }
     for (uint64_t slot = blockIdx.x * 256ull + threadIdx.x; slot <= p.ab_mask; slot += (uint64_t)gridDim.x * 256ull) {
         const unsigned long long h = p.ab_keys[slot];
         if (h != 0ull) hit_abundances(ns, p, (uint64_t)h, p.ab_vals + slot * (uint64_t)S);
@@ -2244,19 +2260,38 @@ __global__ __launch_bounds__(256) void k_skm_loose_novel(SkmGeom sg, ReadsDev rd
     unsigned long long n = sg.ctr[0];
     if (n > sg.loose_cap) n = sg.loose_cap;
     const int k = sg.k, recw = sg.lrecw;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t *rec = sg.loose + i * (uint64_t)recw;
+    const uint32_t lane = threadIdx.x & 63u;
+    auto test_one = [&](const SkmKey<KW> &fw, bool live, uint64_t pos) {
+        if (!live) return;
+        const uint64_t h = skm_key_hash<KW>(skm_canonical<KW>(fw, skm_revcomp<KW>(fw, k)), lut, p.hp);
+        if (band_pass(p, h) && novel_test_fast(ns, p, h, nullptr, 0ull)) skm_mark(p, rd, pos, sg.stride);
+    };
+    // as k_skm_loose_count deals the list: a few records to every wave, a one-k-mer record a lane, a longer record spread over the
+    // lanes k-mer by k-mer (a thread per record rolled through up to ncap k-mers, each a chain of table probes: 0.167 ms for the
+    // handful of records a config-2 scan finds here)
+    const uint64_t total_waves = (uint64_t)gridDim.x * (blockDim.x >> 6), wave_id = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t per = (uint32_t)min((unsigned long long)64, max((unsigned long long)1, (n + total_waves - 1) / total_waves));
+    for (uint64_t i0 = wave_id * per; i0 < n; i0 += total_waves * per) {
+        const uint64_t i = i0 + lane;
+        const bool have = lane < per && i < n;
+        const uint64_t *rec = sg.loose + (have ? i : 0) * (uint64_t)recw;
         uint64_t bw[3];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) bw[t] = t < sg.nbw ? rec[1 + t] : 0ull;
-        const uint64_t hdr = rec[0];
-        const uint32_t nk = skm_hdr_n(hdr);
-        SkmKey<KW> fw = skm_first_kmer<KW>(bw, k);
-        SkmKey<KW> rc = skm_revcomp<KW>(fw, k);
-        for (uint32_t j = 0; j < nk; ++j) {
-            if (j) skm_roll<KW>(fw, rc, skm_base_at(bw, j + (uint32_t)k - 1u), k);
-            const uint64_t h = skm_key_hash<KW>(skm_canonical<KW>(fw, rc), lut, p.hp);
-            if (band_pass(p, h) && novel_test_fast(ns, p, h, nullptr, 0ull)) skm_mark(p, rd, skm_hdr_pos_of(hdr, j), sg.stride);
+        for (int t = 0; t < 3; ++t) bw[t] = (have && t < sg.nbw) ? rec[1 + t] : 0ull;
+        const uint64_t hdr = have ? rec[0] : 0ull;
+        const uint32_t nk = have ? skm_hdr_n(hdr) : 0u;
+        test_one(skm_first_kmer<KW>(bw, k), nk == 1, skm_hdr_pos_of(hdr, 0u));
+        unsigned long long longer = __ballot(nk > 1);
+        while (longer) {
+            const uint32_t src = (uint32_t)__ffsll((long long)longer) - 1u;
+            longer &= longer - 1ull;
+            const uint64_t b0 = skm_shfl64(bw[0], src), b1 = skm_shfl64(bw[1], src), b2 = skm_shfl64(bw[2], src), h_src = skm_shfl64(hdr, src);
+            const uint32_t nk_src = (uint32_t)__shfl((int)nk, (int)src);
+            for (uint32_t j0 = 0; j0 < nk_src; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const bool live = j < nk_src;
+                test_one(skm_kmer_at<KW>(b0, b1, b2, live ? j : 0u, k), live, skm_hdr_pos_of(h_src, live ? j : 0u));
+            }
         }
     }
 }
@@ -3147,6 +3182,11 @@ int kv_skm_novel_mark(const kv_reads *reads, const NovelParams &p, uint64_t n_km
                         : (sg.kw == 1 ? (sg.dbg ? k_skm_novel_list<1, 2048, true> : k_skm_novel_list<1, 2048, false>) : (sg.dbg ? k_skm_novel_list<2, 1024, true> : k_skm_novel_list<2, 1024, false>));
         hipLaunchKernelGGL(kernel, dim3(nwg3), dim3(SKM_THREADS3), lds, st, sg, rd, pl, abls);
         if (p.ab_keys) hipLaunchKernelGGL(k_ab_fill, dim3(2048), dim3(256), 0, st, p);
+        if (p.ab_list && kv_knob("KV_SKM_VERBOSE")) {
+            unsigned int claimed = 0;
+            if (hipMemcpyAsync(&claimed, p.ab_count, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+                fprintf(stderr, "[kv_skm] scan: %u interesting k-mers hold a slot for their abundances (the list takes %u)\n", claimed, p.ab_list_cap);
+        }
         sg.dl_keys = nullptr; sg.dl_hash = nullptr; sg.dl_bstart = nullptr; sg.dl_bcount = nullptr;
     } else {
         KvProfScope prof("k_skm_novel");

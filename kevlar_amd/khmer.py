@@ -851,18 +851,53 @@ class Nodegraph(_Sketch):
 # kevlar/novel.py:123-169)
 # ----------------------------------------------------------------------------------------
 def novel_scan(cases, controls, batch, case_min, ctrl_max, screen=None, band_mode=0, nbands=0,
-               band=0, first_read=0, mask_ptr=None, mask_stride=0):
+               band=0, first_read=0, mask_ptr=None, mask_stride=0, lazy=False):
     """Returns (read_idx, offset, abund[n, S], discarded_reads) as numpy arrays, hits sorted
-    by (read, offset)."""
+    by (read, offset).  lazy: returns a LazyHits instead, as soon as the scan's kernels are done (kv_hits_lazy): the sketches may
+    be cleared and counted into again while the hit arrays are still on their way to the host; .arrays() waits for them."""
     lib = _lib.load()
     S = len(cases) + len(controls)
     ca = (ctypes.c_void_p * len(cases))(*[c._h for c in cases])
     cb = (ctypes.c_void_p * max(1, len(controls)))(*[c._h for c in controls])
     hits = ctypes.c_void_p()
-    check(lib.kv_novel_scan(ca, len(cases), cb, len(controls), batch._h, int(first_read), int(case_min),
-                            int(ctrl_max), int(screen or 0), int(band_mode), int(nbands or 0),
-                            int(band or 0), mask_ptr, int(mask_stride), ctypes.byref(hits)))
+    if lazy:
+        check(lib.kv_hits_lazy(1))
+    try:
+        check(lib.kv_novel_scan(ca, len(cases), cb, len(controls), batch._h, int(first_read), int(case_min),
+                                int(ctrl_max), int(screen or 0), int(band_mode), int(nbands or 0),
+                                int(band or 0), mask_ptr, int(mask_stride), ctypes.byref(hits)))
+    finally:
+        if lazy:
+            lib.kv_hits_lazy(0)
+    if lazy:
+        return LazyHits(hits, S)
     return _hits_arrays(hits, S)
+
+
+class LazyHits(object):
+    """the hits of a novel_scan(lazy=True): how many there are is known at once, the arrays when they have arrived"""
+
+    def __init__(self, handle, S):
+        self._handle, self._S, self._arrays = handle, S, None
+        n = ctypes.c_uint64()
+        check(_lib.load().kv_hits_count(handle, ctypes.byref(n), None))
+        self.n = int(n.value)
+
+    def arrays(self):
+        if self._arrays is None:
+            self._arrays = _hits_arrays(self._handle, self._S)       # (kv_hits_view waits for the copy; the arrays keep the handle alive)
+            self._handle = None
+        return self._arrays
+
+    def __len__(self):
+        return self.n
+
+    def __del__(self):
+        if self._handle is not None and _lib is not None:
+            try:
+                _lib.load().kv_hits_destroy(self._handle)            # (waits for a copy that nobody looked at)
+            except Exception:
+                pass
 
 
 def _hits_arrays(hits, S):

@@ -65,4 +65,6 @@ def test_exchange_layout_with_its_samples_interleaved_equals_the_banded_replay(r
     assert 'exchanged by band' in out['config']['parallelism']
     assert out['selfcheck']['exchange']['layout_fallbacks'] == 0 and out['selfcheck']['exchange']['scan_fallbacks'] == 0
     assert out['selfcheck']['exchange']['unexpected_failures'] == 0 and out['selfcheck']['exchange']['own_failures'] == {}
+    # north_star's collective on the default multi-GPU line: the per-owner bit masks all-reduced inside the step, equal to the gathered hits
+    assert out['selfcheck']['mask_allreduce_equals_gathered_hits'] and 'bit masks' in out['config']['parallelism']
     assert out['selfcheck']['exchange']['scan'] == ('owner' if items == 'minimizer' else 'set')

@@ -276,6 +276,46 @@ def test_skm_novel_scan_matches_oracle(hk, ok, skm, k):
     assert launches('k_skm_emit') == (4 if k == 31 else 3)
 
 
+@pytest.mark.parametrize('path', ['skm', 'tiles'])
+def test_lazy_hits_are_the_hits_and_survive_the_next_count(hk, ok, skm, path):
+    """hk.novel_scan(lazy=True) (kv_hits_lazy): the call returns when its kernels are done, the hit arrays follow on a copy stream of
+    their own.  From then on the sketches may be cleared and counted into again -- bench.py's next step does exactly that -- and a
+    second scan on the stream reuses the device buffers the first one's hits are leaving: the arrays that arrive must be the first
+    scan's, hit for hit the oracle's.  With an abundance screen the call stays eager (its bookkeeping reads the hits on the host)."""
+    reads = trio_reads(50000, 20000, 61)
+    names = ('proband', 'mother', 'father')
+    dev = {n: hk.Counttable(31, 1.5e6, 4) for n in names}
+    ref = {n: ok.Counttable(31, 1.5e6, 4) for n in names}
+    for n in names:
+        dev[n].consume_batch(hk.ReadBatch(reads[n]))
+        bases, offs = ok.concat_reads(reads[n])
+        ok.consume_reads(ref[n], bases, offs, len(reads[n]))
+    os.environ['KV_NOVEL_PATH'] = path
+    batch = hk.ReadBatch(reads['proband'])
+    bases, offs = ok.concat_reads(reads['proband'])
+    want, _ = ok.novel_scan([ref['proband']], [ref['mother'], ref['father']], bases, offs, len(reads['proband']), 31, 6, 1)
+    assert len(want) > 50
+    cases, ctrls = [dev['proband']], [dev['mother'], dev['father']]
+    first = hk.novel_scan(cases, ctrls, batch, 6, 1, lazy=True)
+    assert isinstance(first, hk.LazyHits) and len(first) == len(want)
+    # the sketches change under the copy, and another scan (different thresholds: other hits) writes the same device buffers
+    second = hk.novel_scan(cases, ctrls, batch, 2, 3, lazy=True)
+    assert len(second) > len(first)
+    dev['mother'].clear()
+    dev['mother'].consume_batch(hk.ReadBatch(reads['proband']))
+    r, o, a, disc = first.arrays()
+    assert [(int(r[i]), int(o[i]), tuple(int(x) for x in a[i])) for i in range(len(r))] == want and len(disc) == 0
+    r2, o2, a2, _ = second.arrays()
+    assert len(r2) == len(second) and (a2[:, 0] >= 2).all() and (a2[:, 1:] <= 3).all()
+    del first, second
+    third = hk.novel_scan(cases, [dev['father']], batch, 6, 1, lazy=True)           # a handle nobody reads: destroyed while its copy may be in flight
+    del third
+    screened = hk.novel_scan(cases, [dev['father']], batch, 6, 1, screen=2, lazy=True)
+    eager = hk.novel_scan(cases, [dev['father']], batch, 6, 1, screen=2)
+    for x, y in zip(screened.arrays(), eager):
+        assert np.array_equal(x, y)
+
+
 def test_skm_novel_scan_rebuilds_when_the_case_was_counted_first_and_honours_skips(hk, ok, skm):
     os.environ['KV_SKM_BUCKET_KMERS'] = '2048'
     reads = trio_reads(80000, 24000, 43)
