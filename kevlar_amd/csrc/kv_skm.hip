@@ -1523,6 +1523,14 @@ __host__ __device__ inline uint32_t skm_wave_scratch_words(uint32_t sbw) { retur
 #if !defined(SKM_PL)
 #define SKM_PL 1
 #endif
+// slots of the k = 51 instances' table: their buckets are sized for 2048 slots (the scan kernels' tables), the count's own table may be
+// roomier -- fewer occurrences on the loose list, shorter probe chains -- as long as three workgroups fit a CU (2560: 52.7 KB each)
+#if !defined(SKM_TS51)
+#define SKM_TS51 2560
+#endif
+#if !defined(SKM_TS31)
+#define SKM_TS31 4608
+#endif
 template <int KW, int TS, bool KNOBS, int FK, bool COMPACT = false, bool ORI = false, int RS = 0>
 __global__ __launch_bounds__(SKM_THREADS3, KW == 2 ? SKM_K2_WAVES : (RS >= 1024 ? 4 : 6)) void k_skm_count(SkmGeom sg, const SketchDev *__restrict__ sk,
                                                            const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
@@ -3010,25 +3018,25 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
         void (*kernel)(SkmGeom, const SketchDev *, const SketchDev *, ConsumeFilter, BinGeom) =
             sg.kw == 1 ? (sg.dbg ? k_skm_count<1, 4096, true, 0> : k_skm_count<1, 4096, false, 0>) : (sg.dbg ? k_skm_count<2, 2048, true, 0> : k_skm_count<2, 2048, false, 0>);
         bool pl = false;         // a fixed-k instance: 4 KB of product tables where the others keep 1 KB of ASCII
-        if (sg.k == 31 && sg.recw == 3 && fixed_k) { kernel = k_skm_count<1, 4096, false, 31>; pl = true; }
+        if (sg.k == 31 && sg.recw == 3 && fixed_k) { kernel = k_skm_count<1, SKM_TS31, false, 31>; pl = true; }
         if (sg.compact) {       // 16-byte records (sg.recw == 2): their own instances
             kernel = sg.dbg ? k_skm_count<1, 4096, true, 0, true> : k_skm_count<1, 4096, false, 0, true>;
             pl = false;
-            if (sg.k == 31 && fixed_k) { kernel = k_skm_count<1, 4096, false, 31, true>; pl = true; }
+            if (sg.k == 31 && fixed_k) { kernel = k_skm_count<1, SKM_TS31, false, 31, true>; pl = true; }
         }
         // (BASELINE.json configs[4]: k = 51 -- two-word keys, 128-bit reverse complement, three murmur blocks + a 3-byte tail)
-        if (sg.k == 51 && sg.recw == 4 && fixed_k) { kernel = k_skm_count<2, 2048, false, 51>; pl = true; }
+        if (sg.k == 51 && sg.recw == 4 && fixed_k) { kernel = k_skm_count<2, SKM_TS51, false, 51>; pl = true; }
         if (sg.oriented) {      // oriented records: the same instances with the walk that takes k-mers as they stand
             kernel = sg.kw == 1 ? (sg.dbg ? k_skm_count<1, 4096, true, 0, false, true> : k_skm_count<1, 4096, false, 0, false, true>)
                                 : (sg.dbg ? k_skm_count<2, 2048, true, 0, false, true> : k_skm_count<2, 2048, false, 0, false, true>);
             pl = false;
-            if (sg.k == 31 && sg.recw == 3 && fixed_k) { kernel = k_skm_count<1, 4096, false, 31, false, true>; pl = true; }
+            if (sg.k == 31 && sg.recw == 3 && fixed_k) { kernel = k_skm_count<1, SKM_TS31, false, 31, false, true>; pl = true; }
             if (sg.compact) {
                 kernel = sg.dbg ? k_skm_count<1, 4096, true, 0, true, true> : k_skm_count<1, 4096, false, 0, true, true>;
                 pl = false;
-                if (sg.k == 31 && fixed_k) { kernel = k_skm_count<1, 4096, false, 31, true, true>; pl = true; }
+                if (sg.k == 31 && fixed_k) { kernel = k_skm_count<1, SKM_TS31, false, 31, true, true>; pl = true; }
             }
-            if (sg.k == 51 && sg.recw == 4 && fixed_k) { kernel = k_skm_count<2, 2048, false, 51, false, true>; pl = true; }
+            if (sg.k == 51 && sg.recw == 4 && fixed_k) { kernel = k_skm_count<2, SKM_TS51, false, 51, false, true>; pl = true; }
             // k = 31: identical records are combined before their k-mers are (skm_rec_combine; skm_build sized the buckets for it)
             if (sg.dd_maxn && sg.k == 31 && (sg.compact || sg.recw == 3) && !sg.dbg) {
                 pl = false;
