@@ -13,6 +13,7 @@ for spec in "$@"; do
     [ "$rest" != "$lib" ] && envs=${rest#*:}
     (
         export KV_LIB_PATH=$REPO/$lib
+        [ -n "$envs" ] && export KV_TUNING=1          # (tuning switches are honoured only with it: kevlar_amd/csrc/kv_knobs.h)
         IFS=',' read -ra kv <<< "$envs"
         for e in "${kv[@]}"; do [ -n "$e" ] && export "$e"; done
         timeout 600 python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e --no-replay --traffic none "${ARGS[@]}" > $OUT/$name.json 2> $OUT/$name.err
