@@ -820,11 +820,19 @@ class ClockWatch(object):
         import glob
         import threading
         self.freq, self.power = None, None
-        cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/hwmon/hwmon*'))
-        # (one card per box on the pool; on a node, LOCAL_RANK's card by the order of the render nodes)
+        # the card this process computes on, by its PCI address (a box shows every card of its node in sysfs, whichever one the
+        # process was given: the first collection of round 6 read an idle neighbour's 97 MHz)
+        cards = []
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(dev_index)
+            addr = '{:04x}:{:02x}:{:02x}.0'.format(pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            cards = sorted(glob.glob('/sys/bus/pci/devices/{}/hwmon/hwmon*'.format(addr)))
+        except Exception:
+            cards = []
         cards = [c for c in cards if os.path.exists(os.path.join(c, 'freq1_input'))]
         if cards:
-            hw = cards[min(dev_index, len(cards) - 1)]
+            hw = cards[0]
             self.freq = os.path.join(hw, 'freq1_input')
             for name in ('power1_input', 'power1_average'):
                 if os.path.exists(os.path.join(hw, name)):
@@ -859,7 +867,7 @@ class ClockWatch(object):
 
         def three(v):
             return [round(v[0]), round(v[len(v) // 2]), round(v[-1])] if v else None
-        return {'sclk_mhz': three(f), 'power_w': three(p), 'samples': len(f)}
+        return {'sclk_mhz': three(f), 'power_w': three(p), 'samples': len(f), 'source': os.path.dirname(self.freq)}
 
 
 def band_annotated_reads(hits, genome_len, seed, L, k, S, synth):

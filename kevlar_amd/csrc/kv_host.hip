@@ -1169,7 +1169,7 @@ const KvKnobDef g_knobs[] = {
     {"KV_STAGE_THREADS", S_, "host threads reading a file into the pinned staging buffers (1..16)"},
     {"KEVLAR_PACK_CACHE", S_, "packed-read cache files beside the inputs: unset / 0 never, 1 use and create"},
     {"KV_INGEST", S_, "host: parse every file on the host, never on the device"},
-    {"KV_GUNZIP", S_, "0: ordinary gzip through zlib on the host instead of the device inflater"},
+    {"KV_GUNZIP", S_, "host: ordinary gzip streams through zlib on the host instead of the device inflater (BGZF and plain FASTQ stay on the device)"},
     {"KV_GUNZIP_CRC", S_, "0: skip the CRC-32 check of inflated members"},
     {"KV_PARALLEL_SAMPLES", S_, "1 / 0: count the samples of `kevlar novel` side by side on their own streams / one after the other"},
     {"KV_INGEST_VERBOSE", S_, "wall time of every ingest step on stderr"},
