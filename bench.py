@@ -341,8 +341,6 @@ def main():
     def note_hbm():
         hbm_low[0] = min(hbm_low[0], torch.cuda.mem_get_info(dev_index)[0])
 
-    forced_env = []
-
     def make_sketches(memory):
         sk = {n: hk.Counttable(k, memory / T, T) for n in names}
         if len(batches['proband']) == 1:
@@ -758,8 +756,6 @@ def main():
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args, wl, packed, names, synth)
         if not args.no_e2e:
-            for name in forced_env:
-                os.environ.pop(name, None)          # `kevlar novel` below runs as a user would run it
             e2e = end_to_end(args, wl, packed, names, synth)
 
     if rank == 0:

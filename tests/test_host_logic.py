@@ -948,3 +948,16 @@ def test_every_environment_switch_is_in_the_one_registry(monkeypatch):
     # no compile-time switch of the kernels changes results either: the timing hacks of round 5 live in scratch/patches/
     for path in glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')):
         assert 'SKM_HACK' not in open(path).read() and 'SKM_LANE_DISSECT' not in open(path).read(), path
+
+
+def test_bench_clock_watch_never_raises_and_reports_nothing_without_a_card():
+    """bench.py samples the shader clock and power of the card it computes on (its hwmon files, found by PCI address) beside the timed
+    steps; on a host without a GPU -- or where the files are not readable -- the field is null, never an error"""
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    watch = bench.ClockWatch(0, period=0.005)
+    time.sleep(0.03)
+    got = watch.stop()
+    assert got is None or (set(got) >= {'sclk_mhz', 'power_w', 'samples'} and got['samples'] > 0)
