@@ -756,7 +756,10 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
         const bool lazy = g_hits_lazy && !p.disc_first;
         if (lazy && e == hipSuccess) {
             if (!arenas->copy_stream) {
-                e = hipStreamCreateWithFlags(&arenas->copy_stream, hipStreamNonBlocking);
+                // (lowest priority: the copies are blit kernels, and the count kernels they run beside should win the CUs)
+                int least = 0, greatest = 0;
+                (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+                e = hipStreamCreateWithPriority(&arenas->copy_stream, hipStreamNonBlocking, least);
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&arenas->kdone, hipEventDisableTiming);
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&arenas->copied, hipEventDisableTiming);
             }
