@@ -369,18 +369,22 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash_
 // the LDS cursors, direct stores, exactly as k_bin_hash_direct stores them.  A ticket is BIN2_TILES tiles' worth of reads.
 #define BIN2_CH 10
 #define BIN2_TILES 8u
-template <int THREADS, int KW>
+// FK = 31: the instance for kevlar's default k, with the murmurs' first multiplications from the product tables (skm_key_hash_pl)
+template <int THREADS, int KW, int FK = 0>
 __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash_2bit(
     ReadsDev rd, uint32_t n_units, const SketchDev *__restrict__ sk, const SketchDev *__restrict__ mask, ConsumeFilter f, BinGeom g)
 {
-    __shared__ uint32_t lut[256];
+    __shared__ __attribute__((aligned(8))) uint32_t lut[FK ? 1024 : 256];
     __shared__ uint32_t cur[BIN_MAX_T * BIN_C];
     __shared__ uint32_t next_unit;
     __shared__ unsigned long long queue[(THREADS / 64) * 128];
     const uint32_t ns = (uint32_t)(g.T * g.C);
     for (uint32_t s = threadIdx.x; s < ns; s += THREADS) cur[s] = 0;
-    if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
-    const int k = f.hp.k;
+    if (threadIdx.x < 256) {
+        if (FK) { ((uint64_t *)lut)[threadIdx.x] = skm_ascii4_times(threadIdx.x, MM_C1); ((uint64_t *)lut)[256 + threadIdx.x] = skm_ascii4_times(threadIdx.x, MM_C2); }
+        else lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    }
+    const int k = FK ? FK : f.hp.k;
     const uint32_t L = rd.uni_len, wpr = (L + 15u) >> 4, nk = L - (uint32_t)k + 1u, cpr = (nk + BIN2_CH - 1u) / BIN2_CH;
     const float inv_cpr = 1.0f / (float)cpr;
     const uint64_t reads_per_unit = (uint64_t)BIN2_TILES * rd.uni_per_tile;
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 6 : 4)) void k_bin_hash_
             const bool mine = i < n_items;
             const uint32_t r = mine ? k2_div(i, cpr, inv_cpr) : 0u, j0 = mine ? (i - r * cpr) * BIN2_CH : 0u;
             const uint32_t cnt = mine ? min((uint32_t)BIN2_CH, nk - j0) : 0u;
-            kmer2bit_walk<KW, BIN2_CH>(rd.words + (r0 + r) * wpr, j0, cnt, k, lut, f.hp, [&](bool live, uint64_t h) {
+            kmer2bit_walk<KW, BIN2_CH, FK>(rd.words + (r0 + r) * wpr, j0, cnt, k, lut, f.hp, [&](bool live, uint64_t h) {
                 wave_queue_push(wq, live && consume_filter_pass(f, mask, h), h, route);
             });
         }
@@ -1320,7 +1324,10 @@ int kv_consume_binned(kv_sketch *s, const kv_reads *reads, const uint64_t *d_lis
         KvProfScope prof("k_bin_hash_2bit");
         const SketchDev *d = (const SketchDev *)s->d_desc;
         const bool kw2 = s->h.ksize > 32;
-        if (cmax <= 32 && !kw2) hipLaunchKernelGGL((k_bin_hash_2bit<512, 1>), dim3(g.nwgA), dim3(512), 0, st, reads_dev(reads), n_units2, d, d_mask, filter, g);
+        const bool k31 = !kw2 && s->h.ksize == 31 && !kv_knob("KV_SKM_ANY_K");
+        if (cmax <= 32 && k31) hipLaunchKernelGGL((k_bin_hash_2bit<512, 1, 31>), dim3(g.nwgA), dim3(512), 0, st, reads_dev(reads), n_units2, d, d_mask, filter, g);
+        else if (k31) hipLaunchKernelGGL((k_bin_hash_2bit<1024, 1, 31>), dim3(g.nwgA), dim3(1024), 0, st, reads_dev(reads), n_units2, d, d_mask, filter, g);
+        else if (cmax <= 32 && !kw2) hipLaunchKernelGGL((k_bin_hash_2bit<512, 1>), dim3(g.nwgA), dim3(512), 0, st, reads_dev(reads), n_units2, d, d_mask, filter, g);
         else if (cmax <= 32) hipLaunchKernelGGL((k_bin_hash_2bit<512, 2>), dim3(g.nwgA), dim3(512), 0, st, reads_dev(reads), n_units2, d, d_mask, filter, g);
         else if (!kw2) hipLaunchKernelGGL((k_bin_hash_2bit<1024, 1>), dim3(g.nwgA), dim3(1024), 0, st, reads_dev(reads), n_units2, d, d_mask, filter, g);
         else hipLaunchKernelGGL((k_bin_hash_2bit<1024, 2>), dim3(g.nwgA), dim3(1024), 0, st, reads_dev(reads), n_units2, d, d_mask, filter, g);

@@ -20,10 +20,13 @@ __device__ __forceinline__ uint32_t k2_div(uint32_t q, uint32_t d, float inv)
 }
 
 // body(live, hash): called CH times by every lane (wave-uniform, so the body may ballot); live = this lane has a k-mer
-template <int KW, int CH, typename Body>
-__device__ __forceinline__ void kmer2bit_walk(const uint32_t *read_words, uint32_t j0, uint32_t cnt, int k, const uint32_t *lut,
+// FK != 0: k is FK, known when compiled (shifts and masks are constants) and `lut` holds the two product tables of skm_key_hash_pl
+// (512 x 64 bits: P1 then P2) instead of the 256-entry ASCII table
+template <int KW, int CH, int FK = 0, typename Body>
+__device__ __forceinline__ void kmer2bit_walk(const uint32_t *read_words, uint32_t j0, uint32_t cnt, int k_run, const uint32_t *lut,
                                               const HashParams &hp, Body body)
 {
+    const int k = FK ? FK : k_run;
     SkmKey<KW> fw;
     fw.w[0] = skm_bases32(read_words, j0);
     if (KW == 2) fw.w[KW - 1] = skm_bases32(read_words, j0 + 32u) & skm_topmask<2>(k);
@@ -34,7 +37,12 @@ __device__ __forceinline__ void kmer2bit_walk(const uint32_t *read_words, uint32
     for (uint32_t u = 0; u < (uint32_t)CH; ++u) {
         if (u) skm_roll<KW>(fw, rc, (uint32_t)(tail >> (2u * (u - 1u))) & 3u, k);
         const bool live = u < cnt;
-        body(live, live ? skm_key_hash<KW>(skm_canonical<KW>(fw, rc), lut, hp) : 0ull);
+        uint64_t h = 0;
+        if (live) {
+            if constexpr (FK != 0) h = skm_key_hash_pl<KW, FK>(skm_canonical<KW>(fw, rc), (const uint64_t *)lut, (const uint64_t *)lut + 256);
+            else h = skm_key_hash<KW>(skm_canonical<KW>(fw, rc), lut, hp);
+        }
+        body(live, h);
     }
 }
 

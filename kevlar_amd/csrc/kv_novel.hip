@@ -81,16 +81,19 @@ __device__ __forceinline__ bool novel_test_screen(const NovelParams &p, uint64_t
 // no verdict cache (a batch that repeats its k-mers takes the super-k-mer scan instead).
 #define NM2_CH 10
 #define NM2_THREADS 512
-template <int KW>
+template <int KW, int FK = 0>
 __global__ __launch_bounds__(NM2_THREADS, 6) void k_novel_mark_2bit(ReadsDev rd, NovelParams p)
 {
-    __shared__ uint32_t lut[256];
+    __shared__ __attribute__((aligned(8))) uint32_t lut[FK ? 1024 : 256];          // FK: the product tables of skm_key_hash_pl
     __shared__ NovelShared ns;
     __shared__ unsigned long long queue[2 * (NM2_THREADS / 64) * 128];
-    if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    if (threadIdx.x < 256) {
+        if (FK) { ((uint64_t *)lut)[threadIdx.x] = skm_ascii4_times(threadIdx.x, MM_C1); ((uint64_t *)lut)[256 + threadIdx.x] = skm_ascii4_times(threadIdx.x, MM_C2); }
+        else lut[threadIdx.x] = skm_ascii4(threadIdx.x);
+    }
     load_descs(ns, p);
     __syncthreads();
-    const int k = p.hp.k;
+    const int k = FK ? FK : p.hp.k;
     const uint32_t L = rd.uni_len, wpr = (L + 15u) >> 4, nk = L - (uint32_t)k + 1u, cpr = (nk + NM2_CH - 1u) / NM2_CH;
     WaveQueue2 wq;
     wq.q = queue + (threadIdx.x >> 6) * 256u;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(NM2_THREADS, 6) void k_novel_mark_2bit(ReadsDev rd,
         if (mine && ((rd.flags[r] & 1) || r < p.first_read)) mine = false;        // the scan skips these reads (kevlar/novel.py:134-139)
         const uint32_t cnt = mine ? min((uint32_t)NM2_CH, nk - j0) : 0u;
         uint32_t u = 0;
-        kmer2bit_walk<KW, NM2_CH>(rd.words + r * wpr, j0, cnt, k, lut, p.hp, [&](bool live, uint64_t h) {
+        kmer2bit_walk<KW, NM2_CH, FK>(rd.words + r * wpr, j0, cnt, k, lut, p.hp, [&](bool live, uint64_t h) {
             wave_queue_push2(wq, live && band_pass(p, h), h, r * p.mask_stride + j0 + u, judge);
             u += 1;
         });
@@ -703,7 +706,8 @@ int scan_reads(NovelParams &p, const kv_reads *reads, int fam, uint64_t n_kmers,
                 KvProfScope prof("k_novel_mark_2bit");
                 const uint64_t n_items = reads->n_reads * (((uint64_t)reads->uni_len - (uint64_t)k + 1 + NM2_CH - 1) / NM2_CH);
                 const unsigned grid = (unsigned)std::min<uint64_t>((n_items + NM2_THREADS - 1) / NM2_THREADS, 3u * (unsigned)kv_device_cus() * 4u);
-                if (k <= 32) hipLaunchKernelGGL(k_novel_mark_2bit<1>, dim3(grid), dim3(NM2_THREADS), 0, st, reads_dev(reads), p);
+                if (k == 31 && !kv_knob("KV_SKM_ANY_K")) hipLaunchKernelGGL((k_novel_mark_2bit<1, 31>), dim3(grid), dim3(NM2_THREADS), 0, st, reads_dev(reads), p);
+                else if (k <= 32) hipLaunchKernelGGL(k_novel_mark_2bit<1>, dim3(grid), dim3(NM2_THREADS), 0, st, reads_dev(reads), p);
                 else hipLaunchKernelGGL(k_novel_mark_2bit<2>, dim3(grid), dim3(NM2_THREADS), 0, st, reads_dev(reads), p);
             }
             kv_tile_hits_launch(reads, p, st);
