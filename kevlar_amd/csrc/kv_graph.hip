@@ -471,12 +471,14 @@ struct UniqueArena {
 };
 std::map<hipStream_t, UniqueArena> g_unique_arena;
 std::mutex g_unique_arena_mu;
+thread_local const UniqueArena *tl_unique_held = nullptr;      // the arena the calling thread's own kv_unique_new holds (never try_lock a mutex one owns)
 }
 void kv_unique_scratch_release()
 {
     std::lock_guard<std::mutex> alk(g_unique_arena_mu);
     for (auto &kv : g_unique_arena) {
-        if (!kv.second.busy.try_lock()) continue;       // in use by a running call (possibly the caller's own): not ours to free
+        if (&kv.second == tl_unique_held) continue;     // the caller's own call is using it
+        if (!kv.second.busy.try_lock()) continue;       // in use by another thread's running call: not ours to free
         kv.second.a.release();
         kv.second.busy.unlock();
     }
@@ -511,6 +513,7 @@ extern "C" int kv_unique_new(kv_sketch *s, const kv_reads *batch, int nbands, in
         ua = &g_unique_arena[kv_stream_key(st)];
     }
     std::lock_guard<std::mutex> busy(ua->busy);
+    struct Held { Held(const UniqueArena *u) { tl_unique_held = u; } ~Held() { tl_unique_held = nullptr; } } held(ua);
     KvArena *arena = &ua->a;
     const uint64_t bm_words = (total + 31) / 32;
     size_t need = kv_round_up(bm_words * 4, 256) + 256;

@@ -540,7 +540,7 @@ class ShardedTrio(object):
             self._scan_declined('scan', err, declined)
         all_abund, _ = gather_rows(abund, n_hits, 0, self.group, self.staged)
         torch.cuda.synchronize()
-        self._merge_mask_tags(tags & ((1 << 63) - 1), n_hits)            # (the tag's top bit flags a read the scan skips: kv_hits_from_tagged drops those)
+        self._merge_mask_tags(tags, n_hits)                # (k-mers of reads the scan skips never leave kv_novel_scan_hashes: no flagged tag among these)
         r, o, a = hk.hits_from_tagged(all_tags.data_ptr(), all_abund.data_ptr(), all_tags.shape[0], total, S)
         self.timing['scan'] += t1 - t0
         self.timing['gather'] += time.perf_counter() - t1
