@@ -1236,6 +1236,7 @@ const KvKnobDef g_knobs[] = {
     {"KV_MEX_NWG1", T_, "exchange: S1 writers of a shard (the same on every rank)"},
     {"KV_MEX_CAP2_SLACK", T_, "exchange: S2 segment slack"},
     {"KV_MEX_PASSES", T_, "exchange: combine passes per bucket (power of two)"},
+    {"KV_MEX_DL_POOL", T_, "exchange: 1 = the owner's distinct list as a pool of chunks at once (it is the last resort of an owner short of memory)"},
     {"KV_MEX_PAIRS", T_, "9: (hash, count) pairs travel in the 9-byte block form"},
     {"KV_MEX_TEST_DECLINE", T_, "point:rank -- that rank fails at that point of the exchange (tests of the agreed fallbacks)"},
     {"KV_ROUTE_OVF_CAP", T_, "entries of the route's overflow list (tests: force the capacity error)"},

@@ -50,6 +50,7 @@ struct SkmGeom {
     // distinct list the count pass writes for a batch that is going to be scanned (SkmIndex::dl; dl_keys == nullptr: off): EVERY
     // distinct k-mer of a bucket with its hash, appended like the abundance list (a stretch per workgroup, start + count per bucket)
     uint64_t *dl_keys, *dl_hash; uint32_t *dl_bstart, *dl_bcount; uint32_t dl_cap_wg;
+    uint32_t dl_chunk, dl_nchunks;   // k_skm_route only: != 0 -- the list is a pool of dl_nchunks chunks of dl_chunk entries that the workgroups draw from (ctr[13]) instead of one stretch each
     uint32_t n_src;
     const uint64_t *seg1_off;        // non-null: segment `slot` starts at record seg1_off[slot] (compacted records) instead of slot * cap1
     uint64_t read_base;              // global index of the batch's first read (record positions of a read shard; 0 otherwise)
@@ -1867,6 +1868,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
     __shared__ uint32_t cur[SKM_ROUTE_MAX_DEST];
     __shared__ uint64_t lo[SKM_ROUTE_MAX_DEST];
     __shared__ uint32_t dl_cur, dl_b0, dl_prev;         // distinct list (sg.dl_keys != NULL: the owner will answer the scan from it, kv_skm_mex_scan_set)
+    __shared__ uint32_t dl_org, dl_lim;                 // where the workgroup's entries start and how many fit: its own stretch, or (sg.dl_chunk) the chunk it drew last
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
     uint32_t *lut = dyn, *scratch = dyn + 256;
     if (threadIdx.x < 256) lut[threadIdx.x] = skm_ascii4(threadIdx.x);
@@ -1875,12 +1877,25 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
     uint64_t n_distinct = 0;
     skm_table_clear(tb);
     for (uint32_t i = threadIdx.x; i < TS; i += SKM_THREADS3) cnt[i] = 0;
-    if (threadIdx.x == 0) { next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * sg.bpt; dl_cur = 0; dl_b0 = 0; dl_prev = 0xffffffffu; }
+    if (threadIdx.x == 0) {
+        next_bucket = (uint32_t)atomicAdd(&sg.ctr[3], 1ull) * sg.bpt; dl_cur = 0; dl_b0 = 0; dl_prev = 0xffffffffu;
+        dl_org = sg.dl_chunk ? 0u : blockIdx.x * sg.dl_cap_wg; dl_lim = sg.dl_chunk ? 0u : sg.dl_cap_wg;
+    }
     auto dl_close = [&]() {
         if (sg.dl_keys && dl_prev != 0xffffffffu) {
-            sg.dl_bstart[dl_prev] = blockIdx.x * sg.dl_cap_wg + dl_b0;
+            sg.dl_bstart[dl_prev] = dl_org + dl_b0;
             sg.dl_bcount[dl_prev] = dl_cur - dl_b0;              // (a stretch that ran out is reported through ctr[9]: the whole list is then dropped)
+            if (sg.dl_chunk && dl_cur > dl_lim) atomicAdd(&sg.ctr[9], 1ull);
         }
+    };
+    // passes a bucket is combined in (see below), from its record count
+    auto passes_of = [&](uint32_t b) {
+        uint32_t passes = sg.passes > 1u ? sg.passes : 1u;
+        const uint32_t *cnt2 = sg.cnt2 + (uint64_t)b * sg.nwg2;
+        uint32_t nrec = 0;
+        for (uint32_t s2 = 0; s2 < sg.nwg2; ++s2) nrec += cnt2[s2];
+        while (passes < 64u && 19u * nrec > 10u * ((uint32_t)TS * 7u / 10u) * passes) passes *= 2u;
+        return passes;
     };
     for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
         __syncthreads();
@@ -1889,6 +1904,18 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
         __syncthreads();
         if (threadIdx.x == 0) {
             dl_close();
+            if (sg.dl_keys && sg.dl_chunk) {
+                // The pool (an owner whose share is too big for a stretch per workgroup with slack for the unevenness of their shares:
+                // config 4's 7.9 G occurrences, 1.5 G of them distinct).  A bucket's list is one stretch, and a pass leaves at most a table's
+                // worth of entries: a chunk that may not hold this bucket's is left as it is and the next one drawn.
+                const uint32_t need = passes_of(b) * (uint32_t)TS;
+                if (dl_cur + need > dl_lim) {
+                    const unsigned long long c = atomicAdd(&sg.ctr[13], 1ull);
+                    if (c < sg.dl_nchunks && need <= sg.dl_chunk) { dl_org = (uint32_t)c * sg.dl_chunk; dl_lim = sg.dl_chunk; }
+                    else { dl_org = 0; dl_lim = 0; atomicAdd(&sg.ctr[9], 1ull); }          // the pool is empty (or the bucket beyond any chunk): no list
+                    dl_cur = 0;
+                }
+            }
             dl_prev = b; dl_b0 = dl_cur;
             if ((b + 1u) & (sg.bpt - 1u)) next_bucket = b + 1u;
             else if (taken + 1 >= sg.quota3 || __hip_atomic_load(&sg.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) next_bucket = 0xffffffffu;
@@ -1900,13 +1927,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
         // (how many: by the bucket's own size -- with 12-base minimizers a million buckets are far from even, a popular minimizer makes
         // its bucket several times the average -- from its record count: ~9.5 k-mers a record, a fifth of them distinct at sequencing
         // coverage, a pass's share under 0.7 of the table; sg.passes, the estimate from the average, is the least)
-        uint32_t passes = sg.passes > 1u ? sg.passes : 1u;
-        {
-            const uint32_t *cnt2 = sg.cnt2 + (uint64_t)b * sg.nwg2;
-            uint32_t nrec = 0;
-            for (uint32_t s2 = 0; s2 < sg.nwg2; ++s2) nrec += cnt2[s2];
-            while (passes < 64u && 19u * nrec > 10u * ((uint32_t)TS * 7u / 10u) * passes) passes *= 2u;
-        }
+        const uint32_t passes = passes_of(b);
         for (uint32_t pass = 0; pass < passes; ++pass) {
         if (pass) __syncthreads();                       // (the drain of the pass before empties the table)
         skm_walk_bucket<KW, false, 0, COMPACT, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
@@ -1933,8 +1954,8 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
                 if (lane == leader) base = atomicAdd(&dl_cur, (uint32_t)__popcll(here));
                 base = (uint32_t)__shfl((int)base, (int)leader);
                 const uint32_t at = base + (uint32_t)__popcll(here & ((1ull << lane) - 1ull));
-                if (at < sg.dl_cap_wg) {
-                    const uint64_t e = (uint64_t)blockIdx.x * sg.dl_cap_wg + at;
+                if (at < dl_lim) {
+                    const uint64_t e = (uint64_t)dl_org + at;
                     sg.dl_keys[e * KW] = c.w[0];
                     if (KW == 2) sg.dl_keys[e * KW + (KW - 1)] = c.w[KW - 1];
                     sg.dl_hash[e] = h;
@@ -1947,7 +1968,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
     __syncthreads();
     if (threadIdx.x == 0) {
         dl_close();
-        if (sg.dl_keys && dl_cur > sg.dl_cap_wg) atomicAdd(&sg.ctr[9], 1ull);
+        if (sg.dl_keys && !sg.dl_chunk && dl_cur > sg.dl_cap_wg) atomicAdd(&sg.ctr[9], 1ull);
     }
     if (threadIdx.x < (uint32_t)rs.ndest)
         rs.seg_count[(uint64_t)threadIdx.x * rs.nwg + blockIdx.x] = (uint32_t)min((uint64_t)cur[threadIdx.x], rs.seg_cap);
@@ -2459,6 +2480,8 @@ struct SkmIndex {
     SkmGeom g;
     // distinct list of the batch (kv_sketch::scan_hint): key + hash of every distinct k-mer the count pass drained, bucket by bucket
     KvArena dl;
+    size_t dl_refused = SIZE_MAX;    // the smallest list kv_skm_mex_route asked for and did not get since the arena was last empty (a refused
+                                     // allocation of tens of gigabytes takes a third of a second, and the arena is given up for the attempt)
     uint64_t *dl_keys = nullptr, *dl_hash = nullptr;
     uint32_t *dl_bstart = nullptr, *dl_bcount = nullptr;
     uint32_t dl_cap_wg = 0;
@@ -3504,11 +3527,40 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     // they are -- this rank will answer the scan for its buckets (kv_skm_mex_scan_set).  A stretch holds one and a half average shares
     // of 0.45 distinct k-mers per occurrence; one that runs out drops the list (ctr[9]) and the scan goes the other way.
     bool dl_new = false;
-    if (keep_scan) {
-        const uint64_t cap_wg = std::min<uint64_t>((uint64_t)((double)n_kmers_exp * 0.45 * 1.6 / nwg3) + 4096, 0xfffffff0ull / nwg3);
-        const size_t b_keys = kv_round_up(cap_wg * nwg3 * 8 * g.kw, 256), b_hash = kv_round_up(cap_wg * nwg3 * 8, 256);
+    const char *dl_why = "not asked for";
+    // Room: 0.72 entries per occurrence in one stretch per workgroup covers a shard's 4-15 x with slack for uneven shares.  An owner of
+    // config 4 holds 7.9 G occurrences at 30 x, a fifth of them distinct, and 16 bytes for each of 0.72 x 7.9 G entries is memory it does
+    // not have: half of that next, and last a POOL with room for 0.22 -- chunks the workgroups draw one after the other (ctr[13]), so that
+    // what one workgroup needs beyond its even share comes out of what another leaves (a quarter more than the even share per workgroup
+    // was not enough there: 12-base minimizers make a million buckets far from even).  KV_MEX_DL_POOL=1 (tests): the pool at once.
+    static const double dl_room[3] = {0.72, 0.36, 0.22};
+    const bool pool_first = kv_knob("KV_MEX_DL_POOL") && atoi(kv_knob("KV_MEX_DL_POOL")) != 0;
+    for (int attempt = pool_first ? 2 : 0; keep_scan && attempt < 3 && !dl_new; ++attempt) {
+        const bool pool = attempt == 2;
+        const double room = pool && pool_first ? dl_room[0] : dl_room[attempt];
+        uint64_t cap_wg = std::min<uint64_t>((uint64_t)((double)n_kmers_exp * room / nwg3) + 4096, 0xfffffff0ull / nwg3);
+        uint64_t entries = cap_wg * nwg3, chunk = 0, nchunks = 0;
+        if (pool) {
+            // a chunk holds any bucket's list (a table's worth per pass) four times over and is an eighth of a workgroup's even share
+            // where that is more; every workgroup leaves its last chunk part empty: one chunk each on top
+            chunk = std::min<uint64_t>(std::max<uint64_t>(entries / ((uint64_t)nwg3 * 8), 4ull * std::max<uint32_t>(g.passes, 2u) * 4096ull), 1ull << 20) & ~255ull;
+            nchunks = std::min<uint64_t>(entries / chunk + nwg3, 0xfffffff0ull / chunk);
+            entries = nchunks * chunk;
+            cap_wg = 0;
+        }
+        const size_t b_keys = kv_round_up(entries * 8 * g.kw, 256), b_hash = kv_round_up(entries * 8, 256);
         const size_t b_idx = kv_round_up((uint64_t)g.n_buckets * 4, 256);
-        if (idx.dl.need(b_keys + b_hash + 2 * b_idx) == hipSuccess) {
+        const size_t b_all = b_keys + b_hash + 2 * b_idx;
+        if (idx.dl.bytes == 0) idx.dl_refused = SIZE_MAX;
+        if (b_all > idx.dl.bytes) {
+            // not worth asking: refused before, or more than the device has left beside what the arena itself would give back
+            size_t mem_free = 0, mem_total = 0;
+            if (b_all >= idx.dl_refused || (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && b_all > mem_free + idx.dl.bytes)) {
+                dl_why = "no memory for it";
+                continue;
+            }
+        }
+        if (idx.dl.need(b_all) == hipSuccess) {
             unsigned char *dbase = (unsigned char *)idx.dl.p;
             idx.dl_keys = (uint64_t *)dbase; dbase += b_keys;
             idx.dl_hash = (uint64_t *)dbase; dbase += b_hash;
@@ -3517,9 +3569,13 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
             idx.dl_cap_wg = (uint32_t)cap_wg;
             KV_HIP(hipMemsetAsync(idx.dl_bstart, 0, 2 * b_idx, st));
             g.dl_keys = idx.dl_keys; g.dl_hash = idx.dl_hash; g.dl_bstart = idx.dl_bstart; g.dl_bcount = idx.dl_bcount; g.dl_cap_wg = idx.dl_cap_wg;
+            g.dl_chunk = (uint32_t)chunk; g.dl_nchunks = (uint32_t)nchunks;
             dl_new = true;
+            dl_why = attempt == 0 ? "kept" : attempt == 1 ? "kept (room for 0.36 entries per occurrence)" : "kept (a pool of chunks the workgroups draw from)";
         } else {
             (void)hipGetLastError();                    // no room: no list, the scan goes the other way
+            dl_why = "no memory for it";
+            idx.dl_refused = std::min(idx.dl_refused, b_all);
         }
     }
     {
@@ -3545,7 +3601,7 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     if (after) { const int rc = after(ctx); if (rc != KV_OK) return rc; }
     KvReadback back;
     hipError_t rb_err = hipSuccess;
-    const unsigned long long *sctr = back.add(g.ctr, 10, st, &rb_err);
+    const unsigned long long *sctr = back.add(g.ctr, 14, st, &rb_err);
     KV_HIP(rb_err);
     KV_HIP(back.wait(st));
     const unsigned long long arrived = sctr[8];
@@ -3557,6 +3613,13 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
                         "%llu records outside their bucket's segments\n",
                 arrived, g.n_buckets, g.passes, g.cap2, arrived ? 100.0 * (double)sctr[7] / (double)arrived : 0.0,
                 arrived ? 100.0 * (double)(sctr[0] > sctr[6] ? sctr[0] - sctr[6] : 0) / (double)arrived : 0.0, sctr[6]);
+    if (keep_scan && kv_knob("KV_SKM_VERBOSE")) {
+        fprintf(stderr, "[kv_skm] exchange owner: the distinct list its scan answers from: %s\n",
+                !dl_new ? dl_why : sctr[9] != 0 ? (g.dl_chunk ? "dropped (the pool of chunks ran out)" : "dropped (a workgroup's stretch ran out)")
+                                 : sctr[1] != 0 ? "dropped (loose list overflow)" : dl_why);
+        if (dl_new && g.dl_chunk)
+            fprintf(stderr, "[kv_skm] exchange owner: %llu of %u chunks of %u entries drawn for %llu distinct k-mers\n", sctr[13], g.dl_nchunks, g.dl_chunk, sctr[7]);
+    }
     if (sctr[1] != 0) {
         kv_set_error("kv_mex_route: loose record list overflow (%llu records)", sctr[0]);
         return KV_ERR_CAPACITY;

@@ -8,6 +8,14 @@ LDS table: SkmGeom::passes) and hands band 0 its (hash, occurrences) pairs, whic
 Timed: rank 0's own cut, owner 0's combine, and band 0 adding as many pairs as it receives from all owners.  Checked: band 0's tables
 against a banded count of all reads (kv_consume with band 0 of 8: what bench.py --workload cfg4-band counts).
 
+CFG4_SCAN=1 adds the SCAN of that layout at the same size (round 6; kevlar/novel.py:123-169 answered per band, then
+kevlar/unband.py:41-77): band 0 judges the distinct case k-mers it received (kv_novel_scan_distinct over every owner's pairs of
+band 0), and then every bucket owner in turn -- its buckets combined again with keep_scan -- answers for the occurrences in its
+buckets against the gathered set (kv_mex_scan_set).  The set at hand is band 0's interesting hashes; it is padded with seven shifted
+copies (hashes of the other bands' ranges that no k-mer has) so that set size, probe cost and gathered bytes are those of eight
+bands.  Timed: band 0's judging and owner 0's answer.  Checked: the eight owners' hits together are the hits of the banded scan of
+band 0 over all reads (bench.py --workload cfg4-band: 19575611 of them at 3 Gb), read for read, offset for offset, abundances included.
+
     gpurun -- python scratch/cfg4_exchange_rank.py [genome_mb] [world]       (defaults 3000, 8; 250 is the quick check)"""
 import os
 import sys
@@ -20,6 +28,132 @@ import torch
 import __graft_entry__
 __graft_entry__.build_product()
 from kevlar_amd import _lib, khmer as hk, shardrun
+
+
+def scan_leg(lib, dev, band0, names, case_items, case_n, k, L, T, genome_len, seed, n_reads, world, bounds, pairs_cap):
+    """the scan of the exchange layout at this size: see the module's text (CFG4_SCAN=1); returns the owners' hits (read, offset, abund) sorted"""
+    S = len(names)
+    cap = max(min(case_n, 1 << 26), 1)
+    hashes = torch.empty(cap, dtype=torch.int64, device=dev)
+    abund = torch.empty((cap, S), dtype=torch.uint8, device=dev)
+    t_judge = None
+    for rep in range(2):                                    # (the second call: buffers grown, kernels loaded)
+        lib.kv_synchronize()
+        t0 = time.perf_counter()
+        n_mine = hk.novel_scan_distinct([band0['proband']], [band0['mother'], band0['father']], case_items.data_ptr(), case_n, 6, 1,
+                                        hashes.data_ptr(), abund.data_ptr(), cap)
+        lib.kv_synchronize()
+        t_judge = time.perf_counter() - t0
+    del case_items
+    torch.cuda.empty_cache()
+    # the gathered set: band 0's interesting hashes + the same number in every other band's range
+    bs = (2 ** 64 - 1) // world
+    mine_h, mine_a = hashes[:n_mine].clone(), abund[:n_mine].clone()
+    assert bool(((mine_h.cpu().numpy().view(np.uint64)) < np.uint64(bs)).all()), 'band 0 judged a hash outside its range'
+    parts = [mine_h]
+    for b in range(1, world):
+        shift = (b * bs) & (2 ** 64 - 1)
+        parts.append(mine_h + (shift - 2 ** 64 if shift >= 2 ** 63 else shift))     # (64-bit wrap-around: a hash of band b's range)
+    set_h = torch.cat(parts)
+    set_a = mine_a.repeat(world, 1)
+    n_set = int(set_h.shape[0])
+    del hashes, abund
+    print('scan: band 0 judged {} distinct case k-mers in {:.3f} s: {} interesting; the gathered set holds {} ({:.1f} MB arrive at every rank)'.format(
+        case_n, t_judge, n_mine, n_set, (n_set - n_mine) * (8 + S) / 1e6), flush=True)
+    # every owner in turn: its buckets combined again (keep_scan), then its answer
+    plan = hk.mex_plan(hk.Counttable, k, n_reads, L, world, short=False)      # records with read positions: the sample the scan is answered from
+    recw, nwg1 = int(plan.recw), int(plan.nwg1)
+    print('scan: the case sample cut again with {}-byte records ({:.1f} GB per shard), combined by one owner at a time'.format(8 * recw, int(plan.seg_words) * 8 / 1e9), flush=True)
+    hit_cap = max(1 << 16, 64 * n_set // world)
+    found, t_owner, t_route, n_owner = [], [], [], []
+    by_shard = False          # an owner could not answer: EVERY rank then looks its own shard up in the set (the ranks agree on that in one small
+                              # all-gather, ShardedTrio.scan_minimizer) -- what owners found and what shards found do not add up to the hits
+    d = -1
+    while d + 1 < world:
+        d += 1
+        if by_shard:
+            lo, hi = bounds[d]
+            batch = hk.ReadBatch.generate(genome_len, seed, 0, lo, hi - lo, L)
+            best = None
+            for rep in range(2):
+                lib.kv_synchronize()
+                t0 = time.perf_counter()
+                r, o, a = hk.novel_scan_set(batch, hk.Counttable, k, S, set_h.data_ptr(), set_a.data_ptr(), n_set)
+                lib.kv_synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            found.append((np.asarray(r).astype(np.int64) + lo, np.asarray(o).copy(), np.asarray(a).copy()))
+            t_owner.append(best); n_owner.append(len(r))
+            del batch
+            print('scan: rank {}: its shard of {} reads against the set {:.3f} s, {} hits ({:.1f} MB leave it)'.format(d, hi - lo, best, len(r), len(r) * (8 + S) / 1e6), flush=True)
+            continue
+        hk.scratch_trim()
+        seg = torch.empty(int(plan.seg_words), dtype=torch.int64, device=dev)
+        cnt = torch.empty(int(plan.cnt_entries), dtype=torch.int32, device=dev)
+        out = torch.empty(int(plan.seg_words) // 2 + 4096, dtype=torch.int64, device=dev)
+        got_rec, got_cnt = [], []
+        for r, (lo, hi) in enumerate(bounds):
+            batch = hk.ReadBatch.generate(genome_len, seed, 0, lo, hi - lo, L)
+            per_dest, fitted = hk.mex_emit_pack(batch, plan, lo, seg.data_ptr(), cnt.data_ptr(), out.data_ptr(), out.shape[0])
+            assert fitted, 'the packed records of shard {} did not fit half the segments'.format(r)
+            first = sum(per_dest[:d])
+            got_rec.append(out[first * recw:(first + per_dest[d]) * recw].clone())
+            got_cnt.append(cnt[int(plan.c_lo[d]) * nwg1:int(plan.c_lo[d + 1]) * nwg1].clone())
+            del batch
+        del seg, out, cnt
+        torch.cuda.empty_cache()
+        rs = torch.cat(got_rec); rc = torch.cat(got_cnt)
+        del got_rec, got_cnt
+        torch.cuda.empty_cache()
+        pairs = torch.empty((pairs_cap, 2), dtype=torch.int64, device=dev)
+        best = None
+        for rep in range(2):                                # (the second call: the arenas a trim gave back have grown again)
+            lib.kv_synchronize()
+            t0 = time.perf_counter()
+            hk.mex_route(plan, d, rs.data_ptr(), rc.data_ptr(), world, pairs.data_ptr(), pairs_cap, compact=True, keep_scan=True)
+            lib.kv_synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        t_route.append(best)
+        del pairs
+        torch.cuda.empty_cache()
+        tags = torch.empty(hit_cap, dtype=torch.int64, device=dev)
+        rows = torch.empty((hit_cap, S), dtype=torch.uint8, device=dev)
+        best = None
+        try:
+            if os.environ.get('CFG4_SCAN_FORCE_FALLBACK') and d == 1:
+                raise _lib.KvCapacityError('forced by CFG4_SCAN_FORCE_FALLBACK')
+            for rep in range(2):
+                lib.kv_synchronize()
+                t0 = time.perf_counter()
+                n_hits = hk.mex_scan_set(hk.Counttable, k, S, set_h.data_ptr(), set_a.data_ptr(), n_set, tags.data_ptr(), rows.data_ptr(), hit_cap)
+                lib.kv_synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            r, o, a = hk.hits_from_tagged(tags.data_ptr(), rows.data_ptr(), n_hits, n_hits, S)
+            found.append((np.asarray(r).astype(np.int64), np.asarray(o).copy(), np.asarray(a).copy()))
+        except _lib.KvCapacityError as exc:
+            print('scan: owner {} cannot answer ({}): every rank scans its own shard against the set instead'.format(d, exc), flush=True)
+            del tags, rows, rs, rc
+            hk.scratch_trim()
+            torch.cuda.empty_cache()
+            by_shard, d = True, -1
+            found, t_owner, n_owner = [], [], []
+            continue
+        t_owner.append(best); n_owner.append(n_hits)
+        del tags, rows, rs, rc
+        torch.cuda.empty_cache()
+        print('scan: owner {}: buckets combined with their distinct list in {:.3f} s, answer {:.3f} s, {} hits ({:.1f} MB leave it)'.format(
+            d, t_route[-1], best, n_hits, n_hits * (8 + S) / 1e6), flush=True)
+    hk.scratch_trim()
+    hr, ho, ha = np.concatenate([f[0] for f in found]), np.concatenate([f[1] for f in found]), np.concatenate([f[2] for f in found])
+    order = np.lexsort((ho, hr))
+    hr, ho, ha = hr[order], ho[order], ha[order]
+    line = ('one rank\'s scan: judging its band\'s {} distinct k-mers {:.3f} s + ' + ('its shard against the set' if by_shard else 'answering for its buckets') +
+            ' {:.3f} s (rank 0; the eight: {:.3f}-{:.3f}) = {:.3f} s; it receives {:.1f} MB of the set and sends {:.1f} MB of hits; {} hits in all')
+    print(line.format(case_n, t_judge, t_owner[0], min(t_owner), max(t_owner), t_judge + t_owner[0], (n_set - n_mine) * (8 + S) / 1e6,
+                      n_owner[0] * (8 + S) / 1e6 * (world - 1) / world, len(hr)), flush=True)
+    return np.asarray(hr).copy(), np.asarray(ho).copy(), np.asarray(ha).copy()
 
 
 def main():
@@ -47,8 +181,12 @@ def main():
     pairs_cap = int(n_reads * nk * float(os.environ.get('CFG4_PAIRS_FRAC', '0.205')) / world) + (1 << 22)      # (a fifth of the occurrences are distinct at 30x; the library sizes its own
                                                                     # staging from this number, generously)
     group = int(os.environ.get('CFG4_OWNERS_AT_ONCE', '2'))      # owners whose records are held at once (every shard is cut once per group)
+    want_scan = os.environ.get('CFG4_SCAN') == '1'
+    case_items, case_n = None, 0          # CFG4_SCAN: every (hash, occurrences) pair band 0 receives of the case sample, as its owner keeps them
     for si, n in enumerate(names):
         arrived_all = 0
+        if want_scan and n == 'proband':
+            case_items = torch.empty((pairs_cap, 2), dtype=torch.int64, device=dev)
         for d0 in range(0, world, group):
             owners = list(range(d0, min(world, d0 + group)))
             # every shard's cut; what it holds for these owners is set aside
@@ -113,6 +251,10 @@ def main():
                     del scratch
                 for c0 in range(0, counts[0], 1 << 29):
                     band0[n].consume_hashes_weighted(pairs.data_ptr() + c0 * 16, min(1 << 29, counts[0] - c0))
+                if want_scan and n == 'proband':
+                    assert case_n + counts[0] <= case_items.shape[0], 'band 0 received more pairs of the case sample than CFG4_PAIRS_FRAC allows for'
+                    case_items[case_n:case_n + counts[0]] = pairs[:counts[0]]
+                    case_n += counts[0]
             del pairs
             torch.cuda.empty_cache()
         assert arrived_all == n_reads * nk, (arrived_all, n_reads * nk)
@@ -129,16 +271,40 @@ def main():
             lib.kv_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(nl))
             print('    {:24s} {:10.1f} ms {:6d} launches (all owners, all shards)'.format(name, ms.value, nl.value))
     hk.scratch_trim()
+    owners_hits = None
+    if want_scan:
+        owners_hits = scan_leg(lib, dev, band0, names, case_items, case_n, k, L, T, genome_len, seed, n_reads, world, bounds, pairs_cap)
+        case_items = None
+        hk.scratch_trim()
     # band 0 the banded way
     per_batch = 18_750_000
+    refs = {}
     for si, n in enumerate(names):
         ref = hk.Counttable(k, memory / world / T, T)
         for lo in range(0, n_reads, per_batch):
             ref.consume_batch(hk.ReadBatch.generate(genome_len, seed, si, lo, min(per_batch, n_reads - lo), L), world, 0)
         for t in range(T):
             assert ref.table_bytes(t) == band0[n].table_bytes(t), (n, t)
+        if want_scan:
+            refs[n] = ref
         del ref
         print('{}: band 0 of the exchange layout equals the banded count, table for table'.format(n), flush=True)
+    if want_scan:
+        # the banded scan of band 0 over all reads, batch by batch (what bench.py --workload cfg4-band scans), against the owners' hits
+        rr, oo, aa = [], [], []
+        lib.kv_synchronize()
+        t0 = time.perf_counter()
+        for lo in range(0, n_reads, per_batch):
+            r, o, a, _ = hk.novel_scan([refs['proband']], [refs['mother'], refs['father']], hk.ReadBatch.generate(genome_len, seed, 0, lo, min(per_batch, n_reads - lo), L),
+                                       6, 1, band_mode=1, nbands=world, band=0)
+            rr.append(np.asarray(r).astype(np.int64) + lo); oo.append(np.asarray(o).copy()); aa.append(np.asarray(a).copy())
+        t_banded = time.perf_counter() - t0
+        rr, oo, aa = np.concatenate(rr), np.concatenate(oo), np.concatenate(aa)
+        hr, ho, ha = owners_hits
+        assert len(hr) == len(rr), ('hits', len(hr), len(rr))
+        assert np.array_equal(np.asarray(hr).astype(np.int64), rr) and np.array_equal(ho, oo) and np.array_equal(ha, aa), 'the owners\' hits differ from the banded scan of band 0'
+        print('scan: the {} owners\' hits together are the {} hits of the banded scan of band 0 over all reads ({:.2f} s with the reads generated batch by batch), '
+              'read for read, offset for offset, abundances included'.format(world, len(rr), t_banded), flush=True)
 
 
 if __name__ == '__main__':

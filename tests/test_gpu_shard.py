@@ -531,7 +531,7 @@ def free_port():
                                                     (3, 'gloo', 'minimizer/emit-oom:2'), (2, 'gloo', 'minimizer/route-hip:1'),
                                                     (2, 'gloo', 'minimizer/owner-hip:1'), (2, 'gloo', 'minimizer/scan-fail:0'),
                                                     (2, 'gloo', 'minimizer/ragged:1'), (3, 'gloo', 'minimizer/pairs9'), (1, 'nccl', 'minimizer/pairs9'),
-                                                    (3, 'gloo', 'minimizer/passes4'), (2, 'gloo', 'minimizer/pairs-differ:1'), (2, 'gloo', 'minimizer/unpack-fail:1')])
+                                                    (3, 'gloo', 'minimizer/passes4'), (2, 'gloo', 'minimizer/pool4'), (2, 'gloo', 'minimizer/pairs-differ:1'), (2, 'gloo', 'minimizer/unpack-fail:1')])
 def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
     """N ranks on this one GPU (gloo, staged exchange): each rank's sketches must equal band `rank` of a
     banded count of ALL reads, and the gathered hits the merged banded scan (tests/shard_worker.py).  The
@@ -561,11 +561,13 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
                    MASTER_PORT=str(port), SHARD_BACKEND=backend, SHARD_DISTINCT='1' if distinct else '0',
                    # every layout against the oracle itself (tests/shard_worker.py: against_the_oracle); the forced declines repeat
                    # those layouts and keep to the banded device path (which tests/test_gpu_fullsize.py holds against the oracle)
-                   SHARD_ORACLE='1' if decline in (None, 'passes4', 'pairs9') else '0')
+                   SHARD_ORACLE='1' if decline in (None, 'passes4', 'pool4', 'pairs9') else '0')
         if decline == 'pairs9':                             # (not a decline: the pairs travel in their 9-byte form, KV_MEX_PAIRS=9)
             env['KV_MEX_PAIRS'] = '9'
         elif decline == 'passes4':                          # (nor this: the owner combines every bucket in four passes, as config 4's size makes it)
             env['KV_MEX_PASSES'] = '4'
+        elif decline == 'pool4':                            # (nor this: four passes, and the owner's distinct list -- what it answers the scan from -- as the pool of
+            env.update(KV_MEX_PASSES='4', KV_MEX_DL_POOL='1', KV_SKM_VERBOSE='1')       # chunks an owner of config 4's size falls back on)
         elif decline and decline.startswith('pairs-differ'):    # the 9-byte form on ONE rank only: the size exchange carries the form, every rank
             if rank == int(decline.split(':')[1]):              # sees the disagreement there and the samples go as the shards' own pairs
                 env['KV_MEX_PAIRS'] = '9'
@@ -607,8 +609,10 @@ def test_sharded_trio_ranks_share_one_gpu(hk, world, backend, distinct):
             assert '0 fallbacks, 1 scan fallbacks' in outs[rank], outs[rank][-400:]
         elif decline and decline.startswith('ragged'):
             assert '1 fallbacks, 0 scan fallbacks' in outs[rank], outs[rank][-400:]
-        elif decline in ('pairs9', 'passes4'):
+        elif decline in ('pairs9', 'passes4', 'pool4'):
             assert '0 fallbacks, 0 scan fallbacks' in outs[rank], outs[rank][-400:]
+            if decline == 'pool4':
+                assert 'kept (a pool of chunks the workgroups draw from)' in outs[rank] and 'chunks of' in outs[rank], outs[rank][-1500:]
         elif decline:
             assert '3 fallbacks' in outs[rank], outs[rank][-400:]        # one per sample, on every rank
             assert '1 scan fallbacks' in outs[rank], outs[rank][-400:]   # and the scan of a sample that fell back goes by the shards
