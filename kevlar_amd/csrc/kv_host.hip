@@ -1235,7 +1235,7 @@ const KvKnobDef g_knobs[] = {
     {"KV_INFLATE_WINDOW_BITS", T_, "10..15: LDS window of the BGZF inflater"},
     {"KV_MEX_NWG1", T_, "exchange: S1 writers of a shard (the same on every rank)"},
     {"KV_MEX_CAP2_SLACK", T_, "exchange: S2 segment slack"},
-    {"KV_MEX_PASSES", T_, "exchange: combine passes per bucket (power of two)"},
+    {"KV_MEX_PASSES", T_, "exchange: combine passes per bucket, at least (1-16)"},
     {"KV_MEX_DL_POOL", T_, "exchange: 1 = the owner's distinct list as a pool of chunks at once (it is the last resort of an owner short of memory)"},
     {"KV_MEX_PAIRS", T_, "9: (hash, count) pairs travel in the 9-byte block form"},
     {"KV_MEX_TEST_DECLINE", T_, "point:rank -- that rank fails at that point of the exchange (tests of the agreed fallbacks)"},

@@ -68,7 +68,7 @@ struct SkmGeom {
     // The exchange layouts keep classic records (canonical = the smaller strand, computed by the walk).
     uint32_t oriented;
     uint32_t dd_maxn;                // k_skm_count combines identical records first (records of up to dd_maxn k-mers; 0: it does not)
-    uint32_t passes;                 // k_skm_route takes a bucket's k-mers in this many passes (a power of two; 0 / 1: one) -- buckets bigger than its LDS table
+    uint32_t passes;                 // k_skm_route takes a bucket's k-mers in at least this many passes (0 / 1: one) -- buckets bigger than its LDS table
     uint32_t bpt;                    // buckets per ticket of the bucket kernels' work counter (a power of two)
 };
 
@@ -1890,12 +1890,16 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
     };
     // passes a bucket is combined in (see below), from its record count
     auto passes_of = [&](uint32_t b) {
-        uint32_t passes = sg.passes > 1u ? sg.passes : 1u;
+        const uint32_t least = sg.passes > 1u ? sg.passes : 1u;
         const uint32_t *cnt2 = sg.cnt2 + (uint64_t)b * sg.nwg2;
         uint32_t nrec = 0;
         for (uint32_t s2 = 0; s2 < sg.nwg2; ++s2) nrec += cnt2[s2];
-        while (passes < 64u && 19u * nrec > 10u * ((uint32_t)TS * 7u / 10u) * passes) passes *= 2u;
-        return passes;
+        // ~9.5 k-mers a record, a fifth of them distinct at sequencing coverage: 1.9 distinct k-mers per record, a pass's share under
+        // 0.65 of the table.  Any number of passes (the class of a k-mer is a range of its hash, not a bit field): powers of two made the
+        // average bucket of config 4 take 8 where 5 do.
+        const uint32_t per_pass = (uint32_t)TS * 13u / 20u;
+        const uint32_t want = (19u * nrec / 10u + per_pass - 1u) / per_pass;
+        return min(64u, max(least, want));
     };
     for (uint32_t taken = 0; taken < sg.quota3; ++taken) {
         __syncthreads();
@@ -1932,7 +1936,7 @@ __global__ __launch_bounds__(SKM_THREADS3, 6) void k_skm_route(SkmGeom sg, HashP
         if (pass) __syncthreads();                       // (the drain of the pass before empties the table)
         skm_walk_bucket<KW, false, 0, COMPACT, ORI>(sg, b, scratch, [&](const SkmKey<KW> &c, const SkmKey<KW> &, uint64_t) {
             if (!skm_cacheable<KW>(c)) return pass == 0u;                                           // (travels alone, once)
-            if (passes > 1u && ((skm_slot_hash<KW>(c) >> 12) & (passes - 1u)) != pass) return false;
+            if (passes > 1u && __umulhi(skm_slot_hash<KW>(c) * 0x9E3779B1u, passes) != pass) return false;       // (bits the slot and the probe step do not come from)
             const int slot = skm_table_insert(tb, c);
             if (slot >= 0) atomicAdd(&cnt[slot], 1u);
             return slot < 0;
@@ -3496,11 +3500,11 @@ int kv_skm_mex_route(const kv_mex_plan *plan, int my_dest, const uint64_t *d_rec
     {
         // buckets the geometry could not make small enough (plan->F2 at its limit): k_skm_route combines them in passes, each taking
         // the k-mers of one hash class -- as many passes as bring a pass's distinct k-mers (a fifth of the occurrences at sequencing
-        // coverage) under half the LDS table.  KV_MEX_PASSES=n (tests): that many whatever the size.
+        // coverage) under 0.65 of the LDS table.  KV_MEX_PASSES=n (tests): at least that many whatever the size.
         const double distinct = (double)g.bucket_kmers * 0.2, room = 0.5 * (g.kw == 1 ? 4096.0 : 2048.0);
-        g.passes = 1;
-        while (g.passes < 16u && distinct > room * g.passes) g.passes *= 2u;
-        if (const char *e = kv_knob("KV_MEX_PASSES")) { const int v = atoi(e); if (v >= 1 && v <= 16 && (v & (v - 1)) == 0) g.passes = (uint32_t)v; }
+        // (the least any bucket gets -- k_skm_route goes by a bucket's own record count: what the average bucket needs at 0.65 of the table)
+        g.passes = distinct > room ? std::min<uint32_t>(16u, std::max<uint32_t>(2u, (uint32_t)std::ceil(distinct / (0.65 * 2.0 * room)))) : 1u;
+        if (const char *e = kv_knob("KV_MEX_PASSES")) { const int v = atoi(e); if (v >= 1 && v <= 16) g.passes = (uint32_t)v; }
     }
     if (compact) {
         // the sources sent only the filled part of their segments, in segment order: a segment starts where the counts in

@@ -29,7 +29,7 @@ for trial in range(trials):
     if rng.random() < 0.5:
         knobs['KV_MEX_DL_POOL'] = '1'
     if rng.random() < 0.5:
-        knobs['KV_MEX_PASSES'] = str(rng.choice(['2', '4']))
+        knobs['KV_MEX_PASSES'] = str(rng.choice(['2', '3', '4', '7']))
     desc = 'trial {} k={} world={} n={} L={} {} {}'.format(trial, k, world, n, L, 'text' if text else 'packed', knobs)
     for name in ('KV_MEX_DL_POOL', 'KV_MEX_PASSES'):
         os.environ.pop(name, None)
