@@ -83,7 +83,10 @@ const char *kv_version(void);
 int kv_knobs_describe(int whole_table, char *out, uint64_t cap);
 int kv_knob_get(const char *name, char *value_out, uint64_t cap);
 int kv_device_count(int *n);
-int kv_set_device(int device);       /* one process per GPU: call once with LOCAL_RANK      */
+int kv_set_device(int device);       /* one process per GPU: call once with LOCAL_RANK; every host thread that enters the library
+                                      * afterwards is switched to that GPU (HIP's current device is per thread and starts at 0)  */
+/* what kv_set_device said (-1: never called), what the library last switched the CALLING thread to, what hipGetDevice says now */
+int kv_thread_device_get(int *configured, int *this_thread, int *hip_current);
 int kv_set_stream(void *hip_stream); /* hipStream_t for the CALLING host thread; NULL = null stream */
 int kv_synchronize(void);
 /* streams for host threads that count different samples at the same time (kevlar/novel.py:64-72

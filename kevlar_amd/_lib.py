@@ -40,6 +40,7 @@ SIGNATURES = {
     'kv_version': (cstr, []),
     'kv_device_count': (i32, [ctypes.POINTER(i32)]),
     'kv_set_device': (i32, [i32]),
+    'kv_thread_device_get': (i32, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     'kv_set_stream': (i32, [vp]),
     'kv_synchronize': (i32, []),
     'kv_stream_create': (i32, [vpp]),

@@ -97,6 +97,7 @@ struct KvArena {
     hipError_t need(size_t n)
     {
         if (n <= bytes) return hipSuccess;
+        kv_thread_device();
         if (p) (void)hipFree(p);
         p = nullptr; bytes = 0;
         // an eighth of headroom: the geometry of the next batch (bucket sizes follow the previous batch's statistics) may

@@ -1084,6 +1084,7 @@ int kv_device_cus()
     static int cus = 0;
     if (cus == 0) {
         int dev = 0, n = 256;
+        kv_thread_device();
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         cus = n;

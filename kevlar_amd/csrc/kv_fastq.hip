@@ -236,6 +236,7 @@ struct KvStager {
     {
         if (ready || broken) return ready;
         for (int i = 0; i < KV_STAGE_SLOTS; ++i) {
+            kv_thread_device();
             if (hipHostMalloc(&slot[i], KV_STAGE_CHUNK, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
                 (void)hipGetLastError();
                 broken = true;

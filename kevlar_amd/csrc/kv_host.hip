@@ -29,7 +29,17 @@ uint64_t kv_next_uid()
 }
 
 static thread_local hipStream_t g_stream = nullptr;   // per host thread: concurrent samples use concurrent streams
-hipStream_t kv_stream() { return g_stream; }
+static std::atomic<int> g_device{-1};                  // kv_set_device: the GPU of this process (-1: never said -- HIP's default, device 0)
+static thread_local int tl_device = -1;                // the device this thread was last switched to by the library
+void kv_thread_device()
+{
+    const int d = g_device.load(std::memory_order_relaxed);
+    if (d >= 0 && tl_device != d) {
+        if (hipSetDevice(d) == hipSuccess) tl_device = d;
+        else (void)hipGetLastError();
+    }
+}
+hipStream_t kv_stream() { kv_thread_device(); return g_stream; }
 
 extern "C" const char *kv_last_error(void) { return g_err; }
 extern "C" const char *kv_version(void) { return "kvsketch-hip 0.1 (gfx950)"; }
@@ -46,12 +56,28 @@ extern "C" int kv_device_count(int *n)
 
 extern "C" int kv_set_device(int device)
 {
-    KV_HIP(hipSetDevice(device));
+    if (hipSetDevice(device) != hipSuccess) {
+        kv_set_error("kv_set_device: device %d: %s", device, hipGetErrorString(hipGetLastError()));
+        return KV_ERR_HIP;
+    }
+    g_device.store(device, std::memory_order_relaxed);     // every host thread that enters the library from now on is switched to it (kv_thread_device)
+    tl_device = device;
+    return KV_OK;
+}
+
+extern "C" int kv_thread_device_get(int *configured, int *this_thread, int *hip_current)
+{
+    // (tests: what kv_set_device said, what the library last switched the calling thread to -- -1: it has not been here --, and what HIP says;
+    // the call itself switches nothing)
+    if (configured) *configured = g_device.load(std::memory_order_relaxed);
+    if (this_thread) *this_thread = tl_device;
+    if (hip_current) { int d = -1; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = -1; } *hip_current = d; }
     return KV_OK;
 }
 
 extern "C" int kv_set_stream(void *s)
 {
+    kv_thread_device();
     g_stream = (hipStream_t)s;
     return KV_OK;
 }
@@ -344,7 +370,7 @@ namespace {
 std::mutex g_tabcache_mu;
 std::multimap<std::pair<int, uint64_t>, uint8_t *> g_tabcache;       // (device, bytes) -> buffer
 uint64_t g_tabcache_bytes = 0;
-int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
+int current_device() { kv_thread_device(); int d = 0; (void)hipGetDevice(&d); return d; }
 uint64_t tabcache_cap()
 {
     const char *e = kv_knob("KV_TABLE_CACHE_GB");
@@ -388,6 +414,7 @@ void table_free(uint8_t *p, uint64_t bytes, int device)
 
 hipError_t kv_hip_malloc(void **p, size_t bytes)
 {
+    kv_thread_device();
     hipError_t e = hipMalloc(p, bytes);
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
@@ -718,6 +745,7 @@ void *kv_pinned_get(size_t bytes, size_t *capacity)
     }
     void *p = nullptr;
     const size_t cap = (bytes + 4095) & ~(size_t)4095;
+    kv_thread_device();
     if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     *capacity = cap;
     return p;

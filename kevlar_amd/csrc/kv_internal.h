@@ -279,8 +279,15 @@ void kv_set_error(const char *fmt, ...);
 // the hipError_t behind the calling thread's last KV_ERR_HIP (KV_HIP notes it): callers that can do without the GPU for a step
 // tell "out of memory" from a device fault by it
 extern thread_local int kv_last_hip_code;
+// The device of this process (kv_set_device: one process per GPU, LOCAL_RANK) made the calling host thread's current device.  HIP's
+// current device is per thread and starts at 0: a worker thread of rank 3 -- a sample counted beside the others, a reader of
+// `kevlar count --threads` -- would otherwise allocate and launch on GPU 0.  Cheap (an atomic load and a thread-local compare); called
+// by kv_stream(), by KV_HIP in front of every wrapped call, and by the allocation helpers.
+void kv_thread_device();
+
 #define KV_HIP(call)                                                                        \
     do {                                                                                    \
+        kv_thread_device();                                                                 \
         hipError_t e__ = (call);                                                            \
         if (e__ != hipSuccess) {                                                            \
             kv_last_hip_code = (int)e__;                                                    \

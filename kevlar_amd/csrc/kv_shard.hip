@@ -359,6 +359,7 @@ extern "C" int kv_route_hashes(const kv_reads *reads, int kind, int ksize, int n
     p.cap = cap_items;
     p.out = (uint64_t *)d_out;
     int dev = 0, cus = 256;
+    kv_thread_device();
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const size_t lds = reads->tile_lds_bytes;

@@ -27,6 +27,43 @@ def test_library_loaded_and_device_present(hk):
     assert b'gfx950' in lib.kv_version()
 
 
+def test_every_host_thread_is_switched_to_the_process_device(hk):
+    """One process per GPU: kv_set_device(LOCAL_RANK) names the GPU, and HIP's current device is per host thread, 0 until said
+    otherwise -- a worker thread of rank 3 (samples counted side by side, the readers of `kevlar count --threads`) must not allocate
+    and launch on GPU 0.  The library switches every thread that enters it; on a one-GPU box the device is 0 either way, so what is
+    held here is that a fresh thread HAS been switched (-1 before its first call, the process's device after) by each of the calls
+    such a thread makes first."""
+    import ctypes
+    import threading
+    from kevlar_amd import _lib
+    lib = _lib.load()
+    _lib.require_device()
+
+    def probe():
+        c, t, h = ctypes.c_int(-7), ctypes.c_int(-7), ctypes.c_int(-7)
+        _lib.check(lib.kv_thread_device_get(ctypes.byref(c), ctypes.byref(t), ctypes.byref(h)))
+        return c.value, t.value, h.value
+    configured = probe()[0]
+    assert configured == int(os.environ.get('LOCAL_RANK', '0'))
+    seen = {}
+
+    def first_call_is(name, call):
+        def work():
+            before = probe()
+            call()
+            seen[name] = (before, probe())
+        th = threading.Thread(target=work)
+        th.start(); th.join()
+    first_call_is('sketch', lambda: hk.Counttable(21, 1e5, 4))
+    first_call_is('stream', lambda: hk.Stream().bind())
+    first_call_is('reads', lambda: hk.ReadBatch(['ACGTACGTACGTACGTACGTACGTACGT']))
+    first_call_is('concurrent', lambda: hk.run_concurrently([lambda: hk.Counttable(21, 1e5, 4).n_occupied(), lambda: hk.Counttable(21, 1e5, 4).n_occupied()]))
+    assert len(seen) == 4
+    for name, (before, after) in seen.items():
+        assert before[:2] == (configured, -1), (name, before)             # a fresh thread: the library has not switched it yet
+        assert after == (configured, configured, configured), (name, after)
+
+
 @pytest.mark.parametrize('k', [1, 7, 15, 16, 17, 21, 25, 31, 32, 33, 47, 48, 51, 64, 65, 100])
 def test_device_kmer_hashing_matches_oracle(hk, ok, k):
     reads = random_reads(k, 40, lo=k, hi=k + 60)
