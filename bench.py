@@ -261,6 +261,7 @@ def main():
         raise SystemExit('bench.py --gpus {} was started with WORLD_SIZE={}'.format(args.gpus, world))
     if args.launch_check:
         return launch_check(args, rank, world)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # (ranks started by somebody else's torch.distributed.run: see self_launch)
     global LIVE_PMC
     if world == 1 and args.gpus == 1 and args.traffic == 'live' and args.workload == 'cfg2':
         LIVE_PMC = live_traffic(args)
