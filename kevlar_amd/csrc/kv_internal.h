@@ -73,6 +73,10 @@ struct kv_sketch {
     uint64_t version = 0;  // bumped by everything that changes a table (invalidates cached scan verdicts)
     uint64_t *d_counters; // [0] n_kmers, [1] n_unique (device accumulators)
     bool skm_off = false;  // the last batch counted through the super-k-mer front end did not deduplicate: skip it until cleared
+    uint64_t skm_off_kmers = 0;  // ... and how many k-mers that batch had.  This outlives kv_sketch_clear: a sketch that is cleared and filled
+                                 // again with batches of the same size (a sample counted step after step, band after band) does not cut,
+                                 // bucket and combine its first batch every time just to find the same thing (0.25 of config 4's 2.7 s per
+                                 // step, and 30 GB of buckets per stream); a batch of another size is tried afresh, a success forgets it
     double skm_distinct = 0.0;   // distinct / all k-mers of that batch (0: none yet): sizes the buckets of the next one
     // the scan's own memory (kv_novel_scan, this sketch as the first case sample): the last batch it cut into super-k-mers did not
     // fit the tables -- nothing to deduplicate at that coverage -- and was scanned again tile by tile; batches that follow go

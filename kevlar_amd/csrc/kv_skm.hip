@@ -2956,8 +2956,10 @@ static int skm_fits(int hashfam, int ksize, const kv_reads *reads, uint64_t n_km
 bool kv_skm_eligible(const kv_sketch *s, const kv_reads *reads, uint64_t n_kmers, bool for_scan)
 {
     const int fits = skm_fits(s->h.hashfam, s->h.ksize, reads, n_kmers, for_scan);
-    // skm_off: the previous batch into this sketch did not deduplicate (kv_consume_skm)
-    return fits > 0 || (fits == 0 && !s->skm_off);
+    // skm_off: the previous batch into this sketch did not deduplicate (kv_consume_skm); skm_off_kmers: nor did a batch of this size
+    // before the sketch was cleared (within a tenth)
+    const bool same_shape = !for_scan && s->skm_off_kmers != 0 && n_kmers * 10 >= s->skm_off_kmers * 9 && n_kmers * 10 <= s->skm_off_kmers * 11;
+    return fits > 0 || (fits == 0 && !s->skm_off && !same_shape);
 }
 
 bool kv_skm_eligible_kind(int hashfam, int ksize, const kv_reads *reads, uint64_t n_kmers, bool for_scan)
@@ -3106,6 +3108,9 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
             const double alone = (double)(sc[0] > sc[6] ? sc[0] - sc[6] : 0) / (double)n_kmers;
             const double distinct = (double)sc[7] / (double)n_kmers + alone;
             s->skm_off = rc != KV_OK || alone > 0.03 || distinct > 0.45;
+            // (what the batch itself showed -- or buffers sized for sequencing coverage running over, which is how a batch without repeats ends:
+            // its figures are then those of an aborted count -- not an error of another kind)
+            s->skm_off_kmers = (distinct > 0.45 || rc == KV_ERR_CAPACITY) ? n_kmers : 0;
             s->skm_distinct = distinct;
             { std::lock_guard<std::mutex> glk(g_skm_mu); g_skm_last_distinct = distinct; }
             if (kv_knob("KV_SKM_VERBOSE"))
@@ -3125,6 +3130,17 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
                     rc, sc[0], (unsigned long long)sg.loose_cap, sc[1], sc[5], bc[0], (unsigned long long)plan.g.spill_cap, bc[1],
                     sg.C1, sg.F2, sg.nwg1, sg.nwg2, sg.cap1, sg.cap2);
         }
+    }
+    if (s->skm_off && idx.arena.bytes + idx.dl.bytes >= ((size_t)1 << 30)) {
+        // The batches of this sketch will not come this way again, and what was bucketed here is of no use to a scan of a batch with
+        // nothing to combine: the gigabytes the attempt took (records twice over with their slack: 30 GB per stream for a 37.5 M-read
+        // batch of config 4, which is what kept batches of twice the size from fitting beside the resident reads) go back now instead of
+        // waiting for kv_scratch_trim.
+        idx.valid = false; idx.mex_scan_ready = false; idx.dl_valid = false;
+        idx.arena.release();
+        idx.dl.release();
+        idx.dl_keys = nullptr; idx.dl_hash = nullptr; idx.dl_bstart = nullptr; idx.dl_bcount = nullptr;
+        if (kv_knob("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] the stream's bucket buffers are given back\n");
     }
     return rc;
 }

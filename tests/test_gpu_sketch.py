@@ -57,10 +57,19 @@ def test_every_host_thread_is_switched_to_the_process_device(hk):
     first_call_is('sketch', lambda: hk.Counttable(21, 1e5, 4))
     first_call_is('stream', lambda: hk.Stream().bind())
     first_call_is('reads', lambda: hk.ReadBatch(['ACGTACGTACGTACGTACGTACGTACGT']))
-    first_call_is('concurrent', lambda: hk.run_concurrently([lambda: hk.Counttable(21, 1e5, 4).n_occupied(), lambda: hk.Counttable(21, 1e5, 4).n_occupied()]))
-    assert len(seen) == 4
+    # the threads run_concurrently starts (the thread that calls it may touch nothing itself when the streams come from the pool)
+    def job(name):
+        def work():
+            before = probe()
+            hk.Counttable(21, 1e5, 4).n_occupied()
+            seen[name] = (before[:2] + (None,), probe())
+            return 0
+        return work
+    hk.run_concurrently([job('concurrent-a'), job('concurrent-b')])
+    assert len(seen) == 5
     for name, (before, after) in seen.items():
-        assert before[:2] == (configured, -1), (name, before)             # a fresh thread: the library has not switched it yet
+        if not name.startswith('concurrent'):                             # (run_concurrently binds a stream before the job starts: switched already)
+            assert before[:2] == (configured, -1), (name, before)         # a fresh thread: the library has not switched it yet
         assert after == (configured, configured, configured), (name, after)
 
 
