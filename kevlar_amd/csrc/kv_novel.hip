@@ -99,8 +99,30 @@ __global__ __launch_bounds__(NM2_THREADS, 6) void k_novel_mark_2bit(ReadsDev rd,
     wq.q = queue + (threadIdx.x >> 6) * 256u;
     wq.q2 = wq.q + 128u;
     wq.n = 0;
+    // (the verdict cache, p.vcache_2bit: the kernel is bound by its random 64-byte requests -- table 0 of the case, then the four tables of
+    // the control that rejects an inherited k-mer -- not by the hashing; a set of the cache is one such request)
+    const bool cached_verdicts = p.vcache != nullptr && p.vcache_2bit != 0;
     auto judge = [&](bool have, uint64_t h, uint64_t bit) {
-        if (have && novel_test_fast(ns, p, h, nullptr, 0ull)) atomicOr(&p.mask[bit >> 5], 1u << (bit & 31));
+        unsigned long long *slot = nullptr;
+        unsigned long long cached = 0;
+        if (cached_verdicts && have) {
+            // (the set from the LOW bits of the hash: a band is a range of hashes, its k-mers share the top ones)
+            const unsigned long long *set = p.vcache + ((h & ((1ull << (61 - p.vcache_shift)) - 1ull)) << 3);
+            const ulonglong2 e0 = ((const ulonglong2 *)set)[0], e1 = ((const ulonglong2 *)set)[1];
+            const ulonglong2 e2 = ((const ulonglong2 *)set)[2], e3 = ((const ulonglong2 *)set)[3];
+            const unsigned long long e[8] = {e0.x, e0.y, e1.x, e1.y, e2.x, e2.y, e3.x, e3.y};
+            bool hit = false;
+            uint32_t way = (uint32_t)(h >> 40) & 7u, empty = 8;
+#pragma unroll
+            for (int w = 7; w >= 0; --w) {
+                hit |= e[w] == h;
+                if (e[w] == 0) empty = (uint32_t)w;
+            }
+            if (e[way] != 0 && empty < 8) way = empty;
+            slot = const_cast<unsigned long long *>(set) + way;
+            cached = hit ? h : ~h;
+        }
+        if (have && novel_test_fast(ns, p, h, slot, cached)) atomicOr(&p.mask[bit >> 5], 1u << (bit & 31));
     };
     const uint64_t n_items = rd.n_reads * cpr;
     for (uint64_t i0 = (uint64_t)blockIdx.x * NM2_THREADS + (threadIdx.x & ~63u); i0 < n_items; i0 += (uint64_t)gridDim.x * NM2_THREADS) {
@@ -496,7 +518,8 @@ int attach_vcache(NovelParams &p, kv_sketch *const *ctrls, int ncase, int nctrl,
             vc = &g_vcache[kv_stream_key(st)];
         }
         int want = 20;
-        while (want < 28 && (1ull << want) < n_kmers / 2) ++want;   // ~2 slots per distinct inherited k-mer at 30x
+        // ~2 slots per distinct inherited k-mer at 30x; a batch of many (vcache_2bit) meets the sample's, not its own: room for 2^29
+        while (want < (p.vcache_2bit ? 29 : 28) && (1ull << want) < n_kmers / 2) ++want;
         if (vc->p == nullptr || vc->bits < want) {
             if (vc->p) (void)hipFree(vc->p);
             vc->p = nullptr;
@@ -578,6 +601,7 @@ extern "C" int kv_novel_scan(kv_sketch *const *cases, int ncase, kv_sketch *cons
         }
         const double held = distinct_held * (band_mode == KV_BAND_RANGE ? (double)nbands : 1.0);
         const bool sparse = held > 0.0 && (double)n_kmers < 0.5 * held;
+        p.vcache_2bit = sparse ? 1 : 0;         // one batch of many of its sample: what the controls reject in this batch they rejected in the ones before
         if (cases[0]->skm_scan_off || sparse) {
             use_skm = false;
             if (kv_knob("KV_SKM_VERBOSE"))

@@ -24,6 +24,8 @@ struct NovelParams {
     int vcache_sets;              // k_novel_mark: 8-entry sets indexed by the k-mer's minimizer (0 = direct-mapped by hash)
     uint32_t vcache_set_mask;     // number of sets - 1
     int vcache_window;            // m-mers per k-mer considered for the minimizer
+    int vcache_2bit;              // k_novel_mark_2bit looks the hash up too (8-entry sets indexed by the hash): the batch is one of many of its
+                                  // sample, so an inherited k-mer met in an earlier batch costs one 64-byte request instead of five
     // Set mode (kv_novel_scan_set; the read-sharded multi-GPU scan): the interesting k-mers are already known -- the
     // owners of the hash bands evaluated them -- and arrive as an open-addressing table of their hashes with the S
     // abundances beside each; "interesting" is then membership, and no sketch is touched (sk[] unset, ncase = S).
