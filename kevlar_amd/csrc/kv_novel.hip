@@ -936,9 +936,9 @@ __global__ __launch_bounds__(256) void k_novel_list(NovelParams p, const uint64_
         c.h = v.x; c.tag = v.y;
         c.live = (c.tag >> 63) == 0;
         if (c.live && p.vcache) {
-            // no sequence here, so no minimizer: the set comes from the hash itself; 8 ways still lose
-            // fewer entries to conflicts than a direct-mapped slot
-            const unsigned long long *set = p.vcache + ((c.h >> (p.vcache_shift + 3)) << 3);
+            // no sequence here, so no minimizer: the set comes from the hash itself -- from its LOW bits: the hashes a band owner
+            // receives are a range, they share the top ones --; 8 ways still lose fewer entries to conflicts than a direct-mapped slot
+            const unsigned long long *set = p.vcache + ((c.h & ((1ull << (61 - p.vcache_shift)) - 1ull)) << 3);
             const ulonglong2 e0 = ((const ulonglong2 *)set)[0], e1 = ((const ulonglong2 *)set)[1];
             const ulonglong2 e2 = ((const ulonglong2 *)set)[2], e3 = ((const ulonglong2 *)set)[3];
             const unsigned long long e[8] = {e0.x, e0.y, e1.x, e1.y, e2.x, e2.y, e3.x, e3.y};
