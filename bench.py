@@ -56,10 +56,10 @@ WORKLOADS = {
     'cfg4-proxy': dict(genome_mb=250.0, coverage=30.0, ksize=31, memory=8e9, controls=2, batch_reads=18_750_000,
                        label='one band\'s share of BASELINE.json configs[3] on one GPU: 250 Mb trio, 30x, k=31, 8 GB sketch '
                              'per sample, reads streamed in batches of 18.75 M (four per sample)'),
-    'cfg4-band': dict(genome_mb=3000.0, coverage=30.0, ksize=31, memory=64e9, controls=2, batch_reads=37_500_000, bands=8, band=0,
+    'cfg4-band': dict(genome_mb=3000.0, coverage=30.0, ksize=31, memory=64e9, controls=2, batch_reads=75_000_000, bands=8, band=0,
                       device_generated=True,
                       label='BASELINE.json configs[3] as ONE of its 8 GPUs sees it: 3 Gb trio, 30x, k=31, band 0 of 8 (8 GB sketch per '
-                            'sample on this GPU), all 900 M reads of every sample streamed in batches of 37.5 M (24 per sample: a batch streams the 8 GB of tables once, 56 M do not fit beside the resident reads; generated on the '
+                            'sample on this GPU), all 900 M reads of every sample streamed in batches of 75 M (12 per sample: a batch streams the 8 GB of tables once; generated on the '
                             'device, resident in HBM), then filter and partition of the band\'s annotated reads'),
 }
 

@@ -1204,7 +1204,12 @@ int kv_bin_plan(kv_sketch *s, uint64_t n_items_max, int nbands, bool use_mask, u
     const size_t b_buf1 = kv_round_up(ns * g.nwgA * g.cap1 * 4, 256), b_buf2 = kv_round_up(ns * g.F * g.nwgB * g.cap2 * fine_bytes, 256);
     const size_t b_cnt1 = kv_round_up(ns * g.nwgA * 4, 256), b_cnt2 = kv_round_up(ns * g.F * g.nwgB * 4, 256);
     const size_t b_spill = kv_round_up(g.spill_cap * 8, 256), b_ctr = 256;
-    KV_HIP(scratch.need(b_buf1 + b_buf2 + b_cnt1 + b_cnt2 + b_spill + b_ctr));
+    // (no memory for the staging buffers is a CAPACITY answer: the caller has a path that needs less -- in the end the atomic kernel, which needs none)
+    if (scratch.need(b_buf1 + b_buf2 + b_cnt1 + b_cnt2 + b_spill + b_ctr) != hipSuccess) {
+        (void)hipGetLastError();
+        kv_set_error("no device memory for the partitioned count's staging buffers (%.1f GB)", (double)(b_buf1 + b_buf2 + b_cnt1 + b_cnt2 + b_spill + b_ctr) / 1e9);
+        return KV_ERR_CAPACITY;
+    }
     unsigned char *base = (unsigned char *)scratch.p;
     g.gbuf1 = (uint32_t *)base; base += b_buf1;
     g.gbuf2 = (uint16_t *)base; base += b_buf2;

@@ -2907,7 +2907,14 @@ int skm_build(SkmIndex &idx, const kv_reads *reads, int k, uint64_t n_kmers, hip
     const size_t b_seg1 = kv_round_up((uint64_t)g.C1 * g.nwg1 * g.cap1 * rb, 256), b_cnt1 = kv_round_up((uint64_t)g.C1 * g.nwg1 * 4, 256);
     const size_t b_seg2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * g.cap2 * rb, 256), b_cnt2 = kv_round_up((uint64_t)g.n_buckets * g.nwg2 * 4, 256);
     const size_t b_loose = kv_round_up(g.loose_cap * (size_t)g.lrecw * 8, 256), b_ctr = 256;
-    KV_HIP(idx.arena.need(b_seg1 + b_cnt1 + b_seg2 + b_cnt2 + b_loose + b_ctr));
+    // (no memory for the buckets -- three samples cut side by side in batches of tens of millions of reads -- is a CAPACITY answer: the batch
+    // takes the plain partition, or the tile scan, as it does when a buffer runs over)
+    if (idx.arena.need(b_seg1 + b_cnt1 + b_seg2 + b_cnt2 + b_loose + b_ctr) != hipSuccess) {
+        (void)hipGetLastError();
+        idx.valid = false; idx.mex_scan_ready = false; idx.dl_valid = false;
+        kv_set_error("no device memory for the super-k-mer buckets (%.1f GB)", (double)(b_seg1 + b_cnt1 + b_seg2 + b_cnt2 + b_loose + b_ctr) / 1e9);
+        return KV_ERR_CAPACITY;
+    }
     unsigned char *base = (unsigned char *)idx.arena.p;
     g.seg1 = (uint64_t *)base; base += b_seg1;
     g.cnt1 = (uint32_t *)base; base += b_cnt1;
@@ -2975,7 +2982,24 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     std::lock_guard<std::mutex> lk(idx.mu);
     const int k = s->h.ksize;
     // (a sketch with the scan hint keeps positions: the scan that follows marks occurrences from these very buckets)
-    { const int rc = skm_build(idx, reads, k, n_kmers, st, s->skm_distinct, s->scan_hint != 0); if (rc != KV_OK) return rc; }
+    // no memory for the buckets, or for the staging of the bin stages beside them (three samples cut side by side in batches of tens of
+    // millions of reads): the batch takes the plain partition, this sketch does not ask again -- nor after a clear, for a batch of this
+    // size -- and what the attempt holds goes back at once so that the plain partition finds room for its own staging
+    auto no_memory = [&](int rc) {
+        s->skm_off = true;
+        s->skm_off_kmers = n_kmers;
+        idx.valid = false; idx.mex_scan_ready = false; idx.dl_valid = false;
+        idx.arena.release();
+        idx.dl.release();
+        idx.dl_keys = nullptr; idx.dl_hash = nullptr; idx.dl_bstart = nullptr; idx.dl_bcount = nullptr;
+        if (kv_knob("KV_SKM_VERBOSE")) fprintf(stderr, "[kv_skm] no memory for the bucketed count of this batch: the plain partition, and the stream's bucket buffers are given back\n");
+        return rc;
+    };
+    {
+        const int rc = skm_build(idx, reads, k, n_kmers, st, s->skm_distinct, s->scan_hint != 0);
+        if (rc == KV_ERR_CAPACITY) return no_memory(rc);
+        if (rc != KV_OK) return rc;
+    }
     SkmGeom &sg = idx.g;
     const uint32_t nwg3 = skm_nwg3(sg);
     BinPlan plan;
@@ -2983,7 +3007,11 @@ int kv_consume_skm(kv_sketch *s, const kv_reads *reads, const ConsumeFilter &fil
     // distinct (sequencing coverage leaves 20-35 %); a batch with more spills over, raises the flag, and is redone by
     // the one-item-per-k-mer partition -- which is where a batch that does not deduplicate belongs anyway
     const uint64_t n_items = std::max<uint64_t>(n_kmers * 3 / 5, std::min<uint64_t>(n_kmers, 1u << 22));
-    { const int rc = kv_bin_plan(s, n_items, nbands, filter.use_mask != 0, sg.n_buckets, 0u, nwg3, true, &plan); if (rc != KV_OK) return rc; }
+    {
+        const int rc = kv_bin_plan(s, n_items, nbands, filter.use_mask != 0, sg.n_buckets, 0u, nwg3, true, &plan);
+        if (rc == KV_ERR_CAPACITY) return no_memory(rc);
+        if (rc != KV_OK) return rc;
+    }
     const SketchDev *d_mask = mask ? mask->d_desc : nullptr;
     // abundance list of this batch (KvAbundList): the first super-k-mer count after a clear writes one, unless KV_SKM_ABL=0
     bool abl_new = false;

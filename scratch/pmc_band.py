@@ -1,4 +1,4 @@
-# two batches per sample of config 4's band shape (3 Gb genome, 37.5 M device-generated reads per batch, band 0 of 8, 8 GB band sketches)
+# two batches per sample of config 4's band shape (3 Gb genome, 75 M device-generated reads per batch, band 0 of 8, 8 GB band sketches)
 # counted and scanned once, for rocprofv3 --pmc passes (PMC_SCRIPT=scratch/pmc_band.py scratch/pmc_skm.sh)
 import sys
 import os
@@ -7,7 +7,7 @@ import torch
 torch.cuda.init()
 from kevlar_amd import _lib, khmer as hk
 lib = _lib.load(); _lib.require_device()
-G, L, k, per = 3_000_000_000, 100, 31, 37_500_000
+G, L, k, per = 3_000_000_000, 100, 31, 75_000_000
 names = ('mother', 'father', 'proband')
 batches = {n: [hk.ReadBatch.generate(G, 42, (si + 1) % 3, lo, per, L) for lo in (0, per)] for si, n in enumerate(names)}
 sk = {n: hk.Counttable(k, 8e9 / 4, 4) for n in names}
